@@ -1,0 +1,238 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Never linked into, imported by or called
+ * from the product path (pyamg_amd/).  See oracle/README.md.
+ *
+ * Type-generic body; included twice by amg_oracle.c with
+ *     #define REAL   double|float
+ *     #define FN(x)  orc_##x##_f64 | orc_##x##_f32
+ *
+ * Every function is a plain-C restatement of the *semantics* of one function on
+ * the reference's solve path; the reference file:line each one
+ * follows is cited above it.  Arithmetic is kept in exactly the reference's
+ * order (sequential per-row accumulation, no FMA contraction: build with
+ * -ffp-contract=off) so that results are bit-identical to the reference on x86-64.
+ * Index type is 32-bit int only (reference: instantiate.yml:2-6).
+ */
+
+/* y += A x, CSR.  Follows SciPy sparsetools csr_matvec (third-party, not under
+ * /root/reference; pinned scipy>=1.11, pyproject.toml:52; installed 1.15.3):
+ * the running sum of row i starts from y[i] and adds a_ij*x_j in storage order.
+ * Reference call sites: multilevel.py:545,567,612,614,660; relaxation.py:652,657. */
+void FN(csr_matvec)(int n_row, const int *Ap, const int *Aj, const REAL *Ax,
+                    const REAL *x, REAL *y)
+{
+    for (int r = 0; r < n_row; ++r) {
+        REAL acc = y[r];
+        const int hi = Ap[r + 1];
+        for (int p = Ap[r]; p < hi; ++p)
+            acc += Ax[p] * x[Aj[p]];
+        y[r] = acc;
+    }
+}
+
+/* y += A x, BSR with R x C row-major blocks.  Follows SciPy sparsetools bsr_matvec
+ * (+ dense.h gemv): for R==C==1 it IS the CSR loop; otherwise block row i walks its
+ * blocks in storage order and, per block, each of the R outputs continues its own
+ * running sum over the C block columns. */
+void FN(bsr_matvec)(int n_brow, int R, int C, const int *Ap, const int *Aj,
+                    const REAL *Ax, const REAL *x, REAL *y)
+{
+    if (R == 1 && C == 1) { FN(csr_matvec)(n_brow, Ap, Aj, Ax, x, y); return; }
+    const long RC = (long)R * C;
+    for (int ib = 0; ib < n_brow; ++ib) {
+        REAL *yo = y + (long)R * ib;
+        for (int p = Ap[ib]; p < Ap[ib + 1]; ++p) {
+            const REAL *blk = Ax + RC * p;
+            const REAL *xi = x + (long)C * Aj[p];
+            for (int r = 0; r < R; ++r) {
+                REAL acc = yo[r];
+                for (int c = 0; c < C; ++c)
+                    acc += blk[(long)r * C + c] * xi[c];
+                yo[r] = acc;
+            }
+        }
+    }
+}
+
+/* One Gauss-Seidel sweep over rows row_start, row_start+row_step, ... (!= row_stop),
+ * in place.  Follows amg_core gauss_seidel, relaxation.h:48-76: off-diagonal products
+ * summed in storage order, the LAST stored entry with j==i is the diagonal, a zero or
+ * missing diagonal leaves x[i] untouched. */
+void FN(gauss_seidel)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x,
+                      const REAL *b, int row_start, int row_stop, int row_step)
+{
+    for (int i = row_start; i != row_stop; i += row_step) {
+        REAL offsum = 0, d = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) d = Ax[p];
+            else        offsum += Ax[p] * x[j];
+        }
+        if (d != (REAL)0)
+            x[i] = (b[i] - offsum) / d;
+    }
+}
+
+/* SOR sweep.  Follows amg_core sor_gauss_seidel, relaxation.h:116-145:
+ * x_i <- omega*((b_i - offsum)/d) + (1-omega)*x_i, omega a REAL scalar. */
+void FN(sor_gauss_seidel)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x,
+                          const REAL *b, int row_start, int row_stop, int row_step,
+                          REAL omega)
+{
+    for (int i = row_start; i != row_stop; i += row_step) {
+        REAL offsum = 0, d = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) d = Ax[p];
+            else        offsum += Ax[p] * x[j];
+        }
+        if (d != (REAL)0)
+            x[i] = omega * ((b[i] - offsum) / d) + (1 - omega) * x[i];
+    }
+}
+
+/* Weighted Jacobi.  Follows amg_core jacobi, relaxation.h:309-346: snapshot the swept
+ * entries of x into temp, then x_i <- (1-w) t_i + w*((b_i - offsum)/d) from temp. */
+void FN(jacobi)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REAL *b,
+                REAL *temp, int row_start, int row_stop, int row_step, REAL omega)
+{
+    const REAL one = 1;
+    for (int i = row_start; i != row_stop; i += row_step) temp[i] = x[i];
+    for (int i = row_start; i != row_stop; i += row_step) {
+        REAL offsum = 0, d = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) d = Ax[p];
+            else        offsum += Ax[p] * temp[j];
+        }
+        if (d != (REAL)0)
+            x[i] = (one - omega) * temp[i] + omega * ((b[i] - offsum) / d);
+    }
+}
+
+/* dense helper: out[0..bs) = M(bs x bs, row major) * v, each output a fresh running sum
+ * starting at 0 (the reference's gemm(...,'F','F','T' overwrite), linalg.h:405-438). */
+static void FN(blk_apply)(const REAL *M, const REAL *v, REAL *out, int bs)
+{
+    for (int r = 0; r < bs; ++r) {
+        REAL acc = 0;
+        for (int c = 0; c < bs; ++c) acc += M[r * bs + c] * v[c];
+        out[r] = acc;
+    }
+}
+
+/* shared tail of the two BSR *point* smoothers: point sweep inside the diagonal block D
+ * in the direction of the outer sweep; src supplies the coupled values (x itself for GS,
+ * the snapshot for Jacobi).  relaxation.h:244-259 / 538-556. */
+static void FN(bsr_diag_point)(const REAL *D, REAL *res, const REAL *src, REAL *xi,
+                               int bs, int dirn, int jac, REAL omega)
+{
+    const int k0 = dirn > 0 ? 0 : bs - 1, k1 = dirn > 0 ? bs : -1;
+    for (int k = k0; k != k1; k += dirn) {
+        REAL d = 1;
+        for (int kk = k0; kk != k1; kk += dirn) {
+            if (kk == k) d = D[k * bs + kk];
+            else         res[k] -= D[k * bs + kk] * src[kk];
+        }
+        if (d != (REAL)0) {
+            if (jac) xi[k] = ((REAL)1 - omega) * src[k] + omega * res[k] / d;
+            else     xi[k] = res[k] / d;
+        }
+    }
+}
+
+/* Point Gauss-Seidel on a BSR matrix with square bs x bs blocks.  Follows amg_core
+ * bsr_gauss_seidel, relaxation.h:185-266: res starts at b_I, every off-diagonal block
+ * subtracts its (fresh-summed) block product, then a point sweep inside the diagonal
+ * block; a block row without a stored diagonal block is skipped. */
+void FN(bsr_gauss_seidel)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x,
+                          const REAL *b, int row_start, int row_stop, int row_step, int bs)
+{
+    REAL res[64], prod[64];
+    const int bb = bs * bs, dirn = row_step < 0 ? -1 : 1;
+    for (int i = row_start; i != row_stop; i += row_step) {
+        long dpos = -1;
+        for (int k = 0; k < bs; ++k) res[k] = b[(long)i * bs + k];
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) { dpos = (long)p * bb; continue; }
+            FN(blk_apply)(Ax + (long)p * bb, x + (long)j * bs, prod, bs);
+            for (int k = 0; k < bs; ++k) res[k] -= prod[k];
+        }
+        if (dpos >= 0)
+            FN(bsr_diag_point)(Ax + dpos, res, x + (long)i * bs, x + (long)i * bs,
+                               bs, dirn, 0, (REAL)0);
+    }
+}
+
+/* Point Jacobi on a BSR matrix.  Follows amg_core bsr_jacobi, relaxation.h:472-562
+ * (snapshot of the first |row_stop-row_start|*bs entries, relaxation.h:505-508; the
+ * Python wrapper always sweeps every block row forward, relaxation.py:396-420). */
+void FN(bsr_jacobi)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REAL *b,
+                    REAL *temp, int row_start, int row_stop, int row_step, int bs,
+                    REAL omega)
+{
+    REAL res[64], prod[64];
+    const int bb = bs * bs, dirn = row_step < 0 ? -1 : 1;
+    long ncopy = (long)(row_stop > row_start ? row_stop - row_start : row_start - row_stop) * bs;
+    for (long q = 0; q < ncopy; ++q) temp[q] = x[q];
+    for (int i = row_start; i != row_stop; i += row_step) {
+        long dpos = -1;
+        for (int k = 0; k < bs; ++k) res[k] = b[(long)i * bs + k];
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) { dpos = (long)p * bb; continue; }
+            FN(blk_apply)(Ax + (long)p * bb, temp + (long)j * bs, prod, bs);
+            for (int k = 0; k < bs; ++k) res[k] -= prod[k];
+        }
+        if (dpos >= 0)
+            FN(bsr_diag_point)(Ax + dpos, res, temp + (long)i * bs, x + (long)i * bs,
+                               bs, dirn, 1, omega);
+    }
+}
+
+/* True block Jacobi with precomputed inverse diagonal blocks Dinv (n_brow,bs,bs).
+ * Follows amg_core block_jacobi, relaxation.h:1021-1090. */
+void FN(block_jacobi)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REAL *b,
+                      const REAL *Dinv, REAL *temp, int row_start, int row_stop,
+                      int row_step, REAL omega, int bs)
+{
+    REAL acc[64], v[64];
+    const int bb = bs * bs;
+    const REAL one = 1;
+    for (int i = row_start; i != row_stop; i += row_step)
+        for (int k = 0; k < bs; ++k) temp[(long)i * bs + k] = x[(long)i * bs + k];
+    for (int i = row_start; i != row_stop; i += row_step) {
+        for (int k = 0; k < bs; ++k) acc[k] = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) continue;
+            FN(blk_apply)(Ax + (long)p * bb, temp + (long)j * bs, v, bs);
+            for (int k = 0; k < bs; ++k) acc[k] += v[k];
+        }
+        for (int k = 0; k < bs; ++k) acc[k] = b[(long)i * bs + k] - acc[k];
+        FN(blk_apply)(Dinv + (long)i * bb, acc, v, bs);
+        for (int k = 0; k < bs; ++k)
+            x[(long)i * bs + k] = (one - omega) * temp[(long)i * bs + k] + omega * v[k];
+    }
+}
+
+/* True block Gauss-Seidel.  Follows amg_core block_gauss_seidel, relaxation.h:1242-1298. */
+void FN(block_gauss_seidel)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x,
+                            const REAL *b, const REAL *Dinv, int row_start, int row_stop,
+                            int row_step, int bs)
+{
+    REAL acc[64], v[64];
+    const int bb = bs * bs;
+    for (int i = row_start; i != row_stop; i += row_step) {
+        for (int k = 0; k < bs; ++k) acc[k] = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) continue;
+            FN(blk_apply)(Ax + (long)p * bb, x + (long)j * bs, v, bs);
+            for (int k = 0; k < bs; ++k) acc[k] += v[k];
+        }
+        for (int k = 0; k < bs; ++k) acc[k] = b[(long)i * bs + k] - acc[k];
+        FN(blk_apply)(Dinv + (long)i * bb, acc, x + (long)i * bs, bs);
+    }
+}

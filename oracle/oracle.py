@@ -1,0 +1,320 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+CPU restatement of the reference solve phase: ctypes bindings of ``liboracle.so``
+(``amg_oracle.c``) plus a NumPy restatement of the reference's Python-side logic
+(smoother wrappers, cycle recursion, outer iteration).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; the product path (``pyamg_amd/``) never does.
+
+Parity status: PINNED (tests/test_oracle.py): against the reference's known answers
+(tests/golden/known_answers.json), against the reference's only numeric fixture
+(docs/paper/example.res.txt, 22 residual norms) and bit-for-bit against the real
+reference (oracle/_ref) on seeded inputs.
+
+Each function cites the reference lines it follows.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+_LIB = None
+
+_I = C.c_int
+_P = C.c_void_p
+
+
+def build(force: bool = False) -> Path:
+    so = HERE / "liboracle.so"
+    srcs = [HERE / "amg_oracle.c", HERE / "amg_oracle_impl.h"]
+    if force or not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
+        subprocess.run(["make", "-C", str(HERE), "-B", "liboracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(str(build()))
+    return _LIB
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _sfx(dt):
+    dt = np.dtype(dt)
+    if dt == np.float64:
+        return "f64", C.c_double
+    if dt == np.float32:
+        return "f32", C.c_float
+    raise TypeError(f"oracle: unsupported dtype {dt}")
+
+
+def _call(name, dt, *args):
+    sfx, _ = _sfx(dt)
+    fn = getattr(lib(), f"orc_{name}_{sfx}")
+    fn.restype = None
+    fn(*args)
+
+
+# ----------------------------------------------------------------- kernels (array level)
+def csr_matvec(n_row, Ap, Aj, Ax, x, y):
+    """y += A x (SciPy csr_matvec semantics)."""
+    _call("csr_matvec", Ax.dtype, _I(n_row), _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(y))
+
+
+def bsr_matvec(n_brow, R, Cc, Ap, Aj, Ax, x, y):
+    _call("bsr_matvec", Ax.dtype, _I(n_brow), _I(R), _I(Cc), _ptr(Ap), _ptr(Aj), _ptr(Ax),
+          _ptr(x), _ptr(y))
+
+
+def gauss_seidel(Ap, Aj, Ax, x, b, row_start, row_stop, row_step):
+    _call("gauss_seidel", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b),
+          _I(row_start), _I(row_stop), _I(row_step))
+
+
+def sor_gauss_seidel(Ap, Aj, Ax, x, b, row_start, row_stop, row_step, omega):
+    _, ct = _sfx(Ax.dtype)
+    _call("sor_gauss_seidel", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b),
+          _I(row_start), _I(row_stop), _I(row_step), ct(omega))
+
+
+def bsr_gauss_seidel(Ap, Aj, Ax, x, b, row_start, row_stop, row_step, blocksize):
+    _call("bsr_gauss_seidel", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b),
+          _I(row_start), _I(row_stop), _I(row_step), _I(blocksize))
+
+
+def jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, omega):
+    _, ct = _sfx(Ax.dtype)
+    _call("jacobi", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b), _ptr(temp),
+          _I(row_start), _I(row_stop), _I(row_step), ct(omega))
+
+
+def bsr_jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, blocksize, omega):
+    _, ct = _sfx(Ax.dtype)
+    _call("bsr_jacobi", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b), _ptr(temp),
+          _I(row_start), _I(row_stop), _I(row_step), _I(blocksize), ct(omega))
+
+
+def block_jacobi(Ap, Aj, Ax, x, b, Dinv, temp, row_start, row_stop, row_step, omega, blocksize):
+    _, ct = _sfx(Ax.dtype)
+    _call("block_jacobi", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b), _ptr(Dinv),
+          _ptr(temp), _I(row_start), _I(row_stop), _I(row_step), ct(omega), _I(blocksize))
+
+
+def block_gauss_seidel(Ap, Aj, Ax, x, b, Dinv, row_start, row_stop, row_step, blocksize):
+    _call("block_gauss_seidel", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b),
+          _ptr(Dinv), _I(row_start), _I(row_stop), _I(row_step), _I(blocksize))
+
+
+# ----------------------------------------------------------------- operator level
+def matvec(op, x):
+    """``op @ x`` for a SparseOp-like (fmt, shape, blocksize, indptr, indices, data);
+    fresh zero-initialised result as SciPy's ``_matmul_vector`` does."""
+    y = np.zeros(op.shape[0], dtype=np.result_type(op.data.dtype, x.dtype))
+    x = np.ascontiguousarray(x, dtype=y.dtype)
+    R, Cc = op.blocksize
+    if op.fmt == "csr":
+        csr_matvec(op.shape[0], op.indptr, op.indices, op.data, x, y)
+    else:
+        bsr_matvec(op.shape[0] // R, R, Cc, op.indptr, op.indices, op.data, x, y)
+    return y
+
+
+def _sweep_bounds(sweep, nrows):
+    if sweep == "forward":
+        return 0, nrows, 1
+    if sweep == "backward":
+        return nrows - 1, -1, -1
+    raise ValueError('valid sweep directions: "forward", "backward", and "symmetric"')
+
+
+def relax_gauss_seidel(A, x, b, iterations=1, sweep="forward", omega=1.0):
+    """relaxation.py:265-346 (incl. its quirks: 'symmetric' drops omega, BSR ignores omega)."""
+    R = A.blocksize[0]
+    if A.fmt == "bsr" and A.blocksize[0] != A.blocksize[1]:
+        raise ValueError("BSR blocks must be square")
+    if sweep == "symmetric":
+        for _ in range(iterations):
+            relax_gauss_seidel(A, x, b, 1, "forward")
+            relax_gauss_seidel(A, x, b, 1, "backward")
+        return
+    bs = 1 if A.fmt == "csr" else R
+    r0, r1, rs = _sweep_bounds(sweep, len(x) // bs)
+    for _ in range(iterations):
+        if A.fmt == "csr":
+            if omega != 1.0:
+                sor_gauss_seidel(A.indptr, A.indices, A.data, x, b, r0, r1, rs, omega)
+            else:
+                gauss_seidel(A.indptr, A.indices, A.data, x, b, r0, r1, rs)
+        else:
+            bsr_gauss_seidel(A.indptr, A.indices, A.data, x, b, r0, r1, rs, R)
+
+
+def relax_sor(A, x, b, omega, iterations=1, sweep="forward"):
+    """relaxation.py:100-154."""
+    for _ in range(iterations):
+        relax_gauss_seidel(A, x, b, 1, sweep, omega)
+
+
+def relax_jacobi(A, x, b, iterations=1, omega=1.0):
+    """relaxation.py:349-420 (always a full forward sweep; temp allocated per call)."""
+    n = A.shape[0]
+    if n <= 0:
+        return
+    temp = np.empty_like(x)
+    om = A.data.dtype.type(omega)
+    for _ in range(iterations):
+        if A.fmt == "csr":
+            jacobi(A.indptr, A.indices, A.data, x, b, temp, 0, n, 1, om)
+        else:
+            R = A.blocksize[0]
+            if A.blocksize[0] != A.blocksize[1]:
+                raise ValueError("BSR blocks must be square")
+            bsr_jacobi(A.indptr, A.indices, A.data, x, b, temp, 0, n // R, 1, R, om)
+
+
+def _as_bsr(A, blocksize):
+    """relaxation.py:475,556: ``A.tobsr(blocksize)`` on every call."""
+    if A.fmt == "bsr" and A.blocksize == (blocksize, blocksize):
+        return A
+    from types import SimpleNamespace
+    M = A.to_scipy().tobsr(blocksize=(blocksize, blocksize))
+    return SimpleNamespace(fmt="bsr", shape=M.shape, blocksize=(blocksize, blocksize),
+                           indptr=M.indptr.astype(np.int32), indices=M.indices.astype(np.int32),
+                           data=np.ascontiguousarray(M.data).reshape(-1))
+
+
+def relax_block_jacobi(A, x, b, Dinv, blocksize, iterations=1, omega=1.0):
+    """relaxation.py:423-499."""
+    A = _as_bsr(A, blocksize)
+    nb = A.shape[0] // blocksize
+    temp = np.empty_like(x)
+    Dflat = np.ascontiguousarray(Dinv).reshape(-1)
+    for _ in range(iterations):
+        block_jacobi(A.indptr, A.indices, A.data, x, b, Dflat, temp, 0, nb, 1,
+                     A.data.dtype.type(omega), blocksize)
+
+
+def relax_block_gauss_seidel(A, x, b, Dinv, blocksize, iterations=1, sweep="forward"):
+    """relaxation.py:502-582."""
+    A = _as_bsr(A, blocksize)
+    Dflat = np.ascontiguousarray(Dinv).reshape(-1)
+    if sweep == "symmetric":
+        for _ in range(iterations):
+            relax_block_gauss_seidel(A, x, b, Dinv, blocksize, 1, "forward")
+            relax_block_gauss_seidel(A, x, b, Dinv, blocksize, 1, "backward")
+        return
+    r0, r1, rs = _sweep_bounds(sweep, len(x) // blocksize)
+    for _ in range(iterations):
+        block_gauss_seidel(A.indptr, A.indices, A.data, x, b, Dflat, r0, r1, rs, blocksize)
+
+
+def relax_polynomial(A, x, b, coefficients, iterations=1):
+    """relaxation.py:585-659: Horner evaluation of p(A) r added to x."""
+    for _ in range(iterations):
+        if np.linalg.norm(x) == 0:
+            residual = b
+        else:
+            residual = b - matvec(A, x)
+        h = coefficients[0] * residual
+        for c in coefficients[1:]:
+            h = c * residual + matvec(A, h)
+        x += h
+
+
+def apply_smoother(s, A, x, b):
+    """Dispatch a SmootherSpec exactly as the reference's bound callable would run."""
+    if s is None or s.kind == "none":
+        return
+    if s.kind == "jacobi":
+        relax_jacobi(A, x, b, s.iterations, s.omega)
+    elif s.kind == "gauss_seidel":
+        relax_gauss_seidel(A, x, b, s.iterations, s.sweep)
+    elif s.kind == "sor":
+        relax_sor(A, x, b, s.omega, s.iterations, s.sweep)
+    elif s.kind == "polynomial":
+        relax_polynomial(A, x, b, s.coefficients, s.iterations)
+    elif s.kind == "block_jacobi":
+        relax_block_jacobi(A, x, b, s.Dinv, s.blocksize, s.iterations, s.omega)
+    elif s.kind == "block_gauss_seidel":
+        relax_block_gauss_seidel(A, x, b, s.Dinv, s.blocksize, s.iterations, s.sweep)
+    else:
+        raise ValueError(f"oracle: unknown smoother kind {s.kind}")
+
+
+# ----------------------------------------------------------------- cycle + outer loop
+class OracleSolver:
+    """NumPy restatement of ``MultilevelSolver.solve`` / ``__solve``
+    (multilevel.py:398-582, 584-662) over a HierarchySpec."""
+
+    def __init__(self, spec):
+        self.spec = spec
+
+    def coarse_solve(self, b):
+        """multilevel.py:717-721 (dense operator applied to b) / :801-803 (nnz == 0)."""
+        if self.spec.coarse_kind == "zero":
+            return np.zeros(b.shape)
+        return np.dot(self.spec.coarse_op, b)
+
+    def cycle(self, lvl, x, b, cycle="V", cycles_per_level=1):
+        """multilevel.py:584-662 (V, W, F)."""
+        L = self.spec.levels[lvl]
+        apply_smoother(L.pre, L.A, x, b)
+        residual = b - matvec(L.A, x)
+        coarse_b = matvec(L.R, residual)
+        coarse_x = np.zeros_like(coarse_b)
+        if lvl == len(self.spec.levels) - 2:
+            coarse_x[:] = self.coarse_solve(coarse_b)
+        elif cycle == "V":
+            self.cycle(lvl + 1, coarse_x, coarse_b, "V")
+        elif cycle == "W":
+            self.cycle(lvl + 1, coarse_x, coarse_b, cycle)
+            self.cycle(lvl + 1, coarse_x, coarse_b, cycle)
+        elif cycle == "F":
+            self.cycle(lvl + 1, coarse_x, coarse_b, cycle, cycles_per_level)
+            for _ in range(cycles_per_level):
+                self.cycle(lvl + 1, coarse_x, coarse_b, "V", 1)
+        else:
+            raise TypeError(f"Unrecognized cycle type ({cycle})")
+        x += matvec(L.P, coarse_x)
+        apply_smoother(L.post, L.A, x, b)
+
+    def solve(self, b, x0=None, tol=1e-5, maxiter=100, cycle="V", residuals=None,
+              callback=None, cycles_per_level=1, return_info=False):
+        """multilevel.py:398-582, accel=None branch."""
+        A = self.spec.levels[0].A
+        x = np.zeros_like(b) if x0 is None else np.array(x0)
+        cycle = str(cycle).upper()
+        normb = np.linalg.norm(b)
+        if normb == 0.0:
+            normb = 1.0
+        tp = np.result_type(b.dtype, x.dtype, A.data.dtype)
+        b = np.ravel(np.asarray(b, dtype=tp))
+        x = np.ravel(np.asarray(x, dtype=tp))
+        normr = np.linalg.norm(b - matvec(A, x))
+        if residuals is not None:
+            residuals[:] = [normr]
+        it = 0
+        while True:
+            if len(self.spec.levels) == 1:
+                x = self.coarse_solve(b)
+            else:
+                self.cycle(0, x, b, cycle, cycles_per_level)
+            it += 1
+            normr = np.linalg.norm(b - matvec(A, x))
+            if residuals is not None:
+                residuals.append(normr)
+            if callback is not None:
+                callback(x)
+            if normr < tol * normb:
+                return (x, 0) if return_info else x
+            if it == maxiter:
+                return (x, it) if return_info else x

@@ -1,0 +1,241 @@
+"""Host-side description of a multigrid hierarchy, ready to ship to HBM once.
+
+The setup phase stays in the unmodified reference on the host (north star); this
+module only *reads* a constructed ``pyamg.MultilevelSolver`` -- duck-typed, pyamg
+is never imported here -- and normalises it into plain arrays:
+
+* every operator becomes a row-oriented ``SparseOp`` (CSR or BSR, int32 indices,
+  flattened values).  The reference's level operators arrive as ``csr_array``
+  (Ruge-Stuben; SA level 0), ``bsr_array`` (SA levels >= 1, P, R -- blocksize (1,1)
+  for scalar PDEs, ``aggregation/tentative.py:142-152``) or ``csc_array`` (``R`` of a
+  hand-built hierarchy, ``multilevel.py:180-182``); see SURVEY.md §8(a3), App. A.5.
+* every smoother callable attached by ``change_smoothers`` (``relaxation/smoothing.py:75``)
+  becomes a ``SmootherSpec`` whose scalars are READ BACK from the callable (partial
+  keywords / closure cells) -- they contain Arnoldi estimates seeded from
+  ``np.random`` (``util/linalg.py:336``) and must never be recomputed.
+* the coarsest-level solver (``multilevel.py:665-826``) becomes a dense operator
+  ``x_c = M b_c`` for the linear direct solvers ('pinv', 'lu', 'cholesky', 'splu').
+
+Anything that cannot be represented raises ``NotImplementedError``: there is no CPU
+fallback in the product path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from functools import partial
+from typing import List, Optional, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+__all__ = ["SparseOp", "SmootherSpec", "LevelSpec", "HierarchySpec", "extract",
+           "sparse_op", "smoother_spec"]
+
+SUPPORTED_DTYPES = (np.float64, np.float32)
+
+
+@dataclass
+class SparseOp:
+    """Row-oriented sparse operator (CSR when blocksize == (1, 1) and fmt == 'csr')."""
+    fmt: str                        # 'csr' | 'bsr'  -- the reference's format (selects arithmetic flavour)
+    shape: Tuple[int, int]
+    blocksize: Tuple[int, int]
+    indptr: np.ndarray              # int32 [n_brow + 1]
+    indices: np.ndarray             # int32 [n_blocks]
+    data: np.ndarray                # T [n_blocks * R * C], blocks row-major
+    src_format: str = "csr"         # format the reference level actually held
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def nnz(self) -> int:
+        return int(self.data.size)
+
+    @property
+    def n_brow(self) -> int:
+        return int(self.indptr.size - 1)
+
+    def to_scipy(self):
+        R, C = self.blocksize
+        if self.fmt == "csr":
+            return sp.csr_array((self.data, self.indices, self.indptr), shape=self.shape)
+        return sp.bsr_array((self.data.reshape(-1, R, C), self.indices, self.indptr),
+                            shape=self.shape)
+
+
+@dataclass
+class SmootherSpec:
+    """One pre/post smoother of one level, as the reference would apply it.
+
+    kind: 'jacobi' | 'gauss_seidel' | 'sor' | 'polynomial' | 'block_jacobi' |
+          'block_gauss_seidel' | 'none'
+    """
+    kind: str
+    iterations: int = 1
+    omega: float = 1.0
+    sweep: str = "forward"
+    coefficients: Optional[np.ndarray] = None
+    Dinv: Optional[np.ndarray] = None           # (n_brow, bs, bs)
+    blocksize: int = 1
+    name: str = ""                              # reference-side display name
+
+
+@dataclass
+class LevelSpec:
+    A: SparseOp
+    P: Optional[SparseOp] = None
+    R: Optional[SparseOp] = None
+    pre: Optional[SmootherSpec] = None
+    post: Optional[SmootherSpec] = None
+
+
+@dataclass
+class HierarchySpec:
+    levels: List[LevelSpec] = field(default_factory=list)
+    coarse_kind: str = "dense"                  # 'dense' (x = M b) | 'zero' (A_c.nnz == 0)
+    coarse_op: Optional[np.ndarray] = None      # dense (n_c, n_c), row-major
+    coarse_name: str = "'pinv'"
+
+    @property
+    def dtype(self):
+        return self.levels[0].A.dtype
+
+
+# --------------------------------------------------------------------------- operators
+def _as_int32(a, what):
+    a = np.asarray(a)
+    if a.size and (a.max(initial=0) > np.iinfo(np.int32).max):
+        raise NotImplementedError(f"{what}: index does not fit int32 (reference is int32-only, "
+                                  "amg_core/instantiate.yml:2-6)")
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def sparse_op(M) -> SparseOp:
+    """Normalise a scipy sparse matrix into a row-oriented SparseOp (no value changes).
+
+    csr -> as is.  bsr -> as is (blocks row-major, flattened).  csc (the lazily
+    transposed ``R = P.T`` of hand-built hierarchies) -> CSR with sorted columns, which
+    makes the per-row summation order equal to the column-scatter order of SciPy's
+    ``csc_matvec``.  Anything else -> CSR.
+    """
+    if not sp.issparse(M):
+        raise NotImplementedError(f"operator of type {type(M).__name__} is not a scipy sparse matrix")
+    if M.dtype.type not in SUPPORTED_DTYPES:
+        raise NotImplementedError(f"dtype {M.dtype} not supported on device (float64/float32 only)")
+    src = M.format
+    if src == "bsr":
+        R, C = M.blocksize
+        return SparseOp("bsr", tuple(M.shape), (int(R), int(C)), _as_int32(M.indptr, "indptr"),
+                        _as_int32(M.indices, "indices"),
+                        np.ascontiguousarray(M.data).reshape(-1), src)
+    if src != "csr":
+        M = M.tocsr()
+        if src == "csc":
+            M.sort_indices()
+    return SparseOp("csr", tuple(M.shape), (1, 1), _as_int32(M.indptr, "indptr"),
+                    _as_int32(M.indices, "indices"), np.ascontiguousarray(M.data), src)
+
+
+# --------------------------------------------------------------------------- smoothers
+def _closure_vars(fn) -> dict:
+    names = getattr(getattr(fn, "__code__", None), "co_freevars", ()) or ()
+    cells = getattr(fn, "__closure__", None) or ()
+    return {n: c.cell_contents for n, c in zip(names, cells)}
+
+
+def smoother_spec(fn, A) -> SmootherSpec:
+    """Translate one smoother callable ``fn(A, x, b)`` into a SmootherSpec.
+
+    Dispatch is on the *wrapped* function (``partial.func``) or on the closure contents,
+    never on ``__name__`` (``update_wrapper`` makes a point smoother advertise itself as
+    ``block_gauss_seidel`` when blocksize == 1, ``smoothing.py:595-599``) -- SURVEY §8(b).
+    """
+    if fn is None:
+        return SmootherSpec("none", iterations=0, name="None")
+    shown = getattr(fn, "__name__", type(fn).__name__)
+    if isinstance(fn, partial):
+        base = fn.func.__name__
+        kw = dict(fn.keywords)
+        it = int(kw.get("iterations", 1))
+        if base == "jacobi":
+            return SmootherSpec("jacobi", it, float(np.real(kw.get("omega", 1.0))), name=shown)
+        if base == "gauss_seidel":
+            return SmootherSpec("gauss_seidel", it, 1.0, kw.get("sweep", "forward"), name=shown)
+        if base == "sor":
+            return SmootherSpec("sor", it, float(kw["omega"]), kw.get("sweep", "forward"), name=shown)
+        if base in ("block_jacobi", "block_gauss_seidel"):
+            Dinv = kw.get("Dinv")
+            bs = kw.get("blocksize")
+            if Dinv is None or bs is None:
+                raise NotImplementedError(f"{base} without precomputed Dinv/blocksize")
+            Dinv = np.ascontiguousarray(Dinv, dtype=A.dtype)
+            if base == "block_jacobi":
+                return SmootherSpec("block_jacobi", it, float(np.real(kw.get("omega", 1.0))),
+                                    Dinv=Dinv, blocksize=int(bs), name=shown)
+            return SmootherSpec("block_gauss_seidel", it, 1.0, kw.get("sweep", "forward"),
+                                Dinv=Dinv, blocksize=int(bs), name=shown)
+        raise NotImplementedError(f"smoother '{base}' is not on the device path")
+    cv = _closure_vars(fn)
+    if shown == "chebyshev" and "coefficients" in cv:
+        return SmootherSpec("polynomial", int(cv["iterations"]),
+                            coefficients=np.asarray(cv["coefficients"], dtype=np.float64).copy(),
+                            name="chebyshev")
+    if shown == "richardson" and "omega" in cv:
+        return SmootherSpec("polynomial", int(cv["iterations"]),
+                            coefficients=np.asarray([cv["omega"]], dtype=np.float64),
+                            name="richardson")
+    raise NotImplementedError(f"smoother '{shown}' is not on the device path")
+
+
+# --------------------------------------------------------------------------- coarse solver
+_LINEAR_COARSE = ("'pinv'", "'pinv2'", "'lu'", "'cholesky'", "'splu'")
+
+
+def _coarse_operator(ml, A_c) -> Tuple[str, Optional[np.ndarray], str]:
+    cs = ml.coarse_solver
+    name = cs.name() if hasattr(cs, "name") else repr(cs)
+    if A_c.nnz == 0:                                    # multilevel.py:801-803
+        return "zero", None, name
+    if name not in _LINEAR_COARSE:
+        raise NotImplementedError(f"coarse solver {name} is not a linear direct solver; "
+                                  "device path supports 'pinv', 'lu', 'cholesky', 'splu'")
+    n = A_c.shape[0]
+    if n > 4096:
+        raise NotImplementedError(f"coarsest level too large for a dense device solve (n={n})")
+    if name in ("'pinv'", "'pinv2'"):
+        # multilevel.py:717-721: P = pinv(A.toarray()) cached on first use, x = np.dot(P, b).
+        # Keep the reference's own array (memory order included) -- it IS the operator.
+        cs(A_c, np.zeros(n, dtype=A_c.dtype))
+        if hasattr(cs, "P"):
+            return "dense", np.asarray(cs.P), name
+    # the solver is linear in b: tabulate it column by column with the reference's own
+    # factorisation (cached inside the GenericSolver on first use, multilevel.py:717-721)
+    eye = np.eye(n, dtype=A_c.dtype)
+    M = np.empty((n, n), dtype=A_c.dtype)
+    for k in range(n):
+        M[:, k] = np.ravel(cs(A_c, eye[:, k].copy()))
+    return "dense", np.ascontiguousarray(M), name
+
+
+# --------------------------------------------------------------------------- entry point
+def extract(ml) -> HierarchySpec:
+    """Read a constructed reference ``MultilevelSolver`` into a HierarchySpec."""
+    levels = ml.levels
+    if len(levels) == 0:
+        raise ValueError("empty hierarchy")
+    spec = HierarchySpec()
+    for i, lvl in enumerate(levels):
+        A = sparse_op(lvl.A)
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("expected square matrix")
+        ls = LevelSpec(A=A)
+        if i < len(levels) - 1:
+            ls.P = sparse_op(lvl.P)
+            ls.R = sparse_op(lvl.R)
+            ls.pre = smoother_spec(getattr(lvl, "presmoother", None), lvl.A)
+            ls.post = smoother_spec(getattr(lvl, "postsmoother", None), lvl.A)
+        spec.levels.append(ls)
+    spec.coarse_kind, spec.coarse_op, spec.coarse_name = _coarse_operator(ml, levels[-1].A)
+    return spec
