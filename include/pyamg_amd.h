@@ -1,0 +1,273 @@
+/*
+ * pyamg_amd.h -- C ABI of the MI355X-native AMG solve-phase engine (libpyamg_amd.so).
+ *
+ * Drop-in boundary for the solve phase behind pyamg.multilevel.MultilevelSolver.solve()
+ * (reference: pyamg/multilevel.py:398-662) and for the amg_core relaxation kernels
+ * (reference: pyamg/amg_core/relaxation.h) plus SciPy's sparsetools SpMV that the
+ * reference borrows (call sites multilevel.py:545,567,612,614,660).
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Two layers:
+ *
+ *   Layer 1  "amg_core-compatible": one symbol per (reference function x dtype) with the
+ *            reference's exact argument order (pointer followed by its length, scalars by
+ *            value -- the convention of amg_core/bindthem.py:77-82).  Pointers are HOST
+ *            buffers, exactly what the reference's pybind11 layer hands to amg_core
+ *            (relaxation_bind.cpp:11-44); the call stages them through HBM, runs the HIP
+ *            kernels and writes x back in place.  The reference returns void; we return a
+ *            status.  This is what a maintainer binds to replace `from pyamg import
+ *            amg_core` call by call.
+ *
+ *   Layer 2  "resident engine": opaque handles for operators and for a whole hierarchy that
+ *            is shipped to HBM once; vectors are DEVICE pointers; everything is
+ *            stream-ordered.  This is what sits behind MultilevelSolver.solve() /
+ *            aspreconditioner().
+ *
+ * Status codes: 0 = ok, > 0 = hipError_t from the runtime, < 0 = PAMG_E_* below.
+ * Index type is int32 only and values are f64 or f32 (reference: instantiate.yml:2-6;
+ * complex is not on the device path).
+ *
+ * Arithmetic contract: every kernel accumulates each row's products sequentially in
+ * storage order with separate multiply and add (no FMA contraction), i.e. in exactly the
+ * order of the reference's scalar loops, so results are bit-identical to the reference
+ * on the same inputs (dense coarse solve and norms excepted: last-bit differences).
+ */
+#ifndef PYAMG_AMD_H
+#define PYAMG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAMG_OK              0
+#define PAMG_E_ARG          -1   /* bad argument (size/shape/enum)            */
+#define PAMG_E_UNSUPPORTED  -2   /* valid in the reference, not on the device */
+#define PAMG_E_NODEVICE     -3   /* no HIP device visible                     */
+#define PAMG_E_STATE        -4   /* call sequence violated                    */
+#define PAMG_E_ALLOC        -5   /* host allocation failed                    */
+
+#define PAMG_F64 0
+#define PAMG_F32 1
+
+typedef void *pamg_stream_t;               /* hipStream_t, NULL = default stream */
+typedef void *pamg_event_t;                /* hipEvent_t                         */
+typedef struct pamg_matrix_s *pamg_matrix_t;
+typedef struct pamg_solver_s *pamg_solver_t;
+
+/* ------------------------------------------------------------------ runtime plumbing */
+const char *pamg_version(void);
+const char *pamg_status_string(int status);
+int pamg_device_count(int *count);
+int pamg_set_device(int device);
+int pamg_get_device(int *device);
+int pamg_device_name(int device, char *buf, int buflen);
+int pamg_malloc(void **dptr, size_t bytes);
+int pamg_free(void *dptr);
+int pamg_memcpy_h2d(void *dst, const void *src, size_t bytes, pamg_stream_t s);
+int pamg_memcpy_d2h(void *dst, const void *src, size_t bytes, pamg_stream_t s);
+int pamg_memcpy_d2d(void *dst, const void *src, size_t bytes, pamg_stream_t s);
+int pamg_memset(void *dst, int byte, size_t bytes, pamg_stream_t s);
+int pamg_stream_create(pamg_stream_t *s);
+int pamg_stream_destroy(pamg_stream_t s);
+int pamg_stream_synchronize(pamg_stream_t s);
+int pamg_device_synchronize(void);
+int pamg_event_create(pamg_event_t *e);
+int pamg_event_destroy(pamg_event_t e);
+int pamg_event_record(pamg_event_t e, pamg_stream_t s);
+int pamg_event_synchronize(pamg_event_t e);
+int pamg_event_elapsed_ms(pamg_event_t start, pamg_event_t stop, float *ms);
+
+/* ------------------------------------------------- Layer 1: amg_core-compatible (HOST) */
+/* SciPy sparsetools csr_matvec / bsr_matvec:  Yx += A * Xx  (argument order of
+ * scipy/sparse/sparsetools/csr.h csr_matvec, bsr.h bsr_matvec). */
+int pamg_csr_matvec_f64(int n_row, int n_col, const int32_t *Ap, const int32_t *Aj,
+                        const double *Ax, const double *Xx, double *Yx);
+int pamg_csr_matvec_f32(int n_row, int n_col, const int32_t *Ap, const int32_t *Aj,
+                        const float *Ax, const float *Xx, float *Yx);
+int pamg_bsr_matvec_f64(int n_brow, int n_bcol, int R, int C, const int32_t *Ap,
+                        const int32_t *Aj, const double *Ax, const double *Xx, double *Yx);
+int pamg_bsr_matvec_f32(int n_brow, int n_bcol, int R, int C, const int32_t *Ap,
+                        const int32_t *Aj, const float *Ax, const float *Xx, float *Yx);
+
+/* amg_core::gauss_seidel, relaxation.h:48-56 */
+int pamg_gauss_seidel_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                          const double *Ax, int Ax_size, double *x, int x_size,
+                          const double *b, int b_size,
+                          int32_t row_start, int32_t row_stop, int32_t row_step);
+int pamg_gauss_seidel_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                          const float *Ax, int Ax_size, float *x, int x_size,
+                          const float *b, int b_size,
+                          int32_t row_start, int32_t row_stop, int32_t row_step);
+/* amg_core::sor_gauss_seidel, relaxation.h:116-125 */
+int pamg_sor_gauss_seidel_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                              const double *Ax, int Ax_size, double *x, int x_size,
+                              const double *b, int b_size, int32_t row_start,
+                              int32_t row_stop, int32_t row_step, double omega);
+int pamg_sor_gauss_seidel_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                              const float *Ax, int Ax_size, float *x, int x_size,
+                              const float *b, int b_size, int32_t row_start,
+                              int32_t row_stop, int32_t row_step, float omega);
+/* amg_core::bsr_gauss_seidel, relaxation.h:185-195 */
+int pamg_bsr_gauss_seidel_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                              const double *Ax, int Ax_size, double *x, int x_size,
+                              const double *b, int b_size, int32_t row_start,
+                              int32_t row_stop, int32_t row_step, int32_t blocksize);
+int pamg_bsr_gauss_seidel_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                              const float *Ax, int Ax_size, float *x, int x_size,
+                              const float *b, int b_size, int32_t row_start,
+                              int32_t row_stop, int32_t row_step, int32_t blocksize);
+/* amg_core::jacobi, relaxation.h:309-319 (omega is a 1-element array, as in the reference) */
+int pamg_jacobi_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                    const double *Ax, int Ax_size, double *x, int x_size,
+                    const double *b, int b_size, double *temp, int temp_size,
+                    int32_t row_start, int32_t row_stop, int32_t row_step,
+                    const double *omega, int omega_size);
+int pamg_jacobi_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                    const float *Ax, int Ax_size, float *x, int x_size,
+                    const float *b, int b_size, float *temp, int temp_size,
+                    int32_t row_start, int32_t row_stop, int32_t row_step,
+                    const float *omega, int omega_size);
+/* amg_core::bsr_jacobi, relaxation.h:472-483 */
+int pamg_bsr_jacobi_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                        const double *Ax, int Ax_size, double *x, int x_size,
+                        const double *b, int b_size, double *temp, int temp_size,
+                        int32_t row_start, int32_t row_stop, int32_t row_step,
+                        int32_t blocksize, const double *omega, int omega_size);
+int pamg_bsr_jacobi_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                        const float *Ax, int Ax_size, float *x, int x_size,
+                        const float *b, int b_size, float *temp, int temp_size,
+                        int32_t row_start, int32_t row_stop, int32_t row_step,
+                        int32_t blocksize, const float *omega, int omega_size);
+/* amg_core::block_jacobi, relaxation.h:1021-1033 (Tx = inverse diagonal blocks) */
+int pamg_block_jacobi_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                          const double *Ax, int Ax_size, double *x, int x_size,
+                          const double *b, int b_size, const double *Tx, int Tx_size,
+                          double *temp, int temp_size, int32_t row_start, int32_t row_stop,
+                          int32_t row_step, const double *omega, int omega_size,
+                          int32_t blocksize);
+int pamg_block_jacobi_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                          const float *Ax, int Ax_size, float *x, int x_size,
+                          const float *b, int b_size, const float *Tx, int Tx_size,
+                          float *temp, int temp_size, int32_t row_start, int32_t row_stop,
+                          int32_t row_step, const float *omega, int omega_size,
+                          int32_t blocksize);
+/* amg_core::block_gauss_seidel, relaxation.h:1242-1252 */
+int pamg_block_gauss_seidel_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj,
+                                int Aj_size, const double *Ax, int Ax_size, double *x,
+                                int x_size, const double *b, int b_size, const double *Tx,
+                                int Tx_size, int32_t row_start, int32_t row_stop,
+                                int32_t row_step, int32_t blocksize);
+int pamg_block_gauss_seidel_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj,
+                                int Aj_size, const float *Ax, int Ax_size, float *x,
+                                int x_size, const float *b, int b_size, const float *Tx,
+                                int Tx_size, int32_t row_start, int32_t row_stop,
+                                int32_t row_step, int32_t blocksize);
+
+/* ------------------------------------------------------ Layer 2: resident engine (HBM) */
+/* Operator handle: uploads CSR/BSR arrays (HOST pointers) to HBM once and analyses them
+ * (row-block plan for the LDS-streamed kernels; dependency-level schedules for the
+ * order-exact Gauss-Seidel sweeps are built lazily).
+ *   flavour: PAMG_CSR for a reference csr_array, PAMG_BSR for a reference bsr_array --
+ *   selects which reference loop's arithmetic order the smoothers reproduce (amg_core
+ *   jacobi/gauss_seidel vs bsr_jacobi/bsr_gauss_seidel; SpMV is the same for both).
+ *   R x C is the block size ((1,1) for CSR).  */
+#define PAMG_CSR 0
+#define PAMG_BSR 1
+int pamg_matrix_create(pamg_matrix_t *A, int dtype, int flavour, int n_brow, int n_bcol,
+                       int R, int C, const int32_t *Ap, const int32_t *Aj, const void *Ax);
+int pamg_matrix_destroy(pamg_matrix_t A);
+/* info[0]=rows info[1]=cols info[2]=stored scalars info[3]=row blocks info[4]=lds entries
+ * per block info[5]=bytes resident in HBM info[6]=fwd GS levels (0 = not analysed)
+ * info[7]=bwd GS levels */
+int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
+/* tuning knobs for experiments: key 0 = lds entries per block, 1 = nnz per lane (1|2),
+ * 2 = max rows per block.  Must be called before first use; re-plans the operator. */
+int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
+
+/* SpMV family (x, y, b, v are DEVICE vectors of the operator's dtype).  mode:           */
+#define PAMG_SPMV_SET      0   /* y  = A x                                              */
+#define PAMG_SPMV_ACC      1   /* y += A x              (x += P x_c, multilevel.py:660) */
+#define PAMG_SPMV_RESID    2   /* y  = b - A x          (multilevel.py:612)             */
+#define PAMG_SPMV_AXPBY    3   /* y  = c*v + A x        (relaxation.py:657 Horner step) */
+#define PAMG_SPMV_ACC_AXPBY 4  /* y += c*v + A x        (Horner last step fused with x += h) */
+int pamg_matrix_spmv(pamg_matrix_t A, int mode, const void *x, const void *b_or_v, double c,
+                     void *y, pamg_stream_t s);
+/* ||b - A x||_2^2 without storing the residual; result (one value of dtype f64) written
+ * to DEVICE address out_sumsq (multilevel.py:545,567 convergence check). */
+int pamg_matrix_resid_sumsq(pamg_matrix_t A, const void *x, const void *b, double *out_sumsq,
+                            pamg_stream_t s);
+
+/* Smoothers, in place on DEVICE x (work = DEVICE scratch vector of length n; for the
+ * polynomial smoother 2n).  sweep: */
+#define PAMG_FORWARD   0
+#define PAMG_BACKWARD  1
+#define PAMG_SYMMETRIC 2
+int pamg_matrix_jacobi(pamg_matrix_t A, void *x, const void *b, void *work, double omega,
+                       int iterations, pamg_stream_t s);
+/* gauss_seidel / sor as the reference's Python wrappers run them (relaxation.py:265-346,
+ * 100-154, quirks included: 'symmetric' ignores omega, BSR flavour ignores omega). */
+int pamg_matrix_gauss_seidel(pamg_matrix_t A, void *x, const void *b, int sweep, double omega,
+                             int iterations, pamg_stream_t s);
+/* relaxation.polynomial (relaxation.py:585-659); coeffs is a HOST array; x_is_zero != 0
+ * asserts x == 0 on entry (the reference tests norm(x) == 0, relaxation.py:649). */
+int pamg_matrix_polynomial(pamg_matrix_t A, void *x, const void *b, void *work,
+                           const double *coeffs, int ncoeffs, int iterations, int x_is_zero,
+                           pamg_stream_t s);
+/* true block relaxation with DEVICE Dinv (n_brow x bs x bs) (relaxation.py:423-582) */
+int pamg_matrix_block_jacobi(pamg_matrix_t A, void *x, const void *b, void *work,
+                             const void *Dinv, double omega, int iterations, pamg_stream_t s);
+int pamg_matrix_block_gauss_seidel(pamg_matrix_t A, void *x, const void *b, const void *Dinv,
+                                   int sweep, int iterations, pamg_stream_t s);
+
+/* BLAS-1 on DEVICE vectors */
+int pamg_vec_sumsq(int dtype, int64_t n, const void *x, double *out_sumsq, pamg_stream_t s);
+int pamg_vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, pamg_stream_t s);
+int pamg_vec_scale(int dtype, int64_t n, double a, const void *x, void *y, pamg_stream_t s);
+
+/* Hierarchy / cycle / outer iteration (MultilevelSolver, multilevel.py:17-662).         */
+#define PAMG_SMOOTH_NONE        0
+#define PAMG_SMOOTH_JACOBI      1
+#define PAMG_SMOOTH_GS          2
+#define PAMG_SMOOTH_SOR         3
+#define PAMG_SMOOTH_POLY        4
+#define PAMG_SMOOTH_BLOCK_JACOBI 5
+#define PAMG_SMOOTH_BLOCK_GS    6
+#define PAMG_CYCLE_V 0
+#define PAMG_CYCLE_W 1
+#define PAMG_CYCLE_F 2
+int pamg_solver_create(pamg_solver_t *S, int dtype);
+int pamg_solver_destroy(pamg_solver_t S);
+/* levels are added fine -> coarse; P and R are NULL for the coarsest level.  The solver
+ * borrows the handles (caller keeps them alive and destroys them afterwards). */
+int pamg_solver_add_level(pamg_solver_t S, pamg_matrix_t A, pamg_matrix_t P, pamg_matrix_t R);
+/* which: 0 = presmoother, 1 = postsmoother.  coeffs / Dinv are HOST arrays (copied). */
+int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, int iterations,
+                             double omega, int sweep, const double *coeffs, int ncoeffs,
+                             const void *Dinv, int blocksize);
+/* coarsest solve x_c = M b_c with HOST row-major M (n_c x n_c); M == NULL: x_c = 0
+ * (multilevel.py:717-721, 801-803) */
+int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c);
+int pamg_solver_finalize(pamg_solver_t S);
+/* one multigrid cycle on DEVICE x, b of level 0 (multilevel.py:584-662) */
+int pamg_solver_cycle(pamg_solver_t S, void *x, const void *b, int cycle, int cycles_per_level,
+                      pamg_stream_t s);
+/* the accel=None branch of MultilevelSolver.solve (multilevel.py:537-582) on DEVICE x (in:
+ * initial guess, out: solution) and b.  residuals: HOST array of maxiter+1 doubles (may be
+ * NULL); *n_iter = cycles run; *info = 0 if ||r|| < tol*||b|| was met else n_iter.
+ * check_every: 1 = test convergence after every cycle as the reference does; k > 1 = read
+ * the norms back every k cycles only (fewer host syncs; may overshoot by < k cycles). */
+int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int maxiter,
+                      int cycle, int cycles_per_level, int check_every, double *residuals,
+                      int *n_iter, int *info, pamg_stream_t s);
+/* use hipGraph replay for the cycle (default 1) */
+int pamg_solver_set_graph(pamg_solver_t S, int enable);
+/* stats[0]=levels stats[1]=kernel launches per V-cycle stats[2]=HBM bytes resident
+ * stats[3]=algorithmic bytes per V-cycle (incl. convergence check) */
+int pamg_solver_stats(pamg_solver_t S, int64_t stats[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYAMG_AMD_H */

@@ -1,0 +1,67 @@
+"""Build recipe for libpyamg_amd.so (hand-written HIP for gfx950 only, built in-tree).
+
+    python -m pyamg_amd._build [--force]
+
+hipcc cross-compiles without a GPU.  ``-ffp-contract=off`` is part of the arithmetic
+contract (no FMA contraction: results stay bit-identical to the reference's scalar loops).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libpyamg_amd.so"
+SOURCES = ["pamg_matrix.hip", "pamg_solver.hip", "pamg_capi.hip"]
+HEADERS = ["pamg_common.h", "pamg_kernels.h", "../../include/pyamg_amd.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and Path(c).exists():
+            return c
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libpyamg_amd.so)")
+
+
+def stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + [(CSRC / h).resolve() for h in HEADERS] + [Path(__file__)]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    if not force and not stale():
+        return LIB
+    cc = hipcc()
+    objdir = PKG / "build"
+    objdir.mkdir(exist_ok=True)
+
+    def one(src: str) -> Path:
+        obj = objdir / (src + ".o")
+        cmd = [cc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(one, SOURCES))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,112 @@
+"""GPU twins of the ``pyamg.amg_core`` relaxation entry points and of SciPy's
+``_sparsetools.csr_matvec`` / ``bsr_matvec`` -- same names, same positional arguments
+(NumPy host buffers, in-place on ``x`` / ``Yx``), bound through ctypes to Layer 1 of the
+C ABI (include/pyamg_amd.h).  This is the stub a maintainer drops in place of
+``from pyamg import amg_core`` for the solve path.
+
+Like the reference's pybind11 overload set (relaxation_bind.cpp:708-715, ``.noconvert()``)
+every array must already have the right dtype: a mismatch raises ``TypeError``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi as capi
+
+__all__ = ["csr_matvec", "bsr_matvec", "gauss_seidel", "sor_gauss_seidel", "bsr_gauss_seidel",
+           "jacobi", "bsr_jacobi", "block_jacobi", "block_gauss_seidel"]
+
+
+def _sfx(Ax, *vals):
+    dt = Ax.dtype
+    if dt not in (np.float64, np.float32):
+        raise TypeError("incompatible function arguments (float32/float64 only on the device path)")
+    for v in vals:
+        if not isinstance(v, np.ndarray) or v.dtype != dt or not v.flags.c_contiguous:
+            raise TypeError("incompatible function arguments (dtype mismatch or non-contiguous array)")
+    return "f64" if dt == np.float64 else "f32"
+
+
+def _idx(*arrs):
+    for a in arrs:
+        if not isinstance(a, np.ndarray) or a.dtype != np.int32 or not a.flags.c_contiguous:
+            raise TypeError("incompatible function arguments (index arrays must be contiguous int32)")
+
+
+def _csr5(Ap, Aj, Ax, x, b):
+    p = capi.ptr
+    return (p(Ap), Ap.size, p(Aj), Aj.size, p(Ax), Ax.size, p(x), x.size, p(b), b.size)
+
+
+def csr_matvec(n_row, n_col, Ap, Aj, Ax, Xx, Yx):
+    """Yx += A @ Xx (scipy.sparse._sparsetools.csr_matvec)."""
+    _idx(Ap, Aj)
+    s = _sfx(Ax, Xx, Yx)
+    capi.check(getattr(capi.lib(), f"pamg_csr_matvec_{s}")(int(n_row), int(n_col), capi.ptr(Ap), capi.ptr(Aj),
+                                                          capi.ptr(Ax), capi.ptr(Xx), capi.ptr(Yx)), "csr_matvec")
+
+
+def bsr_matvec(n_brow, n_bcol, R, C, Ap, Aj, Ax, Xx, Yx):
+    """Yx += A @ Xx for BSR with R x C blocks (scipy.sparse._sparsetools.bsr_matvec)."""
+    _idx(Ap, Aj)
+    s = _sfx(Ax, Xx, Yx)
+    capi.check(getattr(capi.lib(), f"pamg_bsr_matvec_{s}")(int(n_brow), int(n_bcol), int(R), int(C), capi.ptr(Ap),
+                                                          capi.ptr(Aj), capi.ptr(Ax), capi.ptr(Xx), capi.ptr(Yx)),
+               "bsr_matvec")
+
+
+def gauss_seidel(Ap, Aj, Ax, x, b, row_start, row_stop, row_step):
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, b)
+    capi.check(getattr(capi.lib(), f"pamg_gauss_seidel_{s}")(*_csr5(Ap, Aj, Ax, x, b), int(row_start),
+                                                            int(row_stop), int(row_step)), "gauss_seidel")
+
+
+def sor_gauss_seidel(Ap, Aj, Ax, x, b, row_start, row_stop, row_step, omega):
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, b)
+    capi.check(getattr(capi.lib(), f"pamg_sor_gauss_seidel_{s}")(*_csr5(Ap, Aj, Ax, x, b), int(row_start),
+                                                                int(row_stop), int(row_step), float(omega)),
+               "sor_gauss_seidel")
+
+
+def bsr_gauss_seidel(Ap, Aj, Ax, x, b, row_start, row_stop, row_step, blocksize):
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, b)
+    capi.check(getattr(capi.lib(), f"pamg_bsr_gauss_seidel_{s}")(*_csr5(Ap, Aj, Ax, x, b), int(row_start),
+                                                                int(row_stop), int(row_step), int(blocksize)),
+               "bsr_gauss_seidel")
+
+
+def jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, omega):
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, b, temp, omega)
+    capi.check(getattr(capi.lib(), f"pamg_jacobi_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(temp), temp.size,
+                                                      int(row_start), int(row_stop), int(row_step),
+                                                      capi.ptr(omega), omega.size), "jacobi")
+
+
+def bsr_jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, blocksize, omega):
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, b, temp, omega)
+    capi.check(getattr(capi.lib(), f"pamg_bsr_jacobi_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(temp), temp.size,
+                                                          int(row_start), int(row_stop), int(row_step),
+                                                          int(blocksize), capi.ptr(omega), omega.size),
+               "bsr_jacobi")
+
+
+def block_jacobi(Ap, Aj, Ax, x, b, Tx, temp, row_start, row_stop, row_step, omega, blocksize):
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, b, Tx, temp, omega)
+    capi.check(getattr(capi.lib(), f"pamg_block_jacobi_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(Tx), Tx.size,
+                                                            capi.ptr(temp), temp.size, int(row_start),
+                                                            int(row_stop), int(row_step), capi.ptr(omega),
+                                                            omega.size, int(blocksize)), "block_jacobi")
+
+
+def block_gauss_seidel(Ap, Aj, Ax, x, b, Tx, row_start, row_stop, row_step, blocksize):
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, b, Tx)
+    capi.check(getattr(capi.lib(), f"pamg_block_gauss_seidel_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(Tx), Tx.size,
+                                                                  int(row_start), int(row_stop), int(row_step),
+                                                                  int(blocksize)), "block_gauss_seidel")

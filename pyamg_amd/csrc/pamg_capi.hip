@@ -1,0 +1,283 @@
+// pamg_capi.hip -- runtime plumbing and Layer 1 of the C ABI: the amg_core-compatible
+// entry points that take HOST buffers exactly like the reference's pybind11 layer
+// (pyamg/amg_core/relaxation_bind.cpp:11-44) and run the sweep on the GPU.
+#include <algorithm>
+#include <new>
+
+#include "pamg_common.h"
+
+using namespace pamg;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return (int)hipMalloc(&p, std::max<size_t>(bytes, 256)); }
+    int put(const void *h, size_t bytes)
+    {
+        PAMG_TRY(alloc(bytes));
+        if (bytes) PAMG_HIP(hipMemcpy(p, h, bytes, hipMemcpyHostToDevice));
+        return PAMG_OK;
+    }
+    int get(void *h, size_t bytes) const
+    {
+        if (bytes) PAMG_HIP(hipMemcpy(h, p, bytes, hipMemcpyDeviceToHost));
+        return PAMG_OK;
+    }
+};
+
+struct MatGuard {
+    pamg_matrix_t A = nullptr;
+    ~MatGuard() { if (A) pamg_matrix_destroy(A); }
+};
+
+template <typename T> constexpr int dt() { return sizeof(T) == 8 ? PAMG_F64 : PAMG_F32; }
+
+int check_csr(const int32_t *Ap, int Ap_size, int Aj_size, int Ax_size, int bb)
+{
+    if (!Ap || Ap_size < 1) return PAMG_E_ARG;
+    const int64_t nb = Ap[Ap_size - 1];
+    if (nb < 0 || nb > Aj_size || nb * bb > Ax_size) return PAMG_E_ARG;
+    return PAMG_OK;
+}
+
+template <typename T>
+int l1_matvec(int n_brow, int n_bcol, int R, int C, const int32_t *Ap, const int32_t *Aj, const T *Ax,
+              const T *Xx, T *Yx)
+{
+    if (n_brow < 0 || n_bcol < 0 || !Ap || (!Xx && n_bcol) || (!Yx && n_brow)) return PAMG_E_ARG;
+    MatGuard g;
+    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), (R == 1 && C == 1) ? PAMG_CSR : PAMG_BSR, n_brow, n_bcol, R, C, Ap, Aj, Ax));
+    DevBuf x, y;
+    PAMG_TRY(x.put(Xx, sizeof(T) * (size_t)n_bcol * C));
+    PAMG_TRY(y.put(Yx, sizeof(T) * (size_t)n_brow * R));
+    PAMG_TRY(stream_launch(g.A, EPI_ACCSEQ, x.p, nullptr, y.p, 0.0, 0.0, nullptr, nullptr));
+    PAMG_HIP(hipDeviceSynchronize());
+    return y.get(Yx, sizeof(T) * (size_t)n_brow * R);
+}
+
+// gauss_seidel / sor_gauss_seidel / bsr_gauss_seidel
+template <typename T>
+int l1_gs(int epi, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size,
+          T *x, int x_size, const T *b, int b_size, int row_start, int row_stop, int row_step, double omega,
+          int bs)
+{
+    if (bs < 1 || !x || !b) return PAMG_E_ARG;
+    PAMG_TRY(check_csr(Ap, Ap_size, Aj_size, Ax_size, bs * bs));
+    const int nb = Ap_size - 1;
+    if ((int64_t)nb * bs > x_size || (int64_t)nb * bs > b_size) return PAMG_E_ARG;
+    if (row_start == row_stop) return PAMG_OK;
+    MatGuard g;
+    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), epi == EPI_GS_B ? PAMG_BSR : PAMG_CSR, nb, nb, bs, bs, Ap, Aj, Ax));
+    DevBuf dx, db;
+    PAMG_TRY(dx.put(x, sizeof(T) * (size_t)nb * bs));
+    PAMG_TRY(db.put(b, sizeof(T) * (size_t)nb * bs));
+    PAMG_TRY(gs_sweep(g.A, epi, dx.p, db.p, omega, row_start, row_stop, row_step, nullptr));
+    PAMG_HIP(hipDeviceSynchronize());
+    return dx.get(x, sizeof(T) * (size_t)nb * bs);
+}
+
+// jacobi / bsr_jacobi: the device sweep relaxes every row out of place; the reference only
+// rewrites the rows of the (row_start,row_stop,row_step) slice and leaves their old values
+// in temp (relaxation.h:321-323), which is applied here while copying back.
+template <typename T>
+int l1_jacobi(bool bsr, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,
+              int Ax_size, T *x, int x_size, const T *b, int b_size, T *temp, int temp_size, int row_start,
+              int row_stop, int row_step, int bs, const T *omega, int omega_size)
+{
+    if (bs < 1 || !x || !b || !temp || !omega || omega_size < 1 || row_step == 0) return PAMG_E_ARG;
+    PAMG_TRY(check_csr(Ap, Ap_size, Aj_size, Ax_size, bs * bs));
+    const int nb = Ap_size - 1;
+    const int64_t n = (int64_t)nb * bs;
+    if (n > x_size || n > b_size || n > temp_size) return PAMG_E_ARG;
+    const long span = (long)row_stop - row_start;
+    if (span % row_step != 0 || span / row_step < 0) return PAMG_E_ARG;
+    const long m = span / row_step;
+    if (m == 0) return PAMG_OK;
+    if (row_start < 0 || row_start >= nb || row_start + (m - 1) * row_step < 0 || row_start + (m - 1) * row_step >= nb)
+        return PAMG_E_ARG;
+    if (bsr && !(row_start == 0 && row_stop == nb && row_step == 1))
+        return PAMG_E_UNSUPPORTED;      // the reference's partial bsr sweep snapshots x[0:m*bs] (relaxation.h:505-508)
+    MatGuard g;
+    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), bsr ? PAMG_BSR : PAMG_CSR, nb, nb, bs, bs, Ap, Aj, Ax));
+    DevBuf dx, db, dn;
+    PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
+    PAMG_TRY(db.put(b, sizeof(T) * (size_t)n));
+    PAMG_TRY(dn.alloc(sizeof(T) * (size_t)n));
+    if (bs > 1)
+        PAMG_TRY(block_jacobi_step(g.A, PNT_JACOBI, nullptr, dx.p, dn.p, db.p, (double)omega[0], nullptr));
+    else
+        PAMG_TRY(stream_launch(g.A, bsr ? EPI_JACOBI_B : EPI_JACOBI, dx.p, db.p, dn.p, 0.0, (double)omega[0], nullptr, nullptr));
+    PAMG_HIP(hipDeviceSynchronize());
+    std::vector<T> xn((size_t)n);
+    PAMG_TRY(dn.get(xn.data(), sizeof(T) * (size_t)n));
+    for (long t = 0; t < m; ++t) {
+        const long i = row_start + t * row_step;
+        for (int k = 0; k < bs; ++k) {
+            temp[i * bs + k] = x[i * bs + k];
+            x[i * bs + k] = xn[(size_t)(i * bs + k)];
+        }
+    }
+    return PAMG_OK;
+}
+
+template <typename T>
+int l1_block(bool gs, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size,
+             T *x, int x_size, const T *b, int b_size, const T *Tx, int Tx_size, T *temp, int temp_size,
+             int row_start, int row_stop, int row_step, const T *omega, int bs)
+{
+    if (bs < 1 || !x || !b || !Tx) return PAMG_E_ARG;
+    if (bs < 2) return PAMG_E_UNSUPPORTED;     // the reference's Python layer maps bs == 1 to the point smoothers
+    PAMG_TRY(check_csr(Ap, Ap_size, Aj_size, Ax_size, bs * bs));
+    const int nb = Ap_size - 1;
+    const int64_t n = (int64_t)nb * bs;
+    if (n > x_size || n > b_size || (int64_t)nb * bs * bs > Tx_size) return PAMG_E_ARG;
+    if (row_start == row_stop) return PAMG_OK;
+    MatGuard g;
+    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), PAMG_BSR, nb, nb, bs, bs, Ap, Aj, Ax));
+    DevBuf dx, db, dd, dn;
+    PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
+    PAMG_TRY(db.put(b, sizeof(T) * (size_t)n));
+    PAMG_TRY(dd.put(Tx, sizeof(T) * (size_t)nb * bs * bs));
+    if (gs) {
+        PAMG_TRY(block_gs_sweep(g.A, dx.p, db.p, dd.p, row_start, row_stop, row_step, nullptr));
+        PAMG_HIP(hipDeviceSynchronize());
+        return dx.get(x, sizeof(T) * (size_t)n);
+    }
+    if (!temp || n > temp_size || !omega) return PAMG_E_ARG;
+    if (!((row_start == 0 && row_stop == nb && row_step == 1) || (row_start == nb - 1 && row_stop == -1 && row_step == -1)))
+        return PAMG_E_UNSUPPORTED;
+    PAMG_TRY(dn.alloc(sizeof(T) * (size_t)n));
+    PAMG_TRY(block_jacobi_step(g.A, BLK_JACOBI, dd.p, dx.p, dn.p, db.p, (double)omega[0], nullptr));
+    PAMG_HIP(hipDeviceSynchronize());
+    std::memcpy(temp, x, sizeof(T) * (size_t)n);
+    return dn.get(x, sizeof(T) * (size_t)n);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------ plumbing
+const char *pamg_version(void) { return "pyamg_amd 0.1.0 (gfx950, ROCm " PAMG_STR(HIP_VERSION_MAJOR) "." PAMG_STR(HIP_VERSION_MINOR) ")"; }
+
+const char *pamg_status_string(int st)
+{
+    switch (st) {
+        case PAMG_OK: return "ok";
+        case PAMG_E_ARG: return "invalid argument";
+        case PAMG_E_UNSUPPORTED: return "not supported on the device path";
+        case PAMG_E_NODEVICE: return "no HIP device";
+        case PAMG_E_STATE: return "invalid call sequence";
+        case PAMG_E_ALLOC: return "host allocation failed";
+    }
+    if (st > 0) return hipGetErrorString((hipError_t)st);
+    return "unknown error";
+}
+
+int pamg_device_count(int *count)
+{
+    if (!count) return PAMG_E_ARG;
+    *count = 0;
+    const hipError_t e = hipGetDeviceCount(count);
+    if (e == hipErrorNoDevice) { *count = 0; return PAMG_OK; }
+    return (int)e;
+}
+int pamg_set_device(int device) { return (int)hipSetDevice(device); }
+int pamg_get_device(int *device) { return device ? (int)hipGetDevice(device) : PAMG_E_ARG; }
+int pamg_device_name(int device, char *buf, int buflen)
+{
+    if (!buf || buflen < 1) return PAMG_E_ARG;
+    hipDeviceProp_t p;
+    PAMG_HIP(hipGetDeviceProperties(&p, device));
+    std::snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return PAMG_OK;
+}
+int pamg_malloc(void **dptr, size_t bytes) { return dptr ? (int)hipMalloc(dptr, std::max<size_t>(bytes, 256)) : PAMG_E_ARG; }
+int pamg_free(void *dptr) { return (int)hipFree(dptr); }
+int pamg_memcpy_h2d(void *dst, const void *src, size_t bytes, pamg_stream_t s)
+{
+    if (!bytes) return PAMG_OK;
+    return s ? (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s)
+             : (int)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+}
+int pamg_memcpy_d2h(void *dst, const void *src, size_t bytes, pamg_stream_t s)
+{
+    if (!bytes) return PAMG_OK;
+    return s ? (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)
+             : (int)hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+}
+int pamg_memcpy_d2d(void *dst, const void *src, size_t bytes, pamg_stream_t s)
+{
+    if (!bytes) return PAMG_OK;
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s);
+}
+int pamg_memset(void *dst, int byte, size_t bytes, pamg_stream_t s)
+{
+    if (!bytes) return PAMG_OK;
+    return (int)hipMemsetAsync(dst, byte, bytes, (hipStream_t)s);
+}
+int pamg_stream_create(pamg_stream_t *s) { return s ? (int)hipStreamCreateWithFlags((hipStream_t *)s, hipStreamNonBlocking) : PAMG_E_ARG; }
+int pamg_stream_destroy(pamg_stream_t s) { return (int)hipStreamDestroy((hipStream_t)s); }
+int pamg_stream_synchronize(pamg_stream_t s) { return (int)hipStreamSynchronize((hipStream_t)s); }
+int pamg_device_synchronize(void) { return (int)hipDeviceSynchronize(); }
+int pamg_event_create(pamg_event_t *e) { return e ? (int)hipEventCreate((hipEvent_t *)e) : PAMG_E_ARG; }
+int pamg_event_destroy(pamg_event_t e) { return (int)hipEventDestroy((hipEvent_t)e); }
+int pamg_event_record(pamg_event_t e, pamg_stream_t s) { return (int)hipEventRecord((hipEvent_t)e, (hipStream_t)s); }
+int pamg_event_synchronize(pamg_event_t e) { return (int)hipEventSynchronize((hipEvent_t)e); }
+int pamg_event_elapsed_ms(pamg_event_t a, pamg_event_t b, float *ms) { return ms ? (int)hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b) : PAMG_E_ARG; }
+
+// -------------------------------------------------------------------- Layer 1 (HOST buffers)
+#define PAMG_L1(T, SFX)                                                                                         \
+    int pamg_csr_matvec_##SFX(int n_row, int n_col, const int32_t *Ap, const int32_t *Aj, const T *Ax,          \
+                              const T *Xx, T *Yx)                                                               \
+    { return l1_matvec<T>(n_row, n_col, 1, 1, Ap, Aj, Ax, Xx, Yx); }                                            \
+    int pamg_bsr_matvec_##SFX(int n_brow, int n_bcol, int R, int C, const int32_t *Ap, const int32_t *Aj,       \
+                              const T *Ax, const T *Xx, T *Yx)                                                  \
+    { return l1_matvec<T>(n_brow, n_bcol, R, C, Ap, Aj, Ax, Xx, Yx); }                                          \
+    int pamg_gauss_seidel_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,    \
+                                int Ax_size, T *x, int x_size, const T *b, int b_size, int32_t row_start,       \
+                                int32_t row_stop, int32_t row_step)                                             \
+    { return l1_gs<T>(EPI_GS, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, row_start, row_stop, \
+                      row_step, 1.0, 1); }                                                                      \
+    int pamg_sor_gauss_seidel_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,             \
+                                    const T *Ax, int Ax_size, T *x, int x_size, const T *b, int b_size,         \
+                                    int32_t row_start, int32_t row_stop, int32_t row_step, T omega)             \
+    { return l1_gs<T>(EPI_SOR, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, row_start,          \
+                      row_stop, row_step, (double)omega, 1); }                                                  \
+    int pamg_bsr_gauss_seidel_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,             \
+                                    const T *Ax, int Ax_size, T *x, int x_size, const T *b, int b_size,         \
+                                    int32_t row_start, int32_t row_stop, int32_t row_step, int32_t blocksize)   \
+    { return l1_gs<T>(EPI_GS_B, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, row_start,         \
+                      row_stop, row_step, 1.0, blocksize); }                                                    \
+    int pamg_jacobi_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,          \
+                          int Ax_size, T *x, int x_size, const T *b, int b_size, T *temp, int temp_size,        \
+                          int32_t row_start, int32_t row_stop, int32_t row_step, const T *omega,                \
+                          int omega_size)                                                                       \
+    { return l1_jacobi<T>(false, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, temp, temp_size,  \
+                          row_start, row_stop, row_step, 1, omega, omega_size); }                               \
+    int pamg_bsr_jacobi_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,      \
+                              int Ax_size, T *x, int x_size, const T *b, int b_size, T *temp, int temp_size,    \
+                              int32_t row_start, int32_t row_stop, int32_t row_step, int32_t blocksize,         \
+                              const T *omega, int omega_size)                                                   \
+    { return l1_jacobi<T>(true, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, temp, temp_size,   \
+                          row_start, row_stop, row_step, blocksize, omega, omega_size); }                       \
+    int pamg_block_jacobi_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,    \
+                                int Ax_size, T *x, int x_size, const T *b, int b_size, const T *Tx,             \
+                                int Tx_size, T *temp, int temp_size, int32_t row_start, int32_t row_stop,       \
+                                int32_t row_step, const T *omega, int omega_size, int32_t blocksize)            \
+    { (void)omega_size;                                                                                         \
+      return l1_block<T>(false, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, Tx, Tx_size, temp, \
+                         temp_size, row_start, row_stop, row_step, omega, blocksize); }                         \
+    int pamg_block_gauss_seidel_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,           \
+                                      const T *Ax, int Ax_size, T *x, int x_size, const T *b, int b_size,       \
+                                      const T *Tx, int Tx_size, int32_t row_start, int32_t row_stop,            \
+                                      int32_t row_step, int32_t blocksize)                                      \
+    { return l1_block<T>(true, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, Tx, Tx_size,        \
+                         nullptr, 0, row_start, row_stop, row_step, nullptr, blocksize); }
+
+PAMG_L1(double, f64)
+PAMG_L1(float, f32)
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// pamg_common.h -- shared declarations for libpyamg_amd.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/pyamg_amd.h"
+
+#define PAMG_STR2(x) #x
+#define PAMG_STR(x) PAMG_STR2(x)
+#define PAMG_HIP(expr)                                   \
+    do {                                                 \
+        hipError_t e__ = (expr);                         \
+        if (e__ != hipSuccess) return (int)e__;          \
+    } while (0)
+#define PAMG_TRY(expr)                                   \
+    do {                                                 \
+        int s__ = (expr);                                \
+        if (s__ != PAMG_OK) return s__;                  \
+    } while (0)
+
+namespace pamg {
+
+constexpr int BLK = 256;           // threads per workgroup = 4 wave64
+constexpr int WAVE = 64;
+
+// epilogues of the LDS-streamed CSR kernel (what is done with a finished row sum)
+enum : int {
+    EPI_SET = 0,        // y = s
+    EPI_ACC,            // y = y + s
+    EPI_RESID,          // y = b - s
+    EPI_AXPBY,          // y = c*v + s
+    EPI_ACC_AXPBY,      // y = y + (c*v + s)
+    EPI_SUMSQ,          // partial[block] = sum (b - s)^2     (nothing stored)
+    EPI_ACCSEQ,         // y = ((y + p0) + p1) + ...  (SciPy csr_matvec's running sum from y)
+    EPI_JACOBI,         // amg_core::jacobi            relaxation.h:309-346
+    EPI_JACOBI_B,       // amg_core::bsr_jacobi, 1x1   relaxation.h:472-562
+    EPI_GS,             // amg_core::gauss_seidel      relaxation.h:48-76
+    EPI_GS_B,           // amg_core::bsr_gauss_seidel, 1x1  relaxation.h:185-266
+    EPI_SOR,            // amg_core::sor_gauss_seidel  relaxation.h:116-145
+    EPI_COUNT
+};
+
+constexpr int MAXBS = 8;          // largest square block handled by the block smoothers
+enum : int { BLK_JACOBI = 0, BLK_GS, PNT_JACOBI, PNT_GS };   // block_relax_kernel flavours
+
+template <typename T>
+struct StreamArgs {
+    const int *rowblk;   // [nblocks+1] first row of each workgroup's row range
+    const int *Ap;       // row pointer (of the operator or of a level-permuted copy)
+    const int *Aj;
+    const T *Ax;
+    const int *rid;      // original row id of stored row r (permuted copies) or nullptr
+    const T *x;          // gather source
+    const T *b;          // right-hand side / v
+    T *y;                // destination (== x for the in-place GS family)
+    double *partial;     // EPI_SUMSQ: one double per workgroup
+    T c;                 // EPI_*AXPBY coefficient
+    T omega;
+    int cap;             // products staged in LDS per workgroup
+};
+
+// One dependency-level schedule for an order-exact sweep (forward or backward, or a
+// general (row_start,row_stop,row_step) sweep): a row-permuted copy of the operator with
+// the rows of each level stored contiguously, so every level streams coalesced.
+struct GsSchedule {
+    int row_start = 0, row_stop = 0, row_step = 0;
+    int nlevels = 0;
+    int64_t nrows = 0, nnz = 0;
+    int *d_Ap = nullptr, *d_Aj = nullptr, *d_rid = nullptr, *d_rowblk = nullptr;
+    void *d_Ax = nullptr;
+    std::vector<int> level_blk;      // [nlevels+1] workgroup range of each level
+    size_t bytes = 0;
+};
+
+}  // namespace pamg
+
+struct pamg_matrix_s {
+    int dtype = PAMG_F64;
+    int flavour = PAMG_CSR;
+    int n_brow = 0, n_bcol = 0, R = 1, C = 1;
+    // scalar (flattened) CSR view actually resident in HBM
+    int64_t nrows = 0, ncols = 0, nnz = 0;
+    int *d_Ap = nullptr, *d_Aj = nullptr;
+    void *d_Ax = nullptr;
+    // block view kept for the true block smoothers (bs > 1): block CSR arrays
+    int *d_bAp = nullptr, *d_bAj = nullptr;   // nullptr when R == C == 1
+    void *d_bAx = nullptr;                    // block-ordered values (square blocks only)
+    int64_t nblocks_b = 0;
+    // host copies of the index arrays (needed for lazy GS analysis / re-planning)
+    std::vector<int> h_Ap, h_Aj;
+    std::vector<int> h_bAp, h_bAj;
+    // plan for the streamed kernels
+    int cap = 2048, npl = 1, max_rows = 1024;
+    int nblk = 0;
+    int *d_rowblk = nullptr;
+    double *d_partial = nullptr;     // nblk doubles (sum-of-squares partials)
+    pamg::GsSchedule *gs[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd, bwd, 2 custom
+    size_t bytes = 0;
+};
+
+namespace pamg {
+// launch wrappers implemented in pamg_matrix.hip
+int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void *y, double c,
+                  double omega, double *partial, hipStream_t s);
+int gs_sweep(pamg_matrix_s *A, int epi, void *x, const void *b, double omega, int row_start,
+             int row_stop, int row_step, hipStream_t s);
+int reduce_partials(const double *partial, int n, double *out, hipStream_t s);
+int vec_sumsq(int dtype, int64_t n, const void *x, double *scratch, double *out, hipStream_t s);
+int vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
+int vec_scale(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
+int dense_gemv(int dtype, int n, const void *M, const void *b, void *x, hipStream_t s);
+int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, int row_start,
+                   int row_stop, int row_step, hipStream_t s);
+int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *xsrc, void *xdst,
+                      const void *b, double omega, hipStream_t s);
+int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step);
+inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }
+}  // namespace pamg

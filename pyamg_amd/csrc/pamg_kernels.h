@@ -1,0 +1,355 @@
+// pamg_kernels.h -- device kernels (gfx950, wave64).  No MFMA anywhere: the whole path is
+// HBM-bound sparse streaming (0.13 flop/byte), so the design rules are coalesced streams,
+// LDS staging and enough workgroups in flight to cover HBM latency.
+//
+// The work-horse is csr_stream_kernel ("LDS-streamed CSR"):
+//   phase 1  the workgroup streams its contiguous slice of (Aj, Ax) with fully coalesced
+//            loads -- one lane per stored entry, independent of row boundaries -- gathers
+//            x[Aj] through L1/L2 and parks the products a_ij*x_j (and, for the smoothers,
+//            the column ids) in LDS;
+//   phase 2  one lane per row walks its products in LDS *in storage order* and applies the
+//            epilogue (SpMV / residual / prolongation-add / Horner step / Jacobi / GS ...).
+// Phase 2's strictly sequential per-row summation with separate multiply and add is what
+// makes every result bit-identical to the reference's scalar loops; it costs nothing
+// because LDS bandwidth is an order of magnitude above the HBM stream that bounds us.
+#pragma once
+#include "pamg_common.h"
+
+namespace pamg {
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// sum over the workgroup, result valid in thread 0; sm = >= BLK/64 doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double *sm)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < BLK / 64; ++i) r += sm[i];
+    }
+    return r;
+}
+
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
+template <int EPI> struct EpiTraits {
+    static constexpr bool need_cols = (EPI >= EPI_JACOBI);
+    static constexpr bool perm = (EPI == EPI_GS || EPI == EPI_GS_B || EPI == EPI_SOR);
+    static constexpr bool bsr_order = (EPI == EPI_JACOBI_B || EPI == EPI_GS_B);
+};
+
+// ---- phase 1: stage products (and column ids) of entries [p0,p1) into LDS slots [p-base]
+template <typename T, bool NEEDC, int NPL>
+__device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, int p1, int base,
+                                               T *prod, int *cols)
+{
+    const int tid = threadIdx.x;
+    if constexpr (NPL == 1) {
+        int p = p0 + tid;
+        for (; p + 3 * BLK < p1; p += 4 * BLK) {      // 4 independent load chains in flight
+            const int c0 = a.Aj[p], c1 = a.Aj[p + BLK], c2 = a.Aj[p + 2 * BLK], c3 = a.Aj[p + 3 * BLK];
+            const T v0 = a.Ax[p], v1 = a.Ax[p + BLK], v2 = a.Ax[p + 2 * BLK], v3 = a.Ax[p + 3 * BLK];
+            const T x0 = a.x[c0], x1 = a.x[c1], x2 = a.x[c2], x3 = a.x[c3];
+            prod[p - base] = v0 * x0;
+            prod[p - base + BLK] = v1 * x1;
+            prod[p - base + 2 * BLK] = v2 * x2;
+            prod[p - base + 3 * BLK] = v3 * x3;
+            if constexpr (NEEDC) {
+                cols[p - base] = c0;
+                cols[p - base + BLK] = c1;
+                cols[p - base + 2 * BLK] = c2;
+                cols[p - base + 3 * BLK] = c3;
+            }
+        }
+        for (; p < p1; p += BLK) {
+            const int c0 = a.Aj[p];
+            const T v0 = a.Ax[p];
+            prod[p - base] = v0 * a.x[c0];
+            if constexpr (NEEDC) cols[p - base] = c0;
+        }
+    } else {
+        // two consecutive entries per lane: 8-byte index loads, 16-byte value loads, 16-byte
+        // LDS stores.  base is even, so every pair is naturally aligned; the operator's
+        // arrays are padded so the pair straddling p1 stays inside the allocation.
+        using T2 = typename Vec2<T>::type;
+#pragma unroll 2
+        for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
+            const int2 cc = *reinterpret_cast<const int2 *>(a.Aj + q);
+            const T2 vv = *reinterpret_cast<const T2 *>(a.Ax + q);
+            const bool ok0 = q >= p0, ok1 = q + 1 < p1;
+            const T x0 = ok0 ? a.x[cc.x] : T(0);
+            const T x1 = ok1 ? a.x[cc.y] : T(0);
+            T2 pr;
+            pr.x = vv.x * x0;
+            pr.y = vv.y * x1;
+            *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
+            if constexpr (NEEDC) *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+        }
+    }
+}
+
+// ---- phase 2 pieces
+template <typename T, int EPI>
+__device__ __forceinline__ void row_accumulate(T &s, int &dpos, const T *prod, const int *cols,
+                                               int lo, int hi, int row, int base)
+{
+    if constexpr (!EpiTraits<EPI>::need_cols) {
+        for (int k = lo; k < hi; ++k) s += prod[k];
+    } else {
+        for (int k = lo; k < hi; ++k) {
+            if (cols[k] == row) dpos = base + k;          // last stored diagonal wins
+            else if constexpr (EpiTraits<EPI>::bsr_order) s -= prod[k];
+            else s += prod[k];
+        }
+    }
+}
+
+template <typename T, int EPI>
+__device__ __forceinline__ void row_finish(const StreamArgs<T> &a, T s, int dpos, int row, double &sq)
+{
+    const T one = T(1);
+    if constexpr (EPI == EPI_SET) {
+        a.y[row] = s;
+    } else if constexpr (EPI == EPI_ACCSEQ) {
+        a.y[row] = s;
+    } else if constexpr (EPI == EPI_ACC) {
+        a.y[row] = a.y[row] + s;
+    } else if constexpr (EPI == EPI_RESID) {
+        a.y[row] = a.b[row] - s;
+    } else if constexpr (EPI == EPI_AXPBY) {
+        const T t = a.c * a.b[row];
+        a.y[row] = t + s;
+    } else if constexpr (EPI == EPI_ACC_AXPBY) {
+        const T t = a.c * a.b[row];
+        const T h = t + s;
+        a.y[row] = a.y[row] + h;
+    } else if constexpr (EPI == EPI_SUMSQ) {
+        const T t = a.b[row] - s;
+        sq += (double)t * (double)t;
+    } else if constexpr (EPI == EPI_JACOBI) {
+        const T xo = a.x[row];
+        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
+        a.y[row] = (d != T(0)) ? (one - a.omega) * xo + a.omega * ((a.b[row] - s) / d) : xo;
+    } else if constexpr (EPI == EPI_JACOBI_B) {
+        const T xo = a.x[row];
+        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
+        a.y[row] = (d != T(0)) ? (one - a.omega) * xo + a.omega * s / d : xo;
+    } else if constexpr (EPI == EPI_GS) {
+        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
+        if (d != T(0)) a.y[row] = (a.b[row] - s) / d;
+    } else if constexpr (EPI == EPI_GS_B) {
+        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
+        if (d != T(0)) a.y[row] = s / d;
+    } else if constexpr (EPI == EPI_SOR) {
+        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
+        if (d != T(0)) a.y[row] = a.omega * ((a.b[row] - s) / d) + (one - a.omega) * a.x[row];
+    }
+}
+
+template <typename T, int EPI, int NPL>
+__global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr bool NEEDC = EpiTraits<EPI>::need_cols;
+    const int cap = a.cap;
+    T *prod = reinterpret_cast<T *>(smem_raw);
+    int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(cap + 2));
+    const int tid = threadIdx.x;
+    const int r0 = a.rowblk[blockIdx.x], r1 = a.rowblk[blockIdx.x + 1];
+    const int p0 = a.Ap[r0], p1 = a.Ap[r1];
+    double sq = 0.0;
+
+    if (p1 - p0 <= cap) {
+        const int base = (NPL == 2) ? (p0 & ~1) : p0;
+        stage_products<T, NEEDC, NPL>(a, p0, p1, base, prod, cols);
+        __syncthreads();
+        for (int r = r0 + tid; r < r1; r += BLK) {
+            const int row = EpiTraits<EPI>::perm ? a.rid[r] : r;
+            T s = EpiTraits<EPI>::bsr_order ? a.b[row] : (EPI == EPI_ACCSEQ ? a.y[row] : T(0));
+            int dpos = -1;
+            row_accumulate<T, EPI>(s, dpos, prod, cols, a.Ap[r] - base, a.Ap[r + 1] - base, row, base);
+            row_finish<T, EPI>(a, s, dpos, row, sq);
+        }
+    } else {
+        // one over-long row (the host plan gives it a workgroup of its own): stream it
+        // through LDS chunk by chunk while lane 0 carries the sequential running sum.
+        const int row = EpiTraits<EPI>::perm ? a.rid[r0] : r0;
+        T s = EpiTraits<EPI>::bsr_order ? a.b[row] : (EPI == EPI_ACCSEQ ? a.y[row] : T(0));
+        int dpos = -1;
+        for (int c0 = p0; c0 < p1; c0 += cap) {
+            const int c1 = min(c0 + cap, p1);
+            const int base = (NPL == 2) ? (c0 & ~1) : c0;
+            __syncthreads();
+            stage_products<T, NEEDC, NPL>(a, c0, c1, base, prod, cols);
+            __syncthreads();
+            if (tid == 0) row_accumulate<T, EPI>(s, dpos, prod, cols, c0 - base, c1 - base, row, base);
+        }
+        if (tid == 0) row_finish<T, EPI>(a, s, dpos, row, sq);
+    }
+    if constexpr (EPI == EPI_SUMSQ) {
+        __syncthreads();                                   // LDS reuse for the reduction
+        const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
+        if (tid == 0) a.partial[blockIdx.x] = tot;
+    }
+}
+
+// ------------------------------------------------------------------ BLAS-1 and friends
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_sumsq_kernel(const T *x, int64_t n, double *partial)
+{
+    __shared__ double sm[BLK / 64];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
+        const double v = (double)x[i];
+        acc += v * v;
+    }
+    const double tot = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(BLK) void reduce_final_kernel(const double *partial, int n, double *out)
+{
+    __shared__ double sm[BLK / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += BLK) acc += partial[i];
+    const double tot = block_sum(acc, sm);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_axpy_kernel(int64_t n, T a, const T *x, T *y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
+        const T t = a * x[i];
+        y[i] = y[i] + t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_scale_kernel(int64_t n, T a, const T *x, T *y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK)
+        y[i] = a * x[i];
+}
+
+// x = M b, dense row-major n x n (coarsest-level solve, multilevel.py:717-721): one wave
+// per row, lanes stride the row, butterfly sum.
+template <typename T>
+__global__ __launch_bounds__(BLK) void dense_gemv_kernel(int n, const T *M, const T *b, T *x)
+{
+    const int row = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    double acc = 0.0;
+    for (int k = lane; k < n; k += 64) acc += (double)M[(size_t)row * n + k] * (double)b[k];
+    acc = wave_sum(acc);
+    if (lane == 0) x[row] = (T)acc;
+}
+
+// ------------------------------------------------------------------ true block smoothers
+// One lane per block row; blocks are tiny (bs <= 8) so the dense products stay in
+// registers.  Arithmetic order follows amg_core::block_jacobi / block_gauss_seidel
+// (relaxation.h:1021-1090, 1242-1298) and bsr_jacobi / bsr_gauss_seidel (:472-562, :185-266).
+
+template <typename T>
+struct BlockArgs {
+    const int *bAp, *bAj;   // block CSR
+    const T *Ax;            // blocks, row-major bs x bs
+    const int *rid;         // block-row ids of this launch (level order) or nullptr
+    const T *Dinv;          // (n_brow, bs, bs) or nullptr for the point variants
+    const T *xsrc;          // values coupled through off-diagonal blocks
+    T *xdst;
+    const T *b;
+    T omega;
+    int bs, first, count;   // rows [first, first+count) of rid (or of 0..n_brow)
+    int dirn;               // +1 forward, -1 backward (point sweep inside the diagonal block)
+};
+
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(BLK) void block_relax_kernel(const BlockArgs<T> a)
+{
+    const int t = blockIdx.x * BLK + threadIdx.x;
+    if (t >= a.count) return;
+    const int i = a.rid ? a.rid[a.first + t] : a.first + t;
+    const int bs = a.bs, bb = bs * bs;
+    T acc[MAXBS], v[MAXBS];
+    long dpos = -1;
+    if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
+        for (int k = 0; k < bs; ++k) acc[k] = T(0);
+    } else {
+        for (int k = 0; k < bs; ++k) acc[k] = a.b[(long)i * bs + k];
+    }
+    for (int p = a.bAp[i]; p < a.bAp[i + 1]; ++p) {
+        const int j = a.bAj[p];
+        if (j == i) { dpos = (long)p * bb; continue; }
+        const T *blk = a.Ax + (long)p * bb;
+        const T *xj = a.xsrc + (long)j * bs;
+        for (int r = 0; r < bs; ++r) {
+            T d = T(0);
+            for (int c = 0; c < bs; ++c) d += blk[r * bs + c] * xj[c];
+            v[r] = d;
+        }
+        if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
+            for (int k = 0; k < bs; ++k) acc[k] += v[k];
+        } else {
+            for (int k = 0; k < bs; ++k) acc[k] -= v[k];
+        }
+    }
+    const T one = T(1);
+    if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
+        for (int k = 0; k < bs; ++k) acc[k] = a.b[(long)i * bs + k] - acc[k];
+        const T *Di = a.Dinv + (long)i * bb;
+        for (int r = 0; r < bs; ++r) {
+            T d = T(0);
+            for (int c = 0; c < bs; ++c) d += Di[r * bs + c] * acc[c];
+            v[r] = d;
+        }
+        if constexpr (KIND == BLK_JACOBI) {
+            for (int k = 0; k < bs; ++k)
+                a.xdst[(long)i * bs + k] = (one - a.omega) * a.xsrc[(long)i * bs + k] + a.omega * v[k];
+        } else {
+            for (int k = 0; k < bs; ++k) a.xdst[(long)i * bs + k] = v[k];
+        }
+    } else {
+        // point sweep inside the diagonal block (untouched when no diagonal block is stored)
+        T loc[MAXBS];
+        for (int k = 0; k < bs; ++k) loc[k] = a.xsrc[(long)i * bs + k];
+        if (dpos >= 0) {
+            const T *D = a.Ax + dpos;
+            const int k0 = a.dirn > 0 ? 0 : bs - 1, k1 = a.dirn > 0 ? bs : -1;
+            for (int k = k0; k != k1; k += a.dirn) {
+                T d = one;
+                for (int kk = k0; kk != k1; kk += a.dirn) {
+                    if (kk == k) d = D[k * bs + kk];
+                    else acc[k] -= D[k * bs + kk] * loc[kk];
+                }
+                if (d != T(0)) {
+                    if constexpr (KIND == PNT_JACOBI) {
+                        a.xdst[(long)i * bs + k] = (one - a.omega) * loc[k] + a.omega * acc[k] / d;
+                    } else {
+                        loc[k] = acc[k] / d;            // GS: later points see the new value
+                        a.xdst[(long)i * bs + k] = loc[k];
+                    }
+                } else if constexpr (KIND == PNT_JACOBI) {
+                    a.xdst[(long)i * bs + k] = loc[k];
+                }
+            }
+        } else if constexpr (KIND == PNT_JACOBI) {
+            for (int k = 0; k < bs; ++k) a.xdst[(long)i * bs + k] = loc[k];
+        }
+    }
+}
+
+}  // namespace pamg

@@ -1,0 +1,585 @@
+// pamg_matrix.hip -- operator handle: upload, planning, dependency-level analysis for the
+// order-exact Gauss-Seidel family, kernel dispatch.
+#include <algorithm>
+#include <new>
+
+#include "pamg_kernels.h"
+
+using namespace pamg;
+
+namespace {
+
+constexpr int PAD = 8;   // elements of slack after every index/value array (vector tail loads)
+
+template <typename U>
+int upload(U **dptr, const U *h, size_t n, size_t *bytes)
+{
+    const size_t sz = (n + PAD) * sizeof(U);
+    PAMG_HIP(hipMalloc((void **)dptr, sz));
+    PAMG_HIP(hipMemset(*dptr, 0, sz));
+    if (n) PAMG_HIP(hipMemcpy(*dptr, h, n * sizeof(U), hipMemcpyHostToDevice));
+    if (bytes) *bytes += sz;
+    return PAMG_OK;
+}
+
+int upload_raw(void **dptr, const void *h, size_t n, size_t elt, size_t *bytes)
+{
+    const size_t sz = (n + PAD) * elt;
+    PAMG_HIP(hipMalloc(dptr, sz));
+    PAMG_HIP(hipMemset(*dptr, 0, sz));
+    if (n) PAMG_HIP(hipMemcpy(*dptr, h, n * elt, hipMemcpyHostToDevice));
+    if (bytes) *bytes += sz;
+    return PAMG_OK;
+}
+
+// Greedy split of rows [begin,end) of a CSR row pointer into workgroup row ranges holding
+// at most `cap` stored entries and `max_rows` rows.  A row longer than `cap` gets a range
+// of its own (the kernel streams it in chunks).  Appends range starts to `out`.
+void plan_rows(const int *Ap, int begin, int end, int cap, int max_rows, std::vector<int> &out)
+{
+    int r = begin;
+    while (r < end) {
+        out.push_back(r);
+        const int p0 = Ap[r];
+        int e = r + 1;
+        while (e < end && e - r < max_rows && Ap[e + 1] - p0 <= cap) ++e;
+        r = e;
+    }
+}
+
+int lds_bytes(int dtype, int epi, int cap)
+{
+    const int per = (int)tsize(dtype) + (epi >= EPI_JACOBI ? 4 : 0);
+    return std::max(64, per * (cap + 2));
+}
+
+template <typename T, int EPI>
+int launch_epi(int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a)
+{
+    if (grid <= 0) return PAMG_OK;
+    if (npl == 2) {
+        if (lds > 48 * 1024)
+            PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 2>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 2>), dim3(grid), dim3(BLK), lds, s, a);
+    } else {
+        if (lds > 48 * 1024)
+            PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 1>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 1>), dim3(grid), dim3(BLK), lds, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int launch_any(int epi, int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a)
+{
+    switch (epi) {
+        case EPI_SET: return launch_epi<T, EPI_SET>(npl, grid, lds, s, a);
+        case EPI_ACC: return launch_epi<T, EPI_ACC>(npl, grid, lds, s, a);
+        case EPI_RESID: return launch_epi<T, EPI_RESID>(npl, grid, lds, s, a);
+        case EPI_AXPBY: return launch_epi<T, EPI_AXPBY>(npl, grid, lds, s, a);
+        case EPI_ACC_AXPBY: return launch_epi<T, EPI_ACC_AXPBY>(npl, grid, lds, s, a);
+        case EPI_SUMSQ: return launch_epi<T, EPI_SUMSQ>(npl, grid, lds, s, a);
+        case EPI_ACCSEQ: return launch_epi<T, EPI_ACCSEQ>(npl, grid, lds, s, a);
+        case EPI_JACOBI: return launch_epi<T, EPI_JACOBI>(npl, grid, lds, s, a);
+        case EPI_JACOBI_B: return launch_epi<T, EPI_JACOBI_B>(npl, grid, lds, s, a);
+        case EPI_GS: return launch_epi<T, EPI_GS>(npl, grid, lds, s, a);
+        case EPI_GS_B: return launch_epi<T, EPI_GS_B>(npl, grid, lds, s, a);
+        case EPI_SOR: return launch_epi<T, EPI_SOR>(npl, grid, lds, s, a);
+    }
+    return PAMG_E_ARG;
+}
+
+int replan(pamg_matrix_s *A)
+{
+    if (A->d_rowblk) { hipFree(A->d_rowblk); A->d_rowblk = nullptr; }
+    if (A->d_partial) { hipFree(A->d_partial); A->d_partial = nullptr; }
+    std::vector<int> blk;
+    blk.reserve((size_t)A->nnz / std::max(1, A->cap / 2) + 16);
+    plan_rows(A->h_Ap.data(), 0, (int)A->nrows, A->cap, A->max_rows, blk);
+    blk.push_back((int)A->nrows);
+    A->nblk = (int)blk.size() - 1;
+    PAMG_TRY(upload(&A->d_rowblk, blk.data(), blk.size(), nullptr));
+    PAMG_HIP(hipMalloc((void **)&A->d_partial, sizeof(double) * (size_t)(A->nblk + 8)));
+    return PAMG_OK;
+}
+
+void free_schedule(GsSchedule *g)
+{
+    if (!g) return;
+    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_rowblk);
+    delete g;
+}
+
+// Dependency levels of the sweep i = row_start, row_start+row_step, ... (!= row_stop) over
+// the pattern (Ap, Aj) with n rows.  Row i must run strictly after every connected row
+// visited before it (it reads that row's NEW value) and strictly before every connected
+// row visited after it (it reads that row's OLD value) -- "connected" through a stored
+// entry in either direction, so non-symmetric patterns are handled too.  Rows of one level
+// never touch each other's unknowns.  Output: `order` = visited rows sorted by level
+// (visit order inside a level), `lptr` = [nlevels+1] offsets into order.
+int analyse_levels(int n, const int *Ap, const int *Aj, int row_start, int row_stop, int row_step,
+                   std::vector<int> &order, std::vector<int> &lptr)
+{
+    if (row_step == 0) return PAMG_E_ARG;
+    const long span = (long)row_stop - row_start;
+    if (span % row_step != 0 || span / row_step < 0) return PAMG_E_ARG;
+    const int m = (int)(span / row_step);
+    order.clear();
+    lptr.assign(1, 0);
+    if (m == 0) return PAMG_OK;
+    const long last = (long)row_start + (long)(m - 1) * row_step;
+    if (row_start < 0 || row_start >= n || last < 0 || last >= n) return PAMG_E_ARG;
+    std::vector<int> vis(n, -1), lvl(n, 0), pend(n, 0);
+    for (int t = 0; t < m; ++t) vis[row_start + t * row_step] = t;
+    int maxl = 0;
+    for (int t = 0; t < m; ++t) {
+        const int i = row_start + t * row_step;
+        int L = pend[i];
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i || j < 0 || j >= n) continue;
+            const int tj = vis[j];
+            if (tj >= 0 && tj < t) L = std::max(L, lvl[j] + 1);
+        }
+        lvl[i] = L;
+        maxl = std::max(maxl, L);
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i || j < 0 || j >= n) continue;
+            if (vis[j] > t) pend[j] = std::max(pend[j], L + 1);
+        }
+    }
+    const int nl = maxl + 1;
+    lptr.assign(nl + 1, 0);
+    for (int t = 0; t < m; ++t) lptr[lvl[row_start + t * row_step] + 1]++;
+    for (int l = 0; l < nl; ++l) lptr[l + 1] += lptr[l];
+    order.resize(m);
+    std::vector<int> cur(lptr.begin(), lptr.end() - 1);
+    for (int t = 0; t < m; ++t) {
+        const int i = row_start + t * row_step;
+        order[cur[lvl[i]]++] = i;
+    }
+    return PAMG_OK;
+}
+
+// schedule for the scalar (streamed) path: level-permuted copy of the operator
+int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out)
+{
+    std::vector<int> order, lptr;
+    PAMG_TRY(analyse_levels((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), row_start, row_stop,
+                            row_step, order, lptr));
+    GsSchedule *g = new (std::nothrow) GsSchedule();
+    if (!g) return PAMG_E_ALLOC;
+    g->row_start = row_start; g->row_stop = row_stop; g->row_step = row_step;
+    g->nlevels = (int)lptr.size() - 1;
+    g->nrows = (int64_t)order.size();
+    const int m = (int)order.size();
+    std::vector<int> pAp((size_t)m + 1, 0);
+    for (int r = 0; r < m; ++r) pAp[r + 1] = pAp[r] + (A->h_Ap[order[r] + 1] - A->h_Ap[order[r]]);
+    g->nnz = pAp[m];
+    // permute on the host (one-time setup cost): the values are fetched back from HBM once
+    std::vector<int> pAj((size_t)g->nnz);
+    const size_t ts = tsize(A->dtype);
+    std::vector<unsigned char> hAx((size_t)A->nnz * ts), pAx((size_t)g->nnz * ts);
+    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    for (int r = 0; r < m; ++r) {
+        const int i = order[r];
+        const int len = A->h_Ap[i + 1] - A->h_Ap[i];
+        if (len) {
+            std::memcpy(&pAj[pAp[r]], &A->h_Aj[A->h_Ap[i]], (size_t)len * sizeof(int));
+            std::memcpy(&pAx[(size_t)pAp[r] * ts], &hAx[(size_t)A->h_Ap[i] * ts], (size_t)len * ts);
+        }
+    }
+    std::vector<int> blk;
+    g->level_blk.assign(1, 0);
+    for (int l = 0; l < g->nlevels; ++l) {
+        plan_rows(pAp.data(), lptr[l], lptr[l + 1], A->cap, A->max_rows, blk);
+        g->level_blk.push_back((int)blk.size());
+    }
+    blk.push_back(m);
+    int st = upload(&g->d_Ap, pAp.data(), pAp.size(), &g->bytes);
+    if (!st) st = upload(&g->d_Aj, pAj.data(), pAj.size(), &g->bytes);
+    if (!st) st = upload_raw(&g->d_Ax, pAx.data(), (size_t)g->nnz, ts, &g->bytes);
+    if (!st) st = upload(&g->d_rid, order.data(), order.size(), &g->bytes);
+    if (!st) st = upload(&g->d_rowblk, blk.data(), blk.size(), &g->bytes);
+    if (st) { free_schedule(g); return st; }
+    *out = g;
+    return PAMG_OK;
+}
+
+// schedule for the block path (bs > 1): level-ordered list of block rows only
+int build_schedule_block(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out)
+{
+    std::vector<int> order, lptr;
+    PAMG_TRY(analyse_levels(A->n_brow, A->h_bAp.data(), A->h_bAj.data(), row_start, row_stop,
+                            row_step, order, lptr));
+    GsSchedule *g = new (std::nothrow) GsSchedule();
+    if (!g) return PAMG_E_ALLOC;
+    g->row_start = row_start; g->row_stop = row_stop; g->row_step = row_step;
+    g->nlevels = (int)lptr.size() - 1;
+    g->nrows = (int64_t)order.size();
+    g->level_blk = lptr;                       // here: row offsets of each level
+    int st = upload(&g->d_rid, order.data(), order.size(), &g->bytes);
+    if (st) { free_schedule(g); return st; }
+    *out = g;
+    return PAMG_OK;
+}
+
+int get_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out)
+{
+    for (int k = 0; k < 4; ++k) {
+        GsSchedule *g = A->gs[k];
+        if (g && g->row_start == row_start && g->row_stop == row_stop && g->row_step == row_step) {
+            *out = g;
+            return PAMG_OK;
+        }
+    }
+    GsSchedule *g = nullptr;
+    const bool block = (A->R > 1);
+    PAMG_TRY(block ? build_schedule_block(A, row_start, row_stop, row_step, &g)
+                   : build_schedule_scalar(A, row_start, row_stop, row_step, &g));
+    int slot = -1;
+    for (int k = 0; k < 4; ++k) if (!A->gs[k]) { slot = k; break; }
+    if (slot < 0) { free_schedule(A->gs[3]); slot = 3; }
+    A->gs[slot] = g;
+    A->bytes += g->bytes;
+    *out = g;
+    return PAMG_OK;
+}
+
+template <typename T>
+StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, void *y, double c,
+                        double omega, double *partial)
+{
+    StreamArgs<T> a;
+    a.rowblk = A->d_rowblk;
+    a.Ap = A->d_Ap;
+    a.Aj = A->d_Aj;
+    a.Ax = (const T *)A->d_Ax;
+    a.rid = nullptr;
+    a.x = (const T *)x;
+    a.b = (const T *)b;
+    a.y = (T *)y;
+    a.partial = partial;
+    a.c = (T)c;
+    a.omega = (T)omega;
+    a.cap = A->cap;
+    return a;
+}
+
+double *g_scratch = nullptr;     // 1024 + 8 doubles for the public vec_sumsq
+int g_scratch_dev = -1;
+
+}  // namespace
+
+namespace pamg {
+
+int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void *y, double c,
+                  double omega, double *partial, hipStream_t s)
+{
+    const int lds = lds_bytes(A->dtype, epi, A->cap);
+    if (A->dtype == PAMG_F64)
+        return launch_any<double>(epi, A->npl, A->nblk, lds, s,
+                                  base_args<double>(A, x, b, y, c, omega, partial));
+    return launch_any<float>(epi, A->npl, A->nblk, lds, s,
+                             base_args<float>(A, x, b, y, c, omega, partial));
+}
+
+template <typename T>
+static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b,
+                             double omega, hipStream_t s)
+{
+    StreamArgs<T> a = base_args<T>(A, x, b, x, 0.0, omega, nullptr);
+    a.Ap = g->d_Ap;
+    a.Aj = g->d_Aj;
+    a.Ax = (const T *)g->d_Ax;
+    a.rid = g->d_rid;
+    const int lds = lds_bytes(A->dtype, epi, A->cap);
+    for (int l = 0; l < g->nlevels; ++l) {
+        a.rowblk = g->d_rowblk + g->level_blk[l];
+        PAMG_TRY(launch_any<T>(epi, A->npl, g->level_blk[l + 1] - g->level_blk[l], lds, s, a));
+    }
+    return PAMG_OK;
+}
+
+template <typename T>
+static int block_launch(pamg_matrix_s *A, int kind, const int *rid, int first, int count,
+                        const void *Dinv, const void *xsrc, void *xdst, const void *b, double omega,
+                        int dirn, hipStream_t s)
+{
+    if (count <= 0) return PAMG_OK;
+    BlockArgs<T> a;
+    a.bAp = A->d_bAp; a.bAj = A->d_bAj;
+    a.Ax = (const T *)A->d_bAx;                // block-ordered values
+    a.rid = rid; a.Dinv = (const T *)Dinv;
+    a.xsrc = (const T *)xsrc; a.xdst = (T *)xdst; a.b = (const T *)b;
+    a.omega = (T)omega; a.bs = A->R; a.first = first; a.count = count; a.dirn = dirn;
+    const int grid = (count + BLK - 1) / BLK;
+    switch (kind) {
+        case BLK_JACOBI: hipLaunchKernelGGL((block_relax_kernel<T, BLK_JACOBI>), dim3(grid), dim3(BLK), 0, s, a); break;
+        case BLK_GS: hipLaunchKernelGGL((block_relax_kernel<T, BLK_GS>), dim3(grid), dim3(BLK), 0, s, a); break;
+        case PNT_JACOBI: hipLaunchKernelGGL((block_relax_kernel<T, PNT_JACOBI>), dim3(grid), dim3(BLK), 0, s, a); break;
+        case PNT_GS: hipLaunchKernelGGL((block_relax_kernel<T, PNT_GS>), dim3(grid), dim3(BLK), 0, s, a); break;
+        default: return PAMG_E_ARG;
+    }
+    return (int)hipGetLastError();
+}
+
+// in-place order-exact sweep.  epi: EPI_GS / EPI_GS_B / EPI_SOR for scalar operators; for
+// block operators (bs > 1) epi selects PNT_GS (EPI_GS_B) or BLK_GS (EPI_GS with Dinv in b2).
+int gs_sweep(pamg_matrix_s *A, int epi, void *x, const void *b, double omega, int row_start,
+             int row_stop, int row_step, hipStream_t s)
+{
+    GsSchedule *g = nullptr;
+    PAMG_TRY(get_schedule(A, row_start, row_stop, row_step, &g));
+    if (A->R == 1) {
+        return A->dtype == PAMG_F64 ? gs_sweep_scalar_t<double>(A, g, epi, x, b, omega, s)
+                                    : gs_sweep_scalar_t<float>(A, g, epi, x, b, omega, s);
+    }
+    const int dirn = row_step < 0 ? -1 : 1;
+    for (int l = 0; l < g->nlevels; ++l) {
+        const int first = g->level_blk[l], count = g->level_blk[l + 1] - first;
+        PAMG_TRY(A->dtype == PAMG_F64
+                     ? block_launch<double>(A, PNT_GS, g->d_rid, first, count, nullptr, x, x, b, omega, dirn, s)
+                     : block_launch<float>(A, PNT_GS, g->d_rid, first, count, nullptr, x, x, b, omega, dirn, s));
+    }
+    return PAMG_OK;
+}
+
+int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, int row_start,
+                   int row_stop, int row_step, hipStream_t s)
+{
+    GsSchedule *g = nullptr;
+    PAMG_TRY(get_schedule(A, row_start, row_stop, row_step, &g));
+    for (int l = 0; l < g->nlevels; ++l) {
+        const int first = g->level_blk[l], count = g->level_blk[l + 1] - first;
+        PAMG_TRY(A->dtype == PAMG_F64
+                     ? block_launch<double>(A, BLK_GS, g->d_rid, first, count, Dinv, x, x, b, 0.0, 1, s)
+                     : block_launch<float>(A, BLK_GS, g->d_rid, first, count, Dinv, x, x, b, 0.0, 1, s));
+    }
+    return PAMG_OK;
+}
+
+int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *xsrc, void *xdst,
+                      const void *b, double omega, hipStream_t s)
+{
+    return A->dtype == PAMG_F64
+               ? block_launch<double>(A, kind, nullptr, 0, A->n_brow, Dinv, xsrc, xdst, b, omega, 1, s)
+               : block_launch<float>(A, kind, nullptr, 0, A->n_brow, Dinv, xsrc, xdst, b, omega, 1, s);
+}
+
+int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step)
+{
+    GsSchedule *g = nullptr;
+    return get_schedule(A, row_start, row_stop, row_step, &g);
+}
+
+int reduce_partials(const double *partial, int n, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(BLK), 0, s, partial, n, out);
+    return (int)hipGetLastError();
+}
+
+int vec_sumsq(int dtype, int64_t n, const void *x, double *scratch, double *out, hipStream_t s)
+{
+    const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + BLK - 1) / BLK));
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_sumsq_kernel<double>), dim3(grid), dim3(BLK), 0, s, (const double *)x, n, scratch);
+    else
+        hipLaunchKernelGGL((vec_sumsq_kernel<float>), dim3(grid), dim3(BLK), 0, s, (const float *)x, n, scratch);
+    PAMG_HIP(hipGetLastError());
+    return reduce_partials(scratch, grid, out, s);
+}
+
+static int vgrid(int64_t n) { return (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + BLK - 1) / BLK)); }
+
+int vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s)
+{
+    if (n <= 0) return PAMG_OK;
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_axpy_kernel<double>), dim3(vgrid(n)), dim3(BLK), 0, s, n, a, (const double *)x, (double *)y);
+    else
+        hipLaunchKernelGGL((vec_axpy_kernel<float>), dim3(vgrid(n)), dim3(BLK), 0, s, n, (float)a, (const float *)x, (float *)y);
+    return (int)hipGetLastError();
+}
+
+int vec_scale(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s)
+{
+    if (n <= 0) return PAMG_OK;
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_scale_kernel<double>), dim3(vgrid(n)), dim3(BLK), 0, s, n, a, (const double *)x, (double *)y);
+    else
+        hipLaunchKernelGGL((vec_scale_kernel<float>), dim3(vgrid(n)), dim3(BLK), 0, s, n, (float)a, (const float *)x, (float *)y);
+    return (int)hipGetLastError();
+}
+
+int dense_gemv(int dtype, int n, const void *M, const void *b, void *x, hipStream_t s)
+{
+    if (n <= 0) return PAMG_OK;
+    const int grid = (n + (BLK / 64) - 1) / (BLK / 64);
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((dense_gemv_kernel<double>), dim3(grid), dim3(BLK), 0, s, n, (const double *)M, (const double *)b, (double *)x);
+    else
+        hipLaunchKernelGGL((dense_gemv_kernel<float>), dim3(grid), dim3(BLK), 0, s, n, (const float *)M, (const float *)b, (float *)x);
+    return (int)hipGetLastError();
+}
+
+}  // namespace pamg
+
+// =============================================================================== C ABI
+extern "C" {
+
+int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, int n_bcol, int R,
+                       int C, const int32_t *Ap, const int32_t *Aj, const void *Ax)
+{
+    if (!out || !Ap || n_brow < 0 || n_bcol < 0 || R < 1 || C < 1) return PAMG_E_ARG;
+    if (dtype != PAMG_F64 && dtype != PAMG_F32) return PAMG_E_UNSUPPORTED;
+    if (flavour != PAMG_CSR && flavour != PAMG_BSR) return PAMG_E_ARG;
+    if (flavour == PAMG_CSR && (R != 1 || C != 1)) return PAMG_E_ARG;
+    if (R > MAXBS || C > MAXBS) return PAMG_E_UNSUPPORTED;
+    const int64_t nblk = Ap[n_brow];
+    if (nblk < 0 || (nblk > 0 && (!Aj || !Ax))) return PAMG_E_ARG;
+    if ((int64_t)n_brow * R > INT32_MAX || (int64_t)n_bcol * C > INT32_MAX || nblk * R * C > INT32_MAX)
+        return PAMG_E_UNSUPPORTED;
+    pamg_matrix_s *A = new (std::nothrow) pamg_matrix_s();
+    if (!A) return PAMG_E_ALLOC;
+    A->dtype = dtype; A->flavour = flavour;
+    A->n_brow = n_brow; A->n_bcol = n_bcol; A->R = R; A->C = C;
+    A->nrows = (int64_t)n_brow * R; A->ncols = (int64_t)n_bcol * C; A->nnz = nblk * R * C;
+    const size_t ts = tsize(dtype);
+    int st = PAMG_OK;
+    if (R == 1 && C == 1) {
+        A->h_Ap.assign(Ap, Ap + n_brow + 1);
+        A->h_Aj.assign(Aj, Aj + nblk);
+        st = upload(&A->d_Ap, A->h_Ap.data(), A->h_Ap.size(), &A->bytes);
+        if (!st) st = upload(&A->d_Aj, A->h_Aj.data(), A->h_Aj.size(), &A->bytes);
+        if (!st) st = upload_raw(&A->d_Ax, Ax, (size_t)nblk, ts, &A->bytes);
+    } else {
+        // scalar (flattened) CSR view: scalar row ib*R+r holds, block after block in
+        // storage order, the C entries of block row r -- the exact summation order of
+        // SciPy's bsr_matvec for that output.  Explicit zeros inside blocks are kept.
+        A->h_Ap.resize((size_t)A->nrows + 1);
+        A->h_Aj.resize((size_t)A->nnz);
+        std::vector<unsigned char> flat((size_t)A->nnz * ts);
+        const unsigned char *src = (const unsigned char *)Ax;
+        int64_t w = 0;
+        for (int ib = 0; ib < n_brow; ++ib)
+            for (int r = 0; r < R; ++r) {
+                A->h_Ap[(size_t)ib * R + r] = (int)w;
+                for (int p = Ap[ib]; p < Ap[ib + 1]; ++p) {
+                    for (int c = 0; c < C; ++c) A->h_Aj[(size_t)w + c] = Aj[p] * C + c;
+                    std::memcpy(&flat[(size_t)w * ts], src + ((size_t)p * R * C + (size_t)r * C) * ts, (size_t)C * ts);
+                    w += C;
+                }
+            }
+        A->h_Ap[(size_t)A->nrows] = (int)w;
+        st = upload(&A->d_Ap, A->h_Ap.data(), A->h_Ap.size(), &A->bytes);
+        if (!st) st = upload(&A->d_Aj, A->h_Aj.data(), A->h_Aj.size(), &A->bytes);
+        if (!st) st = upload_raw(&A->d_Ax, flat.data(), (size_t)A->nnz, ts, &A->bytes);
+        if (R == C && !st) {
+            // square blocks: keep the block view too (point / block smoothers)
+            A->h_bAp.assign(Ap, Ap + n_brow + 1);
+            A->h_bAj.assign(Aj, Aj + nblk);
+            A->nblocks_b = nblk;
+            st = upload(&A->d_bAp, A->h_bAp.data(), A->h_bAp.size(), &A->bytes);
+            if (!st) st = upload(&A->d_bAj, A->h_bAj.data(), A->h_bAj.size(), &A->bytes);
+            if (!st) st = upload_raw(&A->d_bAx, Ax, (size_t)A->nnz, ts, &A->bytes);
+        }
+    }
+    // default plan: ~24 KB of LDS per workgroup for the smoother flavours -> 6 workgroups/CU
+    A->cap = 2048; A->npl = 2; A->max_rows = 1024;
+    if (!st) st = replan(A);
+    if (st) { pamg_matrix_destroy(A); return st; }
+    *out = A;
+    return PAMG_OK;
+}
+
+int pamg_matrix_destroy(pamg_matrix_t A)
+{
+    if (!A) return PAMG_OK;
+    hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax);
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAx); hipFree(A->d_rowblk); hipFree(A->d_partial);
+    for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
+    delete A;
+    return PAMG_OK;
+}
+
+int pamg_matrix_info(pamg_matrix_t A, int64_t info[8])
+{
+    if (!A || !info) return PAMG_E_ARG;
+    info[0] = A->nrows; info[1] = A->ncols; info[2] = A->nnz; info[3] = A->nblk;
+    info[4] = A->cap; info[5] = (int64_t)A->bytes;
+    info[6] = info[7] = 0;
+    const int n = A->R > 1 ? A->n_brow : (int)A->nrows;
+    for (int k = 0; k < 4; ++k) {
+        GsSchedule *g = A->gs[k];
+        if (!g) continue;
+        if (g->row_start == 0 && g->row_stop == n && g->row_step == 1) info[6] = g->nlevels;
+        if (g->row_start == n - 1 && g->row_stop == -1 && g->row_step == -1) info[7] = g->nlevels;
+    }
+    return PAMG_OK;
+}
+
+int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
+{
+    if (!A) return PAMG_E_ARG;
+    switch (key) {
+        case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~1; break;
+        case 1: if (value != 1 && value != 2) return PAMG_E_ARG; A->npl = value; break;
+        case 2: if (value < 1) return PAMG_E_ARG; A->max_rows = value; break;
+        default: return PAMG_E_ARG;
+    }
+    for (int k = 0; k < 4; ++k) { if (A->gs[k]) A->bytes -= A->gs[k]->bytes; free_schedule(A->gs[k]); A->gs[k] = nullptr; }
+    return replan(A);
+}
+
+int pamg_matrix_spmv(pamg_matrix_t A, int mode, const void *x, const void *b_or_v, double c, void *y,
+                     pamg_stream_t s)
+{
+    if (!A || !x || !y) return PAMG_E_ARG;
+    int epi;
+    switch (mode) {
+        case PAMG_SPMV_SET: epi = EPI_SET; break;
+        case PAMG_SPMV_ACC: epi = EPI_ACC; break;
+        case PAMG_SPMV_RESID: epi = EPI_RESID; break;
+        case PAMG_SPMV_AXPBY: epi = EPI_AXPBY; break;
+        case PAMG_SPMV_ACC_AXPBY: epi = EPI_ACC_AXPBY; break;
+        default: return PAMG_E_ARG;
+    }
+    if (mode >= PAMG_SPMV_RESID && !b_or_v) return PAMG_E_ARG;
+    return stream_launch(A, epi, x, b_or_v, y, c, 0.0, nullptr, (hipStream_t)s);
+}
+
+int pamg_matrix_resid_sumsq(pamg_matrix_t A, const void *x, const void *b, double *out_sumsq,
+                            pamg_stream_t s)
+{
+    if (!A || !x || !b || !out_sumsq) return PAMG_E_ARG;
+    PAMG_TRY(stream_launch(A, EPI_SUMSQ, x, b, nullptr, 0.0, 0.0, A->d_partial, (hipStream_t)s));
+    return reduce_partials(A->d_partial, A->nblk, out_sumsq, (hipStream_t)s);
+}
+
+int pamg_vec_sumsq(int dtype, int64_t n, const void *x, double *out_sumsq, pamg_stream_t s)
+{
+    if (n < 0 || !out_sumsq || (n > 0 && !x)) return PAMG_E_ARG;
+    int dev = 0;
+    PAMG_HIP(hipGetDevice(&dev));
+    if (!g_scratch || g_scratch_dev != dev) {
+        PAMG_HIP(hipMalloc((void **)&g_scratch, sizeof(double) * 1032));
+        g_scratch_dev = dev;
+    }
+    return vec_sumsq(dtype, n, x, g_scratch, out_sumsq, (hipStream_t)s);
+}
+
+int pamg_vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, pamg_stream_t s)
+{
+    return vec_axpy(dtype, n, a, x, y, (hipStream_t)s);
+}
+
+int pamg_vec_scale(int dtype, int64_t n, double a, const void *x, void *y, pamg_stream_t s)
+{
+    return vec_scale(dtype, n, a, x, y, (hipStream_t)s);
+}
+
+}  // extern "C"

@@ -1,0 +1,557 @@
+// pamg_solver.hip -- smoother drivers on operator handles and the device-resident
+// multigrid cycle / outer iteration (MultilevelSolver.__solve and .solve,
+// reference pyamg/multilevel.py:584-662 and :537-582).
+//
+// Every level vector is preallocated once; a cycle is a fixed sequence of kernel launches
+// on one stream, captured into a hipGraph per (cycle type, cycles_per_level) and replayed,
+// which removes the host launch cost of the many tiny coarse-level / GS-level kernels.
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <new>
+
+#include "pamg_common.h"
+
+using namespace pamg;
+
+namespace {
+
+struct Smoother {
+    int kind = PAMG_SMOOTH_NONE;
+    int iterations = 1;
+    double omega = 1.0;
+    int sweep = PAMG_FORWARD;
+    std::vector<double> coeffs;
+    void *d_Dinv = nullptr;
+    int blocksize = 1;
+};
+
+struct Level {
+    pamg_matrix_s *A = nullptr, *P = nullptr, *R = nullptr;
+    Smoother pre, post;
+    int64_t n = 0;
+    void *x = nullptr, *xalt = nullptr;   // ping-pong pair; x is where the iterate lives NOW
+    void *x_home = nullptr;               // canonical buffer (graph replays start/end here)
+    void *b = nullptr, *r = nullptr, *work = nullptr;
+};
+
+int sweep_bounds(const pamg_matrix_s *A, int dir, int &r0, int &r1, int &rs)
+{
+    const int n = A->R > 1 ? A->n_brow : (int)A->nrows;
+    if (dir == PAMG_FORWARD) { r0 = 0; r1 = n; rs = 1; }
+    else if (dir == PAMG_BACKWARD) { r0 = n - 1; r1 = -1; rs = -1; }
+    else return PAMG_E_ARG;
+    return PAMG_OK;
+}
+
+bool square_ok(const pamg_matrix_s *A) { return A && A->nrows == A->ncols && A->R == A->C; }
+
+// weighted Jacobi, ping-pong between *px and *palt (relaxation.py:349-420: the reference
+// snapshots x into temp and rewrites x; we read the old iterate and write the new one into
+// the partner buffer, which is the same arithmetic without the copy pass)
+int jacobi_pp(pamg_matrix_s *A, void **px, void **palt, const void *b, double omega, int its, hipStream_t s)
+{
+    if (!square_ok(A)) return PAMG_E_ARG;
+    if (A->nrows == 0) return PAMG_OK;
+    for (int it = 0; it < its; ++it) {
+        if (A->R > 1)
+            PAMG_TRY(block_jacobi_step(A, PNT_JACOBI, nullptr, *px, *palt, b, omega, s));
+        else
+            PAMG_TRY(stream_launch(A, A->flavour == PAMG_BSR ? EPI_JACOBI_B : EPI_JACOBI, *px, b, *palt,
+                                   0.0, omega, nullptr, s));
+        std::swap(*px, *palt);
+    }
+    return PAMG_OK;
+}
+
+int block_jacobi_pp(pamg_matrix_s *A, void **px, void **palt, const void *b, const void *Dinv,
+                    double omega, int its, hipStream_t s)
+{
+    if (!square_ok(A) || A->R < 2 || !Dinv) return PAMG_E_ARG;
+    for (int it = 0; it < its; ++it) {
+        PAMG_TRY(block_jacobi_step(A, BLK_JACOBI, Dinv, *px, *palt, b, omega, s));
+        std::swap(*px, *palt);
+    }
+    return PAMG_OK;
+}
+
+// relaxation.gauss_seidel / relaxation.sor as the reference runs them (relaxation.py:265-346,
+// :100-154).  Quirks mirrored on purpose: sweep='symmetric' drops omega (:326-330), the BSR
+// flavour ignores omega (:343-346).
+int gs_apply(pamg_matrix_s *A, void *x, const void *b, int sweep, double omega, int its, hipStream_t s)
+{
+    if (!square_ok(A)) return PAMG_E_ARG;
+    if (A->nrows == 0) return PAMG_OK;
+    auto one = [&](int dir, double om) -> int {
+        int r0, r1, rs;
+        PAMG_TRY(sweep_bounds(A, dir, r0, r1, rs));
+        int epi;
+        if (A->R > 1 || A->flavour == PAMG_BSR) epi = EPI_GS_B;
+        else epi = (om != 1.0) ? EPI_SOR : EPI_GS;
+        return gs_sweep(A, epi, x, b, om, r0, r1, rs, s);
+    };
+    if (sweep == PAMG_SYMMETRIC) {
+        for (int it = 0; it < its; ++it) {
+            PAMG_TRY(one(PAMG_FORWARD, 1.0));
+            PAMG_TRY(one(PAMG_BACKWARD, 1.0));
+        }
+        return PAMG_OK;
+    }
+    for (int it = 0; it < its; ++it) PAMG_TRY(one(sweep, omega));
+    return PAMG_OK;
+}
+
+int block_gs_apply(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, int sweep, int its,
+                   hipStream_t s)
+{
+    if (!square_ok(A) || A->R < 2 || !Dinv) return PAMG_E_ARG;
+    auto one = [&](int dir) -> int {
+        int r0, r1, rs;
+        PAMG_TRY(sweep_bounds(A, dir, r0, r1, rs));
+        return block_gs_sweep(A, x, b, Dinv, r0, r1, rs, s);
+    };
+    for (int it = 0; it < its; ++it) {
+        if (sweep == PAMG_SYMMETRIC) { PAMG_TRY(one(PAMG_FORWARD)); PAMG_TRY(one(PAMG_BACKWARD)); }
+        else PAMG_TRY(one(sweep));
+    }
+    return PAMG_OK;
+}
+
+// relaxation.polynomial (relaxation.py:647-659).  work = 3n values: [res | h0 | h1].
+// Horner steps are SpMVs with a fused c*res + A h epilogue; the last one also folds x += h.
+int poly_apply(pamg_matrix_s *A, void *x, const void *b, void *work, const double *coeffs, int nc,
+               int its, int x_is_zero, hipStream_t s)
+{
+    if (!A || A->nrows != A->ncols || nc < 1 || !coeffs) return PAMG_E_ARG;
+    const int64_t n = A->nrows;
+    if (n == 0) return PAMG_OK;
+    const size_t ts = tsize(A->dtype);
+    void *res_buf = work, *h0 = (char *)work + n * ts, *h1 = (char *)work + 2 * n * ts;
+    for (int it = 0; it < its; ++it) {
+        const void *res = b;
+        if (!(x_is_zero && it == 0)) {
+            PAMG_TRY(stream_launch(A, EPI_RESID, x, b, res_buf, 0.0, 0.0, nullptr, s));
+            res = res_buf;
+        }
+        if (nc == 1) {
+            PAMG_TRY(vec_axpy(A->dtype, n, coeffs[0], res, x, s));          // x += c0*res
+            continue;
+        }
+        PAMG_TRY(vec_scale(A->dtype, n, coeffs[0], res, h0, s));            // h = c0*res
+        void *hc = h0, *hn = h1;
+        for (int k = 1; k < nc - 1; ++k) {                                  // h = c*res + A h
+            PAMG_TRY(stream_launch(A, EPI_AXPBY, hc, res, hn, coeffs[k], 0.0, nullptr, s));
+            std::swap(hc, hn);
+        }
+        PAMG_TRY(stream_launch(A, EPI_ACC_AXPBY, hc, res, x, coeffs[nc - 1], 0.0, nullptr, s));
+    }
+    return PAMG_OK;
+}
+
+}  // namespace
+
+struct pamg_solver_s {
+    int dtype = PAMG_F64;
+    std::vector<Level> levels;
+    void *d_coarse = nullptr;     // dense coarse operator (row-major n_c x n_c)
+    int n_c = 0;
+    bool coarse_set = false, coarse_zero = false;
+    bool finalized = false;
+    bool use_graph = true;
+    hipStream_t own_stream = nullptr;
+    double *d_norms = nullptr;    // [norms_cap] per-iteration ||r||^2 + 2 aux slots
+    int norms_cap = 0;
+    double *d_slot = nullptr;     // 4 doubles: [0] current ||r||^2, [1] ||b||^2
+    double *d_scratch = nullptr;  // 1032 doubles for vector reductions
+    std::map<int, hipGraphExec_t> graphs;   // key = cycle*1024 + cycles_per_level
+    size_t bytes = 0;
+};
+
+namespace {
+
+int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, hipStream_t s)
+{
+    switch (sm.kind) {
+        case PAMG_SMOOTH_NONE: return PAMG_OK;
+        case PAMG_SMOOTH_JACOBI: return jacobi_pp(L.A, &L.x, &L.xalt, L.b, sm.omega, sm.iterations, s);
+        case PAMG_SMOOTH_GS: return gs_apply(L.A, L.x, L.b, sm.sweep, 1.0, sm.iterations, s);
+        case PAMG_SMOOTH_SOR: return gs_apply(L.A, L.x, L.b, sm.sweep, sm.omega, sm.iterations, s);
+        case PAMG_SMOOTH_POLY:
+            return poly_apply(L.A, L.x, L.b, L.work, sm.coeffs.data(), (int)sm.coeffs.size(),
+                              sm.iterations, x_zero ? 1 : 0, s);
+        case PAMG_SMOOTH_BLOCK_JACOBI:
+            return block_jacobi_pp(L.A, &L.x, &L.xalt, L.b, sm.d_Dinv, sm.omega, sm.iterations, s);
+        case PAMG_SMOOTH_BLOCK_GS:
+            return block_gs_apply(L.A, L.x, L.b, sm.d_Dinv, sm.sweep, sm.iterations, s);
+    }
+    (void)S;
+    return PAMG_E_ARG;
+}
+
+int coarse_solve(pamg_solver_s *S, const void *b, void *x, hipStream_t s)
+{
+    if (S->coarse_zero) return (int)hipMemsetAsync(x, 0, (size_t)S->n_c * tsize(S->dtype), s);
+    return dense_gemv(S->dtype, S->n_c, S->d_coarse, b, x, s);
+}
+
+// multilevel.py:584-662
+int cycle_rec(pamg_solver_s *S, int lvl, int type, int cpl, bool x_zero, hipStream_t s)
+{
+    Level &L = S->levels[lvl];
+    Level &N = S->levels[lvl + 1];
+    const int nlev = (int)S->levels.size();
+    const size_t ts = tsize(S->dtype);
+    PAMG_TRY(apply_smoother(S, L, L.pre, x_zero, s));
+    PAMG_TRY(stream_launch(L.A, EPI_RESID, L.x, L.b, L.r, 0.0, 0.0, nullptr, s));      // r = b - A x
+    PAMG_TRY(stream_launch(L.R, EPI_SET, L.r, nullptr, N.b, 0.0, 0.0, nullptr, s));     // b_c = R r
+    PAMG_HIP(hipMemsetAsync(N.x, 0, (size_t)N.n * ts, s));                              // x_c = 0
+    if (lvl == nlev - 2) {
+        PAMG_TRY(coarse_solve(S, N.b, N.x, s));
+    } else if (type == PAMG_CYCLE_V) {
+        PAMG_TRY(cycle_rec(S, lvl + 1, PAMG_CYCLE_V, 1, true, s));
+    } else if (type == PAMG_CYCLE_W) {
+        PAMG_TRY(cycle_rec(S, lvl + 1, PAMG_CYCLE_W, cpl, true, s));
+        PAMG_TRY(cycle_rec(S, lvl + 1, PAMG_CYCLE_W, cpl, false, s));
+    } else if (type == PAMG_CYCLE_F) {
+        PAMG_TRY(cycle_rec(S, lvl + 1, PAMG_CYCLE_F, cpl, true, s));
+        for (int k = 0; k < cpl; ++k) PAMG_TRY(cycle_rec(S, lvl + 1, PAMG_CYCLE_V, 1, false, s));
+    } else {
+        return PAMG_E_ARG;
+    }
+    PAMG_TRY(stream_launch(L.P, EPI_ACC, N.x, nullptr, L.x, 0.0, 0.0, nullptr, s));     // x += P x_c
+    PAMG_TRY(apply_smoother(S, L, L.post, false, s));
+    if (L.x != L.x_home) {          // odd number of ping-pong swaps: bring the iterate home
+        PAMG_HIP(hipMemcpyAsync(L.x_home, L.x, (size_t)L.n * ts, hipMemcpyDeviceToDevice, s));
+        std::swap(L.x, L.xalt);
+    }
+    return PAMG_OK;
+}
+
+// one full cycle on the internal level-0 buffers followed by ||b - A x||^2 -> d_slot[0]
+int enqueue_cycle(pamg_solver_s *S, int type, int cpl, hipStream_t s)
+{
+    Level &L0 = S->levels[0];
+    if (S->levels.size() == 1) {
+        PAMG_TRY(coarse_solve(S, L0.b, L0.x, s));                  // multilevel.py:559-561
+    } else {
+        PAMG_TRY(cycle_rec(S, 0, type, cpl, false, s));
+    }
+    PAMG_TRY(stream_launch(L0.A, EPI_SUMSQ, L0.x, L0.b, nullptr, 0.0, 0.0, L0.A->d_partial, s));
+    return reduce_partials(L0.A->d_partial, L0.A->nblk, S->d_slot, s);
+}
+
+int run_cycle(pamg_solver_s *S, int type, int cpl, hipStream_t s)
+{
+    if (!S->use_graph) return enqueue_cycle(S, type, cpl, s);
+    const int key = type * 1024 + cpl;
+    auto it = S->graphs.find(key);
+    if (it == S->graphs.end()) {
+        hipGraph_t g = nullptr;
+        PAMG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int st = enqueue_cycle(S, type, cpl, s);
+        const hipError_t e = hipStreamEndCapture(s, &g);
+        if (st != PAMG_OK) { if (g) hipGraphDestroy(g); return st; }
+        if (e != hipSuccess) return (int)e;
+        hipGraphExec_t ex = nullptr;
+        PAMG_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+        hipGraphDestroy(g);
+        it = S->graphs.emplace(key, ex).first;
+    }
+    return (int)hipGraphLaunch(it->second, s);
+}
+
+int prebuild_schedules(Level &L, const Smoother &sm)
+{
+    const bool gs = sm.kind == PAMG_SMOOTH_GS || sm.kind == PAMG_SMOOTH_SOR || sm.kind == PAMG_SMOOTH_BLOCK_GS;
+    if (!gs || L.A->nrows == 0) return PAMG_OK;
+    int r0, r1, rs;
+    if (sm.sweep == PAMG_FORWARD || sm.sweep == PAMG_SYMMETRIC) {
+        PAMG_TRY(sweep_bounds(L.A, PAMG_FORWARD, r0, r1, rs));
+        PAMG_TRY(ensure_schedule(L.A, r0, r1, rs));
+    }
+    if (sm.sweep == PAMG_BACKWARD || sm.sweep == PAMG_SYMMETRIC) {
+        PAMG_TRY(sweep_bounds(L.A, PAMG_BACKWARD, r0, r1, rs));
+        PAMG_TRY(ensure_schedule(L.A, r0, r1, rs));
+    }
+    return PAMG_OK;
+}
+
+int dalloc(pamg_solver_s *S, void **p, size_t bytes)
+{
+    PAMG_HIP(hipMalloc(p, std::max<size_t>(bytes, 256)));
+    PAMG_HIP(hipMemset(*p, 0, std::max<size_t>(bytes, 256)));
+    S->bytes += std::max<size_t>(bytes, 256);
+    return PAMG_OK;
+}
+
+void drop_graphs(pamg_solver_s *S)
+{
+    for (auto &kv : S->graphs) hipGraphExecDestroy(kv.second);
+    S->graphs.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+// ----------------------------------------------------------- smoothers on operator handles
+int pamg_matrix_jacobi(pamg_matrix_t A, void *x, const void *b, void *work, double omega, int iterations,
+                       pamg_stream_t s)
+{
+    if (!A || !x || !b || !work || iterations < 0) return PAMG_E_ARG;
+    void *cur = x, *alt = work;
+    PAMG_TRY(jacobi_pp(A, &cur, &alt, b, omega, iterations, (hipStream_t)s));
+    if (cur != x)
+        PAMG_HIP(hipMemcpyAsync(x, cur, (size_t)A->nrows * tsize(A->dtype), hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return PAMG_OK;
+}
+
+int pamg_matrix_gauss_seidel(pamg_matrix_t A, void *x, const void *b, int sweep, double omega,
+                             int iterations, pamg_stream_t s)
+{
+    if (!A || !x || !b || iterations < 0) return PAMG_E_ARG;
+    if (sweep < PAMG_FORWARD || sweep > PAMG_SYMMETRIC) return PAMG_E_ARG;
+    return gs_apply(A, x, b, sweep, omega, iterations, (hipStream_t)s);
+}
+
+int pamg_matrix_polynomial(pamg_matrix_t A, void *x, const void *b, void *work, const double *coeffs,
+                           int ncoeffs, int iterations, int x_is_zero, pamg_stream_t s)
+{
+    if (!A || !x || !b || !work || iterations < 0) return PAMG_E_ARG;
+    return poly_apply(A, x, b, work, coeffs, ncoeffs, iterations, x_is_zero, (hipStream_t)s);
+}
+
+int pamg_matrix_block_jacobi(pamg_matrix_t A, void *x, const void *b, void *work, const void *Dinv,
+                             double omega, int iterations, pamg_stream_t s)
+{
+    if (!A || !x || !b || !work || iterations < 0) return PAMG_E_ARG;
+    void *cur = x, *alt = work;
+    PAMG_TRY(block_jacobi_pp(A, &cur, &alt, b, Dinv, omega, iterations, (hipStream_t)s));
+    if (cur != x)
+        PAMG_HIP(hipMemcpyAsync(x, cur, (size_t)A->nrows * tsize(A->dtype), hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return PAMG_OK;
+}
+
+int pamg_matrix_block_gauss_seidel(pamg_matrix_t A, void *x, const void *b, const void *Dinv, int sweep,
+                                   int iterations, pamg_stream_t s)
+{
+    if (!A || !x || !b || iterations < 0) return PAMG_E_ARG;
+    if (sweep < PAMG_FORWARD || sweep > PAMG_SYMMETRIC) return PAMG_E_ARG;
+    return block_gs_apply(A, x, b, Dinv, sweep, iterations, (hipStream_t)s);
+}
+
+// ----------------------------------------------------------------------------- solver
+int pamg_solver_create(pamg_solver_t *S, int dtype)
+{
+    if (!S) return PAMG_E_ARG;
+    if (dtype != PAMG_F64 && dtype != PAMG_F32) return PAMG_E_UNSUPPORTED;
+    pamg_solver_s *p = new (std::nothrow) pamg_solver_s();
+    if (!p) return PAMG_E_ALLOC;
+    p->dtype = dtype;
+    *S = p;
+    return PAMG_OK;
+}
+
+int pamg_solver_destroy(pamg_solver_t S)
+{
+    if (!S) return PAMG_OK;
+    drop_graphs(S);
+    for (Level &L : S->levels) {
+        hipFree(L.x); hipFree(L.xalt);
+        hipFree(L.b); hipFree(L.r); hipFree(L.work);
+        hipFree(L.pre.d_Dinv); hipFree(L.post.d_Dinv);
+    }
+    hipFree(S->d_coarse); hipFree(S->d_norms); hipFree(S->d_slot); hipFree(S->d_scratch);
+    if (S->own_stream) hipStreamDestroy(S->own_stream);
+    delete S;
+    return PAMG_OK;
+}
+
+int pamg_solver_add_level(pamg_solver_t S, pamg_matrix_t A, pamg_matrix_t P, pamg_matrix_t R)
+{
+    if (!S || !A) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    if (A->dtype != S->dtype || A->nrows != A->ncols) return PAMG_E_ARG;
+    if ((P == nullptr) != (R == nullptr)) return PAMG_E_ARG;
+    if (!S->levels.empty()) {
+        const Level &prev = S->levels.back();
+        if (!prev.P) return PAMG_E_STATE;                      // a coarsest level was already added
+        if (prev.P->ncols != A->nrows || prev.R->nrows != A->nrows) return PAMG_E_ARG;
+    }
+    if (P && (P->dtype != S->dtype || R->dtype != S->dtype || P->nrows != A->nrows || R->ncols != A->nrows ||
+              P->ncols != R->nrows))
+        return PAMG_E_ARG;
+    Level L;
+    L.A = A; L.P = P; L.R = R; L.n = A->nrows;
+    S->levels.push_back(L);
+    return PAMG_OK;
+}
+
+int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, int iterations, double omega,
+                             int sweep, const double *coeffs, int ncoeffs, const void *Dinv, int blocksize)
+{
+    if (!S || level < 0 || level >= (int)S->levels.size() || (which != 0 && which != 1)) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    if (kind < PAMG_SMOOTH_NONE || kind > PAMG_SMOOTH_BLOCK_GS || iterations < 0) return PAMG_E_ARG;
+    if (sweep < PAMG_FORWARD || sweep > PAMG_SYMMETRIC) return PAMG_E_ARG;
+    Level &L = S->levels[level];
+    Smoother &sm = which == 0 ? L.pre : L.post;
+    if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
+    sm = Smoother();
+    sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep; sm.blocksize = blocksize;
+    if (kind == PAMG_SMOOTH_POLY) {
+        if (!coeffs || ncoeffs < 1) return PAMG_E_ARG;
+        sm.coeffs.assign(coeffs, coeffs + ncoeffs);
+    }
+    if (kind == PAMG_SMOOTH_BLOCK_JACOBI || kind == PAMG_SMOOTH_BLOCK_GS) {
+        if (!Dinv || blocksize < 2 || blocksize != L.A->R || L.A->R != L.A->C) return PAMG_E_ARG;
+        const size_t sz = (size_t)L.A->n_brow * blocksize * blocksize * tsize(S->dtype);
+        PAMG_HIP(hipMalloc(&sm.d_Dinv, std::max<size_t>(sz, 256)));
+        PAMG_HIP(hipMemcpy(sm.d_Dinv, Dinv, sz, hipMemcpyHostToDevice));
+        S->bytes += sz;
+    }
+    if ((kind == PAMG_SMOOTH_JACOBI || kind == PAMG_SMOOTH_GS || kind == PAMG_SMOOTH_SOR) && L.A->R != L.A->C)
+        return PAMG_E_ARG;                                     // "BSR blocks must be square"
+    return PAMG_OK;
+}
+
+int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c)
+{
+    if (!S || n_c < 0) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    if (S->d_coarse) { hipFree(S->d_coarse); S->d_coarse = nullptr; }
+    S->n_c = n_c; S->coarse_set = true; S->coarse_zero = (M == nullptr);
+    if (M && n_c > 0) {
+        const size_t sz = (size_t)n_c * n_c * tsize(S->dtype);
+        PAMG_HIP(hipMalloc(&S->d_coarse, std::max<size_t>(sz, 256)));
+        PAMG_HIP(hipMemcpy(S->d_coarse, M, sz, hipMemcpyHostToDevice));
+        S->bytes += sz;
+    }
+    return PAMG_OK;
+}
+
+int pamg_solver_finalize(pamg_solver_t S)
+{
+    if (!S || S->levels.empty()) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_OK;
+    if (S->levels.back().P) return PAMG_E_STATE;               // last level must be the coarsest
+    if (!S->coarse_set || S->n_c != S->levels.back().n) return PAMG_E_STATE;
+    const size_t ts = tsize(S->dtype);
+    const int nlev = (int)S->levels.size();
+    for (int l = 0; l < nlev; ++l) {
+        Level &L = S->levels[l];
+        const size_t vb = (size_t)L.n * ts;
+        PAMG_TRY(dalloc(S, &L.x, vb));
+        PAMG_TRY(dalloc(S, &L.xalt, vb));
+        PAMG_TRY(dalloc(S, &L.b, vb));
+        L.x_home = L.x;
+        if (l < nlev - 1) {
+            PAMG_TRY(dalloc(S, &L.r, vb));
+            if (L.pre.kind == PAMG_SMOOTH_POLY || L.post.kind == PAMG_SMOOTH_POLY) PAMG_TRY(dalloc(S, &L.work, 3 * vb));
+            PAMG_TRY(prebuild_schedules(L, L.pre));
+            PAMG_TRY(prebuild_schedules(L, L.post));
+        }
+    }
+    PAMG_TRY(dalloc(S, (void **)&S->d_slot, 4 * sizeof(double)));
+    PAMG_TRY(dalloc(S, (void **)&S->d_scratch, 1032 * sizeof(double)));
+    PAMG_HIP(hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking));
+    S->finalized = true;
+    return PAMG_OK;
+}
+
+int pamg_solver_set_graph(pamg_solver_t S, int enable)
+{
+    if (!S) return PAMG_E_ARG;
+    S->use_graph = enable != 0;
+    if (!S->use_graph) drop_graphs(S);
+    return PAMG_OK;
+}
+
+int pamg_solver_cycle(pamg_solver_t S, void *x, const void *b, int cycle, int cycles_per_level, pamg_stream_t s_)
+{
+    if (!S || !x || !b) return PAMG_E_ARG;
+    if (!S->finalized) return PAMG_E_STATE;
+    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
+    hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    Level &L0 = S->levels[0];
+    const size_t vb = (size_t)L0.n * tsize(S->dtype);
+    PAMG_HIP(hipMemcpyAsync(L0.x, x, vb, hipMemcpyDeviceToDevice, s));
+    PAMG_HIP(hipMemcpyAsync(L0.b, b, vb, hipMemcpyDeviceToDevice, s));
+    PAMG_TRY(run_cycle(S, cycle, cycles_per_level, s));
+    PAMG_HIP(hipMemcpyAsync(x, L0.x, vb, hipMemcpyDeviceToDevice, s));
+    if (!s_) PAMG_HIP(hipStreamSynchronize(s));
+    return PAMG_OK;
+}
+
+int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int cycle,
+                      int cycles_per_level, int check_every, double *residuals, int *n_iter, int *info,
+                      pamg_stream_t s_)
+{
+    if (!S || !x || !b || maxiter < 1 || check_every < 1) return PAMG_E_ARG;
+    if (!S->finalized) return PAMG_E_STATE;
+    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
+    hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    Level &L0 = S->levels[0];
+    const size_t vb = (size_t)L0.n * tsize(S->dtype);
+    if (S->norms_cap < maxiter + 2) {
+        if (S->d_norms) hipFree(S->d_norms);
+        S->norms_cap = maxiter + 2;
+        PAMG_HIP(hipMalloc((void **)&S->d_norms, sizeof(double) * (size_t)S->norms_cap));
+    }
+    PAMG_HIP(hipMemcpyAsync(L0.x, x, vb, hipMemcpyDeviceToDevice, s));
+    PAMG_HIP(hipMemcpyAsync(L0.b, b, vb, hipMemcpyDeviceToDevice, s));
+    // normb and the initial residual (multilevel.py:540-547)
+    PAMG_TRY(vec_sumsq(S->dtype, L0.n, L0.b, S->d_scratch, S->d_slot + 1, s));
+    PAMG_TRY(stream_launch(L0.A, EPI_SUMSQ, L0.x, L0.b, nullptr, 0.0, 0.0, L0.A->d_partial, s));
+    PAMG_TRY(reduce_partials(L0.A->d_partial, L0.A->nblk, S->d_slot, s));
+    double h2[2] = {0.0, 0.0};
+    PAMG_HIP(hipMemcpyAsync(h2, S->d_slot, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    PAMG_HIP(hipStreamSynchronize(s));
+    double normb = std::sqrt(h2[1]);
+    if (normb == 0.0) normb = 1.0;
+    if (residuals) residuals[0] = std::sqrt(h2[0]);
+    std::vector<double> hn((size_t)maxiter + 1, 0.0);
+    int it = 0, checked = 0, converged_at = -1;
+    while (true) {
+        PAMG_TRY(run_cycle(S, cycle, cycles_per_level, s));
+        PAMG_HIP(hipMemcpyAsync(S->d_norms + it, S->d_slot, sizeof(double), hipMemcpyDeviceToDevice, s));
+        ++it;
+        if (it % check_every == 0 || it == maxiter) {
+            PAMG_HIP(hipMemcpyAsync(hn.data() + checked, S->d_norms + checked, sizeof(double) * (size_t)(it - checked),
+                                    hipMemcpyDeviceToHost, s));
+            PAMG_HIP(hipStreamSynchronize(s));
+            for (int k = checked; k < it; ++k) {
+                const double nr = std::sqrt(hn[k]);
+                if (residuals) residuals[k + 1] = nr;
+                if (converged_at < 0 && nr < tol * normb) converged_at = k + 1;
+            }
+            checked = it;
+            if (converged_at >= 0) break;
+        }
+        if (it == maxiter) break;
+    }
+    PAMG_HIP(hipMemcpyAsync(x, L0.x, vb, hipMemcpyDeviceToDevice, s));
+    PAMG_HIP(hipStreamSynchronize(s));
+    if (n_iter) *n_iter = it;
+    if (info) *info = converged_at >= 0 ? 0 : it;
+    return PAMG_OK;
+}
+
+int pamg_solver_stats(pamg_solver_t S, int64_t stats[8])
+{
+    if (!S || !stats) return PAMG_E_ARG;
+    for (int k = 0; k < 8; ++k) stats[k] = 0;
+    stats[0] = (int64_t)S->levels.size();
+    size_t bytes = S->bytes;
+    int64_t launches = 0;
+    for (const Level &L : S->levels) {
+        bytes += L.A->bytes + (L.P ? L.P->bytes : 0) + (L.R ? L.R->bytes : 0);
+        for (int k = 0; k < 4; ++k) if (L.A->gs[k]) launches += L.A->gs[k]->nlevels;
+    }
+    stats[1] = launches;           // GS level launches per directional sweep pair (informative)
+    stats[2] = (int64_t)bytes;
+    stats[3] = (int64_t)S->graphs.size();
+    return PAMG_OK;
+}
+
+}  // extern "C"

@@ -29,7 +29,7 @@ import numpy as np
 import scipy.sparse as sp
 
 __all__ = ["SparseOp", "SmootherSpec", "LevelSpec", "HierarchySpec", "extract",
-           "sparse_op", "smoother_spec"]
+           "sparse_op", "smoother_spec", "save_spec", "load_spec"]
 
 SUPPORTED_DTYPES = (np.float64, np.float32)
 
@@ -239,3 +239,76 @@ def extract(ml) -> HierarchySpec:
         spec.levels.append(ls)
     spec.coarse_kind, spec.coarse_op, spec.coarse_name = _coarse_operator(ml, levels[-1].A)
     return spec
+
+
+# --------------------------------------------------------------------------- (de)serialisation
+def _put_op(d, key, op: Optional[SparseOp]):
+    if op is None:
+        return
+    d[f"{key}.indptr"], d[f"{key}.indices"], d[f"{key}.data"] = op.indptr, op.indices, op.data
+    d[f"{key}.meta"] = np.array([op.shape[0], op.shape[1], op.blocksize[0], op.blocksize[1],
+                                 1 if op.fmt == "bsr" else 0], dtype=np.int64)
+    d[f"{key}.src"] = np.array(op.src_format)
+
+
+def _get_op(z, key) -> Optional[SparseOp]:
+    if f"{key}.meta" not in z:
+        return None
+    m = z[f"{key}.meta"]
+    return SparseOp("bsr" if m[4] else "csr", (int(m[0]), int(m[1])), (int(m[2]), int(m[3])),
+                    z[f"{key}.indptr"], z[f"{key}.indices"], z[f"{key}.data"], str(z[f"{key}.src"]))
+
+
+def _put_sm(d, key, s: Optional[SmootherSpec]):
+    if s is None:
+        return
+    d[f"{key}.kind"] = np.array(s.kind)
+    d[f"{key}.num"] = np.array([s.iterations, s.blocksize], dtype=np.int64)
+    d[f"{key}.omega"] = np.array(s.omega, dtype=np.float64)
+    d[f"{key}.sweep"] = np.array(s.sweep)
+    d[f"{key}.name"] = np.array(s.name)
+    if s.coefficients is not None:
+        d[f"{key}.coefficients"] = np.asarray(s.coefficients, dtype=np.float64)
+    if s.Dinv is not None:
+        d[f"{key}.Dinv"] = s.Dinv
+
+
+def _get_sm(z, key) -> Optional[SmootherSpec]:
+    if f"{key}.kind" not in z:
+        return None
+    num = z[f"{key}.num"]
+    return SmootherSpec(str(z[f"{key}.kind"]), int(num[0]), float(z[f"{key}.omega"]), str(z[f"{key}.sweep"]),
+                        z[f"{key}.coefficients"] if f"{key}.coefficients" in z else None,
+                        z[f"{key}.Dinv"] if f"{key}.Dinv" in z else None, int(num[1]), str(z[f"{key}.name"]))
+
+
+def save_spec(path, spec: HierarchySpec, **extra):
+    """Write a HierarchySpec (+ any extra named arrays) to a compressed ``.npz``."""
+    d = {"nlevels": np.array(len(spec.levels)), "coarse_kind": np.array(spec.coarse_kind),
+         "coarse_name": np.array(spec.coarse_name)}
+    if spec.coarse_op is not None:
+        d["coarse_op"] = np.asarray(spec.coarse_op)
+        d["coarse_op_fortran"] = np.array(bool(np.isfortran(spec.coarse_op)))
+    for i, L in enumerate(spec.levels):
+        _put_op(d, f"L{i}.A", L.A)
+        _put_op(d, f"L{i}.P", L.P)
+        _put_op(d, f"L{i}.R", L.R)
+        _put_sm(d, f"L{i}.pre", L.pre)
+        _put_sm(d, f"L{i}.post", L.post)
+    for k, v in extra.items():
+        d[f"extra.{k}"] = np.asarray(v)
+    np.savez_compressed(path, **d)
+
+
+def load_spec(path):
+    """Inverse of ``save_spec``: returns (HierarchySpec, dict of extra arrays)."""
+    z = np.load(path, allow_pickle=False)
+    spec = HierarchySpec(coarse_kind=str(z["coarse_kind"]), coarse_name=str(z["coarse_name"]))
+    if "coarse_op" in z:
+        M = z["coarse_op"]
+        spec.coarse_op = np.asfortranarray(M) if bool(z["coarse_op_fortran"]) else np.ascontiguousarray(M)
+    for i in range(int(z["nlevels"])):
+        spec.levels.append(LevelSpec(A=_get_op(z, f"L{i}.A"), P=_get_op(z, f"L{i}.P"), R=_get_op(z, f"L{i}.R"),
+                                     pre=_get_sm(z, f"L{i}.pre"), post=_get_sm(z, f"L{i}.post")))
+    extra = {k[len("extra."):]: z[k] for k in z.files if k.startswith("extra.")}
+    return spec, extra

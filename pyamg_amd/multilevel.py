@@ -1,0 +1,315 @@
+"""Device-resident drop-in for ``pyamg.multilevel.MultilevelSolver.solve`` /
+``aspreconditioner`` (reference: pyamg/multilevel.py:355-582).
+
+``DeviceMultilevelSolver(ml)`` wraps a hierarchy that the *reference* built on the host
+(setup stays there, north star), ships every level to HBM once and runs the cycle as HIP
+kernels through the C ABI (include/pyamg_amd.h, Layer 2).  Signatures, return conventions
+and error behaviour follow the reference:
+
+* ``solve(b, x0=None, tol=1e-5, maxiter=100, cycle='V', accel=None, callback=None,
+  residuals=None, cycles_per_level=1, return_info=False)`` -- returns a ravelled ``(n,)``
+  array even for ``(n, 1)`` input (multilevel.py:553-554), dtype = upcast of (A, b, x0)
+  (:551-552), ``info`` = 0 on convergence else the iteration count (:574-582),
+  ``residuals[:] = [r0, r1, ...]`` (:546-569), ``callback(x)`` after every cycle (:571-572).
+* ``aspreconditioner(cycle)`` -- SciPy ``LinearOperator`` whose matvec is exactly one cycle
+  from a zero initial guess (:390-396).
+* ``accel=`` -- the Krylov method runs on the host exactly as in the reference (:479-535)
+  with the device cycle as preconditioner ``M``.
+
+There is no CPU fallback: unsupported configurations raise ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+
+from . import _capi as capi
+from .hierarchy import HierarchySpec, SmootherSpec, SparseOp, extract
+
+__all__ = ["DeviceMatrix", "DeviceMultilevelSolver"]
+
+
+class DeviceMatrix:
+    """A SparseOp resident in HBM (``pamg_matrix_t``)."""
+
+    def __init__(self, op: SparseOp):
+        lib = capi.lib()
+        self.op = op
+        self.dtype = np.dtype(op.dtype)
+        R, Cc = op.blocksize
+        h = C.c_void_p()
+        capi.check(lib.pamg_matrix_create(
+            C.byref(h), capi.dtype_code(op.dtype), capi.BSR if op.fmt == "bsr" else capi.CSR,
+            op.shape[0] // R, op.shape[1] // Cc, R, Cc,
+            capi.ptr(op.indptr), capi.ptr(op.indices), capi.ptr(op.data)), "pamg_matrix_create")
+        self.handle = h
+        self.shape = tuple(op.shape)
+
+    # -- info / tuning
+    def info(self) -> dict:
+        a = (C.c_int64 * 8)()
+        capi.check(capi.lib().pamg_matrix_info(self.handle, a), "pamg_matrix_info")
+        keys = ("rows", "cols", "nnz", "row_blocks", "lds_entries", "hbm_bytes", "gs_levels_fwd", "gs_levels_bwd")
+        return dict(zip(keys, [int(v) for v in a]))
+
+    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None):
+        lib = capi.lib()
+        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows)):
+            if v is not None:
+                capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
+
+    # -- kernels on DeviceArray operands
+    def spmv(self, mode, x, y, b=None, c=0.0, stream=None):
+        capi.check(capi.lib().pamg_matrix_spmv(self.handle, mode, x.ptr, b.ptr if b is not None else None,
+                                               float(c), y.ptr, stream), "pamg_matrix_spmv")
+
+    def resid_sumsq(self, x, b, out, stream=None):
+        capi.check(capi.lib().pamg_matrix_resid_sumsq(self.handle, x.ptr, b.ptr, out.ptr, stream),
+                   "pamg_matrix_resid_sumsq")
+
+    def jacobi(self, x, b, work, omega, iterations=1, stream=None):
+        capi.check(capi.lib().pamg_matrix_jacobi(self.handle, x.ptr, b.ptr, work.ptr, float(omega),
+                                                 int(iterations), stream), "pamg_matrix_jacobi")
+
+    def gauss_seidel(self, x, b, sweep="forward", omega=1.0, iterations=1, stream=None):
+        capi.check(capi.lib().pamg_matrix_gauss_seidel(self.handle, x.ptr, b.ptr, capi.SWEEP[sweep],
+                                                       float(omega), int(iterations), stream),
+                   "pamg_matrix_gauss_seidel")
+
+    def polynomial(self, x, b, work, coefficients, iterations=1, x_is_zero=False, stream=None):
+        co = np.ascontiguousarray(coefficients, dtype=np.float64)
+        capi.check(capi.lib().pamg_matrix_polynomial(self.handle, x.ptr, b.ptr, work.ptr, capi.ptr(co),
+                                                     co.size, int(iterations), int(bool(x_is_zero)), stream),
+                   "pamg_matrix_polynomial")
+
+    def block_jacobi(self, x, b, work, Dinv, omega, iterations=1, stream=None):
+        capi.check(capi.lib().pamg_matrix_block_jacobi(self.handle, x.ptr, b.ptr, work.ptr, Dinv.ptr,
+                                                       float(omega), int(iterations), stream),
+                   "pamg_matrix_block_jacobi")
+
+    def block_gauss_seidel(self, x, b, Dinv, sweep="forward", iterations=1, stream=None):
+        capi.check(capi.lib().pamg_matrix_block_gauss_seidel(self.handle, x.ptr, b.ptr, Dinv.ptr,
+                                                             capi.SWEEP[sweep], int(iterations), stream),
+                   "pamg_matrix_block_gauss_seidel")
+
+    def free(self):
+        if getattr(self, "handle", None):
+            try:
+                capi._lib.pamg_matrix_destroy(self.handle)
+            except Exception:       # pragma: no cover
+                pass
+            self.handle = None
+
+    def __del__(self):
+        self.free()
+
+
+def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype):
+    if s is None or s.kind == "none":
+        capi.check(lib.pamg_solver_set_smoother(S, level, which, 0, 0, 1.0, 0, None, 0, None, 1), "set_smoother")
+        return
+    coeffs = None
+    ncoef = 0
+    if s.kind == "polynomial":
+        coeffs = np.ascontiguousarray(s.coefficients, dtype=np.float64)
+        ncoef = coeffs.size
+    Dinv = None
+    if s.kind in ("block_jacobi", "block_gauss_seidel"):
+        Dinv = np.ascontiguousarray(s.Dinv, dtype=dtype)
+    capi.check(lib.pamg_solver_set_smoother(
+        S, level, which, capi.SMOOTH[s.kind], int(s.iterations), float(s.omega),
+        capi.SWEEP.get(s.sweep, 0), capi.ptr(coeffs), ncoef, capi.ptr(Dinv), int(s.blocksize)),
+        f"pamg_solver_set_smoother({s.kind})")
+
+
+class DeviceMultilevelSolver:
+    """MI355X-resident multigrid solve phase for a reference-built hierarchy.
+
+    Parameters
+    ----------
+    ml : pyamg.MultilevelSolver (duck-typed) or HierarchySpec
+    device : int, HIP device ordinal
+    graph : bool, replay cycles from a hipGraph (default) or launch eagerly
+    """
+
+    def __init__(self, ml, device: Optional[int] = None, graph: bool = True):
+        lib = capi.lib()
+        if device is not None:
+            capi.check(lib.pamg_set_device(int(device)), "pamg_set_device")
+        self.ml = None if isinstance(ml, HierarchySpec) else ml
+        self.spec = ml if isinstance(ml, HierarchySpec) else extract(ml)
+        self.dtype = np.dtype(self.spec.dtype)
+        self.shape = tuple(self.spec.levels[0].A.shape)
+        self._mats: List[DeviceMatrix] = []
+        self.A: List[DeviceMatrix] = []
+        h = C.c_void_p()
+        capi.check(lib.pamg_solver_create(C.byref(h), capi.dtype_code(self.dtype)), "pamg_solver_create")
+        self.handle = h
+        nlev = len(self.spec.levels)
+        for i, L in enumerate(self.spec.levels):
+            A = DeviceMatrix(L.A)
+            P = DeviceMatrix(L.P) if i < nlev - 1 else None
+            R = DeviceMatrix(L.R) if i < nlev - 1 else None
+            self._mats += [m for m in (A, P, R) if m is not None]
+            self.A.append(A)
+            capi.check(lib.pamg_solver_add_level(h, A.handle, P.handle if P else None, R.handle if R else None),
+                       "pamg_solver_add_level")
+            if i < nlev - 1:
+                _set_smoother(lib, h, i, 0, L.pre, self.dtype)
+                _set_smoother(lib, h, i, 1, L.post, self.dtype)
+        n_c = self.spec.levels[-1].A.shape[0]
+        if self.spec.coarse_kind == "zero":
+            capi.check(lib.pamg_solver_set_coarse_dense(h, None, n_c), "set_coarse")
+        else:
+            M = np.ascontiguousarray(self.spec.coarse_op, dtype=self.dtype)     # row-major for the device gemv
+            capi.check(lib.pamg_solver_set_coarse_dense(h, capi.ptr(M), n_c), "set_coarse")
+        capi.check(lib.pamg_solver_set_graph(h, int(bool(graph))), "set_graph")
+        capi.check(lib.pamg_solver_finalize(h), "pamg_solver_finalize")
+        self.symmetric_smoothing = getattr(self.ml, "symmetric_smoothing", False)
+        self._xd = capi.DeviceArray(self.shape[0], self.dtype)
+        self._bd = capi.DeviceArray(self.shape[0], self.dtype)
+
+    # ------------------------------------------------------------------ reference-like API
+    @property
+    def levels(self):
+        return self.spec.levels
+
+    def __repr__(self):
+        lines = ["DeviceMultilevelSolver (MI355X resident)", f"Number of Levels:     {len(self.spec.levels)}",
+                 f"Coarse Solver:        {self.spec.coarse_name}", "  level   unknowns     nonzeros"]
+        tot = sum(L.A.nnz for L in self.spec.levels)
+        for i, L in enumerate(self.spec.levels):
+            lines.append(f"{i:>6} {L.A.shape[0]:>11} {L.A.nnz:>12} [{100 * L.A.nnz / max(tot, 1):2.2f}%]")
+        return "\n".join(lines) + "\n"
+
+    def stats(self) -> dict:
+        a = (C.c_int64 * 8)()
+        capi.check(capi.lib().pamg_solver_stats(self.handle, a), "pamg_solver_stats")
+        return {"levels": int(a[0]), "gs_level_launches": int(a[1]), "hbm_bytes": int(a[2]), "graphs": int(a[3])}
+
+    def cycle_device(self, xd, bd, cycle="V", cycles_per_level=1, stream=None):
+        """One cycle on DEVICE vectors (DeviceArray) in place."""
+        capi.check(capi.lib().pamg_solver_cycle(self.handle, xd.ptr, bd.ptr, capi.CYCLE[cycle],
+                                                int(cycles_per_level), stream), "pamg_solver_cycle")
+
+    def solve_device(self, xd, bd, tol=1e-5, maxiter=100, cycle="V", cycles_per_level=1, check_every=1,
+                     stream=None):
+        """accel=None branch of ``solve`` on DEVICE vectors; returns (residuals, n_iter, info)."""
+        res = np.zeros(int(maxiter) + 1, dtype=np.float64)
+        nit, info = C.c_int(0), C.c_int(0)
+        capi.check(capi.lib().pamg_solver_solve(self.handle, xd.ptr, bd.ptr, float(tol), int(maxiter),
+                                                capi.CYCLE[cycle], int(cycles_per_level), int(check_every),
+                                                capi.ptr(res), C.byref(nit), C.byref(info), stream),
+                   "pamg_solver_solve")
+        return res[: nit.value + 1], nit.value, info.value
+
+    def solve(self, b, x0=None, tol=1e-5, maxiter=100, cycle="V", accel=None, callback=None,
+              residuals=None, cycles_per_level=1, return_info=False):
+        """Execute multigrid cycling on the GPU (reference: multilevel.py:398-582)."""
+        b = np.asarray(b)
+        x = np.zeros_like(b) if x0 is None else np.array(x0)       # copy (:464-467)
+        cycle = str(cycle).upper()
+        if cycle == "AMLI":
+            raise NotImplementedError("AMLI cycles are not on the device path")
+        if cycle not in capi.CYCLE:
+            raise TypeError(f"Unrecognized cycle type ({cycle})")
+        n = self.shape[0]
+        if b.size != n or x.size != n:
+            raise ValueError("b and x0 must have as many entries as the fine-level operator has rows")
+
+        if accel is not None:
+            return self._solve_accel(b, x0, tol, maxiter, cycle, accel, callback, residuals, return_info)
+
+        tp = np.result_type(b.dtype, x.dtype, self.dtype)          # upcast (:551-552)
+        if np.dtype(tp) != self.dtype:
+            raise NotImplementedError(f"solve in {tp} with a {self.dtype} hierarchy is not on the device path")
+        self._bd.upload(np.ravel(b).astype(tp, copy=False))
+        self._xd.upload(np.ravel(x).astype(tp, copy=False))
+        if callback is None:
+            res, nit, info = self.solve_device(self._xd, self._bd, tol, maxiter, cycle, cycles_per_level, 1)
+            if residuals is not None:
+                residuals[:] = list(res)
+            out = self._xd.download()
+            return (out, info) if return_info else out
+        # callback(x) needs a host copy of the iterate after every cycle (:571-572)
+        hist, it, info = None, 0, 0
+        while True:
+            res, _, info1 = self.solve_device(self._xd, self._bd, tol, 1, cycle, cycles_per_level, 1)
+            if hist is None:
+                hist = [res[0]]
+                normb = np.linalg.norm(np.ravel(b))
+                normb = 1.0 if normb == 0.0 else normb
+            hist.append(res[-1])
+            it += 1
+            xh = self._xd.download()
+            callback(xh)
+            if res[-1] < tol * normb:
+                info = 0
+                break
+            if it == maxiter:
+                info = it
+                break
+        if residuals is not None:
+            residuals[:] = hist
+        return (xh, info) if return_info else xh
+
+    def _solve_accel(self, b, x0, tol, maxiter, cycle, accel, callback, residuals, return_info):
+        """multilevel.py:479-535: host Krylov method around the device preconditioner."""
+        import scipy.sparse.linalg as sla
+        A = self.spec.levels[0].A.to_scipy()
+        kwargs = {}
+        if isinstance(accel, str):
+            krylov = None
+            if self.ml is not None:
+                import importlib
+                try:
+                    krylov = importlib.import_module(type(self.ml).__module__.split(".")[0] + ".krylov")
+                except Exception:       # pragma: no cover
+                    krylov = None
+            accel = getattr(krylov, accel) if krylov is not None and hasattr(krylov, accel) else getattr(sla, accel)
+        M = self.aspreconditioner(cycle=cycle)
+        try:
+            x, info = accel(A, b, x0=x0, tol=tol, maxiter=maxiter, M=M, callback=callback,
+                            residuals=residuals, **kwargs)
+            return (x, info) if return_info else x
+        except TypeError:
+            if residuals is not None:
+                xz = np.zeros_like(b) if x0 is None else np.array(x0)
+                residuals[:] = [np.linalg.norm(b - A @ xz)]
+
+                def callback_wrapper(xk):
+                    if np.isscalar(xk):
+                        residuals.append(xk)
+                    else:
+                        residuals.append(np.linalg.norm(b - A @ xk))
+                    if callback is not None:
+                        callback(xk)
+            else:
+                callback_wrapper = callback
+            x, info = accel(A, b, x0=x0, maxiter=maxiter, M=M, callback=callback_wrapper, rtol=tol, atol=0)
+            return (x, info) if return_info else x
+
+    def aspreconditioner(self, cycle="V"):
+        """multilevel.py:355-396: LinearOperator applying one cycle from x = 0."""
+        from scipy.sparse.linalg import LinearOperator
+
+        def matvec(b):
+            return self.solve(b, maxiter=1, cycle=cycle, tol=1e-12)
+
+        return LinearOperator(self.shape, matvec, dtype=self.dtype)
+
+    def free(self):
+        if getattr(self, "handle", None):
+            try:
+                capi._lib.pamg_solver_destroy(self.handle)
+            except Exception:       # pragma: no cover
+                pass
+            self.handle = None
+        for m in getattr(self, "_mats", []):
+            m.free()
+        self._mats = []
+
+    def __del__(self):
+        self.free()

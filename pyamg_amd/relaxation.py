@@ -1,0 +1,171 @@
+"""GPU twins of ``pyamg.relaxation.relaxation`` (same names, arguments, in-place semantics
+and error behaviour; reference: pyamg/relaxation/relaxation.py).
+
+``jacobi``, ``gauss_seidel``, ``sor``, ``polynomial``, ``block_jacobi`` and
+``block_gauss_seidel`` take SciPy sparse ``A`` and NumPy ``x`` (updated IN PLACE) / ``b``,
+exactly like the reference, stage them through HBM and run the HIP kernels of the resident
+engine (C ABI Layer 2).  They exist so the reference's own relaxation tests read unchanged
+against the device path; inside a solve the hierarchy stays resident instead
+(``DeviceMultilevelSolver``).  No CPU fallback.
+"""
+from __future__ import annotations
+
+from warnings import warn
+
+import numpy as np
+from scipy import sparse
+
+from . import _capi as capi
+from .hierarchy import sparse_op
+from .multilevel import DeviceMatrix
+
+__all__ = ["make_system", "jacobi", "gauss_seidel", "sor", "polynomial", "block_jacobi",
+           "block_gauss_seidel"]
+
+
+def make_system(A, x, b, formats=None):
+    """Return A, x, b suitable for relaxation or raise -- same contract as the reference's
+    ``make_system`` (relaxation.py:15-97): ValueError for non-square A / bad shapes /
+    non-contiguous x, TypeError for mixed dtypes."""
+    if formats is None:
+        pass
+    elif formats == ["csr"]:
+        if sparse.issparse(A) and A.format == "csr":
+            pass
+        elif sparse.issparse(A) and A.format == "bsr":
+            A = A.tocsr()
+        else:
+            warn("implicit conversion to CSR", sparse.SparseEfficiencyWarning)
+            A = sparse.csr_array(A)
+    elif sparse.issparse(A) and A.format in formats:
+        pass
+    else:
+        A = sparse.csr_array(A).asformat(formats[0])
+
+    if not isinstance(x, np.ndarray):
+        raise ValueError("expected numpy array for argument x")
+    if not isinstance(b, np.ndarray):
+        raise ValueError("expected numpy array for argument b")
+    M, N = A.shape
+    if M != N:
+        raise ValueError("expected square matrix")
+    if x.shape not in [(M,), (M, 1)]:
+        raise ValueError("x has invalid dimensions")
+    if b.shape not in [(M,), (M, 1)]:
+        raise ValueError("b has invalid dimensions")
+    if A.dtype != x.dtype or A.dtype != b.dtype:
+        raise TypeError("arguments A, x, and b must have the same dtype")
+    if not x.flags.carray:
+        raise ValueError("x must be contiguous in memory")
+    return A, np.ravel(x), np.ravel(b)
+
+
+class _Staged:
+    """A, x, b in HBM for the duration of one call; x is copied back on exit."""
+
+    def __init__(self, A, x, b, work=0):
+        self.x_host = x
+        self.A = DeviceMatrix(sparse_op(A))
+        self.x = capi.DeviceArray.from_host(x)
+        self.b = capi.DeviceArray.from_host(b)
+        self.work = capi.DeviceArray(max(1, work * x.size), x.dtype) if work else None
+
+    def finish(self):
+        capi.sync()
+        self.x_host[:] = self.x.download()
+        for d in (self.x, self.b, self.work):
+            if d is not None:
+                d.free()
+        self.A.free()
+
+
+def _square_blocks(A):
+    if sparse.issparse(A) and A.format == "bsr":
+        R, C = A.blocksize
+        if R != C:
+            raise ValueError("BSR blocks must be square")
+
+
+def sor(A, x, b, omega, iterations=1, sweep="forward"):
+    """SOR on Ax=b, in place (reference: relaxation.py:100-154)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    _square_blocks(A)
+    if sweep not in ("forward", "backward", "symmetric"):
+        raise ValueError('valid sweep directions: "forward", "backward", and "symmetric"')
+    st = _Staged(A, x, b)
+    st.A.gauss_seidel(st.x, st.b, sweep=sweep, omega=float(omega), iterations=iterations)
+    st.finish()
+
+
+def gauss_seidel(A, x, b, iterations=1, sweep="forward", omega=1.0):
+    """Gauss-Seidel on Ax=b, in place (reference: relaxation.py:265-346; the reference
+    wrapper has the same private ``omega`` keyword, used by ``sor``)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    _square_blocks(A)
+    if sweep not in ("forward", "backward", "symmetric"):
+        raise ValueError('valid sweep directions: "forward", "backward", and "symmetric"')
+    st = _Staged(A, x, b)
+    st.A.gauss_seidel(st.x, st.b, sweep=sweep, omega=float(omega), iterations=iterations)
+    st.finish()
+
+
+def jacobi(A, x, b, iterations=1, omega=1.0):
+    """Weighted Jacobi on Ax=b, in place (reference: relaxation.py:349-420)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    _square_blocks(A)
+    if A.shape[0] <= 0:
+        return
+    st = _Staged(A, x, b, work=1)
+    st.A.jacobi(st.x, st.b, st.work, float(np.real(omega)), iterations)
+    st.finish()
+
+
+def polynomial(A, x, b, coefficients, iterations=1):
+    """x += p(A) (b - A x) with Horner evaluation, in place (reference: relaxation.py:585-659)."""
+    A, x, b = make_system(A, x, b, formats=None)
+    if not sparse.issparse(A):
+        A = sparse.csr_array(A)
+    st = _Staged(A, x, b, work=3)
+    x_is_zero = bool(np.linalg.norm(x) == 0)          # the reference's own test (:649)
+    st.A.polynomial(st.x, st.b, st.work, np.asarray(coefficients, dtype=np.float64), iterations, x_is_zero)
+    st.finish()
+
+
+def _block_prep(A, blocksize, Dinv):
+    A = A.tobsr(blocksize=(blocksize, blocksize))       # relaxation.py:475,556
+    if Dinv is None:
+        raise NotImplementedError("block relaxation on the device path needs a precomputed Dinv "
+                                  "(the reference computes it at setup: smoothing.py:552-608)")
+    if Dinv.shape[0] != int(A.shape[0] / blocksize):
+        raise ValueError("Dinv and A have incompatible dimensions")
+    if (Dinv.shape[1] != blocksize) or (Dinv.shape[2] != blocksize):
+        raise ValueError("Dinv and blocksize are incompatible")
+    return A, np.ascontiguousarray(Dinv, dtype=A.dtype)
+
+
+def block_jacobi(A, x, b, Dinv=None, blocksize=1, iterations=1, omega=1.0):
+    """Block Jacobi, in place (reference: relaxation.py:423-499)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    if blocksize == 1:
+        raise NotImplementedError("blocksize 1: use jacobi (the reference's setup does the same, smoothing.py:565-569)")
+    A, Dinv = _block_prep(A, blocksize, Dinv)
+    st = _Staged(A, x, b, work=1)
+    dD = capi.DeviceArray.from_host(Dinv.reshape(-1))
+    st.A.block_jacobi(st.x, st.b, st.work, dD, float(np.real(omega)), iterations)
+    st.finish()
+    dD.free()
+
+
+def block_gauss_seidel(A, x, b, iterations=1, sweep="forward", blocksize=1, Dinv=None):
+    """Block Gauss-Seidel, in place (reference: relaxation.py:502-582)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    if blocksize == 1:
+        raise NotImplementedError("blocksize 1: use gauss_seidel (smoothing.py:595-599)")
+    if sweep not in ("forward", "backward", "symmetric"):
+        raise ValueError('valid sweep directions: "forward", "backward", and "symmetric"')
+    A, Dinv = _block_prep(A, blocksize, Dinv)
+    st = _Staged(A, x, b)
+    dD = capi.DeviceArray.from_host(Dinv.reshape(-1))
+    st.A.block_gauss_seidel(st.x, st.b, dD, sweep, iterations)
+    st.finish()
+    dD.free()

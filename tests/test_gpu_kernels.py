@@ -1,0 +1,275 @@
+"""GPU parity, kernel level: HIP kernels (through the C ABI) vs outputs of the real
+reference committed in tests/golden/kernels.npz and vs the oracle on seeded inputs.
+Bar: BIT-EXACT for every kernel (f64 and f32) -- the engine reproduces the reference's
+summation order with unfused multiply/add."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from pyamg_amd import _capi as capi
+from pyamg_amd import amg_core as gcore
+from pyamg_amd import relaxation as grelax
+from pyamg_amd.hierarchy import sparse_op
+from pyamg_amd.multilevel import DeviceMatrix
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(z, tag):
+    n = z[f"{tag}.indptr"].size - 1
+    return sp.csr_array((z[f"{tag}.data"], z[f"{tag}.indices"], z[f"{tag}.indptr"]), shape=(n, n))
+
+
+def _dev(*arrs):
+    return [capi.DeviceArray.from_host(a) for a in arrs]
+
+
+@pytest.mark.parametrize("tag", ["pois", "irr"])
+@pytest.mark.parametrize("npl", [1, 2])
+@pytest.mark.parametrize("cap", [64, 2048])
+def test_spmv_family_bit_exact(kernels_npz, tag, npl, cap):
+    z = kernels_npz
+    A = _csr(z, tag)
+    x, b = z[f"{tag}.x"], z[f"{tag}.b"]
+    dA = DeviceMatrix(sparse_op(A))
+    dA.tune(lds_entries=cap, nnz_per_lane=npl)
+    dx, db = _dev(x, b)
+    dy = capi.DeviceArray(A.shape[0], np.float64)
+    dA.spmv(capi.SPMV_SET, dx, dy)
+    assert np.array_equal(dy.download(), z[f"{tag}.Ax"])
+    dA.spmv(capi.SPMV_RESID, dx, dy, b=db)
+    assert np.array_equal(dy.download(), b - A @ x)
+    dy.upload(b)
+    dA.spmv(capi.SPMV_ACC, dx, dy)
+    assert np.array_equal(dy.download(), b + A @ x)
+    dA.spmv(capi.SPMV_AXPBY, dx, dy, b=db, c=0.37)
+    assert np.array_equal(dy.download(), 0.37 * b + A @ x)
+    dy.upload(x)
+    dA.spmv(capi.SPMV_ACC_AXPBY, dx, dy, b=db, c=-1.7)
+    assert np.array_equal(dy.download(), x + (-1.7 * b + A @ x))
+    out = capi.DeviceArray(1, np.float64)
+    dA.resid_sumsq(dx, db, out)
+    r = b - A @ x
+    assert np.isclose(out.download()[0], np.dot(r, r), rtol=1e-13)
+
+
+@pytest.mark.parametrize("tag", ["pois", "irr"])
+@pytest.mark.parametrize("npl,cap", [(1, 64), (2, 2048)])
+def test_relaxation_bit_exact_vs_reference_outputs(kernels_npz, tag, npl, cap):
+    z = kernels_npz
+    A = _csr(z, tag)
+    x, b = z[f"{tag}.x"], z[f"{tag}.b"]
+    dA = DeviceMatrix(sparse_op(A))
+    dA.tune(lds_entries=cap, nnz_per_lane=npl)
+    (db,) = _dev(b)
+    work = capi.DeviceArray(3 * A.shape[0], np.float64)
+    for sweep in ("forward", "backward", "symmetric"):
+        (dx,) = _dev(x)
+        dA.gauss_seidel(dx, db, sweep=sweep, iterations=2)
+        assert np.array_equal(dx.download(), z[f"{tag}.gs.{sweep}"]), sweep
+        (dx,) = _dev(x)
+        dA.gauss_seidel(dx, db, sweep=sweep, omega=1.3, iterations=2)      # == relaxation.sor
+        assert np.array_equal(dx.download(), z[f"{tag}.sor.{sweep}"]), sweep
+    (dx,) = _dev(x)
+    dA.jacobi(dx, db, work, 0.8, iterations=3)
+    assert np.array_equal(dx.download(), z[f"{tag}.jacobi"])
+    (dx,) = _dev(x)
+    dA.polynomial(dx, db, work, [0.05, -0.4, 0.9], iterations=2)
+    assert np.array_equal(dx.download(), z[f"{tag}.poly"])
+    (dx,) = _dev(np.zeros_like(x))
+    dA.polynomial(dx, db, work, [0.05, -0.4, 0.9], iterations=1, x_is_zero=True)
+    assert np.array_equal(dx.download(), z[f"{tag}.poly0"])
+    # BSR(1,1) flavour: arithmetic order of amg_core::bsr_jacobi / bsr_gauss_seidel
+    dB = DeviceMatrix(sparse_op(A.tobsr(blocksize=(1, 1))))
+    dB.tune(lds_entries=cap, nnz_per_lane=npl)
+    (dx,) = _dev(x)
+    dB.jacobi(dx, db, work, 0.8, iterations=2)
+    assert np.array_equal(dx.download(), z[f"{tag}.bsr1.jacobi"])
+    (dx,) = _dev(x)
+    dB.gauss_seidel(dx, db, sweep="symmetric", iterations=1)
+    assert np.array_equal(dx.download(), z[f"{tag}.bsr1.gs"])
+
+
+def test_block_kernels_bit_exact(kernels_npz):
+    z = kernels_npz
+    nb = z["el.indptr"].size - 1
+    E = sp.bsr_array((z["el.data"].reshape(-1, 2, 2), z["el.indices"], z["el.indptr"]), shape=(2 * nb, 2 * nb))
+    x, b, Dinv = z["el.x"], z["el.b"], z["el.Dinv"]
+    dE = DeviceMatrix(sparse_op(E))
+    dx, db = _dev(x, b)
+    dy = capi.DeviceArray(E.shape[0], np.float64)
+    dE.spmv(capi.SPMV_SET, dx, dy)
+    assert np.array_equal(dy.download(), z["el.Ax"])
+    work = capi.DeviceArray(E.shape[0], np.float64)
+    dE.jacobi(dx, db, work, 0.6, iterations=2)
+    assert np.array_equal(dx.download(), z["el.jacobi"])
+    (dx,) = _dev(x)
+    dE.gauss_seidel(dx, db, sweep="symmetric", iterations=1)
+    assert np.array_equal(dx.download(), z["el.gs"])
+    (dD,) = _dev(Dinv.reshape(-1))
+    (dx,) = _dev(x)
+    dE.block_jacobi(dx, db, work, dD, 0.7, iterations=2)
+    assert np.array_equal(dx.download(), z["el.bjacobi"])
+    (dx,) = _dev(x)
+    dE.block_gauss_seidel(dx, db, dD, sweep="symmetric", iterations=1)
+    assert np.array_equal(dx.download(), z["el.bgs"])
+    # non-square blocks (prolongator of an elasticity hierarchy)
+    m = z["P.meta"]
+    P = sp.bsr_array((z["P.data"].reshape(-1, m[2], m[3]), z["P.indices"], z["P.indptr"]), shape=(m[0], m[1]))
+    dP = DeviceMatrix(sparse_op(P))
+    (dxc,) = _dev(z["P.x"])
+    dy = capi.DeviceArray(P.shape[0], np.float64)
+    dP.spmv(capi.SPMV_SET, dxc, dy)
+    assert np.array_equal(dy.download(), z["P.Ax"])
+
+
+def test_layer1_amg_core_signatures(kernels_npz):
+    """Layer 1 (host buffers, reference argument order) vs the oracle, incl. partial sweeps."""
+    from oracle import oracle as orc
+    z = kernels_npz
+    A = _csr(z, "irr")
+    n = A.shape[0]
+    x, b = z["irr.x"], z["irr.b"]
+    Ap, Aj, Ax = A.indptr, A.indices, A.data
+    y = b.copy(); y2 = b.copy()
+    gcore.csr_matvec(n, n, Ap, Aj, Ax, x, y)
+    orc.csr_matvec(n, Ap, Aj, Ax, x, y2)
+    assert np.array_equal(y, y2)
+    for (r0, r1, rs) in [(0, n, 1), (n - 1, -1, -1), (10, 200, 1), (250, 30, -1), (3, 299, 2), (298, 2, -4)]:
+        a = x.copy(); c = x.copy()
+        gcore.gauss_seidel(Ap, Aj, Ax, a, b, r0, r1, rs)
+        orc.gauss_seidel(Ap, Aj, Ax, c, b, r0, r1, rs)
+        assert np.array_equal(a, c), (r0, r1, rs)
+        a = x.copy(); c = x.copy()
+        gcore.sor_gauss_seidel(Ap, Aj, Ax, a, b, r0, r1, rs, 0.9)
+        orc.sor_gauss_seidel(Ap, Aj, Ax, c, b, r0, r1, rs, 0.9)
+        assert np.array_equal(a, c), (r0, r1, rs)
+        a = x.copy(); c = x.copy(); t1 = np.full(n, -7.0); t2 = np.full(n, -7.0)
+        gcore.jacobi(Ap, Aj, Ax, a, b, t1, r0, r1, rs, np.array([0.7]))
+        orc.jacobi(Ap, Aj, Ax, c, b, t2, r0, r1, rs, 0.7)
+        assert np.array_equal(a, c) and np.array_equal(t1, t2), (r0, r1, rs)
+    a = x.copy(); c = x.copy()
+    gcore.bsr_gauss_seidel(Ap, Aj, Ax, a, b, 0, n, 1, 1)
+    orc.bsr_gauss_seidel(Ap, Aj, Ax, c, b, 0, n, 1, 1)
+    assert np.array_equal(a, c)
+    a = x.copy(); c = x.copy(); t1 = np.empty(n); t2 = np.empty(n)
+    gcore.bsr_jacobi(Ap, Aj, Ax, a, b, t1, 0, n, 1, 1, np.array([0.7]))
+    orc.bsr_jacobi(Ap, Aj, Ax, c, b, t2, 0, n, 1, 1, 0.7)
+    assert np.array_equal(a, c)
+    # blocks
+    nb = z["el.indptr"].size - 1
+    Ep, Ej, Ex = z["el.indptr"], z["el.indices"], z["el.data"]
+    xe, be, Dinv = z["el.x"], z["el.b"], np.ascontiguousarray(z["el.Dinv"]).reshape(-1)
+    ye = be.copy(); ye2 = be.copy()
+    gcore.bsr_matvec(nb, nb, 2, 2, Ep, Ej, Ex, xe, ye)
+    orc.bsr_matvec(nb, 2, 2, Ep, Ej, Ex, xe, ye2)
+    assert np.array_equal(ye, ye2)
+    for (r0, r1, rs) in [(0, nb, 1), (nb - 1, -1, -1), (5, 40, 1)]:
+        a = xe.copy(); c = xe.copy()
+        gcore.bsr_gauss_seidel(Ep, Ej, Ex, a, be, r0, r1, rs, 2)
+        orc.bsr_gauss_seidel(Ep, Ej, Ex, c, be, r0, r1, rs, 2)
+        assert np.array_equal(a, c), (r0, r1, rs)
+        a = xe.copy(); c = xe.copy()
+        gcore.block_gauss_seidel(Ep, Ej, Ex, a, be, Dinv, r0, r1, rs, 2)
+        orc.block_gauss_seidel(Ep, Ej, Ex, c, be, Dinv, r0, r1, rs, 2)
+        assert np.array_equal(a, c), (r0, r1, rs)
+    a = xe.copy(); c = xe.copy(); t1 = np.empty_like(xe); t2 = np.empty_like(xe)
+    gcore.bsr_jacobi(Ep, Ej, Ex, a, be, t1, 0, nb, 1, 2, np.array([0.6]))
+    orc.bsr_jacobi(Ep, Ej, Ex, c, be, t2, 0, nb, 1, 2, 0.6)
+    assert np.array_equal(a, c)
+    a = xe.copy(); c = xe.copy()
+    gcore.block_jacobi(Ep, Ej, Ex, a, be, Dinv, t1, 0, nb, 1, np.array([0.7]), 2)
+    orc.block_jacobi(Ep, Ej, Ex, c, be, Dinv, t2, 0, nb, 1, 0.7, 2)
+    assert np.array_equal(a, c)
+    with pytest.raises(TypeError):          # .noconvert() semantics of the reference bindings
+        gcore.gauss_seidel(Ap, Aj, Ax, x.astype(np.float32), b, 0, n, 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_edge_cases_and_long_rows(dtype):
+    """Empty operator, empty rows, one row longer than the LDS window, n = 1; vs the oracle."""
+    from oracle import oracle as orc
+    rng = np.random.RandomState(11)
+    # long rows: dense-ish 40 x 3000 block + identity rows, cap far below the row length
+    n = 3000
+    M = sp.random(n, n, density=0.002, random_state=rng, format="lil")
+    M[7, :] = rng.rand(n)                    # 3000 entries in one row
+    M[8, ::2] = rng.rand(n // 2)
+    M.setdiag(rng.rand(n) + 2.0)
+    M[20, :] = 0                             # empty row
+    M = sp.csr_array(M.tocsr()).astype(dtype)
+    M.sort_indices()
+    op = sparse_op(M)
+    x = rng.rand(n).astype(dtype); b = rng.rand(n).astype(dtype)
+    for npl, cap in [(1, 64), (2, 128), (2, 2048)]:
+        dM = DeviceMatrix(op)
+        dM.tune(lds_entries=cap, nnz_per_lane=npl)
+        dx, db = _dev(x, b)
+        dy = capi.DeviceArray(n, dtype)
+        dM.spmv(capi.SPMV_SET, dx, dy)
+        assert np.array_equal(dy.download(), orc.matvec(op, x)), (npl, cap)
+        c = x.copy()
+        orc.relax_gauss_seidel(op, c, b, 1, "symmetric")
+        dM.gauss_seidel(dx, db, sweep="symmetric")
+        assert np.array_equal(dx.download(), c), (npl, cap)
+        c = x.copy()
+        orc.relax_jacobi(op, c, b, 2, 0.5)
+        (dx,) = _dev(x)
+        work = capi.DeviceArray(n, dtype)
+        dM.jacobi(dx, db, work, 0.5, iterations=2)
+        assert np.array_equal(dx.download(), c), (npl, cap)
+    # n = 1 and an all-zero operator
+    one = sparse_op(sp.csr_array(np.array([[2.0]], dtype=dtype)))
+    dO = DeviceMatrix(one)
+    dx, db = _dev(np.array([0.0], dtype=dtype), np.array([10.0], dtype=dtype))
+    dO.gauss_seidel(dx, db)
+    assert dx.download()[0] == 5.0
+    Z = sparse_op(sp.csr_array((5, 5), dtype=dtype))
+    dZ = DeviceMatrix(Z)
+    dx, db = _dev(np.arange(5, dtype=dtype), np.ones(5, dtype=dtype))
+    dy = capi.DeviceArray(5, dtype)
+    dZ.spmv(capi.SPMV_RESID, dx, dy, b=db)
+    assert np.array_equal(dy.download(), np.ones(5, dtype=dtype))
+    dZ.gauss_seidel(dx, db)                  # zero diagonal everywhere: x untouched
+    assert np.array_equal(dx.download(), np.arange(5, dtype=dtype))
+    E0 = sparse_op(sp.csr_array((0, 0), dtype=dtype))
+    dE = DeviceMatrix(E0)
+    assert dE.info()["rows"] == 0
+
+
+def test_relaxation_module_contract():
+    """The NumPy-facing twins keep the reference's error contract (test_relaxation.py:48-111)
+    and known answers (:148-197, :299-346, :808-835)."""
+    import json
+    from conftest import GOLDEN
+    ka = json.loads((GOLDEN / "known_answers.json").read_text())
+
+    def tri(N):
+        return sp.diags_array([2 * np.ones(N), -np.ones(N), -np.ones(N)], offsets=[0, -1, 1], shape=(N, N), format="csr")
+    for c in ka["jacobi"]["cases"]:
+        x = np.array(c["x"]); grelax.jacobi(tri(c["N"]), x, np.array(c["b"]), omega=c["omega"])
+        np.testing.assert_almost_equal(x, c["expect"])
+    for c in ka["gauss_seidel"]["cases"]:
+        x = np.array(c["x"]); grelax.gauss_seidel(tri(c["N"]), x, np.array(c["b"]), sweep=c["sweep"])
+        np.testing.assert_almost_equal(x, c["expect"])
+    s = ka["sor_wikipedia"]
+    for its, exp in s["expect_after"].items():
+        x = np.zeros(4)
+        grelax.sor(sp.csr_array(np.array(s["A"])), x, np.array(s["b"]), s["omega"], iterations=int(its))
+        np.testing.assert_allclose(x, exp, rtol=s["rtol"])
+    A = tri(10)
+    x = np.zeros(10); b = np.ones(10)
+    with pytest.raises(TypeError):
+        grelax.jacobi(A, x.astype(np.float32), b)
+    with pytest.raises(ValueError):
+        grelax.gauss_seidel(A, np.zeros(20)[::2], b)
+    with pytest.raises(ValueError):
+        grelax.gauss_seidel(A, x, np.ones(11))
+    with pytest.raises(ValueError):
+        grelax.gauss_seidel(A, x, b, sweep="sideways")
+    with pytest.raises(ValueError):
+        grelax.jacobi(sp.csr_array(np.ones((3, 4))), np.zeros(3), np.zeros(3))
+    # x given as (n,1): updated in place like the reference
+    x2 = np.zeros((10, 1)); grelax.gauss_seidel(A, x2, np.ones((10, 1)))
+    x1 = np.zeros(10); grelax.gauss_seidel(A, x1, b)
+    assert np.array_equal(x2.ravel(), x1) and x1.any()
