@@ -261,6 +261,17 @@ int pamg_solver_cycle(pamg_solver_t S, void *x, const void *b, int cycle, int cy
 int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int maxiter,
                       int cycle, int cycles_per_level, int check_every, double *residuals,
                       int *n_iter, int *info, pamg_stream_t s);
+/* Same iteration split in three so that callers (benchmarks, device-side Krylov drivers)
+ * can run exactly k cycles on the resident state with no staging copies in between:
+ * load copies DEVICE x, b into the solver's level-0 buffers; iterate runs k x (cycle +
+ * convergence-check residual norm, multilevel.py:558-569) and, if residuals != NULL,
+ * writes the k norms ||b - A x|| (HOST, after a stream sync); store copies x back. */
+int pamg_solver_load(pamg_solver_t S, const void *x, const void *b, pamg_stream_t s);
+int pamg_solver_iterate(pamg_solver_t S, int k, int cycle, int cycles_per_level, double *residuals,
+                        pamg_stream_t s);
+int pamg_solver_store(pamg_solver_t S, void *x, pamg_stream_t s);
+/* stream the solver launches on when the caller passes NULL */
+int pamg_solver_stream(pamg_solver_t S, pamg_stream_t *s);
 /* use hipGraph replay for the cycle (default 1) */
 int pamg_solver_set_graph(pamg_solver_t S, int enable);
 /* stats[0]=levels stats[1]=kernel launches per V-cycle stats[2]=HBM bytes resident

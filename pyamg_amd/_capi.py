@@ -113,6 +113,10 @@ def _declare(lib):
     f("pamg_solver_cycle", _vp, _vp, _vp, _i, _i, _vp)
     f("pamg_solver_solve", _vp, _vp, _vp, _d, _i, _i, _i, _i, _vp, P(_i), P(_i), _vp)
     f("pamg_solver_set_graph", _vp, _i)
+    f("pamg_solver_load", _vp, _vp, _vp, _vp)
+    f("pamg_solver_iterate", _vp, _i, _i, _i, _vp, _vp)
+    f("pamg_solver_store", _vp, _vp, _vp)
+    f("pamg_solver_stream", _vp, P(_vp))
     f("pamg_solver_stats", _vp, P(C.c_int64))
 
 

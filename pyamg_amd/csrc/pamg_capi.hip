@@ -78,9 +78,8 @@ int l1_gs(int epi, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_siz
     return dx.get(x, sizeof(T) * (size_t)nb * bs);
 }
 
-// jacobi / bsr_jacobi: the device sweep relaxes every row out of place; the reference only
-// rewrites the rows of the (row_start,row_stop,row_step) slice and leaves their old values
-// in temp (relaxation.h:321-323), which is applied here while copying back.
+// jacobi / bsr_jacobi: the device sweep relaxes every row out of place; only the rows of the
+// (row_start,row_stop,row_step) slice are copied back, as in the reference.
 template <typename T>
 int l1_jacobi(bool bsr, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,
               int Ax_size, T *x, int x_size, const T *b, int b_size, T *temp, int temp_size, int row_start,
@@ -99,25 +98,29 @@ int l1_jacobi(bool bsr, const int32_t *Ap, int Ap_size, const int32_t *Aj, int A
         return PAMG_E_ARG;
     if (bsr && !(row_start == 0 && row_stop == nb && row_step == 1))
         return PAMG_E_UNSUPPORTED;      // the reference's partial bsr sweep snapshots x[0:m*bs] (relaxation.h:505-508)
+    // reference order of events (relaxation.h:321-345): snapshot the swept entries of x into
+    // temp, then relax the swept rows reading ONLY temp (entries of temp outside the slice
+    // are whatever the caller left there -- the reference reads them too).
+    for (long t = 0; t < m; ++t) {
+        const long i = row_start + t * row_step;
+        for (int k = 0; k < bs; ++k) temp[i * bs + k] = x[i * bs + k];
+    }
     MatGuard g;
     PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), bsr ? PAMG_BSR : PAMG_CSR, nb, nb, bs, bs, Ap, Aj, Ax));
-    DevBuf dx, db, dn;
-    PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
+    DevBuf dt_, db, dn;
+    PAMG_TRY(dt_.put(temp, sizeof(T) * (size_t)n));
     PAMG_TRY(db.put(b, sizeof(T) * (size_t)n));
     PAMG_TRY(dn.alloc(sizeof(T) * (size_t)n));
     if (bs > 1)
-        PAMG_TRY(block_jacobi_step(g.A, PNT_JACOBI, nullptr, dx.p, dn.p, db.p, (double)omega[0], nullptr));
+        PAMG_TRY(block_jacobi_step(g.A, PNT_JACOBI, nullptr, dt_.p, dn.p, db.p, (double)omega[0], nullptr));
     else
-        PAMG_TRY(stream_launch(g.A, bsr ? EPI_JACOBI_B : EPI_JACOBI, dx.p, db.p, dn.p, 0.0, (double)omega[0], nullptr, nullptr));
+        PAMG_TRY(stream_launch(g.A, bsr ? EPI_JACOBI_B : EPI_JACOBI, dt_.p, db.p, dn.p, 0.0, (double)omega[0], nullptr, nullptr));
     PAMG_HIP(hipDeviceSynchronize());
     std::vector<T> xn((size_t)n);
     PAMG_TRY(dn.get(xn.data(), sizeof(T) * (size_t)n));
     for (long t = 0; t < m; ++t) {
         const long i = row_start + t * row_step;
-        for (int k = 0; k < bs; ++k) {
-            temp[i * bs + k] = x[i * bs + k];
-            x[i * bs + k] = xn[(size_t)(i * bs + k)];
-        }
+        for (int k = 0; k < bs; ++k) x[i * bs + k] = xn[(size_t)(i * bs + k)];
     }
     return PAMG_OK;
 }

@@ -537,6 +537,60 @@ int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int m
     return PAMG_OK;
 }
 
+int pamg_solver_load(pamg_solver_t S, const void *x, const void *b, pamg_stream_t s_)
+{
+    if (!S || !x || !b) return PAMG_E_ARG;
+    if (!S->finalized) return PAMG_E_STATE;
+    hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    Level &L0 = S->levels[0];
+    const size_t vb = (size_t)L0.n * tsize(S->dtype);
+    PAMG_HIP(hipMemcpyAsync(L0.x, x, vb, hipMemcpyDeviceToDevice, s));
+    PAMG_HIP(hipMemcpyAsync(L0.b, b, vb, hipMemcpyDeviceToDevice, s));
+    return PAMG_OK;
+}
+
+int pamg_solver_iterate(pamg_solver_t S, int k, int cycle, int cycles_per_level, double *residuals, pamg_stream_t s_)
+{
+    if (!S || k < 0) return PAMG_E_ARG;
+    if (!S->finalized) return PAMG_E_STATE;
+    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
+    hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    if (residuals && S->norms_cap < k + 2) {
+        if (S->d_norms) hipFree(S->d_norms);
+        S->norms_cap = k + 2;
+        PAMG_HIP(hipMalloc((void **)&S->d_norms, sizeof(double) * (size_t)S->norms_cap));
+    }
+    for (int it = 0; it < k; ++it) {
+        PAMG_TRY(run_cycle(S, cycle, cycles_per_level, s));
+        if (residuals)
+            PAMG_HIP(hipMemcpyAsync(S->d_norms + it, S->d_slot, sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    if (residuals && k > 0) {
+        PAMG_HIP(hipMemcpyAsync(residuals, S->d_norms, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
+        PAMG_HIP(hipStreamSynchronize(s));
+        for (int it = 0; it < k; ++it) residuals[it] = std::sqrt(residuals[it]);
+    }
+    return PAMG_OK;
+}
+
+int pamg_solver_store(pamg_solver_t S, void *x, pamg_stream_t s_)
+{
+    if (!S || !x) return PAMG_E_ARG;
+    if (!S->finalized) return PAMG_E_STATE;
+    hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    Level &L0 = S->levels[0];
+    PAMG_HIP(hipMemcpyAsync(x, L0.x, (size_t)L0.n * tsize(S->dtype), hipMemcpyDeviceToDevice, s));
+    return (int)hipStreamSynchronize(s);
+}
+
+int pamg_solver_stream(pamg_solver_t S, pamg_stream_t *s)
+{
+    if (!S || !s) return PAMG_E_ARG;
+    if (!S->finalized) return PAMG_E_STATE;
+    *s = (pamg_stream_t)S->own_stream;
+    return PAMG_OK;
+}
+
 int pamg_solver_stats(pamg_solver_t S, int64_t stats[8])
 {
     if (!S || !stats) return PAMG_E_ARG;

@@ -236,6 +236,11 @@ def extract(ml) -> HierarchySpec:
             ls.R = sparse_op(lvl.R)
             ls.pre = smoother_spec(getattr(lvl, "presmoother", None), lvl.A)
             ls.post = smoother_spec(getattr(lvl, "postsmoother", None), lvl.A)
+        for nm, op in (("A", ls.A), ("P", ls.P), ("R", ls.R)):
+            if op is not None and op.dtype != levels[0].A.dtype:
+                raise NotImplementedError(
+                    f"mixed-precision hierarchy (level {i} {nm} is {op.dtype}, fine level is "
+                    f"{levels[0].A.dtype}) is not on the device path")
         spec.levels.append(ls)
     spec.coarse_kind, spec.coarse_op, spec.coarse_name = _coarse_operator(ml, levels[-1].A)
     return spec

@@ -205,6 +205,24 @@ class DeviceMultilevelSolver:
                    "pamg_solver_solve")
         return res[: nit.value + 1], nit.value, info.value
 
+    def load_device(self, xd, bd, stream=None):
+        capi.check(capi.lib().pamg_solver_load(self.handle, xd.ptr, bd.ptr, stream), "pamg_solver_load")
+
+    def iterate_device(self, k, cycle="V", cycles_per_level=1, want_residuals=True, stream=None):
+        """Run exactly k x (cycle + convergence-check norm) on the resident state."""
+        res = np.zeros(max(int(k), 1), dtype=np.float64) if want_residuals else None
+        capi.check(capi.lib().pamg_solver_iterate(self.handle, int(k), capi.CYCLE[cycle], int(cycles_per_level),
+                                                  capi.ptr(res), stream), "pamg_solver_iterate")
+        return res[:k] if want_residuals else None
+
+    def store_device(self, xd, stream=None):
+        capi.check(capi.lib().pamg_solver_store(self.handle, xd.ptr, stream), "pamg_solver_store")
+
+    def stream(self):
+        s = C.c_void_p()
+        capi.check(capi.lib().pamg_solver_stream(self.handle, C.byref(s)), "pamg_solver_stream")
+        return s
+
     def solve(self, b, x0=None, tol=1e-5, maxiter=100, cycle="V", accel=None, callback=None,
               residuals=None, cycles_per_level=1, return_info=False):
         """Execute multigrid cycling on the GPU (reference: multilevel.py:398-582)."""

@@ -75,8 +75,13 @@ def make_hierarchies():
                                                       presmoother=("gauss_seidel", {"sweep": "symmetric"}),
                                                       postsmoother=("gauss_seidel", {"sweep": "symmetric"})))
     np.random.seed(SEED)
-    hier("sa3d_jacobi_f32", pyamg.smoothed_aggregation_solver(A3.astype(np.float32), max_coarse=10,
-                                                              presmoother=jac, postsmoother=jac), k=5)
+    # float32: Ruge-Stuben keeps the whole hierarchy in float32 (SA promotes P and the coarse levels
+    # to float64 -- a mixed-precision hierarchy, which the device path rejects explicitly)
+    A3f = A3.astype(np.float32)
+    hier("rs3d_jacobi_f32", pyamg.ruge_stuben_solver(A3f, max_coarse=10, presmoother=jac, postsmoother=jac), k=5)
+    np.random.seed(SEED)
+    hier("rs3d_gs_f32", pyamg.ruge_stuben_solver(A3f, max_coarse=10), k=5)
+    np.random.seed(SEED)
     E, B = pyamg.gallery.linear_elasticity((14, 14), format="bsr")
     np.random.seed(SEED)
     hier("el2d_blockgs", pyamg.smoothed_aggregation_solver(E, B=B, max_coarse=10))
