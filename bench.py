@@ -101,6 +101,11 @@ def main():
     t0 = time.time()
     dml = DeviceMultilevelSolver(ml, device=local_rank, graph=not args.no_graph)
     t_upload = time.time() - t0
+    if rank == 0:
+        for i, (L, dA) in enumerate(zip(ml.levels, dml.A)):
+            inf = dA.info()
+            log(f"  level {i}: n={L.A.shape[0]} nnz={L.A.nnz} ({L.A.format}) row_ranges={inf['row_blocks']} "
+                f"gs_levels fwd/bwd={inf['gs_levels_fwd']}/{inf['gs_levels_bwd']}")
     xd = capi.DeviceArray.from_host(x0)
     bd = capi.DeviceArray.from_host(b)
     stream = dml.stream()

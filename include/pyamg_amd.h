@@ -183,8 +183,13 @@ int pamg_matrix_destroy(pamg_matrix_t A);
  * info[7]=bwd GS levels */
 int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
 /* tuning knobs for experiments: key 0 = lds entries per block, 1 = nnz per lane (1|2),
- * 2 = max rows per block.  Must be called before first use; re-plans the operator. */
+ * 2 = max rows per block (these three re-plan the operator); 3 = widest dependency level (in
+ * row ranges) up to which an order-exact sweep runs as ONE persistent launch with in-kernel
+ * barriers instead of one launch per level (0 = never, max 256); 4 = force the persistent
+ * sweep for every schedule with grid = min(key 3, widest level). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
+/* *error != 0: a persistent sweep of this operator hit its spin bound (synchronises) */
+int pamg_matrix_flow_error(pamg_matrix_t A, int *error);
 
 /* SpMV family (x, y, b, v are DEVICE vectors of the operator's dtype).  mode:           */
 #define PAMG_SPMV_SET      0   /* y  = A x                                              */

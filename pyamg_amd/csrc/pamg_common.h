@@ -49,11 +49,12 @@ enum : int { BLK_JACOBI = 0, BLK_GS, PNT_JACOBI, PNT_GS };   // block_relax_kern
 
 template <typename T>
 struct StreamArgs {
-    const int *rowblk;   // [nblocks+1] first row of each workgroup's row range
+    const int4 *blkmeta; // [nblocks] {first row, end row, first entry, end entry} per workgroup
     const int *Ap;       // row pointer (of the operator or of a level-permuted copy)
     const int *Aj;
     const T *Ax;
     const int *rid;      // original row id of stored row r (permuted copies) or nullptr
+    const T *diag;       // diagonal value of stored row r (last stored a_ii; 0 = none/zero)
     const T *x;          // gather source
     const T *b;          // right-hand side / v
     T *y;                // destination (== x for the in-place GS family)
@@ -70,8 +71,12 @@ struct GsSchedule {
     int row_start = 0, row_stop = 0, row_step = 0;
     int nlevels = 0;
     int64_t nrows = 0, nnz = 0;
-    int *d_Ap = nullptr, *d_Aj = nullptr, *d_rid = nullptr, *d_rowblk = nullptr;
-    void *d_Ax = nullptr;
+    int *d_Ap = nullptr, *d_Aj = nullptr, *d_rid = nullptr;
+    int4 *d_blkmeta = nullptr;
+    void *d_Ax = nullptr, *d_diag = nullptr;
+    int *d_level_blk = nullptr;      // device copy of level_blk (persistent sweep kernel)
+    unsigned *d_sync = nullptr;      // [0] barrier arrival counter, [1] error flag
+    int max_level_blocks = 0;
     std::vector<int> level_blk;      // [nlevels+1] workgroup range of each level
     size_t bytes = 0;
 };
@@ -86,6 +91,7 @@ struct pamg_matrix_s {
     int64_t nrows = 0, ncols = 0, nnz = 0;
     int *d_Ap = nullptr, *d_Aj = nullptr;
     void *d_Ax = nullptr;
+    void *d_diag = nullptr;                   // diagonal of the scalar view (point smoothers)
     // block view kept for the true block smoothers (bs > 1): block CSR arrays
     int *d_bAp = nullptr, *d_bAj = nullptr;   // nullptr when R == C == 1
     void *d_bAx = nullptr;                    // block-ordered values (square blocks only)
@@ -95,8 +101,10 @@ struct pamg_matrix_s {
     std::vector<int> h_bAp, h_bAj;
     // plan for the streamed kernels
     int cap = 2048, npl = 1, max_rows = 1024;
+    int flow_cap = 32;               // persistent GS kernel when a schedule's widest level has <= this many row ranges
+    int flow_force = 0;              // != 0: persistent GS kernel always, grid = min(flow_cap, widest level)
     int nblk = 0;
-    int *d_rowblk = nullptr;
+    int4 *d_blkmeta = nullptr;
     double *d_partial = nullptr;     // nblk doubles (sum-of-squares partials)
     pamg::GsSchedule *gs[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd, bwd, 2 custom
     size_t bytes = 0;

@@ -49,8 +49,24 @@ template <int EPI> struct EpiTraits {
     static constexpr bool bsr_order = (EPI == EPI_JACOBI_B || EPI == EPI_GS_B);
 };
 
+// x accesses of the persistent Gauss-Seidel kernel: other workgroups rewrite x inside the
+// same launch, so loads must bypass this CU's L1 and stores must write through (agent-scope
+// relaxed atomics lower to global_load/store ... sc1; MI355X_MICROARCH.md, "valid forms").
+template <bool COH, typename T>
+__device__ __forceinline__ T ldx(const T *p)
+{
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ void stx(T *p, T v)
+{
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // ---- phase 1: stage products (and column ids) of entries [p0,p1) into LDS slots [p-base]
-template <typename T, bool NEEDC, int NPL>
+template <typename T, bool NEEDC, int NPL, bool COH = false>
 __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, int p1, int base,
                                                T *prod, int *cols)
 {
@@ -60,7 +76,7 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
         for (; p + 3 * BLK < p1; p += 4 * BLK) {      // 4 independent load chains in flight
             const int c0 = a.Aj[p], c1 = a.Aj[p + BLK], c2 = a.Aj[p + 2 * BLK], c3 = a.Aj[p + 3 * BLK];
             const T v0 = a.Ax[p], v1 = a.Ax[p + BLK], v2 = a.Ax[p + 2 * BLK], v3 = a.Ax[p + 3 * BLK];
-            const T x0 = a.x[c0], x1 = a.x[c1], x2 = a.x[c2], x3 = a.x[c3];
+            const T x0 = ldx<COH>(a.x + c0), x1 = ldx<COH>(a.x + c1), x2 = ldx<COH>(a.x + c2), x3 = ldx<COH>(a.x + c3);
             prod[p - base] = v0 * x0;
             prod[p - base + BLK] = v1 * x1;
             prod[p - base + 2 * BLK] = v2 * x2;
@@ -75,7 +91,7 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
         for (; p < p1; p += BLK) {
             const int c0 = a.Aj[p];
             const T v0 = a.Ax[p];
-            prod[p - base] = v0 * a.x[c0];
+            prod[p - base] = v0 * ldx<COH>(a.x + c0);
             if constexpr (NEEDC) cols[p - base] = c0;
         }
     } else {
@@ -88,8 +104,8 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
             const int2 cc = *reinterpret_cast<const int2 *>(a.Aj + q);
             const T2 vv = *reinterpret_cast<const T2 *>(a.Ax + q);
             const bool ok0 = q >= p0, ok1 = q + 1 < p1;
-            const T x0 = ok0 ? a.x[cc.x] : T(0);
-            const T x1 = ok1 ? a.x[cc.y] : T(0);
+            const T x0 = ok0 ? ldx<COH>(a.x + cc.x) : T(0);
+            const T x1 = ok1 ? ldx<COH>(a.x + cc.y) : T(0);
             T2 pr;
             pr.x = vv.x * x0;
             pr.y = vv.y * x1;
@@ -100,60 +116,142 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
 }
 
 // ---- phase 2 pieces
-template <typename T, int EPI>
-__device__ __forceinline__ void row_accumulate(T &s, int &dpos, const T *prod, const int *cols,
-                                               int lo, int hi, int row, int base)
+// Per-row operands that do not depend on phase 1.  They are loaded BEFORE the products are
+// staged so that their memory latency overlaps the streaming phase instead of extending the
+// dependent chain after the barrier (this matters for the latency-bound per-level launches
+// of the Gauss-Seidel family, where one level is a handful of workgroups).
+template <typename T>
+struct RowPre {
+    int lo, hi, row;
+    T b, y, xo, d;
+};
+
+template <typename T, int EPI, bool COH = false>
+__device__ __forceinline__ RowPre<T> row_prefetch(const StreamArgs<T> &a, int r)
 {
-    if constexpr (!EpiTraits<EPI>::need_cols) {
-        for (int k = lo; k < hi; ++k) s += prod[k];
-    } else {
-        for (int k = lo; k < hi; ++k) {
-            if (cols[k] == row) dpos = base + k;          // last stored diagonal wins
-            else if constexpr (EpiTraits<EPI>::bsr_order) s -= prod[k];
-            else s += prod[k];
+    RowPre<T> q;
+    q.lo = a.Ap[r];
+    q.hi = a.Ap[r + 1];
+    q.row = EpiTraits<EPI>::perm ? a.rid[r] : r;
+    q.b = q.y = q.xo = q.d = T(0);
+    if constexpr (EPI >= EPI_JACOBI) q.d = a.diag[r];           // precomputed diagonal of stored row r
+    if constexpr (EPI == EPI_RESID || EPI == EPI_AXPBY || EPI == EPI_ACC_AXPBY || EPI == EPI_SUMSQ ||
+                  EPI >= EPI_JACOBI)
+        q.b = a.b[q.row];
+    if constexpr (EPI == EPI_ACC || EPI == EPI_ACC_AXPBY || EPI == EPI_ACCSEQ) q.y = a.y[q.row];
+    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B || EPI == EPI_SOR) q.xo = ldx<COH>(a.x + q.row);
+    return q;
+}
+
+// Sequential, storage-order accumulation of one row's products.  LDS reads are issued eight
+// at a time ahead of the dependent add chain (the adds stay strictly in order, so the result
+// is unchanged); without this a 60-entry coarse-level row pays 60 serial LDS round trips.
+template <typename T, int EPI>
+__device__ __forceinline__ void row_accumulate(T &s, const T *prod, const int *cols, int lo, int hi, int row)
+{
+    constexpr int U = 8;
+    for (int k = lo; k < hi; k += U) {
+        T p[U];
+        int c[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int kk = min(k + j, hi - 1);            // clamp: stay inside the staged window
+            p[j] = prod[kk];
+            if constexpr (EpiTraits<EPI>::need_cols) c[j] = cols[kk];
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            bool use = k + j < hi;
+            if constexpr (EpiTraits<EPI>::need_cols) use = use && (c[j] != row);   // diagonal never enters the sum
+            if (use) {
+                if constexpr (EpiTraits<EPI>::bsr_order) s -= p[j];
+                else s += p[j];
+            }
         }
     }
 }
 
 template <typename T, int EPI>
-__device__ __forceinline__ void row_finish(const StreamArgs<T> &a, T s, int dpos, int row, double &sq)
+__device__ __forceinline__ T row_init(const RowPre<T> &q)
+{
+    if constexpr (EpiTraits<EPI>::bsr_order) return q.b;
+    else if constexpr (EPI == EPI_ACCSEQ) return q.y;
+    else return T(0);
+}
+
+template <typename T, int EPI, bool COH = false>
+__device__ __forceinline__ void row_finish(const StreamArgs<T> &a, const RowPre<T> &q, T s, double &sq)
 {
     const T one = T(1);
-    if constexpr (EPI == EPI_SET) {
-        a.y[row] = s;
-    } else if constexpr (EPI == EPI_ACCSEQ) {
+    const int row = q.row;
+    if constexpr (EPI == EPI_SET || EPI == EPI_ACCSEQ) {
         a.y[row] = s;
     } else if constexpr (EPI == EPI_ACC) {
-        a.y[row] = a.y[row] + s;
+        a.y[row] = q.y + s;
     } else if constexpr (EPI == EPI_RESID) {
-        a.y[row] = a.b[row] - s;
+        a.y[row] = q.b - s;
     } else if constexpr (EPI == EPI_AXPBY) {
-        const T t = a.c * a.b[row];
+        const T t = a.c * q.b;
         a.y[row] = t + s;
     } else if constexpr (EPI == EPI_ACC_AXPBY) {
-        const T t = a.c * a.b[row];
+        const T t = a.c * q.b;
         const T h = t + s;
-        a.y[row] = a.y[row] + h;
+        a.y[row] = q.y + h;
     } else if constexpr (EPI == EPI_SUMSQ) {
-        const T t = a.b[row] - s;
+        const T t = q.b - s;
         sq += (double)t * (double)t;
     } else if constexpr (EPI == EPI_JACOBI) {
-        const T xo = a.x[row];
-        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
-        a.y[row] = (d != T(0)) ? (one - a.omega) * xo + a.omega * ((a.b[row] - s) / d) : xo;
+        a.y[row] = (q.d != T(0)) ? (one - a.omega) * q.xo + a.omega * ((q.b - s) / q.d) : q.xo;
     } else if constexpr (EPI == EPI_JACOBI_B) {
-        const T xo = a.x[row];
-        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
-        a.y[row] = (d != T(0)) ? (one - a.omega) * xo + a.omega * s / d : xo;
+        a.y[row] = (q.d != T(0)) ? (one - a.omega) * q.xo + a.omega * s / q.d : q.xo;
     } else if constexpr (EPI == EPI_GS) {
-        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
-        if (d != T(0)) a.y[row] = (a.b[row] - s) / d;
+        if (q.d != T(0)) stx<COH>(a.y + row, (q.b - s) / q.d);
     } else if constexpr (EPI == EPI_GS_B) {
-        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
-        if (d != T(0)) a.y[row] = s / d;
+        if (q.d != T(0)) stx<COH>(a.y + row, s / q.d);
     } else if constexpr (EPI == EPI_SOR) {
-        const T d = dpos >= 0 ? a.Ax[dpos] : T(0);
-        if (d != T(0)) a.y[row] = a.omega * ((a.b[row] - s) / d) + (one - a.omega) * a.x[row];
+        if (q.d != T(0)) stx<COH>(a.y + row, a.omega * ((q.b - s) / q.d) + (one - a.omega) * q.xo);
+    }
+}
+
+// one workgroup, one row range: the two phases described at the top of this file
+template <typename T, int EPI, int NPL, bool COH>
+__device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 meta, unsigned char *smem_raw,
+                                             double &sq)
+{
+    constexpr bool NEEDC = EpiTraits<EPI>::need_cols;
+    const int cap = a.cap;
+    T *prod = reinterpret_cast<T *>(smem_raw);
+    int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(cap + 2));
+    const int tid = threadIdx.x;
+    const int r0 = meta.x, r1 = meta.y, p0 = meta.z, p1 = meta.w;
+    if (p1 - p0 <= cap) {
+        const int base = (NPL == 2) ? (p0 & ~1) : p0;
+        int r = r0 + tid;
+        RowPre<T> q;
+        if (r < r1) q = row_prefetch<T, EPI, COH>(a, r);
+        stage_products<T, NEEDC, NPL, COH>(a, p0, p1, base, prod, cols);
+        __syncthreads();
+        while (r < r1) {
+            T s = row_init<T, EPI>(q);
+            row_accumulate<T, EPI>(s, prod, cols, q.lo - base, q.hi - base, q.row);
+            row_finish<T, EPI, COH>(a, q, s, sq);
+            r += BLK;
+            if (r < r1) q = row_prefetch<T, EPI, COH>(a, r);
+        }
+    } else {
+        // one over-long row (the host plan gives it a row range of its own): stream it
+        // through LDS chunk by chunk while lane 0 carries the sequential running sum.
+        RowPre<T> q = row_prefetch<T, EPI, COH>(a, r0);
+        T s = row_init<T, EPI>(q);
+        for (int c0 = p0; c0 < p1; c0 += cap) {
+            const int c1 = min(c0 + cap, p1);
+            const int base = (NPL == 2) ? (c0 & ~1) : c0;
+            __syncthreads();
+            stage_products<T, NEEDC, NPL, COH>(a, c0, c1, base, prod, cols);
+            __syncthreads();
+            if (tid == 0) row_accumulate<T, EPI>(s, prod, cols, c0 - base, c1 - base, q.row);
+        }
+        if (tid == 0) row_finish<T, EPI, COH>(a, q, s, sq);
     }
 }
 
@@ -161,46 +259,62 @@ template <typename T, int EPI, int NPL>
 __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr bool NEEDC = EpiTraits<EPI>::need_cols;
-    const int cap = a.cap;
-    T *prod = reinterpret_cast<T *>(smem_raw);
-    int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(cap + 2));
-    const int tid = threadIdx.x;
-    const int r0 = a.rowblk[blockIdx.x], r1 = a.rowblk[blockIdx.x + 1];
-    const int p0 = a.Ap[r0], p1 = a.Ap[r1];
     double sq = 0.0;
-
-    if (p1 - p0 <= cap) {
-        const int base = (NPL == 2) ? (p0 & ~1) : p0;
-        stage_products<T, NEEDC, NPL>(a, p0, p1, base, prod, cols);
-        __syncthreads();
-        for (int r = r0 + tid; r < r1; r += BLK) {
-            const int row = EpiTraits<EPI>::perm ? a.rid[r] : r;
-            T s = EpiTraits<EPI>::bsr_order ? a.b[row] : (EPI == EPI_ACCSEQ ? a.y[row] : T(0));
-            int dpos = -1;
-            row_accumulate<T, EPI>(s, dpos, prod, cols, a.Ap[r] - base, a.Ap[r + 1] - base, row, base);
-            row_finish<T, EPI>(a, s, dpos, row, sq);
-        }
-    } else {
-        // one over-long row (the host plan gives it a workgroup of its own): stream it
-        // through LDS chunk by chunk while lane 0 carries the sequential running sum.
-        const int row = EpiTraits<EPI>::perm ? a.rid[r0] : r0;
-        T s = EpiTraits<EPI>::bsr_order ? a.b[row] : (EPI == EPI_ACCSEQ ? a.y[row] : T(0));
-        int dpos = -1;
-        for (int c0 = p0; c0 < p1; c0 += cap) {
-            const int c1 = min(c0 + cap, p1);
-            const int base = (NPL == 2) ? (c0 & ~1) : c0;
-            __syncthreads();
-            stage_products<T, NEEDC, NPL>(a, c0, c1, base, prod, cols);
-            __syncthreads();
-            if (tid == 0) row_accumulate<T, EPI>(s, dpos, prod, cols, c0 - base, c1 - base, row, base);
-        }
-        if (tid == 0) row_finish<T, EPI>(a, s, dpos, row, sq);
-    }
+    stream_block<T, EPI, NPL, false>(a, a.blkmeta[blockIdx.x], smem_raw, sq);
     if constexpr (EPI == EPI_SUMSQ) {
         __syncthreads();                                   // LDS reuse for the reduction
         const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
-        if (tid == 0) a.partial[blockIdx.x] = tot;
+        if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
+    }
+}
+
+// Persistent order-exact sweep: ONE launch walks all dependency levels of a schedule.  The
+// grid's G workgroups share the row ranges of a level round-robin and meet at a software
+// barrier between levels (monotonic arrival counter, relaxed agent-scope polling, bounded
+// spin).  x travels between workgroups through write-through stores and L1-bypassing loads
+// (ldx/stx above), so no cache-maintenance fences are needed.  With G == 1 (COH = false) the
+// barrier is a plain __syncthreads() and x uses ordinary cached accesses.  All G workgroups must be co-resident (host sizes G accordingly).
+template <typename T>
+struct FlowArgs {
+    StreamArgs<T> s;          // blkmeta = all row ranges of the schedule, level after level
+    const int *level_blk;     // [nlevels+1] row-range offsets of the levels (DEVICE)
+    int nlevels;
+    unsigned *sync;           // [0] arrival counter (zeroed before the launch), [1] error flag
+};
+
+template <typename T, int EPI, int NPL, bool COH>
+__global__ __launch_bounds__(BLK) void gs_flow_kernel(const FlowArgs<T> g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const unsigned G = gridDim.x;
+    double sq = 0.0;
+    int lb = g.level_blk[0];
+    for (int l = 0; l < g.nlevels; ++l) {
+        const int le = g.level_blk[l + 1];
+        for (int blk = lb + (int)blockIdx.x; blk < le; blk += (int)G) {
+            stream_block<T, EPI, NPL, COH>(g.s, g.s.blkmeta[blk], smem_raw, sq);
+            __syncthreads();                               // LDS is reused by the next row range
+        }
+        lb = le;
+        if constexpr (!COH) {
+            __syncthreads();                               // single workgroup: same-CU visibility
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned target = (unsigned)(l + 1) * G;
+                __hip_atomic_fetch_add(g.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (__hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {            // ~seconds: a workgroup is not resident
+                        __hip_atomic_store(g.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 

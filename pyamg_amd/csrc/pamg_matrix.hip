@@ -34,15 +34,15 @@ int upload_raw(void **dptr, const void *h, size_t n, size_t elt, size_t *bytes)
 
 // Greedy split of rows [begin,end) of a CSR row pointer into workgroup row ranges holding
 // at most `cap` stored entries and `max_rows` rows.  A row longer than `cap` gets a range
-// of its own (the kernel streams it in chunks).  Appends range starts to `out`.
-void plan_rows(const int *Ap, int begin, int end, int cap, int max_rows, std::vector<int> &out)
+// of its own (the kernel streams it in chunks).  Appends {r0, r1, p0, p1} per range.
+void plan_rows(const int *Ap, int begin, int end, int cap, int max_rows, std::vector<int4> &out)
 {
     int r = begin;
     while (r < end) {
-        out.push_back(r);
         const int p0 = Ap[r];
         int e = r + 1;
         while (e < end && e - r < max_rows && Ap[e + 1] - p0 <= cap) ++e;
+        out.push_back(make_int4(r, e, p0, Ap[e]));
         r = e;
     }
 }
@@ -93,14 +93,13 @@ int launch_any(int epi, int npl, int grid, int lds, hipStream_t s, const StreamA
 
 int replan(pamg_matrix_s *A)
 {
-    if (A->d_rowblk) { hipFree(A->d_rowblk); A->d_rowblk = nullptr; }
+    if (A->d_blkmeta) { hipFree(A->d_blkmeta); A->d_blkmeta = nullptr; }
     if (A->d_partial) { hipFree(A->d_partial); A->d_partial = nullptr; }
-    std::vector<int> blk;
+    std::vector<int4> blk;
     blk.reserve((size_t)A->nnz / std::max(1, A->cap / 2) + 16);
     plan_rows(A->h_Ap.data(), 0, (int)A->nrows, A->cap, A->max_rows, blk);
-    blk.push_back((int)A->nrows);
-    A->nblk = (int)blk.size() - 1;
-    PAMG_TRY(upload(&A->d_rowblk, blk.data(), blk.size(), nullptr));
+    A->nblk = (int)blk.size();
+    PAMG_TRY(upload(&A->d_blkmeta, blk.data(), blk.size(), nullptr));
     PAMG_HIP(hipMalloc((void **)&A->d_partial, sizeof(double) * (size_t)(A->nblk + 8)));
     return PAMG_OK;
 }
@@ -108,7 +107,7 @@ int replan(pamg_matrix_s *A)
 void free_schedule(GsSchedule *g)
 {
     if (!g) return;
-    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_rowblk);
+    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync);
     delete g;
 }
 
@@ -192,18 +191,29 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
             std::memcpy(&pAx[(size_t)pAp[r] * ts], &hAx[(size_t)A->h_Ap[i] * ts], (size_t)len * ts);
         }
     }
-    std::vector<int> blk;
+    // diagonal of every stored row (last stored entry with j == i wins; 0 = none): carried by
+    // the schedule so the sweep does not have to chase it after the LDS scan
+    std::vector<unsigned char> pdiag((size_t)m * ts, 0);
+    for (int r = 0; r < m; ++r)
+        for (int p = pAp[r]; p < pAp[r + 1]; ++p)
+            if (pAj[p] == order[r]) std::memcpy(&pdiag[(size_t)r * ts], &pAx[(size_t)p * ts], ts);
+    std::vector<int4> blk;
     g->level_blk.assign(1, 0);
     for (int l = 0; l < g->nlevels; ++l) {
         plan_rows(pAp.data(), lptr[l], lptr[l + 1], A->cap, A->max_rows, blk);
         g->level_blk.push_back((int)blk.size());
     }
-    blk.push_back(m);
     int st = upload(&g->d_Ap, pAp.data(), pAp.size(), &g->bytes);
     if (!st) st = upload(&g->d_Aj, pAj.data(), pAj.size(), &g->bytes);
     if (!st) st = upload_raw(&g->d_Ax, pAx.data(), (size_t)g->nnz, ts, &g->bytes);
+    if (!st) st = upload_raw(&g->d_diag, pdiag.data(), (size_t)m, ts, &g->bytes);
     if (!st) st = upload(&g->d_rid, order.data(), order.size(), &g->bytes);
-    if (!st) st = upload(&g->d_rowblk, blk.data(), blk.size(), &g->bytes);
+    if (!st) st = upload(&g->d_blkmeta, blk.data(), blk.size(), &g->bytes);
+    if (!st) st = upload(&g->d_level_blk, g->level_blk.data(), g->level_blk.size(), &g->bytes);
+    if (!st) st = (int)hipMalloc((void **)&g->d_sync, 256);
+    if (!st) st = (int)hipMemset(g->d_sync, 0, 256);
+    for (int l = 0; l < g->nlevels; ++l)
+        g->max_level_blocks = std::max(g->max_level_blocks, g->level_blk[l + 1] - g->level_blk[l]);
     if (st) { free_schedule(g); return st; }
     *out = g;
     return PAMG_OK;
@@ -254,11 +264,12 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
                         double omega, double *partial)
 {
     StreamArgs<T> a;
-    a.rowblk = A->d_rowblk;
+    a.blkmeta = A->d_blkmeta;
     a.Ap = A->d_Ap;
     a.Aj = A->d_Aj;
     a.Ax = (const T *)A->d_Ax;
     a.rid = nullptr;
+    a.diag = (const T *)A->d_diag;
     a.x = (const T *)x;
     a.b = (const T *)b;
     a.y = (T *)y;
@@ -287,6 +298,19 @@ int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void 
                              base_args<float>(A, x, b, y, c, omega, partial));
 }
 
+template <typename T, int EPI>
+static int flow_launch(int npl, int grid, int lds, hipStream_t s, const FlowArgs<T> &f)
+{
+    if (grid == 1) {
+        if (npl == 2) hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 2, false>), dim3(1), dim3(BLK), lds, s, f);
+        else hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 1, false>), dim3(1), dim3(BLK), lds, s, f);
+    } else {
+        if (npl == 2) hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 2, true>), dim3(grid), dim3(BLK), lds, s, f);
+        else hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 1, true>), dim3(grid), dim3(BLK), lds, s, f);
+    }
+    return (int)hipGetLastError();
+}
+
 template <typename T>
 static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b,
                              double omega, hipStream_t s)
@@ -296,9 +320,31 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
     a.Aj = g->d_Aj;
     a.Ax = (const T *)g->d_Ax;
     a.rid = g->d_rid;
+    a.diag = (const T *)g->d_diag;
     const int lds = lds_bytes(A->dtype, epi, A->cap);
+    const bool flow = lds <= 48 * 1024 && g->nlevels > 1 &&
+                      (A->flow_force ? A->flow_cap > 0 : g->max_level_blocks <= A->flow_cap);
+    if (flow) {
+        // persistent sweep: one launch, levels separated by an in-kernel barrier.  Grid <= 256
+        // workgroups of 256 threads is always co-resident on the 256 CUs (nothing else runs on
+        // this stream-ordered device while the sweep is in flight).
+        FlowArgs<T> f;
+        f.s = a;
+        f.s.blkmeta = g->d_blkmeta;
+        f.level_blk = g->d_level_blk;
+        f.nlevels = g->nlevels;
+        f.sync = g->d_sync;
+        const int G = std::max(1, std::min(std::min(A->flow_cap, 256), g->max_level_blocks));
+        PAMG_HIP(hipMemsetAsync(g->d_sync, 0, sizeof(unsigned), s));
+        switch (epi) {
+            case EPI_GS: return flow_launch<T, EPI_GS>(A->npl, G, lds, s, f);
+            case EPI_GS_B: return flow_launch<T, EPI_GS_B>(A->npl, G, lds, s, f);
+            case EPI_SOR: return flow_launch<T, EPI_SOR>(A->npl, G, lds, s, f);
+        }
+        return PAMG_E_ARG;
+    }
     for (int l = 0; l < g->nlevels; ++l) {
-        a.rowblk = g->d_rowblk + g->level_blk[l];
+        a.blkmeta = g->d_blkmeta + g->level_blk[l];
         PAMG_TRY(launch_any<T>(epi, A->npl, g->level_blk[l + 1] - g->level_blk[l], lds, s, a));
     }
     return PAMG_OK;
@@ -456,6 +502,17 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
         st = upload(&A->d_Ap, A->h_Ap.data(), A->h_Ap.size(), &A->bytes);
         if (!st) st = upload(&A->d_Aj, A->h_Aj.data(), A->h_Aj.size(), &A->bytes);
         if (!st) st = upload_raw(&A->d_Ax, Ax, (size_t)nblk, ts, &A->bytes);
+        if (!st && n_brow == n_bcol) {
+            // diagonal of every row, found exactly like the reference finds it (last stored
+            // entry with j == i wins, 0 when absent: relaxation.h:64-74); carried separately so
+            // the smoothers do not have to re-read the value stream to fetch it
+            std::vector<unsigned char> dg((size_t)n_brow * ts, 0);
+            const unsigned char *src = (const unsigned char *)Ax;
+            for (int i = 0; i < n_brow; ++i)
+                for (int p = Ap[i]; p < Ap[i + 1]; ++p)
+                    if (Aj[p] == i) std::memcpy(&dg[(size_t)i * ts], src + (size_t)p * ts, ts);
+            st = upload_raw(&A->d_diag, dg.data(), (size_t)n_brow, ts, &A->bytes);
+        }
     } else {
         // scalar (flattened) CSR view: scalar row ib*R+r holds, block after block in
         // storage order, the C entries of block row r -- the exact summation order of
@@ -499,8 +556,8 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
 int pamg_matrix_destroy(pamg_matrix_t A)
 {
     if (!A) return PAMG_OK;
-    hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax);
-    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAx); hipFree(A->d_rowblk); hipFree(A->d_partial);
+    hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag);
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     delete A;
     return PAMG_OK;
@@ -529,10 +586,27 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~1; break;
         case 1: if (value != 1 && value != 2) return PAMG_E_ARG; A->npl = value; break;
         case 2: if (value < 1) return PAMG_E_ARG; A->max_rows = value; break;
+        case 3: if (value < 0 || value > 256) return PAMG_E_ARG; A->flow_cap = value; return PAMG_OK;
+        case 4: A->flow_force = value != 0; return PAMG_OK;
         default: return PAMG_E_ARG;
     }
     for (int k = 0; k < 4; ++k) { if (A->gs[k]) A->bytes -= A->gs[k]->bytes; free_schedule(A->gs[k]); A->gs[k] = nullptr; }
     return replan(A);
+}
+
+int pamg_matrix_flow_error(pamg_matrix_t A, int *error)
+{
+    if (!A || !error) return PAMG_E_ARG;
+    *error = 0;
+    PAMG_HIP(hipDeviceSynchronize());
+    for (int k = 0; k < 4; ++k) {
+        GsSchedule *g = A->gs[k];
+        if (!g || !g->d_sync) continue;
+        unsigned w[2] = {0, 0};
+        PAMG_HIP(hipMemcpy(w, g->d_sync, sizeof(w), hipMemcpyDeviceToHost));
+        if (w[1]) *error = 1;
+    }
+    return PAMG_OK;
 }
 
 int pamg_matrix_spmv(pamg_matrix_t A, int mode, const void *x, const void *b_or_v, double c, void *y,

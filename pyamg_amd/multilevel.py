@@ -54,9 +54,14 @@ class DeviceMatrix:
         keys = ("rows", "cols", "nnz", "row_blocks", "lds_entries", "hbm_bytes", "gs_levels_fwd", "gs_levels_bwd")
         return dict(zip(keys, [int(v) for v in a]))
 
-    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None):
+    def flow_error(self) -> bool:
+        e = C.c_int(0)
+        capi.check(capi.lib().pamg_matrix_flow_error(self.handle, C.byref(e)), "pamg_matrix_flow_error")
+        return bool(e.value)
+
+    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, flow_force=None):
         lib = capi.lib()
-        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows)):
+        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (4, flow_force)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 
