@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: V-cycle iterations/sec + fine-level SpMV GB/s (% of the MI355X HBM
-roofline) -- BASELINE.json's metric -- on one of BASELINE.json's configs.
+roofline) -- BASELINE.json's metric.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c3j] [--cpu-cycles k]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c3j|c4s|small] [--no-extras]
 
-A *step* is one pass of the hot path: one multigrid V-cycle on the device-resident
-hierarchy followed by the convergence-check residual norm ||b - A x|| (exactly one
-iteration of the loop in pyamg/multilevel.py:558-569).  Inputs are resident in HBM when the
-timed region starts.  The hierarchy is built on the host by the reference itself
-(oracle/_ref = the reference compiled from /root/reference; setup stays on the host, north
-star) and shipped to HBM once.
+A *step* is one pass of the hot path: one multigrid V-cycle on the device-resident hierarchy
+followed by the convergence-check residual norm ||b - A x|| (exactly one iteration of the
+loop in pyamg/multilevel.py:558-569).  Inputs are resident in HBM when the timed region
+starts.  The hierarchy is built on the host by the reference itself (oracle/_ref = the
+reference compiled from /root/reference; the setup phase stays on the host, north star) and
+shipped to HBM once.
 
-Prints ONE JSON line (rank 0):  metric/value/unit/... + "roofline" (fine-level CSR SpMV
-kernel, algorithmic bytes / HIP-event time, vs 8 TB/s) + "cpu_baseline" (the reference's
-own serial solve on this host, same hierarchy, same b) + "parity" (residual norms of this
-run's GPU cycles vs the reference's cycles).
+Default workload = BASELINE.json configs[2], the north star's problem: 3-D 7-pt Poisson 256^3,
+smoothed aggregation, symmetric Gauss-Seidel V(1,1), fp64.  Order-exact Gauss-Seidel has a
+global sequential dependency and does not shard, so with --gpus N > 1 this
+workload runs N independent replicas (value = N x rate, "scaling": "weak").  The row-sharded
+path (halo exchange over RCCL, coarse levels collapsed) is measured in the same run on the
+same hierarchy with the Chebyshev(3) smoother of configs[3] and reported under "sharded".
+At N = 1 the line also carries configs[1] (2000^2, weighted Jacobi) under "extra".
+
+Prints ONE JSON line (rank 0): metric/value/unit/... + "roofline" (fine-level CSR SpMV
+kernel: algorithmic bytes / HIP-event time vs 8 TB/s) + "cpu_baseline" (the reference's own
+serial solve on this host, same hierarchy, same b) + "parity" (residual norms of this run's
+GPU cycles vs the reference's cycles).
 """
 import argparse
 import json
@@ -26,24 +34,23 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
-
-WORKLOADS = {
-    # BASELINE.json configs[1]
-    "c2": dict(grid=(2000, 2000), label="gallery.poisson((2000,2000)) SA V-cycle, weighted-Jacobi pre/post, fp64",
-               smoother=("jacobi", {"omega": 4.0 / 3.0})),
-    # BASELINE.json configs[2] (the north-star's 256^3 problem)
-    "c3": dict(grid=(256, 256, 256), label="3D 7-pt Poisson 256^3 SA V-cycle, symmetric Gauss-Seidel, fp64",
-               smoother=("gauss_seidel", {"sweep": "symmetric"})),
-    # same grid as c3 with the Jacobi smoother (bandwidth-bound variant; not a BASELINE config)
-    "c3j": dict(grid=(256, 256, 256), label="3D 7-pt Poisson 256^3 SA V-cycle, weighted-Jacobi pre/post, fp64",
-                smoother=("jacobi", {"omega": 4.0 / 3.0})),
-    "c4s": dict(grid=(256, 256, 256), label="3D 7-pt Poisson 256^3 SA V-cycle, Chebyshev(3) pre/post, fp64",
-                smoother=("chebyshev", {"degree": 3, "iterations": 1})),
-    "small": dict(grid=(64, 64, 64), label="3D 7-pt Poisson 64^3 SA V-cycle, symmetric Gauss-Seidel, fp64 (smoke)",
-                  smoother=("gauss_seidel", {"sweep": "symmetric"})),
-}
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (~6.3 TB/s achievable)
 SEED = 20260924
+JAC = ("jacobi", {"omega": 4.0 / 3.0})
+GS = ("gauss_seidel", {"sweep": "symmetric"})
+CHEB = ("chebyshev", {"degree": 3, "iterations": 1})
+WORKLOADS = {
+    "c2": dict(grid=(2000, 2000), smoother=JAC,
+               label="gallery.poisson((2000,2000)) SA V-cycle, weighted-Jacobi pre/post, fp64"),
+    "c3": dict(grid=(256, 256, 256), smoother=GS,
+               label="3D 7-pt Poisson 256^3 (16.7M dof) SA V-cycle, symmetric Gauss-Seidel, fp64"),
+    "c3j": dict(grid=(256, 256, 256), smoother=JAC,
+                label="3D 7-pt Poisson 256^3 SA V-cycle, weighted-Jacobi pre/post, fp64"),
+    "c4s": dict(grid=(256, 256, 256), smoother=CHEB,
+                label="3D 7-pt Poisson 256^3 SA V-cycle, Chebyshev(3) smoother, fp64"),
+    "small": dict(grid=(64, 64, 64), smoother=GS,
+                  label="3D 7-pt Poisson 64^3 SA V-cycle, symmetric Gauss-Seidel, fp64 (smoke)"),
+}
 
 
 def log(*a):
@@ -56,25 +63,30 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("PAMG_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-cycles", type=int, default=-1, help="reference cycles timed on the host (-1: auto, 0: skip)")
+    ap.add_argument("--cpu-cycles", type=int, default=-1, help="reference cycles timed on the host (-1 auto, 0 skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sharded-Chebyshev and configs[1] legs")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--min-rows", type=int, default=200_000, help="shard levels with at least this many rows")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
-    # torch is plumbing only (process group + the contract's cuda synchronize).  It must be
-    # imported BEFORE libpyamg_amd.so is loaded: both link libamdhip64.so.7 and torch's copy
-    # has to be the one the process binds (measured: the other order loses torch's GPUs).
+    # torch is plumbing only (process group, the contract's cuda synchronize, comm buffers of the
+    # sharded path).  It must be imported BEFORE libpyamg_amd.so is loaded: both link
+    # libamdhip64.so.7 and torch's copy has to be the one the process binds (measured on the
+    # MI355X box: the other order leaves torch without devices).
     import torch
     import numpy as np
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from pyamg_amd import DeviceMultilevelSolver, _capi as capi
+    from pyamg_amd.hierarchy import extract
     from tools.problems import spmv_bytes
     capi.check(capi.lib().pamg_set_device(local_rank), "set_device")
 
@@ -83,21 +95,78 @@ def main():
         raise SystemExit("bench.py needs the reference build oracle/_ref for the host-side setup phase "
                          "(python oracle/build_ref.py in the build container)")
     import pyamg
+    from pyamg.relaxation.smoothing import change_smoothers
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        capi.sync()
+
+    def max_over_ranks(v):
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return v
+
+    def build(wl):
+        t0 = time.time()
+        A = pyamg.gallery.poisson(wl["grid"], format="csr")
+        np.random.seed(SEED)                   # Arnoldi start vectors of the smoother setup
+        ml = pyamg.smoothed_aggregation_solver(A, presmoother=wl["smoother"], postsmoother=wl["smoother"],
+                                               max_coarse=10)
+        return A, ml, time.time() - t0
+
+    def rhs(n):
+        np.random.seed(SEED)
+        return np.random.rand(n), np.zeros(n)
+
+    def time_resident(dml, b, x0, steps, warmup, kpar=6):
+        """exactly `steps` steps on the resident state, bracketed by barrier + synchronize"""
+        xd, bd = capi.DeviceArray.from_host(x0), capi.DeviceArray.from_host(b)
+        dml.load_device(xd, bd)
+        res = dml.iterate_device(kpar)                    # parity run (also builds the graph)
+        dml.load_device(xd, bd)
+        dml.iterate_device(warmup, want_residuals=False)
+        barrier()
+        e0, e1 = capi.Event(), capi.Event()
+        stream = dml.stream()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        dml.iterate_device(steps, want_residuals=False)
+        e1.record(stream)
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        return wall, e0.elapsed_ms(e1), res, xd, bd
+
+    def cpu_reference(ml, A, b, x0, kcpu):
+        r = []
+        t0 = time.perf_counter()
+        ml.solve(b, x0=x0, tol=1e-30, maxiter=kcpu, residuals=r)
+        tcpu = time.perf_counter() - t0
+        ts = time.perf_counter()
+        for _ in range(3):
+            A @ b
+        tsp = (time.perf_counter() - ts) / 3
+        return {"value": round(kcpu / tcpu, 4), "unit": "cycles/s", "cores": 1, "kind": "reference",
+                "sample": f"{kcpu} V-cycles of the same solver/rhs by the reference (oracle/_ref, serial) in {tcpu:.1f}s; "
+                          f"fine-level A@x {tsp * 1e3:.1f} ms = {spmv_bytes(A) / tsp / 1e9:.2f} GB/s",
+                "spmv_GBps": round(spmv_bytes(A) / tsp / 1e9, 3)}, np.array(r)
+
+    def parity_of(res_gpu, res_cpu):
+        m = min(len(res_cpu) - 1, len(res_gpu))
+        d = np.abs(np.asarray(res_gpu)[:m] - res_cpu[1:m + 1])
+        return {"cycles_compared": int(m), "max_abs_diff_over_r0": float(np.max(d) / res_cpu[0]),
+                "max_rel_diff": float(np.max(d / res_cpu[1:m + 1])), "tolerance": "1e-10 * ||r0|| (random rhs)"}
+
+    # =========================================================== main workload
     wl = WORKLOADS[args.workload]
-    t0 = time.time()
-    A = pyamg.gallery.poisson(wl["grid"], format="csr")
+    A, ml, t_setup = build(wl)
     n = A.shape[0]
-    np.random.seed(SEED)                       # Arnoldi start vectors of the smoother setup
-    ml = pyamg.smoothed_aggregation_solver(A, presmoother=wl["smoother"], postsmoother=wl["smoother"],
-                                           max_coarse=10)
-    t_setup = time.time() - t0
-    np.random.seed(SEED)
-    b = np.random.rand(n)
-    x0 = np.zeros(n)
+    b, x0 = rhs(n)
     if rank == 0:
         log(f"workload {args.workload}: n={n} nnz={A.nnz} levels={len(ml.levels)} host setup {t_setup:.1f}s")
-
     t0 = time.time()
     dml = DeviceMultilevelSolver(ml, device=local_rank, graph=not args.no_graph)
     t_upload = time.time() - t0
@@ -106,40 +175,11 @@ def main():
             inf = dA.info()
             log(f"  level {i}: n={L.A.shape[0]} nnz={L.A.nnz} ({L.A.format}) row_ranges={inf['row_blocks']} "
                 f"gs_levels fwd/bwd={inf['gs_levels_fwd']}/{inf['gs_levels_bwd']}")
-    xd = capi.DeviceArray.from_host(x0)
-    bd = capi.DeviceArray.from_host(b)
+    wall, ev_ms, res_gpu, xd, bd = time_resident(dml, b, x0, args.steps, args.warmup)
+
+    # ---- roofline of the dominant bandwidth kernel: fine-level CSR SpMV (r = b - A x), HIP events
+    #      on the solver's stream, algorithmic bytes of SURVEY.md 8(d)
     stream = dml.stream()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        capi.sync()
-
-    # ---- parity run (also the graph build): first k cycles, residual norms kept
-    kpar = 6
-    dml.load_device(xd, bd)
-    res_gpu = dml.iterate_device(kpar)
-    # ---- warmup + timed region: exactly K steps on the resident state
-    dml.load_device(xd, bd)
-    dml.iterate_device(args.warmup, want_residuals=False)
-    barrier()
-    e0, e1 = capi.Event(), capi.Event()
-    t0 = time.perf_counter()
-    e0.record(stream)
-    dml.iterate_device(args.steps, want_residuals=False)
-    e1.record(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    ev_ms = e0.elapsed_ms(e1)
-    if world > 1:
-        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-    ms_per_step = wall * 1e3 / args.steps
-
-    # ---- roofline of the dominant bandwidth kernel: fine-level CSR SpMV (r = b - A x),
-    #      HIP events on the solver's stream, algorithmic bytes of SURVEY.md 8(d)
     A0 = dml.A[0]
     rd = capi.DeviceArray(n, np.float64)
     reps = 50
@@ -167,43 +207,22 @@ def main():
                 "bytes_per_launch": int(bytes_resid), "ms_per_launch": round(spmv_ms, 5)}
 
     out = None
+    cpu = parity = None
+    if rank == 0 and world == 1 and args.cpu_cycles != 0:
+        kcpu = args.cpu_cycles if args.cpu_cycles > 0 else (3 if n > 5_000_000 else 10)
+        cpu, res_cpu = cpu_reference(ml, A, b, x0, kcpu)
+        parity = parity_of(res_gpu, res_cpu)
     if rank == 0:
-        # ---- CPU baseline: the reference's own serial solve on this host (1 core), same ml / b
-        cpu = None
-        res_cpu = None
-        if args.cpu_cycles != 0:
-            kcpu = args.cpu_cycles if args.cpu_cycles > 0 else (3 if n > 5_000_000 else 10)
-            kcpu = max(kcpu, 1)
-            r = []
-            t0 = time.perf_counter()
-            ml.solve(b, x0=x0, tol=1e-30, maxiter=kcpu, residuals=r)
-            tcpu = time.perf_counter() - t0
-            res_cpu = np.array(r)
-            ts = time.perf_counter()
-            for _ in range(3):
-                A @ b
-            t_spmv_cpu = (time.perf_counter() - ts) / 3
-            cpu = {"value": round(kcpu / tcpu, 4), "unit": "cycles/s", "cores": 1, "kind": "reference",
-                   "sample": f"{kcpu} V-cycles of the same solver/rhs via oracle/_ref (pyamg reference, serial) "
-                             f"in {tcpu:.1f}s; fine-level A@x {t_spmv_cpu * 1e3:.1f} ms = "
-                             f"{spmv_bytes(A) / t_spmv_cpu / 1e9:.2f} GB/s",
-                   "spmv_GBps": round(spmv_bytes(A) / t_spmv_cpu / 1e9, 3)}
-        parity = None
-        if res_cpu is not None:
-            m = min(len(res_cpu) - 1, kpar)
-            d = np.abs(res_gpu[:m] - res_cpu[1:m + 1])
-            parity = {"cycles_compared": int(m), "max_abs_diff_over_r0": float(np.max(d) / res_cpu[0]),
-                      "max_rel_diff": float(np.max(d / res_cpu[1:m + 1])), "tolerance": "1e-10 * ||r0|| (random rhs)"}
+        replicas = world > 1
         out = {
-            # N > 1: order-exact Gauss-Seidel has a global sequential dependency and does not shard in
-            # parity mode -> N independent replicas, whole-job value = N x cycles/s
             "metric": "vcycle_iterations_per_sec", "value": round(world * args.steps / wall, 3), "unit": "cycles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic", "config": {"workload": wl["label"], "key": args.workload, "n": int(n),
-                                            "nnz": int(A.nnz), "levels": len(ml.levels),
-                                            "cycle": "V(1,1)", "graph": not args.no_graph,
-                                            "parallelism": "single GPU" if world == 1 else f"{world} replicas"},
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall * 1e3 / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl["label"], "key": args.workload, "n": int(n), "nnz": int(A.nnz),
+                       "levels": len(ml.levels), "cycle": "V(1,1)", "graph": not args.no_graph,
+                       "parallelism": "1 GPU" if not replicas else
+                       f"{world} independent replicas (order-exact Gauss-Seidel does not shard; see 'sharded')"},
             "event_ms_per_step": round(ev_ms / args.steps, 4),
             "spmv_GBps": round(achieved, 1), "spmv_pct_of_hbm_peak": round(100 * achieved / HBM_PEAK_GBPS, 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
@@ -212,6 +231,61 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_reference"] = round(out["value"] / cpu["value"], 1)
+
+    # =========================================================== sharded leg (same hierarchy, Chebyshev)
+    if not args.no_extras and args.workload in ("c3", "small"):
+        dml.free()
+        del dml
+        np.random.seed(SEED)
+        change_smoothers(ml, presmoother=CHEB, postsmoother=CHEB)     # rebinds smoothers, hierarchy unchanged
+        spec = extract(ml)
+        steps2 = max(args.steps, 10)
+        if world == 1:
+            d2 = DeviceMultilevelSolver(spec, device=local_rank, graph=not args.no_graph)
+            w2, _, res2, _, _ = time_resident(d2, b, x0, steps2, args.warmup)
+            d2.free()
+        else:
+            from pyamg_amd.dist import DistMultilevelSolver
+            d2 = DistMultilevelSolver(spec, min_rows=args.min_rows)
+            d2.load(b, x0)
+            res2 = d2.iterate(6)
+            d2.load(b, x0)
+            d2.iterate(args.warmup, want_residuals=False)
+            barrier()
+            t0 = time.perf_counter()
+            d2.iterate(steps2)                                       # each step ends with the all-reduced norm
+            barrier()
+            w2 = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            glabel = "x".join(str(g) for g in wl["grid"])
+            sh = {"workload": f"3D 7-pt Poisson {glabel} SA V-cycle, Chebyshev(3) smoother, fp64" + (f", fine levels row-sharded over {world} GPUs "
+                  "(RCCL halo exchange, coarse levels collapsed)" if world > 1 else ", 1 GPU"),
+                  "value": round(steps2 / w2, 3), "unit": "cycles/s", "ms_per_step": round(w2 * 1e3 / steps2, 4),
+                  "steps": steps2, "scaling": "strong", "n_gpus": world,
+                  "residuals_gpu": [float(v) for v in res2]}
+            if world == 1 and args.cpu_cycles != 0:
+                c2cpu, r2cpu = cpu_reference(ml, A, b, x0, 3)
+                sh["cpu_baseline"] = c2cpu
+                sh["parity"] = parity_of(res2, r2cpu)
+            out["sharded"] = sh
+
+    # =========================================================== configs[1] leg (N = 1 only)
+    if not args.no_extras and world == 1 and args.workload == "c3":
+        wl2 = WORKLOADS["c2"]
+        A2, ml2, ts2 = build(wl2)
+        b2, x02 = rhs(A2.shape[0])
+        d3 = DeviceMultilevelSolver(ml2, device=local_rank, graph=not args.no_graph)
+        w3, _, res3, _, _ = time_resident(d3, b2, x02, 50, 5)
+        ex = {"workload": wl2["label"], "value": round(50 / w3, 3), "unit": "cycles/s",
+              "ms_per_step": round(w3 * 1e3 / 50, 4), "steps": 50, "host_setup_s": round(ts2, 1)}
+        if args.cpu_cycles != 0:
+            c3cpu, r3cpu = cpu_reference(ml2, A2, b2, x02, 10)
+            ex["cpu_baseline"] = c3cpu
+            ex["parity"] = parity_of(res3, r3cpu)
+        out["extra"] = {"c2": ex}
+        d3.free()
+
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

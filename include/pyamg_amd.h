@@ -211,6 +211,11 @@ int pamg_matrix_resid_sumsq(pamg_matrix_t A, const void *x, const void *b, doubl
 #define PAMG_SYMMETRIC 2
 int pamg_matrix_jacobi(pamg_matrix_t A, void *x, const void *b, void *work, double omega,
                        int iterations, pamg_stream_t s);
+/* one out-of-place sweep x_out[0:nrows] = jacobi(x_in).  A may be a row shard of the global
+ * operator in local numbering (n_cols >= n_rows, owned columns first: column i of row i is
+ * its diagonal), x_in then holds [owned | halo] values -- the multi-GPU building block. */
+int pamg_matrix_jacobi_step(pamg_matrix_t A, const void *x_in, const void *b, void *x_out,
+                            double omega, pamg_stream_t s);
 /* gauss_seidel / sor as the reference's Python wrappers run them (relaxation.py:265-346,
  * 100-154, quirks included: 'symmetric' ignores omega, BSR flavour ignores omega). */
 int pamg_matrix_gauss_seidel(pamg_matrix_t A, void *x, const void *b, int sweep, double omega,
@@ -230,6 +235,9 @@ int pamg_matrix_block_gauss_seidel(pamg_matrix_t A, void *x, const void *b, cons
 int pamg_vec_sumsq(int dtype, int64_t n, const void *x, double *out_sumsq, pamg_stream_t s);
 int pamg_vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, pamg_stream_t s);
 int pamg_vec_scale(int dtype, int64_t n, double a, const void *x, void *y, pamg_stream_t s);
+/* dst[k] = src[idx[k]], k < n  (halo packing; idx is a DEVICE int32 array) */
+int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, void *dst,
+                    pamg_stream_t s);
 
 /* Hierarchy / cycle / outer iteration (MultilevelSolver, multilevel.py:17-662).         */
 #define PAMG_SMOOTH_NONE        0

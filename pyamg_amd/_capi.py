@@ -98,6 +98,7 @@ def _declare(lib):
     f("pamg_matrix_spmv", _vp, _i, _vp, _vp, _d, _vp, _vp)
     f("pamg_matrix_resid_sumsq", _vp, _vp, _vp, _vp, _vp)
     f("pamg_matrix_jacobi", _vp, _vp, _vp, _vp, _d, _i, _vp)
+    f("pamg_matrix_jacobi_step", _vp, _vp, _vp, _vp, _d, _vp)
     f("pamg_matrix_gauss_seidel", _vp, _vp, _vp, _i, _d, _i, _vp)
     f("pamg_matrix_polynomial", _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp)
     f("pamg_matrix_block_jacobi", _vp, _vp, _vp, _vp, _vp, _d, _i, _vp)
@@ -105,6 +106,7 @@ def _declare(lib):
     f("pamg_vec_sumsq", _i, C.c_int64, _vp, _vp, _vp)
     f("pamg_vec_axpy", _i, C.c_int64, _d, _vp, _vp, _vp)
     f("pamg_vec_scale", _i, C.c_int64, _d, _vp, _vp, _vp)
+    f("pamg_vec_gather", _i, C.c_int64, _vp, _vp, _vp, _vp)
     f("pamg_solver_create", P(_vp), _i)
     f("pamg_solver_destroy", _vp)
     f("pamg_solver_add_level", _vp, _vp, _vp, _vp)

@@ -357,6 +357,13 @@ __global__ __launch_bounds__(BLK) void vec_scale_kernel(int64_t n, T a, const T 
         y[i] = a * x[i];
 }
 
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_gather_kernel(int64_t n, const int *idx, const T *src, T *dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK)
+        dst[i] = src[idx[i]];
+}
+
 // x = M b, dense row-major n x n (coarsest-level solve, multilevel.py:717-721): one wave
 // per row, lanes stride the row, butterfly sum.
 template <typename T>

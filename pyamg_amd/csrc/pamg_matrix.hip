@@ -502,7 +502,7 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
         st = upload(&A->d_Ap, A->h_Ap.data(), A->h_Ap.size(), &A->bytes);
         if (!st) st = upload(&A->d_Aj, A->h_Aj.data(), A->h_Aj.size(), &A->bytes);
         if (!st) st = upload_raw(&A->d_Ax, Ax, (size_t)nblk, ts, &A->bytes);
-        if (!st && n_brow == n_bcol) {
+        if (!st) {
             // diagonal of every row, found exactly like the reference finds it (last stored
             // entry with j == i wins, 0 when absent: relaxation.h:64-74); carried separately so
             // the smoothers do not have to re-read the value stream to fetch it
@@ -654,6 +654,19 @@ int pamg_vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, pamg_s
 int pamg_vec_scale(int dtype, int64_t n, double a, const void *x, void *y, pamg_stream_t s)
 {
     return vec_scale(dtype, n, a, x, y, (hipStream_t)s);
+}
+
+int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, void *dst, pamg_stream_t s)
+{
+    if (n < 0 || (n > 0 && (!idx || !src || !dst))) return PAMG_E_ARG;
+    if (n == 0) return PAMG_OK;
+    const int grid = (int)std::min<int64_t>(8192, (n + BLK - 1) / BLK);
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_gather_kernel<double>), dim3(grid), dim3(BLK), 0, (hipStream_t)s, n, idx, (const double *)src, (double *)dst);
+    else if (dtype == PAMG_F32)
+        hipLaunchKernelGGL((vec_gather_kernel<float>), dim3(grid), dim3(BLK), 0, (hipStream_t)s, n, idx, (const float *)src, (float *)dst);
+    else return PAMG_E_UNSUPPORTED;
+    return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -306,6 +306,16 @@ int pamg_matrix_jacobi(pamg_matrix_t A, void *x, const void *b, void *work, doub
     return PAMG_OK;
 }
 
+int pamg_matrix_jacobi_step(pamg_matrix_t A, const void *x_in, const void *b, void *x_out, double omega,
+                            pamg_stream_t s)
+{
+    if (!A || !x_in || !b || !x_out) return PAMG_E_ARG;
+    if (A->R != 1 || A->C != 1 || A->ncols < A->nrows) return PAMG_E_UNSUPPORTED;
+    if (A->nrows == 0) return PAMG_OK;
+    return stream_launch(A, A->flavour == PAMG_BSR ? EPI_JACOBI_B : EPI_JACOBI, x_in, b, x_out, 0.0, omega,
+                         nullptr, (hipStream_t)s);
+}
+
 int pamg_matrix_gauss_seidel(pamg_matrix_t A, void *x, const void *b, int sweep, double omega,
                              int iterations, pamg_stream_t s)
 {
@@ -473,6 +483,7 @@ int pamg_solver_cycle(pamg_solver_t S, void *x, const void *b, int cycle, int cy
     if (!S->finalized) return PAMG_E_STATE;
     if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
     hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));   // inputs may have been produced on the default stream
     Level &L0 = S->levels[0];
     const size_t vb = (size_t)L0.n * tsize(S->dtype);
     PAMG_HIP(hipMemcpyAsync(L0.x, x, vb, hipMemcpyDeviceToDevice, s));
@@ -491,6 +502,7 @@ int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int m
     if (!S->finalized) return PAMG_E_STATE;
     if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
     hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));   // inputs may have been produced on the default stream
     Level &L0 = S->levels[0];
     const size_t vb = (size_t)L0.n * tsize(S->dtype);
     if (S->norms_cap < maxiter + 2) {
@@ -542,6 +554,7 @@ int pamg_solver_load(pamg_solver_t S, const void *x, const void *b, pamg_stream_
     if (!S || !x || !b) return PAMG_E_ARG;
     if (!S->finalized) return PAMG_E_STATE;
     hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));   // inputs may have been produced on the default stream
     Level &L0 = S->levels[0];
     const size_t vb = (size_t)L0.n * tsize(S->dtype);
     PAMG_HIP(hipMemcpyAsync(L0.x, x, vb, hipMemcpyDeviceToDevice, s));

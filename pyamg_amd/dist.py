@@ -1,0 +1,425 @@
+"""Row-sharded multigrid cycle: one process per GPU, ``torch.distributed`` (RCCL over xGMI).
+
+What shards: SpMV / residual / restriction / prolongation, weighted Jacobi and
+polynomial (Chebyshev, Richardson) smoothing -- independent rows plus ONE halo exchange of the
+input vector per operator application.  Order-exact Gauss-Seidel does not shard (global
+sequential dependency); hierarchies using it are rejected here (run replicas instead).
+
+Layout.  Every level with at least ``min_rows`` unknowns is split into contiguous row blocks,
+one per rank.  A rank holds its rows of ``A_l``, the rows of ``P_l`` it owns (fine rows) and
+the rows of ``R_l`` it owns (coarse rows), all renumbered into a local column space
+``[owned | halo]`` where the halo of level ``l`` is the union of the off-rank columns that
+``A_l``, ``P_{l-1}`` and ``R_l`` touch, grouped by owning rank.  Every level-``l`` vector is a
+buffer ``[owned | halo]``; one exchange fills the halo straight from the owners' packed send
+buffers (point-to-point ``isend``/``irecv`` with the actual neighbours only -- xGMI is
+point-to-point, a ring all-gather of x would move N times the data).  Per-row arithmetic is
+unchanged (entries keep their storage order), so the sharded iterates are bit-identical to
+the single-GPU ones; only norms (one all-reduced scalar per iteration) differ in the last bits.
+
+Below the last sharded level the hierarchy is tiny (<2 % of the nonzeros): its right-hand
+side is assembled on every rank by an all-reduce of disjoint slices and the remaining cycle
+runs redundantly on every GPU with the resident single-GPU engine -- the "collapse to GPU 0"
+schedule without the broadcast back.
+
+Local arithmetic is delegated to an ``ops`` object: ``DeviceOps`` (HIP kernels through the C
+ABI, this module) in production; the CPU tests inject an oracle-backed twin so the
+partition / halo / cycle logic runs under ``gloo`` without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .hierarchy import HierarchySpec, LevelSpec, SparseOp
+
+__all__ = ["split_even", "ShardedHierarchy", "DistMultilevelSolver", "DeviceOps", "shardable"]
+
+SHARDABLE_SMOOTHERS = ("jacobi", "polynomial", "none")
+
+
+def split_even(n: int, parts: int) -> np.ndarray:
+    """Contiguous row-block offsets [parts+1]."""
+    return np.array([(n * r) // parts for r in range(parts + 1)], dtype=np.int64)
+
+
+def shardable(spec: HierarchySpec) -> bool:
+    for L in spec.levels[:-1]:
+        for s in (L.pre, L.post):
+            if s is not None and s.kind not in SHARDABLE_SMOOTHERS:
+                return False
+        for op in (L.A, L.P, L.R):
+            if op.blocksize != (1, 1):
+                return False
+    return True
+
+
+def _rows(op: SparseOp, r0: int, r1: int):
+    p0, p1 = int(op.indptr[r0]), int(op.indptr[r1])
+    return op.indptr[r0:r1 + 1] - op.indptr[r0], op.indices[p0:p1], op.data[p0:p1]
+
+
+def _ext_cols(op: SparseOp, r0: int, r1: int, c0: int, c1: int) -> np.ndarray:
+    """Sorted unique global columns outside [c0,c1) touched by rows [r0,r1)."""
+    cols = op.indices[int(op.indptr[r0]):int(op.indptr[r1])]
+    ext = cols[(cols < c0) | (cols >= c1)]
+    return np.unique(ext)
+
+
+@dataclass
+class LevelPlan:
+    """Exchange plan of one level on one rank."""
+    off: np.ndarray                     # [N+1] row offsets of the level
+    n_owned: int = 0
+    halo_cols: np.ndarray = None        # global ids of the halo entries, grouped by owner (ascending)
+    recv: List[tuple] = field(default_factory=list)   # (src_rank, halo_begin, count)
+    send: List[tuple] = field(default_factory=list)   # (dst_rank, send_begin, count)
+    send_idx: np.ndarray = None         # owned-local indices to pack, grouped by destination
+
+    @property
+    def n_halo(self) -> int:
+        return int(self.halo_cols.size)
+
+    @property
+    def n_local(self) -> int:
+        return self.n_owned + self.n_halo
+
+
+def _localize(op: SparseOp, r0: int, r1: int, c0: int, c1: int, halo_cols: np.ndarray) -> SparseOp:
+    """Rows [r0,r1) of ``op`` with columns renumbered to [owned | halo]."""
+    indptr, cols, data = _rows(op, r0, r1)
+    owned = (cols >= c0) & (cols < c1)
+    loc = np.empty(cols.size, dtype=np.int32)
+    loc[owned] = (cols[owned] - c0).astype(np.int32)
+    if (~owned).any():
+        pos = np.searchsorted(halo_cols, cols[~owned])
+        assert np.array_equal(halo_cols[pos], cols[~owned])
+        loc[~owned] = ((c1 - c0) + pos).astype(np.int32)
+    return SparseOp(op.fmt, (r1 - r0, (c1 - c0) + int(halo_cols.size)), (1, 1),
+                    np.ascontiguousarray(indptr, dtype=np.int32), loc, np.ascontiguousarray(data), op.src_format)
+
+
+class ShardedHierarchy:
+    """Host-side partitioning of a HierarchySpec for one rank (every rank holds the full spec)."""
+
+    def __init__(self, spec: HierarchySpec, rank: int, world: int, min_rows: int = 200_000):
+        if not shardable(spec):
+            raise NotImplementedError("hierarchy is not shardable (order-exact Gauss-Seidel / block operators): "
+                                      "run replicas instead")
+        self.spec, self.rank, self.world = spec, rank, world
+        nlev = len(spec.levels)
+        # sharded levels: 0 .. ns-1 ; level ns is the collapse level (full vectors on every rank)
+        ns = 0
+        while ns < nlev - 1 and spec.levels[ns].A.shape[0] >= max(min_rows, world):
+            ns += 1
+        if ns == 0:
+            raise NotImplementedError("nothing to shard: fine level smaller than min_rows")
+        self.ns = ns
+        offs = [split_even(spec.levels[l].A.shape[0], world) for l in range(ns + 1)]
+        self.plans: List[LevelPlan] = []
+        self.A: List[SparseOp] = []
+        self.P: List[SparseOp] = []
+        self.R: List[SparseOp] = []
+        # halo of level l = union of off-rank columns of A_l (rows l), P_{l-1} (rows l-1), R_l (rows l+1)
+        for l in range(ns + 1):
+            off = offs[l]
+            needs = []          # per rank d: sorted unique external columns of level l
+            for d in range(world):
+                c0, c1 = int(off[d]), int(off[d + 1])
+                parts = []
+                if l < ns:
+                    parts.append(_ext_cols(spec.levels[l].A, c0, c1, c0, c1))
+                    ro = offs[l + 1]
+                    parts.append(_ext_cols(spec.levels[l].R, int(ro[d]), int(ro[d + 1]), c0, c1))
+                if l > 0:
+                    fo = offs[l - 1]
+                    parts.append(_ext_cols(spec.levels[l - 1].P, int(fo[d]), int(fo[d + 1]), c0, c1))
+                needs.append(np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int32))
+            me = rank
+            plan = LevelPlan(off=off, n_owned=int(off[me + 1] - off[me]), halo_cols=needs[me].astype(np.int64))
+            owner = np.searchsorted(off, plan.halo_cols, side="right") - 1
+            for s in range(world):
+                cnt = int(np.count_nonzero(owner == s))
+                if cnt:
+                    beg = int(np.searchsorted(owner, s, side="left"))
+                    plan.recv.append((s, beg, cnt))
+            sidx, beg = [], 0
+            for d in range(world):
+                if d == me:
+                    continue
+                mine = needs[d][(needs[d] >= off[me]) & (needs[d] < off[me + 1])]
+                if mine.size:
+                    sidx.append((mine - off[me]).astype(np.int32))
+                    plan.send.append((d, beg, int(mine.size)))
+                    beg += int(mine.size)
+            plan.send_idx = np.concatenate(sidx) if sidx else np.zeros(0, dtype=np.int32)
+            self.plans.append(plan)
+        for l in range(ns):
+            o, oc = offs[l], offs[l + 1]
+            r0, r1 = int(o[rank]), int(o[rank + 1])
+            q0, q1 = int(oc[rank]), int(oc[rank + 1])
+            L = spec.levels[l]
+            self.A.append(_localize(L.A, r0, r1, r0, r1, self.plans[l].halo_cols))
+            self.P.append(_localize(L.P, r0, r1, q0, q1, self.plans[l + 1].halo_cols))
+            self.R.append(_localize(L.R, q0, q1, r0, r1, self.plans[l].halo_cols))
+        # remaining (collapsed) hierarchy, replicated on every rank
+        self.coarse_spec = HierarchySpec(levels=[LevelSpec(A=L.A, P=L.P, R=L.R, pre=L.pre, post=L.post)
+                                                 for L in spec.levels[ns:]],
+                                         coarse_kind=spec.coarse_kind, coarse_op=spec.coarse_op,
+                                         coarse_name=spec.coarse_name)
+
+
+# ----------------------------------------------------------------------------------- local ops
+class DeviceOps:
+    """Local arithmetic on the GPU through the C ABI.  Vectors are torch CUDA tensors (torch is
+    plumbing: device memory + the process group); kernels run on the legacy default stream,
+    which is torch's current stream, so collectives and kernels are ordered."""
+
+    def __init__(self, device_index: int, dtype=np.float64):
+        import torch
+        from . import _capi as capi
+        self.torch, self.capi = torch, capi
+        self.device = torch.device("cuda", device_index)
+        self.dtype = np.dtype(dtype)
+        self.tdtype = torch.float64 if self.dtype == np.float64 else torch.float32
+        capi.check(capi.lib().pamg_set_device(device_index), "pamg_set_device")
+
+    # buffers
+    def vector(self, n):
+        return self.torch.zeros(max(int(n), 1), dtype=self.tdtype, device=self.device)
+
+    def index(self, idx):
+        return self.torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int32)).to(self.device)
+
+    def from_host(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=self.dtype)).to(self.device)
+
+    def to_host(self, t, n):
+        return t[:n].cpu().numpy()
+
+    def _p(self, t, offset=0):
+        return C.c_void_p(t.data_ptr() + offset * t.element_size())
+
+    # operators
+    def matrix(self, op: SparseOp):
+        from .multilevel import DeviceMatrix
+        return DeviceMatrix(op)
+
+    def spmv(self, M, mode, x, y, b=None, c=0.0):
+        self.capi.check(self.capi.lib().pamg_matrix_spmv(M.handle, mode, self._p(x), self._p(b) if b is not None else None,
+                                                         float(c), self._p(y), None), "spmv")
+
+    def jacobi_step(self, M, x_in, b, x_out, omega):
+        self.capi.check(self.capi.lib().pamg_matrix_jacobi_step(M.handle, self._p(x_in), self._p(b), self._p(x_out),
+                                                                float(omega), None), "jacobi_step")
+
+    def resid_sumsq(self, M, x, b):
+        out = self.torch.zeros(1, dtype=self.torch.float64, device=self.device)
+        self.capi.check(self.capi.lib().pamg_matrix_resid_sumsq(M.handle, self._p(x), self._p(b), self._p(out), None),
+                        "resid_sumsq")
+        return out
+
+    def axpy(self, n, a, x, y):
+        self.capi.check(self.capi.lib().pamg_vec_axpy(self.capi.dtype_code(self.dtype), int(n), float(a), self._p(x),
+                                                      self._p(y), None), "axpy")
+
+    def scale(self, n, a, x, y):
+        self.capi.check(self.capi.lib().pamg_vec_scale(self.capi.dtype_code(self.dtype), int(n), float(a), self._p(x),
+                                                       self._p(y), None), "scale")
+
+    def gather(self, n, idx, src, dst):
+        self.capi.check(self.capi.lib().pamg_vec_gather(self.capi.dtype_code(self.dtype), int(n), self._p(idx),
+                                                        self._p(src), self._p(dst), None), "gather")
+
+    def coarse_solver(self, spec: HierarchySpec):
+        from .multilevel import DeviceMultilevelSolver
+        return DeviceMultilevelSolver(spec, graph=True)
+
+    def coarse_cycle(self, solver, x, b, cycle):
+        self.capi.sync()                 # inputs were produced on the default stream
+        self.capi.check(self.capi.lib().pamg_solver_cycle(solver.handle, self._p(x), self._p(b), self.capi.CYCLE[cycle],
+                                                          1, None), "coarse cycle")
+
+
+# ------------------------------------------------------------------------------- the solver
+class DistMultilevelSolver:
+    """Sharded twin of ``DeviceMultilevelSolver`` (V-cycle, accel=None branch of ``solve``).
+
+    ``group``: a ``torch.distributed`` process group (None = default).  All ranks call every
+    method collectively with identical arguments (b, x0 are the GLOBAL vectors on the host;
+    each rank uses its slice and ``solve`` returns the global solution on every rank).
+    """
+
+    def __init__(self, spec: HierarchySpec, ops=None, group=None, min_rows: int = 200_000):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.ops = ops if ops is not None else DeviceOps(int(__import__("os").environ.get("LOCAL_RANK", self.rank)),
+                                                         spec.dtype)
+        self.spec = spec
+        self.sh = ShardedHierarchy(spec, self.rank, self.world, min_rows)
+        o = self.ops
+        ns = self.sh.ns
+        self.A = [o.matrix(m) for m in self.sh.A]
+        self.P = [o.matrix(m) for m in self.sh.P]
+        self.R = [o.matrix(m) for m in self.sh.R]
+        self.send_idx = [o.index(p.send_idx) for p in self.sh.plans]
+        self.send_buf = [o.vector(p.send_idx.size) for p in self.sh.plans]
+        nl = [p.n_local for p in self.sh.plans]
+        self.x = [o.vector(nl[l]) for l in range(ns + 1)]
+        self.xalt = [o.vector(nl[l]) for l in range(ns)]
+        self.b = [o.vector(nl[l]) for l in range(ns + 1)]
+        self.r = [o.vector(nl[l]) for l in range(ns)]
+        self.h = [[o.vector(nl[l]), o.vector(nl[l])] if self._has_poly(l) else None for l in range(ns)]
+        nc = spec.levels[ns].A.shape[0]
+        self.bc_full = o.vector(nc)
+        self.xc_full = o.vector(nc)
+        cplan = self.sh.plans[ns]
+        c0 = int(cplan.off[self.rank])
+        self.c_fill_idx = o.index(np.concatenate([np.arange(c0, c0 + cplan.n_owned, dtype=np.int64),
+                                                  cplan.halo_cols]).astype(np.int32))
+        self.coarse = o.coarse_solver(self.sh.coarse_spec)
+        self.shape = tuple(spec.levels[0].A.shape)
+
+    def _has_poly(self, l):
+        L = self.spec.levels[l]
+        return any(s is not None and s.kind == "polynomial" for s in (L.pre, L.post))
+
+    # ---- communication
+    def exchange(self, l, v):
+        """Fill the halo part of level-l vector ``v`` from its owners."""
+        plan = self.sh.plans[l]
+        if not plan.send and not plan.recv:
+            return
+        dist = self.dist
+        if plan.send_idx.size:
+            self.ops.gather(plan.send_idx.size, self.send_idx[l], v, self.send_buf[l])
+        reqs = []
+        for (src, beg, cnt) in plan.recv:
+            reqs.append(dist.P2POp(dist.irecv, v[plan.n_owned + beg: plan.n_owned + beg + cnt], self._peer(src), self.group))
+        for (dst, beg, cnt) in plan.send:
+            reqs.append(dist.P2POp(dist.isend, self.send_buf[l][beg: beg + cnt], self._peer(dst), self.group))
+        for w in dist.batch_isend_irecv(reqs):
+            w.wait()
+
+    def _peer(self, r):
+        return r if self.group is None else self.dist.get_global_rank(self.group, r)
+
+    # ---- smoothers (reference: relaxation.py:349-420, 585-659)
+    def _smooth(self, l, s, x_zero):
+        if s is None or s.kind == "none":
+            return
+        o, A = self.ops, self.A[l]
+        n = self.sh.plans[l].n_owned
+        if s.kind == "jacobi":
+            for it in range(s.iterations):
+                if not (x_zero and it == 0):             # halo of an all-zero iterate is zero already
+                    self.exchange(l, self.x[l])
+                o.jacobi_step(A, self.x[l], self.b[l], self.xalt[l], s.omega)
+                self.x[l], self.xalt[l] = self.xalt[l], self.x[l]
+            return
+        co = np.asarray(s.coefficients, dtype=np.float64)
+        for it in range(s.iterations):
+            if x_zero and it == 0:
+                res = self.b[l]
+            else:
+                self.exchange(l, self.x[l])
+                o.spmv(A, 2, self.x[l], self.r[l], b=self.b[l])          # res = b - A x
+                res = self.r[l]
+            if co.size == 1:
+                o.axpy(n, co[0], res, self.x[l])
+                continue
+            hc, hn = self.h[l]
+            o.scale(n, co[0], res, hc)
+            for k in range(1, co.size - 1):
+                self.exchange(l, hc)
+                o.spmv(A, 3, hc, hn, b=res, c=co[k])                     # h = c*res + A h
+                hc, hn = hn, hc
+            self.exchange(l, hc)
+            o.spmv(A, 4, hc, self.x[l], b=res, c=co[-1])                 # x += c*res + A h
+
+    # ---- one V-cycle on the sharded levels (multilevel.py:584-662)
+    def _cycle(self, l, x_zero, cycle="V"):
+        o, sh = self.ops, self.sh
+        L = self.spec.levels[l]
+        self._smooth(l, L.pre, x_zero)
+        self.exchange(l, self.x[l])
+        o.spmv(self.A[l], 2, self.x[l], self.r[l], b=self.b[l])          # r = b - A x
+        self.exchange(l, self.r[l])
+        if l + 1 < sh.ns:
+            o.spmv(self.R[l], 0, self.r[l], self.b[l + 1])               # b_c = R r
+            self.x[l + 1].zero_()
+            self._cycle(l + 1, True, cycle)
+            self.exchange(l + 1, self.x[l + 1])
+            o.spmv(self.P[l], 1, self.x[l + 1], self.x[l])               # x += P x_c
+        else:
+            cplan = sh.plans[sh.ns]
+            c0 = int(cplan.off[self.rank])
+            self.bc_full.zero_()
+            o.spmv(self.R[l], 0, self.r[l], self.b[sh.ns])               # owned slice of b_c
+            self.bc_full[c0: c0 + cplan.n_owned].copy_(self.b[sh.ns][:cplan.n_owned])
+            self.dist.all_reduce(self.bc_full, group=self.group)         # disjoint slices -> full b_c everywhere
+            self.xc_full.zero_()
+            o.coarse_cycle(self.coarse, self.xc_full, self.bc_full, cycle)
+            o.gather(cplan.n_local, self.c_fill_idx, self.xc_full, self.x[sh.ns])
+            o.spmv(self.P[l], 1, self.x[sh.ns], self.x[l])               # x += P x_c
+        self._smooth(l, L.post, False)
+
+    def resid_norm(self):
+        self.exchange(0, self.x[0])
+        ss = self.ops.resid_sumsq(self.A[0], self.x[0], self.b[0])
+        self.dist.all_reduce(ss, group=self.group)
+        return float(np.sqrt(float(ss.item())))
+
+    def load(self, b, x0):
+        p = self.sh.plans[0]
+        r0 = int(p.off[self.rank])
+        self.b[0][:p.n_owned].copy_(self.ops.from_host(np.ravel(b)[r0:r0 + p.n_owned]))
+        self.x[0][:p.n_owned].copy_(self.ops.from_host(np.ravel(x0)[r0:r0 + p.n_owned]))
+
+    def iterate(self, k, cycle="V", want_residuals=True):
+        """k x (V-cycle + convergence-check norm) on the resident sharded state."""
+        out = []
+        for _ in range(k):
+            self._cycle(0, False, cycle)
+            if want_residuals:
+                out.append(self.resid_norm())
+        return out
+
+    def gather_solution(self):
+        p = self.sh.plans[0]
+        full = self.ops.vector(self.shape[0])
+        full.zero_()
+        r0 = int(p.off[self.rank])
+        full[r0:r0 + p.n_owned].copy_(self.x[0][:p.n_owned])
+        self.dist.all_reduce(full, group=self.group)
+        return self.ops.to_host(full, self.shape[0])
+
+    def solve(self, b, x0=None, tol=1e-5, maxiter=100, cycle="V", residuals=None, return_info=False):
+        """accel=None branch of MultilevelSolver.solve (multilevel.py:537-582), V-cycle."""
+        if str(cycle).upper() != "V":
+            raise NotImplementedError("sharded path: V-cycle only")
+        b = np.asarray(b)
+        x = np.zeros_like(b) if x0 is None else np.array(x0)
+        self.load(b, x)
+        normb = float(np.linalg.norm(b))
+        normb = 1.0 if normb == 0.0 else normb
+        hist = [self.resid_norm()]
+        it, info = 0, 0
+        while True:
+            self._cycle(0, False, "V")
+            it += 1
+            nr = self.resid_norm()
+            hist.append(nr)
+            if nr < tol * normb:
+                info = 0
+                break
+            if it == maxiter:
+                info = it
+                break
+        if residuals is not None:
+            residuals[:] = hist
+        xs = self.gather_solution()
+        return (xs, info) if return_info else xs
