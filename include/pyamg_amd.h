@@ -186,7 +186,11 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * 2 = max rows per block (these three re-plan the operator); 3 = widest dependency level (in
  * row ranges) up to which an order-exact sweep runs as ONE persistent launch with in-kernel
  * barriers instead of one launch per level (0 = never, max 256); 4 = force the persistent
- * sweep for every schedule with grid = min(key 3, widest level). */
+ * sweep for every schedule with grid = min(key 3, widest level); 5 = order-exact sweep mode:
+ * 0 (default) = level launches / barrier kernel, 1 = granular sync-free persistent sweep
+ * (element-level hand-off, no barriers) when the swept pattern is structurally symmetric;
+ * 6 = cap on the granular sweep's persistent grid (0 = auto); 7 = granular sweep restricted
+ * to the workgroups that land on XCD 0 (hand-off through one L2). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* *error != 0: a persistent sweep of this operator hit its spin bound (synchronises) */
 int pamg_matrix_flow_error(pamg_matrix_t A, int *error);

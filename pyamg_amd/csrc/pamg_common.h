@@ -56,6 +56,8 @@ struct StreamArgs {
     const int *rid;      // original row id of stored row r (permuted copies) or nullptr
     const T *diag;       // diagonal value of stored row r (last stored a_ii; 0 = none/zero)
     const T *x;          // gather source
+    T *xs;               // granular sweep: hand-off buffer (sentinel = not published yet)
+    unsigned *err;       // granular sweep: error flag (spin bound hit)
     const T *b;          // right-hand side / v
     T *y;                // destination (== x for the in-place GS family)
     double *partial;     // EPI_SUMSQ: one double per workgroup
@@ -75,6 +77,9 @@ struct GsSchedule {
     int4 *d_blkmeta = nullptr;
     void *d_Ax = nullptr, *d_diag = nullptr;
     int *d_level_blk = nullptr;      // device copy of level_blk (persistent sweep kernel)
+    void *d_xs = nullptr;            // granular sweep: hand-off buffer (one value per matrix row)
+    bool symmetric = false;          // pattern among swept rows is structurally symmetric
+    int nblk_total = 0;
     unsigned *d_sync = nullptr;      // [0] barrier arrival counter, [1] error flag
     int max_level_blocks = 0;
     std::vector<int> level_blk;      // [nlevels+1] workgroup range of each level
@@ -103,6 +108,9 @@ struct pamg_matrix_s {
     int cap = 2048, npl = 1, max_rows = 1024;
     int flow_cap = 32;               // persistent GS kernel when a schedule's widest level has <= this many row ranges
     int flow_force = 0;              // != 0: persistent GS kernel always, grid = min(flow_cap, widest level)
+    int gran_xcd = 0;                // granular sweep restricted to the workgroups that land on XCD 0
+    int gran_cap = 0;                // granular sweep: cap on the persistent grid (0 = auto)
+    int gs_mode = 0;                 // 0: level launches / barrier kernel (default); 1: granular sync-free sweep when the pattern allows
     int nblk = 0;
     int4 *d_blkmeta = nullptr;
     double *d_partial = nullptr;     // nblk doubles (sum-of-squares partials)

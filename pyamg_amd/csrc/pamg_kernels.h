@@ -49,24 +49,71 @@ template <int EPI> struct EpiTraits {
     static constexpr bool bsr_order = (EPI == EPI_JACOBI_B || EPI == EPI_GS_B);
 };
 
-// x accesses of the persistent Gauss-Seidel kernel: other workgroups rewrite x inside the
-// same launch, so loads must bypass this CU's L1 and stores must write through (agent-scope
-// relaxed atomics lower to global_load/store ... sc1; MI355X_MICROARCH.md, "valid forms").
-template <bool COH, typename T>
+// x accesses of the persistent sweeps: other workgroups rewrite x inside the same launch, so
+// loads must bypass this CU's L1 and stores must write through (agent-scope relaxed atomics
+// lower to global_load/store ... sc1; MI355X_MICROARCH.md, "valid forms").
+template <int COH, typename T>
 __device__ __forceinline__ T ldx(const T *p)
 {
-    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (COH == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else return *p;
 }
-template <bool COH, typename T>
-__device__ __forceinline__ void stx(T *p, T v)
+
+// Level schedules mark "early" entries -- columns whose row is visited EARLIER in the same
+// sweep, i.e. whose NEW value must be used -- with the sign bit of the stored column id.
+constexpr int EARLY_BIT = (int)0x80000000u;
+constexpr int COL_MASK = 0x7FFFFFFF;
+
+// Sentinel bit patterns of the hand-off buffer xs (a quiet NaN with a payload no arithmetic
+// produces): xs[j] == sentinel  <=>  row j has not published its new value in this sweep yet.
+template <typename T> struct Sentinel;
+template <> struct Sentinel<double> {
+    using bits_t = unsigned long long;
+    static constexpr bits_t value = 0x7FF8DEADBEEF5A5Aull;
+    static __device__ __forceinline__ bits_t bits(double v) { return (bits_t)__double_as_longlong(v); }
+};
+template <> struct Sentinel<float> {
+    using bits_t = unsigned int;
+    static constexpr bits_t value = 0x7FC5BEEFu;
+    static __device__ __forceinline__ bits_t bits(float v) { return __float_as_uint(v); }
+};
+
+// wait for row j's published value: the 8-byte (4-byte) datum IS the flag -- one write-through
+// store by the producer, relaxed agent-scope polling here (MI355X_MICROARCH.md, hand-off "R2")
+template <typename T>
+__device__ __forceinline__ T spin_value(const T *xs, int j, unsigned *err)
 {
-    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
+    T v = __hip_atomic_load(xs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (Sentinel<T>::bits(v) == Sentinel<T>::value) {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(xs + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > (1u << 22)) {                        // ~seconds: producer not resident / bug
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    return v;
+}
+
+// gather of one x value in the three flavours of the kernel family:
+//   plain (COH = 0): ordinary cached load;  COH = 1: L1-bypassing load (persistent barrier sweep);
+//   COH = 2 (granular sweep): early entries spin on the hand-off buffer, the others read x.
+template <int COH, typename T>
+__device__ __forceinline__ T gather_x(const StreamArgs<T> &a, int c)
+{
+    if constexpr (COH == 2 || COH == 3) {
+        if (c & EARLY_BIT) return spin_value<T>(a.xs, c & COL_MASK, a.err);
+        return a.x[c];
+    } else if constexpr (COH == 1) {
+        return __hip_atomic_load(a.x + (c & COL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        return a.x[c & COL_MASK];
+    }
 }
 
 // ---- phase 1: stage products (and column ids) of entries [p0,p1) into LDS slots [p-base]
-template <typename T, bool NEEDC, int NPL, bool COH = false>
+template <typename T, bool NEEDC, int NPL, int COH = 0>
 __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, int p1, int base,
                                                T *prod, int *cols)
 {
@@ -76,23 +123,24 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
         for (; p + 3 * BLK < p1; p += 4 * BLK) {      // 4 independent load chains in flight
             const int c0 = a.Aj[p], c1 = a.Aj[p + BLK], c2 = a.Aj[p + 2 * BLK], c3 = a.Aj[p + 3 * BLK];
             const T v0 = a.Ax[p], v1 = a.Ax[p + BLK], v2 = a.Ax[p + 2 * BLK], v3 = a.Ax[p + 3 * BLK];
-            const T x0 = ldx<COH>(a.x + c0), x1 = ldx<COH>(a.x + c1), x2 = ldx<COH>(a.x + c2), x3 = ldx<COH>(a.x + c3);
+            const T x0 = gather_x<COH>(a, c0), x1 = gather_x<COH>(a, c1), x2 = gather_x<COH>(a, c2),
+                    x3 = gather_x<COH>(a, c3);
             prod[p - base] = v0 * x0;
             prod[p - base + BLK] = v1 * x1;
             prod[p - base + 2 * BLK] = v2 * x2;
             prod[p - base + 3 * BLK] = v3 * x3;
             if constexpr (NEEDC) {
-                cols[p - base] = c0;
-                cols[p - base + BLK] = c1;
-                cols[p - base + 2 * BLK] = c2;
-                cols[p - base + 3 * BLK] = c3;
+                cols[p - base] = c0 & COL_MASK;
+                cols[p - base + BLK] = c1 & COL_MASK;
+                cols[p - base + 2 * BLK] = c2 & COL_MASK;
+                cols[p - base + 3 * BLK] = c3 & COL_MASK;
             }
         }
         for (; p < p1; p += BLK) {
             const int c0 = a.Aj[p];
             const T v0 = a.Ax[p];
-            prod[p - base] = v0 * ldx<COH>(a.x + c0);
-            if constexpr (NEEDC) cols[p - base] = c0;
+            prod[p - base] = v0 * gather_x<COH>(a, c0);
+            if constexpr (NEEDC) cols[p - base] = c0 & COL_MASK;
         }
     } else {
         // two consecutive entries per lane: 8-byte index loads, 16-byte value loads, 16-byte
@@ -101,16 +149,20 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
         using T2 = typename Vec2<T>::type;
 #pragma unroll 2
         for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
-            const int2 cc = *reinterpret_cast<const int2 *>(a.Aj + q);
+            int2 cc = *reinterpret_cast<const int2 *>(a.Aj + q);
             const T2 vv = *reinterpret_cast<const T2 *>(a.Ax + q);
             const bool ok0 = q >= p0, ok1 = q + 1 < p1;
-            const T x0 = ok0 ? ldx<COH>(a.x + cc.x) : T(0);
-            const T x1 = ok1 ? ldx<COH>(a.x + cc.y) : T(0);
+            const T x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
+            const T x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
             T2 pr;
             pr.x = vv.x * x0;
             pr.y = vv.y * x1;
             *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
-            if constexpr (NEEDC) *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+            if constexpr (NEEDC) {
+                cc.x &= COL_MASK;
+                cc.y &= COL_MASK;
+                *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+            }
         }
     }
 }
@@ -126,7 +178,7 @@ struct RowPre {
     T b, y, xo, d;
 };
 
-template <typename T, int EPI, bool COH = false>
+template <typename T, int EPI, int COH = 0>
 __device__ __forceinline__ RowPre<T> row_prefetch(const StreamArgs<T> &a, int r)
 {
     RowPre<T> q;
@@ -179,7 +231,7 @@ __device__ __forceinline__ T row_init(const RowPre<T> &q)
     else return T(0);
 }
 
-template <typename T, int EPI, bool COH = false>
+template <typename T, int EPI, int COH = 0>
 __device__ __forceinline__ void row_finish(const StreamArgs<T> &a, const RowPre<T> &q, T s, double &sq)
 {
     const T one = T(1);
@@ -204,17 +256,29 @@ __device__ __forceinline__ void row_finish(const StreamArgs<T> &a, const RowPre<
         a.y[row] = (q.d != T(0)) ? (one - a.omega) * q.xo + a.omega * ((q.b - s) / q.d) : q.xo;
     } else if constexpr (EPI == EPI_JACOBI_B) {
         a.y[row] = (q.d != T(0)) ? (one - a.omega) * q.xo + a.omega * s / q.d : q.xo;
-    } else if constexpr (EPI == EPI_GS) {
-        if (q.d != T(0)) stx<COH>(a.y + row, (q.b - s) / q.d);
-    } else if constexpr (EPI == EPI_GS_B) {
-        if (q.d != T(0)) stx<COH>(a.y + row, s / q.d);
-    } else if constexpr (EPI == EPI_SOR) {
-        if (q.d != T(0)) stx<COH>(a.y + row, a.omega * ((q.b - s) / q.d) + (one - a.omega) * q.xo);
+    } else if constexpr (EPI == EPI_GS || EPI == EPI_GS_B || EPI == EPI_SOR) {
+        T v;
+        bool upd = q.d != T(0);
+        if constexpr (EPI == EPI_GS) v = (q.b - s) / q.d;
+        else if constexpr (EPI == EPI_GS_B) v = s / q.d;
+        else v = a.omega * ((q.b - s) / q.d) + (one - a.omega) * q.xo;
+        if constexpr (COH == 2 || COH == 3) {
+            // granular sweep: ALWAYS publish (an untouched row publishes its old value), then
+            // store x for the kernels that follow.  COH == 3: every participant sits on the same
+            // XCD, the shared L2 is the coherence point -> an ordinary (L2-resident) store.
+            if (!upd) v = a.x[row];
+            if constexpr (COH == 2) __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (upd) a.y[row] = v;
+        } else if constexpr (COH == 1) {
+            if (upd) __hip_atomic_store(a.y + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (upd) a.y[row] = v;
+        }
     }
 }
 
-// one workgroup, one row range: the two phases described at the top of this file
-template <typename T, int EPI, int NPL, bool COH>
+template <typename T, int EPI, int NPL, int COH>
 __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 meta, unsigned char *smem_raw,
                                              double &sq)
 {
@@ -260,7 +324,7 @@ __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double sq = 0.0;
-    stream_block<T, EPI, NPL, false>(a, a.blkmeta[blockIdx.x], smem_raw, sq);
+    stream_block<T, EPI, NPL, 0>(a, a.blkmeta[blockIdx.x], smem_raw, sq);
     if constexpr (EPI == EPI_SUMSQ) {
         __syncthreads();                                   // LDS reuse for the reduction
         const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
@@ -292,7 +356,7 @@ __global__ __launch_bounds__(BLK) void gs_flow_kernel(const FlowArgs<T> g)
     for (int l = 0; l < g.nlevels; ++l) {
         const int le = g.level_blk[l + 1];
         for (int blk = lb + (int)blockIdx.x; blk < le; blk += (int)G) {
-            stream_block<T, EPI, NPL, COH>(g.s, g.s.blkmeta[blk], smem_raw, sq);
+            stream_block<T, EPI, NPL, COH ? 1 : 0>(g.s, g.s.blkmeta[blk], smem_raw, sq);
             __syncthreads();                               // LDS is reused by the next row range
         }
         lb = le;
@@ -316,6 +380,62 @@ __global__ __launch_bounds__(BLK) void gs_flow_kernel(const FlowArgs<T> g)
             __syncthreads();
         }
     }
+}
+
+// Granular ("sync-free") order-exact sweep: ONE persistent launch, no barriers at all.  Row
+// ranges are taken in schedule (= dependency-level) order, workgroup w owning ranges w, w+G,
+// w+2G, ...; an entry that needs the NEW value of an earlier row simply waits for that row's
+// datum to appear in the hand-off buffer xs (pre-filled with a sentinel), so the critical
+// path is one write-through store -> one polled load per dependency hop instead of a kernel
+// boundary or a grid barrier per level.  Deadlock-free because a range only ever waits on
+// ranges with smaller ids and every workgroup walks its ranges in increasing order (all G
+// workgroups co-resident; spins are bounded and raise the error flag).  Requires a
+// structurally symmetric pattern among the swept rows (checked on the host): a later row then
+// always waits for every earlier neighbour, which also orders the write-after-read hazards.
+template <typename T, int EPI, int NPL>
+__global__ __launch_bounds__(BLK) void gs_gran_kernel(const StreamArgs<T> a, int nblk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double sq = 0.0;
+    for (int blk = (int)blockIdx.x; blk < nblk; blk += (int)gridDim.x) {
+        stream_block<T, EPI, NPL, 2>(a, a.blkmeta[blk], smem_raw, sq);
+        __syncthreads();                                   // LDS is reused by the next row range
+    }
+}
+
+// Single-XCD variant: the hand-off hop through the memory fabric costs several microseconds,
+// the hop through ONE XCD's L2 a fraction of that.  Every workgroup reads the XCC id it
+// actually runs on (hardware register, no placement assumption); only those on XCD 0 take
+// part, the others leave at once.  Participants claim row ranges from an atomic ticket
+// counter -- ids are handed out in increasing order to workgroups that are already running,
+// so the "only wait on smaller ids" argument still holds -- publish with ordinary stores
+// (they stay in the shared L2) and poll with L1-bypassing loads.
+template <typename T, int EPI, int NPL>
+__global__ __launch_bounds__(BLK) void gs_gran_xcd_kernel(const StreamArgs<T> a, int nblk, unsigned *ticket)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ int next_blk;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF;      // HW_REG_XCC_ID[3:0]
+    if (xcc != 0) return;
+    double sq = 0.0;
+    while (true) {
+        if (threadIdx.x == 0)
+            next_blk = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int blk = next_blk;
+        if (blk >= nblk) break;
+        stream_block<T, EPI, NPL, 3>(a, a.blkmeta[blk], smem_raw, sq);
+        __syncthreads();                                   // LDS (and next_blk) are reused
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void fill_sentinel_kernel(T *xs, int64_t n)
+{
+    using B = typename Sentinel<T>::bits_t;
+    B *p = reinterpret_cast<B *>(xs);
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK)
+        p[i] = Sentinel<T>::value;
 }
 
 // ------------------------------------------------------------------ BLAS-1 and friends

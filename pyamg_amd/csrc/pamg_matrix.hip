@@ -1,7 +1,9 @@
 // pamg_matrix.hip -- operator handle: upload, planning, dependency-level analysis for the
 // order-exact Gauss-Seidel family, kernel dispatch.
 #include <algorithm>
+#include <atomic>
 #include <new>
+#include <thread>
 
 #include "pamg_kernels.h"
 
@@ -107,7 +109,7 @@ int replan(pamg_matrix_s *A)
 void free_schedule(GsSchedule *g)
 {
     if (!g) return;
-    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync);
+    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs);
     delete g;
 }
 
@@ -119,7 +121,7 @@ void free_schedule(GsSchedule *g)
 // never touch each other's unknowns.  Output: `order` = visited rows sorted by level
 // (visit order inside a level), `lptr` = [nlevels+1] offsets into order.
 int analyse_levels(int n, const int *Ap, const int *Aj, int row_start, int row_stop, int row_step,
-                   std::vector<int> &order, std::vector<int> &lptr)
+                   std::vector<int> &order, std::vector<int> &lptr, std::vector<int> *vis_out = nullptr)
 {
     if (row_step == 0) return PAMG_E_ARG;
     const long span = (long)row_stop - row_start;
@@ -127,6 +129,7 @@ int analyse_levels(int n, const int *Ap, const int *Aj, int row_start, int row_s
     const int m = (int)(span / row_step);
     order.clear();
     lptr.assign(1, 0);
+    if (vis_out) vis_out->assign(n, -1);
     if (m == 0) return PAMG_OK;
     const long last = (long)row_start + (long)(m - 1) * row_step;
     if (row_start < 0 || row_start >= n || last < 0 || last >= n) return PAMG_E_ARG;
@@ -160,20 +163,56 @@ int analyse_levels(int n, const int *Ap, const int *Aj, int row_start, int row_s
         const int i = row_start + t * row_step;
         order[cur[lvl[i]]++] = i;
     }
+    if (vis_out) vis_out->swap(vis);
     return PAMG_OK;
+}
+
+template <typename F>
+void parallel_rows(int n, F fn)
+{
+    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int nt = (n < (1 << 16)) ? 1 : (int)hw;
+    if (nt == 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) {
+        const int lo = (int)((int64_t)n * t / nt), hi = (int)((int64_t)n * (t + 1) / nt);
+        th.emplace_back([=] { fn(lo, hi); });
+    }
+    for (auto &x : th) x.join();
+}
+
+// true iff for every stored (i,j), i != j, both swept, (j,i) is stored too
+bool pattern_symmetric(int n, const int *Ap, const int *Aj, const std::vector<int> &vis)
+{
+    std::atomic<bool> ok(true);
+    parallel_rows(n, [&](int lo, int hi) {
+        for (int i = lo; i < hi && ok.load(std::memory_order_relaxed); ++i) {
+            if (vis[i] < 0) continue;
+            for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+                const int j = Aj[p];
+                if (j == i || j < 0 || j >= n || vis[j] < 0) continue;
+                bool found = false;
+                for (int q = Ap[j]; q < Ap[j + 1]; ++q)
+                    if (Aj[q] == i) { found = true; break; }
+                if (!found) { ok.store(false); return; }
+            }
+        }
+    });
+    return ok.load();
 }
 
 // schedule for the scalar (streamed) path: level-permuted copy of the operator
 int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out)
 {
-    std::vector<int> order, lptr;
+    std::vector<int> order, lptr, vis;
     PAMG_TRY(analyse_levels((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), row_start, row_stop,
-                            row_step, order, lptr));
+                            row_step, order, lptr, &vis));
     GsSchedule *g = new (std::nothrow) GsSchedule();
     if (!g) return PAMG_E_ALLOC;
     g->row_start = row_start; g->row_stop = row_stop; g->row_step = row_step;
     g->nlevels = (int)lptr.size() - 1;
     g->nrows = (int64_t)order.size();
+    g->symmetric = pattern_symmetric((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), vis);
     const int m = (int)order.size();
     std::vector<int> pAp((size_t)m + 1, 0);
     for (int r = 0; r < m; ++r) pAp[r + 1] = pAp[r] + (A->h_Ap[order[r] + 1] - A->h_Ap[order[r]]);
@@ -191,6 +230,18 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
             std::memcpy(&pAx[(size_t)pAp[r] * ts], &hAx[(size_t)A->h_Ap[i] * ts], (size_t)len * ts);
         }
     }
+    // "early" entries (column's row is visited earlier in this sweep: the NEW value is needed)
+    // carry the sign bit of the column id; every sweep kernel masks it off, the granular
+    // sweep uses it to know which values to wait for
+    parallel_rows(m, [&](int lo, int hi) {
+        for (int r = lo; r < hi; ++r) {
+            const int i = order[r], ti = vis[i];
+            for (int p = pAp[r]; p < pAp[r + 1]; ++p) {
+                const int j = pAj[p];
+                if (j != i && j >= 0 && j < (int)A->nrows && vis[j] >= 0 && vis[j] < ti) pAj[p] = j | (int)0x80000000u;
+            }
+        }
+    });
     // diagonal of every stored row (last stored entry with j == i wins; 0 = none): carried by
     // the schedule so the sweep does not have to chase it after the LDS scan
     std::vector<unsigned char> pdiag((size_t)m * ts, 0);
@@ -210,6 +261,12 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
     if (!st) st = upload(&g->d_rid, order.data(), order.size(), &g->bytes);
     if (!st) st = upload(&g->d_blkmeta, blk.data(), blk.size(), &g->bytes);
     if (!st) st = upload(&g->d_level_blk, g->level_blk.data(), g->level_blk.size(), &g->bytes);
+    g->nblk_total = (int)blk.size();
+    if (!st && g->symmetric) {
+        const size_t xb = ((size_t)A->nrows + 8) * ts;
+        st = (int)hipMalloc(&g->d_xs, xb);
+        if (!st) g->bytes += xb;
+    }
     if (!st) st = (int)hipMalloc((void **)&g->d_sync, 256);
     if (!st) st = (int)hipMemset(g->d_sync, 0, 256);
     for (int l = 0; l < g->nlevels; ++l)
@@ -271,6 +328,8 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.rid = nullptr;
     a.diag = (const T *)A->d_diag;
     a.x = (const T *)x;
+    a.xs = nullptr;
+    a.err = nullptr;
     a.b = (const T *)b;
     a.y = (T *)y;
     a.partial = partial;
@@ -298,6 +357,66 @@ int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void 
                              base_args<float>(A, x, b, y, c, omega, partial));
 }
 
+template <typename T, int EPI, int NPL>
+static int gran_occupancy(int lds)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gs_gran_kernel<T, EPI, NPL>, BLK, (size_t)lds) != hipSuccess) nb = 1;
+    return nb;
+}
+
+// co-resident grid of the granular sweep: (occupancy - 1, at most 4) workgroups per CU -- the
+// occupancy query can over-report by one per CU (MI355X_MICROARCH.md), every spin is bounded
+template <typename T>
+static int gran_grid(int epi, int npl, int lds)
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        else cus = 64;
+    }
+    int nb;
+    if (npl == 2) nb = epi == EPI_GS ? gran_occupancy<T, EPI_GS, 2>(lds) : epi == EPI_GS_B ? gran_occupancy<T, EPI_GS_B, 2>(lds) : gran_occupancy<T, EPI_SOR, 2>(lds);
+    else nb = epi == EPI_GS ? gran_occupancy<T, EPI_GS, 1>(lds) : epi == EPI_GS_B ? gran_occupancy<T, EPI_GS_B, 1>(lds) : gran_occupancy<T, EPI_SOR, 1>(lds);
+    nb = std::max(1, std::min(nb - 1, 4));
+    return nb * cus;
+}
+
+template <typename T>
+static int gran_launch(int epi, int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a, int nblk)
+{
+#define PAMG_GRAN(E)                                                                                        \
+    if (npl == 2) hipLaunchKernelGGL((gs_gran_kernel<T, E, 2>), dim3(grid), dim3(BLK), lds, s, a, nblk);    \
+    else hipLaunchKernelGGL((gs_gran_kernel<T, E, 1>), dim3(grid), dim3(BLK), lds, s, a, nblk);
+    switch (epi) {
+        case EPI_GS: PAMG_GRAN(EPI_GS) break;
+        case EPI_GS_B: PAMG_GRAN(EPI_GS_B) break;
+        case EPI_SOR: PAMG_GRAN(EPI_SOR) break;
+        default: return PAMG_E_ARG;
+    }
+#undef PAMG_GRAN
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int gran_xcd_launch(int epi, int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a, int nblk,
+                           unsigned *ticket)
+{
+#define PAMG_GRANX(E)                                                                                                 \
+    if (npl == 2) hipLaunchKernelGGL((gs_gran_xcd_kernel<T, E, 2>), dim3(grid), dim3(BLK), lds, s, a, nblk, ticket);  \
+    else hipLaunchKernelGGL((gs_gran_xcd_kernel<T, E, 1>), dim3(grid), dim3(BLK), lds, s, a, nblk, ticket);
+    switch (epi) {
+        case EPI_GS: PAMG_GRANX(EPI_GS) break;
+        case EPI_GS_B: PAMG_GRANX(EPI_GS_B) break;
+        case EPI_SOR: PAMG_GRANX(EPI_SOR) break;
+        default: return PAMG_E_ARG;
+    }
+#undef PAMG_GRANX
+    return (int)hipGetLastError();
+}
+
 template <typename T, int EPI>
 static int flow_launch(int npl, int grid, int lds, hipStream_t s, const FlowArgs<T> &f)
 {
@@ -322,6 +441,25 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
     a.rid = g->d_rid;
     a.diag = (const T *)g->d_diag;
     const int lds = lds_bytes(A->dtype, epi, A->cap);
+    if (A->gs_mode == 1 && g->symmetric && g->d_xs && lds <= 48 * 1024 && g->nlevels > 1) {
+        // granular sync-free sweep: sentinel fill + ONE persistent launch
+        a.blkmeta = g->d_blkmeta;
+        a.xs = (T *)g->d_xs;
+        a.err = g->d_sync + 1;
+        const int64_t n = A->nrows;
+        const int fgrid = (int)std::min<int64_t>(4096, (n + BLK - 1) / BLK);
+        hipLaunchKernelGGL((fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)g->d_xs, n);
+        PAMG_HIP(hipGetLastError());
+        int G = std::max(1, std::min(g->nblk_total, gran_grid<T>(epi, A->npl, lds)));
+        if (A->gran_cap > 0) G = std::min(G, A->gran_cap);
+        if (A->gran_xcd) {
+            // single-XCD variant: full co-resident grid, only the workgroups on XCD 0 take part
+            PAMG_HIP(hipMemsetAsync(g->d_sync + 2, 0, sizeof(unsigned), s));
+            const int Gx = gran_grid<T>(epi, A->npl, lds + 64);
+            return gran_xcd_launch<T>(epi, A->npl, Gx, lds, s, a, g->nblk_total, g->d_sync + 2);
+        }
+        return gran_launch<T>(epi, A->npl, G, lds, s, a, g->nblk_total);
+    }
     const bool flow = lds <= 48 * 1024 && g->nlevels > 1 &&
                       (A->flow_force ? A->flow_cap > 0 : g->max_level_blocks <= A->flow_cap);
     if (flow) {
@@ -588,6 +726,9 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 2: if (value < 1) return PAMG_E_ARG; A->max_rows = value; break;
         case 3: if (value < 0 || value > 256) return PAMG_E_ARG; A->flow_cap = value; return PAMG_OK;
         case 4: A->flow_force = value != 0; return PAMG_OK;
+        case 5: if (value != 0 && value != 1) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
+        case 6: if (value < 0) return PAMG_E_ARG; A->gran_cap = value; return PAMG_OK;
+        case 7: A->gran_xcd = value != 0; return PAMG_OK;
         default: return PAMG_E_ARG;
     }
     for (int k = 0; k < 4; ++k) { if (A->gs[k]) A->bytes -= A->gs[k]->bytes; free_schedule(A->gs[k]); A->gs[k] = nullptr; }

@@ -94,6 +94,18 @@ def make_hierarchies():
     np.random.seed(SEED)
     gs = ("gauss_seidel", {"sweep": "symmetric"})
     hier("el2d_pointgs", pyamg.smoothed_aggregation_solver(E, B=B, max_coarse=10, presmoother=gs, postsmoother=gs))
+    # BASELINE config 5 in miniature: 3-D elasticity, BSR(3,3) -> (6,6), P blocks (3,6)/(6,6)
+    from tools.problems import elasticity3d
+    E3, B3 = elasticity3d(7)
+    np.random.seed(SEED)
+    hier("el3d_blockgs", pyamg.smoothed_aggregation_solver(E3, B=B3, smooth="jacobi", max_coarse=10), k=6)
+    np.random.seed(SEED)
+    hier("el3d_blockjacobi", pyamg.smoothed_aggregation_solver(E3, B=B3, smooth="jacobi", max_coarse=10,
+                                                               presmoother="block_jacobi",
+                                                               postsmoother="block_jacobi"), k=6)
+    np.random.seed(SEED)
+    hier("el3d_jacobi", pyamg.smoothed_aggregation_solver(E3, B=B3, smooth="jacobi", max_coarse=10,
+                                                          presmoother="jacobi", postsmoother="jacobi"), k=6)
     # hand-built two-level hierarchy with a CSC restriction (multilevel.py:180-182)
     np.random.seed(SEED)
     ml0 = pyamg.ruge_stuben_solver(A, max_coarse=500, max_levels=2)
@@ -240,6 +252,7 @@ def make_known_answers():
 
 
 if __name__ == "__main__":
-    make_known_answers()
-    make_kernels()
+    if "--hier-only" not in sys.argv:
+        make_known_answers()
+        make_kernels()
     make_hierarchies()

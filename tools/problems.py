@@ -38,3 +38,51 @@ def spmv_bytes(A):
     n_rows, n_cols = A.shape
     vb = A.dtype.itemsize
     return (vb + 4) * A.nnz + 4 * (n_rows + 1) + vb * n_cols + vb * n_rows
+
+
+def cube_tet_mesh(N):
+    """Structured tetrahedral mesh of the unit cube: N^3 vertices, every hexahedral cell split
+    into 6 tets (Kuhn triangulation).  Input for the reference's gallery.linear_elasticity_p1
+    (BASELINE config 5: the reference ships no 3-D mesher, pyamg/gallery/elasticity.py:53-56)."""
+    g = np.linspace(0.0, 1.0, N)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    V = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    idx = np.arange(N ** 3).reshape(N, N, N)
+    c = idx[:-1, :-1, :-1].ravel()
+    dx, dy, dz = N * N, N, 1
+    corners = {(0, 0, 0): c, (1, 0, 0): c + dx, (0, 1, 0): c + dy, (0, 0, 1): c + dz, (1, 1, 0): c + dx + dy,
+               (1, 0, 1): c + dx + dz, (0, 1, 1): c + dy + dz, (1, 1, 1): c + dx + dy + dz}
+    import itertools
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        p = [(0, 0, 0)]
+        cur = [0, 0, 0]
+        for ax in perm:
+            cur[ax] = 1
+            p.append(tuple(cur))
+        tets.append(np.stack([corners[q] for q in p], axis=1))
+    T = np.concatenate(tets, axis=0)
+    # consistent (positive) orientation
+    d = V[T[:, 1:]] - V[T[:, :1]]
+    neg = np.linalg.det(d) < 0
+    T[neg, 2], T[neg, 3] = T[neg, 3].copy(), T[neg, 2].copy()
+    return V, T
+
+
+def elasticity3d(N):
+    """3-D linear elasticity (P1 tets) on an N^3-vertex cube, clamped on the face x = 0:
+    returns (A as BSR(3,3) with int32 indices, B rigid-body modes).  Needs the reference
+    (oracle/_ref) for the element assembly."""
+    import pyamg
+    V, E = cube_tet_mesh(N)
+    A, B = pyamg.gallery.linear_elasticity_p1(V, E, format="csr")
+    free = np.repeat(V[:, 0] > 0.0, 3)
+    keep = np.flatnonzero(free)
+    A = sp.csr_array(A[keep][:, keep])
+    B = B[keep]
+    A.indptr = A.indptr.astype(np.int32)
+    A.indices = A.indices.astype(np.int32)
+    Ab = A.tobsr(blocksize=(3, 3))
+    Ab.indptr = Ab.indptr.astype(np.int32)
+    Ab.indices = Ab.indices.astype(np.int32)
+    return Ab, B
