@@ -181,6 +181,7 @@ def main():
     #      on the solver's stream, algorithmic bytes of SURVEY.md 8(d)
     stream = dml.stream()
     A0 = dml.A[0]
+    dml.store_device(xd)                              # the current iterate: realistic (non-zero) operand data
     rd = capi.DeviceArray(n, np.float64)
     reps = 50
     for _ in range(5):

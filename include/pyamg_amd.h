@@ -183,14 +183,17 @@ int pamg_matrix_destroy(pamg_matrix_t A);
  * info[7]=bwd GS levels */
 int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
 /* tuning knobs for experiments: key 0 = lds entries per block, 1 = nnz per lane (1|2),
- * 2 = max rows per block (these three re-plan the operator); 3 = widest dependency level (in
- * row ranges) up to which an order-exact sweep runs as ONE persistent launch with in-kernel
- * barriers instead of one launch per level (0 = never, max 256); 4 = force the persistent
- * sweep for every schedule with grid = min(key 3, widest level); 5 = order-exact sweep mode:
+ * 2 = max rows per block (these three re-plan the operator); 3 = flow_cap: an order-exact sweep
+ * whose schedule averages <= flow_cap/16 row ranges per dependency level runs as ONE persistent
+ * single-workgroup launch instead of one launch per level (default 32, 0 = never, max 256);
+ * 4 = force the persistent sweep with grid = min(key 3, widest level) workgroups and an
+ * in-kernel barrier (experiments); 5 = order-exact sweep mode:
  * 0 (default) = level launches / barrier kernel, 1 = granular sync-free persistent sweep
  * (element-level hand-off, no barriers) when the swept pattern is structurally symmetric;
  * 6 = cap on the granular sweep's persistent grid (0 = auto); 7 = granular sweep restricted
- * to the workgroups that land on XCD 0 (hand-off through one L2). */
+ * to the workgroups that land on XCD 0 (hand-off through one L2); 8 = streaming flags of the
+ * whole-operator kernels: bit 0 non-temporal loads of the operator stream, bit 1 XCD-aware
+ * row-range order. */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* *error != 0: a persistent sweep of this operator hit its spin bound (synchronises) */
 int pamg_matrix_flow_error(pamg_matrix_t A, int *error);
@@ -278,6 +281,13 @@ int pamg_solver_cycle(pamg_solver_t S, void *x, const void *b, int cycle, int cy
 int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int maxiter,
                       int cycle, int cycles_per_level, int check_every, double *residuals,
                       int *n_iter, int *info, pamg_stream_t s);
+/* Preconditioned CG with the resident cycle as preconditioner, all vectors on the DEVICE
+ * (reference: pyamg/krylov/_cg.py:98-198, stopping criterion 'rr': ||r|| < tol*||b||, as driven
+ * by MultilevelSolver.solve(accel='cg'), multilevel.py:479-535).  x: in = initial guess, out =
+ * solution.  residuals: HOST array of maxiter+1 doubles or NULL.  *info: 0 converged, -1
+ * indefinite operator/preconditioner detected (as the reference), else the iteration count. */
+int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int cycle,
+                    int cycles_per_level, double *residuals, int *n_iter, int *info, pamg_stream_t s);
 /* Same iteration split in three so that callers (benchmarks, device-side Krylov drivers)
  * can run exactly k cycles on the resident state with no staging copies in between:
  * load copies DEVICE x, b into the solver's level-0 buffers; iterate runs k x (cycle +

@@ -64,6 +64,8 @@ struct StreamArgs {
     T c;                 // EPI_*AXPBY coefficient
     T omega;
     int cap;             // products staged in LDS per workgroup
+    int nblk;            // row ranges of this launch
+    int flags;           // bit 0: non-temporal operator stream, bit 1: XCD-aware range order
 };
 
 // One dependency-level schedule for an order-exact sweep (forward or backward, or a
@@ -106,8 +108,9 @@ struct pamg_matrix_s {
     std::vector<int> h_bAp, h_bAj;
     // plan for the streamed kernels
     int cap = 2048, npl = 1, max_rows = 1024;
-    int flow_cap = 32;               // persistent GS kernel when a schedule's widest level has <= this many row ranges
-    int flow_force = 0;              // != 0: persistent GS kernel always, grid = min(flow_cap, widest level)
+    int flow_cap = 32;               // single-workgroup persistent sweep when a schedule averages <= flow_cap/16 row ranges per level
+    int flow_force = 0;              // != 0: persistent barrier kernel always, grid = min(flow_cap, widest level)
+    int stream_flags = 0;            // StreamArgs::flags for the whole-operator launches
     int gran_xcd = 0;                // granular sweep restricted to the workgroups that land on XCD 0
     int gran_cap = 0;                // granular sweep: cap on the persistent grid (0 = auto)
     int gs_mode = 0;                 // 0: level launches / barrier kernel (default); 1: granular sync-free sweep when the pattern allows
@@ -128,6 +131,8 @@ int reduce_partials(const double *partial, int n, double *out, hipStream_t s);
 int vec_sumsq(int dtype, int64_t n, const void *x, double *scratch, double *out, hipStream_t s);
 int vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
 int vec_scale(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
+int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch, double *out, hipStream_t s);
+int vec_xpby(int dtype, int64_t n, double beta, const void *z, void *p, hipStream_t s);
 int dense_gemv(int dtype, int n, const void *M, const void *b, void *x, hipStream_t s);
 int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, int row_start,
                    int row_stop, int row_step, hipStream_t s);

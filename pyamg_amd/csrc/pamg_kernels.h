@@ -147,10 +147,21 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
         // LDS stores.  base is even, so every pair is naturally aligned; the operator's
         // arrays are padded so the pair straddling p1 stays inside the allocation.
         using T2 = typename Vec2<T>::type;
+        typedef int int2n __attribute__((ext_vector_type(2)));
+        typedef T T2n __attribute__((ext_vector_type(2)));
+        const bool nt = (a.flags & 1) != 0;               // stream the operator past the caches
 #pragma unroll 2
         for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
-            int2 cc = *reinterpret_cast<const int2 *>(a.Aj + q);
-            const T2 vv = *reinterpret_cast<const T2 *>(a.Ax + q);
+            int2 cc;
+            T2 vv;
+            if (nt) {
+                const int2n c2 = __builtin_nontemporal_load(reinterpret_cast<const int2n *>(a.Aj + q));
+                const T2n v2 = __builtin_nontemporal_load(reinterpret_cast<const T2n *>(a.Ax + q));
+                cc.x = c2.x; cc.y = c2.y; vv.x = v2.x; vv.y = v2.y;
+            } else {
+                cc = *reinterpret_cast<const int2 *>(a.Aj + q);
+                vv = *reinterpret_cast<const T2 *>(a.Ax + q);
+            }
             const bool ok0 = q >= p0, ok1 = q + 1 < p1;
             const T x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
             const T x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
@@ -324,11 +335,19 @@ __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double sq = 0.0;
-    stream_block<T, EPI, NPL, 0>(a, a.blkmeta[blockIdx.x], smem_raw, sq);
+    int blk = (int)blockIdx.x;
+    if (a.flags & 2) {
+        // XCD-aware order: workgroup b is observed to run on XCD b % 8; give each XCD a
+        // contiguous chunk of row ranges so neighbouring ranges (which share x) share an L2.
+        // Speed only -- any placement computes the same thing.
+        const int chunk = (a.nblk + 7) >> 3;
+        blk = (blk & 7) * chunk + (blk >> 3);
+    }
+    if (blk < a.nblk) stream_block<T, EPI, NPL, 0>(a, a.blkmeta[blk], smem_raw, sq);
     if constexpr (EPI == EPI_SUMSQ) {
         __syncthreads();                                   // LDS reuse for the reduction
         const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
-        if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
+        if (threadIdx.x == 0 && blk < a.nblk) a.partial[blk] = tot;
     }
 }
 
@@ -461,6 +480,15 @@ __global__ __launch_bounds__(BLK) void reduce_final_kernel(const double *partial
     if (threadIdx.x == 0) out[0] = tot;
 }
 
+__global__ __launch_bounds__(BLK) void reduce_mid_kernel(const double *partial, int n, double *mid)
+{
+    __shared__ double sm[BLK / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) acc += partial[i];
+    const double tot = block_sum(acc, sm);
+    if (threadIdx.x == 0) mid[blockIdx.x] = tot;
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLK) void vec_axpy_kernel(int64_t n, T a, const T *x, T *y)
 {
@@ -482,6 +510,27 @@ __global__ __launch_bounds__(BLK) void vec_gather_kernel(int64_t n, const int *i
 {
     for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK)
         dst[i] = src[idx[i]];
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_dot_kernel(const T *x, const T *y, int64_t n, double *partial)
+{
+    __shared__ double sm[BLK / 64];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK)
+        acc += (double)x[i] * (double)y[i];
+    const double tot = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// p = beta*p + z   (the reference's `p *= beta; p += z`, krylov/_cg.py:167-168)
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_xpby_kernel(int64_t n, T beta, const T *z, T *p)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
+        const T t = p[i] * beta;
+        p[i] = t + z[i];
+    }
 }
 
 // x = M b, dense row-major n x n (coarsest-level solve, multilevel.py:717-721): one wave

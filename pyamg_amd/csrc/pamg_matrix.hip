@@ -102,7 +102,7 @@ int replan(pamg_matrix_s *A)
     plan_rows(A->h_Ap.data(), 0, (int)A->nrows, A->cap, A->max_rows, blk);
     A->nblk = (int)blk.size();
     PAMG_TRY(upload(&A->d_blkmeta, blk.data(), blk.size(), nullptr));
-    PAMG_HIP(hipMalloc((void **)&A->d_partial, sizeof(double) * (size_t)(A->nblk + 8)));
+    PAMG_HIP(hipMalloc((void **)&A->d_partial, sizeof(double) * (size_t)(A->nblk + 264)));
     return PAMG_OK;
 }
 
@@ -336,6 +336,8 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.c = (T)c;
     a.omega = (T)omega;
     a.cap = A->cap;
+    a.nblk = A->nblk;
+    a.flags = 0;
     return a;
 }
 
@@ -350,11 +352,15 @@ int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void 
                   double omega, double *partial, hipStream_t s)
 {
     const int lds = lds_bytes(A->dtype, epi, A->cap);
-    if (A->dtype == PAMG_F64)
-        return launch_any<double>(epi, A->npl, A->nblk, lds, s,
-                                  base_args<double>(A, x, b, y, c, omega, partial));
-    return launch_any<float>(epi, A->npl, A->nblk, lds, s,
-                             base_args<float>(A, x, b, y, c, omega, partial));
+    const int grid = (A->stream_flags & 2) ? 8 * ((A->nblk + 7) / 8) : A->nblk;
+    if (A->dtype == PAMG_F64) {
+        StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
+        a.flags = A->stream_flags;
+        return launch_any<double>(epi, A->npl, grid, lds, s, a);
+    }
+    StreamArgs<float> a = base_args<float>(A, x, b, y, c, omega, partial);
+    a.flags = A->stream_flags;
+    return launch_any<float>(epi, A->npl, grid, lds, s, a);
 }
 
 template <typename T, int EPI, int NPL>
@@ -460,19 +466,23 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
         }
         return gran_launch<T>(epi, A->npl, G, lds, s, a, g->nblk_total);
     }
-    const bool flow = lds <= 48 * 1024 && g->nlevels > 1 &&
-                      (A->flow_force ? A->flow_cap > 0 : g->max_level_blocks <= A->flow_cap);
+    // Scheduling policy (measured, profiles/r01_microbench_gs_*.json): a kernel boundary costs
+    // ~5-8 us per level, the in-kernel barrier between several workgroups about the same, but ONE
+    // workgroup walking the levels with __syncthreads() and ordinary cached accesses ~2-3.5 us per
+    // row range.  So: narrow schedules (<= flow_cap/16 row ranges per level on average, default 2)
+    // run as a single-workgroup persistent sweep, everything else as one launch per level.
+    const bool narrow = (int64_t)g->nblk_total * 16 <= (int64_t)g->nlevels * A->flow_cap;
+    const bool flow = lds <= 48 * 1024 && g->nlevels > 1 && A->flow_cap > 0 && (A->flow_force || narrow);
     if (flow) {
-        // persistent sweep: one launch, levels separated by an in-kernel barrier.  Grid <= 256
-        // workgroups of 256 threads is always co-resident on the 256 CUs (nothing else runs on
-        // this stream-ordered device while the sweep is in flight).
         FlowArgs<T> f;
         f.s = a;
         f.s.blkmeta = g->d_blkmeta;
         f.level_blk = g->d_level_blk;
         f.nlevels = g->nlevels;
         f.sync = g->d_sync;
-        const int G = std::max(1, std::min(std::min(A->flow_cap, 256), g->max_level_blocks));
+        // forced mode (experiments): grid = min(flow_cap, widest level) co-resident workgroups with
+        // the in-kernel barrier; policy mode: one workgroup
+        const int G = A->flow_force ? std::max(1, std::min(std::min(A->flow_cap, 256), g->max_level_blocks)) : 1;
         PAMG_HIP(hipMemsetAsync(g->d_sync, 0, sizeof(unsigned), s));
         switch (epi) {
             case EPI_GS: return flow_launch<T, EPI_GS>(A->npl, G, lds, s, f);
@@ -483,7 +493,8 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
     }
     for (int l = 0; l < g->nlevels; ++l) {
         a.blkmeta = g->d_blkmeta + g->level_blk[l];
-        PAMG_TRY(launch_any<T>(epi, A->npl, g->level_blk[l + 1] - g->level_blk[l], lds, s, a));
+        a.nblk = g->level_blk[l + 1] - g->level_blk[l];
+        PAMG_TRY(launch_any<T>(epi, A->npl, a.nblk, lds, s, a));
     }
     return PAMG_OK;
 }
@@ -560,9 +571,18 @@ int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step)
     return get_schedule(A, row_start, row_stop, row_step, &g);
 }
 
+// deterministic sum of n partials -> out[0].  Large n goes through 256 intermediate sums
+// stored behind the partials (callers allocate n + 264 doubles) so the tail is not one
+// workgroup crawling over tens of thousands of values.
 int reduce_partials(const double *partial, int n, double *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(BLK), 0, s, partial, n, out);
+    if (n > 8192) {
+        double *mid = const_cast<double *>(partial) + n;
+        hipLaunchKernelGGL(reduce_mid_kernel, dim3(256), dim3(BLK), 0, s, partial, n, mid);
+        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(BLK), 0, s, (const double *)mid, 256, out);
+    } else {
+        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(BLK), 0, s, partial, n, out);
+    }
     return (int)hipGetLastError();
 }
 
@@ -575,6 +595,18 @@ int vec_sumsq(int dtype, int64_t n, const void *x, double *scratch, double *out,
         hipLaunchKernelGGL((vec_sumsq_kernel<float>), dim3(grid), dim3(BLK), 0, s, (const float *)x, n, scratch);
     PAMG_HIP(hipGetLastError());
     return reduce_partials(scratch, grid, out, s);
+}
+
+int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch, double *out, hipStream_t s)
+{
+    const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + BLK - 1) / BLK));
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_dot_kernel<double>), dim3(grid), dim3(BLK), 0, s, (const double *)x, (const double *)y, n, scratch);
+    else
+        hipLaunchKernelGGL((vec_dot_kernel<float>), dim3(grid), dim3(BLK), 0, s, (const float *)x, (const float *)y, n, scratch);
+    PAMG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(BLK), 0, s, (const double *)scratch, grid, out);
+    return (int)hipGetLastError();
 }
 
 static int vgrid(int64_t n) { return (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + BLK - 1) / BLK)); }
@@ -596,6 +628,16 @@ int vec_scale(int dtype, int64_t n, double a, const void *x, void *y, hipStream_
         hipLaunchKernelGGL((vec_scale_kernel<double>), dim3(vgrid(n)), dim3(BLK), 0, s, n, a, (const double *)x, (double *)y);
     else
         hipLaunchKernelGGL((vec_scale_kernel<float>), dim3(vgrid(n)), dim3(BLK), 0, s, n, (float)a, (const float *)x, (float *)y);
+    return (int)hipGetLastError();
+}
+
+int vec_xpby(int dtype, int64_t n, double beta, const void *z, void *p, hipStream_t s)
+{
+    if (n <= 0) return PAMG_OK;
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_xpby_kernel<double>), dim3(vgrid(n)), dim3(BLK), 0, s, n, beta, (const double *)z, (double *)p);
+    else
+        hipLaunchKernelGGL((vec_xpby_kernel<float>), dim3(vgrid(n)), dim3(BLK), 0, s, n, (float)beta, (const float *)z, (float *)p);
     return (int)hipGetLastError();
 }
 
@@ -683,8 +725,9 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
             if (!st) st = upload_raw(&A->d_bAx, Ax, (size_t)A->nnz, ts, &A->bytes);
         }
     }
-    // default plan: ~24 KB of LDS per workgroup for the smoother flavours -> 6 workgroups/CU
-    A->cap = 2048; A->npl = 2; A->max_rows = 1024;
+    // default plan (measured best on 256^3 Poisson): 1536 staged entries = 12 KB (SpMV) / 18 KB
+    // (smoothers, with column ids) of LDS per workgroup -> 8 workgroups = 32 waves per CU
+    A->cap = 1536; A->npl = 2; A->max_rows = 1024;
     if (!st) st = replan(A);
     if (st) { pamg_matrix_destroy(A); return st; }
     *out = A;
@@ -729,6 +772,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 5: if (value != 0 && value != 1) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
         case 6: if (value < 0) return PAMG_E_ARG; A->gran_cap = value; return PAMG_OK;
         case 7: A->gran_xcd = value != 0; return PAMG_OK;
+        case 8: if (value < 0 || value > 3) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;
         default: return PAMG_E_ARG;
     }
     for (int k = 0; k < 4; ++k) { if (A->gs[k]) A->bytes -= A->gs[k]->bytes; free_schedule(A->gs[k]); A->gs[k] = nullptr; }

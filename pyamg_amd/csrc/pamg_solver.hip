@@ -163,6 +163,7 @@ struct pamg_solver_s {
     int norms_cap = 0;
     double *d_slot = nullptr;     // 4 doubles: [0] current ||r||^2, [1] ||b||^2
     double *d_scratch = nullptr;  // 1032 doubles for vector reductions
+    void *cg_r = nullptr, *cg_z = nullptr, *cg_p = nullptr, *cg_q = nullptr;   // device PCG work vectors
     std::map<int, hipGraphExec_t> graphs;   // key = cycle*1024 + cycles_per_level
     size_t bytes = 0;
 };
@@ -227,28 +228,29 @@ int cycle_rec(pamg_solver_s *S, int lvl, int type, int cpl, bool x_zero, hipStre
     return PAMG_OK;
 }
 
-// one full cycle on the internal level-0 buffers followed by ||b - A x||^2 -> d_slot[0]
-int enqueue_cycle(pamg_solver_s *S, int type, int cpl, hipStream_t s)
+// one full cycle on the internal level-0 buffers, optionally followed by ||b - A x||^2 -> d_slot[0]
+int enqueue_cycle(pamg_solver_s *S, int type, int cpl, bool check, bool x_zero, hipStream_t s)
 {
     Level &L0 = S->levels[0];
     if (S->levels.size() == 1) {
         PAMG_TRY(coarse_solve(S, L0.b, L0.x, s));                  // multilevel.py:559-561
     } else {
-        PAMG_TRY(cycle_rec(S, 0, type, cpl, false, s));
+        PAMG_TRY(cycle_rec(S, 0, type, cpl, x_zero, s));
     }
+    if (!check) return PAMG_OK;
     PAMG_TRY(stream_launch(L0.A, EPI_SUMSQ, L0.x, L0.b, nullptr, 0.0, 0.0, L0.A->d_partial, s));
     return reduce_partials(L0.A->d_partial, L0.A->nblk, S->d_slot, s);
 }
 
-int run_cycle(pamg_solver_s *S, int type, int cpl, hipStream_t s)
+int run_cycle(pamg_solver_s *S, int type, int cpl, hipStream_t s, bool check = true, bool x_zero = false)
 {
-    if (!S->use_graph) return enqueue_cycle(S, type, cpl, s);
-    const int key = type * 1024 + cpl;
+    if (!S->use_graph) return enqueue_cycle(S, type, cpl, check, x_zero, s);
+    const int key = ((type * 1024 + cpl) * 2 + (check ? 1 : 0)) * 2 + (x_zero ? 1 : 0);
     auto it = S->graphs.find(key);
     if (it == S->graphs.end()) {
         hipGraph_t g = nullptr;
         PAMG_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        const int st = enqueue_cycle(S, type, cpl, s);
+        const int st = enqueue_cycle(S, type, cpl, check, x_zero, s);
         const hipError_t e = hipStreamEndCapture(s, &g);
         if (st != PAMG_OK) { if (g) hipGraphDestroy(g); return st; }
         if (e != hipSuccess) return (int)e;
@@ -372,6 +374,7 @@ int pamg_solver_destroy(pamg_solver_t S)
         hipFree(L.pre.d_Dinv); hipFree(L.post.d_Dinv);
     }
     hipFree(S->d_coarse); hipFree(S->d_norms); hipFree(S->d_slot); hipFree(S->d_scratch);
+    hipFree(S->cg_r); hipFree(S->cg_z); hipFree(S->cg_p); hipFree(S->cg_q);
     if (S->own_stream) hipStreamDestroy(S->own_stream);
     delete S;
     return PAMG_OK;
@@ -601,6 +604,83 @@ int pamg_solver_stream(pamg_solver_t S, pamg_stream_t *s)
     if (!S || !s) return PAMG_E_ARG;
     if (!S->finalized) return PAMG_E_STATE;
     *s = (pamg_stream_t)S->own_stream;
+    return PAMG_OK;
+}
+
+// Preconditioned conjugate gradients with the resident cycle as preconditioner, entirely on
+// the device (reference: pyamg/krylov/_cg.py:98-198 with criteria 'rr', driven by
+// MultilevelSolver.solve(accel='cg'), multilevel.py:479-535).  z = M r is exactly one cycle
+// from a zero initial guess (multilevel.py:390-396) without the two wasted fine-level
+// residual norms of the reference's matvec.  Only the scalars cross PCIe.
+int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int cycle,
+                    int cycles_per_level, double *residuals, int *n_iter, int *info, pamg_stream_t s_)
+{
+    if (!S || !x || !b || maxiter < 1) return PAMG_E_ARG;
+    if (!S->finalized) return PAMG_E_STATE;
+    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
+    hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));
+    Level &L0 = S->levels[0];
+    const int64_t n = L0.n;
+    const int dt = S->dtype;
+    const size_t vb = (size_t)n * tsize(dt);
+    if (!S->cg_r) {
+        PAMG_TRY(dalloc(S, &S->cg_r, vb)); PAMG_TRY(dalloc(S, &S->cg_z, vb));
+        PAMG_TRY(dalloc(S, &S->cg_p, vb)); PAMG_TRY(dalloc(S, &S->cg_q, vb));
+    }
+    void *r = S->cg_r, *z = S->cg_z, *p = S->cg_p, *q = S->cg_q;
+    double *slot = S->d_slot;                    // [0] cycle's norm slot (unused here), [1..3] scalars
+    double h[3];
+    auto precond = [&]() -> int {                // z = M r
+        PAMG_HIP(hipMemcpyAsync(L0.b, r, vb, hipMemcpyDeviceToDevice, s));
+        PAMG_HIP(hipMemsetAsync(L0.x, 0, vb, s));
+        PAMG_TRY(run_cycle(S, cycle, cycles_per_level, s, false, true));
+        return (int)hipMemcpyAsync(z, L0.x, vb, hipMemcpyDeviceToDevice, s);
+    };
+    auto fetch = [&](int k) -> int {             // h[0..k) <- slot[1..1+k)
+        PAMG_HIP(hipMemcpyAsync(h, slot + 1, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
+        return (int)hipStreamSynchronize(s);
+    };
+    // setup (_cg.py:98-112)
+    PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));            // r = b - A x
+    PAMG_TRY(precond());
+    PAMG_HIP(hipMemcpyAsync(p, z, vb, hipMemcpyDeviceToDevice, s));
+    PAMG_TRY(vec_dot(dt, n, r, z, S->d_scratch, slot + 1, s));                           // rz
+    PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 2, s));                            // ||r||^2
+    PAMG_TRY(vec_sumsq(dt, n, b, S->d_scratch, slot + 3, s));                            // ||b||^2
+    PAMG_TRY(fetch(3));
+    double rz = h[0], normr = std::sqrt(h[1]), normb = std::sqrt(h[2]);
+    if (normb == 0.0) normb = 1.0;
+    if (residuals) residuals[0] = normr;
+    const double rtol = tol * normb;
+    int it = 0, inf = -2;
+    if (normr < rtol) inf = 0;
+    while (inf == -2) {
+        PAMG_TRY(stream_launch(L0.A, EPI_SET, p, nullptr, q, 0.0, 0.0, nullptr, s));     // Ap
+        PAMG_TRY(vec_dot(dt, n, q, p, S->d_scratch, slot + 1, s));                       // pAp
+        PAMG_TRY(fetch(1));
+        const double pAp = h[0];
+        if (pAp < 0.0) { inf = -1; break; }                                              // indefinite A
+        const double rz_old = rz, alpha = rz / pAp;
+        PAMG_TRY(vec_axpy(dt, n, alpha, p, x, s));                                       // x += alpha p
+        if ((it % 8) != 0 && it > 0) PAMG_TRY(vec_axpy(dt, n, -alpha, q, r, s));        // r -= alpha Ap
+        else PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));    // r = b - A x (every 8th)
+        PAMG_TRY(precond());
+        PAMG_TRY(vec_dot(dt, n, r, z, S->d_scratch, slot + 1, s));
+        PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 2, s));
+        PAMG_TRY(fetch(2));
+        rz = h[0];
+        if (rz < 0.0) { inf = -1; break; }                                               // indefinite M
+        PAMG_TRY(vec_xpby(dt, n, rz / rz_old, z, p, s));                                 // p = beta p + z
+        ++it;
+        normr = std::sqrt(h[1]);
+        if (residuals) residuals[it] = normr;
+        if (normr < rtol) inf = 0;
+        else if (it == maxiter) inf = it;
+    }
+    PAMG_HIP(hipStreamSynchronize(s));
+    if (n_iter) *n_iter = it;
+    if (info) *info = inf;
     return PAMG_OK;
 }
 

@@ -59,9 +59,9 @@ class DeviceMatrix:
         capi.check(capi.lib().pamg_matrix_flow_error(self.handle, C.byref(e)), "pamg_matrix_flow_error")
         return bool(e.value)
 
-    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, flow_force=None, gs_mode=None, gran_cap=None, gran_xcd=None):
+    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, flow_force=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None):
         lib = capi.lib()
-        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (4, flow_force), (5, gs_mode), (6, gran_cap), (7, gran_xcd)):
+        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (4, flow_force), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 
@@ -278,8 +278,36 @@ class DeviceMultilevelSolver:
             residuals[:] = hist
         return (xh, info) if return_info else xh
 
+    def pcg_device(self, xd, bd, tol=1e-5, maxiter=100, cycle="V", cycles_per_level=1, stream=None):
+        """Device-resident preconditioned CG (krylov/_cg.py, criteria 'rr') on DEVICE vectors;
+        returns (residuals, n_iter, info)."""
+        res = np.zeros(int(maxiter) + 1, dtype=np.float64)
+        nit, info = C.c_int(0), C.c_int(0)
+        capi.check(capi.lib().pamg_solver_pcg(self.handle, xd.ptr, bd.ptr, float(tol), int(maxiter), capi.CYCLE[cycle],
+                                              int(cycles_per_level), capi.ptr(res), C.byref(nit), C.byref(info), stream),
+                   "pamg_solver_pcg")
+        return res[: nit.value + 1], nit.value, info.value
+
     def _solve_accel(self, b, x0, tol, maxiter, cycle, accel, callback, residuals, return_info):
-        """multilevel.py:479-535: host Krylov method around the device preconditioner."""
+        """multilevel.py:479-535.  accel='cg' without a callback runs entirely on the device
+        (``pamg_solver_pcg``); every other accelerator is the host Krylov method of the
+        reference / SciPy around the device preconditioner."""
+        if accel == "cg" and not self.symmetric_smoothing and self.ml is not None:
+            from warnings import warn
+            warn("Incompatible non-symmetric multigrid preconditioner detected, due to presmoother/postsmoother "
+                 "combination. CG requires SPD preconditioner, not just SPD matrix.")
+        if accel == "cg" and callback is None and np.result_type(b.dtype, self.dtype) == self.dtype:
+            x = np.zeros(self.shape[0], dtype=self.dtype) if x0 is None else np.ravel(np.array(x0)).astype(self.dtype)
+            self._bd.upload(np.ravel(b).astype(self.dtype, copy=False))
+            self._xd.upload(x)
+            res, nit, info = self.pcg_device(self._xd, self._bd, tol, maxiter, cycle)
+            if info == -1:
+                from warnings import warn
+                warn("\nIndefinite matrix or preconditioner detected in CG, aborting\n")
+            if residuals is not None:
+                residuals[:] = list(res)
+            out = self._xd.download()
+            return (out, info) if return_info else out
         import scipy.sparse.linalg as sla
         A = self.spec.levels[0].A.to_scipy()
         kwargs = {}

@@ -273,3 +273,52 @@ def test_relaxation_module_contract():
     x2 = np.zeros((10, 1)); grelax.gauss_seidel(A, x2, np.ones((10, 1)))
     x1 = np.zeros(10); grelax.gauss_seidel(A, x1, b)
     assert np.array_equal(x2.ravel(), x1) and x1.any()
+
+
+def test_gs_sweep_modes_all_exact():
+    """Every scheduling mode of the order-exact sweep (one launch per level, persistent barrier
+    kernel, granular sync-free kernel, its single-XCD variant) gives the reference's bits."""
+    from oracle import oracle as orc
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(3)
+    A3 = poisson_csr((24, 20, 22))
+    S = sp.random(4000, 4000, density=0.004, random_state=rng, format="csr")
+    S = sp.csr_array(S + S.T + sp.diags_array(rng.rand(4000) + 4.0))
+    S.sort_indices()
+    for M in (A3, S, sp.csr_array(A3.tobsr(blocksize=(1, 1)))):
+        op = sparse_op(M if M.format == "csr" else M)
+        if M is not A3 and M is not S:
+            op = sparse_op(A3.tobsr(blocksize=(1, 1)))          # BSR(1,1) flavour
+        n = op.shape[0]
+        x = rng.rand(n); b = rng.rand(n)
+        ref = x.copy(); orc.relax_gauss_seidel(op, ref, b, 2, "symmetric")
+        refs = x.copy(); orc.relax_sor(op, refs, b, 1.4, 1, "forward")
+        dA = DeviceMatrix(op)
+        dA.tune(lds_entries=256)
+        db = capi.DeviceArray.from_host(b)
+        for kw in (dict(gs_mode=0, flow_cap=0, flow_force=0), dict(gs_mode=0, flow_cap=8, flow_force=1),
+                   dict(gs_mode=0, flow_cap=1, flow_force=1), dict(gs_mode=1, gran_xcd=0), dict(gs_mode=1, gran_xcd=1),
+                   dict(gs_mode=1, gran_xcd=0, gran_cap=3)):
+            dA.tune(**kw)
+            dx = capi.DeviceArray.from_host(x)
+            dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+            assert np.array_equal(dx.download(), ref), kw
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="forward", omega=1.4)
+            assert np.array_equal(dx.download(), refs), kw
+            assert not dA.flow_error(), kw
+
+
+def test_resid_sumsq_two_stage_reduction():
+    from tools.problems import poisson_csr
+    A = poisson_csr((400, 400))
+    dA = DeviceMatrix(sparse_op(A))
+    dA.tune(lds_entries=64)
+    assert dA.info()["row_blocks"] > 8192
+    rng = np.random.RandomState(5)
+    x = rng.rand(A.shape[0]); b = rng.rand(A.shape[0])
+    dx, db = _dev(x, b)
+    out = capi.DeviceArray(1, np.float64)
+    dA.resid_sumsq(dx, db, out)
+    r = b - A @ x
+    assert np.isclose(out.download()[0], np.dot(r, r), rtol=1e-13)

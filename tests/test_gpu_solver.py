@@ -117,3 +117,58 @@ def test_with_live_reference_if_available():
         dml.solve(b, x0=x0, tol=1e-30, maxiter=10, residuals=r_gpu)
         r_ref, r_gpu = np.array(r_ref), np.array(r_gpu)
         assert np.max(np.abs(r_gpu - r_ref) / r_ref) <= 1e-10
+
+
+def _reference_pcg(A, b, M, tol, maxiter):
+    """NumPy restatement of pyamg/krylov/_cg.py:98-198 (criteria 'rr') for the test."""
+    x = np.zeros_like(b)
+    r = b - A @ x
+    z = M(r)
+    p = z.copy()
+    rz = np.inner(r, z)
+    res = [np.linalg.norm(r)]
+    normb = np.linalg.norm(b) or 1.0
+    it = 0
+    while True:
+        Ap = A @ p
+        rz_old = rz
+        alpha = rz / np.inner(Ap, p)
+        x += alpha * p
+        if np.mod(it, 8) and it > 0:
+            r -= alpha * Ap
+        else:
+            r = b - A @ x
+        z = M(r)
+        rz = np.inner(r, z)
+        p *= rz / rz_old
+        p += z
+        it += 1
+        res.append(np.linalg.norm(r))
+        if res[-1] < tol * normb or it == maxiter:
+            return x, res
+
+
+def test_device_pcg_matches_reference_algorithm(load_hier):
+    """solve(accel='cg') runs CG on the device; compare with the reference's algorithm driven by
+    the oracle's V-cycle as preconditioner (f64: 1e-9 relative on the first residual norms --
+    CG amplifies the last-bit differences of the dot products)."""
+    from oracle import oracle as orc
+    spec, ex = load_hier("sa2d_gs")
+    dml = DeviceMultilevelSolver(spec)
+    osol = orc.OracleSolver(spec)
+    A = spec.levels[0].A.to_scipy()
+    b = ex["b"]
+
+    def M(r):
+        return osol.solve(r, maxiter=1, tol=1e-12)
+
+    xo, ro = _reference_pcg(A, b, M, 1e-10, 12)
+    res = []
+    x, info = dml.solve(b, tol=1e-10, maxiter=12, accel="cg", residuals=res, return_info=True)
+    m = min(len(res), len(ro), 9)
+    assert np.max(np.abs(np.array(res[:m]) - np.array(ro[:m])) / np.array(ro[:m])) <= 1e-9
+    assert np.linalg.norm(b - A @ x) <= 1e-8 * np.linalg.norm(b)
+    # converged run: info == 0 and the last residual is below tol*||b||
+    res = []
+    x, info = dml.solve(b, tol=1e-8, maxiter=50, accel="cg", residuals=res, return_info=True)
+    assert info == 0 and res[-1] < 1e-8 * np.linalg.norm(b) <= res[-2]

@@ -71,15 +71,15 @@ def main():
     out["copy_GBps"] = 2 * (1 << 30) / ms / 1e6
     print(f"d2d copy 1 GiB: {ms:.3f} ms -> {out['copy_GBps']:.0f} GB/s (read+write)", flush=True)
     big.free(); big2.free()
-    configs = [(2048, 2)]
+    configs = [(2048, 2, 0)]
     if a.sweep:
-        configs = [(c, p) for p in (1, 2) for c in (768, 1024, 1536, 2048, 3072, 4096, 6144)]
+        configs = [(c, 2, f) for c in (1536, 2048, 3072) for f in (0, 1, 2, 3)]
     ref = A @ x
-    for cap, npl in configs:
-        dA.tune(lds_entries=cap, nnz_per_lane=npl)
+    for cap, npl, fl in configs:
+        dA.tune(lds_entries=cap, nnz_per_lane=npl, stream_flags=fl)
         dA.spmv(capi.SPMV_SET, dx, dy)
         ok = bool(np.array_equal(dy.download(), ref))
-        r = {"cap": cap, "npl": npl, "bit_exact": ok, "row_blocks": dA.info()["row_blocks"]}
+        r = {"cap": cap, "npl": npl, "flags": fl, "bit_exact": ok, "row_blocks": dA.info()["row_blocks"]}
         ms = timeit(lambda: dA.spmv(capi.SPMV_SET, dx, dy), a.reps)
         r["spmv_ms"] = ms; r["spmv_GBps"] = bytes_spmv / ms / 1e6
         ms = timeit(lambda: dA.spmv(capi.SPMV_RESID, dx, dy, b=db), a.reps)

@@ -28,6 +28,9 @@ for f in glob.glob(str(out / "trace" / "**" / "*kernel_trace.csv"), recursive=Tr
         for r in csv.DictReader(fh):
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             k = short(r["Kernel_Name"])
+            gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
+            if gs >= 256 * 4096:                            # big launches (fine level): keep them apart
+                k = f"{k} [grid {gs // 256} wg]"
             agg[k][0] += 1
             agg[k][1] += d
     tot = sum(v[1] for v in agg.values())
@@ -48,6 +51,9 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
                 if r.get("Counter_Name") != cname:
                     continue
                 k = short(r["Kernel_Name"])
+                gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
+                if gs >= 256 * 4096:
+                    k = f"{k} [grid {gs // 256} wg]"
                 agg[k][0] += 1
                 agg[k][1] += float(r["Counter_Value"])
         summary[cname] = {k: {"calls": c, "avg_value_KB": round(v / c, 1)} for k, (c, v) in
