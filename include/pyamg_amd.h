@@ -185,9 +185,9 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
 /* tuning knobs for experiments: key 0 = lds entries per block, 1 = nnz per lane (1|2),
  * 2 = max rows per block (these three re-plan the operator); 3 = flow_cap: an order-exact sweep
  * whose schedule averages <= flow_cap/16 row ranges per dependency level runs as ONE persistent
- * single-workgroup launch instead of one launch per level (default 32, 0 = never, max 256);
- * 4 = force the persistent sweep with grid = min(key 3, widest level) workgroups and an
- * in-kernel barrier (experiments); 5 = order-exact sweep mode:
+ * single-workgroup launch, wider ones as a persistent grid (widest level, <= 256 workgroups) with
+ * an in-kernel barrier (default 32; 0 = one launch per level always); 4 = force the persistent
+ * grid to min(key 3, widest level) workgroups (experiments); 5 = order-exact sweep mode:
  * 0 (default) = level launches / barrier kernel, 1 = granular sync-free persistent sweep
  * (element-level hand-off, no barriers) when the swept pattern is structurally symmetric;
  * 6 = cap on the granular sweep's persistent grid (0 = auto); 7 = granular sweep restricted

@@ -6,12 +6,13 @@ visible, every entry point raises (``DeviceUnavailable``).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libpyamg_amd.so"
+LIB_PATH = Path(os.environ.get("PAMG_LIB", PKG / "libpyamg_amd.so"))    # PAMG_LIB: experiment builds only
 
 OK = 0
 E_ARG, E_UNSUPPORTED, E_NODEVICE, E_STATE, E_ALLOC = -1, -2, -3, -4, -5

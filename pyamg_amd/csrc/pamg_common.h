@@ -24,7 +24,10 @@
 
 namespace pamg {
 
-constexpr int BLK = 256;           // threads per workgroup = 4 wave64
+#ifndef PAMG_BLK
+#define PAMG_BLK 256
+#endif
+constexpr int BLK = PAMG_BLK;      // threads per workgroup (256 = 4 wave64)
 constexpr int WAVE = 64;
 
 // epilogues of the LDS-streamed CSR kernel (what is done with a finished row sum)

@@ -142,6 +142,35 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
             prod[p - base] = v0 * gather_x<COH>(a, c0);
             if constexpr (NEEDC) cols[p - base] = c0 & COL_MASK;
         }
+    } else if constexpr (NPL == 4) {
+        // four consecutive entries per lane: one 16-byte index load, two 16-byte value loads.
+        // base is a multiple of 4, arrays are padded, out-of-range slots are masked.
+        using T2 = typename Vec2<T>::type;
+        for (int q = base + 4 * tid; q < p1; q += 4 * BLK) {
+            const int4 cc = *reinterpret_cast<const int4 *>(a.Aj + q);
+            const T2 va = *reinterpret_cast<const T2 *>(a.Ax + q);
+            const T2 vb = *reinterpret_cast<const T2 *>(a.Ax + q + 2);
+            const int c[4] = {cc.x, cc.y, cc.z, cc.w};
+            const T v[4] = {va.x, va.y, vb.x, vb.y};
+            T pr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = (q + j >= p0) && (q + j < p1);
+                T xv;
+                if (a.flags & 4) xv = T(c[j]);
+                else xv = ok ? gather_x<COH>(a, c[j]) : T(0);
+                pr[j] = v[j] * xv;
+            }
+            T2 o0, o1;
+            o0.x = pr[0]; o0.y = pr[1]; o1.x = pr[2]; o1.y = pr[3];
+            *reinterpret_cast<T2 *>(prod + (q - base)) = o0;
+            *reinterpret_cast<T2 *>(prod + (q - base) + 2) = o1;
+            if constexpr (NEEDC) {
+                int4 cm;
+                cm.x = c[0] & COL_MASK; cm.y = c[1] & COL_MASK; cm.z = c[2] & COL_MASK; cm.w = c[3] & COL_MASK;
+                *reinterpret_cast<int4 *>(cols + (q - base)) = cm;
+            }
+        }
     } else {
         // two consecutive entries per lane: 8-byte index loads, 16-byte value loads, 16-byte
         // LDS stores.  base is even, so every pair is naturally aligned; the operator's
@@ -163,8 +192,13 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
                 vv = *reinterpret_cast<const T2 *>(a.Ax + q);
             }
             const bool ok0 = q >= p0, ok1 = q + 1 < p1;
-            const T x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
-            const T x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
+            T x0, x1;
+            if (a.flags & 4) {                            // ablation: operator stream only, no gather
+                x0 = T(cc.x); x1 = T(cc.y);
+            } else {
+                x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
+                x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
+            }
             T2 pr;
             pr.x = vv.x * x0;
             pr.y = vv.y * x1;
@@ -296,16 +330,20 @@ __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 
     constexpr bool NEEDC = EpiTraits<EPI>::need_cols;
     const int cap = a.cap;
     T *prod = reinterpret_cast<T *>(smem_raw);
-    int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(cap + 2));
+    int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(cap + 8));
     const int tid = threadIdx.x;
     const int r0 = meta.x, r1 = meta.y, p0 = meta.z, p1 = meta.w;
     if (p1 - p0 <= cap) {
-        const int base = (NPL == 2) ? (p0 & ~1) : p0;
+        const int base = (NPL == 4) ? (p0 & ~3) : (NPL == 2) ? (p0 & ~1) : p0;
         int r = r0 + tid;
         RowPre<T> q;
         if (r < r1) q = row_prefetch<T, EPI, COH>(a, r);
         stage_products<T, NEEDC, NPL, COH>(a, p0, p1, base, prod, cols);
         __syncthreads();
+        if (a.flags & 8) {                                // ablation: no row phase
+            if (tid == 0) a.y[r0] = prod[0];
+            return;
+        }
         while (r < r1) {
             T s = row_init<T, EPI>(q);
             row_accumulate<T, EPI>(s, prod, cols, q.lo - base, q.hi - base, q.row);
@@ -320,7 +358,7 @@ __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 
         T s = row_init<T, EPI>(q);
         for (int c0 = p0; c0 < p1; c0 += cap) {
             const int c1 = min(c0 + cap, p1);
-            const int base = (NPL == 2) ? (c0 & ~1) : c0;
+            const int base = (NPL == 4) ? (c0 & ~3) : (NPL == 2) ? (c0 & ~1) : c0;
             __syncthreads();
             stage_products<T, NEEDC, NPL, COH>(a, c0, c1, base, prod, cols);
             __syncthreads();
@@ -365,27 +403,130 @@ struct FlowArgs {
     unsigned *sync;           // [0] arrival counter (zeroed before the launch), [1] error flag
 };
 
+// ---- software-pipelined row-range processing for the persistent sweeps ------------------
+// Everything a row range needs that does NOT depend on other ranges (its slice of Aj/Ax, row
+// pointers, row ids, diagonal, right-hand side) is fetched into registers one dependency
+// level AHEAD, so that after the barrier only the x gather -> LDS -> in-order row sum ->
+// store chain remains on the critical path.
+constexpr int MAXP = 4;        // prefetchable entry pairs per lane (ranges up to 2*MAXP*BLK entries)
+
+template <typename T>
+struct RangePre {
+    int4 meta;
+    int2 c[MAXP];
+    typename Vec2<T>::type v[MAXP];
+    RowPre<T> q;
+    bool has_row, fits;
+};
+
+template <typename T, int EPI, int COH>
+__device__ __forceinline__ void range_prefetch(const StreamArgs<T> &a, int blk, RangePre<T> &R)
+{
+    using T2 = typename Vec2<T>::type;
+    const int tid = threadIdx.x;
+    R.meta = a.blkmeta[blk];
+    const int p0 = R.meta.z, p1 = R.meta.w, base = p0 & ~1;
+    R.fits = (p1 - base) <= 2 * MAXP * BLK && (R.meta.y - R.meta.x) <= BLK && (p1 - p0) <= a.cap;
+    R.has_row = false;
+    if (!R.fits) return;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int q = base + 2 * tid + k * 2 * BLK;
+        if (q < p1) {
+            R.c[k] = *reinterpret_cast<const int2 *>(a.Aj + q);
+            R.v[k] = *reinterpret_cast<const T2 *>(a.Ax + q);
+        }
+    }
+    const int r = R.meta.x + tid;
+    R.has_row = r < R.meta.y;
+    if (R.has_row) R.q = row_prefetch<T, EPI, COH>(a, r);
+}
+
+// phase 1 from prefetched registers (x gather + products into LDS); phase 2 after the caller's
+// __syncthreads() via range_finish
+template <typename T, int EPI, int COH>
+__device__ __forceinline__ void range_stage(const StreamArgs<T> &a, const RangePre<T> &R, unsigned char *smem_raw)
+{
+    using T2 = typename Vec2<T>::type;
+    T *prod = reinterpret_cast<T *>(smem_raw);
+    int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(a.cap + 8));
+    const int tid = threadIdx.x;
+    const int p0 = R.meta.z, p1 = R.meta.w, base = p0 & ~1;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int q = base + 2 * tid + k * 2 * BLK;
+        if (q < p1) {
+            int2 cc = R.c[k];
+            const bool ok0 = q >= p0, ok1 = q + 1 < p1;
+            const T x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
+            const T x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
+            T2 pr;
+            pr.x = R.v[k].x * x0;
+            pr.y = R.v[k].y * x1;
+            *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
+            cc.x &= COL_MASK;
+            cc.y &= COL_MASK;
+            *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+        }
+    }
+}
+
+template <typename T, int EPI, int COH>
+__device__ __forceinline__ void range_finish(const StreamArgs<T> &a, const RangePre<T> &R, unsigned char *smem_raw)
+{
+    if (!R.has_row) return;
+    const T *prod = reinterpret_cast<const T *>(smem_raw);
+    const int *cols = reinterpret_cast<const int *>(smem_raw + sizeof(T) * (size_t)(a.cap + 8));
+    const int base = R.meta.z & ~1;
+    double sq = 0.0;
+    T s = row_init<T, EPI>(R.q);
+    row_accumulate<T, EPI>(s, prod, cols, R.q.lo - base, R.q.hi - base, R.q.row);
+    row_finish<T, EPI, COH>(a, R.q, s, sq);
+}
+
 template <typename T, int EPI, int NPL, bool COH>
 __global__ __launch_bounds__(BLK) void gs_flow_kernel(const FlowArgs<T> g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const unsigned G = gridDim.x;
+    constexpr int C = COH ? 1 : 0;
+    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    const StreamArgs<T> &a = g.s;
     double sq = 0.0;
+    RangePre<T> cur, nxt;
+    cur.fits = false; cur.has_row = false;
     int lb = g.level_blk[0];
+    int le = g.level_blk[1];
+    bool cur_valid = false;
+    if (lb + bid < le) { range_prefetch<T, EPI, C>(a, lb + bid, cur); cur_valid = true; }
     for (int l = 0; l < g.nlevels; ++l) {
-        const int le = g.level_blk[l + 1];
-        for (int blk = lb + (int)blockIdx.x; blk < le; blk += (int)G) {
-            stream_block<T, EPI, NPL, COH ? 1 : 0>(g.s, g.s.blkmeta[blk], smem_raw, sq);
+        const int nle = (l + 1 < g.nlevels) ? g.level_blk[l + 2] : le;
+        const bool have_next = (l + 1 < g.nlevels) && (le + bid < nle);
+        bool nxt_valid = false;
+        nxt.fits = false; nxt.has_row = false;
+        bool first = true;
+        for (int blk = lb + bid; blk < le; blk += G) {
+            if (first && cur_valid && cur.fits) {
+                range_stage<T, EPI, C>(a, cur, smem_raw);
+                if (have_next) { range_prefetch<T, EPI, C>(a, le + bid, nxt); nxt_valid = true; }
+                __syncthreads();
+                range_finish<T, EPI, C>(a, cur, smem_raw);
+            } else {
+                if (first && have_next) { range_prefetch<T, EPI, C>(a, le + bid, nxt); nxt_valid = true; }
+                stream_block<T, EPI, NPL, C>(a, a.blkmeta[blk], smem_raw, sq);
+            }
+            first = false;
             __syncthreads();                               // LDS is reused by the next row range
         }
-        lb = le;
+        if (first && have_next) { range_prefetch<T, EPI, C>(a, le + bid, nxt); nxt_valid = true; }
         if constexpr (!COH) {
             __syncthreads();                               // single workgroup: same-CU visibility
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
             __syncthreads();
+            // barrier: monotonic arrival counter (a per-workgroup flag array polled in parallel
+            // was measured 3 % slower), relaxed agent-scope polling, bounded spin
             if (threadIdx.x == 0) {
-                const unsigned target = (unsigned)(l + 1) * G;
+                const unsigned target = (unsigned)(l + 1) * (unsigned)G;
                 __hip_atomic_fetch_add(g.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned spins = 0;
                 while (__hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -398,6 +539,40 @@ __global__ __launch_bounds__(BLK) void gs_flow_kernel(const FlowArgs<T> g)
             }
             __syncthreads();
         }
+        cur = nxt;
+        cur_valid = nxt_valid;
+        lb = le;
+        le = nle;
+    }
+}
+
+// single-workgroup persistent sweep: ranges taken one after the other, separated by
+// __syncthreads(), ordinary cached x accesses (same CU); the static operands of range k+1 are
+// fetched while range k is being reduced.
+template <typename T, int EPI, int NPL>
+__global__ __launch_bounds__(BLK) void gs_flow1_kernel(const FlowArgs<T> g)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const StreamArgs<T> &a = g.s;
+    double sq = 0.0;
+    const int b0 = g.level_blk[0], nb = g.level_blk[g.nlevels];
+    RangePre<T> cur, nxt;
+    nxt.fits = false; nxt.has_row = false;
+    if (b0 < nb) range_prefetch<T, EPI, 0>(a, b0, cur);
+    for (int blk = b0; blk < nb; ++blk) {
+        // consecutive ranges are either in the same level (independent) or in consecutive
+        // levels (dependent): the barrier after each covers both LDS reuse and visibility
+        if (cur.fits) {
+            range_stage<T, EPI, 0>(a, cur, smem_raw);
+            if (blk + 1 < nb) range_prefetch<T, EPI, 0>(a, blk + 1, nxt);
+            __syncthreads();
+            range_finish<T, EPI, 0>(a, cur, smem_raw);
+        } else {
+            if (blk + 1 < nb) range_prefetch<T, EPI, 0>(a, blk + 1, nxt);
+            stream_block<T, EPI, NPL, 0>(a, a.blkmeta[blk], smem_raw, sq);
+        }
+        __syncthreads();
+        cur = nxt;
     }
 }
 

@@ -52,14 +52,19 @@ void plan_rows(const int *Ap, int begin, int end, int cap, int max_rows, std::ve
 int lds_bytes(int dtype, int epi, int cap)
 {
     const int per = (int)tsize(dtype) + (epi >= EPI_JACOBI ? 4 : 0);
-    return std::max(64, per * (cap + 2));
+    return std::max(64, per * (cap + 8));
 }
 
 template <typename T, int EPI>
 int launch_epi(int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a)
 {
     if (grid <= 0) return PAMG_OK;
-    if (npl == 2) {
+    if (npl == 4) {
+        if (lds > 48 * 1024)
+            PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 4>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 4>), dim3(grid), dim3(BLK), lds, s, a);
+    } else if (npl == 2) {
         if (lds > 48 * 1024)
             PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 2>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -251,7 +256,7 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
     std::vector<int4> blk;
     g->level_blk.assign(1, 0);
     for (int l = 0; l < g->nlevels; ++l) {
-        plan_rows(pAp.data(), lptr[l], lptr[l + 1], A->cap, A->max_rows, blk);
+        plan_rows(pAp.data(), lptr[l], lptr[l + 1], A->cap, std::min(A->max_rows, BLK), blk);
         g->level_blk.push_back((int)blk.size());
     }
     int st = upload(&g->d_Ap, pAp.data(), pAp.size(), &g->bytes);
@@ -267,8 +272,8 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
         st = (int)hipMalloc(&g->d_xs, xb);
         if (!st) g->bytes += xb;
     }
-    if (!st) st = (int)hipMalloc((void **)&g->d_sync, 256);
-    if (!st) st = (int)hipMemset(g->d_sync, 0, 256);
+    if (!st) st = (int)hipMalloc((void **)&g->d_sync, 2048);
+    if (!st) st = (int)hipMemset(g->d_sync, 0, 2048);
     for (int l = 0; l < g->nlevels; ++l)
         g->max_level_blocks = std::max(g->max_level_blocks, g->level_blk[l + 1] - g->level_blk[l]);
     if (st) { free_schedule(g); return st; }
@@ -427,11 +432,10 @@ template <typename T, int EPI>
 static int flow_launch(int npl, int grid, int lds, hipStream_t s, const FlowArgs<T> &f)
 {
     if (grid == 1) {
-        if (npl == 2) hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 2, false>), dim3(1), dim3(BLK), lds, s, f);
-        else hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 1, false>), dim3(1), dim3(BLK), lds, s, f);
+        if (npl == 2) hipLaunchKernelGGL((gs_flow1_kernel<T, EPI, 2>), dim3(1), dim3(BLK), lds, s, f);
+        else hipLaunchKernelGGL((gs_flow1_kernel<T, EPI, 1>), dim3(1), dim3(BLK), lds, s, f);
     } else {
-        if (npl == 2) hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 2, true>), dim3(grid), dim3(BLK), lds, s, f);
-        else hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 1, true>), dim3(grid), dim3(BLK), lds, s, f);
+        hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 2, true>), dim3(grid), dim3(BLK), lds, s, f);
     }
     return (int)hipGetLastError();
 }
@@ -466,30 +470,31 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
         }
         return gran_launch<T>(epi, A->npl, G, lds, s, a, g->nblk_total);
     }
-    // Scheduling policy (measured, profiles/r01_microbench_gs_*.json): a kernel boundary costs
-    // ~5-8 us per level, the in-kernel barrier between several workgroups about the same, but ONE
-    // workgroup walking the levels with __syncthreads() and ordinary cached accesses ~2-3.5 us per
-    // row range.  So: narrow schedules (<= flow_cap/16 row ranges per level on average, default 2)
-    // run as a single-workgroup persistent sweep, everything else as one launch per level.
+    // Scheduling policy (measured, profiles/r01_microbench_gs_*.json, 96^3 and 256^3 hierarchies):
+    //  * narrow schedules (<= flow_cap/16 row ranges per level on average, default 2): ONE workgroup
+    //    walks all levels with __syncthreads() and cached accesses (1.8-3.5 us per range);
+    //  * otherwise a persistent grid of G = widest level (<= 256, co-resident on 256 CUs) workgroups
+    //    with an in-kernel flag barrier and software-pipelined static operands (3.8-5 us per level);
+    //  * one launch per level (5.4-8 us per level) only as the fallback (oversized LDS window).
     const bool narrow = (int64_t)g->nblk_total * 16 <= (int64_t)g->nlevels * A->flow_cap;
-    const bool flow = lds <= 48 * 1024 && g->nlevels > 1 && A->flow_cap > 0 && (A->flow_force || narrow);
-    if (flow) {
+    const bool can_flow = lds <= 48 * 1024 && g->nlevels > 1 && A->flow_cap > 0 && A->npl == 2;
+    if (can_flow) {
         FlowArgs<T> f;
         f.s = a;
         f.s.blkmeta = g->d_blkmeta;
         f.level_blk = g->d_level_blk;
         f.nlevels = g->nlevels;
         f.sync = g->d_sync;
-        // forced mode (experiments): grid = min(flow_cap, widest level) co-resident workgroups with
-        // the in-kernel barrier; policy mode: one workgroup
-        const int G = A->flow_force ? std::max(1, std::min(std::min(A->flow_cap, 256), g->max_level_blocks)) : 1;
-        PAMG_HIP(hipMemsetAsync(g->d_sync, 0, sizeof(unsigned), s));
-        switch (epi) {
+        int G = (narrow && !A->flow_force) ? 1 : std::max(1, std::min(256, g->max_level_blocks));
+        if (A->flow_force) G = std::max(1, std::min(G, A->flow_cap));
+        else if (G > 128) G = 0;          // very wide levels (fine grids): kernel boundaries are cheaper than a 200-way barrier
+        if (G > 1) PAMG_HIP(hipMemsetAsync(g->d_sync, 0, 2048, s));
+        if (G > 0) switch (epi) {
             case EPI_GS: return flow_launch<T, EPI_GS>(A->npl, G, lds, s, f);
             case EPI_GS_B: return flow_launch<T, EPI_GS_B>(A->npl, G, lds, s, f);
             case EPI_SOR: return flow_launch<T, EPI_SOR>(A->npl, G, lds, s, f);
+            default: return PAMG_E_ARG;
         }
-        return PAMG_E_ARG;
     }
     for (int l = 0; l < g->nlevels; ++l) {
         a.blkmeta = g->d_blkmeta + g->level_blk[l];
@@ -764,15 +769,15 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
 {
     if (!A) return PAMG_E_ARG;
     switch (key) {
-        case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~1; break;
-        case 1: if (value != 1 && value != 2) return PAMG_E_ARG; A->npl = value; break;
+        case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~3; break;
+        case 1: if (value != 1 && value != 2 && value != 4) return PAMG_E_ARG; A->npl = value; break;
         case 2: if (value < 1) return PAMG_E_ARG; A->max_rows = value; break;
         case 3: if (value < 0 || value > 256) return PAMG_E_ARG; A->flow_cap = value; return PAMG_OK;
         case 4: A->flow_force = value != 0; return PAMG_OK;
         case 5: if (value != 0 && value != 1) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
         case 6: if (value < 0) return PAMG_E_ARG; A->gran_cap = value; return PAMG_OK;
         case 7: A->gran_xcd = value != 0; return PAMG_OK;
-        case 8: if (value < 0 || value > 3) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;
+        case 8: if (value < 0 || value > 15) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;
         default: return PAMG_E_ARG;
     }
     for (int k = 0; k < 4; ++k) { if (A->gs[k]) A->bytes -= A->gs[k]->bytes; free_schedule(A->gs[k]); A->gs[k] = nullptr; }

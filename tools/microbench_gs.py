@@ -57,7 +57,7 @@ for li, L in enumerate(spec.levels[:-1]):
     db = capi.DeviceArray.from_host(b)
     dx = capi.DeviceArray.from_host(x)
     rec = {"level": li, "n": n, "nnz": op.nnz, "fmt": op.fmt}
-    for name, kw in [("granxcd", dict(gs_mode=1, gran_xcd=1)), ("gran128", dict(gs_mode=1, gran_xcd=0, gran_cap=128))] + \
+    for name, kw in [("default", dict(gs_mode=0, gran_xcd=0, flow_cap=32, flow_force=0))] + [(f"flowG{G}", dict(gs_mode=0, flow_cap=G, flow_force=1)) for G in (16, 64, 256)] + \
                     [("launch", dict(gs_mode=0, gran_xcd=0, flow_cap=0, flow_force=0)), ("flow1", dict(gs_mode=0, flow_cap=1, flow_force=1))]:
         dA.tune(**kw)
         dx.upload(x)
