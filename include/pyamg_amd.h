@@ -257,6 +257,7 @@ int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, v
 #define PAMG_CYCLE_V 0
 #define PAMG_CYCLE_W 1
 #define PAMG_CYCLE_F 2
+#define PAMG_CYCLE_AMLI 3   /* multilevel.py:628-656 (2 A-orthogonalised inner corrections per level) */
 int pamg_solver_create(pamg_solver_t *S, int dtype);
 int pamg_solver_destroy(pamg_solver_t S);
 /* levels are added fine -> coarse; P and R are NULL for the coarsest level.  The solver

@@ -282,6 +282,22 @@ class OracleSolver:
             self.cycle(lvl + 1, coarse_x, coarse_b, cycle, cycles_per_level)
             for _ in range(cycles_per_level):
                 self.cycle(lvl + 1, coarse_x, coarse_b, "V", 1)
+        elif cycle == "AMLI":
+            # multilevel.py:628-656: two search directions per level, each the result of a
+            # recursive AMLI solve started from ones, made A_c-orthogonal to the earlier one,
+            # then an exact line search; coarse_b is deflated in place between the two.
+            Ac = self.spec.levels[lvl + 1].A
+            dirs = np.zeros((2, coarse_b.shape[0]), dtype=coarse_b.dtype)
+            for k in range(2):
+                dirs[k, :] = 1
+                self.cycle(lvl + 1, dirs[k, :], coarse_b, cycle)
+                for j in range(k):
+                    bkj = np.inner(dirs[j], matvec(Ac, dirs[k])) / np.inner(dirs[j], matvec(Ac, dirs[j]))
+                    dirs[k, :] -= bkj * dirs[j, :]
+                Adk = matvec(Ac, dirs[k, :])
+                step = np.inner(dirs[k], coarse_b) / np.inner(dirs[k], Adk)
+                coarse_x += step * dirs[k]
+                coarse_b -= step * Adk
         else:
             raise TypeError(f"Unrecognized cycle type ({cycle})")
         x += matvec(L.P, coarse_x)

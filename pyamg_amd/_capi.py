@@ -23,7 +23,7 @@ FORWARD, BACKWARD, SYMMETRIC = 0, 1, 2
 SMOOTH = {"none": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
           "block_jacobi": 5, "block_gauss_seidel": 6}
 SWEEP = {"forward": FORWARD, "backward": BACKWARD, "symmetric": SYMMETRIC}
-CYCLE = {"V": 0, "W": 1, "F": 2}
+CYCLE = {"V": 0, "W": 1, "F": 2, "AMLI": 3}
 
 
 class DeviceUnavailable(RuntimeError):

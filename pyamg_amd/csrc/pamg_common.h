@@ -136,6 +136,8 @@ int vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t
 int vec_scale(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
 int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch, double *out, hipStream_t s);
 int vec_xpby(int dtype, int64_t n, double beta, const void *z, void *p, hipStream_t s);
+int vec_axpy_ratio(int dtype, int64_t n, const double *num, const double *den, double sign, const void *x, void *y, hipStream_t s);
+int vec_fill(int dtype, int64_t n, double v, void *y, hipStream_t s);
 int dense_gemv(int dtype, int n, const void *M, const void *b, void *x, hipStream_t s);
 int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, int row_start,
                    int row_stop, int row_step, hipStream_t s);

@@ -708,6 +708,25 @@ __global__ __launch_bounds__(BLK) void vec_xpby_kernel(int64_t n, T beta, const 
     }
 }
 
+// y = y + (sign * num/den) * x with the two scalars read from DEVICE memory (AMLI step sizes:
+// the cycle stays capturable, no host round trip for alpha/beta)
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_axpy_ratio_kernel(int64_t n, const double *num, const double *den, T sign,
+                                                             const T *x, T *y)
+{
+    const T a = sign * (T)(num[0] / den[0]);
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
+        const T t = a * x[i];
+        y[i] = y[i] + t;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_fill_kernel(int64_t n, T v, T *y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) y[i] = v;
+}
+
 // x = M b, dense row-major n x n (coarsest-level solve, multilevel.py:717-721): one wave
 // per row, lanes stride the row, butterfly sum.
 template <typename T>

@@ -646,6 +646,27 @@ int vec_xpby(int dtype, int64_t n, double beta, const void *z, void *p, hipStrea
     return (int)hipGetLastError();
 }
 
+int vec_axpy_ratio(int dtype, int64_t n, const double *num, const double *den, double sign, const void *x, void *y,
+                   hipStream_t s)
+{
+    if (n <= 0) return PAMG_OK;
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_axpy_ratio_kernel<double>), dim3(vgrid(n)), dim3(BLK), 0, s, n, num, den, sign, (const double *)x, (double *)y);
+    else
+        hipLaunchKernelGGL((vec_axpy_ratio_kernel<float>), dim3(vgrid(n)), dim3(BLK), 0, s, n, num, den, (float)sign, (const float *)x, (float *)y);
+    return (int)hipGetLastError();
+}
+
+int vec_fill(int dtype, int64_t n, double v, void *y, hipStream_t s)
+{
+    if (n <= 0) return PAMG_OK;
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_fill_kernel<double>), dim3(vgrid(n)), dim3(BLK), 0, s, n, v, (double *)y);
+    else
+        hipLaunchKernelGGL((vec_fill_kernel<float>), dim3(vgrid(n)), dim3(BLK), 0, s, n, (float)v, (float *)y);
+    return (int)hipGetLastError();
+}
+
 int dense_gemv(int dtype, int n, const void *M, const void *b, void *x, hipStream_t s)
 {
     if (n <= 0) return PAMG_OK;

@@ -33,6 +33,7 @@ struct Level {
     void *x = nullptr, *xalt = nullptr;   // ping-pong pair; x is where the iterate lives NOW
     void *x_home = nullptr;               // canonical buffer (graph replays start/end here)
     void *b = nullptr, *r = nullptr, *work = nullptr;
+    void *amli = nullptr;                 // AMLI: [p0 | p1 | q | acc], 4n values (allocated on first use)
 };
 
 int sweep_bounds(const pamg_matrix_s *A, int dir, int &r0, int &r1, int &rs)
@@ -216,6 +217,35 @@ int cycle_rec(pamg_solver_s *S, int lvl, int type, int cpl, bool x_zero, hipStre
     } else if (type == PAMG_CYCLE_F) {
         PAMG_TRY(cycle_rec(S, lvl + 1, PAMG_CYCLE_F, cpl, true, s));
         for (int k = 0; k < cpl; ++k) PAMG_TRY(cycle_rec(S, lvl + 1, PAMG_CYCLE_V, 1, false, s));
+    } else if (type == PAMG_CYCLE_AMLI) {
+        // multilevel.py:628-656: two inner corrections, each a recursive AMLI solve from an
+        // initial guess of ones, A-orthogonalised against the previous one and line-searched.
+        // Step sizes stay on the device (slot[8..11]) so the cycle remains capturable.
+        if (!N.amli) return PAMG_E_STATE;
+        const int64_t nc = N.n;
+        const int dt = S->dtype;
+        void *p[2] = {N.amli, (char *)N.amli + nc * ts};
+        void *q = (char *)N.amli + 2 * nc * ts, *acc = (char *)N.amli + 3 * nc * ts;
+        double *sl = S->d_slot + 8;
+        PAMG_HIP(hipMemsetAsync(acc, 0, (size_t)nc * ts, s));
+        for (int k = 0; k < 2; ++k) {
+            PAMG_TRY(vec_fill(dt, nc, 1.0, N.x, s));                                     // p[k,:] = 1
+            PAMG_TRY(cycle_rec(S, lvl + 1, PAMG_CYCLE_AMLI, cpl, false, s));
+            PAMG_HIP(hipMemcpyAsync(p[k], N.x, (size_t)nc * ts, hipMemcpyDeviceToDevice, s));
+            for (int j = 0; j < k; ++j) {
+                PAMG_TRY(stream_launch(N.A, EPI_SET, p[k], nullptr, q, 0.0, 0.0, nullptr, s));
+                PAMG_TRY(vec_dot(dt, nc, p[j], q, S->d_scratch, sl + 0, s));              // <p_j, Ac p_k>
+                PAMG_TRY(stream_launch(N.A, EPI_SET, p[j], nullptr, q, 0.0, 0.0, nullptr, s));
+                PAMG_TRY(vec_dot(dt, nc, p[j], q, S->d_scratch, sl + 1, s));              // <p_j, Ac p_j>
+                PAMG_TRY(vec_axpy_ratio(dt, nc, sl + 0, sl + 1, -1.0, p[j], p[k], s));    // p_k -= beta p_j
+            }
+            PAMG_TRY(stream_launch(N.A, EPI_SET, p[k], nullptr, q, 0.0, 0.0, nullptr, s));    // Ap
+            PAMG_TRY(vec_dot(dt, nc, p[k], N.b, S->d_scratch, sl + 2, s));
+            PAMG_TRY(vec_dot(dt, nc, p[k], q, S->d_scratch, sl + 3, s));
+            PAMG_TRY(vec_axpy_ratio(dt, nc, sl + 2, sl + 3, 1.0, p[k], acc, s));          // coarse_x += alpha p
+            PAMG_TRY(vec_axpy_ratio(dt, nc, sl + 2, sl + 3, -1.0, q, N.b, s));            // coarse_b -= alpha Ap
+        }
+        PAMG_HIP(hipMemcpyAsync(N.x, acc, (size_t)nc * ts, hipMemcpyDeviceToDevice, s));
     } else {
         return PAMG_E_ARG;
     }
@@ -262,6 +292,8 @@ int run_cycle(pamg_solver_s *S, int type, int cpl, hipStream_t s, bool check = t
     return (int)hipGraphLaunch(it->second, s);
 }
 
+int ensure_amli(pamg_solver_s *S, int cycle);
+
 int prebuild_schedules(Level &L, const Smoother &sm)
 {
     const bool gs = sm.kind == PAMG_SMOOTH_GS || sm.kind == PAMG_SMOOTH_SOR || sm.kind == PAMG_SMOOTH_BLOCK_GS;
@@ -283,6 +315,16 @@ int dalloc(pamg_solver_s *S, void **p, size_t bytes)
     PAMG_HIP(hipMalloc(p, std::max<size_t>(bytes, 256)));
     PAMG_HIP(hipMemset(*p, 0, std::max<size_t>(bytes, 256)));
     S->bytes += std::max<size_t>(bytes, 256);
+    return PAMG_OK;
+}
+
+int ensure_amli(pamg_solver_s *S, int cycle)
+{
+    if (cycle != PAMG_CYCLE_AMLI) return PAMG_OK;
+    for (size_t l = 1; l < S->levels.size(); ++l) {
+        Level &L = S->levels[l];
+        if (!L.amli) PAMG_TRY(dalloc(S, &L.amli, 4 * (size_t)L.n * tsize(S->dtype)));
+    }
     return PAMG_OK;
 }
 
@@ -370,7 +412,7 @@ int pamg_solver_destroy(pamg_solver_t S)
     drop_graphs(S);
     for (Level &L : S->levels) {
         hipFree(L.x); hipFree(L.xalt);
-        hipFree(L.b); hipFree(L.r); hipFree(L.work);
+        hipFree(L.b); hipFree(L.r); hipFree(L.work); hipFree(L.amli);
         hipFree(L.pre.d_Dinv); hipFree(L.post.d_Dinv);
     }
     hipFree(S->d_coarse); hipFree(S->d_norms); hipFree(S->d_slot); hipFree(S->d_scratch);
@@ -465,7 +507,7 @@ int pamg_solver_finalize(pamg_solver_t S)
             PAMG_TRY(prebuild_schedules(L, L.post));
         }
     }
-    PAMG_TRY(dalloc(S, (void **)&S->d_slot, 4 * sizeof(double)));
+    PAMG_TRY(dalloc(S, (void **)&S->d_slot, 16 * sizeof(double)));
     PAMG_TRY(dalloc(S, (void **)&S->d_scratch, 1032 * sizeof(double)));
     PAMG_HIP(hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking));
     S->finalized = true;
@@ -484,8 +526,9 @@ int pamg_solver_cycle(pamg_solver_t S, void *x, const void *b, int cycle, int cy
 {
     if (!S || !x || !b) return PAMG_E_ARG;
     if (!S->finalized) return PAMG_E_STATE;
-    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
+    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_AMLI || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
     hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    PAMG_TRY(ensure_amli(S, cycle));
     if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));   // inputs may have been produced on the default stream
     Level &L0 = S->levels[0];
     const size_t vb = (size_t)L0.n * tsize(S->dtype);
@@ -503,8 +546,9 @@ int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int m
 {
     if (!S || !x || !b || maxiter < 1 || check_every < 1) return PAMG_E_ARG;
     if (!S->finalized) return PAMG_E_STATE;
-    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
+    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_AMLI || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
     hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    PAMG_TRY(ensure_amli(S, cycle));
     if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));   // inputs may have been produced on the default stream
     Level &L0 = S->levels[0];
     const size_t vb = (size_t)L0.n * tsize(S->dtype);
@@ -569,8 +613,9 @@ int pamg_solver_iterate(pamg_solver_t S, int k, int cycle, int cycles_per_level,
 {
     if (!S || k < 0) return PAMG_E_ARG;
     if (!S->finalized) return PAMG_E_STATE;
-    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
+    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_AMLI || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
     hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    PAMG_TRY(ensure_amli(S, cycle));
     if (residuals && S->norms_cap < k + 2) {
         if (S->d_norms) hipFree(S->d_norms);
         S->norms_cap = k + 2;
@@ -617,8 +662,9 @@ int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int max
 {
     if (!S || !x || !b || maxiter < 1) return PAMG_E_ARG;
     if (!S->finalized) return PAMG_E_STATE;
-    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_F || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
+    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_AMLI || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
     hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    PAMG_TRY(ensure_amli(S, cycle));
     if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));
     Level &L0 = S->levels[0];
     const int64_t n = L0.n;

@@ -235,7 +235,11 @@ class DeviceMultilevelSolver:
         x = np.zeros_like(b) if x0 is None else np.array(x0)       # copy (:464-467)
         cycle = str(cycle).upper()
         if cycle == "AMLI":
-            raise NotImplementedError("AMLI cycles are not on the device path")
+            A0 = getattr(self.ml.levels[0], "A", None) if self.ml is not None else None
+            if A0 is not None and hasattr(A0, "symmetry") and A0.symmetry != "hermitian":
+                raise ValueError("AMLI cycles require symmetry to be hermitian")       # multilevel.py:474-477
+            if accel is not None and accel != "fgmres":
+                raise ValueError("AMLI cycles require acceleration (accel) to be fgmres, or no acceleration")
         if cycle not in capi.CYCLE:
             raise TypeError(f"Unrecognized cycle type ({cycle})")
         n = self.shape[0]
@@ -341,6 +345,17 @@ class DeviceMultilevelSolver:
                 callback_wrapper = callback
             x, info = accel(A, b, x0=x0, maxiter=maxiter, M=M, callback=callback_wrapper, rtol=tol, atol=0)
             return (x, info) if return_info else x
+
+    def change_solve_matrix(self, A):
+        """Swap the fine-level operator (reference: multilevel.py:320-337 -- the host solver
+        rebuilds its level-0 smoothers) and re-ship the hierarchy: the resident copy is
+        invalid once the host ``ml`` changes."""
+        if self.ml is None:
+            raise NotImplementedError("change_solve_matrix needs the wrapped reference solver")
+        self.ml.change_solve_matrix(A)
+        ml, graph = self.ml, True
+        self.free()
+        self.__init__(ml, graph=graph)
 
     def aspreconditioner(self, cycle="V"):
         """multilevel.py:355-396: LinearOperator applying one cycle from x = 0."""

@@ -69,6 +69,9 @@ def make_hierarchies():
     hier("rs2d_jacobi", pyamg.ruge_stuben_solver(A, max_coarse=10, presmoother=jac, postsmoother=jac))
     np.random.seed(SEED)
     hier("rs2d_gs_F", pyamg.ruge_stuben_solver(A, max_coarse=10), cycle="F")
+    np.random.seed(SEED)
+    hier("sa2d_jacobi_AMLI", pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother=jac, postsmoother=jac),
+         cycle="AMLI", k=6)
     A3 = pyamg.gallery.poisson((12, 12, 12), format="csr")
     np.random.seed(SEED)
     hier("sa3d_gs", pyamg.smoothed_aggregation_solver(A3, max_coarse=10,

@@ -63,8 +63,8 @@ def test_solve_api_conventions(load_hier):
     z1 = M @ b
     z2 = dml.solve(b, maxiter=1, tol=1e-12)
     assert np.array_equal(z1, z2) and (M @ b.reshape(-1, 1)).shape == (n, 1)
-    with pytest.raises(NotImplementedError):
-        dml.solve(b, cycle="AMLI")
+    with pytest.raises(ValueError):
+        dml.solve(b, cycle="AMLI", accel="cg")          # multilevel.py:488-490
     with pytest.raises(TypeError):
         dml.solve(b, cycle="Q")
 
@@ -172,3 +172,30 @@ def test_device_pcg_matches_reference_algorithm(load_hier):
     res = []
     x, info = dml.solve(b, tol=1e-8, maxiter=50, accel="cg", residuals=res, return_info=True)
     assert info == 0 and res[-1] < 1e-8 * np.linalg.norm(b) <= res[-2]
+
+
+def test_change_solve_matrix_and_fgmres_amli_with_live_reference():
+    """change_solve_matrix re-ships the hierarchy (multilevel.py:320-337); AMLI cycle as an
+    FGMRES preconditioner (the only accelerator the reference allows with AMLI, :488-490)."""
+    import oracle.refimport as ri
+    if not ri.available():
+        pytest.skip("oracle/_ref not present on this box")
+    import pyamg
+    A = pyamg.gallery.poisson((40, 40), format="csr")
+    np.random.seed(5)
+    jac = ("jacobi", {"omega": 4 / 3})
+    ml = pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother=jac, postsmoother=jac)
+    dml = DeviceMultilevelSolver(ml)
+    b = np.random.rand(A.shape[0])
+    r_ref, r_gpu = [], []
+    x_ref = ml.solve(b, tol=1e-10, maxiter=15, cycle="AMLI", accel="fgmres", residuals=r_ref)
+    x_gpu = dml.solve(b, tol=1e-10, maxiter=15, cycle="AMLI", accel="fgmres", residuals=r_gpu)
+    m = min(len(r_ref), len(r_gpu), 6)
+    assert np.max(np.abs(np.array(r_gpu[:m]) - np.array(r_ref[:m]))) <= 1e-8 * r_ref[0]
+    assert np.linalg.norm(b - A @ x_gpu) <= 1e-8 * np.linalg.norm(b)
+    A2 = (A * 2.0).tocsr()
+    dml.change_solve_matrix(A2)
+    r_ref, r_gpu = [], []
+    ml.solve(b, tol=1e-30, maxiter=4, residuals=r_ref)
+    dml.solve(b, tol=1e-30, maxiter=4, residuals=r_gpu)
+    assert np.max(np.abs(np.array(r_gpu) - np.array(r_ref))) <= 1e-10 * r_ref[0]
