@@ -464,9 +464,11 @@ __device__ __forceinline__ void range_stage(const StreamArgs<T> &a, const RangeP
             pr.x = R.v[k].x * x0;
             pr.y = R.v[k].y * x1;
             *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
-            cc.x &= COL_MASK;
-            cc.y &= COL_MASK;
-            *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+            if constexpr (EpiTraits<EPI>::need_cols) {
+                cc.x &= COL_MASK;
+                cc.y &= COL_MASK;
+                *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+            }
         }
     }
 }

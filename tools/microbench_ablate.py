@@ -46,3 +46,4 @@ for cap in CAPS:
 print(json.dumps({k: v for k, v in out.items() if "vec" in k}))
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
 (ROOT / "gpurun_out" / "microbench_ablate.json").write_text(json.dumps(out, indent=1))
+
