@@ -193,7 +193,7 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * 6 = cap on the granular sweep's persistent grid (0 = auto); 7 = granular sweep restricted
  * to the workgroups that land on XCD 0 (hand-off through one L2); 8 = streaming flags of the
  * whole-operator kernels: bit 0 non-temporal loads of the operator stream, bit 1 XCD-aware
- * row-range order. */
+ * row-range order; 9 = LDS-staged x windows for the whole-operator kernels (re-plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* *error != 0: a persistent sweep of this operator hit its spin bound (synchronises) */
 int pamg_matrix_flow_error(pamg_matrix_t A, int *error);

@@ -113,6 +113,9 @@ struct pamg_matrix_s {
     int cap = 2048, npl = 1, max_rows = 1024;
     int flow_cap = 32;               // single-workgroup persistent sweep when a schedule averages <= flow_cap/16 row ranges per level
     int flow_force = 0;              // != 0: persistent barrier kernel always, grid = min(flow_cap, widest level)
+    int use_xwin = 0;                // LDS-staged x windows for the whole-operator kernels (tune key 9)
+    void *d_xwin = nullptr;          // XWin[nblk] window plan (device)
+    int xw_cap = 0;                  // window budget (values) the plan was built for
     int stream_flags = 0;            // StreamArgs::flags for the whole-operator launches
     int gran_xcd = 0;                // granular sweep restricted to the workgroups that land on XCD 0
     int gran_cap = 0;                // granular sweep: cap on the persistent grid (0 = auto)

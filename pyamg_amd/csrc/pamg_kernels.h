@@ -486,6 +486,85 @@ __device__ __forceinline__ void range_finish(const StreamArgs<T> &a, const Range
     row_finish<T, EPI, COH>(a, R.q, s, sq);
 }
 
+// ---- LDS-staged x windows -------------------------------------------------------------------
+// For banded operators (stencils: fine levels) the columns touched by one row range fall into a
+// few contiguous windows of x.  The host plan records up to XW_MAX windows per range; the
+// workgroup copies them into LDS with coalesced loads and phase 1 gathers from LDS instead of
+// sending scattered 8-byte requests through the texture-addresser/L1 path.  Ranges whose columns
+// do not fit the window budget (irregular coarse operators) fall back to the direct gather.
+constexpr int XW_MAX = 4;
+
+struct XWin {
+    int start[XW_MAX];     // first column of window w   (start[0] < 0: no plan -> direct gather)
+    int len[XW_MAX];       // its length (0 = unused)
+};
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(BLK) void csr_stream_xw_kernel(const StreamArgs<T> a, const XWin *xwin, int wcap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using T2 = typename Vec2<T>::type;
+    constexpr bool NEEDC = EpiTraits<EPI>::need_cols;
+    const int blk = (int)blockIdx.x;
+    const int tid = threadIdx.x;
+    double sq = 0.0;
+    const XWin W = xwin[blk];
+    RangePre<T> R;
+    R.fits = false;
+    if (W.start[0] >= 0) range_prefetch<T, EPI, 0>(a, blk, R);          // operator slice -> registers
+    if (W.start[0] < 0 || !R.fits) {
+        stream_block<T, EPI, 2, 0>(a, a.blkmeta[blk], smem_raw, sq);
+    } else {
+        T *prod = reinterpret_cast<T *>(smem_raw);
+        int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(a.cap + 8));
+        T *xl = reinterpret_cast<T *>(smem_raw + (sizeof(T) + (NEEDC ? 4 : 0)) * (size_t)(a.cap + 8));
+        int off[XW_MAX];
+        int o = 0;
+#pragma unroll
+        for (int w = 0; w < XW_MAX; ++w) {
+            off[w] = o;
+            for (int t = tid; t < W.len[w]; t += BLK) xl[o + t] = a.x[W.start[w] + t];   // coalesced
+            o += W.len[w];
+        }
+        __syncthreads();
+        const int p0 = R.meta.z, p1 = R.meta.w, base = p0 & ~1;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int q = base + 2 * tid + k * 2 * BLK;
+            if (q < p1) {
+                const int2 cc = R.c[k];
+                int i0 = 0, i1 = 0;
+#pragma unroll
+                for (int w = 0; w < XW_MAX; ++w) {
+                    const unsigned d0 = (unsigned)(cc.x - W.start[w]), d1 = (unsigned)(cc.y - W.start[w]);
+                    if (d0 < (unsigned)W.len[w]) i0 = off[w] + (int)d0;
+                    if (d1 < (unsigned)W.len[w]) i1 = off[w] + (int)d1;
+                }
+                const bool ok0 = q >= p0, ok1 = q + 1 < p1;
+                const T x0 = ok0 ? xl[i0] : T(0);
+                const T x1 = ok1 ? xl[i1] : T(0);
+                T2 pr;
+                pr.x = R.v[k].x * x0;
+                pr.y = R.v[k].y * x1;
+                *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
+                if constexpr (NEEDC) *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+            }
+        }
+        __syncthreads();
+        if (R.has_row) {
+            T s = row_init<T, EPI>(R.q);
+            row_accumulate<T, EPI>(s, prod, cols, R.q.lo - base, R.q.hi - base, R.q.row);
+            row_finish<T, EPI, 0>(a, R.q, s, sq);
+        }
+    }
+    if constexpr (EPI == EPI_SUMSQ) {
+        __syncthreads();
+        const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
+        if (tid == 0) a.partial[blk] = tot;
+    }
+    (void)wcap;
+}
+
 template <typename T, int EPI, int NPL, bool COH>
 __global__ __launch_bounds__(BLK) void gs_flow_kernel(const FlowArgs<T> g)
 {

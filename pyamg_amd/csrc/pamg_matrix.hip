@@ -79,6 +79,23 @@ int launch_epi(int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a
 }
 
 template <typename T>
+int xw_launch(int epi, int grid, int lds, hipStream_t s, const StreamArgs<T> &a, const XWin *xw, int wcap)
+{
+    if (grid <= 0) return PAMG_OK;
+#define PAMG_XW(E) case E:                                                                                        \
+        if (lds > 48 * 1024) PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_xw_kernel<T, E>,               \
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));      \
+        hipLaunchKernelGGL((csr_stream_xw_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a, xw, wcap); break;
+    switch (epi) {
+        PAMG_XW(EPI_SET) PAMG_XW(EPI_ACC) PAMG_XW(EPI_RESID) PAMG_XW(EPI_AXPBY) PAMG_XW(EPI_ACC_AXPBY)
+        PAMG_XW(EPI_SUMSQ) PAMG_XW(EPI_ACCSEQ) PAMG_XW(EPI_JACOBI) PAMG_XW(EPI_JACOBI_B)
+        default: return PAMG_E_ARG;
+    }
+#undef PAMG_XW
+    return (int)hipGetLastError();
+}
+
+template <typename T>
 int launch_any(int epi, int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a)
 {
     switch (epi) {
@@ -98,6 +115,22 @@ int launch_any(int epi, int npl, int grid, int lds, hipStream_t s, const StreamA
     return PAMG_E_ARG;
 }
 
+template <typename F>
+void parallel_rows(int n, F fn)
+{
+    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int nt = (n < (1 << 16)) ? 1 : (int)hw;
+    if (nt == 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) {
+        const int lo = (int)((int64_t)n * t / nt), hi = (int)((int64_t)n * (t + 1) / nt);
+        th.emplace_back([=] { fn(lo, hi); });
+    }
+    for (auto &x : th) x.join();
+}
+
+int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap);
+
 int replan(pamg_matrix_s *A)
 {
     if (A->d_blkmeta) { hipFree(A->d_blkmeta); A->d_blkmeta = nullptr; }
@@ -107,7 +140,52 @@ int replan(pamg_matrix_s *A)
     plan_rows(A->h_Ap.data(), 0, (int)A->nrows, A->cap, A->max_rows, blk);
     A->nblk = (int)blk.size();
     PAMG_TRY(upload(&A->d_blkmeta, blk.data(), blk.size(), nullptr));
+    if (A->use_xwin && A->R == 1 && A->npl == 2) PAMG_TRY(plan_windows(A, blk, std::max(256, A->cap)));
+    else if (A->d_xwin) { hipFree(A->d_xwin); A->d_xwin = nullptr; }
     PAMG_HIP(hipMalloc((void **)&A->d_partial, sizeof(double) * (size_t)(A->nblk + 264)));
+    return PAMG_OK;
+}
+
+// x-window plan for the whole-operator kernels: per row range, up to XW_MAX contiguous column
+// windows (gaps > 16 columns split windows) whose total length fits the LDS budget.
+int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap)
+{
+    if (A->d_xwin) { hipFree(A->d_xwin); A->d_xwin = nullptr; }
+    const int nb = (int)blk.size();
+    std::vector<XWin> W((size_t)nb);
+    const int *Aj = A->h_Aj.data();
+    parallel_rows(nb, [&](int lo, int hi) {
+        std::vector<int> c;
+        for (int b = lo; b < hi; ++b) {
+            XWin w;
+            for (int k = 0; k < XW_MAX; ++k) { w.start[k] = 0; w.len[k] = 0; }
+            const int p0 = blk[b].z, p1 = blk[b].w;
+            bool ok = (p1 - p0) <= A->cap && (blk[b].y - blk[b].x) <= BLK && p1 > p0;
+            if (ok) {
+                c.assign(Aj + p0, Aj + p1);
+                std::sort(c.begin(), c.end());
+                int nw = 0, total = 0, ws = c[0], prev = c[0];
+                for (size_t i = 1; i <= c.size() && ok; ++i) {
+                    const bool last = i == c.size();
+                    if (last || c[i] - prev > 16) {
+                        if (nw == XW_MAX) { ok = false; break; }
+                        w.start[nw] = ws; w.len[nw] = prev - ws + 1;
+                        total += w.len[nw];
+                        ++nw;
+                        if (!last) ws = c[i];
+                    }
+                    if (!last) prev = c[i];
+                }
+                if (total > wcap) ok = false;
+            }
+            if (!ok) { w.start[0] = -1; for (int k = 0; k < XW_MAX; ++k) w.len[k] = 0; }
+            W[(size_t)b] = w;
+        }
+    });
+    A->xw_cap = wcap;
+    void *d = nullptr;
+    PAMG_TRY(upload_raw(&d, W.data(), W.size(), sizeof(XWin), nullptr));
+    A->d_xwin = d;
     return PAMG_OK;
 }
 
@@ -170,20 +248,6 @@ int analyse_levels(int n, const int *Ap, const int *Aj, int row_start, int row_s
     }
     if (vis_out) vis_out->swap(vis);
     return PAMG_OK;
-}
-
-template <typename F>
-void parallel_rows(int n, F fn)
-{
-    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const int nt = (n < (1 << 16)) ? 1 : (int)hw;
-    if (nt == 1) { fn(0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t) {
-        const int lo = (int)((int64_t)n * t / nt), hi = (int)((int64_t)n * (t + 1) / nt);
-        th.emplace_back([=] { fn(lo, hi); });
-    }
-    for (auto &x : th) x.join();
 }
 
 // true iff for every stored (i,j), i != j, both swept, (j,i) is stored too
@@ -357,6 +421,14 @@ int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void 
                   double omega, double *partial, hipStream_t s)
 {
     const int lds = lds_bytes(A->dtype, epi, A->cap);
+    if (A->use_xwin && A->d_xwin && A->npl == 2 && epi < EPI_GS) {
+        const int per = (int)tsize(A->dtype) + (epi >= EPI_JACOBI ? 4 : 0);
+        const int ldsx = per * (A->cap + 8) + (int)tsize(A->dtype) * (A->xw_cap + 8);
+        if (ldsx <= 60 * 1024) {
+            if (A->dtype == PAMG_F64) return xw_launch<double>(epi, A->nblk, ldsx, s, base_args<double>(A, x, b, y, c, omega, partial), (const XWin *)A->d_xwin, A->xw_cap);
+            return xw_launch<float>(epi, A->nblk, ldsx, s, base_args<float>(A, x, b, y, c, omega, partial), (const XWin *)A->d_xwin, A->xw_cap);
+        }
+    }
     const int grid = (A->stream_flags & 2) ? 8 * ((A->nblk + 7) / 8) : A->nblk;
     if (A->dtype == PAMG_F64) {
         StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
@@ -764,7 +836,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
 {
     if (!A) return PAMG_OK;
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag);
-    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial);
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     delete A;
     return PAMG_OK;
@@ -799,6 +871,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 6: if (value < 0) return PAMG_E_ARG; A->gran_cap = value; return PAMG_OK;
         case 7: A->gran_xcd = value != 0; return PAMG_OK;
         case 8: if (value < 0 || value > 15) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;
+        case 9: A->use_xwin = value != 0; break;
         default: return PAMG_E_ARG;
     }
     for (int k = 0; k < 4; ++k) { if (A->gs[k]) A->bytes -= A->gs[k]->bytes; free_schedule(A->gs[k]); A->gs[k] = nullptr; }

@@ -59,9 +59,9 @@ class DeviceMatrix:
         capi.check(capi.lib().pamg_matrix_flow_error(self.handle, C.byref(e)), "pamg_matrix_flow_error")
         return bool(e.value)
 
-    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, flow_force=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None):
+    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, flow_force=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, xwin=None):
         lib = capi.lib()
-        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (4, flow_force), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags)):
+        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (4, flow_force), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (9, xwin)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 

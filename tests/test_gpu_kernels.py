@@ -322,3 +322,33 @@ def test_resid_sumsq_two_stage_reduction():
     dA.resid_sumsq(dx, db, out)
     r = b - A @ x
     assert np.isclose(out.download()[0], np.dot(r, r), rtol=1e-13)
+
+
+def test_lds_x_window_variant_bit_exact():
+    """The opt-in LDS-staged x-window kernels (tune key 9) give the same bits as the default
+    gather, on a banded operator (windows apply) and on an irregular one (fallback per range)."""
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(9)
+    A = poisson_csr((40, 36, 30))
+    S = sp.random(5000, 5000, density=0.003, random_state=rng, format="csr")
+    S = sp.csr_array(S + sp.diags_array(rng.rand(5000) + 3.0))
+    S.sort_indices()
+    for M in (A, S):
+        n = M.shape[0]
+        x = rng.rand(n); b = rng.rand(n)
+        dM = DeviceMatrix(sparse_op(M))
+        dx, db = _dev(x, b)
+        outs = []
+        for xw in (0, 1):
+            dM.tune(lds_entries=512, max_rows=256, xwin=xw)
+            dy = capi.DeviceArray(n, np.float64)
+            dM.spmv(capi.SPMV_RESID, dx, dy, b=db)
+            dj = capi.DeviceArray.from_host(x)
+            work = capi.DeviceArray(n, np.float64)
+            dM.jacobi(dj, db, work, 0.8, iterations=3)
+            ss = capi.DeviceArray(1, np.float64)
+            dM.resid_sumsq(dx, db, ss)
+            outs.append((dy.download(), dj.download(), ss.download()[0]))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][0], b - M @ x)
+        assert np.array_equal(outs[0][1], outs[1][1])
+        assert outs[0][2] == outs[1][2]

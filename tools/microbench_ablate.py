@@ -47,3 +47,15 @@ print(json.dumps({k: v for k, v in out.items() if "vec" in k}))
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
 (ROOT / "gpurun_out" / "microbench_ablate.json").write_text(json.dumps(out, indent=1))
 
+
+# LDS-staged x windows (tune key 9); ranges capped at 256 rows so that they map one row per lane
+dj = capi.DeviceArray.from_host(rng.rand(n)); dw = capi.DeviceArray(n, np.float64)
+for cap in (1024, 1536, 2048):
+    for xw in (0, 1):
+        dA.tune(lds_entries=cap, nnz_per_lane=2, stream_flags=0, max_rows=256, xwin=xw)
+        dA.spmv(capi.SPMV_SET, dx, dy)
+        assert np.array_equal(dy.download(), ref), (cap, xw)
+        ms = timeit(lambda: dA.spmv(capi.SPMV_RESID, dx, dy, b=db), 20)
+        msj = timeit(lambda: dA.jacobi(dj, db, dw, 0.7, 2), 10) / 2
+        print("xwin cap", cap, "on" if xw else "off", "resid ms", round(ms, 4), "GB/s", round((B + 8 * n) / ms / 1e6, 1),
+              "| jacobi ms", round(msj, 4), flush=True)
