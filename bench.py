@@ -89,8 +89,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # PAMG_BENCH_BACKEND=gloo + PAMG_BENCH_ONE_GPU=1: rehearsal of the N > 1 control flow on a
+        # single-GPU box (all ranks on device 0, host-staged transport); production = nccl (RCCL)
+        backend = os.environ.get("PAMG_BENCH_BACKEND", "nccl")
+        if os.environ.get("PAMG_BENCH_ONE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     from pyamg_amd import DeviceMultilevelSolver, _capi as capi
     from pyamg_amd.hierarchy import extract
     from tools.problems import spmv_bytes
@@ -111,7 +119,7 @@ def main():
 
     def max_over_ranks(v):
         if world > 1:
-            t = torch.tensor([v], dtype=torch.float64, device="cuda")
+            t = torch.tensor([v], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         return v
@@ -259,8 +267,8 @@ def main():
             w2, _, res2, _, _ = time_resident(d2, b, x0, steps2, args.warmup)
             d2.free()
         else:
-            from pyamg_amd.dist import DistMultilevelSolver
-            d2 = DistMultilevelSolver(spec, min_rows=args.min_rows)
+            from pyamg_amd.dist import DeviceOps, DistMultilevelSolver
+            d2 = DistMultilevelSolver(spec, ops=DeviceOps(local_rank, spec.dtype), min_rows=args.min_rows)
             d2.load(b, x0)
             res2 = d2.iterate(6)
             d2.load(b, x0)

@@ -256,6 +256,7 @@ class DistMultilevelSolver:
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._gloo = dist.get_backend(group) == "gloo"
         self.ops = ops if ops is not None else DeviceOps(int(__import__("os").environ.get("LOCAL_RANK", self.rank)),
                                                          spec.dtype)
         self.spec = spec
@@ -288,6 +289,19 @@ class DistMultilevelSolver:
         return any(s is not None and s.kind == "polynomial" for s in (L.pre, L.post))
 
     # ---- communication
+    def _staged(self, t):
+        """gloo cannot move device memory point-to-point: stage through the host then (single-GPU
+        test rigs; RCCL moves device buffers directly)."""
+        return self._gloo and getattr(t, "is_cuda", False)
+
+    def _all_reduce(self, t):
+        if self._staged(t):
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, group=self.group)
+
     def exchange(self, l, v):
         """Fill the halo part of level-l vector ``v`` from its owners."""
         plan = self.sh.plans[l]
@@ -296,6 +310,16 @@ class DistMultilevelSolver:
         dist = self.dist
         if plan.send_idx.size:
             self.ops.gather(plan.send_idx.size, self.send_idx[l], v, self.send_buf[l])
+        if self._staged(v):
+            sb = self.send_buf[l].cpu()
+            rb = sb.new_zeros(max(plan.n_halo, 1))
+            reqs = [dist.P2POp(dist.irecv, rb[beg:beg + cnt], self._peer(src), self.group) for (src, beg, cnt) in plan.recv]
+            reqs += [dist.P2POp(dist.isend, sb[beg:beg + cnt], self._peer(dst), self.group) for (dst, beg, cnt) in plan.send]
+            for w in dist.batch_isend_irecv(reqs):
+                w.wait()
+            if plan.n_halo:
+                v[plan.n_owned:plan.n_owned + plan.n_halo].copy_(rb[:plan.n_halo])
+            return
         reqs = []
         for (src, beg, cnt) in plan.recv:
             reqs.append(dist.P2POp(dist.irecv, v[plan.n_owned + beg: plan.n_owned + beg + cnt], self._peer(src), self.group))
@@ -360,7 +384,7 @@ class DistMultilevelSolver:
             self.bc_full.zero_()
             o.spmv(self.R[l], 0, self.r[l], self.b[sh.ns])               # owned slice of b_c
             self.bc_full[c0: c0 + cplan.n_owned].copy_(self.b[sh.ns][:cplan.n_owned])
-            self.dist.all_reduce(self.bc_full, group=self.group)         # disjoint slices -> full b_c everywhere
+            self._all_reduce(self.bc_full)                               # disjoint slices -> full b_c everywhere
             self.xc_full.zero_()
             o.coarse_cycle(self.coarse, self.xc_full, self.bc_full, cycle)
             o.gather(cplan.n_local, self.c_fill_idx, self.xc_full, self.x[sh.ns])
@@ -370,7 +394,7 @@ class DistMultilevelSolver:
     def resid_norm(self):
         self.exchange(0, self.x[0])
         ss = self.ops.resid_sumsq(self.A[0], self.x[0], self.b[0])
-        self.dist.all_reduce(ss, group=self.group)
+        self._all_reduce(ss)
         return float(np.sqrt(float(ss.item())))
 
     def load(self, b, x0):
@@ -394,7 +418,7 @@ class DistMultilevelSolver:
         full.zero_()
         r0 = int(p.off[self.rank])
         full[r0:r0 + p.n_owned].copy_(self.x[0][:p.n_owned])
-        self.dist.all_reduce(full, group=self.group)
+        self._all_reduce(full)
         return self.ops.to_host(full, self.shape[0])
 
     def solve(self, b, x0=None, tol=1e-5, maxiter=100, cycle="V", residuals=None, return_info=False):

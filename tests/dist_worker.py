@@ -107,16 +107,10 @@ def run(rank, world, port, name, backend, min_rows, out_dir):
     spec, ex = load_spec(ROOT / "tests" / "golden" / f"hier_{name}.npz")
     if backend == "device":
         from pyamg_amd.dist import DeviceOps
-
-        class StagedDeviceOps(DeviceOps):
-            """DeviceOps whose buffers live on the GPU but whose collectives go through gloo
-            (this box has ONE GPU shared by the ranks): stage through host tensors."""
-        ops = DeviceOps(0, spec.dtype)
+        ops = DeviceOps(0, spec.dtype)          # ranks share the box's one GPU; dist.py stages gloo traffic via host
     else:
         ops = OracleOps(spec.dtype)
     sol = DistMultilevelSolver(spec, ops=ops, min_rows=min_rows)
-    if backend == "device":
-        _patch_gloo_staging(sol, torch, dist)
     k = int(ex["k"])
     res = []
     x = sol.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=k, residuals=res)
@@ -124,38 +118,6 @@ def run(rank, world, port, name, backend, min_rows, out_dir):
              halo=np.array([p.n_halo for p in sol.sh.plans]))
     dist.barrier()
     dist.destroy_process_group()
-
-
-def _patch_gloo_staging(sol, torch, dist):
-    """Route the solver's communication through host tensors (gloo cannot move GPU memory)."""
-    def exchange(l, v):
-        plan = sol.sh.plans[l]
-        if not plan.send and not plan.recv:
-            return
-        if plan.send_idx.size:
-            sol.ops.gather(plan.send_idx.size, sol.send_idx[l], v, sol.send_buf[l])
-        sb = sol.send_buf[l].cpu()
-        rb = torch.zeros(max(plan.n_halo, 1), dtype=v.dtype)
-        reqs = []
-        for (src, beg, cnt) in plan.recv:
-            reqs.append(dist.P2POp(dist.irecv, rb[beg:beg + cnt], src))
-        for (dst, beg, cnt) in plan.send:
-            reqs.append(dist.P2POp(dist.isend, sb[beg:beg + cnt], dst))
-        for w in dist.batch_isend_irecv(reqs):
-            w.wait()
-        if plan.n_halo:
-            v[plan.n_owned:plan.n_owned + plan.n_halo].copy_(rb[:plan.n_halo])
-    sol.exchange = exchange
-
-    class _D:
-        def __getattr__(self, k):
-            return getattr(dist, k)
-
-        def all_reduce(self, t, group=None):
-            h = t.cpu()
-            dist.all_reduce(h)
-            t.copy_(h)
-    sol.dist = _D()
 
 
 if __name__ == "__main__":
