@@ -352,3 +352,30 @@ def test_lds_x_window_variant_bit_exact():
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][0], b - M @ x)
         assert np.array_equal(outs[0][1], outs[1][1])
         assert outs[0][2] == outs[1][2]
+
+
+def test_relaxation_module_block_doctests_and_polynomial():
+    """Device twins reproduce the reference's doctest values (relaxation.py:449-460, 529-541) and
+    the explicit Horner expressions of test_relaxation.py:115-146."""
+    T = sp.diags_array([2 * np.ones(10), -np.ones(10), -np.ones(10)], offsets=[0, -1, 1], shape=(10, 10), format="csr")
+    I = sp.eye_array(10, format="csr")
+    A = sp.csr_array(sp.kron(I, T) + sp.kron(T, I)); A.sort_indices()
+    B = A.tobsr(blocksize=(4, 4))
+    Dinv = np.zeros((25, 4, 4))
+    for i in range(25):
+        for p in range(B.indptr[i], B.indptr[i + 1]):
+            if B.indices[p] == i:
+                Dinv[i] = np.linalg.pinv(B.data[p])
+    b = np.ones((100, 1))
+    x = np.zeros((100, 1)); grelax.block_jacobi(A, x, b, Dinv=Dinv, blocksize=4, iterations=10, omega=1.0)
+    assert f"{np.linalg.norm(b - A @ x):2.4}" == "4.665"
+    x = np.zeros((100, 1)); grelax.block_gauss_seidel(A, x, b, iterations=10, blocksize=4, sweep="symmetric", Dinv=Dinv)
+    assert f"{np.linalg.norm(b - A @ x):2.4}" == "0.9583"
+    T3 = sp.diags_array([2 * np.ones(3), -np.ones(3), -np.ones(3)], offsets=[0, -1, 1], shape=(3, 3), format="csr")
+    x0 = np.arange(3, dtype=float)
+    bv = np.array([10.0, 20.0, 30.0])
+    r = bv - T3 @ x0
+    x = x0.copy(); grelax.polynomial(T3, x, bv, [-0.14285714, 1.0, -2.0])
+    np.testing.assert_almost_equal(x, x0 - 0.14285714 * T3 @ T3 @ r + T3 @ r - 2 * r)
+    x = 0 * x0; grelax.polynomial(T3, x, bv, [-0.14285714, 1.0, -2.0])
+    np.testing.assert_almost_equal(x, -0.14285714 * T3 @ T3 @ bv + T3 @ bv - 2 * bv)

@@ -139,3 +139,23 @@ def test_extract_reads_back_smoother_parameters():
     ml4 = pyamg.smoothed_aggregation_solver(A, max_coarse=10, coarse_solver="cg")
     with pytest.raises(NotImplementedError):
         H.extract(ml4)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/pyamg_amd.h compiles as C99 and a C translation unit that references every
+    declared entry point links against libpyamg_amd.so (no call is made: no GPU here)."""
+    import subprocess
+    hdr = (ROOT / "include" / "pyamg_amd.h").read_text()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(pamg_[a-z0-9_]+)\s*\(", hdr_nc)))
+    src = tmp_path / "abi.c"
+    body = "\n".join(f"    tab[{i}] = (fn_t)&{n};" for i, n in enumerate(names))
+    src.write_text(f'#include "pyamg_amd.h"\n#include <stdio.h>\ntypedef void (*fn_t)(void);\nint main(void) {{\n'
+                   f'    fn_t tab[{len(names)}];\n{body}\n'
+                   f'    printf("%d %d\\n", {len(names)}, tab[0] != 0);\n    return 0;\n}}\n')
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(src),
+                        f"-L{capi.LIB_PATH.parent}", "-lpyamg_amd", f"-Wl,-rpath,{capi.LIB_PATH.parent}",
+                        "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
