@@ -82,6 +82,7 @@ struct GsSchedule {
     int4 *d_blkmeta = nullptr;
     void *d_Ax = nullptr, *d_diag = nullptr;
     int *d_level_blk = nullptr;      // device copy of level_blk (persistent sweep kernel)
+    int *d_pblk = nullptr;           // block schedules: position of scheduled block q in the operator's block arrays
     void *d_xs = nullptr;            // granular sweep: hand-off buffer (one value per matrix row)
     bool symmetric = false;          // pattern among swept rows is structurally symmetric
     int nblk_total = 0;
@@ -106,6 +107,8 @@ struct pamg_matrix_s {
     int *d_bAp = nullptr, *d_bAj = nullptr;   // nullptr when R == C == 1
     void *d_bAx = nullptr;                    // block-ordered values (square blocks only)
     int64_t nblocks_b = 0;
+    int4 *d_bmeta = nullptr;                  // row-range plan over block rows (LDS-streamed BSR relaxation)
+    int bnblk = 0;
     // host copies of the index arrays (needed for lazy GS analysis / re-planning)
     std::vector<int> h_Ap, h_Aj;
     std::vector<int> h_bAp, h_bAj;

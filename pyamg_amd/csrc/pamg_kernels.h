@@ -842,37 +842,24 @@ struct BlockArgs {
 };
 
 
-template <typename T, int KIND>
-__global__ __launch_bounds__(BLK) void block_relax_kernel(const BlockArgs<T> a)
+template <int COH, typename T>
+__device__ __forceinline__ void stxb(T *p, T v)
 {
-    const int t = blockIdx.x * BLK + threadIdx.x;
-    if (t >= a.count) return;
-    const int i = a.rid ? a.rid[a.first + t] : a.first + t;
+    if constexpr (COH == 1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// tail of one block row: acc = sum (block Jacobi/GS) or b - sum (BSR point variants) of the
+// off-diagonal block products is given; apply Dinv / run the point sweep inside the diagonal
+// block (dpos = offset of the diagonal block in Ax or -1) and store.  Arithmetic order follows
+// amg_core::block_jacobi / block_gauss_seidel (relaxation.h:1021-1090, 1242-1298) and
+// bsr_jacobi / bsr_gauss_seidel (:472-562, :185-266).
+template <typename T, int KIND, int COH>
+__device__ __forceinline__ void block_row_finish(const BlockArgs<T> &a, const int i, T (&acc)[MAXBS], long dpos)
+{
     const int bs = a.bs, bb = bs * bs;
-    T acc[MAXBS], v[MAXBS];
-    long dpos = -1;
-    if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
-        for (int k = 0; k < bs; ++k) acc[k] = T(0);
-    } else {
-        for (int k = 0; k < bs; ++k) acc[k] = a.b[(long)i * bs + k];
-    }
-    for (int p = a.bAp[i]; p < a.bAp[i + 1]; ++p) {
-        const int j = a.bAj[p];
-        if (j == i) { dpos = (long)p * bb; continue; }
-        const T *blk = a.Ax + (long)p * bb;
-        const T *xj = a.xsrc + (long)j * bs;
-        for (int r = 0; r < bs; ++r) {
-            T d = T(0);
-            for (int c = 0; c < bs; ++c) d += blk[r * bs + c] * xj[c];
-            v[r] = d;
-        }
-        if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
-            for (int k = 0; k < bs; ++k) acc[k] += v[k];
-        } else {
-            for (int k = 0; k < bs; ++k) acc[k] -= v[k];
-        }
-    }
     const T one = T(1);
+    T v[MAXBS];
     if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
         for (int k = 0; k < bs; ++k) acc[k] = a.b[(long)i * bs + k] - acc[k];
         const T *Di = a.Dinv + (long)i * bb;
@@ -885,12 +872,12 @@ __global__ __launch_bounds__(BLK) void block_relax_kernel(const BlockArgs<T> a)
             for (int k = 0; k < bs; ++k)
                 a.xdst[(long)i * bs + k] = (one - a.omega) * a.xsrc[(long)i * bs + k] + a.omega * v[k];
         } else {
-            for (int k = 0; k < bs; ++k) a.xdst[(long)i * bs + k] = v[k];
+            for (int k = 0; k < bs; ++k) stxb<COH>(a.xdst + (long)i * bs + k, v[k]);
         }
     } else {
         // point sweep inside the diagonal block (untouched when no diagonal block is stored)
         T loc[MAXBS];
-        for (int k = 0; k < bs; ++k) loc[k] = a.xsrc[(long)i * bs + k];
+        for (int k = 0; k < bs; ++k) loc[k] = ldx<COH>(a.xsrc + (long)i * bs + k);
         if (dpos >= 0) {
             const T *D = a.Ax + dpos;
             const int k0 = a.dirn > 0 ? 0 : bs - 1, k1 = a.dirn > 0 ? bs : -1;
@@ -905,7 +892,7 @@ __global__ __launch_bounds__(BLK) void block_relax_kernel(const BlockArgs<T> a)
                         a.xdst[(long)i * bs + k] = (one - a.omega) * loc[k] + a.omega * acc[k] / d;
                     } else {
                         loc[k] = acc[k] / d;            // GS: later points see the new value
-                        a.xdst[(long)i * bs + k] = loc[k];
+                        stxb<COH>(a.xdst + (long)i * bs + k, loc[k]);
                     }
                 } else if constexpr (KIND == PNT_JACOBI) {
                     a.xdst[(long)i * bs + k] = loc[k];
@@ -913,6 +900,143 @@ __global__ __launch_bounds__(BLK) void block_relax_kernel(const BlockArgs<T> a)
             }
         } else if constexpr (KIND == PNT_JACOBI) {
             for (int k = 0; k < bs; ++k) a.xdst[(long)i * bs + k] = loc[k];
+        }
+    }
+}
+
+// one block row i, everything by one lane (simple fallback path)
+template <typename T, int KIND, int COH>
+__device__ __forceinline__ void block_relax_row(const BlockArgs<T> &a, const int i)
+{
+    const int bs = a.bs, bb = bs * bs;
+    T acc[MAXBS], v[MAXBS];
+    long dpos = -1;
+    if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
+        for (int k = 0; k < bs; ++k) acc[k] = T(0);
+    } else {
+        for (int k = 0; k < bs; ++k) acc[k] = a.b[(long)i * bs + k];
+    }
+    for (int p = a.bAp[i]; p < a.bAp[i + 1]; ++p) {
+        const int j = a.bAj[p];
+        if (j == i) { dpos = (long)p * bb; continue; }
+        const T *blk = a.Ax + (long)p * bb;
+        const T *xj = a.xsrc + (long)j * bs;
+        T xv[MAXBS];
+        for (int c = 0; c < bs; ++c) xv[c] = ldx<COH>(xj + c);
+        for (int r = 0; r < bs; ++r) {
+            T d = T(0);
+            for (int c = 0; c < bs; ++c) d += blk[r * bs + c] * xv[c];
+            v[r] = d;
+        }
+        if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
+            for (int k = 0; k < bs; ++k) acc[k] += v[k];
+        } else {
+            for (int k = 0; k < bs; ++k) acc[k] -= v[k];
+        }
+    }
+    block_row_finish<T, KIND, COH>(a, i, acc, dpos);
+}
+
+// ---- LDS-streamed BSR relaxation ----------------------------------------------------------
+// Same two-phase idea as csr_stream_kernel at block granularity: phase 1, one lane per (block,
+// block-row r) pair computes the in-order dot of that block row with x_j -- all blocks of the
+// row range in parallel, coalesced over the contiguous block values -- and parks it in LDS;
+// phase 2, one lane per block row adds the per-block vectors in storage order and runs the
+// (tiny, sequential) diagonal-block tail.  A block row with 40 6x6 blocks is 1440 multiply-adds
+// that the one-lane-per-row kernel executes serially; here they spread over 240 lanes.
+template <typename T>
+struct BsrRange {
+    const int4 *meta;      // [ranges] {first row, end row, first block, end block} in schedule order
+    const int *pAp;        // [rows+1] cumulative block count in schedule order
+    const int *pblk;       // [blocks] position of scheduled block q in Ax/bAj (nullptr = identity)
+    const int *pbj;        // [blocks] block column of scheduled block q
+    int capv;              // LDS capacity in values
+};
+
+template <typename T, int KIND, int COH>
+__device__ __forceinline__ void bsr_range(const BlockArgs<T> &a, const BsrRange<T> &g, const int4 m, T *prodv)
+{
+    const int bs = a.bs, bb = bs * bs;
+    const int r0 = m.x, r1 = m.y, q0 = m.z, q1 = m.w;
+    const int tid = threadIdx.x;
+    const int nent = (q1 - q0) * bs;
+    if (nent <= g.capv) {
+        for (int e = tid; e < nent; e += BLK) {
+            const int q = q0 + e / bs, r = e % bs;
+            const long p = g.pblk ? g.pblk[q] : q;
+            const T *Arow = a.Ax + p * bb + r * bs;
+            const T *xj = a.xsrc + (long)g.pbj[q] * bs;
+            T d = T(0);
+            for (int c = 0; c < bs; ++c) d += Arow[c] * ldx<COH>(xj + c);
+            prodv[e] = d;
+        }
+        __syncthreads();
+        for (int r = r0 + tid; r < r1; r += BLK) {
+            const int i = a.rid ? a.rid[r] : r;
+            T acc[MAXBS];
+            long dpos = -1;
+            if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
+                for (int k = 0; k < bs; ++k) acc[k] = T(0);
+            } else {
+                for (int k = 0; k < bs; ++k) acc[k] = a.b[(long)i * bs + k];
+            }
+            for (int q = g.pAp[r]; q < g.pAp[r + 1]; ++q) {
+                if (g.pbj[q] == i) { dpos = (long)(g.pblk ? g.pblk[q] : q) * bb; continue; }
+                const T *v = prodv + (q - q0) * bs;
+                if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
+                    for (int k = 0; k < bs; ++k) acc[k] += v[k];
+                } else {
+                    for (int k = 0; k < bs; ++k) acc[k] -= v[k];
+                }
+            }
+            block_row_finish<T, KIND, COH>(a, i, acc, dpos);
+        }
+    } else {
+        // over-long block row (own range): the simple one-lane path
+        if (tid == 0) block_relax_row<T, KIND, COH>(a, a.rid ? a.rid[r0] : r0);
+    }
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(BLK) void bsr_stream_kernel(const BlockArgs<T> a, const BsrRange<T> g, int first)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bsr_range<T, KIND, 0>(a, g, g.meta[first + (int)blockIdx.x], reinterpret_cast<T *>(smem_raw));
+}
+
+// persistent order-exact block sweep over row ranges: levels separated by __syncthreads() (one
+// workgroup) or by the arrival-counter barrier with coherent x traffic (several workgroups)
+template <typename T, int KIND, bool COH>
+__global__ __launch_bounds__(BLK) void bsr_flow_kernel(const BlockArgs<T> a, const BsrRange<T> g, const int *level_blk,
+                                                       int nlevels, unsigned *sync)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *prodv = reinterpret_cast<T *>(smem_raw);
+    const int G = (int)gridDim.x;
+    int lb = level_blk[0];
+    for (int l = 0; l < nlevels; ++l) {
+        const int le = level_blk[l + 1];
+        for (int blk = lb + (int)blockIdx.x; blk < le; blk += G) {
+            bsr_range<T, KIND, COH ? 1 : 0>(a, g, g.meta[blk], prodv);
+            __syncthreads();
+        }
+        lb = le;
+        if constexpr (COH) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const unsigned target = (unsigned)(l + 1) * (unsigned)G;
+                __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {
+                        __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }

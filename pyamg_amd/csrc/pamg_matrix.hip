@@ -140,6 +140,13 @@ int replan(pamg_matrix_s *A)
     plan_rows(A->h_Ap.data(), 0, (int)A->nrows, A->cap, A->max_rows, blk);
     A->nblk = (int)blk.size();
     PAMG_TRY(upload(&A->d_blkmeta, blk.data(), blk.size(), nullptr));
+    if (A->d_bmeta) { hipFree(A->d_bmeta); A->d_bmeta = nullptr; A->bnblk = 0; }
+    if (A->R > 1 && A->R == A->C && !A->h_bAp.empty()) {
+        std::vector<int4> bb;
+        plan_rows(A->h_bAp.data(), 0, A->n_brow, std::max(1, A->cap / A->R), BLK, bb);
+        A->bnblk = (int)bb.size();
+        PAMG_TRY(upload(&A->d_bmeta, bb.data(), bb.size(), nullptr));
+    }
     if (A->use_xwin && A->R == 1 && A->npl == 2) PAMG_TRY(plan_windows(A, blk, std::max(256, A->cap)));
     else if (A->d_xwin) { hipFree(A->d_xwin); A->d_xwin = nullptr; }
     PAMG_HIP(hipMalloc((void **)&A->d_partial, sizeof(double) * (size_t)(A->nblk + 264)));
@@ -192,7 +199,7 @@ int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap)
 void free_schedule(GsSchedule *g)
 {
     if (!g) return;
-    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs);
+    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_pblk);
     delete g;
 }
 
@@ -345,7 +352,9 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
     return PAMG_OK;
 }
 
-// schedule for the block path (bs > 1): level-ordered list of block rows only
+// schedule for the block path (bs > 1): block rows in level order plus, per scheduled block,
+// its position in the operator's block arrays and its block column (the values stay where
+// they are: a block row is >= 0.5 KB of contiguous values, which streams well as it is)
 int build_schedule_block(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out)
 {
     std::vector<int> order, lptr;
@@ -356,8 +365,33 @@ int build_schedule_block(pamg_matrix_s *A, int row_start, int row_stop, int row_
     g->row_start = row_start; g->row_stop = row_stop; g->row_step = row_step;
     g->nlevels = (int)lptr.size() - 1;
     g->nrows = (int64_t)order.size();
-    g->level_blk = lptr;                       // here: row offsets of each level
+    const int m = (int)order.size();
+    std::vector<int> pAp((size_t)m + 1, 0);
+    for (int r = 0; r < m; ++r) pAp[r + 1] = pAp[r] + (A->h_bAp[order[r] + 1] - A->h_bAp[order[r]]);
+    g->nnz = pAp[m];
+    std::vector<int> pblk((size_t)g->nnz), pbj((size_t)g->nnz);
+    for (int r = 0; r < m; ++r) {
+        const int i = order[r];
+        int q = pAp[r];
+        for (int p = A->h_bAp[i]; p < A->h_bAp[i + 1]; ++p, ++q) { pblk[q] = p; pbj[q] = A->h_bAj[p]; }
+    }
+    std::vector<int4> blk;
+    g->level_blk.assign(1, 0);
+    for (int l = 0; l < g->nlevels; ++l) {
+        plan_rows(pAp.data(), lptr[l], lptr[l + 1], std::max(1, A->cap / A->R), BLK, blk);
+        g->level_blk.push_back((int)blk.size());
+    }
+    g->nblk_total = (int)blk.size();
+    for (int l = 0; l < g->nlevels; ++l)
+        g->max_level_blocks = std::max(g->max_level_blocks, g->level_blk[l + 1] - g->level_blk[l]);
     int st = upload(&g->d_rid, order.data(), order.size(), &g->bytes);
+    if (!st) st = upload(&g->d_Ap, pAp.data(), pAp.size(), &g->bytes);
+    if (!st) st = upload(&g->d_pblk, pblk.data(), pblk.size(), &g->bytes);
+    if (!st) st = upload(&g->d_Aj, pbj.data(), pbj.size(), &g->bytes);
+    if (!st) st = upload(&g->d_blkmeta, blk.data(), blk.size(), &g->bytes);
+    if (!st) st = upload(&g->d_level_blk, g->level_blk.data(), g->level_blk.size(), &g->bytes);
+    if (!st) st = (int)hipMalloc((void **)&g->d_sync, 2048);
+    if (!st) st = (int)hipMemset(g->d_sync, 0, 2048);
     if (st) { free_schedule(g); return st; }
     *out = g;
     return PAMG_OK;
@@ -577,30 +611,66 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
 }
 
 template <typename T>
-static int block_launch(pamg_matrix_s *A, int kind, const int *rid, int first, int count,
-                        const void *Dinv, const void *xsrc, void *xdst, const void *b, double omega,
-                        int dirn, hipStream_t s)
+static BlockArgs<T> block_args(pamg_matrix_s *A, const int *rid, const void *Dinv, const void *xsrc, void *xdst,
+                               const void *b, double omega, int dirn)
 {
-    if (count <= 0) return PAMG_OK;
     BlockArgs<T> a;
     a.bAp = A->d_bAp; a.bAj = A->d_bAj;
     a.Ax = (const T *)A->d_bAx;                // block-ordered values
     a.rid = rid; a.Dinv = (const T *)Dinv;
     a.xsrc = (const T *)xsrc; a.xdst = (T *)xdst; a.b = (const T *)b;
-    a.omega = (T)omega; a.bs = A->R; a.first = first; a.count = count; a.dirn = dirn;
-    const int grid = (count + BLK - 1) / BLK;
+    a.omega = (T)omega; a.bs = A->R; a.first = 0; a.count = A->n_brow; a.dirn = dirn;
+    return a;
+}
+
+template <typename T>
+static int bsr_stream_launch(int kind, int grid, int lds, hipStream_t s, const BlockArgs<T> &a, const BsrRange<T> &g, int first)
+{
+    if (grid <= 0) return PAMG_OK;
     switch (kind) {
-        case BLK_JACOBI: hipLaunchKernelGGL((block_relax_kernel<T, BLK_JACOBI>), dim3(grid), dim3(BLK), 0, s, a); break;
-        case BLK_GS: hipLaunchKernelGGL((block_relax_kernel<T, BLK_GS>), dim3(grid), dim3(BLK), 0, s, a); break;
-        case PNT_JACOBI: hipLaunchKernelGGL((block_relax_kernel<T, PNT_JACOBI>), dim3(grid), dim3(BLK), 0, s, a); break;
-        case PNT_GS: hipLaunchKernelGGL((block_relax_kernel<T, PNT_GS>), dim3(grid), dim3(BLK), 0, s, a); break;
+        case BLK_JACOBI: hipLaunchKernelGGL((bsr_stream_kernel<T, BLK_JACOBI>), dim3(grid), dim3(BLK), lds, s, a, g, first); break;
+        case BLK_GS: hipLaunchKernelGGL((bsr_stream_kernel<T, BLK_GS>), dim3(grid), dim3(BLK), lds, s, a, g, first); break;
+        case PNT_JACOBI: hipLaunchKernelGGL((bsr_stream_kernel<T, PNT_JACOBI>), dim3(grid), dim3(BLK), lds, s, a, g, first); break;
+        case PNT_GS: hipLaunchKernelGGL((bsr_stream_kernel<T, PNT_GS>), dim3(grid), dim3(BLK), lds, s, a, g, first); break;
         default: return PAMG_E_ARG;
     }
     return (int)hipGetLastError();
 }
 
-// in-place order-exact sweep.  epi: EPI_GS / EPI_GS_B / EPI_SOR for scalar operators; for
-// block operators (bs > 1) epi selects PNT_GS (EPI_GS_B) or BLK_GS (EPI_GS with Dinv in b2).
+// order-exact block sweep (PNT_GS / BLK_GS) over a level schedule, same policy as the scalar
+// sweeps: narrow -> one persistent workgroup, medium -> persistent barrier grid, else launches
+template <typename T>
+static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *Dinv, void *x, const void *b, int dirn,
+                         hipStream_t s)
+{
+    BlockArgs<T> a = block_args<T>(A, g->d_rid, Dinv, x, x, b, 0.0, dirn);
+    a.count = (int)g->nrows;
+    BsrRange<T> r;
+    r.meta = g->d_blkmeta; r.pAp = g->d_Ap; r.pblk = g->d_pblk; r.pbj = g->d_Aj; r.capv = A->cap;
+    const int lds = std::max(64, (int)tsize(A->dtype) * (A->cap + 8));
+    const bool narrow = (int64_t)g->nblk_total * 16 <= (int64_t)g->nlevels * A->flow_cap;
+    int G = 0;
+    if (A->flow_cap > 0 && g->nlevels > 1) {
+        G = narrow ? 1 : std::min(256, g->max_level_blocks);
+        if (A->flow_force) G = std::max(1, std::min(std::min(256, g->max_level_blocks), A->flow_cap));
+        else if (G > 128) G = 0;
+    }
+    if (G > 0) {
+        if (G > 1) PAMG_HIP(hipMemsetAsync(g->d_sync, 0, 2048, s));
+#define PAMG_BF(K)                                                                                                          \
+        if (G == 1) hipLaunchKernelGGL((bsr_flow_kernel<T, K, false>), dim3(1), dim3(BLK), lds, s, a, r, g->d_level_blk, g->nlevels, g->d_sync); \
+        else hipLaunchKernelGGL((bsr_flow_kernel<T, K, true>), dim3(G), dim3(BLK), lds, s, a, r, g->d_level_blk, g->nlevels, g->d_sync);
+        if (kind == PNT_GS) { PAMG_BF(PNT_GS) } else { PAMG_BF(BLK_GS) }
+#undef PAMG_BF
+        return (int)hipGetLastError();
+    }
+    for (int l = 0; l < g->nlevels; ++l)
+        PAMG_TRY(bsr_stream_launch<T>(kind, g->level_blk[l + 1] - g->level_blk[l], lds, s, a, r, g->level_blk[l]));
+    return PAMG_OK;
+}
+
+// in-place order-exact sweep.  epi: EPI_GS / EPI_GS_B / EPI_SOR for scalar operators; block
+// operators (bs > 1) run the BSR point sweep (amg_core::bsr_gauss_seidel).
 int gs_sweep(pamg_matrix_s *A, int epi, void *x, const void *b, double omega, int row_start,
              int row_stop, int row_step, hipStream_t s)
 {
@@ -611,13 +681,8 @@ int gs_sweep(pamg_matrix_s *A, int epi, void *x, const void *b, double omega, in
                                     : gs_sweep_scalar_t<float>(A, g, epi, x, b, omega, s);
     }
     const int dirn = row_step < 0 ? -1 : 1;
-    for (int l = 0; l < g->nlevels; ++l) {
-        const int first = g->level_blk[l], count = g->level_blk[l + 1] - first;
-        PAMG_TRY(A->dtype == PAMG_F64
-                     ? block_launch<double>(A, PNT_GS, g->d_rid, first, count, nullptr, x, x, b, omega, dirn, s)
-                     : block_launch<float>(A, PNT_GS, g->d_rid, first, count, nullptr, x, x, b, omega, dirn, s));
-    }
-    return PAMG_OK;
+    return A->dtype == PAMG_F64 ? block_sweep_t<double>(A, g, PNT_GS, nullptr, x, b, dirn, s)
+                                : block_sweep_t<float>(A, g, PNT_GS, nullptr, x, b, dirn, s);
 }
 
 int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, int row_start,
@@ -625,21 +690,24 @@ int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, i
 {
     GsSchedule *g = nullptr;
     PAMG_TRY(get_schedule(A, row_start, row_stop, row_step, &g));
-    for (int l = 0; l < g->nlevels; ++l) {
-        const int first = g->level_blk[l], count = g->level_blk[l + 1] - first;
-        PAMG_TRY(A->dtype == PAMG_F64
-                     ? block_launch<double>(A, BLK_GS, g->d_rid, first, count, Dinv, x, x, b, 0.0, 1, s)
-                     : block_launch<float>(A, BLK_GS, g->d_rid, first, count, Dinv, x, x, b, 0.0, 1, s));
-    }
-    return PAMG_OK;
+    return A->dtype == PAMG_F64 ? block_sweep_t<double>(A, g, BLK_GS, Dinv, x, b, 1, s)
+                                : block_sweep_t<float>(A, g, BLK_GS, Dinv, x, b, 1, s);
 }
 
+// one out-of-place Jacobi-type step over all block rows (BLK_JACOBI / PNT_JACOBI)
 int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *xsrc, void *xdst,
                       const void *b, double omega, hipStream_t s)
 {
-    return A->dtype == PAMG_F64
-               ? block_launch<double>(A, kind, nullptr, 0, A->n_brow, Dinv, xsrc, xdst, b, omega, 1, s)
-               : block_launch<float>(A, kind, nullptr, 0, A->n_brow, Dinv, xsrc, xdst, b, omega, 1, s);
+    if (!A->d_bmeta) return PAMG_E_STATE;
+    const int lds = std::max(64, (int)tsize(A->dtype) * (A->cap + 8));
+    if (A->dtype == PAMG_F64) {
+        BsrRange<double> r;
+        r.meta = A->d_bmeta; r.pAp = A->d_bAp; r.pblk = nullptr; r.pbj = A->d_bAj; r.capv = A->cap;
+        return bsr_stream_launch<double>(kind, A->bnblk, lds, s, block_args<double>(A, nullptr, Dinv, xsrc, xdst, b, omega, 1), r, 0);
+    }
+    BsrRange<float> r;
+    r.meta = A->d_bmeta; r.pAp = A->d_bAp; r.pblk = nullptr; r.pbj = A->d_bAj; r.capv = A->cap;
+    return bsr_stream_launch<float>(kind, A->bnblk, lds, s, block_args<float>(A, nullptr, Dinv, xsrc, xdst, b, omega, 1), r, 0);
 }
 
 int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step)
@@ -836,7 +904,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
 {
     if (!A) return PAMG_OK;
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag);
-    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin);
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     delete A;
     return PAMG_OK;

@@ -379,3 +379,35 @@ def test_relaxation_module_block_doctests_and_polynomial():
     np.testing.assert_almost_equal(x, x0 - 0.14285714 * T3 @ T3 @ r + T3 @ r - 2 * r)
     x = 0 * x0; grelax.polynomial(T3, x, bv, [-0.14285714, 1.0, -2.0])
     np.testing.assert_almost_equal(x, -0.14285714 * T3 @ T3 @ bv + T3 @ bv - 2 * bv)
+
+
+def test_block_sweep_modes_all_exact():
+    """Block/BSR-point Gauss-Seidel: per-level launches, single-workgroup persistent sweep and the
+    multi-workgroup barrier sweep all give the oracle's bits (BSR 2x2 on a 3-D grid)."""
+    from oracle import oracle as orc
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(12)
+    P = poisson_csr((24, 22, 20))
+    blk = np.array([[2.0, 0.3], [-0.4, 1.5]])
+    M = sp.kron(P, blk, format="bsr")
+    M = sp.bsr_array((M.data, M.indices.astype(np.int32), M.indptr.astype(np.int32)), shape=M.shape, blocksize=(2, 2))
+    op = sparse_op(M)
+    n = op.shape[0]
+    nb = n // 2
+    x = rng.rand(n); b = rng.rand(n)
+    Dinv = np.array([np.linalg.inv(np.asarray(M.data[p])) for i in range(nb)
+                     for p in range(M.indptr[i], M.indptr[i + 1]) if M.indices[p] == i])
+    ref_pnt = x.copy(); orc.relax_gauss_seidel(op, ref_pnt, b, 1, "symmetric")
+    ref_blk = x.copy(); orc.relax_block_gauss_seidel(op, ref_blk, b, Dinv, 2, 1, "symmetric")
+    dM = DeviceMatrix(op)
+    db = capi.DeviceArray.from_host(b)
+    dD = capi.DeviceArray.from_host(Dinv.reshape(-1))
+    for kw in (dict(flow_cap=0), dict(flow_cap=32), dict(flow_cap=256)):
+        dM.tune(**kw)
+        dx = capi.DeviceArray.from_host(x)
+        dM.gauss_seidel(dx, db, sweep="symmetric")
+        assert np.array_equal(dx.download(), ref_pnt), kw
+        dx.upload(x)
+        dM.block_gauss_seidel(dx, db, dD, sweep="symmetric")
+        assert np.array_equal(dx.download(), ref_blk), kw
+        assert not dM.flow_error(), kw
