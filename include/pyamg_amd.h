@@ -195,6 +195,11 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * whole-operator kernels: bit 0 non-temporal loads of the operator stream, bit 1 XCD-aware
  * row-range order; 9 = LDS-staged x windows for the whole-operator kernels (re-plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
+/* Pick the LDS window (key 0) and streaming flags (key 8) of the whole-operator kernels by timing
+ * y = A x on the device with a few candidates (results are bit-identical for every choice; this
+ * is speed only).  allow_cap = 0 keeps the LDS window (level schedules depend on it).  Operators
+ * below 4M stored entries are left alone.  Synchronises. */
+int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap);
 /* *error != 0: a persistent sweep of this operator hit its spin bound (synchronises) */
 int pamg_matrix_flow_error(pamg_matrix_t A, int *error);
 

@@ -946,6 +946,42 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
     return replan(A);
 }
 
+int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
+{
+    if (!A) return PAMG_E_ARG;
+    if (A->nnz < 4000000 || A->npl != 2) return PAMG_OK;
+    const size_t ts = tsize(A->dtype);
+    void *x = nullptr, *y = nullptr;
+    PAMG_HIP(hipMalloc(&x, (size_t)(A->ncols + 8) * ts));
+    if (hipMalloc(&y, (size_t)(A->nrows + 8) * ts) != hipSuccess) { hipFree(x); return (int)hipErrorOutOfMemory; }
+    hipMemset(x, 0, (size_t)(A->ncols + 8) * ts);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int cap0 = A->cap, fl0 = A->stream_flags;
+    const int caps[2] = {cap0, 512};
+    int best_cap = cap0, best_fl = fl0, st = PAMG_OK;
+    float best_ms = 1e30f;
+    for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK; ++ci) {
+        if (caps[ci] != A->cap) { A->cap = caps[ci]; st = replan(A); if (st) break; }
+        for (int fl = 0; fl < 2 && st == PAMG_OK; ++fl) {
+            A->stream_flags = (fl0 & ~1) | fl;
+            for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
+            hipEventRecord(e0, nullptr);
+            for (int r = 0; r < 4 && st == PAMG_OK; ++r) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
+            hipEventRecord(e1, nullptr);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (st == PAMG_OK && ms < best_ms * 0.98f) { best_ms = ms; best_cap = A->cap; best_fl = A->stream_flags; }
+        }
+    }
+    A->stream_flags = best_fl;
+    if (A->cap != best_cap) { A->cap = best_cap; const int s2 = replan(A); if (st == PAMG_OK) st = s2; }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(x); hipFree(y);
+    return st;
+}
+
 int pamg_matrix_flow_error(pamg_matrix_t A, int *error)
 {
     if (!A || !error) return PAMG_E_ARG;

@@ -54,6 +54,9 @@ class DeviceMatrix:
         keys = ("rows", "cols", "nnz", "row_blocks", "lds_entries", "hbm_bytes", "gs_levels_fwd", "gs_levels_bwd")
         return dict(zip(keys, [int(v) for v in a]))
 
+    def autotune(self, allow_cap=True):
+        capi.check(capi.lib().pamg_matrix_autotune(self.handle, int(bool(allow_cap))), "pamg_matrix_autotune")
+
     def flow_error(self) -> bool:
         e = C.c_int(0)
         capi.check(capi.lib().pamg_matrix_flow_error(self.handle, C.byref(e)), "pamg_matrix_flow_error")
@@ -137,9 +140,14 @@ class DeviceMultilevelSolver:
     ml : pyamg.MultilevelSolver (duck-typed) or HierarchySpec
     device : int, HIP device ordinal
     graph : bool, replay cycles from a hipGraph (default) or launch eagerly
+    autotune : bool, time a few LDS-window / streaming-policy candidates per large operator at
+        upload (speed only, results are bit-identical; default on, PAMG_AUTOTUNE=0 disables)
     """
 
-    def __init__(self, ml, device: Optional[int] = None, graph: bool = True):
+    def __init__(self, ml, device: Optional[int] = None, graph: bool = True, autotune: Optional[bool] = None):
+        import os
+        if autotune is None:
+            autotune = os.environ.get("PAMG_AUTOTUNE", "1") != "0"
         lib = capi.lib()
         if device is not None:
             capi.check(lib.pamg_set_device(int(device)), "pamg_set_device")
@@ -159,6 +167,16 @@ class DeviceMultilevelSolver:
             R = DeviceMatrix(L.R) if i < nlev - 1 else None
             self._mats += [m for m in (A, P, R) if m is not None]
             self.A.append(A)
+            if autotune:
+                # speed-only choice of LDS window / streaming policy per large operator; the window of
+                # an operator that carries order-exact sweeps is left alone (its level schedules and
+                # the pipelined sweep kernels are sized for the default)
+                gs_level = i < nlev - 1 and any(s is not None and s.kind in ("gauss_seidel", "sor", "block_gauss_seidel")
+                                                for s in (L.pre, L.post))
+                A.autotune(allow_cap=not gs_level)
+                for m in (P, R):
+                    if m is not None:
+                        m.autotune(allow_cap=True)
             capi.check(lib.pamg_solver_add_level(h, A.handle, P.handle if P else None, R.handle if R else None),
                        "pamg_solver_add_level")
             if i < nlev - 1:
