@@ -47,6 +47,8 @@ extern "C" {
 #define PAMG_E_NODEVICE     -3   /* no HIP device visible                     */
 #define PAMG_E_STATE        -4   /* call sequence violated                    */
 #define PAMG_E_ALLOC        -5   /* host allocation failed                    */
+#define PAMG_E_TIMEOUT      -6   /* a persistent sweep hit its spin bound (a workgroup it waited for never
+                                    ran): the vectors it touched are invalid     */
 
 #define PAMG_F64 0
 #define PAMG_F32 1
@@ -182,24 +184,29 @@ int pamg_matrix_destroy(pamg_matrix_t A);
  * per block info[5]=bytes resident in HBM info[6]=fwd GS levels (0 = not analysed)
  * info[7]=bwd GS levels */
 int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
-/* tuning knobs for experiments: key 0 = lds entries per block, 1 = nnz per lane (1|2),
- * 2 = max rows per block (these three re-plan the operator); 3 = flow_cap: an order-exact sweep
- * whose schedule averages <= flow_cap/16 row ranges per dependency level runs as ONE persistent
- * single-workgroup launch, wider ones as a persistent grid (widest level, <= 256 workgroups) with
- * an in-kernel barrier (default 32; 0 = one launch per level always); 4 = force the persistent
- * grid to min(key 3, widest level) workgroups (experiments); 5 = order-exact sweep mode:
- * 0 (default) = level launches / barrier kernel, 1 = granular sync-free persistent sweep
- * (element-level hand-off, no barriers) when the swept pattern is structurally symmetric;
- * 6 = cap on the granular sweep's persistent grid (0 = auto); 7 = granular sweep restricted
- * to the workgroups that land on XCD 0 (hand-off through one L2); 8 = streaming flags of the
+/* tuning knobs (speed only: every setting computes the same bits).  key 0 = LDS entries per row
+ * range, 1 = entries per lane in the staging phase (1|2|4), 2 = max rows per range (these three
+ * re-plan the operator); 3 = flow_cap: an order-exact sweep whose schedule averages <= flow_cap/16
+ * row ranges per dependency level runs as ONE persistent single-workgroup launch (default 32);
+ * 5 = scheduler of the scalar order-exact sweeps: 0 automatic (narrow -> single workgroup, else the
+ * granular sweep), 1 one launch per dependency level, 2 granular sync-free sweep (one persistent
+ * launch, element-level hand-off, no barriers), 3 single workgroup; block sweeps read 2 as "grid
+ * with a barrier per level"; 6 = cap on the persistent grid (0 = automatic); 7 = granular sweep
+ * inside one XCD's L2: 0 automatic (small operators), 1 always, 2 never; 8 = streaming flags of the
  * whole-operator kernels: bit 0 non-temporal loads of the operator stream, bit 1 XCD-aware
- * row-range order; 9 = LDS-staged x windows for the whole-operator kernels (re-plans). */
+ * row-range order; 9 = LDS-staged x windows for the whole-operator kernels (re-plans);
+ * 11 = record per-row-range time stamps of the granular sweep (diagnostics,
+ * pamg_matrix_gs_profile). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* Pick the LDS window (key 0) and streaming flags (key 8) of the whole-operator kernels by timing
  * y = A x on the device with a few candidates (results are bit-identical for every choice; this
  * is speed only).  allow_cap = 0 keeps the LDS window (level schedules depend on it).  Operators
  * below 4M stored entries are left alone.  Synchronises. */
 int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap);
+/* Diagnostics of the granular sweep (tune key 11): per row range of schedule `which` (0 forward,
+ * 1 backward) eight 64-bit words {arrival, gate open, polled, staged, finished (wall clock, 10 ns),
+ * XCD id, workgroup id, dependency level}.  out == NULL: only *count.  Synchronises. */
+int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count);
 /* *error != 0: a persistent sweep of this operator hit its spin bound (synchronises) */
 int pamg_matrix_flow_error(pamg_matrix_t A, int *error);
 

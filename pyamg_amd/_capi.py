@@ -96,6 +96,7 @@ def _declare(lib):
     f("pamg_matrix_info", _vp, P(C.c_int64))
     f("pamg_matrix_tune", _vp, _i, _i)
     f("pamg_matrix_flow_error", _vp, P(_i))
+    f("pamg_matrix_gs_profile", _vp, _i, _vp, C.c_int64, P(C.c_int64))
     f("pamg_matrix_autotune", _vp, _i)
     f("pamg_matrix_spmv", _vp, _i, _vp, _vp, _d, _vp, _vp)
     f("pamg_matrix_resid_sumsq", _vp, _vp, _vp, _vp, _vp)

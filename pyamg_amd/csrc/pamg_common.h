@@ -84,9 +84,11 @@ struct GsSchedule {
     int *d_level_blk = nullptr;      // device copy of level_blk (persistent sweep kernel)
     int *d_pblk = nullptr;           // block schedules: position of scheduled block q in the operator's block arrays
     void *d_xs = nullptr;            // granular sweep: hand-off buffer (one value per matrix row)
+    void *d_xold = nullptr;          // granular sweep, non-symmetric patterns: snapshot of x (old values)
+    long long *d_prof = nullptr;     // granular sweep diagnostics: [nblk_total][8] time stamps
     bool symmetric = false;          // pattern among swept rows is structurally symmetric
     int nblk_total = 0;
-    unsigned *d_sync = nullptr;      // [0] barrier arrival counter, [1] error flag
+    unsigned *d_sync = nullptr;      // [0] barrier arrival counter (block sweeps), [1] error flag, [20..21] ticket counter + home XCD
     int max_level_blocks = 0;
     std::vector<int> level_blk;      // [nlevels+1] workgroup range of each level
     size_t bytes = 0;
@@ -113,16 +115,16 @@ struct pamg_matrix_s {
     std::vector<int> h_Ap, h_Aj;
     std::vector<int> h_bAp, h_bAj;
     // plan for the streamed kernels
-    int cap = 2048, npl = 1, max_rows = 1024;
+    int cap = 1536, npl = 2, max_rows = 1024;
     int flow_cap = 32;               // single-workgroup persistent sweep when a schedule averages <= flow_cap/16 row ranges per level
-    int flow_force = 0;              // != 0: persistent barrier kernel always, grid = min(flow_cap, widest level)
     int use_xwin = 0;                // LDS-staged x windows for the whole-operator kernels (tune key 9)
     void *d_xwin = nullptr;          // XWin[nblk] window plan (device)
     int xw_cap = 0;                  // window budget (values) the plan was built for
     int stream_flags = 0;            // StreamArgs::flags for the whole-operator launches
-    int gran_xcd = 0;                // granular sweep restricted to the workgroups that land on XCD 0
+    int gran_xcd = 0;                // granular sweep inside one XCD's L2: 0 auto (small operators), 1 always, 2 never
     int gran_cap = 0;                // granular sweep: cap on the persistent grid (0 = auto)
-    int gs_mode = 0;                 // 0: level launches / barrier kernel (default); 1: granular sync-free sweep when the pattern allows
+    int gs_mode = 0;                 // scalar sweep scheduler: 0 auto, 1 one launch per level, 2 granular, 3 single workgroup
+    int gs_prof = 0;                 // granular sweep: record per-range time stamps (tune key 11, diagnostics)
     int nblk = 0;
     int4 *d_blkmeta = nullptr;
     double *d_partial = nullptr;     // nblk doubles (sum-of-squares partials)
@@ -150,5 +152,6 @@ int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, i
 int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *xsrc, void *xdst,
                       const void *b, double omega, hipStream_t s);
 int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step);
+int sweep_error(pamg_matrix_s *A, bool *error);      // spin bound hit since the last call? (caller has synchronised; clears the flag)
 inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }
 }  // namespace pamg

@@ -44,7 +44,8 @@ template <> struct Vec2<double> { using type = double2; };
 template <> struct Vec2<float> { using type = float2; };
 
 template <int EPI> struct EpiTraits {
-    static constexpr bool need_cols = (EPI >= EPI_JACOBI);
+    static constexpr bool need_cols = (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B);   // row phase compares column ids
+    static constexpr bool diag_flag = (EPI == EPI_GS || EPI == EPI_GS_B || EPI == EPI_SOR);   // schedule copies flag a_ii
     static constexpr bool perm = (EPI == EPI_GS || EPI == EPI_GS_B || EPI == EPI_SOR);
     static constexpr bool bsr_order = (EPI == EPI_JACOBI_B || EPI == EPI_GS_B);
 };
@@ -62,7 +63,12 @@ __device__ __forceinline__ T ldx(const T *p)
 // Level schedules mark "early" entries -- columns whose row is visited EARLIER in the same
 // sweep, i.e. whose NEW value must be used -- with the sign bit of the stored column id.
 constexpr int EARLY_BIT = (int)0x80000000u;
-constexpr int COL_MASK = 0x7FFFFFFF;
+// Level schedules also flag the DIAGONAL entries (bit 30): their product is staged as +0, which
+// leaves the in-order sum bit-identical to skipping them (s + (+0) == s and s - (+0) == s for
+// every s the running sums can hold: one that starts at +0 is never -0), so the row phase of the
+// sweeps needs no column ids in LDS and no compare per entry.
+constexpr int DIAG_BIT = 0x40000000;
+constexpr int COL_MASK = 0x3FFFFFFF;
 
 // Sentinel bit patterns of the hand-off buffer xs (a quiet NaN with a payload no arithmetic
 // produces): xs[j] == sentinel  <=>  row j has not published its new value in this sweep yet.
@@ -104,7 +110,7 @@ __device__ __forceinline__ T gather_x(const StreamArgs<T> &a, int c)
 {
     if constexpr (COH == 2 || COH == 3) {
         if (c & EARLY_BIT) return spin_value<T>(a.xs, c & COL_MASK, a.err);
-        return a.x[c];
+        return a.x[c & COL_MASK];
     } else if constexpr (COH == 1) {
         return __hip_atomic_load(a.x + (c & COL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -113,7 +119,7 @@ __device__ __forceinline__ T gather_x(const StreamArgs<T> &a, int c)
 }
 
 // ---- phase 1: stage products (and column ids) of entries [p0,p1) into LDS slots [p-base]
-template <typename T, bool NEEDC, int NPL, int COH = 0>
+template <typename T, bool NEEDC, int NPL, int COH = 0, bool DIAGF = false>
 __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, int p1, int base,
                                                T *prod, int *cols)
 {
@@ -125,10 +131,10 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
             const T v0 = a.Ax[p], v1 = a.Ax[p + BLK], v2 = a.Ax[p + 2 * BLK], v3 = a.Ax[p + 3 * BLK];
             const T x0 = gather_x<COH>(a, c0), x1 = gather_x<COH>(a, c1), x2 = gather_x<COH>(a, c2),
                     x3 = gather_x<COH>(a, c3);
-            prod[p - base] = v0 * x0;
-            prod[p - base + BLK] = v1 * x1;
-            prod[p - base + 2 * BLK] = v2 * x2;
-            prod[p - base + 3 * BLK] = v3 * x3;
+            prod[p - base] = (DIAGF && (c0 & DIAG_BIT)) ? T(0) : v0 * x0;
+            prod[p - base + BLK] = (DIAGF && (c1 & DIAG_BIT)) ? T(0) : v1 * x1;
+            prod[p - base + 2 * BLK] = (DIAGF && (c2 & DIAG_BIT)) ? T(0) : v2 * x2;
+            prod[p - base + 3 * BLK] = (DIAGF && (c3 & DIAG_BIT)) ? T(0) : v3 * x3;
             if constexpr (NEEDC) {
                 cols[p - base] = c0 & COL_MASK;
                 cols[p - base + BLK] = c1 & COL_MASK;
@@ -139,7 +145,7 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
         for (; p < p1; p += BLK) {
             const int c0 = a.Aj[p];
             const T v0 = a.Ax[p];
-            prod[p - base] = v0 * gather_x<COH>(a, c0);
+            prod[p - base] = (DIAGF && (c0 & DIAG_BIT)) ? T(0) : v0 * gather_x<COH>(a, c0);
             if constexpr (NEEDC) cols[p - base] = c0 & COL_MASK;
         }
     } else if constexpr (NPL == 4) {
@@ -159,7 +165,7 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
                 T xv;
                 if (a.flags & 4) xv = T(c[j]);
                 else xv = ok ? gather_x<COH>(a, c[j]) : T(0);
-                pr[j] = v[j] * xv;
+                pr[j] = (DIAGF && (c[j] & DIAG_BIT)) ? T(0) : v[j] * xv;
             }
             T2 o0, o1;
             o0.x = pr[0]; o0.y = pr[1]; o1.x = pr[2]; o1.y = pr[3];
@@ -200,8 +206,8 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
                 x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
             }
             T2 pr;
-            pr.x = vv.x * x0;
-            pr.y = vv.y * x1;
+            pr.x = (DIAGF && (cc.x & DIAG_BIT)) ? T(0) : vv.x * x0;
+            pr.y = (DIAGF && (cc.y & DIAG_BIT)) ? T(0) : vv.y * x1;
             *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
             if constexpr (NEEDC) {
                 cc.x &= COL_MASK;
@@ -240,30 +246,84 @@ __device__ __forceinline__ RowPre<T> row_prefetch(const StreamArgs<T> &a, int r)
     return q;
 }
 
-// Sequential, storage-order accumulation of one row's products.  LDS reads are issued eight
-// at a time ahead of the dependent add chain (the adds stay strictly in order, so the result
-// is unchanged); without this a 60-entry coarse-level row pays 60 serial LDS round trips.
+// Sequential, storage-order accumulation of one row's products.  The adds stay strictly in
+// order (the result is the reference's running sum, bit for bit); everything around them is
+// arranged so that the dependent add chain is all that is left on the critical path.  The row
+// phase is VALU-issue bound (one lane per row, every instruction costs a full wave slot), so:
+// eight consecutive LDS slots are read per batch with constant offsets (reads may run up to
+// eight slots past the row's end -- inside the padded window, never used), the next batch is
+// in flight while the current one is summed, full batches are summed WITHOUT per-entry
+// predicates and the 0..7 leftover entries as a 4 + 2 + 1 decomposition.
 template <typename T, int EPI>
 __device__ __forceinline__ void row_accumulate(T &s, const T *prod, const int *cols, int lo, int hi, int row)
 {
     constexpr int U = 8;
-    for (int k = lo; k < hi; k += U) {
+    if (lo >= hi) return;
+    if constexpr (EpiTraits<EPI>::need_cols) {
+        // Jacobi family on the operator's own arrays: the diagonal is recognised by column id
         T p[U];
         int c[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int kk = min(k + j, hi - 1);            // clamp: stay inside the staged window
-            p[j] = prod[kk];
-            if constexpr (EpiTraits<EPI>::need_cols) c[j] = cols[kk];
-        }
+        for (int j = 0; j < U; ++j) { p[j] = prod[lo + j]; c[j] = cols[lo + j]; }
+        for (int k = lo; k < hi; k += U) {
+            T pn[U];
+            int cn[U];
+            const bool more = k + U < hi;
+            if (more) {
 #pragma unroll
-        for (int j = 0; j < U; ++j) {
-            bool use = k + j < hi;
-            if constexpr (EpiTraits<EPI>::need_cols) use = use && (c[j] != row);   // diagonal never enters the sum
-            if (use) {
+                for (int j = 0; j < U; ++j) { pn[j] = prod[k + U + j]; cn[j] = cols[k + U + j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (k + j < hi && c[j] != row) {           // diagonal never enters the sum
+                    if constexpr (EpiTraits<EPI>::bsr_order) s -= p[j];
+                    else s += p[j];
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < U; ++j) { p[j] = pn[j]; c[j] = cn[j]; }
+            }
+        }
+    } else {
+        const T *q = prod + lo;
+        int n = hi - lo;
+        T p[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) p[j] = q[j];
+        while (n >= U) {
+            T pn[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) pn[j] = q[U + j];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
                 if constexpr (EpiTraits<EPI>::bsr_order) s -= p[j];
                 else s += p[j];
             }
+#pragma unroll
+            for (int j = 0; j < U; ++j) p[j] = pn[j];
+            q += U;
+            n -= U;
+        }
+        if (n & 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (EpiTraits<EPI>::bsr_order) s -= p[j];
+                else s += p[j];
+            }
+            p[0] = p[4]; p[1] = p[5]; p[2] = p[6];
+        }
+        if (n & 2) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (EpiTraits<EPI>::bsr_order) s -= p[j];
+                else s += p[j];
+            }
+            p[0] = p[2];
+        }
+        if (n & 1) {
+            if constexpr (EpiTraits<EPI>::bsr_order) s -= p[0];
+            else s += p[0];
         }
     }
 }
@@ -315,8 +375,6 @@ __device__ __forceinline__ void row_finish(const StreamArgs<T> &a, const RowPre<
             if constexpr (COH == 2) __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (upd) a.y[row] = v;
-        } else if constexpr (COH == 1) {
-            if (upd) __hip_atomic_store(a.y + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             if (upd) a.y[row] = v;
         }
@@ -338,7 +396,7 @@ __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 
         int r = r0 + tid;
         RowPre<T> q;
         if (r < r1) q = row_prefetch<T, EPI, COH>(a, r);
-        stage_products<T, NEEDC, NPL, COH>(a, p0, p1, base, prod, cols);
+        stage_products<T, NEEDC, NPL, COH, EpiTraits<EPI>::diag_flag>(a, p0, p1, base, prod, cols);
         __syncthreads();
         if (a.flags & 8) {                                // ablation: no row phase
             if (tid == 0) a.y[r0] = prod[0];
@@ -360,7 +418,7 @@ __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 
             const int c1 = min(c0 + cap, p1);
             const int base = (NPL == 4) ? (c0 & ~3) : (NPL == 2) ? (c0 & ~1) : c0;
             __syncthreads();
-            stage_products<T, NEEDC, NPL, COH>(a, c0, c1, base, prod, cols);
+            stage_products<T, NEEDC, NPL, COH, EpiTraits<EPI>::diag_flag>(a, c0, c1, base, prod, cols);
             __syncthreads();
             if (tid == 0) row_accumulate<T, EPI>(s, prod, cols, c0 - base, c1 - base, q.row);
         }
@@ -389,25 +447,22 @@ __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
     }
 }
 
-// Persistent order-exact sweep: ONE launch walks all dependency levels of a schedule.  The
-// grid's G workgroups share the row ranges of a level round-robin and meet at a software
-// barrier between levels (monotonic arrival counter, relaxed agent-scope polling, bounded
-// spin).  x travels between workgroups through write-through stores and L1-bypassing loads
-// (ldx/stx above), so no cache-maintenance fences are needed.  With G == 1 (COH = false) the
-// barrier is a plain __syncthreads() and x uses ordinary cached accesses.  All G workgroups must be co-resident (host sizes G accordingly).
+// Single-workgroup persistent sweep (gs_flow1_kernel): ONE workgroup walks all row ranges of a
+// schedule, level after level, with __syncthreads() between them -- the scheduler of choice when
+// the levels are so narrow (<= 2 row ranges on average) that there is nothing to share out.
 template <typename T>
 struct FlowArgs {
     StreamArgs<T> s;          // blkmeta = all row ranges of the schedule, level after level
     const int *level_blk;     // [nlevels+1] row-range offsets of the levels (DEVICE)
     int nlevels;
-    unsigned *sync;           // [0] arrival counter (zeroed before the launch), [1] error flag
+    unsigned *sync;           // [1] error flag
 };
 
 // ---- software-pipelined row-range processing for the persistent sweeps ------------------
 // Everything a row range needs that does NOT depend on other ranges (its slice of Aj/Ax, row
 // pointers, row ids, diagonal, right-hand side) is fetched into registers one dependency
-// level AHEAD, so that after the barrier only the x gather -> LDS -> in-order row sum ->
-// store chain remains on the critical path.
+// range AHEAD, so that only the x gather -> LDS -> in-order row sum -> store chain remains on
+// the critical path.
 constexpr int MAXP = 4;        // prefetchable entry pairs per lane (ranges up to 2*MAXP*BLK entries)
 
 template <typename T>
@@ -461,8 +516,8 @@ __device__ __forceinline__ void range_stage(const StreamArgs<T> &a, const RangeP
             const T x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
             const T x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
             T2 pr;
-            pr.x = R.v[k].x * x0;
-            pr.y = R.v[k].y * x1;
+            pr.x = (EpiTraits<EPI>::diag_flag && (cc.x & DIAG_BIT)) ? T(0) : R.v[k].x * x0;
+            pr.y = (EpiTraits<EPI>::diag_flag && (cc.y & DIAG_BIT)) ? T(0) : R.v[k].y * x1;
             *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
             if constexpr (EpiTraits<EPI>::need_cols) {
                 cc.x &= COL_MASK;
@@ -565,68 +620,6 @@ __global__ __launch_bounds__(BLK) void csr_stream_xw_kernel(const StreamArgs<T> 
     (void)wcap;
 }
 
-template <typename T, int EPI, int NPL, bool COH>
-__global__ __launch_bounds__(BLK) void gs_flow_kernel(const FlowArgs<T> g)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int C = COH ? 1 : 0;
-    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
-    const StreamArgs<T> &a = g.s;
-    double sq = 0.0;
-    RangePre<T> cur, nxt;
-    cur.fits = false; cur.has_row = false;
-    int lb = g.level_blk[0];
-    int le = g.level_blk[1];
-    bool cur_valid = false;
-    if (lb + bid < le) { range_prefetch<T, EPI, C>(a, lb + bid, cur); cur_valid = true; }
-    for (int l = 0; l < g.nlevels; ++l) {
-        const int nle = (l + 1 < g.nlevels) ? g.level_blk[l + 2] : le;
-        const bool have_next = (l + 1 < g.nlevels) && (le + bid < nle);
-        bool nxt_valid = false;
-        nxt.fits = false; nxt.has_row = false;
-        bool first = true;
-        for (int blk = lb + bid; blk < le; blk += G) {
-            if (first && cur_valid && cur.fits) {
-                range_stage<T, EPI, C>(a, cur, smem_raw);
-                if (have_next) { range_prefetch<T, EPI, C>(a, le + bid, nxt); nxt_valid = true; }
-                __syncthreads();
-                range_finish<T, EPI, C>(a, cur, smem_raw);
-            } else {
-                if (first && have_next) { range_prefetch<T, EPI, C>(a, le + bid, nxt); nxt_valid = true; }
-                stream_block<T, EPI, NPL, C>(a, a.blkmeta[blk], smem_raw, sq);
-            }
-            first = false;
-            __syncthreads();                               // LDS is reused by the next row range
-        }
-        if (first && have_next) { range_prefetch<T, EPI, C>(a, le + bid, nxt); nxt_valid = true; }
-        if constexpr (!COH) {
-            __syncthreads();                               // single workgroup: same-CU visibility
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
-            __syncthreads();
-            // barrier: monotonic arrival counter (a per-workgroup flag array polled in parallel
-            // was measured 3 % slower), relaxed agent-scope polling, bounded spin
-            if (threadIdx.x == 0) {
-                const unsigned target = (unsigned)(l + 1) * (unsigned)G;
-                __hip_atomic_fetch_add(g.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while (__hip_atomic_load(g.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22)) {            // ~seconds: a workgroup is not resident
-                        __hip_atomic_store(g.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        cur = nxt;
-        cur_valid = nxt_valid;
-        lb = le;
-        le = nle;
-    }
-}
-
 // single-workgroup persistent sweep: ranges taken one after the other, separated by
 // __syncthreads(), ordinary cached x accesses (same CU); the static operands of range k+1 are
 // fetched while range k is being reduced.
@@ -657,50 +650,208 @@ __global__ __launch_bounds__(BLK) void gs_flow1_kernel(const FlowArgs<T> g)
     }
 }
 
-// Granular ("sync-free") order-exact sweep: ONE persistent launch, no barriers at all.  Row
-// ranges are taken in schedule (= dependency-level) order, workgroup w owning ranges w, w+G,
-// w+2G, ...; an entry that needs the NEW value of an earlier row simply waits for that row's
-// datum to appear in the hand-off buffer xs (pre-filled with a sentinel), so the critical
-// path is one write-through store -> one polled load per dependency hop instead of a kernel
-// boundary or a grid barrier per level.  Deadlock-free because a range only ever waits on
-// ranges with smaller ids and every workgroup walks its ranges in increasing order (all G
-// workgroups co-resident; spins are bounded and raise the error flag).  Requires a
-// structurally symmetric pattern among the swept rows (checked on the host): a later row then
-// always waits for every earlier neighbour, which also orders the write-after-read hazards.
-template <typename T, int EPI, int NPL>
-__global__ __launch_bounds__(BLK) void gs_gran_kernel(const StreamArgs<T> a, int nblk)
+// ---- granular ("sync-free") order-exact sweep ------------------------------------------------
+// ONE persistent launch, no barriers between dependency levels.  Row ranges are taken in schedule
+// (= dependency-level) order; an entry that needs the NEW value of an earlier row ("early" entry)
+// waits for that row's datum to appear in the hand-off buffer xs (pre-filled with a sentinel: the
+// published datum IS the flag, one write-through store -> one polled load per dependency hop),
+// every other entry reads the OLD value from a.x.  Write-after-read hazards: with a structurally
+// symmetric pattern a later row always waits for all its earlier neighbours, so nobody overwrites
+// an old value that is still needed and a.x is the live vector; otherwise the host hands a.x = a
+// snapshot of x taken before the sweep.  Deadlock-free because a range only ever waits on ranges
+// with smaller ids and every workgroup takes its ranges in increasing order (spins are bounded and
+// raise the error flag, which the solver's synchronous entry points report).  Measured
+// (profiles/r01_microbench_gs_granular2_*.json): 1.8-2.7 us per dependency level against 4-7 us for
+// a grid barrier or a kernel boundary per level.  What made the difference:
+//  * the static operands of a workgroup's NEXT range are in registers before it starts to wait,
+//    fetched AFTER the publishing stores of the current one and without a dependent address
+//    chain (the range descriptor is loaded one range further ahead; b is loaded with the polls);
+//  * a lane issues the loads of ALL its entries at once and re-polls only the missing ones, so a
+//    poll round costs one memory round trip whatever the number of entries per lane;
+//  * the grid is sized to ~8 dependency levels of look-ahead (<= 256 workgroups): idle pollers
+//    load the memory system (a progress-counter gate for far-ahead workgroups was measured and
+//    dropped -- the grid size does the same for free).
+template <typename T>
+struct GranArgs {
+    StreamArgs<T> s;          // blkmeta = all row ranges of the schedule, level after level; xs = hand-off buffer
+    int nblk;
+    unsigned *ticket;         // XCD form: [0] ticket counter, [1] home XCD + 1 (both zeroed before the launch)
+    long long *prof;          // nullptr or [nblk][8] time stamps (wall clock, 10 ns): diagnostics
+};
+
+template <typename T, int EPI>
+__device__ __forceinline__ void range_stage_gran(const StreamArgs<T> &a, const RangePre<T> &R, unsigned char *smem_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double sq = 0.0;
-    for (int blk = (int)blockIdx.x; blk < nblk; blk += (int)gridDim.x) {
-        stream_block<T, EPI, NPL, 2>(a, a.blkmeta[blk], smem_raw, sq);
-        __syncthreads();                                   // LDS is reused by the next row range
+    using T2 = typename Vec2<T>::type;
+    T *prod = reinterpret_cast<T *>(smem_raw);
+    int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(a.cap + 8));
+    const int tid = threadIdx.x;
+    const int p0 = R.meta.z, p1 = R.meta.w, base = p0 & ~1;
+    T xv[2 * MAXP];
+    unsigned pend = 0;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int q = base + 2 * tid + k * 2 * BLK;
+        xv[2 * k] = xv[2 * k + 1] = T(0);
+        if (q < p1) {
+            const int2 cc = R.c[k];
+            if (q >= p0) {
+                if (cc.x & EARLY_BIT) { xv[2 * k] = __hip_atomic_load(a.xs + (cc.x & COL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pend |= 1u << (2 * k); }
+                else if (!(cc.x & DIAG_BIT)) xv[2 * k] = a.x[cc.x & COL_MASK];
+            }
+            if (q + 1 < p1) {
+                if (cc.y & EARLY_BIT) { xv[2 * k + 1] = __hip_atomic_load(a.xs + (cc.y & COL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pend |= 1u << (2 * k + 1); }
+                else if (!(cc.y & DIAG_BIT)) xv[2 * k + 1] = a.x[cc.y & COL_MASK];
+            }
+        }
+    }
+    unsigned spins = 0;
+    while (true) {
+#pragma unroll
+        for (int j = 0; j < 2 * MAXP; ++j)
+            if ((pend >> j) & 1u)
+                if (Sentinel<T>::bits(xv[j]) != Sentinel<T>::value) pend &= ~(1u << j);
+        if (!pend) break;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int j = 0; j < 2 * MAXP; ++j)
+            if ((pend >> j) & 1u) {
+                const int2 cc = R.c[j >> 1];
+                const int c = (j & 1) ? cc.y : cc.x;
+                xv[j] = __hip_atomic_load(a.xs + (c & COL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        if (++spins > (1u << 22)) {                        // ~seconds: producer not resident / bug
+            __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int q = base + 2 * tid + k * 2 * BLK;
+        if (q < p1) {
+            int2 cc = R.c[k];
+            T2 pr;
+            pr.x = (cc.x & DIAG_BIT) ? T(0) : R.v[k].x * xv[2 * k];
+            pr.y = (cc.y & DIAG_BIT) ? T(0) : R.v[k].y * xv[2 * k + 1];
+            *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
+            if constexpr (EpiTraits<EPI>::need_cols) {
+                cc.x &= COL_MASK;
+                cc.y &= COL_MASK;
+                *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+            }
+        }
     }
 }
 
-// Single-XCD variant: the hand-off hop through the memory fabric costs several microseconds,
-// the hop through ONE XCD's L2 a fraction of that.  Every workgroup reads the XCC id it
-// actually runs on (hardware register, no placement assumption); only those on XCD 0 take
-// part, the others leave at once.  Participants claim row ranges from an atomic ticket
-// counter -- ids are handed out in increasing order to workgroups that are already running,
-// so the "only wait on smaller ids" argument still holds -- publish with ordinary stores
-// (they stay in the shared L2) and poll with L1-bypassing loads.
-template <typename T, int EPI, int NPL>
-__global__ __launch_bounds__(BLK) void gs_gran_xcd_kernel(const StreamArgs<T> a, int nblk, unsigned *ticket)
+// static operands of the row range described by meta (everything but b / the old own value,
+// whose addresses depend on the row id: those are loaded with the polls): no load here depends
+// on another one, so the issuing wave never waits
+template <typename T, int EPI>
+__device__ __forceinline__ void range_prefetch_static(const StreamArgs<T> &a, const int4 meta, RangePre<T> &R)
+{
+    using T2 = typename Vec2<T>::type;
+    const int tid = threadIdx.x;
+    R.meta = meta;
+    const int p0 = meta.z, p1 = meta.w, base = p0 & ~1;
+    R.fits = (p1 - base) <= 2 * MAXP * BLK && (meta.y - meta.x) <= BLK && (p1 - p0) <= a.cap;
+    R.has_row = false;
+    if (!R.fits) return;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int q = base + 2 * tid + k * 2 * BLK;
+        if (q < p1) {
+            R.c[k] = *reinterpret_cast<const int2 *>(a.Aj + q);
+            R.v[k] = *reinterpret_cast<const T2 *>(a.Ax + q);
+        }
+    }
+    const int r = meta.x + tid;
+    R.has_row = r < meta.y;
+    R.q.b = R.q.y = R.q.xo = R.q.d = T(0);
+    if (R.has_row) {
+        R.q.lo = a.Ap[r];
+        R.q.hi = a.Ap[r + 1];
+        R.q.row = a.rid[r];
+        R.q.d = a.diag[r];
+    }
+}
+
+// XCD = false: workgroup w owns ranges w, w+G, w+2G, ... (all G workgroups co-resident: the host
+// keeps G <= the number of CUs).
+// XCD = true: the hand-off stays inside ONE XCD's L2 (ordinary stores, L1-bypassing loads) -- for
+// operators whose vectors fit that L2.  The first workgroup to arrive claims its XCD (read from
+// the hardware register) as the home; every workgroup that runs elsewhere leaves at once, the
+// others draw row ranges from a ticket counter.  Tickets go out in increasing order to workgroups
+// that are already running, so the sweep completes for ANY placement and residency (at least the
+// claiming workgroup takes part); placement decides speed only.
+template <typename T, int EPI, bool XCD>
+__global__ __launch_bounds__(BLK) void gs_gran2_kernel(const GranArgs<T> g)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ int next_blk;
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF;      // HW_REG_XCC_ID[3:0]
-    if (xcc != 0) return;
+    __shared__ int sh_next;
+    constexpr int C = XCD ? 3 : 2;
+    const StreamArgs<T> &a = g.s;
+    const int G = (int)gridDim.x, tid = threadIdx.x;
     double sq = 0.0;
-    while (true) {
-        if (threadIdx.x == 0)
-            next_blk = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    RangePre<T> cur, nxt;
+    cur.fits = false; cur.has_row = false;
+    int blk = (int)blockIdx.x;
+    if constexpr (XCD) {
+        if (tid == 0) {
+            const unsigned me = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1u;     // HW_REG_XCC_ID[3:0] + 1
+            unsigned home = 0u;
+            __hip_atomic_compare_exchange_strong(g.ticket + 1, &home, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool mine = home == 0u || home == me;      // home holds the previous value
+            sh_next = mine ? (int)__hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g.nblk;
+        }
         __syncthreads();
-        const int blk = next_blk;
-        if (blk >= nblk) break;
-        stream_block<T, EPI, NPL, 3>(a, a.blkmeta[blk], smem_raw, sq);
-        __syncthreads();                                   // LDS (and next_blk) are reused
+        blk = sh_next;
+        __syncthreads();
+    }
+    int4 meta_nxt = make_int4(0, 0, 0, 0);                  // descriptor of the range after the current one (static form)
+    if (blk < g.nblk) {
+        range_prefetch_static<T, EPI>(a, a.blkmeta[blk], cur);
+        if constexpr (!XCD) if (blk + G < g.nblk) meta_nxt = a.blkmeta[blk + G];
+    }
+    while (blk < g.nblk) {
+        long long t0 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (g.prof && tid == 0) t0 = wall_clock64();
+        nxt.fits = false; nxt.has_row = false;
+        if (cur.fits) {
+            if (cur.has_row) {                             // row-id dependent operands, in flight with the polls
+                cur.q.b = a.b[cur.q.row];
+                if constexpr (EPI == EPI_SOR) cur.q.xo = a.x[cur.q.row];
+            }
+            range_stage_gran<T, EPI>(a, cur, smem_raw);
+            if (g.prof && tid == 0) t2 = wall_clock64();
+            __syncthreads();
+            if (g.prof && tid == 0) t3 = wall_clock64();
+            range_finish<T, EPI, C>(a, cur, smem_raw);
+        } else {
+            stream_block<T, EPI, 2, C>(a, a.blkmeta[blk], smem_raw, sq);
+        }
+        if (g.prof && tid == 0) t4 = wall_clock64();
+        // this workgroup's next range and its static operands: AFTER the publishing stores
+        int nb = blk + G;
+        if constexpr (XCD) {
+            if (tid == 0) sh_next = (int)__hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            nb = sh_next;
+            if (nb < g.nblk) range_prefetch_static<T, EPI>(a, a.blkmeta[nb], nxt);
+        } else {
+            if (nb < g.nblk) {
+                range_prefetch_static<T, EPI>(a, meta_nxt, nxt);
+                if (nb + G < g.nblk) meta_nxt = a.blkmeta[nb + G];
+            }
+        }
+        if (g.prof && tid == 0) {
+            long long *o = g.prof + (size_t)blk * 8;
+            o[0] = t0; o[1] = t0; o[2] = t2; o[3] = t3; o[4] = t4;
+            o[5] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF);
+            o[6] = (long long)blockIdx.x;
+        }
+        __syncthreads();                                   // LDS (and sh_next) are reused
+        cur = nxt;
+        blk = nb;
     }
 }
 

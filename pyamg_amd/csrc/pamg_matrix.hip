@@ -51,8 +51,8 @@ void plan_rows(const int *Ap, int begin, int end, int cap, int max_rows, std::ve
 
 int lds_bytes(int dtype, int epi, int cap)
 {
-    const int per = (int)tsize(dtype) + (epi >= EPI_JACOBI ? 4 : 0);
-    return std::max(64, per * (cap + 8));
+    const int per = (int)tsize(dtype) + ((epi == EPI_JACOBI || epi == EPI_JACOBI_B) ? 4 : 0);   // column ids only for the Jacobi row phase
+    return per * (cap + 8) + 64;      // + slack: the row phase reads whole batches of 8 slots
 }
 
 template <typename T, int EPI>
@@ -199,7 +199,7 @@ int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap)
 void free_schedule(GsSchedule *g)
 {
     if (!g) return;
-    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_pblk);
+    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_xold); hipFree(g->d_pblk); hipFree(g->d_prof);
     delete g;
 }
 
@@ -315,6 +315,7 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
             for (int p = pAp[r]; p < pAp[r + 1]; ++p) {
                 const int j = pAj[p];
                 if (j != i && j >= 0 && j < (int)A->nrows && vis[j] >= 0 && vis[j] < ti) pAj[p] = j | (int)0x80000000u;
+                else if (j == i) pAj[p] = j | 0x40000000;      // diagonal: staged as +0 (DIAG_BIT)
             }
         }
     });
@@ -323,7 +324,7 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
     std::vector<unsigned char> pdiag((size_t)m * ts, 0);
     for (int r = 0; r < m; ++r)
         for (int p = pAp[r]; p < pAp[r + 1]; ++p)
-            if (pAj[p] == order[r]) std::memcpy(&pdiag[(size_t)r * ts], &pAx[(size_t)p * ts], ts);
+            if (pAj[p] == (order[r] | 0x40000000)) std::memcpy(&pdiag[(size_t)r * ts], &pAx[(size_t)p * ts], ts);
     std::vector<int4> blk;
     g->level_blk.assign(1, 0);
     for (int l = 0; l < g->nlevels; ++l) {
@@ -338,7 +339,7 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
     if (!st) st = upload(&g->d_blkmeta, blk.data(), blk.size(), &g->bytes);
     if (!st) st = upload(&g->d_level_blk, g->level_blk.data(), g->level_blk.size(), &g->bytes);
     g->nblk_total = (int)blk.size();
-    if (!st && g->symmetric) {
+    if (!st) {                                  // hand-off buffer of the granular sweep
         const size_t xb = ((size_t)A->nrows + 8) * ts;
         st = (int)hipMalloc(&g->d_xs, xb);
         if (!st) g->bytes += xb;
@@ -456,8 +457,8 @@ int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void 
 {
     const int lds = lds_bytes(A->dtype, epi, A->cap);
     if (A->use_xwin && A->d_xwin && A->npl == 2 && epi < EPI_GS) {
-        const int per = (int)tsize(A->dtype) + (epi >= EPI_JACOBI ? 4 : 0);
-        const int ldsx = per * (A->cap + 8) + (int)tsize(A->dtype) * (A->xw_cap + 8);
+        const int per = (int)tsize(A->dtype) + ((epi == EPI_JACOBI || epi == EPI_JACOBI_B) ? 4 : 0);
+        const int ldsx = per * (A->cap + 8) + (int)tsize(A->dtype) * (A->xw_cap + 8) + 64;
         if (ldsx <= 60 * 1024) {
             if (A->dtype == PAMG_F64) return xw_launch<double>(epi, A->nblk, ldsx, s, base_args<double>(A, x, b, y, c, omega, partial), (const XWin *)A->d_xwin, A->xw_cap);
             return xw_launch<float>(epi, A->nblk, ldsx, s, base_args<float>(A, x, b, y, c, omega, partial), (const XWin *)A->d_xwin, A->xw_cap);
@@ -474,18 +475,10 @@ int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void 
     return launch_any<float>(epi, A->npl, grid, lds, s, a);
 }
 
-template <typename T, int EPI, int NPL>
-static int gran_occupancy(int lds)
-{
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gs_gran_kernel<T, EPI, NPL>, BLK, (size_t)lds) != hipSuccess) nb = 1;
-    return nb;
-}
-
-// co-resident grid of the granular sweep: (occupancy - 1, at most 4) workgroups per CU -- the
-// occupancy query can over-report by one per CU (MI355X_MICROARCH.md), every spin is bounded
+// grid ceiling of the granular sweep: its workgroups must be co-resident; (occupancy - 1, at most
+// 4) per CU -- the occupancy query can over-report by one per CU (MI355X_MICROARCH.md)
 template <typename T>
-static int gran_grid(int epi, int npl, int lds)
+static int gran2_grid(int epi, int lds)
 {
     static int cus = 0;
     if (!cus) {
@@ -494,58 +487,45 @@ static int gran_grid(int epi, int npl, int lds)
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
         else cus = 64;
     }
-    int nb;
-    if (npl == 2) nb = epi == EPI_GS ? gran_occupancy<T, EPI_GS, 2>(lds) : epi == EPI_GS_B ? gran_occupancy<T, EPI_GS_B, 2>(lds) : gran_occupancy<T, EPI_SOR, 2>(lds);
-    else nb = epi == EPI_GS ? gran_occupancy<T, EPI_GS, 1>(lds) : epi == EPI_GS_B ? gran_occupancy<T, EPI_GS_B, 1>(lds) : gran_occupancy<T, EPI_SOR, 1>(lds);
+    int nb = 0;
+    hipError_t e;
+    if (epi == EPI_GS) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gs_gran2_kernel<T, EPI_GS, false>, BLK, (size_t)lds);
+    else if (epi == EPI_GS_B) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gs_gran2_kernel<T, EPI_GS_B, false>, BLK, (size_t)lds);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gs_gran2_kernel<T, EPI_SOR, false>, BLK, (size_t)lds);
+    if (e != hipSuccess) nb = 2;
     nb = std::max(1, std::min(nb - 1, 4));
     return nb * cus;
 }
 
-template <typename T>
-static int gran_launch(int epi, int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a, int nblk)
+template <typename T, bool XCD>
+static int gran2_launch(int epi, int grid, int lds, hipStream_t s, const GranArgs<T> &ga)
 {
-#define PAMG_GRAN(E)                                                                                        \
-    if (npl == 2) hipLaunchKernelGGL((gs_gran_kernel<T, E, 2>), dim3(grid), dim3(BLK), lds, s, a, nblk);    \
-    else hipLaunchKernelGGL((gs_gran_kernel<T, E, 1>), dim3(grid), dim3(BLK), lds, s, a, nblk);
     switch (epi) {
-        case EPI_GS: PAMG_GRAN(EPI_GS) break;
-        case EPI_GS_B: PAMG_GRAN(EPI_GS_B) break;
-        case EPI_SOR: PAMG_GRAN(EPI_SOR) break;
+        case EPI_GS: hipLaunchKernelGGL((gs_gran2_kernel<T, EPI_GS, XCD>), dim3(grid), dim3(BLK), lds, s, ga); break;
+        case EPI_GS_B: hipLaunchKernelGGL((gs_gran2_kernel<T, EPI_GS_B, XCD>), dim3(grid), dim3(BLK), lds, s, ga); break;
+        case EPI_SOR: hipLaunchKernelGGL((gs_gran2_kernel<T, EPI_SOR, XCD>), dim3(grid), dim3(BLK), lds, s, ga); break;
         default: return PAMG_E_ARG;
     }
-#undef PAMG_GRAN
-    return (int)hipGetLastError();
-}
-
-template <typename T>
-static int gran_xcd_launch(int epi, int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a, int nblk,
-                           unsigned *ticket)
-{
-#define PAMG_GRANX(E)                                                                                                 \
-    if (npl == 2) hipLaunchKernelGGL((gs_gran_xcd_kernel<T, E, 2>), dim3(grid), dim3(BLK), lds, s, a, nblk, ticket);  \
-    else hipLaunchKernelGGL((gs_gran_xcd_kernel<T, E, 1>), dim3(grid), dim3(BLK), lds, s, a, nblk, ticket);
-    switch (epi) {
-        case EPI_GS: PAMG_GRANX(EPI_GS) break;
-        case EPI_GS_B: PAMG_GRANX(EPI_GS_B) break;
-        case EPI_SOR: PAMG_GRANX(EPI_SOR) break;
-        default: return PAMG_E_ARG;
-    }
-#undef PAMG_GRANX
     return (int)hipGetLastError();
 }
 
 template <typename T, int EPI>
-static int flow_launch(int npl, int grid, int lds, hipStream_t s, const FlowArgs<T> &f)
+static int flow1_launch(int npl, int lds, hipStream_t s, const FlowArgs<T> &f)
 {
-    if (grid == 1) {
-        if (npl == 2) hipLaunchKernelGGL((gs_flow1_kernel<T, EPI, 2>), dim3(1), dim3(BLK), lds, s, f);
-        else hipLaunchKernelGGL((gs_flow1_kernel<T, EPI, 1>), dim3(1), dim3(BLK), lds, s, f);
-    } else {
-        hipLaunchKernelGGL((gs_flow_kernel<T, EPI, 2, true>), dim3(grid), dim3(BLK), lds, s, f);
-    }
+    if (npl == 2) hipLaunchKernelGGL((gs_flow1_kernel<T, EPI, 2>), dim3(1), dim3(BLK), lds, s, f);
+    else hipLaunchKernelGGL((gs_flow1_kernel<T, EPI, 1>), dim3(1), dim3(BLK), lds, s, f);
     return (int)hipGetLastError();
 }
 
+// Scheduling policy of the order-exact sweeps (measured on the 96^3 and 256^3 smoothed-aggregation
+// hierarchies, profiles/r01_microbench_gs_*.json; every scheduler gives the same bits):
+//  * narrow schedules (<= flow_cap/16 row ranges per level on average, default 2): ONE workgroup
+//    walks all ranges with __syncthreads() and cached accesses (1.4-2 us per range);
+//  * otherwise the granular sweep: no barriers, the published datum is the flag (1.8-2.7 us per
+//    dependency level; was 4-7 us with a grid barrier or a kernel boundary per level).  Small
+//    operators (vectors fit one XCD's 4 MB L2, <= 4 ranges per level) keep the hand-off inside one
+//    XCD; patterns that are not structurally symmetric read old values from a snapshot of x;
+//  * one launch per level only as the fallback (oversized LDS window, 1- or 4-entries-per-lane plans).
 template <typename T>
 static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b,
                              double omega, hipStream_t s)
@@ -557,50 +537,65 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
     a.rid = g->d_rid;
     a.diag = (const T *)g->d_diag;
     const int lds = lds_bytes(A->dtype, epi, A->cap);
-    if (A->gs_mode == 1 && g->symmetric && g->d_xs && lds <= 48 * 1024 && g->nlevels > 1) {
-        // granular sync-free sweep: sentinel fill + ONE persistent launch
-        a.blkmeta = g->d_blkmeta;
-        a.xs = (T *)g->d_xs;
-        a.err = g->d_sync + 1;
-        const int64_t n = A->nrows;
-        const int fgrid = (int)std::min<int64_t>(4096, (n + BLK - 1) / BLK);
-        hipLaunchKernelGGL((fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)g->d_xs, n);
-        PAMG_HIP(hipGetLastError());
-        int G = std::max(1, std::min(g->nblk_total, gran_grid<T>(epi, A->npl, lds)));
-        if (A->gran_cap > 0) G = std::min(G, A->gran_cap);
-        if (A->gran_xcd) {
-            // single-XCD variant: full co-resident grid, only the workgroups on XCD 0 take part
-            PAMG_HIP(hipMemsetAsync(g->d_sync + 2, 0, sizeof(unsigned), s));
-            const int Gx = gran_grid<T>(epi, A->npl, lds + 64);
-            return gran_xcd_launch<T>(epi, A->npl, Gx, lds, s, a, g->nblk_total, g->d_sync + 2);
-        }
-        return gran_launch<T>(epi, A->npl, G, lds, s, a, g->nblk_total);
-    }
-    // Scheduling policy (measured, profiles/r01_microbench_gs_*.json, 96^3 and 256^3 hierarchies):
-    //  * narrow schedules (<= flow_cap/16 row ranges per level on average, default 2): ONE workgroup
-    //    walks all levels with __syncthreads() and cached accesses (1.8-3.5 us per range);
-    //  * otherwise a persistent grid of G = widest level (<= 256, co-resident on 256 CUs) workgroups
-    //    with an in-kernel flag barrier and software-pipelined static operands (3.8-5 us per level);
-    //  * one launch per level (5.4-8 us per level) only as the fallback (oversized LDS window).
+    const bool can_persist = lds <= 48 * 1024 && g->nlevels > 1 && A->gs_mode != 1;
     const bool narrow = (int64_t)g->nblk_total * 16 <= (int64_t)g->nlevels * A->flow_cap;
-    const bool can_flow = lds <= 48 * 1024 && g->nlevels > 1 && A->flow_cap > 0 && A->npl == 2;
-    if (can_flow) {
+    const bool single = can_persist && (A->gs_mode == 3 || (A->gs_mode == 0 && narrow));
+    const bool granular = can_persist && !single && A->npl == 2 && g->d_xs;
+    if (single) {
         FlowArgs<T> f;
         f.s = a;
         f.s.blkmeta = g->d_blkmeta;
         f.level_blk = g->d_level_blk;
         f.nlevels = g->nlevels;
         f.sync = g->d_sync;
-        int G = (narrow && !A->flow_force) ? 1 : std::max(1, std::min(256, g->max_level_blocks));
-        if (A->flow_force) G = std::max(1, std::min(G, A->flow_cap));
-        else if (G > 128) G = 0;          // very wide levels (fine grids): kernel boundaries are cheaper than a 200-way barrier
-        if (G > 1) PAMG_HIP(hipMemsetAsync(g->d_sync, 0, 2048, s));
-        if (G > 0) switch (epi) {
-            case EPI_GS: return flow_launch<T, EPI_GS>(A->npl, G, lds, s, f);
-            case EPI_GS_B: return flow_launch<T, EPI_GS_B>(A->npl, G, lds, s, f);
-            case EPI_SOR: return flow_launch<T, EPI_SOR>(A->npl, G, lds, s, f);
+        switch (epi) {
+            case EPI_GS: return flow1_launch<T, EPI_GS>(A->npl, lds, s, f);
+            case EPI_GS_B: return flow1_launch<T, EPI_GS_B>(A->npl, lds, s, f);
+            case EPI_SOR: return flow1_launch<T, EPI_SOR>(A->npl, lds, s, f);
             default: return PAMG_E_ARG;
         }
+    }
+    if (granular) {
+        const size_t ts = tsize(A->dtype);
+        const int64_t n = A->nrows;
+        GranArgs<T> ga;
+        ga.s = a;
+        ga.s.blkmeta = g->d_blkmeta;
+        ga.s.xs = (T *)g->d_xs;
+        ga.s.err = g->d_sync + 1;
+        ga.nblk = g->nblk_total;
+        ga.ticket = g->d_sync + 20;
+        if (!g->symmetric) {
+            // write-after-read hazards are not ordered by the waits: old values come from a snapshot
+            if (!g->d_xold) {
+                PAMG_HIP(hipMalloc(&g->d_xold, ((size_t)n + 8) * ts));
+                g->bytes += ((size_t)n + 8) * ts;
+                A->bytes += ((size_t)n + 8) * ts;
+            }
+            PAMG_HIP(hipMemcpyAsync(g->d_xold, x, (size_t)n * ts, hipMemcpyDeviceToDevice, s));
+            ga.s.x = (const T *)g->d_xold;
+        }
+        if (A->gs_prof && !g->d_prof) {
+            PAMG_HIP(hipMalloc((void **)&g->d_prof, (size_t)g->nblk_total * 8 * sizeof(long long)));
+            PAMG_HIP(hipMemset(g->d_prof, 0, (size_t)g->nblk_total * 8 * sizeof(long long)));
+        }
+        ga.prof = A->gs_prof ? g->d_prof : nullptr;
+        const int fgrid = (int)std::min<int64_t>(4096, (n + BLK - 1) / BLK);
+        hipLaunchKernelGGL((fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)g->d_xs, n);
+        PAMG_HIP(hipGetLastError());
+        // grid: enough workgroups to run ~8 dependency levels ahead (they wait in the poll loop with
+        // their operands in registers), not more -- idle pollers load the memory system (measured)
+        const int per_level = (g->nblk_total + g->nlevels - 1) / g->nlevels;
+        int G = std::max(1, std::min(g->nblk_total, gran2_grid<T>(epi, lds)));
+        if (A->gran_cap > 0) G = std::min(G, A->gran_cap);
+        else G = std::min(G, std::min(256, std::max(32, 8 * per_level)));
+        const bool xcd = A->gran_xcd == 1 || (A->gran_xcd == 0 && per_level <= 4 && n <= 262144);
+        if (xcd) {
+            // 8x the wanted grid is launched; the workgroups off the home XCD leave at once
+            PAMG_HIP(hipMemsetAsync(g->d_sync + 20, 0, 2 * sizeof(unsigned), s));
+            return gran2_launch<T, true>(epi, 8 * std::min(G, 96), lds, s, ga);
+        }
+        return gran2_launch<T, false>(epi, G, lds, s, ga);
     }
     for (int l = 0; l < g->nlevels; ++l) {
         a.blkmeta = g->d_blkmeta + g->level_blk[l];
@@ -637,8 +632,8 @@ static int bsr_stream_launch(int kind, int grid, int lds, hipStream_t s, const B
     return (int)hipGetLastError();
 }
 
-// order-exact block sweep (PNT_GS / BLK_GS) over a level schedule, same policy as the scalar
-// sweeps: narrow -> one persistent workgroup, medium -> persistent barrier grid, else launches
+// order-exact block sweep (PNT_GS / BLK_GS) over a level schedule: narrow -> one persistent
+// workgroup, medium -> persistent grid with a barrier per level, else one launch per level
 template <typename T>
 static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *Dinv, void *x, const void *b, int dirn,
                          hipStream_t s)
@@ -649,11 +644,14 @@ static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *
     r.meta = g->d_blkmeta; r.pAp = g->d_Ap; r.pblk = g->d_pblk; r.pbj = g->d_Aj; r.capv = A->cap;
     const int lds = std::max(64, (int)tsize(A->dtype) * (A->cap + 8));
     const bool narrow = (int64_t)g->nblk_total * 16 <= (int64_t)g->nlevels * A->flow_cap;
+    // gs_mode: 0 auto (narrow -> one workgroup, levels up to 128 row ranges wide -> barrier grid, else
+    // launches), 1 one launch per level, 2 barrier grid always, 3 one workgroup always
     int G = 0;
-    if (A->flow_cap > 0 && g->nlevels > 1) {
-        G = narrow ? 1 : std::min(256, g->max_level_blocks);
-        if (A->flow_force) G = std::max(1, std::min(std::min(256, g->max_level_blocks), A->flow_cap));
-        else if (G > 128) G = 0;
+    if (g->nlevels > 1 && A->gs_mode != 1) {
+        const int wide = std::max(1, std::min(256, g->max_level_blocks));
+        if (A->gs_mode == 3) G = 1;
+        else if (A->gs_mode == 2) G = A->gran_cap > 0 ? std::min(wide, A->gran_cap) : wide;
+        else if (A->flow_cap > 0) { G = narrow ? 1 : wide; if (G > 128) G = 0; }
     }
     if (G > 0) {
         if (G > 1) PAMG_HIP(hipMemsetAsync(g->d_sync, 0, 2048, s));
@@ -821,6 +819,24 @@ int dense_gemv(int dtype, int n, const void *M, const void *b, void *x, hipStrea
 }  // namespace pamg
 
 // =============================================================================== C ABI
+namespace pamg {
+int sweep_error(pamg_matrix_s *A, bool *error)
+{
+    *error = false;
+    for (int k = 0; k < 4; ++k) {
+        GsSchedule *g = A->gs[k];
+        if (!g || !g->d_sync) continue;
+        unsigned w[2] = {0, 0};
+        PAMG_HIP(hipMemcpy(w, g->d_sync, sizeof(w), hipMemcpyDeviceToHost));
+        if (w[1]) {
+            *error = true;
+            PAMG_HIP(hipMemset(g->d_sync + 1, 0, sizeof(unsigned)));
+        }
+    }
+    return PAMG_OK;
+}
+}  // namespace pamg
+
 extern "C" {
 
 int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, int n_bcol, int R,
@@ -833,7 +849,8 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
     if (R > MAXBS || C > MAXBS) return PAMG_E_UNSUPPORTED;
     const int64_t nblk = Ap[n_brow];
     if (nblk < 0 || (nblk > 0 && (!Aj || !Ax))) return PAMG_E_ARG;
-    if ((int64_t)n_brow * R > INT32_MAX || (int64_t)n_bcol * C > INT32_MAX || nblk * R * C > INT32_MAX)
+    // column ids carry two flag bits in the level schedules (pamg_kernels.h: EARLY_BIT, DIAG_BIT)
+    if ((int64_t)n_brow * R > (1 << 30) || (int64_t)n_bcol * C > (1 << 30) || nblk * R * C > INT32_MAX)
         return PAMG_E_UNSUPPORTED;
     pamg_matrix_s *A = new (std::nothrow) pamg_matrix_s();
     if (!A) return PAMG_E_ALLOC;
@@ -934,12 +951,12 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 1: if (value != 1 && value != 2 && value != 4) return PAMG_E_ARG; A->npl = value; break;
         case 2: if (value < 1) return PAMG_E_ARG; A->max_rows = value; break;
         case 3: if (value < 0 || value > 256) return PAMG_E_ARG; A->flow_cap = value; return PAMG_OK;
-        case 4: A->flow_force = value != 0; return PAMG_OK;
-        case 5: if (value != 0 && value != 1) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
+        case 5: if (value < 0 || value > 3) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
         case 6: if (value < 0) return PAMG_E_ARG; A->gran_cap = value; return PAMG_OK;
-        case 7: A->gran_xcd = value != 0; return PAMG_OK;
+        case 7: if (value < 0 || value > 2) return PAMG_E_ARG; A->gran_xcd = value; return PAMG_OK;
         case 8: if (value < 0 || value > 15) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;
         case 9: A->use_xwin = value != 0; break;
+        case 11: A->gs_prof = value != 0; return PAMG_OK;
         default: return PAMG_E_ARG;
     }
     for (int k = 0; k < 4; ++k) { if (A->gs[k]) A->bytes -= A->gs[k]->bytes; free_schedule(A->gs[k]); A->gs[k] = nullptr; }
@@ -982,18 +999,30 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
     return st;
 }
 
+int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count)
+{
+    if (!A || which < 0 || which > 3 || !count) return PAMG_E_ARG;
+    *count = 0;
+    GsSchedule *g = A->gs[which];
+    if (!g || !g->d_prof) return PAMG_OK;
+    PAMG_HIP(hipDeviceSynchronize());
+    *count = g->nblk_total;
+    if (!out) return PAMG_OK;
+    if (capacity < g->nblk_total) return PAMG_E_ARG;
+    PAMG_HIP(hipMemcpy(out, g->d_prof, (size_t)g->nblk_total * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int l = 0; l < g->nlevels; ++l)
+        for (int q = g->level_blk[l]; q < g->level_blk[l + 1]; ++q) out[(size_t)q * 8 + 7] = l;
+    return PAMG_OK;
+}
+
 int pamg_matrix_flow_error(pamg_matrix_t A, int *error)
 {
     if (!A || !error) return PAMG_E_ARG;
     *error = 0;
     PAMG_HIP(hipDeviceSynchronize());
-    for (int k = 0; k < 4; ++k) {
-        GsSchedule *g = A->gs[k];
-        if (!g || !g->d_sync) continue;
-        unsigned w[2] = {0, 0};
-        PAMG_HIP(hipMemcpy(w, g->d_sync, sizeof(w), hipMemcpyDeviceToHost));
-        if (w[1]) *error = 1;
-    }
+    bool e = false;
+    PAMG_TRY(pamg::sweep_error(A, &e));
+    *error = e ? 1 : 0;
     return PAMG_OK;
 }
 

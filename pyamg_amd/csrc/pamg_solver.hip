@@ -190,6 +190,19 @@ int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, 
     return PAMG_E_ARG;
 }
 
+// after a synchronising entry point: did any persistent sweep give up waiting?
+int check_sweeps(pamg_solver_s *S)
+{
+    bool any = false;
+    for (Level &L : S->levels) {
+        if (!L.A) continue;
+        bool e = false;
+        PAMG_TRY(sweep_error(L.A, &e));
+        any = any || e;
+    }
+    return any ? PAMG_E_TIMEOUT : PAMG_OK;
+}
+
 int coarse_solve(pamg_solver_s *S, const void *b, void *x, hipStream_t s)
 {
     if (S->coarse_zero) return (int)hipMemsetAsync(x, 0, (size_t)S->n_c * tsize(S->dtype), s);
@@ -593,7 +606,7 @@ int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int m
     PAMG_HIP(hipStreamSynchronize(s));
     if (n_iter) *n_iter = it;
     if (info) *info = converged_at >= 0 ? 0 : it;
-    return PAMG_OK;
+    return check_sweeps(S);
 }
 
 int pamg_solver_load(pamg_solver_t S, const void *x, const void *b, pamg_stream_t s_)
@@ -630,6 +643,7 @@ int pamg_solver_iterate(pamg_solver_t S, int k, int cycle, int cycles_per_level,
         PAMG_HIP(hipMemcpyAsync(residuals, S->d_norms, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
         PAMG_HIP(hipStreamSynchronize(s));
         for (int it = 0; it < k; ++it) residuals[it] = std::sqrt(residuals[it]);
+        return check_sweeps(S);
     }
     return PAMG_OK;
 }
@@ -727,7 +741,7 @@ int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int max
     PAMG_HIP(hipStreamSynchronize(s));
     if (n_iter) *n_iter = it;
     if (info) *info = inf;
-    return PAMG_OK;
+    return check_sweeps(S);
 }
 
 int pamg_solver_stats(pamg_solver_t S, int64_t stats[8])

@@ -62,9 +62,21 @@ class DeviceMatrix:
         capi.check(capi.lib().pamg_matrix_flow_error(self.handle, C.byref(e)), "pamg_matrix_flow_error")
         return bool(e.value)
 
-    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, flow_force=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, xwin=None):
+    def gs_profile(self, which=0):
+        """time stamps of the granular sweep (tune(gs_prof=1)): int64 array [ranges, 8]"""
+        import numpy as np
+        n = C.c_int64(0)
         lib = capi.lib()
-        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (4, flow_force), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (9, xwin)):
+        capi.check(lib.pamg_matrix_gs_profile(self.handle, which, None, 0, C.byref(n)), "pamg_matrix_gs_profile")
+        out = np.zeros((n.value, 8), dtype=np.int64)
+        if n.value:
+            capi.check(lib.pamg_matrix_gs_profile(self.handle, which, C.c_void_p(out.ctypes.data), n.value, C.byref(n)),
+                       "pamg_matrix_gs_profile")
+        return out
+
+    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, xwin=None, gs_prof=None):
+        lib = capi.lib()
+        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (9, xwin), (11, gs_prof)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 

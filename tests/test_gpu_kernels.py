@@ -276,8 +276,11 @@ def test_relaxation_module_contract():
 
 
 def test_gs_sweep_modes_all_exact():
-    """Every scheduling mode of the order-exact sweep (one launch per level, persistent barrier
-    kernel, granular sync-free kernel, its single-XCD variant) gives the reference's bits."""
+    """Every scheduler of the order-exact sweep (one launch per level, one persistent workgroup,
+    granular sync-free sweep across the chip / inside one XCD / on a tiny grid, automatic choice)
+    gives the reference's bits -- on a stencil, an irregular symmetric pattern, a BSR(1,1)
+    operator, a NON-symmetric pattern (old values from a snapshot), an operator with zero and
+    missing diagonal entries, and in single precision."""
     from oracle import oracle as orc
     from tools.problems import poisson_csr
     rng = np.random.RandomState(3)
@@ -285,27 +288,34 @@ def test_gs_sweep_modes_all_exact():
     S = sp.random(4000, 4000, density=0.004, random_state=rng, format="csr")
     S = sp.csr_array(S + S.T + sp.diags_array(rng.rand(4000) + 4.0))
     S.sort_indices()
-    for M in (A3, S, sp.csr_array(A3.tobsr(blocksize=(1, 1)))):
-        op = sparse_op(M if M.format == "csr" else M)
-        if M is not A3 and M is not S:
-            op = sparse_op(A3.tobsr(blocksize=(1, 1)))          # BSR(1,1) flavour
+    N = sp.random(3000, 3000, density=0.004, random_state=rng, format="csr")
+    N = sp.csr_array(N + sp.diags_array(rng.rand(3000) + 4.0))          # structurally non-symmetric
+    Z = sp.lil_array(S[:1500, :1500])
+    for i in range(0, 1500, 7):
+        Z[i, i] = 0.0                                                    # explicit zero / missing diagonals
+    Z = sp.csr_array(Z)
+    Z.sort_indices()
+    cases = [sparse_op(A3), sparse_op(S), sparse_op(A3.tobsr(blocksize=(1, 1))), sparse_op(N), sparse_op(Z),
+             sparse_op(sp.csr_array(S.astype(np.float32)))]
+    for op in cases:
         n = op.shape[0]
-        x = rng.rand(n); b = rng.rand(n)
+        dt = op.data.dtype
+        x = rng.rand(n).astype(dt); b = rng.rand(n).astype(dt)
         ref = x.copy(); orc.relax_gauss_seidel(op, ref, b, 2, "symmetric")
         refs = x.copy(); orc.relax_sor(op, refs, b, 1.4, 1, "forward")
         dA = DeviceMatrix(op)
         dA.tune(lds_entries=256)
         db = capi.DeviceArray.from_host(b)
-        for kw in (dict(gs_mode=0, flow_cap=0, flow_force=0), dict(gs_mode=0, flow_cap=8, flow_force=1),
-                   dict(gs_mode=0, flow_cap=1, flow_force=1), dict(gs_mode=1, gran_xcd=0), dict(gs_mode=1, gran_xcd=1),
-                   dict(gs_mode=1, gran_xcd=0, gran_cap=3)):
+        for kw in (dict(gs_mode=1), dict(gs_mode=3), dict(gs_mode=2, gran_xcd=2, gran_cap=0),
+                   dict(gs_mode=2, gran_xcd=1, gran_cap=0), dict(gs_mode=2, gran_xcd=2, gran_cap=3),
+                   dict(gs_mode=2, gran_xcd=1, gran_cap=2), dict(gs_mode=0, gran_xcd=0, gran_cap=0)):
             dA.tune(**kw)
             dx = capi.DeviceArray.from_host(x)
             dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
-            assert np.array_equal(dx.download(), ref), kw
+            assert np.array_equal(dx.download(), ref), (kw, op.fmt, dt)
             dx.upload(x)
             dA.gauss_seidel(dx, db, sweep="forward", omega=1.4)
-            assert np.array_equal(dx.download(), refs), kw
+            assert np.array_equal(dx.download(), refs), (kw, op.fmt, dt)
             assert not dA.flow_error(), kw
 
 
@@ -402,7 +412,8 @@ def test_block_sweep_modes_all_exact():
     dM = DeviceMatrix(op)
     db = capi.DeviceArray.from_host(b)
     dD = capi.DeviceArray.from_host(Dinv.reshape(-1))
-    for kw in (dict(flow_cap=0), dict(flow_cap=32), dict(flow_cap=256)):
+    for kw in (dict(flow_cap=0), dict(flow_cap=32), dict(flow_cap=256), dict(gs_mode=1), dict(gs_mode=2), dict(gs_mode=2, gran_cap=3),
+               dict(gs_mode=3)):
         dM.tune(**kw)
         dx = capi.DeviceArray.from_host(x)
         dM.gauss_seidel(dx, db, sweep="symmetric")

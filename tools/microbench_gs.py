@@ -37,6 +37,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, nargs="+", default=[128, 128, 128])
 ap.add_argument("--tag", default="gs")
 ap.add_argument("--check", type=int, default=1)
+ap.add_argument("--prof", type=int, default=1)
 a = ap.parse_args()
 A = pyamg.gallery.poisson(a.grid, format="csr")
 np.random.seed(1)
@@ -57,8 +58,12 @@ for li, L in enumerate(spec.levels[:-1]):
     db = capi.DeviceArray.from_host(b)
     dx = capi.DeviceArray.from_host(x)
     rec = {"level": li, "n": n, "nnz": op.nnz, "fmt": op.fmt}
-    for name, kw in [("default", dict(gs_mode=0, gran_xcd=0, flow_cap=32, flow_force=0))] + [(f"flowG{G}", dict(gs_mode=0, flow_cap=G, flow_force=1)) for G in (16, 64, 256)] + \
-                    [("launch", dict(gs_mode=0, gran_xcd=0, flow_cap=0, flow_force=0)), ("flow1", dict(gs_mode=0, flow_cap=1, flow_force=1))]:
+    variants = [("auto", dict(gs_mode=0, gran_xcd=0, gran_cap=0, gs_prof=0)), ("launch", dict(gs_mode=1)), ("single", dict(gs_mode=3))]
+    variants += [(f"gran_G{G}", dict(gs_mode=2, gran_cap=G, gran_xcd=2, gs_prof=0)) for G in (0, 128, 384)]
+    variants += [(f"granxcd_G{G}", dict(gs_mode=2, gran_cap=G, gran_xcd=1, gs_prof=0)) for G in (0,)]
+    if a.prof:
+        variants += [("granprof", dict(gs_mode=2, gran_cap=0, gran_xcd=2, gs_prof=1))]
+    for name, kw in variants:
         dA.tune(**kw)
         dx.upload(x)
         dA.gauss_seidel(dx, db, sweep="symmetric")
@@ -70,6 +75,26 @@ for li, L in enumerate(spec.levels[:-1]):
         rec[name] = {"fwd_ms": round(ms, 4), "exact": ok, "timeout": err}
         rec["levels_fwd"] = info["gs_levels_fwd"]
         print(li, n, name, rec[name], "levels", info["gs_levels_fwd"], flush=True)
+        if kw.get("gs_prof"):
+            pr = dA.gs_profile(0)
+            if len(pr):
+                lev = pr[:, 7]
+                nl = int(lev.max()) + 1
+                fin = np.zeros(nl); polled = np.zeros(nl); staged = np.zeros(nl); arrive = np.zeros(nl)
+                for l in range(nl):
+                    m = lev == l
+                    fin[l] = pr[m, 4].max(); polled[l] = pr[m, 2].max(); staged[l] = pr[m, 3].max(); arrive[l] = pr[m, 0].max()
+                t = 0.01   # us per tick
+                hop = np.diff(fin) * t
+                wait = (polled[1:] - fin[:-1]) * t        # previous level finished -> this level's data seen (wave 0)
+                stg = (staged[1:] - polled[1:]) * t       # -> all waves staged
+                rowp = (fin[1:] - staged[1:]) * t         # -> row phase + stores issued
+                slack = (fin[:-1] - arrive[1:]) * t       # how early the workgroup arrived
+                q = lambda v: [round(float(np.percentile(v, p)), 2) for p in (10, 50, 90)]
+                rec[name]["prof_us_p10_50_90"] = {"hop": q(hop), "prev_fin_to_polled": q(wait), "polled_to_staged": q(stg),
+                                                  "staged_to_fin": q(rowp), "arrived_before_prev_fin": q(slack),
+                                                  "span_ms": round(float((fin[-1] - pr[:, 0].min()) * t / 1000), 4)}
+                print("   prof", rec[name]["prof_us_p10_50_90"], flush=True)
     out.append(rec)
     dA.free()
 od = ROOT / "gpurun_out"
