@@ -287,8 +287,33 @@ def main():
         if cpu:
             out["speedup_vs_cpu_reference"] = round(out["value"] / cpu["value"], 1)
 
+    # The legs below are extras: whatever happens in them (an exception on one rank, a collective that
+    # never completes on a node this code has not run on yet), the line of the main leg above must still
+    # be printed exactly once.  Exceptions are recorded in the JSON; a watchdog thread prints the line
+    # and ends the process if the extras exceed their time budget (a blocked HIP/RCCL call cannot be
+    # interrupted from Python).
+    import threading
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and out is not None and not printed.is_set():
+            printed.set()
+            print(json.dumps(out), flush=True)
+
+    def bail():
+        if rank == 0 and out is not None:
+            out.setdefault("sharded", {})["error"] = f"extras exceeded {extras_budget:.0f} s; main leg reported without them"
+        emit()
+        os._exit(0)
+
+    extras_budget = float(os.environ.get("PAMG_EXTRAS_TIMEOUT", "900" if world == 1 else "600"))
+    watchdog = threading.Timer(extras_budget, bail)
+    watchdog.daemon = True
+    watchdog.start()
+
     # =========================================================== sharded leg (same hierarchy, Chebyshev)
     if not args.no_extras and args.workload in ("c3", "small"):
+      try:
         dml.free()
         del dml
         np.random.seed(SEED)
@@ -323,9 +348,14 @@ def main():
                 sh["cpu_baseline"] = c2cpu
                 sh["parity"] = parity_of(res2, r2cpu)
             out["sharded"] = sh
+      except Exception as e:                                    # noqa: BLE001 -- extras never take the main line down
+        log(f"sharded leg failed on rank {rank}: {e!r}")
+        if rank == 0 and out is not None:
+            out["sharded"] = {"error": repr(e)[:300]}
 
     # =========================================================== configs[1] leg (N = 1 only)
     if not args.no_extras and world == 1 and args.workload == "c3":
+      try:
         wl2 = WORKLOADS["c2"]
         A2, ml2, ts2 = build(wl2)
         b2, x02 = rhs(A2.shape[0])
@@ -339,12 +369,15 @@ def main():
             ex["parity"] = parity_of(res3, r3cpu)
         out["extra"] = {"c2": ex}
         d3.free()
+      except Exception as e:                                    # noqa: BLE001
+        log(f"configs[1] leg failed: {e!r}")
+        out["extra"] = {"c2": {"error": repr(e)[:300]}}
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    watchdog.cancel()
     return out
 
 
