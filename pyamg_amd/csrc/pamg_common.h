@@ -83,6 +83,7 @@ struct GsSchedule {
     void *d_Ax = nullptr, *d_diag = nullptr;
     int *d_level_blk = nullptr;      // device copy of level_blk (persistent sweep kernel)
     int *d_pblk = nullptr;           // block schedules: position of scheduled block q in the operator's block arrays
+    int *d_dpos = nullptr;           // block schedules: position of each scheduled row's diagonal block (or -1)
     void *d_xs = nullptr;            // granular sweep: hand-off buffer (one value per matrix row)
     void *d_xold = nullptr;          // granular sweep, non-symmetric patterns: snapshot of x (old values)
     long long *d_prof = nullptr;     // granular sweep diagnostics: [nblk_total][8] time stamps
@@ -107,6 +108,7 @@ struct pamg_matrix_s {
     void *d_diag = nullptr;                   // diagonal of the scalar view (point smoothers)
     // block view kept for the true block smoothers (bs > 1): block CSR arrays
     int *d_bAp = nullptr, *d_bAj = nullptr;   // nullptr when R == C == 1
+    int *d_bAjf = nullptr, *d_bdiag = nullptr; // block columns with the diagonal flag (bit 30); diagonal block position per block row
     void *d_bAx = nullptr;                    // block-ordered values (square blocks only)
     int64_t nblocks_b = 0;
     int4 *d_bmeta = nullptr;                  // row-range plan over block rows (LDS-streamed BSR relaxation)

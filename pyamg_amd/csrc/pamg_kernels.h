@@ -990,6 +990,8 @@ struct BlockArgs {
     T omega;
     int bs, first, count;   // rows [first, first+count) of rid (or of 0..n_brow)
     int dirn;               // +1 forward, -1 backward (point sweep inside the diagonal block)
+    T *xs;                  // granular sweep: hand-off buffer (sentinel = not published yet) or nullptr
+    unsigned *err;          // granular sweep: error flag (spin bound hit)
 };
 
 
@@ -1023,7 +1025,11 @@ __device__ __forceinline__ void block_row_finish(const BlockArgs<T> &a, const in
             for (int k = 0; k < bs; ++k)
                 a.xdst[(long)i * bs + k] = (one - a.omega) * a.xsrc[(long)i * bs + k] + a.omega * v[k];
         } else {
-            for (int k = 0; k < bs; ++k) stxb<COH>(a.xdst + (long)i * bs + k, v[k]);
+            for (int k = 0; k < bs; ++k) {
+                stxb<COH>(a.xdst + (long)i * bs + k, v[k]);
+                if constexpr (COH == 2)            // granular sweep: the published datum is the flag
+                    __hip_atomic_store(a.xs + (long)i * bs + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     } else {
         // point sweep inside the diagonal block (untouched when no diagonal block is stored)
@@ -1051,6 +1057,11 @@ __device__ __forceinline__ void block_row_finish(const BlockArgs<T> &a, const in
             }
         } else if constexpr (KIND == PNT_JACOBI) {
             for (int k = 0; k < bs; ++k) a.xdst[(long)i * bs + k] = loc[k];
+        }
+        if constexpr (COH == 2 && KIND == PNT_GS) {
+            // granular sweep: ALWAYS publish the whole block row (an untouched point publishes its old value)
+            for (int k = 0; k < bs; ++k)
+                __hip_atomic_store(a.xs + (long)i * bs + k, loc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1100,7 +1111,8 @@ struct BsrRange {
     const int4 *meta;      // [ranges] {first row, end row, first block, end block} in schedule order
     const int *pAp;        // [rows+1] cumulative block count in schedule order
     const int *pblk;       // [blocks] position of scheduled block q in Ax/bAj (nullptr = identity)
-    const int *pbj;        // [blocks] block column of scheduled block q
+    const int *pbj;        // [blocks] block column of scheduled block q; bit 30: diagonal block, bit 31: early (needs the NEW x_j)
+    const int *dpos;       // [rows] position in Ax (block index) of the row's diagonal block (last stored) or -1
     int capv;              // LDS capacity in values
 };
 
@@ -1114,25 +1126,29 @@ __device__ __forceinline__ void bsr_range(const BlockArgs<T> &a, const BsrRange<
     if (nent <= g.capv) {
         for (int e = tid; e < nent; e += BLK) {
             const int q = q0 + e / bs, r = e % bs;
-            const long p = g.pblk ? g.pblk[q] : q;
-            const T *Arow = a.Ax + p * bb + r * bs;
-            const T *xj = a.xsrc + (long)g.pbj[q] * bs;
+            const int cj = g.pbj[q];
             T d = T(0);
-            for (int c = 0; c < bs; ++c) d += Arow[c] * ldx<COH>(xj + c);
+            if (!(cj & DIAG_BIT)) {                        // the diagonal block is staged as +0 (see DIAG_BIT)
+                const long p = g.pblk ? g.pblk[q] : q;
+                const T *Arow = a.Ax + p * bb + r * bs;
+                const T *xj = a.xsrc + (long)(cj & COL_MASK) * bs;
+                for (int c = 0; c < bs; ++c) d += Arow[c] * ldx<COH>(xj + c);
+            }
             prodv[e] = d;
         }
         __syncthreads();
         for (int r = r0 + tid; r < r1; r += BLK) {
             const int i = a.rid ? a.rid[r] : r;
             T acc[MAXBS];
-            long dpos = -1;
+            const int dq = g.dpos[r];
+            const long dpos = dq >= 0 ? (long)dq * bb : -1;
             if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
                 for (int k = 0; k < bs; ++k) acc[k] = T(0);
             } else {
                 for (int k = 0; k < bs; ++k) acc[k] = a.b[(long)i * bs + k];
             }
-            for (int q = g.pAp[r]; q < g.pAp[r + 1]; ++q) {
-                if (g.pbj[q] == i) { dpos = (long)(g.pblk ? g.pblk[q] : q) * bb; continue; }
+            const int qa = g.pAp[r], qb = g.pAp[r + 1];
+            for (int q = qa; q < qb; ++q) {                // LDS only: nothing here waits on global memory
                 const T *v = prodv + (q - q0) * bs;
                 if constexpr (KIND == BLK_JACOBI || KIND == BLK_GS) {
                     for (int k = 0; k < bs; ++k) acc[k] += v[k];
@@ -1189,6 +1205,233 @@ __global__ __launch_bounds__(BLK) void bsr_flow_kernel(const BlockArgs<T> a, con
             }
             __syncthreads();
         }
+    }
+}
+
+// ---- granular order-exact block sweep -------------------------------------------------------
+// The block twin of gs_gran2_kernel: one persistent launch, no barrier between dependency levels.
+// A lane owns up to GE (block, row-in-block) pairs of its row range.  It first fetches everything
+// that does not depend on other ranges (its row of each block: GE x bs values in registers), then
+// loads ONE x value per pair -- element e of the range's gathered x -- polling the hand-off
+// buffer for the values of block rows visited earlier in the sweep (batch polling: all pending
+// loads per round), parks x in LDS, computes its in-order dots from LDS, and the row phase
+// finishes and publishes as in the barrier form.
+constexpr int GE = 6;          // pairs per lane: ranges of up to GE * BLK values (the default plan's 1536)
+
+// tail of one block row for the granular sweep: like block_row_finish<.., 2>, but every operand that
+// does not depend on other rows was fetched before the wait -- b and the row's own old values in
+// registers, the diagonal block (PNT_GS) or its inverse (BLK_GS) through D (LDS or global; nullptr =
+// no diagonal block stored)
+template <typename T, int KIND>
+__device__ __forceinline__ void block_row_finish_gran(const BlockArgs<T> &a, const int i, T (&acc)[MAXBS], const T *D,
+                                                      const T (&breg)[MAXBS], T (&loc)[MAXBS])
+{
+    const int bs = a.bs;
+    if constexpr (KIND == BLK_GS) {
+        T v[MAXBS];
+        for (int k = 0; k < bs; ++k) acc[k] = breg[k] - acc[k];
+        for (int r = 0; r < bs; ++r) {
+            T d = T(0);
+            for (int c = 0; c < bs; ++c) d += D[r * bs + c] * acc[c];
+            v[r] = d;
+        }
+        for (int k = 0; k < bs; ++k) {
+            a.xdst[(long)i * bs + k] = v[k];
+            __hip_atomic_store(a.xs + (long)i * bs + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        if (D) {
+            const int k0 = a.dirn > 0 ? 0 : bs - 1, k1 = a.dirn > 0 ? bs : -1;
+            for (int k = k0; k != k1; k += a.dirn) {
+                T d = T(1);
+                for (int kk = k0; kk != k1; kk += a.dirn) {
+                    if (kk == k) d = D[k * bs + kk];
+                    else acc[k] -= D[k * bs + kk] * loc[kk];
+                }
+                if (d != T(0)) {
+                    loc[k] = acc[k] / d;                // later points see the new value
+                    a.xdst[(long)i * bs + k] = loc[k];
+                }
+            }
+        }
+        // ALWAYS publish the whole block row (an untouched point publishes its old value)
+        for (int k = 0; k < bs; ++k)
+            __hip_atomic_store(a.xs + (long)i * bs + k, loc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <typename T, int KIND>
+__device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrRange<T> &g, const int4 m, T *xl, T *prodv, T *dl)
+{
+    const int bs = a.bs, bb = bs * bs;
+    const int r0 = m.x, r1 = m.y, q0 = m.z, q1 = m.w;
+    const int tid = threadIdx.x;
+    const int nent = (q1 - q0) * bs;
+    if (nent <= g.capv && nent <= GE * BLK) {
+        // ---- everything that does not depend on other ranges, before the wait
+        T Areg[GE][MAXBS];
+        int cjs[GE];
+#pragma unroll
+        for (int k = 0; k < GE; ++k) {
+            const int e = tid + k * BLK;
+            cjs[k] = DIAG_BIT;
+            if (e < nent) {
+                const int q = q0 + e / bs, r = e % bs;
+                cjs[k] = g.pbj[q];
+                const long p = g.pblk ? g.pblk[q] : q;
+                const T *Arow = a.Ax + p * bb + r * bs;
+#pragma unroll
+                for (int c = 0; c < MAXBS; ++c) Areg[k][c] = c < bs ? Arow[c] : T(0);
+            }
+        }
+        const int nrow = r1 - r0;
+        const bool dl_ok = nrow * bb <= g.capv;              // diagonal blocks (or inverses) of the range fit the LDS slab
+        if (dl_ok) {
+            for (int t = tid; t < nrow * bb; t += BLK) {
+                const int rr = t / bb, u = t - rr * bb;
+                T v = T(0);
+                if constexpr (KIND == BLK_GS) {
+                    v = a.Dinv[(long)(a.rid ? a.rid[r0 + rr] : r0 + rr) * bb + u];
+                } else {
+                    const int dq = g.dpos[r0 + rr];
+                    if (dq >= 0) v = a.Ax[(long)dq * bb + u];
+                }
+                dl[t] = v;
+            }
+        }
+        const int myr = r0 + tid;
+        const bool has_row = myr < r1;
+        int i = 0, qa = 0, qb = 0, dq = -1;
+        T breg[MAXBS], loc[MAXBS];
+        if (has_row) {
+            i = a.rid ? a.rid[myr] : myr;
+            qa = g.pAp[myr]; qb = g.pAp[myr + 1];
+            dq = g.dpos[myr];
+#pragma unroll
+            for (int k = 0; k < MAXBS; ++k) {
+                breg[k] = k < bs ? a.b[(long)i * bs + k] : T(0);
+                loc[k] = (KIND == PNT_GS && k < bs) ? a.xsrc[(long)i * bs + k] : T(0);
+            }
+        }
+        // ---- the wait: one x value per (block, row-in-block) pair, batch-polled
+        T xv[GE];
+        unsigned pend = 0;
+#pragma unroll
+        for (int k = 0; k < GE; ++k) {
+            const int e = tid + k * BLK;
+            xv[k] = T(0);
+            if (e < nent && !(cjs[k] & DIAG_BIT)) {
+                const long at = (long)(cjs[k] & COL_MASK) * bs + e % bs;
+                if (cjs[k] & EARLY_BIT) { xv[k] = __hip_atomic_load(a.xs + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pend |= 1u << k; }
+                else xv[k] = a.xsrc[at];
+            }
+        }
+        unsigned spins = 0;
+        while (true) {
+#pragma unroll
+            for (int k = 0; k < GE; ++k)
+                if ((pend >> k) & 1u)
+                    if (Sentinel<T>::bits(xv[k]) != Sentinel<T>::value) pend &= ~(1u << k);
+            if (!pend) break;
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int k = 0; k < GE; ++k)
+                if ((pend >> k) & 1u) {
+                    const int e = tid + k * BLK;
+                    xv[k] = __hip_atomic_load(a.xs + (long)(cjs[k] & COL_MASK) * bs + e % bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            if (++spins > (1u << 22)) {
+                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < GE; ++k) {
+            const int e = tid + k * BLK;
+            if (e < nent) xl[e] = xv[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GE; ++k) {
+            const int e = tid + k * BLK;
+            if (e < nent) {
+                T d = T(0);
+                if (!(cjs[k] & DIAG_BIT)) {
+                    const T *xq = xl + (e / bs) * bs;
+#pragma unroll
+                    for (int c = 0; c < MAXBS; ++c)
+                        if (c < bs) d += Areg[k][c] * xq[c];
+                }
+                prodv[e] = d;
+            }
+        }
+        __syncthreads();
+        if (has_row) {
+            T acc[MAXBS];
+            if constexpr (KIND == BLK_GS) {
+                for (int k = 0; k < bs; ++k) acc[k] = T(0);
+            } else {
+                for (int k = 0; k < bs; ++k) acc[k] = breg[k];
+            }
+            for (int q = qa; q < qb; ++q) {
+                const T *v = prodv + (q - q0) * bs;
+                if constexpr (KIND == BLK_GS) {
+                    for (int k = 0; k < bs; ++k) acc[k] += v[k];
+                } else {
+                    for (int k = 0; k < bs; ++k) acc[k] -= v[k];
+                }
+            }
+            const T *D;
+            if constexpr (KIND == BLK_GS) D = dl_ok ? dl + (myr - r0) * bb : a.Dinv + (long)i * bb;
+            else D = dq < 0 ? nullptr : (dl_ok ? dl + (myr - r0) * bb : a.Ax + (long)dq * bb);
+            block_row_finish_gran<T, KIND>(a, i, acc, D, breg, loc);
+        }
+    } else if (tid == 0) {
+        // over-long block row (a range of its own): one lane, block after block
+        const int r = r0;
+        const int i = a.rid ? a.rid[r] : r;
+        T acc[MAXBS], v[MAXBS];
+        const int dq = g.dpos[r];
+        const long dpos = dq >= 0 ? (long)dq * bb : -1;
+        if constexpr (KIND == BLK_GS) {
+            for (int k = 0; k < bs; ++k) acc[k] = T(0);
+        } else {
+            for (int k = 0; k < bs; ++k) acc[k] = a.b[(long)i * bs + k];
+        }
+        for (int q = g.pAp[r]; q < g.pAp[r + 1]; ++q) {
+            const int cj = g.pbj[q];
+            if (cj & DIAG_BIT) continue;
+            const T *blk = a.Ax + (long)(g.pblk ? g.pblk[q] : q) * bb;
+            T xq[MAXBS];
+            for (int c = 0; c < bs; ++c) {
+                const long at = (long)(cj & COL_MASK) * bs + c;
+                xq[c] = (cj & EARLY_BIT) ? spin_value<T>(a.xs, (int)at, a.err) : a.xsrc[at];
+            }
+            for (int rr = 0; rr < bs; ++rr) {
+                T d = T(0);
+                for (int c = 0; c < bs; ++c) d += blk[rr * bs + c] * xq[c];
+                v[rr] = d;
+            }
+            if constexpr (KIND == BLK_GS) {
+                for (int k = 0; k < bs; ++k) acc[k] += v[k];
+            } else {
+                for (int k = 0; k < bs; ++k) acc[k] -= v[k];
+            }
+        }
+        block_row_finish<T, KIND, 2>(a, i, acc, dpos);
+    }
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(BLK) void bsr_gran_kernel(const BlockArgs<T> a, const BsrRange<T> g, int nblk)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *xl = reinterpret_cast<T *>(smem_raw);
+    T *prodv = xl + (g.capv + 8);
+    T *dl = prodv + (g.capv + 8);
+    for (int blk = (int)blockIdx.x; blk < nblk; blk += (int)gridDim.x) {
+        bsr_range_gran<T, KIND>(a, g, g.meta[blk], xl, prodv, dl);
+        __syncthreads();                                   // LDS is reused by the next row range
     }
 }
 

@@ -199,7 +199,7 @@ int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap)
 void free_schedule(GsSchedule *g)
 {
     if (!g) return;
-    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_xold); hipFree(g->d_pblk); hipFree(g->d_prof);
+    hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_xold); hipFree(g->d_pblk); hipFree(g->d_dpos); hipFree(g->d_prof);
     delete g;
 }
 
@@ -358,23 +358,32 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
 // they are: a block row is >= 0.5 KB of contiguous values, which streams well as it is)
 int build_schedule_block(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out)
 {
-    std::vector<int> order, lptr;
+    std::vector<int> order, lptr, vis;
     PAMG_TRY(analyse_levels(A->n_brow, A->h_bAp.data(), A->h_bAj.data(), row_start, row_stop,
-                            row_step, order, lptr));
+                            row_step, order, lptr, &vis));
     GsSchedule *g = new (std::nothrow) GsSchedule();
     if (!g) return PAMG_E_ALLOC;
     g->row_start = row_start; g->row_stop = row_stop; g->row_step = row_step;
     g->nlevels = (int)lptr.size() - 1;
     g->nrows = (int64_t)order.size();
+    g->symmetric = pattern_symmetric(A->n_brow, A->h_bAp.data(), A->h_bAj.data(), vis);
     const int m = (int)order.size();
     std::vector<int> pAp((size_t)m + 1, 0);
     for (int r = 0; r < m; ++r) pAp[r + 1] = pAp[r] + (A->h_bAp[order[r] + 1] - A->h_bAp[order[r]]);
     g->nnz = pAp[m];
-    std::vector<int> pblk((size_t)g->nnz), pbj((size_t)g->nnz);
+    // block columns carry the same two flags as the scalar schedules: bit 31 "early" (the column's
+    // block row is visited earlier in this sweep: its NEW values are needed), bit 30 diagonal block
+    std::vector<int> pblk((size_t)g->nnz), pbj((size_t)g->nnz), dpos((size_t)m, -1);
     for (int r = 0; r < m; ++r) {
-        const int i = order[r];
+        const int i = order[r], ti = vis[i];
         int q = pAp[r];
-        for (int p = A->h_bAp[i]; p < A->h_bAp[i + 1]; ++p, ++q) { pblk[q] = p; pbj[q] = A->h_bAj[p]; }
+        for (int p = A->h_bAp[i]; p < A->h_bAp[i + 1]; ++p, ++q) {
+            const int j = A->h_bAj[p];
+            pblk[q] = p;
+            pbj[q] = j;
+            if (j == i) { pbj[q] = j | 0x40000000; dpos[r] = p; }
+            else if (j >= 0 && j < A->n_brow && vis[j] >= 0 && vis[j] < ti) pbj[q] = j | (int)0x80000000u;
+        }
     }
     std::vector<int4> blk;
     g->level_blk.assign(1, 0);
@@ -389,8 +398,14 @@ int build_schedule_block(pamg_matrix_s *A, int row_start, int row_stop, int row_
     if (!st) st = upload(&g->d_Ap, pAp.data(), pAp.size(), &g->bytes);
     if (!st) st = upload(&g->d_pblk, pblk.data(), pblk.size(), &g->bytes);
     if (!st) st = upload(&g->d_Aj, pbj.data(), pbj.size(), &g->bytes);
+    if (!st) st = upload(&g->d_dpos, dpos.data(), dpos.size(), &g->bytes);
     if (!st) st = upload(&g->d_blkmeta, blk.data(), blk.size(), &g->bytes);
     if (!st) st = upload(&g->d_level_blk, g->level_blk.data(), g->level_blk.size(), &g->bytes);
+    if (!st) {                                  // hand-off buffer of the granular sweep
+        const size_t xb = ((size_t)A->nrows + 8) * tsize(A->dtype);
+        st = (int)hipMalloc(&g->d_xs, xb);
+        if (!st) g->bytes += xb;
+    }
     if (!st) st = (int)hipMalloc((void **)&g->d_sync, 2048);
     if (!st) st = (int)hipMemset(g->d_sync, 0, 2048);
     if (st) { free_schedule(g); return st; }
@@ -615,6 +630,7 @@ static BlockArgs<T> block_args(pamg_matrix_s *A, const int *rid, const void *Din
     a.rid = rid; a.Dinv = (const T *)Dinv;
     a.xsrc = (const T *)xsrc; a.xdst = (T *)xdst; a.b = (const T *)b;
     a.omega = (T)omega; a.bs = A->R; a.first = 0; a.count = A->n_brow; a.dirn = dirn;
+    a.xs = nullptr; a.err = nullptr;
     return a;
 }
 
@@ -632,8 +648,11 @@ static int bsr_stream_launch(int kind, int grid, int lds, hipStream_t s, const B
     return (int)hipGetLastError();
 }
 
-// order-exact block sweep (PNT_GS / BLK_GS) over a level schedule: narrow -> one persistent
-// workgroup, medium -> persistent grid with a barrier per level, else one launch per level
+// order-exact block sweep (PNT_GS / BLK_GS) over a level schedule, same policy as the scalar sweeps:
+// narrow -> one persistent workgroup; otherwise the granular sweep (no barriers, the published datum
+// is the flag; old values from a snapshot when the block pattern is not structurally symmetric);
+// gs_mode 1 -> one launch per level, 4 -> persistent grid with a counter barrier per level (kept for
+// comparison), 3 -> one workgroup, 2 -> granular whenever the plan allows it
 template <typename T>
 static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *Dinv, void *x, const void *b, int dirn,
                          hipStream_t s)
@@ -641,17 +660,43 @@ static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *
     BlockArgs<T> a = block_args<T>(A, g->d_rid, Dinv, x, x, b, 0.0, dirn);
     a.count = (int)g->nrows;
     BsrRange<T> r;
-    r.meta = g->d_blkmeta; r.pAp = g->d_Ap; r.pblk = g->d_pblk; r.pbj = g->d_Aj; r.capv = A->cap;
-    const int lds = std::max(64, (int)tsize(A->dtype) * (A->cap + 8));
+    r.meta = g->d_blkmeta; r.pAp = g->d_Ap; r.pblk = g->d_pblk; r.pbj = g->d_Aj; r.dpos = g->d_dpos; r.capv = A->cap;
+    const size_t ts = tsize(A->dtype);
+    const int lds = std::max(64, (int)ts * (A->cap + 8));
     const bool narrow = (int64_t)g->nblk_total * 16 <= (int64_t)g->nlevels * A->flow_cap;
-    // gs_mode: 0 auto (narrow -> one workgroup, levels up to 128 row ranges wide -> barrier grid, else
-    // launches), 1 one launch per level, 2 barrier grid always, 3 one workgroup always
+    const bool persist = g->nlevels > 1 && A->gs_mode != 1;
+    const bool single = persist && (A->gs_mode == 3 || (A->gs_mode == 0 && narrow));
+    const bool granular = persist && !single && A->gs_mode != 4 && g->d_xs && A->cap <= GE * BLK && 3 * lds <= 60 * 1024;
+    if (granular) {
+        const int64_t n = A->nrows;
+        a.xs = (T *)g->d_xs;
+        a.err = g->d_sync + 1;
+        if (!g->symmetric) {
+            if (!g->d_xold) {
+                PAMG_HIP(hipMalloc(&g->d_xold, ((size_t)n + 8) * ts));
+                g->bytes += ((size_t)n + 8) * ts;
+                A->bytes += ((size_t)n + 8) * ts;
+            }
+            PAMG_HIP(hipMemcpyAsync(g->d_xold, x, (size_t)n * ts, hipMemcpyDeviceToDevice, s));
+            a.xsrc = (const T *)g->d_xold;
+        }
+        const int fgrid = (int)std::min<int64_t>(4096, (n + BLK - 1) / BLK);
+        hipLaunchKernelGGL((fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)g->d_xs, n);
+        PAMG_HIP(hipGetLastError());
+        const int per_level = (g->nblk_total + g->nlevels - 1) / g->nlevels;
+        int G = std::max(1, std::min(g->nblk_total, 256));
+        if (A->gran_cap > 0) G = std::min(G, A->gran_cap);
+        else G = std::min(G, std::max(32, 8 * per_level));
+        if (kind == PNT_GS) hipLaunchKernelGGL((bsr_gran_kernel<T, PNT_GS>), dim3(G), dim3(BLK), 3 * lds, s, a, r, g->nblk_total);
+        else hipLaunchKernelGGL((bsr_gran_kernel<T, BLK_GS>), dim3(G), dim3(BLK), 3 * lds, s, a, r, g->nblk_total);
+        return (int)hipGetLastError();
+    }
     int G = 0;
-    if (g->nlevels > 1 && A->gs_mode != 1) {
+    if (persist) {
         const int wide = std::max(1, std::min(256, g->max_level_blocks));
-        if (A->gs_mode == 3) G = 1;
-        else if (A->gs_mode == 2) G = A->gran_cap > 0 ? std::min(wide, A->gran_cap) : wide;
-        else if (A->flow_cap > 0) { G = narrow ? 1 : wide; if (G > 128) G = 0; }
+        if (single) G = 1;
+        else if (A->gs_mode == 4 || A->gs_mode == 2) G = A->gran_cap > 0 ? std::min(wide, A->gran_cap) : wide;
+        else if (A->flow_cap > 0) { G = wide; if (G > 128) G = 0; }
     }
     if (G > 0) {
         if (G > 1) PAMG_HIP(hipMemsetAsync(g->d_sync, 0, 2048, s));
@@ -700,11 +745,11 @@ int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *
     const int lds = std::max(64, (int)tsize(A->dtype) * (A->cap + 8));
     if (A->dtype == PAMG_F64) {
         BsrRange<double> r;
-        r.meta = A->d_bmeta; r.pAp = A->d_bAp; r.pblk = nullptr; r.pbj = A->d_bAj; r.capv = A->cap;
+        r.meta = A->d_bmeta; r.pAp = A->d_bAp; r.pblk = nullptr; r.pbj = A->d_bAjf; r.dpos = A->d_bdiag; r.capv = A->cap;
         return bsr_stream_launch<double>(kind, A->bnblk, lds, s, block_args<double>(A, nullptr, Dinv, xsrc, xdst, b, omega, 1), r, 0);
     }
     BsrRange<float> r;
-    r.meta = A->d_bmeta; r.pAp = A->d_bAp; r.pblk = nullptr; r.pbj = A->d_bAj; r.capv = A->cap;
+    r.meta = A->d_bmeta; r.pAp = A->d_bAp; r.pblk = nullptr; r.pbj = A->d_bAjf; r.dpos = A->d_bdiag; r.capv = A->cap;
     return bsr_stream_launch<float>(kind, A->bnblk, lds, s, block_args<float>(A, nullptr, Dinv, xsrc, xdst, b, omega, 1), r, 0);
 }
 
@@ -906,6 +951,14 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
             st = upload(&A->d_bAp, A->h_bAp.data(), A->h_bAp.size(), &A->bytes);
             if (!st) st = upload(&A->d_bAj, A->h_bAj.data(), A->h_bAj.size(), &A->bytes);
             if (!st) st = upload_raw(&A->d_bAx, Ax, (size_t)A->nnz, ts, &A->bytes);
+            // streamed block kernels: diagonal blocks flagged in the column ids (their product is staged
+            // as +0) and the position of each row's diagonal block (last stored one wins, like the reference)
+            std::vector<int> bjf(A->h_bAj), bdiag((size_t)n_brow, -1);
+            for (int i = 0; i < n_brow; ++i)
+                for (int p = Ap[i]; p < Ap[i + 1]; ++p)
+                    if (Aj[p] == i) { bjf[p] = i | 0x40000000; bdiag[i] = p; }
+            if (!st) st = upload(&A->d_bAjf, bjf.data(), bjf.size(), &A->bytes);
+            if (!st) st = upload(&A->d_bdiag, bdiag.data(), bdiag.size(), &A->bytes);
         }
     }
     // default plan (measured best on 256^3 Poisson): 1536 staged entries = 12 KB (SpMV) / 18 KB
@@ -921,7 +974,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
 {
     if (!A) return PAMG_OK;
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag);
-    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta);
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     delete A;
     return PAMG_OK;
@@ -951,7 +1004,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 1: if (value != 1 && value != 2 && value != 4) return PAMG_E_ARG; A->npl = value; break;
         case 2: if (value < 1) return PAMG_E_ARG; A->max_rows = value; break;
         case 3: if (value < 0 || value > 256) return PAMG_E_ARG; A->flow_cap = value; return PAMG_OK;
-        case 5: if (value < 0 || value > 3) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
+        case 5: if (value < 0 || value > 4) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
         case 6: if (value < 0) return PAMG_E_ARG; A->gran_cap = value; return PAMG_OK;
         case 7: if (value < 0 || value > 2) return PAMG_E_ARG; A->gran_xcd = value; return PAMG_OK;
         case 8: if (value < 0 || value > 15) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;

@@ -392,33 +392,61 @@ def test_relaxation_module_block_doctests_and_polynomial():
 
 
 def test_block_sweep_modes_all_exact():
-    """Block/BSR-point Gauss-Seidel: per-level launches, single-workgroup persistent sweep and the
-    multi-workgroup barrier sweep all give the oracle's bits (BSR 2x2 on a 3-D grid)."""
+    """Block/BSR-point Gauss-Seidel: every scheduler (per-level launches, one persistent workgroup,
+    granular sync-free sweep on its automatic and on a tiny grid, barrier grid, automatic choice)
+    gives the oracle's bits -- BSR 2x2 on a 3-D grid, a structurally NON-symmetric 3x3 block pattern
+    with missing and singular diagonal blocks (old values from a snapshot), and 6x6 blocks."""
     from oracle import oracle as orc
     from tools.problems import poisson_csr
     rng = np.random.RandomState(12)
     P = poisson_csr((24, 22, 20))
     blk = np.array([[2.0, 0.3], [-0.4, 1.5]])
-    M = sp.kron(P, blk, format="bsr")
-    M = sp.bsr_array((M.data, M.indices.astype(np.int32), M.indptr.astype(np.int32)), shape=M.shape, blocksize=(2, 2))
-    op = sparse_op(M)
-    n = op.shape[0]
-    nb = n // 2
-    x = rng.rand(n); b = rng.rand(n)
-    Dinv = np.array([np.linalg.inv(np.asarray(M.data[p])) for i in range(nb)
-                     for p in range(M.indptr[i], M.indptr[i + 1]) if M.indices[p] == i])
-    ref_pnt = x.copy(); orc.relax_gauss_seidel(op, ref_pnt, b, 1, "symmetric")
-    ref_blk = x.copy(); orc.relax_block_gauss_seidel(op, ref_blk, b, Dinv, 2, 1, "symmetric")
-    dM = DeviceMatrix(op)
-    db = capi.DeviceArray.from_host(b)
-    dD = capi.DeviceArray.from_host(Dinv.reshape(-1))
-    for kw in (dict(flow_cap=0), dict(flow_cap=32), dict(flow_cap=256), dict(gs_mode=1), dict(gs_mode=2), dict(gs_mode=2, gran_cap=3),
-               dict(gs_mode=3)):
-        dM.tune(**kw)
-        dx = capi.DeviceArray.from_host(x)
-        dM.gauss_seidel(dx, db, sweep="symmetric")
-        assert np.array_equal(dx.download(), ref_pnt), kw
-        dx.upload(x)
-        dM.block_gauss_seidel(dx, db, dD, sweep="symmetric")
-        assert np.array_equal(dx.download(), ref_blk), kw
-        assert not dM.flow_error(), kw
+    M2 = sp.kron(P, blk, format="bsr")
+    # non-symmetric block pattern, 3x3 blocks, some diagonal blocks missing / with a zero pivot
+    nbr = 900
+    Pn = sp.random(nbr, nbr, density=0.01, random_state=rng, format="lil")
+    for i in range(nbr):
+        if i % 11 != 5:
+            Pn[i, i] = 4.0 + rng.rand()
+    for j in range(100, 140):
+        Pn[450, j] = 1.0                                            # one block row longer than a small LDS window
+    Pn = sp.csr_array(Pn)
+    Pn.sort_indices()
+    dat = rng.rand(Pn.nnz, 3, 3) - 0.5
+    for i in range(nbr):
+        for p in range(Pn.indptr[i], Pn.indptr[i + 1]):
+            if Pn.indices[p] == i:
+                dat[p] += 4.0 * np.eye(3)
+                if i % 13 == 2:
+                    dat[p][1, 1] = 0.0                                  # zero point diagonal inside the block
+    M3 = sp.bsr_array((dat, Pn.indices.astype(np.int32), Pn.indptr.astype(np.int32)), shape=(3 * nbr, 3 * nbr), blocksize=(3, 3))
+    P6 = poisson_csr((7, 6, 5))
+    M6 = sp.kron(P6, rng.rand(6, 6) + 6.0 * np.eye(6), format="bsr")
+    for M, bs in ((M2, 2), (M3, 3), (M6, 6)):
+        M = sp.bsr_array((M.data, M.indices.astype(np.int32), M.indptr.astype(np.int32)), shape=M.shape, blocksize=(bs, bs))
+        op = sparse_op(M)
+        n = op.shape[0]
+        nb = n // bs
+        x = rng.rand(n); b = rng.rand(n)
+        Dinv = np.zeros((nb, bs, bs))
+        for i in range(nb):
+            for p in range(M.indptr[i], M.indptr[i + 1]):
+                if M.indices[p] == i:
+                    Dinv[i] = np.linalg.pinv(np.asarray(M.data[p]))
+        ref_pnt = x.copy(); orc.relax_gauss_seidel(op, ref_pnt, b, 1, "symmetric")
+        ref_blk = x.copy(); orc.relax_block_gauss_seidel(op, ref_blk, b, Dinv, bs, 1, "symmetric")
+        dM = DeviceMatrix(op)
+        db = capi.DeviceArray.from_host(b)
+        dD = capi.DeviceArray.from_host(Dinv.reshape(-1))
+        for kw in (dict(gs_mode=0, flow_cap=0), dict(flow_cap=32), dict(flow_cap=256), dict(gs_mode=1), dict(gs_mode=2, gran_cap=0),
+                   dict(gs_mode=2, gran_cap=3), dict(gs_mode=4, gran_cap=0), dict(gs_mode=4, gran_cap=5), dict(gs_mode=3),
+                   dict(gs_mode=0, flow_cap=32, lds_entries=384), dict(gs_mode=2, lds_entries=96)):
+            dM.tune(**kw)
+            dx = capi.DeviceArray.from_host(x)
+            dM.gauss_seidel(dx, db, sweep="symmetric")
+            assert np.array_equal(dx.download(), ref_pnt), (kw, bs)
+            dx.upload(x)
+            dM.block_gauss_seidel(dx, db, dD, sweep="symmetric")
+            assert np.array_equal(dx.download(), ref_blk), (kw, bs)
+            assert not dM.flow_error(), (kw, bs)
+        dM.tune(lds_entries=1536)
