@@ -43,6 +43,15 @@ template <typename T> struct Vec2;
 template <> struct Vec2<double> { using type = double2; };
 template <> struct Vec2<float> { using type = float2; };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global
+// loads and stores (s_waitcnt vmcnt(0)): inside the granular sweeps that would make every range wait
+// for the acknowledgement of its write-through publishing stores and for the prefetch it has just
+// issued (measured: 2.6 us per range).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int EPI> struct EpiTraits {
     static constexpr bool need_cols = (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B);   // row phase compares column ids
     static constexpr bool diag_flag = (EPI == EPI_GS || EPI == EPI_GS_B || EPI == EPI_SOR);   // schedule copies flag a_ii
@@ -687,39 +696,47 @@ __device__ __forceinline__ void range_stage_gran(const StreamArgs<T> &a, const R
     int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(a.cap + 8));
     const int tid = threadIdx.x;
     const int p0 = R.meta.z, p1 = R.meta.w, base = p0 & ~1;
+    // Every load below is UNCONDITIONAL with a selected address (entries that need nothing read
+    // element 0): loads under divergent branches that write the same register make the compiler
+    // drain the memory pipeline between them (write-after-write on the destination), which turned
+    // the "batch" into up to eight serial round trips.
     T xv[2 * MAXP];
-    unsigned pend = 0;
+    int col[2 * MAXP];
+    unsigned early = 0, old = 0;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
         const int q = base + 2 * tid + k * 2 * BLK;
-        xv[2 * k] = xv[2 * k + 1] = T(0);
-        if (q < p1) {
-            const int2 cc = R.c[k];
-            if (q >= p0) {
-                if (cc.x & EARLY_BIT) { xv[2 * k] = __hip_atomic_load(a.xs + (cc.x & COL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pend |= 1u << (2 * k); }
-                else if (!(cc.x & DIAG_BIT)) xv[2 * k] = a.x[cc.x & COL_MASK];
-            }
-            if (q + 1 < p1) {
-                if (cc.y & EARLY_BIT) { xv[2 * k + 1] = __hip_atomic_load(a.xs + (cc.y & COL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pend |= 1u << (2 * k + 1); }
-                else if (!(cc.y & DIAG_BIT)) xv[2 * k + 1] = a.x[cc.y & COL_MASK];
-            }
-        }
+        const bool v0 = q < p1 && q >= p0, v1 = q + 1 < p1;
+        const int c0 = v0 ? R.c[k].x : DIAG_BIT, c1 = v1 ? R.c[k].y : DIAG_BIT;
+        col[2 * k] = (c0 & DIAG_BIT) ? 0 : (c0 & COL_MASK);
+        col[2 * k + 1] = (c1 & DIAG_BIT) ? 0 : (c1 & COL_MASK);
+        if (!(c0 & DIAG_BIT)) { if (c0 & EARLY_BIT) early |= 1u << (2 * k); else old |= 1u << (2 * k); }
+        if (!(c1 & DIAG_BIT)) { if (c1 & EARLY_BIT) early |= 1u << (2 * k + 1); else old |= 1u << (2 * k + 1); }
     }
+    {
+        T ve[2 * MAXP], vo[2 * MAXP];
+#pragma unroll
+        for (int j = 0; j < 2 * MAXP; ++j)
+            ve[j] = __hip_atomic_load(a.xs + (((early >> j) & 1u) ? col[j] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 2 * MAXP; ++j) vo[j] = a.x[((old >> j) & 1u) ? col[j] : 0];
+#pragma unroll
+        for (int j = 0; j < 2 * MAXP; ++j) xv[j] = ((early >> j) & 1u) ? ve[j] : (((old >> j) & 1u) ? vo[j] : T(0));
+    }
+    unsigned pend = early;
     unsigned spins = 0;
     while (true) {
 #pragma unroll
         for (int j = 0; j < 2 * MAXP; ++j)
-            if ((pend >> j) & 1u)
-                if (Sentinel<T>::bits(xv[j]) != Sentinel<T>::value) pend &= ~(1u << j);
+            if (((pend >> j) & 1u) && Sentinel<T>::bits(xv[j]) != Sentinel<T>::value) pend &= ~(1u << j);
         if (!pend) break;
         __builtin_amdgcn_s_sleep(1);
+        T t[2 * MAXP];
 #pragma unroll
         for (int j = 0; j < 2 * MAXP; ++j)
-            if ((pend >> j) & 1u) {
-                const int2 cc = R.c[j >> 1];
-                const int c = (j & 1) ? cc.y : cc.x;
-                xv[j] = __hip_atomic_load(a.xs + (c & COL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            t[j] = __hip_atomic_load(a.xs + (((pend >> j) & 1u) ? col[j] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 2 * MAXP; ++j) xv[j] = ((pend >> j) & 1u) ? t[j] : xv[j];
         if (++spins > (1u << 22)) {                        // ~seconds: producer not resident / bug
             __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
@@ -775,6 +792,61 @@ __device__ __forceinline__ void range_prefetch_static(const StreamArgs<T> &a, co
     }
 }
 
+// one row range of the granular sweep, from its prefetched static operands to the publishing stores
+template <typename T, int EPI, int C>
+__device__ __forceinline__ void gran_step(const GranArgs<T> &g, RangePre<T> &cur, int blk, unsigned char *smem_raw, double &sq)
+{
+    const StreamArgs<T> &a = g.s;
+    const int tid = threadIdx.x;
+    long long t0 = 0, t2 = 0, t3 = 0, t4 = 0;
+    if (g.prof && tid == 0) t0 = wall_clock64();
+    if (cur.fits) {
+        if (cur.has_row) {                                 // row-id dependent operands, in flight with the polls
+            cur.q.b = a.b[cur.q.row];
+            if constexpr (EPI == EPI_SOR) cur.q.xo = a.x[cur.q.row];
+        }
+        range_stage_gran<T, EPI>(a, cur, smem_raw);
+        if (g.prof && tid == 0) t2 = wall_clock64();
+        lds_barrier();
+        if (g.prof && tid == 0) t3 = wall_clock64();
+        range_finish<T, EPI, C>(a, cur, smem_raw);
+    } else {
+        stream_block<T, EPI, 2, C>(a, a.blkmeta[blk], smem_raw, sq);
+    }
+    if (g.prof && tid == 0) {
+        t4 = wall_clock64();
+        long long *o = g.prof + (size_t)blk * 8;
+        o[0] = t0; o[1] = t0; o[2] = t2; o[3] = t3; o[4] = t4;
+        o[5] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF);
+        o[6] = (long long)blockIdx.x;
+    }
+}
+
+// id of this workgroup's next row range (AFTER the publishing stores of the current one) and the
+// fetch of its static operands into `nxt`.  Static form: the range descriptor was loaded one range
+// further ahead, so nothing here waits.  One-XCD form: a ticket, then descriptor -> operands.
+template <typename T, int EPI, bool XCD>
+__device__ __forceinline__ int gran_next(const GranArgs<T> &g, int blk, RangePre<T> &nxt, int4 &meta_nxt, int *sh_next)
+{
+    const StreamArgs<T> &a = g.s;
+    const int G = (int)gridDim.x;
+    int nb = blk + G;
+    nxt.fits = false; nxt.has_row = false;
+    if constexpr (XCD) {
+        if (threadIdx.x == 0) *sh_next = (int)__hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_barrier();
+        nb = *sh_next;
+        if (nb < g.nblk) range_prefetch_static<T, EPI>(a, a.blkmeta[nb], nxt);
+    } else {
+        if (nb < g.nblk) {
+            range_prefetch_static<T, EPI>(a, meta_nxt, nxt);
+            if (nb + G < g.nblk) meta_nxt = a.blkmeta[nb + G];
+        }
+    }
+    lds_barrier();                                         // LDS (and sh_next) are reused
+    return nb;
+}
+
 // XCD = false: workgroup w owns ranges w, w+G, w+2G, ... (all G workgroups co-resident: the host
 // keeps G <= the number of CUs).
 // XCD = true: the hand-off stays inside ONE XCD's L2 (ordinary stores, L1-bypassing loads) -- for
@@ -783,6 +855,10 @@ __device__ __forceinline__ void range_prefetch_static(const StreamArgs<T> &a, co
 // others draw row ranges from a ticket counter.  Tickets go out in increasing order to workgroups
 // that are already running, so the sweep completes for ANY placement and residency (at least the
 // claiming workgroup takes part); placement decides speed only.
+// The two operand sets P and Q alternate (the loop is unrolled by two): the prefetch lands in the
+// registers it is consumed from, so nothing ever waits for it except its first use -- a copy
+// "cur = nxt" at the end of the body would wait for the loads it just issued (measured: 3 us per
+// range, which made the 100-220-range-wide fronts of the 256^3 fine grid service-bound).
 template <typename T, int EPI, bool XCD>
 __global__ __launch_bounds__(BLK) void gs_gran2_kernel(const GranArgs<T> g)
 {
@@ -792,8 +868,9 @@ __global__ __launch_bounds__(BLK) void gs_gran2_kernel(const GranArgs<T> g)
     const StreamArgs<T> &a = g.s;
     const int G = (int)gridDim.x, tid = threadIdx.x;
     double sq = 0.0;
-    RangePre<T> cur, nxt;
-    cur.fits = false; cur.has_row = false;
+    RangePre<T> P, Q;
+    P.fits = false; P.has_row = false;
+    Q.fits = false; Q.has_row = false;
     int blk = (int)blockIdx.x;
     if constexpr (XCD) {
         if (tid == 0) {
@@ -809,49 +886,15 @@ __global__ __launch_bounds__(BLK) void gs_gran2_kernel(const GranArgs<T> g)
     }
     int4 meta_nxt = make_int4(0, 0, 0, 0);                  // descriptor of the range after the current one (static form)
     if (blk < g.nblk) {
-        range_prefetch_static<T, EPI>(a, a.blkmeta[blk], cur);
+        range_prefetch_static<T, EPI>(a, a.blkmeta[blk], P);
         if constexpr (!XCD) if (blk + G < g.nblk) meta_nxt = a.blkmeta[blk + G];
     }
     while (blk < g.nblk) {
-        long long t0 = 0, t2 = 0, t3 = 0, t4 = 0;
-        if (g.prof && tid == 0) t0 = wall_clock64();
-        nxt.fits = false; nxt.has_row = false;
-        if (cur.fits) {
-            if (cur.has_row) {                             // row-id dependent operands, in flight with the polls
-                cur.q.b = a.b[cur.q.row];
-                if constexpr (EPI == EPI_SOR) cur.q.xo = a.x[cur.q.row];
-            }
-            range_stage_gran<T, EPI>(a, cur, smem_raw);
-            if (g.prof && tid == 0) t2 = wall_clock64();
-            __syncthreads();
-            if (g.prof && tid == 0) t3 = wall_clock64();
-            range_finish<T, EPI, C>(a, cur, smem_raw);
-        } else {
-            stream_block<T, EPI, 2, C>(a, a.blkmeta[blk], smem_raw, sq);
-        }
-        if (g.prof && tid == 0) t4 = wall_clock64();
-        // this workgroup's next range and its static operands: AFTER the publishing stores
-        int nb = blk + G;
-        if constexpr (XCD) {
-            if (tid == 0) sh_next = (int)__hip_atomic_fetch_add(g.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            nb = sh_next;
-            if (nb < g.nblk) range_prefetch_static<T, EPI>(a, a.blkmeta[nb], nxt);
-        } else {
-            if (nb < g.nblk) {
-                range_prefetch_static<T, EPI>(a, meta_nxt, nxt);
-                if (nb + G < g.nblk) meta_nxt = a.blkmeta[nb + G];
-            }
-        }
-        if (g.prof && tid == 0) {
-            long long *o = g.prof + (size_t)blk * 8;
-            o[0] = t0; o[1] = t0; o[2] = t2; o[3] = t3; o[4] = t4;
-            o[5] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF);
-            o[6] = (long long)blockIdx.x;
-        }
-        __syncthreads();                                   // LDS (and sh_next) are reused
-        cur = nxt;
-        blk = nb;
+        gran_step<T, EPI, C>(g, P, blk, smem_raw, sq);
+        blk = gran_next<T, EPI, XCD>(g, blk, Q, meta_nxt, &sh_next);
+        if (blk >= g.nblk) break;
+        gran_step<T, EPI, C>(g, Q, blk, smem_raw, sq);
+        blk = gran_next<T, EPI, XCD>(g, blk, P, meta_nxt, &sh_next);
     }
 }
 
@@ -1314,32 +1357,43 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
             }
         }
         // ---- the wait: one x value per (block, row-in-block) pair, batch-polled
+        // unconditional loads with selected addresses (see range_stage_gran)
         T xv[GE];
-        unsigned pend = 0;
+        long at[GE];
+        unsigned early = 0, old = 0;
 #pragma unroll
         for (int k = 0; k < GE; ++k) {
             const int e = tid + k * BLK;
-            xv[k] = T(0);
+            at[k] = 0;
             if (e < nent && !(cjs[k] & DIAG_BIT)) {
-                const long at = (long)(cjs[k] & COL_MASK) * bs + e % bs;
-                if (cjs[k] & EARLY_BIT) { xv[k] = __hip_atomic_load(a.xs + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pend |= 1u << k; }
-                else xv[k] = a.xsrc[at];
+                at[k] = (long)(cjs[k] & COL_MASK) * bs + e % bs;
+                if (cjs[k] & EARLY_BIT) early |= 1u << k; else old |= 1u << k;
             }
         }
+        {
+            T ve[GE], vo[GE];
+#pragma unroll
+            for (int k = 0; k < GE; ++k)
+                ve[k] = __hip_atomic_load(a.xs + (((early >> k) & 1u) ? at[k] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < GE; ++k) vo[k] = a.xsrc[((old >> k) & 1u) ? at[k] : 0];
+#pragma unroll
+            for (int k = 0; k < GE; ++k) xv[k] = ((early >> k) & 1u) ? ve[k] : (((old >> k) & 1u) ? vo[k] : T(0));
+        }
+        unsigned pend = early;
         unsigned spins = 0;
         while (true) {
 #pragma unroll
             for (int k = 0; k < GE; ++k)
-                if ((pend >> k) & 1u)
-                    if (Sentinel<T>::bits(xv[k]) != Sentinel<T>::value) pend &= ~(1u << k);
+                if (((pend >> k) & 1u) && Sentinel<T>::bits(xv[k]) != Sentinel<T>::value) pend &= ~(1u << k);
             if (!pend) break;
             __builtin_amdgcn_s_sleep(1);
+            T t[GE];
 #pragma unroll
             for (int k = 0; k < GE; ++k)
-                if ((pend >> k) & 1u) {
-                    const int e = tid + k * BLK;
-                    xv[k] = __hip_atomic_load(a.xs + (long)(cjs[k] & COL_MASK) * bs + e % bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                t[k] = __hip_atomic_load(a.xs + (((pend >> k) & 1u) ? at[k] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < GE; ++k) xv[k] = ((pend >> k) & 1u) ? t[k] : xv[k];
             if (++spins > (1u << 22)) {
                 __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -1350,7 +1404,7 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
             const int e = tid + k * BLK;
             if (e < nent) xl[e] = xv[k];
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < GE; ++k) {
             const int e = tid + k * BLK;
@@ -1365,7 +1419,7 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
                 prodv[e] = d;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (has_row) {
             T acc[MAXBS];
             if constexpr (KIND == BLK_GS) {
@@ -1431,7 +1485,7 @@ __global__ __launch_bounds__(BLK) void bsr_gran_kernel(const BlockArgs<T> a, con
     T *dl = prodv + (g.capv + 8);
     for (int blk = (int)blockIdx.x; blk < nblk; blk += (int)gridDim.x) {
         bsr_range_gran<T, KIND>(a, g, g.meta[blk], xl, prodv, dl);
-        __syncthreads();                                   // LDS is reused by the next row range
+        lds_barrier();                                     // LDS is reused by the next row range
     }
 }
 

@@ -39,14 +39,26 @@ ap.add_argument("--tag", default="gs")
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--prof", type=int, default=1)
 ap.add_argument("--grids", type=int, nargs="*", default=[128, 384])
+ap.add_argument("--fine-only", type=int, default=0, help="level 0 only, no hierarchy setup")
 a = ap.parse_args()
 A = pyamg.gallery.poisson(a.grid, format="csr")
 np.random.seed(1)
 t = time.time()
-ml = pyamg.smoothed_aggregation_solver(A, max_coarse=10)
-print(f"setup {time.time() - t:.1f}s levels={len(ml.levels)}", flush=True)
-spec = extract(ml)
+if a.fine_only:
+    from pyamg_amd.hierarchy import sparse_op
+    class _L:  # noqa: E701
+        pass
+    L0 = _L(); L0.A = sparse_op(A)
+    class _S:  # noqa: E701
+        pass
+    spec = _S(); spec.levels = [L0, None]
+else:
+    ml = pyamg.smoothed_aggregation_solver(A, max_coarse=10)
+    print(f"setup {time.time() - t:.1f}s levels={len(ml.levels)}", flush=True)
+    spec = extract(ml)
 out = []
+od_early = ROOT / "gpurun_out"
+od_early.mkdir(exist_ok=True)
 for li, L in enumerate(spec.levels[:-1]):
     op = L.A
     n = op.shape[0]
@@ -78,6 +90,8 @@ for li, L in enumerate(spec.levels[:-1]):
         print(li, n, name, rec[name], "levels", info["gs_levels_fwd"], flush=True)
         if kw.get("gs_prof"):
             pr = dA.gs_profile(0)
+            if len(pr) and a.fine_only:
+                np.save(od_early / f"prof_{a.tag}_{name}.npy", pr)
             if len(pr):
                 lev = pr[:, 7]
                 nl = int(lev.max()) + 1
