@@ -68,7 +68,8 @@ struct StreamArgs {
     T omega;
     int cap;             // products staged in LDS per workgroup
     int nblk;            // row ranges of this launch
-    int flags;           // bit 0: non-temporal operator stream, bit 1: XCD-aware range order
+    int flags;           // bit 0: non-temporal operator stream, bit 1: XCD-aware range order, bits 2/3: ablations
+    int nidle;           // granular sweep: elements of xs that idle lanes may read (>= 1)
 };
 
 // One dependency-level schedule for an order-exact sweep (forward or backward, or a

@@ -703,6 +703,9 @@ __device__ __forceinline__ void range_stage_gran(const StreamArgs<T> &a, const R
     T xv[2 * MAXP];
     int col[2 * MAXP];
     unsigned early = 0, old = 0;
+    // the element read by entries that need nothing: one per wave, spread over the memory channels
+    // (every idle lane of every waiting workgroup re-reading element 0 would hammer one channel)
+    const int idle = (int)(((unsigned)blockIdx.x * 4u + (unsigned)(tid >> 6)) * 16u) % a.nidle;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
         const int q = base + 2 * tid + k * 2 * BLK;
@@ -717,7 +720,7 @@ __device__ __forceinline__ void range_stage_gran(const StreamArgs<T> &a, const R
         T ve[2 * MAXP], vo[2 * MAXP];
 #pragma unroll
         for (int j = 0; j < 2 * MAXP; ++j)
-            ve[j] = __hip_atomic_load(a.xs + (((early >> j) & 1u) ? col[j] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ve[j] = __hip_atomic_load(a.xs + (((early >> j) & 1u) ? col[j] : idle), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int j = 0; j < 2 * MAXP; ++j) vo[j] = a.x[((old >> j) & 1u) ? col[j] : 0];
 #pragma unroll
@@ -734,7 +737,7 @@ __device__ __forceinline__ void range_stage_gran(const StreamArgs<T> &a, const R
         T t[2 * MAXP];
 #pragma unroll
         for (int j = 0; j < 2 * MAXP; ++j)
-            t[j] = __hip_atomic_load(a.xs + (((pend >> j) & 1u) ? col[j] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t[j] = __hip_atomic_load(a.xs + (((pend >> j) & 1u) ? col[j] : idle), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int j = 0; j < 2 * MAXP; ++j) xv[j] = ((pend >> j) & 1u) ? t[j] : xv[j];
         if (++spins > (1u << 22)) {                        // ~seconds: producer not resident / bug
@@ -1034,6 +1037,7 @@ struct BlockArgs {
     int bs, first, count;   // rows [first, first+count) of rid (or of 0..n_brow)
     int dirn;               // +1 forward, -1 backward (point sweep inside the diagonal block)
     T *xs;                  // granular sweep: hand-off buffer (sentinel = not published yet) or nullptr
+    int nidle;              // granular sweep: elements of xs that idle lanes may read (>= 1)
     unsigned *err;          // granular sweep: error flag (spin bound hit)
 };
 
@@ -1361,6 +1365,7 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
         T xv[GE];
         long at[GE];
         unsigned early = 0, old = 0;
+        const long idle = (long)((((unsigned)blockIdx.x * 4u + (unsigned)(tid >> 6)) * 16u) % (unsigned)a.nidle);
 #pragma unroll
         for (int k = 0; k < GE; ++k) {
             const int e = tid + k * BLK;
@@ -1374,7 +1379,7 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
             T ve[GE], vo[GE];
 #pragma unroll
             for (int k = 0; k < GE; ++k)
-                ve[k] = __hip_atomic_load(a.xs + (((early >> k) & 1u) ? at[k] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ve[k] = __hip_atomic_load(a.xs + (((early >> k) & 1u) ? at[k] : idle), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int k = 0; k < GE; ++k) vo[k] = a.xsrc[((old >> k) & 1u) ? at[k] : 0];
 #pragma unroll
@@ -1391,7 +1396,7 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
             T t[GE];
 #pragma unroll
             for (int k = 0; k < GE; ++k)
-                t[k] = __hip_atomic_load(a.xs + (((pend >> k) & 1u) ? at[k] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t[k] = __hip_atomic_load(a.xs + (((pend >> k) & 1u) ? at[k] : idle), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int k = 0; k < GE; ++k) xv[k] = ((pend >> k) & 1u) ? t[k] : xv[k];
             if (++spins > (1u << 22)) {

@@ -457,6 +457,7 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.cap = A->cap;
     a.nblk = A->nblk;
     a.flags = 0;
+    a.nidle = 1;
     return a;
 }
 
@@ -580,6 +581,7 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
         ga.s.err = g->d_sync + 1;
         ga.nblk = g->nblk_total;
         ga.ticket = g->d_sync + 20;
+        ga.s.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(A->nrows, 1 << 20));
         if (!g->symmetric) {
             // write-after-read hazards are not ordered by the waits: old values come from a snapshot
             if (!g->d_xold) {
@@ -630,7 +632,7 @@ static BlockArgs<T> block_args(pamg_matrix_s *A, const int *rid, const void *Din
     a.rid = rid; a.Dinv = (const T *)Dinv;
     a.xsrc = (const T *)xsrc; a.xdst = (T *)xdst; a.b = (const T *)b;
     a.omega = (T)omega; a.bs = A->R; a.first = 0; a.count = A->n_brow; a.dirn = dirn;
-    a.xs = nullptr; a.err = nullptr;
+    a.xs = nullptr; a.err = nullptr; a.nidle = 1;
     return a;
 }
 
@@ -671,6 +673,7 @@ static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *
         const int64_t n = A->nrows;
         a.xs = (T *)g->d_xs;
         a.err = g->d_sync + 1;
+        a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
         if (!g->symmetric) {
             if (!g->d_xold) {
                 PAMG_HIP(hipMalloc(&g->d_xold, ((size_t)n + 8) * ts));

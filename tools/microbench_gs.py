@@ -39,6 +39,7 @@ ap.add_argument("--tag", default="gs")
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--prof", type=int, default=1)
 ap.add_argument("--grids", type=int, nargs="*", default=[128, 384])
+ap.add_argument("--xgrids", type=int, nargs="*", default=[])
 ap.add_argument("--fine-only", type=int, default=0, help="level 0 only, no hierarchy setup")
 a = ap.parse_args()
 A = pyamg.gallery.poisson(a.grid, format="csr")
@@ -73,7 +74,7 @@ for li, L in enumerate(spec.levels[:-1]):
     rec = {"level": li, "n": n, "nnz": op.nnz, "fmt": op.fmt}
     variants = [("auto", dict(gs_mode=0, gran_xcd=0, gran_cap=0, gs_prof=0)), ("launch", dict(gs_mode=1)), ("single", dict(gs_mode=3))]
     variants += [(f"gran_G{G}", dict(gs_mode=2, gran_cap=G, gran_xcd=2, gs_prof=0)) for G in ([0] + a.grids)]
-    variants += [(f"granxcd_G{G}", dict(gs_mode=2, gran_cap=G, gran_xcd=1, gs_prof=0)) for G in (0,)]
+    variants += [(f"granxcd_G{G}", dict(gs_mode=2, gran_cap=G, gran_xcd=1, gs_prof=0)) for G in [0] + a.xgrids]
     if a.prof:
         variants += [("granprof", dict(gs_mode=2, gran_cap=0, gran_xcd=2, gs_prof=1))]
     for name, kw in variants:
