@@ -343,6 +343,10 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
         const size_t xb = ((size_t)A->nrows + 8) * ts;
         st = (int)hipMalloc(&g->d_xs, xb);
         if (!st) g->bytes += xb;
+        if (!st && !g->symmetric) {             // + snapshot of x (allocated here: sweeps may run inside a graph capture)
+            st = (int)hipMalloc(&g->d_xold, xb);
+            if (!st) g->bytes += xb;
+        }
     }
     if (!st) st = (int)hipMalloc((void **)&g->d_sync, 2048);
     if (!st) st = (int)hipMemset(g->d_sync, 0, 2048);
@@ -401,10 +405,14 @@ int build_schedule_block(pamg_matrix_s *A, int row_start, int row_stop, int row_
     if (!st) st = upload(&g->d_dpos, dpos.data(), dpos.size(), &g->bytes);
     if (!st) st = upload(&g->d_blkmeta, blk.data(), blk.size(), &g->bytes);
     if (!st) st = upload(&g->d_level_blk, g->level_blk.data(), g->level_blk.size(), &g->bytes);
-    if (!st) {                                  // hand-off buffer of the granular sweep
+    if (!st) {                                  // hand-off buffer of the granular sweep (+ snapshot of x)
         const size_t xb = ((size_t)A->nrows + 8) * tsize(A->dtype);
         st = (int)hipMalloc(&g->d_xs, xb);
         if (!st) g->bytes += xb;
+        if (!st && !g->symmetric) {
+            st = (int)hipMalloc(&g->d_xold, xb);
+            if (!st) g->bytes += xb;
+        }
     }
     if (!st) st = (int)hipMalloc((void **)&g->d_sync, 2048);
     if (!st) st = (int)hipMemset(g->d_sync, 0, 2048);
@@ -584,11 +592,7 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
         ga.s.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(A->nrows, 1 << 20));
         if (!g->symmetric) {
             // write-after-read hazards are not ordered by the waits: old values come from a snapshot
-            if (!g->d_xold) {
-                PAMG_HIP(hipMalloc(&g->d_xold, ((size_t)n + 8) * ts));
-                g->bytes += ((size_t)n + 8) * ts;
-                A->bytes += ((size_t)n + 8) * ts;
-            }
+            if (!g->d_xold) return PAMG_E_STATE;
             PAMG_HIP(hipMemcpyAsync(g->d_xold, x, (size_t)n * ts, hipMemcpyDeviceToDevice, s));
             ga.s.x = (const T *)g->d_xold;
         }
@@ -675,11 +679,7 @@ static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *
         a.err = g->d_sync + 1;
         a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
         if (!g->symmetric) {
-            if (!g->d_xold) {
-                PAMG_HIP(hipMalloc(&g->d_xold, ((size_t)n + 8) * ts));
-                g->bytes += ((size_t)n + 8) * ts;
-                A->bytes += ((size_t)n + 8) * ts;
-            }
+            if (!g->d_xold) return PAMG_E_STATE;
             PAMG_HIP(hipMemcpyAsync(g->d_xold, x, (size_t)n * ts, hipMemcpyDeviceToDevice, s));
             a.xsrc = (const T *)g->d_xold;
         }

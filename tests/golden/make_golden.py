@@ -32,7 +32,12 @@ from pyamg_amd import hierarchy  # noqa: E402
 SEED = 20260924
 
 
+ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]     # regenerate selected hierarchies only
+
+
 def hier(name, ml, k=8, cycle="V"):
+    if ONLY and name not in ONLY:
+        return
     spec = hierarchy.extract(ml)
     n = ml.levels[0].A.shape[0]
     rng = np.random.RandomState(SEED)
@@ -109,6 +114,16 @@ def make_hierarchies():
     np.random.seed(SEED)
     hier("el3d_jacobi", pyamg.smoothed_aggregation_solver(E3, B=B3, smooth="jacobi", max_coarse=10,
                                                           presmoother="jacobi", postsmoother="jacobi"), k=6)
+    # structurally NON-symmetric operator (first-order upwind convection in x, diffusion in y): the
+    # order-exact sweeps then read old values from a snapshot -- inside the captured cycle
+    import scipy.sparse as sp
+    m = 28
+    Dx = sp.diags_array([np.ones(m), -np.ones(m - 1)], offsets=[0, -1], shape=(m, m))
+    Dy = sp.diags_array([2 * np.ones(m), -np.ones(m - 1), -np.ones(m - 1)], offsets=[0, -1, 1], shape=(m, m))
+    An = sp.csr_array(3.0 * sp.kron(sp.eye_array(m), Dx) + sp.kron(Dy, sp.eye_array(m)))
+    An.sort_indices()
+    np.random.seed(SEED)
+    hier("rs2d_nonsym_gs", pyamg.ruge_stuben_solver(An, max_coarse=10))
     # hand-built two-level hierarchy with a CSC restriction (multilevel.py:180-182)
     np.random.seed(SEED)
     ml0 = pyamg.ruge_stuben_solver(A, max_coarse=500, max_levels=2)
@@ -253,6 +268,10 @@ def make_known_answers():
     (HERE / "known_answers.json").write_text(json.dumps(ka, indent=1))
     print("known_answers.json written; sor doctest norm =", ka["doctest_sor_norm"]["expect_norm_3dec"])
 
+
+if __name__ == "__main__" and ONLY:
+    make_hierarchies()
+    sys.exit(0)
 
 if __name__ == "__main__":
     if "--hier-only" not in sys.argv:
