@@ -48,7 +48,7 @@ enum : int {
 };
 
 constexpr int MAXBS = 8;          // largest square block handled by the block smoothers
-enum : int { BLK_JACOBI = 0, BLK_GS, PNT_JACOBI, PNT_GS };   // block_relax_kernel flavours
+enum : int { BLK_JACOBI = 0, BLK_GS, PNT_JACOBI, PNT_GS };   // flavours of the block (BSR) relaxation kernels
 
 template <typename T>
 struct StreamArgs {

@@ -112,7 +112,7 @@ __device__ __forceinline__ T spin_value(const T *xs, int j, unsigned *err)
 }
 
 // gather of one x value in the three flavours of the kernel family:
-//   plain (COH = 0): ordinary cached load;  COH = 1: L1-bypassing load (persistent barrier sweep);
+//   plain (COH = 0): ordinary cached load;  COH = 1: L1-bypassing load (block sweeps with a barrier per level);
 //   COH = 2 (granular sweep): early entries spin on the hand-off buffer, the others read x.
 template <int COH, typename T>
 __device__ __forceinline__ T gather_x(const StreamArgs<T> &a, int c)
