@@ -301,6 +301,16 @@ int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int m
  * indefinite operator/preconditioner detected (as the reference), else the iteration count. */
 int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int cycle,
                     int cycles_per_level, double *residuals, int *n_iter, int *info, pamg_stream_t s);
+/* Flexible GMRES with the resident cycle as preconditioner, all vectors on the DEVICE (reference:
+ * pyamg/krylov/_fgmres.py:120-345 as driven by MultilevelSolver.solve(accel='fgmres'),
+ * multilevel.py:479-535: Householder reflectors + Givens rotations, the same control flow, stopping
+ * rules and residual history).  maxiter / restart <= 0 mean "None".  x: in = initial
+ * guess, out = solution.  residuals: HOST array of residuals_cap doubles (may be NULL); *n_res =
+ * entries the reference's list would hold.  *info: 0 converged, -1 stagnation, else the number of
+ * inner iterations.  Needs (2 * inner iterations + 4) device vectors. */
+int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int restart,
+                       int cycle, int cycles_per_level, double *residuals, int residuals_cap, int *n_res,
+                       int *n_iter, int *info, pamg_stream_t s);
 /* Same iteration split in three so that callers (benchmarks, device-side Krylov drivers)
  * can run exactly k cycles on the resident state with no staging copies in between:
  * load copies DEVICE x, b into the solver's level-0 buffers; iterate runs k x (cycle +

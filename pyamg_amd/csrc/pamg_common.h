@@ -146,6 +146,7 @@ int vec_sumsq(int dtype, int64_t n, const void *x, double *scratch, double *out,
 int vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
 int vec_scale(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
 int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch, double *out, hipStream_t s);
+int vec_maxratio(int dtype, int64_t n, const void *u, const void *x, double *scratch, double *out, hipStream_t s);
 int vec_xpby(int dtype, int64_t n, double beta, const void *z, void *p, hipStream_t s);
 int vec_axpy_ratio(int dtype, int64_t n, const double *num, const double *den, double sign, const void *x, void *y, hipStream_t s);
 int vec_fill(int dtype, int64_t n, double v, void *y, hipStream_t s);

@@ -999,6 +999,40 @@ __global__ __launch_bounds__(BLK) void vec_axpy_ratio_kernel(int64_t n, const do
     }
 }
 
+// max_i |u_i / x_i| over x_i != 0 (stagnation test of the reference's FGMRES, krylov/_fgmres.py:316-322):
+// one partial maximum per workgroup, reduced by reduce_max_kernel
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_maxratio_kernel(const T *u, const T *x, int64_t n, double *partial)
+{
+    __shared__ double sm[BLK];
+    double m = -1.0;                                        // -1: no x_i != 0 seen
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
+        const T xi = x[i];
+        if (xi != T(0)) m = fmax(m, fabs((double)(u[i] / xi)));
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = BLK / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+
+__global__ __launch_bounds__(BLK) void reduce_max_kernel(const double *partial, int n, double *out)
+{
+    __shared__ double sm[BLK];
+    double m = -1.0;
+    for (int i = threadIdx.x; i < n; i += BLK) m = fmax(m, partial[i]);
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = BLK / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLK) void vec_fill_kernel(int64_t n, T v, T *y)
 {

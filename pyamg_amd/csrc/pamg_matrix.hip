@@ -800,6 +800,18 @@ int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch,
     return (int)hipGetLastError();
 }
 
+int vec_maxratio(int dtype, int64_t n, const void *u, const void *x, double *scratch, double *out, hipStream_t s)
+{
+    const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + BLK - 1) / BLK));
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_maxratio_kernel<double>), dim3(grid), dim3(BLK), 0, s, (const double *)u, (const double *)x, n, scratch);
+    else
+        hipLaunchKernelGGL((vec_maxratio_kernel<float>), dim3(grid), dim3(BLK), 0, s, (const float *)u, (const float *)x, n, scratch);
+    PAMG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_max_kernel, dim3(1), dim3(BLK), 0, s, (const double *)scratch, grid, out);
+    return (int)hipGetLastError();
+}
+
 static int vgrid(int64_t n) { return (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + BLK - 1) / BLK)); }
 
 int vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s)

@@ -744,6 +744,212 @@ int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int max
     return check_sweeps(S);
 }
 
+// Flexible GMRES with the resident cycle as (right) preconditioner, all vectors on the device: a
+// faithful restatement of the reference's krylov/_fgmres.py:120-345 as driven by
+// MultilevelSolver.solve(accel='fgmres') (multilevel.py:479-535) -- Householder reflectors
+// (amg_core::apply_householders, krylov.h:37-56), Givens rotations on the leading entries
+// (apply_givens, krylov.h:158-183), the same stopping rules, residual history and return codes.  The
+// Householder form is kept on purpose: its basis vectors differ from Gram-Schmidt ones by signs, which a
+// linear preconditioner cannot see but the AMLI cycle (inner Krylov steps from a guess of ones) can.
+// Only the n-vectors live on the device; the leading <= restart+1 entries the rotations work on are read
+// back per iteration.
+int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int restart, int cycle,
+                       int cycles_per_level, double *residuals, int residuals_cap, int *n_res, int *n_iter,
+                       int *info, pamg_stream_t s_)
+{
+    if (!S || !x || !b) return PAMG_E_ARG;
+    if (!S->finalized) return PAMG_E_STATE;
+    if (cycle < PAMG_CYCLE_V || cycle > PAMG_CYCLE_AMLI || cycles_per_level < 1 || cycles_per_level > 1023) return PAMG_E_ARG;
+    hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
+    PAMG_TRY(ensure_amli(S, cycle));
+    if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));
+    Level &L0 = S->levels[0];
+    const int64_t n = L0.n;
+    if (n < 2) return PAMG_E_UNSUPPORTED;              // the reference special-cases n == 1 on the host
+    const int dt = S->dtype;
+    const size_t ts = tsize(dt);
+    const size_t vb = (size_t)n * ts;
+    // iteration limits exactly as _fgmres.py:139-160
+    int max_outer, max_inner;
+    if (restart > 0) {
+        max_outer = maxiter > 0 ? maxiter : 1;
+        max_inner = (int)std::min<int64_t>(restart, n);
+    } else {
+        max_outer = 1;
+        max_inner = maxiter > 0 ? (int)std::min<int64_t>(maxiter, n) : (int)std::min<int64_t>(n, 40);
+    }
+    const int m = max_inner;
+    int nres = 0, inf = 0, nit = 0;
+    auto push = [&](double v) { if (residuals && nres < residuals_cap) residuals[nres] = v; ++nres; };
+    std::vector<void *> W((size_t)m, nullptr), Z((size_t)m, nullptr);
+    void *v = nullptr, *u = nullptr, *r = nullptr;
+    auto release = [&]() {
+        for (void *p : W) if (p) hipFree(p);
+        for (void *p : Z) if (p) hipFree(p);
+        if (v) hipFree(v);
+        if (u) hipFree(u);
+        if (r) hipFree(r);
+    };
+    auto grab = [&](void **p) -> int { return *p ? PAMG_OK : (int)hipMalloc(p, vb + 64); };
+    int st = grab(&v);
+    if (!st) st = grab(&u);
+    if (!st) st = grab(&r);
+    if (!st) st = grab(&W[0]);
+    if (st) { release(); return st; }
+    double *slot = S->d_slot;
+    double h1[2];
+    std::vector<unsigned char> hbuf((size_t)(m + 2) * ts);
+    auto fetch = [&](int k) -> int {
+        PAMG_HIP(hipMemcpyAsync(h1, slot + 1, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
+        return (int)hipStreamSynchronize(s);
+    };
+    auto at = [&](void *p, int64_t idx) -> void * { return (unsigned char *)p + (size_t)idx * ts; };
+    auto get = [&](void *p, int64_t idx, int cnt, double *out) -> int {     // out[0..cnt) = p[idx..idx+cnt)
+        PAMG_HIP(hipMemcpyAsync(hbuf.data(), at(p, idx), (size_t)cnt * ts, hipMemcpyDeviceToHost, s));
+        PAMG_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < cnt; ++k)
+            out[k] = dt == PAMG_F64 ? reinterpret_cast<const double *>(hbuf.data())[k] : (double)reinterpret_cast<const float *>(hbuf.data())[k];
+        return PAMG_OK;
+    };
+    auto put = [&](void *p, int64_t idx, double val) -> int {
+        double vd = val; float vf = (float)val;
+        PAMG_HIP(hipMemcpyAsync(at(p, idx), dt == PAMG_F64 ? (const void *)&vd : (const void *)&vf, ts, hipMemcpyHostToDevice, s));
+        return (int)hipStreamSynchronize(s);                               // the host scalar goes out of scope
+    };
+    auto norm2 = [&](const void *p, int64_t len, double *out) -> int {
+        PAMG_TRY(vec_sumsq(dt, len, p, S->d_scratch, slot + 1, s));
+        PAMG_TRY(fetch(1));
+        *out = std::sqrt(h1[0]);
+        return PAMG_OK;
+    };
+    auto reflect = [&](void *z, const void *wj) -> int {                   // z -= 2 (w_j . z) w_j
+        PAMG_TRY(vec_dot(dt, n, wj, z, S->d_scratch, slot + 1, s));
+        PAMG_TRY(fetch(1));
+        return vec_axpy(dt, n, -2.0 * h1[0], wj, z, s);
+    };
+    auto precond = [&](const void *vin, void *zout) -> int {               // z = M v: one cycle from x = 0
+        PAMG_HIP(hipMemcpyAsync(L0.b, vin, vb, hipMemcpyDeviceToDevice, s));
+        PAMG_HIP(hipMemsetAsync(L0.x, 0, vb, s));
+        PAMG_TRY(run_cycle(S, cycle, cycles_per_level, s, false, true));
+        return (int)hipMemcpyAsync(zout, L0.x, vb, hipMemcpyDeviceToDevice, s);
+    };
+    auto mysign = [](double t) { return t == 0.0 ? 1.0 : t / std::fabs(t); };
+    auto body = [&]() -> int {
+        double normr, normb;
+        PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));        // r = b - A x
+        PAMG_TRY(norm2(r, n, &normr));
+        PAMG_TRY(norm2(b, n, &normb));
+        push(normr);
+        if (normb == 0.0) normb = 1.0;
+        if (normr < tol * normb) { inf = 0; return PAMG_OK; }
+        int niter = 0;
+        std::vector<double> H((size_t)m * m), Q((size_t)4 * m), g((size_t)m + 1), y((size_t)m), hv((size_t)m + 2);
+        auto Hx = [&](int i, int j) -> double & { return H[(size_t)j * m + i]; };
+        for (int outer = 0; outer < max_outer; ++outer) {
+            std::fill(H.begin(), H.end(), 0.0);
+            std::fill(g.begin(), g.end(), 0.0);
+            // first reflector from the residual (:184-197)
+            double t, nw;
+            PAMG_HIP(hipMemcpyAsync(W[0], r, vb, hipMemcpyDeviceToDevice, s));
+            PAMG_TRY(get(W[0], 0, 1, &t));
+            const double beta = mysign(t) * normr;
+            PAMG_TRY(put(W[0], 0, t + beta));
+            PAMG_TRY(norm2(W[0], n, &nw));
+            PAMG_TRY(vec_scale(dt, n, 1.0 / nw, W[0], W[0], s));
+            g[0] = -beta;
+            int wi = 0, inner = 0;
+            for (inner = 0; inner < m; ++inner) {
+                void *w = W[wi];
+                // v = e_inner - 2 w[inner] w, then the earlier reflectors in reverse (:209-214)
+                PAMG_TRY(get(w, inner, 1, &t));
+                PAMG_TRY(vec_scale(dt, n, -2.0 * t, w, v, s));
+                PAMG_TRY(get(v, inner, 1, &t));
+                PAMG_TRY(put(v, inner, t + 1.0));
+                for (int j = inner - 1; j >= 0; --j) PAMG_TRY(reflect(v, W[j]));
+                PAMG_TRY(grab(&Z[inner]));
+                PAMG_TRY(precond(v, Z[inner]));                                           // z = M v
+                PAMG_TRY(stream_launch(L0.A, EPI_SET, Z[inner], nullptr, v, 0.0, 0.0, nullptr, s));   // v = A z
+                for (int j = 0; j <= inner; ++j) PAMG_TRY(reflect(v, W[j]));
+                if (inner != n - 1) {                                                     // next reflector (:229-246)
+                    if (inner < m - 1) wi = inner + 1;
+                    double alpha;
+                    PAMG_TRY(norm2(at(v, inner + 1), n - inner - 1, &alpha));
+                    if (alpha != 0.0) {
+                        PAMG_TRY(get(v, inner + 1, 1, &t));
+                        alpha = mysign(t) * alpha;
+                        if (inner < m - 1) {
+                            PAMG_TRY(grab(&W[inner + 1]));
+                            void *wn = W[inner + 1];
+                            PAMG_HIP(hipMemsetAsync(wn, 0, (size_t)(inner + 1) * ts, s));
+                            PAMG_HIP(hipMemcpyAsync(at(wn, inner + 1), at(v, inner + 1), (size_t)(n - inner - 1) * ts, hipMemcpyDeviceToDevice, s));
+                            PAMG_TRY(put(wn, inner + 1, t + alpha));
+                            PAMG_TRY(norm2(wn, n, &nw));
+                            PAMG_TRY(vec_scale(dt, n, 1.0 / nw, wn, wn, s));
+                        }
+                        PAMG_TRY(put(v, inner + 1, -alpha));                              // v[inner+2:] = 0 is implied below
+                    }
+                }
+                // the rotations work on the leading entries only (:248-266)
+                const int lead = (int)std::min<int64_t>(inner + 2, n);
+                std::fill(hv.begin(), hv.end(), 0.0);
+                PAMG_TRY(get(v, 0, lead, hv.data()));
+                for (int rot = 0; rot < inner; ++rot) {
+                    const double xt = hv[rot];
+                    hv[rot] = Q[4 * rot] * xt + Q[4 * rot + 1] * hv[rot + 1];
+                    hv[rot + 1] = Q[4 * rot + 2] * xt + Q[4 * rot + 3] * hv[rot + 1];
+                }
+                if (inner != n - 1 && hv[inner + 1] != 0.0) {
+                    const double f = hv[inner], gg = hv[inner + 1];                       // LAPACK lartg
+                    double c, sn;
+                    if (f == 0.0) { c = 0.0; sn = 1.0; }
+                    else { const double rr = std::copysign(std::hypot(f, gg), f); c = f / rr; sn = gg / rr; }
+                    Q[4 * inner] = c; Q[4 * inner + 1] = sn; Q[4 * inner + 2] = -sn; Q[4 * inner + 3] = c;
+                    const double g0 = g[inner], g1 = g[inner + 1];
+                    g[inner] = c * g0 + sn * g1;
+                    g[inner + 1] = -sn * g0 + c * g1;
+                    hv[inner] = c * f + sn * gg;
+                    hv[inner + 1] = 0.0;
+                }
+                for (int i = 0; i < m; ++i) Hx(i, inner) = i < lead ? hv[i] : 0.0;
+                if (inner < m - 1) {                                                      // :283-289
+                    normr = std::fabs(g[inner + 1]);
+                    if (normr < tol * normb) break;
+                    push(normr);
+                }
+                ++niter;
+            }
+            const int k = std::min(inner + 1, m);
+            for (int i = k - 1; i >= 0; --i) {                                            // H is upper triangular now
+                double acc = g[i];
+                for (int j = i + 1; j < k; ++j) acc -= Hx(i, j) * y[j];
+                y[i] = acc / Hx(i, i);
+            }
+            PAMG_TRY(vec_scale(dt, n, y[0], Z[0], u, s));                                 // update = Z y
+            for (int j = 1; j < k; ++j) PAMG_TRY(vec_axpy(dt, n, y[j], Z[j], u, s));
+            PAMG_TRY(vec_axpy(dt, n, 1.0, u, x, s));
+            PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));
+            PAMG_TRY(norm2(r, n, &normr));
+            push(normr);
+            PAMG_TRY(vec_maxratio(dt, n, u, x, S->d_scratch, slot + 1, s));               // stagnation, :316-322
+            PAMG_TRY(fetch(1));
+            nit = niter;
+            if (h1[0] >= 0.0 && h1[0] < 1e-12) { inf = -1; return PAMG_OK; }
+            if (normr < tol * normb) { inf = 0; return PAMG_OK; }
+        }
+        inf = niter;
+        nit = niter;
+        return PAMG_OK;
+    };
+    st = body();
+    hipStreamSynchronize(s);
+    release();
+    if (info) *info = inf;
+    if (n_iter) *n_iter = nit;
+    if (n_res) *n_res = nres;
+    if (st) return st;
+    return check_sweeps(S);
+}
+
 int pamg_solver_stats(pamg_solver_t S, int64_t stats[8])
 {
     if (!S || !stats) return PAMG_E_ARG;

@@ -322,10 +322,24 @@ class DeviceMultilevelSolver:
                    "pamg_solver_pcg")
         return res[: nit.value + 1], nit.value, info.value
 
+    def fgmres_device(self, xd, bd, tol=1e-5, maxiter=None, restart=None, cycle="V", cycles_per_level=1, stream=None):
+        """Device-resident flexible GMRES (krylov/_fgmres.py's control flow and residual history) on
+        DEVICE vectors; returns (residuals, n_iter, info)."""
+        n = self.shape[0]
+        inner = min(int(restart), n) if restart else (min(int(maxiter), n) if maxiter else min(n, 40))
+        outer = (int(maxiter) if maxiter else 1) if restart else 1
+        cap = 1 + outer * (inner + 1)
+        res = np.zeros(cap, dtype=np.float64)
+        nres, nit, info = C.c_int(0), C.c_int(0), C.c_int(0)
+        capi.check(capi.lib().pamg_solver_fgmres(self.handle, xd.ptr, bd.ptr, float(tol), int(maxiter or 0), int(restart or 0),
+                                                 capi.CYCLE[cycle], int(cycles_per_level), capi.ptr(res), cap, C.byref(nres),
+                                                 C.byref(nit), C.byref(info), stream), "pamg_solver_fgmres")
+        return res[: min(nres.value, cap)], nit.value, info.value
+
     def _solve_accel(self, b, x0, tol, maxiter, cycle, accel, callback, residuals, return_info):
-        """multilevel.py:479-535.  accel='cg' without a callback runs entirely on the device
-        (``pamg_solver_pcg``); every other accelerator is the host Krylov method of the
-        reference / SciPy around the device preconditioner."""
+        """multilevel.py:479-535.  accel='cg' and accel='fgmres' without a callback run entirely on
+        the device (``pamg_solver_pcg`` / ``pamg_solver_fgmres``); every other accelerator is the host
+        Krylov method of the reference / SciPy around the device preconditioner."""
         if accel == "cg" and not self.symmetric_smoothing and self.ml is not None:
             from warnings import warn
             warn("Incompatible non-symmetric multigrid preconditioner detected, due to presmoother/postsmoother "
@@ -338,6 +352,15 @@ class DeviceMultilevelSolver:
             if info == -1:
                 from warnings import warn
                 warn("\nIndefinite matrix or preconditioner detected in CG, aborting\n")
+            if residuals is not None:
+                residuals[:] = list(res)
+            out = self._xd.download()
+            return (out, info) if return_info else out
+        if accel == "fgmres" and callback is None and self.shape[0] > 1 and np.result_type(b.dtype, self.dtype) == self.dtype:
+            x = np.zeros(self.shape[0], dtype=self.dtype) if x0 is None else np.ravel(np.array(x0)).astype(self.dtype)
+            self._bd.upload(np.ravel(b).astype(self.dtype, copy=False))
+            self._xd.upload(x)
+            res, nit, info = self.fgmres_device(self._xd, self._bd, tol, maxiter, None, cycle)
             if residuals is not None:
                 residuals[:] = list(res)
             out = self._xd.download()

@@ -35,8 +35,44 @@ SEED = 20260924
 ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]     # regenerate selected hierarchies only
 
 
+ACCEL_ONLY = "--accel-only" in sys.argv      # only (re)generate accel_fgmres.npz
+ACCEL_CASES = ("sa2d_gs", "sa2d_jacobi_AMLI", "rs2d_nonsym_gs", "el2d_blockgs", "sa3d_gs")
+ACCEL = {}
+
+
+def accel_case(name, ml, cycle):
+    """MultilevelSolver.solve(accel='fgmres') of the reference (multilevel.py:479-535 ->
+    krylov/_fgmres.py) on the same hierarchy: residual history, solution, info."""
+    n = ml.levels[0].A.shape[0]
+    b = np.random.RandomState(SEED + 7).rand(n)
+    for tag, kw in (("a", dict(tol=1e-10, maxiter=12)), ("b", dict(tol=1e-6, maxiter=40))):
+        res = []
+        x, info = ml.solve(b, cycle=cycle, accel="fgmres", residuals=res, return_info=True, **kw)
+        ACCEL[f"{name}.{tag}.res"] = np.array(res)
+        ACCEL[f"{name}.{tag}.x"] = x
+        ACCEL[f"{name}.{tag}.info"] = np.array(info)
+        ACCEL[f"{name}.{tag}.tol"] = np.array(kw["tol"])
+        ACCEL[f"{name}.{tag}.maxiter"] = np.array(kw["maxiter"])
+    ACCEL[f"{name}.b"] = b
+    ACCEL[f"{name}.cycle"] = np.array(cycle)
+    print(f"accel fgmres {name}: lens {len(ACCEL[name + '.a.res'])}/{len(ACCEL[name + '.b.res'])} info {ACCEL[name + '.a.info']}/{ACCEL[name + '.b.info']}")
+
+
 def hier(name, ml, k=8, cycle="V"):
     if ONLY and name not in ONLY:
+        return
+    if name in ACCEL_CASES:
+        if ACCEL_ONLY:
+            # the hierarchy must be the committed one, array for array
+            ref, _ = hierarchy.load_spec(HERE / f"hier_{name}.npz")
+            new = hierarchy.extract(ml)
+            assert len(ref.levels) == len(new.levels)
+            for La, Lb in zip(ref.levels, new.levels):
+                for oa, ob in ((La.A, Lb.A), (La.P, Lb.P), (La.R, Lb.R)):
+                    if oa is not None:
+                        assert np.array_equal(oa.data, ob.data) and np.array_equal(oa.indices, ob.indices), name
+        accel_case(name, ml, cycle)
+    if ACCEL_ONLY:
         return
     spec = hierarchy.extract(ml)
     n = ml.levels[0].A.shape[0]
@@ -269,8 +305,15 @@ def make_known_answers():
     print("known_answers.json written; sor doctest norm =", ka["doctest_sor_norm"]["expect_norm_3dec"])
 
 
-if __name__ == "__main__" and ONLY:
+def save_accel():
+    if ACCEL:
+        np.savez_compressed(HERE / "accel_fgmres.npz", **ACCEL)
+        print("accel_fgmres.npz written:", len(ACCEL), "arrays")
+
+
+if __name__ == "__main__" and (ONLY or ACCEL_ONLY):
     make_hierarchies()
+    save_accel()
     sys.exit(0)
 
 if __name__ == "__main__":
@@ -278,3 +321,4 @@ if __name__ == "__main__":
         make_known_answers()
         make_kernels()
     make_hierarchies()
+    save_accel()
