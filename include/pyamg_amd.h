@@ -311,6 +311,13 @@ int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int max
 int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int restart,
                        int cycle, int cycles_per_level, double *residuals, int residuals_cap, int *n_res,
                        int *n_iter, int *info, pamg_stream_t s);
+/* The reference's default GMRES (krylov/_gmres_householder.py, what solve(accel='gmres') and
+ * pyamg.solve() on non-symmetric operators run): LEFT-preconditioned, so every norm in `residuals` is a
+ * preconditioned-residual norm and the tolerance is relative to ||M b||.  Arguments as pamg_solver_fgmres;
+ * needs (inner iterations + 4) device vectors. */
+int pamg_solver_gmres(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int restart,
+                      int cycle, int cycles_per_level, double *residuals, int residuals_cap, int *n_res,
+                      int *n_iter, int *info, pamg_stream_t s);
 /* Same iteration split in three so that callers (benchmarks, device-side Krylov drivers)
  * can run exactly k cycles on the resident state with no staging copies in between:
  * load copies DEVICE x, b into the solver's level-0 buffers; iterate runs k x (cycle +

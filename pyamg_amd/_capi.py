@@ -121,6 +121,7 @@ def _declare(lib):
     f("pamg_solver_set_graph", _vp, _i)
     f("pamg_solver_pcg", _vp, _vp, _vp, _d, _i, _i, _i, _vp, P(_i), P(_i), _vp)
     f("pamg_solver_fgmres", _vp, _vp, _vp, _d, _i, _i, _i, _i, _vp, _i, P(_i), P(_i), P(_i), _vp)
+    f("pamg_solver_gmres", _vp, _vp, _vp, _d, _i, _i, _i, _i, _vp, _i, P(_i), P(_i), P(_i), _vp)
     f("pamg_solver_load", _vp, _vp, _vp, _vp)
     f("pamg_solver_iterate", _vp, _i, _i, _i, _vp, _vp)
     f("pamg_solver_store", _vp, _vp, _vp)

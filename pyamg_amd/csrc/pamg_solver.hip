@@ -753,9 +753,13 @@ int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int max
 // linear preconditioner cannot see but the AMLI cycle (inner Krylov steps from a guess of ones) can.
 // Only the n-vectors live on the device; the leading <= restart+1 entries the rotations work on are read
 // back per iteration.
-int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int restart, int cycle,
-                       int cycles_per_level, double *residuals, int residuals_cap, int *n_res, int *n_iter,
-                       int *info, pamg_stream_t s_)
+// flexible = true: FGMRES (right preconditioning, the preconditioned vectors Z are kept);
+// flexible = false: the reference's default GMRES, krylov/_gmres_householder.py:120-330 (LEFT
+// preconditioning: every norm is a preconditioned-residual norm, tolerance relative to ||M b||; the update
+// is mapped back through the reflectors by amg_core::householder_hornerscheme, krylov.h:106-130).
+static int krylov_householder(pamg_solver_t S, bool flexible, void *x, const void *b, double tol, int maxiter, int restart,
+                              int cycle, int cycles_per_level, double *residuals, int residuals_cap, int *n_res,
+                              int *n_iter, int *info, pamg_stream_t s_)
 {
     if (!S || !x || !b) return PAMG_E_ARG;
     if (!S->finalized) return PAMG_E_STATE;
@@ -836,11 +840,20 @@ int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int 
     auto mysign = [](double t) { return t == 0.0 ? 1.0 : t / std::fabs(t); };
     auto body = [&]() -> int {
         double normr, normb;
-        PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));        // r = b - A x
+        auto residual = [&]() -> int {                                                    // r = b - A x  (GMRES: M (b - A x))
+            if (flexible) return stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s);
+            PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, v, 0.0, 0.0, nullptr, s));
+            return precond(v, r);
+        };
+        PAMG_TRY(residual());
         PAMG_TRY(norm2(r, n, &normr));
         PAMG_TRY(norm2(b, n, &normb));
         push(normr);
         if (normb == 0.0) normb = 1.0;
+        else if (!flexible) {                                                             // tolerance relative to ||M b||
+            PAMG_TRY(precond(b, v));
+            PAMG_TRY(norm2(v, n, &normb));
+        }
         if (normr < tol * normb) { inf = 0; return PAMG_OK; }
         int niter = 0;
         std::vector<double> H((size_t)m * m), Q((size_t)4 * m), g((size_t)m + 1), y((size_t)m), hv((size_t)m + 2);
@@ -866,9 +879,14 @@ int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int 
                 PAMG_TRY(get(v, inner, 1, &t));
                 PAMG_TRY(put(v, inner, t + 1.0));
                 for (int j = inner - 1; j >= 0; --j) PAMG_TRY(reflect(v, W[j]));
-                PAMG_TRY(grab(&Z[inner]));
-                PAMG_TRY(precond(v, Z[inner]));                                           // z = M v
-                PAMG_TRY(stream_launch(L0.A, EPI_SET, Z[inner], nullptr, v, 0.0, 0.0, nullptr, s));   // v = A z
+                if (flexible) {
+                    PAMG_TRY(grab(&Z[inner]));
+                    PAMG_TRY(precond(v, Z[inner]));                                       // z = M v
+                    PAMG_TRY(stream_launch(L0.A, EPI_SET, Z[inner], nullptr, v, 0.0, 0.0, nullptr, s));   // v = A z
+                } else {
+                    PAMG_TRY(stream_launch(L0.A, EPI_SET, v, nullptr, u, 0.0, 0.0, nullptr, s));          // v = M (A v)
+                    PAMG_TRY(precond(u, v));
+                }
                 for (int j = 0; j <= inner; ++j) PAMG_TRY(reflect(v, W[j]));
                 if (inner != n - 1) {                                                     // next reflector (:229-246)
                     if (inner < m - 1) wi = inner + 1;
@@ -911,12 +929,13 @@ int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int 
                     hv[inner + 1] = 0.0;
                 }
                 for (int i = 0; i < m; ++i) Hx(i, inner) = i < lead ? hv[i] : 0.0;
+                if (!flexible) ++niter;                                                   // GMRES counts before the test
                 if (inner < m - 1) {                                                      // :283-289
                     normr = std::fabs(g[inner + 1]);
                     if (normr < tol * normb) break;
                     push(normr);
                 }
-                ++niter;
+                if (flexible) ++niter;
             }
             const int k = std::min(inner + 1, m);
             for (int i = k - 1; i >= 0; --i) {                                            // H is upper triangular now
@@ -924,10 +943,19 @@ int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int 
                 for (int j = i + 1; j < k; ++j) acc -= Hx(i, j) * y[j];
                 y[i] = acc / Hx(i, i);
             }
-            PAMG_TRY(vec_scale(dt, n, y[0], Z[0], u, s));                                 // update = Z y
-            for (int j = 1; j < k; ++j) PAMG_TRY(vec_axpy(dt, n, y[j], Z[j], u, s));
+            if (flexible) {
+                PAMG_TRY(vec_scale(dt, n, y[0], Z[0], u, s));                             // update = Z y
+                for (int j = 1; j < k; ++j) PAMG_TRY(vec_axpy(dt, n, y[j], Z[j], u, s));
+            } else {
+                PAMG_HIP(hipMemsetAsync(u, 0, vb, s));                                    // Horner scheme through the reflectors
+                for (int j = k - 1; j >= 0; --j) {
+                    PAMG_TRY(get(u, j, 1, &t));
+                    PAMG_TRY(put(u, j, t + y[j]));
+                    PAMG_TRY(reflect(u, W[j]));
+                }
+            }
             PAMG_TRY(vec_axpy(dt, n, 1.0, u, x, s));
-            PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));
+            PAMG_TRY(residual());
             PAMG_TRY(norm2(r, n, &normr));
             push(normr);
             PAMG_TRY(vec_maxratio(dt, n, u, x, S->d_scratch, slot + 1, s));               // stagnation, :316-322
@@ -948,6 +976,22 @@ int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int 
     if (n_res) *n_res = nres;
     if (st) return st;
     return check_sweeps(S);
+}
+
+int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int restart, int cycle,
+                       int cycles_per_level, double *residuals, int residuals_cap, int *n_res, int *n_iter,
+                       int *info, pamg_stream_t s)
+{
+    return krylov_householder(S, true, x, b, tol, maxiter, restart, cycle, cycles_per_level, residuals, residuals_cap,
+                              n_res, n_iter, info, s);
+}
+
+int pamg_solver_gmres(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int restart, int cycle,
+                      int cycles_per_level, double *residuals, int residuals_cap, int *n_res, int *n_iter,
+                      int *info, pamg_stream_t s)
+{
+    return krylov_householder(S, false, x, b, tol, maxiter, restart, cycle, cycles_per_level, residuals, residuals_cap,
+                              n_res, n_iter, info, s);
 }
 
 int pamg_solver_stats(pamg_solver_t S, int64_t stats[8])

@@ -322,7 +322,13 @@ class DeviceMultilevelSolver:
                    "pamg_solver_pcg")
         return res[: nit.value + 1], nit.value, info.value
 
-    def fgmres_device(self, xd, bd, tol=1e-5, maxiter=None, restart=None, cycle="V", cycles_per_level=1, stream=None):
+    def gmres_device(self, xd, bd, tol=1e-5, maxiter=None, restart=None, cycle="V", cycles_per_level=1, stream=None):
+        """Device-resident GMRES, the reference's default Householder variant (krylov/_gmres_householder.py:
+        left-preconditioned, residuals are preconditioned-residual norms); returns (residuals, n_iter, info)."""
+        return self.fgmres_device(xd, bd, tol, maxiter, restart, cycle, cycles_per_level, stream, _entry="pamg_solver_gmres")
+
+    def fgmres_device(self, xd, bd, tol=1e-5, maxiter=None, restart=None, cycle="V", cycles_per_level=1, stream=None,
+                      _entry="pamg_solver_fgmres"):
         """Device-resident flexible GMRES (krylov/_fgmres.py's control flow and residual history) on
         DEVICE vectors; returns (residuals, n_iter, info)."""
         n = self.shape[0]
@@ -331,14 +337,14 @@ class DeviceMultilevelSolver:
         cap = 1 + outer * (inner + 1)
         res = np.zeros(cap, dtype=np.float64)
         nres, nit, info = C.c_int(0), C.c_int(0), C.c_int(0)
-        capi.check(capi.lib().pamg_solver_fgmres(self.handle, xd.ptr, bd.ptr, float(tol), int(maxiter or 0), int(restart or 0),
-                                                 capi.CYCLE[cycle], int(cycles_per_level), capi.ptr(res), cap, C.byref(nres),
-                                                 C.byref(nit), C.byref(info), stream), "pamg_solver_fgmres")
+        capi.check(getattr(capi.lib(), _entry)(self.handle, xd.ptr, bd.ptr, float(tol), int(maxiter or 0), int(restart or 0),
+                                               capi.CYCLE[cycle], int(cycles_per_level), capi.ptr(res), cap, C.byref(nres),
+                                               C.byref(nit), C.byref(info), stream), _entry)
         return res[: min(nres.value, cap)], nit.value, info.value
 
     def _solve_accel(self, b, x0, tol, maxiter, cycle, accel, callback, residuals, return_info):
-        """multilevel.py:479-535.  accel='cg' and accel='fgmres' without a callback run entirely on
-        the device (``pamg_solver_pcg`` / ``pamg_solver_fgmres``); every other accelerator is the host
+        """multilevel.py:479-535.  accel='cg', 'fgmres' and 'gmres' without a callback run entirely on
+        the device (``pamg_solver_pcg`` / ``pamg_solver_fgmres`` / ``pamg_solver_gmres``); every other accelerator is the host
         Krylov method of the reference / SciPy around the device preconditioner."""
         if accel == "cg" and not self.symmetric_smoothing and self.ml is not None:
             from warnings import warn
@@ -356,11 +362,12 @@ class DeviceMultilevelSolver:
                 residuals[:] = list(res)
             out = self._xd.download()
             return (out, info) if return_info else out
-        if accel == "fgmres" and callback is None and self.shape[0] > 1 and np.result_type(b.dtype, self.dtype) == self.dtype:
+        if accel in ("fgmres", "gmres") and callback is None and self.shape[0] > 1 and np.result_type(b.dtype, self.dtype) == self.dtype:
             x = np.zeros(self.shape[0], dtype=self.dtype) if x0 is None else np.ravel(np.array(x0)).astype(self.dtype)
             self._bd.upload(np.ravel(b).astype(self.dtype, copy=False))
             self._xd.upload(x)
-            res, nit, info = self.fgmres_device(self._xd, self._bd, tol, maxiter, None, cycle)
+            run = self.fgmres_device if accel == "fgmres" else self.gmres_device
+            res, nit, info = run(self._xd, self._bd, tol, maxiter, None, cycle)
             if residuals is not None:
                 residuals[:] = list(res)
             out = self._xd.download()

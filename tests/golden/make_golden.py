@@ -53,6 +53,13 @@ def accel_case(name, ml, cycle):
         ACCEL[f"{name}.{tag}.info"] = np.array(info)
         ACCEL[f"{name}.{tag}.tol"] = np.array(kw["tol"])
         ACCEL[f"{name}.{tag}.maxiter"] = np.array(kw["maxiter"])
+    if cycle != "AMLI":        # the reference allows AMLI cycles only under fgmres (multilevel.py:488-490)
+        for tag, kw in (("a", dict(tol=1e-10, maxiter=12)), ("b", dict(tol=1e-6, maxiter=40))):
+            res = []
+            x, info = ml.solve(b, cycle=cycle, accel="gmres", residuals=res, return_info=True, **kw)
+            ACCEL[f"{name}.gmres.{tag}.res"] = np.array(res)
+            ACCEL[f"{name}.gmres.{tag}.x"] = x
+            ACCEL[f"{name}.gmres.{tag}.info"] = np.array(info)
     ACCEL[f"{name}.b"] = b
     ACCEL[f"{name}.cycle"] = np.array(cycle)
     print(f"accel fgmres {name}: lens {len(ACCEL[name + '.a.res'])}/{len(ACCEL[name + '.b.res'])} info {ACCEL[name + '.a.info']}/{ACCEL[name + '.b.info']}")

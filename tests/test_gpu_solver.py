@@ -211,7 +211,7 @@ def test_device_fgmres_matches_reference():
     from conftest import GOLDEN
     from pyamg_amd.hierarchy import load_spec
     z = np.load(GOLDEN / "accel_fgmres.npz")
-    names = sorted({k.split(".")[0] for k in z.files})
+    names = sorted({k.split(".")[0] for k in z.files})      # keys: <hierarchy>.[gmres.]<a|b>.<res|x|info|...>
     assert len(names) >= 5
     for name in names:
         spec, _ = load_spec(GOLDEN / f"hier_{name}.npz")
@@ -227,4 +227,15 @@ def test_device_fgmres_matches_reference():
             assert np.max(np.abs(np.array(res) - ref)) <= 1e-10 * ref[0], (name, tag)
             xr = z[f"{name}.{tag}.x"]
             assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr), (name, tag)
+            if f"{name}.gmres.{tag}.res" not in z.files:
+                continue
+            # the reference's default GMRES (left-preconditioned Householder): pamg_solver_gmres
+            res = []
+            x, info = dml.solve(b, tol=float(z[f"{name}.{tag}.tol"]), maxiter=int(z[f"{name}.{tag}.maxiter"]), cycle=cyc,
+                                accel="gmres", residuals=res, return_info=True)
+            ref = z[f"{name}.gmres.{tag}.res"]
+            assert len(res) == len(ref) and info == int(z[f"{name}.gmres.{tag}.info"]), (name, tag, "gmres", len(res), len(ref), info)
+            assert np.max(np.abs(np.array(res) - ref)) <= 1e-10 * ref[0], (name, tag, "gmres")
+            xr = z[f"{name}.gmres.{tag}.x"]
+            assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr), (name, tag, "gmres")
         dml.free()
