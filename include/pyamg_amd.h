@@ -131,6 +131,15 @@ int pamg_jacobi_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_si
                     const float *b, int b_size, float *temp, int temp_size,
                     int32_t row_start, int32_t row_stop, int32_t row_step,
                     const float *omega, int omega_size);
+/* amg_core::jacobi_indexed, relaxation.h:382-390 (the kernel of cf_jacobi / fc_jacobi) */
+int pamg_jacobi_indexed_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                            const double *Ax, int Ax_size, double *x, int x_size,
+                            const double *b, int b_size, const int32_t *indices, int indices_size,
+                            const double *omega, int omega_size);
+int pamg_jacobi_indexed_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                            const float *Ax, int Ax_size, float *x, int x_size,
+                            const float *b, int b_size, const int32_t *indices, int indices_size,
+                            const float *omega, int omega_size);
 /* amg_core::bsr_jacobi, relaxation.h:472-483 */
 int pamg_bsr_jacobi_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
                         const double *Ax, int Ax_size, double *x, int x_size,
@@ -207,6 +216,12 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap);
  * 1 backward) eight 64-bit words {arrival, gate open, polled, staged, finished (wall clock, 10 ns),
  * XCD id, workgroup id, dependency level}.  out == NULL: only *count.  Synchronises. */
 int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count);
+/* Row-subset copy of a CSR operator (rows: HOST list, kept in list order) for the indexed smoothers,
+ * and amg_core::jacobi_indexed (relaxation.h:382-427) on it: every listed row of x is relaxed from the
+ * OLD x (x, b: DEVICE vectors of the parent's size; work: DEVICE, one value per listed row). */
+int pamg_matrix_subset_rows(pamg_matrix_t A, const int32_t *rows, int nrows, pamg_matrix_t *sub);
+int pamg_matrix_jacobi_indexed(pamg_matrix_t sub, void *x, const void *b, double omega, void *work,
+                               pamg_stream_t s);
 /* *error != 0: a persistent sweep of this operator hit its spin bound (synchronises) */
 int pamg_matrix_flow_error(pamg_matrix_t A, int *error);
 
@@ -266,6 +281,8 @@ int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, v
 #define PAMG_SMOOTH_POLY        4
 #define PAMG_SMOOTH_BLOCK_JACOBI 5
 #define PAMG_SMOOTH_BLOCK_GS    6
+#define PAMG_SMOOTH_CF_JACOBI   7   /* relaxation.cf_jacobi  relaxation.py:1141-1203: C sweeps, then F sweeps */
+#define PAMG_SMOOTH_FC_JACOBI   8   /* relaxation.fc_jacobi  relaxation.py:1206-1268: F sweeps, then C sweeps */
 #define PAMG_CYCLE_V 0
 #define PAMG_CYCLE_W 1
 #define PAMG_CYCLE_F 2
@@ -279,6 +296,13 @@ int pamg_solver_add_level(pamg_solver_t S, pamg_matrix_t A, pamg_matrix_t P, pam
 int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, int iterations,
                              double omega, int sweep, const double *coeffs, int ncoeffs,
                              const void *Dinv, int blocksize);
+/* CF / FC Jacobi (the AIR solver's default F/C relaxation): per outer iteration c_iterations sweeps of
+ * amg_core::jacobi_indexed (relaxation.h:382-427) over Cpts and f_iterations over Fpts, in the order the
+ * kind names.  Fpts / Cpts: HOST row lists (copied; the solver keeps row-subset copies of the level's
+ * operator).  CSR levels only. */
+int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind, int iterations,
+                                int f_iterations, int c_iterations, double omega, const int32_t *Fpts,
+                                int nF, const int32_t *Cpts, int nC);
 /* coarsest solve x_c = M b_c with HOST row-major M (n_c x n_c); M == NULL: x_c = 0
  * (multilevel.py:717-721, 801-803) */
 int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c);

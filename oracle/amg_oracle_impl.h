@@ -110,6 +110,27 @@ void FN(jacobi)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REA
     }
 }
 
+/* Weighted Jacobi on a list of rows.  Follows amg_core jacobi_indexed, relaxation.h:382-427:
+ * temp = x (the whole vector), then every listed row is relaxed from temp; a zero / missing
+ * diagonal leaves the row untouched (the reference also prints a warning). */
+void FN(jacobi_indexed)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, int n, const REAL *b,
+                        const int *indices, int n_indices, REAL *temp, REAL omega)
+{
+    const REAL one = 1;
+    for (int i = 0; i < n; ++i) temp[i] = x[i];
+    for (int k = 0; k < n_indices; ++k) {
+        const int row = indices[k];
+        REAL rsum = 0, diag = 0;
+        for (int p = Ap[row]; p < Ap[row + 1]; ++p) {
+            const int col = Aj[p];
+            if (row == col) diag = Ax[p];
+            else            rsum += Ax[p] * temp[col];
+        }
+        if (diag != (REAL)0)
+            x[row] = (one - omega) * temp[row] + omega * ((b[row] - rsum) / diag);
+    }
+}
+
 /* dense helper: out[0..bs) = M(bs x bs, row major) * v, each output a fresh running sum
  * starting at 0 (the reference's gemm(...,'F','F','T' overwrite), linalg.h:405-438). */
 static void FN(blk_apply)(const REAL *M, const REAL *v, REAL *out, int bs)

@@ -97,6 +97,15 @@ def jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, omega):
           _I(row_start), _I(row_stop), _I(row_step), ct(omega))
 
 
+def jacobi_indexed(Ap, Aj, Ax, x, b, indices, omega):
+    """amg_core.jacobi_indexed (relaxation.h:382-427)."""
+    _, ct = _sfx(Ax.dtype)
+    temp = np.empty_like(x)
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    _call("jacobi_indexed", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _I(x.size), _ptr(b), _ptr(idx),
+          _I(idx.size), _ptr(temp), ct(omega))
+
+
 def bsr_jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, blocksize, omega):
     _, ct = _sfx(Ax.dtype)
     _call("bsr_jacobi", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b), _ptr(temp),
@@ -230,6 +239,27 @@ def relax_polynomial(A, x, b, coefficients, iterations=1):
         x += h
 
 
+def relax_jacobi_indexed(A, x, b, indices, iterations=1, omega=1.0):
+    """relaxation.py:1077-1138 (CSR)."""
+    if A.fmt != "csr":
+        raise NotImplementedError("oracle: indexed Jacobi is restated for CSR operators")
+    om = A.data.dtype.type(omega)
+    for _ in range(iterations):
+        jacobi_indexed(A.indptr, A.indices, A.data, x, b, indices, om)
+
+
+def relax_cf_jacobi(A, x, b, Cpts, Fpts, iterations=1, f_iterations=1, c_iterations=1, omega=1.0, f_first=False):
+    """relaxation.py:1141-1203 (cf_jacobi) and :1206-1268 (fc_jacobi, f_first=True)."""
+    if A.fmt != "csr":
+        raise NotImplementedError("oracle: CF/FC Jacobi is restated for CSR operators")
+    om = A.data.dtype.type(omega)
+    plan = [(Fpts, f_iterations), (Cpts, c_iterations)] if f_first else [(Cpts, c_iterations), (Fpts, f_iterations)]
+    for _ in range(iterations):
+        for pts, sweeps in plan:
+            for _ in range(sweeps):
+                jacobi_indexed(A.indptr, A.indices, A.data, x, b, pts, om)
+
+
 def apply_smoother(s, A, x, b):
     """Dispatch a SmootherSpec exactly as the reference's bound callable would run."""
     if s is None or s.kind == "none":
@@ -246,6 +276,9 @@ def apply_smoother(s, A, x, b):
         relax_block_jacobi(A, x, b, s.Dinv, s.blocksize, s.iterations, s.omega)
     elif s.kind == "block_gauss_seidel":
         relax_block_gauss_seidel(A, x, b, s.Dinv, s.blocksize, s.iterations, s.sweep)
+    elif s.kind in ("cf_jacobi", "fc_jacobi"):
+        relax_cf_jacobi(A, x, b, s.Cpts, s.Fpts, s.iterations, s.f_iterations, s.c_iterations, s.omega,
+                        f_first=(s.kind == "fc_jacobi"))
     else:
         raise ValueError(f"oracle: unknown smoother kind {s.kind}")
 

@@ -86,6 +86,16 @@ def jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, omega):
                                                       capi.ptr(omega), omega.size), "jacobi")
 
 
+def jacobi_indexed(Ap, Aj, Ax, x, b, indices, omega):
+    """amg_core.jacobi_indexed (relaxation.h:382-427)."""
+    _idx(Ap, Aj)
+    if indices.dtype != np.int32:
+        raise TypeError("jacobi_indexed(): incompatible function arguments (indices must be int32)")
+    s = _sfx(Ax, x, b, omega)
+    capi.check(getattr(capi.lib(), f"pamg_jacobi_indexed_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(indices), indices.size,
+                                                              capi.ptr(omega), omega.size), "jacobi_indexed")
+
+
 def bsr_jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, blocksize, omega):
     _idx(Ap, Aj)
     s = _sfx(Ax, x, b, temp, omega)

@@ -125,6 +125,30 @@ int l1_jacobi(bool bsr, const int32_t *Ap, int Ap_size, const int32_t *Aj, int A
     return PAMG_OK;
 }
 
+// jacobi_indexed (relaxation.h:382-427): temp = x; every listed row is relaxed from temp.  A row listed
+// twice is simply relaxed twice from the same old values -- same result as the reference's loop.
+template <typename T>
+int l1_jacobi_indexed(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size, T *x,
+                      int x_size, const T *b, int b_size, const int32_t *indices, int indices_size, const T *omega,
+                      int omega_size)
+{
+    if (!x || !b || !omega || omega_size < 1 || indices_size < 0 || (indices_size > 0 && !indices)) return PAMG_E_ARG;
+    PAMG_TRY(check_csr(Ap, Ap_size, Aj_size, Ax_size, 1));
+    const int n = Ap_size - 1;
+    if (n > x_size || n > b_size) return PAMG_E_ARG;
+    if (indices_size == 0) return PAMG_OK;
+    MatGuard g, sub;
+    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), PAMG_CSR, n, n, 1, 1, Ap, Aj, Ax));
+    PAMG_TRY(matrix_row_subset(g.A, indices, indices_size, &sub.A));
+    DevBuf dx, db, dw;
+    PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
+    PAMG_TRY(db.put(b, sizeof(T) * (size_t)n));
+    PAMG_TRY(dw.alloc(sizeof(T) * (size_t)indices_size));
+    PAMG_TRY(jacobi_indexed(sub.A, dx.p, db.p, (double)omega[0], dw.p, nullptr));
+    PAMG_HIP(hipDeviceSynchronize());
+    return dx.get(x, sizeof(T) * (size_t)n);
+}
+
 template <typename T>
 int l1_block(bool gs, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size,
              T *x, int x_size, const T *b, int b_size, const T *Tx, int Tx_size, T *temp, int temp_size,
@@ -261,6 +285,11 @@ int pamg_event_elapsed_ms(pamg_event_t a, pamg_event_t b, float *ms) { return ms
                           int omega_size)                                                                       \
     { return l1_jacobi<T>(false, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, temp, temp_size,  \
                           row_start, row_stop, row_step, 1, omega, omega_size); }                               \
+    int pamg_jacobi_indexed_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,  \
+                                  int Ax_size, T *x, int x_size, const T *b, int b_size,                        \
+                                  const int32_t *indices, int indices_size, const T *omega, int omega_size)     \
+    { return l1_jacobi_indexed<T>(Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, indices,         \
+                                  indices_size, omega, omega_size); }                                           \
     int pamg_bsr_jacobi_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,      \
                               int Ax_size, T *x, int x_size, const T *b, int b_size, T *temp, int temp_size,    \
                               int32_t row_start, int32_t row_stop, int32_t row_step, int32_t blocksize,         \

@@ -44,6 +44,7 @@ enum : int {
     EPI_GS,             // amg_core::gauss_seidel      relaxation.h:48-76
     EPI_GS_B,           // amg_core::bsr_gauss_seidel, 1x1  relaxation.h:185-266
     EPI_SOR,            // amg_core::sor_gauss_seidel  relaxation.h:116-145
+    EPI_JACOBI_IDX,     // amg_core::jacobi_indexed    relaxation.h:382-427 (row-subset operator, out[r] = new x[rid[r]])
     EPI_COUNT
 };
 
@@ -107,6 +108,7 @@ struct pamg_matrix_s {
     int *d_Ap = nullptr, *d_Aj = nullptr;
     void *d_Ax = nullptr;
     void *d_diag = nullptr;                   // diagonal of the scalar view (point smoothers)
+    int *d_rowid = nullptr;                   // row-subset operators (indexed Jacobi): original row of stored row r
     // block view kept for the true block smoothers (bs > 1): block CSR arrays
     int *d_bAp = nullptr, *d_bAj = nullptr;   // nullptr when R == C == 1
     int *d_bAjf = nullptr, *d_bdiag = nullptr; // block columns with the diagonal flag (bit 30); diagonal block position per block row
@@ -146,6 +148,9 @@ int vec_sumsq(int dtype, int64_t n, const void *x, double *scratch, double *out,
 int vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
 int vec_scale(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
 int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch, double *out, hipStream_t s);
+int vec_scatter(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s);
+int matrix_row_subset(pamg_matrix_s *A, const int32_t *rows, int nrows, pamg_matrix_s **out);   // rows: HOST
+int jacobi_indexed(pamg_matrix_s *sub, void *x, const void *b, double omega, void *work, hipStream_t s);
 int vec_maxratio(int dtype, int64_t n, const void *u, const void *x, double *scratch, double *out, hipStream_t s);
 int vec_xpby(int dtype, int64_t n, double beta, const void *z, void *p, hipStream_t s);
 int vec_axpy_ratio(int dtype, int64_t n, const double *num, const double *den, double sign, const void *x, void *y, hipStream_t s);

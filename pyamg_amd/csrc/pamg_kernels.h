@@ -53,9 +53,9 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 template <int EPI> struct EpiTraits {
-    static constexpr bool need_cols = (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B);   // row phase compares column ids
+    static constexpr bool need_cols = (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B || EPI == EPI_JACOBI_IDX);   // row phase compares column ids
     static constexpr bool diag_flag = (EPI == EPI_GS || EPI == EPI_GS_B || EPI == EPI_SOR);   // schedule copies flag a_ii
-    static constexpr bool perm = (EPI == EPI_GS || EPI == EPI_GS_B || EPI == EPI_SOR);
+    static constexpr bool perm = (EPI == EPI_GS || EPI == EPI_GS_B || EPI == EPI_SOR || EPI == EPI_JACOBI_IDX);   // stored row r is row rid[r]
     static constexpr bool bsr_order = (EPI == EPI_JACOBI_B || EPI == EPI_GS_B);
 };
 
@@ -234,7 +234,7 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
 // of the Gauss-Seidel family, where one level is a handful of workgroups).
 template <typename T>
 struct RowPre {
-    int lo, hi, row;
+    int lo, hi, row, pos;
     T b, y, xo, d;
 };
 
@@ -245,13 +245,14 @@ __device__ __forceinline__ RowPre<T> row_prefetch(const StreamArgs<T> &a, int r)
     q.lo = a.Ap[r];
     q.hi = a.Ap[r + 1];
     q.row = EpiTraits<EPI>::perm ? a.rid[r] : r;
+    q.pos = r;
     q.b = q.y = q.xo = q.d = T(0);
     if constexpr (EPI >= EPI_JACOBI) q.d = a.diag[r];           // precomputed diagonal of stored row r
     if constexpr (EPI == EPI_RESID || EPI == EPI_AXPBY || EPI == EPI_ACC_AXPBY || EPI == EPI_SUMSQ ||
                   EPI >= EPI_JACOBI)
         q.b = a.b[q.row];
     if constexpr (EPI == EPI_ACC || EPI == EPI_ACC_AXPBY || EPI == EPI_ACCSEQ) q.y = a.y[q.row];
-    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B || EPI == EPI_SOR) q.xo = ldx<COH>(a.x + q.row);
+    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B || EPI == EPI_SOR || EPI == EPI_JACOBI_IDX) q.xo = ldx<COH>(a.x + q.row);
     return q;
 }
 
@@ -368,6 +369,9 @@ __device__ __forceinline__ void row_finish(const StreamArgs<T> &a, const RowPre<
         sq += (double)t * (double)t;
     } else if constexpr (EPI == EPI_JACOBI) {
         a.y[row] = (q.d != T(0)) ? (one - a.omega) * q.xo + a.omega * ((q.b - s) / q.d) : q.xo;
+    } else if constexpr (EPI == EPI_JACOBI_IDX) {
+        // out-of-place (every listed row reads the OLD x, relaxation.h:393-399): y is indexed by position
+        a.y[q.pos] = (q.d != T(0)) ? (one - a.omega) * q.xo + a.omega * ((q.b - s) / q.d) : q.xo;
     } else if constexpr (EPI == EPI_JACOBI_B) {
         a.y[row] = (q.d != T(0)) ? (one - a.omega) * q.xo + a.omega * s / q.d : q.xo;
     } else if constexpr (EPI == EPI_GS || EPI == EPI_GS_B || EPI == EPI_SOR) {
@@ -791,6 +795,7 @@ __device__ __forceinline__ void range_prefetch_static(const StreamArgs<T> &a, co
         R.q.lo = a.Ap[r];
         R.q.hi = a.Ap[r + 1];
         R.q.row = a.rid[r];
+        R.q.pos = r;
         R.q.d = a.diag[r];
     }
 }
@@ -963,6 +968,12 @@ __global__ __launch_bounds__(BLK) void vec_gather_kernel(int64_t n, const int *i
 {
     for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK)
         dst[i] = src[idx[i]];
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_scatter_kernel(int64_t n, const int *idx, const T *src, T *dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) dst[idx[i]] = src[i];
 }
 
 template <typename T>

@@ -51,7 +51,7 @@ void plan_rows(const int *Ap, int begin, int end, int cap, int max_rows, std::ve
 
 int lds_bytes(int dtype, int epi, int cap)
 {
-    const int per = (int)tsize(dtype) + ((epi == EPI_JACOBI || epi == EPI_JACOBI_B) ? 4 : 0);   // column ids only for the Jacobi row phase
+    const int per = (int)tsize(dtype) + ((epi == EPI_JACOBI || epi == EPI_JACOBI_B || epi == EPI_JACOBI_IDX) ? 4 : 0);   // column ids only for the Jacobi row phase
     return per * (cap + 8) + 64;      // + slack: the row phase reads whole batches of 8 slots
 }
 
@@ -111,6 +111,7 @@ int launch_any(int epi, int npl, int grid, int lds, hipStream_t s, const StreamA
         case EPI_GS: return launch_epi<T, EPI_GS>(npl, grid, lds, s, a);
         case EPI_GS_B: return launch_epi<T, EPI_GS_B>(npl, grid, lds, s, a);
         case EPI_SOR: return launch_epi<T, EPI_SOR>(npl, grid, lds, s, a);
+        case EPI_JACOBI_IDX: return launch_epi<T, EPI_JACOBI_IDX>(npl, grid, lds, s, a);
     }
     return PAMG_E_ARG;
 }
@@ -452,7 +453,7 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.Ap = A->d_Ap;
     a.Aj = A->d_Aj;
     a.Ax = (const T *)A->d_Ax;
-    a.rid = nullptr;
+    a.rid = A->d_rowid;
     a.diag = (const T *)A->d_diag;
     a.x = (const T *)x;
     a.xs = nullptr;
@@ -800,6 +801,73 @@ int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch,
     return (int)hipGetLastError();
 }
 
+int vec_scatter(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s)
+{
+    if (n <= 0) return PAMG_OK;
+    const int grid = (int)std::min<int64_t>(8192, (n + BLK - 1) / BLK);
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_scatter_kernel<double>), dim3(grid), dim3(BLK), 0, s, n, idx, (const double *)src, (double *)dst);
+    else
+        hipLaunchKernelGGL((vec_scatter_kernel<float>), dim3(grid), dim3(BLK), 0, s, n, idx, (const float *)src, (float *)dst);
+    return (int)hipGetLastError();
+}
+
+// Row-subset copy of a scalar CSR operator for the indexed smoothers (CF/FC Jacobi): the listed rows,
+// in list order, stored contiguously so they stream like any other operator; d_rowid maps a stored row
+// back to its row in the parent, the diagonal is the parent's (last stored a_ii of that row).
+int matrix_row_subset(pamg_matrix_s *A, const int32_t *rows, int nrows, pamg_matrix_s **out)
+{
+    if (!A || !out || nrows < 0 || (nrows > 0 && !rows)) return PAMG_E_ARG;
+    if (A->flavour != PAMG_CSR || A->R != 1 || A->C != 1 || A->nrows != A->ncols) return PAMG_E_UNSUPPORTED;
+    const int n = (int)A->nrows;
+    for (int r = 0; r < nrows; ++r) if (rows[r] < 0 || rows[r] >= n) return PAMG_E_ARG;
+    const size_t ts = tsize(A->dtype);
+    std::vector<unsigned char> hAx((size_t)A->nnz * ts);
+    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    pamg_matrix_s *B = new (std::nothrow) pamg_matrix_s();
+    if (!B) return PAMG_E_ALLOC;
+    B->dtype = A->dtype; B->flavour = PAMG_CSR;
+    B->n_brow = nrows; B->n_bcol = (int)A->ncols; B->R = 1; B->C = 1;
+    B->nrows = nrows; B->ncols = A->ncols;
+    B->h_Ap.assign((size_t)nrows + 1, 0);
+    for (int r = 0; r < nrows; ++r) B->h_Ap[r + 1] = B->h_Ap[r] + (A->h_Ap[rows[r] + 1] - A->h_Ap[rows[r]]);
+    B->nnz = B->h_Ap[nrows];
+    B->h_Aj.assign((size_t)B->nnz + 8, 0);
+    std::vector<unsigned char> bAx(((size_t)B->nnz + 8) * ts, 0), bdiag(((size_t)nrows + 8) * ts, 0);
+    for (int r = 0; r < nrows; ++r) {
+        const int i = rows[r], lo = A->h_Ap[i], len = A->h_Ap[i + 1] - lo, at = B->h_Ap[r];
+        if (len) {
+            std::memcpy(&B->h_Aj[at], &A->h_Aj[lo], (size_t)len * sizeof(int));
+            std::memcpy(&bAx[(size_t)at * ts], &hAx[(size_t)lo * ts], (size_t)len * ts);
+        }
+        for (int p = lo; p < lo + len; ++p)
+            if (A->h_Aj[p] == i) std::memcpy(&bdiag[(size_t)r * ts], &hAx[(size_t)p * ts], ts);     // last one wins
+    }
+    int st = upload(&B->d_Ap, B->h_Ap.data(), B->h_Ap.size(), &B->bytes);
+    if (!st) st = upload(&B->d_Aj, B->h_Aj.data(), B->h_Aj.size(), &B->bytes);
+    if (!st) st = upload_raw(&B->d_Ax, bAx.data(), (size_t)B->nnz + 8, ts, &B->bytes);
+    if (!st) st = upload_raw(&B->d_diag, bdiag.data(), (size_t)nrows + 8, ts, &B->bytes);
+    std::vector<int> rid(rows, rows + nrows);
+    rid.resize((size_t)nrows + 8, 0);
+    if (!st) st = upload(&B->d_rowid, rid.data(), rid.size(), &B->bytes);
+    B->h_Aj.resize((size_t)B->nnz);
+    B->cap = 1536; B->npl = 2; B->max_rows = 1024;
+    if (!st) st = replan(B);
+    if (st) { pamg_matrix_destroy(B); return st; }
+    *out = B;
+    return PAMG_OK;
+}
+
+// amg_core::jacobi_indexed (relaxation.h:382-427) on a row-subset operator: new values of the listed
+// rows from the OLD x into work (one value per listed row), then scattered into x
+int jacobi_indexed(pamg_matrix_s *sub, void *x, const void *b, double omega, void *work, hipStream_t s)
+{
+    if (!sub || !sub->d_rowid || !x || !b || !work) return PAMG_E_ARG;
+    if (sub->nrows == 0) return PAMG_OK;
+    PAMG_TRY(stream_launch(sub, EPI_JACOBI_IDX, x, b, work, 0.0, omega, nullptr, s));
+    return vec_scatter(sub->dtype, sub->nrows, sub->d_rowid, work, x, s);
+}
+
 int vec_maxratio(int dtype, int64_t n, const void *u, const void *x, double *scratch, double *out, hipStream_t s)
 {
     const int grid = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n + BLK - 1) / BLK));
@@ -988,7 +1056,7 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
 int pamg_matrix_destroy(pamg_matrix_t A)
 {
     if (!A) return PAMG_OK;
-    hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag);
+    hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag); hipFree(A->d_rowid);
     hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     delete A;
@@ -1081,6 +1149,16 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
     for (int l = 0; l < g->nlevels; ++l)
         for (int q = g->level_blk[l]; q < g->level_blk[l + 1]; ++q) out[(size_t)q * 8 + 7] = l;
     return PAMG_OK;
+}
+
+int pamg_matrix_subset_rows(pamg_matrix_t A, const int32_t *rows, int nrows, pamg_matrix_t *sub)
+{
+    return pamg::matrix_row_subset(A, rows, nrows, sub);
+}
+
+int pamg_matrix_jacobi_indexed(pamg_matrix_t sub, void *x, const void *b, double omega, void *work, pamg_stream_t s)
+{
+    return pamg::jacobi_indexed(sub, x, b, omega, work, (hipStream_t)s);
 }
 
 int pamg_matrix_flow_error(pamg_matrix_t A, int *error)

@@ -24,6 +24,10 @@ struct Smoother {
     std::vector<double> coeffs;
     void *d_Dinv = nullptr;
     int blocksize = 1;
+    // CF / FC Jacobi: row-subset copies of the level operator and one work value per listed row
+    pamg_matrix_s *AF = nullptr, *AC = nullptr;
+    void *wF = nullptr, *wC = nullptr;
+    int f_iterations = 1, c_iterations = 1;
 };
 
 struct Level {
@@ -185,6 +189,19 @@ int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, 
             return block_jacobi_pp(L.A, &L.x, &L.xalt, L.b, sm.d_Dinv, sm.omega, sm.iterations, s);
         case PAMG_SMOOTH_BLOCK_GS:
             return block_gs_apply(L.A, L.x, L.b, sm.d_Dinv, sm.sweep, sm.iterations, s);
+        case PAMG_SMOOTH_CF_JACOBI:
+        case PAMG_SMOOTH_FC_JACOBI:
+            for (int it = 0; it < sm.iterations; ++it) {
+                const bool f_first = sm.kind == PAMG_SMOOTH_FC_JACOBI;
+                for (int half = 0; half < 2; ++half) {
+                    const bool f = (half == 0) == f_first;
+                    pamg_matrix_s *sub = f ? sm.AF : sm.AC;
+                    void *w = f ? sm.wF : sm.wC;
+                    const int reps = f ? sm.f_iterations : sm.c_iterations;
+                    for (int k = 0; k < reps; ++k) PAMG_TRY(jacobi_indexed(sub, L.x, L.b, sm.omega, w, s));
+                }
+            }
+            return PAMG_OK;
     }
     (void)S;
     return PAMG_E_ARG;
@@ -427,6 +444,11 @@ int pamg_solver_destroy(pamg_solver_t S)
         hipFree(L.x); hipFree(L.xalt);
         hipFree(L.b); hipFree(L.r); hipFree(L.work); hipFree(L.amli);
         hipFree(L.pre.d_Dinv); hipFree(L.post.d_Dinv);
+        for (Smoother *sm : {&L.pre, &L.post}) {
+            if (sm->AF) pamg_matrix_destroy(sm->AF);
+            if (sm->AC) pamg_matrix_destroy(sm->AC);
+            hipFree(sm->wF); hipFree(sm->wC);
+        }
     }
     hipFree(S->d_coarse); hipFree(S->d_norms); hipFree(S->d_slot); hipFree(S->d_scratch);
     hipFree(S->cg_r); hipFree(S->cg_z); hipFree(S->cg_p); hipFree(S->cg_q);
@@ -465,6 +487,9 @@ int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, in
     Level &L = S->levels[level];
     Smoother &sm = which == 0 ? L.pre : L.post;
     if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
+    if (sm.AF) pamg_matrix_destroy(sm.AF);
+    if (sm.AC) pamg_matrix_destroy(sm.AC);
+    hipFree(sm.wF); hipFree(sm.wC);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep; sm.blocksize = blocksize;
     if (kind == PAMG_SMOOTH_POLY) {
@@ -480,6 +505,31 @@ int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, in
     }
     if ((kind == PAMG_SMOOTH_JACOBI || kind == PAMG_SMOOTH_GS || kind == PAMG_SMOOTH_SOR) && L.A->R != L.A->C)
         return PAMG_E_ARG;                                     // "BSR blocks must be square"
+    return PAMG_OK;
+}
+
+int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind, int iterations, int f_iterations,
+                                int c_iterations, double omega, const int32_t *Fpts, int nF, const int32_t *Cpts, int nC)
+{
+    if (!S || level < 0 || level >= (int)S->levels.size() || (which != 0 && which != 1)) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    if (kind != PAMG_SMOOTH_CF_JACOBI && kind != PAMG_SMOOTH_FC_JACOBI) return PAMG_E_ARG;
+    if (iterations < 0 || f_iterations < 0 || c_iterations < 0 || nF < 0 || nC < 0) return PAMG_E_ARG;
+    Level &L = S->levels[level];
+    Smoother &sm = which == 0 ? L.pre : L.post;
+    if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
+    if (sm.AF) pamg_matrix_destroy(sm.AF);
+    if (sm.AC) pamg_matrix_destroy(sm.AC);
+    hipFree(sm.wF); hipFree(sm.wC);
+    sm = Smoother();
+    sm.kind = kind; sm.iterations = iterations; sm.omega = omega;
+    sm.f_iterations = f_iterations; sm.c_iterations = c_iterations;
+    PAMG_TRY(matrix_row_subset(L.A, Fpts, nF, &sm.AF));
+    PAMG_TRY(matrix_row_subset(L.A, Cpts, nC, &sm.AC));
+    const size_t ts = tsize(S->dtype);
+    PAMG_HIP(hipMalloc(&sm.wF, std::max<size_t>((size_t)nF * ts, 256)));
+    PAMG_HIP(hipMalloc(&sm.wC, std::max<size_t>((size_t)nC * ts, 256)));
+    S->bytes += sm.AF->bytes + sm.AC->bytes + (size_t)(nF + nC) * ts;
     return PAMG_OK;
 }
 

@@ -70,7 +70,7 @@ class SmootherSpec:
     """One pre/post smoother of one level, as the reference would apply it.
 
     kind: 'jacobi' | 'gauss_seidel' | 'sor' | 'polynomial' | 'block_jacobi' |
-          'block_gauss_seidel' | 'none'
+          'block_gauss_seidel' | 'cf_jacobi' | 'fc_jacobi' | 'none'
     """
     kind: str
     iterations: int = 1
@@ -80,6 +80,10 @@ class SmootherSpec:
     Dinv: Optional[np.ndarray] = None           # (n_brow, bs, bs)
     blocksize: int = 1
     name: str = ""                              # reference-side display name
+    Fpts: Optional[np.ndarray] = None           # cf_jacobi / fc_jacobi: int32 row lists
+    Cpts: Optional[np.ndarray] = None
+    f_iterations: int = 1
+    c_iterations: int = 1
 
 
 @dataclass
@@ -176,8 +180,17 @@ def smoother_spec(fn, A) -> SmootherSpec:
                                     Dinv=Dinv, blocksize=int(bs), name=shown)
             return SmootherSpec("block_gauss_seidel", it, 1.0, kw.get("sweep", "forward"),
                                 Dinv=Dinv, blocksize=int(bs), name=shown)
+        if base in ("cf_jacobi", "fc_jacobi"):
+            if getattr(A, "format", "csr") != "csr":
+                raise NotImplementedError(f"{base} on a {A.format} level is not on the device path (CSR only)")
+            return SmootherSpec(base, it, float(np.real(kw.get("omega", 1.0))), name=shown,
+                                Fpts=np.ascontiguousarray(kw["Fpts"], dtype=np.int32),
+                                Cpts=np.ascontiguousarray(kw["Cpts"], dtype=np.int32),
+                                f_iterations=int(kw.get("f_iterations", 1)), c_iterations=int(kw.get("c_iterations", 1)))
         raise NotImplementedError(f"smoother '{base}' is not on the device path")
     cv = _closure_vars(fn)
+    if shown == "none" and not cv:                                  # smoothing.py setup_none: def none(A, x, b): pass
+        return SmootherSpec("none", iterations=0, name="None")
     if shown == "chebyshev" and "coefficients" in cv:
         return SmootherSpec("polynomial", int(cv["iterations"]),
                             coefficients=np.asarray(cv["coefficients"], dtype=np.float64).copy(),
@@ -276,15 +289,23 @@ def _put_sm(d, key, s: Optional[SmootherSpec]):
         d[f"{key}.coefficients"] = np.asarray(s.coefficients, dtype=np.float64)
     if s.Dinv is not None:
         d[f"{key}.Dinv"] = s.Dinv
+    if s.Fpts is not None:
+        d[f"{key}.Fpts"] = np.asarray(s.Fpts, dtype=np.int32)
+        d[f"{key}.Cpts"] = np.asarray(s.Cpts, dtype=np.int32)
+        d[f"{key}.fc_iters"] = np.array([s.f_iterations, s.c_iterations], dtype=np.int64)
 
 
 def _get_sm(z, key) -> Optional[SmootherSpec]:
     if f"{key}.kind" not in z:
         return None
     num = z[f"{key}.num"]
-    return SmootherSpec(str(z[f"{key}.kind"]), int(num[0]), float(z[f"{key}.omega"]), str(z[f"{key}.sweep"]),
-                        z[f"{key}.coefficients"] if f"{key}.coefficients" in z else None,
-                        z[f"{key}.Dinv"] if f"{key}.Dinv" in z else None, int(num[1]), str(z[f"{key}.name"]))
+    sm = SmootherSpec(str(z[f"{key}.kind"]), int(num[0]), float(z[f"{key}.omega"]), str(z[f"{key}.sweep"]),
+                      z[f"{key}.coefficients"] if f"{key}.coefficients" in z else None,
+                      z[f"{key}.Dinv"] if f"{key}.Dinv" in z else None, int(num[1]), str(z[f"{key}.name"]))
+    if f"{key}.Fpts" in z:
+        sm.Fpts, sm.Cpts = z[f"{key}.Fpts"], z[f"{key}.Cpts"]
+        sm.f_iterations, sm.c_iterations = (int(v) for v in z[f"{key}.fc_iters"])
+    return sm
 
 
 def save_spec(path, spec: HierarchySpec, **extra):

@@ -57,6 +57,22 @@ class DeviceMatrix:
     def autotune(self, allow_cap=True):
         capi.check(capi.lib().pamg_matrix_autotune(self.handle, int(bool(allow_cap))), "pamg_matrix_autotune")
 
+    def subset_rows(self, rows) -> "DeviceMatrix":
+        """row-subset copy (rows: int32 host list, kept in order) for the indexed smoothers"""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        sub = DeviceMatrix.__new__(DeviceMatrix)
+        h = C.c_void_p()
+        capi.check(capi.lib().pamg_matrix_subset_rows(self.handle, capi.ptr(rows), rows.size, C.byref(h)),
+                   "pamg_matrix_subset_rows")
+        sub.__dict__.update(self.__dict__)
+        sub.handle = h
+        return sub
+
+    def jacobi_indexed(self, x, b, omega, work, stream=None):
+        """amg_core.jacobi_indexed on a row-subset operator (self): relaxes the listed rows of x from the old x"""
+        capi.check(capi.lib().pamg_matrix_jacobi_indexed(self.handle, x.ptr, b.ptr, float(omega), work.ptr, stream),
+                   "pamg_matrix_jacobi_indexed")
+
     def flow_error(self) -> bool:
         e = C.c_int(0)
         capi.check(capi.lib().pamg_matrix_flow_error(self.handle, C.byref(e)), "pamg_matrix_flow_error")
@@ -129,6 +145,14 @@ class DeviceMatrix:
 def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype):
     if s is None or s.kind == "none":
         capi.check(lib.pamg_solver_set_smoother(S, level, which, 0, 0, 1.0, 0, None, 0, None, 1), "set_smoother")
+        return
+    if s.kind in ("cf_jacobi", "fc_jacobi"):
+        F = np.ascontiguousarray(s.Fpts, dtype=np.int32)
+        Cp = np.ascontiguousarray(s.Cpts, dtype=np.int32)
+        capi.check(lib.pamg_solver_set_cf_smoother(S, level, which, capi.SMOOTH[s.kind], int(s.iterations),
+                                                   int(s.f_iterations), int(s.c_iterations), float(s.omega),
+                                                   capi.ptr(F), F.size, capi.ptr(Cp), Cp.size),
+                   f"pamg_solver_set_cf_smoother({s.kind})")
         return
     coeffs = None
     ncoef = 0

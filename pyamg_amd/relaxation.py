@@ -120,6 +120,50 @@ def jacobi(A, x, b, iterations=1, omega=1.0):
     st.finish()
 
 
+def _indexed_sweeps(A, x, b, plan, iterations, omega):
+    """Shared body of jacobi_indexed / cf_jacobi / fc_jacobi: ``plan`` = [(row list, sweeps), ...] run
+    ``iterations`` times, each sweep one amg_core.jacobi_indexed (relaxation.h:382-427), device-resident."""
+    if sparse.issparse(A) and A.format == "bsr":
+        raise NotImplementedError("indexed Jacobi on BSR operators is not on the device path (CSR only)")
+    st = _Staged(A, x, b)
+    subs = []
+    for rows, _ in plan:
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        sub = st.A.subset_rows(rows)
+        subs.append((sub, capi.DeviceArray(max(rows.size, 1), st.A.dtype)))
+    for _ in range(iterations):
+        for (sub, work), (_, sweeps) in zip(subs, plan):
+            for _ in range(sweeps):
+                sub.jacobi_indexed(st.x, st.b, float(np.real(omega)), work)
+    st.finish()
+    for sub, work in subs:
+        sub.free()
+        work.free()
+
+
+def jacobi_indexed(A, x, b, indices, iterations=1, omega=1.0):
+    """Weighted Jacobi on the listed rows only, in place (reference: relaxation.py:1077-1138)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    indices = np.asarray(indices, dtype=np.int32)
+    if (indices.min(initial=0) < 0) or (indices.max(initial=-1) > A.shape[0] - 1):
+        raise ValueError("indices must range from 0, ..., N-1")       # relaxation.py:1108-1109
+    _indexed_sweeps(A, x, b, [(indices, 1)], iterations, omega)
+
+
+def cf_jacobi(A, x, b, Cpts, Fpts, iterations=1, f_iterations=1, c_iterations=1, omega=1.0):
+    """CF Jacobi, in place: per iteration c_iterations sweeps over Cpts, then f_iterations over Fpts
+    (reference: relaxation.py:1141-1203)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    _indexed_sweeps(A, x, b, [(Cpts, c_iterations), (Fpts, f_iterations)], iterations, omega)
+
+
+def fc_jacobi(A, x, b, Cpts, Fpts, iterations=1, f_iterations=1, c_iterations=1, omega=1.0):
+    """FC Jacobi, in place: per iteration f_iterations sweeps over Fpts, then c_iterations over Cpts
+    (reference: relaxation.py:1206-1268)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    _indexed_sweeps(A, x, b, [(Fpts, f_iterations), (Cpts, c_iterations)], iterations, omega)
+
+
 def polynomial(A, x, b, coefficients, iterations=1):
     """x += p(A) (b - A x) with Horner evaluation, in place (reference: relaxation.py:585-659)."""
     A, x, b = make_system(A, x, b, formats=None)

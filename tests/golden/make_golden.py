@@ -36,7 +36,7 @@ ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]    
 
 
 ACCEL_ONLY = "--accel-only" in sys.argv      # only (re)generate accel_fgmres.npz
-ACCEL_CASES = ("sa2d_gs", "sa2d_jacobi_AMLI", "rs2d_nonsym_gs", "el2d_blockgs", "sa3d_gs")
+ACCEL_CASES = ("sa2d_gs", "sa2d_jacobi_AMLI", "rs2d_nonsym_gs", "el2d_blockgs", "sa3d_gs", "air2d_fcjacobi")
 ACCEL = {}
 
 
@@ -167,6 +167,12 @@ def make_hierarchies():
     An.sort_indices()
     np.random.seed(SEED)
     hier("rs2d_nonsym_gs", pyamg.ruge_stuben_solver(An, max_coarse=10))
+    # AIR (approximate ideal restriction, classical/air.py) on an advection-dominated operator: no
+    # presmoother, FC Jacobi (2 F-sweeps, 1 C-sweep of amg_core.jacobi_indexed) as postsmoother, R != P^T
+    Aa = sp.csr_array(3.0 * sp.kron(sp.eye_array(m), Dx) + 0.3 * sp.kron(Dy, sp.eye_array(m)))
+    Aa.sort_indices()
+    np.random.seed(SEED)
+    hier("air2d_fcjacobi", pyamg.air_solver(Aa, max_coarse=20))
     # hand-built two-level hierarchy with a CSC restriction (multilevel.py:180-182)
     np.random.seed(SEED)
     ml0 = pyamg.ruge_stuben_solver(A, max_coarse=500, max_levels=2)
@@ -312,11 +318,49 @@ def make_known_answers():
     print("known_answers.json written; sor doctest norm =", ka["doctest_sor_norm"]["expect_norm_3dec"])
 
 
+def make_kernels_indexed():
+    """amg_core.jacobi_indexed and relaxation.cf_jacobi / fc_jacobi of the reference -> kernels_indexed.npz"""
+    import scipy.sparse as sp
+    from pyamg import amg_core
+    rng = np.random.RandomState(SEED + 11)
+    out = {}
+    G = sp.random(400, 400, density=0.03, random_state=rng, format="lil")
+    G.setdiag(rng.rand(400) + 1.0)
+    G[7, :] = 0                       # empty row
+    G[11, 11] = 0.0                   # missing diagonal
+    G = sp.csr_array(G.tocsr())
+    G.sort_indices()
+    P = pyamg.gallery.poisson((21, 19), format="csr")
+    for tag, M in (("irr", G), ("pois", P)):
+        for dt in (np.float64, np.float32):
+            Md = sp.csr_array(M.astype(dt))
+            n = Md.shape[0]
+            x = rng.rand(n).astype(dt); b = rng.rand(n).astype(dt)
+            idx = rng.permutation(n)[: n // 3].astype(np.int32)
+            F = np.sort(rng.permutation(n)[: (2 * n) // 3]).astype(np.int32)
+            Cp = np.setdiff1d(np.arange(n, dtype=np.int32), F).astype(np.int32)
+            k = f"{tag}_{np.dtype(dt).name}"
+            out[f"{k}.indptr"], out[f"{k}.indices"], out[f"{k}.data"] = Md.indptr, Md.indices, Md.data
+            out[f"{k}.x"], out[f"{k}.b"], out[f"{k}.idx"], out[f"{k}.F"], out[f"{k}.C"] = x, b, idx, F, Cp
+            y = x.copy(); amg_core.jacobi_indexed(Md.indptr, Md.indices, Md.data, y, b, idx, np.array([0.7], dtype=dt))
+            out[f"{k}.jacobi_indexed"] = y
+            y = x.copy(); rr.fc_jacobi(Md, y, b, Cp, F, iterations=2, f_iterations=2, c_iterations=1, omega=0.9)
+            out[f"{k}.fc_jacobi"] = y
+            y = x.copy(); rr.cf_jacobi(Md, y, b, Cp, F, iterations=1, f_iterations=1, c_iterations=2, omega=1.0)
+            out[f"{k}.cf_jacobi"] = y
+    np.savez_compressed(HERE / "kernels_indexed.npz", **out)
+    print("kernels_indexed.npz written:", len(out), "arrays")
+
+
 def save_accel():
     if ACCEL:
         np.savez_compressed(HERE / "accel_fgmres.npz", **ACCEL)
         print("accel_fgmres.npz written:", len(ACCEL), "arrays")
 
+
+if __name__ == "__main__" and "--indexed-only" in sys.argv:
+    make_kernels_indexed()
+    sys.exit(0)
 
 if __name__ == "__main__" and (ONLY or ACCEL_ONLY):
     make_hierarchies()
@@ -327,5 +371,6 @@ if __name__ == "__main__":
     if "--hier-only" not in sys.argv:
         make_known_answers()
         make_kernels()
+        make_kernels_indexed()
     make_hierarchies()
     save_accel()

@@ -450,3 +450,30 @@ def test_block_sweep_modes_all_exact():
             assert np.array_equal(dx.download(), ref_blk), (kw, bs)
             assert not dM.flow_error(), (kw, bs)
         dM.tune(lds_entries=1536)
+
+
+def test_indexed_jacobi_bit_exact():
+    """jacobi_indexed (Layer 1, the amg_core twin) and the cf_jacobi / fc_jacobi wrappers (resident row-subset
+    operators, csr_stream_kernel<JACOBI_IDX> + scatter) vs the reference's outputs in kernels_indexed.npz --
+    bit for bit, f64 and f32, incl. an empty row and a missing diagonal; plus the wrappers' error contract."""
+    from conftest import GOLDEN
+    import pyamg_amd.amg_core as gcore
+    z = np.load(GOLDEN / "kernels_indexed.npz")
+    keys = sorted({k.split(".")[0] for k in z.files})
+    for k in keys:
+        Ap, Aj, Ax = z[f"{k}.indptr"].astype(np.int32), z[f"{k}.indices"].astype(np.int32), z[f"{k}.data"]
+        n = Ap.size - 1
+        M = sp.csr_array((Ax, Aj, Ap), shape=(n, n))
+        x, b, idx, F, Cp = (z[f"{k}.{t}"] for t in ("x", "b", "idx", "F", "C"))
+        y = x.copy(); gcore.jacobi_indexed(Ap, Aj, Ax, y, b, idx, np.array([0.7], dtype=Ax.dtype))
+        assert np.array_equal(y, z[f"{k}.jacobi_indexed"]), k
+        y = x.copy(); grelax.jacobi_indexed(M, y, b, idx, iterations=1, omega=0.7)
+        assert np.array_equal(y, z[f"{k}.jacobi_indexed"]), k
+        y = x.copy(); grelax.fc_jacobi(M, y, b, Cp, F, iterations=2, f_iterations=2, c_iterations=1, omega=0.9)
+        assert np.array_equal(y, z[f"{k}.fc_jacobi"]), k
+        y = x.copy(); grelax.cf_jacobi(M, y, b, Cp, F, iterations=1, f_iterations=1, c_iterations=2, omega=1.0)
+        assert np.array_equal(y, z[f"{k}.cf_jacobi"]), k
+    with pytest.raises(ValueError):
+        grelax.jacobi_indexed(M, x.copy(), b, np.array([0, n], dtype=np.int32))          # relaxation.py:1108-1109
+    with pytest.raises(TypeError):
+        gcore.jacobi_indexed(Ap, Aj, Ax, x.copy(), b, idx.astype(np.int64), np.array([0.7], dtype=Ax.dtype))
