@@ -220,6 +220,14 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
  * and amg_core::jacobi_indexed (relaxation.h:382-427) on it: every listed row of x is relaxed from the
  * OLD x (x, b: DEVICE vectors of the parent's size; work: DEVICE, one value per listed row). */
 int pamg_matrix_subset_rows(pamg_matrix_t A, const int32_t *rows, int nrows, pamg_matrix_t *sub);
+/* Kaczmarz-type sweeps over the rows of L, order-exact (dependency levels over shared column indices):
+ * nr = 0: amg_core::gauss_seidel_ne (relaxation.h:875-904) with L = A, v = x, b, Dinv = 1/||row||^2;
+ * nr = 1: amg_core::gauss_seidel_nr (relaxation.h:939-975) with L = CSR of A^T (the CSC arrays of A), v = the
+ * running residual z, Dinv = 1/||column||^2, xout = x (b unused).  sweep: PAMG_FORWARD / BACKWARD /
+ * SYMMETRIC (forward then backward per iteration, on the SAME v -- the reference's gauss_seidel_nr wrapper
+ * refreshes z = b - A x before every directional call: callers that mirror it run directional sweeps). */
+int pamg_matrix_kaczmarz(pamg_matrix_t L, int nr, void *v, const void *b, const void *Dinv, double omega,
+                         int sweep, int iterations, void *xout, pamg_stream_t s);
 int pamg_matrix_jacobi_indexed(pamg_matrix_t sub, void *x, const void *b, double omega, void *work,
                                pamg_stream_t s);
 /* *error != 0: a persistent sweep of this operator hit its spin bound (synchronises) */
@@ -270,6 +278,8 @@ int pamg_vec_sumsq(int dtype, int64_t n, const void *x, double *out_sumsq, pamg_
 int pamg_vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, pamg_stream_t s);
 int pamg_vec_scale(int dtype, int64_t n, double a, const void *x, void *y, pamg_stream_t s);
 /* dst[k] = src[idx[k]], k < n  (halo packing; idx is a DEVICE int32 array) */
+/* y = a .* b (element-wise) */
+int pamg_vec_mul(int dtype, int64_t n, const void *a, const void *b, void *y, pamg_stream_t s);
 int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, void *dst,
                     pamg_stream_t s);
 
@@ -283,6 +293,9 @@ int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, v
 #define PAMG_SMOOTH_BLOCK_GS    6
 #define PAMG_SMOOTH_CF_JACOBI   7   /* relaxation.cf_jacobi  relaxation.py:1141-1203: C sweeps, then F sweeps */
 #define PAMG_SMOOTH_FC_JACOBI   8   /* relaxation.fc_jacobi  relaxation.py:1206-1268: F sweeps, then C sweeps */
+#define PAMG_SMOOTH_GS_NE       9   /* relaxation.gauss_seidel_ne (Kaczmarz)  relaxation.py:815-901  */
+#define PAMG_SMOOTH_GS_NR      10   /* relaxation.gauss_seidel_nr             relaxation.py:904-988  */
+#define PAMG_SMOOTH_JACOBI_NE  11   /* relaxation.jacobi_ne                   relaxation.py:741-812  */
 #define PAMG_CYCLE_V 0
 #define PAMG_CYCLE_W 1
 #define PAMG_CYCLE_F 2
@@ -303,6 +316,15 @@ int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, in
 int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind, int iterations,
                                 int f_iterations, int c_iterations, double omega, const int32_t *Fpts,
                                 int nF, const int32_t *Cpts, int nC);
+/* Normal-equation smoothers (f64/f32 CSR-like levels).  Dinv: HOST vector of the level's size -- 1/||row||^2
+ * (GS_NE, JACOBI_NE) or 1/||column||^2 (GS_NR), computed by the caller exactly as the reference's
+ * get_diagonal(A, norm_eq=..., inv=True) (util/utils.py:583-598).  At (borrowed handle, kept alive by the caller):
+ * GS_NE: NULL; GS_NR: the CSR form of A^T, i.e. the CSC arrays of A (sorted); JACOBI_NE: the same with every
+ * value pre-multiplied by omega (the reference multiplies omega * a_ij first, relaxation.h:835).  Ar (GS_NR,
+ * borrowed, may be NULL): the level operator with SORTED rows for the residual r = b - A x -- the reference forms it
+ * with the CSC matrix, i.e. per row in ascending column order; NULL = the level's own A already is sorted. */
+int pamg_solver_set_ne_smoother(pamg_solver_t S, int level, int which, int kind, int iterations, double omega,
+                                int sweep, const void *Dinv, pamg_matrix_t At, pamg_matrix_t Ar);
 /* coarsest solve x_c = M b_c with HOST row-major M (n_c x n_c); M == NULL: x_c = 0
  * (multilevel.py:717-721, 801-803) */
 int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c);

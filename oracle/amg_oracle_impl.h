@@ -131,6 +131,44 @@ void FN(jacobi_indexed)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, i
     }
 }
 
+/* Kaczmarz (Gauss-Seidel on A A^H y = b, x = A^H y).  Follows amg_core gauss_seidel_ne,
+ * relaxation.h:875-904: row by row, delta = (b_i - <a_i, x>) * Dinv_i * omega, x += a_i^H delta. */
+void FN(gauss_seidel_ne)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REAL *b,
+                         int row_start, int row_stop, int row_step, const REAL *Dinv, REAL omega)
+{
+    for (int i = row_start; i != row_stop; i += row_step) {
+        REAL delta = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) delta += Ax[p] * x[Aj[p]];
+        delta = (b[i] - delta) * Dinv[i] * omega;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) x[Aj[p]] += Ax[p] * delta;
+    }
+}
+
+/* Gauss-Seidel on A^H A x = A^H b.  Follows amg_core gauss_seidel_nr, relaxation.h:939-975: the
+ * arrays are the CSC form of A (column by column); z is the running residual b - A x. */
+void FN(gauss_seidel_nr)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, REAL *z,
+                         int col_start, int col_stop, int col_step, const REAL *Dinv, REAL omega)
+{
+    for (int i = col_start; i != col_stop; i += col_step) {
+        REAL delta = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) delta += Ax[p] * z[Aj[p]];
+        delta *= (Dinv[i] * omega);
+        x[i] += delta;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) z[Aj[p]] -= delta * Ax[p];
+    }
+}
+
+/* Jacobi on the normal equations.  Follows amg_core jacobi_ne, relaxation.h:811-840: delta is the
+ * row-scaled residual handed in by the wrapper; temp accumulates omega * a_ij * delta_i row after row. */
+void FN(jacobi_ne)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REAL *delta, REAL *temp,
+                   int row_start, int row_stop, int row_step, REAL omega)
+{
+    for (int i = row_start; i < row_stop; i += row_step) temp[i] = 0;
+    for (int i = row_start; i < row_stop; i += row_step)
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) temp[Aj[p]] += omega * Ax[p] * delta[i];
+    for (int i = row_start; i < row_stop; i += row_step) x[i] += temp[i];
+}
+
 /* dense helper: out[0..bs) = M(bs x bs, row major) * v, each output a fresh running sum
  * starting at 0 (the reference's gemm(...,'F','F','T' overwrite), linalg.h:405-438). */
 static void FN(blk_apply)(const REAL *M, const REAL *v, REAL *out, int bs)

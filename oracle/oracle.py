@@ -106,6 +106,27 @@ def jacobi_indexed(Ap, Aj, Ax, x, b, indices, omega):
           _I(idx.size), _ptr(temp), ct(omega))
 
 
+def gauss_seidel_ne(Ap, Aj, Ax, x, b, row_start, row_stop, row_step, Dinv, omega):
+    """amg_core.gauss_seidel_ne (relaxation.h:875-904)."""
+    _, ct = _sfx(Ax.dtype)
+    _call("gauss_seidel_ne", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b), _I(row_start), _I(row_stop),
+          _I(row_step), _ptr(Dinv), ct(omega))
+
+
+def gauss_seidel_nr(Ap, Aj, Ax, x, z, col_start, col_stop, col_step, Dinv, omega):
+    """amg_core.gauss_seidel_nr (relaxation.h:939-975); Ap/Aj/Ax = CSC arrays of A."""
+    _, ct = _sfx(Ax.dtype)
+    _call("gauss_seidel_nr", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(z), _I(col_start), _I(col_stop),
+          _I(col_step), _ptr(Dinv), ct(omega))
+
+
+def jacobi_ne(Ap, Aj, Ax, x, delta, temp, row_start, row_stop, row_step, omega):
+    """amg_core.jacobi_ne (relaxation.h:811-840)."""
+    _, ct = _sfx(Ax.dtype)
+    _call("jacobi_ne", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(delta), _ptr(temp), _I(row_start),
+          _I(row_stop), _I(row_step), ct(omega))
+
+
 def bsr_jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, blocksize, omega):
     _, ct = _sfx(Ax.dtype)
     _call("bsr_jacobi", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b), _ptr(temp),
@@ -260,6 +281,42 @@ def relax_cf_jacobi(A, x, b, Cpts, Fpts, iterations=1, f_iterations=1, c_iterati
                 jacobi_indexed(A.indptr, A.indices, A.data, x, b, pts, om)
 
 
+def relax_gauss_seidel_ne(A, x, b, Dinv, iterations=1, sweep="forward", omega=1.0):
+    """relaxation.py:815-901 (Kaczmarz; A: CSR SparseOp, Dinv = 1 / squared row norms)."""
+    if sweep == "symmetric":
+        for _ in range(iterations):
+            relax_gauss_seidel_ne(A, x, b, Dinv, 1, "forward", omega)
+            relax_gauss_seidel_ne(A, x, b, Dinv, 1, "backward", omega)
+        return
+    r0, r1, rs = _sweep_bounds(sweep, len(x))
+    for _ in range(iterations):
+        gauss_seidel_ne(A.indptr, A.indices, A.data, x, b, r0, r1, rs, Dinv, omega)
+
+
+def relax_gauss_seidel_nr(A, At, x, b, Dinv, iterations=1, sweep="forward", omega=1.0, Ar=None):
+    """relaxation.py:904-988.  A: CSR SparseOp (for r = b - A x), At: CSR SparseOp of A^T = the CSC arrays
+    of A, Dinv = 1 / squared column norms.  The residual is formed once per directional call (:983)."""
+    if sweep == "symmetric":
+        for _ in range(iterations):
+            relax_gauss_seidel_nr(A, At, x, b, Dinv, 1, "forward", omega, Ar)
+            relax_gauss_seidel_nr(A, At, x, b, Dinv, 1, "backward", omega, Ar)
+        return
+    c0, c1, cs = _sweep_bounds(sweep, len(x))
+    r = b - matvec(A if Ar is None else Ar, x)           # Ar: A with sorted rows (= the CSC product's order)
+    for _ in range(iterations):
+        gauss_seidel_nr(At.indptr, At.indices, At.data, x, r, c0, c1, cs, Dinv, omega)
+
+
+def relax_jacobi_ne(A, x, b, Dinv, iterations=1, omega=1.0):
+    """relaxation.py:741-812 (A: CSR SparseOp, Dinv = 1 / squared row norms)."""
+    n = len(x)
+    temp = np.zeros_like(x)
+    om = A.data.dtype.type(omega)
+    for _ in range(iterations):
+        delta = (np.ravel(b - matvec(A, x)) * np.ravel(Dinv)).astype(A.data.dtype)
+        jacobi_ne(A.indptr, A.indices, A.data, x, delta, temp, 0, n, 1, om)
+
+
 def apply_smoother(s, A, x, b):
     """Dispatch a SmootherSpec exactly as the reference's bound callable would run."""
     if s is None or s.kind == "none":
@@ -276,6 +333,12 @@ def apply_smoother(s, A, x, b):
         relax_block_jacobi(A, x, b, s.Dinv, s.blocksize, s.iterations, s.omega)
     elif s.kind == "block_gauss_seidel":
         relax_block_gauss_seidel(A, x, b, s.Dinv, s.blocksize, s.iterations, s.sweep)
+    elif s.kind == "gauss_seidel_ne":
+        relax_gauss_seidel_ne(A, x, b, s.Dinv, s.iterations, s.sweep, s.omega)
+    elif s.kind == "gauss_seidel_nr":
+        relax_gauss_seidel_nr(A, s.At, x, b, s.Dinv, s.iterations, s.sweep, s.omega, getattr(s, "Ar", None))
+    elif s.kind == "jacobi_ne":
+        relax_jacobi_ne(A, x, b, s.Dinv, s.iterations, s.omega)
     elif s.kind in ("cf_jacobi", "fc_jacobi"):
         relax_cf_jacobi(A, x, b, s.Cpts, s.Fpts, s.iterations, s.f_iterations, s.c_iterations, s.omega,
                         f_first=(s.kind == "fc_jacobi"))

@@ -20,7 +20,7 @@ F64, F32 = 0, 1
 CSR, BSR = 0, 1
 SPMV_SET, SPMV_ACC, SPMV_RESID, SPMV_AXPBY, SPMV_ACC_AXPBY = 0, 1, 2, 3, 4
 FORWARD, BACKWARD, SYMMETRIC = 0, 1, 2
-SMOOTH = {"cf_jacobi": 7, "fc_jacobi": 8, "none": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
+SMOOTH = {"gauss_seidel_ne": 9, "gauss_seidel_nr": 10, "jacobi_ne": 11, "cf_jacobi": 7, "fc_jacobi": 8, "none": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
           "block_jacobi": 5, "block_gauss_seidel": 6}
 SWEEP = {"forward": FORWARD, "backward": BACKWARD, "symmetric": SYMMETRIC}
 CYCLE = {"V": 0, "W": 1, "F": 2, "AMLI": 3}
@@ -98,6 +98,8 @@ def _declare(lib):
     f("pamg_matrix_tune", _vp, _i, _i)
     f("pamg_matrix_flow_error", _vp, P(_i))
     f("pamg_matrix_subset_rows", _vp, _vp, _i, P(_vp))
+    f("pamg_matrix_kaczmarz", _vp, _i, _vp, _vp, _vp, _d, _i, _i, _vp, _vp)
+    f("pamg_vec_mul", _i, C.c_int64, _vp, _vp, _vp, _vp)
     f("pamg_matrix_jacobi_indexed", _vp, _vp, _vp, _d, _vp, _vp)
     f("pamg_matrix_gs_profile", _vp, _i, _vp, C.c_int64, P(C.c_int64))
     f("pamg_matrix_autotune", _vp, _i)
@@ -117,6 +119,7 @@ def _declare(lib):
     f("pamg_solver_destroy", _vp)
     f("pamg_solver_add_level", _vp, _vp, _vp, _vp)
     f("pamg_solver_set_smoother", _vp, _i, _i, _i, _i, _d, _i, _vp, _i, _vp, _i)
+    f("pamg_solver_set_ne_smoother", _vp, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp)
     f("pamg_solver_set_cf_smoother", _vp, _i, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i)
     f("pamg_solver_set_coarse_dense", _vp, _vp, _i)
     f("pamg_solver_finalize", _vp)

@@ -97,6 +97,16 @@ struct GsSchedule {
     size_t bytes = 0;
 };
 
+// Dependency levels of a Kaczmarz-type sweep over the lines (rows) of an operator: two lines conflict when they
+// share a column index; lines of one level are pairwise conflict-free.
+struct LineSchedule {
+    int start = 0, stop = 0, step = 0;
+    int nlevels = 0;
+    int *d_lines = nullptr;          // line ids, level after level
+    std::vector<int> level_ptr;      // [nlevels+1]
+    size_t bytes = 0;
+};
+
 }  // namespace pamg
 
 struct pamg_matrix_s {
@@ -134,6 +144,7 @@ struct pamg_matrix_s {
     int4 *d_blkmeta = nullptr;
     double *d_partial = nullptr;     // nblk doubles (sum-of-squares partials)
     pamg::GsSchedule *gs[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd, bwd, 2 custom
+    pamg::LineSchedule *ls[4] = {nullptr, nullptr, nullptr, nullptr};  // Kaczmarz sweeps over this operator's rows
     size_t bytes = 0;
 };
 
@@ -148,6 +159,10 @@ int vec_sumsq(int dtype, int64_t n, const void *x, double *scratch, double *out,
 int vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
 int vec_scale(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s);
 int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch, double *out, hipStream_t s);
+int vec_mul(int dtype, int64_t n, const void *a, const void *b, void *y, hipStream_t s);
+int kaczmarz_sweep(pamg_matrix_s *L, bool nr, void *v, const void *b, const void *Dinv, double omega, int start, int stop,
+                   int step, void *xout, hipStream_t s);
+int ensure_line_schedule(pamg_matrix_s *L, int start, int stop, int step);
 int vec_scatter(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s);
 int matrix_row_subset(pamg_matrix_s *A, const int32_t *rows, int nrows, pamg_matrix_s **out);   // rows: HOST
 int jacobi_indexed(pamg_matrix_s *sub, void *x, const void *b, double omega, void *work, hipStream_t s);

@@ -970,6 +970,45 @@ __global__ __launch_bounds__(BLK) void vec_gather_kernel(int64_t n, const int *i
         dst[i] = src[idx[i]];
 }
 
+// One dependency level of a Kaczmarz-type sweep: every listed "line" (a row of A for Gauss-Seidel NE,
+// a column of A for Gauss-Seidel NR) is handled by one lane -- in-order dot with the read-modify-write
+// vector v, the step, then the in-order scatter update.  Lines of one level share no index of v (host
+// schedule), so no atomics and the result is the sequential sweep's, bit for bit.
+//   NR = false: amg_core::gauss_seidel_ne (relaxation.h:889-902): d = (b_i - s) * Dinv_i * omega; v[j] += a d
+//   NR = true : amg_core::gauss_seidel_nr (relaxation.h:954-973): d = s * (Dinv_i * omega); x_i += d; v[j] -= d a
+template <typename T, bool NR>
+__global__ __launch_bounds__(BLK) void kaczmarz_level_kernel(const int *lines, int first, int count, const int *Lp,
+                                                             const int *Lj, const T *Lx, T *v, const T *b,
+                                                             const T *Dinv, T omega, T *xout)
+{
+    const int k = (int)blockIdx.x * BLK + (int)threadIdx.x;
+    if (k >= count) return;
+    const int i = lines[first + k];
+    const int lo = Lp[i], hi = Lp[i + 1];
+    T s = T(0);
+    for (int p = lo; p < hi; ++p) s += Lx[p] * v[Lj[p]];
+    if constexpr (NR) {
+        const T d = s * (Dinv[i] * omega);
+        xout[i] = xout[i] + d;
+        for (int p = lo; p < hi; ++p) {
+            const T t = d * Lx[p];
+            v[Lj[p]] = v[Lj[p]] - t;
+        }
+    } else {
+        const T d = (b[i] - s) * Dinv[i] * omega;
+        for (int p = lo; p < hi; ++p) {
+            const T t = Lx[p] * d;
+            v[Lj[p]] = v[Lj[p]] + t;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_mul_kernel(int64_t n, const T *a, const T *b, T *y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) y[i] = a[i] * b[i];
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLK) void vec_scatter_kernel(int64_t n, const int *idx, const T *src, T *dst)
 {

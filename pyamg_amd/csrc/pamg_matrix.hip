@@ -801,6 +801,90 @@ int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch,
     return (int)hipGetLastError();
 }
 
+int vec_mul(int dtype, int64_t n, const void *a, const void *b, void *y, hipStream_t s)
+{
+    if (n <= 0) return PAMG_OK;
+    const int grid = (int)std::min<int64_t>(8192, (n + BLK - 1) / BLK);
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_mul_kernel<double>), dim3(grid), dim3(BLK), 0, s, n, (const double *)a, (const double *)b, (double *)y);
+    else
+        hipLaunchKernelGGL((vec_mul_kernel<float>), dim3(grid), dim3(BLK), 0, s, n, (const float *)a, (const float *)b, (float *)y);
+    return (int)hipGetLastError();
+}
+
+// Order-exact schedule of a Kaczmarz-type sweep over the rows of L in the order (start, stop, step): level of
+// a line = 1 + the highest level among EARLIER lines that touch one of its indices -- found in O(nnz) with one
+// "highest level seen so far" per index (the conflict graph L L^T is never formed).
+static int get_line_schedule(pamg_matrix_s *L, int start, int stop, int step, LineSchedule **out)
+{
+    for (int k = 0; k < 4; ++k) {
+        LineSchedule *g = L->ls[k];
+        if (g && g->start == start && g->stop == stop && g->step == step) { *out = g; return PAMG_OK; }
+    }
+    if (step == 0) return PAMG_E_ARG;
+    const long span = (long)stop - start;
+    if (span % step != 0 || span / step < 0) return PAMG_E_ARG;
+    const int m = (int)(span / step), n = (int)L->nrows;
+    if (m > 0 && (start < 0 || start >= n || start + (long)(m - 1) * step < 0 || start + (long)(m - 1) * step >= n)) return PAMG_E_ARG;
+    std::vector<int> seen((size_t)L->ncols, -1), lvl((size_t)std::max(m, 1));
+    int nl = 0;
+    for (int t = 0; t < m; ++t) {
+        const int i = start + t * step;
+        int lv = 0;
+        for (int p = L->h_Ap[i]; p < L->h_Ap[i + 1]; ++p) lv = std::max(lv, seen[L->h_Aj[p]] + 1);
+        for (int p = L->h_Ap[i]; p < L->h_Ap[i + 1]; ++p) seen[L->h_Aj[p]] = lv;
+        lvl[t] = lv;
+        nl = std::max(nl, lv + 1);
+    }
+    LineSchedule *g = new (std::nothrow) LineSchedule();
+    if (!g) return PAMG_E_ALLOC;
+    g->start = start; g->stop = stop; g->step = step; g->nlevels = nl;
+    g->level_ptr.assign((size_t)nl + 1, 0);
+    for (int t = 0; t < m; ++t) g->level_ptr[lvl[t] + 1]++;
+    for (int l = 0; l < nl; ++l) g->level_ptr[l + 1] += g->level_ptr[l];
+    std::vector<int> lines((size_t)std::max(m, 1)), cur(g->level_ptr.begin(), g->level_ptr.end() - (nl ? 1 : 0));
+    for (int t = 0; t < m; ++t) lines[cur[lvl[t]]++] = start + t * step;
+    const int st = upload(&g->d_lines, lines.data(), (size_t)m, &g->bytes);
+    if (st) { delete g; return st; }
+    int slot = -1;
+    for (int k = 0; k < 4; ++k) if (!L->ls[k]) { slot = k; break; }
+    if (slot < 0) { hipFree(L->ls[3]->d_lines); delete L->ls[3]; slot = 3; }
+    L->ls[slot] = g;
+    L->bytes += g->bytes;
+    *out = g;
+    return PAMG_OK;
+}
+
+int ensure_line_schedule(pamg_matrix_s *L, int start, int stop, int step)
+{
+    LineSchedule *g = nullptr;
+    return get_line_schedule(L, start, stop, step, &g);
+}
+
+// one directional sweep: one launch per dependency level
+int kaczmarz_sweep(pamg_matrix_s *L, bool nr, void *v, const void *b, const void *Dinv, double omega, int start, int stop,
+                   int step, void *xout, hipStream_t s)
+{
+    if (!L || !v || !Dinv || (nr ? !xout : !b)) return PAMG_E_ARG;
+    if (L->R != 1 || L->C != 1) return PAMG_E_UNSUPPORTED;
+    LineSchedule *g = nullptr;
+    PAMG_TRY(get_line_schedule(L, start, stop, step, &g));
+    for (int l = 0; l < g->nlevels; ++l) {
+        const int first = g->level_ptr[l], count = g->level_ptr[l + 1] - first;
+        if (count <= 0) continue;
+        const int grid = (count + BLK - 1) / BLK;
+        if (L->dtype == PAMG_F64) {
+            if (nr) hipLaunchKernelGGL((kaczmarz_level_kernel<double, true>), dim3(grid), dim3(BLK), 0, s, g->d_lines, first, count, L->d_Ap, L->d_Aj, (const double *)L->d_Ax, (double *)v, (const double *)b, (const double *)Dinv, omega, (double *)xout);
+            else hipLaunchKernelGGL((kaczmarz_level_kernel<double, false>), dim3(grid), dim3(BLK), 0, s, g->d_lines, first, count, L->d_Ap, L->d_Aj, (const double *)L->d_Ax, (double *)v, (const double *)b, (const double *)Dinv, omega, (double *)xout);
+        } else {
+            if (nr) hipLaunchKernelGGL((kaczmarz_level_kernel<float, true>), dim3(grid), dim3(BLK), 0, s, g->d_lines, first, count, L->d_Ap, L->d_Aj, (const float *)L->d_Ax, (float *)v, (const float *)b, (const float *)Dinv, (float)omega, (float *)xout);
+            else hipLaunchKernelGGL((kaczmarz_level_kernel<float, false>), dim3(grid), dim3(BLK), 0, s, g->d_lines, first, count, L->d_Ap, L->d_Aj, (const float *)L->d_Ax, (float *)v, (const float *)b, (const float *)Dinv, (float)omega, (float *)xout);
+        }
+        PAMG_HIP(hipGetLastError());
+    }
+    return PAMG_OK;
+}
+
 int vec_scatter(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s)
 {
     if (n <= 0) return PAMG_OK;
@@ -1059,6 +1143,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag); hipFree(A->d_rowid);
     hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
+    for (int k = 0; k < 4; ++k) if (A->ls[k]) { hipFree(A->ls[k]->d_lines); delete A->ls[k]; }
     delete A;
     return PAMG_OK;
 }
@@ -1149,6 +1234,25 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
     for (int l = 0; l < g->nlevels; ++l)
         for (int q = g->level_blk[l]; q < g->level_blk[l + 1]; ++q) out[(size_t)q * 8 + 7] = l;
     return PAMG_OK;
+}
+
+int pamg_matrix_kaczmarz(pamg_matrix_t L, int nr, void *v, const void *b, const void *Dinv, double omega, int sweep,
+                         int iterations, void *xout, pamg_stream_t s)
+{
+    if (!L || iterations < 0 || sweep < PAMG_FORWARD || sweep > PAMG_SYMMETRIC) return PAMG_E_ARG;
+    const int n = (int)L->nrows;
+    if (n == 0) return PAMG_OK;
+    for (int it = 0; it < iterations; ++it) {
+        if (sweep != PAMG_BACKWARD) PAMG_TRY(pamg::kaczmarz_sweep(L, nr != 0, v, b, Dinv, omega, 0, n, 1, xout, (hipStream_t)s));
+        if (sweep != PAMG_FORWARD) PAMG_TRY(pamg::kaczmarz_sweep(L, nr != 0, v, b, Dinv, omega, n - 1, -1, -1, xout, (hipStream_t)s));
+    }
+    return PAMG_OK;
+}
+
+int pamg_vec_mul(int dtype, int64_t n, const void *a, const void *b, void *y, pamg_stream_t s)
+{
+    if (dtype != PAMG_F64 && dtype != PAMG_F32) return PAMG_E_ARG;
+    return pamg::vec_mul(dtype, n, a, b, y, (hipStream_t)s);
 }
 
 int pamg_matrix_subset_rows(pamg_matrix_t A, const int32_t *rows, int nrows, pamg_matrix_t *sub)

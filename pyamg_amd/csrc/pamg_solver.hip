@@ -28,6 +28,8 @@ struct Smoother {
     pamg_matrix_s *AF = nullptr, *AC = nullptr;
     void *wF = nullptr, *wC = nullptr;
     int f_iterations = 1, c_iterations = 1;
+    // normal-equation smoothers: d_Dinv holds 1/||row||^2 or 1/||col||^2; At is borrowed (see the header)
+    pamg_matrix_s *At = nullptr, *Ar = nullptr;
 };
 
 struct Level {
@@ -189,6 +191,37 @@ int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, 
             return block_jacobi_pp(L.A, &L.x, &L.xalt, L.b, sm.d_Dinv, sm.omega, sm.iterations, s);
         case PAMG_SMOOTH_BLOCK_GS:
             return block_gs_apply(L.A, L.x, L.b, sm.d_Dinv, sm.sweep, sm.iterations, s);
+        case PAMG_SMOOTH_GS_NE: {
+            const int n = (int)L.A->nrows;
+            for (int it = 0; it < sm.iterations; ++it) {
+                if (sm.sweep != PAMG_BACKWARD) PAMG_TRY(kaczmarz_sweep(L.A, false, L.x, L.b, sm.d_Dinv, sm.omega, 0, n, 1, nullptr, s));
+                if (sm.sweep != PAMG_FORWARD) PAMG_TRY(kaczmarz_sweep(L.A, false, L.x, L.b, sm.d_Dinv, sm.omega, n - 1, -1, -1, nullptr, s));
+            }
+            return PAMG_OK;
+        }
+        case PAMG_SMOOTH_GS_NR: {
+            // relaxation.py:968-988: the residual is formed once per DIRECTIONAL call (symmetric = forward call
+            // then backward call per iteration, each with iterations = 1), then swept `iterations` times
+            const int n = (int)L.A->nrows;
+            auto call = [&](bool fwd, int its) -> int {
+                PAMG_TRY(stream_launch(sm.Ar ? sm.Ar : L.A, EPI_RESID, L.x, L.b, L.r, 0.0, 0.0, nullptr, s));
+                for (int k = 0; k < its; ++k)
+                    PAMG_TRY(kaczmarz_sweep(sm.At, true, L.r, nullptr, sm.d_Dinv, sm.omega, fwd ? 0 : n - 1, fwd ? n : -1, fwd ? 1 : -1, L.x, s));
+                return PAMG_OK;
+            };
+            if (sm.sweep == PAMG_SYMMETRIC) {
+                for (int it = 0; it < sm.iterations; ++it) { PAMG_TRY(call(true, 1)); PAMG_TRY(call(false, 1)); }
+                return PAMG_OK;
+            }
+            return call(sm.sweep == PAMG_FORWARD, sm.iterations);
+        }
+        case PAMG_SMOOTH_JACOBI_NE:
+            for (int it = 0; it < sm.iterations; ++it) {
+                PAMG_TRY(stream_launch(L.A, EPI_RESID, L.x, L.b, L.r, 0.0, 0.0, nullptr, s));        // r = b - A x
+                PAMG_TRY(vec_mul(S->dtype, L.n, L.r, sm.d_Dinv, L.r, s));                           // delta = r .* Dinv
+                PAMG_TRY(stream_launch(sm.At, EPI_ACC, L.r, nullptr, L.x, 0.0, 0.0, nullptr, s));   // x += (omega A)^T delta
+            }
+            return PAMG_OK;
         case PAMG_SMOOTH_CF_JACOBI:
         case PAMG_SMOOTH_FC_JACOBI:
             for (int it = 0; it < sm.iterations; ++it) {
@@ -326,6 +359,15 @@ int ensure_amli(pamg_solver_s *S, int cycle);
 
 int prebuild_schedules(Level &L, const Smoother &sm)
 {
+    if (sm.kind == PAMG_SMOOTH_GS_NE || sm.kind == PAMG_SMOOTH_GS_NR) {
+        // the Kaczmarz line schedules allocate: build them here, never inside a graph capture
+        pamg_matrix_s *Lm = sm.kind == PAMG_SMOOTH_GS_NE ? L.A : sm.At;
+        const int n = (int)Lm->nrows;
+        if (n == 0) return PAMG_OK;
+        if (sm.sweep != PAMG_BACKWARD) PAMG_TRY(ensure_line_schedule(Lm, 0, n, 1));
+        if (sm.sweep != PAMG_FORWARD) PAMG_TRY(ensure_line_schedule(Lm, n - 1, -1, -1));
+        return PAMG_OK;
+    }
     const bool gs = sm.kind == PAMG_SMOOTH_GS || sm.kind == PAMG_SMOOTH_SOR || sm.kind == PAMG_SMOOTH_BLOCK_GS;
     if (!gs || L.A->nrows == 0) return PAMG_OK;
     int r0, r1, rs;
@@ -530,6 +572,36 @@ int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind,
     PAMG_HIP(hipMalloc(&sm.wF, std::max<size_t>((size_t)nF * ts, 256)));
     PAMG_HIP(hipMalloc(&sm.wC, std::max<size_t>((size_t)nC * ts, 256)));
     S->bytes += sm.AF->bytes + sm.AC->bytes + (size_t)(nF + nC) * ts;
+    return PAMG_OK;
+}
+
+int pamg_solver_set_ne_smoother(pamg_solver_t S, int level, int which, int kind, int iterations, double omega,
+                                int sweep, const void *Dinv, pamg_matrix_t At, pamg_matrix_t Ar)
+{
+    if (!S || level < 0 || level >= (int)S->levels.size() || (which != 0 && which != 1) || !Dinv) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    if (kind != PAMG_SMOOTH_GS_NE && kind != PAMG_SMOOTH_GS_NR && kind != PAMG_SMOOTH_JACOBI_NE) return PAMG_E_ARG;
+    if (iterations < 0 || sweep < PAMG_FORWARD || sweep > PAMG_SYMMETRIC) return PAMG_E_ARG;
+    Level &L = S->levels[level];
+    if (L.A->R != 1 || L.A->C != 1) return PAMG_E_UNSUPPORTED;
+    if (kind != PAMG_SMOOTH_GS_NE) {
+        if (!At || At->dtype != S->dtype || At->R != 1 || At->C != 1 || At->nrows != L.A->ncols || At->ncols != L.A->nrows)
+            return PAMG_E_ARG;
+    }
+    if (Ar && (Ar->dtype != S->dtype || Ar->nrows != L.A->nrows || Ar->ncols != L.A->ncols)) return PAMG_E_ARG;
+    Smoother &sm = which == 0 ? L.pre : L.post;
+    if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
+    if (sm.AF) pamg_matrix_destroy(sm.AF);
+    if (sm.AC) pamg_matrix_destroy(sm.AC);
+    hipFree(sm.wF); hipFree(sm.wC);
+    sm = Smoother();
+    sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep;
+    sm.At = kind == PAMG_SMOOTH_GS_NE ? nullptr : At;
+    sm.Ar = kind == PAMG_SMOOTH_GS_NR ? Ar : nullptr;
+    const size_t sz = (size_t)L.A->nrows * tsize(S->dtype);
+    PAMG_HIP(hipMalloc(&sm.d_Dinv, std::max<size_t>(sz, 256)));
+    PAMG_HIP(hipMemcpy(sm.d_Dinv, Dinv, sz, hipMemcpyHostToDevice));
+    S->bytes += sz;
     return PAMG_OK;
 }
 

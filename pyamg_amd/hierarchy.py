@@ -70,7 +70,8 @@ class SmootherSpec:
     """One pre/post smoother of one level, as the reference would apply it.
 
     kind: 'jacobi' | 'gauss_seidel' | 'sor' | 'polynomial' | 'block_jacobi' |
-          'block_gauss_seidel' | 'cf_jacobi' | 'fc_jacobi' | 'none'
+          'block_gauss_seidel' | 'cf_jacobi' | 'fc_jacobi' | 'gauss_seidel_ne' |
+          'gauss_seidel_nr' | 'jacobi_ne' | 'none'
     """
     kind: str
     iterations: int = 1
@@ -84,6 +85,8 @@ class SmootherSpec:
     Cpts: Optional[np.ndarray] = None
     f_iterations: int = 1
     c_iterations: int = 1
+    At: Optional["SparseOp"] = None             # gauss_seidel_nr: CSR of A^T (= CSC arrays of A); jacobi_ne: same, values * omega
+    Ar: Optional["SparseOp"] = None             # gauss_seidel_nr: A with sorted rows for r = b - A x (None: the level's A is)
 
 
 @dataclass
@@ -189,6 +192,8 @@ def smoother_spec(fn, A) -> SmootherSpec:
                                 f_iterations=int(kw.get("f_iterations", 1)), c_iterations=int(kw.get("c_iterations", 1)))
         raise NotImplementedError(f"smoother '{base}' is not on the device path")
     cv = _closure_vars(fn)
+    if shown in ("gauss_seidel_ne", "gauss_seidel_nr", "jacobi_ne") and "iterations" in cv and "omega" in cv:
+        return _normal_equation_spec(shown, A, int(cv["iterations"]), cv.get("sweep", "forward"), cv["omega"])
     if shown == "none" and not cv:                                  # smoothing.py setup_none: def none(A, x, b): pass
         return SmootherSpec("none", iterations=0, name="None")
     if shown == "chebyshev" and "coefficients" in cv:
@@ -200,6 +205,48 @@ def smoother_spec(fn, A) -> SmootherSpec:
                             coefficients=np.asarray([cv["omega"]], dtype=np.float64),
                             name="richardson")
     raise NotImplementedError(f"smoother '{shown}' is not on the device path")
+
+
+def _inv_or_zero(D):
+    Dinv = np.zeros_like(D)
+    mask = D != 0.0
+    Dinv[mask] = 1.0 / D[mask]
+    return Dinv
+
+
+def _normal_equation_spec(kind, A, iterations, sweep, omega) -> SmootherSpec:
+    """gauss_seidel_ne / gauss_seidel_nr / jacobi_ne (smoothing.py:641-675): the operands the reference's
+    wrappers build on every call -- the inverse squared row / column norms, with the very SciPy expression of
+    ``get_diagonal(A, norm_eq=.., inv=True)`` (util/utils.py:583-598), and the column-major form of A."""
+    if A.dtype.type is not np.float64:
+        # the reference passes a float64 Dinv to a float32 kernel: TypeError (noconvert bindings)
+        raise NotImplementedError(f"{kind} on a {A.dtype} level is not on the device path (float64 only)")
+    if A.format == "bsr" and tuple(A.blocksize) != (1, 1):
+        raise NotImplementedError(f"{kind} on BSR blocks {A.blocksize} is not on the device path")
+    n = A.shape[0]
+    if kind == "gauss_seidel_nr":
+        Mc = A.tocsc()                                  # matrix_asformat(lvl, 'A', 'csc')
+        Mc.sort_indices()
+        Mt = Mc.T
+        D = (Mt.multiply(Mt.conjugate())) @ np.ones((Mt.shape[0],))
+        At = SparseOp("csr", (n, n), (1, 1), _as_int32(Mc.indptr, "indptr"), _as_int32(Mc.indices, "indices"),
+                      np.ascontiguousarray(Mc.data), "csc")
+        # the wrapper forms r = b - A @ x with the CSC matrix (relaxation.py:983): per row that is a sum in
+        # ascending column order -- the level's own A gives the same bits only if its rows are sorted
+        Ar = None if (A.format in ("csr", "bsr") and A.has_sorted_indices) else sparse_op(Mc.tocsr())
+        return SmootherSpec(kind, iterations, float(omega), sweep, Dinv=np.ravel(_inv_or_zero(D)), At=At, Ar=Ar, name=kind)
+    M = A.tocsr()
+    M.sort_indices()
+    D = (M.multiply(M.conjugate())) @ np.ones((M.shape[0],))
+    Dinv = np.ravel(_inv_or_zero(D))
+    if kind == "gauss_seidel_ne":
+        return SmootherSpec(kind, iterations, float(omega), sweep, Dinv=Dinv, name=kind)
+    Mc = M.tocsc()
+    Mc.sort_indices()
+    om = A.dtype.type(np.real(omega))                   # type_prep(A.dtype, [omega]); omega2 * Ax[j] in the kernel
+    At = SparseOp("csr", (n, n), (1, 1), _as_int32(Mc.indptr, "indptr"), _as_int32(Mc.indices, "indices"),
+                  np.ascontiguousarray(om * Mc.data), "csc")
+    return SmootherSpec(kind, iterations, float(np.real(omega)), "forward", Dinv=Dinv, At=At, name=kind)
 
 
 # --------------------------------------------------------------------------- coarse solver
@@ -249,6 +296,14 @@ def extract(ml) -> HierarchySpec:
             ls.R = sparse_op(lvl.R)
             ls.pre = smoother_spec(getattr(lvl, "presmoother", None), lvl.A)
             ls.post = smoother_spec(getattr(lvl, "postsmoother", None), lvl.A)
+            kinds = {sm.kind for sm in (ls.pre, ls.post) if sm is not None}
+            if kinds & {"gauss_seidel_ne", "jacobi_ne"} and lvl.A.format == "csr" and not lvl.A.has_sorted_indices:
+                # the reference's wrappers call get_diagonal(lvl.Acsr) -- lvl.Acsr IS lvl.A for a CSR level -- which
+                # sorts the matrix IN PLACE (util/utils.py:583) the first time the smoother runs: from then on
+                # every product with this level's A sums in sorted order.  Ship it sorted.
+                As = lvl.A.copy()
+                As.sort_indices()
+                ls.A = sparse_op(As)
         for nm, op in (("A", ls.A), ("P", ls.P), ("R", ls.R)):
             if op is not None and op.dtype != levels[0].A.dtype:
                 raise NotImplementedError(
@@ -289,6 +344,10 @@ def _put_sm(d, key, s: Optional[SmootherSpec]):
         d[f"{key}.coefficients"] = np.asarray(s.coefficients, dtype=np.float64)
     if s.Dinv is not None:
         d[f"{key}.Dinv"] = s.Dinv
+    if s.At is not None:
+        _put_op(d, f"{key}.At", s.At)
+    if s.Ar is not None:
+        _put_op(d, f"{key}.Ar", s.Ar)
     if s.Fpts is not None:
         d[f"{key}.Fpts"] = np.asarray(s.Fpts, dtype=np.int32)
         d[f"{key}.Cpts"] = np.asarray(s.Cpts, dtype=np.int32)
@@ -302,6 +361,8 @@ def _get_sm(z, key) -> Optional[SmootherSpec]:
     sm = SmootherSpec(str(z[f"{key}.kind"]), int(num[0]), float(z[f"{key}.omega"]), str(z[f"{key}.sweep"]),
                       z[f"{key}.coefficients"] if f"{key}.coefficients" in z else None,
                       z[f"{key}.Dinv"] if f"{key}.Dinv" in z else None, int(num[1]), str(z[f"{key}.name"]))
+    sm.At = _get_op(z, f"{key}.At")
+    sm.Ar = _get_op(z, f"{key}.Ar")
     if f"{key}.Fpts" in z:
         sm.Fpts, sm.Cpts = z[f"{key}.Fpts"], z[f"{key}.Cpts"]
         sm.f_iterations, sm.c_iterations = (int(v) for v in z[f"{key}.fc_iters"])

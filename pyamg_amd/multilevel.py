@@ -68,6 +68,14 @@ class DeviceMatrix:
         sub.handle = h
         return sub
 
+    def kaczmarz(self, v, Dinv, omega, sweep="forward", iterations=1, b=None, xout=None, stream=None):
+        """Kaczmarz-type sweeps over the rows of this operator (pamg_matrix_kaczmarz): b given ->
+        gauss_seidel_ne on v = x; xout given -> gauss_seidel_nr (self = CSR of A^T, v = running residual)."""
+        nr = xout is not None
+        capi.check(capi.lib().pamg_matrix_kaczmarz(self.handle, int(nr), v.ptr, b.ptr if b is not None else None, Dinv.ptr,
+                                                   float(omega), capi.SWEEP[sweep], int(iterations),
+                                                   xout.ptr if nr else None, stream), "pamg_matrix_kaczmarz")
+
     def jacobi_indexed(self, x, b, omega, work, stream=None):
         """amg_core.jacobi_indexed on a row-subset operator (self): relaxes the listed rows of x from the old x"""
         capi.check(capi.lib().pamg_matrix_jacobi_indexed(self.handle, x.ptr, b.ptr, float(omega), work.ptr, stream),
@@ -142,9 +150,24 @@ class DeviceMatrix:
         self.free()
 
 
-def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype):
+def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype, aux):
     if s is None or s.kind == "none":
         capi.check(lib.pamg_solver_set_smoother(S, level, which, 0, 0, 1.0, 0, None, 0, None, 1), "set_smoother")
+        return
+    if s.kind in ("gauss_seidel_ne", "gauss_seidel_nr", "jacobi_ne"):
+        Dinv = np.ascontiguousarray(s.Dinv, dtype=dtype)
+        At = None
+        if s.At is not None:
+            At = DeviceMatrix(s.At)
+            aux.append(At)                      # borrowed by the solver: keep it alive
+        Ar = None
+        if getattr(s, "Ar", None) is not None:
+            Ar = DeviceMatrix(s.Ar)
+            aux.append(Ar)
+        capi.check(lib.pamg_solver_set_ne_smoother(S, level, which, capi.SMOOTH[s.kind], int(s.iterations), float(s.omega),
+                                                   capi.SWEEP.get(s.sweep, 0), capi.ptr(Dinv), At.handle if At else None,
+                                                   Ar.handle if Ar else None),
+                   f"pamg_solver_set_ne_smoother({s.kind})")
         return
     if s.kind in ("cf_jacobi", "fc_jacobi"):
         F = np.ascontiguousarray(s.Fpts, dtype=np.int32)
@@ -192,6 +215,7 @@ class DeviceMultilevelSolver:
         self.dtype = np.dtype(self.spec.dtype)
         self.shape = tuple(self.spec.levels[0].A.shape)
         self._mats: List[DeviceMatrix] = []
+        self._aux: List[DeviceMatrix] = []          # operators borrowed by smoothers (A^T forms)
         self.A: List[DeviceMatrix] = []
         h = C.c_void_p()
         capi.check(lib.pamg_solver_create(C.byref(h), capi.dtype_code(self.dtype)), "pamg_solver_create")
@@ -216,8 +240,8 @@ class DeviceMultilevelSolver:
             capi.check(lib.pamg_solver_add_level(h, A.handle, P.handle if P else None, R.handle if R else None),
                        "pamg_solver_add_level")
             if i < nlev - 1:
-                _set_smoother(lib, h, i, 0, L.pre, self.dtype)
-                _set_smoother(lib, h, i, 1, L.post, self.dtype)
+                _set_smoother(lib, h, i, 0, L.pre, self.dtype, self._aux)
+                _set_smoother(lib, h, i, 1, L.post, self.dtype, self._aux)
         n_c = self.spec.levels[-1].A.shape[0]
         if self.spec.coarse_kind == "zero":
             capi.check(lib.pamg_solver_set_coarse_dense(h, None, n_c), "set_coarse")
@@ -457,9 +481,10 @@ class DeviceMultilevelSolver:
             except Exception:       # pragma: no cover
                 pass
             self.handle = None
-        for m in getattr(self, "_mats", []):
+        for m in getattr(self, "_mats", []) + getattr(self, "_aux", []):
             m.free()
         self._mats = []
+        self._aux = []
 
     def __del__(self):
         self.free()

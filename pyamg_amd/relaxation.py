@@ -20,7 +20,8 @@ from .hierarchy import sparse_op
 from .multilevel import DeviceMatrix
 
 __all__ = ["make_system", "jacobi", "gauss_seidel", "sor", "polynomial", "block_jacobi",
-           "block_gauss_seidel"]
+           "block_gauss_seidel", "jacobi_indexed", "cf_jacobi", "fc_jacobi", "gauss_seidel_ne",
+           "gauss_seidel_nr", "jacobi_ne"]
 
 
 def make_system(A, x, b, formats=None):
@@ -162,6 +163,73 @@ def fc_jacobi(A, x, b, Cpts, Fpts, iterations=1, f_iterations=1, c_iterations=1,
     (reference: relaxation.py:1206-1268)."""
     A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
     _indexed_sweeps(A, x, b, [(Fpts, f_iterations), (Cpts, c_iterations)], iterations, omega)
+
+
+def _ne_spec(kind, A, iterations, sweep, omega):
+    from .hierarchy import _normal_equation_spec
+    return _normal_equation_spec(kind, A, iterations, sweep, omega)
+
+
+def gauss_seidel_ne(A, x, b, iterations=1, sweep="forward", omega=1.0, Dinv=None):
+    """Kaczmarz relaxation (Gauss-Seidel on A A^H y = b, x = A^H y), in place
+    (reference: relaxation.py:815-901)."""
+    A, x, b = make_system(A, x, b, formats=["csr"])
+    if sweep not in ("forward", "backward", "symmetric"):
+        raise ValueError('valid sweep directions: "forward", "backward", and "symmetric"')
+    sm = _ne_spec("gauss_seidel_ne", A, iterations, sweep, omega)
+    dD = capi.DeviceArray.from_host(np.ascontiguousarray(sm.Dinv if Dinv is None else np.ravel(Dinv), dtype=A.dtype))
+    st = _Staged(A, x, b)
+    st.A.kaczmarz(st.x, dD, float(omega), sweep, iterations, b=st.b)
+    st.finish()
+    dD.free()
+
+
+def gauss_seidel_nr(A, x, b, iterations=1, sweep="forward", omega=1.0, Dinv=None):
+    """Gauss-Seidel on A^H A x = A^H b, in place (reference: relaxation.py:904-988): the residual is formed
+    once per directional call, then swept ``iterations`` times; 'symmetric' = forward call + backward call."""
+    from .multilevel import DeviceMatrix
+    A, x, b = make_system(A, x, b, formats=["csc", "csr"])
+    if sweep not in ("forward", "backward", "symmetric"):
+        raise ValueError('valid sweep directions: "forward", "backward", and "symmetric"')
+    sm = _ne_spec("gauss_seidel_nr", A, iterations, sweep, omega)
+    dD = capi.DeviceArray.from_host(np.ascontiguousarray(sm.Dinv if Dinv is None else np.ravel(Dinv), dtype=A.dtype))
+    st = _Staged(A, x, b, work=1)
+    At = DeviceMatrix(sm.At)
+    Ar = DeviceMatrix(sm.Ar) if sm.Ar is not None else st.A        # rows sorted = the CSC product's summation order
+
+    def call(direction, its):
+        Ar.spmv(capi.SPMV_RESID, st.x, st.work, b=st.b)                      # r = b - A x  (:983)
+        At.kaczmarz(st.work, dD, float(omega), direction, its, xout=st.x)
+
+    if sweep == "symmetric":
+        for _ in range(iterations):
+            call("forward", 1)
+            call("backward", 1)
+    else:
+        call(sweep, iterations)
+    st.finish()
+    At.free()
+    if Ar is not st.A:
+        Ar.free()
+    dD.free()
+
+
+def jacobi_ne(A, x, b, iterations=1, omega=1.0):
+    """Jacobi on the normal equations A A^H y = b, x = A^H y, in place (reference: relaxation.py:741-812)."""
+    from .multilevel import DeviceMatrix
+    A, x, b = make_system(A, x, b, formats=["csr"])
+    sm = _ne_spec("jacobi_ne", A, iterations, "forward", omega)
+    dD = capi.DeviceArray.from_host(np.ascontiguousarray(sm.Dinv, dtype=A.dtype))
+    st = _Staged(A, x, b, work=1)
+    At = DeviceMatrix(sm.At)                                               # (omega A)^T, row-oriented
+    for _ in range(iterations):
+        st.A.spmv(capi.SPMV_RESID, st.x, st.work, b=st.b)                    # r = b - A x
+        capi.check(capi.lib().pamg_vec_mul(capi.dtype_code(A.dtype), x.size, st.work.ptr, dD.ptr, st.work.ptr, None),
+                   "pamg_vec_mul")                                       # delta = r .* Dinv
+        At.spmv(capi.SPMV_ACC, st.work, st.x)                              # x += (omega A)^T delta
+    st.finish()
+    At.free()
+    dD.free()
 
 
 def polynomial(A, x, b, coefficients, iterations=1):

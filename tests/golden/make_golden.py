@@ -36,7 +36,8 @@ ONLY = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]    
 
 
 ACCEL_ONLY = "--accel-only" in sys.argv      # only (re)generate accel_fgmres.npz
-ACCEL_CASES = ("sa2d_gs", "sa2d_jacobi_AMLI", "rs2d_nonsym_gs", "el2d_blockgs", "sa3d_gs", "air2d_fcjacobi")
+ACCEL_CASES = ("sa2d_gs", "sa2d_jacobi_AMLI", "rs2d_nonsym_gs", "el2d_blockgs", "sa3d_gs", "air2d_fcjacobi",
+               "bb2d_nonsym_gsnr")
 ACCEL = {}
 
 
@@ -167,6 +168,17 @@ def make_hierarchies():
     An.sort_indices()
     np.random.seed(SEED)
     hier("rs2d_nonsym_gs", pyamg.ruge_stuben_solver(An, max_coarse=10))
+    # normal-equation smoothers on the same non-symmetric operator: Kaczmarz (gauss_seidel_ne), Gauss-Seidel on
+    # A^H A (gauss_seidel_nr -- what pyamg.solve() configures for non-symmetric matrices, blackbox.py:112-114)
+    # and jacobi_ne; plus the blackbox configuration itself (energy-minimisation SA, 2 levels)
+    for tag, smo in (("gsnr", ("gauss_seidel_nr", {"sweep": "symmetric", "iterations": 1})),
+                     ("gsne", ("gauss_seidel_ne", {"sweep": "symmetric", "iterations": 1})),
+                     ("jacobine", ("jacobi_ne", {"iterations": 2}))):
+        np.random.seed(SEED)
+        hier(f"rs2d_nonsym_{tag}", pyamg.ruge_stuben_solver(An, max_coarse=10, presmoother=smo, postsmoother=smo))
+    from pyamg import blackbox
+    np.random.seed(SEED)
+    hier("bb2d_nonsym_gsnr", blackbox.solver(An, blackbox.solver_configuration(An, verb=False)))
     # AIR (approximate ideal restriction, classical/air.py) on an advection-dominated operator: no
     # presmoother, FC Jacobi (2 F-sweeps, 1 C-sweep of amg_core.jacobi_indexed) as postsmoother, R != P^T
     Aa = sp.csr_array(3.0 * sp.kron(sp.eye_array(m), Dx) + 0.3 * sp.kron(Dy, sp.eye_array(m)))
@@ -352,6 +364,36 @@ def make_kernels_indexed():
     print("kernels_indexed.npz written:", len(out), "arrays")
 
 
+def make_kernels_ne():
+    """relaxation.gauss_seidel_ne / gauss_seidel_nr / jacobi_ne of the reference -> kernels_ne.npz (float64: the
+    reference hands a float64 Dinv to its float32 kernels, i.e. raises TypeError there)."""
+    import scipy.sparse as sp
+    rng = np.random.RandomState(SEED + 13)
+    out = {}
+    G = sp.random(350, 350, density=0.03, random_state=rng, format="lil")
+    G.setdiag(rng.rand(350) + 1.0)
+    G[7, :] = 0                       # empty row
+    G[:, 13] = 0                      # empty column
+    G = sp.csr_array(G.tocsr())
+    G.eliminate_zeros()
+    G.sort_indices()
+    P = sp.csr_array(pyamg.gallery.poisson((19, 17), format="csr"))
+    for tag, M in (("irr", G), ("pois", P)):
+        n = M.shape[0]
+        x = rng.rand(n); b = rng.rand(n)
+        out[f"{tag}.indptr"], out[f"{tag}.indices"], out[f"{tag}.data"] = M.indptr, M.indices, M.data
+        out[f"{tag}.x"], out[f"{tag}.b"] = x, b
+        for sweep in ("forward", "backward", "symmetric"):
+            y = x.copy(); rr.gauss_seidel_ne(M, y, b, iterations=2, sweep=sweep, omega=0.9)
+            out[f"{tag}.gauss_seidel_ne.{sweep}"] = y
+            y = x.copy(); rr.gauss_seidel_nr(sp.csc_array(M), y, b, iterations=2, sweep=sweep, omega=1.1)
+            out[f"{tag}.gauss_seidel_nr.{sweep}"] = y
+        y = x.copy(); rr.jacobi_ne(M, y, b, iterations=3, omega=0.6)
+        out[f"{tag}.jacobi_ne"] = y
+    np.savez_compressed(HERE / "kernels_ne.npz", **out)
+    print("kernels_ne.npz written:", len(out), "arrays")
+
+
 def save_accel():
     if ACCEL:
         np.savez_compressed(HERE / "accel_fgmres.npz", **ACCEL)
@@ -360,6 +402,10 @@ def save_accel():
 
 if __name__ == "__main__" and "--indexed-only" in sys.argv:
     make_kernels_indexed()
+    sys.exit(0)
+
+if __name__ == "__main__" and "--ne-only" in sys.argv:
+    make_kernels_ne()
     sys.exit(0)
 
 if __name__ == "__main__" and (ONLY or ACCEL_ONLY):
@@ -372,5 +418,6 @@ if __name__ == "__main__":
         make_known_answers()
         make_kernels()
         make_kernels_indexed()
+        make_kernels_ne()
     make_hierarchies()
     save_accel()

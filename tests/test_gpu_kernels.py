@@ -477,3 +477,24 @@ def test_indexed_jacobi_bit_exact():
         grelax.jacobi_indexed(M, x.copy(), b, np.array([0, n], dtype=np.int32))          # relaxation.py:1108-1109
     with pytest.raises(TypeError):
         gcore.jacobi_indexed(Ap, Aj, Ax, x.copy(), b, idx.astype(np.int64), np.array([0.7], dtype=Ax.dtype))
+
+
+def test_normal_equation_smoothers_bit_exact():
+    """gauss_seidel_ne (Kaczmarz), gauss_seidel_nr and jacobi_ne on the device (order-exact level schedules
+    over shared indices; (omega A)^T SpMV) vs the reference's outputs in kernels_ne.npz -- bit for bit, all
+    sweep directions, incl. an empty row and an empty column."""
+    from conftest import GOLDEN
+    z = np.load(GOLDEN / "kernels_ne.npz")
+    for tag in ("irr", "pois"):
+        n = z[f"{tag}.indptr"].size - 1
+        M = sp.csr_array((z[f"{tag}.data"], z[f"{tag}.indices"].astype(np.int32), z[f"{tag}.indptr"].astype(np.int32)), shape=(n, n))
+        x, b = z[f"{tag}.x"], z[f"{tag}.b"]
+        for sweep in ("forward", "backward", "symmetric"):
+            y = x.copy(); grelax.gauss_seidel_ne(M, y, b, iterations=2, sweep=sweep, omega=0.9)
+            assert np.array_equal(y, z[f"{tag}.gauss_seidel_ne.{sweep}"]), (tag, sweep)
+            y = x.copy(); grelax.gauss_seidel_nr(sp.csc_array(M), y, b, iterations=2, sweep=sweep, omega=1.1)
+            assert np.array_equal(y, z[f"{tag}.gauss_seidel_nr.{sweep}"]), (tag, sweep)
+        y = x.copy(); grelax.jacobi_ne(M, y, b, iterations=3, omega=0.6)
+        assert np.array_equal(y, z[f"{tag}.jacobi_ne"]), tag
+    with pytest.raises(ValueError):
+        grelax.gauss_seidel_nr(M, x.copy(), b, sweep="sideways")
