@@ -140,6 +140,35 @@ int pamg_jacobi_indexed_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, i
                             const float *Ax, int Ax_size, float *x, int x_size,
                             const float *b, int b_size, const int32_t *indices, int indices_size,
                             const float *omega, int omega_size);
+/* amg_core::gauss_seidel_ne relaxation.h:875-884 (Tx = 1/||row||^2), gauss_seidel_nr :939-948 (Ap/Aj/Ax = the CSC
+ * arrays of A, z = running residual, Tx = 1/||column||^2; omega by value like the reference's F),
+ * jacobi_ne :811-821 (Tx = the row-scaled residual "delta"; full row range only) */
+int pamg_gauss_seidel_ne_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                            const double *Ax, int Ax_size, double *x, int x_size, const double *b, int b_size,
+                            int32_t row_start, int32_t row_stop, int32_t row_step,
+                            const double *Tx, int Tx_size, double omega);
+int pamg_gauss_seidel_nr_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                            const double *Ax, int Ax_size, double *x, int x_size, double *z, int z_size,
+                            int32_t col_start, int32_t col_stop, int32_t col_step,
+                            const double *Tx, int Tx_size, double omega);
+int pamg_jacobi_ne_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                      const double *Ax, int Ax_size, double *x, int x_size, const double *b, int b_size,
+                      const double *Tx, int Tx_size, double *temp, int temp_size,
+                      int32_t row_start, int32_t row_stop, int32_t row_step,
+                      const double *omega, int omega_size);
+int pamg_gauss_seidel_ne_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                            const float *Ax, int Ax_size, float *x, int x_size, const float *b, int b_size,
+                            int32_t row_start, int32_t row_stop, int32_t row_step,
+                            const float *Tx, int Tx_size, float omega);
+int pamg_gauss_seidel_nr_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                            const float *Ax, int Ax_size, float *x, int x_size, float *z, int z_size,
+                            int32_t col_start, int32_t col_stop, int32_t col_step,
+                            const float *Tx, int Tx_size, float omega);
+int pamg_jacobi_ne_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                      const float *Ax, int Ax_size, float *x, int x_size, const float *b, int b_size,
+                      const float *Tx, int Tx_size, float *temp, int temp_size,
+                      int32_t row_start, int32_t row_stop, int32_t row_step,
+                      const float *omega, int omega_size);
 /* amg_core::bsr_jacobi, relaxation.h:472-483 */
 int pamg_bsr_jacobi_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
                         const double *Ax, int Ax_size, double *x, int x_size,

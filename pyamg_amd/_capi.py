@@ -90,6 +90,9 @@ def _declare(lib):
         f(f"pamg_jacobi_{sfx}", *csr5, _vp, _i, _i, _i, _i, _vp, _i)
         f(f"pamg_bsr_jacobi_{sfx}", *csr5, _vp, _i, _i, _i, _i, _i, _vp, _i)
         f(f"pamg_jacobi_indexed_{sfx}", *csr5, _vp, _i, _vp, _i)
+        f(f"pamg_gauss_seidel_ne_{sfx}", *csr5, _i, _i, _i, _vp, _i, ct)
+        f(f"pamg_gauss_seidel_nr_{sfx}", *csr5, _i, _i, _i, _vp, _i, ct)
+        f(f"pamg_jacobi_ne_{sfx}", *csr5, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i)
         f(f"pamg_block_jacobi_{sfx}", *csr5, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i)
         f(f"pamg_block_gauss_seidel_{sfx}", *csr5, _vp, _i, _i, _i, _i, _i)
     f("pamg_matrix_create", P(_vp), _i, _i, _i, _i, _i, _i, _vp, _vp, _vp)

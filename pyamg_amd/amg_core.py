@@ -14,7 +14,8 @@ import numpy as np
 from . import _capi as capi
 
 __all__ = ["csr_matvec", "bsr_matvec", "gauss_seidel", "sor_gauss_seidel", "bsr_gauss_seidel",
-           "jacobi", "bsr_jacobi", "block_jacobi", "block_gauss_seidel"]
+           "jacobi", "bsr_jacobi", "block_jacobi", "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_ne",
+           "gauss_seidel_nr", "jacobi_ne"]
 
 
 def _sfx(Ax, *vals):
@@ -84,6 +85,33 @@ def jacobi(Ap, Aj, Ax, x, b, temp, row_start, row_stop, row_step, omega):
     capi.check(getattr(capi.lib(), f"pamg_jacobi_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(temp), temp.size,
                                                       int(row_start), int(row_stop), int(row_step),
                                                       capi.ptr(omega), omega.size), "jacobi")
+
+
+def gauss_seidel_ne(Ap, Aj, Ax, x, b, row_start, row_stop, row_step, Tx, omega):
+    """amg_core.gauss_seidel_ne (relaxation.h:875-904)."""
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, b, Tx)
+    capi.check(getattr(capi.lib(), f"pamg_gauss_seidel_ne_{s}")(*_csr5(Ap, Aj, Ax, x, b), int(row_start), int(row_stop),
+                                                               int(row_step), capi.ptr(Tx), Tx.size, float(omega)),
+               "gauss_seidel_ne")
+
+
+def gauss_seidel_nr(Ap, Aj, Ax, x, z, col_start, col_stop, col_step, Tx, omega):
+    """amg_core.gauss_seidel_nr (relaxation.h:939-975); Ap/Aj/Ax are the CSC arrays of A, z the residual."""
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, z, Tx)
+    capi.check(getattr(capi.lib(), f"pamg_gauss_seidel_nr_{s}")(*_csr5(Ap, Aj, Ax, x, z), int(col_start), int(col_stop),
+                                                               int(col_step), capi.ptr(Tx), Tx.size, float(omega)),
+               "gauss_seidel_nr")
+
+
+def jacobi_ne(Ap, Aj, Ax, x, b, Tx, temp, row_start, row_stop, row_step, omega):
+    """amg_core.jacobi_ne (relaxation.h:811-840); Tx = delta, the row-scaled residual."""
+    _idx(Ap, Aj)
+    s = _sfx(Ax, x, b, Tx, temp, omega)
+    capi.check(getattr(capi.lib(), f"pamg_jacobi_ne_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(Tx), Tx.size, capi.ptr(temp),
+                                                         temp.size, int(row_start), int(row_stop), int(row_step),
+                                                         capi.ptr(omega), omega.size), "jacobi_ne")
 
 
 def jacobi_indexed(Ap, Aj, Ax, x, b, indices, omega):

@@ -149,6 +149,73 @@ int l1_jacobi_indexed(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_
     return dx.get(x, sizeof(T) * (size_t)n);
 }
 
+// gauss_seidel_ne / gauss_seidel_nr: the arrays are the lines the sweep walks (rows of A for NE, the CSC
+// arrays of A for NR); v is the vector the sweep reads and updates (x for NE, the residual z for NR)
+template <typename T>
+int l1_kaczmarz(bool nr, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size, T *x,
+                int x_size, T *v_nr, const T *b, int vb_size, int start, int stop, int step, const T *Tx, int Tx_size,
+                double omega)
+{
+    if (!x || !Tx || (nr ? !v_nr : !b)) return PAMG_E_ARG;
+    PAMG_TRY(check_csr(Ap, Ap_size, Aj_size, Ax_size, 1));
+    const int n = Ap_size - 1;
+    if (n > x_size || n > vb_size || n > Tx_size) return PAMG_E_ARG;
+    if (start == stop) return PAMG_OK;
+    MatGuard g;
+    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), PAMG_CSR, n, n, 1, 1, Ap, Aj, Ax));
+    DevBuf dx, dv, dD;
+    PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
+    PAMG_TRY(dv.put(nr ? (const void *)v_nr : (const void *)b, sizeof(T) * (size_t)n));
+    PAMG_TRY(dD.put(Tx, sizeof(T) * (size_t)n));
+    if (nr) PAMG_TRY(kaczmarz_sweep(g.A, true, dv.p, nullptr, dD.p, omega, start, stop, step, dx.p, nullptr));
+    else PAMG_TRY(kaczmarz_sweep(g.A, false, dx.p, dv.p, dD.p, omega, start, stop, step, nullptr, nullptr));
+    PAMG_HIP(hipDeviceSynchronize());
+    if (nr) PAMG_TRY(dv.get(v_nr, sizeof(T) * (size_t)n));
+    return dx.get(x, sizeof(T) * (size_t)n);
+}
+
+// jacobi_ne (relaxation.h:811-840), full row range: temp = sum over rows of omega * a_ij * delta_i in row order
+// -- an SpMV with the transposed operator whose values are omega * a_ij -- then x += temp
+template <typename T>
+int l1_jacobi_ne(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size, T *x, int x_size,
+                 const T *delta, int delta_size, T *temp, int temp_size, int row_start, int row_stop, int row_step,
+                 const T *omega, int omega_size)
+{
+    if (!x || !delta || !temp || !omega || omega_size < 1) return PAMG_E_ARG;
+    PAMG_TRY(check_csr(Ap, Ap_size, Aj_size, Ax_size, 1));
+    const int n = Ap_size - 1;
+    if (n > x_size || n > delta_size || n > temp_size) return PAMG_E_ARG;
+    if (!(row_start == 0 && row_stop == n && row_step == 1)) return PAMG_E_UNSUPPORTED;   // the wrapper's only call
+    if (n == 0) return PAMG_OK;
+    const int nnz = Ap[n];
+    std::vector<int32_t> tp((size_t)n + 1, 0), tj((size_t)std::max(nnz, 1));
+    std::vector<T> tx((size_t)std::max(nnz, 1));
+    for (int p = 0; p < nnz; ++p) {
+        if (Aj[p] < 0 || Aj[p] >= n) return PAMG_E_ARG;
+        tp[Aj[p] + 1]++;
+    }
+    for (int j = 0; j < n; ++j) tp[j + 1] += tp[j];
+    std::vector<int32_t> cur(tp.begin(), tp.end() - 1);
+    const T om = omega[0];
+    for (int i = 0; i < n; ++i)
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int q = cur[Aj[p]]++;
+            tj[q] = i;
+            tx[q] = om * Ax[p];                          // omega2 * conjugate(Ax[j]), :835
+        }
+    MatGuard g;
+    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), PAMG_CSR, n, n, 1, 1, tp.data(), tj.data(), tx.data()));
+    DevBuf dx, dd, dtmp;
+    PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
+    PAMG_TRY(dd.put(delta, sizeof(T) * (size_t)n));
+    PAMG_TRY(dtmp.alloc(sizeof(T) * (size_t)n));
+    PAMG_TRY(stream_launch(g.A, EPI_SET, dd.p, nullptr, dtmp.p, 0.0, 0.0, nullptr, nullptr));
+    PAMG_TRY(vec_axpy(dt<T>(), n, 1.0, dtmp.p, dx.p, nullptr));
+    PAMG_HIP(hipDeviceSynchronize());
+    PAMG_TRY(dtmp.get(temp, sizeof(T) * (size_t)n));
+    return dx.get(x, sizeof(T) * (size_t)n);
+}
+
 template <typename T>
 int l1_block(bool gs, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size,
              T *x, int x_size, const T *b, int b_size, const T *Tx, int Tx_size, T *temp, int temp_size,
@@ -285,6 +352,23 @@ int pamg_event_elapsed_ms(pamg_event_t a, pamg_event_t b, float *ms) { return ms
                           int omega_size)                                                                       \
     { return l1_jacobi<T>(false, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, temp, temp_size,  \
                           row_start, row_stop, row_step, 1, omega, omega_size); }                               \
+    int pamg_gauss_seidel_ne_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, \
+                                   int Ax_size, T *x, int x_size, const T *b, int b_size, int32_t row_start,   \
+                                   int32_t row_stop, int32_t row_step, const T *Tx, int Tx_size, T omega)      \
+    { return l1_kaczmarz<T>(false, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, nullptr, b, b_size,       \
+                            row_start, row_stop, row_step, Tx, Tx_size, (double)omega); }                       \
+    int pamg_gauss_seidel_nr_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, \
+                                   int Ax_size, T *x, int x_size, T *z, int z_size, int32_t col_start,         \
+                                   int32_t col_stop, int32_t col_step, const T *Tx, int Tx_size, T omega)      \
+    { return l1_kaczmarz<T>(true, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, z, nullptr, z_size,        \
+                            col_start, col_stop, col_step, Tx, Tx_size, (double)omega); }                       \
+    int pamg_jacobi_ne_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,       \
+                             int Ax_size, T *x, int x_size, const T *b, int b_size, const T *Tx, int Tx_size,  \
+                             T *temp, int temp_size, int32_t row_start, int32_t row_stop, int32_t row_step,    \
+                             const T *omega, int omega_size)                                                   \
+    { (void)b; (void)b_size;                                                                                    \
+      return l1_jacobi_ne<T>(Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, Tx, Tx_size, temp, temp_size,   \
+                             row_start, row_stop, row_step, omega, omega_size); }                               \
     int pamg_jacobi_indexed_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,  \
                                   int Ax_size, T *x, int x_size, const T *b, int b_size,                        \
                                   const int32_t *indices, int indices_size, const T *omega, int omega_size)     \

@@ -498,3 +498,22 @@ def test_normal_equation_smoothers_bit_exact():
         assert np.array_equal(y, z[f"{tag}.jacobi_ne"]), tag
     with pytest.raises(ValueError):
         grelax.gauss_seidel_nr(M, x.copy(), b, sweep="sideways")
+    # Layer 1: the amg_core twins on host buffers, driven exactly as the reference's wrappers drive amg_core
+    import pyamg_amd.amg_core as gcore
+    from pyamg_amd.hierarchy import _normal_equation_spec
+    ne = _normal_equation_spec("gauss_seidel_ne", M, 1, "forward", 0.9)
+    nr = _normal_equation_spec("gauss_seidel_nr", M, 1, "forward", 1.1)
+    y = x.copy()
+    for _ in range(2):
+        gcore.gauss_seidel_ne(M.indptr, M.indices, M.data, y, b, 0, n, 1, ne.Dinv, 0.9)
+    assert np.array_equal(y, z[f"{tag}.gauss_seidel_ne.forward"])
+    y = x.copy(); r = b - M @ y
+    for _ in range(2):
+        gcore.gauss_seidel_nr(nr.At.indptr, nr.At.indices, nr.At.data, y, r, n - 1, -1, -1, nr.Dinv, 1.1)
+    assert np.array_equal(y, z[f"{tag}.gauss_seidel_nr.backward"])
+    y = x.copy(); temp = np.zeros(n)
+    jn = _normal_equation_spec("jacobi_ne", M, 1, "forward", 0.6)
+    for _ in range(3):
+        delta = (np.ravel(b - M @ y) * jn.Dinv).astype(M.dtype)
+        gcore.jacobi_ne(M.indptr, M.indices, M.data, y, b, delta, temp, 0, n, 1, np.array([0.6]))
+    assert np.array_equal(y, z[f"{tag}.jacobi_ne"])
