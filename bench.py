@@ -54,6 +54,13 @@ WORKLOADS = {
                 label="3D linear elasticity 40^3 vertices (BSR 3x3, 187K dof) SA V-cycle, block Jacobi, fp64"),
     "c5g": dict(grid=(40,), elasticity=True, smoother="block_gauss_seidel",
                 label="3D linear elasticity 40^3 vertices (BSR 3x3, 187K dof) SA V-cycle, block Gauss-Seidel (SA default), fp64"),
+    # the "next" rows measured the same way: what pyamg.solve() configures for a NON-symmetric operator
+    # (blackbox.py:100-131: energy-minimisation SA + gauss_seidel_nr, 2 symmetric sweeps) and the AIR solver
+    # (classical/air.py: FC Jacobi) on upwind convection-diffusion
+    "c6n": dict(grid=(384, 384), convdiff=3.0, kind="blackbox", smoother="gauss_seidel_nr",
+                label="2D upwind convection-diffusion 384^2, pyamg.solve() configuration (SA energy-min, gauss_seidel_nr x2 symmetric) V-cycle, fp64"),
+    "c7a": dict(grid=(512, 512), convdiff=3.0, kind="air", smoother="fc_jacobi",
+                label="2D upwind convection-diffusion 512^2, AIR V-cycle (FC Jacobi: 2 F-sweeps + 1 C-sweep), fp64"),
     "small": dict(grid=(64, 64, 64), smoother=GS,
                   label="3D 7-pt Poisson 64^3 SA V-cycle, symmetric Gauss-Seidel, fp64 (smoke)"),
 }
@@ -132,6 +139,20 @@ def main():
             np.random.seed(SEED)
             ml = pyamg.smoothed_aggregation_solver(A, B=B, smooth="jacobi", presmoother=wl["smoother"],
                                                    postsmoother=wl["smoother"], max_coarse=10)
+            return A, ml, time.time() - t0
+        if wl.get("convdiff"):
+            import scipy.sparse as sp
+            mx, my = wl["grid"]
+            Dx = sp.diags_array([np.ones(mx), -np.ones(mx - 1)], offsets=[0, -1], shape=(mx, mx))
+            Dy = sp.diags_array([2 * np.ones(my), -np.ones(my - 1), -np.ones(my - 1)], offsets=[0, -1, 1], shape=(my, my))
+            A = sp.csr_array(wl["convdiff"] * sp.kron(sp.eye_array(my), Dx) + sp.kron(Dy, sp.eye_array(mx)))
+            A.sort_indices()
+            np.random.seed(SEED)
+            if wl["kind"] == "air":
+                ml = pyamg.air_solver(A, max_coarse=20)
+            else:
+                from pyamg import blackbox
+                ml = blackbox.solver(A, blackbox.solver_configuration(A, verb=False))
             return A, ml, time.time() - t0
         A = pyamg.gallery.poisson(wl["grid"], format="csr")
         np.random.seed(SEED)                   # Arnoldi start vectors of the smoother setup

@@ -103,6 +103,7 @@ struct LineSchedule {
     int start = 0, stop = 0, step = 0;
     int nlevels = 0;
     int *d_lines = nullptr;          // line ids, level after level
+    int *d_level_ptr = nullptr;      // device copy of level_ptr (persistent kernel)
     std::vector<int> level_ptr;      // [nlevels+1]
     size_t bytes = 0;
 };

@@ -970,20 +970,11 @@ __global__ __launch_bounds__(BLK) void vec_gather_kernel(int64_t n, const int *i
         dst[i] = src[idx[i]];
 }
 
-// One dependency level of a Kaczmarz-type sweep: every listed "line" (a row of A for Gauss-Seidel NE,
-// a column of A for Gauss-Seidel NR) is handled by one lane -- in-order dot with the read-modify-write
-// vector v, the step, then the in-order scatter update.  Lines of one level share no index of v (host
-// schedule), so no atomics and the result is the sequential sweep's, bit for bit.
-//   NR = false: amg_core::gauss_seidel_ne (relaxation.h:889-902): d = (b_i - s) * Dinv_i * omega; v[j] += a d
-//   NR = true : amg_core::gauss_seidel_nr (relaxation.h:954-973): d = s * (Dinv_i * omega); x_i += d; v[j] -= d a
+// one line of a Kaczmarz-type sweep (shared by the per-level and the persistent kernels)
 template <typename T, bool NR>
-__global__ __launch_bounds__(BLK) void kaczmarz_level_kernel(const int *lines, int first, int count, const int *Lp,
-                                                             const int *Lj, const T *Lx, T *v, const T *b,
-                                                             const T *Dinv, T omega, T *xout)
+__device__ __forceinline__ void kaczmarz_line(int i, const int *Lp, const int *Lj, const T *Lx, T *v, const T *b,
+                                              const T *Dinv, T omega, T *xout)
 {
-    const int k = (int)blockIdx.x * BLK + (int)threadIdx.x;
-    if (k >= count) return;
-    const int i = lines[first + k];
     const int lo = Lp[i], hi = Lp[i + 1];
     T s = T(0);
     for (int p = lo; p < hi; ++p) s += Lx[p] * v[Lj[p]];
@@ -1000,6 +991,39 @@ __global__ __launch_bounds__(BLK) void kaczmarz_level_kernel(const int *lines, i
             const T t = Lx[p] * d;
             v[Lj[p]] = v[Lj[p]] + t;
         }
+    }
+}
+
+// One dependency level of a Kaczmarz-type sweep: every listed "line" (a row of A for Gauss-Seidel NE,
+// a column of A for Gauss-Seidel NR) is handled by one lane -- in-order dot with the read-modify-write
+// vector v, the step, then the in-order scatter update.  Lines of one level share no index of v (host
+// schedule), so no atomics and the result is the sequential sweep's, bit for bit.
+//   NR = false: amg_core::gauss_seidel_ne (relaxation.h:889-902): d = (b_i - s) * Dinv_i * omega; v[j] += a d
+//   NR = true : amg_core::gauss_seidel_nr (relaxation.h:954-973): d = s * (Dinv_i * omega); x_i += d; v[j] -= d a
+template <typename T, bool NR>
+__global__ __launch_bounds__(BLK) void kaczmarz_level_kernel(const int *lines, int first, int count, const int *Lp,
+                                                             const int *Lj, const T *Lx, T *v, const T *b,
+                                                             const T *Dinv, T omega, T *xout)
+{
+    const int k = (int)blockIdx.x * BLK + (int)threadIdx.x;
+    if (k >= count) return;
+    kaczmarz_line<T, NR>(lines[first + k], Lp, Lj, Lx, v, b, Dinv, omega, xout);
+}
+
+// Persistent single-workgroup form: ONE launch walks all dependency levels with __syncthreads() between them
+// (same-CU visibility, as gs_flow1_kernel) -- the scheduler for narrow schedules (a few hundred lines per level:
+// 2-D operators), where one launch per level is pure launch latency.
+template <typename T, bool NR>
+__global__ __launch_bounds__(BLK) void kaczmarz_flow1_kernel(const int *lines, const int *level_ptr, int nlevels, const int *Lp,
+                                                             const int *Lj, const T *Lx, T *v, const T *b, const T *Dinv,
+                                                             T omega, T *xout)
+{
+    int first = level_ptr[0];
+    for (int l = 0; l < nlevels; ++l) {
+        const int end = level_ptr[l + 1];
+        for (int k = first + (int)threadIdx.x; k < end; k += BLK) kaczmarz_line<T, NR>(lines[k], Lp, Lj, Lx, v, b, Dinv, omega, xout);
+        first = end;
+        __syncthreads();
     }
 }
 

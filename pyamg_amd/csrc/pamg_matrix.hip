@@ -844,11 +844,12 @@ static int get_line_schedule(pamg_matrix_s *L, int start, int stop, int step, Li
     for (int l = 0; l < nl; ++l) g->level_ptr[l + 1] += g->level_ptr[l];
     std::vector<int> lines((size_t)std::max(m, 1)), cur(g->level_ptr.begin(), g->level_ptr.end() - (nl ? 1 : 0));
     for (int t = 0; t < m; ++t) lines[cur[lvl[t]]++] = start + t * step;
-    const int st = upload(&g->d_lines, lines.data(), (size_t)m, &g->bytes);
-    if (st) { delete g; return st; }
+    int st = upload(&g->d_lines, lines.data(), (size_t)m, &g->bytes);
+    if (!st) st = upload(&g->d_level_ptr, g->level_ptr.data(), g->level_ptr.size(), &g->bytes);
+    if (st) { hipFree(g->d_lines); delete g; return st; }
     int slot = -1;
     for (int k = 0; k < 4; ++k) if (!L->ls[k]) { slot = k; break; }
-    if (slot < 0) { hipFree(L->ls[3]->d_lines); delete L->ls[3]; slot = 3; }
+    if (slot < 0) { hipFree(L->ls[3]->d_lines); hipFree(L->ls[3]->d_level_ptr); delete L->ls[3]; slot = 3; }
     L->ls[slot] = g;
     L->bytes += g->bytes;
     *out = g;
@@ -869,6 +870,18 @@ int kaczmarz_sweep(pamg_matrix_s *L, bool nr, void *v, const void *b, const void
     if (L->R != 1 || L->C != 1) return PAMG_E_UNSUPPORTED;
     LineSchedule *g = nullptr;
     PAMG_TRY(get_line_schedule(L, start, stop, step, &g));
+    // narrow schedules (on average <= 512 lines per level: 2-D operators): ONE persistent workgroup walks the levels
+    // (about 2 us per level instead of a launch per level); gs_mode 1 keeps the per-level launches
+    const int m_lines = g->level_ptr.empty() ? 0 : g->level_ptr.back();
+    if (g->nlevels > 1 && L->gs_mode != 1 && (int64_t)m_lines <= (int64_t)512 * g->nlevels) {
+#define PAMG_KF(T, NRV)                                                                                                       \
+        hipLaunchKernelGGL((kaczmarz_flow1_kernel<T, NRV>), dim3(1), dim3(BLK), 0, s, g->d_lines, g->d_level_ptr, g->nlevels,  \
+                           L->d_Ap, L->d_Aj, (const T *)L->d_Ax, (T *)v, (const T *)b, (const T *)Dinv, (T)omega, (T *)xout)
+        if (L->dtype == PAMG_F64) { if (nr) PAMG_KF(double, true); else PAMG_KF(double, false); }
+        else { if (nr) PAMG_KF(float, true); else PAMG_KF(float, false); }
+#undef PAMG_KF
+        return (int)hipGetLastError();
+    }
     for (int l = 0; l < g->nlevels; ++l) {
         const int first = g->level_ptr[l], count = g->level_ptr[l + 1] - first;
         if (count <= 0) continue;
@@ -1143,7 +1156,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag); hipFree(A->d_rowid);
     hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
-    for (int k = 0; k < 4; ++k) if (A->ls[k]) { hipFree(A->ls[k]->d_lines); delete A->ls[k]; }
+    for (int k = 0; k < 4; ++k) if (A->ls[k]) { hipFree(A->ls[k]->d_lines); hipFree(A->ls[k]->d_level_ptr); delete A->ls[k]; }
     delete A;
     return PAMG_OK;
 }

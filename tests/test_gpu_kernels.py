@@ -498,6 +498,18 @@ def test_normal_equation_smoothers_bit_exact():
         assert np.array_equal(y, z[f"{tag}.jacobi_ne"]), tag
     with pytest.raises(ValueError):
         grelax.gauss_seidel_nr(M, x.copy(), b, sweep="sideways")
+    # both schedulers of the Kaczmarz sweeps: one persistent workgroup (default on these narrow schedules) and one
+    # launch per dependency level (gs_mode = 1)
+    from pyamg_amd.hierarchy import _normal_equation_spec as _nes
+    ne0 = _nes("gauss_seidel_ne", M, 1, "forward", 0.9)
+    dA = DeviceMatrix(sparse_op(M))
+    dD = capi.DeviceArray.from_host(ne0.Dinv)
+    db = capi.DeviceArray.from_host(b)
+    for mode in (0, 1):
+        dA.tune(gs_mode=mode)
+        dx = capi.DeviceArray.from_host(x)
+        dA.kaczmarz(dx, dD, 0.9, "symmetric", 2, b=db)
+        assert np.array_equal(dx.download(), z[f"{tag}.gauss_seidel_ne.symmetric"]), mode
     # Layer 1: the amg_core twins on host buffers, driven exactly as the reference's wrappers drive amg_core
     import pyamg_amd.amg_core as gcore
     from pyamg_amd.hierarchy import _normal_equation_spec
