@@ -59,6 +59,8 @@ WORKLOADS = {
     # (classical/air.py: FC Jacobi) on upwind convection-diffusion
     "c6n": dict(grid=(384, 384), convdiff=3.0, kind="blackbox", smoother="gauss_seidel_nr",
                 label="2D upwind convection-diffusion 384^2, pyamg.solve() configuration (SA energy-min, gauss_seidel_nr x2 symmetric) V-cycle, fp64"),
+    "c6n3": dict(grid=(64, 64, 64), convdiff=3.0, kind="blackbox", smoother="gauss_seidel_nr",
+                 label="3D upwind convection-diffusion 64^3, pyamg.solve() configuration (SA energy-min, gauss_seidel_nr x2 symmetric) V-cycle, fp64"),
     "c7a": dict(grid=(512, 512), convdiff=3.0, kind="air", smoother="fc_jacobi",
                 label="2D upwind convection-diffusion 512^2, AIR V-cycle (FC Jacobi: 2 F-sweeps + 1 C-sweep), fp64"),
     "small": dict(grid=(64, 64, 64), smoother=GS,
@@ -142,10 +144,14 @@ def main():
             return A, ml, time.time() - t0
         if wl.get("convdiff"):
             import scipy.sparse as sp
-            mx, my = wl["grid"]
+            mx, my = wl["grid"][:2]
             Dx = sp.diags_array([np.ones(mx), -np.ones(mx - 1)], offsets=[0, -1], shape=(mx, mx))
             Dy = sp.diags_array([2 * np.ones(my), -np.ones(my - 1), -np.ones(my - 1)], offsets=[0, -1, 1], shape=(my, my))
             A = sp.csr_array(wl["convdiff"] * sp.kron(sp.eye_array(my), Dx) + sp.kron(Dy, sp.eye_array(mx)))
+            if len(wl["grid"]) == 3:                     # + diffusion in z
+                mz = wl["grid"][2]
+                Dz = sp.diags_array([2 * np.ones(mz), -np.ones(mz - 1), -np.ones(mz - 1)], offsets=[0, -1, 1], shape=(mz, mz))
+                A = sp.csr_array(sp.kron(sp.eye_array(mz), A) + sp.kron(Dz, sp.eye_array(mx * my)))
             A.sort_indices()
             np.random.seed(SEED)
             if wl["kind"] == "air":
