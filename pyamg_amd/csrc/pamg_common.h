@@ -104,6 +104,8 @@ struct LineSchedule {
     int nlevels = 0;
     int *d_lines = nullptr;          // line ids, level after level
     int *d_level_ptr = nullptr;      // device copy of level_ptr (persistent kernel)
+    int *d_len = nullptr, *d_lo = nullptr, *d_ej = nullptr;   // persistent kernel: per scheduled line its length, first-entry
+    void *d_ea = nullptr;            //   offset and a dense slab of its first KZ entries (indices / values), schedule order
     std::vector<int> level_ptr;      // [nlevels+1]
     size_t bytes = 0;
 };
@@ -164,6 +166,7 @@ int vec_mul(int dtype, int64_t n, const void *a, const void *b, void *y, hipStre
 int kaczmarz_sweep(pamg_matrix_s *L, bool nr, void *v, const void *b, const void *Dinv, double omega, int start, int stop,
                    int step, void *xout, hipStream_t s);
 int ensure_line_schedule(pamg_matrix_s *L, int start, int stop, int step);
+void free_line_schedule(LineSchedule *g);
 int vec_scatter(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s);
 int matrix_row_subset(pamg_matrix_s *A, const int32_t *rows, int nrows, pamg_matrix_s **out);   // rows: HOST
 int jacobi_indexed(pamg_matrix_s *sub, void *x, const void *b, double omega, void *work, hipStream_t s);

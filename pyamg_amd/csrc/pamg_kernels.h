@@ -973,9 +973,9 @@ __global__ __launch_bounds__(BLK) void vec_gather_kernel(int64_t n, const int *i
 // one line of a Kaczmarz-type sweep (shared by the per-level and the persistent kernels)
 template <typename T, bool NR>
 __device__ __forceinline__ void kaczmarz_line(int i, const int *Lp, const int *Lj, const T *Lx, T *v, const T *b,
-                                              const T *Dinv, T omega, T *xout)
+                                              const T *Dinv, T omega, T *xout, int lo_ = 0, int len_ = -1)
 {
-    const int lo = Lp[i], hi = Lp[i + 1];
+    const int lo = len_ >= 0 ? lo_ : Lp[i], hi = len_ >= 0 ? lo_ + len_ : Lp[i + 1];
     T s = T(0);
     for (int p = lo; p < hi; ++p) s += Lx[p] * v[Lj[p]];
     if constexpr (NR) {
@@ -1010,20 +1010,89 @@ __global__ __launch_bounds__(BLK) void kaczmarz_level_kernel(const int *lines, i
     kaczmarz_line<T, NR>(lines[first + k], Lp, Lj, Lx, v, b, Dinv, omega, xout);
 }
 
-// Persistent single-workgroup form: ONE launch walks all dependency levels with __syncthreads() between them
-// (same-CU visibility, as gs_flow1_kernel) -- the scheduler for narrow schedules (a few hundred lines per level:
-// 2-D operators), where one launch per level is pure launch latency.
+// Persistent single-workgroup form (the scheduler for narrow schedules -- a few hundred lines per level: 2-D
+// operators, SA coarse levels -- where one launch per level is pure launch latency): ONE launch walks all dependency
+// levels with __syncthreads() between them (same-CU visibility, as gs_flow1_kernel), software-pipelined:
+// a level is one dependent step; everything a step needs
+// that does not depend on earlier steps is in registers before the step starts: the host lays the first KZ entries
+// of every scheduled line out as a dense slab in schedule order (so their addresses follow from the position alone),
+// and the line id of the level after next is fetched one level further ahead (Dinv / b need it).  What stays between
+// two barriers: gather v -> in-order dot -> step -> in-order scatter.  Lines longer than KZ entries continue from the
+// operator's arrays; levels wider than the workgroup fall back to kaczmarz_line for the surplus lines.
+constexpr int KZ = 8;
+
+template <typename T>
+struct KzSched {
+    const int *lines;      // [m] line id at scheduled position k
+    const int *level_ptr;  // [nlevels+1]
+    const int *len, *lo;   // [m] length of the line, offset of its first entry in Lj/Lx
+    const int *ej;         // [m*KZ] indices of the first KZ entries (unused slots: 0)
+    const T *ea;           // [m*KZ] their values (unused slots: 0)
+    int nlevels;
+};
+
 template <typename T, bool NR>
-__global__ __launch_bounds__(BLK) void kaczmarz_flow1_kernel(const int *lines, const int *level_ptr, int nlevels, const int *Lp,
-                                                             const int *Lj, const T *Lx, T *v, const T *b, const T *Dinv,
-                                                             T omega, T *xout)
+__global__ __launch_bounds__(BLK) void kaczmarz_flow1p_kernel(const KzSched<T> g, const int *Lj, const T *Lx, T *v,
+                                                              const T *b, const T *Dinv, T omega, T *xout)
 {
-    int first = level_ptr[0];
-    for (int l = 0; l < nlevels; ++l) {
-        const int end = level_ptr[l + 1];
-        for (int k = first + (int)threadIdx.x; k < end; k += BLK) kaczmarz_line<T, NR>(lines[k], Lp, Lj, Lx, v, b, Dinv, omega, xout);
-        first = end;
+    const int tid = (int)threadIdx.x;
+    struct Pre { int i, len, lo; int j[KZ]; T a[KZ]; T dinv, bb; };
+    Pre cur, nxt;
+    auto line_id = [&](int lvl) -> int {
+        if (lvl >= g.nlevels) return -1;
+        const int k = g.level_ptr[lvl] + tid;
+        return k < g.level_ptr[lvl + 1] ? g.lines[k] : -1;
+    };
+    auto fetch = [&](Pre &P, int lvl, int i) {               // i = line_id(lvl), already known
+        P.i = i;
+        P.len = 0; P.lo = 0; P.dinv = T(0); P.bb = T(0);
+        if (i >= 0) {
+            const int k = g.level_ptr[lvl] + tid;
+            P.len = g.len[k];
+            P.lo = g.lo[k];
+#pragma unroll
+            for (int e = 0; e < KZ; ++e) { P.j[e] = g.ej[(size_t)k * KZ + e]; P.a[e] = g.ea[(size_t)k * KZ + e]; }
+            P.dinv = Dinv[i];
+            if constexpr (!NR) P.bb = b[i];
+        } else {
+#pragma unroll
+            for (int e = 0; e < KZ; ++e) { P.j[e] = 0; P.a[e] = T(0); }
+        }
+    };
+    int i1 = line_id(0);
+    fetch(cur, 0, i1);
+    i1 = line_id(1);
+    for (int l = 0; l < g.nlevels; ++l) {
+        fetch(nxt, l + 1, i1);                               // operands of the next step, in flight during this one
+        const int i2 = line_id(l + 2);
+        if (cur.i >= 0) {
+            T x8[KZ];
+#pragma unroll
+            for (int e = 0; e < KZ; ++e) x8[e] = v[cur.j[e]];          // slot 0.. beyond len reads v[0]: unused
+            T s = T(0);
+#pragma unroll
+            for (int e = 0; e < KZ; ++e) if (e < cur.len) s += cur.a[e] * x8[e];
+            for (int p = cur.lo + KZ; p < cur.lo + cur.len; ++p) s += Lx[p] * v[Lj[p]];
+            T d;
+            if constexpr (NR) { d = s * (cur.dinv * omega); xout[cur.i] = xout[cur.i] + d; }
+            else d = (cur.bb - s) * cur.dinv * omega;
+#pragma unroll
+            for (int e = 0; e < KZ; ++e)
+                if (e < cur.len) {
+                    if constexpr (NR) { const T t = d * cur.a[e]; v[cur.j[e]] = v[cur.j[e]] - t; }
+                    else { const T t = cur.a[e] * d; v[cur.j[e]] = v[cur.j[e]] + t; }
+                }
+            for (int p = cur.lo + KZ; p < cur.lo + cur.len; ++p) {
+                if constexpr (NR) { const T t = d * Lx[p]; v[Lj[p]] = v[Lj[p]] - t; }
+                else { const T t = Lx[p] * d; v[Lj[p]] = v[Lj[p]] + t; }
+            }
+        }
+        // levels wider than the workgroup: the surplus lines, one after the other per lane
+        for (int k = g.level_ptr[l] + BLK + tid; k < g.level_ptr[l + 1]; k += BLK)
+            kaczmarz_line<T, NR>(g.lines[k], nullptr, Lj, Lx, v, b, Dinv, omega, xout, g.lo[k], g.len[k]);
         __syncthreads();
+        cur = nxt;
+        i1 = i2;
     }
 }
 

@@ -812,6 +812,13 @@ int vec_mul(int dtype, int64_t n, const void *a, const void *b, void *y, hipStre
     return (int)hipGetLastError();
 }
 
+void free_line_schedule(LineSchedule *g)
+{
+    if (!g) return;
+    hipFree(g->d_lines); hipFree(g->d_level_ptr); hipFree(g->d_len); hipFree(g->d_lo); hipFree(g->d_ej); hipFree(g->d_ea);
+    delete g;
+}
+
 // Order-exact schedule of a Kaczmarz-type sweep over the rows of L in the order (start, stop, step): level of
 // a line = 1 + the highest level among EARLIER lines that touch one of its indices -- found in O(nnz) with one
 // "highest level seen so far" per index (the conflict graph L L^T is never formed).
@@ -846,10 +853,30 @@ static int get_line_schedule(pamg_matrix_s *L, int start, int stop, int step, Li
     for (int t = 0; t < m; ++t) lines[cur[lvl[t]]++] = start + t * step;
     int st = upload(&g->d_lines, lines.data(), (size_t)m, &g->bytes);
     if (!st) st = upload(&g->d_level_ptr, g->level_ptr.data(), g->level_ptr.size(), &g->bytes);
-    if (st) { hipFree(g->d_lines); delete g; return st; }
+    if (!st) {
+        // dense slab of the first KZ entries of every scheduled line (kaczmarz_flow1p_kernel)
+        const size_t ts = tsize(L->dtype);
+        std::vector<unsigned char> hAx((size_t)L->nnz * ts), ea((size_t)std::max(m, 1) * KZ * ts, 0);
+        if (L->nnz) st = (int)hipMemcpy(hAx.data(), L->d_Ax, (size_t)L->nnz * ts, hipMemcpyDeviceToHost);
+        std::vector<int> len((size_t)std::max(m, 1), 0), lo((size_t)std::max(m, 1), 0), ej((size_t)std::max(m, 1) * KZ, 0);
+        for (int k = 0; k < m; ++k) {
+            const int i = lines[k];
+            lo[k] = L->h_Ap[i];
+            len[k] = L->h_Ap[i + 1] - L->h_Ap[i];
+            for (int e = 0; e < std::min(len[k], KZ); ++e) {
+                ej[(size_t)k * KZ + e] = L->h_Aj[lo[k] + e];
+                std::memcpy(&ea[((size_t)k * KZ + e) * ts], &hAx[(size_t)(lo[k] + e) * ts], ts);
+            }
+        }
+        if (!st) st = upload(&g->d_len, len.data(), (size_t)m, &g->bytes);
+        if (!st) st = upload(&g->d_lo, lo.data(), (size_t)m, &g->bytes);
+        if (!st) st = upload(&g->d_ej, ej.data(), (size_t)m * KZ, &g->bytes);
+        if (!st) st = upload_raw(&g->d_ea, ea.data(), (size_t)m * KZ, ts, &g->bytes);
+    }
+    if (st) { free_line_schedule(g); return st; }
     int slot = -1;
     for (int k = 0; k < 4; ++k) if (!L->ls[k]) { slot = k; break; }
-    if (slot < 0) { hipFree(L->ls[3]->d_lines); hipFree(L->ls[3]->d_level_ptr); delete L->ls[3]; slot = 3; }
+    if (slot < 0) { free_line_schedule(L->ls[3]); slot = 3; }
     L->ls[slot] = g;
     L->bytes += g->bytes;
     *out = g;
@@ -875,10 +902,15 @@ int kaczmarz_sweep(pamg_matrix_s *L, bool nr, void *v, const void *b, const void
     const int m_lines = g->level_ptr.empty() ? 0 : g->level_ptr.back();
     if (g->nlevels > 1 && L->gs_mode != 1 && (int64_t)m_lines <= (int64_t)512 * g->nlevels) {
 #define PAMG_KF(T, NRV)                                                                                                       \
-        hipLaunchKernelGGL((kaczmarz_flow1_kernel<T, NRV>), dim3(1), dim3(BLK), 0, s, g->d_lines, g->d_level_ptr, g->nlevels,  \
-                           L->d_Ap, L->d_Aj, (const T *)L->d_Ax, (T *)v, (const T *)b, (const T *)Dinv, (T)omega, (T *)xout)
-        if (L->dtype == PAMG_F64) { if (nr) PAMG_KF(double, true); else PAMG_KF(double, false); }
-        else { if (nr) PAMG_KF(float, true); else PAMG_KF(float, false); }
+        {                                                                                                                     \
+            KzSched<T> ks;                                                                                                    \
+            ks.lines = g->d_lines; ks.level_ptr = g->d_level_ptr; ks.len = g->d_len; ks.lo = g->d_lo; ks.ej = g->d_ej;        \
+            ks.ea = (const T *)g->d_ea; ks.nlevels = g->nlevels;                                                              \
+            hipLaunchKernelGGL((kaczmarz_flow1p_kernel<T, NRV>), dim3(1), dim3(BLK), 0, s, ks, L->d_Aj, (const T *)L->d_Ax,    \
+                               (T *)v, (const T *)b, (const T *)Dinv, (T)omega, (T *)xout);                                   \
+        }
+        if (L->dtype == PAMG_F64) { if (nr) PAMG_KF(double, true) else PAMG_KF(double, false) }
+        else { if (nr) PAMG_KF(float, true) else PAMG_KF(float, false) }
 #undef PAMG_KF
         return (int)hipGetLastError();
     }
@@ -1156,7 +1188,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag); hipFree(A->d_rowid);
     hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
-    for (int k = 0; k < 4; ++k) if (A->ls[k]) { hipFree(A->ls[k]->d_lines); hipFree(A->ls[k]->d_level_ptr); delete A->ls[k]; }
+    for (int k = 0; k < 4; ++k) pamg::free_line_schedule(A->ls[k]);
     delete A;
     return PAMG_OK;
 }
