@@ -141,6 +141,60 @@ def test_extract_reads_back_smoother_parameters():
         H.extract(ml4)
 
 
+def test_extract_new_smoother_kinds_and_roundtrip(tmp_path):
+    """AIR (no presmoother + FC Jacobi), the blackbox configuration (gauss_seidel_nr) and the other
+    normal-equation smoothers: operands are built as the reference's wrappers build them, survive
+    save/load, and what the reference itself cannot run (float32 Dinv mismatch) is refused."""
+    import oracle.refimport as ri
+    if not ri.available():
+        pytest.skip("oracle/_ref not built")
+    import pyamg
+    from pyamg.util.utils import get_diagonal
+    m = 16
+    Dx = sp.diags_array([np.ones(m), -np.ones(m - 1)], offsets=[0, -1], shape=(m, m))
+    Dy = sp.diags_array([2 * np.ones(m), -np.ones(m - 1), -np.ones(m - 1)], offsets=[0, -1, 1], shape=(m, m))
+    A = sp.csr_array(3.0 * sp.kron(sp.eye_array(m), Dx) + sp.kron(Dy, sp.eye_array(m)))
+    A.sort_indices()
+    np.random.seed(2)
+    air = H.extract(pyamg.air_solver(A, max_coarse=20))
+    L0 = air.levels[0]
+    assert L0.pre.kind == "none" and L0.post.kind == "fc_jacobi" and L0.post.f_iterations == 2 and L0.post.c_iterations == 1
+    assert L0.post.Fpts.dtype == np.int32 and len(L0.post.Fpts) + len(L0.post.Cpts) == A.shape[0]
+    for kind, kw in (("gauss_seidel_nr", {"sweep": "symmetric", "iterations": 2}), ("gauss_seidel_ne", {"sweep": "backward"}),
+                     ("jacobi_ne", {"iterations": 2, "omega": 0.5, "withrho": False})):
+        np.random.seed(2)
+        ml = pyamg.ruge_stuben_solver(A, max_coarse=10, presmoother=(kind, kw), postsmoother=(kind, kw))
+        spec = H.extract(ml)
+        s0 = spec.levels[0].pre
+        assert s0.kind == kind and s0.iterations == kw.get("iterations", 1)
+        Mc = sp.csc_array(A)
+        if kind == "gauss_seidel_nr":
+            assert np.array_equal(s0.Dinv, np.ravel(get_diagonal(Mc, norm_eq=1, inv=True))) and s0.sweep == "symmetric"
+            assert np.array_equal(s0.At.indptr, Mc.indptr) and np.array_equal(s0.At.data, Mc.data)
+        else:
+            assert np.array_equal(s0.Dinv, np.ravel(get_diagonal(A, norm_eq=2, inv=True)))
+        if kind == "jacobi_ne":
+            assert s0.omega == 0.5 and np.array_equal(s0.At.data, 0.5 * Mc.data)
+        H.save_spec(tmp_path / "s.npz", spec)
+        spec2, _ = H.load_spec(tmp_path / "s.npz")
+        t0 = spec2.levels[0].pre
+        assert t0.kind == kind and np.array_equal(t0.Dinv, s0.Dinv) and (t0.At is None) == (s0.At is None)
+        if s0.At is not None:
+            assert np.array_equal(t0.At.data, s0.At.data) and np.array_equal(t0.At.indices, s0.At.indices)
+        # every coarse RS level is CSR here; unsorted ones are shipped sorted for the NE kinds / get an Ar for NR
+        for Ls, lv in zip(spec.levels[:-1], ml.levels[:-1]):
+            if kind == "gauss_seidel_nr":
+                assert (Ls.pre.Ar is None) == bool(lv.A.has_sorted_indices)
+            else:
+                M = sp.csr_array((Ls.A.data, Ls.A.indices, Ls.A.indptr), shape=Ls.A.shape)
+                assert M.has_sorted_indices
+    with pytest.raises(NotImplementedError):
+        H._normal_equation_spec("gauss_seidel_ne", sp.csr_array(A.astype(np.float32)), 1, "forward", 1.0)
+    H.save_spec(tmp_path / "a.npz", air)
+    air2, _ = H.load_spec(tmp_path / "a.npz")
+    assert np.array_equal(air2.levels[0].post.Fpts, L0.post.Fpts) and air2.levels[0].post.f_iterations == 2
+
+
 def test_header_is_plain_c_and_links(tmp_path):
     """include/pyamg_amd.h compiles as C99 and a C translation unit that references every
     declared entry point links against libpyamg_amd.so (no call is made: no GPU here)."""
