@@ -233,8 +233,12 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * inside one XCD's L2: 0 automatic (small operators), 1 always, 2 never; 8 = streaming flags of the
  * whole-operator kernels: bit 0 non-temporal loads of the operator stream, bit 1 XCD-aware
  * row-range order; 9 = LDS-staged x windows for the whole-operator kernels (re-plans);
- * 11 = record per-row-range time stamps of the granular sweep (diagnostics,
- * pamg_matrix_gs_profile). */
+ * 5 also accepts 5 = TILED sweep (one persistent workgroup per contiguous chunk of rows; dependency chains
+ * stay in LDS, only chunk-crossing edges use the global hand-off); 11 = record time stamps of the granular /
+ * tiled sweep (diagnostics, pamg_matrix_gs_profile); 12 = tiles of the tiled sweep (0 = automatic),
+ * 13 = its LDS ring slots (power of two, 256..8192), 14 = its entries per step (0 = automatic),
+ * 15 = let the automatic choice (key 5 = 0) prefer the tiled sweep.
+ * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* Pick the LDS window (key 0) and streaming flags (key 8) of the whole-operator kernels by timing
  * y = A x on the device with a few candidates (results are bit-identical for every choice; this
@@ -245,6 +249,10 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap);
  * 1 backward) eight 64-bit words {arrival, gate open, polled, staged, finished (wall clock, 10 ns),
  * XCD id, workgroup id, dependency level}.  out == NULL: only *count.  Synchronises. */
 int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count);
+/* Plan of the tiled sweep for schedule `which` (built by the first sweep / pamg_solver_finalize):
+ * {tiles, ring slots, entry pairs per lane, steps, early entries served from LDS, early entries served by the
+ * global hand-off, publishing rows, LDS bytes}; all zero when that schedule has no tile plan. */
+int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8]);
 /* Row-subset copy of a CSR operator (rows: HOST list, kept in list order) for the indexed smoothers,
  * and amg_core::jacobi_indexed (relaxation.h:382-427) on it: every listed row of x is relaxed from the
  * OLD x (x, b: DEVICE vectors of the parent's size; work: DEVICE, one value per listed row). */

@@ -95,6 +95,21 @@ struct GsSchedule {
     int max_level_blocks = 0;
     std::vector<int> level_blk;      // [nlevels+1] workgroup range of each level
     size_t bytes = 0;
+    std::vector<int> h_vis, h_lvl;   // scalar schedules: visit index (-1 = not swept) and dependency level of every row
+    bool has_level_part = false;     // the level-permuted copy above is built (granular / single-workgroup / per-level schedulers)
+    struct TileSched *tile = nullptr; // tiled sweep (pamg_tile_plan.h / pamg_tile_kernels.h), built on demand
+};
+
+// Device side of a tile plan: tile-major copy of the operator (rows of a tile in dependency-level order),
+// step descriptors, entry codes.
+struct TileSched {
+    int G = 0, W = 0, maxp = 4, nsteps = 0, lds = 0;
+    int4 *d_steps = nullptr;
+    int *d_tile_step = nullptr, *d_Ap = nullptr, *d_Aj = nullptr, *d_rid = nullptr;
+    void *d_Ax = nullptr, *d_diag = nullptr;
+    long long *d_prof = nullptr;     // [nsteps][4] diagnostics (tune key 11)
+    int64_t n_local = 0, n_global = 0, n_publish = 0, max_step_entries = 0;
+    size_t bytes = 0;
 };
 
 // Dependency levels of a Kaczmarz-type sweep over the lines (rows) of an operator: two lines conflict when they
@@ -141,7 +156,13 @@ struct pamg_matrix_s {
     int stream_flags = 0;            // StreamArgs::flags for the whole-operator launches
     int gran_xcd = 0;                // granular sweep inside one XCD's L2: 0 auto (small operators), 1 always, 2 never
     int gran_cap = 0;                // granular sweep: cap on the persistent grid (0 = auto)
-    int gs_mode = 0;                 // scalar sweep scheduler: 0 auto, 1 one launch per level, 2 granular, 3 single workgroup
+    int gs_mode = 0;                 // scalar sweep scheduler: 0 auto, 1 one launch per level, 2 granular, 3 single workgroup, 5 tiled
+    int tile_G = 0;                  // tiled sweep: tiles (0 = auto)
+    int tile_W = 2048;               // tiled sweep: LDS ring slots (power of two)
+    int tile_cap = 0;                // tiled sweep: scheduled entries per step (0 = auto)
+    bool tile_default = false;       // auto mode (gs_mode 0) prefers the tiled sweep
+    int max_row_len = 0;             // longest row of the scalar view
+    int borrowed = 0;                // solvers holding this operator (tuning is refused while > 0: captured graphs point into the schedules)
     int gs_prof = 0;                 // granular sweep: record per-range time stamps (tune key 11, diagnostics)
     int nblk = 0;
     int4 *d_blkmeta = nullptr;

@@ -6,6 +6,8 @@
 #include <thread>
 
 #include "pamg_kernels.h"
+#include "pamg_tile_kernels.h"
+#include "pamg_tile_plan.h"
 
 using namespace pamg;
 
@@ -197,9 +199,12 @@ int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap)
     return PAMG_OK;
 }
 
+void free_tile_part(TileSched *t);
+
 void free_schedule(GsSchedule *g)
 {
     if (!g) return;
+    free_tile_part(g->tile);
     hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_xold); hipFree(g->d_pblk); hipFree(g->d_dpos); hipFree(g->d_prof);
     delete g;
 }
@@ -278,19 +283,53 @@ bool pattern_symmetric(int n, const int *Ap, const int *Aj, const std::vector<in
     return ok.load();
 }
 
-// schedule for the scalar (streamed) path: level-permuted copy of the operator
-int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out)
+// A scalar schedule starts as the ANALYSIS only (visit index and dependency level of every row, symmetry of the
+// swept pattern, the hand-off buffers); the device copies of the operator are built on demand for the scheduler
+// that is going to run: the level-permuted copy (build_level_part) or the tile-major copy (build_tile_part).
+int new_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out)
 {
-    std::vector<int> order, lptr, vis;
-    PAMG_TRY(analyse_levels((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), row_start, row_stop,
-                            row_step, order, lptr, &vis));
     GsSchedule *g = new (std::nothrow) GsSchedule();
     if (!g) return PAMG_E_ALLOC;
+    int m = 0, nl = 0;
+    if (sweep_levels((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), row_start, row_stop, row_step, g->h_vis, g->h_lvl, m, nl)) {
+        delete g;
+        return PAMG_E_ARG;
+    }
     g->row_start = row_start; g->row_stop = row_stop; g->row_step = row_step;
-    g->nlevels = (int)lptr.size() - 1;
-    g->nrows = (int64_t)order.size();
-    g->symmetric = pattern_symmetric((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), vis);
-    const int m = (int)order.size();
+    g->nlevels = nl;
+    g->nrows = m;
+    g->symmetric = pattern_symmetric((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), g->h_vis);
+    const size_t ts = tsize(A->dtype);
+    const size_t xb = ((size_t)A->nrows + 8) * ts;     // hand-off buffer of the granular / tiled sweeps
+    int st = (int)hipMalloc(&g->d_xs, xb);
+    if (!st) g->bytes += xb;
+    if (!st && !g->symmetric) {                        // + snapshot of x (allocated here: sweeps may run inside a graph capture)
+        st = (int)hipMalloc(&g->d_xold, xb);
+        if (!st) g->bytes += xb;
+    }
+    if (!st) st = (int)hipMalloc((void **)&g->d_sync, 2048);
+    if (!st) st = (int)hipMemset(g->d_sync, 0, 2048);
+    if (st) { free_schedule(g); return st; }
+    *out = g;
+    return PAMG_OK;
+}
+
+// level-permuted copy of the operator: the rows of each dependency level stored contiguously
+int build_level_part(pamg_matrix_s *A, GsSchedule *g)
+{
+    if (g->has_level_part) return PAMG_OK;
+    const int m = (int)g->nrows;
+    const std::vector<int> &vis = g->h_vis;
+    std::vector<int> lptr((size_t)g->nlevels + 1, 0), order((size_t)m);
+    for (int t = 0; t < m; ++t) lptr[g->h_lvl[g->row_start + t * g->row_step] + 1]++;
+    for (int l = 0; l < g->nlevels; ++l) lptr[l + 1] += lptr[l];
+    {
+        std::vector<int> cur(lptr.begin(), lptr.end() - 1);
+        for (int t = 0; t < m; ++t) {
+            const int i = g->row_start + t * g->row_step;
+            order[cur[g->h_lvl[i]]++] = i;
+        }
+    }
     std::vector<int> pAp((size_t)m + 1, 0);
     for (int r = 0; r < m; ++r) pAp[r + 1] = pAp[r] + (A->h_Ap[order[r] + 1] - A->h_Ap[order[r]]);
     g->nnz = pAp[m];
@@ -299,14 +338,16 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
     const size_t ts = tsize(A->dtype);
     std::vector<unsigned char> hAx((size_t)A->nnz * ts), pAx((size_t)g->nnz * ts);
     if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
-    for (int r = 0; r < m; ++r) {
-        const int i = order[r];
-        const int len = A->h_Ap[i + 1] - A->h_Ap[i];
-        if (len) {
-            std::memcpy(&pAj[pAp[r]], &A->h_Aj[A->h_Ap[i]], (size_t)len * sizeof(int));
-            std::memcpy(&pAx[(size_t)pAp[r] * ts], &hAx[(size_t)A->h_Ap[i] * ts], (size_t)len * ts);
+    parallel_rows(m, [&](int lo, int hi) {
+        for (int r = lo; r < hi; ++r) {
+            const int i = order[r];
+            const int len = A->h_Ap[i + 1] - A->h_Ap[i];
+            if (len) {
+                std::memcpy(&pAj[pAp[r]], &A->h_Aj[A->h_Ap[i]], (size_t)len * sizeof(int));
+                std::memcpy(&pAx[(size_t)pAp[r] * ts], &hAx[(size_t)A->h_Ap[i] * ts], (size_t)len * ts);
+            }
         }
-    }
+    });
     // "early" entries (column's row is visited earlier in this sweep: the NEW value is needed)
     // carry the sign bit of the column id; every sweep kernel masks it off, the granular
     // sweep uses it to know which values to wait for
@@ -323,38 +364,96 @@ int build_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row
     // diagonal of every stored row (last stored entry with j == i wins; 0 = none): carried by
     // the schedule so the sweep does not have to chase it after the LDS scan
     std::vector<unsigned char> pdiag((size_t)m * ts, 0);
-    for (int r = 0; r < m; ++r)
-        for (int p = pAp[r]; p < pAp[r + 1]; ++p)
-            if (pAj[p] == (order[r] | 0x40000000)) std::memcpy(&pdiag[(size_t)r * ts], &pAx[(size_t)p * ts], ts);
+    parallel_rows(m, [&](int lo, int hi) {
+        for (int r = lo; r < hi; ++r)
+            for (int p = pAp[r]; p < pAp[r + 1]; ++p)
+                if (pAj[p] == (order[r] | 0x40000000)) std::memcpy(&pdiag[(size_t)r * ts], &pAx[(size_t)p * ts], ts);
+    });
     std::vector<int4> blk;
     g->level_blk.assign(1, 0);
     for (int l = 0; l < g->nlevels; ++l) {
         plan_rows(pAp.data(), lptr[l], lptr[l + 1], A->cap, std::min(A->max_rows, BLK), blk);
         g->level_blk.push_back((int)blk.size());
     }
-    int st = upload(&g->d_Ap, pAp.data(), pAp.size(), &g->bytes);
-    if (!st) st = upload(&g->d_Aj, pAj.data(), pAj.size(), &g->bytes);
-    if (!st) st = upload_raw(&g->d_Ax, pAx.data(), (size_t)g->nnz, ts, &g->bytes);
-    if (!st) st = upload_raw(&g->d_diag, pdiag.data(), (size_t)m, ts, &g->bytes);
-    if (!st) st = upload(&g->d_rid, order.data(), order.size(), &g->bytes);
-    if (!st) st = upload(&g->d_blkmeta, blk.data(), blk.size(), &g->bytes);
-    if (!st) st = upload(&g->d_level_blk, g->level_blk.data(), g->level_blk.size(), &g->bytes);
+    size_t bytes = 0;
+    int st = upload(&g->d_Ap, pAp.data(), pAp.size(), &bytes);
+    if (!st) st = upload(&g->d_Aj, pAj.data(), pAj.size(), &bytes);
+    if (!st) st = upload_raw(&g->d_Ax, pAx.data(), (size_t)g->nnz, ts, &bytes);
+    if (!st) st = upload_raw(&g->d_diag, pdiag.data(), (size_t)m, ts, &bytes);
+    if (!st) st = upload(&g->d_rid, order.data(), order.size(), &bytes);
+    if (!st) st = upload(&g->d_blkmeta, blk.data(), blk.size(), &bytes);
+    if (!st) st = upload(&g->d_level_blk, g->level_blk.data(), g->level_blk.size(), &bytes);
     g->nblk_total = (int)blk.size();
-    if (!st) {                                  // hand-off buffer of the granular sweep
-        const size_t xb = ((size_t)A->nrows + 8) * ts;
-        st = (int)hipMalloc(&g->d_xs, xb);
-        if (!st) g->bytes += xb;
-        if (!st && !g->symmetric) {             // + snapshot of x (allocated here: sweeps may run inside a graph capture)
-            st = (int)hipMalloc(&g->d_xold, xb);
-            if (!st) g->bytes += xb;
-        }
-    }
-    if (!st) st = (int)hipMalloc((void **)&g->d_sync, 2048);
-    if (!st) st = (int)hipMemset(g->d_sync, 0, 2048);
+    g->max_level_blocks = 0;
     for (int l = 0; l < g->nlevels; ++l)
         g->max_level_blocks = std::max(g->max_level_blocks, g->level_blk[l + 1] - g->level_blk[l]);
-    if (st) { free_schedule(g); return st; }
-    *out = g;
+    if (st) return st;
+    g->bytes += bytes;
+    A->bytes += bytes;
+    g->has_level_part = true;
+    return PAMG_OK;
+}
+
+void free_tile_part(TileSched *t)
+{
+    if (!t) return;
+    hipFree(t->d_steps); hipFree(t->d_tile_step); hipFree(t->d_Ap); hipFree(t->d_Aj); hipFree(t->d_rid); hipFree(t->d_Ax); hipFree(t->d_diag); hipFree(t->d_prof);
+    delete t;
+}
+
+int tile_grid_max(int dtype, int epi, int maxp, int lds);
+
+// tile-major copy of the operator for the tiled sweep (pamg_tile_plan.h)
+int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
+{
+    if (g->tile) return PAMG_OK;
+    const int m = (int)g->nrows;
+    const size_t ts = tsize(A->dtype);
+    const int W = A->tile_W;
+    int cap = A->tile_cap > 0 ? A->tile_cap : 2 * MAXP_TILE * BLK - 2;
+    cap = std::min(cap, 2 * MAXP_TILE * BLK - 2);
+    // tiles: about seven rows of every dependency level per tile (measured sweet spot between the serial chain
+    // of steps inside a tile and the hand-offs between tiles), never more than can be co-resident
+    int G = A->tile_G;
+    if (G <= 0) G = (int)std::max<int64_t>(1, (int64_t)m / std::max<int64_t>(1, (int64_t)7 * g->nlevels));
+    TilePlan P;
+    const int lds_probe = (int)((2 * MAXP_TILE * BLK + 8) * ts + (size_t)W * (ts + 4) + 64);
+    G = std::max(1, std::min(G, tile_grid_max(A->dtype, EPI_GS, MAXP_TILE, lds_probe)));
+    if (build_tile_plan_from((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), g->row_start, g->row_step, m, g->nlevels,
+                             g->h_vis, g->h_lvl, G, W, cap, BLK, P))
+        return PAMG_E_ARG;
+    TileSched *t = new (std::nothrow) TileSched();
+    if (!t) return PAMG_E_ALLOC;
+    t->G = P.G; t->W = W; t->nsteps = (int)P.steps.size();
+    t->n_local = P.n_local; t->n_global = P.n_global; t->n_publish = P.n_publish;
+    for (const TileStep &s : P.steps) t->max_step_entries = std::max<int64_t>(t->max_step_entries, s.p1 - (s.p0 & ~1));
+    t->maxp = t->max_step_entries <= 2 * 2 * BLK ? 2 : MAXP_TILE;
+    t->lds = (int)((2 * t->maxp * BLK + 8) * ts + (size_t)W * (ts + 4) + 64);
+    const int nnz = P.Ap[m];
+    std::vector<unsigned char> hAx((size_t)A->nnz * ts), pAx((size_t)nnz * ts), pdiag((size_t)m * ts, 0);
+    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    parallel_rows(m, [&](int lo, int hi) {
+        for (int r = lo; r < hi; ++r) {
+            const int i = P.rid[r] & COL_MASK;
+            for (int q = P.Ap[r]; q < P.Ap[r + 1]; ++q) {
+                std::memcpy(&pAx[(size_t)q * ts], &hAx[(size_t)P.src[q] * ts], ts);
+                // diagonal: last stored a_ii wins, like the reference (relaxation.h:64-74)
+                if (A->h_Aj[P.src[q]] == i) std::memcpy(&pdiag[(size_t)r * ts], &hAx[(size_t)P.src[q] * ts], ts);
+            }
+        }
+    });
+    static_assert(sizeof(TileStep) == sizeof(int4), "step descriptor layout");
+    int st = upload(&t->d_Ap, P.Ap.data(), P.Ap.size(), &t->bytes);
+    if (!st) st = upload(&t->d_Aj, P.Aj.data(), P.Aj.size(), &t->bytes);
+    if (!st) st = upload_raw(&t->d_Ax, pAx.data(), (size_t)nnz, ts, &t->bytes);
+    if (!st) st = upload_raw(&t->d_diag, pdiag.data(), (size_t)m, ts, &t->bytes);
+    if (!st) st = upload(&t->d_rid, P.rid.data(), P.rid.size(), &t->bytes);
+    if (!st) st = upload_raw((void **)&t->d_steps, P.steps.data(), P.steps.size(), sizeof(int4), &t->bytes);
+    if (!st) st = upload(&t->d_tile_step, P.tile_step.data(), P.tile_step.size(), &t->bytes);
+    if (st) { free_tile_part(t); return st; }
+    g->tile = t;
+    g->bytes += t->bytes;
+    A->bytes += t->bytes;
     return PAMG_OK;
 }
 
@@ -418,6 +517,7 @@ int build_schedule_block(pamg_matrix_s *A, int row_start, int row_stop, int row_
     if (!st) st = (int)hipMalloc((void **)&g->d_sync, 2048);
     if (!st) st = (int)hipMemset(g->d_sync, 0, 2048);
     if (st) { free_schedule(g); return st; }
+    g->has_level_part = true;
     *out = g;
     return PAMG_OK;
 }
@@ -434,7 +534,7 @@ int get_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step, Gs
     GsSchedule *g = nullptr;
     const bool block = (A->R > 1);
     PAMG_TRY(block ? build_schedule_block(A, row_start, row_stop, row_step, &g)
-                   : build_schedule_scalar(A, row_start, row_stop, row_step, &g));
+                   : new_schedule_scalar(A, row_start, row_stop, row_step, &g));
     int slot = -1;
     for (int k = 0; k < 4; ++k) if (!A->gs[k]) { slot = k; break; }
     if (slot < 0) { free_schedule(A->gs[3]); slot = 3; }
@@ -542,8 +642,88 @@ static int flow1_launch(int npl, int lds, hipStream_t s, const FlowArgs<T> &f)
     return (int)hipGetLastError();
 }
 
-// Scheduling policy of the order-exact sweeps (measured on the 96^3 and 256^3 smoothed-aggregation
-// hierarchies, profiles/r01_microbench_gs_*.json; every scheduler gives the same bits):
+// ---- tiled sweep: launch plumbing
+template <typename T, int EPI>
+static const void *tile_kernel_ptr(int maxp)
+{
+    return maxp == 2 ? (const void *)gs_tile_kernel<T, EPI, 2> : (const void *)gs_tile_kernel<T, EPI, MAXP_TILE>;
+}
+
+template <typename T>
+static const void *tile_kernel_any(int epi, int maxp)
+{
+    switch (epi) {
+        case EPI_GS: return tile_kernel_ptr<T, EPI_GS>(maxp);
+        case EPI_GS_B: return tile_kernel_ptr<T, EPI_GS_B>(maxp);
+        case EPI_SOR: return tile_kernel_ptr<T, EPI_SOR>(maxp);
+    }
+    return nullptr;
+}
+
+}  // namespace pamg
+
+namespace {
+// ceiling of the tiled sweep's grid: every workgroup must be resident for the whole launch.  (occupancy - 1, at
+// least 1) per CU: the occupancy query can over-report by one per CU (MI355X_MICROARCH.md, residency)
+int tile_grid_max(int dtype, int epi, int maxp, int lds)
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        else cus = 64;
+    }
+    const void *k = dtype == PAMG_F64 ? pamg::tile_kernel_any<double>(epi, maxp) : pamg::tile_kernel_any<float>(epi, maxp);
+    int nb = 0;
+    if (!k || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, TILE_THREADS, (size_t)lds) != hipSuccess) nb = 1;
+    nb = std::max(1, std::min(nb - 1, 3));
+    return nb * cus;
+}
+}  // namespace
+
+namespace pamg {
+
+template <typename T>
+static int tile_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s)
+{
+    TileSched *t = g->tile;
+    const size_t ts = tsize(A->dtype);
+    const int64_t n = A->nrows;
+    TileArgs<T> a;
+    a.steps = t->d_steps; a.tile_step = t->d_tile_step;
+    a.Ap = t->d_Ap; a.Aj = t->d_Aj; a.Ax = (const T *)t->d_Ax; a.rid = t->d_rid; a.diag = (const T *)t->d_diag;
+    a.x = (const T *)x; a.xs = (T *)g->d_xs; a.y = (T *)x; a.b = (const T *)b;
+    a.err = g->d_sync + 1;
+    a.omega = (T)omega; a.W = t->W; a.G = t->G;
+    a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
+    if (!g->symmetric) {
+        // write-after-read hazards are not ordered by the waits: old values come from a snapshot
+        if (!g->d_xold) return PAMG_E_STATE;
+        PAMG_HIP(hipMemcpyAsync(g->d_xold, x, (size_t)n * ts, hipMemcpyDeviceToDevice, s));
+        a.x = (const T *)g->d_xold;
+    }
+    if (A->gs_prof && !t->d_prof) {
+        PAMG_HIP(hipMalloc((void **)&t->d_prof, (size_t)t->nsteps * 4 * sizeof(long long)));
+        PAMG_HIP(hipMemset(t->d_prof, 0, (size_t)t->nsteps * 4 * sizeof(long long)));
+    }
+    a.prof = A->gs_prof ? t->d_prof : nullptr;
+    if (t->n_publish) {
+        const int fgrid = (int)std::min<int64_t>(4096, (n + BLK - 1) / BLK);
+        hipLaunchKernelGGL((fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)g->d_xs, n);
+        PAMG_HIP(hipGetLastError());
+    }
+    const void *k = tile_kernel_any<T>(epi, t->maxp);
+    if (!k) return PAMG_E_ARG;
+    if (t->lds > 48 * 1024) PAMG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, t->lds));
+    void *args[] = {(void *)&a};
+    PAMG_HIP(hipLaunchKernel(k, dim3(t->G), dim3(TILE_THREADS), args, (size_t)t->lds, s));
+    return PAMG_OK;
+}
+
+// Scheduling policy of the order-exact sweeps (every scheduler gives the same bits):
+//  * tiled sweep (gs_mode 5; pamg_tile_kernels.h): one persistent workgroup per contiguous chunk of rows, dependency
+//    chains stay in LDS, only tile-crossing edges use the global hand-off;
 //  * narrow schedules (<= flow_cap/16 row ranges per level on average, default 2): ONE workgroup
 //    walks all ranges with __syncthreads() and cached accesses (1.4-2 us per range);
 //  * otherwise the granular sweep: no barriers, the published datum is the flag (1.8-2.7 us per
@@ -551,10 +731,31 @@ static int flow1_launch(int npl, int lds, hipStream_t s, const FlowArgs<T> &f)
 //    operators (vectors fit one XCD's 4 MB L2, <= 4 ranges per level) keep the hand-off inside one
 //    XCD; patterns that are not structurally symmetric read old values from a snapshot of x;
 //  * one launch per level only as the fallback (oversized LDS window, 1- or 4-entries-per-lane plans).
+static bool tile_eligible(const pamg_matrix_s *A, const GsSchedule *g)
+{
+    return g->nlevels > 1 && A->max_row_len <= 2 * MAXP_TILE * BLK - 2 && g->d_xs != nullptr;
+}
+
+static bool want_tiles(const pamg_matrix_s *A, const GsSchedule *g)
+{
+    if (!tile_eligible(A, g)) return false;
+    return A->gs_mode == 5 || (A->gs_mode == 0 && A->tile_default);
+}
+
+// device copies the scheduler of choice needs (called before any graph capture through ensure_schedule)
+static int ensure_parts(pamg_matrix_s *A, GsSchedule *g)
+{
+    if (A->R > 1) return PAMG_OK;
+    if (want_tiles(A, g)) return build_tile_part(A, g);
+    return build_level_part(A, g);
+}
+
 template <typename T>
 static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b,
                              double omega, hipStream_t s)
 {
+    PAMG_TRY(ensure_parts(A, g));
+    if (want_tiles(A, g)) return tile_launch<T>(A, g, epi, x, b, omega, s);
     StreamArgs<T> a = base_args<T>(A, x, b, x, 0.0, omega, nullptr);
     a.Ap = g->d_Ap;
     a.Aj = g->d_Aj;
@@ -564,7 +765,7 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
     const int lds = lds_bytes(A->dtype, epi, A->cap);
     const bool can_persist = lds <= 48 * 1024 && g->nlevels > 1 && A->gs_mode != 1;
     const bool narrow = (int64_t)g->nblk_total * 16 <= (int64_t)g->nlevels * A->flow_cap;
-    const bool single = can_persist && (A->gs_mode == 3 || (A->gs_mode == 0 && narrow));
+    const bool single = can_persist && (A->gs_mode == 3 || ((A->gs_mode == 0 || A->gs_mode == 5) && narrow));
     const bool granular = can_persist && !single && A->npl == 2 && g->d_xs;
     if (single) {
         FlowArgs<T> f;
@@ -760,7 +961,8 @@ int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *
 int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step)
 {
     GsSchedule *g = nullptr;
-    return get_schedule(A, row_start, row_stop, row_step, &g);
+    PAMG_TRY(get_schedule(A, row_start, row_stop, row_step, &g));
+    return ensure_parts(A, g);
 }
 
 // deterministic sum of n partials -> out[0].  Large n goes through 256 intermediate sums
@@ -1105,7 +1307,13 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
     if (flavour == PAMG_CSR && (R != 1 || C != 1)) return PAMG_E_ARG;
     if (R > MAXBS || C > MAXBS) return PAMG_E_UNSUPPORTED;
     const int64_t nblk = Ap[n_brow];
-    if (nblk < 0 || (nblk > 0 && (!Aj || !Ax))) return PAMG_E_ARG;
+    if (nblk < 0 || (nblk > 0 && (!Aj || !Ax)) || Ap[0] != 0) return PAMG_E_ARG;
+    // a malformed operator would mean out-of-bounds device accesses and (with the flag bits the schedules put
+    // into column ids) wrong dependency analysis: check the structure once, here
+    for (int i = 0; i < n_brow; ++i)
+        if (Ap[i + 1] < Ap[i]) return PAMG_E_ARG;
+    for (int64_t p = 0; p < nblk; ++p)
+        if (Aj[p] < 0 || Aj[p] >= n_bcol) return PAMG_E_ARG;
     // column ids carry two flag bits in the level schedules (pamg_kernels.h: EARLY_BIT, DIAG_BIT)
     if ((int64_t)n_brow * R > (1 << 30) || (int64_t)n_bcol * C > (1 << 30) || nblk * R * C > INT32_MAX)
         return PAMG_E_UNSUPPORTED;
@@ -1173,6 +1381,7 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
             if (!st) st = upload(&A->d_bdiag, bdiag.data(), bdiag.size(), &A->bytes);
         }
     }
+    for (int64_t i = 0; i < A->nrows && !st; ++i) A->max_row_len = std::max(A->max_row_len, A->h_Ap[i + 1] - A->h_Ap[i]);
     // default plan (measured best on 256^3 Poisson): 1536 staged entries = 12 KB (SpMV) / 18 KB
     // (smoothers, with column ids) of LDS per workgroup -> 8 workgroups = 32 waves per CU
     A->cap = 1536; A->npl = 2; A->max_rows = 1024;
@@ -1212,18 +1421,31 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8])
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
 {
     if (!A) return PAMG_E_ARG;
+    // a finalised solver's captured graphs point into the schedules and plans this call would free
+    if (A->borrowed > 0) return PAMG_E_STATE;
     switch (key) {
         case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~3; break;
         case 1: if (value != 1 && value != 2 && value != 4) return PAMG_E_ARG; A->npl = value; break;
         case 2: if (value < 1) return PAMG_E_ARG; A->max_rows = value; break;
         case 3: if (value < 0 || value > 256) return PAMG_E_ARG; A->flow_cap = value; return PAMG_OK;
-        case 5: if (value < 0 || value > 4) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
+        case 5: if (value < 0 || value > 5) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
         case 6: if (value < 0) return PAMG_E_ARG; A->gran_cap = value; return PAMG_OK;
         case 7: if (value < 0 || value > 2) return PAMG_E_ARG; A->gran_xcd = value; return PAMG_OK;
         case 8: if (value < 0 || value > 15) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;
         case 9: A->use_xwin = value != 0; break;
         case 11: A->gs_prof = value != 0; return PAMG_OK;
+        case 12: if (value < 0) return PAMG_E_ARG; A->tile_G = value; break;
+        case 13: if (value < 256 || value > 8192 || (value & (value - 1))) return PAMG_E_ARG; A->tile_W = value; break;
+        case 14: if (value < 0 || value > 2 * MAXP_TILE * BLK - 2) return PAMG_E_ARG; A->tile_cap = value; break;
+        case 15: A->tile_default = value != 0; return PAMG_OK;
         default: return PAMG_E_ARG;
+    }
+    if (key >= 12) {                                  // tile plan parameters: drop the tile parts only
+        for (int k = 0; k < 4; ++k) {
+            GsSchedule *g = A->gs[k];
+            if (g && g->tile) { A->bytes -= g->tile->bytes; g->bytes -= g->tile->bytes; free_tile_part(g->tile); g->tile = nullptr; }
+        }
+        return PAMG_OK;
     }
     for (int k = 0; k < 4; ++k) { if (A->gs[k]) A->bytes -= A->gs[k]->bytes; free_schedule(A->gs[k]); A->gs[k] = nullptr; }
     return replan(A);
@@ -1232,6 +1454,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
 int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
 {
     if (!A) return PAMG_E_ARG;
+    if (A->borrowed > 0) return PAMG_E_STATE;
     if (A->nnz < 4000000 || A->npl != 2) return PAMG_OK;
     const size_t ts = tsize(A->dtype);
     void *x = nullptr, *y = nullptr;
@@ -1270,6 +1493,26 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
     if (!A || which < 0 || which > 3 || !count) return PAMG_E_ARG;
     *count = 0;
     GsSchedule *g = A->gs[which];
+    if (g && g->tile && g->tile->d_prof) {
+        // tiled sweep: [nsteps][4] = {time after barrier 1, after barrier 2 (10 ns ticks), XCD, tile}, repacked into
+        // the 8-column layout: {0,0,t_b1,t_b1,t_b2,xcd,tile,step-in-tile}
+        PAMG_HIP(hipDeviceSynchronize());
+        TileSched *t = g->tile;
+        *count = t->nsteps;
+        if (!out) return PAMG_OK;
+        if (capacity < t->nsteps) return PAMG_E_ARG;
+        std::vector<long long> raw((size_t)t->nsteps * 4);
+        PAMG_HIP(hipMemcpy(raw.data(), t->d_prof, raw.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        std::vector<int> ts((size_t)t->G + 1);
+        PAMG_HIP(hipMemcpy(ts.data(), t->d_tile_step, ts.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int k = 0; k < t->G; ++k)
+            for (int q = ts[k]; q < ts[k + 1]; ++q) {
+                long long *o = out + (size_t)q * 8;
+                o[0] = o[1] = 0; o[2] = o[3] = raw[(size_t)q * 4]; o[4] = raw[(size_t)q * 4 + 1];
+                o[5] = raw[(size_t)q * 4 + 2]; o[6] = k; o[7] = q - ts[k];
+            }
+        return PAMG_OK;
+    }
     if (!g || !g->d_prof) return PAMG_OK;
     PAMG_HIP(hipDeviceSynchronize());
     *count = g->nblk_total;
@@ -1278,6 +1521,18 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
     PAMG_HIP(hipMemcpy(out, g->d_prof, (size_t)g->nblk_total * 8 * sizeof(long long), hipMemcpyDeviceToHost));
     for (int l = 0; l < g->nlevels; ++l)
         for (int q = g->level_blk[l]; q < g->level_blk[l + 1]; ++q) out[(size_t)q * 8 + 7] = l;
+    return PAMG_OK;
+}
+
+int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8])
+{
+    if (!A || which < 0 || which > 3 || !info) return PAMG_E_ARG;
+    for (int k = 0; k < 8; ++k) info[k] = 0;
+    const GsSchedule *g = A->gs[which];
+    if (!g || !g->tile) return PAMG_OK;
+    const TileSched *t = g->tile;
+    info[0] = t->G; info[1] = t->W; info[2] = t->maxp; info[3] = t->nsteps;
+    info[4] = t->n_local; info[5] = t->n_global; info[6] = t->n_publish; info[7] = t->lds;
     return PAMG_OK;
 }
 

@@ -483,6 +483,9 @@ int pamg_solver_destroy(pamg_solver_t S)
     if (!S) return PAMG_OK;
     drop_graphs(S);
     for (Level &L : S->levels) {
+        if (L.A) L.A->borrowed--;
+        if (L.P) L.P->borrowed--;
+        if (L.R) L.R->borrowed--;
         hipFree(L.x); hipFree(L.xalt);
         hipFree(L.b); hipFree(L.r); hipFree(L.work); hipFree(L.amli);
         hipFree(L.pre.d_Dinv); hipFree(L.post.d_Dinv);
@@ -516,6 +519,11 @@ int pamg_solver_add_level(pamg_solver_t S, pamg_matrix_t A, pamg_matrix_t P, pam
     Level L;
     L.A = A; L.P = P; L.R = R; L.n = A->nrows;
     S->levels.push_back(L);
+    // from here on captured graphs may point into the operators' plans and schedules: pamg_matrix_tune /
+    // pamg_matrix_autotune refuse (PAMG_E_STATE) until the solver is destroyed
+    A->borrowed++;
+    if (P) P->borrowed++;
+    if (R) R->borrowed++;
     return PAMG_OK;
 }
 

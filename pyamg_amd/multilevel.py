@@ -98,9 +98,19 @@ class DeviceMatrix:
                        "pamg_matrix_gs_profile")
         return out
 
-    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, xwin=None, gs_prof=None):
+    def tile_info(self, which=0):
+        """plan of the tiled sweep (schedule 0 = forward, 1 = backward): dict, all zero if none is built"""
+        a = (C.c_int64 * 8)()
+        capi.check(capi.lib().pamg_matrix_tile_info(self.handle, which, a), "pamg_matrix_tile_info")
+        return dict(zip(("tiles", "ring", "maxp", "steps", "early_local", "early_global", "publishing_rows", "lds_bytes"), list(a)))
+
+    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, xwin=None, gs_prof=None,
+             tile_G=None, tile_W=None, tile_cap=None, tile_default=None):
+        """Speed-only knobs (every setting computes the same bits).  Refused (PAMG_E_STATE) once a solver holds the
+        operator: captured graphs point into the plans these calls rebuild."""
         lib = capi.lib()
-        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (9, xwin), (11, gs_prof)):
+        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (9, xwin), (11, gs_prof),
+                       (12, tile_G), (13, tile_W), (14, tile_cap), (15, tile_default)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 
@@ -203,10 +213,12 @@ class DeviceMultilevelSolver:
         upload (speed only, results are bit-identical; default on, PAMG_AUTOTUNE=0 disables)
     """
 
-    def __init__(self, ml, device: Optional[int] = None, graph: bool = True, autotune: Optional[bool] = None):
+    def __init__(self, ml, device: Optional[int] = None, graph: bool = True, autotune: Optional[bool] = None,
+                 level_tune=None):
         import os
         if autotune is None:
             autotune = os.environ.get("PAMG_AUTOTUNE", "1") != "0"
+        self._device, self._graph, self._autotune, self._level_tune = device, graph, autotune, level_tune
         lib = capi.lib()
         if device is not None:
             capi.check(lib.pamg_set_device(int(device)), "pamg_set_device")
@@ -237,6 +249,12 @@ class DeviceMultilevelSolver:
                 for m in (P, R):
                     if m is not None:
                         m.autotune(allow_cap=True)
+            if level_tune is not None:
+                # speed-only knobs per level operator (DeviceMatrix.tune keywords), before the solver borrows it:
+                # a dict for every level or a callable level index -> dict / None
+                kw = level_tune(i) if callable(level_tune) else level_tune
+                if kw:
+                    A.tune(**kw)
             capi.check(lib.pamg_solver_add_level(h, A.handle, P.handle if P else None, R.handle if R else None),
                        "pamg_solver_add_level")
             if i < nlev - 1:
@@ -461,9 +479,10 @@ class DeviceMultilevelSolver:
         if self.ml is None:
             raise NotImplementedError("change_solve_matrix needs the wrapped reference solver")
         self.ml.change_solve_matrix(A)
-        ml, graph = self.ml, True
+        ml = self.ml
+        device, graph, autotune, level_tune = self._device, self._graph, self._autotune, self._level_tune
         self.free()
-        self.__init__(ml, graph=graph)
+        self.__init__(ml, device=device, graph=graph, autotune=autotune, level_tune=level_tune)
 
     def aspreconditioner(self, cycle="V"):
         """multilevel.py:355-396: LinearOperator applying one cycle from x = 0."""

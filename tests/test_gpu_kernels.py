@@ -308,7 +308,11 @@ def test_gs_sweep_modes_all_exact():
         db = capi.DeviceArray.from_host(b)
         for kw in (dict(gs_mode=1), dict(gs_mode=3), dict(gs_mode=2, gran_xcd=2, gran_cap=0),
                    dict(gs_mode=2, gran_xcd=1, gran_cap=0), dict(gs_mode=2, gran_xcd=2, gran_cap=3),
-                   dict(gs_mode=2, gran_xcd=1, gran_cap=2), dict(gs_mode=0, gran_xcd=0, gran_cap=0)):
+                   dict(gs_mode=2, gran_xcd=1, gran_cap=2), dict(gs_mode=0, gran_xcd=0, gran_cap=0),
+                   # tiled sweep: automatic tiling; one tile; many small tiles with a tiny ring (in-tile values that
+                   # fall out of the ring go through the global hand-off) and short steps; the narrow-step kernel
+                   dict(gs_mode=5, tile_G=0, tile_W=2048, tile_cap=0), dict(gs_mode=5, tile_G=1),
+                   dict(gs_mode=5, tile_G=37, tile_W=256, tile_cap=96), dict(gs_mode=5, tile_G=200, tile_W=1024, tile_cap=900)):
             dA.tune(**kw)
             dx = capi.DeviceArray.from_host(x)
             dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
