@@ -236,8 +236,9 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * 5 also accepts 5 = TILED sweep (one persistent workgroup per contiguous chunk of rows; dependency chains
  * stay in LDS, only chunk-crossing edges use the global hand-off); 11 = record time stamps of the granular /
  * tiled sweep (diagnostics, pamg_matrix_gs_profile); 12 = tiles of the tiled sweep (0 = automatic),
- * 13 = its LDS ring slots (power of two, 256..8192), 14 = its entries per step (0 = automatic),
- * 15 = let the automatic choice (key 5 = 0) prefer the tiled sweep.
+ * 13 = its LDS ring slots (0 = automatic, else a power of two, 64..8192), 14 = its entries per step
+ * (0 = automatic, <= 1020), 15 = let the automatic choice (key 5 = 0) prefer the tiled sweep, 16 = cap on the
+ * steps resident in LDS per tile (0 = automatic), 17 = cap on the steps its loader keeps in flight (-1 = automatic).
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* Pick the LDS window (key 0) and streaming flags (key 8) of the whole-operator kernels by timing
@@ -250,8 +251,9 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap);
  * XCD id, workgroup id, dependency level}.  out == NULL: only *count.  Synchronises. */
 int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count);
 /* Plan of the tiled sweep for schedule `which` (built by the first sweep / pamg_solver_finalize):
- * {tiles, ring slots, entry pairs per lane, steps, early entries served from LDS, early entries served by the
- * global hand-off, publishing rows, LDS bytes}; all zero when that schedule has no tile plan. */
+ * {tiles, ring slots, geometry = code chunks per step | LDS slots << 8 | gather depth << 16 | loader steps in
+ * flight << 24, steps, early entries served from LDS, early entries served by the global hand-off, publishing
+ * rows, LDS bytes}; all zero when that schedule has no tile plan. */
 int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8]);
 /* Row-subset copy of a CSR operator (rows: HOST list, kept in list order) for the indexed smoothers,
  * and amg_core::jacobi_indexed (relaxation.h:382-427) on it: every listed row of x is relaxed from the

@@ -98,15 +98,15 @@ struct GsSchedule {
     std::vector<int> h_vis, h_lvl;   // scalar schedules: visit index (-1 = not swept) and dependency level of every row
     bool has_level_part = false;     // the level-permuted copy above is built (granular / single-workgroup / per-level schedulers)
     struct TileSched *tile = nullptr; // tiled sweep (pamg_tile_plan.h / pamg_tile_kernels.h), built on demand
+    bool tile_unfit = false;         // the tile planner declined this schedule (a step would not fit): other schedulers run it
 };
 
-// Device side of a tile plan: tile-major copy of the operator (rows of a tile in dependency-level order),
-// step descriptors, entry codes.
+// Device side of a tile plan: the step blocks (pamg_tile_plan.h: one fixed-size block of entry codes, values and
+// row records per step, tile after tile) and the launch geometry chosen for them.
 struct TileSched {
-    int G = 0, W = 0, maxp = 4, nsteps = 0, lds = 0;
-    int4 *d_steps = nullptr;
-    int *d_tile_step = nullptr, *d_Ap = nullptr, *d_Aj = nullptr, *d_rid = nullptr;
-    void *d_Ax = nullptr, *d_diag = nullptr;
+    int G = 0, W = 0, NCH = 1, NV = 1, wide = 0, xo = 0, D = 0, Q = 0, nsteps = 0, lds = 0;   // wide: kernel variant (0 = small gather lists, several workgroups per CU allowed)
+    unsigned char *d_blocks = nullptr;
+    int *d_tile_step = nullptr;
     long long *d_prof = nullptr;     // [nsteps][4] diagnostics (tune key 11)
     int64_t n_local = 0, n_global = 0, n_publish = 0, max_step_entries = 0;
     size_t bytes = 0;
@@ -158,8 +158,9 @@ struct pamg_matrix_s {
     int gran_cap = 0;                // granular sweep: cap on the persistent grid (0 = auto)
     int gs_mode = 0;                 // scalar sweep scheduler: 0 auto, 1 one launch per level, 2 granular, 3 single workgroup, 5 tiled
     int tile_G = 0;                  // tiled sweep: tiles (0 = auto)
-    int tile_W = 2048;               // tiled sweep: LDS ring slots (power of two)
+    int tile_W = 0;                  // tiled sweep: LDS ring slots (power of two; 0 = auto)
     int tile_cap = 0;                // tiled sweep: scheduled entries per step (0 = auto)
+    int tile_D = 0, tile_Q = -1;     // tiled sweep: LDS slots per tile / steps in flight behind the landed mark (0 / -1 = auto)
     bool tile_default = false;       // auto mode (gs_mode 0) prefers the tiled sweep
     int max_row_len = 0;             // longest row of the scalar view
     int borrowed = 0;                // solvers holding this operator (tuning is refused while > 0: captured graphs point into the schedules)

@@ -397,58 +397,96 @@ int build_level_part(pamg_matrix_s *A, GsSchedule *g)
 void free_tile_part(TileSched *t)
 {
     if (!t) return;
-    hipFree(t->d_steps); hipFree(t->d_tile_step); hipFree(t->d_Ap); hipFree(t->d_Aj); hipFree(t->d_rid); hipFree(t->d_Ax); hipFree(t->d_diag); hipFree(t->d_prof);
+    hipFree(t->d_blocks); hipFree(t->d_tile_step); hipFree(t->d_prof);
     delete t;
 }
 
-int tile_grid_max(int dtype, int epi, int maxp, int lds);
+int tile_occupancy(int dtype, int variant, int lds);
+// kernel variants by the gather items a step may carry: {rounds of old items, rounds of hand-off items, steps the
+// gatherer keeps in registers}; RO + RG + 2 loads per step, all variants stay below the 63 the memory counter can count
+constexpr int TILE_VAR[2][3] = {{4, 2, 6}, {8, 4, 4}};
 
-// tile-major copy of the operator for the tiled sweep (pamg_tile_plan.h)
+// step blocks of the tiled sweep (pamg_tile_plan.h) and the launch geometry that goes with them
 int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
 {
     if (g->tile) return PAMG_OK;
     const int m = (int)g->nrows;
-    const size_t ts = tsize(A->dtype);
-    const int W = A->tile_W;
-    int cap = A->tile_cap > 0 ? A->tile_cap : 2 * MAXP_TILE * BLK - 2;
-    cap = std::min(cap, 2 * MAXP_TILE * BLK - 2);
-    // tiles: about seven rows of every dependency level per tile (measured sweet spot between the serial chain
-    // of steps inside a tile and the hand-offs between tiles), never more than can be co-resident
+    const int ts = (int)tsize(A->dtype);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 64;
+    }
+    // tiles: about seven rows of every dependency level per tile, at most four workgroups per CU (every workgroup must
+    // be resident for the whole launch)
     int G = A->tile_G;
     if (G <= 0) G = (int)std::max<int64_t>(1, (int64_t)m / std::max<int64_t>(1, (int64_t)7 * g->nlevels));
+    G = std::max(1, std::min(G, 4 * cus));
+    int cap_user = A->tile_cap;
     TilePlan P;
-    const int lds_probe = (int)((2 * MAXP_TILE * BLK + 8) * ts + (size_t)W * (ts + 4) + 64);
-    G = std::max(1, std::min(G, tile_grid_max(A->dtype, EPI_GS, MAXP_TILE, lds_probe)));
-    if (build_tile_plan_from((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), g->row_start, g->row_step, m, g->nlevels,
-                             g->h_vis, g->h_lvl, G, W, cap, BLK, P))
-        return PAMG_E_ARG;
+    TileGeom geom{1, 1, ts};
+    int W = 0, D = 0, Q = 0, wide = 0, lds = 0;
+    for (int attempt = 0; ; ++attempt) {
+        const int wpc = (G + cus - 1) / cus;              // workgroups per CU
+        W = A->tile_W > 0 ? A->tile_W : (wpc > 1 ? 512 : 2048);
+        // entries per step: fat steps for the single-workgroup-per-CU form (fewer, longer steps amortise the fixed cost of
+        // a step; the LDS slots still have to hold a few of them), lean ones when several workgroups share a CU
+        int cap = cap_user > 0 ? cap_user : (wpc > 1 ? 512 : 1024);
+        cap = std::min(TILE_MAX_ENTRIES, std::max(cap, A->max_row_len));
+        if (build_tile_plan_from((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), g->row_start, g->row_step, m, g->nlevels,
+                                 g->h_vis, g->h_lvl, G, W, cap, TILE_ROWS, P))
+            return PAMG_E_ARG;
+        int mo = 0, mg = 0;
+        if (!tile_geometry(P, ts, geom, &mo, &mg)) return PAMG_E_ARG;
+        wide = (mo <= 256 && mg <= 128) ? 0 : 1;          // kernel variant
+        const int KG = TILE_VAR[wide][2];
+        if (wide > 0 && wpc > 1 && attempt <= 5) { G = cus; continue; }
+        const int budget = std::min(150 * 1024, (160 * 1024) / wpc - 1024);
+        const int fixed = 64 + W * ts;
+        D = (budget - fixed) / geom.slot_bytes();
+        if (A->tile_D > 0) D = std::min(D, A->tile_D);
+        D = std::min(D, 32);
+        if (D < KG + 2) {                                  // does not fit: leaner steps, else fewer workgroups per CU
+            if (attempt > 5) return PAMG_E_ARG;
+            if (cap > 512 && cap > A->max_row_len) { cap_user = std::max(512, cap / 2); continue; }
+            if (wpc == 1) return PAMG_E_ARG;
+            G = (wpc - 1) * cus;
+            continue;
+        }
+        Q = std::min(std::min(4, 63 / geom.chunks()), D - KG - 1);
+        if (A->tile_Q >= 0) Q = std::min(Q, A->tile_Q);
+        lds = fixed + D * geom.slot_bytes();
+        const int occ = tile_occupancy(A->dtype, wide, lds);
+        if (occ >= wpc || attempt > 5) {
+            if (occ < wpc) return PAMG_E_STATE;
+            break;
+        }
+        G = std::max(1, occ) * cus;
+    }
     TileSched *t = new (std::nothrow) TileSched();
     if (!t) return PAMG_E_ALLOC;
-    t->G = P.G; t->W = W; t->nsteps = (int)P.steps.size();
+    t->G = P.G; t->W = W; t->NCH = geom.NCH; t->NV = geom.NV; t->wide = wide; t->D = D; t->Q = Q; t->lds = lds;
+    t->nsteps = (int)P.steps.size();
     t->n_local = P.n_local; t->n_global = P.n_global; t->n_publish = P.n_publish;
-    for (const TileStep &s : P.steps) t->max_step_entries = std::max<int64_t>(t->max_step_entries, s.p1 - (s.p0 & ~1));
-    t->maxp = t->max_step_entries <= 2 * 2 * BLK ? 2 : MAXP_TILE;
-    t->lds = (int)((2 * t->maxp * BLK + 8) * ts + (size_t)W * (ts + 4) + 64);
-    const int nnz = P.Ap[m];
-    std::vector<unsigned char> hAx((size_t)A->nnz * ts), pAx((size_t)nnz * ts), pdiag((size_t)m * ts, 0);
+    for (const TileStep &s : P.steps) t->max_step_entries = std::max<int64_t>(t->max_step_entries, s.p1 - s.p0);
+    std::vector<unsigned char> hAx((size_t)A->nnz * ts), blocks;
     if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
-    parallel_rows(m, [&](int lo, int hi) {
-        for (int r = lo; r < hi; ++r) {
-            const int i = P.rid[r] & COL_MASK;
-            for (int q = P.Ap[r]; q < P.Ap[r + 1]; ++q) {
-                std::memcpy(&pAx[(size_t)q * ts], &hAx[(size_t)P.src[q] * ts], ts);
-                // diagonal: last stored a_ii wins, like the reference (relaxation.h:64-74)
-                if (A->h_Aj[P.src[q]] == i) std::memcpy(&pdiag[(size_t)r * ts], &hAx[(size_t)P.src[q] * ts], ts);
-            }
+    // the rows' own old values are only needed when a diagonal is missing or zero (or by SOR, which always asks)
+    {
+        std::vector<unsigned char> hd((size_t)A->nrows * ts);
+        if (A->nrows && A->d_diag) PAMG_HIP(hipMemcpy(hd.data(), A->d_diag, (size_t)A->nrows * ts, hipMemcpyDeviceToHost));
+        t->xo = A->d_diag ? 0 : 1;
+        for (int64_t i = 0; i < A->nrows && !t->xo; ++i) {
+            if (ts == 8) { double v; std::memcpy(&v, &hd[(size_t)i * 8], 8); if (!(v != 0.0)) t->xo = 1; }
+            else { float v; std::memcpy(&v, &hd[(size_t)i * 4], 4); if (!(v != 0.0f)) t->xo = 1; }
         }
-    });
-    static_assert(sizeof(TileStep) == sizeof(int4), "step descriptor layout");
-    int st = upload(&t->d_Ap, P.Ap.data(), P.Ap.size(), &t->bytes);
-    if (!st) st = upload(&t->d_Aj, P.Aj.data(), P.Aj.size(), &t->bytes);
-    if (!st) st = upload_raw(&t->d_Ax, pAx.data(), (size_t)nnz, ts, &t->bytes);
-    if (!st) st = upload_raw(&t->d_diag, pdiag.data(), (size_t)m, ts, &t->bytes);
-    if (!st) st = upload(&t->d_rid, P.rid.data(), P.rid.size(), &t->bytes);
-    if (!st) st = upload_raw((void **)&t->d_steps, P.steps.data(), P.steps.size(), sizeof(int4), &t->bytes);
+    }
+    int bad;
+    if (A->dtype == PAMG_F64) bad = pack_tile_blocks<double>(P, geom, reinterpret_cast<const double *>(hAx.data()), A->h_Aj.data(), blocks);
+    else bad = pack_tile_blocks<float>(P, geom, reinterpret_cast<const float *>(hAx.data()), A->h_Aj.data(), blocks);
+    if (bad) { delete t; return PAMG_E_ARG; }
+    int st = upload_raw((void **)&t->d_blocks, blocks.data(), blocks.size(), 1, &t->bytes);
     if (!st) st = upload(&t->d_tile_step, P.tile_step.data(), P.tile_step.size(), &t->bytes);
     if (st) { free_tile_part(t); return st; }
     g->tile = t;
@@ -643,19 +681,22 @@ static int flow1_launch(int npl, int lds, hipStream_t s, const FlowArgs<T> &f)
 }
 
 // ---- tiled sweep: launch plumbing
+// kernel variants (TILE_VAR); with or without the rows' own old values
 template <typename T, int EPI>
-static const void *tile_kernel_ptr(int maxp)
+static const void *tile_kernel_ptr(int variant, int xo)
 {
-    return maxp == 2 ? (const void *)gs_tile_kernel<T, EPI, 2> : (const void *)gs_tile_kernel<T, EPI, MAXP_TILE>;
+    if (EPI == EPI_SOR) xo = 1;
+    if (variant == 0) return xo ? (const void *)gs_tile_kernel<T, EPI, 4, 2, 6, true> : (const void *)gs_tile_kernel<T, EPI, 4, 2, 6, false>;
+    return xo ? (const void *)gs_tile_kernel<T, EPI, 8, 4, 4, true> : (const void *)gs_tile_kernel<T, EPI, 8, 4, 4, false>;
 }
 
 template <typename T>
-static const void *tile_kernel_any(int epi, int maxp)
+static const void *tile_kernel_any(int epi, int wide, int xo)
 {
     switch (epi) {
-        case EPI_GS: return tile_kernel_ptr<T, EPI_GS>(maxp);
-        case EPI_GS_B: return tile_kernel_ptr<T, EPI_GS_B>(maxp);
-        case EPI_SOR: return tile_kernel_ptr<T, EPI_SOR>(maxp);
+        case EPI_GS: return tile_kernel_ptr<T, EPI_GS>(wide, xo);
+        case EPI_GS_B: return tile_kernel_ptr<T, EPI_GS_B>(wide, xo);
+        case EPI_SOR: return tile_kernel_ptr<T, EPI_SOR>(wide, xo);
     }
     return nullptr;
 }
@@ -663,22 +704,21 @@ static const void *tile_kernel_any(int epi, int maxp)
 }  // namespace pamg
 
 namespace {
-// ceiling of the tiled sweep's grid: every workgroup must be resident for the whole launch.  (occupancy - 1, at
-// least 1) per CU: the occupancy query can over-report by one per CU (MI355X_MICROARCH.md, residency)
-int tile_grid_max(int dtype, int epi, int maxp, int lds)
+// workgroups of the tiled sweep one CU holds (every workgroup of a launch must be resident): the minimum over the
+// variants a schedule may launch
+int tile_occupancy(int dtype, int wide, int lds)
 {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-        else cus = 64;
-    }
-    const void *k = dtype == PAMG_F64 ? pamg::tile_kernel_any<double>(epi, maxp) : pamg::tile_kernel_any<float>(epi, maxp);
-    int nb = 0;
-    if (!k || hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, TILE_THREADS, (size_t)lds) != hipSuccess) nb = 1;
-    nb = std::max(1, std::min(nb - 1, 3));
-    return nb * cus;
+    int best = 1 << 30;
+    for (int epi : {(int)EPI_GS, (int)EPI_GS_B, (int)EPI_SOR})
+        for (int xo = 0; xo < 2; ++xo) {
+            const void *k = dtype == PAMG_F64 ? pamg::tile_kernel_any<double>(epi, wide, xo) : pamg::tile_kernel_any<float>(epi, wide, xo);
+            if (!k) return 0;
+            if (lds > 48 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, TILE_THREADS, (size_t)lds) != hipSuccess) return 0;
+            best = std::min(best, nb);
+        }
+    return best;
 }
 }  // namespace
 
@@ -691,11 +731,10 @@ static int tile_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const 
     const size_t ts = tsize(A->dtype);
     const int64_t n = A->nrows;
     TileArgs<T> a;
-    a.steps = t->d_steps; a.tile_step = t->d_tile_step;
-    a.Ap = t->d_Ap; a.Aj = t->d_Aj; a.Ax = (const T *)t->d_Ax; a.rid = t->d_rid; a.diag = (const T *)t->d_diag;
+    a.blocks = t->d_blocks; a.tile_step = t->d_tile_step;
     a.x = (const T *)x; a.xs = (T *)g->d_xs; a.y = (T *)x; a.b = (const T *)b;
     a.err = g->d_sync + 1;
-    a.omega = (T)omega; a.W = t->W; a.G = t->G;
+    a.omega = (T)omega; a.W = t->W; a.D = t->D; a.Q = t->Q; a.G = t->G; a.NCH = t->NCH; a.NV = t->NV;
     a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
     if (!g->symmetric) {
         // write-after-read hazards are not ordered by the waits: old values come from a snapshot
@@ -704,8 +743,8 @@ static int tile_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const 
         a.x = (const T *)g->d_xold;
     }
     if (A->gs_prof && !t->d_prof) {
-        PAMG_HIP(hipMalloc((void **)&t->d_prof, (size_t)t->nsteps * 4 * sizeof(long long)));
-        PAMG_HIP(hipMemset(t->d_prof, 0, (size_t)t->nsteps * 4 * sizeof(long long)));
+        PAMG_HIP(hipMalloc((void **)&t->d_prof, (size_t)t->nsteps * 8 * sizeof(long long)));
+        PAMG_HIP(hipMemset(t->d_prof, 0, (size_t)t->nsteps * 8 * sizeof(long long)));
     }
     a.prof = A->gs_prof ? t->d_prof : nullptr;
     if (t->n_publish) {
@@ -713,7 +752,7 @@ static int tile_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const 
         hipLaunchKernelGGL((fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)g->d_xs, n);
         PAMG_HIP(hipGetLastError());
     }
-    const void *k = tile_kernel_any<T>(epi, t->maxp);
+    const void *k = tile_kernel_any<T>(epi, t->wide, t->xo);
     if (!k) return PAMG_E_ARG;
     if (t->lds > 48 * 1024) PAMG_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, t->lds));
     void *args[] = {(void *)&a};
@@ -733,12 +772,12 @@ static int tile_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const 
 //  * one launch per level only as the fallback (oversized LDS window, 1- or 4-entries-per-lane plans).
 static bool tile_eligible(const pamg_matrix_s *A, const GsSchedule *g)
 {
-    return g->nlevels > 1 && A->max_row_len <= 2 * MAXP_TILE * BLK - 2 && g->d_xs != nullptr;
+    return g->nlevels > 1 && A->max_row_len <= TILE_MAX_ENTRIES && g->d_xs != nullptr;
 }
 
 static bool want_tiles(const pamg_matrix_s *A, const GsSchedule *g)
 {
-    if (!tile_eligible(A, g)) return false;
+    if (!tile_eligible(A, g) || g->tile_unfit) return false;
     return A->gs_mode == 5 || (A->gs_mode == 0 && A->tile_default);
 }
 
@@ -746,7 +785,11 @@ static bool want_tiles(const pamg_matrix_s *A, const GsSchedule *g)
 static int ensure_parts(pamg_matrix_s *A, GsSchedule *g)
 {
     if (A->R > 1) return PAMG_OK;
-    if (want_tiles(A, g)) return build_tile_part(A, g);
+    if (want_tiles(A, g)) {
+        const int st = build_tile_part(A, g);
+        if (st != PAMG_E_ARG) return st;
+        g->tile_unfit = true;                              // not representable as step blocks: the level schedulers take it
+    }
     return build_level_part(A, g);
 }
 
@@ -1435,14 +1478,17 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 9: A->use_xwin = value != 0; break;
         case 11: A->gs_prof = value != 0; return PAMG_OK;
         case 12: if (value < 0) return PAMG_E_ARG; A->tile_G = value; break;
-        case 13: if (value < 256 || value > 8192 || (value & (value - 1))) return PAMG_E_ARG; A->tile_W = value; break;
-        case 14: if (value < 0 || value > 2 * MAXP_TILE * BLK - 2) return PAMG_E_ARG; A->tile_cap = value; break;
+        case 13: if (value != 0 && (value < 64 || value > 8192 || (value & (value - 1)))) return PAMG_E_ARG; A->tile_W = value; break;
+        case 14: if (value < 0 || value > TILE_MAX_ENTRIES) return PAMG_E_ARG; A->tile_cap = value; break;
         case 15: A->tile_default = value != 0; return PAMG_OK;
+        case 16: if (value < 0 || value > 32) return PAMG_E_ARG; A->tile_D = value; break;
+        case 17: if (value < -1 || value > 4) return PAMG_E_ARG; A->tile_Q = value; break;
         default: return PAMG_E_ARG;
     }
     if (key >= 12) {                                  // tile plan parameters: drop the tile parts only
         for (int k = 0; k < 4; ++k) {
             GsSchedule *g = A->gs[k];
+            if (g) g->tile_unfit = false;
             if (g && g->tile) { A->bytes -= g->tile->bytes; g->bytes -= g->tile->bytes; free_tile_part(g->tile); g->tile = nullptr; }
         }
         return PAMG_OK;
@@ -1494,23 +1540,19 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
     *count = 0;
     GsSchedule *g = A->gs[which];
     if (g && g->tile && g->tile->d_prof) {
-        // tiled sweep: [nsteps][4] = {time after barrier 1, after barrier 2 (10 ns ticks), XCD, tile}, repacked into
-        // the 8-column layout: {0,0,t_b1,t_b1,t_b2,xcd,tile,step-in-tile}
+        // tiled sweep: [nsteps][8] = {compute wave: operands of the step seen ready, step done (10 ns ticks), XCD, tile,
+        // loader: step issued, gatherer: gathers issued, finish started, ready published}; XCD / tile are replaced by the
+        // tile and the step's index inside it
         PAMG_HIP(hipDeviceSynchronize());
         TileSched *t = g->tile;
         *count = t->nsteps;
         if (!out) return PAMG_OK;
         if (capacity < t->nsteps) return PAMG_E_ARG;
-        std::vector<long long> raw((size_t)t->nsteps * 4);
-        PAMG_HIP(hipMemcpy(raw.data(), t->d_prof, raw.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        PAMG_HIP(hipMemcpy(out, t->d_prof, (size_t)t->nsteps * 8 * sizeof(long long), hipMemcpyDeviceToHost));
         std::vector<int> ts((size_t)t->G + 1);
         PAMG_HIP(hipMemcpy(ts.data(), t->d_tile_step, ts.size() * sizeof(int), hipMemcpyDeviceToHost));
         for (int k = 0; k < t->G; ++k)
-            for (int q = ts[k]; q < ts[k + 1]; ++q) {
-                long long *o = out + (size_t)q * 8;
-                o[0] = o[1] = 0; o[2] = o[3] = raw[(size_t)q * 4]; o[4] = raw[(size_t)q * 4 + 1];
-                o[5] = raw[(size_t)q * 4 + 2]; o[6] = k; o[7] = q - ts[k];
-            }
+            for (int q = ts[k]; q < ts[k + 1]; ++q) { out[(size_t)q * 8 + 2] = k; out[(size_t)q * 8 + 3] = q - ts[k]; }
         return PAMG_OK;
     }
     if (!g || !g->d_prof) return PAMG_OK;
@@ -1531,7 +1573,7 @@ int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8])
     const GsSchedule *g = A->gs[which];
     if (!g || !g->tile) return PAMG_OK;
     const TileSched *t = g->tile;
-    info[0] = t->G; info[1] = t->W; info[2] = t->maxp; info[3] = t->nsteps;
+    info[0] = t->G; info[1] = t->W; info[2] = (t->NCH + t->NV + 1) | (t->D << 8) | (TILE_VAR[t->wide][2] << 16) | (t->Q << 24); info[3] = t->nsteps;
     info[4] = t->n_local; info[5] = t->n_global; info[6] = t->n_publish; info[7] = t->lds;
     return PAMG_OK;
 }

@@ -5,15 +5,28 @@
 // row i runs after every connected row visited before it.  The level-scheduled granular sweep pays
 // one cross-workgroup hand-off (>= 1.5 us through L2/HBM) per dependency LEVEL.  Here the visited
 // rows are cut into G contiguous chunks of the visit order ("tiles"), ONE persistent workgroup per
-// tile.  A workgroup walks the rows of its tile level after level ("steps": rows of one level,
-// mutually independent); new values needed by a later step of the SAME tile travel through an LDS
-// ring (one LDS round trip per level), only edges that cross tiles use the global hand-off buffer.
-// With contiguous chunks of a banded operator tile k depends on tile k-1 (and rarely further back),
-// so the tiles run as a skewed pipeline: tile k settles one hand-off latency behind tile k-1 and
-// thereafter finds its cross-tile operands already published -- the hand-off latency is paid once
-// per tile on the critical path instead of once per level.
+// tile.  A workgroup walks the rows of its tile level after level ("steps": at most 64 rows of one
+// level, mutually independent); new values needed by a later step of the SAME tile travel through
+// an LDS ring (one LDS round trip per level), only edges that cross tiles use the global hand-off
+// buffer.  With contiguous chunks of a banded operator tile k depends on tile k-1 (and rarely
+// further back), so the tiles run as a skewed pipeline: tile k settles one hand-off latency behind
+// tile k-1 -- the hand-off latency is paid once per tile on the critical path instead of once per level.
 //
-// Entry codes (32-bit "column" of a scheduled entry):
+// Device layout ("step blocks", pack_tile_blocks): every step is ONE fixed-size block of 1-KiB chunks
+//   [ lists: NCH chunks | entry values T: NV chunks | 64 row records of 16 bytes ]
+// so a loader wave streams a tile with LDS-DMA (1 KiB per instruction) and needs no descriptors.
+//   lists = header {rows, tile-local index of the first row, old | handoff << 16, local} (16 bytes), then
+//           "local" items    entry position | ring slot << 16  4 bytes: x_j is a NEW value of THIS tile (LDS ring)
+//           (padded to an even count), then
+//           "old" items      {entry position, column j}        8 bytes: x_j is the value from before the sweep
+//           "hand-off" items {entry position, column j}        8 bytes: x_j is a NEW value of ANOTHER tile (poll xs[j])
+//   so each consumer walks a dense list of exactly its own work (the gather wave the first two, the compute
+//   wave the third) instead of classifying every entry.
+//   values = a_ij in storage order of the step's rows; the diagonal entry holds +0 (s + (+0) == s for every s
+//           the sums can hold), so a row sum is a plain in-order walk.
+//   row record = {T diag @0, int (original row | publish bit 31) @8, int (first entry | entries << 16) @12}.
+//
+// Entry codes of the flat plan (TilePlan::Aj, consumed by the packer):
 //   bit31 | bit30   meaning                      low 30 bits
 //     0       0     OLD value   x[j]             j
 //     1       0     NEW value, global hand-off   j      (poll xs[j])
@@ -23,6 +36,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -34,6 +48,7 @@ struct TilePlan {
     int G = 0;                    // tiles (= persistent workgroups)
     int W = 0;                    // LDS ring slots (power of two)
     int cap = 0;                  // scheduled entries per step (one row longer than cap forms a step of its own)
+    std::vector<int> step_old, step_glob, step_loc;   // [nsteps] items per list
     int nlevels = 0;
     bool symmetric = true;
     std::vector<int> rid;         // [m]   original row of stored row r | PUBLISH_BIT
@@ -65,6 +80,8 @@ constexpr int TP_EARLY = (int)0x80000000u;
 constexpr int TP_DIAG = 0x40000000;
 constexpr int TP_MASK = 0x3FFFFFFF;
 constexpr int TP_PUBLISH = (int)0x80000000u;  // in rid[]
+inline int tile_list_bytes(int n_old, int n_glob, int n_loc) { return 16 + 4 * ((n_loc + 1) & ~1) + 8 * (n_old + n_glob); }
+constexpr int TILE_MAX_OLD = 512, TILE_MAX_GLOB = 256, TILE_MAX_LIST_BYTES = 12288, TILE_MAX_ENTRIES = 2048;   // per step
 
 // Dependency levels of the sweep i = row_start, row_start+row_step, ... (!= row_stop): level[i] for
 // visited rows, vis[i] = visit index or -1.  Row i runs strictly after every connected row visited
@@ -113,7 +130,7 @@ inline int sweep_levels(int n, const int *Ap, const int *Aj, int row_start, int 
 // per step.
 inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_start, int row_step, int m, int nl,
                                 const std::vector<int> &vis, const std::vector<int> &lvl, int G_want, int W, int cap,
-                                int max_rows, TilePlan &P)
+                                int max_rows, TilePlan &P, int partition = 0)
 {
     if (W < 64 || (W & (W - 1)) || cap < 2 || max_rows < 1) return 1;
     P = TilePlan();
@@ -169,39 +186,20 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
     P.Ap.assign((size_t)m + 1, 0);
     for (int r = 0; r < m; ++r) P.Ap[r + 1] = P.Ap[r] + (Ap[order[r] + 1] - Ap[order[r]]);
     const int nnz = P.Ap[m];
-    // steps
-    P.tile_step.assign(1, 0);
-    std::vector<int> step_first((size_t)m, 0);   // first stored row of the step a stored row belongs to
-    for (int k = 0; k < G; ++k) {
-        int r = tcount[k];
-        const int rend = tcount[k + 1];
-        while (r < rend) {
-            const int L = lvl[order[r]];
-            TileStep s{r, r, P.Ap[r], P.Ap[r]};
-            while (s.r1 < rend && lvl[order[s.r1]] == L && s.r1 - s.r0 < max_rows) {
-                const int len = P.Ap[s.r1 + 1] - P.Ap[s.r1];
-                if (s.r1 > s.r0 && (s.p1 - s.p0) + len > cap) break;
-                s.p1 += len;
-                s.r1++;
-            }
-            for (int q = s.r0; q < s.r1; ++q) step_first[q] = s.r0;
-            P.steps.push_back(s);
-            P.step_level.push_back(L);
-            r = s.r1;
-        }
-        P.tile_step.push_back((int)P.steps.size());
-    }
-    // entry codes
+    // entry codes first (the step builder needs the list sizes).  A NEW value of the same tile is served by the
+    // LDS ring when its slot (rj - tile base) mod W still holds it: the slot is next written by stored row rj + W,
+    // which must not belong to an earlier step than the consumer's -- guaranteed when rj + W >= r (the consumer's
+    // own stored position; its step starts at or before r).
     P.Aj.resize((size_t)nnz);
     P.src.resize((size_t)nnz);
     P.rid.assign(order.begin(), order.end());
     std::vector<unsigned char> publish((size_t)m, 0);
+    std::vector<int> row_old((size_t)m, 0), row_glob((size_t)m, 0), row_loc((size_t)m, 0);
     std::atomic<int64_t> n_local(0), n_global(0);
     tp_parallel(m, [&](int rlo, int rhi) {
         int64_t nloc = 0, nglob = 0;
         for (int r = rlo; r < rhi; ++r) {
             const int i = order[r], ti = vis[i], k = tile[i];
-            const int first = step_first[r];
             int q = P.Ap[r];
             for (int p = Ap[i]; p < Ap[i + 1]; ++p, ++q) {
                 const int j = Aj[p];
@@ -211,24 +209,49 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
                 const int tj = vis[j];
                 if (tj >= 0 && tj < ti) {
                     const int rj = pos[j];
-                    // same tile and the ring slot still holds row j's value when this step reads it: slot
-                    // (rj - tile base) mod W is next written by stored row rj + W, whose step must not
-                    // precede this one
-                    if (tile[j] == k && rj + W >= first) {
+                    if (tile[j] == k && rj + W >= r) {
                         P.Aj[q] = ((rj - tcount[k]) & (W - 1)) | TP_EARLY | TP_DIAG;
-                        nloc++;
+                        row_loc[r]++;
                     } else {
                         P.Aj[q] = j | TP_EARLY;
                         publish[rj] = 1;          // several threads may store the same 1: benign
-                        nglob++;
+                        row_glob[r]++;
                     }
                 } else {
                     P.Aj[q] = j;
+                    row_old[r]++;
                 }
             }
+            nloc += row_loc[r]; nglob += row_glob[r];
         }
         n_local += nloc; n_global += nglob;
     });
+    // steps: rows of one level of one tile, bounded by rows, entries and list sizes
+    P.tile_step.assign(1, 0);
+    for (int k = 0; k < G; ++k) {
+        int r = tcount[k];
+        const int rend = tcount[k + 1];
+        while (r < rend) {
+            const int L = lvl[order[r]];
+            TileStep s{r, r, P.Ap[r], P.Ap[r]};
+            int no = 0, ng = 0, nl = 0;
+            while (s.r1 < rend && lvl[order[s.r1]] == L && s.r1 - s.r0 < max_rows) {
+                const int len = P.Ap[s.r1 + 1] - P.Ap[s.r1];
+                const int o2 = no + row_old[s.r1], g2 = ng + row_glob[s.r1], l2 = nl + row_loc[s.r1];
+                if (s.r1 > s.r0 && ((s.p1 - s.p0) + len > cap || o2 > TILE_MAX_OLD || g2 > TILE_MAX_GLOB ||
+                                    tile_list_bytes(o2, g2, l2) > TILE_MAX_LIST_BYTES))
+                    break;
+                s.p1 += len;
+                no = o2; ng = g2; nl = l2;
+                s.r1++;
+            }
+            P.steps.push_back(s);
+            P.step_level.push_back(L);
+            P.step_old.push_back(no); P.step_glob.push_back(ng); P.step_loc.push_back(nl);
+            r = s.r1;
+        }
+        P.tile_step.push_back((int)P.steps.size());
+    }
     P.n_local = n_local; P.n_global = n_global;
     for (int r = 0; r < m; ++r)
         if (publish[r]) { P.rid[r] |= TP_PUBLISH; P.n_publish++; }
@@ -242,6 +265,98 @@ inline int build_tile_plan(int n, const int *Ap, const int *Aj, int row_start, i
     int m = 0, nl = 0;
     if (sweep_levels(n, Ap, Aj, row_start, row_stop, row_step, vis, lvl, m, nl)) return 1;
     return build_tile_plan_from(n, Ap, Aj, row_start, row_step, m, nl, vis, lvl, G_want, W, cap, max_rows, P);
+}
+
+// ---- fixed-size step blocks (the device layout)
+constexpr int TILE_ROWS = 64;                 // rows per step (one lane of the compute wave each)
+struct TileGeom {
+    int NCH;                                  // 1-KiB chunks of lists per step
+    int NV;                                   // 1-KiB chunks of entry values per step
+    int tsize;                                // sizeof(T)
+    int val_off() const { return 1024 * NCH; }
+    int row_off() const { return 1024 * (NCH + NV); }
+    int block_bytes() const { return 1024 * (NCH + NV + 1); }
+    int chunks() const { return NCH + NV + 1; }                   // LDS-DMA instructions per step
+    int slot_bytes() const { return block_bytes() + 2 * TILE_ROWS * tsize + 32; }   // LDS: block + b[64] + xold[64] + 4 time stamps
+    int max_entries() const { return 1024 * NV / tsize; }
+};
+
+// smallest geometry whose blocks hold every step of the plan; false = a step does not fit (a row longer than
+// TILE_MAX_ENTRIES, or with more old / hand-off operands than one step may carry)
+inline bool tile_geometry(const TilePlan &P, int tsize, TileGeom &g, int *max_old = nullptr, int *max_glob = nullptr)
+{
+    int ment = 0, mlist = 16, mo = 0, mg = 0;
+    for (size_t s = 0; s < P.steps.size(); ++s) {
+        ment = std::max(ment, P.steps[s].p1 - P.steps[s].p0);
+        mlist = std::max(mlist, tile_list_bytes(P.step_old[s], P.step_glob[s], P.step_loc[s]));
+        mo = std::max(mo, P.step_old[s]);
+        mg = std::max(mg, P.step_glob[s]);
+    }
+    if (max_old) *max_old = mo;
+    if (max_glob) *max_glob = mg;
+    if (ment > TILE_MAX_ENTRIES || mo > TILE_MAX_OLD || mg > TILE_MAX_GLOB || mlist > TILE_MAX_LIST_BYTES) return false;
+    g.tsize = tsize;
+    g.NCH = (mlist + 1023) / 1024;
+    g.NV = std::max(1, (ment * tsize + 1023) / 1024);
+    return true;
+}
+
+// Pack the plan into step blocks.  Ax = the operator's values in its own order (P.src maps scheduled entries to them),
+// Aj_op = its column indices (to recognise the diagonal: last stored a_ii wins, relaxation.h:64-74).
+template <typename T>
+inline int pack_tile_blocks(const TilePlan &P, const TileGeom &g, const T *Ax, const int *Aj_op, std::vector<unsigned char> &out)
+{
+    if ((int)sizeof(T) != g.tsize) return 1;
+    const size_t nsteps = P.steps.size();
+    const size_t bb = (size_t)g.block_bytes();
+    out.assign(nsteps * bb + 1024, 0);        // + slack: a DMA chunk never reads past the allocation
+    std::atomic<int> bad(0);
+    tp_parallel(P.G, [&](int klo, int khi) {
+        for (int k = klo; k < khi; ++k) {
+            const int sa = P.tile_step[k], sb = P.tile_step[k + 1];
+            if (sa >= sb) continue;
+            const int tile_r0 = P.steps[sa].r0;
+            for (int s = sa; s < sb; ++s) {
+                const TileStep &st = P.steps[s];
+                const int nrows = st.r1 - st.r0, nent = st.p1 - st.p0;
+                const int no = P.step_old[s], ng = P.step_glob[s], nl = P.step_loc[s];
+                if (nrows > TILE_ROWS || nent > g.max_entries() || tile_list_bytes(no, ng, nl) > 1024 * g.NCH) { bad = 1; continue; }
+                unsigned char *blk = out.data() + (size_t)s * bb;
+                int *hdr = reinterpret_cast<int *>(blk);
+                unsigned *loc_items = reinterpret_cast<unsigned *>(hdr + 4);
+                int *old_items = hdr + 4 + ((nl + 1) & ~1), *glob_items = old_items + 2 * no;
+                T *vals = reinterpret_cast<T *>(blk + g.val_off());
+                unsigned char *rows = blk + g.row_off();
+                int io = 0, ig = 0, il = 0;
+                for (int r = st.r0; r < st.r1; ++r) {
+                    const int i = P.rid[r] & TP_MASK;
+                    T d = T(0);
+                    for (int q = P.Ap[r]; q < P.Ap[r + 1]; ++q) {
+                        const int e = q - st.p0, c = P.Aj[q];
+                        const bool early = c < 0, dg = (c & TP_DIAG) != 0;
+                        if (dg && !early) {                            // diagonal (or an invalid column): +0
+                            if (Aj_op[P.src[q]] == i) d = Ax[P.src[q]];
+                            vals[e] = T(0);
+                            continue;
+                        }
+                        vals[e] = Ax[P.src[q]];
+                        if (early && dg) loc_items[il++] = (unsigned)e | ((unsigned)(c & TP_MASK) << 16);
+                        else if (early) { glob_items[2 * ig] = e; glob_items[2 * ig + 1] = c & TP_MASK; ++ig; }
+                        else { old_items[2 * io] = e; old_items[2 * io + 1] = c & TP_MASK; ++io; }
+                    }
+                    unsigned char *rec = rows + 16 * (size_t)(r - st.r0);
+                    std::memcpy(rec, &d, sizeof(T));
+                    const int rid = P.rid[r];
+                    const int lohi = (P.Ap[r] - st.p0) | ((P.Ap[r + 1] - P.Ap[r]) << 16);
+                    std::memcpy(rec + 8, &rid, 4);
+                    std::memcpy(rec + 12, &lohi, 4);
+                }
+                if (io != no || ig != ng || il != nl) bad = 1;
+                hdr[0] = nrows; hdr[1] = st.r0 - tile_r0; hdr[2] = no | (ng << 16); hdr[3] = nl;
+            }
+        }
+    });
+    return bad.load();
 }
 
 }  // namespace pamg

@@ -1,6 +1,7 @@
 """Host logic of the TILED order-exact sweep (CPU, no GPU): the plan built by
 pyamg_amd/csrc/pamg_tile_plan.h is replayed by tests/tile_plan_emul.cpp the way gs_tile_kernel consumes it
-(LDS ring with wrap-around, global hand-off with sentinel, publish flags, OLD operands fetched one step ahead)
+(packed step blocks, LDS ring with wrap-around, global hand-off with sentinel, publish flags, OLD operands fetched
+several steps ahead)
 under three interleavings of the tiles, and must reproduce the oracle's sequential sweep
 (amg_core::gauss_seidel / sor_gauss_seidel / bsr_gauss_seidel, relaxation.h:48-76,116-145,185-266) bit for bit."""
 import ctypes
@@ -32,7 +33,7 @@ def emul():
     return lib
 
 
-def run_emul(lib, A, x, b, start, stop, step, G, W, cap, max_rows, epi=0, omega=1.0, snapshot=0, policy=0):
+def run_emul(lib, A, x, b, start, stop, step, G, W, cap, max_rows, epi=0, omega=1.0, snapshot=0, policy=0, look=5):
     A = sp.csr_array(A)
     Ap = np.ascontiguousarray(A.indptr, dtype=np.int32)
     Aj = np.ascontiguousarray(A.indices, dtype=np.int32)
@@ -41,7 +42,7 @@ def run_emul(lib, A, x, b, start, stop, step, G, W, cap, max_rows, epi=0, omega=
     stats = np.zeros(8, dtype=np.int64)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     rc = lib.tile_emul_sweep_f64(ctypes.c_int(A.shape[0]), p(Ap), p(Aj), p(Ax), p(xx), p(np.ascontiguousarray(b)), start, stop, step,
-                                 G, W, cap, max_rows, epi, ctypes.c_double(omega), snapshot, policy, p(stats))
+                                 G, W, cap, min(max_rows, 64), epi, ctypes.c_double(omega), snapshot, policy, look, p(stats))
     assert rc == 0
     return xx, stats
 
@@ -103,7 +104,7 @@ def test_replay_is_bit_exact(emul, name, policy):
         if span % step:
             stop = start + (span // step) * step
         ref = ref_sweep(A, x, b, start, stop, step)
-        for (G, W, cap, mr) in [(1, 64, 2046, 256), (3, 64, 40, 8), (7, 256, 2046, 256), (16, 64, 16, 4), (64, 128, 100, 256)]:
+        for (G, W, cap, mr) in [(1, 64, 1020, 64), (3, 64, 40, 8), (7, 256, 508, 64), (16, 64, 16, 4), (64, 128, 100, 64)]:
             got, st = run_emul(emul, A, x, b, start, stop, step, G, W, cap, mr, snapshot=snapshot, policy=policy)
             assert st[6] == 0 and st[7] == 0, (name, G, W, cap, st)
             assert np.array_equal(got, ref), (name, (start, stop, step), (G, W, cap, mr), policy)
@@ -130,12 +131,12 @@ def test_ring_wraps_and_far_values_go_global(emul):
     rng = np.random.RandomState(3)
     x, b = rng.rand(n), rng.rand(n)
     ref = ref_sweep(A, x, b, 0, n, 1)
-    got, st = run_emul(emul, A, x, b, 0, n, 1, 2, 64, 2046, 256, policy=1)
+    got, st = run_emul(emul, A, x, b, 0, n, 1, 2, 64, 1020, 64, policy=1)
     assert st[4] > 0 and st[3] > 0          # both kinds of early entries occur
     assert st[6] == 0 and st[7] == 0
     assert np.array_equal(got, ref)
     # one tile, ring larger than the operator: nothing is published
-    got, st = run_emul(emul, A, x, b, 0, n, 1, 1, 2048, 2046, 256)
+    got, st = run_emul(emul, A, x, b, 0, n, 1, 1, 2048, 1020, 64)
     assert st[4] == 0 and st[5] == 0
     assert np.array_equal(got, ref)
 
@@ -145,7 +146,7 @@ def test_plan_statistics_of_a_stencil(emul):
     A = poisson_csr((16, 16, 16))
     n = A.shape[0]
     x, b = np.ones(n), np.ones(n)
-    _, st = run_emul(emul, A, x, b, 0, n, 1, 16, 2048, 2046, 256)
+    _, st = run_emul(emul, A, x, b, 0, n, 1, 16, 2048, 1020, 64)
     assert st[0] == 16 and st[2] == 46       # 16 tiles, 3*16-2 dependency levels
     # chunks are balanced by work, so they are z-planes up to a few rows: about one z-neighbour per row crosses a
     # tile boundary, the x- and y-neighbours stay local

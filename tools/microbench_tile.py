@@ -37,12 +37,15 @@ ap.add_argument("--grid", type=int, nargs="+", default=[128, 128, 128])
 ap.add_argument("--tag", default="tile")
 ap.add_argument("--check", type=int, default=1)
 ap.add_argument("--tiles", type=int, nargs="*", default=[0])
-ap.add_argument("--rings", type=int, nargs="*", default=[2048])
+ap.add_argument("--rings", type=int, nargs="*", default=[0])
+ap.add_argument("--slots", type=int, nargs="*", default=[0])
+ap.add_argument("--inflight", type=int, nargs="*", default=[-1])
 ap.add_argument("--caps", type=int, nargs="*", default=[0])
 ap.add_argument("--levels", type=int, nargs="*", default=None)
 ap.add_argument("--baseline", type=int, default=1)
 ap.add_argument("--prof", type=int, default=1)
 ap.add_argument("--fine-only", type=int, default=0)
+ap.add_argument("--save-prof", type=int, default=0)
 a = ap.parse_args()
 A = pyamg.gallery.poisson(a.grid, format="csr")
 np.random.seed(1)
@@ -85,7 +88,9 @@ for li, L in enumerate(spec.levels[:-1]):
     for G in a.tiles:
         for W in a.rings:
             for cap in a.caps:
-                variants.append((f"tile_G{G}_W{W}_c{cap}", dict(gs_mode=5, tile_G=G, tile_W=W, tile_cap=cap, gs_prof=0)))
+                for D in a.slots:
+                    for Q in a.inflight:
+                        variants.append((f"tile_G{G}_W{W}_c{cap}_D{D}_Q{Q}", dict(gs_mode=5, tile_G=G, tile_W=W, tile_cap=cap, tile_D=D, tile_Q=Q, gs_prof=0)))
     for name, kw in variants:
         dA.tune(**kw)
         dx.upload(x)
@@ -109,27 +114,28 @@ for li, L in enumerate(spec.levels[:-1]):
                 pr = dA.gs_profile(0)
                 dA.tune(gs_prof=0)
                 if len(pr):
-                    tb1, tb2, tile, sidx = pr[:, 2].astype(np.float64), pr[:, 4].astype(np.float64), pr[:, 6], pr[:, 7]
                     tick = 0.01    # us
-                    t_start = tb1[tb1 > 0].min()
-                    span = (tb2.max() - t_start) * tick
-                    row_phase = (tb2 - tb1) * tick
-                    # stage phase of step s = t_b1[s] - t_b2[s-1] inside a tile
+                    c0, c1, tile, sidx = pr[:, 0].astype(np.float64), pr[:, 1].astype(np.float64), pr[:, 2], pr[:, 3]
+                    lo_, gi, gf, gr = (pr[:, k].astype(np.float64) for k in (4, 5, 6, 7))
+                    t_start = min(c0[c0 > 0].min(), lo_[lo_ > 0].min())
+                    span = (c1.max() - t_start) * tick
                     order = np.lexsort((sidx, tile))
-                    tb1o, tb2o, tileo = tb1[order], tb2[order], tile[order]
+                    c0o, c1o, tileo = c0[order], c1[order], tile[order]
                     same = tileo[1:] == tileo[:-1]
-                    stage = ((tb1o[1:] - tb2o[:-1]) * tick)[same]
+                    wait = ((c0o[1:] - c1o[:-1]) * tick)[same]
                     first = np.r_[True, ~same]
                     last = np.r_[~same, True]
-                    tile_start = (tb1o[first] - t_start) * tick
-                    tile_end = (tb2o[last] - t_start) * tick
-                    q = lambda v: [round(float(np.percentile(v, p)), 3) for p in (10, 50, 90, 99)]
-                    rec[name]["prof"] = {"span_us": round(float(span), 1), "row_phase_us_p10_50_90_99": q(row_phase),
-                                         "stage_phase_us_p10_50_90_99": q(stage),
+                    tile_start = (c0o[first] - t_start) * tick
+                    tile_end = (c1o[last] - t_start) * tick
+                    q = lambda v: [round(float(np.percentile(v, p)), 2) for p in (10, 50, 90, 99)]
+                    rec[name]["prof"] = {"span_us": round(float(span), 1), "compute_step_us": q((c1 - c0) * tick),
+                                         "compute_wait_us": q(wait), "dma_to_gather_us": q((gi - lo_) * tick),
+                                         "gather_flight_us": q((gf - gi) * tick), "gather_finish_us": q((gr - gf) * tick),
+                                         "ready_to_compute_us": q((c0 - gr) * tick),
                                          "tile_busy_us_p50_max": [round(float(np.median(tile_end - tile_start)), 1), round(float((tile_end - tile_start).max()), 1)],
-                                         "tile_first_b1_us_p50_max": [round(float(np.median(tile_start)), 1), round(float(tile_start.max()), 1)],
+                                         "tile_first_us_p50_max": [round(float(np.median(tile_start)), 1), round(float(tile_start.max()), 1)],
                                          "steps_per_tile_max": int(np.bincount(tile.astype(np.int64)).max())}
-                    if li == 0 or a.fine_only:
+                    if a.save_prof and (li == 0 or a.fine_only):
                         np.save(od / f"prof_{a.tag}_L{li}_{name}.npy", pr)
         print(li, n, name, json.dumps(rec[name]), "levels", info["gs_levels_fwd"], flush=True)
     out.append(rec)
