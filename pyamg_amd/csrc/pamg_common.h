@@ -161,7 +161,8 @@ struct pamg_matrix_s {
     int tile_W = 0;                  // tiled sweep: LDS ring slots (power of two; 0 = auto)
     int tile_cap = 0;                // tiled sweep: scheduled entries per step (0 = auto)
     int tile_D = 0, tile_Q = -1;     // tiled sweep: LDS slots per tile / steps in flight behind the landed mark (0 / -1 = auto)
-    bool tile_default = false;       // auto mode (gs_mode 0) prefers the tiled sweep
+    int tile_part = 1;               // tiled sweep: 1 = pencil tiles when the operator is a three-band grid stencil, 0 = contiguous chunks always
+    bool tile_default = false;       // auto mode (gs_mode 0) prefers the tiled sweep everywhere (default: only where it measured faster)
     int max_row_len = 0;             // longest row of the scalar view
     int borrowed = 0;                // solvers holding this operator (tuning is refused while > 0: captured graphs point into the schedules)
     int gs_prof = 0;                 // granular sweep: record per-range time stamps (tune key 11, diagnostics)

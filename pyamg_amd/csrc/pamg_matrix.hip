@@ -402,9 +402,9 @@ void free_tile_part(TileSched *t)
 }
 
 int tile_occupancy(int dtype, int variant, int lds);
-// kernel variants by the gather items a step may carry: {rounds of old items, rounds of hand-off items, steps the
-// gatherer keeps in registers}; RO + RG + 2 loads per step, all variants stay below the 63 the memory counter can count
-constexpr int TILE_VAR[2][3] = {{4, 2, 6}, {8, 4, 4}};
+// kernel variants by the gather items a step may carry: {rounds of old items, rounds of hand-off items, steps per
+// gather batch}; RO + RG + 2 loads per step, a batch stays below the 63 the memory counter can count
+constexpr int TILE_VAR[2][3] = {{4, 2, 3}, {8, 4, 3}};
 
 // step blocks of the tiled sweep (pamg_tile_plan.h) and the launch geometry that goes with them
 int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
@@ -421,8 +421,8 @@ int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
     // tiles: about seven rows of every dependency level per tile, at most four workgroups per CU (every workgroup must
     // be resident for the whole launch)
     int G = A->tile_G;
-    if (G <= 0) G = (int)std::max<int64_t>(1, (int64_t)m / std::max<int64_t>(1, (int64_t)7 * g->nlevels));
-    G = std::max(1, std::min(G, 4 * cus));
+    if (G <= 0) G = m <= 1024 ? 1 : (int)std::max<int64_t>(1, (int64_t)m / std::max<int64_t>(1, (int64_t)7 * g->nlevels));
+    G = std::max(1, std::min(G, 2 * cus));
     int cap_user = A->tile_cap;
     TilePlan P;
     TileGeom geom{1, 1, ts};
@@ -435,7 +435,7 @@ int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
         int cap = cap_user > 0 ? cap_user : (wpc > 1 ? 512 : 1024);
         cap = std::min(TILE_MAX_ENTRIES, std::max(cap, A->max_row_len));
         if (build_tile_plan_from((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), g->row_start, g->row_step, m, g->nlevels,
-                                 g->h_vis, g->h_lvl, G, W, cap, TILE_ROWS, P))
+                                 g->h_vis, g->h_lvl, G, W, cap, TILE_ROWS, P, A->tile_part))
             return PAMG_E_ARG;
         int mo = 0, mg = 0;
         if (!tile_geometry(P, ts, geom, &mo, &mg)) return PAMG_E_ARG;
@@ -447,14 +447,14 @@ int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
         D = (budget - fixed) / geom.slot_bytes();
         if (A->tile_D > 0) D = std::min(D, A->tile_D);
         D = std::min(D, 32);
-        if (D < KG + 2) {                                  // does not fit: leaner steps, else fewer workgroups per CU
+        if (D < 2 * KG + 2) {                              // two gather batches + the compute wave's step + one landing: does not fit -> leaner steps, else fewer workgroups per CU
             if (attempt > 5) return PAMG_E_ARG;
             if (cap > 512 && cap > A->max_row_len) { cap_user = std::max(512, cap / 2); continue; }
             if (wpc == 1) return PAMG_E_ARG;
             G = (wpc - 1) * cus;
             continue;
         }
-        Q = std::min(std::min(4, 63 / geom.chunks()), D - KG - 1);
+        Q = std::max(0, std::min(std::min(4, 63 / geom.chunks()), D - 2 * KG - 1));
         if (A->tile_Q >= 0) Q = std::min(Q, A->tile_Q);
         lds = fixed + D * geom.slot_bytes();
         const int occ = tile_occupancy(A->dtype, wide, lds);
@@ -686,8 +686,8 @@ template <typename T, int EPI>
 static const void *tile_kernel_ptr(int variant, int xo)
 {
     if (EPI == EPI_SOR) xo = 1;
-    if (variant == 0) return xo ? (const void *)gs_tile_kernel<T, EPI, 4, 2, 6, true> : (const void *)gs_tile_kernel<T, EPI, 4, 2, 6, false>;
-    return xo ? (const void *)gs_tile_kernel<T, EPI, 8, 4, 4, true> : (const void *)gs_tile_kernel<T, EPI, 8, 4, 4, false>;
+    if (variant == 0) return xo ? (const void *)gs_tile_kernel<T, EPI, 4, 2, 3, true> : (const void *)gs_tile_kernel<T, EPI, 4, 2, 3, false>;
+    return xo ? (const void *)gs_tile_kernel<T, EPI, 8, 4, 3, true> : (const void *)gs_tile_kernel<T, EPI, 8, 4, 3, false>;
 }
 
 template <typename T>
@@ -775,10 +775,22 @@ static bool tile_eligible(const pamg_matrix_s *A, const GsSchedule *g)
     return g->nlevels > 1 && A->max_row_len <= TILE_MAX_ENTRIES && g->d_xs != nullptr;
 }
 
+// Where the tiled sweep is the automatic choice (measured on MI355X, profiles/r02_microbench_tile_*.json): schedules with
+// wide dependency levels (>= 2048 rows per level on average: the fine levels of 3-D problems; 1.9 vs 2.9 ms per sweep on
+// 256^3, 0.47 vs 1.0 ms on 128^3) and tiny ones that fit a single tile (<= 1024 rows: one workgroup, every hand-off in
+// LDS; 0.20 vs 0.29 ms).  In between (SA coarse levels: ~1000 rows and 30-70 entries per row and level) the in-order row
+// sums dominate a step and the granular / single-workgroup schedulers are as fast or faster.
+static bool tile_auto(const pamg_matrix_s *A, const GsSchedule *g)
+{
+    if (A->tile_default) return true;
+    if (g->nrows <= 1024) return true;
+    return g->nrows / std::max(1, g->nlevels) >= 2048;
+}
+
 static bool want_tiles(const pamg_matrix_s *A, const GsSchedule *g)
 {
     if (!tile_eligible(A, g) || g->tile_unfit) return false;
-    return A->gs_mode == 5 || (A->gs_mode == 0 && A->tile_default);
+    return A->gs_mode == 5 || (A->gs_mode == 0 && tile_auto(A, g));
 }
 
 // device copies the scheduler of choice needs (called before any graph capture through ensure_schedule)
@@ -1483,6 +1495,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 15: A->tile_default = value != 0; return PAMG_OK;
         case 16: if (value < 0 || value > 32) return PAMG_E_ARG; A->tile_D = value; break;
         case 17: if (value < -1 || value > 4) return PAMG_E_ARG; A->tile_Q = value; break;
+        case 18: if (value < 0 || value > 1) return PAMG_E_ARG; A->tile_part = value; break;
         default: return PAMG_E_ARG;
     }
     if (key >= 12) {                                  // tile plan parameters: drop the tile parts only

@@ -1,11 +1,11 @@
 // pamg_tile_kernels.h -- the TILED order-exact sweep (gfx950).  Plan and block layout: pamg_tile_plan.h.
 //
-// One persistent workgroup of THREE specialised waves per tile; they meet only in LDS (no s_barrier,
+// One persistent workgroup of FOUR specialised waves per tile; they meet only in LDS (no s_barrier,
 // no global flag):
 //   * wave 1, the LOADER: streams the tile's step blocks (entry codes | entry values | row records, one
 //     fixed-size block per step) into a ring of D LDS slots with LDS-DMA (global_load_lds_dwordx4, 1 KiB
 //     per instruction, no registers), Q steps in flight, counted with explicit s_waitcnt vmcnt.
-//   * wave 2, the GATHERER: KG steps ahead in registers, walks the two gather lists of a landed step and
+//   * waves 2 and 3, the GATHERERS (alternating batches of KG steps): walk the two gather lists of a landed step and
 //     fetches what the step needs from global memory -- OLD values x[j], NEW values of other tiles from
 //     the hand-off buffer xs (polled: the published datum IS the flag), b and the old value of each row --
 //     and turns every entry it owns into the finished product a_ij * x_j in place.
@@ -17,7 +17,7 @@
 // The dependency chain inside a tile therefore costs one LDS round trip + one in-order row sum per
 // level; global latency (operator stream, gathers) is hidden by the ring, the cross-tile hand-off is
 // paid once per tile boundary on the critical path.
-// Progress words in LDS: landed (loader -> gatherer), ready (gatherer -> compute), done (compute ->
+// Progress words in LDS: landed (loader -> gatherers), ready x 2 (gatherer -> compute), done (compute ->
 // loader, frees slots).  Deadlock freedom: every workgroup takes its steps in non-decreasing level order
 // and a step only waits for rows of strictly lower levels, so the lexicographically smallest unfinished
 // (level, tile) can always run PROVIDED all G workgroups are resident (the host sizes G by the occupancy
@@ -33,7 +33,7 @@ namespace pamg {
 typedef int tile_v4i __attribute__((ext_vector_type(4)));   // plain vector types: live in any address space
 typedef int tile_v2i __attribute__((ext_vector_type(2)));
 
-constexpr int TILE_THREADS = 192;             // compute wave, loader wave, gather wave
+constexpr int TILE_THREADS = 256;             // compute wave, loader wave, two gather waves
 constexpr unsigned TILE_SPIN_LIMIT = 1u << 21;
 
 template <typename T>
@@ -95,7 +95,7 @@ __device__ __forceinline__ void wait_vmcnt_rt(int n)
 }
 
 // LDS control words (byte offsets)
-constexpr unsigned TC_LANDED = 0, TC_READY = 4, TC_DONE = 8, TC_ABORT = 12, TC_BYTES = 64;
+constexpr unsigned TC_LANDED = 0, TC_READY = 4 /* and 8: one word per gather wave */, TC_DONE = 12, TC_ABORT = 16, TC_BYTES = 64;
 
 // spin until the progress word exceeds v; false = aborted (another wave timed out) or timed out here
 __device__ __forceinline__ bool tile_wait(unsigned flag, int v, unsigned *err)
@@ -252,7 +252,8 @@ struct StepRegs {
 struct ComputeState {
     unsigned slot;            // LDS address of the current step's slot
     int sl;                   // its index in the ring of slots
-    int ready;                // last value read from the ready word
+    int kb;                   // position of the current step inside its batch (batches alternate between the gather waves)
+    unsigned rflag;           // ready word of the gather wave that serves the current step
     bool have;                // the operand registers of the current step were filled ahead of time
 };
 
@@ -271,22 +272,22 @@ __device__ __forceinline__ void step_operands(const SlotGeom &sg, StepRegs<T> &R
 // One step of the compute wave.  The dependent chain is: ring read -> multiply -> product write -> in-order row
 // sum -> divide -> ring write; the operands of the NEXT step (N) are requested between the row sum and the divide,
 // speculatively: they are valid iff the ready word read just before them already covered that step.
-template <typename T, int EPI, bool XO>
+template <typename T, int EPI, int KG, bool XO>
 __device__ __forceinline__ bool compute_step(const TileArgs<T> &a, const SlotGeom &sg, StepRegs<T> &R, StepRegs<T> &N, ComputeState &st,
                                              int t, int ns, int s0, int tile, int lane, unsigned ring, unsigned slot0)
 {
     const unsigned wmask = (unsigned)a.W - 1u;
     const unsigned slot = st.slot;
     if (!st.have) {
-        if (st.ready <= t) {
-            if (!tile_wait(TC_READY, t, a.err)) return false;
-            st.ready = t + 1;
-        }
+        if (!tile_wait(st.rflag, t, a.err)) return false;
         step_operands<T, XO>(sg, R, slot, lane);
     }
     long long tp0 = 0;
     if (a.prof) tp0 = wall_clock64();
-    const int rdy = (int)lds_flag_load(TC_READY);           // rides along with the stage reads; decides further down
+    // the next step's gather wave (the other one at a batch boundary): its ready word rides along with the stage reads
+    const int nkb = st.kb + 1 == KG ? 0 : st.kb + 1;
+    const unsigned nflag = nkb == 0 ? (TC_READY + TC_READY + 4u) - st.rflag : st.rflag;
+    const int rdy = (int)lds_flag_load(nflag);
     const int nrows = R.hdr.x, rbase = R.hdr.y, nloc = R.hdr.w;
     const unsigned vals = slot + (unsigned)sg.val_off;
     if (nloc > 0) {
@@ -357,7 +358,8 @@ __device__ __forceinline__ bool compute_step(const TileArgs<T> &a, const SlotGeo
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[4 + k] = stamps[k];
     }
-    st.ready = rdy > st.ready ? rdy : st.ready;
+    st.kb = nkb;
+    st.rflag = nflag;
     st.have = (t + 1 < ns) && (rdy > t + 1);
     st.slot = nslot;
     st.sl = nsl;
@@ -369,7 +371,7 @@ __device__ __forceinline__ bool compute_step(const TileArgs<T> &a, const SlotGeo
 // needed (SOR, or an operator with a missing / zero diagonal).  The <4, 2, 4> variants run several workgroups per CU
 // (wide levels: bandwidth matters, registers capped for three waves per SIMD).
 template <typename T, int EPI, int RO, int RG, int KG, bool XO>
-__global__ __launch_bounds__(TILE_THREADS, (RO <= 4 ? 3 : 1)) void gs_tile_kernel(const TileArgs<T> a)
+__global__ __launch_bounds__(TILE_THREADS, (RO <= 4 ? 2 : 1)) void gs_tile_kernel(const TileArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tile = (int)blockIdx.x;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(TILE_THREADS, (RO <= 4 ? 3 : 1)) void gs_tile_kerne
     sg.slot_b = sg.st_off + 32;
     const unsigned ring = TC_BYTES;
     const unsigned slot0 = TC_BYTES + (unsigned)a.W * (unsigned)sizeof(T);
-    if (threadIdx.x < 4) lds_flag_store(4u * threadIdx.x, 0u);
+    if (threadIdx.x < 5) lds_flag_store(4u * threadIdx.x, 0u);
     __syncthreads();
 
     if (wave == 1) {
@@ -409,55 +411,57 @@ __global__ __launch_bounds__(TILE_THREADS, (RO <= 4 ? 3 : 1)) void gs_tile_kerne
         return;
     }
 
-    if (wave == 2) {
-        // ---- gatherer: KG steps in registers; finish(t - KG) then issue(t), so the loads of KG steps are in flight.
-        // The steady-state loop is free of conditional loads (prologue and tail are peeled): any branch that MAY issue
-        // loads makes the compiler assume the fewest younger loads at the next wait, i.e. a wait for nearly everything.
-        // hipcc also drains the memory counter at the first wait behind a loop header whatever the state on its
-        // incoming edges (seen in the ISA: vmcnt(0) there, exact counts everywhere else), so one trip covers UNR * KG
-        // steps: the drain is paid once per trip.
+    if (wave >= 2) {
+        // ---- two gatherers, alternating BATCHES of KG steps: all loads of a batch are issued, then its steps are
+        // finished in order, and nothing stays in flight across the loop's back edge.  (A rotating pipeline with loads in
+        // flight across iterations needs exact memory-counter waits; hipcc falls back to near-complete drains there --
+        // seen in the ISA -- so the overlap comes from the second wave instead: while one waits for its batch, the
+        // other issues or finishes.)
+        const int w = wave - 2;
+        const unsigned rflag = TC_READY + 4u * (unsigned)w;
         GatherSet<T, RO, RG> S[KG];
-        int sl_issue = 0, sl_fin = 0;
-        auto issue = [&](GatherSet<T, RO, RG> &set, int t) -> bool {
-            if (!tile_wait(TC_LANDED, t, a.err)) return false;
-            const unsigned sa = slot0 + (unsigned)sl_issue * (unsigned)sg.slot_b;
-            if (a.prof && lane == 0) ldsp<long long>(sa + (unsigned)sg.st_off)[1] = wall_clock64();
-            gather_issue<T, RO, RG, XO>(a, sg, set, sa, lane);
-            if (++sl_issue == D) sl_issue = 0;
-            return true;
-        };
-        auto finish = [&](GatherSet<T, RO, RG> &set, int t) -> bool {
-            const unsigned sa = slot0 + (unsigned)sl_fin * (unsigned)sg.slot_b;
-            if (a.prof && lane == 0) ldsp<long long>(sa + (unsigned)sg.st_off)[2] = wall_clock64();
-            if (!gather_finish<T, RO, RG, XO>(a, sg, set, sa, lane)) return false;
-            if (a.prof && lane == 0) ldsp<long long>(sa + (unsigned)sg.st_off)[3] = wall_clock64();
-            if (++sl_fin == D) sl_fin = 0;
-            lds_drain();
-            lds_flag_store(TC_READY, (unsigned)(t + 1));
-            return true;
-        };
-        int t = 0;
-        if (ns >= 2 * KG) {
+        int sl = (w * KG) % D;                               // slot of the batch's first step
+        for (int t0 = w * KG; t0 < ns; t0 += 2 * KG) {
+            const bool full = t0 + KG <= ns;
+            if (full) {
+                int s1 = sl;
 #pragma unroll
-            for (int k = 0; k < KG; ++k)
-                if (!issue(S[k], k)) return;
-            constexpr int UNR = KG >= 6 ? 2 : 4;
-            for (t = KG; t + UNR * KG <= ns; t += UNR * KG) {
+                for (int k = 0; k < KG; ++k) {
+                    if (!tile_wait(TC_LANDED, t0 + k, a.err)) return;
+                    const unsigned sa = slot0 + (unsigned)s1 * (unsigned)sg.slot_b;
+                    if (a.prof && lane == 0) ldsp<long long>(sa + (unsigned)sg.st_off)[1] = wall_clock64();
+                    gather_issue<T, RO, RG, XO>(a, sg, S[k], sa, lane);
+                    if (++s1 == D) s1 = 0;
+                }
+                s1 = sl;
 #pragma unroll
-                for (int u = 0; u < UNR * KG; ++u) {
-                    if (!finish(S[u % KG], t + u - KG)) return;
-                    if (!issue(S[u % KG], t + u)) return;
+                for (int k = 0; k < KG; ++k) {
+                    const unsigned sa = slot0 + (unsigned)s1 * (unsigned)sg.slot_b;
+                    if (a.prof && lane == 0) ldsp<long long>(sa + (unsigned)sg.st_off)[2] = wall_clock64();
+                    if (!gather_finish<T, RO, RG, XO>(a, sg, S[k], sa, lane)) return;
+                    if (a.prof && lane == 0) ldsp<long long>(sa + (unsigned)sg.st_off)[3] = wall_clock64();
+                    lds_drain();
+                    lds_flag_store(rflag, (unsigned)(t0 + k + 1));
+                    if (++s1 == D) s1 = 0;
+                }
+            } else {
+                // the tile's last, partial batch: one step at a time
+                int s1 = sl;
+                for (int t = t0; t < ns; ++t) {
+                    if (!tile_wait(TC_LANDED, t, a.err)) return;
+                    const unsigned sa = slot0 + (unsigned)s1 * (unsigned)sg.slot_b;
+                    if (a.prof && lane == 0) ldsp<long long>(sa + (unsigned)sg.st_off)[1] = wall_clock64();
+                    gather_issue<T, RO, RG, XO>(a, sg, S[0], sa, lane);
+                    if (a.prof && lane == 0) ldsp<long long>(sa + (unsigned)sg.st_off)[2] = wall_clock64();
+                    if (!gather_finish<T, RO, RG, XO>(a, sg, S[0], sa, lane)) return;
+                    if (a.prof && lane == 0) ldsp<long long>(sa + (unsigned)sg.st_off)[3] = wall_clock64();
+                    lds_drain();
+                    lds_flag_store(rflag, (unsigned)(t + 1));
+                    if (++s1 == D) s1 = 0;
                 }
             }
-        }
-        // head of short tiles and the tail: steps t - KG .. are still to be finished, steps t .. to be issued
-        for (; t < ns + KG; t += KG) {
-#pragma unroll
-            for (int k = 0; k < KG; ++k) {
-                const int u = t + k;
-                if (u >= KG && u - KG < ns && !finish(S[k], u - KG)) return;
-                if (u < ns && !issue(S[k], u)) return;
-            }
+            sl += (2 * KG) % D;
+            if (sl >= D) sl -= D;
         }
         return;
     }
@@ -465,11 +469,11 @@ __global__ __launch_bounds__(TILE_THREADS, (RO <= 4 ? 3 : 1)) void gs_tile_kerne
     // ---- compute wave (two steps per trip: the operand registers of step t + 1 are filled while step t divides)
     StepRegs<T> R0, R1;
     ComputeState st;
-    st.slot = slot0; st.sl = 0; st.ready = 0; st.have = false;
+    st.slot = slot0; st.sl = 0; st.kb = 0; st.rflag = TC_READY; st.have = false;
     for (int t = 0; t < ns; t += 2) {
-        if (!compute_step<T, EPI, XO>(a, sg, R0, R1, st, t, ns, s0, tile, lane, ring, slot0)) return;
+        if (!compute_step<T, EPI, KG, XO>(a, sg, R0, R1, st, t, ns, s0, tile, lane, ring, slot0)) return;
         if (t + 1 >= ns) break;
-        if (!compute_step<T, EPI, XO>(a, sg, R1, R0, st, t + 1, ns, s0, tile, lane, ring, slot0)) return;
+        if (!compute_step<T, EPI, KG, XO>(a, sg, R1, R0, st, t + 1, ns, s0, tile, lane, ring, slot0)) return;
     }
 }
 

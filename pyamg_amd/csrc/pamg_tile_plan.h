@@ -81,7 +81,11 @@ constexpr int TP_DIAG = 0x40000000;
 constexpr int TP_MASK = 0x3FFFFFFF;
 constexpr int TP_PUBLISH = (int)0x80000000u;  // in rid[]
 inline int tile_list_bytes(int n_old, int n_glob, int n_loc) { return 16 + 4 * ((n_loc + 1) & ~1) + 8 * (n_old + n_glob); }
+#ifndef PAMG_TILE_SIM_LIMITS
 constexpr int TILE_MAX_OLD = 512, TILE_MAX_GLOB = 256, TILE_MAX_LIST_BYTES = 12288, TILE_MAX_ENTRIES = 2048;   // per step
+#else
+constexpr int TILE_MAX_OLD = 1 << 20, TILE_MAX_GLOB = 1 << 20, TILE_MAX_LIST_BYTES = 1 << 28, TILE_MAX_ENTRIES = 1 << 20;   // design aid (tools/tile_sim.cpp): no limits
+#endif
 
 // Dependency levels of the sweep i = row_start, row_start+row_step, ... (!= row_stop): level[i] for
 // visited rows, vis[i] = visit index or -1.  Row i runs strictly after every connected row visited
@@ -125,6 +129,33 @@ inline int sweep_levels(int n, const int *Ap, const int *Aj, int row_start, int 
     return 0;
 }
 
+// Is the operator a three-band stencil on a lexicographic grid?  Looks at the backward offsets i - j of a sample of
+// rows: the three most frequent ones must be 1 < nx < nx*ny with nx | nx*ny and carry (nearly) all backward entries.
+inline bool tile_detect_grid(int n, const int *Ap, const int *Aj, int64_t &nx, int64_t &nxy)
+{
+    std::vector<std::pair<int64_t, int64_t>> hist;     // (offset, count), tiny
+    int64_t total = 0;
+    const int stride = std::max(1, n / 4096) | 1;          // odd: does not resonate with power-of-two grid lines
+    for (int i = n / 2; i < n; i += stride) {
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int64_t d = (int64_t)i - Aj[p];
+            if (d <= 0) continue;
+            ++total;
+            bool found = false;
+            for (auto &h : hist) if (h.first == d) { h.second++; found = true; break; }
+            if (!found) { if (hist.size() > 64) return false; hist.push_back({d, 1}); }
+        }
+    }
+    if (hist.size() < 3 || total == 0) return false;
+    std::sort(hist.begin(), hist.end(), [](const auto &a, const auto &b) { return a.second > b.second; });
+    int64_t d[3] = {hist[0].first, hist[1].first, hist[2].first};
+    std::sort(d, d + 3);
+    if (hist[0].second + hist[1].second + hist[2].second < total * 95 / 100) return false;
+    if (d[0] != 1 || d[1] < 4 || d[2] % d[1] != 0 || d[2] / d[1] < 4) return false;
+    nx = d[1]; nxy = d[2];
+    return true;
+}
+
 // Build the plan from a finished analysis (vis / lvl of sweep_levels, m visited rows, nl levels).  G_want tiles
 // (clipped to the number of visited rows), ring of W slots (power of two), at most cap entries and max_rows rows
 // per step.
@@ -135,12 +166,39 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
     if (W < 64 || (W & (W - 1)) || cap < 2 || max_rows < 1) return 1;
     P = TilePlan();
     P.W = W; P.cap = cap; P.nlevels = nl;
-    const int G = std::max(1, std::min(G_want, std::max(1, m)));
-    P.G = G;
-    // tile of each visited row: contiguous chunks of the visit order, balanced by work (entries + a
-    // per-row constant)
+    int G = std::max(1, std::min(G_want, std::max(1, m)));
+    // tile of each visited row.  partition 0: contiguous chunks of the visit order, balanced by work (entries + a
+    // per-row constant).  partition 1: when the operator is a three-band stencil on a lexicographic grid (offsets 1, nx,
+    // nx*ny between connected rows), tiles are PENCILS -- all of x, ty lines, tz planes -- so a dependency chain crosses
+    // a tile boundary every ty-th step in y and every tz-th step in z instead of at every plane; anything else falls
+    // back to partition 0.
     std::vector<int> tile((size_t)n, -1);
-    {
+    bool pencils = false;
+    if (partition == 1 && m >= 512 && (row_step == 1 || row_step == -1) && m == n) {
+        int64_t nx = 0, nxy = 0;
+        if (tile_detect_grid(n, Ap, Aj, nx, nxy)) {
+            const int64_t ny = nxy / nx, nz = ((int64_t)n + nxy - 1) / nxy;
+            // lines per tile, split as evenly as the plane counts allow (powers of two)
+            const double lines = std::max(1.0, (double)m / G / (double)nx);
+            int64_t ty = 1, tz = 1;
+            while (ty * tz * 2 <= lines + 0.5) { if (ty <= tz && ty * 2 <= ny) ty *= 2; else if (tz * 2 <= nz) tz *= 2; else if (ty * 2 <= ny) ty *= 2; else break; }
+            const int64_t gy = (ny + ty - 1) / ty, gz = (nz + tz - 1) / tz;
+            if (gy * gz <= (int64_t)G_want * 2 && gy * gz >= 1) {
+                G = (int)(gy * gz);
+                for (int t = 0; t < m; ++t) {
+                    const int i = row_start + t * row_step;
+                    const int64_t p = row_step == 1 ? (int64_t)t : (int64_t)(m - 1 - t);   // lexicographic position of the row
+                    const int64_t z = p / nxy, y = (p % nxy) / nx;
+                    int64_t k = (z / tz) * gy + (y / ty);
+                    if (row_step != 1) k = (int64_t)G - 1 - k;         // tiles numbered along the sweep
+                    tile[i] = (int)k;
+                }
+                pencils = true;
+            }
+        }
+    }
+    P.G = G;
+    if (!pencils) {
         std::vector<int64_t> cum((size_t)m + 1, 0);
         for (int t = 0; t < m; ++t) {
             const int i = row_start + t * row_step;
@@ -155,32 +213,31 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
             tile[row_start + t * row_step] = k;
         }
     }
-    // stored order: tile-major, inside a tile by (level, visit order)
+    // stored order: tile-major, inside a tile by (level, visit order): two stable counting sorts
     std::vector<int> tcount((size_t)G + 1, 0);
     for (int t = 0; t < m; ++t) tcount[tile[row_start + t * row_step] + 1]++;
     for (int k = 0; k < G; ++k) tcount[k + 1] += tcount[k];
     std::vector<int> order((size_t)m);
-    // a tile's rows are contiguous in visit order: counting sort of each chunk by level (stable, so the visit
-    // order survives inside a level)
-    tp_parallel(G, [&](int klo, int khi) {
-        std::vector<int> cnt;
-        for (int k = klo; k < khi; ++k) {
-            const int t0 = tcount[k], t1 = tcount[k + 1];
-            if (t0 >= t1) continue;
-            int lmin = lvl[row_start + t0 * row_step], lmax = lmin;
-            for (int t = t0; t < t1; ++t) {
-                const int L = lvl[row_start + t * row_step];
-                lmin = std::min(lmin, L); lmax = std::max(lmax, L);
-            }
-            cnt.assign((size_t)(lmax - lmin) + 2, 0);
-            for (int t = t0; t < t1; ++t) cnt[lvl[row_start + t * row_step] - lmin + 1]++;
-            for (int l = 0; l <= lmax - lmin; ++l) cnt[l + 1] += cnt[l];
-            for (int t = t0; t < t1; ++t) {
-                const int i = row_start + t * row_step;
-                order[t0 + cnt[lvl[i] - lmin]++] = i;
-            }
+    {
+        std::vector<int> bytile((size_t)m), cur(tcount.begin(), tcount.end() - 1);
+        for (int t = 0; t < m; ++t) {
+            const int i = row_start + t * row_step;
+            bytile[cur[tile[i]]++] = i;
         }
-    });
+        tp_parallel(G, [&](int klo, int khi) {
+            std::vector<int> cnt;
+            for (int k = klo; k < khi; ++k) {
+                const int t0 = tcount[k], t1 = tcount[k + 1];
+                if (t0 >= t1) continue;
+                int lmin = lvl[bytile[t0]], lmax = lmin;
+                for (int t = t0; t < t1; ++t) { lmin = std::min(lmin, lvl[bytile[t]]); lmax = std::max(lmax, lvl[bytile[t]]); }
+                cnt.assign((size_t)(lmax - lmin) + 2, 0);
+                for (int t = t0; t < t1; ++t) cnt[lvl[bytile[t]] - lmin + 1]++;
+                for (int l = 0; l <= lmax - lmin; ++l) cnt[l + 1] += cnt[l];
+                for (int t = t0; t < t1; ++t) order[t0 + cnt[lvl[bytile[t]] - lmin]++] = bytile[t];
+            }
+        });
+    }
     std::vector<int> pos((size_t)n, -1);      // stored position of a visited row
     for (int r = 0; r < m; ++r) pos[order[r]] = r;
     P.Ap.assign((size_t)m + 1, 0);
@@ -259,12 +316,12 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
 }
 
 inline int build_tile_plan(int n, const int *Ap, const int *Aj, int row_start, int row_stop, int row_step,
-                           int G_want, int W, int cap, int max_rows, TilePlan &P)
+                           int G_want, int W, int cap, int max_rows, TilePlan &P, int partition = 0)
 {
     std::vector<int> vis, lvl;
     int m = 0, nl = 0;
     if (sweep_levels(n, Ap, Aj, row_start, row_stop, row_step, vis, lvl, m, nl)) return 1;
-    return build_tile_plan_from(n, Ap, Aj, row_start, row_step, m, nl, vis, lvl, G_want, W, cap, max_rows, P);
+    return build_tile_plan_from(n, Ap, Aj, row_start, row_step, m, nl, vis, lvl, G_want, W, cap, max_rows, P, partition);
 }
 
 // ---- fixed-size step blocks (the device layout)

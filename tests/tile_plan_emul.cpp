@@ -140,10 +140,10 @@ extern "C" {
 // [5] publishing rows, [6] hazards (sentinel consumed), [7] stuck (deadlock in the replay)
 int tile_emul_sweep_f64(int n, const int *Ap, const int *Aj, const double *Ax, double *x, const double *b, int row_start,
                         int row_stop, int row_step, int G, int W, int cap, int max_rows, int epi, double omega,
-                        int use_snapshot, int policy, int look, int64_t *stats)
+                        int use_snapshot, int policy, int look, int partition, int64_t *stats)
 {
     TilePlan P;
-    if (build_tile_plan(n, Ap, Aj, row_start, row_stop, row_step, G, W, cap, max_rows, P)) return 1;
+    if (build_tile_plan(n, Ap, Aj, row_start, row_stop, row_step, G, W, cap, max_rows, P, partition)) return 1;
     TileGeom geom{0, 0, 8};
     if (!tile_geometry(P, 8, geom)) return 2;
     std::vector<double> xv(x, x + n), snap;

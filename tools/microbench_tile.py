@@ -40,6 +40,7 @@ ap.add_argument("--tiles", type=int, nargs="*", default=[0])
 ap.add_argument("--rings", type=int, nargs="*", default=[0])
 ap.add_argument("--slots", type=int, nargs="*", default=[0])
 ap.add_argument("--inflight", type=int, nargs="*", default=[-1])
+ap.add_argument("--parts", type=int, nargs="*", default=[1])
 ap.add_argument("--caps", type=int, nargs="*", default=[0])
 ap.add_argument("--levels", type=int, nargs="*", default=None)
 ap.add_argument("--baseline", type=int, default=1)
@@ -90,7 +91,8 @@ for li, L in enumerate(spec.levels[:-1]):
             for cap in a.caps:
                 for D in a.slots:
                     for Q in a.inflight:
-                        variants.append((f"tile_G{G}_W{W}_c{cap}_D{D}_Q{Q}", dict(gs_mode=5, tile_G=G, tile_W=W, tile_cap=cap, tile_D=D, tile_Q=Q, gs_prof=0)))
+                        for pt in a.parts:
+                            variants.append((f"tile_G{G}_W{W}_c{cap}_D{D}_Q{Q}_p{pt}", dict(gs_mode=5, tile_G=G, tile_W=W, tile_cap=cap, tile_D=D, tile_Q=Q, tile_part=pt, gs_prof=0)))
     for name, kw in variants:
         dA.tune(**kw)
         dx.upload(x)

@@ -18,6 +18,9 @@ ap.add_argument("--c1", type=float, default=0.011)
 ap.add_argument("--W", type=int, default=2048)
 ap.add_argument("--cap", type=int, default=512)
 ap.add_argument("--backward", type=int, default=0)
+ap.add_argument("--rows", type=int, default=64)
+ap.add_argument("--c2", type=float, default=0.0)
+ap.add_argument("--nolimit", type=int, default=0)
 a = ap.parse_args()
 cache = Path("/tmp") / ("hier_" + "x".join(map(str, a.grid)) + ".npz")
 if not cache.exists():
@@ -34,11 +37,11 @@ if not cache.exists():
     np.savez(cache, **d)
     print(f"setup {time.time()-t:.1f}s")
 Z = np.load(cache)
-so = Path("/tmp/tile_sim.so")
+so = Path("/tmp/tile_sim_nolimit.so" if a.nolimit else "/tmp/tile_sim.so")
 src = ROOT / "tools" / "tile_sim.cpp"
 hdr = ROOT / "pyamg_amd" / "csrc" / "pamg_tile_plan.h"
 if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
-    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", str(src), "-o", str(so), "-lpthread"], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC"] + (["-DSIM_NOLIMIT"] if a.nolimit else []) + [str(src), "-o", str(so), "-lpthread"], check=True)
 lib = ctypes.CDLL(str(so))
 for li in a.levels:
     if f"p{li}" not in Z:
@@ -51,7 +54,7 @@ for li in a.levels:
             start, stop, step = (n - 1, -1, -1) if a.backward else (0, n, 1)
             nl_guess = 0
             t = time.time()
-            rc = lib.tile_sim(n, Ap.ctypes.data_as(ctypes.c_void_p), Aj.ctypes.data_as(ctypes.c_void_p), start, stop, step, G if G > 0 else -1, a.W, a.cap,
-                              ctypes.c_double(a.c0), ctypes.c_double(a.c1), ctypes.c_double(a.hop), mode, out.ctypes.data_as(ctypes.c_void_p))
+            rc = lib.tile_sim(n, Ap.ctypes.data_as(ctypes.c_void_p), Aj.ctypes.data_as(ctypes.c_void_p), start, stop, step, G if G > 0 else -1, a.W, a.cap, a.rows,
+                              ctypes.c_double(a.c0), ctypes.c_double(a.c1), ctypes.c_double(a.c2), ctypes.c_double(a.hop), mode, out.ctypes.data_as(ctypes.c_void_p))
             print(f"L{li} n={n} nnz={Ap[-1]} mode={mode} G={int(out[5])} rc={rc}: span {out[0]/1000:.3f} ms  steps {int(out[1])} levels {int(out[2])} "
                   f"crit.crossings {int(out[3])} busiest tile {out[4]/1000:.3f} ms ideal(levels*c) {out[8]/1000:.3f} ms  glob {int(out[6])} loc {int(out[7])}  [{time.time()-t:.1f}s]", flush=True)
