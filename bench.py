@@ -42,6 +42,9 @@ CHEB = ("chebyshev", {"degree": 3, "iterations": 1})
 WORKLOADS = {
     "c2": dict(grid=(2000, 2000), smoother=JAC,
                label="gallery.poisson((2000,2000)) SA V-cycle, weighted-Jacobi pre/post, fp64"),
+    # BASELINE configs[0]: the reference's own README example (README.md:126-153), CPU-runnable; Jacobi pre/post
+    "c1": dict(grid=(500, 500), smoother=JAC, kind="rs",
+               label="gallery.poisson((500,500)) CSR, ruge_stuben_solver, Jacobi pre/post, fp64"),
     "c3": dict(grid=(256, 256, 256), smoother=GS,
                label="3D 7-pt Poisson 256^3 (16.7M dof) SA V-cycle, symmetric Gauss-Seidel, fp64"),
     "c3j": dict(grid=(256, 256, 256), smoother=JAC,
@@ -72,6 +75,26 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, the same
+    environment contract torch.distributed.run provides), pass rank 0's JSON line through, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit(f"bench ranks exited with {rcs}")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +106,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--min-rows", type=int, default=200_000, help="shard levels with at least this many rows")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,6 +188,9 @@ def main():
             return A, ml, time.time() - t0
         A = pyamg.gallery.poisson(wl["grid"], format="csr")
         np.random.seed(SEED)                   # Arnoldi start vectors of the smoother setup
+        if wl.get("kind") == "rs":
+            ml = pyamg.ruge_stuben_solver(A, presmoother=wl["smoother"], postsmoother=wl["smoother"])
+            return A, ml, time.time() - t0
         ml = pyamg.smoothed_aggregation_solver(A, presmoother=wl["smoother"], postsmoother=wl["smoother"],
                                                max_coarse=10)
         return A, ml, time.time() - t0
@@ -207,6 +236,27 @@ def main():
         d = np.abs(np.asarray(res_gpu)[:m] - res_cpu[1:m + 1])
         return {"cycles_compared": int(m), "max_abs_diff_over_r0": float(np.max(d) / res_cpu[0]),
                 "max_rel_diff": float(np.max(d / res_cpu[1:m + 1])), "tolerance": "1e-10 * ||r0|| (random rhs)"}
+
+    def protocol_parity(dml, ml, n, k=10):
+        """the reference's own convergence protocol (docs/paper/example.py:11-14): b = 0, x0 = rand -- r = -A x has no
+        cancellation, so every residual norm of the first k cycles must agree to 1e-10 RELATIVE"""
+        np.random.seed(2022)
+        x0r = np.random.rand(n)
+        b0 = np.zeros(n)
+        xz, bz = capi.DeviceArray.from_host(x0r), capi.DeviceArray.from_host(b0)
+        dml.load_device(xz, bz)
+        g = np.asarray(dml.iterate_device(k))
+        xz.free(); bz.free()
+        r = []
+        t0 = time.perf_counter()
+        ml.solve(b0, x0=x0r, tol=1e-30, maxiter=k, residuals=r)
+        tc = time.perf_counter() - t0
+        c = np.asarray(r)[1:k + 1]
+        m = min(len(g), len(c))
+        rel = np.abs(g[:m] - c[:m]) / c[:m]
+        return {"protocol": "b = 0, x0 = rand (seed 2022), reference residual norms after each cycle", "cycles_compared": int(m),
+                "max_rel_diff": float(rel.max()), "tolerance": "1e-10 relative, every cycle", "ok": bool(rel.max() <= 1e-10),
+                "first_last_norm": [float(c[0]), float(c[m - 1])], "cpu_s": round(tc, 1)}
 
     # =========================================================== main workload
     wl = WORKLOADS[args.workload]
@@ -290,6 +340,7 @@ def main():
         kcpu = args.cpu_cycles if args.cpu_cycles > 0 else (3 if n > 5_000_000 else 10)
         cpu, res_cpu = cpu_reference(ml, A, b, x0, kcpu)
         parity = parity_of(res_gpu, res_cpu)
+        parity["reference_protocol"] = protocol_parity(dml, ml, n)
     if rank == 0:
         replicas = world > 1
         out = {
@@ -394,11 +445,35 @@ def main():
             c3cpu, r3cpu = cpu_reference(ml2, A2, b2, x02, 10)
             ex["cpu_baseline"] = c3cpu
             ex["parity"] = parity_of(res3, r3cpu)
+            ex["parity"]["reference_protocol"] = protocol_parity(d3, ml2, A2.shape[0])
         out["extra"] = {"c2": ex}
         d3.free()
       except Exception as e:                                    # noqa: BLE001
         log(f"configs[1] leg failed: {e!r}")
         out["extra"] = {"c2": {"error": repr(e)[:300]}}
+      # configs[0]: the README's Ruge-Stuben example -- an irregular classical hierarchy at size, with the published
+      # level sizes as the anchor (README.md:143-151)
+      try:
+        wl1 = WORKLOADS["c1"]
+        A1, ml1, ts1 = build(wl1)
+        b1, x01 = rhs(A1.shape[0])
+        d1 = DeviceMultilevelSolver(ml1, device=local_rank, graph=not args.no_graph)
+        w1, _, res1, _, _ = time_resident(d1, b1, x01, 50, 5)
+        sizes = [[int(L.A.shape[0]), int(L.A.nnz)] for L in ml1.levels]
+        ex1 = {"workload": wl1["label"], "value": round(50 / w1, 3), "unit": "cycles/s", "ms_per_step": round(w1 * 1e3 / 50, 4),
+               "steps": 50, "host_setup_s": round(ts1, 1), "levels": len(ml1.levels), "level_sizes": sizes[:4],
+               "readme_anchor": {"levels": 9, "level0": [250000, 1248000], "level1": [125000, 1121002],
+                                 "match": bool(len(ml1.levels) == 9 and sizes[0] == [250000, 1248000] and sizes[1] == [125000, 1121002])}}
+        if args.cpu_cycles != 0:
+            c1cpu, r1cpu = cpu_reference(ml1, A1, b1, x01, 10)
+            ex1["cpu_baseline"] = c1cpu
+            ex1["parity"] = parity_of(res1, r1cpu)
+            ex1["parity"]["reference_protocol"] = protocol_parity(d1, ml1, A1.shape[0])
+        out.setdefault("extra", {})["c1"] = ex1
+        d1.free()
+      except Exception as e:                                    # noqa: BLE001
+        log(f"configs[0] leg failed: {e!r}")
+        out.setdefault("extra", {})["c1"] = {"error": repr(e)[:300]}
 
     emit()
     if world > 1:

@@ -353,6 +353,9 @@ __device__ __forceinline__ void row_finish(const StreamArgs<T> &a, const RowPre<
     const int row = q.row;
     if constexpr (EPI == EPI_SET || EPI == EPI_ACCSEQ) {
         a.y[row] = s;
+        // EPI_SET can clear a second vector of the same length on the way (the cycle's b_c = R r also sets x_c = 0:
+        // one launch less per level than a separate fill); the otherwise unused `partial` slot carries its address
+        if constexpr (EPI == EPI_SET) { if (a.partial) reinterpret_cast<T *>(a.partial)[row] = T(0); }
     } else if constexpr (EPI == EPI_ACC) {
         a.y[row] = q.y + s;
     } else if constexpr (EPI == EPI_RESID) {

@@ -268,8 +268,8 @@ int cycle_rec(pamg_solver_s *S, int lvl, int type, int cpl, bool x_zero, hipStre
     const size_t ts = tsize(S->dtype);
     PAMG_TRY(apply_smoother(S, L, L.pre, x_zero, s));
     PAMG_TRY(stream_launch(L.A, EPI_RESID, L.x, L.b, L.r, 0.0, 0.0, nullptr, s));      // r = b - A x
-    PAMG_TRY(stream_launch(L.R, EPI_SET, L.r, nullptr, N.b, 0.0, 0.0, nullptr, s));     // b_c = R r
-    PAMG_HIP(hipMemsetAsync(N.x, 0, (size_t)N.n * ts, s));                              // x_c = 0
+    // b_c = R r and x_c = 0 in one launch (multilevel.py:613-615)
+    PAMG_TRY(stream_launch(L.R, EPI_SET, L.r, nullptr, N.b, 0.0, 0.0, reinterpret_cast<double *>(N.x), s));
     if (lvl == nlev - 2) {
         PAMG_TRY(coarse_solve(S, N.b, N.x, s));
     } else if (type == PAMG_CYCLE_V) {

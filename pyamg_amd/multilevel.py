@@ -441,39 +441,48 @@ class DeviceMultilevelSolver:
                 residuals[:] = list(res)
             out = self._xd.download()
             return (out, info) if return_info else out
+        return self._host_krylov(b, x0, tol, maxiter, cycle, accel, callback, residuals, return_info)
+
+    def _host_krylov(self, b, x0, tol, maxiter, cycle, accel, callback, residuals, return_info):
+        """Host Krylov method around the device cycle (reference: multilevel.py:494-535).  ``accel`` is a callable or
+        the name of one -- looked up in the reference package's ``krylov`` module when this solver wraps a reference
+        hierarchy, else in ``scipy.sparse.linalg``.  The two families differ in how they report residuals: the
+        reference's solvers take ``residuals=``/``tol=``, SciPy's take ``rtol=``/``atol=`` and only a callback."""
         import scipy.sparse.linalg as sla
         A = self.spec.levels[0].A.to_scipy()
-        kwargs = {}
-        if isinstance(accel, str):
-            krylov = None
-            if self.ml is not None:
-                import importlib
-                try:
-                    krylov = importlib.import_module(type(self.ml).__module__.split(".")[0] + ".krylov")
-                except Exception:       # pragma: no cover
-                    krylov = None
-            accel = getattr(krylov, accel) if krylov is not None and hasattr(krylov, accel) else getattr(sla, accel)
+        solver = accel if callable(accel) else self._find_krylov(accel, sla)
         M = self.aspreconditioner(cycle=cycle)
-        try:
-            x, info = accel(A, b, x0=x0, tol=tol, maxiter=maxiter, M=M, callback=callback,
-                            residuals=residuals, **kwargs)
-            return (x, info) if return_info else x
-        except TypeError:
-            if residuals is not None:
-                xz = np.zeros_like(b) if x0 is None else np.array(x0)
-                residuals[:] = [np.linalg.norm(b - A @ xz)]
+        finish = (lambda x, info: (x, info)) if return_info else (lambda x, info: x)
 
-                def callback_wrapper(xk):
-                    if np.isscalar(xk):
-                        residuals.append(xk)
-                    else:
-                        residuals.append(np.linalg.norm(b - A @ xk))
+        def pyamg_style():
+            return solver(A, b, x0=x0, tol=tol, maxiter=maxiter, M=M, callback=callback, residuals=residuals)
+
+        def scipy_style():
+            cb = callback
+            if residuals is not None:
+                start = np.zeros_like(b) if x0 is None else np.asarray(x0)
+                residuals[:] = [np.linalg.norm(b - A @ start)]
+
+                def cb(xk):                                  # SciPy hands over the iterate or (GMRES) a residual norm
+                    residuals.append(xk if np.isscalar(xk) else np.linalg.norm(b - A @ xk))
                     if callback is not None:
                         callback(xk)
-            else:
-                callback_wrapper = callback
-            x, info = accel(A, b, x0=x0, maxiter=maxiter, M=M, callback=callback_wrapper, rtol=tol, atol=0)
-            return (x, info) if return_info else x
+            return solver(A, b, x0=x0, maxiter=maxiter, M=M, callback=cb, rtol=tol, atol=0)
+
+        try:
+            return finish(*pyamg_style())
+        except TypeError:                                    # no ``residuals=`` / ``tol=``: a SciPy-style signature
+            return finish(*scipy_style())
+
+    def _find_krylov(self, name, sla):
+        pkg = None
+        if self.ml is not None:
+            import importlib
+            try:
+                pkg = importlib.import_module(type(self.ml).__module__.split(".")[0] + ".krylov")
+            except Exception:       # pragma: no cover
+                pkg = None
+        return getattr(pkg, name) if pkg is not None and hasattr(pkg, name) else getattr(sla, name)
 
     def change_solve_matrix(self, A):
         """Swap the fine-level operator (reference: multilevel.py:320-337 -- the host solver

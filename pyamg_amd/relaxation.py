@@ -24,41 +24,48 @@ __all__ = ["make_system", "jacobi", "gauss_seidel", "sor", "polynomial", "block_
            "gauss_seidel_nr", "jacobi_ne"]
 
 
-def make_system(A, x, b, formats=None):
-    """Return A, x, b suitable for relaxation or raise -- same contract as the reference's
-    ``make_system`` (relaxation.py:15-97): ValueError for non-square A / bad shapes /
-    non-contiguous x, TypeError for mixed dtypes."""
-    if formats is None:
-        pass
-    elif formats == ["csr"]:
-        if sparse.issparse(A) and A.format == "csr":
-            pass
-        elif sparse.issparse(A) and A.format == "bsr":
-            A = A.tocsr()
-        else:
-            warn("implicit conversion to CSR", sparse.SparseEfficiencyWarning)
-            A = sparse.csr_array(A)
-    elif sparse.issparse(A) and A.format in formats:
-        pass
-    else:
-        A = sparse.csr_array(A).asformat(formats[0])
+def _as_format(A, formats):
+    """A in one of the wanted storage formats (first one preferred); ``['csr']`` alone keeps the reference's
+    habit of warning when something that is neither CSR nor BSR has to be converted."""
+    have = A.format if sparse.issparse(A) else None
+    if formats is None or have in formats:
+        return A
+    if list(formats) == ["csr"]:
+        if have == "bsr":
+            return A.tocsr()
+        warn("implicit conversion to CSR", sparse.SparseEfficiencyWarning)
+        return sparse.csr_array(A)
+    return sparse.csr_array(A).asformat(formats[0])
 
-    if not isinstance(x, np.ndarray):
-        raise ValueError("expected numpy array for argument x")
-    if not isinstance(b, np.ndarray):
-        raise ValueError("expected numpy array for argument b")
-    M, N = A.shape
-    if M != N:
-        raise ValueError("expected square matrix")
-    if x.shape not in [(M,), (M, 1)]:
-        raise ValueError("x has invalid dimensions")
-    if b.shape not in [(M,), (M, 1)]:
-        raise ValueError("b has invalid dimensions")
-    if A.dtype != x.dtype or A.dtype != b.dtype:
-        raise TypeError("arguments A, x, and b must have the same dtype")
-    if not x.flags.carray:
-        raise ValueError("x must be contiguous in memory")
-    return A, np.ravel(x), np.ravel(b)
+
+def _system_defects(A, x, b):
+    """(exception type, message) for everything the relaxation entry points refuse, in the order the
+    reference reports them (relaxation.py:59-97)."""
+    for name, v in (("x", x), ("b", b)):
+        if not isinstance(v, np.ndarray):
+            yield ValueError, f"expected numpy array for argument {name}"
+            return
+    rows, cols = A.shape
+    if rows != cols:
+        yield ValueError, "expected square matrix"
+    ok_shapes = ((rows,), (rows, 1))
+    for name, v in (("x", x), ("b", b)):
+        if v.shape not in ok_shapes:
+            yield ValueError, f"{name} has invalid dimensions"
+    if len({np.dtype(A.dtype), x.dtype, b.dtype}) != 1:
+        yield TypeError, "arguments A, x, and b must have the same dtype"
+    if not x.flags.c_contiguous or not x.flags.aligned or not x.flags.writeable:
+        yield ValueError, "x must be contiguous in memory"
+
+
+def make_system(A, x, b, formats=None):
+    """A (in an accepted format), flat views of x and b -- or the exception the reference's ``make_system``
+    raises for the same arguments (relaxation.py:15-97): ValueError for non-square A, wrong shapes, non-array
+    or non-contiguous x; TypeError for mixed dtypes.  x is returned as a VIEW: the sweeps update it in place."""
+    A = _as_format(A, formats)
+    for exc, msg in _system_defects(A, x, b):
+        raise exc(msg)
+    return A, x.reshape(-1), b.reshape(-1)
 
 
 class _Staged:

@@ -39,6 +39,8 @@ ACCEL_ONLY = "--accel-only" in sys.argv      # only (re)generate accel_fgmres.np
 ACCEL_CASES = ("sa2d_gs", "sa2d_jacobi_AMLI", "rs2d_nonsym_gs", "el2d_blockgs", "sa3d_gs", "air2d_fcjacobi",
                "bb2d_nonsym_gsnr")
 ACCEL = {}
+ACCEL_CG = {}
+CG_CASES = ("sa2d_gs", "sa3d_gs", "el2d_blockgs")     # SPD operator + symmetric smoothing: solve(accel='cg') is legitimate
 
 
 def accel_case(name, ml, cycle):
@@ -61,6 +63,18 @@ def accel_case(name, ml, cycle):
             ACCEL[f"{name}.gmres.{tag}.res"] = np.array(res)
             ACCEL[f"{name}.gmres.{tag}.x"] = x
             ACCEL[f"{name}.gmres.{tag}.info"] = np.array(info)
+    if name in CG_CASES:
+        # MultilevelSolver.solve(accel='cg') of the reference (multilevel.py:479-535 -> krylov/_cg.py)
+        for tag, kw in (("a", dict(tol=1e-10, maxiter=12)), ("b", dict(tol=1e-8, maxiter=50))):
+            res = []
+            x, info = ml.solve(b, cycle=cycle, accel="cg", residuals=res, return_info=True, **kw)
+            ACCEL_CG[f"{name}.{tag}.res"] = np.array(res)
+            ACCEL_CG[f"{name}.{tag}.x"] = x
+            ACCEL_CG[f"{name}.{tag}.info"] = np.array(info)
+            ACCEL_CG[f"{name}.{tag}.tol"] = np.array(kw["tol"])
+            ACCEL_CG[f"{name}.{tag}.maxiter"] = np.array(kw["maxiter"])
+        ACCEL_CG[f"{name}.b"] = b
+        ACCEL_CG[f"{name}.cycle"] = np.array(cycle)
     ACCEL[f"{name}.b"] = b
     ACCEL[f"{name}.cycle"] = np.array(cycle)
     print(f"accel fgmres {name}: lens {len(ACCEL[name + '.a.res'])}/{len(ACCEL[name + '.b.res'])} info {ACCEL[name + '.a.info']}/{ACCEL[name + '.b.info']}")
@@ -398,6 +412,9 @@ def save_accel():
     if ACCEL:
         np.savez_compressed(HERE / "accel_fgmres.npz", **ACCEL)
         print("accel_fgmres.npz written:", len(ACCEL), "arrays")
+    if ACCEL_CG:
+        np.savez_compressed(HERE / "accel_cg.npz", **ACCEL_CG)
+        print("accel_cg.npz written:", len(ACCEL_CG), "arrays")
 
 
 if __name__ == "__main__" and "--indexed-only" in sys.argv:

@@ -174,6 +174,32 @@ def test_device_pcg_matches_reference_algorithm(load_hier):
     assert info == 0 and res[-1] < 1e-8 * np.linalg.norm(b) <= res[-2]
 
 
+def test_device_pcg_matches_reference_history():
+    """solve(accel='cg') on the device against the reference's OWN MultilevelSolver.solve(accel='cg') histories on
+    the committed hierarchies (tests/golden/accel_cg.npz, make_golden.py --accel-only): same list length and info,
+    every residual norm within 1e-10 ||r0||, solution within 1e-9 relative (SA 2-D / 3-D symmetric GS, BSR block GS)."""
+    from conftest import GOLDEN
+    from pyamg_amd.hierarchy import load_spec
+    z = np.load(GOLDEN / "accel_cg.npz")
+    names = sorted({k.split(".")[0] for k in z.files})
+    assert len(names) >= 3
+    for name in names:
+        spec, _ = load_spec(GOLDEN / f"hier_{name}.npz")
+        dml = DeviceMultilevelSolver(spec)
+        b = z[f"{name}.b"]
+        cyc = str(z[f"{name}.cycle"])
+        for tag in ("a", "b"):
+            res = []
+            x, info = dml.solve(b, tol=float(z[f"{name}.{tag}.tol"]), maxiter=int(z[f"{name}.{tag}.maxiter"]), cycle=cyc,
+                                accel="cg", residuals=res, return_info=True)
+            ref = z[f"{name}.{tag}.res"]
+            assert len(res) == len(ref) and info == int(z[f"{name}.{tag}.info"]), (name, tag, len(res), len(ref), info)
+            assert np.max(np.abs(np.array(res) - ref)) <= 1e-10 * ref[0], (name, tag)
+            xr = z[f"{name}.{tag}.x"]
+            assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr), (name, tag)
+        dml.free()
+
+
 def test_change_solve_matrix_and_fgmres_amli_with_live_reference():
     """change_solve_matrix re-ships the hierarchy (multilevel.py:320-337); AMLI cycle as an
     FGMRES preconditioner (the only accelerator the reference allows with AMLI, :488-490)."""
@@ -199,6 +225,41 @@ def test_change_solve_matrix_and_fgmres_amli_with_live_reference():
     ml.solve(b, tol=1e-30, maxiter=4, residuals=r_ref)
     dml.solve(b, tol=1e-30, maxiter=4, residuals=r_gpu)
     assert np.max(np.abs(np.array(r_gpu) - np.array(r_ref))) <= 1e-10 * r_ref[0]
+
+
+def test_midsize_symmetric_gs_against_the_live_reference():
+    """3-D Poisson 96^3 (885K rows) SA, symmetric Gauss-Seidel: big enough that the fine level runs the tiled sweep on
+    pencil tiles across all XCDs, level 1 the multi-XCD granular sweep and the coarse levels the single-workgroup /
+    single-tile forms.  The reference's own protocol (b = 0, x0 = rand; docs/paper/example.py:11-14): every residual
+    norm of 10 V-cycles within 1e-10 RELATIVE of the reference's, the iterate within 1e-12; graph replay and eager
+    launches agree bit for bit."""
+    import oracle.refimport as ri
+    if not ri.available():
+        pytest.skip("oracle/_ref not present on this box")
+    import pyamg
+    A = pyamg.gallery.poisson((96, 96, 96), format="csr")
+    np.random.seed(11)
+    gs = ("gauss_seidel", {"sweep": "symmetric"})
+    ml = pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother=gs, postsmoother=gs)
+    np.random.seed(2022)
+    x0 = np.random.rand(A.shape[0])
+    b = np.zeros(A.shape[0])
+    r_ref = []
+    x_ref = ml.solve(b, x0=x0, tol=1e-30, maxiter=10, residuals=r_ref)
+    outs = []
+    for graph in (True, False):
+        dml = DeviceMultilevelSolver(ml, graph=graph)
+        if graph:
+            plans = [dA.tile_info(0)["tiles"] for dA in dml.A[:-1]]
+        r_gpu = []
+        outs.append(dml.solve(b, x0=x0, tol=1e-30, maxiter=10, residuals=r_gpu))
+        dml.free()
+        r_ref_a, r_gpu_a = np.array(r_ref), np.array(r_gpu)
+        assert len(r_gpu_a) == len(r_ref_a) == 11
+        assert np.max(np.abs(r_gpu_a - r_ref_a) / r_ref_a) <= 1e-10
+        assert np.linalg.norm(outs[-1] - x_ref) <= 1e-12 * np.linalg.norm(x_ref)
+    assert np.array_equal(outs[0], outs[1])
+    assert plans[0] > 1                               # the fine level runs the tiled sweep
 
 
 def test_device_fgmres_matches_reference():
