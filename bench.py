@@ -53,6 +53,8 @@ WORKLOADS = {
                 label="3D 7-pt Poisson 256^3 SA V-cycle, Chebyshev(3) smoother, fp64"),
     # BASELINE configs[4] in miniature: 3-D linear elasticity (P1 tets on an N^3-vertex cube), BSR(3,3),
     # SA with Jacobi prolongation smoothing and 6 rigid-body modes, block Jacobi / the default block GS
+    "c5": dict(grid=(64,), elasticity=True, smoother="block_gauss_seidel",
+               label="3D linear elasticity 64^3 vertices (BSR 3x3, 774K dof, 6 rigid-body modes) SA with Jacobi prolongation smoothing, V-cycle, block Gauss-Seidel (SA default), fp64"),
     "c5s": dict(grid=(40,), elasticity=True, smoother="block_jacobi",
                 label="3D linear elasticity 40^3 vertices (BSR 3x3, 187K dof) SA V-cycle, block Jacobi, fp64"),
     "c5g": dict(grid=(40,), elasticity=True, smoother="block_gauss_seidel",
@@ -451,6 +453,32 @@ def main():
       except Exception as e:                                    # noqa: BLE001
         log(f"configs[1] leg failed: {e!r}")
         out["extra"] = {"c2": {"error": repr(e)[:300]}}
+      # configs[4] on one GPU: 3-D elasticity, BSR(3,3) -> (6,6); the SA default block Gauss-Seidel, then block Jacobi (the
+      # smoother that shards) on the same hierarchy
+      try:
+        wl5 = WORKLOADS["c5"]
+        A5, ml5, ts5 = build(wl5)
+        b5, x05 = rhs(A5.shape[0])
+        ex5 = {"workload": wl5["label"], "host_setup_s": round(ts5, 1), "levels": len(ml5.levels),
+               "level_sizes": [[int(L.A.shape[0]), int(L.A.nnz), list(L.A.blocksize)] for L in ml5.levels][:3]}
+        for tag, sm in (("block_gauss_seidel", None), ("block_jacobi", "block_jacobi")):
+            if sm is not None:
+                np.random.seed(SEED)
+                change_smoothers(ml5, presmoother=sm, postsmoother=sm)
+            d5 = DeviceMultilevelSolver(ml5, device=local_rank, graph=not args.no_graph)
+            w5, _, res5, _, _ = time_resident(d5, b5, x05, 30, 3)
+            leg = {"value": round(30 / w5, 3), "unit": "cycles/s", "ms_per_step": round(w5 * 1e3 / 30, 4), "steps": 30}
+            if args.cpu_cycles != 0:
+                c5cpu, r5cpu = cpu_reference(ml5, A5, b5, x05, 5)
+                leg["cpu_baseline"] = c5cpu
+                leg["parity"] = parity_of(res5, r5cpu)
+                leg["parity"]["reference_protocol"] = protocol_parity(d5, ml5, A5.shape[0])
+            d5.free()
+            ex5[tag] = leg
+        out.setdefault("extra", {})["c5"] = ex5
+      except Exception as e:                                    # noqa: BLE001
+        log(f"configs[4] leg failed: {e!r}")
+        out.setdefault("extra", {})["c5"] = {"error": repr(e)[:300]}
       # configs[0]: the README's Ruge-Stuben example -- an irregular classical hierarchy at size, with the published
       # level sizes as the anchor (README.md:143-151)
       try:

@@ -298,6 +298,11 @@ int pamg_matrix_jacobi(pamg_matrix_t A, void *x, const void *b, void *work, doub
  * its diagonal), x_in then holds [owned | halo] values -- the multi-GPU building block. */
 int pamg_matrix_jacobi_step(pamg_matrix_t A, const void *x_in, const void *b, void *x_out,
                             double omega, pamg_stream_t s);
+/* the same for amg_core::block_jacobi (relaxation.h:1021-1090) on a square-block BSR operator or a row shard of
+ * one (block rows cut, block columns [owned | halo]); Dinv: DEVICE, the shard's n_brow x bs x bs inverted diagonal
+ * blocks.  pamg_matrix_jacobi_step accepts such operators too (point Jacobi on BSR, relaxation.h:472-562). */
+int pamg_matrix_block_jacobi_step(pamg_matrix_t A, const void *Dinv, const void *x_in, const void *b, void *x_out,
+                                  double omega, pamg_stream_t s);
 /* gauss_seidel / sor as the reference's Python wrappers run them (relaxation.py:265-346,
  * 100-154, quirks included: 'symmetric' ignores omega, BSR flavour ignores omega). */
 int pamg_matrix_gauss_seidel(pamg_matrix_t A, void *x, const void *b, int sweep, double omega,

@@ -426,10 +426,20 @@ int pamg_matrix_jacobi_step(pamg_matrix_t A, const void *x_in, const void *b, vo
                             pamg_stream_t s)
 {
     if (!A || !x_in || !b || !x_out) return PAMG_E_ARG;
-    if (A->R != 1 || A->C != 1 || A->ncols < A->nrows) return PAMG_E_UNSUPPORTED;
+    if (A->R != A->C || A->ncols < A->nrows) return PAMG_E_UNSUPPORTED;
     if (A->nrows == 0) return PAMG_OK;
+    if (A->R > 1) return block_jacobi_step(A, PNT_JACOBI, nullptr, x_in, x_out, b, omega, (hipStream_t)s);
     return stream_launch(A, A->flavour == PAMG_BSR ? EPI_JACOBI_B : EPI_JACOBI, x_in, b, x_out, 0.0, omega,
                          nullptr, (hipStream_t)s);
+}
+
+int pamg_matrix_block_jacobi_step(pamg_matrix_t A, const void *Dinv, const void *x_in, const void *b, void *x_out,
+                                  double omega, pamg_stream_t s)
+{
+    if (!A || !Dinv || !x_in || !b || !x_out) return PAMG_E_ARG;
+    if (A->R != A->C || A->R < 2 || A->ncols < A->nrows) return PAMG_E_UNSUPPORTED;
+    if (A->nrows == 0) return PAMG_OK;
+    return block_jacobi_step(A, BLK_JACOBI, Dinv, x_in, x_out, b, omega, (hipStream_t)s);
 }
 
 int pamg_matrix_gauss_seidel(pamg_matrix_t A, void *x, const void *b, int sweep, double omega,

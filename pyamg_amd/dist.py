@@ -37,7 +37,7 @@ from .hierarchy import HierarchySpec, LevelSpec, SparseOp
 
 __all__ = ["split_even", "ShardedHierarchy", "DistMultilevelSolver", "DeviceOps", "shardable"]
 
-SHARDABLE_SMOOTHERS = ("jacobi", "polynomial", "none")
+SHARDABLE_SMOOTHERS = ("jacobi", "polynomial", "block_jacobi", "none")     # row-independent sweeps: each row reads the OLD iterate
 
 
 def split_even(n: int, parts: int) -> np.ndarray:
@@ -46,19 +46,30 @@ def split_even(n: int, parts: int) -> np.ndarray:
 
 
 def shardable(spec: HierarchySpec) -> bool:
-    for L in spec.levels[:-1]:
+    """Row-independent smoothers on every level; block (BSR) operators are cut along BLOCK rows, so the level
+    operators must carry square blocks and P / R blocks that fit them (SA on a BSR matrix: (3,3), (3,6), (6,6) ...)."""
+    for i, L in enumerate(spec.levels[:-1]):
+        bs = L.A.blocksize[0]
+        if L.A.blocksize != (bs, bs) or L.A.shape[0] % bs:
+            return False
+        nxt = spec.levels[i + 1].A.blocksize[0] if spec.levels[i + 1].A.blocksize[0] == spec.levels[i + 1].A.blocksize[1] else 0
+        if nxt == 0 or L.P.blocksize != (bs, nxt) or L.R.blocksize != (nxt, bs):
+            return False
         for s in (L.pre, L.post):
-            if s is not None and s.kind not in SHARDABLE_SMOOTHERS:
+            if s is None:
+                continue
+            if s.kind not in SHARDABLE_SMOOTHERS:
                 return False
-        for op in (L.A, L.P, L.R):
-            if op.blocksize != (1, 1):
+            if s.kind == "block_jacobi" and (bs == 1 or int(s.blocksize) != bs):
                 return False
     return True
 
 
 def _rows(op: SparseOp, r0: int, r1: int):
+    """(block) rows [r0, r1): row pointer, (block) column ids, values (R*C per stored block, flat)"""
     p0, p1 = int(op.indptr[r0]), int(op.indptr[r1])
-    return op.indptr[r0:r1 + 1] - op.indptr[r0], op.indices[p0:p1], op.data[p0:p1]
+    per = int(op.blocksize[0]) * int(op.blocksize[1])
+    return op.indptr[r0:r1 + 1] - op.indptr[r0], op.indices[p0:p1], np.ravel(op.data)[p0 * per:p1 * per]
 
 
 def _ext_cols(op: SparseOp, r0: int, r1: int, c0: int, c1: int) -> np.ndarray:
@@ -70,8 +81,10 @@ def _ext_cols(op: SparseOp, r0: int, r1: int, c0: int, c1: int) -> np.ndarray:
 
 @dataclass
 class LevelPlan:
-    """Exchange plan of one level on one rank."""
-    off: np.ndarray                     # [N+1] row offsets of the level
+    """Exchange plan of one level on one rank.  All counts and indices are in BLOCK units of the level (bs values per
+    block; bs = 1 for scalar levels): ``*_s`` give the scalar sizes the vectors and messages have."""
+    off: np.ndarray                     # [N+1] (block) row offsets of the level
+    bs: int = 1
     n_owned: int = 0
     halo_cols: np.ndarray = None        # global ids of the halo entries, grouped by owner (ascending)
     recv: List[tuple] = field(default_factory=list)   # (src_rank, halo_begin, count)
@@ -86,9 +99,31 @@ class LevelPlan:
     def n_local(self) -> int:
         return self.n_owned + self.n_halo
 
+    @property
+    def n_owned_s(self) -> int:
+        return self.n_owned * self.bs
+
+    @property
+    def n_halo_s(self) -> int:
+        return self.n_halo * self.bs
+
+    @property
+    def n_local_s(self) -> int:
+        return self.n_local * self.bs
+
+    def row0_s(self, rank) -> int:
+        return int(self.off[rank]) * self.bs
+
+    @property
+    def send_idx_s(self) -> np.ndarray:
+        """scalar indices to pack"""
+        if self.bs == 1:
+            return self.send_idx
+        return (self.send_idx.astype(np.int64)[:, None] * self.bs + np.arange(self.bs)).ravel().astype(np.int32)
+
 
 def _localize(op: SparseOp, r0: int, r1: int, c0: int, c1: int, halo_cols: np.ndarray) -> SparseOp:
-    """Rows [r0,r1) of ``op`` with columns renumbered to [owned | halo]."""
+    """(Block) rows [r0,r1) of ``op`` with (block) columns renumbered to [owned | halo]."""
     indptr, cols, data = _rows(op, r0, r1)
     owned = (cols >= c0) & (cols < c1)
     loc = np.empty(cols.size, dtype=np.int32)
@@ -97,7 +132,8 @@ def _localize(op: SparseOp, r0: int, r1: int, c0: int, c1: int, halo_cols: np.nd
         pos = np.searchsorted(halo_cols, cols[~owned])
         assert np.array_equal(halo_cols[pos], cols[~owned])
         loc[~owned] = ((c1 - c0) + pos).astype(np.int32)
-    return SparseOp(op.fmt, (r1 - r0, (c1 - c0) + int(halo_cols.size)), (1, 1),
+    R, Cb = op.blocksize
+    return SparseOp(op.fmt, ((r1 - r0) * R, ((c1 - c0) + int(halo_cols.size)) * Cb), (R, Cb),
                     np.ascontiguousarray(indptr, dtype=np.int32), loc, np.ascontiguousarray(data), op.src_format)
 
 
@@ -106,8 +142,8 @@ class ShardedHierarchy:
 
     def __init__(self, spec: HierarchySpec, rank: int, world: int, min_rows: int = 200_000):
         if not shardable(spec):
-            raise NotImplementedError("hierarchy is not shardable (order-exact Gauss-Seidel / block operators): "
-                                      "run replicas instead")
+            raise NotImplementedError("hierarchy is not shardable (order-exact Gauss-Seidel, or block shapes that do not "
+                                      "line up across levels): run replicas instead")
         self.spec, self.rank, self.world = spec, rank, world
         nlev = len(spec.levels)
         # sharded levels: 0 .. ns-1 ; level ns is the collapse level (full vectors on every rank)
@@ -117,7 +153,8 @@ class ShardedHierarchy:
         if ns == 0:
             raise NotImplementedError("nothing to shard: fine level smaller than min_rows")
         self.ns = ns
-        offs = [split_even(spec.levels[l].A.shape[0], world) for l in range(ns + 1)]
+        bss = [int(spec.levels[l].A.blocksize[0]) for l in range(ns + 1)]          # values per block, level by level
+        offs = [split_even(spec.levels[l].A.shape[0] // bss[l], world) for l in range(ns + 1)]   # block rows
         self.plans: List[LevelPlan] = []
         self.A: List[SparseOp] = []
         self.P: List[SparseOp] = []
@@ -138,7 +175,7 @@ class ShardedHierarchy:
                     parts.append(_ext_cols(spec.levels[l - 1].P, int(fo[d]), int(fo[d + 1]), c0, c1))
                 needs.append(np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int32))
             me = rank
-            plan = LevelPlan(off=off, n_owned=int(off[me + 1] - off[me]), halo_cols=needs[me].astype(np.int64))
+            plan = LevelPlan(off=off, bs=bss[l], n_owned=int(off[me + 1] - off[me]), halo_cols=needs[me].astype(np.int64))
             owner = np.searchsorted(off, plan.halo_cols, side="right") - 1
             for s in range(world):
                 cnt = int(np.count_nonzero(owner == s))
@@ -164,6 +201,12 @@ class ShardedHierarchy:
             self.A.append(_localize(L.A, r0, r1, r0, r1, self.plans[l].halo_cols))
             self.P.append(_localize(L.P, r0, r1, q0, q1, self.plans[l + 1].halo_cols))
             self.R.append(_localize(L.R, q0, q1, r0, r1, self.plans[l].halo_cols))
+        # block Jacobi: this rank's slice of the inverted diagonal blocks
+        self.Dinv: List[dict] = []
+        for l in range(ns):
+            r0, r1 = int(offs[l][rank]), int(offs[l][rank + 1])
+            self.Dinv.append({k: np.ascontiguousarray(sm.Dinv[r0:r1]) for k, sm in (("pre", spec.levels[l].pre), ("post", spec.levels[l].post))
+                              if sm is not None and sm.kind == "block_jacobi"})
         # remaining (collapsed) hierarchy, replicated on every rank
         self.coarse_spec = HierarchySpec(levels=[LevelSpec(A=L.A, P=L.P, R=L.R, pre=L.pre, post=L.post)
                                                  for L in spec.levels[ns:]],
@@ -214,6 +257,10 @@ class DeviceOps:
     def jacobi_step(self, M, x_in, b, x_out, omega):
         self.capi.check(self.capi.lib().pamg_matrix_jacobi_step(M.handle, self._p(x_in), self._p(b), self._p(x_out),
                                                                 float(omega), None), "jacobi_step")
+
+    def block_jacobi_step(self, M, Dinv, x_in, b, x_out, omega):
+        self.capi.check(self.capi.lib().pamg_matrix_block_jacobi_step(M.handle, self._p(Dinv), self._p(x_in), self._p(b), self._p(x_out),
+                                                                      float(omega), None), "block_jacobi_step")
 
     def resid_sumsq(self, M, x, b):
         out = self.torch.zeros(1, dtype=self.torch.float64, device=self.device)
@@ -266,9 +313,10 @@ class DistMultilevelSolver:
         self.A = [o.matrix(m) for m in self.sh.A]
         self.P = [o.matrix(m) for m in self.sh.P]
         self.R = [o.matrix(m) for m in self.sh.R]
-        self.send_idx = [o.index(p.send_idx) for p in self.sh.plans]
-        self.send_buf = [o.vector(p.send_idx.size) for p in self.sh.plans]
-        nl = [p.n_local for p in self.sh.plans]
+        self.send_idx = [o.index(p.send_idx_s) for p in self.sh.plans]
+        self.send_buf = [o.vector(p.send_idx.size * p.bs) for p in self.sh.plans]
+        nl = [p.n_local_s for p in self.sh.plans]
+        self.Dinv = [{k: o.from_host(v.ravel()) for k, v in d.items()} for d in self.sh.Dinv]
         self.x = [o.vector(nl[l]) for l in range(ns + 1)]
         self.xalt = [o.vector(nl[l]) for l in range(ns)]
         self.b = [o.vector(nl[l]) for l in range(ns + 1)]
@@ -279,8 +327,8 @@ class DistMultilevelSolver:
         self.xc_full = o.vector(nc)
         cplan = self.sh.plans[ns]
         c0 = int(cplan.off[self.rank])
-        self.c_fill_idx = o.index(np.concatenate([np.arange(c0, c0 + cplan.n_owned, dtype=np.int64),
-                                                  cplan.halo_cols]).astype(np.int32))
+        fill = np.concatenate([np.arange(c0, c0 + cplan.n_owned, dtype=np.int64), cplan.halo_cols])     # blocks: owned | halo
+        self.c_fill_idx = o.index((fill[:, None] * cplan.bs + np.arange(cplan.bs)).ravel().astype(np.int32))
         self.coarse = o.coarse_solver(self.sh.coarse_spec)
         self.shape = tuple(spec.levels[0].A.shape)
 
@@ -308,23 +356,24 @@ class DistMultilevelSolver:
         if not plan.send and not plan.recv:
             return
         dist = self.dist
+        bs, no = plan.bs, plan.n_owned_s
         if plan.send_idx.size:
-            self.ops.gather(plan.send_idx.size, self.send_idx[l], v, self.send_buf[l])
+            self.ops.gather(plan.send_idx.size * bs, self.send_idx[l], v, self.send_buf[l])
         if self._staged(v):
             sb = self.send_buf[l].cpu()
-            rb = sb.new_zeros(max(plan.n_halo, 1))
-            reqs = [dist.P2POp(dist.irecv, rb[beg:beg + cnt], self._peer(src), self.group) for (src, beg, cnt) in plan.recv]
-            reqs += [dist.P2POp(dist.isend, sb[beg:beg + cnt], self._peer(dst), self.group) for (dst, beg, cnt) in plan.send]
+            rb = sb.new_zeros(max(plan.n_halo_s, 1))
+            reqs = [dist.P2POp(dist.irecv, rb[beg * bs:(beg + cnt) * bs], self._peer(src), self.group) for (src, beg, cnt) in plan.recv]
+            reqs += [dist.P2POp(dist.isend, sb[beg * bs:(beg + cnt) * bs], self._peer(dst), self.group) for (dst, beg, cnt) in plan.send]
             for w in dist.batch_isend_irecv(reqs):
                 w.wait()
             if plan.n_halo:
-                v[plan.n_owned:plan.n_owned + plan.n_halo].copy_(rb[:plan.n_halo])
+                v[no:no + plan.n_halo_s].copy_(rb[:plan.n_halo_s])
             return
         reqs = []
         for (src, beg, cnt) in plan.recv:
-            reqs.append(dist.P2POp(dist.irecv, v[plan.n_owned + beg: plan.n_owned + beg + cnt], self._peer(src), self.group))
+            reqs.append(dist.P2POp(dist.irecv, v[no + beg * bs: no + (beg + cnt) * bs], self._peer(src), self.group))
         for (dst, beg, cnt) in plan.send:
-            reqs.append(dist.P2POp(dist.isend, self.send_buf[l][beg: beg + cnt], self._peer(dst), self.group))
+            reqs.append(dist.P2POp(dist.isend, self.send_buf[l][beg * bs: (beg + cnt) * bs], self._peer(dst), self.group))
         for w in dist.batch_isend_irecv(reqs):
             w.wait()
 
@@ -336,7 +385,15 @@ class DistMultilevelSolver:
         if s is None or s.kind == "none":
             return
         o, A = self.ops, self.A[l]
-        n = self.sh.plans[l].n_owned
+        n = self.sh.plans[l].n_owned_s
+        if s.kind == "block_jacobi":
+            Dinv = self.Dinv[l]["pre" if s is self.spec.levels[l].pre else "post"]
+            for it in range(s.iterations):
+                if not (x_zero and it == 0):
+                    self.exchange(l, self.x[l])
+                o.block_jacobi_step(A, Dinv, self.x[l], self.b[l], self.xalt[l], s.omega)
+                self.x[l], self.xalt[l] = self.xalt[l], self.x[l]
+            return
         if s.kind == "jacobi":
             for it in range(s.iterations):
                 if not (x_zero and it == 0):             # halo of an all-zero iterate is zero already
@@ -380,14 +437,14 @@ class DistMultilevelSolver:
             o.spmv(self.P[l], 1, self.x[l + 1], self.x[l])               # x += P x_c
         else:
             cplan = sh.plans[sh.ns]
-            c0 = int(cplan.off[self.rank])
+            c0 = cplan.row0_s(self.rank)
             self.bc_full.zero_()
             o.spmv(self.R[l], 0, self.r[l], self.b[sh.ns])               # owned slice of b_c
-            self.bc_full[c0: c0 + cplan.n_owned].copy_(self.b[sh.ns][:cplan.n_owned])
+            self.bc_full[c0: c0 + cplan.n_owned_s].copy_(self.b[sh.ns][:cplan.n_owned_s])
             self._all_reduce(self.bc_full)                               # disjoint slices -> full b_c everywhere
             self.xc_full.zero_()
             o.coarse_cycle(self.coarse, self.xc_full, self.bc_full, cycle)
-            o.gather(cplan.n_local, self.c_fill_idx, self.xc_full, self.x[sh.ns])
+            o.gather(cplan.n_local_s, self.c_fill_idx, self.xc_full, self.x[sh.ns])
             o.spmv(self.P[l], 1, self.x[sh.ns], self.x[l])               # x += P x_c
         self._smooth(l, L.post, False)
 
@@ -399,9 +456,9 @@ class DistMultilevelSolver:
 
     def load(self, b, x0):
         p = self.sh.plans[0]
-        r0 = int(p.off[self.rank])
-        self.b[0][:p.n_owned].copy_(self.ops.from_host(np.ravel(b)[r0:r0 + p.n_owned]))
-        self.x[0][:p.n_owned].copy_(self.ops.from_host(np.ravel(x0)[r0:r0 + p.n_owned]))
+        r0, no = p.row0_s(self.rank), p.n_owned_s
+        self.b[0][:no].copy_(self.ops.from_host(np.ravel(b)[r0:r0 + no]))
+        self.x[0][:no].copy_(self.ops.from_host(np.ravel(x0)[r0:r0 + no]))
 
     def iterate(self, k, cycle="V", want_residuals=True):
         """k x (V-cycle + convergence-check norm) on the resident sharded state."""
@@ -416,8 +473,8 @@ class DistMultilevelSolver:
         p = self.sh.plans[0]
         full = self.ops.vector(self.shape[0])
         full.zero_()
-        r0 = int(p.off[self.rank])
-        full[r0:r0 + p.n_owned].copy_(self.x[0][:p.n_owned])
+        r0 = p.row0_s(self.rank)
+        full[r0:r0 + p.n_owned_s].copy_(self.x[0][:p.n_owned_s])
         self._all_reduce(full)
         return self.ops.to_host(full, self.shape[0])
 

@@ -65,8 +65,17 @@ class OracleOps:
         if M.fmt == "csr":
             self.orc.jacobi(M.indptr, M.indices, M.data, xo, b.numpy()[:n].copy(), temp, 0, n, 1, self.dtype.type(omega))
         else:
-            self.orc.bsr_jacobi(M.indptr, M.indices, M.data, xo, b.numpy()[:n].copy(), temp, 0, n, 1, 1,
+            bs = M.blocksize[0]
+            self.orc.bsr_jacobi(M.indptr, M.indices, M.data, xo, b.numpy()[:n].copy(), temp, 0, n // bs, 1, bs,
                                 self.dtype.type(omega))
+        x_out.numpy()[:n] = xo[:n]
+
+    def block_jacobi_step(self, M, Dinv, x_in, b, x_out, omega):
+        n, bs = M.shape[0], M.blocksize[0]
+        xin = x_in.numpy()[:M.shape[1]].copy()
+        xo, temp = xin.copy(), xin.copy()
+        self.orc.block_jacobi(M.indptr, M.indices, M.data, xo, b.numpy()[:n].copy(), Dinv.numpy(), temp, 0, n // bs, 1,
+                              self.dtype.type(omega), bs)
         x_out.numpy()[:n] = xo[:n]
 
     def resid_sumsq(self, M, x, b):

@@ -213,3 +213,25 @@ def test_header_is_plain_c_and_links(tmp_path):
                         "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-o", str(exe)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_batched_elasticity_assembly_matches_the_reference_gallery():
+    """tools/problems.elasticity_p1_batched (the C5 workload generator) against the reference's element-by-element
+    ``gallery.linear_elasticity_p1`` on a small tet mesh: same operator (1e-14 relative), same rigid-body modes, with and
+    without clamped vertices"""
+    import oracle.refimport as ri
+    if not ri.available():
+        pytest.skip("oracle/_ref not present")
+    import pyamg
+    import scipy.sparse as sp
+    from tools.problems import cube_tet_mesh, elasticity_p1_batched
+    V, T = cube_tet_mesh(6)
+    A0, B0 = pyamg.gallery.linear_elasticity_p1(V, T, format="csr")
+    A1, B1 = elasticity_p1_batched(V, T)
+    assert A1.blocksize == (3, 3) and np.array_equal(B0, B1)
+    assert abs(A0 - A1.tocsr()).max() <= 1e-14 * abs(A0).max()
+    keep = np.flatnonzero(V[:, 0] > 0)
+    k = np.flatnonzero(np.repeat(V[:, 0] > 0, 3))
+    A2, B2 = elasticity_p1_batched(V, T, keep=keep)
+    assert abs(sp.csr_array(A0[k][:, k]) - A2.tocsr()).max() <= 1e-14 * abs(A0).max() and np.array_equal(B0[k], B2)
+    assert A2.indices.dtype == np.int32 and A2.indptr.dtype == np.int32
