@@ -49,6 +49,10 @@ WORKLOADS = {
                label="3D 7-pt Poisson 256^3 (16.7M dof) SA V-cycle, symmetric Gauss-Seidel, fp64"),
     "c3j": dict(grid=(256, 256, 256), smoother=JAC,
                 label="3D 7-pt Poisson 256^3 SA V-cycle, weighted-Jacobi pre/post, fp64"),
+    # BASELINE configs[3] at the largest size whose SERIAL reference setup (aggregation.py:280-431, ~60 s and ~10 GB per
+    # 16.7M rows) still fits a bench run: 384^3 = 56.6M rows (the 512^3 setup takes ~16 min and ~78 GB on the host)
+    "c4": dict(grid=(384, 384, 384), smoother=CHEB,
+               label="3D 7-pt Poisson 384^3 (56.6M dof) SA V-cycle, Chebyshev(3) smoother, fp64"),
     "c4s": dict(grid=(256, 256, 256), smoother=CHEB,
                 label="3D 7-pt Poisson 256^3 SA V-cycle, Chebyshev(3) smoother, fp64"),
     # BASELINE configs[4] in miniature: 3-D linear elasticity (P1 tets on an N^3-vertex cube), BSR(3,3),
@@ -75,6 +79,49 @@ WORKLOADS = {
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def measure_traffic(grid, nrows):
+    """HBM bytes per launch of the fine-level residual kernel, counted in THIS run: tools/spmv_pmc.py (the same operator,
+    the same kernel) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, kernel trace only),
+    corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE tallies 128-byte requests at
+    64 bytes: x 2; WRITE_SIZE 1:1; both in KiB).  None if the profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3") or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="pamg_pmc_")
+    try:
+        for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, cname)
+            cmd = ["rocprofv3", "--pmc", cname, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, str(ROOT / "tools" / "spmv_pmc.py")] + [str(g) for g in grid]
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
+                           env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+            tot, cnt = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") == cname and "csr_stream_kernel" in r.get("Kernel_Name", "") and \
+                                int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= 256 * 1024:
+                            tot += float(r["Counter_Value"])
+                            cnt += 1
+            if cnt == 0:
+                return None
+            vals[cname] = 1024.0 * tot / cnt
+        fetch = 2.0 * vals["FETCH_SIZE"]
+        return {"bytes_per_launch": int(fetch + vals["WRITE_SIZE"]), "fetch_size_raw": int(vals["FETCH_SIZE"]),
+                "fetch_corrected_x2": int(fetch), "write_size": int(vals["WRITE_SIZE"]),
+                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE on tools/spmv_pmc.py, this run"}
+    except Exception as e:                                      # noqa: BLE001 -- a missing profiler must not fail the bench
+        log(f"PMC pass skipped: {e!r}")
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def spawn_ranks(n):
@@ -106,6 +153,7 @@ def main():
     ap.add_argument("--cpu-cycles", type=int, default=-1, help="reference cycles timed on the host (-1 auto, 0 skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the sharded-Chebyshev and configs[1] legs")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes that measure the SpMV's HBM traffic")
     ap.add_argument("--min-rows", type=int, default=200_000, help="shard levels with at least this many rows")
     args = ap.parse_args()
 
@@ -295,17 +343,16 @@ def main():
     spmv_ms = f0.elapsed_ms(f1) / reps
     bytes_resid = spmv_bytes(A.tocsr() if A.format != "csr" else A) + 8 * n               # + b read (scalar-CSR view)
     achieved = bytes_resid / spmv_ms / 1e6            # GB/s
-    traffic = None
-    pm = ROOT / "profiles" / f"pmc_{args.workload}.json"
-    if pm.exists():
-        try:
-            traffic = json.loads(pm.read_text()).get("resid_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    pmc = None
+    if rank == 0 and world == 1 and not args.no_pmc and "grid" in wl and not wl.get("elasticity") and not wl.get("convdiff"):
+        pmc = measure_traffic(wl["grid"], n)
     roofline = {"kernel": "csr_stream_kernel<double, RESID> (fine-level r = b - A x)", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc["bytes_per_launch"] if pmc else None,
                 "bytes_per_launch": int(bytes_resid), "ms_per_launch": round(spmv_ms, 5)}
+    if pmc:
+        roofline["traffic_detail"] = pmc
+        roofline["traffic_over_algorithmic"] = round(pmc["bytes_per_launch"] / bytes_resid, 3)
 
     # ---- the order-exact sweeps: latency-bound by the dependency chain of the reference's row order
     #      (levels of the schedule), not by HBM -- reported beside the bandwidth roofline so that the
