@@ -41,6 +41,8 @@ ap.add_argument("--rings", type=int, nargs="*", default=[0])
 ap.add_argument("--slots", type=int, nargs="*", default=[0])
 ap.add_argument("--inflight", type=int, nargs="*", default=[-1])
 ap.add_argument("--parts", type=int, nargs="*", default=[1])
+ap.add_argument("--extra", default="", help="JSON list of tune() keyword dicts measured as further variants")
+ap.add_argument("--no-tiles", type=int, default=0)
 ap.add_argument("--caps", type=int, nargs="*", default=[0])
 ap.add_argument("--levels", type=int, nargs="*", default=None)
 ap.add_argument("--baseline", type=int, default=1)
@@ -93,7 +95,12 @@ for li, L in enumerate(spec.levels[:-1]):
                     for Q in a.inflight:
                         for pt in a.parts:
                             variants.append((f"tile_G{G}_W{W}_c{cap}_D{D}_Q{Q}_p{pt}", dict(gs_mode=5, tile_G=G, tile_W=W, tile_cap=cap, tile_D=D, tile_Q=Q, tile_part=pt, gs_prof=0)))
+    if a.no_tiles:
+        variants = [v for v in variants if not v[0].startswith("tile_")]
+    for kw in (json.loads(a.extra) if a.extra else []):
+        variants.append(("x_" + "_".join(f"{k}{v}" for k, v in kw.items()), dict(tile_default=0, **kw)))
     for name, kw in variants:
+        dA.tune(gs_mode=0, gran_xcd=0, gran_cap=0, flow_cap=32)
         dA.tune(**kw)
         dx.upload(x)
         t1 = time.time()
