@@ -334,11 +334,11 @@ def apply_smoother(s, A, x, b):
     elif s.kind == "block_gauss_seidel":
         relax_block_gauss_seidel(A, x, b, s.Dinv, s.blocksize, s.iterations, s.sweep)
     elif s.kind == "gauss_seidel_ne":
-        relax_gauss_seidel_ne(A, x, b, s.Dinv, s.iterations, s.sweep, s.omega)
+        relax_gauss_seidel_ne(A if getattr(s, "Ar", None) is None else s.Ar, x, b, s.Dinv, s.iterations, s.sweep, s.omega)
     elif s.kind == "gauss_seidel_nr":
         relax_gauss_seidel_nr(A, s.At, x, b, s.Dinv, s.iterations, s.sweep, s.omega, getattr(s, "Ar", None))
     elif s.kind == "jacobi_ne":
-        relax_jacobi_ne(A, x, b, s.Dinv, s.iterations, s.omega)
+        relax_jacobi_ne(A if getattr(s, "Ar", None) is None else s.Ar, x, b, s.Dinv, s.iterations, s.omega)
     elif s.kind in ("cf_jacobi", "fc_jacobi"):
         relax_cf_jacobi(A, x, b, s.Cpts, s.Fpts, s.iterations, s.f_iterations, s.c_iterations, s.omega,
                         f_first=(s.kind == "fc_jacobi"))

@@ -944,9 +944,29 @@ static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *
         hipLaunchKernelGGL((fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)g->d_xs, n);
         PAMG_HIP(hipGetLastError());
         const int per_level = (g->nblk_total + g->nlevels - 1) / g->nlevels;
-        int G = std::max(1, std::min(g->nblk_total, 256));
+        // every workgroup of the persistent grid must be resident (a workgroup spins on ranges owned by others): cap
+        // the grid by what the device holds of THIS kernel with THIS much LDS, one per CU below the query as for the
+        // scalar sweep (gran2_grid) -- matters on partitioned devices and smaller parts
+        int resident = 256;
+        {
+            static int cus = 0;
+            if (!cus) {
+                int dev = 0;
+                hipDeviceProp_t p;
+                cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 64;
+            }
+            int nb = 0;
+            const hipError_t e = kind == PNT_GS
+                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bsr_gran_kernel<T, PNT_GS>, BLK, (size_t)(3 * lds))
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bsr_gran_kernel<T, BLK_GS>, BLK, (size_t)(3 * lds));
+            if (e != hipSuccess || nb < 1) nb = 1;
+            resident = std::max(1, std::min(nb - 1, 4)) * cus;
+            if (nb == 1) resident = cus;
+        }
+        int G = std::max(1, std::min(g->nblk_total, std::min(256, resident)));
         if (A->gran_cap > 0) G = std::min(G, A->gran_cap);
         else G = std::min(G, std::max(32, 8 * per_level));
+        G = std::min(G, resident);
         if (kind == PNT_GS) hipLaunchKernelGGL((bsr_gran_kernel<T, PNT_GS>), dim3(G), dim3(BLK), 3 * lds, s, a, r, g->nblk_total);
         else hipLaunchKernelGGL((bsr_gran_kernel<T, BLK_GS>), dim3(G), dim3(BLK), 3 * lds, s, a, r, g->nblk_total);
         return (int)hipGetLastError();

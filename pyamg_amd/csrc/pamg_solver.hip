@@ -194,8 +194,9 @@ int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, 
         case PAMG_SMOOTH_GS_NE: {
             const int n = (int)L.A->nrows;
             for (int it = 0; it < sm.iterations; ++it) {
-                if (sm.sweep != PAMG_BACKWARD) PAMG_TRY(kaczmarz_sweep(L.A, false, L.x, L.b, sm.d_Dinv, sm.omega, 0, n, 1, nullptr, s));
-                if (sm.sweep != PAMG_FORWARD) PAMG_TRY(kaczmarz_sweep(L.A, false, L.x, L.b, sm.d_Dinv, sm.omega, n - 1, -1, -1, nullptr, s));
+                pamg_matrix_s *Ak = sm.Ar ? sm.Ar : L.A;
+                if (sm.sweep != PAMG_BACKWARD) PAMG_TRY(kaczmarz_sweep(Ak, false, L.x, L.b, sm.d_Dinv, sm.omega, 0, n, 1, nullptr, s));
+                if (sm.sweep != PAMG_FORWARD) PAMG_TRY(kaczmarz_sweep(Ak, false, L.x, L.b, sm.d_Dinv, sm.omega, n - 1, -1, -1, nullptr, s));
             }
             return PAMG_OK;
         }
@@ -217,7 +218,7 @@ int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, 
         }
         case PAMG_SMOOTH_JACOBI_NE:
             for (int it = 0; it < sm.iterations; ++it) {
-                PAMG_TRY(stream_launch(L.A, EPI_RESID, L.x, L.b, L.r, 0.0, 0.0, nullptr, s));        // r = b - A x
+                PAMG_TRY(stream_launch(sm.Ar ? sm.Ar : L.A, EPI_RESID, L.x, L.b, L.r, 0.0, 0.0, nullptr, s));   // r = b - A x
                 PAMG_TRY(vec_mul(S->dtype, L.n, L.r, sm.d_Dinv, L.r, s));                           // delta = r .* Dinv
                 PAMG_TRY(stream_launch(sm.At, EPI_ACC, L.r, nullptr, L.x, 0.0, 0.0, nullptr, s));   // x += (omega A)^T delta
             }
@@ -361,7 +362,7 @@ int prebuild_schedules(Level &L, const Smoother &sm)
 {
     if (sm.kind == PAMG_SMOOTH_GS_NE || sm.kind == PAMG_SMOOTH_GS_NR) {
         // the Kaczmarz line schedules allocate: build them here, never inside a graph capture
-        pamg_matrix_s *Lm = sm.kind == PAMG_SMOOTH_GS_NE ? L.A : sm.At;
+        pamg_matrix_s *Lm = sm.kind == PAMG_SMOOTH_GS_NE ? (sm.Ar ? sm.Ar : L.A) : sm.At;
         const int n = (int)Lm->nrows;
         if (n == 0) return PAMG_OK;
         if (sm.sweep != PAMG_BACKWARD) PAMG_TRY(ensure_line_schedule(Lm, 0, n, 1));
@@ -615,7 +616,7 @@ int pamg_solver_set_ne_smoother(pamg_solver_t S, int level, int which, int kind,
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep;
     sm.At = kind == PAMG_SMOOTH_GS_NE ? nullptr : At;
-    sm.Ar = kind == PAMG_SMOOTH_GS_NR ? Ar : nullptr;
+    sm.Ar = Ar;                                            // the level's operator with sorted rows, where the reference's wrapper sees one
     const size_t sz = (size_t)L.A->nrows * tsize(S->dtype);
     PAMG_HIP(hipMalloc(&sm.d_Dinv, std::max<size_t>(sz, 256)));
     PAMG_HIP(hipMemcpy(sm.d_Dinv, Dinv, sz, hipMemcpyHostToDevice));

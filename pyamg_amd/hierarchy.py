@@ -86,7 +86,7 @@ class SmootherSpec:
     f_iterations: int = 1
     c_iterations: int = 1
     At: Optional["SparseOp"] = None             # gauss_seidel_nr: CSR of A^T (= CSC arrays of A); jacobi_ne: same, values * omega
-    Ar: Optional["SparseOp"] = None             # gauss_seidel_nr: A with sorted rows for r = b - A x (None: the level's A is)
+    Ar: Optional["SparseOp"] = None             # normal-equation smoothers: A with sorted rows as the reference's wrapper sees it (None: the level's A is)
 
 
 @dataclass
@@ -239,14 +239,18 @@ def _normal_equation_spec(kind, A, iterations, sweep, omega) -> SmootherSpec:
     M.sort_indices()
     D = (M.multiply(M.conjugate())) @ np.ones((M.shape[0],))
     Dinv = np.ravel(_inv_or_zero(D))
+    # On a BSR(1,1) level (SA coarse levels) the reference smooths with lvl.Acsr = lvl.A.tocsr(), whose rows come out
+    # SORTED, while the cycle's own products keep the level's stored order: ship the sorted copy for the smoother when
+    # the two orders differ.  (A CSR level is sorted in place by the reference -- extract() ships it sorted as a whole.)
+    Ar = sparse_op(M) if (A.format == "bsr" and not A.has_sorted_indices) else None
     if kind == "gauss_seidel_ne":
-        return SmootherSpec(kind, iterations, float(omega), sweep, Dinv=Dinv, name=kind)
+        return SmootherSpec(kind, iterations, float(omega), sweep, Dinv=Dinv, Ar=Ar, name=kind)
     Mc = M.tocsc()
     Mc.sort_indices()
     om = A.dtype.type(np.real(omega))                   # type_prep(A.dtype, [omega]); omega2 * Ax[j] in the kernel
     At = SparseOp("csr", (n, n), (1, 1), _as_int32(Mc.indptr, "indptr"), _as_int32(Mc.indices, "indices"),
                   np.ascontiguousarray(om * Mc.data), "csc")
-    return SmootherSpec(kind, iterations, float(np.real(omega)), "forward", Dinv=Dinv, At=At, name=kind)
+    return SmootherSpec(kind, iterations, float(np.real(omega)), "forward", Dinv=Dinv, At=At, Ar=Ar, name=kind)
 
 
 # --------------------------------------------------------------------------- coarse solver

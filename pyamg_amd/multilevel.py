@@ -347,6 +347,10 @@ class DeviceMultilevelSolver:
 
         if accel is not None:
             return self._solve_accel(b, x0, tol, maxiter, cycle, accel, callback, residuals, return_info)
+        if maxiter is None or int(maxiter) < 1:
+            # the reference loops `while True ... if it == maxiter` (multilevel.py:558-580): nothing but a positive
+            # integer terminates it by count -- refuse instead of spinning
+            raise ValueError("maxiter must be a positive integer when no accelerator is given")
 
         tp = np.result_type(b.dtype, x.dtype, self.dtype)          # upcast (:551-552)
         if np.dtype(tp) != self.dtype:
@@ -384,6 +388,10 @@ class DeviceMultilevelSolver:
     def pcg_device(self, xd, bd, tol=1e-5, maxiter=100, cycle="V", cycles_per_level=1, stream=None):
         """Device-resident preconditioned CG (krylov/_cg.py, criteria 'rr') on DEVICE vectors;
         returns (residuals, n_iter, info)."""
+        if maxiter is None:                                  # krylov/_cg.py:92-96
+            maxiter = int(1.3 * self.shape[0]) + 2
+        elif maxiter < 1:
+            raise ValueError("Number of iterations must be positive")
         res = np.zeros(int(maxiter) + 1, dtype=np.float64)
         nit, info = C.c_int(0), C.c_int(0)
         capi.check(capi.lib().pamg_solver_pcg(self.handle, xd.ptr, bd.ptr, float(tol), int(maxiter), capi.CYCLE[cycle],

@@ -227,6 +227,38 @@ def test_change_solve_matrix_and_fgmres_amli_with_live_reference():
     assert np.max(np.abs(np.array(r_gpu) - np.array(r_ref))) <= 1e-10 * r_ref[0]
 
 
+@pytest.mark.parametrize("name", ["rs2d_nonsym_gsne", "rs2d_nonsym_jacobine"])
+def test_ne_smoother_on_an_unsorted_bsr_level(load_hier, name):
+    """On a BSR(1,1) level whose rows are stored unsorted the reference smooths with the sorted lvl.Acsr while the
+    cycle's own products keep the stored order (smoothing.py setup_*_ne): the spec then carries the sorted copy
+    (SmootherSpec.Ar) for the smoother.  Built here from a committed hierarchy by storing level 1 as BSR(1,1) with
+    every row reversed; the device must agree with the oracle, which applies the same rule."""
+    import copy
+    from oracle import oracle as orc
+    from pyamg_amd.hierarchy import SparseOp
+    spec, ex = load_hier(name)
+    spec = copy.deepcopy(spec)
+    L = spec.levels[1]
+    A = L.A
+    assert A.blocksize == (1, 1)
+    idx, dat = A.indices.copy(), np.ravel(A.data).copy()
+    for i in range(A.shape[0]):
+        p0, p1 = int(A.indptr[i]), int(A.indptr[i + 1])
+        idx[p0:p1] = idx[p0:p1][::-1]
+        dat[p0:p1] = dat[p0:p1][::-1]
+    sorted_copy = SparseOp("csr", A.shape, (1, 1), A.indptr.copy(), A.indices.copy(), np.ravel(A.data).copy(), "csr")
+    L.A = SparseOp("bsr", A.shape, (1, 1), A.indptr.copy(), idx, dat, "bsr")
+    for sm in (L.pre, L.post):
+        sm.Ar = sorted_copy
+    dml = DeviceMultilevelSolver(spec)
+    r_gpu, r_orc = [], []
+    x = dml.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=5, residuals=r_gpu)
+    xo = orc.OracleSolver(spec).solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=5, residuals=r_orc)
+    dml.free()
+    assert np.max(np.abs(np.array(r_gpu) - np.array(r_orc))) <= 1e-10 * r_orc[0]
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+
+
 def test_midsize_symmetric_gs_against_the_live_reference():
     """3-D Poisson 96^3 (885K rows) SA, symmetric Gauss-Seidel: big enough that the fine level runs the tiled sweep on
     pencil tiles across all XCDs, level 1 the multi-XCD granular sweep and the coarse levels the single-workgroup /
