@@ -60,6 +60,11 @@ typedef struct pamg_solver_s *pamg_solver_t;
 
 /* ------------------------------------------------------------------ runtime plumbing */
 const char *pamg_version(void);
+/* Layer 1 keeps the last few operators it was handed resident (keyed by the identity of the three host arrays AND a
+ * hash of their full contents), so a smoother applied call after call does not re-upload the matrix or redo the
+ * dependency analysis of the order-exact sweeps.  PAMG_L1_CACHE=0 in the environment disables it. */
+int pamg_l1_cache_clear(void);
+int pamg_l1_cache_size(int *entries);
 const char *pamg_status_string(int status);
 int pamg_device_count(int *count);
 int pamg_set_device(int device);

@@ -110,6 +110,8 @@ def _declare(lib):
     f("pamg_matrix_spmv", _vp, _i, _vp, _vp, _d, _vp, _vp)
     f("pamg_matrix_resid_sumsq", _vp, _vp, _vp, _vp, _vp)
     f("pamg_matrix_jacobi", _vp, _vp, _vp, _vp, _d, _i, _vp)
+    f("pamg_l1_cache_clear")
+    f("pamg_l1_cache_size", P(C.c_int))
     f("pamg_matrix_jacobi_step", _vp, _vp, _vp, _vp, _d, _vp)
     f("pamg_matrix_block_jacobi_step", _vp, _vp, _vp, _vp, _vp, _d, _vp)
     f("pamg_matrix_gauss_seidel", _vp, _vp, _vp, _i, _d, _i, _vp)

@@ -2,7 +2,10 @@
 // entry points that take HOST buffers exactly like the reference's pybind11 layer
 // (pyamg/amg_core/relaxation_bind.cpp:11-44) and run the sweep on the GPU.
 #include <algorithm>
+#include <cstdlib>
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "pamg_common.h"
 
@@ -29,8 +32,95 @@ struct DevBuf {
 
 struct MatGuard {
     pamg_matrix_t A = nullptr;
-    ~MatGuard() { if (A) pamg_matrix_destroy(A); }
+    bool cached = false;          // owned by the Layer-1 operator cache
+    ~MatGuard() { if (A && !cached) pamg_matrix_destroy(A); }
 };
+
+// ---- Layer-1 operator cache.  The amg_core entry points get the operator as three host arrays on EVERY call; a
+// smoother applied sweep after sweep would upload the matrix and redo the dependency analysis each time.  The last few
+// operators stay resident instead, keyed by the identity of the arrays (addresses, sizes, dtype, block shape) AND a
+// 64-bit hash of their full contents, so an operator modified in place is never mistaken for its old self.  Hashing
+// streams the arrays once on the host (~10 GB/s): cheap next to the upload and the analysis it saves.  Layer-1 calls
+// are synchronous and serialised by the cache's mutex.  PAMG_L1_CACHE=0 disables it; pamg_l1_cache_clear() empties it.
+struct L1Entry {
+    const void *Ap, *Aj, *Ax;
+    int dtype, flavour, nbr, nbc, R, C;
+    int64_t nblk;
+    uint64_t hash;
+    pamg_matrix_t A;
+    uint64_t stamp;
+};
+std::mutex l1_mu;
+std::vector<L1Entry> l1_entries;
+uint64_t l1_clock = 0;
+constexpr size_t L1_CAPACITY = 4;
+
+uint64_t hash_bytes(const void *p, size_t bytes, uint64_t seed)
+{
+    const unsigned char *c = static_cast<const unsigned char *>(p);
+    uint64_t h[4] = {seed ^ 0x9E3779B97F4A7C15ull, seed ^ 0xC2B2AE3D27D4EB4Full, seed ^ 0x165667B19E3779F9ull, seed ^ 0x27D4EB2F165667C5ull};
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, c + i, 32);
+        for (int k = 0; k < 4; ++k) { h[k] = (h[k] ^ w[k]) * 0xFF51AFD7ED558CCDull; h[k] ^= h[k] >> 29; }
+    }
+    uint64_t tail = 0;
+    if (i < bytes) std::memcpy(&tail, c + i, std::min<size_t>(8, bytes - i));
+    uint64_t r = (h[0] ^ tail) * 0xC4CEB9FE1A85EC53ull;
+    for (size_t j = i + 8; j < bytes; ++j) r = (r ^ c[j]) * 0x100000001B3ull;
+    r ^= h[1] + 0x9E3779B97F4A7C15ull + (r << 6) + (r >> 2);
+    r ^= h[2] + 0x9E3779B97F4A7C15ull + (r << 6) + (r >> 2);
+    r ^= h[3] + 0x9E3779B97F4A7C15ull + (r << 6) + (r >> 2);
+    return r ^ bytes;
+}
+
+bool l1_enabled()
+{
+    static const bool on = [] { const char *e = std::getenv("PAMG_L1_CACHE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// the operator behind (Ap, Aj, Ax): from the cache or created (and cached).  Caller holds l1_mu.
+int l1_acquire(MatGuard &g, int dtype, int flavour, int nbr, int nbc, int R, int C, const int32_t *Ap, const int32_t *Aj,
+               const void *Ax)
+{
+    if (!l1_enabled() || nbr < 0 || !Ap) return pamg_matrix_create(&g.A, dtype, flavour, nbr, nbc, R, C, Ap, Aj, Ax);
+    const int64_t nblk = Ap[nbr];
+    if (nblk < 0) return PAMG_E_ARG;
+    const size_t ts = dtype == PAMG_F64 ? 8 : 4;
+    uint64_t h = hash_bytes(Ap, sizeof(int32_t) * ((size_t)nbr + 1), 1);
+    h = hash_bytes(Aj, sizeof(int32_t) * (size_t)nblk, h);
+    h = hash_bytes(Ax, ts * (size_t)nblk * R * C, h);
+    for (L1Entry &e : l1_entries) {
+        if (e.Ap == Ap && e.Aj == Aj && e.Ax == Ax && e.dtype == dtype && e.flavour == flavour && e.nbr == nbr && e.nbc == nbc &&
+            e.R == R && e.C == C && e.nblk == nblk && e.hash == h) {
+            e.stamp = ++l1_clock;
+            g.A = e.A;
+            g.cached = true;
+            return PAMG_OK;
+        }
+    }
+    // same arrays, different contents: the old copy is stale
+    for (size_t k = 0; k < l1_entries.size();) {
+        if (l1_entries[k].Ap == Ap && l1_entries[k].Aj == Aj && l1_entries[k].Ax == Ax) {
+            pamg_matrix_destroy(l1_entries[k].A);
+            l1_entries.erase(l1_entries.begin() + (long)k);
+        } else {
+            ++k;
+        }
+    }
+    PAMG_TRY(pamg_matrix_create(&g.A, dtype, flavour, nbr, nbc, R, C, Ap, Aj, Ax));
+    if (l1_entries.size() >= L1_CAPACITY) {
+        size_t old = 0;
+        for (size_t k = 1; k < l1_entries.size(); ++k) if (l1_entries[k].stamp < l1_entries[old].stamp) old = k;
+        pamg_matrix_destroy(l1_entries[old].A);
+        l1_entries.erase(l1_entries.begin() + (long)old);
+    }
+    l1_entries.push_back(L1Entry{Ap, Aj, Ax, dtype, flavour, nbr, nbc, R, C, nblk, h, g.A, ++l1_clock});
+    g.cached = true;
+    return PAMG_OK;
+}
 
 template <typename T> constexpr int dt() { return sizeof(T) == 8 ? PAMG_F64 : PAMG_F32; }
 
@@ -47,8 +137,9 @@ int l1_matvec(int n_brow, int n_bcol, int R, int C, const int32_t *Ap, const int
               const T *Xx, T *Yx)
 {
     if (n_brow < 0 || n_bcol < 0 || !Ap || (!Xx && n_bcol) || (!Yx && n_brow)) return PAMG_E_ARG;
+    std::lock_guard<std::mutex> lock(l1_mu);
     MatGuard g;
-    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), (R == 1 && C == 1) ? PAMG_CSR : PAMG_BSR, n_brow, n_bcol, R, C, Ap, Aj, Ax));
+    PAMG_TRY(l1_acquire(g, dt<T>(), (R == 1 && C == 1) ? PAMG_CSR : PAMG_BSR, n_brow, n_bcol, R, C, Ap, Aj, Ax));
     DevBuf x, y;
     PAMG_TRY(x.put(Xx, sizeof(T) * (size_t)n_bcol * C));
     PAMG_TRY(y.put(Yx, sizeof(T) * (size_t)n_brow * R));
@@ -68,8 +159,9 @@ int l1_gs(int epi, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_siz
     const int nb = Ap_size - 1;
     if ((int64_t)nb * bs > x_size || (int64_t)nb * bs > b_size) return PAMG_E_ARG;
     if (row_start == row_stop) return PAMG_OK;
+    std::lock_guard<std::mutex> lock(l1_mu);
     MatGuard g;
-    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), epi == EPI_GS_B ? PAMG_BSR : PAMG_CSR, nb, nb, bs, bs, Ap, Aj, Ax));
+    PAMG_TRY(l1_acquire(g, dt<T>(), epi == EPI_GS_B ? PAMG_BSR : PAMG_CSR, nb, nb, bs, bs, Ap, Aj, Ax));
     DevBuf dx, db;
     PAMG_TRY(dx.put(x, sizeof(T) * (size_t)nb * bs));
     PAMG_TRY(db.put(b, sizeof(T) * (size_t)nb * bs));
@@ -105,8 +197,9 @@ int l1_jacobi(bool bsr, const int32_t *Ap, int Ap_size, const int32_t *Aj, int A
         const long i = row_start + t * row_step;
         for (int k = 0; k < bs; ++k) temp[i * bs + k] = x[i * bs + k];
     }
+    std::lock_guard<std::mutex> lock(l1_mu);
     MatGuard g;
-    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), bsr ? PAMG_BSR : PAMG_CSR, nb, nb, bs, bs, Ap, Aj, Ax));
+    PAMG_TRY(l1_acquire(g, dt<T>(), bsr ? PAMG_BSR : PAMG_CSR, nb, nb, bs, bs, Ap, Aj, Ax));
     DevBuf dt_, db, dn;
     PAMG_TRY(dt_.put(temp, sizeof(T) * (size_t)n));
     PAMG_TRY(db.put(b, sizeof(T) * (size_t)n));
@@ -137,8 +230,9 @@ int l1_jacobi_indexed(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_
     const int n = Ap_size - 1;
     if (n > x_size || n > b_size) return PAMG_E_ARG;
     if (indices_size == 0) return PAMG_OK;
+    std::lock_guard<std::mutex> lock(l1_mu);
     MatGuard g, sub;
-    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), PAMG_CSR, n, n, 1, 1, Ap, Aj, Ax));
+    PAMG_TRY(l1_acquire(g, dt<T>(), PAMG_CSR, n, n, 1, 1, Ap, Aj, Ax));
     PAMG_TRY(matrix_row_subset(g.A, indices, indices_size, &sub.A));
     DevBuf dx, db, dw;
     PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
@@ -161,8 +255,9 @@ int l1_kaczmarz(bool nr, const int32_t *Ap, int Ap_size, const int32_t *Aj, int 
     const int n = Ap_size - 1;
     if (n > x_size || n > vb_size || n > Tx_size) return PAMG_E_ARG;
     if (start == stop) return PAMG_OK;
+    std::lock_guard<std::mutex> lock(l1_mu);
     MatGuard g;
-    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), PAMG_CSR, n, n, 1, 1, Ap, Aj, Ax));
+    PAMG_TRY(l1_acquire(g, dt<T>(), PAMG_CSR, n, n, 1, 1, Ap, Aj, Ax));
     DevBuf dx, dv, dD;
     PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
     PAMG_TRY(dv.put(nr ? (const void *)v_nr : (const void *)b, sizeof(T) * (size_t)n));
@@ -228,8 +323,9 @@ int l1_block(bool gs, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_
     const int64_t n = (int64_t)nb * bs;
     if (n > x_size || n > b_size || (int64_t)nb * bs * bs > Tx_size) return PAMG_E_ARG;
     if (row_start == row_stop) return PAMG_OK;
+    std::lock_guard<std::mutex> lock(l1_mu);
     MatGuard g;
-    PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), PAMG_BSR, nb, nb, bs, bs, Ap, Aj, Ax));
+    PAMG_TRY(l1_acquire(g, dt<T>(), PAMG_BSR, nb, nb, bs, bs, Ap, Aj, Ax));
     DevBuf dx, db, dd, dn;
     PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
     PAMG_TRY(db.put(b, sizeof(T) * (size_t)n));
@@ -254,6 +350,22 @@ int l1_block(bool gs, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_
 extern "C" {
 
 // ------------------------------------------------------------------------------ plumbing
+int pamg_l1_cache_clear(void)
+{
+    std::lock_guard<std::mutex> lock(l1_mu);
+    for (L1Entry &e : l1_entries) pamg_matrix_destroy(e.A);
+    l1_entries.clear();
+    return PAMG_OK;
+}
+
+int pamg_l1_cache_size(int *entries)
+{
+    if (!entries) return PAMG_E_ARG;
+    std::lock_guard<std::mutex> lock(l1_mu);
+    *entries = (int)l1_entries.size();
+    return PAMG_OK;
+}
+
 const char *pamg_version(void) { return "pyamg_amd 0.1.0 (gfx950, ROCm " PAMG_STR(HIP_VERSION_MAJOR) "." PAMG_STR(HIP_VERSION_MINOR) ")"; }
 
 const char *pamg_status_string(int st)

@@ -533,3 +533,45 @@ def test_normal_equation_smoothers_bit_exact():
         delta = (np.ravel(b - M @ y) * jn.Dinv).astype(M.dtype)
         gcore.jacobi_ne(M.indptr, M.indices, M.data, y, b, delta, temp, 0, n, 1, np.array([0.6]))
     assert np.array_equal(y, z[f"{tag}.jacobi_ne"])
+
+
+def test_layer1_operator_cache():
+    """Layer 1 keeps the last operators resident: the same three arrays again -> no new entry; the same arrays with
+    CHANGED contents -> the stale copy is replaced and the sweep uses the new values; other arrays -> another entry.
+    Results equal the oracle's in every case."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from pyamg_amd import _capi as capi
+    from tools.problems import poisson_csr
+    lib = capi.lib()
+
+    def size():
+        k = C.c_int(0)
+        capi.check(lib.pamg_l1_cache_size(C.byref(k)), "pamg_l1_cache_size")
+        return k.value
+
+    capi.check(lib.pamg_l1_cache_clear(), "pamg_l1_cache_clear")
+    A = poisson_csr((30, 30))
+    n = A.shape[0]
+    Ap, Aj, Ax = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    rng = np.random.RandomState(3)
+    x0, b = rng.rand(n), rng.rand(n)
+    for trial in range(3):
+        x, ref = x0.copy(), x0.copy()
+        gcore.gauss_seidel(Ap, Aj, Ax, x, b, 0, n, 1)
+        orc.gauss_seidel(Ap, Aj, Ax, ref, b, 0, n, 1)
+        assert np.array_equal(x, ref)
+        assert size() == 1
+        if trial == 1:
+            Ax[::3] *= 1.5                                  # in place: same addresses, new contents
+    B = poisson_csr((17, 19))
+    Bp, Bj, Bx = B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data.copy()
+    m = B.shape[0]
+    y, yref = rng.rand(m), None
+    yref = y.copy()
+    c = rng.rand(m)
+    gcore.gauss_seidel(Bp, Bj, Bx, y, c, m - 1, -1, -1)
+    orc.gauss_seidel(Bp, Bj, Bx, yref, c, m - 1, -1, -1)
+    assert np.array_equal(y, yref) and size() == 2
+    capi.check(lib.pamg_l1_cache_clear(), "pamg_l1_cache_clear")
+    assert size() == 0
