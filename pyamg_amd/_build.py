@@ -18,7 +18,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpyamg_amd.so"
 SOURCES = ["pamg_matrix.hip", "pamg_solver.hip", "pamg_capi.hip"]
-HEADERS = ["pamg_common.h", "pamg_kernels.h", "pamg_tile_kernels.h", "pamg_tile_plan.h", "../../include/pyamg_amd.h"]
+HEADERS = ["pamg_common.h", "pamg_kernels.h", "pamg_tile_kernels.h", "pamg_tile_plan.h", "amg_core_bind.cpp", "../../include/pyamg_amd.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
@@ -59,7 +59,34 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    build_pybind(verbose)
     return LIB
+
+
+def pybind_path() -> Path:
+    import sysconfig
+    return PKG / ("_amg_core_pybind" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_pybind(verbose: bool = True):
+    """the pybind11 face of Layer 1 (csrc/amg_core_bind.cpp): plain g++ against libpyamg_amd.so.  Optional -- the
+    ctypes twin (amg_core.py) covers the same surface; skipped when pybind11 or a host compiler is missing."""
+    try:
+        import pybind11
+        import sysconfig
+    except Exception:       # pragma: no cover
+        return None
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if not cxx:             # pragma: no cover
+        return None
+    out = pybind_path()
+    src = CSRC / "amg_core_bind.cpp"
+    cmd = [cxx, "-O2", "-std=c++17", "-shared", "-fPIC", f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}",
+           str(src), "-o", str(out), f"-L{PKG}", "-l:libpyamg_amd.so", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -575,3 +575,32 @@ def test_layer1_operator_cache():
     assert np.array_equal(y, yref) and size() == 2
     capi.check(lib.pamg_l1_cache_clear(), "pamg_l1_cache_clear")
     assert size() == 0
+
+
+def test_pybind11_module_runs_the_same_kernels(kernels_npz):
+    """the pybind11 module and the ctypes twin are two faces of the same C ABI: identical bits, equal to the oracle"""
+    from pyamg_amd import _build
+    if not _build.pybind_path().exists():
+        pytest.skip("pybind11 module not built")
+    from oracle import oracle as orc
+    from pyamg_amd import _amg_core_pybind as pb
+    from tools.problems import poisson_csr
+    A = poisson_csr((21, 13))
+    n = A.shape[0]
+    Ap, Aj, Ax = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.copy()
+    rng = np.random.RandomState(8)
+    x0, b = rng.rand(n), rng.rand(n)
+    for (r0, r1, rs) in ((0, n, 1), (n - 1, -1, -1)):
+        xa, xb, xr = x0.copy(), x0.copy(), x0.copy()
+        pb.gauss_seidel(Ap, Aj, Ax, xa, b, r0, r1, rs)
+        gcore.gauss_seidel(Ap, Aj, Ax, xb, b, r0, r1, rs)
+        orc.gauss_seidel(Ap, Aj, Ax, xr, b, r0, r1, rs)
+        assert np.array_equal(xa, xr) and np.array_equal(xb, xr)
+    y = np.zeros(n)
+    pb.csr_matvec(n, n, Ap, Aj, Ax, x0, y)
+    assert np.array_equal(y, A @ x0)
+    om = np.array([0.7])
+    xa, xr, t1, t2 = x0.copy(), x0.copy(), np.zeros(n), np.zeros(n)
+    pb.jacobi(Ap, Aj, Ax, xa, b, t1, 0, n, 1, om)
+    orc.jacobi(Ap, Aj, Ax, xr, b, t2, 0, n, 1, om[0])
+    assert np.array_equal(xa, xr)

@@ -235,3 +235,24 @@ def test_batched_elasticity_assembly_matches_the_reference_gallery():
     A2, B2 = elasticity_p1_batched(V, T, keep=keep)
     assert abs(sp.csr_array(A0[k][:, k]) - A2.tocsr()).max() <= 1e-14 * abs(A0).max() and np.array_equal(B0[k], B2)
     assert A2.indices.dtype == np.int32 and A2.indptr.dtype == np.int32
+
+
+def test_pybind11_binding_module_surface():
+    """The pybind11 face of Layer 1 (pyamg_amd/csrc/amg_core_bind.cpp, built by _build.py with plain g++): same
+    function names as the ctypes twin, and -- like the reference's `.noconvert()` overload sets
+    (relaxation_bind.cpp:708-715) -- a dtype mismatch is a TypeError, never a silent conversion.  No device needed."""
+    import torch  # noqa: F401  (libamdhip64 binding order, as everywhere)
+    from pyamg_amd import _build
+    if not _build.pybind_path().exists():
+        pytest.skip("pybind11 module not built")
+    from pyamg_amd import _amg_core_pybind as pb
+    from pyamg_amd import amg_core as ct
+    assert set(ct.__all__) <= {n for n in dir(pb) if not n.startswith("_")}
+    assert "pyamg_amd" in pb.version()
+    Ap, Aj = np.zeros(2, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    with pytest.raises(TypeError):
+        pb.gauss_seidel(Ap, Aj, np.zeros(1, dtype=np.float32), np.zeros(1), np.zeros(1), 0, 1, 1)          # mixed dtypes
+    with pytest.raises(TypeError):
+        pb.gauss_seidel(Ap.astype(np.int64), Aj, np.zeros(1), np.zeros(1), np.zeros(1), 0, 1, 1)           # int64 indices
+    with pytest.raises(TypeError):
+        pb.jacobi(Ap, Aj, np.zeros(1), np.zeros(1), np.zeros(1), np.zeros(1), 0, 1, 1, 1.0)                # omega is an array
