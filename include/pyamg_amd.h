@@ -244,7 +244,8 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * 13 = its LDS ring slots (0 = automatic, else a power of two, 64..8192), 14 = its entries per step
  * (0 = automatic, <= 1020), 15 = let the automatic choice (key 5 = 0) prefer the tiled sweep, 16 = cap on the
  * steps resident in LDS per tile (0 = automatic), 17 = cap on the steps its loader keeps in flight (-1 = automatic),
- * 18 = tile shapes: 1 (default) pencils on three-band grid stencils, 0 contiguous chunks of the visit order always.
+ * 18 = tile shapes: 1 (default) pencils on three-band grid stencils, 0 contiguous chunks of the visit order always;
+ * 19 = 16-bit windowed column stream of the whole-operator kernels (default 1; 0 = 32-bit columns).
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* Pick the LDS window (key 0) and streaming flags (key 8) of the whole-operator kernels by timing

@@ -33,6 +33,12 @@ def hipcc() -> str:
 def stale() -> bool:
     if not LIB.exists():
         return True
+    try:
+        import pybind11  # noqa: F401
+        if shutil.which("g++") and not pybind_path().exists():
+            return True
+    except Exception:       # pragma: no cover
+        pass
     t = LIB.stat().st_mtime
     deps = [CSRC / s for s in SOURCES] + [(CSRC / h).resolve() for h in HEADERS] + [Path(__file__)]
     return any(d.stat().st_mtime > t for d in deps)

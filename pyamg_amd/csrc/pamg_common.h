@@ -71,6 +71,9 @@ struct StreamArgs {
     int nblk;            // row ranges of this launch
     int flags;           // bit 0: non-temporal operator stream, bit 1: XCD-aware range order, bits 2/3: ablations
     int nidle;           // granular sweep: elements of xs that idle lanes may read (>= 1)
+    const unsigned short *Aj16;   // whole-operator kernels: column ids as 16-bit window codes (window << 14 | offset) or nullptr
+    const int4 *wbase;            //   per row range: the first column of its (up to four) windows
+    int4 wb;                      //   the current range's window bases (set by the kernel)
 };
 
 // One dependency-level schedule for an order-exact sweep (forward or backward, or a
@@ -150,6 +153,9 @@ struct pamg_matrix_s {
     // plan for the streamed kernels
     int cap = 1536, npl = 2, max_rows = 1024;
     int flow_cap = 32;               // single-workgroup persistent sweep when a schedule averages <= flow_cap/16 row ranges per level
+    unsigned short *d_Aj16 = nullptr; // column ids of the scalar view as 16-bit window codes (csr_stream_kernel reads 2 instead of 4 bytes per entry)
+    int4 *d_wbase = nullptr;         //   window bases per row range; both null when some range needs more than four 16 K-column windows
+    int use_idx16 = 1;               // tune key 19
     int use_xwin = 0;                // LDS-staged x windows for the whole-operator kernels (tune key 9)
     void *d_xwin = nullptr;          // XWin[nblk] window plan (device)
     int xw_cap = 0;                  // window budget (values) the plan was built for

@@ -194,6 +194,30 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
         typedef int int2n __attribute__((ext_vector_type(2)));
         typedef T T2n __attribute__((ext_vector_type(2)));
         const bool nt = (a.flags & 1) != 0;               // stream the operator past the caches
+        if (a.Aj16) {
+            // 16-bit column stream: every column of this row range lies in one of (up to) four windows of 16 K columns;
+            // an entry stores window << 14 | offset.  Two bytes less per entry on the operator stream, same arithmetic.
+            const int4 wb = a.wb;
+#pragma unroll 2
+            for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
+                const unsigned pr2 = *reinterpret_cast<const unsigned *>(a.Aj16 + q);
+                const T2 vv = *reinterpret_cast<const T2 *>(a.Ax + q);
+                const unsigned c0 = pr2 & 0xFFFFu, c1 = pr2 >> 16;
+                const unsigned w0 = c0 >> 14, w1 = c1 >> 14;
+                int2 cc;
+                cc.x = (w0 == 0 ? wb.x : w0 == 1 ? wb.y : w0 == 2 ? wb.z : wb.w) + (int)(c0 & 0x3FFFu);
+                cc.y = (w1 == 0 ? wb.x : w1 == 1 ? wb.y : w1 == 2 ? wb.z : wb.w) + (int)(c1 & 0x3FFFu);
+                const bool ok0 = q >= p0, ok1 = q + 1 < p1;
+                const T x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
+                const T x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
+                T2 pr;
+                pr.x = vv.x * x0;
+                pr.y = vv.y * x1;
+                *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
+                if constexpr (NEEDC) *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+            }
+            return;
+        }
 #pragma unroll 2
         for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
             int2 cc;
@@ -455,7 +479,15 @@ __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
         const int chunk = (a.nblk + 7) >> 3;
         blk = (blk & 7) * chunk + (blk >> 3);
     }
-    if (blk < a.nblk) stream_block<T, EPI, NPL, 0>(a, a.blkmeta[blk], smem_raw, sq);
+    if (blk < a.nblk) {
+        if (NPL == 2 && a.Aj16) {
+            StreamArgs<T> aw = a;
+            aw.wb = a.wbase[blk];
+            stream_block<T, EPI, NPL, 0>(aw, a.blkmeta[blk], smem_raw, sq);
+        } else {
+            stream_block<T, EPI, NPL, 0>(a, a.blkmeta[blk], smem_raw, sq);
+        }
+    }
     if constexpr (EPI == EPI_SUMSQ) {
         __syncthreads();                                   // LDS reuse for the reduction
         const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));

@@ -134,6 +134,52 @@ void parallel_rows(int n, F fn)
 
 int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap);
 
+// 16-bit column codes for the whole-operator kernels: per row range up to four windows of 16 K columns (greedy over the
+// range's sorted columns); an entry becomes window << 14 | (column - window base).  All-or-nothing per operator: one
+// range that needs a fifth window keeps the operator on 32-bit columns.
+int plan_idx16(pamg_matrix_s *A, const std::vector<int4> &blk)
+{
+    if (A->d_Aj16) { hipFree(A->d_Aj16); A->d_Aj16 = nullptr; }
+    if (A->d_wbase) { hipFree(A->d_wbase); A->d_wbase = nullptr; }
+    if (A->npl != 2 || A->nnz == 0 || A->d_rowid) return PAMG_OK;
+    const int nb = (int)blk.size();
+    std::vector<int4> wb((size_t)nb);
+    std::vector<unsigned short> code((size_t)A->nnz + 16, 0);
+    const int *Aj = A->h_Aj.data();
+    std::atomic<int> ok(1);
+    parallel_rows(nb, [&](int lo, int hi) {
+        std::vector<int> c;
+        for (int b = lo; b < hi && ok.load(std::memory_order_relaxed); ++b) {
+            const int p0 = blk[b].z, p1 = blk[b].w;
+            int base[4] = {0, 0, 0, 0};
+            if (p1 > p0) {
+                c.assign(Aj + p0, Aj + p1);
+                std::sort(c.begin(), c.end());
+                int nw = 0;
+                for (int v : c) {
+                    if (nw == 0 || v >= base[nw - 1] + 16384) {
+                        if (nw == 4) { ok = 0; break; }
+                        base[nw++] = v;
+                    }
+                }
+                if (!ok.load(std::memory_order_relaxed)) break;
+                for (int p = p0; p < p1; ++p) {
+                    const int v = Aj[p];
+                    int w = nw - 1;
+                    while (w > 0 && v < base[w]) --w;
+                    code[(size_t)p] = (unsigned short)((w << 14) | (v - base[w]));
+                }
+            }
+            wb[(size_t)b] = make_int4(base[0], base[1], base[2], base[3]);
+        }
+    });
+    if (!ok.load()) return PAMG_OK;
+    size_t bytes = 0;
+    PAMG_TRY(upload_raw((void **)&A->d_Aj16, code.data(), code.size(), sizeof(unsigned short), &bytes));
+    PAMG_TRY(upload_raw((void **)&A->d_wbase, wb.data(), wb.size(), sizeof(int4), &bytes));
+    return PAMG_OK;
+}
+
 int replan(pamg_matrix_s *A)
 {
     if (A->d_blkmeta) { hipFree(A->d_blkmeta); A->d_blkmeta = nullptr; }
@@ -150,6 +196,7 @@ int replan(pamg_matrix_s *A)
         A->bnblk = (int)bb.size();
         PAMG_TRY(upload(&A->d_bmeta, bb.data(), bb.size(), nullptr));
     }
+    PAMG_TRY(plan_idx16(A, blk));
     if (A->use_xwin && A->R == 1 && A->npl == 2) PAMG_TRY(plan_windows(A, blk, std::max(256, A->cap)));
     else if (A->d_xwin) { hipFree(A->d_xwin); A->d_xwin = nullptr; }
     PAMG_HIP(hipMalloc((void **)&A->d_partial, sizeof(double) * (size_t)(A->nblk + 264)));
@@ -605,6 +652,9 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.nblk = A->nblk;
     a.flags = 0;
     a.nidle = 1;
+    a.Aj16 = nullptr;            // set by stream_launch only: the sweeps run on permuted copies with their own column codes
+    a.wbase = nullptr;
+    a.wb = make_int4(0, 0, 0, 0);
     return a;
 }
 
@@ -628,13 +678,16 @@ int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void 
         }
     }
     const int grid = (A->stream_flags & 2) ? 8 * ((A->nblk + 7) / 8) : A->nblk;
+    const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2 && !(A->stream_flags & 4);
     if (A->dtype == PAMG_F64) {
         StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
         a.flags = A->stream_flags;
+        if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; }
         return launch_any<double>(epi, A->npl, grid, lds, s, a);
     }
     StreamArgs<float> a = base_args<float>(A, x, b, y, c, omega, partial);
     a.flags = A->stream_flags;
+    if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; }
     return launch_any<float>(epi, A->npl, grid, lds, s, a);
 }
 
@@ -1470,7 +1523,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
 {
     if (!A) return PAMG_OK;
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag); hipFree(A->d_rowid);
-    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta);
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta); hipFree(A->d_Aj16); hipFree(A->d_wbase);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     for (int k = 0; k < 4; ++k) pamg::free_line_schedule(A->ls[k]);
     delete A;
@@ -1516,6 +1569,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 16: if (value < 0 || value > 32) return PAMG_E_ARG; A->tile_D = value; break;
         case 17: if (value < -1 || value > 4) return PAMG_E_ARG; A->tile_Q = value; break;
         case 18: if (value < 0 || value > 1) return PAMG_E_ARG; A->tile_part = value; break;
+        case 19: A->use_idx16 = value != 0; return PAMG_OK;
         default: return PAMG_E_ARG;
     }
     if (key >= 12) {                                  // tile plan parameters: drop the tile parts only

@@ -604,3 +604,32 @@ def test_pybind11_module_runs_the_same_kernels(kernels_npz):
     pb.jacobi(Ap, Aj, Ax, xa, b, t1, 0, n, 1, om)
     orc.jacobi(Ap, Aj, Ax, xr, b, t2, 0, n, 1, om[0])
     assert np.array_equal(xa, xr)
+
+
+def test_16bit_column_stream_is_bit_identical():
+    """The whole-operator kernels read the columns as 16-bit window codes where every row range fits four windows of
+    16 K columns (tune key 19 switches back to 32-bit columns): same bits either way, on a banded stencil (three
+    windows per range), a wide random operator (falls back to 32-bit: more than four windows) and BSR(1,1)."""
+    import scipy.sparse as sp
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(5)
+    ops = [poisson_csr((40, 40, 40)),
+           sp.csr_array(sp.random(70000, 70000, density=2e-4, format="csr", random_state=6) + sp.eye_array(70000)),
+           sp.bsr_array(poisson_csr((64, 64)), blocksize=(1, 1))]
+    for A in ops:
+        n = A.shape[0]
+        x, b = rng.rand(n), rng.rand(n)
+        dA = DeviceMatrix(sparse_op(A))
+        dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
+        out = {}
+        for flag in (1, 0):
+            dA.tune(idx16=flag)
+            dy = capi.DeviceArray(n, np.float64)
+            dA.spmv(capi.SPMV_RESID, dx, dy, b=db)
+            dj = capi.DeviceArray.from_host(x)
+            dw = capi.DeviceArray(n, np.float64)
+            dA.jacobi(dj, db, dw, 0.8, iterations=2)
+            out[flag] = (dy.download(), dj.download())
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        assert np.array_equal(out[1][0], b - sp.csr_array(A) @ x)
+        dA.free()

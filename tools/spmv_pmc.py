@@ -28,7 +28,21 @@ rng = np.random.RandomState(0)
 x = capi.DeviceArray.from_host(rng.rand(n))
 b = capi.DeviceArray.from_host(rng.rand(n))
 r = capi.DeviceArray(n, np.float64)
+idx16 = None
+for a in sys.argv[1:]:
+    if a.startswith("--idx16="):
+        idx16 = int(a.split("=", 1)[1])
+if idx16 is not None:
+    dA.tune(idx16=idx16)
 for _ in range(launches):
     dA.spmv(capi.SPMV_RESID, x, r, b=b)
 capi.sync()
-print("ok", n, A.nnz, launches)
+e0, e1 = capi.Event(), capi.Event()
+e0.record()
+for _ in range(launches):
+    dA.spmv(capi.SPMV_RESID, x, r, b=b)
+e1.record()
+e1.synchronize()
+ms = e0.elapsed_ms(e1) / launches
+by = 12 * A.nnz + 4 * (n + 1) + 24 * n
+print("ok", n, A.nnz, launches, f"idx16={idx16} resid {ms:.4f} ms  {by / ms / 1e6:.1f} GB/s algorithmic ({100 * by / ms / 1e6 / 8000:.1f} % of 8 TB/s)")
