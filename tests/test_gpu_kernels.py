@@ -613,9 +613,11 @@ def test_16bit_column_stream_is_bit_identical():
     import scipy.sparse as sp
     from tools.problems import poisson_csr
     rng = np.random.RandomState(5)
-    ops = [poisson_csr((40, 40, 40)),
-           sp.csr_array(sp.random(70000, 70000, density=2e-4, format="csr", random_state=6) + sp.eye_array(70000)),
-           sp.bsr_array(poisson_csr((64, 64)), blocksize=(1, 1))]
+    nw = 70000                                             # wide random operator: 12 scattered columns per row
+    cols = rng.randint(0, nw, size=(nw, 12)).astype(np.int32)
+    wide = sp.csr_array((rng.rand(nw * 12), cols.ravel(), np.arange(0, nw * 12 + 1, 12, dtype=np.int32)), shape=(nw, nw))
+    wide.sum_duplicates()
+    ops = [poisson_csr((40, 40, 40)), wide, sp.bsr_array(poisson_csr((64, 64)), blocksize=(1, 1))]
     for A in ops:
         n = A.shape[0]
         x, b = rng.rand(n), rng.rand(n)
