@@ -1481,54 +1481,92 @@ constexpr int GE = 6;          // pairs per lane: ranges of up to GE * BLK value
 // does not depend on other rows was fetched before the wait -- b and the row's own old values in
 // registers, the diagonal block (PNT_GS) or its inverse (BLK_GS) through D (LDS or global; nullptr =
 // no diagonal block stored)
-template <typename T, int KIND>
+template <typename T, int KIND, int BS = 0>
 __device__ __forceinline__ void block_row_finish_gran(const BlockArgs<T> &a, const int i, T (&acc)[MAXBS], const T *D,
                                                       const T (&breg)[MAXBS], T (&loc)[MAXBS])
 {
-    const int bs = a.bs;
+    // BS > 0: the block size is a compile-time constant -- every loop below unrolls and acc / loc / v stay in
+    // registers with static indices (run-time bounds cost a select chain per access); BS == 0: generic
+    constexpr int NB = BS > 0 ? BS : MAXBS;
+    const int bs = BS > 0 ? BS : a.bs;
     if constexpr (KIND == BLK_GS) {
         T v[MAXBS];
-        for (int k = 0; k < bs; ++k) acc[k] = breg[k] - acc[k];
-        for (int r = 0; r < bs; ++r) {
-            T d = T(0);
-            for (int c = 0; c < bs; ++c) d += D[r * bs + c] * acc[c];
-            v[r] = d;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) if (BS > 0 || k < bs) acc[k] = breg[k] - acc[k];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            if (BS > 0 || r < bs) {
+                T d = T(0);
+#pragma unroll
+                for (int c = 0; c < NB; ++c) if (BS > 0 || c < bs) d += D[r * bs + c] * acc[c];
+                v[r] = d;
+            }
         }
-        for (int k = 0; k < bs; ++k) {
-            a.xdst[(long)i * bs + k] = v[k];
-            __hip_atomic_store(a.xs + (long)i * bs + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if (BS > 0 || k < bs) {
+                a.xdst[(long)i * bs + k] = v[k];
+                __hip_atomic_store(a.xs + (long)i * bs + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     } else {
         if (D) {
-            const int k0 = a.dirn > 0 ? 0 : bs - 1, k1 = a.dirn > 0 ? bs : -1;
-            for (int k = k0; k != k1; k += a.dirn) {
-                T d = T(1);
-                for (int kk = k0; kk != k1; kk += a.dirn) {
-                    if (kk == k) d = D[k * bs + kk];
-                    else acc[k] -= D[k * bs + kk] * loc[kk];
+            if (a.dirn > 0) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    if (BS > 0 || k < bs) {
+                        T d = T(1);
+#pragma unroll
+                        for (int kk = 0; kk < NB; ++kk) {
+                            if (BS > 0 || kk < bs) {
+                                if (kk == k) d = D[k * bs + kk];
+                                else acc[k] -= D[k * bs + kk] * loc[kk];
+                            }
+                        }
+                        if (d != T(0)) {
+                            loc[k] = acc[k] / d;            // later points see the new value
+                            a.xdst[(long)i * bs + k] = loc[k];
+                        }
+                    }
                 }
-                if (d != T(0)) {
-                    loc[k] = acc[k] / d;                // later points see the new value
-                    a.xdst[(long)i * bs + k] = loc[k];
+            } else {
+#pragma unroll
+                for (int k = NB - 1; k >= 0; --k) {
+                    if (BS > 0 || k < bs) {
+                        T d = T(1);
+#pragma unroll
+                        for (int kk = NB - 1; kk >= 0; --kk) {
+                            if (BS > 0 || kk < bs) {
+                                if (kk == k) d = D[k * bs + kk];
+                                else acc[k] -= D[k * bs + kk] * loc[kk];
+                            }
+                        }
+                        if (d != T(0)) {
+                            loc[k] = acc[k] / d;
+                            a.xdst[(long)i * bs + k] = loc[k];
+                        }
+                    }
                 }
             }
         }
         // ALWAYS publish the whole block row (an untouched point publishes its old value)
-        for (int k = 0; k < bs; ++k)
-            __hip_atomic_store(a.xs + (long)i * bs + k, loc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (BS > 0 || k < bs) __hip_atomic_store(a.xs + (long)i * bs + k, loc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-template <typename T, int KIND>
+template <typename T, int KIND, int BS = 0>
 __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrRange<T> &g, const int4 m, T *xl, T *prodv, T *dl)
 {
-    const int bs = a.bs, bb = bs * bs;
+    constexpr int NB = BS > 0 ? BS : MAXBS;               // BS > 0: compile-time block size (static loops, registers)
+    const int bs = BS > 0 ? BS : a.bs, bb = bs * bs;
     const int r0 = m.x, r1 = m.y, q0 = m.z, q1 = m.w;
     const int tid = threadIdx.x;
     const int nent = (q1 - q0) * bs;
     if (nent <= g.capv && nent <= GE * BLK) {
         // ---- everything that does not depend on other ranges, before the wait
-        T Areg[GE][MAXBS];
+        T Areg[GE][NB];
         int cjs[GE];
 #pragma unroll
         for (int k = 0; k < GE; ++k) {
@@ -1540,7 +1578,7 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
                 const long p = g.pblk ? g.pblk[q] : q;
                 const T *Arow = a.Ax + p * bb + r * bs;
 #pragma unroll
-                for (int c = 0; c < MAXBS; ++c) Areg[k][c] = c < bs ? Arow[c] : T(0);
+                for (int c = 0; c < NB; ++c) Areg[k][c] = (BS > 0 || c < bs) ? Arow[c] : T(0);
             }
         }
         const int nrow = r1 - r0;
@@ -1568,8 +1606,8 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
             dq = g.dpos[myr];
 #pragma unroll
             for (int k = 0; k < MAXBS; ++k) {
-                breg[k] = k < bs ? a.b[(long)i * bs + k] : T(0);
-                loc[k] = (KIND == PNT_GS && k < bs) ? a.xsrc[(long)i * bs + k] : T(0);
+                breg[k] = (k < NB && k < bs) ? a.b[(long)i * bs + k] : T(0);
+                loc[k] = (KIND == PNT_GS && k < NB && k < bs) ? a.xsrc[(long)i * bs + k] : T(0);
             }
         }
         // ---- the wait: one x value per (block, row-in-block) pair, batch-polled
@@ -1630,8 +1668,8 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
                 if (!(cjs[k] & DIAG_BIT)) {
                     const T *xq = xl + (e / bs) * bs;
 #pragma unroll
-                    for (int c = 0; c < MAXBS; ++c)
-                        if (c < bs) d += Areg[k][c] * xq[c];
+                    for (int c = 0; c < NB; ++c)
+                        if (BS > 0 || c < bs) d += Areg[k][c] * xq[c];
                 }
                 prodv[e] = d;
             }
@@ -1639,23 +1677,22 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
         lds_barrier();
         if (has_row) {
             T acc[MAXBS];
-            if constexpr (KIND == BLK_GS) {
-                for (int k = 0; k < bs; ++k) acc[k] = T(0);
-            } else {
-                for (int k = 0; k < bs; ++k) acc[k] = breg[k];
-            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[k] = (KIND == BLK_GS) ? T(0) : breg[k];
             for (int q = qa; q < qb; ++q) {
                 const T *v = prodv + (q - q0) * bs;
-                if constexpr (KIND == BLK_GS) {
-                    for (int k = 0; k < bs; ++k) acc[k] += v[k];
-                } else {
-                    for (int k = 0; k < bs; ++k) acc[k] -= v[k];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    if (BS > 0 || k < bs) {
+                        if constexpr (KIND == BLK_GS) acc[k] += v[k];
+                        else acc[k] -= v[k];
+                    }
                 }
             }
             const T *D;
             if constexpr (KIND == BLK_GS) D = dl_ok ? dl + (myr - r0) * bb : a.Dinv + (long)i * bb;
             else D = dq < 0 ? nullptr : (dl_ok ? dl + (myr - r0) * bb : a.Ax + (long)dq * bb);
-            block_row_finish_gran<T, KIND>(a, i, acc, D, breg, loc);
+            block_row_finish_gran<T, KIND, BS>(a, i, acc, D, breg, loc);
         }
     } else if (tid == 0) {
         // over-long block row (a range of its own): one lane, block after block
@@ -1693,7 +1730,7 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
     }
 }
 
-template <typename T, int KIND>
+template <typename T, int KIND, int BS = 0>
 __global__ __launch_bounds__(BLK) void bsr_gran_kernel(const BlockArgs<T> a, const BsrRange<T> g, int nblk)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1701,7 +1738,7 @@ __global__ __launch_bounds__(BLK) void bsr_gran_kernel(const BlockArgs<T> a, con
     T *prodv = xl + (g.capv + 8);
     T *dl = prodv + (g.capv + 8);
     for (int blk = (int)blockIdx.x; blk < nblk; blk += (int)gridDim.x) {
-        bsr_range_gran<T, KIND>(a, g, g.meta[blk], xl, prodv, dl);
+        bsr_range_gran<T, KIND, BS>(a, g, g.meta[blk], xl, prodv, dl);
         lds_barrier();                                     // LDS is reused by the next row range
     }
 }

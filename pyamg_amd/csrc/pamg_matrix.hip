@@ -1020,8 +1020,19 @@ static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *
         if (A->gran_cap > 0) G = std::min(G, A->gran_cap);
         else G = std::min(G, std::max(32, 8 * per_level));
         G = std::min(G, resident);
-        if (kind == PNT_GS) hipLaunchKernelGGL((bsr_gran_kernel<T, PNT_GS>), dim3(G), dim3(BLK), 3 * lds, s, a, r, g->nblk_total);
-        else hipLaunchKernelGGL((bsr_gran_kernel<T, BLK_GS>), dim3(G), dim3(BLK), 3 * lds, s, a, r, g->nblk_total);
+        // compile-time block sizes for the common ones (elasticity: 2, 3, 6; 4), the generic kernel otherwise
+#define PAMG_BG(K, B) hipLaunchKernelGGL((bsr_gran_kernel<T, K, B>), dim3(G), dim3(BLK), 3 * lds, s, a, r, g->nblk_total)
+#define PAMG_BGS(K)                                                                      \
+        switch (A->R) {                                                                  \
+            case 2: PAMG_BG(K, 2); break;                                                \
+            case 3: PAMG_BG(K, 3); break;                                                \
+            case 4: PAMG_BG(K, 4); break;                                                \
+            case 6: PAMG_BG(K, 6); break;                                                \
+            default: PAMG_BG(K, 0); break;                                               \
+        }
+        if (kind == PNT_GS) { PAMG_BGS(PNT_GS) } else { PAMG_BGS(BLK_GS) }
+#undef PAMG_BGS
+#undef PAMG_BG
         return (int)hipGetLastError();
     }
     int G = 0;
