@@ -1596,6 +1596,14 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
                 dl[t] = v;
             }
         }
+        // compile-time block sizes: the block-row sums are formed by BS lanes per block row (lane = (row, component);
+        // each still adds its component block after block in storage order), the small dense finish by one lane per row
+        int pq0 = 0, pq1 = 0;
+        const bool par_ok = KIND == BLK_GS && BS > 0 && nrow * BS <= BLK && nrow * BS <= g.capv;   // (the point sweep's b - v0 - v1 ... cannot be split)
+        if (par_ok && tid < nrow * BS) {
+            pq0 = g.pAp[r0 + tid / BS];
+            pq1 = g.pAp[r0 + tid / BS + 1];
+        }
         const int myr = r0 + tid;
         const bool has_row = myr < r1;
         int i = 0, qa = 0, qb = 0, dq = -1;
@@ -1675,11 +1683,29 @@ __device__ __forceinline__ void bsr_range_gran(const BlockArgs<T> &a, const BsrR
             }
         }
         lds_barrier();
+        if (par_ok) {
+            if (tid < nrow * BS) {
+                const int k = tid % BS;
+                T sk = T(0);
+                const T *v = prodv + (pq0 - q0) * bs + k;
+                for (int q = pq0; q < pq1; ++q, v += bs) sk += *v;       // component k, block after block
+                xl[tid] = sk;                                            // the x staging area is free again
+            }
+            lds_barrier();
+        }
         if (has_row) {
             T acc[MAXBS];
 #pragma unroll
             for (int k = 0; k < NB; ++k) acc[k] = (KIND == BLK_GS) ? T(0) : breg[k];
-            for (int q = qa; q < qb; ++q) {
+            if (par_ok) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const T sk = xl[(myr - r0) * NB + k];
+                    if constexpr (KIND == BLK_GS) acc[k] = sk;           // 0 + p0 + p1 ... == the running sum from +0
+                    else acc[k] = breg[k];
+                }
+            }
+            for (int q = par_ok && KIND == BLK_GS ? qb : qa; q < qb; ++q) {
                 const T *v = prodv + (q - q0) * bs;
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
