@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes that measure the SpMV's HBM traffic")
     ap.add_argument("--min-rows", type=int, default=200_000, help="shard levels with at least this many rows")
+    ap.add_argument("--host-setup", action="store_true", help="build the hierarchies with the reference alone (no device setup operators)")
+    ap.add_argument("--no-setup-compare", action="store_true", help="skip the second, reference-only setup of the main workload")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -209,14 +211,23 @@ def main():
             return float(t.item())
         return v
 
-    def build(wl):
+    import contextlib
+    from pyamg_amd.aggregation import device_setup
+
+    def setup_ctx(device, prolongation=True):
+        # the reference's setup with its spectral radii / prolongation smoothing run by pyamg_amd.aggregation on the GPU
+        return device_setup(pyamg, prolongation=prolongation) if device else contextlib.nullcontext()
+
+    def build(wl, device=None):
+        device = (not args.host_setup) if device is None else device
         t0 = time.time()
         if wl.get("elasticity"):
             from tools.problems import elasticity3d
             A, B = elasticity3d(wl["grid"][0])
             np.random.seed(SEED)
-            ml = pyamg.smoothed_aggregation_solver(A, B=B, smooth="jacobi", presmoother=wl["smoother"],
-                                                   postsmoother=wl["smoother"], max_coarse=10)
+            with setup_ctx(device, prolongation=False):     # 3x3 blocks: prolongation smoothing stays with the reference
+                ml = pyamg.smoothed_aggregation_solver(A, B=B, smooth="jacobi", presmoother=wl["smoother"],
+                                                       postsmoother=wl["smoother"], max_coarse=10)
             return A, ml, time.time() - t0
         if wl.get("convdiff"):
             import scipy.sparse as sp
@@ -238,11 +249,12 @@ def main():
             return A, ml, time.time() - t0
         A = pyamg.gallery.poisson(wl["grid"], format="csr")
         np.random.seed(SEED)                   # Arnoldi start vectors of the smoother setup
-        if wl.get("kind") == "rs":
-            ml = pyamg.ruge_stuben_solver(A, presmoother=wl["smoother"], postsmoother=wl["smoother"])
-            return A, ml, time.time() - t0
-        ml = pyamg.smoothed_aggregation_solver(A, presmoother=wl["smoother"], postsmoother=wl["smoother"],
-                                               max_coarse=10)
+        with setup_ctx(device):
+            if wl.get("kind") == "rs":
+                ml = pyamg.ruge_stuben_solver(A, presmoother=wl["smoother"], postsmoother=wl["smoother"])
+            else:
+                ml = pyamg.smoothed_aggregation_solver(A, presmoother=wl["smoother"], postsmoother=wl["smoother"],
+                                                       max_coarse=10)
         return A, ml, time.time() - t0
 
     def rhs(n):
@@ -390,6 +402,20 @@ def main():
         cpu, res_cpu = cpu_reference(ml, A, b, x0, kcpu)
         parity = parity_of(res_gpu, res_cpu)
         parity["reference_protocol"] = protocol_parity(dml, ml, n)
+    setup_cmp = None
+    if rank == 0 and world == 1 and not args.host_setup and not args.no_setup_compare and not wl.get("convdiff"):
+        # the same setup by the reference alone: what the device setup operators buy, and what they change
+        import scipy.sparse as sp
+        A_r, ml_r, t_ref_setup = build(wl, device=False)
+        sizes_d = [[int(L.A.shape[0]), int(L.A.nnz)] for L in ml.levels]
+        sizes_r = [[int(L.A.shape[0]), int(L.A.nnz)] for L in ml_r.levels]
+        setup_cmp = {"reference_setup_s": round(t_ref_setup, 1), "speedup": round(t_ref_setup / max(t_setup, 1e-9), 2),
+                     "level_sizes_match": sizes_d == sizes_r}
+        if sizes_d == sizes_r and len(ml.levels) > 1:
+            d1 = abs(sp.csr_array(ml.levels[1].A) - sp.csr_array(ml_r.levels[1].A))
+            setup_cmp["level1_A_max_rel_diff"] = float(d1.max() / abs(ml_r.levels[1].A).max())
+        log(f"setup: reference alone {t_ref_setup:.1f}s, with the device setup operators {t_setup:.1f}s; {setup_cmp}")
+        del A_r, ml_r
     if rank == 0:
         replicas = world > 1
         out = {
@@ -404,7 +430,10 @@ def main():
             "event_ms_per_step": round(ev_ms / args.steps, 4),
             "spmv_GBps": round(achieved, 1), "spmv_pct_of_hbm_peak": round(100 * achieved / HBM_PEAK_GBPS, 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
-            "host": {"setup_s": round(t_setup, 1), "upload_s": round(t_upload, 1), "cores": os.cpu_count()},
+            "host": {"setup_s": round(t_setup, 1), "upload_s": round(t_upload, 1), "cores": os.cpu_count(),
+                     "setup": "reference (oracle/_ref) alone" if args.host_setup else
+                              "reference (oracle/_ref) with pyamg_amd.aggregation.device_setup: spectral radii (Arnoldi) and prolongation smoothing on the GPU",
+                     **(setup_cmp or {})},
             "residuals_gpu": [float(v) for v in res_gpu],
         }
         if sweeps:

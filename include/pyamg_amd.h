@@ -432,6 +432,51 @@ int pamg_solver_set_graph(pamg_solver_t S, int enable);
  * stats[3]=algorithmic bytes per V-cycle (incl. convergence check) */
 int pamg_solver_stats(pamg_solver_t S, int64_t stats[8]);
 
+/* ------------------------------------------------------------------------------------------------
+ * Setup-phase operators: what the reference's smoothed-aggregation setup spends its
+ * time in -- approximate_spectral_radius (util/linalg.py:255-370), the prolongation smoother
+ * P = T - (omega/rho) D^-1 A T (aggregation/smooth.py:61-207) and the Galerkin product
+ * A_c = R @ A @ P (aggregation/aggregation.py:425) -- on device-resident CSR operands (fp64, int32).
+ *
+ * pamg_csr_t: a plain CSR matrix in HBM.  pamg_csr_matmat is SciPy's csr_matmat: its arithmetic order
+ * (for k in row i of A in stored order, for j in row k of B: sums[j] += a_ik * b_kj), its emission order
+ * (a row's entries in reverse order of first touch) and its dropping of sums that are exactly zero -- the
+ * result is the array `A @ B` produces, entry for entry (the next level's aggregation walks that order).
+ * keep_zeros = 1 (with col_block = width of the result's column blocks): the scalar view of a BSR product
+ * with true blocks -- bsr_matmat stores whole blocks, zeros included, in FORWARD order of first touch.  pamg_csr_subtract is csr_binop_csr with minus: the canonical
+ * merge when both operands have sorted duplicate-free rows, SciPy's general algorithm (and its emission
+ * order) otherwise.  PAMG_E_UNSUPPORTED: a row of B longer than 2048 entries meets a row of the product with
+ * more than 4096 terms. */
+typedef struct pamg_csr_s *pamg_csr_t;
+int pamg_csr_create(pamg_csr_t *out, int64_t nrows, int64_t ncols, const int32_t *Ap, const int32_t *Aj,
+                    const double *Ax);                       /* HOST arrays */
+/* non-owning scalar-CSR view of an fp64 operator (BSR operators: their flattened scalar view, whose row
+ * order is SciPy's bsr_matmat accumulation order); A must outlive the view */
+int pamg_csr_view(pamg_csr_t *out, pamg_matrix_t A);
+int pamg_csr_destroy(pamg_csr_t A);
+int pamg_csr_info(pamg_csr_t A, int64_t info[4]);            /* rows, columns, stored entries, owns */
+int pamg_csr_download(pamg_csr_t A, int32_t *Ap, int32_t *Aj, double *Ax);   /* HOST arrays */
+int pamg_csr_matmat(pamg_csr_t A, pamg_csr_t B, int col_block, int keep_zeros, pamg_csr_t *C);
+int pamg_csr_subtract(pamg_csr_t A, pamg_csr_t B, pamg_csr_t *C);
+int pamg_csr_scale(pamg_csr_t A, double alpha);             /* a_ij <- a_ij * alpha, in place (owning matrices only) */
+/* util/utils.py scale_rows (a_ij <- a_ij * d_i, d: HOST, one per row) and `alpha * A` (a_ij <- a_ij * alpha)
+ * on a resident scalar fp64 operator, in place.  PAMG_E_STATE once a sweep schedule or a solver holds it. */
+int pamg_matrix_scale_rows(pamg_matrix_t A, const double *d);
+int pamg_matrix_scale_values(pamg_matrix_t A, double alpha);
+/* Arnoldi process of util/linalg.py:154-253 (the non-symmetric branch, the only one
+ * approximate_spectral_radius uses) on a resident operator: modified Gram-Schmidt, basis in HBM.
+ * run: start vector from the HOST (v0_im NULL: real) or, with v0_re NULL, the vector the last combine
+ * left on the device; H: HOST, (maxiter+1) x maxiter entries as (re, im) pairs, row-major; *ncols = valid
+ * columns (the reference's j + 1); *breakdown_flag as in the reference.  combine: next start vector =
+ * V[:, :ncols] @ coef (linalg.py:352), coef_im NULL for a real eigenvector.  vector: download it. */
+typedef struct pamg_arnoldi_s *pamg_arnoldi_t;
+int pamg_arnoldi_create(pamg_arnoldi_t *out, pamg_matrix_t A, int maxiter);
+int pamg_arnoldi_destroy(pamg_arnoldi_t h);
+int pamg_arnoldi_run(pamg_arnoldi_t h, const double *v0_re, const double *v0_im, double breakdown, double *H,
+                     int *ncols, int *breakdown_flag);
+int pamg_arnoldi_combine(pamg_arnoldi_t h, int ncols, const double *coef_re, const double *coef_im);
+int pamg_arnoldi_vector(pamg_arnoldi_t h, double *re, double *im, int *planes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,6 +141,21 @@ def _declare(lib):
     f("pamg_solver_store", _vp, _vp, _vp)
     f("pamg_solver_stream", _vp, P(_vp))
     f("pamg_solver_stats", _vp, P(C.c_int64))
+    f("pamg_csr_create", P(_vp), C.c_int64, C.c_int64, _vp, _vp, _vp)
+    f("pamg_csr_view", P(_vp), _vp)
+    f("pamg_csr_destroy", _vp)
+    f("pamg_csr_info", _vp, P(C.c_int64))
+    f("pamg_csr_download", _vp, _vp, _vp, _vp)
+    f("pamg_csr_matmat", _vp, _vp, _i, _i, P(_vp))
+    f("pamg_csr_subtract", _vp, _vp, P(_vp))
+    f("pamg_csr_scale", _vp, _d)
+    f("pamg_matrix_scale_rows", _vp, _vp)
+    f("pamg_matrix_scale_values", _vp, _d)
+    f("pamg_arnoldi_create", P(_vp), _vp, _i)
+    f("pamg_arnoldi_destroy", _vp)
+    f("pamg_arnoldi_run", _vp, _vp, _vp, _d, _vp, P(_i), P(_i))
+    f("pamg_arnoldi_combine", _vp, _i, _vp, _vp)
+    f("pamg_arnoldi_vector", _vp, _vp, _vp, P(_i))
 
 
 def load(require_device: bool = False):

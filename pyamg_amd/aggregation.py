@@ -1,0 +1,426 @@
+"""Setup-phase operators on the device: drop-ins for the three places the reference's
+smoothed-aggregation setup spends its time in.
+
+* ``approximate_spectral_radius``   -- pyamg/util/linalg.py:255-370 (Arnoldi of :154-253 on the device)
+* ``jacobi_prolongation_smoother``  -- pyamg/aggregation/smooth.py:61-207 (weighting 'diagonal' / 'local')
+* ``richardson_prolongation_smoother`` -- smooth.py:210-272
+* ``galerkin_product(R, A, P)``     -- the ``R @ A @ P`` of aggregation.py:425 / classical.py:201
+
+Same signatures, same side effects (``A.rho`` caching, the in-place index sort of ``get_diagonal``, the global
+NumPy random stream consumed by the start vector), same return formats.  The sparse products reproduce SciPy's
+accumulation order AND its emission order (rows in reverse order of first touch, exact zeros dropped), so a product or
+a difference is the array SciPy would have produced, entry for entry -- which matters: the next level's aggregation
+walks the stored order (amg_core/smoothed_aggregation.h:185-199).  The spectral radius differs from the reference's
+by the rounding of its dot products (different summation order), about 1e-15 relative, and P inherits that.
+
+``device_setup(pyamg)`` patches a reference package the caller hands in (this package never imports it) so that
+``pyamg.smoothed_aggregation_solver`` runs those pieces here.  No CPU fallback: what is not supported raises.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+from warnings import warn
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.linalg import eig
+
+from . import _capi as capi
+from .hierarchy import sparse_op
+
+__all__ = ["DeviceCSR", "approximate_spectral_radius", "jacobi_prolongation_smoother",
+           "richardson_prolongation_smoother", "galerkin_product", "device_setup"]
+
+
+def _i32(a):
+    a = np.asarray(a)
+    if a.dtype != np.int32:
+        if a.size and (a.max() > np.iinfo(np.int32).max):
+            raise NotImplementedError("index arrays beyond int32 are not supported on the device path")
+        a = a.astype(np.int32)
+    return np.ascontiguousarray(a)
+
+
+class DeviceCSR:
+    """A scalar fp64 CSR matrix in HBM (``pamg_csr_t``)."""
+
+    def __init__(self, handle, keep=None):
+        self.handle = handle
+        self._keep = keep                   # the DeviceMatrix a view points into
+
+    @classmethod
+    def from_scipy(cls, M) -> "DeviceCSR":
+        if not sp.issparse(M):
+            raise NotImplementedError(f"operand of type {type(M).__name__} is not a scipy sparse matrix")
+        if M.dtype != np.float64:
+            raise NotImplementedError(f"setup operators on the device are float64 only (got {M.dtype})")
+        if M.format == "bsr" and tuple(M.blocksize) != (1, 1):
+            # the flattened scalar view (block after block, row-major inside a block) is SciPy's bsr_matmat order
+            from .multilevel import DeviceMatrix
+            dm = DeviceMatrix(sparse_op(M))
+            h = C.c_void_p()
+            capi.check(capi.lib().pamg_csr_view(C.byref(h), dm.handle), "pamg_csr_view")
+            return cls(h, keep=dm)
+        if M.format not in ("csr", "bsr"):
+            M = M.tocsr()
+        indptr, indices, data = _i32(M.indptr), _i32(M.indices), np.ascontiguousarray(M.data, dtype=np.float64).reshape(-1)
+        h = C.c_void_p()
+        capi.check(capi.lib().pamg_csr_create(C.byref(h), M.shape[0], M.shape[1], capi.ptr(indptr), capi.ptr(indices),
+                                              capi.ptr(data)), "pamg_csr_create")
+        return cls(h)
+
+    @classmethod
+    def view_of(cls, dm) -> "DeviceCSR":
+        h = C.c_void_p()
+        capi.check(capi.lib().pamg_csr_view(C.byref(h), dm.handle), "pamg_csr_view")
+        return cls(h, keep=dm)
+
+    @property
+    def info(self):
+        a = (C.c_int64 * 4)()
+        capi.check(capi.lib().pamg_csr_info(self.handle, a), "pamg_csr_info")
+        return int(a[0]), int(a[1]), int(a[2])
+
+    @property
+    def shape(self):
+        m, n, _ = self.info
+        return (m, n)
+
+    def matmat(self, other: "DeviceCSR", col_block=1, keep_zeros=False) -> "DeviceCSR":
+        """``self @ other`` as SciPy computes and stores it; col_block / keep_zeros: scalar view of a BSR product"""
+        h = C.c_void_p()
+        capi.check(capi.lib().pamg_csr_matmat(self.handle, other.handle, int(col_block), int(bool(keep_zeros)), C.byref(h)),
+                   "pamg_csr_matmat")
+        return DeviceCSR(h)
+
+    __matmul__ = matmat
+
+    def __sub__(self, other: "DeviceCSR") -> "DeviceCSR":
+        h = C.c_void_p()
+        capi.check(capi.lib().pamg_csr_subtract(self.handle, other.handle, C.byref(h)), "pamg_csr_subtract")
+        return DeviceCSR(h)
+
+    def to_scipy(self, blocksize=None):
+        m, n, nnz = self.info
+        indptr = np.empty(m + 1, dtype=np.int32)
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.empty(nnz, dtype=np.float64)
+        capi.check(capi.lib().pamg_csr_download(self.handle, capi.ptr(indptr), capi.ptr(indices), capi.ptr(data)),
+                   "pamg_csr_download")
+        if blocksize is not None and tuple(blocksize) == (1, 1):
+            M = sp.bsr_array((data.reshape(-1, 1, 1), indices, indptr), shape=(m, n))
+        else:
+            M = sp.csr_array((data, indices, indptr), shape=(m, n))
+            if blocksize is not None:
+                M = M.tobsr(blocksize=tuple(blocksize))
+        return M
+
+    def free(self):
+        if getattr(self, "handle", None):
+            try:
+                capi.load().pamg_csr_destroy(self.handle)
+            except Exception:       # pragma: no cover
+                pass
+            self.handle = None
+        self._keep = None
+
+    def __del__(self):
+        self.free()
+
+
+# --------------------------------------------------------------------------- spectral radius
+def _set_tol(dtype):
+    """util/params.py set_tol"""
+    c = np.dtype(dtype).char.lower()
+    if c == "f":
+        return 1e3 * np.finfo(np.single).eps
+    if c == "d":
+        return 1e6 * np.finfo(np.double).eps
+    raise ValueError("Attempting to set a tolerance for an unsupported precision.")
+
+
+class _Arnoldi:
+    def __init__(self, dm, maxiter):
+        self.n = dm.shape[0]
+        self.m = int(min(self.n, maxiter))
+        self.dm = dm
+        h = C.c_void_p()
+        capi.check(capi.lib().pamg_arnoldi_create(C.byref(h), dm.handle, self.m), "pamg_arnoldi_create")
+        self.handle = h
+        self.planes = 0
+
+    def run(self, v0, breakdown):
+        """one process; v0: host (n, 1) array or None (the vector combine() left on the device)"""
+        H = np.zeros((self.m + 1, self.m, 2))
+        nc, flag = C.c_int(0), C.c_int(0)
+        re = im = None
+        if v0 is not None:
+            v0 = np.ravel(v0)
+            re = np.ascontiguousarray(v0.real, dtype=np.float64)
+            im = np.ascontiguousarray(v0.imag, dtype=np.float64) if np.iscomplexobj(v0) else None
+            self.planes = 2 if im is not None else 1
+        capi.check(capi.lib().pamg_arnoldi_run(self.handle, capi.ptr(re), capi.ptr(im), float(breakdown), capi.ptr(H),
+                                               C.byref(nc), C.byref(flag)), "pamg_arnoldi_run")
+        Hc = H[..., 0] + 1j * H[..., 1] if self.planes == 2 else np.ascontiguousarray(H[..., 0])
+        return Hc, int(nc.value), bool(flag.value)
+
+    def combine(self, coef):
+        coef = np.ravel(coef)
+        re = np.ascontiguousarray(coef.real, dtype=np.float64)
+        im = np.ascontiguousarray(coef.imag, dtype=np.float64) if np.iscomplexobj(coef) else None
+        capi.check(capi.lib().pamg_arnoldi_combine(self.handle, re.size, capi.ptr(re), capi.ptr(im)), "pamg_arnoldi_combine")
+        if im is not None:
+            self.planes = 2
+
+    def vector(self):
+        re = np.empty(self.n)
+        im = np.empty(self.n) if self.planes == 2 else None
+        p = C.c_int(0)
+        capi.check(capi.lib().pamg_arnoldi_vector(self.handle, capi.ptr(re), capi.ptr(im), C.byref(p)), "pamg_arnoldi_vector")
+        v = re + 1j * im if self.planes == 2 else re
+        return v.reshape(-1, 1)
+
+    def free(self):
+        if getattr(self, "handle", None):
+            try:
+                capi.load().pamg_arnoldi_destroy(self.handle)
+            except Exception:       # pragma: no cover
+                pass
+            self.handle = None
+
+    def __del__(self):
+        self.free()
+
+
+def _spectral_radius(dm, tol, maxiter, restart, v0, want_vector=False):
+    """the restart loop of linalg.py:336-363 on a resident operator"""
+    arn = _Arnoldi(dm, maxiter)
+    breakdown = _set_tol(np.float64)
+    try:
+        ev = evect = None
+        max_index = 0
+        for j in range(restart + 1):
+            H, nvecs, breakdown_flag = arn.run(v0 if j == 0 else None, breakdown)
+            ev, evect = eig(H[:nvecs, :nvecs], left=False, right=True)
+            max_index = np.abs(ev).argmax()
+            error = H[nvecs, nvecs - 1] * evect[-1, max_index] if nvecs < H.shape[0] else 0.0
+            arn.combine(evect[:, max_index])
+            if np.abs(error) / np.abs(ev[max_index]) < tol:
+                break
+            if breakdown_flag:
+                warn(f"Breakdown occurred in step {j}")
+                break
+        rho = np.abs(ev[max_index])
+        return (rho, arn.vector()) if want_vector else rho
+    finally:
+        arn.free()
+
+
+def approximate_spectral_radius(A, tol=0.01, maxiter=15, restart=5, symmetric=None, initial_guess=None,
+                                return_vector=False):
+    """pyamg.util.linalg.approximate_spectral_radius (linalg.py:255-370) with the Arnoldi processes on the device."""
+    if not hasattr(A, "rho") or return_vector:
+        symmetric = False                                   # linalg.py:311 -- the restart needs the whole basis
+        if maxiter < 1:
+            raise ValueError("expected maxiter > 0")
+        if restart < 0:
+            raise ValueError("expected restart >= 0")
+        if A.dtype == int:
+            raise ValueError("expected A to be float (complex or real)")
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("expected square A")
+        if np.iscomplexobj(A) or (sp.issparse(A) and A.dtype != np.float64):
+            raise NotImplementedError(f"approximate_spectral_radius on the device is float64 only (got {A.dtype})")
+        if initial_guess is None:
+            v0 = np.random.rand(A.shape[1], 1)              # the reference's draw from the global stream
+        else:
+            if initial_guess.shape[0] != A.shape[0]:
+                raise ValueError("initial_guess and A must have same shape")
+            if (len(initial_guess.shape) > 1) and (initial_guess.shape[1] > 1):
+                raise ValueError("initial_guess must be an (n,1) or (n,) vector")
+            v0 = initial_guess.reshape(-1, 1)
+            v0 = np.array(v0, dtype=A.dtype)
+        from .multilevel import DeviceMatrix
+        M = A if sp.issparse(A) else sp.csr_array(np.asarray(A, dtype=np.float64))
+        dm = DeviceMatrix(sparse_op(M))
+        try:
+            out = _spectral_radius(dm, tol, maxiter, restart, v0, want_vector=return_vector)
+        finally:
+            dm.free()
+        rho = out[0] if return_vector else out
+        if sp.issparse(A):
+            A.rho = rho
+        return out if return_vector else rho
+    return A.rho
+
+
+# --------------------------------------------------------------------------- prolongation smoothing
+def _diag_inv(S):
+    """util/utils.py get_diagonal(S, inv=True): sorts S's indices in place, like the reference does"""
+    S.sort_indices()
+    D = S.diagonal()
+    Dinv = np.zeros_like(D)
+    mask = D != 0.0
+    Dinv[mask] = 1.0 / D[mask]
+    return Dinv
+
+
+def _scalar_resident(S):
+    """S as a resident scalar operator whose values may be rescaled in place"""
+    from .multilevel import DeviceMatrix
+    if S.format == "bsr" and tuple(S.blocksize) != (1, 1):
+        raise NotImplementedError("prolongation smoothing of block (BSR) operators is not on the device path")
+    return DeviceMatrix(sparse_op(S))
+
+
+def _smooth(W, T, degree, product_weight=None):
+    """P = T; degree times: P = P - (W @ P)  [richardson: P - product_weight * (W @ P)], W resident"""
+    P = DeviceCSR.from_scipy(T)
+    for _ in range(degree):
+        U = W.matmat(P)
+        if product_weight is not None:
+            capi.check(capi.lib().pamg_csr_scale(U.handle, float(product_weight)), "pamg_csr_scale")
+        Pn = P - U
+        U.free()
+        P.free()
+        P = Pn
+    out = P.to_scipy(blocksize=T.blocksize if T.format == "bsr" else None)
+    P.free()
+    return out
+
+
+def jacobi_prolongation_smoother(S, T, C, B, omega=4.0 / 3.0, degree=1, filter_entries=False, weighting="diagonal"):
+    """pyamg.aggregation.smooth.jacobi_prolongation_smoother (smooth.py:61-207): P = (I - omega/rho(D^-1 S) D^-1 S)^degree T,
+    with the spectral radius, the scaled operator and the sparse products on the device."""
+    if weighting == "block":
+        if sp.issparse(S) and S.format == "csr":
+            weighting = "diagonal"
+        elif sp.issparse(S) and S.format == "bsr":
+            if S.blocksize[0] == 1:
+                weighting = "diagonal"
+        else:
+            raise TypeError("S must be sparse BSR or CSR format")
+    if filter_entries:
+        raise NotImplementedError("jacobi_prolongation_smoother(filter_entries=True) is not on the device path")
+    if not (sp.issparse(S) and S.format in ("csr", "bsr")) or not (sp.issparse(T) and T.format in ("csr", "bsr")):
+        raise NotImplementedError("jacobi_prolongation_smoother on the device takes CSR / BSR operands")
+    if S.dtype != np.float64 or T.dtype != np.float64:
+        raise NotImplementedError("jacobi_prolongation_smoother on the device is float64 only")
+    if weighting == "block":
+        raise NotImplementedError("jacobi_prolongation_smoother(weighting='block') on BSR blocks is not on the device path")
+    if weighting not in ("diagonal", "local"):
+        raise ValueError("Incorrect weighting option")
+    lib = capi.lib()
+    if weighting == "diagonal":
+        D_inv = _diag_inv(S)
+        dm = _scalar_resident(S)
+        try:
+            capi.check(lib.pamg_matrix_scale_rows(dm.handle, capi.ptr(np.ascontiguousarray(D_inv, dtype=np.float64))), "scale_rows")
+            rho = _spectral_radius(dm, 0.01, 15, 5, np.random.rand(S.shape[1], 1))
+            capi.check(lib.pamg_matrix_scale_values(dm.handle, float(omega / rho)), "scale_values")
+            W = DeviceCSR.view_of(dm)
+            try:
+                return _smooth(W, T, degree)
+            finally:
+                W.free()
+        finally:
+            dm.free()
+    if weighting == "local":
+        D = np.abs(S) @ np.ones((S.shape[0], 1), dtype=S.dtype)
+        D_inv = np.zeros_like(D)
+        D_inv[D != 0] = 1.0 / np.abs(D[D != 0])
+        dm = _scalar_resident(S)
+        try:
+            capi.check(lib.pamg_matrix_scale_rows(dm.handle, capi.ptr(np.ascontiguousarray(np.ravel(D_inv), dtype=np.float64))), "scale_rows")
+            capi.check(lib.pamg_matrix_scale_values(dm.handle, float(omega)), "scale_values")
+            W = DeviceCSR.view_of(dm)
+            try:
+                return _smooth(W, T, degree)
+            finally:
+                W.free()
+        finally:
+            dm.free()
+    raise ValueError("Incorrect weighting option")      # pragma: no cover
+
+
+def richardson_prolongation_smoother(S, T, omega=4.0 / 3.0, degree=1):
+    """pyamg.aggregation.smooth.richardson_prolongation_smoother (smooth.py:210-272): P = P - weight * (S @ P)."""
+    if not (sp.issparse(S) and S.format in ("csr", "bsr")) or not (sp.issparse(T) and T.format in ("csr", "bsr")):
+        raise NotImplementedError("richardson_prolongation_smoother on the device takes CSR / BSR operands")
+    if S.dtype != np.float64 or T.dtype != np.float64:
+        raise NotImplementedError("richardson_prolongation_smoother on the device is float64 only")
+    weight = omega / approximate_spectral_radius(S)
+    Sd = DeviceCSR.from_scipy(S)
+    try:
+        return _smooth(Sd, T, degree, product_weight=weight)   # weight * (S @ P): the product's values scaled, then P - that
+    finally:
+        Sd.free()
+
+
+# --------------------------------------------------------------------------- Galerkin product
+def _block(M):
+    return tuple(int(v) for v in M.blocksize) if M.format == "bsr" else (1, 1)
+
+
+def galerkin_product(R, A, P):
+    """``R @ A @ P`` (aggregation.py:425, classical.py:201) with both sparse products on the device, in SciPy's
+    association -- (R @ A) @ P -- accumulation order and stored order.  The result has the format SciPy's expression
+    gives it: that of R (BSR with blocks (R's block rows, P's block columns), or CSR).  Operand combinations for which
+    SciPy would first re-block an operand raise."""
+    for M in (R, A, P):
+        if not sp.issparse(M) or M.dtype != np.float64 or M.format not in ("csr", "bsr"):
+            raise NotImplementedError("galerkin_product on the device takes float64 CSR / BSR operands")
+    if R.format == "csr":
+        if A.format != "csr" or P.format != "csr":
+            raise NotImplementedError("galerkin_product: a CSR restriction with BSR operands (SciPy converts and re-sorts them)")
+        rb = ab = cb = 1
+    else:
+        (rb, rc), (ar, ab), (pr, cb) = _block(R), _block(A), _block(P)
+        if (A.format == "bsr" and ar != rc) or (A.format == "csr" and rc != 1) or \
+           (P.format == "bsr" and pr != ab) or (P.format == "csr" and ab != 1):
+            raise NotImplementedError("galerkin_product: block sizes that make SciPy re-block an operand")
+    Rd, Ad, Pd = (DeviceCSR.from_scipy(M) for M in (R, A, P))
+    RA = Rd.matmat(Ad, col_block=ab, keep_zeros=(rb, ab) != (1, 1))
+    Ac = RA.matmat(Pd, col_block=cb, keep_zeros=(rb, cb) != (1, 1))
+    out = Ac.to_scipy(blocksize=(rb, cb) if R.format == "bsr" else None)
+    for d in (RA, Ac, Rd, Ad, Pd):
+        d.free()
+    return out
+
+
+# --------------------------------------------------------------------------- patching a reference package
+@contextlib.contextmanager
+def device_setup(pyamg, prolongation=True):
+    """Run the setup pieces above inside a reference package the CALLER imported::
+
+        with pyamg_amd.aggregation.device_setup(pyamg):
+            ml = pyamg.smoothed_aggregation_solver(A)
+
+    Patched while the block runs: the prolongation smoothers seen by ``pyamg.aggregation.aggregation`` and every
+    by-name import of ``approximate_spectral_radius`` (prolongation smoothing, the rho(D^-1 A) of the Jacobi /
+    Chebyshev smoother setup).  The Galerkin product is an inline expression in the reference (aggregation.py:425);
+    INTEGRATION.md shows the one-line change that routes it to ``galerkin_product``.  ``prolongation=False`` leaves the
+    prolongation smoothers alone (block operators: they are not on the device path) and patches the spectral radius only."""
+    import importlib
+    targets = []
+    for mod, name, fn in (("aggregation.aggregation", "jacobi_prolongation_smoother", jacobi_prolongation_smoother),
+                          ("aggregation.aggregation", "richardson_prolongation_smoother", richardson_prolongation_smoother),
+                          ("aggregation.smooth", "approximate_spectral_radius", approximate_spectral_radius),
+                          ("relaxation.smoothing", "approximate_spectral_radius", approximate_spectral_radius),
+                          ("relaxation.chebyshev", "approximate_spectral_radius", approximate_spectral_radius),
+                          ("util.linalg", "approximate_spectral_radius", approximate_spectral_radius)):
+        try:
+            m = importlib.import_module(f"{pyamg.__name__}.{mod}")
+        except ImportError:     # pragma: no cover
+            continue
+        if not prolongation and name.endswith("prolongation_smoother"):
+            continue
+        if hasattr(m, name):
+            targets.append((m, name, getattr(m, name)))
+            setattr(m, name, fn)
+    try:
+        yield
+    finally:
+        for m, name, old in targets:
+            setattr(m, name, old)

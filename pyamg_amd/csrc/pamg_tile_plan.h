@@ -161,7 +161,7 @@ inline bool tile_detect_grid(int n, const int *Ap, const int *Aj, int64_t &nx, i
 // per step.
 inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_start, int row_step, int m, int nl,
                                 const std::vector<int> &vis, const std::vector<int> &lvl, int G_want, int W, int cap,
-                                int max_rows, TilePlan &P, int partition = 0)
+                                int max_rows, TilePlan &P, int partition = 0, const int *row_tile = nullptr)
 {
     if (W < 64 || (W & (W - 1)) || cap < 2 || max_rows < 1) return 1;
     P = TilePlan();
@@ -196,6 +196,17 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
                 pencils = true;
             }
         }
+    }
+    // partition 2: the caller supplies the tile of every row (row_tile[i] in [0, G_want)), e.g. pencils in coordinates
+    // inherited from a finer grid level
+    if (partition == 2 && row_tile) {
+        bool ok = true;
+        for (int t = 0; t < m && ok; ++t) {
+            const int i = row_start + t * row_step;
+            if (row_tile[i] < 0 || row_tile[i] >= G_want) ok = false;
+            else tile[i] = row_tile[i];
+        }
+        if (ok) { G = G_want; pencils = true; }
     }
     P.G = G;
     if (!pencils) {

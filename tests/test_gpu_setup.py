@@ -1,0 +1,255 @@
+"""GPU parity, setup-phase operators: pyamg_amd.aggregation against SciPy (whose sparse products ARE
+what the reference's setup computes: aggregation.py:425, smooth.py:199) and against the live reference (oracle/_ref).
+
+Bars: sparse products and differences are THE ARRAYS SciPy produces -- same stored order (its linked-list emission
+order), same pattern (exact zeros dropped like SciPy drops them), same bits; spectral radius within 1e-10
+relative of the reference's for the same random stream (only the dot products' summation order differs); smoothed
+prolongators and coarse operators within 1e-13 relative (they inherit the spectral radius' last bits)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _shuffle_rows(M, rng):
+    """same matrix, stored entries of every row in random order (SciPy's products depend on that order)"""
+    M = M.tocsr().copy()
+    for i in range(M.shape[0]):
+        lo, hi = M.indptr[i], M.indptr[i + 1]
+        p = rng.permutation(hi - lo)
+        M.indices[lo:hi] = M.indices[lo:hi][p]
+        M.data[lo:hi] = M.data[lo:hi][p]
+    M.has_sorted_indices = False
+    return M
+
+
+def _sorted(M):
+    M = M.tocsr().copy()
+    M.sort_indices()
+    return M
+
+
+def _same(C, ref):
+    """the very arrays SciPy produced: same stored order, same pattern, same bits"""
+    assert C.shape == ref.shape and C.nnz == ref.nnz and C.format == ref.format
+    assert np.array_equal(C.indptr, ref.indptr) and np.array_equal(C.indices, ref.indices)
+    assert np.array_equal(np.ravel(C.data), np.ravel(ref.data))
+
+
+def test_matmat_bit_exact_against_scipy():
+    from pyamg_amd.aggregation import DeviceCSR
+    rng = np.random.default_rng(5)
+    for (m, k, n, da, db) in ((300, 200, 250, 0.05, 0.05), (1, 1, 1, 1.0, 1.0), (50, 70, 3, 0.3, 0.5), (2000, 2000, 2000, 0.004, 0.004)):
+        A = _shuffle_rows(sp.random_array((m, k), density=da, random_state=rng, format="csr"), rng)
+        B = sp.random_array((k, n), density=db, random_state=rng, format="csr")
+        Ad, Bd = DeviceCSR.from_scipy(A), DeviceCSR.from_scipy(B)
+        C = (Ad @ Bd).to_scipy()
+        _same(C, A @ B)
+    # empty rows / empty operands
+    Z = sp.csr_array((40, 40))
+    _same((DeviceCSR.from_scipy(Z) @ DeviceCSR.from_scipy(Z)).to_scipy(), Z @ Z)
+    E = sp.csr_array(np.eye(40))
+    E = sp.csr_array((E.data[:20], E.indices[:20], np.r_[E.indptr[:21], [20] * 20]), shape=(40, 40))
+    _same((DeviceCSR.from_scipy(E) @ DeviceCSR.from_scipy(E)).to_scipy(), E @ E)
+
+
+def test_matmat_drops_exact_zeros_like_scipy():
+    from pyamg_amd.aggregation import DeviceCSR
+    A = sp.csr_array(np.array([[1.0, -1.0, 0.0], [2.0, 0.0, 1.0], [0.0, 0.0, 0.0]]))
+    B = sp.csr_array(np.array([[3.0, 1.0], [3.0, 0.0], [-6.0, 5.0]]))
+    ref = A @ B
+    C = (DeviceCSR.from_scipy(A) @ DeviceCSR.from_scipy(B)).to_scipy()
+    assert ref.nnz == 2
+    _same(C, ref)
+
+
+def test_matmat_long_rows():
+    """rows with more than 4096 products (every row of a coarse Galerkin product) take the dense-accumulator path:
+    windows of 2048 output columns, batches in sequence order, SciPy's emission order restored per finished row"""
+    from pyamg_amd.aggregation import DeviceCSR
+    rng = np.random.default_rng(6)
+    m, k, n = 64, 3000, 5000
+    A = sp.random_array((m, k), density=0.002, random_state=rng, format="lil")
+    A[3, :] = rng.standard_normal(k)                        # 3000 entries x ~10 each = 30 000 products
+    A[40, ::2] = rng.standard_normal(k // 2)
+    A = _shuffle_rows(A.tocsr(), rng)
+    B = sp.random_array((k, n), density=0.002, random_state=rng, format="csr")
+    B.sort_indices()
+    C = (DeviceCSR.from_scipy(A) @ DeviceCSR.from_scipy(B)).to_scipy()
+    _same(C, A @ B)
+    Bu = _shuffle_rows(B, rng)                              # unsorted right operand
+    _same((DeviceCSR.from_scipy(A) @ DeviceCSR.from_scipy(Bu)).to_scipy(), A @ Bu)
+    # every row long, few distinct output columns (the shape of (R A) P on a coarse level), exact cancellations
+    m, k, n = 40, 900, 300
+    A2 = _shuffle_rows(sp.random_array((m, k), density=0.6, random_state=rng, format="csr"), rng)
+    B2 = sp.random_array((k, n), density=0.05, random_state=rng, format="csr")
+    B2.data = np.sign(B2.data - 0.5)                        # +-1: sums cancel exactly now and then
+    A2.data = np.round(A2.data * 4.0)
+    A2.eliminate_zeros()
+    ref = A2 @ B2
+    assert np.diff(ref.indptr).max() <= n and (A2 @ abs(B2)).nnz > ref.nnz
+    _same((DeviceCSR.from_scipy(A2) @ DeviceCSR.from_scipy(B2)).to_scipy(), ref)
+
+
+def test_subtract_bit_exact_against_scipy():
+    from pyamg_amd.aggregation import DeviceCSR
+    rng = np.random.default_rng(7)
+    A = sp.random_array((400, 300), density=0.05, random_state=rng, format="csr")
+    B = sp.random_array((400, 300), density=0.05, random_state=rng, format="csr")
+    B = (B + 0.5 * A).tocsr()                               # shared pattern + own entries
+    B.data[::7] = 0.0                                       # explicit zeros in an operand
+    A.sort_indices(); B.sort_indices()
+    C = (DeviceCSR.from_scipy(A) - DeviceCSR.from_scipy(B)).to_scipy()
+    _same(C, A - B)
+    D = (DeviceCSR.from_scipy(A) - DeviceCSR.from_scipy(A.copy())).to_scipy()     # everything cancels: empty result
+    assert D.nnz == 0 and D.shape == A.shape
+    # an operand with unsorted rows: SciPy switches to its general algorithm (another emission order)
+    Bu = _shuffle_rows(B, rng)
+    _same((DeviceCSR.from_scipy(A) - DeviceCSR.from_scipy(Bu)).to_scipy(), A - Bu)
+    Au = _shuffle_rows(A, rng)
+    _same((DeviceCSR.from_scipy(Au) - DeviceCSR.from_scipy(B)).to_scipy(), Au - B)
+
+
+def test_galerkin_product_matches_scipy_expression():
+    from pyamg_amd.aggregation import galerkin_product
+    rng = np.random.default_rng(8)
+    n, nc = 900, 120
+    A = sp.random_array((n, n), density=0.01, random_state=rng, format="csr")
+    A = (A + A.T + 4.0 * sp.eye_array(n)).tocsr()
+    P = sp.random_array((n, nc), density=0.03, random_state=rng, format="csr")
+    R = P.T.tocsr()
+    _same(galerkin_product(R, A, P), R @ A @ P)
+    # the formats of an SA hierarchy: BSR(1,1) restriction / prolongation, CSR operator -> BSR(1,1) coarse operator
+    Pb, Rb = sp.bsr_array(P, blocksize=(1, 1)), sp.bsr_array(R, blocksize=(1, 1))
+    Ac = galerkin_product(Rb, A, Pb)
+    ref = Rb @ A @ Pb
+    assert Ac.format == ref.format == "bsr" and tuple(Ac.blocksize) == tuple(ref.blocksize) == (1, 1)
+    _same(Ac, ref)
+    # true blocks (elasticity-like): 2x2 fine blocks, 2x3 prolongation blocks
+    nb, ncb = 150, 20
+    Ab = sp.random_array((nb, nb), density=0.05, random_state=rng, format="csr")
+    Ab = sp.kron(Ab + Ab.T + 4.0 * sp.eye_array(nb), np.array([[2.0, 0.5], [0.5, 3.0]]), format="bsr")
+    Ab = sp.bsr_array(Ab, blocksize=(2, 2))
+    Pk = sp.bsr_array(sp.kron(sp.random_array((nb, ncb), density=0.1, random_state=rng, format="csr"),
+                              rng.standard_normal((2, 3)), format="bsr"), blocksize=(2, 3))
+    Rk = sp.bsr_array(Pk.T.tocsr(), blocksize=(3, 2))
+    Acb = galerkin_product(Rk, Ab, Pk)
+    refb = Rk @ Ab @ Pk
+    assert Acb.format == "bsr" and tuple(Acb.blocksize) == (3, 3)
+    _same(Acb, refb)                                        # block order and the zeros inside blocks included
+    with pytest.raises(NotImplementedError):
+        galerkin_product(R, sp.bsr_array(A, blocksize=(2, 2)), P)
+
+
+def _reference():
+    import oracle.refimport as ri
+    if not ri.available():
+        pytest.skip("oracle/_ref not present on this box")
+    import pyamg
+    return pyamg
+
+
+def test_spectral_radius_against_the_reference():
+    pyamg = _reference()
+    from pyamg.util.linalg import approximate_spectral_radius as ref_rho
+    from pyamg_amd.aggregation import approximate_spectral_radius
+    cases = []
+    A = pyamg.gallery.poisson((60, 60), format="csr")
+    cases.append(A)
+    cases.append(pyamg.gallery.poisson((20, 20, 20), format="csr"))
+    # D^-1 A scaled copy as the prolongation smoother forms it, BSR(1,1) storage
+    D = A.diagonal()
+    cases.append(sp.bsr_array(sp.csr_array(A.multiply(1.0 / D[:, None])), blocksize=(1, 1)))
+    # non-symmetric with a complex dominant pair: the restart vector becomes complex (planes = 2 on the device)
+    rng = np.random.default_rng(3)
+    n = 400
+    K = sp.diags_array([np.ones(n - 1), -np.ones(n - 1)], offsets=[1, -1], format="csr") * 3.0
+    cases.append((K + sp.random_array((n, n), density=0.01, random_state=rng, format="csr") * 0.1 + 0.05 * sp.eye_array(n)).tocsr())
+    for k, M in enumerate(cases):
+        for kw in ({}, {"maxiter": 8, "restart": 2}, {"tol": 1e-6, "maxiter": 20, "restart": 8}):
+            M1, M2 = M.copy(), M.copy()
+            np.random.seed(17 + k)
+            r_ref = ref_rho(M1, **kw)
+            np.random.seed(17 + k)
+            r_dev = approximate_spectral_radius(M2, **kw)
+            assert abs(r_dev - r_ref) <= 1e-10 * abs(r_ref), (k, kw, r_dev, r_ref)
+            assert M2.rho == r_dev and approximate_spectral_radius(M2) == r_dev        # cached on the matrix
+    # the random stream is consumed exactly like the reference consumes it
+    np.random.seed(5); ref_rho(cases[0].copy()); a = np.random.rand()
+    np.random.seed(5); approximate_spectral_radius(cases[0].copy()); b = np.random.rand()
+    assert a == b
+    # return_vector / initial_guess
+    v0 = np.random.rand(cases[0].shape[0], 1)
+    r1, v1 = ref_rho(cases[0].copy(), initial_guess=v0.copy(), return_vector=True)
+    r2, v2 = approximate_spectral_radius(cases[0].copy(), initial_guess=v0.copy(), return_vector=True)
+    assert abs(r1 - r2) <= 1e-10 * r1 and v2.shape == v1.shape
+    assert np.linalg.norm(v2 - v1) <= 1e-8 * np.linalg.norm(v1)
+    # error behaviour
+    with pytest.raises(ValueError):
+        approximate_spectral_radius(sp.csr_array((3, 4)))
+    with pytest.raises(ValueError):
+        approximate_spectral_radius(cases[0].copy(), maxiter=0)
+
+
+def test_prolongation_smoothers_against_the_reference():
+    pyamg = _reference()
+    from pyamg.aggregation.smooth import jacobi_prolongation_smoother as ref_jac, richardson_prolongation_smoother as ref_rich
+    from pyamg.aggregation.aggregate import standard_aggregation
+    from pyamg.aggregation.tentative import fit_candidates
+    from pyamg.strength import symmetric_strength_of_connection
+    from pyamg_amd.aggregation import jacobi_prolongation_smoother, richardson_prolongation_smoother
+    for grid in ((50, 50), (16, 16, 16)):
+        A = pyamg.gallery.poisson(grid, format="csr")
+        Cs = symmetric_strength_of_connection(A)
+        AggOp, _ = standard_aggregation(Cs)
+        T, _ = fit_candidates(AggOp, np.ones((A.shape[0], 1)))
+        for kw in ({}, {"degree": 2}, {"weighting": "local"}, {"omega": 1.0, "weighting": "block"}):
+            np.random.seed(3)
+            Pr = ref_jac(A.copy(), T, Cs, np.ones((A.shape[0], 1)), **kw)
+            np.random.seed(3)
+            Pd = jacobi_prolongation_smoother(A.copy(), T, Cs, np.ones((A.shape[0], 1)), **kw)
+            assert Pd.format == Pr.format and tuple(Pd.blocksize) == tuple(Pr.blocksize)
+            assert np.array_equal(Pd.indptr, Pr.indptr) and np.array_equal(Pd.indices, Pr.indices)      # stored order too
+            assert np.max(np.abs(np.ravel(Pd.data) - np.ravel(Pr.data))) <= 1e-13 * np.max(np.abs(Pr.data))
+        np.random.seed(4)
+        Pr = ref_rich(A.copy(), T)
+        np.random.seed(4)
+        Pd = richardson_prolongation_smoother(A.copy(), T)
+        assert np.array_equal(Pd.indices, Pr.indices)
+        assert np.max(np.abs(np.ravel(Pd.data) - np.ravel(Pr.data))) <= 1e-13 * np.max(np.abs(Pr.data))
+    with pytest.raises(NotImplementedError):
+        jacobi_prolongation_smoother(A, T, Cs, np.ones((A.shape[0], 1)), filter_entries=True)
+
+
+def test_device_setup_inside_the_reference_solver():
+    """smoothed_aggregation_solver with the setup pieces patched in: same level sizes, operators within 1e-12, and the
+    device cycle on the resulting hierarchy converges like the reference's own."""
+    pyamg = _reference()
+    from pyamg_amd import DeviceMultilevelSolver
+    from pyamg_amd.aggregation import device_setup, galerkin_product
+    A = pyamg.gallery.poisson((40, 40, 40), format="csr")
+    np.random.seed(9)
+    ml_ref = pyamg.smoothed_aggregation_solver(A.copy(), max_coarse=10)
+    before = pyamg.aggregation.aggregation.jacobi_prolongation_smoother
+    np.random.seed(9)
+    with device_setup(pyamg):
+        assert pyamg.aggregation.aggregation.jacobi_prolongation_smoother is not before
+        ml_dev = pyamg.smoothed_aggregation_solver(A.copy(), max_coarse=10)
+    assert pyamg.aggregation.aggregation.jacobi_prolongation_smoother is before
+    assert len(ml_dev.levels) == len(ml_ref.levels)
+    for k, (Ld, Lr) in enumerate(zip(ml_dev.levels, ml_ref.levels)):
+        assert Ld.A.shape == Lr.A.shape and Ld.A.nnz == Lr.A.nnz
+        assert np.array_equal(Ld.A.indptr, Lr.A.indptr) and np.array_equal(Ld.A.indices, Lr.A.indices)      # stored order too
+        d = abs(sp.csr_array(Ld.A) - sp.csr_array(Lr.A))
+        # the spectral radius' last bits travel down: 1e-14 on level 1, looser on the tiny coarse levels
+        assert d.max() <= (1e-14 if k <= 1 else 1e-10) * abs(Lr.A).max(), (k, d.max())
+    # the Galerkin product of the reference's own operators, level by level
+    for Lr, Ln in zip(ml_ref.levels[:-1], ml_ref.levels[1:]):
+        _same(galerkin_product(Lr.R, Lr.A, Lr.P), Lr.R @ Lr.A @ Lr.P)
+    b = np.random.rand(A.shape[0])
+    r_ref, r_dev = [], []
+    ml_ref.solve(b, tol=1e-10, residuals=r_ref)
+    DeviceMultilevelSolver(ml_dev).solve(b, tol=1e-10, residuals=r_dev)
+    assert len(r_ref) == len(r_dev)
+    assert np.max(np.abs(np.array(r_dev) - np.array(r_ref))) <= 1e-8 * r_ref[0]

@@ -18,14 +18,14 @@ extern "C" {
 // out: [0] makespan us, [1] steps, [2] levels, [3] critical-path crossings, [4] sum of step costs on the busiest tile,
 //      [5] tiles, [6] global early entries, [7] local early entries, [8] ideal = levels * mean step cost
 int tile_sim(int n, const int *Ap, const int *Aj, int row_start, int row_stop, int row_step, int G, int W, int cap, int max_rows,
-             double c0, double c1, double c2, double hop, int mode, double *out)
+             double c0, double c1, double c2, double hop, int mode, double *out, const int *row_tile)
 {
     std::vector<int> vis, lvl;
     int m = 0, nl = 0;
     if (sweep_levels(n, Ap, Aj, row_start, row_stop, row_step, vis, lvl, m, nl)) return 1;
     if (G <= 0) G = std::max(1, (int)((long)m / std::max(1L, 7L * nl)));
     TilePlan P;
-    if (build_tile_plan_from(n, Ap, Aj, row_start, row_step, m, nl, vis, lvl, G, W, cap, max_rows, P, mode)) return 2;
+    if (build_tile_plan_from(n, Ap, Aj, row_start, row_step, m, nl, vis, lvl, G, W, cap, max_rows, P, mode, row_tile)) return 2;
     const int ns = (int)P.steps.size();
     // stored row -> step
     std::vector<int> step_of((size_t)m, 0), tile_of_step((size_t)ns, 0);

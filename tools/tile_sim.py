@@ -55,6 +55,6 @@ for li in a.levels:
             nl_guess = 0
             t = time.time()
             rc = lib.tile_sim(n, Ap.ctypes.data_as(ctypes.c_void_p), Aj.ctypes.data_as(ctypes.c_void_p), start, stop, step, G if G > 0 else -1, a.W, a.cap, a.rows,
-                              ctypes.c_double(a.c0), ctypes.c_double(a.c1), ctypes.c_double(a.c2), ctypes.c_double(a.hop), mode, out.ctypes.data_as(ctypes.c_void_p))
+                              ctypes.c_double(a.c0), ctypes.c_double(a.c1), ctypes.c_double(a.c2), ctypes.c_double(a.hop), mode, out.ctypes.data_as(ctypes.c_void_p), None)
             print(f"L{li} n={n} nnz={Ap[-1]} mode={mode} G={int(out[5])} rc={rc}: span {out[0]/1000:.3f} ms  steps {int(out[1])} levels {int(out[2])} "
                   f"crit.crossings {int(out[3])} busiest tile {out[4]/1000:.3f} ms ideal(levels*c) {out[8]/1000:.3f} ms  glob {int(out[6])} loc {int(out[7])}  [{time.time()-t:.1f}s]", flush=True)
