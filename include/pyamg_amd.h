@@ -458,6 +458,10 @@ int pamg_csr_info(pamg_csr_t A, int64_t info[4]);            /* rows, columns, s
 int pamg_csr_download(pamg_csr_t A, int32_t *Ap, int32_t *Aj, double *Ax);   /* HOST arrays */
 int pamg_csr_matmat(pamg_csr_t A, pamg_csr_t B, int col_block, int keep_zeros, pamg_csr_t *C);
 int pamg_csr_subtract(pamg_csr_t A, pamg_csr_t B, pamg_csr_t *C);
+/* strength.py:248-348 for a CSR operator: amg_core::symmetric_strength_of_connection (smoothed_aggregation.h:56-110:
+ * |a_ij|^2 >= theta^2 |a_ii| |a_jj|, the diagonal always kept, stored order kept), then magnitudes, every row scaled by
+ * the reciprocal of its largest entry */
+int pamg_csr_strength_symmetric(pamg_csr_t A, double theta, pamg_csr_t *S);
 int pamg_csr_scale(pamg_csr_t A, double alpha);             /* a_ij <- a_ij * alpha, in place (owning matrices only) */
 /* util/utils.py scale_rows (a_ij <- a_ij * d_i, d: HOST, one per row) and `alpha * A` (a_ij <- a_ij * alpha)
  * on a resident scalar fp64 operator, in place.  PAMG_E_STATE once a sweep schedule or a solver holds it. */

@@ -29,8 +29,8 @@ from scipy.linalg import eig
 from . import _capi as capi
 from .hierarchy import sparse_op
 
-__all__ = ["DeviceCSR", "approximate_spectral_radius", "jacobi_prolongation_smoother",
-           "richardson_prolongation_smoother", "galerkin_product", "device_setup"]
+__all__ = ["DeviceCSR", "symmetric_strength_of_connection", "approximate_spectral_radius", "jacobi_prolongation_smoother",
+           "richardson_prolongation_smoother", "galerkin_product", "device_setup", "device_products"]
 
 
 def _i32(a):
@@ -358,6 +358,44 @@ def richardson_prolongation_smoother(S, T, omega=4.0 / 3.0, degree=1):
         Sd.free()
 
 
+# --------------------------------------------------------------------------- strength of connection
+def symmetric_strength_of_connection(A, theta=0):
+    """pyamg.strength.symmetric_strength_of_connection (strength.py:248-348): the strong connections
+    ``|a_ij| >= theta sqrt(|a_ii| |a_jj|)`` in A's stored order, as magnitudes scaled by each row's largest.  CSR
+    operators go through ``pamg_csr_strength_symmetric``; a BSR operator is reduced to its block pattern / block
+    Frobenius norms on the host first, as the reference does."""
+    if theta < 0:
+        raise ValueError("expected a positive theta")
+    if sp.issparse(A) and A.format == "bsr":
+        M, N = A.shape
+        R, Cb = A.blocksize
+        if R != Cb:
+            raise ValueError("matrix must have square blocks")
+        if theta == 0:
+            # every block is a strong connection; |1| scaled by the row maximum 1 stays 1
+            return sp.csr_array((np.ones(len(A.indices), dtype=A.dtype), A.indices.copy(), A.indptr.copy()),
+                                shape=(M // R, N // Cb))
+        norms = np.sqrt((np.conjugate(A.data) * A.data).reshape(-1, R * Cb).sum(axis=1))
+        return symmetric_strength_of_connection(sp.csr_array((norms, A.indices, A.indptr), shape=(M // R, N // Cb)), theta)
+    if not (sp.issparse(A) and A.format == "csr"):
+        raise TypeError("expected CSR or BSR sparse format")
+    if A.dtype != np.float64:
+        raise NotImplementedError(f"symmetric_strength_of_connection on the device is float64 only (got {A.dtype})")
+    if A.shape[0] != A.shape[1]:
+        raise NotImplementedError("symmetric_strength_of_connection on the device takes square operators")
+    Ad = DeviceCSR.from_scipy(A)
+    try:
+        h = C.c_void_p()
+        capi.check(capi.lib().pamg_csr_strength_symmetric(Ad.handle, float(theta), C.byref(h)), "pamg_csr_strength_symmetric")
+        S = DeviceCSR(h)
+        try:
+            return S.to_scipy()
+        finally:
+            S.free()
+    finally:
+        Ad.free()
+
+
 # --------------------------------------------------------------------------- Galerkin product
 def _block(M):
     return tuple(int(v) for v in M.blocksize) if M.format == "bsr" else (1, 1)
@@ -389,9 +427,76 @@ def galerkin_product(R, A, P):
     return out
 
 
+# --------------------------------------------------------------------------- SciPy's sparse @ sparse
+def _device_product(self, other):
+    """``self @ other`` for two float64 CSR operands, or a BSR left operand with a right operand SciPy would not have to
+    re-block -- the array SciPy's ``_matmul_sparse`` returns, computed on the device.  NotImplementedError otherwise."""
+    if not (sp.issparse(other) and self.ndim == 2 and other.ndim == 2 and self.dtype == np.float64 and other.dtype == np.float64):
+        raise NotImplementedError
+    if min(self.shape) == 0 or min(other.shape) == 0 or self.nnz == 0 or other.nnz == 0:
+        raise NotImplementedError
+    if self.format == "csr":
+        if other.format != "csr":
+            raise NotImplementedError
+        rb = cb = 1
+    elif self.format == "bsr":
+        rb, n = (int(v) for v in self.blocksize)
+        if other.format == "bsr":
+            if int(other.blocksize[0]) != n:
+                raise NotImplementedError
+            cb = int(other.blocksize[1])
+        elif other.format == "csr" and n == 1:
+            cb = 1
+        else:
+            raise NotImplementedError
+    else:
+        raise NotImplementedError
+    Ad, Bd = DeviceCSR.from_scipy(self), DeviceCSR.from_scipy(other)
+    try:
+        Cd = Ad.matmat(Bd, col_block=cb, keep_zeros=(rb, cb) != (1, 1))
+        try:
+            M = Cd.to_scipy(blocksize=(rb, cb) if self.format == "bsr" else None)
+        finally:
+            Cd.free()
+    finally:
+        Ad.free()
+        Bd.free()
+    if self.format == "bsr":
+        return self._bsr_container((M.data, M.indices, M.indptr), shape=M.shape)
+    return self.__class__((M.data, M.indices, M.indptr), shape=M.shape)
+
+
+@contextlib.contextmanager
+def device_products():
+    """While the block runs, ``A @ B`` of two float64 CSR arrays (or BSR @ BSR/CSR without re-blocking) is computed by
+    ``pamg_csr_matmat`` -- SciPy's own result, array for array -- through a wrapper around the classes' private
+    ``_matmul_sparse`` hook; every other combination takes SciPy's code as before.  This is how the inline
+    ``R @ A @ P`` of the reference's setup (aggregation.py:425) reaches the device without editing the reference."""
+    saved = []
+    for cls in (sp.csr_array, sp.csr_matrix, sp.bsr_array, sp.bsr_matrix):
+        orig = cls._matmul_sparse
+        own = cls.__dict__.get("_matmul_sparse")
+
+        def wrapper(self, other, _orig=orig):
+            try:
+                return _device_product(self, other)
+            except NotImplementedError:
+                return _orig(self, other)
+        saved.append((cls, own))
+        cls._matmul_sparse = wrapper
+    try:
+        yield
+    finally:
+        for cls, own in saved:
+            if own is None:
+                del cls._matmul_sparse
+            else:
+                cls._matmul_sparse = own
+
+
 # --------------------------------------------------------------------------- patching a reference package
 @contextlib.contextmanager
-def device_setup(pyamg, prolongation=True):
+def device_setup(pyamg, prolongation=True, products=True):
     """Run the setup pieces above inside a reference package the CALLER imported::
 
         with pyamg_amd.aggregation.device_setup(pyamg):
@@ -399,13 +504,16 @@ def device_setup(pyamg, prolongation=True):
 
     Patched while the block runs: the prolongation smoothers seen by ``pyamg.aggregation.aggregation`` and every
     by-name import of ``approximate_spectral_radius`` (prolongation smoothing, the rho(D^-1 A) of the Jacobi /
-    Chebyshev smoother setup).  The Galerkin product is an inline expression in the reference (aggregation.py:425);
-    INTEGRATION.md shows the one-line change that routes it to ``galerkin_product``.  ``prolongation=False`` leaves the
+    Chebyshev smoother setup).  The Galerkin product is an inline expression in the reference (aggregation.py:425):
+    ``products=True`` runs the block under ``device_products()`` so its two sparse products reach the device too
+    (INTEGRATION.md shows the one-line change that routes it to ``galerkin_product`` instead).  ``prolongation=False`` leaves the
     prolongation smoothers alone (block operators: they are not on the device path) and patches the spectral radius only."""
     import importlib
     targets = []
     for mod, name, fn in (("aggregation.aggregation", "jacobi_prolongation_smoother", jacobi_prolongation_smoother),
                           ("aggregation.aggregation", "richardson_prolongation_smoother", richardson_prolongation_smoother),
+                          ("aggregation.aggregation", "symmetric_strength_of_connection", symmetric_strength_of_connection),
+                          ("strength", "symmetric_strength_of_connection", symmetric_strength_of_connection),
                           ("aggregation.smooth", "approximate_spectral_radius", approximate_spectral_radius),
                           ("relaxation.smoothing", "approximate_spectral_radius", approximate_spectral_radius),
                           ("relaxation.chebyshev", "approximate_spectral_radius", approximate_spectral_radius),
@@ -420,7 +528,8 @@ def device_setup(pyamg, prolongation=True):
             targets.append((m, name, getattr(m, name)))
             setattr(m, name, fn)
     try:
-        yield
+        with (device_products() if products else contextlib.nullcontext()):
+            yield
     finally:
         for m, name, old in targets:
             setattr(m, name, old)

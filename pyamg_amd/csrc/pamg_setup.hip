@@ -520,6 +520,41 @@ __global__ __launch_bounds__(BLK) void canonical_kernel(int m, const int *Ap, co
     }
 }
 
+// ---- amg_core::symmetric_strength_of_connection (smoothed_aggregation.h:56-110) followed by what strength.py:343-348
+// does to its result: magnitudes, every row scaled by the reciprocal of its largest entry
+__global__ __launch_bounds__(BLK) void strength_diag_kernel(int m, const int *Ap, const int *Aj, const double *Ax, double *diag)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < m; i += gridDim.x * BLK) {
+        double d = 0.0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) if (Aj[p] == i) d += Ax[p];     // duplicates are summed
+        diag[i] = fabs(d);
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(BLK) void strength_kernel(int m, double theta, const int *Ap, const int *Aj, const double *Ax,
+                                                       const double *diag, int *cnt, const int *Sp, int *Sj, double *Sx)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < m; i += gridDim.x * BLK) {
+        const double eps = theta * theta * diag[i];
+        int w = FILL ? Sp[i] : 0;
+        double big = 2.2250738585072014e-308;                 // maximum_row_value starts from numeric_limits<F>::min() (ruge_stuben.h:238)
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            const double a = Ax[p];
+            if (j == i || a * a >= eps * diag[j]) {
+                if (FILL) { Sj[w] = j; Sx[w] = fabs(a); big = big < fabs(a) ? fabs(a) : big; }
+                ++w;
+            }
+        }
+        if (!FILL) cnt[i] = w;
+        else if (big != 0.0) {
+            const double r = 1.0 / big;
+            for (int q = Sp[i]; q < w; ++q) Sx[q] = Sx[q] * r;
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLK) void scale_rows_kernel(int m, const int *Ap, double *Ax, double *diag, const double *d)
 {
     for (int i = blockIdx.x * BLK + threadIdx.x; i < m; i += gridDim.x * BLK) {
@@ -977,6 +1012,39 @@ int pamg_csr_scale(pamg_csr_t A, double alpha)
 }
 
 int pamg_csr_subtract(pamg_csr_t A, pamg_csr_t B, pamg_csr_t *C) { return subtract(A, B, C); }
+
+int pamg_csr_strength_symmetric(pamg_csr_t A, double theta, pamg_csr_t *out)
+{
+    if (!A || !out || A->m != A->n || !(theta >= 0.0)) return PAMG_E_ARG;
+    const int m = (int)A->m;
+    double *d_diag = nullptr;
+    int *d_cnt = nullptr;
+    pamg_csr_s *S = nullptr;
+    PAMG_HIP(hipMalloc((void **)&d_diag, sizeof(double) * ((size_t)m + 1)));
+    int st = (int)hipMalloc((void **)&d_cnt, sizeof(int) * ((size_t)m + 1));
+    std::vector<int> hp;
+    int64_t nnz = 0;
+    if (!st && m) {
+        hipLaunchKernelGGL(strength_diag_kernel, dim3(grid_for(m)), dim3(BLK), 0, 0, m, A->d_p, A->d_j, A->d_x, d_diag);
+        hipLaunchKernelGGL((strength_kernel<false>), dim3(grid_for(m)), dim3(BLK), 0, 0, m, theta, A->d_p, A->d_j, A->d_x, (const double *)d_diag,
+                           d_cnt, (const int *)nullptr, (int *)nullptr, (double *)nullptr);
+        st = (int)hipGetLastError();
+    }
+    if (!st) st = counts_to_ptr(m, d_cnt, hp, nnz);
+    if (!st) st = new_csr(m, A->n, nnz, &S);
+    if (!st) st = (int)hipMemcpy(S->d_p, hp.data(), sizeof(int) * ((size_t)m + 1), hipMemcpyHostToDevice);
+    if (!st && m) {
+        hipLaunchKernelGGL((strength_kernel<true>), dim3(grid_for(m)), dim3(BLK), 0, 0, m, theta, A->d_p, A->d_j, A->d_x, (const double *)d_diag,
+                           (int *)nullptr, (const int *)S->d_p, S->d_j, S->d_x);
+        st = (int)hipGetLastError();
+    }
+    if (!st) st = (int)hipDeviceSynchronize();
+    hipFree(d_diag); hipFree(d_cnt);
+    if (st) { if (S) pamg_csr_destroy(S); return st; }
+    S->h_p = hp;
+    *out = S;
+    return PAMG_OK;
+}
 
 int pamg_matrix_scale_rows(pamg_matrix_t A, const double *d)
 {

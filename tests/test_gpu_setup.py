@@ -222,6 +222,51 @@ def test_prolongation_smoothers_against_the_reference():
         jacobi_prolongation_smoother(A, T, Cs, np.ones((A.shape[0], 1)), filter_entries=True)
 
 
+def test_symmetric_strength_against_the_reference():
+    pyamg = _reference()
+    from pyamg.strength import symmetric_strength_of_connection as ref_soc
+    from pyamg_amd.aggregation import symmetric_strength_of_connection
+    rng = np.random.default_rng(12)
+    A = pyamg.gallery.poisson((30, 30, 30), format="csr")
+    B = sp.random_array((500, 500), density=0.02, random_state=rng, format="csr")
+    B = _shuffle_rows((B + B.T + sp.diags_array(rng.standard_normal(500))).tocsr(), rng)      # unsorted rows, signed diagonal
+    Z = sp.csr_array((B.data.copy(), B.indices.copy(), B.indptr.copy()), shape=B.shape)
+    Z.data[Z.indices == np.repeat(np.arange(500), np.diff(Z.indptr))] = 0.0                  # zero diagonals
+    for M in (A, B, Z, sp.csr_array((7, 7))):
+        for theta in (0, 0.0, 0.25, 0.9):
+            Sr, Sd = ref_soc(M.copy(), theta), symmetric_strength_of_connection(M.copy(), theta)
+            _same(Sd, Sr)
+    # BSR: block pattern (theta = 0) / block Frobenius norms
+    Ab = sp.bsr_array(sp.kron(B, np.array([[2.0, 0.5], [0.5, 3.0]])), blocksize=(2, 2))
+    for theta in (0, 0.3):
+        _same(symmetric_strength_of_connection(Ab, theta), ref_soc(Ab, theta))
+    with pytest.raises(ValueError):
+        symmetric_strength_of_connection(A, -1.0)
+    with pytest.raises(TypeError):
+        symmetric_strength_of_connection(A.tocsc())
+
+
+def test_device_products_hook_returns_scipys_arrays():
+    """sparse @ sparse inside device_products(): the same arrays as outside, other operand kinds untouched"""
+    from pyamg_amd.aggregation import device_products
+    rng = np.random.default_rng(13)
+    A = _shuffle_rows(sp.random_array((300, 300), density=0.03, random_state=rng, format="csr"), rng)
+    P = sp.random_array((300, 40), density=0.1, random_state=rng, format="csr")
+    Pb, Rb = sp.bsr_array(P, blocksize=(1, 1)), sp.bsr_array(P.T.tocsr(), blocksize=(1, 1))
+    x = rng.standard_normal(300)
+    ref = [A @ A, Rb @ A @ Pb, Rb @ sp.bsr_array(A, blocksize=(1, 1)), A @ P.tocsc(), A @ x, sp.csr_matrix(A) @ sp.csr_matrix(P)]
+    with device_products():
+        assert "_matmul_sparse" in sp.csr_array.__dict__
+        got = [A @ A, Rb @ A @ Pb, Rb @ sp.bsr_array(A, blocksize=(1, 1)), A @ P.tocsc(), A @ x, sp.csr_matrix(A) @ sp.csr_matrix(P)]
+    assert "_matmul_sparse" not in sp.csr_array.__dict__
+    for g, r in zip(got, ref):
+        if sp.issparse(r):
+            assert type(g) is type(r)
+            _same(g, r)
+        else:
+            assert np.array_equal(g, r)
+
+
 def test_device_setup_inside_the_reference_solver():
     """smoothed_aggregation_solver with the setup pieces patched in: same level sizes, operators within 1e-12, and the
     device cycle on the resulting hierarchy converges like the reference's own."""
