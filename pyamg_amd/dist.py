@@ -137,10 +137,54 @@ def _localize(op: SparseOp, r0: int, r1: int, c0: int, c1: int, halo_cols: np.nd
                     np.ascontiguousarray(indptr, dtype=np.int32), loc, np.ascontiguousarray(data), op.src_format)
 
 
-class ShardedHierarchy:
-    """Host-side partitioning of a HierarchySpec for one rank (every rank holds the full spec)."""
+def _halo_needs(spec: HierarchySpec, offs, ns: int, world: int):
+    """per level, per rank: sorted unique off-rank (block) columns of A_l (rows l), P_{l-1} (rows l-1), R_l (rows l+1)"""
+    out = []
+    for l in range(ns + 1):
+        off = offs[l]
+        needs = []
+        for d in range(world):
+            c0, c1 = int(off[d]), int(off[d + 1])
+            parts = []
+            if l < ns:
+                parts.append(_ext_cols(spec.levels[l].A, c0, c1, c0, c1))
+                ro = offs[l + 1]
+                parts.append(_ext_cols(spec.levels[l].R, int(ro[d]), int(ro[d + 1]), c0, c1))
+            if l > 0:
+                fo = offs[l - 1]
+                parts.append(_ext_cols(spec.levels[l - 1].P, int(fo[d]), int(fo[d + 1]), c0, c1))
+            needs.append(np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int32))
+        out.append(needs)
+    return out
 
-    def __init__(self, spec: HierarchySpec, rank: int, world: int, min_rows: int = 200_000):
+
+def _slim(sm):
+    """a smoother spec without its per-row arrays (those are sliced per rank separately)"""
+    import dataclasses
+    return None if sm is None else dataclasses.replace(sm, Dinv=None)
+
+
+class ShardedHierarchy:
+    """Host-side partitioning of a HierarchySpec: what ONE rank needs -- its row blocks of the sharded levels with
+    columns renumbered to [owned | halo], the exchange plans, its slices of the block-Jacobi inverses, the smoother
+    parameters, and the collapsed coarse hierarchy.  Built from the full spec either by every rank for itself, or by
+    rank 0 for everybody (``all_ranks`` + ``DistMultilevelSolver.from_rank0``): nothing here refers to the full spec once
+    ``detach()`` has been called, so the object can be pickled to its rank."""
+
+    @classmethod
+    def all_ranks(cls, spec: HierarchySpec, world: int, min_rows: int = 200_000):
+        """the parts of all ranks, one after another (the halo analysis is done once); each is detached from the spec"""
+        shared = {}
+        for d in range(world):
+            part = cls(spec, d, world, min_rows, _shared=shared)
+            part.detach()
+            yield part
+
+    def detach(self):
+        self.spec = None
+        return self
+
+    def __init__(self, spec: HierarchySpec, rank: int, world: int, min_rows: int = 200_000, _shared=None):
         if not shardable(spec):
             raise NotImplementedError("hierarchy is not shardable (order-exact Gauss-Seidel, or block shapes that do not "
                                       "line up across levels): run replicas instead")
@@ -160,20 +204,19 @@ class ShardedHierarchy:
         self.P: List[SparseOp] = []
         self.R: List[SparseOp] = []
         # halo of level l = union of off-rank columns of A_l (rows l), P_{l-1} (rows l-1), R_l (rows l+1)
+        if _shared is not None and "needs" in _shared:
+            all_needs = _shared["needs"]
+        else:
+            all_needs = _halo_needs(spec, offs, ns, world)
+            if _shared is not None:
+                _shared["needs"] = all_needs
+        self.smoothers = [(_slim(spec.levels[l].pre), _slim(spec.levels[l].post)) for l in range(ns)]
+        self.shape0 = tuple(spec.levels[0].A.shape)
+        self.dtype = spec.dtype
+        self.nc = int(spec.levels[ns].A.shape[0])
         for l in range(ns + 1):
             off = offs[l]
-            needs = []          # per rank d: sorted unique external columns of level l
-            for d in range(world):
-                c0, c1 = int(off[d]), int(off[d + 1])
-                parts = []
-                if l < ns:
-                    parts.append(_ext_cols(spec.levels[l].A, c0, c1, c0, c1))
-                    ro = offs[l + 1]
-                    parts.append(_ext_cols(spec.levels[l].R, int(ro[d]), int(ro[d + 1]), c0, c1))
-                if l > 0:
-                    fo = offs[l - 1]
-                    parts.append(_ext_cols(spec.levels[l - 1].P, int(fo[d]), int(fo[d + 1]), c0, c1))
-                needs.append(np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int32))
+            needs = all_needs[l]          # per rank d: sorted unique external columns of level l
             me = rank
             plan = LevelPlan(off=off, bs=bss[l], n_owned=int(off[me + 1] - off[me]), halo_cols=needs[me].astype(np.int64))
             owner = np.searchsorted(off, plan.halo_cols, side="right") - 1
@@ -299,15 +342,16 @@ class DistMultilevelSolver:
     each rank uses its slice and ``solve`` returns the global solution on every rank).
     """
 
-    def __init__(self, spec: HierarchySpec, ops=None, group=None, min_rows: int = 200_000):
+    def __init__(self, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000, sharded=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
+        self.sh = sharded if sharded is not None else ShardedHierarchy(spec, self.rank, self.world, min_rows)
+        if self.sh.rank != self.rank or self.sh.world != self.world:
+            raise ValueError("sharded part belongs to another rank / world size")
         self.ops = ops if ops is not None else DeviceOps(int(__import__("os").environ.get("LOCAL_RANK", self.rank)),
-                                                         spec.dtype)
-        self.spec = spec
-        self.sh = ShardedHierarchy(spec, self.rank, self.world, min_rows)
+                                                         self.sh.dtype)
         o = self.ops
         ns = self.sh.ns
         self.A = [o.matrix(m) for m in self.sh.A]
@@ -322,7 +366,7 @@ class DistMultilevelSolver:
         self.b = [o.vector(nl[l]) for l in range(ns + 1)]
         self.r = [o.vector(nl[l]) for l in range(ns)]
         self.h = [[o.vector(nl[l]), o.vector(nl[l])] if self._has_poly(l) else None for l in range(ns)]
-        nc = spec.levels[ns].A.shape[0]
+        nc = self.sh.nc
         self.bc_full = o.vector(nc)
         self.xc_full = o.vector(nc)
         cplan = self.sh.plans[ns]
@@ -330,11 +374,22 @@ class DistMultilevelSolver:
         fill = np.concatenate([np.arange(c0, c0 + cplan.n_owned, dtype=np.int64), cplan.halo_cols])     # blocks: owned | halo
         self.c_fill_idx = o.index((fill[:, None] * cplan.bs + np.arange(cplan.bs)).ravel().astype(np.int32))
         self.coarse = o.coarse_solver(self.sh.coarse_spec)
-        self.shape = tuple(spec.levels[0].A.shape)
+        self.shape = self.sh.shape0
+
+    @classmethod
+    def from_rank0(cls, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000):
+        """The hierarchy exists on rank 0 only (``spec`` is None elsewhere): rank 0 partitions it for everybody and
+        scatters the parts, so no other rank ever builds or holds the full hierarchy (a 512^3 SA hierarchy is 78 GB on the
+        host).  Collective over ``group``."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        parts = list(ShardedHierarchy.all_ranks(spec, world, min_rows)) if rank == 0 else None
+        mine = [None]
+        dist.scatter_object_list(mine, parts, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        return cls(None, ops=ops, group=group, min_rows=min_rows, sharded=mine[0])
 
     def _has_poly(self, l):
-        L = self.spec.levels[l]
-        return any(s is not None and s.kind == "polynomial" for s in (L.pre, L.post))
+        return any(s is not None and s.kind == "polynomial" for s in self.sh.smoothers[l])
 
     # ---- communication
     def _staged(self, t):
@@ -387,7 +442,7 @@ class DistMultilevelSolver:
         o, A = self.ops, self.A[l]
         n = self.sh.plans[l].n_owned_s
         if s.kind == "block_jacobi":
-            Dinv = self.Dinv[l]["pre" if s is self.spec.levels[l].pre else "post"]
+            Dinv = self.Dinv[l]["pre" if s is self.sh.smoothers[l][0] else "post"]
             for it in range(s.iterations):
                 if not (x_zero and it == 0):
                     self.exchange(l, self.x[l])
@@ -424,8 +479,8 @@ class DistMultilevelSolver:
     # ---- one V-cycle on the sharded levels (multilevel.py:584-662)
     def _cycle(self, l, x_zero, cycle="V"):
         o, sh = self.ops, self.sh
-        L = self.spec.levels[l]
-        self._smooth(l, L.pre, x_zero)
+        pre, post = self.sh.smoothers[l]
+        self._smooth(l, pre, x_zero)
         self.exchange(l, self.x[l])
         o.spmv(self.A[l], 2, self.x[l], self.r[l], b=self.b[l])          # r = b - A x
         self.exchange(l, self.r[l])
@@ -446,7 +501,7 @@ class DistMultilevelSolver:
             o.coarse_cycle(self.coarse, self.xc_full, self.bc_full, cycle)
             o.gather(cplan.n_local_s, self.c_fill_idx, self.xc_full, self.x[sh.ns])
             o.spmv(self.P[l], 1, self.x[sh.ns], self.x[l])               # x += P x_c
-        self._smooth(l, L.post, False)
+        self._smooth(l, post, False)
 
     def resid_norm(self):
         self.exchange(0, self.x[0])

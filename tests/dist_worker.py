@@ -114,12 +114,21 @@ def run(rank, world, port, name, backend, min_rows, out_dir):
     from pyamg_amd.hierarchy import load_spec
     from pyamg_amd.dist import DistMultilevelSolver
     spec, ex = load_spec(ROOT / "tests" / "golden" / f"hier_{name}.npz")
+    scatter = backend.endswith("+rank0")         # the hierarchy exists on rank 0 only, parts are scattered
+    backend = backend.split("+")[0]
     if backend == "device":
         from pyamg_amd.dist import DeviceOps
         ops = DeviceOps(0, spec.dtype)          # ranks share the box's one GPU; dist.py stages gloo traffic via host
     else:
         ops = OracleOps(spec.dtype)
-    sol = DistMultilevelSolver(spec, ops=ops, min_rows=min_rows)
+    if scatter:
+        dtype = spec.dtype
+        if rank != 0:
+            spec = None                          # nothing but rank 0 ever sees the full hierarchy
+        sol = DistMultilevelSolver.from_rank0(spec, ops=ops, min_rows=min_rows)
+        assert sol.sh.spec is None and sol.sh.dtype == dtype
+    else:
+        sol = DistMultilevelSolver(spec, ops=ops, min_rows=min_rows)
     k = int(ex["k"])
     res = []
     x = sol.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=k, residuals=res)

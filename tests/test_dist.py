@@ -86,6 +86,39 @@ def test_sharded_cycle_gloo_oracle(tmp_path, load_hier, world, name):
         assert np.max(np.abs(o["res"] - ex["res"])) <= 1e-12 * ex["res"][0]
 
 
+@pytest.mark.parametrize("name,world", [("sa2d_cheby", 3), ("el3d_blockjacobi", 2)])
+def test_hierarchy_built_on_rank0_and_scattered(tmp_path, load_hier, name, world):
+    """DistMultilevelSolver.from_rank0: only rank 0 holds the hierarchy, partitions it for everybody (one halo analysis)
+    and scatters the parts; same bits as when every rank partitions the full hierarchy itself"""
+    outs = _run(world, name, "oracle+rank0", 100, tmp_path)
+    spec, ex = load_hier(name)
+    for o in outs:
+        assert np.array_equal(o["x"], ex["x"])
+        assert np.max(np.abs(o["res"] - ex["res"])) <= 1e-12 * ex["res"][0]
+
+
+def test_all_ranks_parts_equal_per_rank_construction():
+    import pickle
+    from pyamg_amd.dist import ShardedHierarchy
+    from pyamg_amd.hierarchy import load_spec
+    from conftest import GOLDEN
+    spec, _ = load_spec(GOLDEN / "hier_sa2d_jacobi.npz")
+    world = 3
+    parts = list(ShardedHierarchy.all_ranks(spec, world, min_rows=100))
+    for r, part in enumerate(parts):
+        own = ShardedHierarchy(spec, r, world, min_rows=100)
+        assert part.spec is None and part.rank == r and part.ns == own.ns
+        part = pickle.loads(pickle.dumps(part))                      # what scatter_object_list does to it
+        for l in range(own.ns + 1):
+            a, b = part.plans[l], own.plans[l]
+            assert a.send == b.send and a.recv == b.recv and np.array_equal(a.halo_cols, b.halo_cols)
+            assert np.array_equal(a.send_idx, b.send_idx)
+        for l in range(own.ns):
+            for x, y in ((part.A[l], own.A[l]), (part.P[l], own.P[l]), (part.R[l], own.R[l])):
+                assert np.array_equal(x.indptr, y.indptr) and np.array_equal(x.indices, y.indices) and np.array_equal(x.data, y.data)
+            assert part.smoothers[l][0].kind == spec.levels[l].pre.kind and part.smoothers[l][0].Dinv is None
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_block_operators_gloo_oracle(tmp_path, load_hier, world):
     """3-D elasticity, BSR (3,3) -> (6,6) levels with (3,6) / (6,3) transfer blocks, block Jacobi: the hierarchy is cut
