@@ -145,6 +145,28 @@ int pamg_jacobi_indexed_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, i
                             const float *Ax, int Ax_size, float *x, int x_size,
                             const float *b, int b_size, const int32_t *indices, int indices_size,
                             const float *omega, int omega_size);
+/* amg_core::gauss_seidel_indexed, relaxation.h:736-745: the rows Id[row_start], Id[row_start + row_step], ... in that order,
+ * in place (a row may be listed more than once) */
+int pamg_gauss_seidel_indexed_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                                  const double *Ax, int Ax_size, double *x, int x_size,
+                                  const double *b, int b_size, const int32_t *Id, int Id_size,
+                                  int32_t row_start, int32_t row_stop, int32_t row_step);
+int pamg_gauss_seidel_indexed_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                                  const float *Ax, int Ax_size, float *x, int x_size,
+                                  const float *b, int b_size, const int32_t *Id, int Id_size,
+                                  int32_t row_start, int32_t row_stop, int32_t row_step);
+/* amg_core::block_jacobi_indexed, relaxation.h:1129-1138 (the kernel of cf_block_jacobi / fc_block_jacobi; Tx = inverse
+ * diagonal blocks, indices = block rows) */
+int pamg_block_jacobi_indexed_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                                  const double *Ax, int Ax_size, double *x, int x_size,
+                                  const double *b, int b_size, const double *Tx, int Tx_size,
+                                  const int32_t *indices, int indices_size,
+                                  const double *omega, int omega_size, int32_t blocksize);
+int pamg_block_jacobi_indexed_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                                  const float *Ax, int Ax_size, float *x, int x_size,
+                                  const float *b, int b_size, const float *Tx, int Tx_size,
+                                  const int32_t *indices, int indices_size,
+                                  const float *omega, int omega_size, int32_t blocksize);
 /* amg_core::gauss_seidel_ne relaxation.h:875-884 (Tx = 1/||row||^2), gauss_seidel_nr :939-948 (Ap/Aj/Ax = the CSC
  * arrays of A, z = running residual, Tx = 1/||column||^2; omega by value like the reference's F),
  * jacobi_ne :811-821 (Tx = the row-scaled residual "delta"; full row range only) */
@@ -309,6 +331,11 @@ int pamg_matrix_jacobi_step(pamg_matrix_t A, const void *x_in, const void *b, vo
  * blocks.  pamg_matrix_jacobi_step accepts such operators too (point Jacobi on BSR, relaxation.h:472-562). */
 int pamg_matrix_block_jacobi_step(pamg_matrix_t A, const void *Dinv, const void *x_in, const void *b, void *x_out,
                                   double omega, pamg_stream_t s);
+/* amg_core::block_jacobi_indexed (relaxation.h:1129-1199) on a resident square-block operator: one block-Jacobi step
+ * from the old x, taken over for the listed rows only.  idx: DEVICE, the SCALAR indices of the listed block rows
+ * (row * blocksize + k); work: DEVICE scratch of x's length. */
+int pamg_matrix_block_jacobi_indexed(pamg_matrix_t A, const void *Dinv, void *x, const void *b, const int32_t *idx,
+                                     int64_t nidx, double omega, void *work, pamg_stream_t s);
 /* gauss_seidel / sor as the reference's Python wrappers run them (relaxation.py:265-346,
  * 100-154, quirks included: 'symmetric' ignores omega, BSR flavour ignores omega). */
 int pamg_matrix_gauss_seidel(pamg_matrix_t A, void *x, const void *b, int sweep, double omega,
@@ -347,6 +374,8 @@ int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, v
 #define PAMG_SMOOTH_GS_NE       9   /* relaxation.gauss_seidel_ne (Kaczmarz)  relaxation.py:815-901  */
 #define PAMG_SMOOTH_GS_NR      10   /* relaxation.gauss_seidel_nr             relaxation.py:904-988  */
 #define PAMG_SMOOTH_JACOBI_NE  11   /* relaxation.jacobi_ne                   relaxation.py:741-812  */
+#define PAMG_SMOOTH_CF_BLOCK_JACOBI 12   /* relaxation.cf_block_jacobi  relaxation.py:1271-1340: C block rows, then F */
+#define PAMG_SMOOTH_FC_BLOCK_JACOBI 13   /* relaxation.fc_block_jacobi  relaxation.py:1342-1411: F block rows, then C */
 #define PAMG_CYCLE_V 0
 #define PAMG_CYCLE_W 1
 #define PAMG_CYCLE_F 2
@@ -367,6 +396,12 @@ int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, in
 int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind, int iterations,
                                 int f_iterations, int c_iterations, double omega, const int32_t *Fpts,
                                 int nF, const int32_t *Cpts, int nC);
+/* CF / FC block Jacobi on a level with square blocks of `blocksize` >= 2: amg_core::block_jacobi_indexed
+ * (relaxation.h:1129-1199) over the C then the F block rows (or F then C).  Dinv: HOST, the inverted diagonal blocks
+ * (block rows x blocksize x blocksize, copied); Fpts / Cpts: HOST lists of BLOCK rows (copied). */
+int pamg_solver_set_cf_block_smoother(pamg_solver_t S, int level, int which, int kind, int iterations,
+                                      int f_iterations, int c_iterations, double omega, const void *Dinv,
+                                      int blocksize, const int32_t *Fpts, int nF, const int32_t *Cpts, int nC);
 /* Normal-equation smoothers (f64/f32 CSR-like levels).  Dinv: HOST vector of the level's size -- 1/||row||^2
  * (GS_NE, JACOBI_NE) or 1/||column||^2 (GS_NR), computed by the caller exactly as the reference's
  * get_diagonal(A, norm_eq=..., inv=True) (util/utils.py:583-598).  At (borrowed handle, kept alive by the caller):

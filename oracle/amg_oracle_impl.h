@@ -110,6 +110,22 @@ void FN(jacobi)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REA
     }
 }
 
+/* Gauss-Seidel on a list of rows, in list order.  Follows amg_core gauss_seidel_indexed, relaxation.h:736-790. */
+void FN(gauss_seidel_indexed)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REAL *b, const int *Id,
+                              int row_start, int row_stop, int row_step)
+{
+    for (int q = row_start; q != row_stop; q += row_step) {
+        const int i = Id[q];
+        REAL rsum = 0, diag = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) diag = Ax[p];
+            else rsum += Ax[p] * x[j];
+        }
+        if (diag != (REAL)0) x[i] = (b[i] - rsum) / diag;
+    }
+}
+
 /* Weighted Jacobi on a list of rows.  Follows amg_core jacobi_indexed, relaxation.h:382-427:
  * temp = x (the whole vector), then every listed row is relaxed from temp; a zero / missing
  * diagonal leaves the row untouched (the reference also prints a warning). */
@@ -262,6 +278,31 @@ void FN(block_jacobi)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, con
     for (int i = row_start; i != row_stop; i += row_step)
         for (int k = 0; k < bs; ++k) temp[(long)i * bs + k] = x[(long)i * bs + k];
     for (int i = row_start; i != row_stop; i += row_step) {
+        for (int k = 0; k < bs; ++k) acc[k] = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) continue;
+            FN(blk_apply)(Ax + (long)p * bb, temp + (long)j * bs, v, bs);
+            for (int k = 0; k < bs; ++k) acc[k] += v[k];
+        }
+        for (int k = 0; k < bs; ++k) acc[k] = b[(long)i * bs + k] - acc[k];
+        FN(blk_apply)(Dinv + (long)i * bb, acc, v, bs);
+        for (int k = 0; k < bs; ++k)
+            x[(long)i * bs + k] = (one - omega) * temp[(long)i * bs + k] + omega * v[k];
+    }
+}
+
+/* Block Jacobi on a list of block rows.  Follows amg_core block_jacobi_indexed, relaxation.h:1129-1199: the whole x is
+ * snapshotted into temp, the listed block rows are updated from the snapshot. */
+void FN(block_jacobi_indexed)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, int n, const REAL *b,
+                              const REAL *Dinv, const int *indices, int nidx, REAL *temp, REAL omega, int bs)
+{
+    REAL acc[64], v[64];
+    const int bb = bs * bs;
+    const REAL one = 1;
+    for (int i = 0; i < n; ++i) temp[i] = x[i];
+    for (int q = 0; q < nidx; ++q) {
+        const int i = indices[q];
         for (int k = 0; k < bs; ++k) acc[k] = 0;
         for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
             const int j = Aj[p];

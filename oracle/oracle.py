@@ -106,6 +106,35 @@ def jacobi_indexed(Ap, Aj, Ax, x, b, indices, omega):
           _I(idx.size), _ptr(temp), ct(omega))
 
 
+def gauss_seidel_indexed(Ap, Aj, Ax, x, b, Id, row_start, row_stop, row_step):
+    """amg_core.gauss_seidel_indexed (relaxation.h:736-790)."""
+    idx = np.ascontiguousarray(Id, dtype=np.int32)
+    _call("gauss_seidel_indexed", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b), _ptr(idx),
+          _I(row_start), _I(row_stop), _I(row_step))
+
+
+def relax_gauss_seidel_indexed(A, x, b, indices, iterations=1, sweep="forward"):
+    """relaxation.py:662-731 (CSR)."""
+    m = len(indices)
+    if sweep == "symmetric":
+        for _ in range(iterations):
+            relax_gauss_seidel_indexed(A, x, b, indices, 1, "forward")
+            relax_gauss_seidel_indexed(A, x, b, indices, 1, "backward")
+        return
+    r = (0, m, 1) if sweep == "forward" else (m - 1, -1, -1)
+    for _ in range(iterations):
+        gauss_seidel_indexed(A.indptr, A.indices, A.data, x, b, indices, *r)
+
+
+def block_jacobi_indexed(Ap, Aj, Ax, x, b, Dinv, indices, omega, blocksize):
+    """amg_core.block_jacobi_indexed (relaxation.h:1129-1199)."""
+    _, ct = _sfx(Ax.dtype)
+    temp = np.empty_like(x)
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    _call("block_jacobi_indexed", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _I(x.size), _ptr(b), _ptr(Dinv),
+          _ptr(idx), _I(idx.size), _ptr(temp), ct(omega), _I(blocksize))
+
+
 def gauss_seidel_ne(Ap, Aj, Ax, x, b, row_start, row_stop, row_step, Dinv, omega):
     """amg_core.gauss_seidel_ne (relaxation.h:875-904)."""
     _, ct = _sfx(Ax.dtype)
@@ -281,6 +310,19 @@ def relax_cf_jacobi(A, x, b, Cpts, Fpts, iterations=1, f_iterations=1, c_iterati
                 jacobi_indexed(A.indptr, A.indices, A.data, x, b, pts, om)
 
 
+def relax_cf_block_jacobi(A, x, b, Cpts, Fpts, Dinv, blocksize, iterations=1, f_iterations=1, c_iterations=1, omega=1.0,
+                          f_first=False):
+    """relaxation.py:1271-1340 (cf_block_jacobi) and :1342-1411 (fc_block_jacobi, f_first=True)."""
+    A = _as_bsr(A, blocksize)
+    om = A.data.dtype.type(omega)
+    Dflat = np.ascontiguousarray(Dinv).reshape(-1)
+    plan = [(Fpts, f_iterations), (Cpts, c_iterations)] if f_first else [(Cpts, c_iterations), (Fpts, f_iterations)]
+    for _ in range(iterations):
+        for pts, sweeps in plan:
+            for _ in range(sweeps):
+                block_jacobi_indexed(A.indptr, A.indices, A.data, x, b, Dflat, pts, om, blocksize)
+
+
 def relax_gauss_seidel_ne(A, x, b, Dinv, iterations=1, sweep="forward", omega=1.0):
     """relaxation.py:815-901 (Kaczmarz; A: CSR SparseOp, Dinv = 1 / squared row norms)."""
     if sweep == "symmetric":
@@ -342,6 +384,9 @@ def apply_smoother(s, A, x, b):
     elif s.kind in ("cf_jacobi", "fc_jacobi"):
         relax_cf_jacobi(A, x, b, s.Cpts, s.Fpts, s.iterations, s.f_iterations, s.c_iterations, s.omega,
                         f_first=(s.kind == "fc_jacobi"))
+    elif s.kind in ("cf_block_jacobi", "fc_block_jacobi"):
+        relax_cf_block_jacobi(A, x, b, s.Cpts, s.Fpts, s.Dinv, s.blocksize, s.iterations, s.f_iterations, s.c_iterations,
+                              s.omega, f_first=(s.kind == "fc_block_jacobi"))
     else:
         raise ValueError(f"oracle: unknown smoother kind {s.kind}")
 

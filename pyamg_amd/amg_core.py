@@ -14,7 +14,7 @@ import numpy as np
 from . import _capi as capi
 
 __all__ = ["csr_matvec", "bsr_matvec", "gauss_seidel", "sor_gauss_seidel", "bsr_gauss_seidel",
-           "jacobi", "bsr_jacobi", "block_jacobi", "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_ne",
+           "jacobi", "bsr_jacobi", "block_jacobi", "block_jacobi_indexed", "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_indexed", "gauss_seidel_ne",
            "gauss_seidel_nr", "jacobi_ne"]
 
 
@@ -140,6 +140,28 @@ def block_jacobi(Ap, Aj, Ax, x, b, Tx, temp, row_start, row_stop, row_step, omeg
                                                             capi.ptr(temp), temp.size, int(row_start),
                                                             int(row_stop), int(row_step), capi.ptr(omega),
                                                             omega.size, int(blocksize)), "block_jacobi")
+
+
+def gauss_seidel_indexed(Ap, Aj, Ax, x, b, Id, row_start, row_stop, row_step):
+    """amg_core.gauss_seidel_indexed (relaxation.h:736-790)."""
+    _idx(Ap, Aj)
+    if Id.dtype != np.int32:
+        raise TypeError("gauss_seidel_indexed(): incompatible function arguments (Id must be int32)")
+    s = _sfx(Ax, x, b)
+    capi.check(getattr(capi.lib(), f"pamg_gauss_seidel_indexed_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(Id), Id.size,
+                                                                    int(row_start), int(row_stop), int(row_step)),
+               "gauss_seidel_indexed")
+
+
+def block_jacobi_indexed(Ap, Aj, Ax, x, b, Tx, indices, omega, blocksize):
+    """amg_core.block_jacobi_indexed (relaxation.h:1129-1199)."""
+    _idx(Ap, Aj)
+    if indices.dtype != np.int32:
+        raise TypeError("block_jacobi_indexed(): incompatible function arguments (indices must be int32)")
+    s = _sfx(Ax, x, b, Tx, omega)
+    capi.check(getattr(capi.lib(), f"pamg_block_jacobi_indexed_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(Tx), Tx.size,
+                                                                    capi.ptr(indices), indices.size, capi.ptr(omega),
+                                                                    omega.size, int(blocksize)), "block_jacobi_indexed")
 
 
 def block_gauss_seidel(Ap, Aj, Ax, x, b, Tx, row_start, row_stop, row_step, blocksize):

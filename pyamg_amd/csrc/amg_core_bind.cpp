@@ -42,6 +42,8 @@ template <typename T> struct L1;
         static constexpr auto jacobi_ne = pamg_jacobi_ne_##S;                              \
         static constexpr auto block_jacobi = pamg_block_jacobi_##S;                        \
         static constexpr auto block_gauss_seidel = pamg_block_gauss_seidel_##S;            \
+        static constexpr auto block_jacobi_indexed = pamg_block_jacobi_indexed_##S;        \
+        static constexpr auto gauss_seidel_indexed = pamg_gauss_seidel_indexed_##S;        \
     };
 PAMG_L1(double, f64)
 PAMG_L1(float, f32)
@@ -104,6 +106,14 @@ void bind(py::module_ &m)
                              blocksize), "block_jacobi");
     }, nc("Ap"), nc("Aj"), nc("Ax"), nc("x"), nc("b"), nc("Tx"), nc("temp"), py::arg("row_start"), py::arg("row_stop"), py::arg("row_step"),
        nc("omega"), py::arg("blocksize"));
+    m.def("gauss_seidel_indexed", [](Idx &Ap, Idx &Aj, Vec<T> &Ax, Vec<T> &x, Vec<T> &b, Idx &Id, int row_start, int row_stop, int row_step) {
+        done(F::gauss_seidel_indexed(Ap.data(), len(Ap), Aj.data(), len(Aj), Ax.data(), len(Ax), x.mutable_data(), len(x), b.data(), len(b),
+                                     Id.data(), len(Id), row_start, row_stop, row_step), "gauss_seidel_indexed");
+    }, nc("Ap"), nc("Aj"), nc("Ax"), nc("x"), nc("b"), nc("Id"), py::arg("row_start"), py::arg("row_stop"), py::arg("row_step"));
+    m.def("block_jacobi_indexed", [](Idx &Ap, Idx &Aj, Vec<T> &Ax, Vec<T> &x, Vec<T> &b, Vec<T> &Tx, Idx &indices, Vec<T> &omega, int blocksize) {
+        done(F::block_jacobi_indexed(Ap.data(), len(Ap), Aj.data(), len(Aj), Ax.data(), len(Ax), x.mutable_data(), len(x), b.data(), len(b),
+                                     Tx.data(), len(Tx), indices.data(), len(indices), omega.data(), len(omega), blocksize), "block_jacobi_indexed");
+    }, nc("Ap"), nc("Aj"), nc("Ax"), nc("x"), nc("b"), nc("Tx"), nc("indices"), nc("omega"), py::arg("blocksize"));
     m.def("block_gauss_seidel", [](Idx &Ap, Idx &Aj, Vec<T> &Ax, Vec<T> &x, Vec<T> &b, Vec<T> &Tx, int row_start, int row_stop, int row_step,
                                    int blocksize) {
         done(F::block_gauss_seidel(Ap.data(), len(Ap), Aj.data(), len(Aj), Ax.data(), len(Ax), x.mutable_data(), len(x), b.data(), len(b),

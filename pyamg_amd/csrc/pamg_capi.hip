@@ -170,6 +170,73 @@ int l1_gs(int epi, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_siz
     return dx.get(x, sizeof(T) * (size_t)nb * bs);
 }
 
+// amg_core::gauss_seidel_indexed (relaxation.h:736-790): the rows Id[row_start], Id[row_start + row_step], ... relaxed in
+// place in that order.  Renumbering the unknowns so that the listed rows come first, in list order, turns this into a
+// plain forward sweep over rows 0..m-1 of the renumbered operator: the stored order inside every row is kept, so every
+// row sum has the reference's bits, and a listed column is "new" exactly when its row comes earlier in the list.  Rows
+// that are not listed are never relaxed: the renumbered operator keeps them empty.  A list that names a row twice is
+// cut into duplicate-free pieces, swept one after another.
+template <typename T>
+int l1_gs_indexed(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size, T *x, int x_size,
+                  const T *b, int b_size, const int32_t *Id, int Id_size, int row_start, int row_stop, int row_step)
+{
+    if (!x || !b || Id_size < 0 || (Id_size > 0 && !Id) || row_step == 0) return PAMG_E_ARG;
+    PAMG_TRY(check_csr(Ap, Ap_size, Aj_size, Ax_size, 1));
+    const int n = Ap_size - 1;
+    if (n > x_size || n > b_size) return PAMG_E_ARG;
+    const long span = (long)row_stop - row_start;
+    if (span % row_step != 0 || span / row_step < 0) return PAMG_E_ARG;
+    const long m_all = span / row_step;
+    if (m_all == 0) return PAMG_OK;
+    if (row_start < 0 || row_start >= Id_size || row_start + (m_all - 1) * row_step < 0 || row_start + (m_all - 1) * row_step >= Id_size)
+        return PAMG_E_ARG;
+    std::vector<int> list((size_t)m_all);
+    for (long t = 0; t < m_all; ++t) {
+        list[(size_t)t] = Id[row_start + t * row_step];
+        if (list[(size_t)t] < 0 || list[(size_t)t] >= n) return PAMG_E_ARG;
+    }
+    std::lock_guard<std::mutex> lock(l1_mu);
+    std::vector<int> stamp((size_t)n, -1), pos((size_t)n), inv((size_t)n), tp, tj;
+    std::vector<T> tx, xs((size_t)n), bs_((size_t)n);
+    size_t t0 = 0;
+    int piece = 0;
+    while (t0 < list.size()) {
+        size_t t1 = t0;
+        while (t1 < list.size() && stamp[(size_t)list[t1]] != piece) { stamp[(size_t)list[t1]] = piece; ++t1; }
+        const int m = (int)(t1 - t0);
+        // new number of every old row: listed rows 0..m-1 in list order, the others behind them
+        std::fill(pos.begin(), pos.end(), -1);
+        for (int t = 0; t < m; ++t) { pos[(size_t)list[t0 + t]] = t; inv[(size_t)t] = list[t0 + t]; }
+        int next = m;
+        for (int i = 0; i < n; ++i) if (pos[(size_t)i] < 0) { pos[(size_t)i] = next; inv[(size_t)next] = i; ++next; }
+        tp.assign((size_t)n + 1, 0);
+        for (int r = 0; r < m; ++r) tp[(size_t)r + 1] = tp[(size_t)r] + (Ap[inv[(size_t)r] + 1] - Ap[inv[(size_t)r]]);
+        for (int r = m; r < n; ++r) tp[(size_t)r + 1] = tp[(size_t)r];
+        tj.resize((size_t)tp[(size_t)m] + 1);
+        tx.resize((size_t)tp[(size_t)m] + 1);
+        for (int r = 0; r < m; ++r) {
+            const int i = inv[(size_t)r];
+            int w = tp[(size_t)r];
+            for (int p = Ap[i]; p < Ap[i + 1]; ++p, ++w) { tj[(size_t)w] = pos[(size_t)Aj[p]]; tx[(size_t)w] = Ax[p]; }
+        }
+        for (int r = 0; r < n; ++r) { xs[(size_t)r] = x[inv[(size_t)r]]; bs_[(size_t)r] = b[inv[(size_t)r]]; }
+        {
+            MatGuard g;
+            PAMG_TRY(l1_acquire(g, dt<T>(), PAMG_CSR, n, n, 1, 1, tp.data(), tj.data(), tx.data()));
+            DevBuf dx, db;
+            PAMG_TRY(dx.put(xs.data(), sizeof(T) * (size_t)n));
+            PAMG_TRY(db.put(bs_.data(), sizeof(T) * (size_t)n));
+            PAMG_TRY(gs_sweep(g.A, EPI_GS, dx.p, db.p, 1.0, 0, m, 1, nullptr));
+            PAMG_HIP(hipDeviceSynchronize());
+            PAMG_TRY(dx.get(xs.data(), sizeof(T) * (size_t)n));
+        }
+        for (int r = 0; r < m; ++r) x[inv[(size_t)r]] = xs[(size_t)r];
+        t0 = t1;
+        ++piece;
+    }
+    return PAMG_OK;
+}
+
 // jacobi / bsr_jacobi: the device sweep relaxes every row out of place; only the rows of the
 // (row_start,row_stop,row_step) slice are copied back, as in the reference.
 template <typename T>
@@ -345,6 +412,38 @@ int l1_block(bool gs, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_
     return dn.get(x, sizeof(T) * (size_t)n);
 }
 
+// amg_core::block_jacobi_indexed (relaxation.h:1129-1199): one block-Jacobi step from the old x, kept for the listed
+// block rows only
+template <typename T>
+int l1_block_jacobi_indexed(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size, T *x,
+                            int x_size, const T *b, int b_size, const T *Tx, int Tx_size, const int32_t *indices,
+                            int indices_size, const T *omega, int omega_size, int bs)
+{
+    if (bs < 1 || !x || !b || !Tx || !omega || omega_size < 1 || indices_size < 0 || (indices_size > 0 && !indices)) return PAMG_E_ARG;
+    if (bs < 2) return PAMG_E_UNSUPPORTED;     // 1x1 blocks: the reference's setup layer uses the point kernel (smoothing.py:731-734)
+    PAMG_TRY(check_csr(Ap, Ap_size, Aj_size, Ax_size, bs * bs));
+    const int nb = Ap_size - 1;
+    const int64_t n = (int64_t)nb * bs;
+    if (n > x_size || n > b_size || (int64_t)nb * bs * bs > Tx_size) return PAMG_E_ARG;
+    for (int k = 0; k < indices_size; ++k) if (indices[k] < 0 || indices[k] >= nb) return PAMG_E_ARG;
+    if (indices_size == 0) return PAMG_OK;
+    std::lock_guard<std::mutex> lock(l1_mu);
+    MatGuard g;
+    PAMG_TRY(l1_acquire(g, dt<T>(), PAMG_BSR, nb, nb, bs, bs, Ap, Aj, Ax));
+    std::vector<int> idx((size_t)indices_size * bs);
+    for (int k = 0; k < indices_size; ++k) for (int c = 0; c < bs; ++c) idx[(size_t)k * bs + c] = indices[k] * bs + c;
+    DevBuf dx, db, dd, dn, di;
+    PAMG_TRY(dx.put(x, sizeof(T) * (size_t)n));
+    PAMG_TRY(db.put(b, sizeof(T) * (size_t)n));
+    PAMG_TRY(dd.put(Tx, sizeof(T) * (size_t)nb * bs * bs));
+    PAMG_TRY(di.put(idx.data(), sizeof(int) * idx.size()));
+    PAMG_TRY(dn.alloc(sizeof(T) * (size_t)n));
+    PAMG_TRY(block_jacobi_step(g.A, BLK_JACOBI, dd.p, dx.p, dn.p, db.p, (double)omega[0], nullptr));
+    PAMG_TRY(vec_copy_indexed(dt<T>(), (int64_t)idx.size(), (const int *)di.p, dn.p, dx.p, nullptr));
+    PAMG_HIP(hipDeviceSynchronize());
+    return dx.get(x, sizeof(T) * (size_t)n);
+}
+
 }  // namespace
 
 extern "C" {
@@ -448,6 +547,11 @@ int pamg_event_elapsed_ms(pamg_event_t a, pamg_event_t b, float *ms) { return ms
                                 int32_t row_stop, int32_t row_step)                                             \
     { return l1_gs<T>(EPI_GS, Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, row_start, row_stop, \
                       row_step, 1.0, 1); }                                                                      \
+    int pamg_gauss_seidel_indexed_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, \
+                                        int Ax_size, T *x, int x_size, const T *b, int b_size, const int32_t *Id,\
+                                        int Id_size, int32_t row_start, int32_t row_stop, int32_t row_step)     \
+    { return l1_gs_indexed<T>(Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, Id, Id_size,         \
+                              row_start, row_stop, row_step); }                                                 \
     int pamg_sor_gauss_seidel_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,             \
                                     const T *Ax, int Ax_size, T *x, int x_size, const T *b, int b_size,         \
                                     int32_t row_start, int32_t row_stop, int32_t row_step, T omega)             \
@@ -486,6 +590,12 @@ int pamg_event_elapsed_ms(pamg_event_t a, pamg_event_t b, float *ms) { return ms
                                   const int32_t *indices, int indices_size, const T *omega, int omega_size)     \
     { return l1_jacobi_indexed<T>(Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, indices,         \
                                   indices_size, omega, omega_size); }                                           \
+    int pamg_block_jacobi_indexed_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, \
+                                        int Ax_size, T *x, int x_size, const T *b, int b_size, const T *Tx,      \
+                                        int Tx_size, const int32_t *indices, int indices_size, const T *omega,  \
+                                        int omega_size, int32_t blocksize)                                      \
+    { return l1_block_jacobi_indexed<T>(Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, Tx, Tx_size,\
+                                        indices, indices_size, omega, omega_size, blocksize); }                 \
     int pamg_bsr_jacobi_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax,      \
                               int Ax_size, T *x, int x_size, const T *b, int b_size, T *temp, int temp_size,    \
                               int32_t row_start, int32_t row_stop, int32_t row_step, int32_t blocksize,         \

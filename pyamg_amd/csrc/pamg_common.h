@@ -197,6 +197,7 @@ int kaczmarz_sweep(pamg_matrix_s *L, bool nr, void *v, const void *b, const void
 int ensure_line_schedule(pamg_matrix_s *L, int start, int stop, int step);
 void free_line_schedule(LineSchedule *g);
 int vec_scatter(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s);
+int vec_copy_indexed(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s);   // dst[idx[i]] = src[idx[i]]
 int matrix_row_subset(pamg_matrix_s *A, const int32_t *rows, int nrows, pamg_matrix_s **out);   // rows: HOST
 int jacobi_indexed(pamg_matrix_s *sub, void *x, const void *b, double omega, void *work, hipStream_t s);
 int vec_maxratio(int dtype, int64_t n, const void *u, const void *x, double *scratch, double *out, hipStream_t s);

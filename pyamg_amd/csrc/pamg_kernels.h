@@ -1137,6 +1137,17 @@ __global__ __launch_bounds__(BLK) void vec_mul_kernel(int64_t n, const T *a, con
     for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) y[i] = a[i] * b[i];
 }
 
+// dst[idx[i]] = src[idx[i]]: the listed entries of a full-length result (indexed block Jacobi: rows outside the list keep
+// their old values)
+template <typename T>
+__global__ __launch_bounds__(BLK) void vec_copy_indexed_kernel(int64_t n, const int *idx, const T *src, T *dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
+        const int k = idx[i];
+        dst[k] = src[k];
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLK) void vec_scatter_kernel(int64_t n, const int *idx, const T *src, T *dst)
 {

@@ -1282,6 +1282,17 @@ int vec_scatter(int dtype, int64_t n, const int *idx, const void *src, void *dst
     return (int)hipGetLastError();
 }
 
+int vec_copy_indexed(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s)
+{
+    if (n <= 0) return PAMG_OK;
+    const int grid = (int)std::min<int64_t>(8192, (n + BLK - 1) / BLK);
+    if (dtype == PAMG_F64)
+        hipLaunchKernelGGL((vec_copy_indexed_kernel<double>), dim3(grid), dim3(BLK), 0, s, n, idx, (const double *)src, (double *)dst);
+    else
+        hipLaunchKernelGGL((vec_copy_indexed_kernel<float>), dim3(grid), dim3(BLK), 0, s, n, idx, (const float *)src, (float *)dst);
+    return (int)hipGetLastError();
+}
+
 // Row-subset copy of a scalar CSR operator for the indexed smoothers (CF/FC Jacobi): the listed rows,
 // in list order, stored contiguously so they stream like any other operator; d_rowid maps a stored row
 // back to its row in the parent, the diagonal is the parent's (last stored a_ii of that row).

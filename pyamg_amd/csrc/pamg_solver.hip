@@ -28,6 +28,9 @@ struct Smoother {
     pamg_matrix_s *AF = nullptr, *AC = nullptr;
     void *wF = nullptr, *wC = nullptr;
     int f_iterations = 1, c_iterations = 1;
+    // CF / FC block Jacobi: scalar indices of the listed block rows
+    int *iF = nullptr, *iC = nullptr;
+    int64_t nF = 0, nC = 0;
     // normal-equation smoothers: d_Dinv holds 1/||row||^2 or 1/||col||^2; At is borrowed (see the header)
     pamg_matrix_s *At = nullptr, *Ar = nullptr;
 };
@@ -233,6 +236,23 @@ int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, 
                     void *w = f ? sm.wF : sm.wC;
                     const int reps = f ? sm.f_iterations : sm.c_iterations;
                     for (int k = 0; k < reps; ++k) PAMG_TRY(jacobi_indexed(sub, L.x, L.b, sm.omega, w, s));
+                }
+            }
+            return PAMG_OK;
+        case PAMG_SMOOTH_CF_BLOCK_JACOBI:
+        case PAMG_SMOOTH_FC_BLOCK_JACOBI:
+            // relaxation.py:1271-1340 / :1342-1411: amg_core::block_jacobi_indexed (relaxation.h:1129-1199) on the C then the
+            // F block rows (or F then C).  One full block-Jacobi step from the old iterate into the partner buffer -- the
+            // per-row arithmetic of block_jacobi_indexed IS block_jacobi's -- then only the listed rows are taken over.
+            for (int it = 0; it < sm.iterations; ++it) {
+                const bool f_first = sm.kind == PAMG_SMOOTH_FC_BLOCK_JACOBI;
+                for (int half = 0; half < 2; ++half) {
+                    const bool f = (half == 0) == f_first;
+                    const int reps = f ? sm.f_iterations : sm.c_iterations;
+                    for (int k = 0; k < reps; ++k) {
+                        PAMG_TRY(block_jacobi_step(L.A, BLK_JACOBI, sm.d_Dinv, L.x, L.xalt, L.b, sm.omega, s));
+                        PAMG_TRY(vec_copy_indexed(S->dtype, f ? sm.nF : sm.nC, f ? sm.iF : sm.iC, L.xalt, L.x, s));
+                    }
                 }
             }
             return PAMG_OK;
@@ -443,6 +463,16 @@ int pamg_matrix_block_jacobi_step(pamg_matrix_t A, const void *Dinv, const void 
     return block_jacobi_step(A, BLK_JACOBI, Dinv, x_in, x_out, b, omega, (hipStream_t)s);
 }
 
+int pamg_matrix_block_jacobi_indexed(pamg_matrix_t A, const void *Dinv, void *x, const void *b, const int32_t *idx,
+                                     int64_t nidx, double omega, void *work, pamg_stream_t s)
+{
+    if (!A || !Dinv || !x || !b || !work || nidx < 0 || (nidx > 0 && !idx)) return PAMG_E_ARG;
+    if (A->R != A->C || A->R < 2 || A->ncols != A->nrows) return PAMG_E_UNSUPPORTED;
+    if (A->nrows == 0 || nidx == 0) return PAMG_OK;
+    PAMG_TRY(block_jacobi_step(A, BLK_JACOBI, Dinv, x, work, b, omega, (hipStream_t)s));
+    return vec_copy_indexed(A->dtype, nidx, idx, work, x, (hipStream_t)s);
+}
+
 int pamg_matrix_gauss_seidel(pamg_matrix_t A, void *x, const void *b, int sweep, double omega,
                              int iterations, pamg_stream_t s)
 {
@@ -503,7 +533,7 @@ int pamg_solver_destroy(pamg_solver_t S)
         for (Smoother *sm : {&L.pre, &L.post}) {
             if (sm->AF) pamg_matrix_destroy(sm->AF);
             if (sm->AC) pamg_matrix_destroy(sm->AC);
-            hipFree(sm->wF); hipFree(sm->wC);
+            hipFree(sm->wF); hipFree(sm->wC); hipFree(sm->iF); hipFree(sm->iC);
         }
     }
     hipFree(S->d_coarse); hipFree(S->d_norms); hipFree(S->d_slot); hipFree(S->d_scratch);
@@ -550,7 +580,7 @@ int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, in
     if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
-    hipFree(sm.wF); hipFree(sm.wC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep; sm.blocksize = blocksize;
     if (kind == PAMG_SMOOTH_POLY) {
@@ -581,7 +611,7 @@ int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind,
     if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
-    hipFree(sm.wF); hipFree(sm.wC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega;
     sm.f_iterations = f_iterations; sm.c_iterations = c_iterations;
@@ -591,6 +621,44 @@ int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind,
     PAMG_HIP(hipMalloc(&sm.wF, std::max<size_t>((size_t)nF * ts, 256)));
     PAMG_HIP(hipMalloc(&sm.wC, std::max<size_t>((size_t)nC * ts, 256)));
     S->bytes += sm.AF->bytes + sm.AC->bytes + (size_t)(nF + nC) * ts;
+    return PAMG_OK;
+}
+
+int pamg_solver_set_cf_block_smoother(pamg_solver_t S, int level, int which, int kind, int iterations, int f_iterations,
+                                      int c_iterations, double omega, const void *Dinv, int blocksize, const int32_t *Fpts,
+                                      int nF, const int32_t *Cpts, int nC)
+{
+    if (!S || level < 0 || level >= (int)S->levels.size() || (which != 0 && which != 1) || !Dinv) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    if (kind != PAMG_SMOOTH_CF_BLOCK_JACOBI && kind != PAMG_SMOOTH_FC_BLOCK_JACOBI) return PAMG_E_ARG;
+    if (iterations < 0 || f_iterations < 0 || c_iterations < 0 || nF < 0 || nC < 0) return PAMG_E_ARG;
+    Level &L = S->levels[level];
+    if (L.A->R != L.A->C || L.A->R != blocksize || blocksize < 2) return PAMG_E_UNSUPPORTED;
+    const int nb = L.A->n_brow;
+    for (int k = 0; k < nF; ++k) if (Fpts[k] < 0 || Fpts[k] >= nb) return PAMG_E_ARG;
+    for (int k = 0; k < nC; ++k) if (Cpts[k] < 0 || Cpts[k] >= nb) return PAMG_E_ARG;
+    Smoother &sm = which == 0 ? L.pre : L.post;
+    if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
+    if (sm.AF) pamg_matrix_destroy(sm.AF);
+    if (sm.AC) pamg_matrix_destroy(sm.AC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    sm = Smoother();
+    sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.blocksize = blocksize;
+    sm.f_iterations = f_iterations; sm.c_iterations = c_iterations;
+    const size_t sz = (size_t)nb * blocksize * blocksize * tsize(S->dtype);
+    PAMG_HIP(hipMalloc(&sm.d_Dinv, std::max<size_t>(sz, 256)));
+    PAMG_HIP(hipMemcpy(sm.d_Dinv, Dinv, sz, hipMemcpyHostToDevice));
+    auto expand = [&](const int32_t *pts, int n, int **dptr, int64_t *cnt) -> int {
+        std::vector<int> idx((size_t)n * blocksize);
+        for (int k = 0; k < n; ++k) for (int c = 0; c < blocksize; ++c) idx[(size_t)k * blocksize + c] = pts[k] * blocksize + c;
+        *cnt = (int64_t)idx.size();
+        PAMG_HIP(hipMalloc((void **)dptr, std::max<size_t>(idx.size() * sizeof(int), 256)));
+        if (!idx.empty()) PAMG_HIP(hipMemcpy(*dptr, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+        return PAMG_OK;
+    };
+    PAMG_TRY(expand(Fpts, nF, &sm.iF, &sm.nF));
+    PAMG_TRY(expand(Cpts, nC, &sm.iC, &sm.nC));
+    S->bytes += sz + (size_t)(sm.nF + sm.nC) * sizeof(int);
     return PAMG_OK;
 }
 
@@ -612,7 +680,7 @@ int pamg_solver_set_ne_smoother(pamg_solver_t S, int level, int which, int kind,
     if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
-    hipFree(sm.wF); hipFree(sm.wC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep;
     sm.At = kind == PAMG_SMOOTH_GS_NE ? nullptr : At;

@@ -190,6 +190,17 @@ def smoother_spec(fn, A) -> SmootherSpec:
                                 Fpts=np.ascontiguousarray(kw["Fpts"], dtype=np.int32),
                                 Cpts=np.ascontiguousarray(kw["Cpts"], dtype=np.int32),
                                 f_iterations=int(kw.get("f_iterations", 1)), c_iterations=int(kw.get("c_iterations", 1)))
+        if base in ("cf_block_jacobi", "fc_block_jacobi"):
+            Dinv, bs = kw.get("Dinv"), kw.get("blocksize")
+            if Dinv is None or bs is None or int(bs) < 2:
+                raise NotImplementedError(f"{base} without precomputed Dinv / with blocksize 1")
+            if getattr(A, "format", "csr") != "bsr" or tuple(A.blocksize) != (int(bs), int(bs)):
+                raise NotImplementedError(f"{base}: the level operator must be BSR with {bs}x{bs} blocks on the device path")
+            return SmootherSpec(base, it, float(np.real(kw.get("omega", 1.0))), name=shown,
+                                Dinv=np.ascontiguousarray(Dinv, dtype=A.dtype), blocksize=int(bs),
+                                Fpts=np.ascontiguousarray(kw["Fpts"], dtype=np.int32),
+                                Cpts=np.ascontiguousarray(kw["Cpts"], dtype=np.int32),
+                                f_iterations=int(kw.get("f_iterations", 1)), c_iterations=int(kw.get("c_iterations", 1)))
         raise NotImplementedError(f"smoother '{base}' is not on the device path")
     cv = _closure_vars(fn)
     if shown in ("gauss_seidel_ne", "gauss_seidel_nr", "jacobi_ne") and "iterations" in cv and "omega" in cv:

@@ -190,6 +190,16 @@ def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype, aux):
                                                    capi.ptr(F), F.size, capi.ptr(Cp), Cp.size),
                    f"pamg_solver_set_cf_smoother({s.kind})")
         return
+    if s.kind in ("cf_block_jacobi", "fc_block_jacobi"):
+        F = np.ascontiguousarray(s.Fpts, dtype=np.int32)
+        Cp = np.ascontiguousarray(s.Cpts, dtype=np.int32)
+        Dinv = np.ascontiguousarray(s.Dinv, dtype=dtype)
+        capi.check(lib.pamg_solver_set_cf_block_smoother(S, level, which, capi.SMOOTH[s.kind], int(s.iterations),
+                                                         int(s.f_iterations), int(s.c_iterations), float(s.omega),
+                                                         capi.ptr(Dinv), int(s.blocksize), capi.ptr(F), F.size,
+                                                         capi.ptr(Cp), Cp.size),
+                   f"pamg_solver_set_cf_block_smoother({s.kind})")
+        return
     coeffs = None
     ncoef = 0
     if s.kind == "polynomial":

@@ -20,7 +20,7 @@ from .hierarchy import sparse_op
 from .multilevel import DeviceMatrix
 
 __all__ = ["make_system", "jacobi", "gauss_seidel", "sor", "polynomial", "block_jacobi",
-           "block_gauss_seidel", "jacobi_indexed", "cf_jacobi", "fc_jacobi", "gauss_seidel_ne",
+           "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_indexed", "cf_jacobi", "fc_jacobi", "cf_block_jacobi", "fc_block_jacobi", "gauss_seidel_ne",
            "gauss_seidel_nr", "jacobi_ne"]
 
 
@@ -158,6 +158,30 @@ def jacobi_indexed(A, x, b, indices, iterations=1, omega=1.0):
     _indexed_sweeps(A, x, b, [(indices, 1)], iterations, omega)
 
 
+def gauss_seidel_indexed(A, x, b, indices, iterations=1, sweep="forward"):
+    """Gauss-Seidel on the listed rows, in the listed order, in place (reference: relaxation.py:662-731; a row may be
+    listed more than once; 'backward' walks the list from its end, 'symmetric' = forward then backward)."""
+    from . import amg_core
+    A, x, b = make_system(A, x, b, formats=["csr"])
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    if indices.size and (indices.min() < 0 or indices.max() > A.shape[0] - 1):
+        raise ValueError("indices must range from 0, ..., N-1")
+    if sweep == "forward":
+        row_start, row_stop, row_step = 0, len(indices), 1
+    elif sweep == "backward":
+        row_start, row_stop, row_step = len(indices) - 1, -1, -1
+    elif sweep == "symmetric":
+        for _ in range(iterations):
+            gauss_seidel_indexed(A, x, b, indices, iterations=1, sweep="forward")
+            gauss_seidel_indexed(A, x, b, indices, iterations=1, sweep="backward")
+        return
+    else:
+        raise ValueError('valid sweep directions: "forward", "backward", and "symmetric"')
+    Ap, Aj = np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32)
+    for _ in range(iterations):
+        amg_core.gauss_seidel_indexed(Ap, Aj, A.data, x, b, indices, row_start, row_stop, row_step)
+
+
 def cf_jacobi(A, x, b, Cpts, Fpts, iterations=1, f_iterations=1, c_iterations=1, omega=1.0):
     """CF Jacobi, in place: per iteration c_iterations sweeps over Cpts, then f_iterations over Fpts
     (reference: relaxation.py:1141-1203)."""
@@ -273,6 +297,50 @@ def block_jacobi(A, x, b, Dinv=None, blocksize=1, iterations=1, omega=1.0):
     st.A.block_jacobi(st.x, st.b, st.work, dD, float(np.real(omega)), iterations)
     st.finish()
     dD.free()
+
+
+def _indexed_block_sweeps(A, x, b, plan, Dinv, blocksize, iterations, omega):
+    """Shared body of cf_block_jacobi / fc_block_jacobi: ``plan`` = [(block-row list, sweeps), ...] run ``iterations``
+    times, each sweep one amg_core.block_jacobi_indexed (relaxation.h:1129-1199), device-resident."""
+    if blocksize == 1:
+        raise NotImplementedError("blocksize 1: use cf_jacobi / fc_jacobi (the reference's setup does the same, smoothing.py:731-734)")
+    A, Dinv = _block_prep(A, blocksize, Dinv)
+    nb = A.shape[0] // blocksize
+    lists = []
+    for rows, _ in plan:
+        rows = np.asarray(rows, dtype=np.int64)
+        if rows.size and (rows.min() < 0 or rows.max() > nb - 1):
+            raise ValueError("block indices must range from 0, ..., N/blocksize - 1")
+        lists.append(np.ascontiguousarray((rows[:, None] * blocksize + np.arange(blocksize)).ravel(), dtype=np.int32))
+    st = _Staged(A, x, b, work=1)
+    dD = capi.DeviceArray.from_host(Dinv.reshape(-1))
+    dI = [capi.DeviceArray.from_host(idx) if idx.size else None for idx in lists]
+    lib = capi.lib()
+    for _ in range(iterations):
+        for idx, d, (_, sweeps) in zip(lists, dI, plan):
+            for _ in range(sweeps):
+                if d is not None:
+                    capi.check(lib.pamg_matrix_block_jacobi_indexed(st.A.handle, dD.ptr, st.x.ptr, st.b.ptr, d.ptr, idx.size,
+                                                                    float(np.real(omega)), st.work.ptr, None),
+                               "pamg_matrix_block_jacobi_indexed")
+    st.finish()
+    dD.free()
+    for d in dI:
+        if d is not None:
+            d.free()
+
+
+def cf_block_jacobi(A, x, b, Cpts, Fpts, Dinv=None, blocksize=1, iterations=1, f_iterations=1, c_iterations=1, omega=1.0):
+    """CF block Jacobi, in place: per iteration c_iterations sweeps over the C block rows, then f_iterations over the F
+    block rows (reference: relaxation.py:1271-1340)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    _indexed_block_sweeps(A, x, b, [(Cpts, c_iterations), (Fpts, f_iterations)], Dinv, blocksize, iterations, omega)
+
+
+def fc_block_jacobi(A, x, b, Cpts, Fpts, Dinv=None, blocksize=1, iterations=1, f_iterations=1, c_iterations=1, omega=1.0):
+    """FC block Jacobi, in place: F block rows first, then C (reference: relaxation.py:1342-1411)."""
+    A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
+    _indexed_block_sweeps(A, x, b, [(Fpts, f_iterations), (Cpts, c_iterations)], Dinv, blocksize, iterations, omega)
 
 
 def block_gauss_seidel(A, x, b, iterations=1, sweep="forward", blocksize=1, Dinv=None):

@@ -210,6 +210,17 @@ def make_hierarchies():
     change_smoothers(mlc, presmoother=("gauss_seidel", {"sweep": "forward"}),
                      postsmoother=("gauss_seidel", {"sweep": "backward"}))
     hier("rs2d_cscR_splu", mlc)
+    # CF / FC block Jacobi (relaxation.py:1271-1411, amg_core.block_jacobi_indexed) on the 2-D elasticity hierarchy:
+    # the registry needs a C/F splitting per level (an AIR-style solver on a block system would bring its own; here a
+    # seeded one is attached to the SA levels), the smoothers are then the reference's own bound callables
+    np.random.seed(SEED)
+    mlb = pyamg.smoothed_aggregation_solver(E, B=B, max_coarse=10)
+    rs = np.random.RandomState(SEED + 21)
+    for lvl in mlb.levels[:-1]:
+        lvl.splitting = rs.rand(lvl.A.shape[0] // lvl.A.blocksize[0]) < 0.35
+    change_smoothers(mlb, presmoother=("cf_block_jacobi", {"omega": 0.8, "f_iterations": 2, "c_iterations": 1}),
+                     postsmoother=("fc_block_jacobi", {"omega": 0.9, "iterations": 2}))
+    hier("el2d_cfblockjacobi", mlb)
 
 
 def make_kernels():
@@ -378,6 +389,81 @@ def make_kernels_indexed():
     print("kernels_indexed.npz written:", len(out), "arrays")
 
 
+def make_kernels_gsidx():
+    """amg_core.gauss_seidel_indexed / relaxation.gauss_seidel_indexed of the reference -> kernels_gsidx.npz"""
+    import scipy.sparse as sp
+    from pyamg import amg_core
+    rng = np.random.RandomState(SEED + 19)
+    out = {}
+    G = sp.random(300, 300, density=0.04, random_state=rng, format="lil")
+    G.setdiag(rng.rand(300) + 1.0)
+    G[9, :] = 0                       # empty row
+    G[17, 17] = 0.0                   # missing diagonal
+    G = sp.csr_array(G.tocsr())
+    G.sort_indices()
+    P = pyamg.gallery.poisson((17, 15), format="csr")
+    for tag, M in (("irr", G), ("pois", P)):
+        for dt in (np.float64, np.float32):
+            Md = sp.csr_array(M.astype(dt))
+            n = Md.shape[0]
+            x = rng.rand(n).astype(dt); b = rng.rand(n).astype(dt)
+            idx = rng.permutation(n)[: (2 * n) // 3].astype(np.int32)           # no row twice, arbitrary order
+            dup = np.concatenate([idx[:40], idx[20:60][::-1], idx[:10]]).astype(np.int32)    # rows listed two and three times
+            k = f"{tag}_{np.dtype(dt).name}"
+            out[f"{k}.indptr"], out[f"{k}.indices"], out[f"{k}.data"] = Md.indptr, Md.indices, Md.data
+            out[f"{k}.x"], out[f"{k}.b"], out[f"{k}.idx"], out[f"{k}.dup"] = x, b, idx, dup
+            for sweep in ("forward", "backward", "symmetric"):
+                y = x.copy(); rr.gauss_seidel_indexed(Md, y, b, idx, iterations=2, sweep=sweep)
+                out[f"{k}.{sweep}"] = y
+            y = x.copy(); rr.gauss_seidel_indexed(Md, y, b, dup, iterations=1, sweep="forward")
+            out[f"{k}.dup.forward"] = y
+            y = x.copy(); amg_core.gauss_seidel_indexed(Md.indptr, Md.indices, Md.data, y, b, idx, 1, len(idx) - 1, 2)   # strided slice of the list
+            out[f"{k}.strided"] = y
+    np.savez_compressed(HERE / "kernels_gsidx.npz", **out)
+    print("kernels_gsidx.npz written:", len(out), "arrays")
+
+
+def make_kernels_blockidx():
+    """amg_core.block_jacobi_indexed and relaxation.cf_block_jacobi / fc_block_jacobi of the reference -> kernels_blockidx.npz"""
+    import scipy.sparse as sp
+    from pyamg import amg_core
+    from pyamg.util.utils import get_block_diag
+    rng = np.random.RandomState(SEED + 17)
+    out = {}
+    for tag, bs, nb in (("b3", 3, 90), ("b2", 2, 150)):
+        G = sp.random(nb, nb, density=0.06, random_state=rng, format="lil")
+        G.setdiag(1.0)
+        G[5, :] = 0                                  # empty block row (no diagonal block either)
+        pat = sp.csr_array(G.tocsr())
+        pat.eliminate_zeros()
+        blocks = rng.rand(pat.nnz, bs, bs) - 0.3
+        M = sp.bsr_array((blocks, pat.indices, pat.indptr), shape=(nb * bs, nb * bs))
+        for i in range(nb):                          # dominant diagonal blocks
+            for p in range(M.indptr[i], M.indptr[i + 1]):
+                if M.indices[p] == i:
+                    M.data[p] += 4.0 * np.eye(bs)
+        for dt in (np.float64, np.float32):
+            Md = sp.bsr_array((M.data.astype(dt), M.indices, M.indptr), shape=M.shape)
+            n = Md.shape[0]
+            x = rng.rand(n).astype(dt); b = rng.rand(n).astype(dt)
+            Dinv = get_block_diag(Md, blocksize=bs, inv_flag=True).astype(dt)
+            idx = rng.permutation(nb)[: nb // 3].astype(np.int32)
+            F = np.sort(rng.permutation(nb)[: (2 * nb) // 3]).astype(np.int32)
+            Cp = np.setdiff1d(np.arange(nb, dtype=np.int32), F).astype(np.int32)
+            k = f"{tag}_{np.dtype(dt).name}"
+            out[f"{k}.indptr"], out[f"{k}.indices"], out[f"{k}.data"] = Md.indptr, Md.indices, Md.data
+            out[f"{k}.x"], out[f"{k}.b"], out[f"{k}.idx"], out[f"{k}.F"], out[f"{k}.C"], out[f"{k}.Dinv"] = x, b, idx, F, Cp, Dinv
+            y = x.copy()
+            amg_core.block_jacobi_indexed(Md.indptr, Md.indices, np.ravel(Md.data), y, b, np.ravel(Dinv), idx, np.array([0.7], dtype=dt), bs)
+            out[f"{k}.block_jacobi_indexed"] = y
+            y = x.copy(); rr.fc_block_jacobi(Md, y, b, Cp, F, Dinv=Dinv, blocksize=bs, iterations=2, f_iterations=2, c_iterations=1, omega=0.9)
+            out[f"{k}.fc_block_jacobi"] = y
+            y = x.copy(); rr.cf_block_jacobi(Md, y, b, Cp, F, Dinv=Dinv, blocksize=bs, iterations=1, f_iterations=1, c_iterations=2, omega=1.0)
+            out[f"{k}.cf_block_jacobi"] = y
+    np.savez_compressed(HERE / "kernels_blockidx.npz", **out)
+    print("kernels_blockidx.npz written:", len(out), "arrays")
+
+
 def make_kernels_ne():
     """relaxation.gauss_seidel_ne / gauss_seidel_nr / jacobi_ne of the reference -> kernels_ne.npz (float64: the
     reference hands a float64 Dinv to its float32 kernels, i.e. raises TypeError there)."""
@@ -421,6 +507,14 @@ if __name__ == "__main__" and "--indexed-only" in sys.argv:
     make_kernels_indexed()
     sys.exit(0)
 
+if __name__ == "__main__" and "--gsidx-only" in sys.argv:
+    make_kernels_gsidx()
+    sys.exit(0)
+
+if __name__ == "__main__" and "--blockidx-only" in sys.argv:
+    make_kernels_blockidx()
+    sys.exit(0)
+
 if __name__ == "__main__" and "--ne-only" in sys.argv:
     make_kernels_ne()
     sys.exit(0)
@@ -435,6 +529,8 @@ if __name__ == "__main__":
         make_known_answers()
         make_kernels()
         make_kernels_indexed()
+        make_kernels_blockidx()
+        make_kernels_gsidx()
         make_kernels_ne()
     make_hierarchies()
     save_accel()

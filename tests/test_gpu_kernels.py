@@ -483,6 +483,65 @@ def test_indexed_jacobi_bit_exact():
         gcore.jacobi_indexed(Ap, Aj, Ax, x.copy(), b, idx.astype(np.int64), np.array([0.7], dtype=Ax.dtype))
 
 
+def test_indexed_gauss_seidel_bit_exact():
+    """gauss_seidel_indexed (Layer 1 twin and the relaxation wrapper): the listed rows in list order as a forward sweep of
+    the renumbered operator -- vs the reference's outputs in kernels_gsidx.npz, bit for bit: arbitrary order, rows listed
+    two and three times, a strided slice of the list, forward / backward / symmetric, f64 and f32."""
+    from conftest import GOLDEN
+    import pyamg_amd.amg_core as gcore
+    z = np.load(GOLDEN / "kernels_gsidx.npz")
+    keys = sorted({k.split(".")[0] for k in z.files})
+    assert len(keys) == 4
+    for k in keys:
+        Ap, Aj, Ax = z[f"{k}.indptr"].astype(np.int32), z[f"{k}.indices"].astype(np.int32), z[f"{k}.data"]
+        n = Ap.size - 1
+        M = sp.csr_array((Ax, Aj, Ap), shape=(n, n))
+        x, b, idx, dup = (z[f"{k}.{t}"] for t in ("x", "b", "idx", "dup"))
+        for sweep in ("forward", "backward", "symmetric"):
+            y = x.copy(); grelax.gauss_seidel_indexed(M, y, b, idx, iterations=2, sweep=sweep)
+            assert np.array_equal(y, z[f"{k}.{sweep}"]), (k, sweep)
+        y = x.copy(); grelax.gauss_seidel_indexed(M, y, b, dup, iterations=1, sweep="forward")
+        assert np.array_equal(y, z[f"{k}.dup.forward"]), k
+        y = x.copy(); gcore.gauss_seidel_indexed(Ap, Aj, Ax, y, b, idx, 1, len(idx) - 1, 2)
+        assert np.array_equal(y, z[f"{k}.strided"]), k
+    with pytest.raises(ValueError):
+        grelax.gauss_seidel_indexed(M, x.copy(), b, np.array([0, n], dtype=np.int32))
+    with pytest.raises(ValueError):
+        grelax.gauss_seidel_indexed(M, x.copy(), b, idx, sweep="sideways")
+    with pytest.raises(TypeError):
+        gcore.gauss_seidel_indexed(Ap, Aj, Ax, x.copy(), b, idx.astype(np.int64), 0, 3, 1)
+
+
+def test_indexed_block_jacobi_bit_exact():
+    """block_jacobi_indexed (Layer 1, the amg_core twin) and the cf_block_jacobi / fc_block_jacobi wrappers (one full
+    block-Jacobi step + take-over of the listed block rows) vs the reference's outputs in kernels_blockidx.npz -- bit for
+    bit, 3x3 and 2x2 blocks, f64 and f32, incl. an empty block row; plus the error contract."""
+    from conftest import GOLDEN
+    import pyamg_amd.amg_core as gcore
+    z = np.load(GOLDEN / "kernels_blockidx.npz")
+    keys = sorted({k.split(".")[0] for k in z.files})
+    assert len(keys) == 4
+    for k in keys:
+        Ap, Aj, Ax = z[f"{k}.indptr"].astype(np.int32), z[f"{k}.indices"].astype(np.int32), z[f"{k}.data"]
+        bs = Ax.shape[1]
+        nb = Ap.size - 1
+        M = sp.bsr_array((Ax, Aj, Ap), shape=(nb * bs, nb * bs))
+        x, b, idx, F, Cp, Dinv = (z[f"{k}.{t}"] for t in ("x", "b", "idx", "F", "C", "Dinv"))
+        y = x.copy()
+        gcore.block_jacobi_indexed(Ap, Aj, np.ravel(Ax), y, b, np.ravel(Dinv), idx, np.array([0.7], dtype=Ax.dtype), bs)
+        assert np.array_equal(y, z[f"{k}.block_jacobi_indexed"]), k
+        y = x.copy(); grelax.fc_block_jacobi(M, y, b, Cp, F, Dinv=Dinv, blocksize=bs, iterations=2, f_iterations=2, c_iterations=1, omega=0.9)
+        assert np.array_equal(y, z[f"{k}.fc_block_jacobi"]), k
+        y = x.copy(); grelax.cf_block_jacobi(M, y, b, Cp, F, Dinv=Dinv, blocksize=bs, iterations=1, f_iterations=1, c_iterations=2, omega=1.0)
+        assert np.array_equal(y, z[f"{k}.cf_block_jacobi"]), k
+    with pytest.raises(ValueError):
+        grelax.cf_block_jacobi(M, x.copy(), b, np.array([nb], dtype=np.int32), F, Dinv=Dinv, blocksize=bs)
+    with pytest.raises(NotImplementedError):
+        grelax.cf_block_jacobi(M, x.copy(), b, Cp, F, Dinv=Dinv.reshape(-1, 1, 1)[:nb * bs], blocksize=1)
+    with pytest.raises(TypeError):
+        gcore.block_jacobi_indexed(Ap, Aj, np.ravel(Ax), x.copy(), b, np.ravel(Dinv), idx.astype(np.int64), np.array([0.7], dtype=Ax.dtype), bs)
+
+
 def test_normal_equation_smoothers_bit_exact():
     """gauss_seidel_ne (Kaczmarz), gauss_seidel_nr and jacobi_ne on the device (order-exact level schedules
     over shared indices; (omega A)^T SpMV) vs the reference's outputs in kernels_ne.npz -- bit for bit, all
