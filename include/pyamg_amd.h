@@ -145,6 +145,20 @@ int pamg_jacobi_indexed_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, i
                             const float *Ax, int Ax_size, float *x, int x_size,
                             const float *b, int b_size, const int32_t *indices, int indices_size,
                             const float *omega, int omega_size);
+/* amg_core::overlapping_schwarz_csr, relaxation.h:1420-1434 (Tx/Tp: the inverted diagonal blocks of the subdomains,
+ * row-major, and their offsets; Sj/Sp: the rows of every subdomain, sorted and unique) */
+int pamg_overlapping_schwarz_csr_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                                     const double *Ax, int Ax_size, double *x, int x_size,
+                                     const double *b, int b_size, const double *Tx, int Tx_size,
+                                     const int32_t *Tp, int Tp_size, const int32_t *Sj, int Sj_size,
+                                     const int32_t *Sp, int Sp_size, int32_t nsdomains, int32_t nrows,
+                                     int32_t row_start, int32_t row_stop, int32_t row_step);
+int pamg_overlapping_schwarz_csr_f32(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                                     const float *Ax, int Ax_size, float *x, int x_size,
+                                     const float *b, int b_size, const float *Tx, int Tx_size,
+                                     const int32_t *Tp, int Tp_size, const int32_t *Sj, int Sj_size,
+                                     const int32_t *Sp, int Sp_size, int32_t nsdomains, int32_t nrows,
+                                     int32_t row_start, int32_t row_stop, int32_t row_step);
 /* amg_core::gauss_seidel_indexed, relaxation.h:736-745: the rows Id[row_start], Id[row_start + row_step], ... in that order,
  * in place (a row may be listed more than once) */
 int pamg_gauss_seidel_indexed_f64(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
@@ -376,6 +390,7 @@ int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, v
 #define PAMG_SMOOTH_JACOBI_NE  11   /* relaxation.jacobi_ne                   relaxation.py:741-812  */
 #define PAMG_SMOOTH_CF_BLOCK_JACOBI 12   /* relaxation.cf_block_jacobi  relaxation.py:1271-1340: C block rows, then F */
 #define PAMG_SMOOTH_FC_BLOCK_JACOBI 13   /* relaxation.fc_block_jacobi  relaxation.py:1342-1411: F block rows, then C */
+#define PAMG_SMOOTH_SCHWARZ    14   /* relaxation.schwarz  relaxation.py:157-262 (also what strength_based_schwarz runs) */
 #define PAMG_CYCLE_V 0
 #define PAMG_CYCLE_W 1
 #define PAMG_CYCLE_F 2
@@ -402,6 +417,23 @@ int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind,
 int pamg_solver_set_cf_block_smoother(pamg_solver_t S, int level, int which, int kind, int iterations,
                                       int f_iterations, int c_iterations, double omega, const void *Dinv,
                                       int blocksize, const int32_t *Fpts, int nF, const int32_t *Cpts, int nC);
+/* Multiplicative overlapping Schwarz (relaxation.schwarz, relaxation.py:157-262 -> amg_core::overlapping_schwarz_csr,
+ * relaxation.h:1420-1492) on a resident scalar CSR operator A (borrowed; the reference sweeps lvl.Acsr, whose rows are
+ * sorted).  Sp/Sj/Tp/Tx: HOST, copied -- the subdomains' row lists and their inverted diagonal blocks exactly as the
+ * reference's schwarz_parameters built them.  The sweep visits subdomains row_start, row_start + row_step, ... like
+ * the reference; subdomains of one dependency level run side by side, results are bit-identical.  Subdomains of more
+ * than 2048 rows: PAMG_E_UNSUPPORTED. */
+typedef struct pamg_schwarz_s *pamg_schwarz_t;
+int pamg_schwarz_create(pamg_schwarz_t *out, pamg_matrix_t A, int nsub, const int32_t *Sp, const int32_t *Sj,
+                        const int32_t *Tp, const void *Tx);
+int pamg_schwarz_destroy(pamg_schwarz_t h);
+int pamg_schwarz_sweep(pamg_schwarz_t h, void *x, const void *b, int row_start, int row_stop, int row_step,
+                       pamg_stream_t s);
+int pamg_schwarz_info(pamg_schwarz_t h, int64_t info[4]);   /* subdomains, largest, dependency levels fwd / bwd */
+/* Schwarz as a level's smoother: `iterations` x (forward | backward | forward then backward) sweeps.  Ar: the level's
+ * operator as the reference's smoother sees it (lvl.Acsr; NULL = the level operator itself); the solver borrows it. */
+int pamg_solver_set_schwarz_smoother(pamg_solver_t S, int level, int which, int iterations, int sweep, pamg_matrix_t Ar,
+                                     int nsub, const int32_t *Sp, const int32_t *Sj, const int32_t *Tp, const void *Tx);
 /* Normal-equation smoothers (f64/f32 CSR-like levels).  Dinv: HOST vector of the level's size -- 1/||row||^2
  * (GS_NE, JACOBI_NE) or 1/||column||^2 (GS_NR), computed by the caller exactly as the reference's
  * get_diagonal(A, norm_eq=..., inv=True) (util/utils.py:583-598).  At (borrowed handle, kept alive by the caller):

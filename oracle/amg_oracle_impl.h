@@ -110,6 +110,32 @@ void FN(jacobi)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REA
     }
 }
 
+/* Multiplicative overlapping Schwarz.  Follows amg_core overlapping_schwarz_csr, relaxation.h:1420-1492: per subdomain
+ * the residual of its rows from the current x (rsum -= a*x entry by entry, += b last), times the dense inverse of its
+ * block (row-major, k ascending), added to x.  work: 2 * (largest subdomain) values. */
+void FN(overlapping_schwarz_csr)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REAL *b, const REAL *Tx,
+                                 const int *Tp, const int *Sj, const int *Sp, int row_start, int row_stop, int row_step,
+                                 REAL *work, int maxsize)
+{
+    REAL *rsum = work, *dr = work + maxsize;
+    for (int d = row_start; d != row_stop; d += row_step) {
+        const int size = Sp[d + 1] - Sp[d];
+        for (int q = 0; q < size; ++q) {
+            const int row = Sj[Sp[d] + q];
+            REAL r = 0;
+            for (int p = Ap[row]; p < Ap[row + 1]; ++p) r -= Ax[p] * x[Aj[p]];
+            r += b[row];
+            rsum[q] = r;
+        }
+        for (int i = 0; i < size; ++i) {
+            REAL s = 0;
+            for (int k = 0; k < size; ++k) s += Tx[Tp[d] + (long)i * size + k] * rsum[k];
+            dr[i] = s;
+        }
+        for (int q = 0; q < size; ++q) x[Sj[Sp[d] + q]] += dr[q];
+    }
+}
+
 /* Gauss-Seidel on a list of rows, in list order.  Follows amg_core gauss_seidel_indexed, relaxation.h:736-790. */
 void FN(gauss_seidel_indexed)(const int *Ap, const int *Aj, const REAL *Ax, REAL *x, const REAL *b, const int *Id,
                               int row_start, int row_stop, int row_step)

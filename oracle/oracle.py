@@ -106,6 +106,29 @@ def jacobi_indexed(Ap, Aj, Ax, x, b, indices, omega):
           _I(idx.size), _ptr(temp), ct(omega))
 
 
+def overlapping_schwarz_csr(Ap, Aj, Ax, x, b, Tx, Tp, Sj, Sp, row_start, row_stop, row_step):
+    """amg_core.overlapping_schwarz_csr (relaxation.h:1420-1492)."""
+    Tp, Sj, Sp = (np.ascontiguousarray(a, dtype=np.int32) for a in (Tp, Sj, Sp))
+    Tx = np.ascontiguousarray(Tx, dtype=Ax.dtype)
+    maxsize = int(np.diff(Sp).max(initial=1))
+    work = np.zeros(2 * maxsize, dtype=Ax.dtype)
+    _call("overlapping_schwarz_csr", Ax.dtype, _ptr(Ap), _ptr(Aj), _ptr(Ax), _ptr(x), _ptr(b), _ptr(Tx), _ptr(Tp), _ptr(Sj),
+          _ptr(Sp), _I(row_start), _I(row_stop), _I(row_step), _ptr(work), _I(maxsize))
+
+
+def relax_schwarz(A, x, b, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr, iterations=1, sweep="forward"):
+    """relaxation.py:157-262 (A: CSR SparseOp with sorted rows = lvl.Acsr)."""
+    nsub = len(subdomain_ptr) - 1
+    if sweep == "symmetric":
+        for _ in range(iterations):
+            relax_schwarz(A, x, b, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr, 1, "forward")
+            relax_schwarz(A, x, b, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr, 1, "backward")
+        return
+    r = (0, nsub, 1) if sweep == "forward" else (nsub - 1, -1, -1)
+    for _ in range(iterations):
+        overlapping_schwarz_csr(A.indptr, A.indices, A.data, x, b, inv_subblock, inv_subblock_ptr, subdomain, subdomain_ptr, *r)
+
+
 def gauss_seidel_indexed(Ap, Aj, Ax, x, b, Id, row_start, row_stop, row_step):
     """amg_core.gauss_seidel_indexed (relaxation.h:736-790)."""
     idx = np.ascontiguousarray(Id, dtype=np.int32)
@@ -384,6 +407,9 @@ def apply_smoother(s, A, x, b):
     elif s.kind in ("cf_jacobi", "fc_jacobi"):
         relax_cf_jacobi(A, x, b, s.Cpts, s.Fpts, s.iterations, s.f_iterations, s.c_iterations, s.omega,
                         f_first=(s.kind == "fc_jacobi"))
+    elif s.kind == "schwarz":
+        relax_schwarz(A if getattr(s, "Ar", None) is None else s.Ar, x, b, s.subdomain, s.subdomain_ptr, s.inv_subblock,
+                      s.inv_subblock_ptr, s.iterations, s.sweep)
     elif s.kind in ("cf_block_jacobi", "fc_block_jacobi"):
         relax_cf_block_jacobi(A, x, b, s.Cpts, s.Fpts, s.Dinv, s.blocksize, s.iterations, s.f_iterations, s.c_iterations,
                               s.omega, f_first=(s.kind == "fc_block_jacobi"))

@@ -20,7 +20,7 @@ F64, F32 = 0, 1
 CSR, BSR = 0, 1
 SPMV_SET, SPMV_ACC, SPMV_RESID, SPMV_AXPBY, SPMV_ACC_AXPBY = 0, 1, 2, 3, 4
 FORWARD, BACKWARD, SYMMETRIC = 0, 1, 2
-SMOOTH = {"cf_block_jacobi": 12, "fc_block_jacobi": 13, "gauss_seidel_ne": 9, "gauss_seidel_nr": 10, "jacobi_ne": 11, "cf_jacobi": 7, "fc_jacobi": 8, "none": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
+SMOOTH = {"schwarz": 14, "cf_block_jacobi": 12, "fc_block_jacobi": 13, "gauss_seidel_ne": 9, "gauss_seidel_nr": 10, "jacobi_ne": 11, "cf_jacobi": 7, "fc_jacobi": 8, "none": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
           "block_jacobi": 5, "block_gauss_seidel": 6}
 SWEEP = {"forward": FORWARD, "backward": BACKWARD, "symmetric": SYMMETRIC}
 CYCLE = {"V": 0, "W": 1, "F": 2, "AMLI": 3}
@@ -86,6 +86,7 @@ def _declare(lib):
         csr5 = (_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i)
         f(f"pamg_gauss_seidel_{sfx}", *csr5, _i, _i, _i)
         f(f"pamg_sor_gauss_seidel_{sfx}", *csr5, _i, _i, _i, ct)
+        f(f"pamg_overlapping_schwarz_csr_{sfx}", *csr5, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i)
         f(f"pamg_gauss_seidel_indexed_{sfx}", *csr5, _vp, _i, _i, _i, _i)
         f(f"pamg_bsr_gauss_seidel_{sfx}", *csr5, _i, _i, _i, _i)
         f(f"pamg_jacobi_{sfx}", *csr5, _vp, _i, _i, _i, _i, _vp, _i)
@@ -117,6 +118,11 @@ def _declare(lib):
     f("pamg_matrix_jacobi_step", _vp, _vp, _vp, _vp, _d, _vp)
     f("pamg_matrix_block_jacobi_step", _vp, _vp, _vp, _vp, _vp, _d, _vp)
     f("pamg_matrix_block_jacobi_indexed", _vp, _vp, _vp, _vp, _vp, C.c_int64, _d, _vp, _vp)
+    f("pamg_schwarz_create", P(_vp), _vp, _i, _vp, _vp, _vp, _vp)
+    f("pamg_schwarz_destroy", _vp)
+    f("pamg_schwarz_sweep", _vp, _vp, _vp, _i, _i, _i, _vp)
+    f("pamg_schwarz_info", _vp, P(C.c_int64))
+    f("pamg_solver_set_schwarz_smoother", _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp)
     f("pamg_solver_set_cf_block_smoother", _vp, _i, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _vp, _i)
     f("pamg_matrix_gauss_seidel", _vp, _vp, _vp, _i, _d, _i, _vp)
     f("pamg_matrix_polynomial", _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp)

@@ -14,7 +14,7 @@ import numpy as np
 from . import _capi as capi
 
 __all__ = ["csr_matvec", "bsr_matvec", "gauss_seidel", "sor_gauss_seidel", "bsr_gauss_seidel",
-           "jacobi", "bsr_jacobi", "block_jacobi", "block_jacobi_indexed", "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_indexed", "gauss_seidel_ne",
+           "jacobi", "bsr_jacobi", "block_jacobi", "block_jacobi_indexed", "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_indexed", "overlapping_schwarz_csr", "gauss_seidel_ne",
            "gauss_seidel_nr", "jacobi_ne"]
 
 
@@ -140,6 +140,20 @@ def block_jacobi(Ap, Aj, Ax, x, b, Tx, temp, row_start, row_stop, row_step, omeg
                                                             capi.ptr(temp), temp.size, int(row_start),
                                                             int(row_stop), int(row_step), capi.ptr(omega),
                                                             omega.size, int(blocksize)), "block_jacobi")
+
+
+def overlapping_schwarz_csr(Ap, Aj, Ax, x, b, Tx, Tp, Sj, Sp, nsdomains, nrows, row_start, row_stop, row_step):
+    """amg_core.overlapping_schwarz_csr (relaxation.h:1420-1492)."""
+    _idx(Ap, Aj)
+    for a, n in ((Tp, "Tp"), (Sj, "Sj"), (Sp, "Sp")):
+        if a.dtype != np.int32:
+            raise TypeError(f"overlapping_schwarz_csr(): incompatible function arguments ({n} must be int32)")
+    s = _sfx(Ax, x, b, Tx)
+    capi.check(getattr(capi.lib(), f"pamg_overlapping_schwarz_csr_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(Tx), Tx.size,
+                                                                       capi.ptr(Tp), Tp.size, capi.ptr(Sj), Sj.size,
+                                                                       capi.ptr(Sp), Sp.size, int(nsdomains), int(nrows),
+                                                                       int(row_start), int(row_stop), int(row_step)),
+               "overlapping_schwarz_csr")
 
 
 def gauss_seidel_indexed(Ap, Aj, Ax, x, b, Id, row_start, row_stop, row_step):

@@ -44,6 +44,7 @@ template <typename T> struct L1;
         static constexpr auto block_gauss_seidel = pamg_block_gauss_seidel_##S;            \
         static constexpr auto block_jacobi_indexed = pamg_block_jacobi_indexed_##S;        \
         static constexpr auto gauss_seidel_indexed = pamg_gauss_seidel_indexed_##S;        \
+        static constexpr auto overlapping_schwarz_csr = pamg_overlapping_schwarz_csr_##S;  \
     };
 PAMG_L1(double, f64)
 PAMG_L1(float, f32)
@@ -106,6 +107,13 @@ void bind(py::module_ &m)
                              blocksize), "block_jacobi");
     }, nc("Ap"), nc("Aj"), nc("Ax"), nc("x"), nc("b"), nc("Tx"), nc("temp"), py::arg("row_start"), py::arg("row_stop"), py::arg("row_step"),
        nc("omega"), py::arg("blocksize"));
+    m.def("overlapping_schwarz_csr", [](Idx &Ap, Idx &Aj, Vec<T> &Ax, Vec<T> &x, Vec<T> &b, Vec<T> &Tx, Idx &Tp, Idx &Sj, Idx &Sp, int nsdomains,
+                                        int nrows, int row_start, int row_stop, int row_step) {
+        done(F::overlapping_schwarz_csr(Ap.data(), len(Ap), Aj.data(), len(Aj), Ax.data(), len(Ax), x.mutable_data(), len(x), b.data(), len(b),
+                                        Tx.data(), len(Tx), Tp.data(), len(Tp), Sj.data(), len(Sj), Sp.data(), len(Sp), nsdomains, nrows,
+                                        row_start, row_stop, row_step), "overlapping_schwarz_csr");
+    }, nc("Ap"), nc("Aj"), nc("Ax"), nc("x"), nc("b"), nc("Tx"), nc("Tp"), nc("Sj"), nc("Sp"), py::arg("nsdomains"), py::arg("nrows"),
+       py::arg("row_start"), py::arg("row_stop"), py::arg("row_step"));
     m.def("gauss_seidel_indexed", [](Idx &Ap, Idx &Aj, Vec<T> &Ax, Vec<T> &x, Vec<T> &b, Idx &Id, int row_start, int row_stop, int row_step) {
         done(F::gauss_seidel_indexed(Ap.data(), len(Ap), Aj.data(), len(Aj), Ax.data(), len(Ax), x.mutable_data(), len(x), b.data(), len(b),
                                      Id.data(), len(Id), row_start, row_stop, row_step), "gauss_seidel_indexed");

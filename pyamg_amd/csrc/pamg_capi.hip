@@ -237,6 +237,33 @@ int l1_gs_indexed(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size
     return PAMG_OK;
 }
 
+// amg_core::overlapping_schwarz_csr (relaxation.h:1420-1492)
+template <typename T>
+int l1_schwarz(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, const T *Ax, int Ax_size, T *x, int x_size,
+               const T *b, int b_size, const T *Tx, int Tx_size, const int32_t *Tp, int Tp_size, const int32_t *Sj, int Sj_size,
+               const int32_t *Sp, int Sp_size, int nsdomains, int nrows, int row_start, int row_stop, int row_step)
+{
+    if (!x || !b || !Tp || !Sp || nsdomains < 0 || Sp_size < nsdomains + 1 || Tp_size < nsdomains + 1) return PAMG_E_ARG;
+    PAMG_TRY(check_csr(Ap, Ap_size, Aj_size, Ax_size, 1));
+    const int n = Ap_size - 1;
+    if (n != nrows || n > x_size || n > b_size) return PAMG_E_ARG;
+    if (Sp[nsdomains] > Sj_size || Tp[nsdomains] > Tx_size) return PAMG_E_ARG;
+    if (row_start == row_stop) return PAMG_OK;
+    std::lock_guard<std::mutex> lock(l1_mu);
+    MatGuard g;
+    PAMG_TRY(l1_acquire(g, dt<T>(), PAMG_CSR, n, n, 1, 1, Ap, Aj, Ax));
+    pamg_schwarz_t h = nullptr;
+    PAMG_TRY(pamg_schwarz_create(&h, g.A, nsdomains, Sp, Sj, Tp, Tx));
+    DevBuf dx, db;
+    int st = dx.put(x, sizeof(T) * (size_t)n);
+    if (!st) st = db.put(b, sizeof(T) * (size_t)n);
+    if (!st) st = schwarz_sweep(h, dx.p, db.p, row_start, row_stop, row_step, nullptr);
+    if (!st) st = (int)hipDeviceSynchronize();
+    if (!st) st = dx.get(x, sizeof(T) * (size_t)n);
+    pamg_schwarz_destroy(h);
+    return st;
+}
+
 // jacobi / bsr_jacobi: the device sweep relaxes every row out of place; only the rows of the
 // (row_start,row_stop,row_step) slice are copied back, as in the reference.
 template <typename T>
@@ -552,6 +579,14 @@ int pamg_event_elapsed_ms(pamg_event_t a, pamg_event_t b, float *ms) { return ms
                                         int Id_size, int32_t row_start, int32_t row_stop, int32_t row_step)     \
     { return l1_gs_indexed<T>(Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, Id, Id_size,         \
                               row_start, row_stop, row_step); }                                                 \
+    int pamg_overlapping_schwarz_csr_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,      \
+                                           const T *Ax, int Ax_size, T *x, int x_size, const T *b, int b_size,  \
+                                           const T *Tx, int Tx_size, const int32_t *Tp, int Tp_size,            \
+                                           const int32_t *Sj, int Sj_size, const int32_t *Sp, int Sp_size,      \
+                                           int32_t nsdomains, int32_t nrows, int32_t row_start,                 \
+                                           int32_t row_stop, int32_t row_step)                                  \
+    { return l1_schwarz<T>(Ap, Ap_size, Aj, Aj_size, Ax, Ax_size, x, x_size, b, b_size, Tx, Tx_size, Tp, Tp_size,\
+                           Sj, Sj_size, Sp, Sp_size, nsdomains, nrows, row_start, row_stop, row_step); }        \
     int pamg_sor_gauss_seidel_##SFX(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,             \
                                     const T *Ax, int Ax_size, T *x, int x_size, const T *b, int b_size,         \
                                     int32_t row_start, int32_t row_stop, int32_t row_step, T omega)             \

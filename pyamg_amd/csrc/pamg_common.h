@@ -180,7 +180,12 @@ struct pamg_matrix_s {
     size_t bytes = 0;
 };
 
+struct pamg_schwarz_s;
+
 namespace pamg {
+// pamg_schwarz.hip
+int schwarz_sweep(pamg_schwarz_s *h, void *x, const void *b, int start, int stop, int step, hipStream_t s);
+int schwarz_prepare(pamg_schwarz_s *h, int sweep);
 // launch wrappers implemented in pamg_matrix.hip
 int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void *y, double c,
                   double omega, double *partial, hipStream_t s);

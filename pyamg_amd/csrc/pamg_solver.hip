@@ -31,6 +31,7 @@ struct Smoother {
     // CF / FC block Jacobi: scalar indices of the listed block rows
     int *iF = nullptr, *iC = nullptr;
     int64_t nF = 0, nC = 0;
+    pamg_schwarz_s *sw = nullptr;     // Schwarz: subdomains + inverted blocks + schedules (owned)
     // normal-equation smoothers: d_Dinv holds 1/||row||^2 or 1/||col||^2; At is borrowed (see the header)
     pamg_matrix_s *At = nullptr, *Ar = nullptr;
 };
@@ -239,6 +240,16 @@ int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, 
                 }
             }
             return PAMG_OK;
+        case PAMG_SMOOTH_SCHWARZ: {
+            // relaxation.py:240-262: forward / backward sweeps over the subdomains; symmetric = forward then backward per iteration
+            int nsub = 0;
+            { int64_t info[4]; PAMG_TRY(pamg_schwarz_info(sm.sw, info)); nsub = (int)info[0]; }
+            for (int it = 0; it < sm.iterations; ++it) {
+                if (sm.sweep != PAMG_BACKWARD) PAMG_TRY(schwarz_sweep(sm.sw, L.x, L.b, 0, nsub, 1, s));
+                if (sm.sweep != PAMG_FORWARD) PAMG_TRY(schwarz_sweep(sm.sw, L.x, L.b, nsub - 1, -1, -1, s));
+            }
+            return PAMG_OK;
+        }
         case PAMG_SMOOTH_CF_BLOCK_JACOBI:
         case PAMG_SMOOTH_FC_BLOCK_JACOBI:
             // relaxation.py:1271-1340 / :1342-1411: amg_core::block_jacobi_indexed (relaxation.h:1129-1199) on the C then the
@@ -534,6 +545,7 @@ int pamg_solver_destroy(pamg_solver_t S)
             if (sm->AF) pamg_matrix_destroy(sm->AF);
             if (sm->AC) pamg_matrix_destroy(sm->AC);
             hipFree(sm->wF); hipFree(sm->wC); hipFree(sm->iF); hipFree(sm->iC);
+            if (sm->sw) pamg_schwarz_destroy(sm->sw);
         }
     }
     hipFree(S->d_coarse); hipFree(S->d_norms); hipFree(S->d_slot); hipFree(S->d_scratch);
@@ -581,6 +593,7 @@ int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, in
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
     hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    if (sm.sw) pamg_schwarz_destroy(sm.sw);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep; sm.blocksize = blocksize;
     if (kind == PAMG_SMOOTH_POLY) {
@@ -612,6 +625,7 @@ int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind,
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
     hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    if (sm.sw) pamg_schwarz_destroy(sm.sw);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega;
     sm.f_iterations = f_iterations; sm.c_iterations = c_iterations;
@@ -642,6 +656,7 @@ int pamg_solver_set_cf_block_smoother(pamg_solver_t S, int level, int which, int
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
     hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    if (sm.sw) pamg_schwarz_destroy(sm.sw);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.blocksize = blocksize;
     sm.f_iterations = f_iterations; sm.c_iterations = c_iterations;
@@ -659,6 +674,28 @@ int pamg_solver_set_cf_block_smoother(pamg_solver_t S, int level, int which, int
     PAMG_TRY(expand(Fpts, nF, &sm.iF, &sm.nF));
     PAMG_TRY(expand(Cpts, nC, &sm.iC, &sm.nC));
     S->bytes += sz + (size_t)(sm.nF + sm.nC) * sizeof(int);
+    return PAMG_OK;
+}
+
+int pamg_solver_set_schwarz_smoother(pamg_solver_t S, int level, int which, int iterations, int sweep, pamg_matrix_t Ar,
+                                     int nsub, const int32_t *Sp, const int32_t *Sj, const int32_t *Tp, const void *Tx)
+{
+    if (!S || level < 0 || level >= (int)S->levels.size() || (which != 0 && which != 1)) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    if (iterations < 0 || sweep < PAMG_FORWARD || sweep > PAMG_SYMMETRIC) return PAMG_E_ARG;
+    Level &L = S->levels[level];
+    pamg_matrix_s *Aop = Ar ? Ar : L.A;
+    if (Aop->dtype != S->dtype || Aop->nrows != L.A->nrows || Aop->ncols != L.A->ncols) return PAMG_E_ARG;
+    Smoother &sm = which == 0 ? L.pre : L.post;
+    if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
+    if (sm.AF) pamg_matrix_destroy(sm.AF);
+    if (sm.AC) pamg_matrix_destroy(sm.AC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    if (sm.sw) pamg_schwarz_destroy(sm.sw);
+    sm = Smoother();
+    sm.kind = PAMG_SMOOTH_SCHWARZ; sm.iterations = iterations; sm.sweep = sweep;
+    PAMG_TRY(pamg_schwarz_create(&sm.sw, Aop, nsub, Sp, Sj, Tp, Tx));
+    PAMG_TRY(schwarz_prepare(sm.sw, sweep));           // the sweeps run inside a graph capture: no allocation there
     return PAMG_OK;
 }
 
@@ -681,6 +718,7 @@ int pamg_solver_set_ne_smoother(pamg_solver_t S, int level, int which, int kind,
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
     hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    if (sm.sw) pamg_schwarz_destroy(sm.sw);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep;
     sm.At = kind == PAMG_SMOOTH_GS_NE ? nullptr : At;

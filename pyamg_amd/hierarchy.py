@@ -71,7 +71,7 @@ class SmootherSpec:
 
     kind: 'jacobi' | 'gauss_seidel' | 'sor' | 'polynomial' | 'block_jacobi' |
           'block_gauss_seidel' | 'cf_jacobi' | 'fc_jacobi' | 'gauss_seidel_ne' |
-          'gauss_seidel_nr' | 'jacobi_ne' | 'none'
+          'gauss_seidel_nr' | 'jacobi_ne' | 'cf_block_jacobi' | 'fc_block_jacobi' | 'schwarz' | 'none'
     """
     kind: str
     iterations: int = 1
@@ -86,7 +86,11 @@ class SmootherSpec:
     f_iterations: int = 1
     c_iterations: int = 1
     At: Optional["SparseOp"] = None             # gauss_seidel_nr: CSR of A^T (= CSC arrays of A); jacobi_ne: same, values * omega
-    Ar: Optional["SparseOp"] = None             # normal-equation smoothers: A with sorted rows as the reference's wrapper sees it (None: the level's A is)
+    Ar: Optional["SparseOp"] = None             # normal-equation smoothers / schwarz: A with sorted rows as the reference's wrapper sees it (None: the level's A is)
+    subdomain: Optional[np.ndarray] = None      # schwarz: rows of every subdomain (sorted, unique), int32
+    subdomain_ptr: Optional[np.ndarray] = None
+    inv_subblock: Optional[np.ndarray] = None   # schwarz: inverted diagonal blocks, row-major, one after another
+    inv_subblock_ptr: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -205,6 +209,21 @@ def smoother_spec(fn, A) -> SmootherSpec:
     cv = _closure_vars(fn)
     if shown in ("gauss_seidel_ne", "gauss_seidel_nr", "jacobi_ne") and "iterations" in cv and "omega" in cv:
         return _normal_equation_spec(shown, A, int(cv["iterations"]), cv.get("sweep", "forward"), cv["omega"])
+    if shown == "schwarz" and "subdomain_ptr" in cv and "inv_subblock" in cv:
+        # smoothing.py:511-528: the closure holds what schwarz_parameters built at setup; the sweep runs on lvl.Acsr
+        return _schwarz_spec(cv["lvl"], A, int(cv["iterations"]), cv["sweep"], cv["subdomain"], cv["subdomain_ptr"],
+                             cv["inv_subblock"], cv["inv_subblock_ptr"], shown)
+    if shown == "strength_based_schwarz" and "subdomain_ptr" in cv and "lvl" in cv:
+        # smoothing.py:531-549: setup_schwarz is called at every application with the subdomains of the strength matrix;
+        # the inverted blocks are what schwarz_parameters computes on first use (and caches on lvl.Acsr)
+        from .relaxation import schwarz_parameters
+        lvl = cv["lvl"]
+        Acsr = getattr(lvl, "Acsr", None)
+        if Acsr is None:
+            Acsr = A.tocsr()
+        Acsr.sort_indices()
+        sub, sptr, inv, iptr = schwarz_parameters(Acsr, cv["subdomain"], cv["subdomain_ptr"], None, None)
+        return _schwarz_spec(lvl, A, int(cv["iterations"]), cv["sweep"], sub, sptr, inv, iptr, shown, Acsr=Acsr)
     if shown == "none" and not cv:                                  # smoothing.py setup_none: def none(A, x, b): pass
         return SmootherSpec("none", iterations=0, name="None")
     if shown == "chebyshev" and "coefficients" in cv:
@@ -216,6 +235,22 @@ def smoother_spec(fn, A) -> SmootherSpec:
                             coefficients=np.asarray([cv["omega"]], dtype=np.float64),
                             name="richardson")
     raise NotImplementedError(f"smoother '{shown}' is not on the device path")
+
+
+def _schwarz_spec(lvl, A, iterations, sweep, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr, name, Acsr=None) -> SmootherSpec:
+    if A.dtype.type not in SUPPORTED_DTYPES:
+        raise NotImplementedError(f"schwarz on a {A.dtype} level is not on the device path")
+    if Acsr is None:
+        Acsr = getattr(lvl, "Acsr", None)
+    if Acsr is None:
+        raise NotImplementedError("schwarz smoother without lvl.Acsr")
+    # the sweep's operator is lvl.Acsr (sorted rows); ship it separately when the level's own rows are stored differently
+    same = A.format == "csr" and A.has_sorted_indices and A.nnz == Acsr.nnz
+    Ar = None if same else sparse_op(Acsr)
+    return SmootherSpec("schwarz", iterations, 1.0, sweep, name=name, Ar=Ar,
+                        subdomain=_as_int32(subdomain, "subdomain"), subdomain_ptr=_as_int32(subdomain_ptr, "subdomain_ptr"),
+                        inv_subblock=np.ascontiguousarray(inv_subblock, dtype=A.dtype),
+                        inv_subblock_ptr=_as_int32(inv_subblock_ptr, "inv_subblock_ptr"))
 
 
 def _inv_or_zero(D):
@@ -363,6 +398,9 @@ def _put_sm(d, key, s: Optional[SmootherSpec]):
         _put_op(d, f"{key}.At", s.At)
     if s.Ar is not None:
         _put_op(d, f"{key}.Ar", s.Ar)
+    if s.subdomain_ptr is not None:
+        d[f"{key}.subdomain"], d[f"{key}.subdomain_ptr"] = s.subdomain, s.subdomain_ptr
+        d[f"{key}.inv_subblock"], d[f"{key}.inv_subblock_ptr"] = s.inv_subblock, s.inv_subblock_ptr
     if s.Fpts is not None:
         d[f"{key}.Fpts"] = np.asarray(s.Fpts, dtype=np.int32)
         d[f"{key}.Cpts"] = np.asarray(s.Cpts, dtype=np.int32)
@@ -378,6 +416,9 @@ def _get_sm(z, key) -> Optional[SmootherSpec]:
                       z[f"{key}.Dinv"] if f"{key}.Dinv" in z else None, int(num[1]), str(z[f"{key}.name"]))
     sm.At = _get_op(z, f"{key}.At")
     sm.Ar = _get_op(z, f"{key}.Ar")
+    if f"{key}.subdomain_ptr" in z:
+        sm.subdomain, sm.subdomain_ptr = z[f"{key}.subdomain"], z[f"{key}.subdomain_ptr"]
+        sm.inv_subblock, sm.inv_subblock_ptr = z[f"{key}.inv_subblock"], z[f"{key}.inv_subblock_ptr"]
     if f"{key}.Fpts" in z:
         sm.Fpts, sm.Cpts = z[f"{key}.Fpts"], z[f"{key}.Cpts"]
         sm.f_iterations, sm.c_iterations = (int(v) for v in z[f"{key}.fc_iters"])

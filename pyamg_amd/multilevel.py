@@ -190,6 +190,18 @@ def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype, aux):
                                                    capi.ptr(F), F.size, capi.ptr(Cp), Cp.size),
                    f"pamg_solver_set_cf_smoother({s.kind})")
         return
+    if s.kind == "schwarz":
+        Ar = None
+        if getattr(s, "Ar", None) is not None:
+            Ar = DeviceMatrix(s.Ar)
+            aux.append(Ar)                      # borrowed by the solver: keep it alive
+        Sp, Sj = np.ascontiguousarray(s.subdomain_ptr, dtype=np.int32), np.ascontiguousarray(s.subdomain, dtype=np.int32)
+        Tp, Tx = np.ascontiguousarray(s.inv_subblock_ptr, dtype=np.int32), np.ascontiguousarray(s.inv_subblock, dtype=dtype)
+        capi.check(lib.pamg_solver_set_schwarz_smoother(S, level, which, int(s.iterations), capi.SWEEP.get(s.sweep, 0),
+                                                        Ar.handle if Ar else None, Sp.size - 1, capi.ptr(Sp), capi.ptr(Sj),
+                                                        capi.ptr(Tp), capi.ptr(Tx)),
+                   "pamg_solver_set_schwarz_smoother")
+        return
     if s.kind in ("cf_block_jacobi", "fc_block_jacobi"):
         F = np.ascontiguousarray(s.Fpts, dtype=np.int32)
         Cp = np.ascontiguousarray(s.Cpts, dtype=np.int32)

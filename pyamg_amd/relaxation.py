@@ -20,7 +20,7 @@ from .hierarchy import sparse_op
 from .multilevel import DeviceMatrix
 
 __all__ = ["make_system", "jacobi", "gauss_seidel", "sor", "polynomial", "block_jacobi",
-           "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_indexed", "cf_jacobi", "fc_jacobi", "cf_block_jacobi", "fc_block_jacobi", "gauss_seidel_ne",
+           "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_indexed", "schwarz", "schwarz_parameters", "cf_jacobi", "fc_jacobi", "cf_block_jacobi", "fc_block_jacobi", "gauss_seidel_ne",
            "gauss_seidel_nr", "jacobi_ne"]
 
 
@@ -156,6 +156,82 @@ def jacobi_indexed(A, x, b, indices, iterations=1, omega=1.0):
     if (indices.min(initial=0) < 0) or (indices.max(initial=-1) > A.shape[0] - 1):
         raise ValueError("indices must range from 0, ..., N-1")       # relaxation.py:1108-1109
     _indexed_sweeps(A, x, b, [(indices, 1)], iterations, omega)
+
+
+def _subdomain_blocks(A, subdomain, subdomain_ptr):
+    """amg_core.extract_subblocks (relaxation.h:1332-1418): the dense diagonal block A[S_d, S_d] of every subdomain,
+    row-major, one after another (A's rows and every S_d sorted)."""
+    sizes = np.diff(subdomain_ptr)
+    ptr = np.zeros(subdomain_ptr.shape, dtype=A.indices.dtype)
+    ptr[1:] = np.cumsum(sizes * sizes)
+    out = np.zeros((ptr[-1],), dtype=A.dtype)
+    for d in range(len(sizes)):
+        rows = subdomain[subdomain_ptr[d]:subdomain_ptr[d + 1]]
+        m = rows.size
+        blk = out[ptr[d]:ptr[d + 1]].reshape(m, m)
+        for r, row in enumerate(rows):
+            cols = A.indices[A.indptr[row]:A.indptr[row + 1]]
+            at = np.searchsorted(rows, cols)
+            hit = (at < m) & (rows[np.minimum(at, m - 1)] == cols)
+            blk[r, at[hit]] = A.data[A.indptr[row]:A.indptr[row + 1]][hit]
+    return out, ptr
+
+
+def schwarz_parameters(A, subdomain=None, subdomain_ptr=None, inv_subblock=None, inv_subblock_ptr=None):
+    """The subdomains and inverted diagonal blocks of Schwarz relaxation (reference: relaxation.py:1002-1075): by default
+    one subdomain per row, its sparsity pattern; every block inverted by LAPACK's gelss with the reference's rank
+    tolerance; cached on the matrix as ``A.schwarz_parameters`` like the reference caches it."""
+    import scipy.linalg as la
+    if hasattr(A, "schwarz_parameters"):
+        if subdomain is not None and subdomain_ptr is not None:
+            if np.array(A.schwarz_parameters[0] == subdomain).all() and np.array(A.schwarz_parameters[1] == subdomain_ptr).all():
+                return A.schwarz_parameters
+        else:
+            return A.schwarz_parameters
+    if subdomain is None or subdomain_ptr is None:
+        subdomain_ptr = A.indptr.copy()
+        subdomain = A.indices.copy()
+    if inv_subblock is None or inv_subblock_ptr is None:
+        inv_subblock, inv_subblock_ptr = _subdomain_blocks(A, subdomain, subdomain_ptr)
+        c = np.dtype(A.dtype).char.lower()
+        cond = 1e3 * np.finfo(np.single).eps if c == "f" else 1e6 * np.finfo(np.double).eps       # util/params.py set_tol
+        gelss, = la.get_lapack_funcs(["gelss"], (np.ones((1,), dtype=A.dtype),))
+        sizes = np.diff(subdomain_ptr)
+        for d in range(len(sizes)):
+            m = sizes[d]
+            j0, j1 = inv_subblock_ptr[d], inv_subblock_ptr[d + 1]
+            res = gelss(inv_subblock[j0:j1].reshape(m, m), np.eye(m, m, dtype=A.dtype), cond=cond, overwrite_a=True, overwrite_b=True)
+            inv_subblock[j0:j1] = np.ravel(res[1])
+    A.schwarz_parameters = (subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr)
+    return A.schwarz_parameters
+
+
+def schwarz(A, x, b, iterations=1, subdomain=None, subdomain_ptr=None, inv_subblock=None, inv_subblock_ptr=None,
+            sweep="forward"):
+    """Multiplicative overlapping Schwarz, in place (reference: relaxation.py:157-262)."""
+    from . import amg_core
+    A, x, b = make_system(A, x, b, formats=["csr"])
+    A.sort_indices()
+    if subdomain is None and inv_subblock is not None:
+        raise ValueError("inv_subblock must be None if subdomain is None")
+    subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr = schwarz_parameters(A, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr)
+    nsub = subdomain_ptr.shape[0] - 1
+    if sweep == "forward":
+        row_start, row_stop, row_step = 0, nsub, 1
+    elif sweep == "backward":
+        row_start, row_stop, row_step = nsub - 1, -1, -1
+    elif sweep == "symmetric":
+        for _ in range(iterations):
+            schwarz(A, x, b, 1, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr, "forward")
+            schwarz(A, x, b, 1, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr, "backward")
+        return
+    else:
+        raise ValueError("valid sweep directions: 'forward', 'backward', and 'symmetric'")
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)       # noqa: E731
+    Ap, Aj, Sp, Sj, Tp = i32(A.indptr), i32(A.indices), i32(subdomain_ptr), i32(subdomain), i32(inv_subblock_ptr)
+    Tx = np.ascontiguousarray(inv_subblock, dtype=A.dtype)
+    for _ in range(iterations):
+        amg_core.overlapping_schwarz_csr(Ap, Aj, A.data, x, b, Tx, Tp, Sj, Sp, nsub, A.shape[0], row_start, row_stop, row_step)
 
 
 def gauss_seidel_indexed(A, x, b, indices, iterations=1, sweep="forward"):

@@ -210,6 +210,15 @@ def make_hierarchies():
     change_smoothers(mlc, presmoother=("gauss_seidel", {"sweep": "forward"}),
                      postsmoother=("gauss_seidel", {"sweep": "backward"}))
     hier("rs2d_cscR_splu", mlc)
+    # Schwarz smoothers: the reference's doctest configuration (relaxation.py:217-225) and the strength-based variant
+    np.random.seed(SEED)
+    A20 = pyamg.gallery.poisson((20, 20), format="csr")
+    hier("sa2d_schwarz", pyamg.smoothed_aggregation_solver(A20, B=np.ones((A20.shape[0], 1)), coarse_solver="pinv", max_coarse=50,
+                                                           presmoother="schwarz", postsmoother=("schwarz", {"sweep": "backward"})), k=5)
+    np.random.seed(SEED)
+    hier("sa2d_sbschwarz", pyamg.smoothed_aggregation_solver(A20, max_coarse=20, keep=True,
+                                                             presmoother=("strength_based_schwarz", {"sweep": "symmetric"}),
+                                                             postsmoother=("strength_based_schwarz", {"sweep": "symmetric"})), k=4)
     # CF / FC block Jacobi (relaxation.py:1271-1411, amg_core.block_jacobi_indexed) on the 2-D elasticity hierarchy:
     # the registry needs a C/F splitting per level (an AIR-style solver on a block system would bring its own; here a
     # seeded one is attached to the SA levels), the smoothers are then the reference's own bound callables
@@ -389,6 +398,55 @@ def make_kernels_indexed():
     print("kernels_indexed.npz written:", len(out), "arrays")
 
 
+def make_kernels_schwarz():
+    """amg_core.overlapping_schwarz_csr / relaxation.schwarz of the reference -> kernels_schwarz.npz (the subdomains and
+    inverted blocks are the reference's own schwarz_parameters)."""
+    import scipy.sparse as sp
+    from pyamg import amg_core
+    rng = np.random.RandomState(SEED + 23)
+    out = {}
+    G = sp.random(260, 260, density=0.03, random_state=rng, format="csr")
+    G = sp.csr_array(G + G.T + 6.0 * sp.eye_array(260))
+    G.sort_indices()
+    P = pyamg.gallery.poisson((16, 14), format="csr")
+    for tag, M in (("irr", G), ("pois", P)):
+        for dt in (np.float64, np.float32):
+            Md = sp.csr_array(M.astype(dt))
+            Md.sort_indices()
+            n = Md.shape[0]
+            x = rng.rand(n).astype(dt); b = rng.rand(n).astype(dt)
+            sub, sptr, inv, iptr = rr.schwarz_parameters(Md)
+            k = f"{tag}_{np.dtype(dt).name}"
+            out[f"{k}.indptr"], out[f"{k}.indices"], out[f"{k}.data"] = Md.indptr, Md.indices, Md.data
+            out[f"{k}.x"], out[f"{k}.b"] = x, b
+            out[f"{k}.sub"], out[f"{k}.sptr"], out[f"{k}.inv"], out[f"{k}.iptr"] = sub, sptr, inv, iptr
+            for sweep in ("forward", "backward", "symmetric"):
+                y = x.copy(); rr.schwarz(Md, y, b, iterations=2, sweep=sweep)
+                out[f"{k}.{sweep}"] = y
+            y = x.copy()
+            amg_core.overlapping_schwarz_csr(Md.indptr, Md.indices, Md.data, y, b, inv, iptr, sub, sptr, len(sptr) - 1, n, 3, n - 1, 2)
+            out[f"{k}.strided"] = y
+        if tag == "irr":
+            continue
+        # fewer, larger subdomains (two-hop neighbourhoods of every third row)
+        Md = sp.csr_array(M.astype(np.float64)); Md.sort_indices()
+        C2 = sp.csr_array(Md @ Md); C2.sort_indices()
+        rows = np.arange(0, Md.shape[0], 3)
+        sptr = np.zeros(len(rows) + 1, dtype=np.int32)
+        sptr[1:] = np.cumsum([C2.indptr[r + 1] - C2.indptr[r] for r in rows])
+        sub = np.concatenate([C2.indices[C2.indptr[r]:C2.indptr[r + 1]] for r in rows]).astype(np.int32)
+        x = rng.rand(Md.shape[0]); b = rng.rand(Md.shape[0])
+        Mc = sp.csr_array(Md.copy())
+        y = x.copy(); rr.schwarz(Mc, y, b, iterations=1, subdomain=sub, subdomain_ptr=sptr, sweep="symmetric")
+        k = f"{tag}_big"
+        out[f"{k}.indptr"], out[f"{k}.indices"], out[f"{k}.data"] = Md.indptr, Md.indices, Md.data
+        out[f"{k}.x"], out[f"{k}.b"], out[f"{k}.sub"], out[f"{k}.sptr"] = x, b, sub, sptr
+        out[f"{k}.inv"], out[f"{k}.iptr"] = Mc.schwarz_parameters[2], Mc.schwarz_parameters[3]
+        out[f"{k}.symmetric"] = y
+    np.savez_compressed(HERE / "kernels_schwarz.npz", **out)
+    print("kernels_schwarz.npz written:", len(out), "arrays")
+
+
 def make_kernels_gsidx():
     """amg_core.gauss_seidel_indexed / relaxation.gauss_seidel_indexed of the reference -> kernels_gsidx.npz"""
     import scipy.sparse as sp
@@ -507,6 +565,10 @@ if __name__ == "__main__" and "--indexed-only" in sys.argv:
     make_kernels_indexed()
     sys.exit(0)
 
+if __name__ == "__main__" and "--schwarz-only" in sys.argv:
+    make_kernels_schwarz()
+    sys.exit(0)
+
 if __name__ == "__main__" and "--gsidx-only" in sys.argv:
     make_kernels_gsidx()
     sys.exit(0)
@@ -531,6 +593,7 @@ if __name__ == "__main__":
         make_kernels_indexed()
         make_kernels_blockidx()
         make_kernels_gsidx()
+        make_kernels_schwarz()
         make_kernels_ne()
     make_hierarchies()
     save_accel()

@@ -483,6 +483,37 @@ def test_indexed_jacobi_bit_exact():
         gcore.jacobi_indexed(Ap, Aj, Ax, x.copy(), b, idx.astype(np.int64), np.array([0.7], dtype=Ax.dtype))
 
 
+def test_schwarz_bit_exact():
+    """overlapping_schwarz_csr (Layer 1 twin) and relaxation.schwarz: subdomains of one dependency level side by side, one
+    wave each, the reference's arithmetic order -- vs the reference's outputs in kernels_schwarz.npz, bit for bit: all
+    sweep directions, a strided sweep, large two-hop subdomains, f64 and f32."""
+    from conftest import GOLDEN
+    import pyamg_amd.amg_core as gcore
+    z = np.load(GOLDEN / "kernels_schwarz.npz")
+    keys = sorted({k.split(".")[0] for k in z.files})
+    assert len(keys) == 5
+    for k in keys:
+        Ap, Aj, Ax = z[f"{k}.indptr"].astype(np.int32), z[f"{k}.indices"].astype(np.int32), z[f"{k}.data"]
+        n = Ap.size - 1
+        M = sp.csr_array((Ax, Aj, Ap), shape=(n, n))
+        x, b, sub, sptr, inv, iptr = (z[f"{k}.{t}"] for t in ("x", "b", "sub", "sptr", "inv", "iptr"))
+        if k.endswith("_big"):
+            y = x.copy(); grelax.schwarz(M, y, b, iterations=1, subdomain=sub, subdomain_ptr=sptr, sweep="symmetric")
+            assert np.array_equal(y, z[f"{k}.symmetric"]), k
+            continue
+        for sweep in ("forward", "backward", "symmetric"):
+            y = x.copy(); grelax.schwarz(sp.csr_array(M.copy()), y, b, iterations=2, sweep=sweep)
+            assert np.array_equal(y, z[f"{k}.{sweep}"]), (k, sweep)
+        y = x.copy()
+        gcore.overlapping_schwarz_csr(Ap, Aj, Ax, y, b, inv, iptr.astype(np.int32), sub.astype(np.int32), sptr.astype(np.int32),
+                                      len(sptr) - 1, n, 3, n - 1, 2)
+        assert np.array_equal(y, z[f"{k}.strided"]), k
+    with pytest.raises(ValueError):
+        grelax.schwarz(M, x.copy(), b, inv_subblock=inv)
+    with pytest.raises(ValueError):
+        grelax.schwarz(M, x.copy(), b, sweep="sideways")
+
+
 def test_indexed_gauss_seidel_bit_exact():
     """gauss_seidel_indexed (Layer 1 twin and the relaxation wrapper): the listed rows in list order as a forward sweep of
     the renumbered operator -- vs the reference's outputs in kernels_gsidx.npz, bit for bit: arbitrary order, rows listed

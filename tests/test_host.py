@@ -133,9 +133,18 @@ def test_extract_reads_back_smoother_parameters():
                                             postsmoother="block_jacobi")
     s2 = H.extract(ml2)
     assert s2.levels[0].pre.kind == "gauss_seidel" and s2.levels[0].post.kind == "jacobi"
-    ml3 = pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother="schwarz", postsmoother="schwarz")
+    # Schwarz: the subdomains and inverted blocks are the arrays the reference's setup built (closure cells), and the
+    # sweep's operator is lvl.Acsr -- shipped separately where the level's own storage differs (BSR(1,1) SA levels)
+    ml3 = pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother="schwarz", postsmoother=("schwarz", {"sweep": "backward"}))
+    s3 = H.extract(ml3)
+    for L, lv in zip(s3.levels[:-1], ml3.levels[:-1]):
+        sub, sptr, inv, iptr = lv.Acsr.schwarz_parameters
+        assert L.pre.kind == "schwarz" and L.post.sweep == "backward"
+        assert np.array_equal(L.pre.subdomain, sub) and np.array_equal(L.pre.inv_subblock, inv)
+        assert (L.pre.Ar is None) == (lv.A.format == "csr")
+    ml3g = pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother=("gmres", {"maxiter": 2}), postsmoother="schwarz")
     with pytest.raises(NotImplementedError):
-        H.extract(ml3)
+        H.extract(ml3g)
     ml4 = pyamg.smoothed_aggregation_solver(A, max_coarse=10, coarse_solver="cg")
     with pytest.raises(NotImplementedError):
         H.extract(ml4)
