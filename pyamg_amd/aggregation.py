@@ -495,6 +495,17 @@ def device_products():
 
 
 # --------------------------------------------------------------------------- patching a reference package
+def _rho_or_reference(reference_fn):
+    """the patched ``approximate_spectral_radius``: float64 sparse matrices go to the device; anything else the reference
+    accepts -- a LinearOperator whose matvec is host code (rho_block_D_inv_A), dense arrays, float32 / complex -- stays
+    with the reference function that was patched out"""
+    def approximate_spectral_radius_(A, *args, **kwargs):
+        if sp.issparse(A) and A.dtype == np.float64:
+            return approximate_spectral_radius(A, *args, **kwargs)
+        return reference_fn(A, *args, **kwargs)
+    return approximate_spectral_radius_
+
+
 @contextlib.contextmanager
 def device_setup(pyamg, prolongation=True, products=True):
     """Run the setup pieces above inside a reference package the CALLER imported::
@@ -525,8 +536,9 @@ def device_setup(pyamg, prolongation=True, products=True):
         if not prolongation and name.endswith("prolongation_smoother"):
             continue
         if hasattr(m, name):
-            targets.append((m, name, getattr(m, name)))
-            setattr(m, name, fn)
+            old = getattr(m, name)
+            targets.append((m, name, old))
+            setattr(m, name, _rho_or_reference(old) if name == "approximate_spectral_radius" else fn)
     try:
         with (device_products() if products else contextlib.nullcontext()):
             yield

@@ -92,7 +92,12 @@ def test_device_setup_patches_and_restores():
     with ag.device_setup(pyamg):
         assert agg.jacobi_prolongation_smoother is ag.jacobi_prolongation_smoother
         assert agg.richardson_prolongation_smoother is ag.richardson_prolongation_smoother
-        assert smoothing.approximate_spectral_radius is ag.approximate_spectral_radius
+        assert smoothing.approximate_spectral_radius is not before[2]
+        # operands the device path does not take stay with the reference function (a LinearOperator's matvec is host code)
+        from scipy.sparse.linalg import aslinearoperator
+        np.random.seed(0)
+        rho = smoothing.approximate_spectral_radius(aslinearoperator(sp.csr_array(np.diag([1.0, 2.0, 3.0]))))
+        assert abs(rho - 3.0) < 1e-12
     assert before == (agg.jacobi_prolongation_smoother, agg.richardson_prolongation_smoother, smoothing.approximate_spectral_radius)
     with pytest.raises(RuntimeError):
         with ag.device_setup(pyamg):
