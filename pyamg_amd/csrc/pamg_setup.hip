@@ -779,8 +779,11 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
         SPG_CHECK(hipMalloc((void **)&d_long, sizeof(int) * (size_t)nlong));
         SPG_CHECK(hipMalloc((void **)&d_lohi, sizeof(int) * 2 * (size_t)nlong + 16));
         SPG_CHECK(hipMemcpy(d_long, long_rows.data(), sizeof(int) * (size_t)nlong, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(spg_minmax_kernel, dim3(nlong), dim3(BLK), 0, 0, (const int *)d_long, A->d_p, A->d_j, B->d_p, B->d_j, d_lohi);
-        SPG_CHECK(hipGetLastError());
+        for (int off = 0; off < nlong; off += (1 << 22)) {
+            hipLaunchKernelGGL(spg_minmax_kernel, dim3(std::min(1 << 22, nlong - off)), dim3(BLK), 0, 0, (const int *)d_long + off, A->d_p, A->d_j, B->d_p,
+                               B->d_j, d_lohi + 2 * off);
+            SPG_CHECK(hipGetLastError());
+        }
         lohi.resize(2 * (size_t)nlong);
         SPG_CHECK(hipMemcpy(lohi.data(), d_lohi, sizeof(int) * 2 * (size_t)nlong, hipMemcpyDeviceToHost));
         // a batch holds whole rows of B: the longest one must fit
@@ -810,9 +813,25 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
     a.cb = col_block; a.keep = keep_zeros ? 1 : 0;
     SpgArgs al = a;
     al.ids = d_ids + ns;
-    if (ns) hipLaunchKernelGGL((spg_kernel<false>), dim3(ns), dim3(BLK), spg_lds(false), 0, a);
-    if (nl) hipLaunchKernelGGL((spg_long_kernel<false>), dim3(nl), dim3(BLK), 0, 0, al);
-    SPG_CHECK(hipGetLastError());
+    // a launch may not exceed 2^32 threads (grid x block): coarse Galerkin products have tens of millions of window
+    // tasks (measured: 33 M at 384^3, and a single launch silently ran only the first 2^24), so tasks go out in slices
+    auto launch_tasks = [&](bool numeric) -> int {
+        constexpr int SLICE = 1 << 22;
+        for (int off = 0; off < ns; off += SLICE) {
+            SpgArgs s1 = a;
+            s1.ids = a.ids + off;
+            if (numeric) hipLaunchKernelGGL((spg_kernel<true>), dim3(std::min(SLICE, ns - off)), dim3(BLK), spg_lds(true), 0, s1);
+            else hipLaunchKernelGGL((spg_kernel<false>), dim3(std::min(SLICE, ns - off)), dim3(BLK), spg_lds(false), 0, s1);
+        }
+        for (int off = 0; off < nl; off += SLICE) {
+            SpgArgs s1 = al;
+            s1.ids = al.ids + off;
+            if (numeric) hipLaunchKernelGGL((spg_long_kernel<true>), dim3(std::min(SLICE, nl - off)), dim3(BLK), 0, 0, s1);
+            else hipLaunchKernelGGL((spg_long_kernel<false>), dim3(std::min(SLICE, nl - off)), dim3(BLK), 0, 0, s1);
+        }
+        return (int)hipGetLastError();
+    };
+    SPG_CHECK(launch_tasks(false));
     std::vector<int> hp;
     int64_t nnz = 0;
     SPG_CHECK(counts_to_ptr(m, d_rowcount, hp, nnz));
@@ -828,11 +847,10 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
     if (nt) SPG_CHECK(hipMemcpy(d_obase, ob.data(), sizeof(int) * (size_t)nt, hipMemcpyHostToDevice));
     if (nl) SPG_CHECK(hipMalloc((void **)&d_seq, sizeof(int) * ((size_t)nnz + 8)));
     a.Cj = al.Cj = C->d_j; a.Cx = al.Cx = C->d_x; al.Cseq = d_seq;
-    if (ns) hipLaunchKernelGGL((spg_kernel<true>), dim3(ns), dim3(BLK), spg_lds(true), 0, a);
-    if (nl) hipLaunchKernelGGL((spg_long_kernel<true>), dim3(nl), dim3(BLK), 0, 0, al);
-    SPG_CHECK(hipGetLastError());
-    if (nlong) {
-        hipLaunchKernelGGL(spg_reorder_kernel, dim3((unsigned)nlong), dim3(BLK), 0, 0, (const int *)d_long, (const int *)C->d_p, C->d_j, C->d_x, d_seq);
+    SPG_CHECK(launch_tasks(true));
+    for (int off = 0; off < nlong; off += (1 << 22)) {
+        hipLaunchKernelGGL(spg_reorder_kernel, dim3((unsigned)std::min(1 << 22, nlong - off)), dim3(BLK), 0, 0, (const int *)d_long + off, (const int *)C->d_p,
+                           C->d_j, C->d_x, d_seq);
         SPG_CHECK(hipGetLastError());
     }
     SPG_CHECK(hipMemcpy(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost));
