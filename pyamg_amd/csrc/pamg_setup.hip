@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "pamg_common.h"
+#include "pamg_spg_plan.h"
 
 struct pamg_csr_s {
     int64_t m = 0, n = 0, nnz = 0;
@@ -48,8 +49,6 @@ struct pamg_arnoldi_s {
 namespace pamg {
 namespace {
 
-constexpr int SPG_CAP = 4096;         // products per row range (LDS: 8 B key + 8 B value each)
-constexpr int SPG_ROWS = 1024;        // rows per range (10 bits of the key)
 constexpr int ARN_GRID = 2048;
 
 __device__ __forceinline__ double wsum(double v)
@@ -255,8 +254,6 @@ __global__ __launch_bounds__(BLK) void spg_kernel(const SpgArgs a)
 // products of the window); a batch is sorted by (column, sequence), and the run of each column continues that column's
 // accumulator -- one lane per run, so the additions of a column happen in sequence order across batches.  The first
 // touch of a column is remembered (its row-wide sequence number) for the reorder pass.
-constexpr int SPL_CAP = 2048;        // products per batch
-constexpr int SPL_WIN = 2048;        // columns per window
 constexpr int SPL_PER = SPL_CAP / BLK;
 
 __global__ __launch_bounds__(BLK) void spg_minmax_kernel(const int *rows, const int *Ap, const int *Aj, const int *Bp, const int *Bj,
@@ -708,31 +705,6 @@ int counts_to_ptr(int m, const int *d_cnt, std::vector<int> &hp, int64_t &nnz)
     return PAMG_OK;
 }
 
-// Tasks of the product, in row order: runs of whole rows while their products fit SPG_CAP; a row with more products
-// becomes windows of SPL_WIN columns over the span of its product columns (lohi: per long row, from the device).
-void plan_product(int m, const std::vector<int> &nprod, const std::vector<int> &long_rows, const std::vector<int> &lohi,
-                  std::vector<int4> &tasks)
-{
-    tasks.clear();
-    tasks.reserve((size_t)m / 64 + 16);
-    size_t nl = 0;
-    int r = 0;
-    while (r < m) {
-        if (nprod[r] > SPG_CAP) {
-            const int lo = lohi[2 * nl], hi = lohi[2 * nl + 1];
-            ++nl;
-            for (int64_t w = lo; w <= hi; w += SPL_WIN) tasks.push_back(make_int4(r, r + 1, (int)w, (int)std::min<int64_t>(w + SPL_WIN, (int64_t)hi + 1)));
-            ++r;
-            continue;
-        }
-        int acc = 0, r1 = r;
-        while (r1 < m && r1 - r < SPG_ROWS && nprod[r1] <= SPG_CAP && acc + nprod[r1] <= SPG_CAP) { acc += nprod[r1]; ++r1; }
-        tasks.push_back(make_int4(r, r1, 0, INT_MAX));
-        r = r1;
-    }
-    (void)long_rows;
-}
-
 size_t spg_lds(bool numeric)
 {
     return (size_t)(numeric ? 16 : 8) * SPG_CAP + sizeof(double) * BLK + sizeof(int) * (size_t)(4 * BLK + 2 + 2 * SPG_ROWS + 2);
@@ -795,7 +767,12 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
         if (maxlen > SPL_CAP) SPG_CHECK(PAMG_E_UNSUPPORTED);
     }
     std::vector<int4> tasks;
-    plan_product(m, nprod, long_rows, lohi, tasks);
+    {
+        std::vector<SpgTask> plan;
+        spg_plan(m, nprod, lohi, plan);                  // pamg_spg_plan.h
+        tasks.reserve(plan.size());
+        for (const SpgTask &t : plan) tasks.push_back(make_int4(t.row0, t.row1, t.col0, t.col1));
+    }
     const int nt = (int)tasks.size();
     std::vector<int> ids_short, ids_long;
     for (int t = 0; t < nt; ++t) (tasks[t].w == INT_MAX && tasks[t].z == 0 ? ids_short : ids_long).push_back(t);
@@ -816,7 +793,7 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
     // a launch may not exceed 2^32 threads (grid x block): coarse Galerkin products have tens of millions of window
     // tasks (measured: 33 M at 384^3, and a single launch silently ran only the first 2^24), so tasks go out in slices
     auto launch_tasks = [&](bool numeric) -> int {
-        constexpr int SLICE = 1 << 22;
+        constexpr int SLICE = SPG_SLICE;
         for (int off = 0; off < ns; off += SLICE) {
             SpgArgs s1 = a;
             s1.ids = a.ids + off;

@@ -1,8 +1,13 @@
 """CPU tests of the setup-phase host logic (pyamg_amd/aggregation.py): the restart loop of approximate_spectral_radius
 with a NumPy stand-in that has the semantics of the device Arnoldi (pamg_arnoldi_*: all steps are run, the process is
 truncated at the first breakdown, the restart vector stays with the process), checked against the reference
-(oracle/_ref); and the patching of a reference package by device_setup().  No device work here."""
+(oracle/_ref); the patching of a reference package by device_setup(); and the order-exact sparse product: the host
+task plan (csrc/pamg_spg_plan.h) replayed on the CPU by tests/spg_emul.cpp the way the kernels consume it, against
+SciPy's `A @ B` -- the same arrays, stored order included.  No device work here."""
+import ctypes
+import subprocess
 import warnings
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -121,3 +126,127 @@ def test_argument_checks_need_no_device():
         ag.jacobi_prolongation_smoother(sp.csr_array(np.eye(3)), sp.csr_array(np.eye(3)), None, None, filter_entries=True)
     with pytest.raises(ValueError):
         ag.jacobi_prolongation_smoother(sp.csr_array(np.eye(3)), sp.csr_array(np.eye(3)), None, None, weighting="nope")
+
+
+# --------------------------------------------------------------------------- sparse product: plan + CPU replay
+HERE = Path(__file__).resolve().parent
+
+
+@pytest.fixture(scope="module")
+def spg():
+    out = HERE / "build"
+    out.mkdir(exist_ok=True)
+    so = out / "spg_emul.so"
+    src = HERE / "spg_emul.cpp"
+    hdr = HERE.parent / "pyamg_amd" / "csrc" / "pamg_spg_plan.h"
+    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def _replay(lib, A, B, col_block=1, keep=0):
+    A, B = sp.csr_array(A), sp.csr_array(B)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)       # noqa: E731
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)       # noqa: E731
+    Ap, Aj, Bp, Bj = i32(A.indptr), i32(A.indices), i32(B.indptr), i32(B.indices)
+    Ax, Bx = np.ascontiguousarray(A.data, dtype=np.float64), np.ascontiguousarray(B.data, dtype=np.float64)
+    cap = int((A @ sp.csr_array((np.ones(B.nnz), Bj, Bp), shape=B.shape)).nnz + 16) if A.nnz and B.nnz else 16
+    cap = max(cap, int(np.sum(np.diff(Bp)[Aj])) + 16)
+    Cp, Cj, Cx = np.zeros(A.shape[0] + 1, dtype=np.int32), np.zeros(cap, dtype=np.int32), np.zeros(cap)
+    stats = np.zeros(4, dtype=np.int64)
+    rc = lib.spg_emul_f64(A.shape[0], B.shape[1], p(Ap), p(Aj), p(Ax), p(Bp), p(Bj), p(Bx), col_block, keep, p(Cp), p(Cj), p(Cx),
+                          ctypes.c_int64(cap), p(stats))
+    assert rc == 0, rc
+    nnz = Cp[-1]
+    return sp.csr_array((Cx[:nnz], Cj[:nnz], Cp), shape=(A.shape[0], B.shape[1])), stats
+
+
+def _shuffled(M, rng):
+    M = sp.csr_array(M).copy()
+    for i in range(M.shape[0]):
+        lo, hi = M.indptr[i], M.indptr[i + 1]
+        q = rng.permutation(hi - lo)
+        M.indices[lo:hi], M.data[lo:hi] = M.indices[lo:hi][q], M.data[lo:hi][q]
+    M.has_sorted_indices = False
+    return M
+
+
+def _same_arrays(C, ref):
+    assert C.nnz == ref.nnz and np.array_equal(C.indptr, ref.indptr)
+    assert np.array_equal(C.indices, ref.indices) and np.array_equal(np.ravel(C.data), np.ravel(ref.data))
+
+
+def test_product_replay_is_scipys_array(spg):
+    lim = (ctypes.c_int * 5)()
+    spg.spg_emul_limits(lim)
+    assert lim[4] * 256 < 2 ** 32                      # a launch slice stays below the 2^32-thread limit
+    rng = np.random.default_rng(21)
+    for (m, k, n, da, db) in ((300, 200, 250, 0.05, 0.05), (1, 1, 1, 1.0, 1.0), (2000, 1500, 1800, 0.004, 0.006)):
+        A = _shuffled(sp.random_array((m, k), density=da, random_state=rng, format="csr"), rng)
+        B = _shuffled(sp.random_array((k, n), density=db, random_state=rng, format="csr"), rng)
+        C, st = _replay(spg, A, B)
+        _same_arrays(C, A @ B)
+        assert st[1] == 0
+    # exact cancellations are dropped like SciPy drops them
+    A = sp.csr_array(np.array([[1.0, -1.0, 0.0], [2.0, 0.0, 1.0], [0.0, 0.0, 0.0]]))
+    B = sp.csr_array(np.array([[3.0, 1.0], [3.0, 0.0], [-6.0, 5.0]]))
+    C, st = _replay(spg, A, B)
+    _same_arrays(C, A @ B)
+    assert st[3] == 2
+
+
+def test_product_replay_long_rows(spg):
+    """rows beyond 4096 products: windows of 2048 columns, batches cut by the prefix of in-window products, accumulators
+    continued across batches, SciPy's emission order restored over the finished row"""
+    rng = np.random.default_rng(22)
+    m, k, n = 40, 3000, 9000
+    A = sp.random_array((m, k), density=0.002, random_state=rng, format="lil")
+    A[3, :] = rng.standard_normal(k)
+    A[20, ::2] = rng.standard_normal(k // 2)
+    A = _shuffled(A.tocsr(), rng)
+    B = _shuffled(sp.random_array((k, n), density=0.003, random_state=rng, format="csr"), rng)
+    C, st = _replay(spg, A, B)
+    _same_arrays(C, A @ B)
+    assert st[1] == 2 and st[2] >= 2 * (n // 2048)      # two long rows, several windows each
+    # the shape of a coarse Galerkin product: every row long, few distinct columns, +-1 values (cancellations)
+    A2 = _shuffled(sp.random_array((30, 900), density=0.6, random_state=rng, format="csr"), rng)
+    A2.data = np.round(A2.data * 4.0)
+    A2.eliminate_zeros()
+    B2 = sp.random_array((900, 300), density=0.05, random_state=rng, format="csr")
+    B2.data = np.sign(B2.data - 0.5)
+    C2, st2 = _replay(spg, A2, B2)
+    _same_arrays(C2, A2 @ B2)
+    assert st2[1] == 30 and st2[3] > 0
+    # a batch that must be cut: B rows of ~1500 in-window entries, 256 candidate entries per batch
+    A3 = sp.csr_array(np.ones((2, 40)))
+    B3 = sp.random_array((40, 1900), density=0.8, random_state=rng, format="csr")
+    C3, st3 = _replay(spg, A3, B3)
+    _same_arrays(C3, A3 @ B3)
+
+
+def test_product_replay_true_blocks(spg):
+    """BSR operands with true blocks: the scalar view with whole blocks in FORWARD order of first touch and the zeros inside
+    them kept is what SciPy's bsr_matmat stores"""
+    rng = np.random.default_rng(23)
+    nb, ncb = 60, 12
+    pat = sp.random_array((nb, nb), density=0.08, random_state=rng, format="csr")
+    Ab = sp.bsr_array(sp.kron(pat + pat.T + 4.0 * sp.eye_array(nb), np.array([[2.0, 0.0], [0.5, 3.0]]), format="bsr"), blocksize=(2, 2))
+    Pk = sp.bsr_array(sp.kron(sp.random_array((nb, ncb), density=0.15, random_state=rng, format="csr"), rng.standard_normal((2, 3)), format="bsr"),
+                      blocksize=(2, 3))
+    ref = Ab @ Pk
+
+    def flat(M):                                         # the device's scalar view: block after block, row-major inside
+        R, Cb = M.blocksize
+        ip, ix, dat = [0], [], []
+        for I in range(M.shape[0] // R):
+            for r in range(R):
+                for p in range(M.indptr[I], M.indptr[I + 1]):
+                    ix.extend(M.indices[p] * Cb + np.arange(Cb))
+                    dat.extend(M.data[p, r, :])
+                ip.append(len(ix))
+        return sp.csr_array((np.array(dat), np.array(ix, dtype=np.int32), np.array(ip, dtype=np.int32)), shape=M.shape)
+
+    C, _ = _replay(spg, flat(Ab), flat(Pk), col_block=3, keep=1)
+    Cb = C.tobsr(blocksize=(2, 3))
+    assert np.array_equal(Cb.indptr, ref.indptr) and np.array_equal(Cb.indices, ref.indices) and np.array_equal(Cb.data, ref.data)
+
