@@ -53,6 +53,10 @@ WORKLOADS = {
     # 16.7M rows) still fits a bench run: 384^3 = 56.6M rows (the 512^3 setup takes ~16 min and ~78 GB on the host)
     "c4": dict(grid=(384, 384, 384), smoother=CHEB,
                label="3D 7-pt Poisson 384^3 (56.6M dof) SA V-cycle, Chebyshev(3) smoother, fp64"),
+    # BASELINE configs[3] at its own size: with the device setup operators the hierarchy is a ~1.5 min build (the reference
+    # alone: ~16 min); 134 M rows, ~25 GB resident.  Not part of the default run.
+    "c4x": dict(grid=(512, 512, 512), smoother=CHEB,
+                label="3D 7-pt Poisson 512^3 (134M dof) SA V-cycle, Chebyshev(3) smoother, fp64"),
     "c4s": dict(grid=(256, 256, 256), smoother=CHEB,
                 label="3D 7-pt Poisson 256^3 SA V-cycle, Chebyshev(3) smoother, fp64"),
     # BASELINE configs[4] in miniature: 3-D linear elasticity (P1 tets on an N^3-vertex cube), BSR(3,3),
@@ -157,6 +161,7 @@ def main():
     ap.add_argument("--min-rows", type=int, default=200_000, help="shard levels with at least this many rows")
     ap.add_argument("--host-setup", action="store_true", help="build the hierarchies with the reference alone (no device setup operators)")
     ap.add_argument("--no-setup-compare", action="store_true", help="skip the second, reference-only setup of the main workload")
+    ap.add_argument("--protocol-cycles", type=int, default=10, help="cycles of the reference-protocol parity run (b = 0, x0 = rand); 0 skips it")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -401,7 +406,8 @@ def main():
         kcpu = args.cpu_cycles if args.cpu_cycles > 0 else (3 if n > 5_000_000 else 10)
         cpu, res_cpu = cpu_reference(ml, A, b, x0, kcpu)
         parity = parity_of(res_gpu, res_cpu)
-        parity["reference_protocol"] = protocol_parity(dml, ml, n)
+        if args.protocol_cycles > 0:
+            parity["reference_protocol"] = protocol_parity(dml, ml, n, k=args.protocol_cycles)
     setup_cmp = None
     if rank == 0 and world == 1 and not args.host_setup and not args.no_setup_compare and not wl.get("convdiff"):
         # the same setup by the reference alone: what the device setup operators buy, and what they change

@@ -500,7 +500,8 @@ def _rho_or_reference(reference_fn):
     accepts -- a LinearOperator whose matvec is host code (rho_block_D_inv_A), dense arrays, float32 / complex -- stays
     with the reference function that was patched out"""
     def approximate_spectral_radius_(A, *args, **kwargs):
-        if sp.issparse(A) and A.dtype == np.float64:
+        if sp.issparse(A) and A.dtype == np.float64 and A.shape[0] == A.shape[1] and \
+                (A.format != "bsr" or (A.blocksize[0] == A.blocksize[1] and A.blocksize[0] <= 8)):
             return approximate_spectral_radius(A, *args, **kwargs)
         return reference_fn(A, *args, **kwargs)
     return approximate_spectral_radius_
