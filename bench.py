@@ -8,7 +8,9 @@ A *step* is one pass of the hot path: one multigrid V-cycle on the device-reside
 followed by the convergence-check residual norm ||b - A x|| (exactly one iteration of the
 loop in pyamg/multilevel.py:558-569).  Inputs are resident in HBM when the timed region
 starts.  The hierarchy is built on the host by the reference itself (oracle/_ref = the
-reference compiled from /root/reference; the setup phase stays on the host, north star) and
+reference compiled from /root/reference; the setup phase stays on the host, north star) -- by default with
+its spectral radii, prolongation smoothing, strength filter and sparse products run through
+pyamg_amd.aggregation.device_setup (--host-setup: the reference alone; "host" reports both times) -- and
 shipped to HBM once.
 
 Default workload = BASELINE.json configs[2], the north star's problem: 3-D 7-pt Poisson 256^3,
@@ -17,7 +19,8 @@ global sequential dependency and does not shard, so with --gpus N
 workload runs N independent replicas (value = N x rate, "scaling": "weak").  The row-sharded
 path (halo exchange over RCCL, coarse levels collapsed) is measured in the same run on the
 same hierarchy with the Chebyshev(3) smoother of configs[3] and reported under "sharded".
-At N = 1 the line also carries configs[1] (2000^2, weighted Jacobi) under "extra".
+At N = 1 the line also carries, under "extra": configs[1] (2000^2, weighted Jacobi), configs[4] on one GPU (3-D
+elasticity, block GS and block Jacobi), configs[0] (the README anchor) and configs[3]'s smoother at 384^3.
 
 Prints ONE JSON line (rank 0): metric/value/unit/... + "roofline" (fine-level CSR SpMV
 kernel: algorithmic bytes / HIP-event time vs 8 TB/s) + "cpu_baseline" (the reference's own
@@ -584,6 +587,30 @@ def main():
       except Exception as e:                                    # noqa: BLE001
         log(f"configs[0] leg failed: {e!r}")
         out.setdefault("extra", {})["c1"] = {"error": repr(e)[:300]}
+      # configs[3]'s smoother at the largest size this run can afford: 384^3 Chebyshev(3) on one GPU (the hierarchy is built
+      # under device_setup in ~30 s; the reference alone needs ~5 min for it).  Last leg: if it overruns, everything above is out.
+      if args.workload == "c3":
+        try:
+            wl4 = WORKLOADS["c4"]
+            A4, ml4, ts4 = build(wl4)
+            b4, x04 = rhs(A4.shape[0])
+            t0 = time.time()
+            d4 = DeviceMultilevelSolver(ml4, device=local_rank, graph=not args.no_graph)
+            tu4 = time.time() - t0
+            w4, _, res4, _, _ = time_resident(d4, b4, x04, 10, 3)
+            ex4 = {"workload": wl4["label"], "value": round(10 / w4, 3), "unit": "cycles/s", "ms_per_step": round(w4 * 1e3 / 10, 4),
+                   "steps": 10, "host_setup_s": round(ts4, 1), "upload_s": round(tu4, 1), "levels": len(ml4.levels),
+                   "n": int(A4.shape[0]), "nnz": int(A4.nnz)}
+            if args.cpu_cycles != 0:
+                c4cpu, r4cpu = cpu_reference(ml4, A4, b4, x04, 1)
+                ex4["cpu_baseline"] = c4cpu
+                ex4["parity"] = parity_of(res4, r4cpu)
+                ex4["parity"]["reference_protocol"] = protocol_parity(d4, ml4, A4.shape[0], k=3)
+            out.setdefault("extra", {})["c4"] = ex4
+            d4.free()
+        except Exception as e:                                    # noqa: BLE001
+            log(f"configs[3] leg failed: {e!r}")
+            out.setdefault("extra", {})["c4"] = {"error": repr(e)[:300]}
 
     emit()
     if world > 1:
