@@ -471,7 +471,7 @@ def main():
         emit()
         os._exit(0)
 
-    extras_budget = float(os.environ.get("PAMG_EXTRAS_TIMEOUT", "900" if world == 1 else "600"))
+    extras_budget = float(os.environ.get("PAMG_EXTRAS_TIMEOUT", "480" if world == 1 else "600"))
     watchdog = threading.Timer(extras_budget, bail)
     watchdog.daemon = True
     watchdog.start()
