@@ -182,26 +182,22 @@ def schwarz_parameters(A, subdomain=None, subdomain_ptr=None, inv_subblock=None,
     one subdomain per row, its sparsity pattern; every block inverted by LAPACK's gelss with the reference's rank
     tolerance; cached on the matrix as ``A.schwarz_parameters`` like the reference caches it."""
     import scipy.linalg as la
-    if hasattr(A, "schwarz_parameters"):
-        if subdomain is not None and subdomain_ptr is not None:
-            if np.array(A.schwarz_parameters[0] == subdomain).all() and np.array(A.schwarz_parameters[1] == subdomain_ptr).all():
-                return A.schwarz_parameters
-        else:
-            return A.schwarz_parameters
-    if subdomain is None or subdomain_ptr is None:
-        subdomain_ptr = A.indptr.copy()
-        subdomain = A.indices.copy()
+    cached = getattr(A, "schwarz_parameters", None)
+    if cached is not None:
+        given = subdomain is not None and subdomain_ptr is not None
+        if not given or (np.array_equal(cached[0], subdomain) and np.array_equal(cached[1], subdomain_ptr)):
+            return cached                                   # same subdomains (or none asked for): what was built before
+    if subdomain is None or subdomain_ptr is None:          # default: row i's subdomain = the columns of row i
+        subdomain, subdomain_ptr = A.indices.copy(), A.indptr.copy()
     if inv_subblock is None or inv_subblock_ptr is None:
         inv_subblock, inv_subblock_ptr = _subdomain_blocks(A, subdomain, subdomain_ptr)
-        c = np.dtype(A.dtype).char.lower()
-        cond = 1e3 * np.finfo(np.single).eps if c == "f" else 1e6 * np.finfo(np.double).eps       # util/params.py set_tol
+        single = np.dtype(A.dtype).char.lower() == "f"
+        rank_tol = (1e3 * np.finfo(np.single).eps) if single else (1e6 * np.finfo(np.double).eps)    # util/params.py set_tol
         gelss, = la.get_lapack_funcs(["gelss"], (np.ones((1,), dtype=A.dtype),))
-        sizes = np.diff(subdomain_ptr)
-        for d in range(len(sizes)):
-            m = sizes[d]
-            j0, j1 = inv_subblock_ptr[d], inv_subblock_ptr[d + 1]
-            res = gelss(inv_subblock[j0:j1].reshape(m, m), np.eye(m, m, dtype=A.dtype), cond=cond, overwrite_a=True, overwrite_b=True)
-            inv_subblock[j0:j1] = np.ravel(res[1])
+        for d, m in enumerate(np.diff(subdomain_ptr)):
+            blk = inv_subblock[inv_subblock_ptr[d]:inv_subblock_ptr[d + 1]]
+            # pseudo-inverse of the block: least-squares solve against the identity, like the reference does it
+            blk[:] = np.ravel(gelss(blk.reshape(m, m), np.eye(m, m, dtype=A.dtype), cond=rank_tol, overwrite_a=True, overwrite_b=True)[1])
     A.schwarz_parameters = (subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr)
     return A.schwarz_parameters
 
