@@ -13,14 +13,19 @@ its spectral radii, prolongation smoothing, strength filter and sparse products 
 pyamg_amd.aggregation.device_setup (--host-setup: the reference alone; "host" reports both times) -- and
 shipped to HBM once.
 
-Default workload = BASELINE.json configs[2], the north star's problem: 3-D 7-pt Poisson 256^3,
-smoothed aggregation, symmetric Gauss-Seidel V(1,1), fp64.  Order-exact Gauss-Seidel has a
-global sequential dependency and does not shard, so with --gpus N > 1 this
-workload runs N independent replicas (value = N x rate, "scaling": "weak").  The row-sharded
-path (halo exchange over RCCL, coarse levels collapsed) is measured in the same run on the
-same hierarchy with the Chebyshev(3) smoother of configs[3] and reported under "sharded".
-At N = 1 the line also carries, under "extra": configs[1] (2000^2, weighted Jacobi), configs[4] on one GPU (3-D
-elasticity, block GS and block Jacobi), configs[0] (the README anchor) and configs[3]'s smoother at 384^3.
+N = 1: the workload is BASELINE.json configs[2], the north star's problem: 3-D 7-pt Poisson 256^3,
+smoothed aggregation, symmetric Gauss-Seidel V(1,1), fp64.  The line also carries, under "sharded", the
+Chebyshev(3) cycle of configs[3] on the same hierarchy run by the resident engine AND by the row-sharded C++ driver
+(pamg_dist_*, one rank, no peers: what the driver costs over the resident cycle), and under "extra": configs[1]
+(2000^2, weighted Jacobi), configs[4] on one GPU (3-D elasticity, block GS and block Jacobi), configs[0] (the README
+anchor) and configs[3] at its own size (512^3 Chebyshev(3) on one GPU; 384^3 if that fails).
+
+N > 1: order-exact Gauss-Seidel has a global sequential dependency and does not shard, so the HEADLINE
+of a multi-GPU run is configs[3], the workload the north star shards: 3-D Poisson 512^3, SA, Chebyshev(3), fine levels
+row-sharded over the N GPUs (RCCL halo exchange over xGMI overlapped with the interior rows, coarse levels collapsed),
+"scaling": "strong" -- the same problem for every N; its N = 1 point is "extra.c4" of the N = 1 line.  The hierarchy is
+built ONCE, on rank 0, and shipped to the ranks array by array (DistMultilevelSolver.from_rank0).  N independent
+replicas of the Gauss-Seidel workload are reported under "extra.replicas".
 
 Prints ONE JSON line (rank 0): metric/value/unit/... + "roofline" (fine-level CSR SpMV
 kernel: algorithmic bytes / HIP-event time vs 8 TB/s) + "cpu_baseline" (the reference's own
@@ -165,6 +170,8 @@ def main():
     ap.add_argument("--host-setup", action="store_true", help="build the hierarchies with the reference alone (no device setup operators)")
     ap.add_argument("--no-setup-compare", action="store_true", help="skip the second, reference-only setup of the main workload")
     ap.add_argument("--protocol-cycles", type=int, default=10, help="cycles of the reference-protocol parity run (b = 0, x0 = rand); 0 skips it")
+    ap.add_argument("--shard-workload", default=os.environ.get("PAMG_SHARD_WORKLOAD", "c4x"), choices=sorted(WORKLOADS),
+                    help="N > 1: the row-sharded headline workload (BASELINE configs[3] = c4x, 512^3 Chebyshev)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -190,10 +197,11 @@ def main():
         if os.environ.get("PAMG_BENCH_ONE_GPU"):
             local_rank = 0
         torch.cuda.set_device(local_rank)
+        from datetime import timedelta
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timedelta(minutes=45))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timedelta(minutes=45))
     from pyamg_amd import DeviceMultilevelSolver, _capi as capi
     from pyamg_amd.hierarchy import extract
     from tools.problems import spmv_bytes
@@ -287,19 +295,27 @@ def main():
         wall = max_over_ranks(time.perf_counter() - t0)
         return wall, e0.elapsed_ms(e1), res, xd, bd
 
+    def spmv_cpu_ms(A, v, reps=7):
+        """SciPy's serial A @ v on this host: two untimed products (page-in, allocator), then the median of `reps`"""
+        for _ in range(2):
+            A @ v
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            A @ v
+            ts.append(time.perf_counter() - t0)
+        return 1e3 * float(np.median(ts))
+
     def cpu_reference(ml, A, b, x0, kcpu):
         r = []
         t0 = time.perf_counter()
         ml.solve(b, x0=x0, tol=1e-30, maxiter=kcpu, residuals=r)
         tcpu = time.perf_counter() - t0
-        ts = time.perf_counter()
-        for _ in range(3):
-            A @ b
-        tsp = (time.perf_counter() - ts) / 3
+        tsp = spmv_cpu_ms(A, b)
         return {"value": round(kcpu / tcpu, 4), "unit": "cycles/s", "cores": 1, "kind": "reference",
                 "sample": f"{kcpu} V-cycles of the same solver/rhs by the reference (oracle/_ref, serial) in {tcpu:.1f}s; "
-                          f"fine-level A@x {tsp * 1e3:.1f} ms",
-                "spmv_ms": round(tsp * 1e3, 3)}, np.array(r)
+                          f"fine-level A@x {tsp:.1f} ms (median of 7 after 2 warm-up products)",
+                "spmv_ms": round(tsp, 3)}, np.array(r)
 
     def parity_of(res_gpu, res_cpu):
         m = min(len(res_cpu) - 1, len(res_gpu))
@@ -326,7 +342,179 @@ def main():
         rel = np.abs(g[:m] - c[:m]) / c[:m]
         return {"protocol": "b = 0, x0 = rand (seed 2022), reference residual norms after each cycle", "cycles_compared": int(m),
                 "max_rel_diff": float(rel.max()), "tolerance": "1e-10 relative, every cycle", "ok": bool(rel.max() <= 1e-10),
-                "first_last_norm": [float(c[0]), float(c[m - 1])], "cpu_s": round(tc, 1)}
+                "first_last_norm": [float(c[0]), float(c[m - 1])], "cpu_s": round(tc, 1), "cpu_cycles": int(k)}
+
+    def cpu_from_protocol(pp, A, v):
+        """the cpu_baseline of a leg whose only reference run is the protocol run (512^3: one reference cycle is ~45 s)"""
+        tsp = spmv_cpu_ms(A, v, reps=5)
+        return {"value": round(pp["cpu_cycles"] / pp["cpu_s"], 4), "unit": "cycles/s", "cores": 1, "kind": "reference",
+                "sample": f"{pp['cpu_cycles']} V-cycles of the same solver by the reference (oracle/_ref, serial) in {pp['cpu_s']:.1f}s "
+                          f"(the b = 0 / x0 = rand protocol run); fine-level A@x {tsp:.1f} ms (median of 5 after 2 warm-up products)",
+                "spmv_ms": round(tsp, 3)}
+
+    SETUP_NOTE = ("reference (oracle/_ref) alone" if args.host_setup else
+                  "reference (oracle/_ref) with pyamg_amd.aggregation.device_setup: spectral radii (Arnoldi), strength filter, "
+                  "prolongation smoothing and the Galerkin products on the GPU")
+
+    import threading
+    printed = threading.Event()
+    box = {"out": None}
+
+    def emit():
+        if rank == 0 and box["out"] is not None and not printed.is_set():
+            printed.set()
+            print(json.dumps(box["out"]), flush=True)
+
+    def start_watchdog(budget, what):
+        """whatever happens in the legs that follow (an exception on one rank, a collective that never completes on a node
+        this code has not run on yet): the line assembled so far is printed exactly once and the process ends"""
+        def bail():
+            if rank == 0 and box["out"] is not None:
+                box["out"].setdefault("notes", []).append(f"{what} exceeded {budget:.0f} s; reported without them")
+            emit()
+            os._exit(0)
+        t = threading.Timer(budget, bail)
+        t.daemon = True
+        t.start()
+        return t
+
+    # =========================================================== N > 1: the row-sharded workload is the headline
+    if world > 1:
+        from pyamg_amd.dist import DeviceOps, DistMultilevelSolver
+        wls = WORKLOADS[args.shard_workload]
+
+        def fail_line(why):
+            # a multi-GPU run that cannot produce its number still prints ONE line saying so
+            if rank == 0 and not printed.is_set():
+                printed.set()
+                print(json.dumps({"metric": "vcycle_iterations_per_sec", "value": None, "unit": "cycles/s", "n_gpus": world,
+                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                                  "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                                  "config": {"workload": wls["label"], "key": args.shard_workload}, "error": why}), flush=True)
+            os._exit(1)
+
+        budget0 = float(os.environ.get("PAMG_SHARD_TIMEOUT", "2700"))
+        wd0 = threading.Timer(budget0, lambda: fail_line(f"the sharded run did not finish within {budget0:.0f} s"))
+        wd0.daemon = True
+        wd0.start()
+        import traceback
+        _excepthook = sys.excepthook
+
+        def hook(tp, val, tb):
+            traceback.print_exception(tp, val, tb)
+            fail_line(f"rank {rank}: {val!r}"[:400])
+        sys.excepthook = hook
+        if wls["smoother"] == GS or isinstance(wls["smoother"], str):
+            raise SystemExit("--shard-workload needs a row-independent smoother (Jacobi / Chebyshev)")
+        t0 = time.time()
+        spec, n, nnz, nlev, t_setup = None, 0, 0, 0, 0.0
+        if rank == 0:
+            A, ml, t_setup = build(wls)
+            n, nnz, nlev = int(A.shape[0]), int(A.nnz), len(ml.levels)
+            spec = extract(ml)
+            log(f"sharded workload {args.shard_workload}: n={n} nnz={nnz} levels={nlev} host setup {t_setup:.1f}s (rank 0 only)")
+        meta = [n, nnz, nlev]
+        dist.broadcast_object_list(meta, src=0)
+        n, nnz, nlev = meta
+        t1 = time.time()
+        d2 = DistMultilevelSolver.from_rank0(spec, ops=DeviceOps(local_rank, np.float64), min_rows=args.min_rows)
+        t_ship = time.time() - t1
+        b, x0 = rhs(n)
+        kpar = 4
+        d2.load(b, x0)
+        res_sh = d2.iterate(kpar)                                  # parity run (and graph / communicator warm-up)
+        d2.load(b, x0)
+        d2.iterate(args.warmup, want_residuals=False)
+        barrier()
+        t0 = time.perf_counter()
+        d2.iterate(args.steps)                                     # every step ends with the all-reduced convergence-check norm
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0)
+        info = d2.native.info() if d2.native is not None else {}
+        # fine-level residual kernel on this rank's shard (interior + boundary ranges = the whole shard), HIP events
+        roofline = None
+        if rank == 0:
+            A0, p0 = d2.A[0], d2.sh.plans[0]
+            op0 = d2.sh.A[0]
+            by = 12 * op0.nnz + 4 * (p0.n_owned_s + 1) + 8 * p0.n_local_s + 8 * p0.n_owned_s + 8 * p0.n_owned_s
+            xs_, bs_, rs_ = (capi.DeviceArray(p0.n_local_s, np.float64) for _ in range(3))
+            xs_.upload(np.random.RandomState(0).rand(p0.n_local_s))
+            bs_.upload(np.random.RandomState(1).rand(p0.n_local_s))
+            for _ in range(3):
+                A0.spmv(capi.SPMV_RESID, xs_, rs_, b=bs_)
+            f0, f1 = capi.Event(), capi.Event()
+            f0.record(None)
+            for _ in range(20):
+                A0.spmv(capi.SPMV_RESID, xs_, rs_, b=bs_)
+            f1.record(None)
+            f1.synchronize()
+            ms = f0.elapsed_ms(f1) / 20
+            roofline = {"kernel": "csr_stream_kernel<double, RESID> (rank 0's row shard of the fine level, r = b - A x)", "bound": "hbm",
+                        "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                        "traffic": None, "bytes_per_launch": int(by), "ms_per_launch": round(ms, 5)}
+            for d_ in (xs_, bs_, rs_):
+                d_.free()
+        # the same cycles by the resident single-GPU engine on rank 0 (the engine whose parity with the reference the
+        # N = 1 line establishes): sharding must not change a bit of the iterates, the norms agree to all-reduce rounding
+        check = None
+        if rank == 0 and os.environ.get("PAMG_SHARD_CHECK", "1") != "0":
+            try:
+                d1 = DeviceMultilevelSolver(spec, device=local_rank, graph=not args.no_graph)
+                xd, bd = capi.DeviceArray.from_host(x0), capi.DeviceArray.from_host(b)
+                d1.load_device(xd, bd)
+                r1 = np.asarray(d1.iterate_device(kpar))
+                rel = np.abs(np.asarray(res_sh) - r1) / r1
+                check = {"against": "the resident single-GPU engine on rank 0, same hierarchy / rhs", "cycles_compared": kpar,
+                         "max_rel_diff": float(rel.max()), "tolerance": "1e-12 relative (only the all-reduced norm may differ)",
+                         "ok": bool(rel.max() <= 1e-12)}
+                d1.free(); xd.free(); bd.free()
+            except Exception as e:                                  # noqa: BLE001
+                check = {"error": repr(e)[:300]}
+        if rank == 0:
+            box["out"] = {
+                "metric": "vcycle_iterations_per_sec", "value": round(args.steps / wall, 3), "unit": "cycles/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall * 1e3 / args.steps, 4),
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": wls["label"], "key": args.shard_workload, "n": n, "nnz": nnz, "levels": nlev, "cycle": "V(1,1)",
+                           "parallelism": f"levels with >= {args.min_rows} rows row-sharded over {world} GPUs ({d2.sh.ns} levels), halo exchange "
+                                          f"({info.get('transport', 'python schedule')}) overlapped with the interior rows, coarser levels replicated; "
+                                          "hierarchy built once on rank 0 and shipped as arrays",
+                           "hierarchy_setup": SETUP_NOTE,
+                           "n1_point": "the N = 1 point of this strong-scaling curve is extra.c4 of the N = 1 line (the N = 1 headline is configs[2], "
+                                       "whose order-exact Gauss-Seidel does not shard)"},
+                "roofline": roofline, "cpu_baseline": None,
+                "parity": {"sharded_vs_resident": check, "note": "parity of the resident engine with the reference on this workload: extra.c4 of the N = 1 line"},
+                "sharded_driver": info,
+                "host": {"setup_s": round(t_setup, 1), "partition_and_ship_s": round(t_ship, 1), "cores": os.cpu_count(), "setup": SETUP_NOTE},
+                "residuals_gpu": [float(v) for v in res_sh],
+            }
+        del d2
+        wd0.cancel()
+        sys.excepthook = _excepthook
+        # extras: N independent replicas of the Gauss-Seidel workload (what does not shard)
+        wd = start_watchdog(float(os.environ.get("PAMG_EXTRAS_TIMEOUT", "600")), "the replica leg")
+        if not args.no_extras:
+            try:
+                wlr = WORKLOADS[args.workload]
+                A, ml, ts = build(wlr)
+                br, xr = rhs(A.shape[0])
+                dr = DeviceMultilevelSolver(ml, device=local_rank, graph=not args.no_graph)
+                wr, _, resr, _, _ = time_resident(dr, br, xr, args.steps, args.warmup)
+                dr.free()
+                if rank == 0:
+                    box["out"].setdefault("extra", {})["replicas"] = {
+                        "workload": wlr["label"], "value": round(world * args.steps / wr, 3), "unit": "cycles/s", "scaling": "weak",
+                        "ms_per_step": round(wr * 1e3 / args.steps, 4), "n_gpus": world,
+                        "note": f"{world} independent replicas, one per GPU (order-exact Gauss-Seidel does not shard)"}
+            except Exception as e:                                  # noqa: BLE001
+                log(f"replica leg failed on rank {rank}: {e!r}")
+                if rank == 0:
+                    box["out"].setdefault("extra", {})["replicas"] = {"error": repr(e)[:300]}
+        emit()
+        dist.barrier()
+        dist.destroy_process_group()
+        wd.cancel()
+        return box["out"]
 
     # =========================================================== main workload
     wl = WORKLOADS[args.workload]
@@ -426,7 +614,6 @@ def main():
         log(f"setup: reference alone {t_ref_setup:.1f}s, with the device setup operators {t_setup:.1f}s; {setup_cmp}")
         del A_r, ml_r
     if rank == 0:
-        replicas = world > 1
         out = {
             "metric": "vcycle_iterations_per_sec", "value": round(world * args.steps / wall, 3), "unit": "cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -434,15 +621,14 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["label"], "key": args.workload, "n": int(n), "nnz": int(A.nnz),
                        "levels": len(ml.levels), "cycle": "V(1,1)", "graph": not args.no_graph,
-                       "parallelism": "1 GPU" if not replicas else
-                       f"{world} independent replicas (order-exact Gauss-Seidel does not shard; see 'sharded')"},
+                       "parallelism": "1 GPU",
+                       "hierarchy_setup": SETUP_NOTE + ("" if args.host_setup else
+                                                        "; the CPU reference and the parity runs use this same hierarchy object"),},
             "event_ms_per_step": round(ev_ms / args.steps, 4),
             "spmv_GBps": round(achieved, 1), "spmv_pct_of_hbm_peak": round(100 * achieved / HBM_PEAK_GBPS, 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
             "host": {"setup_s": round(t_setup, 1), "upload_s": round(t_upload, 1), "cores": os.cpu_count(),
-                     "setup": "reference (oracle/_ref) alone" if args.host_setup else
-                              "reference (oracle/_ref) with pyamg_amd.aggregation.device_setup: spectral radii (Arnoldi) and prolongation smoothing on the GPU",
-                     **(setup_cmp or {})},
+                     "setup": SETUP_NOTE, **(setup_cmp or {})},
             "residuals_gpu": [float(v) for v in res_gpu],
         }
         if sweeps:
@@ -452,29 +638,12 @@ def main():
         if cpu:
             out["speedup_vs_cpu_reference"] = round(out["value"] / cpu["value"], 1)
 
-    # The legs below are extras: whatever happens in them (an exception on one rank, a collective that
-    # never completes on a node this code has not run on yet), the line of the main leg above must still
-    # be printed exactly once.  Exceptions are recorded in the JSON; a watchdog thread prints the line
-    # and ends the process if the extras exceed their time budget (a blocked HIP/RCCL call cannot be
-    # interrupted from Python).
-    import threading
-    printed = threading.Event()
-
-    def emit():
-        if rank == 0 and out is not None and not printed.is_set():
-            printed.set()
-            print(json.dumps(out), flush=True)
-
-    def bail():
-        if rank == 0 and out is not None:
-            out.setdefault("sharded", {})["error"] = f"extras exceeded {extras_budget:.0f} s; main leg reported without them"
-        emit()
-        os._exit(0)
-
-    extras_budget = float(os.environ.get("PAMG_EXTRAS_TIMEOUT", "480" if world == 1 else "600"))
-    watchdog = threading.Timer(extras_budget, bail)
-    watchdog.daemon = True
-    watchdog.start()
+    # The legs below are extras: whatever happens in them, the line of the main leg above must still be printed exactly
+    # once.  Exceptions are recorded in the JSON; the watchdog prints the line and ends the process if the extras exceed
+    # their time budget (a blocked HIP call cannot be interrupted from Python).
+    box["out"] = out
+    extras_budget = float(os.environ.get("PAMG_EXTRAS_TIMEOUT", "1500"))
+    watchdog = start_watchdog(extras_budget, "the extra legs")
 
     # =========================================================== sharded leg (same hierarchy, Chebyshev)
     if not args.no_extras and args.workload in ("c3", "small"):
@@ -485,28 +654,37 @@ def main():
         change_smoothers(ml, presmoother=CHEB, postsmoother=CHEB)     # rebinds smoothers, hierarchy unchanged
         spec = extract(ml)
         steps2 = max(args.steps, 10)
-        if world == 1:
-            d2 = DeviceMultilevelSolver(spec, device=local_rank, graph=not args.no_graph)
-            w2, _, res2, _, _ = time_resident(d2, b, x0, steps2, args.warmup)
-            d2.free()
-        else:
+        d2 = DeviceMultilevelSolver(spec, device=local_rank, graph=not args.no_graph)
+        w2, _, res2, _, _ = time_resident(d2, b, x0, steps2, args.warmup)
+        d2.free()
+        # the same cycles through the row-sharded C++ driver with ONE rank (no peers, so no exchange): what the driver's
+        # own structure -- [owned | halo] vectors, split launches, its graph -- costs over the resident cycle
+        drv = None
+        try:
             from pyamg_amd.dist import DeviceOps, DistMultilevelSolver
-            d2 = DistMultilevelSolver(spec, ops=DeviceOps(local_rank, spec.dtype), min_rows=args.min_rows)
-            d2.load(b, x0)
-            res2 = d2.iterate(6)
-            d2.load(b, x0)
-            d2.iterate(args.warmup, want_residuals=False)
+            d2s = DistMultilevelSolver(spec, ops=DeviceOps(local_rank, spec.dtype), min_rows=args.min_rows)
+            d2s.load(b, x0)
+            res2s = d2s.iterate(6)
+            d2s.load(b, x0)
+            d2s.iterate(args.warmup, want_residuals=False)
             barrier()
             t0 = time.perf_counter()
-            d2.iterate(steps2)                                       # each step ends with the all-reduced norm
+            d2s.iterate(steps2)
             barrier()
-            w2 = max_over_ranks(time.perf_counter() - t0)
+            w2s = time.perf_counter() - t0
+            drv = {"ms_per_step": round(w2s * 1e3 / steps2, 4), "value": round(steps2 / w2s, 3), "unit": "cycles/s",
+                   "residual_norms_equal_resident": bool(np.array_equal(np.asarray(res2s), np.asarray(res2)[:len(res2s)])),
+                   "max_rel_diff_vs_resident": float(np.max(np.abs(np.asarray(res2s) - np.asarray(res2)[:len(res2s)]) / np.asarray(res2)[:len(res2s)])),
+                   **(d2s.native.info() if d2s.native is not None else {})}
+            del d2s
+        except Exception as e:                                  # noqa: BLE001
+            drv = {"error": repr(e)[:300]}
         if rank == 0:
             glabel = "x".join(str(g) for g in wl["grid"])
-            sh = {"workload": f"3D 7-pt Poisson {glabel} SA V-cycle, Chebyshev(3) smoother, fp64" + (f", fine levels row-sharded over {world} GPUs "
-                  "(RCCL halo exchange, coarse levels collapsed)" if world > 1 else ", 1 GPU"),
+            sh = {"workload": f"3D 7-pt Poisson {glabel} SA V-cycle, Chebyshev(3) smoother, fp64, 1 GPU (resident engine)",
                   "value": round(steps2 / w2, 3), "unit": "cycles/s", "ms_per_step": round(w2 * 1e3 / steps2, 4),
                   "steps": steps2, "scaling": "strong", "n_gpus": world,
+                  "sharded_driver_one_rank": drv,
                   "residuals_gpu": [float(v) for v in res2]}
             if world == 1 and args.cpu_cycles != 0:
                 c2cpu, r2cpu = cpu_reference(ml, A, b, x0, 3)
@@ -587,35 +765,39 @@ def main():
       except Exception as e:                                    # noqa: BLE001
         log(f"configs[0] leg failed: {e!r}")
         out.setdefault("extra", {})["c1"] = {"error": repr(e)[:300]}
-      # configs[3]'s smoother at the largest size this run can afford: 384^3 Chebyshev(3) on one GPU (the hierarchy is built
-      # under device_setup in ~30 s; the reference alone needs ~5 min for it).  Last leg: if it overruns, everything above is out.
+      # configs[3] at its own size on one GPU: 512^3 Chebyshev(3) (134 M rows, ~25 GB resident; the hierarchy is a ~1.5 min
+      # build under device_setup, ~16 min by the reference alone); 384^3 only if that fails.  One reference run serves both
+      # the parity protocol (b = 0, x0 = rand, 3 cycles, 1e-10 relative) and the CPU baseline (a 512^3 reference cycle is ~45 s).
+      # Last leg: if it overruns, everything above is out.
       if args.workload == "c3":
-        try:
-            wl4 = WORKLOADS["c4"]
-            A4, ml4, ts4 = build(wl4)
-            b4, x04 = rhs(A4.shape[0])
-            t0 = time.time()
-            d4 = DeviceMultilevelSolver(ml4, device=local_rank, graph=not args.no_graph)
-            tu4 = time.time() - t0
-            w4, _, res4, _, _ = time_resident(d4, b4, x04, 10, 3)
-            ex4 = {"workload": wl4["label"], "value": round(10 / w4, 3), "unit": "cycles/s", "ms_per_step": round(w4 * 1e3 / 10, 4),
-                   "steps": 10, "host_setup_s": round(ts4, 1), "upload_s": round(tu4, 1), "levels": len(ml4.levels),
-                   "n": int(A4.shape[0]), "nnz": int(A4.nnz)}
-            if args.cpu_cycles != 0:
-                c4cpu, r4cpu = cpu_reference(ml4, A4, b4, x04, 1)
-                ex4["cpu_baseline"] = c4cpu
-                ex4["parity"] = parity_of(res4, r4cpu)
-                ex4["parity"]["reference_protocol"] = protocol_parity(d4, ml4, A4.shape[0], k=3)
-            out.setdefault("extra", {})["c4"] = ex4
-            d4.free()
-        except Exception as e:                                    # noqa: BLE001
-            log(f"configs[3] leg failed: {e!r}")
-            out.setdefault("extra", {})["c4"] = {"error": repr(e)[:300]}
+        ex4 = None
+        for key4 in ("c4x", "c4"):
+            try:
+                wl4 = WORKLOADS[key4]
+                A4, ml4, ts4 = build(wl4)
+                b4, x04 = rhs(A4.shape[0])
+                t0 = time.time()
+                d4 = DeviceMultilevelSolver(ml4, device=local_rank, graph=not args.no_graph)
+                tu4 = time.time() - t0
+                log(f"configs[3] leg ({key4}): n={A4.shape[0]} setup {ts4:.1f}s upload {tu4:.1f}s")
+                w4, _, res4, _, _ = time_resident(d4, b4, x04, 10, 3)
+                log(f"configs[3] leg ({key4}): {w4 * 100:.2f} ms per step")
+                ex4 = {"workload": wl4["label"], "key": key4, "value": round(10 / w4, 3), "unit": "cycles/s", "ms_per_step": round(w4 * 1e3 / 10, 4),
+                       "steps": 10, "host_setup_s": round(ts4, 1), "upload_s": round(tu4, 1), "levels": len(ml4.levels),
+                       "n": int(A4.shape[0]), "nnz": int(A4.nnz), "hbm_bytes": int(d4.stats()["hbm_bytes"]),
+                       "residuals_gpu": [float(v) for v in res4]}
+                if args.cpu_cycles != 0:
+                    pp = protocol_parity(d4, ml4, A4.shape[0], k=3)
+                    ex4["cpu_baseline"] = cpu_from_protocol(pp, A4, b4)
+                    ex4["parity"] = {"reference_protocol": pp}
+                d4.free()
+                break
+            except Exception as e:                                    # noqa: BLE001
+                log(f"configs[3] leg ({key4}) failed: {e!r}")
+                ex4 = {"error": repr(e)[:300], "key": key4}
+        out.setdefault("extra", {})["c4"] = ex4
 
     emit()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
     watchdog.cancel()
     return out
 

@@ -49,6 +49,7 @@ extern "C" {
 #define PAMG_E_ALLOC        -5   /* host allocation failed                    */
 #define PAMG_E_TIMEOUT      -6   /* a persistent sweep hit its spin bound (a workgroup it waited for never
                                     ran): the vectors it touched are invalid     */
+/* -7 = PAMG_E_COMM, declared with the sharded cycle below */
 
 #define PAMG_F64 0
 #define PAMG_F32 1
@@ -498,6 +499,63 @@ int pamg_solver_set_graph(pamg_solver_t S, int enable);
 /* stats[0]=levels stats[1]=kernel launches per V-cycle stats[2]=HBM bytes resident
  * stats[3]=algorithmic bytes per V-cycle (incl. convergence check) */
 int pamg_solver_stats(pamg_solver_t S, int64_t stats[8]);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-sharded cycle of ONE rank (one process per GPU): MultilevelSolver.__solve (multilevel.py:584-662) and
+ * the accel=None loop of .solve (:537-582) on a hierarchy whose fine levels are cut into contiguous row blocks.  The
+ * host side (pyamg_amd/dist.py) plans the cut; every operator of a sharded level arrives as a ROW SHARD in local
+ * numbering -- columns [owned | halo], the halo grouped by owning rank -- and every level vector is such a buffer.
+ * Per operator application one halo exchange of the input vector, overlapped with the row ranges that read owned
+ * columns only (second stream).  Smoothers: the row-independent ones (Jacobi, block Jacobi, polynomial); order-exact
+ * sweeps do not shard (PAMG_E_UNSUPPORTED).  Below the last sharded level the right-hand side is assembled by an
+ * all-reduce of disjoint slices and the remaining cycle runs on every rank with `coarse`.
+ * Transport: RCCL (pamg_dist_set_rccl: a communicator of this library's own, built from an id rank 0 obtained with
+ * pamg_dist_rccl_unique_id and the host side broadcast), or host callbacks (test rigs: several ranks on one GPU).
+ * world = 1 needs none.  Iterates are bit-identical to the single-GPU engine's; the all-reduced norm differs in the
+ * last bits. */
+#define PAMG_E_COMM         -7   /* RCCL reported an error / a transport callback failed */
+typedef struct pamg_dist_s *pamg_dist_t;
+/* fill `halo` (DEVICE, halo_count values: the level's halo in plan order) from the peers and hand them the
+ * send_count values packed at `send_buf` (DEVICE, plan order); blocking; returns 0 or a status */
+typedef int (*pamg_dist_exchange_fn)(void *user, int level, const void *send_buf, int64_t send_count, void *halo,
+                                     int64_t halo_count);
+/* in-place sum over all ranks of `count` values of dtype (PAMG_F64 / PAMG_F32) at DEVICE address buf; blocking */
+typedef int (*pamg_dist_allreduce_fn)(void *user, void *buf, int64_t count, int dtype);
+int pamg_dist_create(pamg_dist_t *D, int dtype, int rank, int world);
+int pamg_dist_destroy(pamg_dist_t D);
+/* sharded levels, fine -> coarse.  A: owned rows x [owned | halo]; P: owned rows x [owned | halo] of the NEXT level;
+ * R: owned rows of the next level x [owned | halo] of this one (all borrowed).  Exchange plan in SCALAR units:
+ * send_idx[send_off[k] .. send_off[k+1]) = owned-local indices whose values go to send_peer[k]; the halo entries
+ * recv_off[k] .. recv_off[k+1] come from recv_peer[k] (HOST arrays, copied). */
+int pamg_dist_add_level(pamg_dist_t D, pamg_matrix_t A, pamg_matrix_t P, pamg_matrix_t R, int64_t n_owned, int64_t n_halo,
+                        int nsend, const int *send_peer, const int64_t *send_off, const int32_t *send_idx,
+                        int nrecv, const int *recv_peer, const int64_t *recv_off);
+/* the first replicated level: nc unknowns, of which this rank's R shard produces rows [row0, row0 + n_owned);
+ * fill_idx[n_owned + n_halo] (HOST) = global index of every entry of this level's local vector; coarse: the resident
+ * solver of the replicated rest of the hierarchy (borrowed) */
+int pamg_dist_set_collapse(pamg_dist_t D, pamg_solver_t coarse, int64_t nc, int64_t row0, int64_t n_owned, int64_t n_halo,
+                           const int32_t *fill_idx);
+/* kind: PAMG_SMOOTH_NONE / JACOBI / POLY / BLOCK_JACOBI; Dinv: HOST, this rank's slice of the inverted diagonal blocks */
+int pamg_dist_set_smoother(pamg_dist_t D, int level, int which, int kind, int iterations, double omega, const double *coeffs,
+                           int ncoeffs, const void *Dinv, int blocksize);
+int pamg_dist_set_callbacks(pamg_dist_t D, pamg_dist_exchange_fn exchange, pamg_dist_allreduce_fn allreduce, void *user);
+int pamg_dist_rccl_unique_id(void *id128);                 /* 128 bytes; PAMG_E_UNSUPPORTED: no librccl to bind */
+int pamg_dist_set_rccl(pamg_dist_t D, const void *id128);  /* collective: ncclCommInitRank(world, id, rank) */
+int pamg_dist_finalize(pamg_dist_t D);
+/* use_graph / overlap: 0 or 1, -1 = leave (defaults 1 / 1; RCCL work is captured only with PAMG_DIST_GRAPH=1) */
+int pamg_dist_set_options(pamg_dist_t D, int use_graph, int overlap);
+int pamg_dist_load(pamg_dist_t D, const void *x_owned, const void *b_owned);     /* DEVICE slices, n_owned values */
+int pamg_dist_store(pamg_dist_t D, void *x_owned);
+/* k x (V-cycle + all-reduced ||b - A x||): residuals = HOST array of k norms (synchronises), or NULL: k cycles
+ * without norms, queued only (pamg_dist_sync waits) */
+int pamg_dist_iterate(pamg_dist_t D, int k, double *residuals);
+int pamg_dist_resid_norm(pamg_dist_t D, double *norm);
+int pamg_dist_sync(pamg_dist_t D);
+int pamg_dist_stream(pamg_dist_t D, pamg_stream_t *s);
+/* [0] sharded levels [1] transport (0 none, 1 callbacks, 2 RCCL) [2] halo exchanges per iteration [3] of those,
+ * overlapped with interior rows [4] iteration replayed from a hipGraph [5] bytes of vectors [6] values sent per
+ * exchange round [7] interior row ranges of the fine-level shard */
+int pamg_dist_info(pamg_dist_t D, int64_t info[8]);
 
 /* ------------------------------------------------------------------------------------------------
  * Setup-phase operators: what the reference's smoothed-aggregation setup spends its

@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("PAMG_LIB", PKG / "libpyamg_amd.so"))    # PAMG_L
 
 OK = 0
 E_ARG, E_UNSUPPORTED, E_NODEVICE, E_STATE, E_ALLOC = -1, -2, -3, -4, -5
+E_TIMEOUT, E_COMM = -6, -7
 F64, F32 = 0, 1
 CSR, BSR = 0, 1
 SPMV_SET, SPMV_ACC, SPMV_RESID, SPMV_AXPBY, SPMV_ACC_AXPBY = 0, 1, 2, 3, 4
@@ -151,6 +152,23 @@ def _declare(lib):
     f("pamg_solver_store", _vp, _vp, _vp)
     f("pamg_solver_stream", _vp, P(_vp))
     f("pamg_solver_stats", _vp, P(C.c_int64))
+    f("pamg_dist_create", P(_vp), _i, _i, _i)
+    f("pamg_dist_destroy", _vp)
+    f("pamg_dist_add_level", _vp, _vp, _vp, _vp, C.c_int64, C.c_int64, _i, _vp, _vp, _vp, _i, _vp, _vp)
+    f("pamg_dist_set_collapse", _vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp)
+    f("pamg_dist_set_smoother", _vp, _i, _i, _i, _i, _d, _vp, _i, _vp, _i)
+    f("pamg_dist_set_callbacks", _vp, _vp, _vp, _vp)
+    f("pamg_dist_rccl_unique_id", _vp)
+    f("pamg_dist_set_rccl", _vp, _vp)
+    f("pamg_dist_finalize", _vp)
+    f("pamg_dist_set_options", _vp, _i, _i)
+    f("pamg_dist_load", _vp, _vp, _vp)
+    f("pamg_dist_store", _vp, _vp)
+    f("pamg_dist_iterate", _vp, _i, _vp)
+    f("pamg_dist_resid_norm", _vp, P(_d))
+    f("pamg_dist_sync", _vp)
+    f("pamg_dist_stream", _vp, P(_vp))
+    f("pamg_dist_info", _vp, P(C.c_int64))
     f("pamg_csr_create", P(_vp), C.c_int64, C.c_int64, _vp, _vp, _vp)
     f("pamg_csr_view", P(_vp), _vp)
     f("pamg_csr_destroy", _vp)

@@ -130,6 +130,9 @@ class DeviceCSR:
 
 
 # --------------------------------------------------------------------------- spectral radius
+ARNOLDI_MAX_BASIS = 31          # pamg_arnoldi_create: basis vectors a device Arnoldi process holds (PAMG_E_ARG beyond)
+
+
 def _set_tol(dtype):
     """util/params.py set_tol"""
     c = np.dtype(dtype).char.lower()
@@ -232,6 +235,9 @@ def approximate_spectral_radius(A, tol=0.01, maxiter=15, restart=5, symmetric=No
             raise ValueError("expected square A")
         if np.iscomplexobj(A) or (sp.issparse(A) and A.dtype != np.float64):
             raise NotImplementedError(f"approximate_spectral_radius on the device is float64 only (got {A.dtype})")
+        if min(A.shape[0], int(maxiter)) > ARNOLDI_MAX_BASIS:
+            raise NotImplementedError(f"approximate_spectral_radius on the device holds at most {ARNOLDI_MAX_BASIS} basis vectors "
+                                      f"(maxiter={maxiter})")
         if initial_guess is None:
             v0 = np.random.rand(A.shape[1], 1)              # the reference's draw from the global stream
         else:
@@ -401,6 +407,12 @@ def _block(M):
     return tuple(int(v) for v in M.blocksize) if M.format == "bsr" else (1, 1)
 
 
+def _keeps_zeros(rb, inner, cb):
+    """does SciPy's ``bsr_matmat`` store this product block-wise (forward first-touch order, zeros kept)?  Only the
+    all-ones shape R == N == C == 1 is forwarded to ``csr_matmat``."""
+    return not (rb == 1 and inner == 1 and cb == 1)
+
+
 def galerkin_product(R, A, P):
     """``R @ A @ P`` (aggregation.py:425, classical.py:201) with both sparse products on the device, in SciPy's
     association -- (R @ A) @ P -- accumulation order and stored order.  The result has the format SciPy's expression
@@ -419,8 +431,11 @@ def galerkin_product(R, A, P):
            (P.format == "bsr" and pr != ab) or (P.format == "csr" and ab != 1):
             raise NotImplementedError("galerkin_product: block sizes that make SciPy re-block an operand")
     Rd, Ad, Pd = (DeviceCSR.from_scipy(M) for M in (R, A, P))
-    RA = Rd.matmat(Ad, col_block=ab, keep_zeros=(rb, ab) != (1, 1))
-    Ac = RA.matmat(Pd, col_block=cb, keep_zeros=(rb, cb) != (1, 1))
+    # SciPy's bsr_matmat takes the csr_matmat shortcut (reverse first-touch order, exact zeros dropped) only when the
+    # row block, the INNER block and the column block are all 1 (sparsetools/bsr.h); every other shape stores whole
+    # blocks in forward first-touch order -- R(1,3) @ A(3,3) and (RA)(1,3) @ P(3,1) included
+    RA = Rd.matmat(Ad, col_block=ab, keep_zeros=_keeps_zeros(rb, rc if R.format == "bsr" else 1, ab))
+    Ac = RA.matmat(Pd, col_block=cb, keep_zeros=_keeps_zeros(rb, ab, cb))
     out = Ac.to_scipy(blocksize=(rb, cb) if R.format == "bsr" else None)
     for d in (RA, Ac, Rd, Ad, Pd):
         d.free()
@@ -438,7 +453,7 @@ def _device_product(self, other):
     if self.format == "csr":
         if other.format != "csr":
             raise NotImplementedError
-        rb = cb = 1
+        rb = cb = n = 1
     elif self.format == "bsr":
         rb, n = (int(v) for v in self.blocksize)
         if other.format == "bsr":
@@ -453,7 +468,7 @@ def _device_product(self, other):
         raise NotImplementedError
     Ad, Bd = DeviceCSR.from_scipy(self), DeviceCSR.from_scipy(other)
     try:
-        Cd = Ad.matmat(Bd, col_block=cb, keep_zeros=(rb, cb) != (1, 1))
+        Cd = Ad.matmat(Bd, col_block=cb, keep_zeros=_keeps_zeros(rb, n, cb))
         try:
             M = Cd.to_scipy(blocksize=(rb, cb) if self.format == "bsr" else None)
         finally:
@@ -500,7 +515,9 @@ def _rho_or_reference(reference_fn):
     accepts -- a LinearOperator whose matvec is host code (rho_block_D_inv_A), dense arrays, float32 / complex -- stays
     with the reference function that was patched out"""
     def approximate_spectral_radius_(A, *args, **kwargs):
+        maxiter = kwargs.get("maxiter", args[1] if len(args) > 1 else 15)
         if sp.issparse(A) and A.dtype == np.float64 and A.shape[0] == A.shape[1] and \
+                min(A.shape[0], int(maxiter)) <= ARNOLDI_MAX_BASIS and \
                 (A.format != "bsr" or (A.blocksize[0] == A.blocksize[1] and A.blocksize[0] <= 8)):
             return approximate_spectral_radius(A, *args, **kwargs)
         return reference_fn(A, *args, **kwargs)

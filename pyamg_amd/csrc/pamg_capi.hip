@@ -504,6 +504,7 @@ const char *pamg_status_string(int st)
         case PAMG_E_STATE: return "invalid call sequence";
         case PAMG_E_ALLOC: return "host allocation failed";
         case PAMG_E_TIMEOUT: return "a persistent sweep hit its spin bound; results are invalid";
+        case PAMG_E_COMM: return "RCCL / transport failure in the sharded cycle";
     }
     if (st > 0) return hipGetErrorString((hipError_t)st);
     return "unknown error";

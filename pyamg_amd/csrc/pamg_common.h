@@ -74,6 +74,7 @@ struct StreamArgs {
     const unsigned short *Aj16;   // whole-operator kernels: column ids as 16-bit window codes (window << 14 | offset) or nullptr
     const int4 *wbase;            //   per row range: the first column of its (up to four) windows
     int4 wb;                      //   the current range's window bases (set by the kernel)
+    const int *blkmap;            // whole-operator kernels: launch index -> row range (nullptr = identity); nblk = ranges launched
 };
 
 // One dependency-level schedule for an order-exact sweep (forward or backward, or a
@@ -173,6 +174,9 @@ struct pamg_matrix_s {
     int borrowed = 0;                // solvers holding this operator (tuning is refused while > 0: captured graphs point into the schedules)
     int gs_prof = 0;                 // granular sweep: record per-range time stamps (tune key 11, diagnostics)
     int nblk = 0;
+    int *d_part[2] = {nullptr, nullptr};   // row shards (pamg_dist.hip): row ranges that read owned columns only / that read the halo
+    int npart[2] = {0, 0};
+    int64_t part_cols = -1;          //   owned columns the split was made for (-1 = none)
     int4 *d_blkmeta = nullptr;
     double *d_partial = nullptr;     // nblk doubles (sum-of-squares partials)
     pamg::GsSchedule *gs[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd, bwd, 2 custom
@@ -181,6 +185,7 @@ struct pamg_matrix_s {
 };
 
 struct pamg_schwarz_s;
+struct pamg_solver_s;
 
 namespace pamg {
 // pamg_schwarz.hip
@@ -189,6 +194,9 @@ int schwarz_prepare(pamg_schwarz_s *h, int sweep);
 // launch wrappers implemented in pamg_matrix.hip
 int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void *y, double c,
                   double omega, double *partial, hipStream_t s);
+int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const void *b, void *y, double c,
+                       double omega, double *partial, hipStream_t s);
+int matrix_split_ranges(pamg_matrix_s *A, int64_t n_owned_cols);
 int gs_sweep(pamg_matrix_s *A, int epi, void *x, const void *b, double omega, int row_start,
              int row_stop, int row_step, hipStream_t s);
 int reduce_partials(const double *partial, int n, double *out, hipStream_t s);
@@ -215,6 +223,7 @@ int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, i
 int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *xsrc, void *xdst,
                       const void *b, double omega, hipStream_t s);
 int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step);
+int solver_cycle_inline(pamg_solver_s *S, void *x, const void *b, int cycle, int cpl, hipStream_t s, bool allow_graph);   // pamg_solver.hip
 int sweep_error(pamg_matrix_s *A, bool *error);      // spin bound hit since the last call? (caller has synchronised; clears the flag)
 inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }
 }  // namespace pamg

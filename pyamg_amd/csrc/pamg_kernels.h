@@ -479,7 +479,11 @@ __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
         const int chunk = (a.nblk + 7) >> 3;
         blk = (blk & 7) * chunk + (blk >> 3);
     }
-    if (blk < a.nblk) {
+    const bool live = blk < a.nblk;
+    // a launch over a SUBSET of the row ranges (the interior / boundary halves of a row shard, pamg_dist.hip): the
+    // launch index picks the range out of a list; everything per range (plan, window bases, partial) keeps its place
+    if (live && a.blkmap) blk = a.blkmap[blk];
+    if (live) {
         if (NPL == 2 && a.Aj16) {
             StreamArgs<T> aw = a;
             aw.wb = a.wbase[blk];
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
     if constexpr (EPI == EPI_SUMSQ) {
         __syncthreads();                                   // LDS reuse for the reduction
         const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
-        if (threadIdx.x == 0 && blk < a.nblk) a.partial[blk] = tot;
+        if (threadIdx.x == 0 && live) a.partial[blk] = tot;
     }
 }
 

@@ -2,6 +2,7 @@
 // order-exact Gauss-Seidel family, kernel dispatch.
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <new>
 #include <thread>
 
@@ -184,6 +185,8 @@ int replan(pamg_matrix_s *A)
 {
     if (A->d_blkmeta) { hipFree(A->d_blkmeta); A->d_blkmeta = nullptr; }
     if (A->d_partial) { hipFree(A->d_partial); A->d_partial = nullptr; }
+    for (int k = 0; k < 2; ++k) { if (A->d_part[k]) { hipFree(A->d_part[k]); A->d_part[k] = nullptr; } A->npart[k] = 0; }
+    A->part_cols = -1;               // an interior / boundary split refers to the old plan
     std::vector<int4> blk;
     blk.reserve((size_t)A->nnz / std::max(1, A->cap / 2) + 16);
     plan_rows(A->h_Ap.data(), 0, (int)A->nrows, A->cap, A->max_rows, blk);
@@ -655,6 +658,7 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.Aj16 = nullptr;            // set by stream_launch only: the sweeps run on permuted copies with their own column codes
     a.wbase = nullptr;
     a.wb = make_int4(0, 0, 0, 0);
+    a.blkmap = nullptr;
     return a;
 }
 
@@ -665,9 +669,69 @@ int g_scratch_dev = -1;
 
 namespace pamg {
 
+// Row ranges of a row shard in local numbering [owned | halo] cut in two: INTERIOR ranges touch owned columns only
+// (they can run while the halo is still in flight), BOUNDARY ranges read at least one halo column.  Two index lists
+// into the existing plan -- no operator data is copied.
+int matrix_split_ranges(pamg_matrix_s *A, int64_t n_owned_cols)
+{
+    if (!A || n_owned_cols < 0) return PAMG_E_ARG;
+    for (int k = 0; k < 2; ++k) { if (A->d_part[k]) { hipFree(A->d_part[k]); A->d_part[k] = nullptr; } A->npart[k] = 0; }
+    A->part_cols = -1;
+    if (A->nblk == 0 || A->h_Ap.empty()) { A->part_cols = n_owned_cols; return PAMG_OK; }
+    std::vector<int4> blk;
+    blk.reserve((size_t)A->nblk);
+    plan_rows(A->h_Ap.data(), 0, (int)A->nrows, A->cap, A->max_rows, blk);
+    if ((int)blk.size() != A->nblk) return PAMG_E_STATE;
+    std::vector<unsigned char> bnd(blk.size(), 0);
+    const int *Aj = A->h_Aj.data();
+    const int lim = (int)std::min<int64_t>(n_owned_cols, INT_MAX);
+    parallel_rows((int)blk.size(), [&](int lo, int hi) {
+        for (int b = lo; b < hi; ++b) {
+            unsigned char any = 0;
+            for (int p = blk[b].z; p < blk[b].w && !any; ++p) any = Aj[p] >= lim;
+            bnd[(size_t)b] = any;
+        }
+    });
+    std::vector<int> part[2];
+    for (int b = 0; b < (int)blk.size(); ++b) part[bnd[(size_t)b] ? 1 : 0].push_back(b);
+    for (int k = 0; k < 2; ++k) {
+        A->npart[k] = (int)part[k].size();
+        PAMG_TRY(upload(&A->d_part[k], part[k].data(), part[k].size(), &A->bytes));
+    }
+    A->part_cols = n_owned_cols;
+    return PAMG_OK;
+}
+
 int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void *y, double c,
                   double omega, double *partial, hipStream_t s)
 {
+    return stream_launch_part(A, 0, epi, x, b, y, c, omega, partial, s);
+}
+
+// part: 0 = every row range, 1 = the interior ranges, 2 = the boundary ranges (matrix_split_ranges)
+int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const void *b, void *y, double c,
+                       double omega, double *partial, hipStream_t s)
+{
+    if (part < 0 || part > 2) return PAMG_E_ARG;
+    if (part && A->part_cols < 0) return PAMG_E_STATE;
+    if (part) {
+        const int n = A->npart[part - 1];
+        if (n == 0) return PAMG_OK;
+        const int lds = lds_bytes(A->dtype, epi, A->cap);
+        const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2 && !(A->stream_flags & 4);
+        if (A->dtype == PAMG_F64) {
+            StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
+            a.flags = A->stream_flags & ~2;
+            a.nblk = n; a.blkmap = A->d_part[part - 1];
+            if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; }
+            return launch_any<double>(epi, A->npl, n, lds, s, a);
+        }
+        StreamArgs<float> a = base_args<float>(A, x, b, y, c, omega, partial);
+        a.flags = A->stream_flags & ~2;
+        a.nblk = n; a.blkmap = A->d_part[part - 1];
+        if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; }
+        return launch_any<float>(epi, A->npl, n, lds, s, a);
+    }
     const int lds = lds_bytes(A->dtype, epi, A->cap);
     if (A->use_xwin && A->d_xwin && A->npl == 2 && epi < EPI_GS) {
         const int per = (int)tsize(A->dtype) + ((epi == EPI_JACOBI || epi == EPI_JACOBI_B) ? 4 : 0);
@@ -1546,6 +1610,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
     if (!A) return PAMG_OK;
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag); hipFree(A->d_rowid);
     hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta); hipFree(A->d_Aj16); hipFree(A->d_wbase);
+    hipFree(A->d_part[0]); hipFree(A->d_part[1]);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     for (int k = 0; k < 4; ++k) pamg::free_line_schedule(A->ls[k]);
     delete A;

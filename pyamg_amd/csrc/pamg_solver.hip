@@ -800,6 +800,30 @@ int pamg_solver_cycle(pamg_solver_t S, void *x, const void *b, int cycle, int cy
     return PAMG_OK;
 }
 
+}  // extern "C"
+
+namespace pamg {
+// one cycle on DEVICE x, b as part of a caller's stream-ordered sequence (the collapsed part of the sharded cycle,
+// pamg_dist.hip): no synchronisation, no convergence-check norm; allow_graph = false launches the kernels one by one
+// (the caller is capturing the stream into a graph of its own)
+int solver_cycle_inline(pamg_solver_s *S, void *x, const void *b, int cycle, int cpl, hipStream_t s, bool allow_graph)
+{
+    if (!S || !x || !b || !s) return PAMG_E_ARG;
+    if (!S->finalized) return PAMG_E_STATE;
+    if (cycle == PAMG_CYCLE_AMLI) return PAMG_E_UNSUPPORTED;     // its work vectors are allocated on first use
+    Level &L0 = S->levels[0];
+    const size_t vb = (size_t)L0.n * tsize(S->dtype);
+    PAMG_HIP(hipMemcpyAsync(L0.x, x, vb, hipMemcpyDeviceToDevice, s));
+    PAMG_HIP(hipMemcpyAsync(L0.b, b, vb, hipMemcpyDeviceToDevice, s));
+    if (allow_graph) PAMG_TRY(run_cycle(S, cycle, cpl, s, false, false));
+    else PAMG_TRY(enqueue_cycle(S, cycle, cpl, false, false, s));
+    PAMG_HIP(hipMemcpyAsync(x, L0.x, vb, hipMemcpyDeviceToDevice, s));
+    return PAMG_OK;
+}
+}  // namespace pamg
+
+extern "C" {
+
 int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int cycle,
                       int cycles_per_level, int check_every, double *residuals, int *n_iter, int *info,
                       pamg_stream_t s_)

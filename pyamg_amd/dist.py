@@ -21,9 +21,13 @@ side is assembled on every rank by an all-reduce of disjoint slices and the rema
 runs redundantly on every GPU with the resident single-GPU engine -- the "collapse to GPU 0"
 schedule without the broadcast back.
 
-Local arithmetic is delegated to an ``ops`` object: ``DeviceOps`` (HIP kernels through the C
-ABI, this module) in production; the CPU tests inject an oracle-backed twin so the
-partition / halo / cycle logic runs under ``gloo`` without a GPU.
+Two executors of the same plan.  In production (``DeviceOps``) the cycle is driven from C++
+(``csrc/pamg_dist.hip`` behind ``pamg_dist_*``, ``_NativeCycle`` below): pack -> exchange -> unpack are stream-ordered
+work, the halo travels on a second stream (RCCL send/recv straight into the halo part of the vector) while the row
+ranges that read owned columns only are already running, and with no peers (world = 1) the whole iteration is one
+hipGraph.  The Python schedule of this module (``_cycle`` and friends, one call per operator through an ``ops``
+object) is the specification of that driver and what the CPU tests run: they inject an oracle-backed twin of
+``DeviceOps`` so the partition / halo / cycle logic is exercised under ``gloo`` without a GPU.
 """
 from __future__ import annotations
 
@@ -291,7 +295,10 @@ class DeviceOps:
     # operators
     def matrix(self, op: SparseOp):
         from .multilevel import DeviceMatrix
-        return DeviceMatrix(op)
+        M = DeviceMatrix(op)
+        if __import__("os").environ.get("PAMG_AUTOTUNE", "1") != "0":
+            M.autotune(allow_cap=True)          # speed only (LDS window / streaming flags of large operators); no order-exact sweeps here
+        return M
 
     def spmv(self, M, mode, x, y, b=None, c=0.0):
         self.capi.check(self.capi.lib().pamg_matrix_spmv(M.handle, mode, self._p(x), self._p(b) if b is not None else None,
@@ -342,11 +349,14 @@ class DistMultilevelSolver:
     each rank uses its slice and ``solve`` returns the global solution on every rank).
     """
 
-    def __init__(self, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000, sharded=None):
+    def __init__(self, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000, sharded=None, native=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        self._gloo = dist.get_backend(group) == "gloo"
+        if dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            self._gloo = dist.get_backend(group) == "gloo"
+        else:                                    # a single process without a process group: one rank, nobody to talk to
+            self.rank, self.world, self._gloo = 0, 1, False
         self.sh = sharded if sharded is not None else ShardedHierarchy(spec, self.rank, self.world, min_rows)
         if self.sh.rank != self.rank or self.sh.world != self.world:
             raise ValueError("sharded part belongs to another rank / world size")
@@ -375,18 +385,31 @@ class DistMultilevelSolver:
         self.c_fill_idx = o.index((fill[:, None] * cplan.bs + np.arange(cplan.bs)).ravel().astype(np.int32))
         self.coarse = o.coarse_solver(self.sh.coarse_spec)
         self.shape = self.sh.shape0
+        # the C++ driver runs the cycle whenever the local arithmetic is the HIP engine's (PAMG_DIST_NATIVE=0: the Python
+        # schedule below, kernel by kernel -- the specification the driver is checked against)
+        if native is None:
+            native = isinstance(o, DeviceOps) and __import__("os").environ.get("PAMG_DIST_NATIVE", "1") != "0"
+        self.native = _NativeCycle(self) if native else None
 
     @classmethod
-    def from_rank0(cls, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000):
-        """The hierarchy exists on rank 0 only (``spec`` is None elsewhere): rank 0 partitions it for everybody and
-        scatters the parts, so no other rank ever builds or holds the full hierarchy (a 512^3 SA hierarchy is 78 GB on the
-        host).  Collective over ``group``."""
+    def from_rank0(cls, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000, native=None):
+        """The hierarchy exists on rank 0 only (``spec`` is None elsewhere): rank 0 partitions it for everybody, one part
+        after another, and ships every part to its rank AS ARRAYS -- a small pickled skeleton plus one point-to-point
+        transfer per index / value array (``_send_part`` / ``_recv_part``) -- so no other rank ever builds or holds the full
+        hierarchy (a 512^3 SA hierarchy is 78 GB on the host) and nothing multi-GB goes through pickle.  Collective."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        parts = list(ShardedHierarchy.all_ranks(spec, world, min_rows)) if rank == 0 else None
-        mine = [None]
-        dist.scatter_object_list(mine, parts, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
-        return cls(None, ops=ops, group=group, min_rows=min_rows, sharded=mine[0])
+        mine = None
+        if rank == 0:
+            for part in ShardedHierarchy.all_ranks(spec, world, min_rows):
+                if part.rank == 0:
+                    mine = part
+                else:
+                    _send_part(part, part.rank, group)
+                    del part
+        else:
+            mine = _recv_part(0, group)
+        return cls(None, ops=ops, group=group, min_rows=min_rows, sharded=mine, native=native)
 
     def _has_poly(self, l):
         return any(s is not None and s.kind == "polynomial" for s in self.sh.smoothers[l])
@@ -398,6 +421,8 @@ class DistMultilevelSolver:
         return self._gloo and getattr(t, "is_cuda", False)
 
     def _all_reduce(self, t):
+        if self.world == 1:
+            return
         if self._staged(t):
             h = t.cpu()
             self.dist.all_reduce(h, group=self.group)
@@ -504,6 +529,8 @@ class DistMultilevelSolver:
         self._smooth(l, post, False)
 
     def resid_norm(self):
+        if self.native is not None:
+            return self.native.resid_norm()
         self.exchange(0, self.x[0])
         ss = self.ops.resid_sumsq(self.A[0], self.x[0], self.b[0])
         self._all_reduce(ss)
@@ -514,9 +541,15 @@ class DistMultilevelSolver:
         r0, no = p.row0_s(self.rank), p.n_owned_s
         self.b[0][:no].copy_(self.ops.from_host(np.ravel(b)[r0:r0 + no]))
         self.x[0][:no].copy_(self.ops.from_host(np.ravel(x0)[r0:r0 + no]))
+        if self.native is not None:
+            self.native.load(self.x[0], self.b[0])
 
     def iterate(self, k, cycle="V", want_residuals=True):
         """k x (V-cycle + convergence-check norm) on the resident sharded state."""
+        if self.native is not None:
+            if str(cycle).upper() != "V":
+                raise NotImplementedError("sharded path: V-cycle only")
+            return self.native.iterate(k, want_residuals)
         out = []
         for _ in range(k):
             self._cycle(0, False, cycle)
@@ -526,6 +559,8 @@ class DistMultilevelSolver:
 
     def gather_solution(self):
         p = self.sh.plans[0]
+        if self.native is not None:
+            self.native.store(self.x[0])
         full = self.ops.vector(self.shape[0])
         full.zero_()
         r0 = p.row0_s(self.rank)
@@ -545,9 +580,12 @@ class DistMultilevelSolver:
         hist = [self.resid_norm()]
         it, info = 0, 0
         while True:
-            self._cycle(0, False, "V")
+            if self.native is not None:
+                nr = self.native.iterate(1, True)[0]
+            else:
+                self._cycle(0, False, "V")
+                nr = self.resid_norm()
             it += 1
-            nr = self.resid_norm()
             hist.append(nr)
             if nr < tol * normb:
                 info = 0
@@ -559,3 +597,232 @@ class DistMultilevelSolver:
             residuals[:] = hist
         xs = self.gather_solution()
         return (xs, info) if return_info else xs
+
+
+# ------------------------------------------------------------------------------- the C++ driver
+class _NativeCycle:
+    """``pamg_dist_*`` (csrc/pamg_dist.hip) wired to one rank's plan: the operators are the DeviceMatrix shards the
+    solver already holds, the exchange plans are handed over in scalar units, the transport is RCCL when the process
+    group is NCCL, two ctypes callbacks staging through the host when it is gloo (test rigs with several ranks on one
+    GPU), none when the world is one rank."""
+
+    def __init__(self, sol: "DistMultilevelSolver"):
+        from . import _capi as capi
+        self.capi, self.sol = capi, sol
+        lib = capi.lib()
+        sh, ns = sol.sh, sol.sh.ns
+        h = C.c_void_p()
+        capi.check(lib.pamg_dist_create(C.byref(h), capi.dtype_code(sh.dtype), sol.rank, sol.world), "pamg_dist_create")
+        self.handle = h
+        self._keep = []
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        for l in range(ns):
+            p = sh.plans[l]
+            sp_, so_ = i32([d for (d, _, _) in p.send]), i64([b * p.bs for (_, b, _) in p.send] + [p.send_idx.size * p.bs])
+            rp_, ro_ = i32([s_ for (s_, _, _) in p.recv]), i64([b * p.bs for (_, b, _) in p.recv] + [p.n_halo_s])
+            sidx = i32(p.send_idx_s)
+            capi.check(lib.pamg_dist_add_level(h, sol.A[l].handle, sol.P[l].handle, sol.R[l].handle, p.n_owned_s, p.n_halo_s,
+                                               sp_.size, capi.ptr(sp_), capi.ptr(so_), capi.ptr(sidx),
+                                               rp_.size, capi.ptr(rp_), capi.ptr(ro_)), f"pamg_dist_add_level({l})")
+        cp = sh.plans[ns]
+        c0 = int(cp.off[sol.rank])
+        fill = np.concatenate([np.arange(c0, c0 + cp.n_owned, dtype=np.int64), cp.halo_cols])
+        fill = i32((fill[:, None] * cp.bs + np.arange(cp.bs)).ravel())
+        capi.check(lib.pamg_dist_set_collapse(h, sol.coarse.handle, sh.nc, cp.row0_s(sol.rank), cp.n_owned_s, cp.n_halo_s,
+                                              capi.ptr(fill)), "pamg_dist_set_collapse")
+        for l in range(ns):
+            for which, sm in enumerate(sh.smoothers[l]):
+                kind = "none" if sm is None else sm.kind
+                co = None if kind != "polynomial" else np.ascontiguousarray(sm.coefficients, dtype=np.float64)
+                Dinv = None
+                if kind == "block_jacobi":
+                    Dinv = np.ascontiguousarray(sh.Dinv[l]["pre" if which == 0 else "post"], dtype=sh.dtype)
+                capi.check(lib.pamg_dist_set_smoother(h, l, which, capi.SMOOTH[kind], int(sm.iterations) if sm else 0,
+                                                      float(sm.omega) if sm else 1.0, capi.ptr(co), 0 if co is None else co.size,
+                                                      capi.ptr(Dinv), int(sm.blocksize) if sm else 1),
+                           f"pamg_dist_set_smoother({l}, {kind})")
+        if sol.world > 1:
+            if sol._gloo:
+                self._host_transport(lib)
+            else:
+                self._rccl_transport(lib)
+        capi.check(lib.pamg_dist_finalize(h), "pamg_dist_finalize")
+
+    # RCCL: rank 0 draws the id, everybody learns it through the process group, the communicator is this library's own
+    def _rccl_transport(self, lib):
+        import torch
+        sol, capi = self.sol, self.capi
+        ident = np.zeros(128, dtype=np.uint8)
+        if sol.rank == 0:
+            capi.check(lib.pamg_dist_rccl_unique_id(capi.ptr(ident)), "pamg_dist_rccl_unique_id")
+        t = torch.from_numpy(ident).to(sol.ops.device)
+        sol.dist.broadcast(t, src=sol._peer(0), group=sol.group)
+        ident = np.ascontiguousarray(t.cpu().numpy())
+        capi.check(lib.pamg_dist_set_rccl(self.handle, capi.ptr(ident)), "pamg_dist_set_rccl")
+
+    # gloo cannot move device memory: two blocking callbacks staging through the host
+    def _host_transport(self, lib):
+        import traceback
+        import torch
+        sol, capi = self.sol, self.capi
+        dist, npdt = sol.dist, np.dtype(sol.sh.dtype)
+        EX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+        def exchange(_user, level, send_buf, send_count, halo, halo_count):
+            try:
+                plan = sol.sh.plans[level]
+                bs = plan.bs
+                sb = np.empty(max(int(send_count), 1), dtype=npdt)
+                if send_count:
+                    capi.check(lib.pamg_memcpy_d2h(capi.ptr(sb), send_buf, int(send_count) * npdt.itemsize, None), "d2h")
+                rb = np.zeros(max(int(halo_count), 1), dtype=npdt)
+                st, rt = torch.from_numpy(sb), torch.from_numpy(rb)
+                reqs = [dist.P2POp(dist.irecv, rt[beg * bs:(beg + cnt) * bs], sol._peer(src), sol.group) for (src, beg, cnt) in plan.recv]
+                reqs += [dist.P2POp(dist.isend, st[beg * bs:(beg + cnt) * bs], sol._peer(dst), sol.group) for (dst, beg, cnt) in plan.send]
+                for w in dist.batch_isend_irecv(reqs):
+                    w.wait()
+                if halo_count:
+                    capi.check(lib.pamg_memcpy_h2d(halo, capi.ptr(rb), int(halo_count) * npdt.itemsize, None), "h2d")
+                return 0
+            except Exception:                    # noqa: BLE001 -- an exception must not unwind through the C frames
+                traceback.print_exc()
+                return capi.E_COMM
+
+        def allreduce(_user, buf, count, dtype):
+            try:
+                dt = np.dtype(np.float64 if dtype == capi.F64 else np.float32)
+                hb = np.empty(int(count), dtype=dt)
+                capi.check(lib.pamg_memcpy_d2h(capi.ptr(hb), buf, hb.nbytes, None), "d2h")
+                t = torch.from_numpy(hb)
+                dist.all_reduce(t, group=sol.group)
+                capi.check(lib.pamg_memcpy_h2d(buf, capi.ptr(hb), hb.nbytes, None), "h2d")
+                return 0
+            except Exception:                    # noqa: BLE001
+                traceback.print_exc()
+                return capi.E_COMM
+
+        self._cb = (EX(exchange), AR(allreduce))
+        capi.check(lib.pamg_dist_set_callbacks(self.handle, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None),
+                   "pamg_dist_set_callbacks")
+
+    def load(self, x, b):
+        p = lambda t: C.c_void_p(t.data_ptr())
+        self.capi.check(self.capi.lib().pamg_dist_load(self.handle, p(x), p(b)), "pamg_dist_load")
+
+    def store(self, x):
+        self.capi.check(self.capi.lib().pamg_dist_store(self.handle, C.c_void_p(x.data_ptr())), "pamg_dist_store")
+
+    def iterate(self, k, want_residuals=True):
+        res = np.zeros(max(int(k), 1), dtype=np.float64) if want_residuals else None
+        self.capi.check(self.capi.lib().pamg_dist_iterate(self.handle, int(k), self.capi.ptr(res)), "pamg_dist_iterate")
+        if not want_residuals:
+            self.capi.check(self.capi.lib().pamg_dist_sync(self.handle), "pamg_dist_sync")
+            return []
+        return [float(v) for v in res[:k]]
+
+    def resid_norm(self):
+        v = C.c_double(0.0)
+        self.capi.check(self.capi.lib().pamg_dist_resid_norm(self.handle, C.byref(v)), "pamg_dist_resid_norm")
+        return float(v.value)
+
+    def info(self) -> dict:
+        a = (C.c_int64 * 8)()
+        self.capi.check(self.capi.lib().pamg_dist_info(self.handle, a), "pamg_dist_info")
+        keys = ("sharded_levels", "transport", "exchanges_per_iteration", "overlapped_exchanges", "graph", "vector_bytes",
+                "values_sent_per_round", "interior_ranges_level0")
+        d = dict(zip(keys, [int(v) for v in a]))
+        d["transport"] = {0: "none", 1: "host callbacks (gloo)", 2: "rccl"}[d["transport"]]
+        return d
+
+    def free(self):
+        if getattr(self, "handle", None):
+            try:
+                self.capi._lib.pamg_dist_destroy(self.handle)
+            except Exception:       # pragma: no cover
+                pass
+            self.handle = None
+
+    def __del__(self):
+        self.free()
+
+
+# ------------------------------------------------------------------------------- shipping a part to its rank
+_CHUNK = 1 << 28            # bytes per point-to-point message
+
+
+def _split_part(part):
+    """(skeleton bytes, arrays): the part pickled with every sizeable ndarray taken out and replaced by its number"""
+    import io
+    import pickle
+    arrays = []
+
+    class Pk(pickle.Pickler):
+        def persistent_id(self, obj):
+            if isinstance(obj, np.ndarray) and obj.dtype.kind in "iuf" and obj.nbytes >= 1024:
+                arrays.append(np.ascontiguousarray(obj))
+                return ("ndarray", len(arrays) - 1)
+            return None
+
+    f = io.BytesIO()
+    Pk(f, protocol=4).dump(part)
+    return f.getvalue(), arrays
+
+
+def _join_part(skeleton: bytes, arrays):
+    import io
+    import pickle
+
+    class Up(pickle.Unpickler):
+        def persistent_load(self, pid):
+            return arrays[pid[1]]
+
+    return Up(io.BytesIO(skeleton)).load()
+
+
+def _p2p_bytes(buf: np.ndarray, peer: int, group, send: bool):
+    """one flat uint8 array, point to point in chunks; NCCL moves device memory only: staged through a device buffer"""
+    import torch
+    import torch.distributed as dist
+    nccl = dist.get_backend(group) == "nccl"
+    peer = peer if group is None else dist.get_global_rank(group, peer)
+    stage = torch.empty(min(_CHUNK, max(buf.size, 1)), dtype=torch.uint8, device="cuda") if nccl else None
+    for o in range(0, buf.size, _CHUNK):
+        piece = torch.from_numpy(buf[o:o + _CHUNK])
+        if not nccl:
+            (dist.send if send else dist.recv)(piece, peer, group=group)
+        elif send:
+            stage[:piece.numel()].copy_(piece)
+            dist.send(stage[:piece.numel()], peer, group=group)
+        else:
+            dist.recv(stage[:piece.numel()], peer, group=group)
+            piece.copy_(stage[:piece.numel()])
+
+
+def _send_part(part, dst: int, group=None):
+    skeleton, arrays = _split_part(part)
+    head = np.array([len(skeleton), len(arrays)], dtype=np.int64)
+    _p2p_bytes(head.view(np.uint8), dst, group, True)
+    _p2p_bytes(np.frombuffer(skeleton, dtype=np.uint8).copy(), dst, group, True)
+    desc = np.array([[ord(a.dtype.kind), a.dtype.itemsize, a.ndim, a.nbytes] + list(a.shape) + [0] * (4 - a.ndim) for a in arrays],
+                    dtype=np.int64).reshape(-1, 8)
+    _p2p_bytes(desc.view(np.uint8).reshape(-1), dst, group, True)
+    for a in arrays:
+        _p2p_bytes(a.view(np.uint8).reshape(-1), dst, group, True)
+
+
+def _recv_part(src: int, group=None):
+    head = np.zeros(2, dtype=np.int64)
+    _p2p_bytes(head.view(np.uint8), src, group, False)
+    skeleton = np.zeros(int(head[0]), dtype=np.uint8)
+    _p2p_bytes(skeleton, src, group, False)
+    desc = np.zeros((int(head[1]), 8), dtype=np.int64)
+    _p2p_bytes(desc.view(np.uint8).reshape(-1), src, group, False)
+    arrays = []
+    for kind, itemsize, ndim, nbytes, *shape in desc:
+        a = np.empty(tuple(int(v) for v in shape[:int(ndim)]), dtype=np.dtype(f"{chr(int(kind))}{int(itemsize)}"))
+        assert a.nbytes == int(nbytes)
+        _p2p_bytes(a.view(np.uint8).reshape(-1), src, group, False)
+        arrays.append(a)
+    return _join_part(skeleton.tobytes(), arrays)

@@ -116,24 +116,29 @@ def run(rank, world, port, name, backend, min_rows, out_dir):
     spec, ex = load_spec(ROOT / "tests" / "golden" / f"hier_{name}.npz")
     scatter = backend.endswith("+rank0")         # the hierarchy exists on rank 0 only, parts are scattered
     backend = backend.split("+")[0]
-    if backend == "device":
+    native = None
+    if backend in ("device", "devicepy"):
         from pyamg_amd.dist import DeviceOps
-        ops = DeviceOps(0, spec.dtype)          # ranks share the box's one GPU; dist.py stages gloo traffic via host
+        ops = DeviceOps(0, spec.dtype)          # ranks share the box's one GPU; gloo traffic is staged through the host
+        native = backend == "device"            # "device": the C++ driver (pamg_dist_*); "devicepy": the Python schedule, kernel by kernel
     else:
         ops = OracleOps(spec.dtype)
     if scatter:
         dtype = spec.dtype
         if rank != 0:
             spec = None                          # nothing but rank 0 ever sees the full hierarchy
-        sol = DistMultilevelSolver.from_rank0(spec, ops=ops, min_rows=min_rows)
+        sol = DistMultilevelSolver.from_rank0(spec, ops=ops, min_rows=min_rows, native=native)
         assert sol.sh.spec is None and sol.sh.dtype == dtype
     else:
-        sol = DistMultilevelSolver(spec, ops=ops, min_rows=min_rows)
+        sol = DistMultilevelSolver(spec, ops=ops, min_rows=min_rows, native=native)
+    assert (sol.native is not None) == (backend == "device")
     k = int(ex["k"])
     res = []
     x = sol.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=k, residuals=res)
+    info = sol.native.info() if sol.native is not None else {}
     np.savez(Path(out_dir) / f"out_{rank}.npz", x=x, res=np.array(res), ns=sol.sh.ns,
-             halo=np.array([p.n_halo for p in sol.sh.plans]))
+             halo=np.array([p.n_halo for p in sol.sh.plans]), exchanges=info.get("exchanges_per_iteration", -1),
+             overlapped=info.get("overlapped_exchanges", -1))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -134,14 +134,42 @@ def test_sharded_block_operators_gloo_oracle(tmp_path, load_hier, world):
         assert np.max(np.abs(o["res"] - ex["res"])) <= 1e-12 * ex["res"][0]
 
 
+def test_part_travels_as_arrays():
+    """from_rank0 ships a part as a small pickled skeleton + its arrays one by one: nothing sizeable is left in the
+    skeleton and the part comes back identical"""
+    from pyamg_amd.dist import ShardedHierarchy, _join_part, _split_part
+    from pyamg_amd.hierarchy import load_spec
+    from conftest import GOLDEN
+    spec, _ = load_spec(GOLDEN / "hier_el3d_blockjacobi.npz")
+    part = list(ShardedHierarchy.all_ranks(spec, 2, min_rows=100))[1]
+    skeleton, arrays = _split_part(part)
+    assert len(skeleton) < 64 * 1024 and sum(a.nbytes for a in arrays) > 10 * len(skeleton)
+    back = _join_part(skeleton, arrays)
+    assert back.rank == 1 and back.ns == part.ns and back.nc == part.nc
+    for l in range(part.ns):
+        for x, y in ((back.A[l], part.A[l]), (back.P[l], part.P[l]), (back.R[l], part.R[l])):
+            assert x.shape == y.shape and x.blocksize == y.blocksize
+            assert np.array_equal(x.indptr, y.indptr) and np.array_equal(x.indices, y.indices) and np.array_equal(x.data, y.data)
+        assert all(np.array_equal(back.Dinv[l][k], part.Dinv[l][k]) for k in part.Dinv[l])
+        assert np.array_equal(back.plans[l].send_idx, part.plans[l].send_idx) and back.plans[l].recv == part.plans[l].recv
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["device", "devicepy", "device+rank0"])
 @pytest.mark.parametrize("name", ["sa2d_jacobi", "sa2d_cheby", "el3d_blockjacobi"])
-def test_sharded_cycle_device_kernels(tmp_path, load_hier, name):
+def test_sharded_cycle_device_kernels(tmp_path, load_hier, name, backend):
     """two ranks (sharing the box's GPU, gloo transport) against the UNSHARDED device run of the same cycles: the
     per-row arithmetic does not change with the partition, so the iterates are bit-identical; and both stay within the
-    usual distance of the reference's history"""
+    usual distance of the reference's history.  "device" = the C++ driver (pamg_dist_*: interior rows overlapped with the
+    halo exchange), "devicepy" = the Python schedule it mirrors, "+rank0" = hierarchy shipped from rank 0 as arrays."""
     from pyamg_amd import DeviceMultilevelSolver
-    outs = _run(2, name, "device", 100, tmp_path)
+    if backend == "device+rank0" and name != "sa2d_cheby":
+        pytest.skip("one hierarchy is enough for the shipping path")
+    outs = _run(2, name, backend, 100, tmp_path)
+    if backend.startswith("device") and backend != "devicepy":
+        assert all(int(o["exchanges"]) > 0 for o in outs)
+        if name != "el3d_blockjacobi":          # scalar shards: every exchange runs its interior ranges meanwhile
+            assert all(int(o["overlapped"]) > 0 for o in outs)
     spec, ex = load_hier(name)
     dml = DeviceMultilevelSolver(spec)
     r1 = []
@@ -151,3 +179,50 @@ def test_sharded_cycle_device_kernels(tmp_path, load_hier, name):
         assert np.array_equal(o["x"], x1)
         assert np.max(np.abs(o["res"] - ex["res"])) <= 1e-10 * ex["res"][0]
         assert np.linalg.norm(o["x"] - ex["x"]) <= 1e-12 * np.linalg.norm(ex["x"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sa2d_jacobi", "sa2d_cheby", "el3d_blockjacobi"])
+def test_sharded_driver_one_rank_is_the_resident_cycle(load_hier, name):
+    """one rank, no peers: the C++ driver replays its whole iteration from one hipGraph and must reproduce the resident
+    engine bit for bit -- iterate AND residual norms (no all-reduce to reorder the sum)"""
+    from pyamg_amd import DeviceMultilevelSolver
+    from pyamg_amd.dist import DeviceOps, DistMultilevelSolver
+    spec, ex = load_hier(name)
+    k = int(ex["k"])
+    dml = DeviceMultilevelSolver(spec)
+    r1 = []
+    x1 = dml.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=k, residuals=r1)
+    dml.free()
+    sol = DistMultilevelSolver(spec, ops=DeviceOps(0, spec.dtype), min_rows=100)
+    info = sol.native.info()
+    assert info["transport"] == "none" and info["graph"] == 1 and info["sharded_levels"] == sol.sh.ns >= 1
+    r2 = []
+    x2 = sol.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=k, residuals=r2)
+    assert np.array_equal(x2, x1)
+    assert np.array_equal(np.asarray(r2), np.asarray(r1))
+    # resident state API: k cycles in one call, norms only
+    sol.load(ex["b"], ex["x0"])
+    assert np.array_equal(np.asarray(sol.iterate(k)), np.asarray(r1)[1:])
+
+
+@pytest.mark.gpu
+def test_rccl_binds_and_initialises_a_communicator():
+    """the production transport: librccl is bound at run time and a communicator of our own comes up (one rank here --
+    RCCL refuses two ranks on one GPU; the N > 1 exchange itself runs on the multi-GPU node only)"""
+    import ctypes as C
+    import torch                                  # noqa: F401 -- torch first: its librccl is the copy to bind
+    from pyamg_amd import _capi as capi
+    lib = capi.lib()
+    ident = np.zeros(128, dtype=np.uint8)
+    capi.check(lib.pamg_dist_rccl_unique_id(capi.ptr(ident)), "pamg_dist_rccl_unique_id")
+    assert ident.any()
+    h = C.c_void_p()
+    capi.check(lib.pamg_dist_create(C.byref(h), capi.F64, 0, 1), "pamg_dist_create")
+    try:
+        capi.check(lib.pamg_dist_set_rccl(h, capi.ptr(ident)), "pamg_dist_set_rccl")
+        info = (C.c_int64 * 8)()
+        capi.check(lib.pamg_dist_info(h, info), "pamg_dist_info")
+        assert info[1] == 2
+    finally:
+        lib.pamg_dist_destroy(h)

@@ -142,6 +142,34 @@ def test_galerkin_product_matches_scipy_expression():
         galerkin_product(R, sp.bsr_array(A, blocksize=(2, 2)), P)
 
 
+def test_products_with_a_unit_outer_block_and_a_true_inner_block():
+    """SA on a BSR operator with ONE candidate: R has (1,3) blocks, P (3,1).  SciPy's bsr_matmat takes the csr_matmat
+    shortcut (reverse first-touch order, zeros dropped) only for R == N == C == 1; (1,3) @ (3,1) and (1,3) @ (3,3) are
+    stored block-wise -- forward first-touch order, zeros kept -- although the result has 1x1 blocks."""
+    from pyamg_amd.aggregation import DeviceCSR, _device_product, galerkin_product
+    rng = np.random.default_rng(23)
+    nb, ncb = 90, 25
+    Ab = sp.random_array((nb, nb), density=0.06, random_state=rng, format="csr")
+    Ab = sp.bsr_array(sp.kron(Ab + Ab.T + 4.0 * sp.eye_array(nb), np.array([[2.0, 0.5, 0.0], [0.5, 3.0, 1.0], [0.0, 1.0, 4.0]]), format="bsr"),
+                      blocksize=(3, 3))
+    Pk = sp.bsr_array(sp.kron(sp.random_array((nb, ncb), density=0.12, random_state=rng, format="csr"),
+                              np.array([[1.0], [-2.0], [0.5]]), format="bsr"), blocksize=(3, 1))
+    Rk = sp.bsr_array(Pk.T.tocsr(), blocksize=(1, 3))
+    ref1 = Rk @ Pk                                           # (1,3) @ (3,1) -> 1x1 blocks, stored block-wise
+    assert ref1.format == "bsr" and tuple(ref1.blocksize) == (1, 1)
+    _same(_device_product(Rk, Pk), ref1)
+    ref = Rk @ Ab @ Pk
+    Ac = galerkin_product(Rk, Ab, Pk)
+    assert Ac.format == "bsr" and tuple(Ac.blocksize) == (1, 1)
+    _same(Ac, ref)
+    # a product whose exact zeros the block-wise path must KEEP: rows of R orthogonal to the matching block of P
+    Pz = sp.bsr_array((np.array([[[1.0], [1.0], [0.0]], [[2.0], [0.0], [1.0]]]), np.array([0, 1]), np.array([0, 1, 2])), shape=(6, 2))
+    Rz = sp.bsr_array((np.array([[[1.0, -1.0, 5.0]], [[0.0, 3.0, 0.0]]]), np.array([0, 1]), np.array([0, 1, 2])), shape=(2, 6))
+    refz = Rz @ Pz
+    assert refz.nnz == 2 and refz.data.ravel()[0] == 0.0 and refz.data.ravel()[1] == 0.0
+    _same(_device_product(Rz, Pz), refz)
+
+
 def _reference():
     import oracle.refimport as ri
     if not ri.available():

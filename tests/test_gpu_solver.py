@@ -294,6 +294,47 @@ def test_midsize_symmetric_gs_against_the_live_reference():
     assert plans[0] > 1                               # the fine level runs the tiled sweep
 
 
+@pytest.mark.parametrize("case", ["poisson3d_128", "poisson2d_2000"])
+def test_long_dependency_chains_against_the_live_reference(case):
+    """Order-exact symmetric Gauss-Seidel where the dependency chains are LONG, against the live reference (b = 0,
+    x0 = rand, every residual norm within 1e-10 relative): 3-D Poisson 128^3 SA (2.1 M rows; its SA level 1 -- 263 K
+    rows of ~30 entries, > 1 000 dependency levels -- run by the default scheduler AND forced onto the multi-XCD granular
+    sweep the 256^3 hierarchy uses there), and 2-D Poisson 2000^2 SA (4 M rows: 3 999 dependency levels on the fine
+    level, ~2 000 on level 1).  A scheduler change that only breaks on deep schedules is caught here, not only by bench.py."""
+    import oracle.refimport as ri
+    if not ri.available():
+        pytest.skip("oracle/_ref not present on this box")
+    import pyamg
+    grid = (128, 128, 128) if case == "poisson3d_128" else (2000, 2000)
+    A = pyamg.gallery.poisson(grid, format="csr")
+    np.random.seed(5)
+    gs = ("gauss_seidel", {"sweep": "symmetric"})
+    ml = pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother=gs, postsmoother=gs)
+    np.random.seed(2022)
+    x0 = np.random.rand(A.shape[0])
+    b = np.zeros(A.shape[0])
+    k = 3
+    r_ref = []
+    x_ref = ml.solve(b, x0=x0, tol=1e-30, maxiter=k, residuals=r_ref)
+    r_ref = np.array(r_ref)
+    tunes = [None] if case != "poisson3d_128" else [None, lambda i: {"gs_mode": 2, "gran_xcd": 2} if i == 1 else None]
+    outs = []
+    for tune in tunes:
+        dml = DeviceMultilevelSolver(ml, level_tune=tune)
+        depth = [dA.info()["gs_levels_fwd"] for dA in dml.A[:-1]]
+        r_gpu = []
+        outs.append(dml.solve(b, x0=x0, tol=1e-30, maxiter=k, residuals=r_gpu))
+        assert not any(dA.flow_error() for dA in dml.A)
+        dml.free()
+        r_gpu = np.array(r_gpu)
+        assert len(r_gpu) == len(r_ref) == k + 1
+        assert np.max(np.abs(r_gpu - r_ref) / r_ref) <= 1e-10, (case, np.max(np.abs(r_gpu - r_ref) / r_ref))
+        assert np.linalg.norm(outs[-1] - x_ref) <= 1e-12 * np.linalg.norm(x_ref)
+        assert max(depth) >= (2000 if case == "poisson2d_2000" else 1000), depth
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])                 # schedulers differ in speed only
+
+
 def test_device_fgmres_matches_reference():
     """solve(accel='fgmres') runs flexible GMRES on the device (pamg_solver_fgmres); compared with the
     reference's own MultilevelSolver.solve(accel='fgmres') on the committed hierarchies
