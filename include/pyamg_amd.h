@@ -247,6 +247,13 @@ int pamg_block_gauss_seidel_f32(const int32_t *Ap, int Ap_size, const int32_t *A
                                 int Tx_size, int32_t row_start, int32_t row_stop,
                                 int32_t row_step, int32_t blocksize);
 
+/* amg_core::pinv_array, linalg.h:930-1000: every n x n block of AA (m, n, n; HOST) replaced by its pseudo-inverse
+ * (one-sided Jacobi SVD per block, linalg.h:546-812) -- what get_block_diag(A, bs, inv_flag=True) (util/utils.py:603-692)
+ * runs for the Dinv of the block smoothers.  TransA 'T': row-major blocks (how Python calls it), 'F': column-major.
+ * n <= 6 (the reference itself leaves this routine at n >= 7, utils.py:682-687): larger n -> PAMG_E_UNSUPPORTED. */
+int pamg_pinv_array_f64(double *AA, int AA_size, int32_t m, int32_t n, char TransA);
+int pamg_pinv_array_f32(float *AA, int AA_size, int32_t m, int32_t n, char TransA);
+
 /* ------------------------------------------------------ Layer 2: resident engine (HBM) */
 /* Operator handle: uploads CSR/BSR arrays (HOST pointers) to HBM once and analyses them
  * (row-block plan for the LDS-streamed kernels; dependency-level schedules for the
@@ -365,6 +372,9 @@ int pamg_matrix_block_jacobi(pamg_matrix_t A, void *x, const void *b, void *work
                              const void *Dinv, double omega, int iterations, pamg_stream_t s);
 int pamg_matrix_block_gauss_seidel(pamg_matrix_t A, void *x, const void *b, const void *Dinv,
                                    int sweep, int iterations, pamg_stream_t s);
+
+/* pinv_array on a DEVICE array (m, n, n), in place, stream-ordered */
+int pamg_dev_pinv_array(int dtype, void *AA, int64_t m, int n, int transA, pamg_stream_t s);
 
 /* BLAS-1 on DEVICE vectors */
 int pamg_vec_sumsq(int dtype, int64_t n, const void *x, double *out_sumsq, pamg_stream_t s);

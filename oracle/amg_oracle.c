@@ -14,14 +14,29 @@
  *
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off -shared -fPIC)
  */
+#include <float.h>
+#include <math.h>
+
 #define REAL double
 #define FN(x) orc_##x##_f64
+#define RSQRT sqrt
+#define RFABS fabs
+#define REPS DBL_EPSILON
 #include "amg_oracle_impl.h"
 #undef REAL
 #undef FN
+#undef RSQRT
+#undef RFABS
+#undef REPS
 
 #define REAL float
 #define FN(x) orc_##x##_f32
+#define RSQRT sqrtf
+#define RFABS fabsf
+#define REPS FLT_EPSILON
 #include "amg_oracle_impl.h"
 #undef REAL
 #undef FN
+#undef RSQRT
+#undef RFABS
+#undef REPS

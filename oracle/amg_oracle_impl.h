@@ -362,3 +362,98 @@ void FN(block_gauss_seidel)(const int *Ap, const int *Aj, const REAL *Ax, REAL *
         FN(blk_apply)(Dinv + (long)i * bb, acc, x + (long)i * bs, bs);
     }
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Pseudo-inverse of every n x n block of AA[m][n][n], in place.  Follows amg_core pinv_array,
+ * linalg.h:930-1000: per block a one-sided Jacobi SVD A = U S V^T (svd_jacobi, linalg.h:546-812,
+ * column-major factors), the reciprocals of the non-zero singular values, W = S^-1 U^T, block <- V W
+ * accumulated from zero over the inner index (gemm, linalg.h:437-458).  TransA = 'T': the blocks are
+ * row-major (how util/utils.py:684 calls it for get_block_diag).  n <= 8 here (the reference uses this
+ * routine for n < 7 only, utils.py:682).
+ * Mixed precision of the reference kept: its literals 1.0 / 2.0 / 50.0 are doubles, so with REAL = float the
+ * rotation tangent and cosine are evaluated in double and rounded once. */
+static REAL FN(pinv_colnorm)(const REAL *U, int n, int a)
+{
+    REAL s = 0;
+    for (int i = 0; i < n; ++i) s += U[a * n + i] * U[a * n + i];
+    return RSQRT(s);
+}
+
+static void FN(pinv_svd)(const REAL *A, REAL *U, REAL *V, REAL *S, int n)
+{
+    const int nn = n * n;
+    if (n == 1) {                                          /* linalg.h:559-571 */
+        const REAL na = RFABS(A[0]);
+        V[0] = 1; S[0] = na;
+        U[0] = (na == 0) ? (REAL)1 : A[0] / na;
+        return;
+    }
+    const REAL eps = REPS;
+    const int sweepmax = 15 * n > 30 ? 15 * n : 30;
+    const REAL tol = RSQRT((REAL)n) * eps;
+    int count = 1, sweep = 0;
+    for (int i = 0; i < nn; ++i) { V[i] = 0; U[i] = A[i]; }
+    for (int i = 0; i < nn; i += n + 1) V[i] = 1;
+    for (int j = 0; j < n; ++j) S[j] = eps * FN(pinv_colnorm)(U, n, j);
+    while (count > 0 && sweep <= sweepmax) {
+        count = n * (n - 1) / 2;
+        for (int j = 0; j + 1 < n; ++j)
+            for (int k = j + 1; k < n; ++k) {
+                const REAL a = FN(pinv_colnorm)(U, n, j), b = FN(pinv_colnorm)(U, n, k);
+                REAL d = 0;
+                for (int i = 0; i < n; ++i) d += U[j * n + i] * U[k * n + i];
+                const REAL nd = RFABS(d), ea = S[j], eb = S[k];
+                const int sorted = a >= b, orthog = nd <= tol * a * b;
+                if (sorted && (orthog || a < ea || b < eb)) { --count; continue; }
+                if (!sorted || (nd == 0 && a == b)) {      /* :651-686 swap with one sign flip */
+                    S[j] = eb; S[k] = ea;
+                    for (int i = 0; i < n; ++i) { const REAL uj = U[j * n + i], uk = U[k * n + i]; U[j * n + i] = -uk; U[k * n + i] = uj; }
+                    for (int i = 0; i < n; ++i) { const REAL vj = V[j * n + i], vk = V[k * n + i]; V[j * n + i] = -vk; V[k * n + i] = vj; }
+                    continue;
+                }
+                const REAL tau = (REAL)((b * b - a * a) / (2.0 * nd));                      /* :694-699 */
+                const REAL sg = tau < 0 ? (REAL)-1 : (REAL)1;
+                const REAL t = (REAL)(sg / (RFABS(tau) + sqrt(1.0 + tau * tau)));
+                const REAL c = (REAL)(1.0 / sqrt(1.0 + t * t));
+                const REAL s = d * (t * c / nd), ms = -s, ns = RFABS(s);
+                S[j] = RFABS(c) * ea + ns * eb;
+                S[k] = ns * ea + RFABS(c) * eb;
+                for (int i = 0; i < n; ++i) { const REAL uj = U[j * n + i], uk = U[k * n + i]; U[j * n + i] = uj * c + ms * uk; U[k * n + i] = s * uj + uk * c; }
+                for (int i = 0; i < n; ++i) { const REAL vj = V[j * n + i], vk = V[k * n + i]; V[j * n + i] = vj * c + ms * vk; V[k * n + i] = s * vj + vk * c; }
+            }
+        ++sweep;
+    }
+    REAL sigma_tol = 0;
+    int iszero = n;
+    for (int j = 0; j < n; ++j) {                          /* :745-790 */
+        const REAL cn = FN(pinv_colnorm)(U, n, j);
+        if (j == 0) { const REAL alpha = (REAL)(50.0 / RSQRT(RSQRT(eps))); sigma_tol = alpha * cn * eps; }
+        if (cn <= sigma_tol) { --iszero; S[j] = 0; for (int i = 0; i < n; ++i) U[j * n + i] = 0; }
+        else { S[j] = cn; for (int i = 0; i < n; ++i) U[j * n + i] = U[j * n + i] / cn; }
+    }
+    if (iszero == 0) {                                     /* :792-805 */
+        for (int i = 0; i < nn; ++i) V[i] = 0;
+        for (int i = 0; i < nn; i += n + 1) { V[i] = 1; U[i] = 1; }
+    }
+}
+
+void FN(pinv_array)(REAL *AA, int m, int n, char TransA)
+{
+    REAL in[64], U[64], V[64], W[64], S[8];
+    if (n < 1 || n > 8) return;
+    for (long blk = 0; blk < m; ++blk) {
+        REAL *a = AA + blk * n * n;
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) in[TransA == 'T' ? c * n + r : r * n + c] = a[r * n + c];
+        FN(pinv_svd)(in, U, V, S, n);
+        for (int j = 0; j < n; ++j) if (S[j] != 0) S[j] = (REAL)(1.0 / S[j]);
+        for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k) W[j * n + k] = U[k * n + j] * S[k];
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                REAL acc = 0;
+                for (int k = 0; k < n; ++k) acc += V[k * n + i] * W[j * n + k];
+                a[i * n + j] = acc;
+            }
+    }
+}

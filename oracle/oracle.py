@@ -197,6 +197,12 @@ def block_gauss_seidel(Ap, Aj, Ax, x, b, Dinv, row_start, row_stop, row_step, bl
 
 
 # ----------------------------------------------------------------- operator level
+def pinv_array(AA, m, n, TransA="T"):
+    """in place: every n x n block of AA (m, n, n) replaced by its pseudo-inverse (amg_core.pinv_array, linalg.h:930-1000)"""
+    assert AA.flags.c_contiguous and AA.size == m * n * n
+    _call("pinv_array", AA.dtype, _ptr(AA), _I(m), _I(n), C.c_char(TransA.encode()))
+
+
 def matvec(op, x):
     """``op @ x`` for a SparseOp-like (fmt, shape, blocksize, indptr, indices, data);
     fresh zero-initialised result as SciPy's ``_matmul_vector`` does."""

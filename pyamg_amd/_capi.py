@@ -99,6 +99,9 @@ def _declare(lib):
         f(f"pamg_block_jacobi_{sfx}", *csr5, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i)
         f(f"pamg_block_gauss_seidel_{sfx}", *csr5, _vp, _i, _i, _i, _i, _i)
         f(f"pamg_block_jacobi_indexed_{sfx}", *csr5, _vp, _i, _vp, _i, _vp, _i, _i)
+    f("pamg_pinv_array_f64", _vp, _i, _i, _i, C.c_char)
+    f("pamg_pinv_array_f32", _vp, _i, _i, _i, C.c_char)
+    f("pamg_dev_pinv_array", _i, _vp, C.c_int64, _i, _i, _vp)
     f("pamg_matrix_create", P(_vp), _i, _i, _i, _i, _i, _i, _vp, _vp, _vp)
     f("pamg_matrix_destroy", _vp)
     f("pamg_matrix_info", _vp, P(C.c_int64))

@@ -15,7 +15,7 @@ from . import _capi as capi
 
 __all__ = ["csr_matvec", "bsr_matvec", "gauss_seidel", "sor_gauss_seidel", "bsr_gauss_seidel",
            "jacobi", "bsr_jacobi", "block_jacobi", "block_jacobi_indexed", "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_indexed", "overlapping_schwarz_csr", "gauss_seidel_ne",
-           "gauss_seidel_nr", "jacobi_ne"]
+           "gauss_seidel_nr", "jacobi_ne", "pinv_array"]
 
 
 def _sfx(Ax, *vals):
@@ -184,3 +184,13 @@ def block_gauss_seidel(Ap, Aj, Ax, x, b, Tx, row_start, row_stop, row_step, bloc
     capi.check(getattr(capi.lib(), f"pamg_block_gauss_seidel_{s}")(*_csr5(Ap, Aj, Ax, x, b), capi.ptr(Tx), Tx.size,
                                                                   int(row_start), int(row_stop), int(row_step),
                                                                   int(blocksize)), "block_gauss_seidel")
+
+
+def pinv_array(AA, m, n, TransA):
+    """amg_core.pinv_array (linalg.h:930-1000): the (m, n, n) array AA, passed ravelled like the reference's callers do
+    (util/utils.py:684), is overwritten block by block with the pseudo-inverses.  n <= 6."""
+    if not isinstance(AA, np.ndarray) or AA.dtype not in (np.float64, np.float32) or not AA.flags.c_contiguous:
+        raise TypeError("incompatible function arguments (contiguous float32/float64 array expected)")
+    s = "f64" if AA.dtype == np.float64 else "f32"
+    t = TransA if isinstance(TransA, bytes) else str(TransA).encode()
+    capi.check(getattr(capi.lib(), f"pamg_pinv_array_{s}")(capi.ptr(AA), AA.size, int(m), int(n), t[:1]), "pinv_array")

@@ -45,6 +45,7 @@ template <typename T> struct L1;
         static constexpr auto block_jacobi_indexed = pamg_block_jacobi_indexed_##S;        \
         static constexpr auto gauss_seidel_indexed = pamg_gauss_seidel_indexed_##S;        \
         static constexpr auto overlapping_schwarz_csr = pamg_overlapping_schwarz_csr_##S;  \
+        static constexpr auto pinv_array = pamg_pinv_array_##S;                            \
     };
 PAMG_L1(double, f64)
 PAMG_L1(float, f32)
@@ -127,6 +128,10 @@ void bind(py::module_ &m)
         done(F::block_gauss_seidel(Ap.data(), len(Ap), Aj.data(), len(Aj), Ax.data(), len(Ax), x.mutable_data(), len(x), b.data(), len(b),
                                    Tx.data(), len(Tx), row_start, row_stop, row_step, blocksize), "block_gauss_seidel");
     }, nc("Ap"), nc("Aj"), nc("Ax"), nc("x"), nc("b"), nc("Tx"), py::arg("row_start"), py::arg("row_stop"), py::arg("row_step"), py::arg("blocksize"));
+    // amg_core.pinv_array (linalg_bind.cpp:12-30): AA ravelled, (m, n, n), TransA 'T' / 'F'
+    m.def("pinv_array", [](Vec<T> &AA, int m_, int n, char TransA) {
+        done(F::pinv_array(AA.mutable_data(), len(AA), m_, n, TransA), "pinv_array");
+    }, nc("AA"), py::arg("m"), py::arg("n"), py::arg("TransA"));
 }
 
 }  // namespace

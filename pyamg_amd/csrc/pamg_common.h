@@ -4,6 +4,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <vector>
 
@@ -226,4 +228,20 @@ int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step)
 int solver_cycle_inline(pamg_solver_s *S, void *x, const void *b, int cycle, int cpl, hipStream_t s, bool allow_graph);   // pamg_solver.hip
 int sweep_error(pamg_matrix_s *A, bool *error);      // spin bound hit since the last call? (caller has synchronised; clears the flag)
 inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }
+
+// PAMG_TIMING=1: wall-clock of the host-side phases of upload / analysis / planning on stderr (diagnostics)
+struct PhaseTimer {
+    const char *name;
+    int64_t items;
+    timespec t0;
+    static bool on() { static const int v = [] { const char *e = getenv("PAMG_TIMING"); return (e && *e && *e != '0') ? 1 : 0; }(); return v != 0; }
+    explicit PhaseTimer(const char *n, int64_t k = 0) : name(n), items(k) { if (on()) clock_gettime(CLOCK_MONOTONIC, &t0); }
+    ~PhaseTimer()
+    {
+        if (!on()) return;
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        fprintf(stderr, "[pamg timing] %-28s %8.3f s  (%lld)\n", name, (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec), (long long)items);
+    }
+};
 }  // namespace pamg

@@ -140,6 +140,7 @@ int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap);
 // range that needs a fifth window keeps the operator on 32-bit columns.
 int plan_idx16(pamg_matrix_s *A, const std::vector<int4> &blk)
 {
+    PhaseTimer pt_("plan_idx16", A->nnz);
     if (A->d_Aj16) { hipFree(A->d_Aj16); A->d_Aj16 = nullptr; }
     if (A->d_wbase) { hipFree(A->d_wbase); A->d_wbase = nullptr; }
     if (A->npl != 2 || A->nnz == 0 || A->d_rowid) return PAMG_OK;
@@ -183,6 +184,7 @@ int plan_idx16(pamg_matrix_s *A, const std::vector<int4> &blk)
 
 int replan(pamg_matrix_s *A)
 {
+    PhaseTimer pt_("replan (incl. idx16)", A->nnz);
     if (A->d_blkmeta) { hipFree(A->d_blkmeta); A->d_blkmeta = nullptr; }
     if (A->d_partial) { hipFree(A->d_partial); A->d_partial = nullptr; }
     for (int k = 0; k < 2; ++k) { if (A->d_part[k]) { hipFree(A->d_part[k]); A->d_part[k] = nullptr; } A->npart[k] = 0; }
@@ -340,6 +342,7 @@ int new_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row_s
 {
     GsSchedule *g = new (std::nothrow) GsSchedule();
     if (!g) return PAMG_E_ALLOC;
+    PhaseTimer pt_("schedule analysis", A->nnz);
     int m = 0, nl = 0;
     if (sweep_levels((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), row_start, row_stop, row_step, g->h_vis, g->h_lvl, m, nl)) {
         delete g;
@@ -368,6 +371,7 @@ int new_schedule_scalar(pamg_matrix_s *A, int row_start, int row_stop, int row_s
 int build_level_part(pamg_matrix_s *A, GsSchedule *g)
 {
     if (g->has_level_part) return PAMG_OK;
+    PhaseTimer pt_("build_level_part", A->nnz);
     const int m = (int)g->nrows;
     const std::vector<int> &vis = g->h_vis;
     std::vector<int> lptr((size_t)g->nlevels + 1, 0), order((size_t)m);
@@ -460,6 +464,7 @@ constexpr int TILE_VAR[2][3] = {{4, 2, 3}, {8, 4, 3}};
 int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
 {
     if (g->tile) return PAMG_OK;
+    PhaseTimer pt_("build_tile_part", A->nnz);
     const int m = (int)g->nrows;
     const int ts = (int)tsize(A->dtype);
     static int cus = 0;
@@ -1521,6 +1526,7 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
     if (flavour == PAMG_CSR && (R != 1 || C != 1)) return PAMG_E_ARG;
     if (R > MAXBS || C > MAXBS) return PAMG_E_UNSUPPORTED;
     const int64_t nblk = Ap[n_brow];
+    PhaseTimer pt_("matrix_create (total)", nblk * R * C);
     if (nblk < 0 || (nblk > 0 && (!Aj || !Ax)) || Ap[0] != 0) return PAMG_E_ARG;
     // a malformed operator would mean out-of-bounds device accesses and (with the flag bits the schedules put
     // into column ids) wrong dependency analysis: check the structure once, here

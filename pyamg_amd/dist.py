@@ -364,9 +364,20 @@ class DistMultilevelSolver:
                                                          self.sh.dtype)
         o = self.ops
         ns = self.sh.ns
+        # the C++ driver runs the cycle whenever the local arithmetic is the HIP engine's (PAMG_DIST_NATIVE=0: the Python
+        # schedule below, kernel by kernel -- the specification the driver is checked against)
+        if native is None:
+            native = isinstance(o, DeviceOps) and __import__("os").environ.get("PAMG_DIST_NATIVE", "1") != "0"
         self.A = [o.matrix(m) for m in self.sh.A]
         self.P = [o.matrix(m) for m in self.sh.P]
         self.R = [o.matrix(m) for m in self.sh.R]
+        self.coarse = o.coarse_solver(self.sh.coarse_spec)
+        self.shape = self.sh.shape0
+        self.native = None
+        if native:
+            # every level vector, the exchange buffers and the collapse buffers live inside the driver
+            self.native = _NativeCycle(self)
+            return
         self.send_idx = [o.index(p.send_idx_s) for p in self.sh.plans]
         self.send_buf = [o.vector(p.send_idx.size * p.bs) for p in self.sh.plans]
         nl = [p.n_local_s for p in self.sh.plans]
@@ -383,13 +394,6 @@ class DistMultilevelSolver:
         c0 = int(cplan.off[self.rank])
         fill = np.concatenate([np.arange(c0, c0 + cplan.n_owned, dtype=np.int64), cplan.halo_cols])     # blocks: owned | halo
         self.c_fill_idx = o.index((fill[:, None] * cplan.bs + np.arange(cplan.bs)).ravel().astype(np.int32))
-        self.coarse = o.coarse_solver(self.sh.coarse_spec)
-        self.shape = self.sh.shape0
-        # the C++ driver runs the cycle whenever the local arithmetic is the HIP engine's (PAMG_DIST_NATIVE=0: the Python
-        # schedule below, kernel by kernel -- the specification the driver is checked against)
-        if native is None:
-            native = isinstance(o, DeviceOps) and __import__("os").environ.get("PAMG_DIST_NATIVE", "1") != "0"
-        self.native = _NativeCycle(self) if native else None
 
     @classmethod
     def from_rank0(cls, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000, native=None):
@@ -539,10 +543,11 @@ class DistMultilevelSolver:
     def load(self, b, x0):
         p = self.sh.plans[0]
         r0, no = p.row0_s(self.rank), p.n_owned_s
+        if self.native is not None:
+            self.native.load(np.ravel(x0)[r0:r0 + no], np.ravel(b)[r0:r0 + no])
+            return
         self.b[0][:no].copy_(self.ops.from_host(np.ravel(b)[r0:r0 + no]))
         self.x[0][:no].copy_(self.ops.from_host(np.ravel(x0)[r0:r0 + no]))
-        if self.native is not None:
-            self.native.load(self.x[0], self.b[0])
 
     def iterate(self, k, cycle="V", want_residuals=True):
         """k x (V-cycle + convergence-check norm) on the resident sharded state."""
@@ -559,11 +564,20 @@ class DistMultilevelSolver:
 
     def gather_solution(self):
         p = self.sh.plans[0]
+        r0 = p.row0_s(self.rank)
         if self.native is not None:
-            self.native.store(self.x[0])
+            mine = self.native.store()
+            if self.world == 1:
+                return mine
+            import torch
+            full = torch.zeros(self.shape[0], dtype=torch.float64 if mine.dtype == np.float64 else torch.float32)
+            full[r0:r0 + p.n_owned_s] = torch.from_numpy(mine)
+            if not self._gloo:
+                full = full.to(self.ops.device)
+            self.dist.all_reduce(full, group=self.group)           # disjoint slices -> the whole vector on every rank
+            return full.cpu().numpy()
         full = self.ops.vector(self.shape[0])
         full.zero_()
-        r0 = p.row0_s(self.rank)
         full[r0:r0 + p.n_owned_s].copy_(self.x[0][:p.n_owned_s])
         self._all_reduce(full)
         return self.ops.to_host(full, self.shape[0])
@@ -707,12 +721,26 @@ class _NativeCycle:
         capi.check(lib.pamg_dist_set_callbacks(self.handle, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None),
                    "pamg_dist_set_callbacks")
 
-    def load(self, x, b):
-        p = lambda t: C.c_void_p(t.data_ptr())
-        self.capi.check(self.capi.lib().pamg_dist_load(self.handle, p(x), p(b)), "pamg_dist_load")
+    def load(self, x_owned, b_owned):
+        """this rank's slices of x0 and b (HOST arrays) into the driver's level-0 vectors"""
+        capi, dt = self.capi, np.dtype(self.sol.sh.dtype)
+        xd = capi.DeviceArray.from_host(np.ascontiguousarray(x_owned, dtype=dt))
+        bd = capi.DeviceArray.from_host(np.ascontiguousarray(b_owned, dtype=dt))
+        try:
+            capi.check(capi.lib().pamg_dist_load(self.handle, xd.ptr, bd.ptr), "pamg_dist_load")
+        finally:
+            xd.free()
+            bd.free()
 
-    def store(self, x):
-        self.capi.check(self.capi.lib().pamg_dist_store(self.handle, C.c_void_p(x.data_ptr())), "pamg_dist_store")
+    def store(self) -> np.ndarray:
+        """this rank's slice of the iterate (HOST array)"""
+        capi = self.capi
+        xd = capi.DeviceArray(self.sol.sh.plans[0].n_owned_s, self.sol.sh.dtype)
+        try:
+            capi.check(capi.lib().pamg_dist_store(self.handle, xd.ptr), "pamg_dist_store")
+            return xd.download()
+        finally:
+            xd.free()
 
     def iterate(self, k, want_residuals=True):
         res = np.zeros(max(int(k), 1), dtype=np.float64) if want_residuals else None

@@ -346,11 +346,48 @@ def polynomial(A, x, b, coefficients, iterations=1):
     st.finish()
 
 
+def get_block_diag(A, blocksize, inv_flag=True):
+    """The block diagonal of A as an (N/blocksize, blocksize, blocksize) array, inverted block by block when
+    ``inv_flag`` (reference: util/utils.py:603-692 -- same result, same caching on ``A.block_D_inv`` / ``A.block_D``).
+    The pseudo-inverses are ``amg_core.pinv_array`` on the device (``pamg_pinv_array``: the reference's one-sided Jacobi
+    SVD per block, bit for bit); blocks of 7 and more go through LAPACK in the reference and are not on the device path."""
+    if not sparse.issparse(A):
+        raise TypeError("Expected sparse matrix")
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Expected square matrix")
+    if np.mod(A.shape[0], blocksize) != 0:
+        raise ValueError("blocksize and A.shape must be compatible")
+    nb = A.shape[0] // blocksize
+    cached = getattr(A, "block_D_inv" if inv_flag else "block_D", None)
+    if cached is not None and cached.shape == (nb, blocksize, blocksize):
+        return cached
+    if A.format != "bsr" or tuple(A.blocksize) != (blocksize, blocksize):
+        A = A.tobsr(blocksize=(blocksize, blocksize))
+    if A.dtype.kind != "f":
+        A = A.astype(np.float64)
+    # the stored block at (i, i); with duplicates SciPy's diagonal() of the position matrix adds the positions up -- the
+    # reference inherits that; canonical operators have one
+    rows = np.repeat(np.arange(nb), np.diff(A.indptr))
+    on = np.flatnonzero(A.indices == rows)
+    block_diag = np.zeros((nb, blocksize, blocksize), dtype=A.dtype)
+    if np.unique(rows[on]).size != on.size:
+        raise NotImplementedError("get_block_diag: duplicate diagonal blocks are not on the device path")
+    block_diag[rows[on]] = A.data[on]
+    if not inv_flag:
+        A.block_D = block_diag
+        return block_diag
+    if blocksize >= 7:
+        raise NotImplementedError("get_block_diag(inv_flag=True) with blocks of 7 and more (LAPACK in the reference) is not on the device path")
+    from . import amg_core
+    amg_core.pinv_array(block_diag.ravel(), nb, blocksize, "T")
+    A.block_D_inv = block_diag
+    return block_diag
+
+
 def _block_prep(A, blocksize, Dinv):
     A = A.tobsr(blocksize=(blocksize, blocksize))       # relaxation.py:475,556
     if Dinv is None:
-        raise NotImplementedError("block relaxation on the device path needs a precomputed Dinv "
-                                  "(the reference computes it at setup: smoothing.py:552-608)")
+        Dinv = get_block_diag(A, blocksize=blocksize, inv_flag=True)     # relaxation.py:477-478
     if Dinv.shape[0] != int(A.shape[0] / blocksize):
         raise ValueError("Dinv and A have incompatible dimensions")
     if (Dinv.shape[1] != blocksize) or (Dinv.shape[2] != blocksize):

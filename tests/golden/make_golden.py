@@ -552,6 +552,40 @@ def make_kernels_ne():
     print("kernels_ne.npz written:", len(out), "arrays")
 
 
+def make_kernels_setup():
+    """setup-phase kernels: amg_core.pinv_array on seeded blocks (regular, singular, rank-deficient,
+    zero, tiny), both storage conventions, f64 and f32; get_block_diag of an elasticity operator"""
+    from pyamg import amg_core
+    from pyamg.util.utils import get_block_diag
+    rng = np.random.default_rng(SEED)
+    out = {}
+    for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+        for n in (1, 2, 3, 4, 5, 6):
+            m = 200
+            A = rng.standard_normal((m, n, n)).astype(dt)
+            A[0] = 0
+            A[4] = np.eye(n) * 1e-30
+            A[5] = np.eye(n) * 3.0
+            if n > 1:
+                A[1, :, 0] = A[1, :, 1]
+                A[2] = np.ones((n, n))
+                A[3] = np.diag(np.arange(n)).astype(dt)
+                A[6] = np.triu(A[6])
+            out[f"pinv.{tag}.{n}.in"] = A.copy()
+            for tr in ("T", "F"):
+                R = A.copy()
+                amg_core.pinv_array(R.ravel(), m, n, tr)
+                out[f"pinv.{tag}.{n}.{tr}"] = R
+    A, _ = pyamg.gallery.linear_elasticity((12, 12), format="bsr")
+    out["bd.indptr"], out["bd.indices"], out["bd.data"] = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+    out["bd.shape"] = np.array(A.shape)
+    out["bd.inv2"] = get_block_diag(A.copy(), blocksize=2, inv_flag=True)
+    out["bd.blk2"] = get_block_diag(A.copy(), blocksize=2, inv_flag=False)
+    out["bd.inv4"] = get_block_diag(pyamg.gallery.poisson((10, 10), format="csr"), blocksize=4, inv_flag=True)
+    np.savez_compressed(HERE / "kernels_setup.npz", **out)
+    print("kernels_setup.npz written:", len(out), "arrays")
+
+
 def save_accel():
     if ACCEL:
         np.savez_compressed(HERE / "accel_fgmres.npz", **ACCEL)
@@ -577,6 +611,10 @@ if __name__ == "__main__" and "--blockidx-only" in sys.argv:
     make_kernels_blockidx()
     sys.exit(0)
 
+if __name__ == "__main__" and "--setup-only" in sys.argv:
+    make_kernels_setup()
+    sys.exit(0)
+
 if __name__ == "__main__" and "--ne-only" in sys.argv:
     make_kernels_ne()
     sys.exit(0)
@@ -595,5 +633,6 @@ if __name__ == "__main__":
         make_kernels_gsidx()
         make_kernels_schwarz()
         make_kernels_ne()
+        make_kernels_setup()
     make_hierarchies()
     save_accel()

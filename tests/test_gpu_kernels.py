@@ -395,6 +395,42 @@ def test_relaxation_module_block_doctests_and_polynomial():
     np.testing.assert_almost_equal(x, -0.14285714 * T3 @ T3 @ bv + T3 @ bv - 2 * bv)
 
 
+def test_pinv_array_and_block_diag_bit_exact():
+    """amg_core.pinv_array on the device (pamg_pinv_array: one lane per block, the reference's Jacobi SVD expression
+    by expression) against the reference's outputs and the oracle -- bit for bit, n = 1..6, f64 / f32, both storage
+    conventions -- and get_block_diag / the Dinv=None form of the block smoothers (reference doctests,
+    relaxation.py:449-460, 529-541, run UNMODIFIED: no Dinv passed)"""
+    from conftest import GOLDEN
+    from oracle import oracle as orc
+    z = np.load(GOLDEN / "kernels_setup.npz")
+    for tag in ("f64", "f32"):
+        for n in range(1, 7):
+            A = z[f"pinv.{tag}.{n}.in"]
+            for tr in ("T", "F"):
+                out = A.copy()
+                gcore.pinv_array(out.ravel(), A.shape[0], n, tr)
+                assert np.array_equal(out, z[f"pinv.{tag}.{n}.{tr}"]), (tag, n, tr)
+                chk = A.copy()
+                orc.pinv_array(chk, A.shape[0], n, tr)
+                assert np.array_equal(out, chk)
+    with pytest.raises(NotImplementedError):
+        gcore.pinv_array(np.zeros(2 * 49), 2, 7, "T")
+    Ab = sp.bsr_array((z["bd.data"], z["bd.indices"], z["bd.indptr"]), shape=tuple(z["bd.shape"]))
+    assert np.array_equal(grelax.get_block_diag(Ab.copy(), 2, inv_flag=False), z["bd.blk2"])
+    Ab2 = Ab.copy()
+    assert np.array_equal(grelax.get_block_diag(Ab2, 2, inv_flag=True), z["bd.inv2"])
+    assert Ab2.block_D_inv is grelax.get_block_diag(Ab2, 2)                      # cached like the reference caches it
+    T = sp.diags_array([2 * np.ones(10), -np.ones(10), -np.ones(10)], offsets=[0, -1, 1], shape=(10, 10), format="csr")
+    I = sp.eye_array(10, format="csr")
+    A = sp.csr_array(sp.kron(I, T) + sp.kron(T, I)); A.sort_indices()
+    assert np.array_equal(grelax.get_block_diag(A, 4), z["bd.inv4"])
+    b = np.ones((100, 1))
+    x = np.zeros((100, 1)); grelax.block_jacobi(A, x, b, blocksize=4, iterations=10, omega=1.0)
+    assert f"{np.linalg.norm(b - A @ x):2.4}" == "4.665"
+    x = np.zeros((100, 1)); grelax.block_gauss_seidel(A, x, b, iterations=10, blocksize=4, sweep="symmetric")
+    assert f"{np.linalg.norm(b - A @ x):2.4}" == "0.9583"
+
+
 def test_block_sweep_modes_all_exact():
     """Block/BSR-point Gauss-Seidel: every scheduler (per-level launches, one persistent workgroup,
     granular sync-free sweep on its automatic and on a tiny grid, barrier grid, automatic choice)

@@ -298,7 +298,7 @@ def test_midsize_symmetric_gs_against_the_live_reference():
 def test_long_dependency_chains_against_the_live_reference(case):
     """Order-exact symmetric Gauss-Seidel where the dependency chains are LONG, against the live reference (b = 0,
     x0 = rand, every residual norm within 1e-10 relative): 3-D Poisson 128^3 SA (2.1 M rows; its SA level 1 -- 263 K
-    rows of ~30 entries, > 1 000 dependency levels -- run by the default scheduler AND forced onto the multi-XCD granular
+    rows of ~30 entries, 613 dependency levels -- run by the default scheduler AND forced onto the multi-XCD granular
     sweep the 256^3 hierarchy uses there), and 2-D Poisson 2000^2 SA (4 M rows: 3 999 dependency levels on the fine
     level, ~2 000 on level 1).  A scheduler change that only breaks on deep schedules is caught here, not only by bench.py."""
     import oracle.refimport as ri
@@ -330,7 +330,7 @@ def test_long_dependency_chains_against_the_live_reference(case):
         assert len(r_gpu) == len(r_ref) == k + 1
         assert np.max(np.abs(r_gpu - r_ref) / r_ref) <= 1e-10, (case, np.max(np.abs(r_gpu - r_ref) / r_ref))
         assert np.linalg.norm(outs[-1] - x_ref) <= 1e-12 * np.linalg.norm(x_ref)
-        assert max(depth) >= (2000 if case == "poisson2d_2000" else 1000), depth
+        assert max(depth) >= (2000 if case == "poisson2d_2000" else 600), depth
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])                 # schedulers differ in speed only
 
