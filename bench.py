@@ -241,7 +241,7 @@ def main():
             from tools.problems import elasticity3d
             A, B = elasticity3d(wl["grid"][0])
             np.random.seed(SEED)
-            with setup_ctx(device, prolongation=False):     # 3x3 blocks: prolongation smoothing stays with the reference
+            with setup_ctx(device):                          # block operators included: bsr_matmat / bsr_binop_bsr semantics on the device
                 ml = pyamg.smoothed_aggregation_solver(A, B=B, smooth="jacobi", presmoother=wl["smoother"],
                                                        postsmoother=wl["smoother"], max_coarse=10)
             return A, ml, time.time() - t0

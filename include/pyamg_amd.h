@@ -593,13 +593,20 @@ int pamg_csr_info(pamg_csr_t A, int64_t info[4]);            /* rows, columns, s
 int pamg_csr_download(pamg_csr_t A, int32_t *Ap, int32_t *Aj, double *Ax);   /* HOST arrays */
 int pamg_csr_matmat(pamg_csr_t A, pamg_csr_t B, int col_block, int keep_zeros, pamg_csr_t *C);
 int pamg_csr_subtract(pamg_csr_t A, pamg_csr_t B, pamg_csr_t *C);
+/* A - B for the scalar views of two BSR matrices with R x C blocks: SciPy's bsr_binop_bsr (sparsetools/bsr.h) -- block
+ * columns merged per block row, a result block kept when any of its entries is non-zero; ascending block columns when
+ * both operands have sorted duplicate-free block rows, reverse order of first touch (A's blocks, then B's) otherwise.
+ * PAMG_E_ARG: an operand is not the scalar view of R x C blocks. */
+int pamg_csr_subtract_bsr(pamg_csr_t A, pamg_csr_t B, int R, int C, pamg_csr_t *out);
 /* strength.py:248-348 for a CSR operator: amg_core::symmetric_strength_of_connection (smoothed_aggregation.h:56-110:
  * |a_ij|^2 >= theta^2 |a_ii| |a_jj|, the diagonal always kept, stored order kept), then magnitudes, every row scaled by
  * the reciprocal of its largest entry */
 int pamg_csr_strength_symmetric(pamg_csr_t A, double theta, pamg_csr_t *S);
 int pamg_csr_scale(pamg_csr_t A, double alpha);             /* a_ij <- a_ij * alpha, in place (owning matrices only) */
 /* util/utils.py scale_rows (a_ij <- a_ij * d_i, d: HOST, one per row) and `alpha * A` (a_ij <- a_ij * alpha)
- * on a resident scalar fp64 operator, in place.  PAMG_E_STATE once a sweep schedule or a solver holds it. */
+ * on a resident fp64 operator, in place (block operators: the scalar view SpMV / Arnoldi / the sparse products read;
+ * their block arrays are released -- no block smoothers on it afterwards).  PAMG_E_STATE once a sweep schedule or a
+ * solver holds it. */
 int pamg_matrix_scale_rows(pamg_matrix_t A, const double *d);
 int pamg_matrix_scale_values(pamg_matrix_t A, double alpha);
 /* Arnoldi process of util/linalg.py:154-253 (the non-symmetric branch, the only one

@@ -179,6 +179,7 @@ def _declare(lib):
     f("pamg_csr_download", _vp, _vp, _vp, _vp)
     f("pamg_csr_matmat", _vp, _vp, _i, _i, P(_vp))
     f("pamg_csr_subtract", _vp, _vp, P(_vp))
+    f("pamg_csr_subtract_bsr", _vp, _vp, _i, _i, P(_vp))
     f("pamg_csr_scale", _vp, _d)
     f("pamg_csr_strength_symmetric", _vp, _d, P(_vp))
     f("pamg_matrix_scale_rows", _vp, _vp)

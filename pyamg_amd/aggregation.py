@@ -273,27 +273,42 @@ def _diag_inv(S):
 
 
 def _scalar_resident(S):
-    """S as a resident scalar operator whose values may be rescaled in place"""
+    """S as a resident operator whose values may be rescaled in place (block operators: through their scalar view)"""
     from .multilevel import DeviceMatrix
-    if S.format == "bsr" and tuple(S.blocksize) != (1, 1):
-        raise NotImplementedError("prolongation smoothing of block (BSR) operators is not on the device path")
+    if S.format == "bsr" and (S.blocksize[0] != S.blocksize[1] or S.blocksize[0] > 8):
+        raise NotImplementedError("prolongation smoothing on the device takes square blocks of at most 8")
     return DeviceMatrix(sparse_op(S))
 
 
-def _smooth(W, T, degree, product_weight=None):
-    """P = T; degree times: P = P - (W @ P)  [richardson: P - product_weight * (W @ P)], W resident"""
+def _smooth(W, T, degree, product_weight=None, wblock=1):
+    """P = T; degree times: P = P - (W @ P)  [richardson: P - product_weight * (W @ P)], W resident.  ``wblock``: the
+    (square) block size of W.  With true blocks anywhere SciPy runs bsr_matmat (whole blocks, forward first-touch order)
+    and bsr_binop_bsr (a block survives when any entry is non-zero); with 1x1 blocks throughout the CSR routines."""
+    tb = tuple(int(v) for v in T.blocksize) if T.format == "bsr" else (1, 1)
+    if wblock != tb[0]:
+        raise NotImplementedError("prolongation smoothing: the operator's blocks and T's row blocks differ (SciPy re-blocks an operand)")
+    blocks = not _all_ones(wblock, wblock, tb[1])
     P = DeviceCSR.from_scipy(T)
     for _ in range(degree):
-        U = W.matmat(P)
+        U = W.matmat(P, col_block=tb[1], keep_zeros=blocks)
         if product_weight is not None:
             capi.check(capi.lib().pamg_csr_scale(U.handle, float(product_weight)), "pamg_csr_scale")
-        Pn = P - U
+        if tb == (1, 1):
+            Pn = P - U
+        else:
+            h = C.c_void_p()
+            capi.check(capi.lib().pamg_csr_subtract_bsr(P.handle, U.handle, tb[0], tb[1], C.byref(h)), "pamg_csr_subtract_bsr")
+            Pn = DeviceCSR(h)
         U.free()
         P.free()
         P = Pn
     out = P.to_scipy(blocksize=T.blocksize if T.format == "bsr" else None)
     P.free()
     return out
+
+
+def _all_ones(rb, inner, cb):
+    return rb == 1 and inner == 1 and cb == 1
 
 
 def jacobi_prolongation_smoother(S, T, C, B, omega=4.0 / 3.0, degree=1, filter_entries=False, weighting="diagonal"):
@@ -313,11 +328,40 @@ def jacobi_prolongation_smoother(S, T, C, B, omega=4.0 / 3.0, degree=1, filter_e
         raise NotImplementedError("jacobi_prolongation_smoother on the device takes CSR / BSR operands")
     if S.dtype != np.float64 or T.dtype != np.float64:
         raise NotImplementedError("jacobi_prolongation_smoother on the device is float64 only")
-    if weighting == "block":
-        raise NotImplementedError("jacobi_prolongation_smoother(weighting='block') on BSR blocks is not on the device path")
-    if weighting not in ("diagonal", "local"):
+    if weighting not in ("diagonal", "local", "block"):
         raise ValueError("Incorrect weighting option")
     lib = capi.lib()
+    sb = int(S.blocksize[0]) if S.format == "bsr" else 1
+    if weighting == "block":
+        # smooth.py:165-172: D_inv = the inverted diagonal blocks as a block-diagonal BSR matrix, D_inv_S = D_inv @ S
+        # (bsr_matmat with true blocks), scaled by omega / rho(D_inv_S)
+        from .relaxation import get_block_diag
+        if S.blocksize[0] != S.blocksize[1]:
+            raise NotImplementedError("jacobi_prolongation_smoother(weighting='block') takes square blocks")
+        D_inv = get_block_diag(S, blocksize=sb, inv_flag=True)
+        nb = D_inv.shape[0]
+        Dm = sp.bsr_array((D_inv, np.arange(nb, dtype=np.int32), np.arange(nb + 1, dtype=np.int32)), shape=S.shape)
+        Dd, Sd = DeviceCSR.from_scipy(Dm), DeviceCSR.from_scipy(S)
+        try:
+            DS = Dd.matmat(Sd, col_block=sb, keep_zeros=True)
+        finally:
+            Dd.free()
+            Sd.free()
+        try:
+            M = DS.to_scipy(blocksize=(sb, sb))
+        finally:
+            DS.free()
+        dm = _scalar_resident(M)
+        try:
+            rho = _spectral_radius(dm, 0.01, 15, 5, np.random.rand(S.shape[1], 1))
+            capi.check(lib.pamg_matrix_scale_values(dm.handle, float(omega / rho)), "scale_values")
+            W = DeviceCSR.view_of(dm)
+            try:
+                return _smooth(W, T, degree, wblock=sb)
+            finally:
+                W.free()
+        finally:
+            dm.free()
     if weighting == "diagonal":
         D_inv = _diag_inv(S)
         dm = _scalar_resident(S)
@@ -327,7 +371,7 @@ def jacobi_prolongation_smoother(S, T, C, B, omega=4.0 / 3.0, degree=1, filter_e
             capi.check(lib.pamg_matrix_scale_values(dm.handle, float(omega / rho)), "scale_values")
             W = DeviceCSR.view_of(dm)
             try:
-                return _smooth(W, T, degree)
+                return _smooth(W, T, degree, wblock=sb)
             finally:
                 W.free()
         finally:
@@ -342,7 +386,7 @@ def jacobi_prolongation_smoother(S, T, C, B, omega=4.0 / 3.0, degree=1, filter_e
             capi.check(lib.pamg_matrix_scale_values(dm.handle, float(omega)), "scale_values")
             W = DeviceCSR.view_of(dm)
             try:
-                return _smooth(W, T, degree)
+                return _smooth(W, T, degree, wblock=sb)
             finally:
                 W.free()
         finally:
@@ -359,7 +403,8 @@ def richardson_prolongation_smoother(S, T, omega=4.0 / 3.0, degree=1):
     weight = omega / approximate_spectral_radius(S)
     Sd = DeviceCSR.from_scipy(S)
     try:
-        return _smooth(Sd, T, degree, product_weight=weight)   # weight * (S @ P): the product's values scaled, then P - that
+        return _smooth(Sd, T, degree, product_weight=weight,   # weight * (S @ P): the product's values scaled, then P - that
+                       wblock=int(S.blocksize[0]) if S.format == "bsr" else 1)
     finally:
         Sd.free()
 

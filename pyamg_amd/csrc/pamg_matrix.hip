@@ -2,6 +2,7 @@
 // order-exact Gauss-Seidel family, kernel dispatch.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <climits>
 #include <new>
 #include <thread>
@@ -15,6 +16,10 @@ using namespace pamg;
 namespace {
 
 constexpr int PAD = 8;   // elements of slack after every index/value array (vector tail loads)
+
+// schedules of one operator may be built by several host threads at once (pamg_solver_finalize: forward and backward
+// sweeps, every level); the slot table and the byte count are the only shared state
+std::mutex g_sched_mu;
 
 template <typename U>
 int upload(U **dptr, const U *h, size_t n, size_t *bytes)
@@ -122,8 +127,9 @@ int launch_any(int epi, int npl, int grid, int lds, hipStream_t s, const StreamA
 template <typename F>
 void parallel_rows(int n, F fn)
 {
-    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const int nt = (n < (1 << 16)) ? 1 : (int)hw;
+    // n counts rows or row ranges (of ~1.5 K entries): a few hundred of either are worth a thread
+    const unsigned hw = std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
+    const int nt = (n < 512) ? 1 : (int)std::min<unsigned>(hw, (unsigned)(n / 256));
     if (nt == 1) { fn(0, n); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) {
@@ -443,7 +449,7 @@ int build_level_part(pamg_matrix_s *A, GsSchedule *g)
         g->max_level_blocks = std::max(g->max_level_blocks, g->level_blk[l + 1] - g->level_blk[l]);
     if (st) return st;
     g->bytes += bytes;
-    A->bytes += bytes;
+    { std::lock_guard<std::mutex> lk(g_sched_mu); A->bytes += bytes; }
     g->has_level_part = true;
     return PAMG_OK;
 }
@@ -489,9 +495,12 @@ int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
         // a step; the LDS slots still have to hold a few of them), lean ones when several workgroups share a CU
         int cap = cap_user > 0 ? cap_user : (wpc > 1 ? 512 : 1024);
         cap = std::min(TILE_MAX_ENTRIES, std::max(cap, A->max_row_len));
-        if (build_tile_plan_from((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), g->row_start, g->row_step, m, g->nlevels,
-                                 g->h_vis, g->h_lvl, G, W, cap, TILE_ROWS, P, A->tile_part))
-            return PAMG_E_ARG;
+        {
+            PhaseTimer pt2_("  tile plan attempt", m);
+            if (build_tile_plan_from((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), g->row_start, g->row_step, m, g->nlevels,
+                                     g->h_vis, g->h_lvl, G, W, cap, TILE_ROWS, P, A->tile_part))
+                return PAMG_E_ARG;
+        }
         int mo = 0, mg = 0;
         if (!tile_geometry(P, ts, geom, &mo, &mg)) return PAMG_E_ARG;
         wide = (mo <= 256 && mg <= 128) ? 0 : 1;          // kernel variant
@@ -526,7 +535,10 @@ int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
     t->n_local = P.n_local; t->n_global = P.n_global; t->n_publish = P.n_publish;
     for (const TileStep &s : P.steps) t->max_step_entries = std::max<int64_t>(t->max_step_entries, s.p1 - s.p0);
     std::vector<unsigned char> hAx((size_t)A->nnz * ts), blocks;
-    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    {
+        PhaseTimer pt2_("  tile values d2h", A->nnz);
+        if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    }
     // the rows' own old values are only needed when a diagonal is missing or zero (or by SOR, which always asks)
     {
         std::vector<unsigned char> hd((size_t)A->nrows * ts);
@@ -538,15 +550,19 @@ int build_tile_part(pamg_matrix_s *A, GsSchedule *g)
         }
     }
     int bad;
-    if (A->dtype == PAMG_F64) bad = pack_tile_blocks<double>(P, geom, reinterpret_cast<const double *>(hAx.data()), A->h_Aj.data(), blocks);
-    else bad = pack_tile_blocks<float>(P, geom, reinterpret_cast<const float *>(hAx.data()), A->h_Aj.data(), blocks);
+    {
+        PhaseTimer pt2_("  tile pack", A->nnz);
+        if (A->dtype == PAMG_F64) bad = pack_tile_blocks<double>(P, geom, reinterpret_cast<const double *>(hAx.data()), A->h_Aj.data(), blocks);
+        else bad = pack_tile_blocks<float>(P, geom, reinterpret_cast<const float *>(hAx.data()), A->h_Aj.data(), blocks);
+    }
     if (bad) { delete t; return PAMG_E_ARG; }
+    PhaseTimer pt3_("  tile upload", (int64_t)blocks.size());
     int st = upload_raw((void **)&t->d_blocks, blocks.data(), blocks.size(), 1, &t->bytes);
     if (!st) st = upload(&t->d_tile_step, P.tile_step.data(), P.tile_step.size(), &t->bytes);
     if (st) { free_tile_part(t); return st; }
     g->tile = t;
     g->bytes += t->bytes;
-    A->bytes += t->bytes;
+    { std::lock_guard<std::mutex> lk(g_sched_mu); A->bytes += t->bytes; }
     return PAMG_OK;
 }
 
@@ -617,17 +633,23 @@ int build_schedule_block(pamg_matrix_s *A, int row_start, int row_stop, int row_
 
 int get_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out)
 {
-    for (int k = 0; k < 4; ++k) {
-        GsSchedule *g = A->gs[k];
-        if (g && g->row_start == row_start && g->row_stop == row_stop && g->row_step == row_step) {
-            *out = g;
-            return PAMG_OK;
+    auto find = [&]() -> GsSchedule * {
+        for (int k = 0; k < 4; ++k) {
+            GsSchedule *g = A->gs[k];
+            if (g && g->row_start == row_start && g->row_stop == row_stop && g->row_step == row_step) return g;
         }
+        return nullptr;
+    };
+    {
+        std::lock_guard<std::mutex> lk(g_sched_mu);
+        if (GsSchedule *g = find()) { *out = g; return PAMG_OK; }
     }
     GsSchedule *g = nullptr;
     const bool block = (A->R > 1);
     PAMG_TRY(block ? build_schedule_block(A, row_start, row_stop, row_step, &g)
                    : new_schedule_scalar(A, row_start, row_stop, row_step, &g));
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    if (GsSchedule *other = find()) { free_schedule(g); *out = other; return PAMG_OK; }
     int slot = -1;
     for (int k = 0; k < 4; ++k) if (!A->gs[k]) { slot = k; break; }
     if (slot < 0) { free_schedule(A->gs[3]); slot = 3; }

