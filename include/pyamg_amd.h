@@ -254,6 +254,30 @@ int pamg_block_gauss_seidel_f32(const int32_t *Ap, int Ap_size, const int32_t *A
 int pamg_pinv_array_f64(double *AA, int AA_size, int32_t m, int32_t n, char TransA);
 int pamg_pinv_array_f32(float *AA, int AA_size, int32_t m, int32_t n, char TransA);
 
+/* amg_core::standard_aggregation, smoothed_aggregation.h:137-268 (bindings :49-75): the greedy aggregation of a
+ * strength graph -- x[i] = aggregate of node i (-1: none), y[k] = root node of aggregate k, *naggs = their number (the
+ * reference returns it) -- aggregate for aggregate, number for number.  The sequential first pass runs as ONE persistent
+ * launch ordered by per-node turn counters (csrc/pamg_aggregate.hip).  Symmetric patterns without duplicate entries
+ * (strength-of-connection matrices); anything else: PAMG_E_UNSUPPORTED. */
+int pamg_standard_aggregation(int32_t n_row, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size,
+                              int32_t *x, int x_size, int32_t *y, int y_size, int32_t *naggs);
+/* amg_core::fit_candidates (real), smoothed_aggregation.h:484-660 (bindings :134-170): Ap / Ai = the CSC arrays of AggOp
+ * (the nodes of every aggregate), B = (n_row * K1, K2) candidates; Ax (nnz, K1, K2) receives the orthonormalised blocks
+ * in CSC order, R (n_col, K2, K2) the coefficients.  One lane per aggregate, the reference's modified Gram-Schmidt loops. */
+int pamg_fit_candidates_f64(int32_t n_row, int32_t n_col, int32_t K1, int32_t K2, const int32_t *Ap, int Ap_size,
+                            const int32_t *Ai, int Ai_size, double *Ax, int Ax_size, const double *B, int B_size,
+                            double *R, int R_size, double tol);
+int pamg_fit_candidates_f32(int32_t n_row, int32_t n_col, int32_t K1, int32_t K2, const int32_t *Ap, int Ap_size,
+                            const int32_t *Ai, int Ai_size, float *Ax, int Ax_size, const float *B, int B_size,
+                            float *R, int R_size, float tol);
+/* aggregation.tentative.fit_candidates (tentative.py:9-152) in one call: AggOp as CSR (Tp / Tj, at most one entry per
+ * row), B -> Qx = the (K1, K2) blocks of the tentative prolongator in AggOp's ROW order (its BSR data array) and R; the
+ * per-aggregate node lists (what AggOp.tocsc() gives the reference) are formed on the device. */
+int pamg_fit_tentative_f64(int32_t n_fine, int32_t n_coarse, int32_t K1, int32_t K2, const int32_t *Tp, const int32_t *Tj,
+                           const double *B, double *Qx, double *R, double tol);
+int pamg_fit_tentative_f32(int32_t n_fine, int32_t n_coarse, int32_t K1, int32_t K2, const int32_t *Tp, const int32_t *Tj,
+                           const float *B, float *Qx, float *R, float tol);
+
 /* ------------------------------------------------------ Layer 2: resident engine (HBM) */
 /* Operator handle: uploads CSR/BSR arrays (HOST pointers) to HBM once and analyses them
  * (row-block plan for the LDS-streamed kernels; dependency-level schedules for the
@@ -602,7 +626,9 @@ int pamg_csr_subtract_bsr(pamg_csr_t A, pamg_csr_t B, int R, int C, pamg_csr_t *
  * |a_ij|^2 >= theta^2 |a_ii| |a_jj|, the diagonal always kept, stored order kept), then magnitudes, every row scaled by
  * the reciprocal of its largest entry */
 int pamg_csr_strength_symmetric(pamg_csr_t A, double theta, pamg_csr_t *S);
-int pamg_csr_scale(pamg_csr_t A, double alpha);             /* a_ij <- a_ij * alpha, in place (owning matrices only) */
+int pamg_csr_scale(pamg_csr_t A, double alpha);
+/* pamg_standard_aggregation on a device-resident pattern (x, y: HOST arrays of A's row count) */
+int pamg_csr_standard_aggregation(pamg_csr_t C, int32_t *x, int32_t *y, int32_t *naggs);             /* a_ij <- a_ij * alpha, in place (owning matrices only) */
 /* util/utils.py scale_rows (a_ij <- a_ij * d_i, d: HOST, one per row) and `alpha * A` (a_ij <- a_ij * alpha)
  * on a resident fp64 operator, in place (block operators: the scalar view SpMV / Arnoldi / the sparse products read;
  * their block arrays are released -- no block smoothers on it afterwards).  PAMG_E_STATE once a sweep schedule or a

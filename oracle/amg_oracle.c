@@ -40,3 +40,48 @@
 #undef RSQRT
 #undef RFABS
 #undef REPS
+
+
+/* Greedy aggregation of a strength graph.  Follows amg_core standard_aggregation, smoothed_aggregation.h:137-268:
+ * pass 1 -- in index order a node none of whose neighbours (nor itself) is taken founds an aggregate of itself and
+ * all its neighbours; nodes without neighbours are set aside; pass 2 -- a node still free joins the aggregate of the
+ * first neighbour (storage order) that pass 1 placed; pass 3 -- numbers become 0-based, nodes set aside get -1, a node
+ * still free founds an aggregate with whichever neighbours read 0 at that moment (a 0 that may by then be the NUMBER of
+ * aggregate 0: the reference's quirk, kept).  x: aggregate of every node, y: root nodes; returns their count. */
+int orc_standard_aggregation(int n, const int *Ap, const int *Aj, int *x, int *y)
+{
+    int next = 1;
+    for (int i = 0; i < n; ++i) x[i] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (x[i]) continue;
+        int taken = 0, nbrs = 0;
+        for (int p = Ap[i]; p < Ap[i + 1] && !taken; ++p)
+            if (Aj[p] != i) { nbrs = 1; taken = x[Aj[p]] != 0; }
+        if (!nbrs) { x[i] = -n; continue; }
+        if (taken) continue;
+        x[i] = next;
+        y[next - 1] = i;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) x[Aj[p]] = next;
+        ++next;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (x[i]) continue;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p)
+            if (x[Aj[p]] > 0) { x[i] = -x[Aj[p]]; break; }
+    }
+    --next;
+    for (int i = 0; i < n; ++i) {
+        const int v = x[i];
+        if (v > 0) x[i] = v - 1;
+        else if (v == -n) x[i] = -1;
+        else if (v < 0) x[i] = -v - 1;
+        else {
+            x[i] = next;
+            y[next] = i;
+            for (int p = Ap[i]; p < Ap[i + 1]; ++p)
+                if (x[Aj[p]] == 0) x[Aj[p]] = next;
+            ++next;
+        }
+    }
+    return next;
+}

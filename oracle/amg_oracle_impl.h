@@ -457,3 +457,40 @@ void FN(pinv_array)(REAL *AA, int m, int n, char TransA)
             }
     }
 }
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Tentative prolongator blocks.  Follows amg_core fit_candidates_common (real), smoothed_aggregation.h:484-610:
+ * Ap / Ai list the nodes of every aggregate (CSC of AggOp); the K1 x K2 blocks of B belonging to aggregate j are
+ * copied into Ax in list order, giving a (nodes * K1) x K2 matrix whose columns are orthonormalised left to right by
+ * modified Gram-Schmidt -- every norm and inner product a plain running sum down the rows -- R[j] (K2 x K2) taking
+ * the coefficients; a column whose norm after orthogonalisation is not above tol * (its norm before) becomes zero. */
+void FN(fit_candidates)(int n_col, int K1, int K2, const int *Ap, const int *Ai, REAL *Ax, const REAL *B, REAL *R, REAL tol)
+{
+    const int bs = K1 * K2;
+    for (long k = 0; k < (long)n_col * K2 * K2; ++k) R[k] = 0;
+    for (int j = 0; j < n_col; ++j)
+        for (int ii = Ap[j]; ii < Ap[j + 1]; ++ii)
+            for (int e = 0; e < bs; ++e) Ax[(long)bs * ii + e] = B[(long)bs * Ai[ii] + e];
+    for (int j = 0; j < n_col; ++j) {
+        REAL *lo = Ax + (long)bs * Ap[j], *hi = Ax + (long)bs * Ap[j + 1], *Rj = R + (long)j * K2 * K2;
+        for (int c = 0; c < K2; ++c) {
+            REAL before = 0;
+            for (REAL *p = lo + c; p < hi; p += K2) before += (*p) * (*p);
+            before = RSQRT(before);
+            for (int q = 0; q < c; ++q) {
+                REAL ip = 0;
+                for (REAL *a = lo + q, *b = lo + c; a < hi; a += K2, b += K2) ip += (*a) * (*b);
+                for (REAL *a = lo + q, *b = lo + c; a < hi; a += K2, b += K2) *b -= ip * (*a);
+                Rj[K2 * q + c] = ip;
+            }
+            REAL after = 0;
+            for (REAL *p = lo + c; p < hi; p += K2) after += (*p) * (*p);
+            after = RSQRT(after);
+            REAL scale = 0;
+            if (after > tol * before) { scale = (REAL)(1.0 / after); Rj[K2 * c + c] = after; }
+            else Rj[K2 * c + c] = 0;
+            for (REAL *p = lo + c; p < hi; p += K2) *p *= scale;
+        }
+    }
+}

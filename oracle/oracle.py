@@ -203,6 +203,30 @@ def pinv_array(AA, m, n, TransA="T"):
     _call("pinv_array", AA.dtype, _ptr(AA), _I(m), _I(n), C.c_char(TransA.encode()))
 
 
+def standard_aggregation(Ap, Aj):
+    """(x, y, count): amg_core.standard_aggregation (smoothed_aggregation.h:137-268)"""
+    n = Ap.size - 1
+    x = np.empty(n, dtype=np.int32)
+    y = np.empty(max(n, 1), dtype=np.int32)
+    fn = lib().orc_standard_aggregation
+    fn.restype = C.c_int
+    cnt = fn(_I(n), _ptr(np.ascontiguousarray(Ap, dtype=np.int32)), _ptr(np.ascontiguousarray(Aj, dtype=np.int32)), _ptr(x), _ptr(y))
+    return x, y[:cnt], int(cnt)
+
+
+def fit_candidates(n_col, K1, K2, Ap, Ai, B, tol):
+    """(Ax, R): amg_core.fit_candidates (smoothed_aggregation.h:484-610) on the CSC arrays of AggOp"""
+    B = np.ascontiguousarray(B)
+    Ax = np.empty((Ai.size, K1, K2), dtype=B.dtype)
+    R = np.empty((n_col, K2, K2), dtype=B.dtype)
+    sfx, ct = _sfx(B.dtype)
+    fn = getattr(lib(), f"orc_fit_candidates_{sfx}")
+    fn.restype = None
+    fn(_I(n_col), _I(K1), _I(K2), _ptr(np.ascontiguousarray(Ap, dtype=np.int32)), _ptr(np.ascontiguousarray(Ai, dtype=np.int32)),
+       _ptr(Ax), _ptr(B), _ptr(R), ct(tol))
+    return Ax, R
+
+
 def matvec(op, x):
     """``op @ x`` for a SparseOp-like (fmt, shape, blocksize, indptr, indices, data);
     fresh zero-initialised result as SciPy's ``_matmul_vector`` does."""

@@ -29,7 +29,7 @@ from scipy.linalg import eig
 from . import _capi as capi
 from .hierarchy import sparse_op
 
-__all__ = ["DeviceCSR", "symmetric_strength_of_connection", "approximate_spectral_radius", "jacobi_prolongation_smoother",
+__all__ = ["DeviceCSR", "symmetric_strength_of_connection", "standard_aggregation", "fit_candidates", "approximate_spectral_radius", "jacobi_prolongation_smoother",
            "richardson_prolongation_smoother", "galerkin_product", "device_setup", "device_products"]
 
 
@@ -439,12 +439,125 @@ def symmetric_strength_of_connection(A, theta=0):
         h = C.c_void_p()
         capi.check(capi.lib().pamg_csr_strength_symmetric(Ad.handle, float(theta), C.byref(h)), "pamg_csr_strength_symmetric")
         S = DeviceCSR(h)
-        try:
-            return S.to_scipy()
-        finally:
-            S.free()
+        out = S.to_scipy()
+        _keep_resident(out, S)                               # standard_aggregation(out) comes next in the SA setup
+        return out
     finally:
         Ad.free()
+
+
+# --------------------------------------------------------------------------- aggregation, tentative prolongator
+def standard_aggregation(C):
+    """pyamg.aggregation.aggregate.standard_aggregation (aggregate.py:12-96): the greedy aggregation of the strength graph
+    on the device (``pamg_standard_aggregation``: the reference's three passes, the sequential first one ordered by per-node
+    turn counters -- the same aggregates with the same numbers, the same C-points).  Returns (AggOp, Cpts) like the
+    reference.  A strength matrix that ``symmetric_strength_of_connection`` of this module just produced is still resident
+    and is not shipped again."""
+    if not sp.issparse(C) or C.format != "csr":
+        raise TypeError("expected csr_array")
+    if C.shape[0] != C.shape[1]:
+        raise ValueError("expected square matrix")
+    index_type = C.indptr.dtype
+    n = C.shape[0]
+    Tj = np.empty(n, dtype=np.int32)
+    Cpts = np.empty(n, dtype=np.int32)
+    import ctypes
+    na = ctypes.c_int(0)
+    lib = capi.lib()
+    dev = _resident_copy(C)
+    if dev is not None:
+        capi.check(lib.pamg_csr_standard_aggregation(dev.handle, capi.ptr(Tj), capi.ptr(Cpts), ctypes.byref(na)),
+                   "pamg_csr_standard_aggregation")
+        _drop_resident(C)
+    else:
+        indptr, indices = _i32(C.indptr), _i32(C.indices)
+        capi.check(lib.pamg_standard_aggregation(n, capi.ptr(indptr), indptr.size, capi.ptr(indices), indices.size,
+                                                 capi.ptr(Tj), n, capi.ptr(Cpts), n, ctypes.byref(na)), "pamg_standard_aggregation")
+    num_aggregates = int(na.value)
+    Tj = Tj.astype(index_type, copy=False)
+    Cpts = Cpts[:num_aggregates].astype(index_type, copy=False)
+    if num_aggregates == 0:                                  # aggregate.py:76-79
+        return sp.csr_array((n, 1), dtype=np.int32), np.array([], dtype=index_type)
+    shape = (n, num_aggregates)
+    if Tj.min() == -1:                                       # aggregate.py:84-89: some nodes not aggregated
+        mask = Tj != -1
+        row = np.arange(n, dtype=index_type)[mask]
+        col = Tj[mask]
+        data = np.ones(len(col), dtype=np.int32)
+        return sp.coo_array((data, (row, col)), shape=shape).tocsr(), Cpts
+    Tp = np.arange(n + 1, dtype=index_type)
+    Tx = np.ones(len(Tj), dtype=np.int32)
+    return sp.csr_array((Tx, Tj, Tp), shape=shape), Cpts
+
+
+def fit_candidates(AggOp, B, tol=1e-10):
+    """pyamg.aggregation.tentative.fit_candidates (tentative.py:9-152): the tentative prolongator Q and the coarse
+    candidates R with ``Q @ R = B`` on the aggregates, ``Q.T @ Q = I`` -- per aggregate the reference's modified
+    Gram-Schmidt (amg_core.fit_candidates, smoothed_aggregation.h:484-610) on the device, one lane per aggregate, the sums
+    in the reference's order.  The blocks come back in AggOp's row order, which is what ``Q.T.tobsr()`` of the reference
+    stores, so no transposes are formed on the host."""
+    if not sp.issparse(AggOp) or AggOp.format != "csr":
+        raise TypeError("expected csr_array for argument AggOp")
+    B = np.asarray(B)
+    if B.dtype not in ("float32", "float64", "complex64", "complex128"):
+        B = np.asarray(B, dtype="float64")
+    if len(B.shape) != 2:
+        raise ValueError("expected 2d array for argument B")
+    if B.shape[0] % AggOp.shape[0] != 0:
+        raise ValueError(f"Dimensions of AggOp {AggOp.shape} and B {B.shape} are incompatible")
+    if B.dtype.kind == "c":
+        raise NotImplementedError("fit_candidates on the device is real only")
+    N_fine, N_coarse = AggOp.shape
+    K1 = int(B.shape[0] / N_fine)
+    K2 = B.shape[1]
+    if AggOp.nnz and int(np.diff(AggOp.indptr).max()) > 1:
+        raise NotImplementedError("fit_candidates on the device takes an aggregation (one aggregate per node)")
+    Tp, Tj = _i32(AggOp.indptr), _i32(AggOp.indices)
+    Bc = np.ascontiguousarray(B)
+    R = np.empty((N_coarse, K2, K2), dtype=B.dtype)
+    Qx = np.empty((AggOp.nnz, K1, K2), dtype=B.dtype)
+    fn = capi.lib().pamg_fit_tentative_f64 if B.dtype == np.float64 else capi.lib().pamg_fit_tentative_f32
+    capi.check(fn(N_fine, N_coarse, K1, K2, capi.ptr(Tp), capi.ptr(Tj), capi.ptr(Bc), capi.ptr(Qx), capi.ptr(R),
+                  float(tol)), "pamg_fit_tentative")
+    # the reference builds Q^T as BSR over the CSC arrays and transposes it (tentative.py:146-148): the same matrix
+    Q = sp.bsr_array((Qx, Tj.astype(AggOp.indices.dtype, copy=False), Tp.astype(AggOp.indptr.dtype, copy=False)),
+                     shape=(K1 * N_fine, K2 * N_coarse))
+    return Q, R.reshape(-1, K2)
+
+
+# a device copy handed from one setup step to the next (strength -> aggregation) without a round trip through the host
+_RESIDENT = {}
+_HANDOFF = [False]                  # only inside device_setup(): there the next step is known to follow at once
+
+
+def _clear_resident():
+    for ent in _RESIDENT.values():
+        ent[0].free()
+    _RESIDENT.clear()
+
+
+def _keep_resident(M, dev):
+    _clear_resident()                                        # one hand-off at a time: nothing piles up in HBM
+    if not _HANDOFF[0]:
+        dev.free()
+        return
+    _RESIDENT[id(M)] = (dev, M.indices.ctypes.data, M.indptr.ctypes.data, M.nnz)
+
+
+def _resident_copy(M):
+    ent = _RESIDENT.get(id(M))
+    if ent is None:
+        return None
+    dev, pj, pp, nnz = ent
+    if M.indices.ctypes.data != pj or M.indptr.ctypes.data != pp or M.nnz != nnz or dev.handle is None:
+        return None
+    return dev
+
+
+def _drop_resident(M):
+    ent = _RESIDENT.pop(id(M), None)
+    if ent is not None:
+        ent[0].free()
 
 
 # --------------------------------------------------------------------------- Galerkin product
@@ -555,6 +668,18 @@ def device_products():
 
 
 # --------------------------------------------------------------------------- patching a reference package
+def _device_or_reference(device_fn, reference_fn):
+    """a patched setup function: the device twin, and the reference function that was patched out for the inputs the
+    device path does not take (it says so with NotImplementedError)"""
+    def patched(*args, **kwargs):
+        try:
+            return device_fn(*args, **kwargs)
+        except NotImplementedError:
+            return reference_fn(*args, **kwargs)
+    patched.__name__ = getattr(reference_fn, "__name__", "patched")
+    return patched
+
+
 def _rho_or_reference(reference_fn):
     """the patched ``approximate_spectral_radius``: float64 sparse matrices go to the device; anything else the reference
     accepts -- a LinearOperator whose matvec is host code (rho_block_D_inv_A), dense arrays, float32 / complex -- stays
@@ -588,6 +713,8 @@ def device_setup(pyamg, prolongation=True, products=True):
                           ("aggregation.aggregation", "richardson_prolongation_smoother", richardson_prolongation_smoother),
                           ("aggregation.aggregation", "symmetric_strength_of_connection", symmetric_strength_of_connection),
                           ("strength", "symmetric_strength_of_connection", symmetric_strength_of_connection),
+                          ("aggregation.aggregation", "standard_aggregation", standard_aggregation),
+                          ("aggregation.aggregation", "fit_candidates", fit_candidates),
                           ("aggregation.smooth", "approximate_spectral_radius", approximate_spectral_radius),
                           ("relaxation.smoothing", "approximate_spectral_radius", approximate_spectral_radius),
                           ("relaxation.chebyshev", "approximate_spectral_radius", approximate_spectral_radius),
@@ -601,10 +728,19 @@ def device_setup(pyamg, prolongation=True, products=True):
         if hasattr(m, name):
             old = getattr(m, name)
             targets.append((m, name, old))
-            setattr(m, name, _rho_or_reference(old) if name == "approximate_spectral_radius" else fn)
+            if name == "approximate_spectral_radius":
+                setattr(m, name, _rho_or_reference(old))
+            elif name in ("standard_aggregation", "fit_candidates"):
+                setattr(m, name, _device_or_reference(fn, old))
+            else:
+                setattr(m, name, fn)
+    was = _HANDOFF[0]
+    _HANDOFF[0] = True
     try:
         with (device_products() if products else contextlib.nullcontext()):
             yield
     finally:
+        _HANDOFF[0] = was
+        _clear_resident()
         for m, name, old in targets:
             setattr(m, name, old)

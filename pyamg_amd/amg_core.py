@@ -15,7 +15,7 @@ from . import _capi as capi
 
 __all__ = ["csr_matvec", "bsr_matvec", "gauss_seidel", "sor_gauss_seidel", "bsr_gauss_seidel",
            "jacobi", "bsr_jacobi", "block_jacobi", "block_jacobi_indexed", "block_gauss_seidel", "jacobi_indexed", "gauss_seidel_indexed", "overlapping_schwarz_csr", "gauss_seidel_ne",
-           "gauss_seidel_nr", "jacobi_ne", "pinv_array"]
+           "gauss_seidel_nr", "jacobi_ne", "pinv_array", "standard_aggregation", "fit_candidates"]
 
 
 def _sfx(Ax, *vals):
@@ -194,3 +194,24 @@ def pinv_array(AA, m, n, TransA):
     s = "f64" if AA.dtype == np.float64 else "f32"
     t = TransA if isinstance(TransA, bytes) else str(TransA).encode()
     capi.check(getattr(capi.lib(), f"pamg_pinv_array_{s}")(capi.ptr(AA), AA.size, int(m), int(n), t[:1]), "pinv_array")
+
+
+def standard_aggregation(n_row, Ap, Aj, x, y):
+    """amg_core.standard_aggregation (smoothed_aggregation.h:137-268): x <- aggregate of every node (-1: none), y <- root
+    nodes; returns the number of aggregates, like the reference."""
+    import ctypes
+    _idx(Ap, Aj, x, y)
+    na = ctypes.c_int(0)
+    capi.check(capi.lib().pamg_standard_aggregation(int(n_row), capi.ptr(Ap), Ap.size, capi.ptr(Aj), Aj.size, capi.ptr(x), x.size,
+                                                   capi.ptr(y), y.size, ctypes.byref(na)), "standard_aggregation")
+    return int(na.value)
+
+
+def fit_candidates(n_row, n_col, K1, K2, Ap, Ai, Ax, B, R, tol):
+    """amg_core.fit_candidates (real; smoothed_aggregation.h:484-660): Ap / Ai = CSC arrays of AggOp, Ax (ravelled
+    (nnz, K1, K2)) and R (ravelled (n_col, K2, K2)) are overwritten."""
+    _idx(Ap, Ai)
+    s = _sfx(Ax, B, R)
+    capi.check(getattr(capi.lib(), f"pamg_fit_candidates_{s}")(int(n_row), int(n_col), int(K1), int(K2), capi.ptr(Ap), Ap.size,
+                                                              capi.ptr(Ai), Ai.size, capi.ptr(Ax), Ax.size, capi.ptr(B), B.size,
+                                                              capi.ptr(R), R.size, float(tol)), "fit_candidates")

@@ -46,6 +46,7 @@ template <typename T> struct L1;
         static constexpr auto gauss_seidel_indexed = pamg_gauss_seidel_indexed_##S;        \
         static constexpr auto overlapping_schwarz_csr = pamg_overlapping_schwarz_csr_##S;  \
         static constexpr auto pinv_array = pamg_pinv_array_##S;                            \
+        static constexpr auto fit_candidates = pamg_fit_candidates_##S;                    \
     };
 PAMG_L1(double, f64)
 PAMG_L1(float, f32)
@@ -132,6 +133,11 @@ void bind(py::module_ &m)
     m.def("pinv_array", [](Vec<T> &AA, int m_, int n, char TransA) {
         done(F::pinv_array(AA.mutable_data(), len(AA), m_, n, TransA), "pinv_array");
     }, nc("AA"), py::arg("m"), py::arg("n"), py::arg("TransA"));
+    // amg_core.fit_candidates, real overloads (smoothed_aggregation_bind.cpp:134-170)
+    m.def("fit_candidates", [](int n_row, int n_col, int K1, int K2, Idx &Ap, Idx &Ai, Vec<T> &Ax, Vec<T> &B, Vec<T> &R, T tol) {
+        done(F::fit_candidates(n_row, n_col, K1, K2, Ap.data(), len(Ap), Ai.data(), len(Ai), Ax.mutable_data(), len(Ax), B.data(), len(B),
+                               R.mutable_data(), len(R), tol), "fit_candidates");
+    }, py::arg("n_row"), py::arg("n_col"), py::arg("K1"), py::arg("K2"), nc("Ap"), nc("Ai"), nc("Ax"), nc("B"), nc("R"), py::arg("tol"));
 }
 
 }  // namespace
@@ -142,5 +148,12 @@ PYBIND11_MODULE(_amg_core_pybind, m)
               "signature-compatible with pyamg.amg_core";
     bind<float>(m);
     bind<double>(m);
+    // amg_core.standard_aggregation (smoothed_aggregation_bind.cpp:49-75): returns the number of aggregates
+    m.def("standard_aggregation", [](int n_row, Idx &Ap, Idx &Aj, Idx &x, Idx &y) {
+        int naggs = 0;
+        done(pamg_standard_aggregation(n_row, Ap.data(), len(Ap), Aj.data(), len(Aj), x.mutable_data(), len(x), y.mutable_data(), len(y), &naggs),
+             "standard_aggregation");
+        return naggs;
+    }, py::arg("n_row"), py::arg("Ap").noconvert(), py::arg("Aj").noconvert(), py::arg("x").noconvert(), py::arg("y").noconvert());
     m.def("version", [] { return std::string(pamg_version()); });
 }

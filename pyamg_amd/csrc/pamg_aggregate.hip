@@ -5,7 +5,10 @@
 //     the block-weighted prolongation smoother.
 // The arithmetic follows the reference expression by expression (separate multiply and add, IEEE divide and square
 // root, the same loop nests), so the blocks come out bit for bit.
+#include <algorithm>
+#include <climits>
 #include <limits>
+#include <vector>
 
 #include "pamg_common.h"
 
@@ -195,5 +198,448 @@ int pamg_dev_pinv_array(int dtype, void *AA, int64_t m, int n, int transA, pamg_
     if (n > PN) return PAMG_E_UNSUPPORTED;
     return pinv_launch(dtype, AA, m, n, transA ? 1 : 0, (hipStream_t)s);
 }
+
+}  // extern "C"
+
+// ================================================================================================================
+// amg_core::standard_aggregation (reference pyamg/amg_core/smoothed_aggregation.h:137-268) on a device-resident CSR
+// pattern -- the same aggregates, the same numbering, the same C-points, integer for integer.
+//
+// The reference's first pass is a sequential greedy sweep: vertex i becomes the root of a new aggregate iff, when its
+// turn comes, neither i nor any of its neighbours carries a mark; a root marks itself and its neighbours.  What i reads
+// (the marks of N[i] = {i} + row(i)) was possibly written by every earlier vertex k with N[k] meeting N[i] -- a dependency
+// of distance two.  It is honoured here without computing two-hop neighbourhoods: every vertex keeps a counter cnt[v] of
+// the members of N[v] that have had their turn.  Any two members of one N[v] depend on each other, so they take their
+// turns in index order, and "all members of N[v] below i are through" is simply cnt[v] >= need(i, v), the rank of i in
+// N[v] (computed once per stored entry).  Vertex i waits for that on every v in N[i] -- then all marks it reads are
+// final -- decides, writes its marks, and bumps the counters of N[i].  One lane per vertex, chunks of consecutive
+// vertices handed out in index order by a ticket counter to workgroups that are already running: a waiting vertex only
+// ever waits for smaller ones, whose chunks are out, so the sweep completes for any residency.  (Symmetric patterns
+// without duplicate entries: what strength-of-connection matrices are.  Anything else: PAMG_E_UNSUPPORTED.)
+// Passes 2 and 3 of the reference read only what pass 1 wrote (on a symmetric pattern its third pass never opens a new
+// aggregate: every vertex is within distance two of a root) and are plain data-parallel kernels plus a prefix sum.
+namespace {
+
+constexpr int AGG_ISO = INT32_MIN;          // isolated vertex (the reference's x = -n_row)
+
+__device__ __forceinline__ int ald(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ast(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// need[p] for every stored entry (i -> v), need_self[i]; flags: bit 0 pattern not symmetric, bit 1 duplicate entries
+__global__ __launch_bounds__(BLK) void agg_need_kernel(int n, const int *Ap, const int *Aj, int *need, int *need_self, unsigned *flag)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        int self = 0;
+        bool dup = false;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int v = Aj[p];
+            for (int q = p + 1; q < Ap[i + 1]; ++q) dup = dup || Aj[q] == v;
+            if (v == i) { need[p] = 0; continue; }
+            self += v < i ? 1 : 0;
+            int lt = v < i ? 1 : 0, found = 0;                 // v itself is a member of N[v]
+            for (int q = Ap[v]; q < Ap[v + 1]; ++q) {
+                const int k = Aj[q];
+                if (k == v) continue;
+                lt += k < i ? 1 : 0;
+                found += k == i ? 1 : 0;
+            }
+            need[p] = lt;
+            if (found == 0) atomicOr(flag, 1u);
+        }
+        need_self[i] = self;
+        if (dup) atomicOr(flag, 2u);
+    }
+}
+
+__global__ __launch_bounds__(BLK) void agg_pass1_kernel(int n, const int *Ap, const int *Aj, const int *need, const int *need_self,
+                                                         int *cnt, int *mark, unsigned *ticket, unsigned *err)
+{
+    __shared__ unsigned sh_chunk;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) sh_chunk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const long long base = (long long)sh_chunk * BLK;
+        if (base >= n) break;
+        const int i = (int)base + threadIdx.x;
+        bool done = i >= n;
+        int lo = 0, hi = 0;
+        if (!done) {
+            lo = Ap[i]; hi = Ap[i + 1];
+            bool has_nb = false;
+            for (int p = lo; p < hi; ++p) has_nb = has_nb || Aj[p] != i;
+            if (!has_nb) {                                       // isolated: never aggregated, nobody waits for it
+                ast(mark + i, AGG_ISO);
+                done = true;
+            }
+        }
+        unsigned spins = 0;
+        while (__any(!done)) {
+            if (!done) {
+                bool ready = ald(cnt + i) >= need_self[i];
+                for (int p = lo; p < hi && ready; ++p) {
+                    const int v = Aj[p];
+                    if (v != i) ready = ald(cnt + v) >= need[p];
+                }
+                if (ready) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    bool free = ald(mark + i) == 0;
+                    for (int p = lo; p < hi && free; ++p) free = ald(mark + Aj[p]) == 0;
+                    if (free) {                                  // a new aggregate: the root and its neighbours (smoothed_aggregation.h:177-185)
+                        ast(mark + i, i + 1);
+                        for (int p = lo; p < hi; ++p) ast(mark + Aj[p], i + 1);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_fetch_add(cnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int p = lo; p < hi; ++p)
+                        if (Aj[p] != i) __hip_atomic_fetch_add(cnt + Aj[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    done = true;
+                }
+            }
+            if (++spins > (1u << 24)) {                          // a vertex we wait for never had its turn: report, do not hang
+                if (!done) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            if (!done) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+// pass 2 (smoothed_aggregation.h:190-205): an unmarked vertex joins the aggregate of its first neighbour (storage order)
+// that pass 1 put into one; recorded as the negative mark
+__global__ __launch_bounds__(BLK) void agg_pass2_kernel(int n, const int *Ap, const int *Aj, int *mark)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        if (mark[i] != 0) continue;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int m = mark[Aj[p]];
+            if (m > 0) { mark[i] = -m; break; }
+        }
+    }
+}
+
+constexpr int SCAN_PER = 8;                 // elements per lane in the block scan
+
+// roots per block of BLK * SCAN_PER vertices
+__global__ __launch_bounds__(BLK) void agg_count_kernel(int n, const int *mark, int *blocksum)
+{
+    __shared__ int sm[BLK];
+    const long long b0 = (long long)blockIdx.x * BLK * SCAN_PER + (long long)threadIdx.x * SCAN_PER;
+    int c = 0;
+    for (int e = 0; e < SCAN_PER; ++e) { const long long i = b0 + e; if (i < n && mark[i] == (int)i + 1) ++c; }
+    sm[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = BLK / 2; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = sm[0];
+}
+
+// rid[i] = number of roots below i (the aggregate number of root i), y[rid[i]] = i for roots
+__global__ __launch_bounds__(BLK) void agg_rank_kernel(int n, const int *mark, const int *blockoff, int *rid, int *y)
+{
+    __shared__ int sm[BLK];
+    const long long b0 = (long long)blockIdx.x * BLK * SCAN_PER + (long long)threadIdx.x * SCAN_PER;
+    int c = 0;
+    for (int e = 0; e < SCAN_PER; ++e) { const long long i = b0 + e; if (i < n && mark[i] == (int)i + 1) ++c; }
+    sm[threadIdx.x] = c;
+    __syncthreads();
+    for (int d = 1; d < BLK; d <<= 1) {                          // inclusive scan over the lanes
+        const int t = (int)threadIdx.x >= d ? sm[threadIdx.x - d] : 0;
+        __syncthreads();
+        sm[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = blockoff[blockIdx.x] + sm[threadIdx.x] - c;
+    for (int e = 0; e < SCAN_PER; ++e) {
+        const long long i = b0 + e;
+        if (i >= n) break;
+        rid[i] = run;
+        if (mark[i] == (int)i + 1) { y[run] = (int)i; ++run; }
+    }
+}
+
+// pass 3 (smoothed_aggregation.h:210-245) on what passes 1 and 2 left: aggregate numbers from 0, -1 for isolated vertices
+__global__ __launch_bounds__(BLK) void agg_final_kernel(int n, const int *mark, const int *rid, int *x, unsigned *flag)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        const int m = mark[i];
+        if (m == AGG_ISO) x[i] = -1;
+        else if (m > 0) x[i] = rid[m - 1];
+        else if (m < 0) x[i] = rid[-m - 1];
+        else { x[i] = -1; atomicOr(flag, 4u); }                  // would open an aggregate in the reference's third pass
+    }
+}
+
+int agg_grid(int64_t n, int cap = 4096) { return (int)std::min<int64_t>(cap, std::max<int64_t>(1, (n + BLK - 1) / BLK)); }
+
+// device arrays Ap[n+1], Aj[nnz] -> device x[n], y[n]; *count
+int standard_aggregation_device(int n, const int *d_Ap, const int *d_Aj, int64_t nnz, int *d_x, int *d_y, int *count)
+{
+    *count = 0;
+    if (n == 0) return PAMG_OK;
+    int *need = nullptr, *need_self = nullptr, *cnt = nullptr, *mark = nullptr, *rid = nullptr, *bsum = nullptr;
+    unsigned *ctl = nullptr;                                     // [0] flags, [1] ticket, [2] error
+    const int nb = (int)(((int64_t)n + (int64_t)BLK * SCAN_PER - 1) / ((int64_t)BLK * SCAN_PER));
+    int st = PAMG_OK;
+    auto cleanup = [&]() { hipFree(need); hipFree(need_self); hipFree(cnt); hipFree(mark); hipFree(rid); hipFree(bsum); hipFree(ctl); };
+#define AGG_CHECK(expr) do { st = (int)(expr); if (st) { cleanup(); return st; } } while (0)
+    AGG_CHECK(hipMalloc((void **)&need, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1)));
+    AGG_CHECK(hipMalloc((void **)&need_self, sizeof(int) * (size_t)n));
+    AGG_CHECK(hipMalloc((void **)&cnt, sizeof(int) * (size_t)n));
+    AGG_CHECK(hipMalloc((void **)&mark, sizeof(int) * (size_t)n));
+    AGG_CHECK(hipMalloc((void **)&rid, sizeof(int) * (size_t)n));
+    AGG_CHECK(hipMalloc((void **)&bsum, sizeof(int) * (size_t)(nb + 1)));
+    AGG_CHECK(hipMalloc((void **)&ctl, 4 * sizeof(unsigned)));
+    AGG_CHECK(hipMemset(cnt, 0, sizeof(int) * (size_t)n));
+    AGG_CHECK(hipMemset(mark, 0, sizeof(int) * (size_t)n));
+    AGG_CHECK(hipMemset(ctl, 0, 4 * sizeof(unsigned)));
+    hipLaunchKernelGGL(agg_need_kernel, dim3(agg_grid(n)), dim3(BLK), 0, 0, n, d_Ap, d_Aj, need, need_self, ctl);
+    AGG_CHECK(hipGetLastError());
+    unsigned h[4] = {0, 0, 0, 0};
+    AGG_CHECK(hipMemcpy(h, ctl, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[0] & 3u) { cleanup(); return PAMG_E_UNSUPPORTED; }     // not symmetric / duplicate entries: the dependency argument above does not hold
+    int dev = 0, cus = 64;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const int grid = (int)std::min<int64_t>((int64_t)cus * 8, ((int64_t)n + BLK - 1) / BLK);
+    hipLaunchKernelGGL(agg_pass1_kernel, dim3(grid), dim3(BLK), 0, 0, n, d_Ap, d_Aj, (const int *)need, (const int *)need_self, cnt, mark,
+                       ctl + 1, ctl + 2);
+    AGG_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(agg_pass2_kernel, dim3(agg_grid(n)), dim3(BLK), 0, 0, n, d_Ap, d_Aj, mark);
+    hipLaunchKernelGGL(agg_count_kernel, dim3(nb), dim3(BLK), 0, 0, n, (const int *)mark, bsum);
+    AGG_CHECK(hipGetLastError());
+    std::vector<int> hb((size_t)nb + 1, 0);
+    AGG_CHECK(hipMemcpy(hb.data(), bsum, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost));
+    int64_t acc = 0;
+    for (int b = 0; b < nb; ++b) { const int c = hb[b]; hb[b] = (int)acc; acc += c; }
+    *count = (int)acc;
+    AGG_CHECK(hipMemcpy(bsum, hb.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(agg_rank_kernel, dim3(nb), dim3(BLK), 0, 0, n, (const int *)mark, (const int *)bsum, rid, d_y);
+    hipLaunchKernelGGL(agg_final_kernel, dim3(agg_grid(n)), dim3(BLK), 0, 0, n, (const int *)mark, (const int *)rid, d_x, ctl);
+    AGG_CHECK(hipGetLastError());
+    AGG_CHECK(hipMemcpy(h, ctl, sizeof(h), hipMemcpyDeviceToHost));
+#undef AGG_CHECK
+    cleanup();
+    if (h[2]) return PAMG_E_TIMEOUT;
+    if (h[0] & 4u) return PAMG_E_UNSUPPORTED;
+    return PAMG_OK;
+}
+
+// ================================================================================================================
+// amg_core::fit_candidates (smoothed_aggregation.h:484-610): per aggregate the rows of B that belong to it -- a
+// (nodes * K1) x K2 dense matrix -- are orthonormalised column by column (modified Gram-Schmidt, every sum over the rows
+// in order), R gets the coefficients.  One lane per aggregate, the reference's loops as they are.
+// lists: Ap[n_col + 1] / Ai = the nodes of every aggregate (the CSC arrays of AggOp); work: (nnz, K1, K2) in list order;
+// sort != 0: the lists were filled in arbitrary order and are sorted first (ascending node = what tocsc() produces);
+// out / outpos != nullptr: block ii of the work array is finally copied to out[outpos[Ai[ii]]] (row order of AggOp).
+template <typename T>
+__global__ __launch_bounds__(64) void fit_candidates_kernel(int n_col, int K1, int K2, const int *Ap, int *Ai, T *work, const T *B, T *R,
+                                                            T tol, int sort, T *out, const int *outpos)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_col) return;
+    const int BS = K1 * K2;
+    const int c0 = Ap[j], c1 = Ap[j + 1];
+    if (sort)
+        for (int a = c0 + 1; a < c1; ++a) {                       // insertion sort: aggregates hold a few tens of nodes
+            const int v = Ai[a];
+            int b = a - 1;
+            while (b >= c0 && Ai[b] > v) { Ai[b + 1] = Ai[b]; --b; }
+            Ai[b + 1] = v;
+        }
+    T *Rj = R + (size_t)j * K2 * K2;
+    for (int e = 0; e < K2 * K2; ++e) Rj[e] = T(0);
+    T *W0 = work + (size_t)BS * c0, *W1 = work + (size_t)BS * c1;
+    for (int ii = c0; ii < c1; ++ii)
+        for (int e = 0; e < BS; ++e) work[(size_t)BS * ii + e] = B[(size_t)BS * Ai[ii] + e];
+    for (int bj = 0; bj < K2; ++bj) {
+        T norm_j = T(0);
+        for (T *p = W0 + bj; p < W1; p += K2) norm_j += (*p) * (*p);
+        norm_j = sqrt(norm_j);
+        const T threshold_j = tol * norm_j;
+        for (int bi = 0; bi < bj; ++bi) {
+            T dot = T(0);
+            for (T *pi = W0 + bi, *pj = W0 + bj; pi < W1; pi += K2, pj += K2) dot += (*pi) * (*pj);
+            for (T *pi = W0 + bi, *pj = W0 + bj; pi < W1; pi += K2, pj += K2) *pj -= dot * (*pi);
+            Rj[K2 * bi + bj] = dot;
+        }
+        norm_j = T(0);
+        for (T *p = W0 + bj; p < W1; p += K2) norm_j += (*p) * (*p);
+        norm_j = sqrt(norm_j);
+        T scale;
+        if (norm_j > threshold_j) { scale = (T)(1.0 / norm_j); Rj[K2 * bj + bj] = norm_j; }
+        else { scale = T(0); Rj[K2 * bj + bj] = T(0); }
+        for (T *p = W0 + bj; p < W1; p += K2) *p *= scale;
+    }
+    if (out)
+        for (int ii = c0; ii < c1; ++ii)
+            for (int e = 0; e < BS; ++e) out[(size_t)BS * outpos[Ai[ii]] + e] = work[(size_t)BS * ii + e];
+}
+
+// aggregate sizes / node lists from the aggregate number of every node (-1: none)
+__global__ __launch_bounds__(BLK) void agglist_count_kernel(int n, const int *Tp, const int *Tj, int *cnt)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+        if (Tp[i + 1] > Tp[i]) atomicAdd(cnt + Tj[Tp[i]], 1);
+}
+
+__global__ __launch_bounds__(BLK) void agglist_fill_kernel(int n, const int *Tp, const int *Tj, const int *Cp, int *cursor, int *Ci)
+{
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK)
+        if (Tp[i + 1] > Tp[i]) { const int a = Tj[Tp[i]]; Ci[Cp[a] + atomicAdd(cursor + a, 1)] = i; }
+}
+
+template <typename T>
+int fit_launch(int n_col, int K1, int K2, const int *Ap, int *Ai, T *work, const T *B, T *R, T tol, int sort, T *out, const int *outpos)
+{
+    if (n_col == 0) return PAMG_OK;
+    hipLaunchKernelGGL((fit_candidates_kernel<T>), dim3((n_col + 63) / 64), dim3(64), 0, 0, n_col, K1, K2, Ap, Ai, work, B, R, tol, sort, out, outpos);
+    return (int)hipGetLastError();
+}
+
+struct DevBufs {
+    std::vector<void *> p;
+    ~DevBufs() { for (void *q : p) hipFree(q); }
+    template <typename U> int get(U **out, size_t count)
+    {
+        void *q = nullptr;
+        const hipError_t e = hipMalloc(&q, std::max<size_t>(count * sizeof(U), 256));
+        if (e != hipSuccess) return (int)e;
+        p.push_back(q);
+        *out = (U *)q;
+        return PAMG_OK;
+    }
+};
+
+// amg_core.fit_candidates on HOST buffers (the reference's argument order, smoothed_aggregation_bind.cpp:134-170)
+template <typename T>
+int fit_candidates_host(int n_row, int n_col, int K1, int K2, const int32_t *Ap, int Ap_size, const int32_t *Ai, int Ai_size, T *Ax, int Ax_size,
+                        const T *B, int B_size, T *R, int R_size, T tol)
+{
+    if (n_row < 0 || n_col < 0 || K1 < 1 || K2 < 1 || !Ap || Ap_size != n_col + 1) return PAMG_E_ARG;
+    const int64_t nnz = Ap[n_col];
+    if (nnz < 0 || nnz != Ai_size || (int64_t)Ax_size != nnz * K1 * K2 || (int64_t)B_size != (int64_t)n_row * K1 * K2 ||
+        (int64_t)R_size != (int64_t)n_col * K2 * K2 || (nnz && (!Ai || !Ax || !B)) || (n_col && !R))
+        return PAMG_E_ARG;
+    for (int64_t k = 0; k < nnz; ++k) if (Ai[k] < 0 || Ai[k] >= n_row) return PAMG_E_ARG;
+    if (n_col == 0) return PAMG_OK;
+    DevBufs d;
+    int *dAp, *dAi;
+    T *dW, *dB, *dR;
+    PAMG_TRY(d.get(&dAp, (size_t)n_col + 1)); PAMG_TRY(d.get(&dAi, (size_t)nnz));
+    PAMG_TRY(d.get(&dW, (size_t)Ax_size)); PAMG_TRY(d.get(&dB, (size_t)B_size)); PAMG_TRY(d.get(&dR, (size_t)R_size));
+    PAMG_HIP(hipMemcpy(dAp, Ap, sizeof(int) * ((size_t)n_col + 1), hipMemcpyHostToDevice));
+    if (nnz) PAMG_HIP(hipMemcpy(dAi, Ai, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+    if (B_size) PAMG_HIP(hipMemcpy(dB, B, sizeof(T) * (size_t)B_size, hipMemcpyHostToDevice));
+    PAMG_TRY(fit_launch<T>(n_col, K1, K2, dAp, dAi, dW, dB, dR, tol, 0, nullptr, nullptr));
+    if (Ax_size) PAMG_HIP(hipMemcpy(Ax, dW, sizeof(T) * (size_t)Ax_size, hipMemcpyDeviceToHost));
+    PAMG_HIP(hipMemcpy(R, dR, sizeof(T) * (size_t)R_size, hipMemcpyDeviceToHost));
+    return PAMG_OK;
+}
+
+// tentative.fit_candidates fused (aggregation/tentative.py:9-152): AggOp in CSR (at most one entry per row), B (n_fine * K1, K2)
+// -> the blocks of the tentative prolongator in AggOp's row order (T.data) and the coarse candidates R (n_coarse * K2, K2)
+template <typename T>
+int fit_tentative_host(int n_fine, int n_coarse, int K1, int K2, const int32_t *Tp, const int32_t *Tj, const T *B, T *Qx, T *R, T tol)
+{
+    if (n_fine < 0 || n_coarse < 0 || K1 < 1 || K2 < 1 || !Tp || (n_fine && !B)) return PAMG_E_ARG;
+    const int64_t nnz = Tp[n_fine];
+    if (nnz < 0 || nnz > n_fine || (nnz && (!Tj || !Qx)) || (n_coarse && !R)) return PAMG_E_ARG;
+    for (int i = 0; i < n_fine; ++i) {
+        if (Tp[i + 1] - Tp[i] < 0 || Tp[i + 1] - Tp[i] > 1) return PAMG_E_UNSUPPORTED;      // AggOp of an aggregation: a node is in one aggregate
+        if (Tp[i + 1] > Tp[i] && (Tj[Tp[i]] < 0 || Tj[Tp[i]] >= n_coarse)) return PAMG_E_ARG;
+    }
+    if (n_coarse == 0) return PAMG_OK;
+    const size_t BS = (size_t)K1 * K2;
+    DevBufs d;
+    int *dTp, *dTj, *dCp, *dCi, *dCur;
+    T *dW, *dB, *dR, *dQ;
+    PAMG_TRY(d.get(&dTp, (size_t)n_fine + 1)); PAMG_TRY(d.get(&dTj, (size_t)std::max<int64_t>(nnz, 1)));
+    PAMG_TRY(d.get(&dCp, (size_t)n_coarse + 1)); PAMG_TRY(d.get(&dCi, (size_t)std::max<int64_t>(nnz, 1))); PAMG_TRY(d.get(&dCur, (size_t)n_coarse));
+    PAMG_TRY(d.get(&dW, (size_t)nnz * BS)); PAMG_TRY(d.get(&dQ, (size_t)nnz * BS));
+    PAMG_TRY(d.get(&dB, (size_t)n_fine * BS)); PAMG_TRY(d.get(&dR, (size_t)n_coarse * K2 * K2));
+    PAMG_HIP(hipMemcpy(dTp, Tp, sizeof(int) * ((size_t)n_fine + 1), hipMemcpyHostToDevice));
+    if (nnz) PAMG_HIP(hipMemcpy(dTj, Tj, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+    if (n_fine) PAMG_HIP(hipMemcpy(dB, B, sizeof(T) * (size_t)n_fine * BS, hipMemcpyHostToDevice));
+    PAMG_HIP(hipMemset(dCur, 0, sizeof(int) * (size_t)n_coarse));
+    if (n_fine) hipLaunchKernelGGL(agglist_count_kernel, dim3(agg_grid(n_fine)), dim3(BLK), 0, 0, n_fine, (const int *)dTp, (const int *)dTj, dCur);
+    PAMG_HIP(hipGetLastError());
+    std::vector<int> cp((size_t)n_coarse + 1, 0);
+    PAMG_HIP(hipMemcpy(cp.data() + 1, dCur, sizeof(int) * (size_t)n_coarse, hipMemcpyDeviceToHost));
+    for (int a = 0; a < n_coarse; ++a) cp[(size_t)a + 1] += cp[(size_t)a];
+    PAMG_HIP(hipMemcpy(dCp, cp.data(), sizeof(int) * ((size_t)n_coarse + 1), hipMemcpyHostToDevice));
+    PAMG_HIP(hipMemset(dCur, 0, sizeof(int) * (size_t)n_coarse));
+    if (n_fine) hipLaunchKernelGGL(agglist_fill_kernel, dim3(agg_grid(n_fine)), dim3(BLK), 0, 0, n_fine, (const int *)dTp, (const int *)dTj, (const int *)dCp, dCur, dCi);
+    PAMG_HIP(hipGetLastError());
+    PAMG_TRY(fit_launch<T>(n_coarse, K1, K2, dCp, dCi, dW, dB, dR, tol, 1, dQ, dTp));          // outpos[node] = Tp[node]: its only entry
+    if (nnz) PAMG_HIP(hipMemcpy(Qx, dQ, sizeof(T) * (size_t)nnz * BS, hipMemcpyDeviceToHost));
+    PAMG_HIP(hipMemcpy(R, dR, sizeof(T) * (size_t)n_coarse * K2 * K2, hipMemcpyDeviceToHost));
+    return PAMG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// amg_core::standard_aggregation on HOST arrays (smoothed_aggregation_bind.cpp:49-75): returns the number of aggregates
+// through *naggs (the reference returns it); x = aggregate of every node (-1: none), y = the C-points
+int pamg_standard_aggregation(int32_t n_row, const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size, int32_t *x, int x_size,
+                              int32_t *y, int y_size, int32_t *naggs)
+{
+    if (n_row < 0 || !Ap || Ap_size != n_row + 1 || x_size < n_row || y_size < n_row || !naggs || (n_row && (!x || !y))) return PAMG_E_ARG;
+    const int64_t nnz = Ap[n_row];
+    if (nnz < 0 || nnz != Aj_size || (nnz && !Aj) || Ap[0] != 0) return PAMG_E_ARG;
+    for (int i = 0; i < n_row; ++i) if (Ap[i + 1] < Ap[i]) return PAMG_E_ARG;
+    for (int64_t p = 0; p < nnz; ++p) if (Aj[p] < 0 || Aj[p] >= n_row) return PAMG_E_ARG;
+    *naggs = 0;
+    if (n_row == 0) return PAMG_OK;
+    DevBufs d;
+    int *dAp, *dAj, *dx, *dy;
+    PAMG_TRY(d.get(&dAp, (size_t)n_row + 1)); PAMG_TRY(d.get(&dAj, (size_t)std::max<int64_t>(nnz, 1)));
+    PAMG_TRY(d.get(&dx, (size_t)n_row)); PAMG_TRY(d.get(&dy, (size_t)n_row));
+    PAMG_HIP(hipMemcpy(dAp, Ap, sizeof(int) * ((size_t)n_row + 1), hipMemcpyHostToDevice));
+    if (nnz) PAMG_HIP(hipMemcpy(dAj, Aj, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+    int count = 0;
+    PAMG_TRY(standard_aggregation_device(n_row, dAp, dAj, nnz, dx, dy, &count));
+    PAMG_HIP(hipMemcpy(x, dx, sizeof(int) * (size_t)n_row, hipMemcpyDeviceToHost));
+    if (count) PAMG_HIP(hipMemcpy(y, dy, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost));
+    *naggs = count;
+    return PAMG_OK;
+}
+
+// the same on a device-resident pattern (e.g. the strength matrix pamg_csr_strength_symmetric just produced): x, y HOST
+int pamg_csr_standard_aggregation(pamg_csr_t C, int32_t *x, int32_t *y, int32_t *naggs)
+{
+    if (!C || !naggs) return PAMG_E_ARG;
+    CsrArrays a;
+    PAMG_TRY(csr_device_arrays(C, &a));
+    if (a.m != a.n || a.m > INT32_MAX) return PAMG_E_ARG;
+    const int n = (int)a.m;
+    *naggs = 0;
+    if (n == 0) return PAMG_OK;
+    if (!x || !y) return PAMG_E_ARG;
+    DevBufs d;
+    int *dx, *dy;
+    PAMG_TRY(d.get(&dx, (size_t)n)); PAMG_TRY(d.get(&dy, (size_t)n));
+    int count = 0;
+    PAMG_TRY(standard_aggregation_device(n, a.p, a.j, a.nnz, dx, dy, &count));
+    PAMG_HIP(hipMemcpy(x, dx, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    if (count) PAMG_HIP(hipMemcpy(y, dy, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost));
+    *naggs = count;
+    return PAMG_OK;
+}
+
+int pamg_fit_candidates_f64(int32_t n_row, int32_t n_col, int32_t K1, int32_t K2, const int32_t *Ap, int Ap_size, const int32_t *Ai, int Ai_size,
+                            double *Ax, int Ax_size, const double *B, int B_size, double *R, int R_size, double tol)
+{ return fit_candidates_host<double>(n_row, n_col, K1, K2, Ap, Ap_size, Ai, Ai_size, Ax, Ax_size, B, B_size, R, R_size, tol); }
+int pamg_fit_candidates_f32(int32_t n_row, int32_t n_col, int32_t K1, int32_t K2, const int32_t *Ap, int Ap_size, const int32_t *Ai, int Ai_size,
+                            float *Ax, int Ax_size, const float *B, int B_size, float *R, int R_size, float tol)
+{ return fit_candidates_host<float>(n_row, n_col, K1, K2, Ap, Ap_size, Ai, Ai_size, Ax, Ax_size, B, B_size, R, R_size, tol); }
+
+int pamg_fit_tentative_f64(int32_t n_fine, int32_t n_coarse, int32_t K1, int32_t K2, const int32_t *Tp, const int32_t *Tj, const double *B,
+                           double *Qx, double *R, double tol)
+{ return fit_tentative_host<double>(n_fine, n_coarse, K1, K2, Tp, Tj, B, Qx, R, tol); }
+int pamg_fit_tentative_f32(int32_t n_fine, int32_t n_coarse, int32_t K1, int32_t K2, const int32_t *Tp, const int32_t *Tj, const float *B,
+                           float *Qx, float *R, float tol)
+{ return fit_tentative_host<float>(n_fine, n_coarse, K1, K2, Tp, Tj, B, Qx, R, tol); }
 
 }  // extern "C"

@@ -188,6 +188,7 @@ struct pamg_matrix_s {
 
 struct pamg_schwarz_s;
 struct pamg_solver_s;
+struct pamg_csr_s;
 
 namespace pamg {
 // pamg_schwarz.hip
@@ -225,6 +226,8 @@ int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, i
 int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *xsrc, void *xdst,
                       const void *b, double omega, hipStream_t s);
 int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step);
+struct CsrArrays { int64_t m, n, nnz; const int *p, *j; const double *x; };
+int csr_device_arrays(struct ::pamg_csr_s *A, CsrArrays *out);                                  // pamg_setup.hip: the device arrays behind a pamg_csr_t
 int solver_cycle_inline(pamg_solver_s *S, void *x, const void *b, int cycle, int cpl, hipStream_t s, bool allow_graph);   // pamg_solver.hip
 int sweep_error(pamg_matrix_s *A, bool *error);      // spin bound hit since the last call? (caller has synchronised; clears the flag)
 inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }

@@ -1089,6 +1089,13 @@ int subtract_bsr(pamg_csr_s *A, pamg_csr_s *B, int R, int C, pamg_csr_s **out)
 }
 
 }  // namespace
+
+int csr_device_arrays(pamg_csr_s *A, CsrArrays *out)
+{
+    if (!A || !out) return PAMG_E_ARG;
+    out->m = A->m; out->n = A->n; out->nnz = A->nnz; out->p = A->d_p; out->j = A->d_j; out->x = A->d_x;
+    return PAMG_OK;
+}
 }  // namespace pamg
 
 using namespace pamg;

@@ -62,11 +62,12 @@ struct TilePlan {
 };
 
 // fn(lo, hi) over [0, n) on a few host threads (planning is a one-time setup cost, but a 16.7M-row level is big)
+// grain: items one thread should at least get (rows: 64; whole tiles: 1)
 template <typename F>
-inline void tp_parallel(int n, F fn)
+inline void tp_parallel(int n, F fn, int grain = 64)
 {
     const unsigned hw = std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
-    const int nt = (n < 256) ? 1 : (int)std::min<unsigned>(hw, (unsigned)(n / 64));
+    const int nt = (n < 4 * grain) ? 1 : (int)std::min<unsigned>(hw, (unsigned)(n / grain));
     if (nt == 1) { fn(0, n); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) {
@@ -185,14 +186,16 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
             const int64_t gy = (ny + ty - 1) / ty, gz = (nz + tz - 1) / tz;
             if (gy * gz <= (int64_t)G_want * 2 && gy * gz >= 1) {
                 G = (int)(gy * gz);
-                for (int t = 0; t < m; ++t) {
-                    const int i = row_start + t * row_step;
-                    const int64_t p = row_step == 1 ? (int64_t)t : (int64_t)(m - 1 - t);   // lexicographic position of the row
-                    const int64_t z = p / nxy, y = (p % nxy) / nx;
-                    int64_t k = (z / tz) * gy + (y / ty);
-                    if (row_step != 1) k = (int64_t)G - 1 - k;         // tiles numbered along the sweep
-                    tile[i] = (int)k;
-                }
+                tp_parallel(m, [&](int tlo, int thi) {
+                    for (int t = tlo; t < thi; ++t) {
+                        const int i = row_start + t * row_step;
+                        const int64_t p = row_step == 1 ? (int64_t)t : (int64_t)(m - 1 - t);   // lexicographic position of the row
+                        const int64_t z = p / nxy, y = (p % nxy) / nx;
+                        int64_t k = (z / tz) * gy + (y / ty);
+                        if (row_step != 1) k = (int64_t)G - 1 - k;         // tiles numbered along the sweep
+                        tile[i] = (int)k;
+                    }
+                });
                 pencils = true;
             }
         }
@@ -247,7 +250,7 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
                 for (int l = 0; l <= lmax - lmin; ++l) cnt[l + 1] += cnt[l];
                 for (int t = t0; t < t1; ++t) order[t0 + cnt[lvl[bytile[t]] - lmin]++] = bytile[t];
             }
-        });
+        }, 1);
     }
     std::vector<int> pos((size_t)n, -1);      // stored position of a visited row
     tp_parallel(m, [&](int lo, int hi) { for (int r = lo; r < hi; ++r) pos[order[r]] = r; });
@@ -294,30 +297,43 @@ inline int build_tile_plan_from(int n, const int *Ap, const int *Aj, int row_sta
         }
         n_local += nloc; n_global += nglob;
     });
-    // steps: rows of one level of one tile, bounded by rows, entries and list sizes
+    // steps: rows of one level of one tile, bounded by rows, entries and list sizes -- every tile on its own, strung together after
+    struct TileSteps { std::vector<TileStep> steps; std::vector<int> level, no, ng, nl; };
+    std::vector<TileSteps> per((size_t)G);
+    tp_parallel(G, [&](int klo, int khi) {
+        for (int k = klo; k < khi; ++k) {
+            TileSteps &ts = per[(size_t)k];
+            int r = tcount[k];
+            const int rend = tcount[k + 1];
+            while (r < rend) {
+                const int L = lvl[order[r]];
+                TileStep s{r, r, P.Ap[r], P.Ap[r]};
+                int no = 0, ng = 0, nl = 0;
+                while (s.r1 < rend && lvl[order[s.r1]] == L && s.r1 - s.r0 < max_rows) {
+                    const int len = P.Ap[s.r1 + 1] - P.Ap[s.r1];
+                    const int o2 = no + row_old[s.r1], g2 = ng + row_glob[s.r1], l2 = nl + row_loc[s.r1];
+                    if (s.r1 > s.r0 && ((s.p1 - s.p0) + len > cap || o2 > TILE_MAX_OLD || g2 > TILE_MAX_GLOB ||
+                                        tile_list_bytes(o2, g2, l2) > TILE_MAX_LIST_BYTES))
+                        break;
+                    s.p1 += len;
+                    no = o2; ng = g2; nl = l2;
+                    s.r1++;
+                }
+                ts.steps.push_back(s);
+                ts.level.push_back(L);
+                ts.no.push_back(no); ts.ng.push_back(ng); ts.nl.push_back(nl);
+                r = s.r1;
+            }
+        }
+    }, 1);
     P.tile_step.assign(1, 0);
     for (int k = 0; k < G; ++k) {
-        int r = tcount[k];
-        const int rend = tcount[k + 1];
-        while (r < rend) {
-            const int L = lvl[order[r]];
-            TileStep s{r, r, P.Ap[r], P.Ap[r]};
-            int no = 0, ng = 0, nl = 0;
-            while (s.r1 < rend && lvl[order[s.r1]] == L && s.r1 - s.r0 < max_rows) {
-                const int len = P.Ap[s.r1 + 1] - P.Ap[s.r1];
-                const int o2 = no + row_old[s.r1], g2 = ng + row_glob[s.r1], l2 = nl + row_loc[s.r1];
-                if (s.r1 > s.r0 && ((s.p1 - s.p0) + len > cap || o2 > TILE_MAX_OLD || g2 > TILE_MAX_GLOB ||
-                                    tile_list_bytes(o2, g2, l2) > TILE_MAX_LIST_BYTES))
-                    break;
-                s.p1 += len;
-                no = o2; ng = g2; nl = l2;
-                s.r1++;
-            }
-            P.steps.push_back(s);
-            P.step_level.push_back(L);
-            P.step_old.push_back(no); P.step_glob.push_back(ng); P.step_loc.push_back(nl);
-            r = s.r1;
-        }
+        const TileSteps &ts = per[(size_t)k];
+        P.steps.insert(P.steps.end(), ts.steps.begin(), ts.steps.end());
+        P.step_level.insert(P.step_level.end(), ts.level.begin(), ts.level.end());
+        P.step_old.insert(P.step_old.end(), ts.no.begin(), ts.no.end());
+        P.step_glob.insert(P.step_glob.end(), ts.ng.begin(), ts.ng.end());
+        P.step_loc.insert(P.step_loc.end(), ts.nl.begin(), ts.nl.end());
         P.tile_step.push_back((int)P.steps.size());
     }
     P.n_local = n_local; P.n_global = n_global;
@@ -425,7 +441,7 @@ inline int pack_tile_blocks(const TilePlan &P, const TileGeom &g, const T *Ax, c
                 hdr[0] = nrows; hdr[1] = st.r0 - tile_r0; hdr[2] = no | (ng << 16); hdr[3] = nl;
             }
         }
-    });
+    }, 1);
     return bad.load();
 }
 

@@ -582,6 +582,40 @@ def make_kernels_setup():
     out["bd.inv2"] = get_block_diag(A.copy(), blocksize=2, inv_flag=True)
     out["bd.blk2"] = get_block_diag(A.copy(), blocksize=2, inv_flag=False)
     out["bd.inv4"] = get_block_diag(pyamg.gallery.poisson((10, 10), format="csr"), blocksize=4, inv_flag=True)
+    # amg_core.standard_aggregation on strength graphs (2-D / 3-D stencils, an irregular symmetric pattern, isolated nodes)
+    # and amg_core.fit_candidates / tentative.fit_candidates on the aggregates (scalar, vector and rank-deficient candidates)
+    import scipy.sparse as sp
+    from pyamg.aggregation.aggregate import standard_aggregation
+    from pyamg.aggregation.tentative import fit_candidates
+    from pyamg.strength import symmetric_strength_of_connection
+    graphs = {"p2d": symmetric_strength_of_connection(pyamg.gallery.poisson((40, 40), format="csr"), theta=0.0),
+              "p3d": symmetric_strength_of_connection(pyamg.gallery.poisson((14, 14, 14), format="csr"), theta=0.0)}
+    M = sp.random_array((600, 600), density=0.002, random_state=rng, format="csr")
+    M = (M + M.T).tocsr()
+    M.setdiag(0)
+    M.eliminate_zeros()                                      # some nodes end up without any neighbour
+    M = (M + sp.diags_array((np.arange(600) % 3 == 0).astype(float))).tocsr()     # diagonal entries on a third of the rows
+    M.eliminate_zeros()
+    graphs["irr"] = M
+    aniso = pyamg.gallery.stencil_grid(np.array([[0, -1.0, 0], [-0.001, 2.002, -0.001], [0, -1.0, 0]]), (30, 30), format="csr")
+    graphs["aniso"] = symmetric_strength_of_connection(aniso, theta=0.25)
+    for name, Cg in graphs.items():
+        Cg = sp.csr_array(Cg)
+        n = Cg.shape[0]
+        x, y = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        cnt = amg_core.standard_aggregation(n, Cg.indptr.astype(np.int32), Cg.indices.astype(np.int32), x, y)
+        out[f"agg.{name}.indptr"], out[f"agg.{name}.indices"] = Cg.indptr.astype(np.int32), Cg.indices.astype(np.int32)
+        out[f"agg.{name}.x"], out[f"agg.{name}.y"] = x, y[:cnt]
+    AggOp, _ = standard_aggregation(sp.csr_array(graphs["p2d"]))
+    out["fit.Tp"], out["fit.Tj"] = AggOp.indptr.astype(np.int32), AggOp.indices.astype(np.int32)
+    out["fit.shape"] = np.array(AggOp.shape)
+    for tag, K1, K2, dt in (("a", 1, 1, np.float64), ("b", 2, 3, np.float64), ("c", 3, 6, np.float64), ("d", 1, 2, np.float32)):
+        B = rng.standard_normal((AggOp.shape[0] * K1, K2)).astype(dt)
+        if K2 > 1:
+            B[:, 1] = 2 * B[:, 0]                            # a dependent candidate: its column of Q is zeroed
+        Q, R = fit_candidates(AggOp, B)
+        out[f"fit.{tag}.B"], out[f"fit.{tag}.Q"], out[f"fit.{tag}.R"] = B, Q.data, R
+        assert np.array_equal(Q.indptr, AggOp.indptr) and np.array_equal(Q.indices, AggOp.indices)
     np.savez_compressed(HERE / "kernels_setup.npz", **out)
     print("kernels_setup.npz written:", len(out), "arrays")
 

@@ -322,6 +322,79 @@ def test_block_difference_is_scipys():
             assert np.array_equal(out.data, want.data)
 
 
+def test_aggregation_and_tentative_prolongator_on_the_device():
+    """f4: amg_core.standard_aggregation and fit_candidates on the device against the reference's outputs (committed) and
+    the oracle: aggregates, their numbering and the C-points integer for integer; tentative-prolongator blocks and coarse
+    candidates bit for bit (the per-aggregate sums run in the reference's order)"""
+    from conftest import GOLDEN
+    from oracle import oracle as orc
+    from pyamg_amd import amg_core as gcore
+    from pyamg_amd.aggregation import fit_candidates, standard_aggregation
+    z = np.load(GOLDEN / "kernels_setup.npz")
+    for name in ("p2d", "p3d", "irr", "aniso"):
+        Ap, Aj = z[f"agg.{name}.indptr"], z[f"agg.{name}.indices"]
+        n = Ap.size - 1
+        x, y = np.full(n, -7, dtype=np.int32), np.full(n, -7, dtype=np.int32)
+        cnt = gcore.standard_aggregation(n, Ap, Aj, x, y)
+        assert cnt == z[f"agg.{name}.y"].size, name
+        assert np.array_equal(x, z[f"agg.{name}.x"]) and np.array_equal(y[:cnt], z[f"agg.{name}.y"]), name
+        Cg = sp.csr_array((np.ones(Aj.size), Aj, Ap), shape=(n, n))
+        AggOp, Cpts = standard_aggregation(Cg)
+        assert np.array_equal(Cpts, z[f"agg.{name}.y"]) and AggOp.shape == (n, cnt) and AggOp.dtype == np.int32
+        keep = z[f"agg.{name}.x"] >= 0
+        assert np.array_equal(AggOp.indices, z[f"agg.{name}.x"][keep]) and np.array_equal(np.diff(AggOp.indptr), keep.astype(np.int32))
+    # a non-symmetric pattern is refused (the reference's third pass could open aggregates there): NotImplementedError
+    Cn = sp.csr_array((np.ones(3), np.array([1, 2, 0], dtype=np.int32), np.array([0, 1, 2, 3], dtype=np.int32)), shape=(3, 3))
+    with pytest.raises(NotImplementedError):
+        standard_aggregation(Cn)
+    Tp, Tj, shape = z["fit.Tp"], z["fit.Tj"], tuple(z["fit.shape"])
+    AggOp = sp.csr_array((np.ones(Tj.size, dtype=np.int32), Tj, Tp), shape=shape)
+    csc = AggOp.tocsc()
+    for tag, K1, K2 in (("a", 1, 1), ("b", 2, 3), ("c", 3, 6), ("d", 1, 2)):
+        B = z[f"fit.{tag}.B"]
+        Q, R = fit_candidates(AggOp, B)
+        assert Q.format == "bsr" and tuple(Q.blocksize) == (K1, K2) and Q.shape == (K1 * shape[0], K2 * shape[1])
+        assert np.array_equal(Q.indptr, Tp) and np.array_equal(Q.indices, Tj)
+        assert np.array_equal(Q.data, z[f"fit.{tag}.Q"]), tag
+        assert np.array_equal(R, z[f"fit.{tag}.R"]), tag
+        # the amg_core-signature entry point: CSC lists in, blocks in CSC order out
+        Ax = np.zeros(Tj.size * K1 * K2, dtype=B.dtype)
+        Rr = np.zeros(shape[1] * K2 * K2, dtype=B.dtype)
+        gcore.fit_candidates(shape[0], shape[1], K1, K2, csc.indptr.astype(np.int32), csc.indices.astype(np.int32), Ax, np.ravel(B).copy(), Rr, 1e-10)
+        Axo, Ro = orc.fit_candidates(shape[1], K1, K2, csc.indptr, csc.indices, B, 1e-10)
+        assert np.array_equal(Ax, np.ravel(Axo)) and np.array_equal(Rr, np.ravel(Ro))
+
+
+def test_device_aggregation_inside_the_reference_setup():
+    """device_setup patches standard_aggregation and fit_candidates too: on 3-D Poisson 128^3 and 3-D elasticity 40^3 the
+    reference's solver built through them has the SAME aggregates (AggOp, C-points) and tentative prolongators as the
+    solver built by the reference alone (integers exact; floats <= 1e-14 relative: T and B_coarse bit-identical on the
+    fine level, coarser levels inherit the last bits of the device spectral radii through the smoothed prolongator)"""
+    pyamg = _reference()
+    import sys
+    sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
+    from tools.problems import elasticity3d
+    from pyamg_amd.aggregation import device_setup
+    A1 = pyamg.gallery.poisson((128, 128, 128), format="csr")
+    A2, B2 = elasticity3d(40)
+    for A, kw in ((A1, {}), (A2, {"B": B2, "smooth": "jacobi"})):
+        np.random.seed(9)
+        ref = pyamg.smoothed_aggregation_solver(A.copy(), max_coarse=10, keep=True, **kw)
+        np.random.seed(9)
+        with device_setup(pyamg):
+            dev = pyamg.smoothed_aggregation_solver(A.copy(), max_coarse=10, keep=True, **kw)
+        assert len(dev.levels) == len(ref.levels)
+        for l, (Ld, Lr) in enumerate(zip(dev.levels[:-1], ref.levels[:-1])):
+            assert np.array_equal(Ld.AggOp.indptr, Lr.AggOp.indptr) and np.array_equal(Ld.AggOp.indices, Lr.AggOp.indices), l
+            assert np.array_equal(Ld.T.indptr, Lr.T.indptr) and np.array_equal(Ld.T.indices, Lr.T.indices), l
+            scale = np.max(np.abs(Lr.T.data))
+            assert np.max(np.abs(Ld.T.data - Lr.T.data)) <= 1e-14 * scale, (l, np.max(np.abs(Ld.T.data - Lr.T.data)) / scale)
+            Bd, Br = dev.levels[l + 1].B, ref.levels[l + 1].B
+            assert np.max(np.abs(Bd - Br)) <= 1e-14 * np.max(np.abs(Br)), l
+            if l == 0:
+                assert np.array_equal(Ld.T.data, Lr.T.data) and np.array_equal(Bd, Br)
+
+
 def test_symmetric_strength_against_the_reference():
     pyamg = _reference()
     from pyamg.strength import symmetric_strength_of_connection as ref_soc
