@@ -313,7 +313,9 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * (0 = automatic, <= 1020), 15 = let the automatic choice (key 5 = 0) prefer the tiled sweep, 16 = cap on the
  * steps resident in LDS per tile (0 = automatic), 17 = cap on the steps its loader keeps in flight (-1 = automatic),
  * 18 = tile shapes: 1 (default) pencils on three-band grid stencils, 0 contiguous chunks of the visit order always;
- * 19 = 16-bit windowed column stream of the whole-operator kernels (default 1; 0 = 32-bit columns).
+ * 19 = 16-bit windowed column stream of the whole-operator kernels (default 1; 0 = 32-bit columns);
+ * 20 = entries per row range of the level schedules of the order-exact sweeps (0 = automatic: key 0's value, 512 where the
+ * multi-XCD granular sweep runs SA-like rows; else 64..2048).
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* Pick the LDS window (key 0) and streaming flags (key 8) of the whole-operator kernels by timing
@@ -481,6 +483,10 @@ int pamg_solver_set_ne_smoother(pamg_solver_t S, int level, int which, int kind,
 /* coarsest solve x_c = M b_c with HOST row-major M (n_c x n_c); M == NULL: x_c = 0
  * (multilevel.py:717-721, 801-803) */
 int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c);
+/* coarsest solve = the relaxation method set as smoother `which = 0` of the LAST level, applied from x_c = 0
+ * (coarse_solver='gauss_seidel' / 'jacobi' / 'chebyshev' ...: multilevel.py:765-782).  Call after the level's
+ * pamg_solver_set_*smoother. */
+int pamg_solver_set_coarse_relax(pamg_solver_t S);
 int pamg_solver_finalize(pamg_solver_t S);
 /* one multigrid cycle on DEVICE x, b of level 0 (multilevel.py:584-662) */
 int pamg_solver_cycle(pamg_solver_t S, void *x, const void *b, int cycle, int cycles_per_level,
@@ -530,8 +536,11 @@ int pamg_solver_store(pamg_solver_t S, void *x, pamg_stream_t s);
 int pamg_solver_stream(pamg_solver_t S, pamg_stream_t *s);
 /* use hipGraph replay for the cycle (default 1) */
 int pamg_solver_set_graph(pamg_solver_t S, int enable);
-/* stats[0]=levels stats[1]=kernel launches per V-cycle stats[2]=HBM bytes resident
- * stats[3]=algorithmic bytes per V-cycle (incl. convergence check) */
+/* stats[0]=levels stats[1]=dependency levels of the order-exact schedules stats[2]=HBM bytes resident
+ * stats[3]=graphs instantiated stats[4]=times a persistent sweep hit its spin bound (PAMG_E_TIMEOUT: not all of its
+ * workgroups were running) and the solver switched to one launch per dependency level -- pamg_solver_solve then runs
+ * the solve again from the caller's initial guess and succeeds; pamg_solver_iterate / pcg / (f)gmres report the timeout
+ * once (their state is on the device) and are safe from the next call on */
 int pamg_solver_stats(pamg_solver_t S, int64_t stats[8]);
 
 /* ------------------------------------------------------------------------------------------------

@@ -457,6 +457,10 @@ class OracleSolver:
 
     def coarse_solve(self, b):
         """multilevel.py:717-721 (dense operator applied to b) / :801-803 (nnz == 0)."""
+        if self.spec.coarse_kind == "relax":                 # multilevel.py:765-782: sweeps from x = 0
+            x = np.zeros_like(b)
+            apply_smoother(self.spec.coarse_smoother, self.spec.levels[-1].A, x, b)
+            return x
         if self.spec.coarse_kind == "zero":
             return np.zeros(b.shape)
         return np.dot(self.spec.coarse_op, b)

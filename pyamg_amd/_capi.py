@@ -149,6 +149,7 @@ def _declare(lib):
     f("pamg_solver_set_ne_smoother", _vp, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp)
     f("pamg_solver_set_cf_smoother", _vp, _i, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i)
     f("pamg_solver_set_coarse_dense", _vp, _vp, _i)
+    f("pamg_solver_set_coarse_relax", _vp)
     f("pamg_solver_finalize", _vp)
     f("pamg_solver_cycle", _vp, _vp, _vp, _i, _i, _vp)
     f("pamg_solver_solve", _vp, _vp, _vp, _d, _i, _i, _i, _i, _vp, P(_i), P(_i), _vp)

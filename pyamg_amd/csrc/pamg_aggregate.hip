@@ -208,101 +208,100 @@ int pamg_dev_pinv_array(int dtype, void *AA, int64_t m, int n, int transA, pamg_
 // The reference's first pass is a sequential greedy sweep: vertex i becomes the root of a new aggregate iff, when its
 // turn comes, neither i nor any of its neighbours carries a mark; a root marks itself and its neighbours.  What i reads
 // (the marks of N[i] = {i} + row(i)) was possibly written by every earlier vertex k with N[k] meeting N[i] -- a dependency
-// of distance two.  It is honoured here without computing two-hop neighbourhoods: every vertex keeps a counter cnt[v] of
-// the members of N[v] that have had their turn.  Any two members of one N[v] depend on each other, so they take their
-// turns in index order, and "all members of N[v] below i are through" is simply cnt[v] >= need(i, v), the rank of i in
-// N[v] (computed once per stored entry).  Vertex i waits for that on every v in N[i] -- then all marks it reads are
-// final -- decides, writes its marks, and bumps the counters of N[i].  One lane per vertex, chunks of consecutive
-// vertices handed out in index order by a ticket counter to workgroups that are already running: a waiting vertex only
-// ever waits for smaller ones, whose chunks are out, so the sweep completes for any residency.  (Symmetric patterns
-// without duplicate entries: what strength-of-connection matrices are.  Anything else: PAMG_E_UNSUPPORTED.)
-// Passes 2 and 3 of the reference read only what pass 1 wrote (on a symmetric pattern its third pass never opens a new
-// aggregate: every vertex is within distance two of a root) and are plain data-parallel kernels plus a prefix sum.
+// of distance two.  It is honoured here without ever forming two-hop neighbourhoods: any two members of one N[v] depend
+// on each other, so within N[v] the turns go in index order -- every v simply passes a token down its SORTED member list:
+// when the member of rank c has had its turn, v hands the token to the member of rank c + 1.  A vertex may take its turn
+// once it holds the token of every v in N[i] (pend[i] counts the ones still missing; the smallest member of a list holds
+// that list's token from the start).  That is a topological traversal of the dependency graph: rounds of one launch
+// each, the vertices that became ready in round r run in round r + 1 (so everything they read was written before their
+// launch began -- no fences, no polling), 1 500 rounds on the 256^3 grid, a few microseconds each.
+// (Symmetric patterns without duplicate entries: what strength-of-connection matrices are.  Anything else:
+// PAMG_E_UNSUPPORTED.)  Passes 2 and 3 of the reference read only what pass 1 wrote (on a symmetric pattern its third
+// pass never opens a new aggregate: every vertex is within distance two of a root) and are plain data-parallel kernels
+// plus a prefix sum.
 namespace {
 
 constexpr int AGG_ISO = INT32_MIN;          // isolated vertex (the reference's x = -n_row)
 
-__device__ __forceinline__ int ald(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ast(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// need[p] for every stored entry (i -> v), need_self[i]; flags: bit 0 pattern not symmetric, bit 1 duplicate entries
-__global__ __launch_bounds__(BLK) void agg_need_kernel(int n, const int *Ap, const int *Aj, int *need, int *need_self, unsigned *flag)
+// Member lists: Ns[Ap[v] + v ...] = {v} + row(v) sorted ascending, nsize[v] members.  flags: bit 0 pattern not symmetric,
+// bit 1 duplicate entries.  Isolated vertices (no neighbour but themselves) are marked at once and take no part.
+__global__ __launch_bounds__(BLK) void agg_lists_kernel(int n, const int *Ap, const int *Aj, int *Ns, int *nsize, int *mark, unsigned *flag,
+                                                        unsigned *nlive)
 {
-    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
-        int self = 0;
+    for (int v = blockIdx.x * BLK + threadIdx.x; v < n; v += gridDim.x * BLK) {
+        int *L = Ns + (size_t)Ap[v] + v;
+        int m = 0;
+        L[m++] = v;
         bool dup = false;
-        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
-            const int v = Aj[p];
-            for (int q = p + 1; q < Ap[i + 1]; ++q) dup = dup || Aj[q] == v;
-            if (v == i) { need[p] = 0; continue; }
-            self += v < i ? 1 : 0;
-            int lt = v < i ? 1 : 0, found = 0;                 // v itself is a member of N[v]
-            for (int q = Ap[v]; q < Ap[v + 1]; ++q) {
-                const int k = Aj[q];
-                if (k == v) continue;
-                lt += k < i ? 1 : 0;
-                found += k == i ? 1 : 0;
-            }
-            need[p] = lt;
-            if (found == 0) atomicOr(flag, 1u);
+        for (int p = Ap[v]; p < Ap[v + 1]; ++p) {
+            const int k = Aj[p];
+            if (k == v) { for (int q = p + 1; q < Ap[v + 1]; ++q) dup = dup || Aj[q] == v; continue; }
+            int b = m - 1;                                      // insertion sort: rows hold a few tens of entries
+            while (b >= 0 && L[b] > k) { L[b + 1] = L[b]; --b; }
+            if (b >= 0 && L[b] == k) { dup = true; for (int t = b + 1; t < m; ++t) L[t] = L[t + 1]; continue; }
+            L[b + 1] = k;
+            ++m;
         }
-        need_self[i] = self;
+        nsize[v] = m;
         if (dup) atomicOr(flag, 2u);
+        if (m == 1) mark[v] = AGG_ISO;
+        else atomicAdd(nlive, 1u);
     }
 }
 
-__global__ __launch_bounds__(BLK) void agg_pass1_kernel(int n, const int *Ap, const int *Aj, const int *need, const int *need_self,
-                                                         int *cnt, int *mark, unsigned *ticket, unsigned *err)
+// pend[i] = lists of N[i] whose token i does not hold from the start; symmetry check (i must be a member of every list it reads);
+// vertices that hold every token go on the first work list
+__global__ __launch_bounds__(BLK) void agg_pend_kernel(int n, const int *Ap, const int *Ns, const int *nsize, int *pend, int *wl, unsigned *wcount,
+                                                       unsigned *flag)
 {
-    __shared__ unsigned sh_chunk;
-    while (true) {
-        __syncthreads();
-        if (threadIdx.x == 0) sh_chunk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const long long base = (long long)sh_chunk * BLK;
-        if (base >= n) break;
-        const int i = (int)base + threadIdx.x;
-        bool done = i >= n;
-        int lo = 0, hi = 0;
-        if (!done) {
-            lo = Ap[i]; hi = Ap[i + 1];
-            bool has_nb = false;
-            for (int p = lo; p < hi; ++p) has_nb = has_nb || Aj[p] != i;
-            if (!has_nb) {                                       // isolated: never aggregated, nobody waits for it
-                ast(mark + i, AGG_ISO);
-                done = true;
-            }
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        const int m = nsize[i];
+        if (m == 1) { pend[i] = 0; continue; }
+        const int *L = Ns + (size_t)Ap[i] + i;
+        int need = 0;
+        for (int t = 0; t < m; ++t) {
+            const int v = L[t];
+            const int *Lv = Ns + (size_t)Ap[v] + v;
+            const int mv = nsize[v];
+            int lo = 0, hi = mv;                                // i's place in v's list
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (Lv[mid] < i) lo = mid + 1; else hi = mid; }
+            if (lo >= mv || Lv[lo] != i) atomicOr(flag, 1u);
+            need += lo > 0 ? 1 : 0;
         }
-        unsigned spins = 0;
-        while (__any(!done)) {
-            if (!done) {
-                bool ready = ald(cnt + i) >= need_self[i];
-                for (int p = lo; p < hi && ready; ++p) {
-                    const int v = Aj[p];
-                    if (v != i) ready = ald(cnt + v) >= need[p];
-                }
-                if (ready) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    bool free = ald(mark + i) == 0;
-                    for (int p = lo; p < hi && free; ++p) free = ald(mark + Aj[p]) == 0;
-                    if (free) {                                  // a new aggregate: the root and its neighbours (smoothed_aggregation.h:177-185)
-                        ast(mark + i, i + 1);
-                        for (int p = lo; p < hi; ++p) ast(mark + Aj[p], i + 1);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    __hip_atomic_fetch_add(cnt + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (int p = lo; p < hi; ++p)
-                        if (Aj[p] != i) __hip_atomic_fetch_add(cnt + Aj[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    done = true;
-                }
+        pend[i] = need;
+        if (need == 0) wl[atomicAdd(wcount, 1u)] = i;
+    }
+}
+
+// one round: the vertices of the incoming work list take their turn (smoothed_aggregation.h:160-188), then every list
+// they belong to passes its token on; vertices that now hold all their tokens form the next work list
+__global__ __launch_bounds__(BLK) void agg_round_kernel(const int *Ap, const int *Aj, const int *Ns, const int *nsize, int *cnt, int *pend, int *mark,
+                                                        const int *wl_in, const unsigned *n_in, int *wl_out, unsigned *n_out, unsigned *n_clear,
+                                                        unsigned *ndone)
+{
+    const unsigned nin = *n_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_clear = 0u;    // the list after next: nobody reads or writes it in this round
+    for (unsigned t = blockIdx.x * BLK + threadIdx.x; t < nin; t += gridDim.x * BLK) {
+        const int i = wl_in[t];
+        const int lo = Ap[i], hi = Ap[i + 1];
+        bool free = mark[i] == 0;
+        for (int p = lo; p < hi && free; ++p) free = mark[Aj[p]] == 0;
+        if (free) {                                             // a new aggregate: the root and its neighbours
+            mark[i] = i + 1;
+            for (int p = lo; p < hi; ++p) mark[Aj[p]] = i + 1;
+        }
+        const int *L = Ns + (size_t)lo + i;
+        const int m = nsize[i];
+        for (int q = 0; q < m; ++q) {
+            const int v = L[q];
+            const int c = atomicAdd(cnt + v, 1) + 1;            // members of v's list that have had their turn
+            if (c < nsize[v]) {
+                const int nxt = Ns[(size_t)Ap[v] + v + c];
+                if (atomicSub(pend + nxt, 1) == 1) wl_out[atomicAdd(n_out, 1u)] = nxt;
             }
-            if (++spins > (1u << 24)) {                          // a vertex we wait for never had its turn: report, do not hang
-                if (!done) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            if (!done) __builtin_amdgcn_s_sleep(1);
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ndone, nin);
 }
 
 // pass 2 (smoothed_aggregation.h:190-205): an unmarked vertex joins the aggregate of its first neighbour (storage order)
@@ -376,34 +375,50 @@ int standard_aggregation_device(int n, const int *d_Ap, const int *d_Aj, int64_t
 {
     *count = 0;
     if (n == 0) return PAMG_OK;
-    int *need = nullptr, *need_self = nullptr, *cnt = nullptr, *mark = nullptr, *rid = nullptr, *bsum = nullptr;
-    unsigned *ctl = nullptr;                                     // [0] flags, [1] ticket, [2] error
+    int *Ns = nullptr, *nsize = nullptr, *cnt = nullptr, *pend = nullptr, *mark = nullptr, *rid = nullptr, *bsum = nullptr, *wl = nullptr;
+    unsigned *ctl = nullptr;                                     // [0] flags, [1] live vertices, [2] vertices done, [4..6] work-list sizes
     const int nb = (int)(((int64_t)n + (int64_t)BLK * SCAN_PER - 1) / ((int64_t)BLK * SCAN_PER));
     int st = PAMG_OK;
-    auto cleanup = [&]() { hipFree(need); hipFree(need_self); hipFree(cnt); hipFree(mark); hipFree(rid); hipFree(bsum); hipFree(ctl); };
+    auto cleanup = [&]() { hipFree(Ns); hipFree(nsize); hipFree(cnt); hipFree(pend); hipFree(mark); hipFree(rid); hipFree(bsum); hipFree(wl); hipFree(ctl); };
 #define AGG_CHECK(expr) do { st = (int)(expr); if (st) { cleanup(); return st; } } while (0)
-    AGG_CHECK(hipMalloc((void **)&need, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1)));
-    AGG_CHECK(hipMalloc((void **)&need_self, sizeof(int) * (size_t)n));
+    AGG_CHECK(hipMalloc((void **)&Ns, sizeof(int) * ((size_t)nnz + (size_t)n + 8)));
+    AGG_CHECK(hipMalloc((void **)&nsize, sizeof(int) * (size_t)n));
     AGG_CHECK(hipMalloc((void **)&cnt, sizeof(int) * (size_t)n));
+    AGG_CHECK(hipMalloc((void **)&pend, sizeof(int) * (size_t)n));
     AGG_CHECK(hipMalloc((void **)&mark, sizeof(int) * (size_t)n));
     AGG_CHECK(hipMalloc((void **)&rid, sizeof(int) * (size_t)n));
     AGG_CHECK(hipMalloc((void **)&bsum, sizeof(int) * (size_t)(nb + 1)));
-    AGG_CHECK(hipMalloc((void **)&ctl, 4 * sizeof(unsigned)));
+    AGG_CHECK(hipMalloc((void **)&wl, sizeof(int) * 3 * (size_t)n));
+    AGG_CHECK(hipMalloc((void **)&ctl, 8 * sizeof(unsigned)));
     AGG_CHECK(hipMemset(cnt, 0, sizeof(int) * (size_t)n));
     AGG_CHECK(hipMemset(mark, 0, sizeof(int) * (size_t)n));
-    AGG_CHECK(hipMemset(ctl, 0, 4 * sizeof(unsigned)));
-    hipLaunchKernelGGL(agg_need_kernel, dim3(agg_grid(n)), dim3(BLK), 0, 0, n, d_Ap, d_Aj, need, need_self, ctl);
+    AGG_CHECK(hipMemset(ctl, 0, 8 * sizeof(unsigned)));
+    hipLaunchKernelGGL(agg_lists_kernel, dim3(agg_grid(n)), dim3(BLK), 0, 0, n, d_Ap, d_Aj, Ns, nsize, mark, ctl, ctl + 1);
+    hipLaunchKernelGGL(agg_pend_kernel, dim3(agg_grid(n)), dim3(BLK), 0, 0, n, d_Ap, (const int *)Ns, (const int *)nsize, pend, wl, ctl + 4, ctl);
     AGG_CHECK(hipGetLastError());
-    unsigned h[4] = {0, 0, 0, 0};
+    unsigned h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     AGG_CHECK(hipMemcpy(h, ctl, sizeof(h), hipMemcpyDeviceToHost));
-    if (h[0] & 3u) { cleanup(); return PAMG_E_UNSUPPORTED; }     // not symmetric / duplicate entries: the dependency argument above does not hold
+    if (h[0] & 3u) { cleanup(); return PAMG_E_UNSUPPORTED; }     // not symmetric / duplicate entries: the token argument above does not hold
+    const unsigned live = h[1];
+    // rounds in batches (no host synchronisation inside a batch: every launch reads its list size from the device)
     int dev = 0, cus = 64;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    const int grid = (int)std::min<int64_t>((int64_t)cus * 8, ((int64_t)n + BLK - 1) / BLK);
-    hipLaunchKernelGGL(agg_pass1_kernel, dim3(grid), dim3(BLK), 0, 0, n, d_Ap, d_Aj, (const int *)need, (const int *)need_self, cnt, mark,
-                       ctl + 1, ctl + 2);
-    AGG_CHECK(hipGetLastError());
+    const int grid = std::max(1, std::min(cus * 4, (n + BLK - 1) / BLK));
+    unsigned done = 0;
+    int round = 0;
+    const int64_t round_cap = 4 * (int64_t)n + 64;               // a traversal needs at most one round per vertex
+    while (done < live) {
+        for (int k = 0; k < 256; ++k, ++round) {
+            const int a = round % 3, b = (round + 1) % 3, c = (round + 2) % 3;
+            hipLaunchKernelGGL(agg_round_kernel, dim3(grid), dim3(BLK), 0, 0, d_Ap, d_Aj, (const int *)Ns, (const int *)nsize, cnt, pend, mark,
+                               (const int *)(wl + (size_t)a * n), (const unsigned *)(ctl + 4 + a), wl + (size_t)b * n, ctl + 4 + b, ctl + 4 + c, ctl + 2);
+        }
+        AGG_CHECK(hipGetLastError());
+        const unsigned before = done;
+        AGG_CHECK(hipMemcpy(&done, ctl + 2, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if ((done == before && done < live) || round > round_cap) { cleanup(); return PAMG_E_STATE; }   // no progress: cannot happen on a valid pattern
+    }
     hipLaunchKernelGGL(agg_pass2_kernel, dim3(agg_grid(n)), dim3(BLK), 0, 0, n, d_Ap, d_Aj, mark);
     hipLaunchKernelGGL(agg_count_kernel, dim3(nb), dim3(BLK), 0, 0, n, (const int *)mark, bsum);
     AGG_CHECK(hipGetLastError());
@@ -416,10 +431,9 @@ int standard_aggregation_device(int n, const int *d_Ap, const int *d_Aj, int64_t
     hipLaunchKernelGGL(agg_rank_kernel, dim3(nb), dim3(BLK), 0, 0, n, (const int *)mark, (const int *)bsum, rid, d_y);
     hipLaunchKernelGGL(agg_final_kernel, dim3(agg_grid(n)), dim3(BLK), 0, 0, n, (const int *)mark, (const int *)rid, d_x, ctl);
     AGG_CHECK(hipGetLastError());
-    AGG_CHECK(hipMemcpy(h, ctl, sizeof(h), hipMemcpyDeviceToHost));
+    AGG_CHECK(hipMemcpy(h, ctl, sizeof(unsigned), hipMemcpyDeviceToHost));
 #undef AGG_CHECK
     cleanup();
-    if (h[2]) return PAMG_E_TIMEOUT;
     if (h[0] & 4u) return PAMG_E_UNSUPPORTED;
     return PAMG_OK;
 }

@@ -103,6 +103,7 @@ struct GsSchedule {
     size_t bytes = 0;
     std::vector<int> h_vis, h_lvl;   // scalar schedules: visit index (-1 = not swept) and dependency level of every row
     bool has_level_part = false;     // the level-permuted copy above is built (granular / single-workgroup / per-level schedulers)
+    int cap = 0;                     // entries per row range of the level-permuted copy (the LDS window its kernels run with)
     struct TileSched *tile = nullptr; // tiled sweep (pamg_tile_plan.h / pamg_tile_kernels.h), built on demand
     bool tile_unfit = false;         // the tile planner declined this schedule (a step would not fit): other schedulers run it
 };
@@ -175,6 +176,7 @@ struct pamg_matrix_s {
     int max_row_len = 0;             // longest row of the scalar view
     int borrowed = 0;                // solvers holding this operator (tuning is refused while > 0: captured graphs point into the schedules)
     int gs_prof = 0;                 // granular sweep: record per-range time stamps (tune key 11, diagnostics)
+    int gs_cap = 0;                  // entries per row range of the level schedules (tune key 20; 0 = automatic: `cap`, 512 on the multi-XCD granular sweep of SA-like rows)
     int nblk = 0;
     int *d_part[2] = {nullptr, nullptr};   // row shards (pamg_dist.hip): row ranges that read owned columns only / that read the halo
     int npart[2] = {0, 0};

@@ -430,11 +430,28 @@ int build_level_part(pamg_matrix_s *A, GsSchedule *g)
                 if (pAj[p] == (order[r] | 0x40000000)) std::memcpy(&pdiag[(size_t)r * ts], &pAx[(size_t)p * ts], ts);
     });
     std::vector<int4> blk;
-    g->level_blk.assign(1, 0);
-    for (int l = 0; l < g->nlevels; ++l) {
-        plan_rows(pAp.data(), lptr[l], lptr[l + 1], A->cap, std::min(A->max_rows, BLK), blk);
-        g->level_blk.push_back((int)blk.size());
+    auto plan = [&](int cap_) {
+        blk.clear();
+        g->level_blk.assign(1, 0);
+        for (int l = 0; l < g->nlevels; ++l) {
+            plan_rows(pAp.data(), lptr[l], lptr[l + 1], cap_, std::min(A->max_rows, BLK), blk);
+            g->level_blk.push_back((int)blk.size());
+        }
+    };
+    int gcap = A->gs_cap > 0 ? A->gs_cap : A->cap;
+    plan(gcap);
+    if (A->gs_cap == 0 && (A->gs_mode == 0 || A->gs_mode == 2) && gcap > 512 && A->npl == 2) {
+        // Where this schedule will run as the multi-XCD granular sweep (neither narrow enough for one workgroup nor small
+        // enough for the one-XCD form) on SA-like rows, finer ranges win: a range waits for the slowest of its early
+        // entries, so 512-entry ranges (~16 rows of 31) track the dependency graph more closely than 1536-entry ones
+        // (measured on level 1 of the 256^3 hierarchy, profiles/r03_microbench_gs_range_geometry.json: 4.48 vs 5.04 ms).
+        const int64_t nblk = (int64_t)blk.size();
+        const bool narrow = nblk * 16 <= (int64_t)g->nlevels * A->flow_cap;
+        const int64_t per_level = (nblk + g->nlevels - 1) / std::max(1, g->nlevels);
+        const bool xcd = A->gran_xcd == 1 || (A->gran_xcd == 0 && per_level <= 4 && A->nrows <= 262144);
+        if (!narrow && !xcd && g->nnz >= 16 * (int64_t)m) { gcap = 512; plan(gcap); }
     }
+    g->cap = gcap;
     size_t bytes = 0;
     int st = upload(&g->d_Ap, pAp.data(), pAp.size(), &bytes);
     if (!st) st = upload(&g->d_Aj, pAj.data(), pAj.size(), &bytes);
@@ -961,7 +978,8 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
     a.Ax = (const T *)g->d_Ax;
     a.rid = g->d_rid;
     a.diag = (const T *)g->d_diag;
-    const int lds = lds_bytes(A->dtype, epi, A->cap);
+    if (g->cap > 0) a.cap = g->cap;                      // the level-permuted copy carries its own range size
+    const int lds = lds_bytes(A->dtype, epi, a.cap);
     const bool can_persist = lds <= 48 * 1024 && g->nlevels > 1 && A->gs_mode != 1;
     const bool narrow = (int64_t)g->nblk_total * 16 <= (int64_t)g->nlevels * A->flow_cap;
     const bool single = can_persist && (A->gs_mode == 3 || ((A->gs_mode == 0 || A->gs_mode == 5) && narrow));
@@ -1685,6 +1703,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 17: if (value < -1 || value > 4) return PAMG_E_ARG; A->tile_Q = value; break;
         case 18: if (value < 0 || value > 1) return PAMG_E_ARG; A->tile_part = value; break;
         case 19: A->use_idx16 = value != 0; return PAMG_OK;
+        case 20: if (value != 0 && (value < 64 || value > 2048)) return PAMG_E_ARG; A->gs_cap = value & ~3; break;
         default: return PAMG_E_ARG;
     }
     if (key >= 12) {                                  // tile plan parameters: drop the tile parts only

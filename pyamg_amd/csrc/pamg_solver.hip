@@ -167,7 +167,7 @@ struct pamg_solver_s {
     std::vector<Level> levels;
     void *d_coarse = nullptr;     // dense coarse operator (row-major n_c x n_c)
     int n_c = 0;
-    bool coarse_set = false, coarse_zero = false;
+    bool coarse_set = false, coarse_zero = false, coarse_relax = false;
     bool finalized = false;
     bool use_graph = true;
     hipStream_t own_stream = nullptr;
@@ -177,6 +177,7 @@ struct pamg_solver_s {
     double *d_scratch = nullptr;  // 1032 doubles for vector reductions
     void *cg_r = nullptr, *cg_z = nullptr, *cg_p = nullptr, *cg_q = nullptr;   // device PCG work vectors
     std::map<int, hipGraphExec_t> graphs;   // key = cycle*1024 + cycles_per_level
+    int fallbacks = 0;            // times a persistent sweep timed out and the solver switched to per-level launches
     size_t bytes = 0;
 };
 
@@ -273,6 +274,9 @@ int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, 
     return PAMG_E_ARG;
 }
 
+void drop_graphs(pamg_solver_s *S);
+int prebuild_schedules(Level &L, const Smoother &sm);
+
 // after a synchronising entry point: did any persistent sweep give up waiting?
 int check_sweeps(pamg_solver_s *S)
 {
@@ -283,11 +287,43 @@ int check_sweeps(pamg_solver_s *S)
         PAMG_TRY(sweep_error(L.A, &e));
         any = any || e;
     }
+    static int forced = [] { const char *e = getenv("PAMG_FORCE_TIMEOUT"); return e ? atoi(e) : 0; }();   // test hook: report the first N checks as timed out
+    if (forced > 0) { --forced; any = true; }
     return any ? PAMG_E_TIMEOUT : PAMG_OK;
+}
+
+// A persistent sweep gave up waiting (PAMG_E_TIMEOUT): its workgroups were not all running -- another process on the
+// device, a debugger, a tiny partition.  From then on this solver runs every order-exact sweep as one launch per
+// dependency level (scheduler mode 1: no workgroup ever waits for another), slower and always live.  The captured graphs
+// point at the persistent kernels and are dropped; level-permuted copies are built where only tile plans existed.
+int fall_back_to_level_launches(pamg_solver_s *S)
+{
+    hipDeviceSynchronize();
+    drop_graphs(S);
+    for (Level &L : S->levels) {
+        if (!L.A) continue;
+        L.A->gs_mode = 1;
+        L.A->tile_default = false;
+        for (Smoother *sm : {&L.pre, &L.post}) PAMG_TRY(prebuild_schedules(L, *sm));
+    }
+    S->fallbacks++;
+    return PAMG_OK;
 }
 
 int coarse_solve(pamg_solver_s *S, const void *b, void *x, hipStream_t s)
 {
+    if (S->coarse_relax) {
+        // multilevel.py:765-782: x = zeros_like(b); relax(A, x, b).  Always called on the coarsest level's own buffers.
+        Level &L = S->levels.back();
+        if (b != L.b || x != L.x) return PAMG_E_STATE;
+        PAMG_HIP(hipMemsetAsync(L.x, 0, (size_t)L.n * tsize(S->dtype), s));
+        PAMG_TRY(apply_smoother(S, L, L.pre, true, s));
+        if (L.x != L.x_home) {
+            PAMG_HIP(hipMemcpyAsync(L.x_home, L.x, (size_t)L.n * tsize(S->dtype), hipMemcpyDeviceToDevice, s));
+            std::swap(L.x, L.xalt);
+        }
+        return PAMG_OK;
+    }
     if (S->coarse_zero) return (int)hipMemsetAsync(x, 0, (size_t)S->n_c * tsize(S->dtype), s);
     return dense_gemv(S->dtype, S->n_c, S->d_coarse, b, x, s);
 }
@@ -787,6 +823,17 @@ int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c)
     return PAMG_OK;
 }
 
+int pamg_solver_set_coarse_relax(pamg_solver_t S)
+{
+    if (!S || S->levels.empty()) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    if (S->levels.back().P) return PAMG_E_STATE;
+    if (S->levels.back().pre.kind == PAMG_SMOOTH_NONE) return PAMG_E_ARG;
+    S->coarse_relax = true; S->coarse_set = true; S->coarse_zero = false;
+    S->n_c = (int)S->levels.back().n;
+    return PAMG_OK;
+}
+
 int pamg_solver_finalize(pamg_solver_t S)
 {
     if (!S || S->levels.empty()) return PAMG_E_ARG;
@@ -802,17 +849,18 @@ int pamg_solver_finalize(pamg_solver_t S)
         PAMG_TRY(dalloc(S, &L.xalt, vb));
         PAMG_TRY(dalloc(S, &L.b, vb));
         L.x_home = L.x;
-        if (l < nlev - 1) {
+        if (l < nlev - 1 || S->coarse_relax) {
             PAMG_TRY(dalloc(S, &L.r, vb));
             if (L.pre.kind == PAMG_SMOOTH_POLY || L.post.kind == PAMG_SMOOTH_POLY) PAMG_TRY(dalloc(S, &L.work, 3 * vb));
         }
     }
+    const int nsm = S->coarse_relax ? nlev : nlev - 1;      // levels that carry a relaxation method
     {
         std::vector<SchedJob> jobs;
-        for (int l = 0; l < nlev - 1; ++l) { sched_jobs_of(S->levels[l], S->levels[l].pre, jobs); sched_jobs_of(S->levels[l], S->levels[l].post, jobs); }
+        for (int l = 0; l < nsm; ++l) { sched_jobs_of(S->levels[l], S->levels[l].pre, jobs); sched_jobs_of(S->levels[l], S->levels[l].post, jobs); }
         PAMG_TRY(run_sched_jobs(jobs));
     }
-    for (int l = 0; l < nlev - 1; ++l) {       // whatever the jobs did not cover (Kaczmarz line schedules); the rest is found built
+    for (int l = 0; l < nsm; ++l) {            // whatever the jobs did not cover (Kaczmarz line schedules); the rest is found built
         Level &L = S->levels[l];
         PAMG_TRY(prebuild_schedules(L, L.pre));
         PAMG_TRY(prebuild_schedules(L, L.post));
@@ -923,11 +971,18 @@ int pamg_solver_solve(pamg_solver_t S, void *x, const void *b, double tol, int m
         }
         if (it == maxiter) break;
     }
+    PAMG_HIP(hipStreamSynchronize(s));
+    const int swept = check_sweeps(S);
+    if (swept == PAMG_E_TIMEOUT && S->fallbacks == 0) {
+        // the iterate is invalid; the caller's x still holds the initial guess: switch schedulers and run the solve again
+        PAMG_TRY(fall_back_to_level_launches(S));
+        return pamg_solver_solve(S, x, b, tol, maxiter, cycle, cycles_per_level, check_every, residuals, n_iter, info, s_);
+    }
     PAMG_HIP(hipMemcpyAsync(x, L0.x, vb, hipMemcpyDeviceToDevice, s));
     PAMG_HIP(hipStreamSynchronize(s));
     if (n_iter) *n_iter = it;
     if (info) *info = converged_at >= 0 ? 0 : it;
-    return check_sweeps(S);
+    return swept;
 }
 
 int pamg_solver_load(pamg_solver_t S, const void *x, const void *b, pamg_stream_t s_)
@@ -964,7 +1019,10 @@ int pamg_solver_iterate(pamg_solver_t S, int k, int cycle, int cycles_per_level,
         PAMG_HIP(hipMemcpyAsync(residuals, S->d_norms, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
         PAMG_HIP(hipStreamSynchronize(s));
         for (int it = 0; it < k; ++it) residuals[it] = std::sqrt(residuals[it]);
-        return check_sweeps(S);
+        const int swept = check_sweeps(S);
+        // the resident iterate cannot be restored here: report, but make the NEXT load / iterate safe
+        if (swept == PAMG_E_TIMEOUT && S->fallbacks == 0) PAMG_TRY(fall_back_to_level_launches(S));
+        return swept;
     }
     return PAMG_OK;
 }
@@ -1329,6 +1387,7 @@ int pamg_solver_stats(pamg_solver_t S, int64_t stats[8])
     stats[1] = launches;           // GS level launches per directional sweep pair (informative)
     stats[2] = (int64_t)bytes;
     stats[3] = (int64_t)S->graphs.size();
+    stats[4] = S->fallbacks;       // persistent sweeps timed out: the solver switched to one launch per dependency level
     return PAMG_OK;
 }
 

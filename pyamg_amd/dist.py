@@ -258,7 +258,7 @@ class ShardedHierarchy:
         self.coarse_spec = HierarchySpec(levels=[LevelSpec(A=L.A, P=L.P, R=L.R, pre=L.pre, post=L.post)
                                                  for L in spec.levels[ns:]],
                                          coarse_kind=spec.coarse_kind, coarse_op=spec.coarse_op,
-                                         coarse_name=spec.coarse_name)
+                                         coarse_name=spec.coarse_name, coarse_smoother=spec.coarse_smoother)
 
 
 # ----------------------------------------------------------------------------------- local ops

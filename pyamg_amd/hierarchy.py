@@ -105,9 +105,10 @@ class LevelSpec:
 @dataclass
 class HierarchySpec:
     levels: List[LevelSpec] = field(default_factory=list)
-    coarse_kind: str = "dense"                  # 'dense' (x = M b) | 'zero' (A_c.nnz == 0)
+    coarse_kind: str = "dense"                  # 'dense' (x = M b) | 'zero' (A_c.nnz == 0) | 'relax' (sweeps from x = 0)
     coarse_op: Optional[np.ndarray] = None      # dense (n_c, n_c), row-major
     coarse_name: str = "'pinv'"
+    coarse_smoother: Optional[SmootherSpec] = None   # 'relax': the relaxation method the reference's coarse solver applies
 
     @property
     def dtype(self):
@@ -301,6 +302,29 @@ def _normal_equation_spec(kind, A, iterations, sweep, omega) -> SmootherSpec:
 
 # --------------------------------------------------------------------------- coarse solver
 _LINEAR_COARSE = ("'pinv'", "'pinv2'", "'lu'", "'cholesky'", "'splu'")
+# multilevel.py:765-782: x = 0; setup_<name>(lvl, **kwargs)(A, x, b) with iterations defaulting to 10
+_RELAX_COARSE = ("gauss_seidel", "jacobi", "block_gauss_seidel", "schwarz", "block_jacobi", "richardson", "sor", "chebyshev",
+                 "jacobi_ne", "gauss_seidel_ne", "gauss_seidel_nr")
+
+
+def _relaxation_coarse_smoother(ml, cs, A_c):
+    """The relaxation method behind ``coarse_solver='gauss_seidel'`` & co. (multilevel.py:765-782): the reference builds
+    it from ``smoothing.setup_<name>(lvl, **kwargs)`` at every coarse solve; the keyword arguments live in the closure of
+    the solver it returned.  Built once here with the reference's own setup function, so every parameter (a spectral
+    radius for Jacobi / Chebyshev / Richardson: cached on the matrix by the reference, hence the same number in its own
+    later solves) is the reference's."""
+    import importlib
+    call = getattr(type(cs), "__call__", None)
+    cells = dict(zip(getattr(call.__code__, "co_freevars", ()), [c.cell_contents for c in (call.__closure__ or ())]))
+    solve = cells.get("solve")
+    inner = _closure_vars(solve) if solve is not None else {}
+    if "kwargs" not in inner or "solver" not in inner:
+        raise NotImplementedError("coarse solver: cannot read the relaxation method's arguments back")
+    smoothing = importlib.import_module(type(ml).__module__.split(".")[0] + ".relaxation.smoothing")
+    lvl = type(ml).Level()
+    lvl.A = A_c
+    return smoother_spec(getattr(smoothing, "setup_" + str(inner["solver"]))(lvl, **dict(inner["kwargs"])), A_c)
+
 
 
 def _coarse_operator(ml, A_c) -> Tuple[str, Optional[np.ndarray], str]:
@@ -308,9 +332,11 @@ def _coarse_operator(ml, A_c) -> Tuple[str, Optional[np.ndarray], str]:
     name = cs.name() if hasattr(cs, "name") else repr(cs)
     if A_c.nnz == 0:                                    # multilevel.py:801-803
         return "zero", None, name
+    if name.strip("'") in _RELAX_COARSE:
+        return "relax", _relaxation_coarse_smoother(ml, cs, A_c), name
     if name not in _LINEAR_COARSE:
-        raise NotImplementedError(f"coarse solver {name} is not a linear direct solver; "
-                                  "device path supports 'pinv', 'lu', 'cholesky', 'splu'")
+        raise NotImplementedError(f"coarse solver {name} is neither a linear direct solver ('pinv', 'lu', 'cholesky', 'splu') "
+                                  "nor a relaxation method; Krylov coarse solvers are not on the device path")
     n = A_c.shape[0]
     if n > 4096:
         raise NotImplementedError(f"coarsest level too large for a dense device solve (n={n})")
@@ -360,7 +386,12 @@ def extract(ml) -> HierarchySpec:
                     f"mixed-precision hierarchy (level {i} {nm} is {op.dtype}, fine level is "
                     f"{levels[0].A.dtype}) is not on the device path")
         spec.levels.append(ls)
-    spec.coarse_kind, spec.coarse_op, spec.coarse_name = _coarse_operator(ml, levels[-1].A)
+    kind, op, spec.coarse_name = _coarse_operator(ml, levels[-1].A)
+    spec.coarse_kind = kind
+    if kind == "relax":
+        spec.coarse_smoother = op
+    else:
+        spec.coarse_op = op
     return spec
 
 
@@ -432,6 +463,7 @@ def save_spec(path, spec: HierarchySpec, **extra):
     if spec.coarse_op is not None:
         d["coarse_op"] = np.asarray(spec.coarse_op)
         d["coarse_op_fortran"] = np.array(bool(np.isfortran(spec.coarse_op)))
+    _put_sm(d, "coarse_smoother", spec.coarse_smoother)
     for i, L in enumerate(spec.levels):
         _put_op(d, f"L{i}.A", L.A)
         _put_op(d, f"L{i}.P", L.P)
@@ -450,6 +482,7 @@ def load_spec(path):
     if "coarse_op" in z:
         M = z["coarse_op"]
         spec.coarse_op = np.asfortranarray(M) if bool(z["coarse_op_fortran"]) else np.ascontiguousarray(M)
+    spec.coarse_smoother = _get_sm(z, "coarse_smoother")
     for i in range(int(z["nlevels"])):
         spec.levels.append(LevelSpec(A=_get_op(z, f"L{i}.A"), P=_get_op(z, f"L{i}.P"), R=_get_op(z, f"L{i}.R"),
                                      pre=_get_sm(z, f"L{i}.pre"), post=_get_sm(z, f"L{i}.post")))

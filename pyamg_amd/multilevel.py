@@ -108,12 +108,12 @@ class DeviceMatrix:
         return d
 
     def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, xwin=None, gs_prof=None,
-             tile_G=None, tile_W=None, tile_cap=None, tile_default=None, tile_D=None, tile_Q=None, tile_part=None, idx16=None):
+             tile_G=None, tile_W=None, tile_cap=None, tile_default=None, tile_D=None, tile_Q=None, tile_part=None, idx16=None, gs_cap=None):
         """Speed-only knobs (every setting computes the same bits).  Refused (PAMG_E_STATE) once a solver holds the
         operator: captured graphs point into the plans these calls rebuild."""
         lib = capi.lib()
         for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (9, xwin), (11, gs_prof),
-                       (12, tile_G), (13, tile_W), (14, tile_cap), (15, tile_default), (16, tile_D), (17, tile_Q), (18, tile_part), (19, idx16)):
+                       (12, tile_G), (13, tile_W), (14, tile_cap), (15, tile_default), (16, tile_D), (17, tile_Q), (18, tile_part), (19, idx16), (20, gs_cap)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 
@@ -305,7 +305,11 @@ class DeviceMultilevelSolver:
                 _set_smoother(lib, h, i, 0, L.pre, self.dtype, self._aux)
                 _set_smoother(lib, h, i, 1, L.post, self.dtype, self._aux)
         n_c = self.spec.levels[-1].A.shape[0]
-        if self.spec.coarse_kind == "zero":
+        if self.spec.coarse_kind == "relax":
+            # multilevel.py:765-782: sweeps of a relaxation method from x = 0 -- the smoother slot of the coarsest level
+            _set_smoother(lib, h, nlev - 1, 0, self.spec.coarse_smoother, self.dtype, self._aux)
+            capi.check(lib.pamg_solver_set_coarse_relax(h), "set_coarse_relax")
+        elif self.spec.coarse_kind == "zero":
             capi.check(lib.pamg_solver_set_coarse_dense(h, None, n_c), "set_coarse")
         else:
             M = np.ascontiguousarray(self.spec.coarse_op, dtype=self.dtype)     # row-major for the device gemv
@@ -332,7 +336,8 @@ class DeviceMultilevelSolver:
     def stats(self) -> dict:
         a = (C.c_int64 * 8)()
         capi.check(capi.lib().pamg_solver_stats(self.handle, a), "pamg_solver_stats")
-        return {"levels": int(a[0]), "gs_level_launches": int(a[1]), "hbm_bytes": int(a[2]), "graphs": int(a[3])}
+        return {"levels": int(a[0]), "gs_level_launches": int(a[1]), "hbm_bytes": int(a[2]), "graphs": int(a[3]),
+                "sweep_timeouts_recovered": int(a[4])}
 
     def cycle_device(self, xd, bd, cycle="V", cycles_per_level=1, stream=None):
         """One cycle on DEVICE vectors (DeviceArray) in place."""

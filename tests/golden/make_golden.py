@@ -128,6 +128,14 @@ def make_hierarchies():
     np.random.seed(SEED)
     hier("sa2d_richardson_W", pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother="richardson",
                                                                 postsmoother="richardson"), cycle="W")
+    # relaxation methods as the coarsest-level solver (multilevel.py:765-782): sweeps from x = 0 on a 50-100 unknown level
+    np.random.seed(SEED)
+    hier("sa2d_coarse_gs", pyamg.smoothed_aggregation_solver(A, max_coarse=60, coarse_solver="gauss_seidel"))
+    np.random.seed(SEED)
+    hier("sa2d_coarse_jacobi", pyamg.smoothed_aggregation_solver(A, max_coarse=60, presmoother=jac, postsmoother=jac,
+                                                                 coarse_solver=("jacobi", {"iterations": 4})))
+    np.random.seed(SEED)
+    hier("sa2d_coarse_cheby", pyamg.smoothed_aggregation_solver(A, max_coarse=60, coarse_solver=("chebyshev", {"degree": 4, "iterations": 2})))
     np.random.seed(SEED)
     hier("rs2d_jacobi", pyamg.ruge_stuben_solver(A, max_coarse=10, presmoother=jac, postsmoother=jac))
     np.random.seed(SEED)

@@ -335,6 +335,35 @@ def test_long_dependency_chains_against_the_live_reference(case):
         assert np.array_equal(o, outs[0])                 # schedulers differ in speed only
 
 
+def test_sweep_timeout_falls_back_to_level_launches():
+    """a persistent sweep that reports PAMG_E_TIMEOUT (not all of its workgroups were running -- forced here through the
+    PAMG_FORCE_TIMEOUT test hook): solve() switches every order-exact sweep to one launch per dependency level, runs the
+    solve again from the initial guess and returns the reference's answer; the switch is reported in stats()"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from pyamg_amd import DeviceMultilevelSolver\n"
+        "from pyamg_amd.hierarchy import load_spec\n"
+        f"spec, ex = load_spec({str(ROOT / 'tests' / 'golden' / 'hier_sa3d_gs.npz')!r})\n"
+        "dml = DeviceMultilevelSolver(spec)\n"
+        "r = []\n"
+        "x = dml.solve(ex['b'], x0=ex['x0'], tol=1e-30, maxiter=int(ex['k']), residuals=r)\n"
+        "st = dml.stats()\n"
+        "assert st['sweep_timeouts_recovered'] == 1, st\n"
+        "assert np.max(np.abs(np.array(r) - ex['res'])) <= 1e-10 * ex['res'][0]\n"
+        "assert np.linalg.norm(x - ex['x']) <= 1e-12 * np.linalg.norm(ex['x'])\n"
+        "r2 = []\n"
+        "x2 = dml.solve(ex['b'], x0=ex['x0'], tol=1e-30, maxiter=int(ex['k']), residuals=r2)\n"
+        "assert np.array_equal(x2, x) and dml.stats()['sweep_timeouts_recovered'] == 1\n"
+        "print('fallback ok')\n")
+    import os
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PAMG_FORCE_TIMEOUT="1"))
+    assert r.returncode == 0 and "fallback ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_device_fgmres_matches_reference():
     """solve(accel='fgmres') runs flexible GMRES on the device (pamg_solver_fgmres); compared with the
     reference's own MultilevelSolver.solve(accel='fgmres') on the committed hierarchies
