@@ -409,7 +409,8 @@ int standard_aggregation_device(int n, const int *d_Ap, const int *d_Aj, int64_t
     int round = 0;
     const int64_t round_cap = 4 * (int64_t)n + 64;               // a traversal needs at most one round per vertex
     while (done < live) {
-        for (int k = 0; k < 256; ++k, ++round) {
+        const int batch = (int)std::min<int64_t>(256, std::max<int64_t>(8, (int64_t)live - done));
+        for (int k = 0; k < batch; ++k, ++round) {
             const int a = round % 3, b = (round + 1) % 3, c = (round + 2) % 3;
             hipLaunchKernelGGL(agg_round_kernel, dim3(grid), dim3(BLK), 0, 0, d_Ap, d_Aj, (const int *)Ns, (const int *)nsize, cnt, pend, mark,
                                (const int *)(wl + (size_t)a * n), (const unsigned *)(ctl + 4 + a), wl + (size_t)b * n, ctl + 4 + b, ctl + 4 + c, ctl + 2);
@@ -417,7 +418,14 @@ int standard_aggregation_device(int n, const int *d_Ap, const int *d_Aj, int64_t
         AGG_CHECK(hipGetLastError());
         const unsigned before = done;
         AGG_CHECK(hipMemcpy(&done, ctl + 2, sizeof(unsigned), hipMemcpyDeviceToHost));
-        if ((done == before && done < live) || round > round_cap) { cleanup(); return PAMG_E_STATE; }   // no progress: cannot happen on a valid pattern
+        if (done < live && (done == before || round > round_cap)) {                                      // no progress: cannot happen on a valid pattern
+            unsigned w[8];
+            hipMemcpy(w, ctl, sizeof(w), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[pamg aggregation] no progress: n %d nnz %lld round %d done %u of %u, list sizes %u %u %u, flags %u\n", n, (long long)nnz, round,
+                    done, live, w[4], w[5], w[6], w[0]);
+            cleanup();
+            return PAMG_E_STATE;
+        }
     }
     hipLaunchKernelGGL(agg_pass2_kernel, dim3(agg_grid(n)), dim3(BLK), 0, 0, n, d_Ap, d_Aj, mark);
     hipLaunchKernelGGL(agg_count_kernel, dim3(nb), dim3(BLK), 0, 0, n, (const int *)mark, bsum);

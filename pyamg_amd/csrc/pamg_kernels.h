@@ -17,12 +17,9 @@
 
 namespace pamg {
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
+}  // namespace pamg
+#include "pamg_tail_kernel.h"      // wave_sum lives there (shared with the solver's translation unit)
+namespace pamg {
 
 // sum over the workgroup, result valid in thread 0; sm = >= BLK/64 doubles of LDS
 __device__ __forceinline__ double block_sum(double v, double *sm)

@@ -337,7 +337,7 @@ class DeviceMultilevelSolver:
         a = (C.c_int64 * 8)()
         capi.check(capi.lib().pamg_solver_stats(self.handle, a), "pamg_solver_stats")
         return {"levels": int(a[0]), "gs_level_launches": int(a[1]), "hbm_bytes": int(a[2]), "graphs": int(a[3]),
-                "sweep_timeouts_recovered": int(a[4])}
+                "sweep_timeouts_recovered": int(a[4]), "tail_from_level": int(a[5]), "tail_operations": int(a[6])}
 
     def cycle_device(self, xd, bd, cycle="V", cycles_per_level=1, stream=None):
         """One cycle on DEVICE vectors (DeviceArray) in place."""

@@ -381,7 +381,7 @@ def test_device_aggregation_inside_the_reference_setup():
         np.random.seed(9)
         ref = pyamg.smoothed_aggregation_solver(A.copy(), max_coarse=10, keep=True, **kw)
         np.random.seed(9)
-        with device_setup(pyamg):
+        with device_setup(pyamg, aggregation=True):
             dev = pyamg.smoothed_aggregation_solver(A.copy(), max_coarse=10, keep=True, **kw)
         assert len(dev.levels) == len(ref.levels)
         for l, (Ld, Lr) in enumerate(zip(dev.levels[:-1], ref.levels[:-1])):
