@@ -278,6 +278,15 @@ int pamg_fit_tentative_f64(int32_t n_fine, int32_t n_coarse, int32_t K1, int32_t
 int pamg_fit_tentative_f32(int32_t n_fine, int32_t n_coarse, int32_t K1, int32_t K2, const int32_t *Tp, const int32_t *Tj,
                            const float *B, float *Qx, float *R, float tol);
 
+/* SciPy's bsr_transpose / csr_tocsc (sparsetools): B = A^T for A of n_brow x n_bcol blocks, R x C each (R = C = 1: CSR);
+ * HOST arrays; Bp[n_bcol + 1], Bi[nblk], Bx[nblk * C * R] receive the arrays `A.T` holds in SciPy -- the blocks of a
+ * column in the order of their rows, blocks transposed.  R = P.T of the SA setup (aggregation.py:394-397).
+ * PAMG_E_UNSUPPORTED: a column with more than 4096 blocks. */
+int pamg_bsr_transpose_f64(int32_t n_brow, int32_t n_bcol, int32_t R, int32_t C, const int32_t *Ap, const int32_t *Aj,
+                           const double *Ax, int32_t *Bp, int32_t *Bi, double *Bx);
+int pamg_bsr_transpose_f32(int32_t n_brow, int32_t n_bcol, int32_t R, int32_t C, const int32_t *Ap, const int32_t *Aj,
+                           const float *Ax, int32_t *Bp, int32_t *Bi, float *Bx);
+
 /* ------------------------------------------------------ Layer 2: resident engine (HBM) */
 /* Operator handle: uploads CSR/BSR arrays (HOST pointers) to HBM once and analyses them
  * (row-block plan for the LDS-streamed kernels; dependency-level schedules for the

@@ -102,6 +102,8 @@ def _declare(lib):
     f("pamg_pinv_array_f64", _vp, _i, _i, _i, C.c_char)
     f("pamg_pinv_array_f32", _vp, _i, _i, _i, C.c_char)
     f("pamg_dev_pinv_array", _i, _vp, C.c_int64, _i, _i, _vp)
+    f("pamg_bsr_transpose_f64", _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp)
+    f("pamg_bsr_transpose_f32", _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp)
     f("pamg_standard_aggregation", _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, P(_i))
     f("pamg_csr_standard_aggregation", _vp, _vp, _vp, P(_i))
     f("pamg_fit_candidates_f64", _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _d)

@@ -639,6 +639,31 @@ def _device_product(self, other):
     return self.__class__((M.data, M.indices, M.indptr), shape=M.shape)
 
 
+def _device_transpose(self, axes=None, copy=False):
+    """``self.T`` of a float CSR / BSR array as SciPy builds it (bsr_transpose / csr_tocsc: the same index and value
+    arrays, order included), on the device.  NotImplementedError: anything SciPy should keep doing itself."""
+    if axes is not None and axes != (1, 0):
+        raise NotImplementedError
+    if self.dtype not in (np.float64, np.float32) or self.nnz < (1 << 20) or self.indices.dtype != np.int32:
+        raise NotImplementedError                       # small operands: the host is as fast as the round trip
+    M, N = self.shape
+    if self.format == "bsr":
+        R, Cb = (int(v) for v in self.blocksize)
+    else:
+        raise NotImplementedError                       # csr.T is a zero-copy view as CSC in SciPy: nothing to speed up
+    nbr, nbc = M // R, N // Cb
+    nblk = int(self.indptr[-1])
+    indptr = np.empty(nbc + 1, dtype=np.int32)
+    indices = np.empty(nblk, dtype=np.int32)
+    data = np.empty((nblk, Cb, R), dtype=self.dtype)
+    Ap, Aj = _i32(self.indptr), _i32(self.indices)
+    Ax = np.ascontiguousarray(self.data).reshape(-1)
+    fn = capi.lib().pamg_bsr_transpose_f64 if self.dtype == np.float64 else capi.lib().pamg_bsr_transpose_f32
+    capi.check(fn(nbr, nbc, R, Cb, capi.ptr(Ap), capi.ptr(Aj), capi.ptr(Ax), capi.ptr(indptr), capi.ptr(indices), capi.ptr(data)),
+               "pamg_bsr_transpose")
+    return self._bsr_container((data, indices, indptr), shape=(N, M), copy=copy)
+
+
 @contextlib.contextmanager
 def device_products():
     """While the block runs, ``A @ B`` of two float64 CSR arrays (or BSR @ BSR/CSR without re-blocking) is computed by
@@ -655,16 +680,28 @@ def device_products():
                 return _device_product(self, other)
             except NotImplementedError:
                 return _orig(self, other)
-        saved.append((cls, own))
+        saved.append((cls, "_matmul_sparse", own))
         cls._matmul_sparse = wrapper
+    # P.T of a BSR prolongator (R = P.T, aggregation.py:394-397): bsr_transpose is serial host code in SciPy
+    for cls in (sp.bsr_array, sp.bsr_matrix):
+        orig = cls.transpose
+        own = cls.__dict__.get("transpose")
+
+        def twrapper(self, axes=None, copy=False, _orig=orig):
+            try:
+                return _device_transpose(self, axes, copy)
+            except NotImplementedError:
+                return _orig(self, axes=axes, copy=copy)
+        saved.append((cls, "transpose", own))
+        cls.transpose = twrapper
     try:
         yield
     finally:
-        for cls, own in saved:
+        for cls, attr, own in saved:
             if own is None:
-                del cls._matmul_sparse
+                delattr(cls, attr)
             else:
-                cls._matmul_sparse = own
+                setattr(cls, attr, own)
 
 
 # --------------------------------------------------------------------------- patching a reference package

@@ -665,3 +665,110 @@ int pamg_fit_tentative_f32(int32_t n_fine, int32_t n_coarse, int32_t K1, int32_t
 { return fit_tentative_host<float>(n_fine, n_coarse, K1, K2, Tp, Tj, B, Qx, R, tol); }
 
 }  // extern "C"
+
+// ================================================================================================================
+// Transpose of a CSR / BSR matrix as SciPy forms it (sparsetools bsr_transpose -> csr_tocsc on the block pattern, blocks
+// transposed): the blocks of a column keep the order of their rows and, inside a row, their stored order -- i.e. ascending
+// source position.  R = P.T of the SA setup (aggregation.py:394-397) is 0.6 s of serial host code at 256^3.
+// count per column (atomics) -> offsets (host prefix sum) -> unordered fill -> every column sorts its few source
+// positions (one lane per column) -> blocks copied transposed.
+namespace {
+
+__global__ __launch_bounds__(BLK) void tr_count_kernel(int64_t nblk, const int *Aj, int *cnt)
+{
+    for (int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x; p < nblk; p += (int64_t)gridDim.x * BLK) atomicAdd(cnt + Aj[p], 1);
+}
+
+__global__ __launch_bounds__(BLK) void tr_fill_kernel(int64_t nblk, const int *Aj, const int *Bp, int *cursor, int *src)
+{
+    for (int64_t p = (int64_t)blockIdx.x * BLK + threadIdx.x; p < nblk; p += (int64_t)gridDim.x * BLK) {
+        const int j = Aj[p];
+        src[Bp[j] + atomicAdd(cursor + j, 1)] = (int)p;
+    }
+}
+
+// one lane per column: ascending source positions; the row of a position by bisection of the row pointer
+__global__ __launch_bounds__(BLK) void tr_sort_kernel(int n_bcol, int n_brow, const int *Ap, const int *Bp, int *src, int *Bi)
+{
+    for (int j = blockIdx.x * BLK + threadIdx.x; j < n_bcol; j += gridDim.x * BLK) {
+        const int c0 = Bp[j], c1 = Bp[j + 1];
+        for (int a = c0 + 1; a < c1; ++a) {
+            const int v = src[a];
+            int b = a - 1;
+            while (b >= c0 && src[b] > v) { src[b + 1] = src[b]; --b; }
+            src[b + 1] = v;
+        }
+        for (int a = c0; a < c1; ++a) {
+            const int p = src[a];
+            int lo = 0, hi = n_brow;                               // largest i with Ap[i] <= p
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (Ap[mid] <= p) lo = mid; else hi = mid; }
+            Bi[a] = lo;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void tr_blocks_kernel(int64_t nblk, int R, int C, const int *src, const T *Ax, T *Bx)
+{
+    const int64_t RC = (int64_t)R * C;
+    for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < nblk * RC; e += (int64_t)gridDim.x * BLK) {
+        const int64_t q = e / RC;
+        const int k = (int)(e - q * RC), c = k / R, r = k - c * R;   // destination block is C x R, row-major: (c, r)
+        Bx[e] = Ax[(int64_t)src[q] * RC + (int64_t)r * C + c];
+    }
+}
+
+template <typename T>
+int transpose_host(int n_brow, int n_bcol, int R, int C, const int32_t *Ap, const int32_t *Aj, const T *Ax, int32_t *Bp, int32_t *Bi, T *Bx)
+{
+    if (n_brow < 0 || n_bcol < 0 || R < 1 || C < 1 || !Ap || !Bp) return PAMG_E_ARG;
+    const int64_t nblk = Ap[n_brow];
+    if (nblk < 0 || nblk > INT32_MAX || (nblk && (!Aj || !Ax || !Bi || !Bx))) return PAMG_E_ARG;
+    for (int j = 0; j <= n_bcol; ++j) Bp[j] = 0;
+    if (nblk == 0) return PAMG_OK;
+    const size_t RC = (size_t)R * C;
+    DevBufs d;
+    int *dAp, *dAj, *dBp, *dCur, *dSrc, *dBi;
+    T *dAx, *dBx;
+    PAMG_TRY(d.get(&dAp, (size_t)n_brow + 1)); PAMG_TRY(d.get(&dAj, (size_t)nblk)); PAMG_TRY(d.get(&dBp, (size_t)n_bcol + 1));
+    PAMG_TRY(d.get(&dCur, (size_t)n_bcol + 1)); PAMG_TRY(d.get(&dSrc, (size_t)nblk)); PAMG_TRY(d.get(&dBi, (size_t)nblk));
+    PAMG_TRY(d.get(&dAx, (size_t)nblk * RC)); PAMG_TRY(d.get(&dBx, (size_t)nblk * RC));
+    PAMG_HIP(hipMemcpy(dAp, Ap, sizeof(int) * ((size_t)n_brow + 1), hipMemcpyHostToDevice));
+    PAMG_HIP(hipMemcpy(dAj, Aj, sizeof(int) * (size_t)nblk, hipMemcpyHostToDevice));
+    PAMG_HIP(hipMemcpy(dAx, Ax, sizeof(T) * (size_t)nblk * RC, hipMemcpyHostToDevice));
+    PAMG_HIP(hipMemset(dCur, 0, sizeof(int) * ((size_t)n_bcol + 1)));
+    const int grid = agg_grid(nblk, 8192);
+    hipLaunchKernelGGL(tr_count_kernel, dim3(grid), dim3(BLK), 0, 0, nblk, (const int *)dAj, dCur);
+    PAMG_HIP(hipGetLastError());
+    std::vector<int> cnt((size_t)n_bcol + 1, 0);
+    PAMG_HIP(hipMemcpy(cnt.data(), dCur, sizeof(int) * (size_t)n_bcol, hipMemcpyDeviceToHost));
+    int mx = 0;
+    int64_t acc = 0;
+    for (int j = 0; j < n_bcol; ++j) { const int c = cnt[(size_t)j]; mx = std::max(mx, c); Bp[j] = (int)acc; acc += c; }
+    Bp[n_bcol] = (int)acc;
+    if (mx > 4096) return PAMG_E_UNSUPPORTED;                      // a column of thousands of blocks: the per-column sort is quadratic
+    PAMG_HIP(hipMemcpy(dBp, Bp, sizeof(int) * ((size_t)n_bcol + 1), hipMemcpyHostToDevice));
+    PAMG_HIP(hipMemset(dCur, 0, sizeof(int) * ((size_t)n_bcol + 1)));
+    hipLaunchKernelGGL(tr_fill_kernel, dim3(grid), dim3(BLK), 0, 0, nblk, (const int *)dAj, (const int *)dBp, dCur, dSrc);
+    hipLaunchKernelGGL(tr_sort_kernel, dim3(agg_grid(n_bcol)), dim3(BLK), 0, 0, n_bcol, n_brow, (const int *)dAp, (const int *)dBp, dSrc, dBi);
+    hipLaunchKernelGGL((tr_blocks_kernel<T>), dim3(agg_grid((int64_t)nblk * RC, 8192)), dim3(BLK), 0, 0, nblk, R, C, (const int *)dSrc, (const T *)dAx, dBx);
+    PAMG_HIP(hipGetLastError());
+    PAMG_HIP(hipMemcpy(Bi, dBi, sizeof(int) * (size_t)nblk, hipMemcpyDeviceToHost));
+    PAMG_HIP(hipMemcpy(Bx, dBx, sizeof(T) * (size_t)nblk * RC, hipMemcpyDeviceToHost));
+    return PAMG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* SciPy's bsr_transpose / csr_tocsc (sparsetools): B = A^T for A (n_brow x n_bcol blocks of R x C; R = C = 1: CSR), all
+ * arrays HOST; Bp[n_bcol + 1], Bi[nblk], Bx[nblk * C * R] receive what `A.T` holds in SciPy, order included. */
+int pamg_bsr_transpose_f64(int32_t n_brow, int32_t n_bcol, int32_t R, int32_t C, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                           int32_t *Bp, int32_t *Bi, double *Bx)
+{ return transpose_host<double>(n_brow, n_bcol, R, C, Ap, Aj, Ax, Bp, Bi, Bx); }
+int pamg_bsr_transpose_f32(int32_t n_brow, int32_t n_bcol, int32_t R, int32_t C, const int32_t *Ap, const int32_t *Aj, const float *Ax,
+                           int32_t *Bp, int32_t *Bi, float *Bx)
+{ return transpose_host<float>(n_brow, n_bcol, R, C, Ap, Aj, Ax, Bp, Bi, Bx); }
+
+}  // extern "C"

@@ -1033,7 +1033,7 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
         if (xcd) {
             // 8x the wanted grid is launched; the workgroups off the home XCD leave at once
             PAMG_HIP(hipMemsetAsync(g->d_sync + 20, 0, 2 * sizeof(unsigned), s));
-            return gran2_launch<T, true>(epi, 8 * std::min(G, 96), lds, s, ga);
+            return gran2_launch<T, true>(epi, 8 * std::min(G, A->gran_cap > 0 ? A->gran_cap : 96), lds, s, ga);
         }
         return gran2_launch<T, false>(epi, G, lds, s, ga);
     }

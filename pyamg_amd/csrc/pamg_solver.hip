@@ -410,8 +410,12 @@ void record_tail(pamg_solver_s *S, int lvl, bool x_zero, std::vector<TailOp> &op
 int build_tail(pamg_solver_s *S)
 {
     S->tail_from = -1;
+    // Opt-in (PAMG_TAIL=1).  Measured on MI355X (profiles/r03_tail_kernel_c2_c1.json): inside a hipGraph the small levels'
+    // launches cost ~2 us each, less than one workgroup needs to walk the same rows with dependent loads -- 2000^2 Jacobi
+    // 0.559 ms per cycle with the tail in one launch against 0.521 ms without, 500^2 RS 0.233 against 0.199.  Kept for
+    // eager (graph-less) runs, where a launch costs 6-8 us.
     const char *e = getenv("PAMG_TAIL");
-    if (e && *e == '0') return PAMG_OK;
+    if (!e || *e != '1') return PAMG_OK;
     const int nlev = (int)S->levels.size();
     if (nlev < 2 || S->coarse_relax || S->n_c > TAIL_MAX_ROWS) return PAMG_OK;
     int from = nlev - 1;                                           // the coarsest level always qualifies here

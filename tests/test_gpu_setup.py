@@ -395,6 +395,39 @@ def test_device_aggregation_inside_the_reference_setup():
                 assert np.array_equal(Ld.T.data, Lr.T.data) and np.array_equal(Bd, Br)
 
 
+def test_bsr_transpose_is_scipys():
+    """pamg_bsr_transpose (R = P.T of the SA setup) against SciPy's bsr_transpose: the same three arrays for 1x1 and
+    true blocks, unsorted rows, empty rows and columns; inside device_products() `P.T` of a large BSR operand is routed
+    there, a small one stays with SciPy"""
+    import ctypes  # noqa: F401
+    from pyamg_amd import _capi as capi
+    from pyamg_amd.aggregation import _device_transpose, device_products
+    rng = np.random.default_rng(17)
+    for (nbr, nbc, R, Cc, dens) in ((300, 200, 1, 1, 0.05), (150, 220, 3, 2, 0.04), (64, 64, 2, 2, 0.2)):
+        pat = _shuffle_rows(sp.random_array((nbr, nbc), density=dens, random_state=rng, format="csr"), rng)
+        data = rng.standard_normal((pat.nnz, R, Cc))
+        A = sp.bsr_array((data, pat.indices.astype(np.int32), pat.indptr.astype(np.int32)), shape=(nbr * R, nbc * Cc))
+        ref = A.T
+        Bp = np.empty(nbc + 1, dtype=np.int32)
+        Bi = np.empty(pat.nnz, dtype=np.int32)
+        Bx = np.empty((pat.nnz, Cc, R))
+        capi.check(capi.lib().pamg_bsr_transpose_f64(nbr, nbc, R, Cc, capi.ptr(A.indptr), capi.ptr(A.indices), capi.ptr(np.ascontiguousarray(A.data).ravel()),
+                                                     capi.ptr(Bp), capi.ptr(Bi), capi.ptr(Bx)), "pamg_bsr_transpose")
+        assert np.array_equal(Bp, ref.indptr) and np.array_equal(Bi, ref.indices) and np.array_equal(Bx, ref.data)
+    n = 1200
+    big = sp.bsr_array(sp.random_array((n, n), density=0.9, random_state=rng, format="csr"), blocksize=(1, 1))
+    big.indices, big.indptr = big.indices.astype(np.int32), big.indptr.astype(np.int32)
+    assert big.nnz >= (1 << 20)
+    want = big.T
+    with device_products():
+        got = big.T
+        small = A.T
+    assert got.format == "bsr" and np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+    assert np.array_equal(got.data, want.data) and np.array_equal(small.data, ref.data)
+    assert np.array_equal(_device_transpose(big).data, want.data)
+    assert "transpose" not in sp.bsr_array.__dict__          # the hook is gone again
+
+
 def test_symmetric_strength_against_the_reference():
     pyamg = _reference()
     from pyamg.strength import symmetric_strength_of_connection as ref_soc

@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, nargs="+", default=[256, 256, 256])
 ap.add_argument("--levels", type=int, nargs="+", default=[1, 2])
 ap.add_argument("--tag", default="gs2")
+ap.add_argument("--exp", default="a")
 a = ap.parse_args()
 A = pyamg.gallery.poisson(tuple(a.grid), format="csr")
 np.random.seed(1)
@@ -48,15 +49,23 @@ for li in a.levels:
     db, dx = capi.DeviceArray.from_host(b), capi.DeviceArray.from_host(x)
     ref = None
     variants = [("default", {})]
-    for cap in (512, 768, 1024, 2048):
-        variants.append((f"cap{cap}", dict(lds_entries=cap, gs_mode=2, gran_xcd=2)))
-    for mr in (16, 32, 64):
-        variants.append((f"rows{mr}", dict(lds_entries=1536, max_rows=mr, gs_mode=2, gran_xcd=2)))
-    for cap, G in ((768, 512), (512, 768), (1536, 512), (1024, 384)):
-        variants.append((f"cap{cap}_G{G}", dict(lds_entries=cap, max_rows=1024, gs_mode=2, gran_xcd=2, gran_cap=G)))
-    for cap in (768, 1536):
-        variants.append((f"cap{cap}_xcd", dict(lds_entries=cap, max_rows=1024, gs_mode=2, gran_xcd=1, gran_cap=0)))
-    variants.append(("tiled", dict(lds_entries=1536, max_rows=1024, gs_mode=5, gran_xcd=0, gran_cap=0)))
+    if a.exp == "b":
+        for cap in (256, 384, 512):
+            variants.append((f"gcap{cap}", dict(lds_entries=1536, gs_cap=cap, gs_mode=2, gran_xcd=2, gran_cap=0)))
+        for cap, G in ((512, 128), (512, 256), (256, 256), (1024, 192)):
+            variants.append((f"gcap{cap}_xcd_G{G}", dict(lds_entries=1536, gs_cap=cap, gs_mode=2, gran_xcd=1, gran_cap=G)))
+        for cap, G in ((512, 384), (256, 512)):
+            variants.append((f"gcap{cap}_G{G}", dict(lds_entries=1536, gs_cap=cap, gs_mode=2, gran_xcd=2, gran_cap=G)))
+    else:
+        for cap in (512, 768, 1024, 2048):
+            variants.append((f"cap{cap}", dict(lds_entries=cap, gs_mode=2, gran_xcd=2)))
+        for mr in (16, 32, 64):
+            variants.append((f"rows{mr}", dict(lds_entries=1536, max_rows=mr, gs_mode=2, gran_xcd=2)))
+        for cap, G in ((768, 512), (512, 768), (1536, 512), (1024, 384)):
+            variants.append((f"cap{cap}_G{G}", dict(lds_entries=cap, max_rows=1024, gs_mode=2, gran_xcd=2, gran_cap=G)))
+        for cap in (768, 1536):
+            variants.append((f"cap{cap}_xcd", dict(lds_entries=cap, max_rows=1024, gs_mode=2, gran_xcd=1, gran_cap=0)))
+        variants.append(("tiled", dict(lds_entries=1536, max_rows=1024, gs_mode=5, gran_xcd=0, gran_cap=0)))
     for name, kw in variants:
         try:
             if kw:
