@@ -6,7 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/pyamg_amd.h"
@@ -233,6 +236,21 @@ int csr_device_arrays(struct ::pamg_csr_s *A, CsrArrays *out);                  
 int solver_cycle_inline(pamg_solver_s *S, void *x, const void *b, int cycle, int cpl, hipStream_t s, bool allow_graph);   // pamg_solver.hip
 int sweep_error(pamg_matrix_s *A, bool *error);      // spin bound hit since the last call? (caller has synchronised; clears the flag)
 inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }
+
+// fn(lo, hi) over [0, n) on a few host threads (structure checks and scans over 10^8 stored entries are worth it)
+template <typename F>
+inline void host_parallel(int64_t n, F fn, int64_t grain = 1 << 20)
+{
+    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int nt = n < 2 * grain ? 1 : (int)std::min<int64_t>(hw, n / grain);
+    if (nt <= 1) { fn((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        th.emplace_back([=] { fn(lo, hi); });
+    }
+    for (auto &x : th) x.join();
+}
 
 // PAMG_TIMING=1: wall-clock of the host-side phases of upload / analysis / planning on stderr (diagnostics)
 struct PhaseTimer {

@@ -1009,6 +1009,7 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
         ga.nblk = g->nblk_total;
         ga.ticket = g->d_sync + 20;
         ga.s.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(A->nrows, 1 << 20));
+
         if (!g->symmetric) {
             // write-after-read hazards are not ordered by the waits: old values come from a snapshot
             if (!g->d_xold) return PAMG_E_STATE;
@@ -1570,10 +1571,12 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
     if (nblk < 0 || (nblk > 0 && (!Aj || !Ax)) || Ap[0] != 0) return PAMG_E_ARG;
     // a malformed operator would mean out-of-bounds device accesses and (with the flag bits the schedules put
     // into column ids) wrong dependency analysis: check the structure once, here
-    for (int i = 0; i < n_brow; ++i)
-        if (Ap[i + 1] < Ap[i]) return PAMG_E_ARG;
-    for (int64_t p = 0; p < nblk; ++p)
-        if (Aj[p] < 0 || Aj[p] >= n_bcol) return PAMG_E_ARG;
+    {
+        std::atomic<int> bad(0);
+        host_parallel(n_brow, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) if (Ap[i + 1] < Ap[i]) bad = 1; });
+        host_parallel(nblk, [&](int64_t lo, int64_t hi) { int b = 0; for (int64_t p = lo; p < hi; ++p) b |= (Aj[p] < 0) | (Aj[p] >= n_bcol); if (b) bad = 1; });
+        if (bad.load()) return PAMG_E_ARG;
+    }
     // column ids carry two flag bits in the level schedules (pamg_kernels.h: EARLY_BIT, DIAG_BIT)
     if ((int64_t)n_brow * R > (1 << 30) || (int64_t)n_bcol * C > (1 << 30) || nblk * R * C > INT32_MAX)
         return PAMG_E_UNSUPPORTED;
@@ -1596,9 +1599,11 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
             // the smoothers do not have to re-read the value stream to fetch it
             std::vector<unsigned char> dg((size_t)n_brow * ts, 0);
             const unsigned char *src = (const unsigned char *)Ax;
-            for (int i = 0; i < n_brow; ++i)
-                for (int p = Ap[i]; p < Ap[i + 1]; ++p)
-                    if (Aj[p] == i) std::memcpy(&dg[(size_t)i * ts], src + (size_t)p * ts, ts);
+            host_parallel(n_brow, [&](int64_t lo, int64_t hi) {
+                for (int64_t i = lo; i < hi; ++i)
+                    for (int p = Ap[i]; p < Ap[i + 1]; ++p)
+                        if (Aj[p] == (int)i) std::memcpy(&dg[(size_t)i * ts], src + (size_t)p * ts, ts);
+            }, 1 << 18);
             st = upload_raw(&A->d_diag, dg.data(), (size_t)n_brow, ts, &A->bytes);
         }
     } else {
@@ -1641,7 +1646,16 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
             if (!st) st = upload(&A->d_bdiag, bdiag.data(), bdiag.size(), &A->bytes);
         }
     }
-    for (int64_t i = 0; i < A->nrows && !st; ++i) A->max_row_len = std::max(A->max_row_len, A->h_Ap[i + 1] - A->h_Ap[i]);
+    if (!st) {
+        std::atomic<int> mx(0);
+        host_parallel(A->nrows, [&](int64_t lo, int64_t hi) {
+            int m = 0;
+            for (int64_t i = lo; i < hi; ++i) m = std::max(m, A->h_Ap[i + 1] - A->h_Ap[i]);
+            int cur = mx.load();
+            while (m > cur && !mx.compare_exchange_weak(cur, m)) {}
+        });
+        A->max_row_len = mx.load();
+    }
     // default plan (measured best on 256^3 Poisson): 1536 staged entries = 12 KB (SpMV) / 18 KB
     // (smoothers, with column ids) of LDS per workgroup -> 8 workgroups = 32 waves per CU
     A->cap = 1536; A->npl = 2; A->max_rows = 1024;
@@ -1736,16 +1750,16 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
     float best_ms = 1e30f;
     for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK; ++ci) {
         if (caps[ci] != A->cap) { A->cap = caps[ci]; st = replan(A); if (st) break; }
-        for (int fl = 0; fl < 2 && st == PAMG_OK; ++fl) {
-            A->stream_flags = (fl0 & ~1) | fl;
+        for (int fl = 0; fl < 4 && st == PAMG_OK; ++fl) {      // bit 0 non-temporal operator stream, bit 1 XCD-contiguous range order
+            A->stream_flags = (fl0 & ~3) | fl;
             for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
             hipEventRecord(e0, nullptr);
-            for (int r = 0; r < 4 && st == PAMG_OK; ++r) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
+            for (int r = 0; r < 6 && st == PAMG_OK; ++r) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
             hipEventRecord(e1, nullptr);
             hipEventSynchronize(e1);
             float ms = 0.f;
             hipEventElapsedTime(&ms, e0, e1);
-            if (st == PAMG_OK && ms < best_ms * 0.98f) { best_ms = ms; best_cap = A->cap; best_fl = A->stream_flags; }
+            if (st == PAMG_OK && ms < best_ms * 0.99f) { best_ms = ms; best_cap = A->cap; best_fl = A->stream_flags; }
         }
     }
     A->stream_flags = best_fl;

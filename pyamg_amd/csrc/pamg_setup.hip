@@ -781,11 +781,14 @@ void par_for(int n, F fn)
 
 int ensure_host_index(pamg_csr_s *A)
 {
-    if (!A->h_p.empty()) return PAMG_OK;
-    A->h_p.resize((size_t)A->m + 1);
-    A->h_j.resize((size_t)A->nnz);
-    PAMG_HIP(hipMemcpy(A->h_p.data(), A->d_p, sizeof(int) * ((size_t)A->m + 1), hipMemcpyDeviceToHost));
-    if (A->nnz) PAMG_HIP(hipMemcpy(A->h_j.data(), A->d_j, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+    if (A->h_p.empty()) {
+        A->h_p.resize((size_t)A->m + 1);
+        PAMG_HIP(hipMemcpy(A->h_p.data(), A->d_p, sizeof(int) * ((size_t)A->m + 1), hipMemcpyDeviceToHost));
+    }
+    if (A->h_j.size() != (size_t)A->nnz) {
+        A->h_j.resize((size_t)A->nnz);
+        if (A->nnz) PAMG_HIP(hipMemcpy(A->h_j.data(), A->d_j, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToHost));
+    }
     return PAMG_OK;
 }
 
@@ -1107,16 +1110,19 @@ int pamg_csr_create(pamg_csr_t *out, int64_t m, int64_t n, const int32_t *Ap, co
     if (!out || !Ap || m < 0 || n < 0 || m > (1 << 30) || n > (1 << 30) || Ap[0] != 0) return PAMG_E_ARG;
     const int64_t nnz = Ap[m];
     if (nnz < 0 || (nnz > 0 && (!Aj || !Ax))) return PAMG_E_ARG;
-    for (int64_t i = 0; i < m; ++i) if (Ap[i + 1] < Ap[i]) return PAMG_E_ARG;
-    for (int64_t p = 0; p < nnz; ++p) if (Aj[p] < 0 || Aj[p] >= n) return PAMG_E_ARG;
+    {
+        std::atomic<int> bad(0);
+        host_parallel(m, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) if (Ap[i + 1] < Ap[i]) bad = 1; });
+        host_parallel(nnz, [&](int64_t lo, int64_t hi) { int b = 0; for (int64_t p = lo; p < hi; ++p) b |= (Aj[p] < 0) | (Aj[p] >= n); if (b) bad = 1; });
+        if (bad.load()) return PAMG_E_ARG;
+    }
     pamg_csr_s *C = nullptr;
     PAMG_TRY(new_csr(m, n, nnz, &C));
     int st = (int)hipMemcpy(C->d_p, Ap, sizeof(int) * ((size_t)m + 1), hipMemcpyHostToDevice);
     if (!st && nnz) st = (int)hipMemcpy(C->d_j, Aj, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice);
     if (!st && nnz) st = (int)hipMemcpy(C->d_x, Ax, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice);
     if (st) { pamg_csr_destroy(C); return st; }
-    C->h_p.assign(Ap, Ap + m + 1);
-    C->h_j.assign(Aj, Aj + nnz);
+    C->h_p.assign(Ap, Ap + m + 1);                        // the column ids stay on the device (ensure_host_index fetches them if a plan ever asks)
     *out = C;
     return PAMG_OK;
 }

@@ -49,7 +49,11 @@ for li in a.levels:
     db, dx = capi.DeviceArray.from_host(b), capi.DeviceArray.from_host(x)
     ref = None
     variants = [("default", {})]
-    if a.exp == "b":
+    if a.exp == "c":
+        variants = [("transposed", dict(gs_cap=0, _env="1")), ("plain", dict(gs_cap=0, _env="0")), ("transposed_again", dict(gs_cap=0, _env="1")),
+                    ("transposed_gcap384", dict(gs_cap=384, _env="1")), ("transposed_gcap768", dict(gs_cap=768, _env="1")),
+                    ("transposed_gcap1536", dict(gs_cap=1536, _env="1"))]
+    elif a.exp == "b":
         for cap in (256, 384, 512):
             variants.append((f"gcap{cap}", dict(lds_entries=1536, gs_cap=cap, gs_mode=2, gran_xcd=2, gran_cap=0)))
         for cap, G in ((512, 128), (512, 256), (256, 256), (1024, 192)):
@@ -68,6 +72,10 @@ for li in a.levels:
         variants.append(("tiled", dict(lds_entries=1536, max_rows=1024, gs_mode=5, gran_xcd=0, gran_cap=0)))
     for name, kw in variants:
         try:
+            import os
+            kw = dict(kw)
+            if "_env" in kw:
+                os.environ["PAMG_GS_TRANSPOSED"] = kw.pop("_env")
             if kw:
                 dA.tune(**kw)
             dx.upload(x)
