@@ -104,7 +104,7 @@ __global__ __launch_bounds__(BLK) void spg_count_kernel(int m, const int *Ap, co
     }
 }
 
-constexpr int SPG_PER = SPG_CAP / BLK;   // sorted positions per thread
+
 
 // bitonic network on (key, value) pairs in LDS; keys are unique, so the order is total
 template <bool WITHV>
@@ -128,13 +128,14 @@ __device__ __forceinline__ void lds_sort(unsigned long long *K, double *V, int N
 
 // Whole rows (at most SPG_CAP products per task).  Key of a product: local row (11 bits) | column (31) | sequence
 // number inside the task (22).
-template <bool NUMERIC>
+template <bool NUMERIC, int CAP>
 __global__ __launch_bounds__(BLK) void spg_kernel(const SpgArgs a)
 {
+    constexpr int SPG_PER = CAP / BLK;                                             // sorted positions per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *K = reinterpret_cast<unsigned long long *>(smem);
-    double *V = reinterpret_cast<double *>(smem + 8 * SPG_CAP);                    // numeric only
-    unsigned char *misc = smem + (NUMERIC ? 16 : 8) * SPG_CAP;
+    double *V = reinterpret_cast<double *>(smem + 8 * CAP);                        // numeric only
+    unsigned char *misc = smem + (NUMERIC ? 16 : 8) * CAP;
     double *sA = reinterpret_cast<double *>(misc);                                 // [BLK]
     int *sScan = reinterpret_cast<int *>(sA + BLK);                                // [BLK]
     int *sOff = sScan + BLK;                                                       // [BLK + 1]
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(BLK) void spg_kernel(const SpgArgs a)
         if (NUMERIC) sA[tid] = av;
         if (tid == 0) sOff[BLK] = chunk;
         __syncthreads();
-        if (total + chunk > SPG_CAP) { overflow = true; break; }
+        if (total + chunk > CAP) { overflow = true; break; }
         for (int q = tid; q < chunk; q += BLK) {
             int lo = 0, hi = BLK;                         // largest i with sOff[i] <= q  (empty entries share an offset: take the last)
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sOff[mid] <= q) lo = mid; else hi = mid; }
@@ -817,9 +818,9 @@ int counts_to_ptr(int m, const int *d_cnt, std::vector<int> &hp, int64_t &nnz)
     return PAMG_OK;
 }
 
-size_t spg_lds(bool numeric)
+size_t spg_lds(bool numeric, int cap = SPG_CAP)
 {
-    return (size_t)(numeric ? 16 : 8) * SPG_CAP + sizeof(double) * BLK + sizeof(int) * (size_t)(4 * BLK + 2 + 2 * SPG_ROWS + 2);
+    return (size_t)(numeric ? 16 : 8) * cap + sizeof(double) * BLK + sizeof(int) * (size_t)(4 * BLK + 2 + 2 * SPG_ROWS + 2);
 }
 
 int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr_s **out)
@@ -829,8 +830,10 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
     const int m = (int)A->m;
     static bool attr_set = false;
     if (!attr_set) {
-        PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(true)));
-        PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(false)));
+        PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<true, SPG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(true)));
+        PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<false, SPG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(false)));
+        PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<true, SPG_CAP2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(true, SPG_CAP2)));
+        PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<false, SPG_CAP2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(false, SPG_CAP2)));
         attr_set = true;
     }
     int *d_nprod = nullptr, *d_rowcount = nullptr, *d_rcount = nullptr, *d_obase = nullptr, *d_seq = nullptr, *d_long = nullptr,
@@ -856,7 +859,7 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
         SPG_CHECK(hipMemcpy(nprod.data(), d_nprod, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
     }
     std::vector<int> long_rows, lohi;                    // rows handled window by window, and the span of their product columns
-    for (int r = 0; r < m; ++r) if (nprod[r] > SPG_CAP) long_rows.push_back(r);
+    for (int r = 0; r < m; ++r) if (nprod[r] > SPG_CAP2) long_rows.push_back(r);
     const int nlong = (int)long_rows.size();
     if (nlong) {
         for (int r : long_rows) if (nprod[r] == INT_MAX) SPG_CHECK(PAMG_E_UNSUPPORTED);       // sequence numbers are 31-bit
@@ -886,22 +889,28 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
         for (const SpgTask &t : plan) tasks.push_back(make_int4(t.row0, t.row1, t.col0, t.col1));
     }
     const int nt = (int)tasks.size();
-    std::vector<int> ids_short, ids_long;
-    for (int t = 0; t < nt; ++t) (tasks[t].w == INT_MAX && tasks[t].z == 0 ? ids_short : ids_long).push_back(t);
-    const int ns = (int)ids_short.size(), nl = (int)ids_long.size();
+    std::vector<int> ids_short, ids_big, ids_long;        // whole rows packed to SPG_CAP / one row of up to SPG_CAP2 products / column windows
+    for (int t = 0; t < nt; ++t) {
+        const bool whole = tasks[t].w == INT_MAX && tasks[t].z == 0;
+        const bool big = whole && tasks[t].y - tasks[t].x == 1 && nprod[(size_t)tasks[t].x] > SPG_CAP;
+        (big ? ids_big : whole ? ids_short : ids_long).push_back(t);
+    }
+    const int ns = (int)ids_short.size(), nb = (int)ids_big.size(), nl = (int)ids_long.size();
     SPG_CHECK(hipMalloc((void **)&d_tasks, sizeof(int4) * ((size_t)nt + 1)));
     SPG_CHECK(hipMalloc((void **)&d_rcount, sizeof(int) * ((size_t)nt + 1)));
     SPG_CHECK(hipMalloc((void **)&d_obase, sizeof(int) * ((size_t)nt + 1)));
     SPG_CHECK(hipMalloc((void **)&d_ids, sizeof(int) * ((size_t)nt + 1)));
     if (nt) SPG_CHECK(hipMemcpy(d_tasks, tasks.data(), sizeof(int4) * (size_t)nt, hipMemcpyHostToDevice));
     if (ns) SPG_CHECK(hipMemcpy(d_ids, ids_short.data(), sizeof(int) * (size_t)ns, hipMemcpyHostToDevice));
-    if (nl) SPG_CHECK(hipMemcpy(d_ids + ns, ids_long.data(), sizeof(int) * (size_t)nl, hipMemcpyHostToDevice));
+    if (nb) SPG_CHECK(hipMemcpy(d_ids + ns, ids_big.data(), sizeof(int) * (size_t)nb, hipMemcpyHostToDevice));
+    if (nl) SPG_CHECK(hipMemcpy(d_ids + ns + nb, ids_long.data(), sizeof(int) * (size_t)nl, hipMemcpyHostToDevice));
     SpgArgs a;
     a.ranges = d_tasks; a.ids = d_ids; a.Ap = A->d_p; a.Aj = A->d_j; a.Ax = A->d_x; a.Bp = B->d_p; a.Bj = B->d_j; a.Bx = B->d_x;
     a.rowcount = d_rowcount; a.rcount = d_rcount; a.obase = d_obase; a.Cj = nullptr; a.Cx = nullptr; a.Cseq = nullptr; a.flags = d_flags;
     a.cb = col_block; a.keep = keep_zeros ? 1 : 0;
-    SpgArgs al = a;
-    al.ids = d_ids + ns;
+    SpgArgs ab = a, al = a;
+    ab.ids = d_ids + ns;
+    al.ids = d_ids + ns + nb;
     // a launch may not exceed 2^32 threads (grid x block): coarse Galerkin products have tens of millions of window
     // tasks (measured: 33 M at 384^3, and a single launch silently ran only the first 2^24), so tasks go out in slices
     auto launch_tasks = [&](bool numeric) -> int {
@@ -909,8 +918,14 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
         for (int off = 0; off < ns; off += SLICE) {
             SpgArgs s1 = a;
             s1.ids = a.ids + off;
-            if (numeric) hipLaunchKernelGGL((spg_kernel<true>), dim3(std::min(SLICE, ns - off)), dim3(BLK), spg_lds(true), 0, s1);
-            else hipLaunchKernelGGL((spg_kernel<false>), dim3(std::min(SLICE, ns - off)), dim3(BLK), spg_lds(false), 0, s1);
+            if (numeric) hipLaunchKernelGGL((spg_kernel<true, SPG_CAP>), dim3(std::min(SLICE, ns - off)), dim3(BLK), spg_lds(true), 0, s1);
+            else hipLaunchKernelGGL((spg_kernel<false, SPG_CAP>), dim3(std::min(SLICE, ns - off)), dim3(BLK), spg_lds(false), 0, s1);
+        }
+        for (int off = 0; off < nb; off += SLICE) {
+            SpgArgs s1 = ab;
+            s1.ids = ab.ids + off;
+            if (numeric) hipLaunchKernelGGL((spg_kernel<true, SPG_CAP2>), dim3(std::min(SLICE, nb - off)), dim3(BLK), spg_lds(true, SPG_CAP2), 0, s1);
+            else hipLaunchKernelGGL((spg_kernel<false, SPG_CAP2>), dim3(std::min(SLICE, nb - off)), dim3(BLK), spg_lds(false, SPG_CAP2), 0, s1);
         }
         for (int off = 0; off < nl; off += SLICE) {
             SpgArgs s1 = al;
@@ -935,7 +950,7 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
     SPG_CHECK(hipMemcpy(C->d_p, hp.data(), sizeof(int) * ((size_t)m + 1), hipMemcpyHostToDevice));
     if (nt) SPG_CHECK(hipMemcpy(d_obase, ob.data(), sizeof(int) * (size_t)nt, hipMemcpyHostToDevice));
     if (nl) SPG_CHECK(hipMalloc((void **)&d_seq, sizeof(int) * ((size_t)nnz + 8)));
-    a.Cj = al.Cj = C->d_j; a.Cx = al.Cx = C->d_x; al.Cseq = d_seq;
+    a.Cj = ab.Cj = al.Cj = C->d_j; a.Cx = ab.Cx = al.Cx = C->d_x; al.Cseq = d_seq;
     SPG_CHECK(launch_tasks(true));
     for (int off = 0; off < nlong; off += (1 << 22)) {
         hipLaunchKernelGGL(spg_reorder_kernel, dim3((unsigned)std::min(1 << 22, nlong - off)), dim3(BLK), 0, 0, (const int *)d_long + off, (const int *)C->d_p,

@@ -38,7 +38,7 @@ int spg_emul_f64(int m, int n, const int *Ap, const int *Aj, const double *Ax, c
             for (int p = Bp[k]; p < Bp[k + 1]; ++p) { lo = std::min(lo, Bj[p]); hi = std::max(hi, Bj[p]); }
         }
         nprod[(size_t)i] = (int)std::min<long long>(c, INT_MAX);
-        if (nprod[(size_t)i] > SPG_CAP) { lohi.push_back(lo); lohi.push_back(hi); any_long = true; }
+        if (nprod[(size_t)i] > SPG_CAP2) { lohi.push_back(lo); lohi.push_back(hi); any_long = true; }
     }
     std::vector<SpgTask> tasks;
     spg_plan(m, nprod, lohi, tasks);
@@ -66,7 +66,7 @@ int spg_emul_f64(int m, int n, const int *Ap, const int *Aj, const double *Ax, c
                         V.push_back(Ax[e] * Bx[p]);
                     }
                 }
-            if (seq > (unsigned)SPG_CAP) return 3;
+            if (seq > (unsigned)(t.row1 - t.row0 == 1 ? SPG_CAP2 : SPG_CAP)) return 3;
             std::vector<int> idx(K.size());
             for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
             std::sort(idx.begin(), idx.end(), [&](int a, int b) { return K[(size_t)a] < K[(size_t)b]; });

@@ -65,7 +65,7 @@ def test_matmat_drops_exact_zeros_like_scipy():
 
 
 def test_matmat_long_rows():
-    """rows with more than 4096 products (every row of a coarse Galerkin product) take the dense-accumulator path:
+    """rows with more than 8192 products (every row of a coarse Galerkin product) take the dense-accumulator path:
     windows of 2048 output columns, batches in sequence order, SciPy's emission order restored per finished row"""
     from pyamg_amd.aggregation import DeviceCSR
     rng = np.random.default_rng(6)
@@ -83,13 +83,20 @@ def test_matmat_long_rows():
     # every row long, few distinct output columns (the shape of (R A) P on a coarse level), exact cancellations
     m, k, n = 40, 900, 300
     A2 = _shuffle_rows(sp.random_array((m, k), density=0.6, random_state=rng, format="csr"), rng)
-    B2 = sp.random_array((k, n), density=0.05, random_state=rng, format="csr")
+    B2 = sp.random_array((k, n), density=0.09, random_state=rng, format="csr")
     B2.data = np.sign(B2.data - 0.5)                        # +-1: sums cancel exactly now and then
     A2.data = np.round(A2.data * 4.0)
     A2.eliminate_zeros()
     ref = A2 @ B2
     assert np.diff(ref.indptr).max() <= n and (A2 @ abs(B2)).nnz > ref.nnz
     _same((DeviceCSR.from_scipy(A2) @ DeviceCSR.from_scipy(B2)).to_scipy(), ref)
+    # rows of 4096 .. 8192 products: whole-row tasks of the big variant (136 KB of LDS), no windows
+    B4 = sp.random_array((k, n), density=0.04, random_state=rng, format="csr")
+    B4.data = np.sign(B4.data - 0.5)
+    ref4 = A2 @ B4
+    _same((DeviceCSR.from_scipy(A2) @ DeviceCSR.from_scipy(B4)).to_scipy(), ref4)
+    B4u = _shuffle_rows(B4, rng)
+    _same((DeviceCSR.from_scipy(A2) @ DeviceCSR.from_scipy(B4u)).to_scipy(), A2 @ B4u)
 
 
 def test_subtract_bit_exact_against_scipy():

@@ -212,11 +212,20 @@ def test_product_replay_long_rows(spg):
     A2 = _shuffled(sp.random_array((30, 900), density=0.6, random_state=rng, format="csr"), rng)
     A2.data = np.round(A2.data * 4.0)
     A2.eliminate_zeros()
-    B2 = sp.random_array((900, 300), density=0.05, random_state=rng, format="csr")
+    B2 = sp.random_array((900, 300), density=0.09, random_state=rng, format="csr")
     B2.data = np.sign(B2.data - 0.5)
     C2, st2 = _replay(spg, A2, B2)
     _same_arrays(C2, A2 @ B2)
     assert st2[1] == 30 and st2[3] > 0
+    # between 4096 and 8192 products per row: whole-row tasks of their own (the big variant of the expand - sort - compress
+    # kernel), no windows -- the rows of the level-1 -> 2 Galerkin products of 3-D problems
+    B4 = sp.random_array((900, 300), density=0.04, random_state=rng, format="csr")
+    B4.data = np.sign(B4.data - 0.5)
+    npr = np.array([(B4.indptr[A2.indices[A2.indptr[i]:A2.indptr[i + 1]] + 1] - B4.indptr[A2.indices[A2.indptr[i]:A2.indptr[i + 1]]]).sum() for i in range(30)])
+    assert ((npr > 4096) & (npr <= 8192)).sum() >= 20
+    C4, st4 = _replay(spg, A2, B4)
+    _same_arrays(C4, A2 @ B4)
+    assert st4[1] == int((npr > 8192).sum())
     # a batch that must be cut: B rows of ~1500 in-window entries, 256 candidate entries per batch
     A3 = sp.csr_array(np.ones((2, 40)))
     B3 = sp.random_array((40, 1900), density=0.8, random_state=rng, format="csr")
