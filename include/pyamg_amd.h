@@ -324,9 +324,15 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * 18 = tile shapes: 1 (default) pencils on three-band grid stencils, 0 contiguous chunks of the visit order always;
  * 19 = 16-bit windowed column stream of the whole-operator kernels (default 1; 0 = 32-bit columns);
  * 20 = entries per row range of the level schedules of the order-exact sweeps (0 = automatic: key 0's value, 512 where the
- * multi-XCD granular sweep runs SA-like rows; else 64..2048).
+ * multi-XCD granular sweep runs SA-like rows; else 64..2048);
+ * 21 = 8-bit value codes of the whole-operator kernels (default 1): an operator with at most 256 distinct values
+ * (the stencils of pyamg.gallery: 2) streams one byte per value, the kernel looks the value up in an LDS copy of
+ * the dictionary -- same bits, same products; needs key 19.
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
+/* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes
+ * (tune key 21), 0 when they stream the values themselves. */
+int pamg_matrix_value_codes(pamg_matrix_t A, int *n_values);
 /* Pick the LDS window (key 0) and streaming flags (key 8) of the whole-operator kernels by timing
  * y = A x on the device with a few candidates (results are bit-identical for every choice; this
  * is speed only).  allow_cap = 0 keeps the LDS window (level schedules depend on it).  Operators

@@ -80,6 +80,9 @@ struct StreamArgs {
     const int4 *wbase;            //   per row range: the first column of its (up to four) windows
     int4 wb;                      //   the current range's window bases (set by the kernel)
     const int *blkmap;            // whole-operator kernels: launch index -> row range (nullptr = identity); nblk = ranges launched
+    const unsigned char *Ax8;     // whole-operator kernels: values as 8-bit codes into vdict (operators with <= 256 distinct values) or nullptr
+    const T *vdict;               //   the distinct values (bit patterns in increasing order), nvd of them
+    int nvd;
 };
 
 // One dependency-level schedule for an order-exact sweep (forward or backward, or a
@@ -163,6 +166,11 @@ struct pamg_matrix_s {
     unsigned short *d_Aj16 = nullptr; // column ids of the scalar view as 16-bit window codes (csr_stream_kernel reads 2 instead of 4 bytes per entry)
     int4 *d_wbase = nullptr;         //   window bases per row range; both null when some range needs more than four 16 K-column windows
     int use_idx16 = 1;               // tune key 19
+    unsigned char *d_Ax8 = nullptr;  // values of the scalar view as 8-bit codes into d_vdict: operators with <= 256 distinct values (stencils)
+    void *d_vdict = nullptr;         //   stream 1 instead of 8 bytes per value; needs the 16-bit column stream; null otherwise
+    int nvdict = 0;
+    int use_val8 = 1;                // tune key 21
+    int cap_from_val8 = 0;           // cap was raised to 2048 because the operator streams value codes (level schedules keep 1536)
     int use_xwin = 0;                // LDS-staged x windows for the whole-operator kernels (tune key 9)
     void *d_xwin = nullptr;          // XWin[nblk] window plan (device)
     int xw_cap = 0;                  // window budget (values) the plan was built for
@@ -205,6 +213,7 @@ int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void 
 int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const void *b, void *y, double c,
                        double omega, double *partial, hipStream_t s);
 int matrix_split_ranges(pamg_matrix_s *A, int64_t n_owned_cols);
+void matrix_drop_value_codes(pamg_matrix_s *A);
 int gs_sweep(pamg_matrix_s *A, int epi, void *x, const void *b, double omega, int row_start,
              int row_stop, int row_step, hipStream_t s);
 int reduce_partials(const double *partial, int n, double *out, hipStream_t s);

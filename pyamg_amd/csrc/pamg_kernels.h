@@ -124,10 +124,45 @@ __device__ __forceinline__ T gather_x(const StreamArgs<T> &a, int c)
     }
 }
 
+// ---- phase 1 with 16-bit column codes AND 8-bit value codes (operators with at most 256 distinct values: stencils).
+// 3 instead of 12 bytes of operator stream per entry: the kernel is no longer bound by the stream but by the gather --
+// so the lanes of a wave take CONSECUTIVE entries (one 2-byte and one 1-byte load per entry, each a single cache line per
+// wave) and a gather instruction covers 64 consecutive entries = ~9 rows of a stencil = one or two lines of x per band,
+// instead of the 3-5 lines per band of the several-entries-per-lane layouts.  NCH independent chains per lane in flight.
+// The value is looked up in the LDS copy of the dictionary: the very same bits the 8-byte stream would have delivered.
+template <typename T, bool NEEDC, int COH, int NCH>
+__device__ __forceinline__ void stage_val8(const StreamArgs<T> &a, int p0, int p1, int base, T *prod, int *cols, const T *vd)
+{
+    const int4 wb = a.wb;
+    for (int p = p0 + (int)threadIdx.x; p < p1; p += NCH * BLK) {
+        int pk[NCH];
+        unsigned c[NCH], v[NCH];
+        int cc[NCH];
+        T xv[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) pk[j] = (p + j * BLK < p1) ? p + j * BLK : p;      // out of range: repeat a valid entry
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) { c[j] = a.Aj16[pk[j]]; v[j] = a.Ax8[pk[j]]; }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const unsigned w = c[j] >> 14;
+            cc[j] = (w == 0 ? wb.x : w == 1 ? wb.y : w == 2 ? wb.z : wb.w) + (int)(c[j] & 0x3FFFu);
+            xv[j] = gather_x<COH>(a, cc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            if (j == 0 || p + j * BLK < p1) {
+                prod[pk[j] - base] = vd[v[j]] * xv[j];
+                if constexpr (NEEDC) cols[pk[j] - base] = cc[j];
+            }
+        }
+    }
+}
+
 // ---- phase 1: stage products (and column ids) of entries [p0,p1) into LDS slots [p-base]
 template <typename T, bool NEEDC, int NPL, int COH = 0, bool DIAGF = false>
 __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, int p1, int base,
-                                               T *prod, int *cols)
+                                               T *prod, int *cols, const T *vd = nullptr)
 {
     const int tid = threadIdx.x;
     if constexpr (NPL == 1) {
@@ -195,6 +230,58 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
             // 16-bit column stream: every column of this row range lies in one of (up to) four windows of 16 K columns;
             // an entry stores window << 14 | offset.  Two bytes less per entry on the operator stream, same arithmetic.
             const int4 wb = a.wb;
+            if (vd) {
+                if (a.flags & 16) { stage_val8<T, NEEDC, COH, 6>(a, p0, p1, base, prod, cols, vd); return; }
+                // four consecutive entries per lane and step (8 + 4 bytes of operator stream for them), TWO steps in flight:
+                // with 3 bytes per entry the kernel is bound by its dependent round trips (codes -> gather), so the codes of
+                // both steps are requested before the first gather.  base is a multiple of 4 here.
+                for (int q = base + 4 * tid; q < p1; q += 8 * BLK) {
+                    const int q2 = q + 4 * BLK;
+                    const bool two = q2 < p1;
+                    const int qb = two ? q2 : q;
+                    const uint2 cwa = *reinterpret_cast<const uint2 *>(a.Aj16 + q);
+                    const unsigned vca = *reinterpret_cast<const unsigned *>(a.Ax8 + q);
+                    const uint2 cwb = *reinterpret_cast<const uint2 *>(a.Aj16 + qb);
+                    const unsigned vcb = *reinterpret_cast<const unsigned *>(a.Ax8 + qb);
+                    const unsigned c[8] = {cwa.x & 0xFFFFu, cwa.x >> 16, cwa.y & 0xFFFFu, cwa.y >> 16,
+                                           cwb.x & 0xFFFFu, cwb.x >> 16, cwb.y & 0xFFFFu, cwb.y >> 16};
+                    int cc[8];
+                    T xv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const unsigned w = c[j] >> 14;
+                        cc[j] = (w == 0 ? wb.x : w == 1 ? wb.y : w == 2 ? wb.z : wb.w) + (int)(c[j] & 0x3FFFu);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int e = (j < 4 ? q : qb) + (j & 3);
+                        const bool ok = (e >= p0) && (e < p1) && (j < 4 || two);
+                        xv[j] = ok ? gather_x<COH>(a, cc[j]) : T(0);
+                    }
+                    T2 o0, o1;
+                    o0.x = vd[vca & 0xFFu] * xv[0]; o0.y = vd[(vca >> 8) & 0xFFu] * xv[1];
+                    o1.x = vd[(vca >> 16) & 0xFFu] * xv[2]; o1.y = vd[vca >> 24] * xv[3];
+                    *reinterpret_cast<T2 *>(prod + (q - base)) = o0;
+                    *reinterpret_cast<T2 *>(prod + (q - base) + 2) = o1;
+                    if constexpr (NEEDC) {
+                        int4 cm;
+                        cm.x = cc[0]; cm.y = cc[1]; cm.z = cc[2]; cm.w = cc[3];
+                        *reinterpret_cast<int4 *>(cols + (q - base)) = cm;
+                    }
+                    if (two) {
+                        o0.x = vd[vcb & 0xFFu] * xv[4]; o0.y = vd[(vcb >> 8) & 0xFFu] * xv[5];
+                        o1.x = vd[(vcb >> 16) & 0xFFu] * xv[6]; o1.y = vd[vcb >> 24] * xv[7];
+                        *reinterpret_cast<T2 *>(prod + (q2 - base)) = o0;
+                        *reinterpret_cast<T2 *>(prod + (q2 - base) + 2) = o1;
+                        if constexpr (NEEDC) {
+                            int4 cm;
+                            cm.x = cc[4]; cm.y = cc[5]; cm.z = cc[6]; cm.w = cc[7];
+                            *reinterpret_cast<int4 *>(cols + (q2 - base)) = cm;
+                        }
+                    }
+                }
+                return;
+            }
 #pragma unroll 2
             for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
                 const unsigned pr2 = *reinterpret_cast<const unsigned *>(a.Aj16 + q);
@@ -424,16 +511,30 @@ __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 
 {
     constexpr bool NEEDC = EpiTraits<EPI>::need_cols;
     const int cap = a.cap;
+    // slots per LDS array: the window + the alignment slack below the first entry + the row phase's batch over-read
+    const int slots = cap + ((NPL == 2 && COH == 0 && a.Ax8) ? 16 : 8);
     T *prod = reinterpret_cast<T *>(smem_raw);
-    int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(cap + 8));
+    int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)slots);
     const int tid = threadIdx.x;
     const int r0 = meta.x, r1 = meta.y, p0 = meta.z, p1 = meta.w;
+    const T *vd = nullptr;
+    int amask = (NPL == 4) ? ~3 : (NPL == 2) ? ~1 : ~0;
+    if constexpr (NPL == 2 && COH == 0) {
+        if (a.Ax8) {
+            // value dictionary -> LDS (behind the products and column ids); read after the barrier below
+            T *d = reinterpret_cast<T *>(smem_raw + ((sizeof(T) * (size_t)slots + (NEEDC ? sizeof(int) * (size_t)slots : 0) + 15) & ~(size_t)15));
+            if (tid < a.nvd) d[tid] = a.vdict[tid];
+            vd = d;
+            amask = (a.flags & 16) ? ~0 : ~3;
+        }
+    }
     if (p1 - p0 <= cap) {
-        const int base = (NPL == 4) ? (p0 & ~3) : (NPL == 2) ? (p0 & ~1) : p0;
+        const int base = p0 & amask;
         int r = r0 + tid;
         RowPre<T> q;
         if (r < r1) q = row_prefetch<T, EPI, COH>(a, r);
-        stage_products<T, NEEDC, NPL, COH, EpiTraits<EPI>::diag_flag>(a, p0, p1, base, prod, cols);
+        if (vd) __syncthreads();
+        stage_products<T, NEEDC, NPL, COH, EpiTraits<EPI>::diag_flag>(a, p0, p1, base, prod, cols, vd);
         __syncthreads();
         if (a.flags & 8) {                                // ablation: no row phase
             if (tid == 0) a.y[r0] = prod[0];
@@ -453,9 +554,9 @@ __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 
         T s = row_init<T, EPI>(q);
         for (int c0 = p0; c0 < p1; c0 += cap) {
             const int c1 = min(c0 + cap, p1);
-            const int base = (NPL == 4) ? (c0 & ~3) : (NPL == 2) ? (c0 & ~1) : c0;
+            const int base = c0 & amask;
             __syncthreads();
-            stage_products<T, NEEDC, NPL, COH, EpiTraits<EPI>::diag_flag>(a, c0, c1, base, prod, cols);
+            stage_products<T, NEEDC, NPL, COH, EpiTraits<EPI>::diag_flag>(a, c0, c1, base, prod, cols, vd);
             __syncthreads();
             if (tid == 0) row_accumulate<T, EPI>(s, prod, cols, c0 - base, c1 - base, q.row);
         }

@@ -63,6 +63,13 @@ int lds_bytes(int dtype, int epi, int cap)
     return per * (cap + 8) + 64;      // + slack: the row phase reads whole batches of 8 slots
 }
 
+// extra LDS of the 8-bit value-code path: 8 more slots per array (entries are staged in groups of eight) + the dictionary
+int val8_lds(const pamg_matrix_s *A, int epi)
+{
+    const int per = (int)tsize(A->dtype) + ((epi == EPI_JACOBI || epi == EPI_JACOBI_B || epi == EPI_JACOBI_IDX) ? 4 : 0);
+    return 8 * per + 16 + (int)tsize(A->dtype) * ((A->nvdict + 1) & ~1);
+}
+
 template <typename T, int EPI>
 int launch_epi(int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a)
 {
@@ -186,6 +193,85 @@ int plan_idx16(pamg_matrix_s *A, const std::vector<int4> &blk)
     PAMG_TRY(upload_raw((void **)&A->d_Aj16, code.data(), code.size(), sizeof(unsigned short), &bytes));
     PAMG_TRY(upload_raw((void **)&A->d_wbase, wb.data(), wb.size(), sizeof(int4), &bytes));
     return PAMG_OK;
+}
+
+// 8-bit value codes for the whole-operator kernels: an operator with at most 256 distinct values (bit patterns: +0 and
+// -0, NaN payloads stay apart) -- the stencils of the gallery: 2 values -- streams one byte per value instead of eight;
+// the kernel looks the value up in an LDS copy of the dictionary, so the product is formed from the very same bits.
+// vals: the scalar view's values on the host, in storage order.  Independent of the row-range plan.
+template <typename U>
+static int plan_val8_t(pamg_matrix_s *A, const U *v)
+{
+    const int64_t n = A->nnz;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(64u, hw), n / (1 << 20)));
+    std::vector<std::vector<U>> sets((size_t)nt);
+    std::atomic<int> over(0);
+    auto scan = [&](int t) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        std::vector<U> &d = sets[(size_t)t];
+        U last = 0;
+        bool have = false;
+        for (int64_t p = lo; p < hi; ++p) {
+            const U x = v[p];
+            if (have && x == last) continue;
+            last = x; have = true;
+            auto it = std::lower_bound(d.begin(), d.end(), x);
+            if (it != d.end() && *it == x) continue;
+            if (d.size() == 256) { over = 1; return; }
+            d.insert(it, x);
+            if ((p & 0xFFFF) == 0 && over.load(std::memory_order_relaxed)) return;
+        }
+    };
+    if (nt == 1) scan(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(scan, t);
+        for (auto &x : th) x.join();
+    }
+    if (over.load()) return PAMG_OK;
+    std::vector<U> dict;
+    for (auto &d : sets) dict.insert(dict.end(), d.begin(), d.end());
+    std::sort(dict.begin(), dict.end());
+    dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
+    if (dict.size() > 256 || dict.empty()) return PAMG_OK;
+    std::vector<unsigned char> code((size_t)n + 16, 0);
+    host_parallel(n, [&](int64_t lo, int64_t hi) {
+        U last = 0;
+        unsigned char lc = 0;
+        bool have = false;
+        for (int64_t p = lo; p < hi; ++p) {
+            const U x = v[p];
+            if (!have || x != last) {
+                last = x; have = true;
+                lc = (unsigned char)(std::lower_bound(dict.begin(), dict.end(), x) - dict.begin());
+            }
+            code[(size_t)p] = lc;
+        }
+    }, 1 << 20);
+    A->nvdict = (int)dict.size();
+    dict.resize(256, 0);
+    size_t bytes = 0;
+    PAMG_TRY(upload_raw((void **)&A->d_Ax8, code.data(), code.size(), 1, &bytes));
+    PAMG_TRY(upload_raw(&A->d_vdict, dict.data(), dict.size(), sizeof(U), &bytes));
+    A->bytes += bytes;
+    return PAMG_OK;
+}
+
+void drop_val8(pamg_matrix_s *A)
+{
+    if (A->d_Ax8) { hipFree(A->d_Ax8); A->d_Ax8 = nullptr; }
+    if (A->d_vdict) { hipFree(A->d_vdict); A->d_vdict = nullptr; }
+    A->nvdict = 0;
+}
+
+int plan_val8(pamg_matrix_s *A, const void *vals)
+{
+    PhaseTimer pt_("plan_val8", A->nnz);
+    drop_val8(A);
+    if (!vals || A->nnz < (1 << 16) || A->d_rowid) return PAMG_OK;      // small operators: nothing to gain
+    if (A->dtype == PAMG_F64) return plan_val8_t<uint64_t>(A, (const uint64_t *)vals);
+    return plan_val8_t<uint32_t>(A, (const uint32_t *)vals);
 }
 
 int replan(pamg_matrix_s *A)
@@ -438,7 +524,7 @@ int build_level_part(pamg_matrix_s *A, GsSchedule *g)
             g->level_blk.push_back((int)blk.size());
         }
     };
-    int gcap = A->gs_cap > 0 ? A->gs_cap : A->cap;
+    int gcap = A->gs_cap > 0 ? A->gs_cap : (A->cap_from_val8 ? 1536 : A->cap);
     plan(gcap);
     if (A->gs_cap == 0 && (A->gs_mode == 0 || A->gs_mode == 2) && gcap > 512 && A->npl == 2) {
         // Where this schedule will run as the multi-XCD granular sweep (neither narrow enough for one workgroup nor small
@@ -703,6 +789,9 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.wbase = nullptr;
     a.wb = make_int4(0, 0, 0, 0);
     a.blkmap = nullptr;
+    a.Ax8 = nullptr;             // set by stream_launch only, with the 16-bit column stream
+    a.vdict = nullptr;
+    a.nvd = 0;
     return a;
 }
 
@@ -712,6 +801,9 @@ int g_scratch_dev = -1;
 }  // namespace
 
 namespace pamg {
+
+// the operator's values are about to change in place (setup kernels rescale a resident operator): its value codes go
+void matrix_drop_value_codes(pamg_matrix_s *A) { if (A) drop_val8(A); }
 
 // Row ranges of a row shard in local numbering [owned | halo] cut in two: INTERIOR ranges touch owned columns only
 // (they can run while the halo is still in flight), BOUNDARY ranges read at least one halo column.  Two index lists
@@ -761,22 +853,23 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
     if (part) {
         const int n = A->npart[part - 1];
         if (n == 0) return PAMG_OK;
-        const int lds = lds_bytes(A->dtype, epi, A->cap);
         const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2 && !(A->stream_flags & 4);
+        const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
+        const int lds = lds_bytes(A->dtype, epi, A->cap) + (val8 ? val8_lds(A, epi) : 0);
         if (A->dtype == PAMG_F64) {
             StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
             a.flags = A->stream_flags & ~2;
             a.nblk = n; a.blkmap = A->d_part[part - 1];
-            if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; }
+            if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
             return launch_any<double>(epi, A->npl, n, lds, s, a);
         }
         StreamArgs<float> a = base_args<float>(A, x, b, y, c, omega, partial);
         a.flags = A->stream_flags & ~2;
         a.nblk = n; a.blkmap = A->d_part[part - 1];
-        if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; }
+        if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
         return launch_any<float>(epi, A->npl, n, lds, s, a);
     }
-    const int lds = lds_bytes(A->dtype, epi, A->cap);
+    int lds = lds_bytes(A->dtype, epi, A->cap);
     if (A->use_xwin && A->d_xwin && A->npl == 2 && epi < EPI_GS) {
         const int per = (int)tsize(A->dtype) + ((epi == EPI_JACOBI || epi == EPI_JACOBI_B) ? 4 : 0);
         const int ldsx = per * (A->cap + 8) + (int)tsize(A->dtype) * (A->xw_cap + 8) + 64;
@@ -787,15 +880,17 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
     }
     const int grid = (A->stream_flags & 2) ? 8 * ((A->nblk + 7) / 8) : A->nblk;
     const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2 && !(A->stream_flags & 4);
+    const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
+    if (val8) lds += val8_lds(A, epi);
     if (A->dtype == PAMG_F64) {
         StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
         a.flags = A->stream_flags;
-        if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; }
+        if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
         return launch_any<double>(epi, A->npl, grid, lds, s, a);
     }
     StreamArgs<float> a = base_args<float>(A, x, b, y, c, omega, partial);
     a.flags = A->stream_flags;
-    if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; }
+    if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
     return launch_any<float>(epi, A->npl, grid, lds, s, a);
 }
 
@@ -1593,6 +1688,7 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
         st = upload(&A->d_Ap, A->h_Ap.data(), A->h_Ap.size(), &A->bytes);
         if (!st) st = upload(&A->d_Aj, A->h_Aj.data(), A->h_Aj.size(), &A->bytes);
         if (!st) st = upload_raw(&A->d_Ax, Ax, (size_t)nblk, ts, &A->bytes);
+        if (!st) st = plan_val8(A, Ax);
         if (!st) {
             // diagonal of every row, found exactly like the reference finds it (last stored
             // entry with j == i wins, 0 when absent: relaxation.h:64-74); carried separately so
@@ -1628,6 +1724,7 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
         st = upload(&A->d_Ap, A->h_Ap.data(), A->h_Ap.size(), &A->bytes);
         if (!st) st = upload(&A->d_Aj, A->h_Aj.data(), A->h_Aj.size(), &A->bytes);
         if (!st) st = upload_raw(&A->d_Ax, flat.data(), (size_t)A->nnz, ts, &A->bytes);
+        if (!st) st = plan_val8(A, flat.data());
         if (R == C && !st) {
             // square blocks: keep the block view too (point / block smoothers)
             A->h_bAp.assign(Ap, Ap + n_brow + 1);
@@ -1659,6 +1756,10 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
     // default plan (measured best on 256^3 Poisson): 1536 staged entries = 12 KB (SpMV) / 18 KB
     // (smoothers, with column ids) of LDS per workgroup -> 8 workgroups = 32 waves per CU
     A->cap = 1536; A->npl = 2; A->max_rows = 1024;
+    // with 8-bit value codes the whole-operator kernels stage four entries per lane in two steps that are in flight
+    // together: 2048 entries fill both (measured on the 256^3 stencil: 0.242 ms against 0.262 with 1536); the level
+    // schedules of the order-exact sweeps keep 1536
+    if (A->d_Ax8 && R == 1 && C == 1) { A->cap = 2048; A->cap_from_val8 = 1; }
     if (!st) st = replan(A);
     if (st) { pamg_matrix_destroy(A); return st; }
     *out = A;
@@ -1669,7 +1770,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
 {
     if (!A) return PAMG_OK;
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag); hipFree(A->d_rowid);
-    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta); hipFree(A->d_Aj16); hipFree(A->d_wbase);
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta); hipFree(A->d_Aj16); hipFree(A->d_wbase); hipFree(A->d_Ax8); hipFree(A->d_vdict);
     hipFree(A->d_part[0]); hipFree(A->d_part[1]);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     for (int k = 0; k < 4; ++k) pamg::free_line_schedule(A->ls[k]);
@@ -1693,20 +1794,28 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8])
     return PAMG_OK;
 }
 
+int pamg_matrix_value_codes(pamg_matrix_t A, int *n_values)
+{
+    if (!A || !n_values) return PAMG_E_ARG;
+    *n_values = (A->d_Ax8 && A->use_val8 && A->use_idx16 && A->d_Aj16 && A->npl == 2) ? A->nvdict : 0;
+    return PAMG_OK;
+}
+
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
 {
     if (!A) return PAMG_E_ARG;
     // a finalised solver's captured graphs point into the schedules and plans this call would free
+    if (key == 21) { A->use_val8 = value != 0; return PAMG_OK; }      // read at launch time only: no plan depends on it
     if (A->borrowed > 0) return PAMG_E_STATE;
     switch (key) {
-        case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~3; break;
+        case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~3; A->cap_from_val8 = 0; break;
         case 1: if (value != 1 && value != 2 && value != 4) return PAMG_E_ARG; A->npl = value; break;
         case 2: if (value < 1) return PAMG_E_ARG; A->max_rows = value; break;
         case 3: if (value < 0 || value > 256) return PAMG_E_ARG; A->flow_cap = value; return PAMG_OK;
         case 5: if (value < 0 || value > 5) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
         case 6: if (value < 0) return PAMG_E_ARG; A->gran_cap = value; return PAMG_OK;
         case 7: if (value < 0 || value > 2) return PAMG_E_ARG; A->gran_xcd = value; return PAMG_OK;
-        case 8: if (value < 0 || value > 15) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;
+        case 8: if (value < 0 || value > 63) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;
         case 9: A->use_xwin = value != 0; break;
         case 11: A->gs_prof = value != 0; return PAMG_OK;
         case 12: if (value < 0) return PAMG_E_ARG; A->tile_G = value; break;

@@ -1252,6 +1252,7 @@ int pamg_matrix_scale_rows(pamg_matrix_t A, const double *d)
     PAMG_HIP(hipMalloc((void **)&dd, sizeof(double) * ((size_t)m + 1)));
     int st = (int)hipMemcpy(dd, d, sizeof(double) * (size_t)m, hipMemcpyHostToDevice);
     if (!st && m) {
+        matrix_drop_value_codes(A);
         hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(m)), dim3(BLK), 0, 0, m, A->d_Ap, (double *)A->d_Ax, (double *)A->d_diag, dd);
         st = (int)hipGetLastError();
     }
@@ -1267,6 +1268,7 @@ int pamg_matrix_scale_values(pamg_matrix_t A, double alpha)
     if (A->borrowed) return PAMG_E_STATE;
     for (int k = 0; k < 4; ++k) if (A->gs[k] || A->ls[k]) return PAMG_E_STATE;
     drop_block_view(A);
+    matrix_drop_value_codes(A);
     if (A->nnz) hipLaunchKernelGGL(scale_values_kernel, dim3(grid_for(A->nnz)), dim3(BLK), 0, 0, A->nnz, alpha, (double *)A->d_Ax);
     if (A->nrows && A->d_diag) hipLaunchKernelGGL(scale_values_kernel, dim3(grid_for(A->nrows)), dim3(BLK), 0, 0, A->nrows, alpha, (double *)A->d_diag);
     PAMG_HIP(hipGetLastError());

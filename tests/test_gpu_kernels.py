@@ -732,6 +732,58 @@ def test_pybind11_module_runs_the_same_kernels(kernels_npz):
     assert np.array_equal(xa, xr)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_8bit_value_codes_are_bit_identical(dtype):
+    """Operators with at most 256 distinct values (the gallery's stencils: 2) stream one byte per value and look the
+    value up in an LDS dictionary (tune key 21 switches back to the values themselves): same bits either way -- on the
+    7-point stencil, with exactly 256 and with 257 distinct values (no codes), with +0 / -0 / explicit zeros as
+    separate dictionary entries, with one row longer than the LDS window, and on a BSR(1,1) operator."""
+    import scipy.sparse as sp
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(8)
+    P3 = poisson_csr((48, 48, 48))
+    nn = 30000
+
+    def banded(values):
+        cols = (np.arange(nn)[:, None] + np.array([-40, -1, 0, 1, 40])[None, :]) % nn
+        data = rng.choice(np.asarray(values, dtype=np.float64), size=cols.size)
+        A = sp.csr_array((data, cols.ravel().astype(np.int32), np.arange(0, cols.size + 1, 5, dtype=np.int32)), shape=(nn, nn))
+        return A
+    v256 = np.concatenate([[0.0, -0.0], rng.randn(254)])
+    A256, A257 = banded(v256), banded(np.concatenate([v256, [7.25]]))
+    A257.data[:257] = np.concatenate([v256, [7.25]])            # all 257 present for sure
+    A256.data[:256] = v256
+    long_row = banded([1.0, -2.0, 0.5]).tolil()
+    long_row[17, :6000] = rng.choice([3.0, -1.5], size=6000)
+    long_row = long_row.tocsr()
+    cases = [(P3, 2), (A256, 256), (A257, 0), (long_row, 5), (sp.bsr_array(poisson_csr((300, 300)), blocksize=(1, 1)), 2)]
+    for A, expect in cases:
+        A = A.astype(dtype)
+        n = A.shape[0]
+        x, b = rng.rand(n).astype(dtype), rng.rand(n).astype(dtype)
+        dA = DeviceMatrix(sparse_op(A))
+        assert dA.value_codes() == expect
+        dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
+        out = {}
+        for flag in (1, 0):
+            dA.tune(val8=flag)
+            assert dA.value_codes() == (expect if flag else 0)
+            dy = capi.DeviceArray(n, dtype)
+            dA.spmv(capi.SPMV_RESID, dx, dy, b=db)
+            dz = capi.DeviceArray(n, dtype)
+            dA.spmv(capi.SPMV_SET, dx, dz)
+            dj = capi.DeviceArray.from_host(x)
+            dw = capi.DeviceArray(n, dtype)
+            dA.jacobi(dj, db, dw, 0.8, iterations=2)
+            out[flag] = (dy.download(), dz.download(), dj.download())
+        for k in range(3):
+            assert np.array_equal(out[0][k], out[1][k], equal_nan=True)
+        if dtype == np.float64:
+            assert np.array_equal(out[1][1], sp.csr_array(A) @ x)
+        dA.free()
+
+
 def test_16bit_column_stream_is_bit_identical():
     """The whole-operator kernels read the columns as 16-bit window codes where every row range fits four windows of
     16 K columns (tune key 19 switches back to 32-bit columns): same bits either way, on a banded stencil (three

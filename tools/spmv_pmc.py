@@ -34,6 +34,13 @@ for a in sys.argv[1:]:
         idx16 = int(a.split("=", 1)[1])
 if idx16 is not None:
     dA.tune(idx16=idx16)
+opt = {k: int(v) for k, v in (a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a) if k in ("val8", "flags", "cap")}
+if "cap" in opt:
+    dA.tune(lds_entries=opt["cap"])
+if "flags" in opt:
+    dA.tune(stream_flags=opt["flags"])
+if "val8" in opt:
+    dA.tune(val8=opt["val8"])
 for _ in range(launches):
     dA.spmv(capi.SPMV_RESID, x, r, b=b)
 capi.sync()
@@ -45,4 +52,4 @@ e1.record()
 e1.synchronize()
 ms = e0.elapsed_ms(e1) / launches
 by = 12 * A.nnz + 4 * (n + 1) + 24 * n
-print("ok", n, A.nnz, launches, f"idx16={idx16} resid {ms:.4f} ms  {by / ms / 1e6:.1f} GB/s algorithmic ({100 * by / ms / 1e6 / 8000:.1f} % of 8 TB/s)")
+print("ok", n, A.nnz, launches, f"idx16={idx16} {opt} codes={dA.value_codes()} resid {ms:.4f} ms  {by / ms / 1e6:.1f} GB/s algorithmic ({100 * by / ms / 1e6 / 8000:.1f} % of 8 TB/s)")
