@@ -443,6 +443,11 @@ int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, v
 #define PAMG_SMOOTH_CF_BLOCK_JACOBI 12   /* relaxation.cf_block_jacobi  relaxation.py:1271-1340: C block rows, then F */
 #define PAMG_SMOOTH_FC_BLOCK_JACOBI 13   /* relaxation.fc_block_jacobi  relaxation.py:1342-1411: F block rows, then C */
 #define PAMG_SMOOTH_SCHWARZ    14   /* relaxation.schwarz  relaxation.py:157-262 (also what strength_based_schwarz runs) */
+#define PAMG_SMOOTH_KRYLOV     15   /* a Krylov method as smoother  smoothing.py:794-830 (pamg_solver_set_krylov_smoother) */
+#define PAMG_KRYLOV_CG    0         /* krylov/_cg.py   */
+#define PAMG_KRYLOV_GMRES 1         /* krylov/_gmres_householder.py (the reference's default orthogonalisation) */
+#define PAMG_KRYLOV_CGNE  2         /* krylov/_cgne.py */
+#define PAMG_KRYLOV_CGNR  3         /* krylov/_cgnr.py */
 #define PAMG_CYCLE_V 0
 #define PAMG_CYCLE_W 1
 #define PAMG_CYCLE_F 2
@@ -495,6 +500,13 @@ int pamg_solver_set_schwarz_smoother(pamg_solver_t S, int level, int which, int 
  * with the CSC matrix, i.e. per row in ascending column order; NULL = the level's own A already is sorted. */
 int pamg_solver_set_ne_smoother(pamg_solver_t S, int level, int which, int kind, int iterations, double omega,
                                 int sweep, const void *Dinv, pamg_matrix_t At, pamg_matrix_t Ar);
+/* A Krylov method as pre- / post-smoother of a level (smoothing.py:794-830: x[:] = cg | gmres | cgne | cgnr (A, b, x0 = x, tol,
+ * maxiter[, restart])[0], M = None), and -- set as smoother 0 of the LAST level followed by pamg_solver_set_coarse_relax -- as
+ * coarse solver (multilevel.py:752-762: from x = 0).  maxiter = 0 / restart = 0: the method's own default (None in the
+ * reference).  At (cgne / cgnr; borrowed, kept alive by the caller): the CSR form of A^H.  The methods' stopping rules read
+ * scalars back on the host, so a solver with such a smoother runs its cycles without hipGraph capture. */
+int pamg_solver_set_krylov_smoother(pamg_solver_t S, int level, int which, int method, double tol, int maxiter, int restart,
+                                    pamg_matrix_t At);
 /* coarsest solve x_c = M b_c with HOST row-major M (n_c x n_c); M == NULL: x_c = 0
  * (multilevel.py:717-721, 801-803) */
 int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c);

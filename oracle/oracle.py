@@ -412,6 +412,186 @@ def relax_jacobi_ne(A, x, b, Dinv, iterations=1, omega=1.0):
         jacobi_ne(A.indptr, A.indices, A.data, x, delta, temp, 0, n, 1, om)
 
 
+# ----------------------------------------------------------------- Krylov methods as smoothers / coarse solvers
+def _vnorm(v):
+    """util/linalg.py:13-52 norm(): sqrt of the inner product"""
+    v = np.ravel(v)
+    return np.sqrt(np.inner(v.conj(), v)).real
+
+
+def krylov_cg(A, b, x, tol, maxiter):
+    """krylov/_cg.py:87-200 with M = identity (z IS r), criteria 'rr'; x is updated in place and returned"""
+    if not maxiter:
+        maxiter = int(1.3 * len(b)) + 2
+    r = b - matvec(A, x)
+    p = r.copy()
+    rz = np.inner(r, r)
+    normb = _vnorm(b)
+    if normb == 0.0:
+        normb = 1.0
+    if np.linalg.norm(r) < tol * normb:
+        return x
+    it = 0
+    while True:
+        Ap = matvec(A, p)
+        rz_old = rz
+        pAp = np.inner(Ap, p)
+        if pAp < 0.0:
+            return x
+        alpha = rz / pAp
+        x += alpha * p
+        if it % 8 and it > 0:
+            r -= alpha * Ap
+        else:
+            r = b - matvec(A, x)
+        rz = np.inner(r, r)
+        if rz < 0.0:
+            return x
+        p *= rz / rz_old
+        p += r
+        it += 1
+        if np.linalg.norm(r) < tol * normb or it == maxiter:
+            return x
+
+
+def krylov_cgn(A, At, b, x, tol, maxiter, nr):
+    """krylov/_cgne.py:96-210 (nr = False) and krylov/_cgnr.py:96-212 (nr = True), M = identity, criteria 'rr'"""
+    n = len(b)
+    if not maxiter or maxiter > 1.3 * n:
+        maxiter = int(np.ceil(1.3 * n)) + 2
+    r = b - matvec(A, x)
+    if nr:
+        rhat = matvec(At, r)
+        p = rhat.copy()
+        old_zr = np.inner(rhat, rhat)
+    else:
+        p = matvec(At, r)
+        old_zr = np.inner(r, r)
+    normb = _vnorm(b)
+    if normb == 0.0:
+        normb = 1.0
+    if _vnorm(r) < tol * normb:
+        return x
+    it = 0
+    while True:
+        if nr:
+            w = matvec(A, p)
+            alpha = old_zr / np.inner(w, w)
+        else:
+            alpha = old_zr / np.inner(p, p)
+        x += alpha * p
+        if it % 8 and it > 0:
+            r -= alpha * (w if nr else matvec(A, p))
+        else:
+            r = b - matvec(A, x)
+        if nr:
+            rhat = matvec(At, r)
+            new_zr = np.inner(rhat, rhat)
+        else:
+            new_zr = np.inner(r, r)
+        beta = new_zr / old_zr
+        old_zr = new_zr
+        p *= beta
+        p += rhat if nr else matvec(At, r)
+        it += 1
+        if np.linalg.norm(r) < tol * normb or it == maxiter:
+            return x
+
+
+def krylov_gmres(A, b, x, tol, maxiter, restart):
+    """krylov/_gmres_householder.py:120-330 with M = identity: Householder reflectors, Givens rotations on the leading
+    entries, Horner-scheme update.  NumPy dot products where the reference runs sequential C loops (krylov.h:37-130), so
+    this restatement is pinned to the reference to 1e-12, not bit for bit."""
+    n = len(b)
+    if n < 2:
+        raise NotImplementedError("n == 1 is special-cased by the reference")
+    if restart:
+        max_outer, max_inner = (maxiter if maxiter else 1), min(restart, n)
+    else:
+        max_outer, max_inner = 1, (min(maxiter, n) if maxiter else min(n, 40))
+    m = max_inner
+    sign = lambda t: 1.0 if t == 0.0 else t / abs(t)     # noqa: E731
+    r = b - matvec(A, x)
+    normr = _vnorm(r)
+    normb = _vnorm(b)
+    if normb == 0.0:
+        normb = 1.0
+    if normr < tol * normb:
+        return x
+    for _ in range(max_outer):
+        H = np.zeros((m, m))
+        g = np.zeros(m + 1)
+        Q = []
+        W = np.zeros((m, n))
+        w = r.copy()
+        beta = sign(w[0]) * normr
+        w[0] += beta
+        w /= _vnorm(w)
+        W[0] = w
+        g[0] = -beta
+        inner = 0
+        for inner in range(m):
+            v = -2.0 * W[inner][inner] * W[inner]
+            v[inner] += 1.0
+            for j in range(inner - 1, -1, -1):
+                v -= 2.0 * np.dot(W[j], v) * W[j]
+            v = matvec(A, v)
+            for j in range(inner + 1):
+                v -= 2.0 * np.dot(W[j], v) * W[j]
+            if inner != n - 1:
+                alpha = _vnorm(v[inner + 1:])
+                if alpha != 0.0:
+                    alpha = sign(v[inner + 1]) * alpha
+                    if inner < m - 1:
+                        wn = np.zeros(n)
+                        wn[inner + 1:] = v[inner + 1:]
+                        wn[inner + 1] += alpha
+                        wn /= _vnorm(wn)
+                        W[inner + 1] = wn
+                    v[inner + 1] = -alpha
+                    v[inner + 2:] = 0.0
+            lead = min(inner + 2, n)
+            hv = np.zeros(m + 2)
+            hv[:lead] = v[:lead]
+            for k, (c, sn) in enumerate(Q):
+                t = hv[k]
+                hv[k] = c * t + sn * hv[k + 1]
+                hv[k + 1] = -sn * t + c * hv[k + 1]
+            if inner != n - 1 and hv[inner + 1] != 0.0:
+                f, gg = hv[inner], hv[inner + 1]
+                if f == 0.0:
+                    c, sn = 0.0, 1.0
+                else:
+                    rr = np.copysign(np.hypot(f, gg), f)
+                    c, sn = f / rr, gg / rr
+                Q.append((c, sn))
+                g[inner], g[inner + 1] = c * g[inner] + sn * g[inner + 1], -sn * g[inner] + c * g[inner + 1]
+                hv[inner], hv[inner + 1] = c * f + sn * gg, 0.0
+            H[:, inner] = hv[:m]
+            if inner < m - 1:
+                normr = abs(g[inner + 1])
+                if normr < tol * normb:
+                    break
+        k = min(inner + 1, m)
+        y = np.zeros(k)
+        for i in range(k - 1, -1, -1):
+            y[i] = (g[i] - np.dot(H[i, i + 1:k], y[i + 1:k])) / H[i, i]
+        u = np.zeros(n)
+        for j in range(k - 1, -1, -1):
+            u[j] += y[j]
+            u -= 2.0 * np.dot(W[j], u) * W[j]
+        x += u
+        r = b - matvec(A, x)
+        normr = _vnorm(r)
+        mx = np.abs(x)
+        ok = mx != 0.0
+        if ok.any() and np.max(np.abs(u[ok]) / mx[ok]) < 1e-12:
+            return x
+        if normr < tol * normb:
+            return x
+    return x
+
+
 def apply_smoother(s, A, x, b):
     """Dispatch a SmootherSpec exactly as the reference's bound callable would run."""
     if s is None or s.kind == "none":
@@ -443,6 +623,12 @@ def apply_smoother(s, A, x, b):
     elif s.kind in ("cf_block_jacobi", "fc_block_jacobi"):
         relax_cf_block_jacobi(A, x, b, s.Cpts, s.Fpts, s.Dinv, s.blocksize, s.iterations, s.f_iterations, s.c_iterations,
                               s.omega, f_first=(s.kind == "fc_block_jacobi"))
+    elif s.kind == "cg":
+        x[:] = krylov_cg(A, b, x.copy(), s.tol, s.iterations)
+    elif s.kind in ("cgne", "cgnr"):
+        x[:] = krylov_cgn(A, s.At, b, x.copy(), s.tol, s.iterations, s.kind == "cgnr")
+    elif s.kind == "gmres":
+        x[:] = krylov_gmres(A, b, x.copy(), s.tol, s.iterations, s.restart)
     else:
         raise ValueError(f"oracle: unknown smoother kind {s.kind}")
 

@@ -23,6 +23,7 @@ SPMV_SET, SPMV_ACC, SPMV_RESID, SPMV_AXPBY, SPMV_ACC_AXPBY = 0, 1, 2, 3, 4
 FORWARD, BACKWARD, SYMMETRIC = 0, 1, 2
 SMOOTH = {"schwarz": 14, "cf_block_jacobi": 12, "fc_block_jacobi": 13, "gauss_seidel_ne": 9, "gauss_seidel_nr": 10, "jacobi_ne": 11, "cf_jacobi": 7, "fc_jacobi": 8, "none": 0, "jacobi": 1, "gauss_seidel": 2, "sor": 3, "polynomial": 4,
           "block_jacobi": 5, "block_gauss_seidel": 6}
+KRYLOV = {"cg": 0, "gmres": 1, "cgne": 2, "cgnr": 3}
 SWEEP = {"forward": FORWARD, "backward": BACKWARD, "symmetric": SYMMETRIC}
 CYCLE = {"V": 0, "W": 1, "F": 2, "AMLI": 3}
 
@@ -150,6 +151,7 @@ def _declare(lib):
     f("pamg_solver_add_level", _vp, _vp, _vp, _vp)
     f("pamg_solver_set_smoother", _vp, _i, _i, _i, _i, _d, _i, _vp, _i, _vp, _i)
     f("pamg_solver_set_ne_smoother", _vp, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp)
+    f("pamg_solver_set_krylov_smoother", _vp, _i, _i, _i, _d, _i, _i, _vp)
     f("pamg_solver_set_cf_smoother", _vp, _i, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i)
     f("pamg_solver_set_coarse_dense", _vp, _vp, _i)
     f("pamg_solver_set_coarse_relax", _vp)

@@ -7,6 +7,7 @@
 // which removes the host launch cost of the many tiny coarse-level / GS-level kernels.
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <map>
 #include <new>
 #include <thread>
@@ -35,6 +36,10 @@ struct Smoother {
     pamg_schwarz_s *sw = nullptr;     // Schwarz: subdomains + inverted blocks + schedules (owned)
     // normal-equation smoothers: d_Dinv holds 1/||row||^2 or 1/||col||^2; At is borrowed (see the header)
     pamg_matrix_s *At = nullptr, *Ar = nullptr;
+    // Krylov methods as smoothers (smoothing.py:794-830): x[:] = method(A, b, x0=x, tol, maxiter, [restart])[0]; At (borrowed) = A^H for cgne / cgnr
+    int kmethod = 0, kmaxiter = 1, krestart = 0;
+    double ktol = 1e-12;
+    void *kw = nullptr;               // 4 n work values
 };
 
 struct Level {
@@ -180,11 +185,14 @@ struct pamg_solver_s {
     int tail_from = -1;           // levels tail_from .. coarsest run as ONE launch (cycle_tail_kernel); -1: none
     TailOp *d_tail = nullptr;     // its recorded operations
     int n_tail = 0;
+    bool host_sync = false;       // a Krylov smoother / coarse solver reads scalars back inside the cycle: no graph capture
     int fallbacks = 0;            // times a persistent sweep timed out and the solver switched to per-level launches
     size_t bytes = 0;
 };
 
 namespace {
+
+int krylov_smooth(pamg_solver_s *S, Level &L, const Smoother &sm, hipStream_t s);
 
 int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, hipStream_t s)
 {
@@ -245,6 +253,7 @@ int apply_smoother(pamg_solver_s *S, Level &L, const Smoother &sm, bool x_zero, 
                 }
             }
             return PAMG_OK;
+        case PAMG_SMOOTH_KRYLOV: return krylov_smooth(S, L, sm, s);
         case PAMG_SMOOTH_SCHWARZ: {
             // relaxation.py:240-262: forward / backward sweeps over the subdomains; symmetric = forward then backward per iteration
             int nsub = 0;
@@ -522,7 +531,7 @@ int enqueue_cycle(pamg_solver_s *S, int type, int cpl, bool check, bool x_zero, 
 
 int run_cycle(pamg_solver_s *S, int type, int cpl, hipStream_t s, bool check = true, bool x_zero = false)
 {
-    if (!S->use_graph) return enqueue_cycle(S, type, cpl, check, x_zero, s);
+    if (!S->use_graph || S->host_sync) return enqueue_cycle(S, type, cpl, check, x_zero, s);
     const int key = ((type * 1024 + cpl) * 2 + (check ? 1 : 0)) * 2 + (x_zero ? 1 : 0);
     auto it = S->graphs.find(key);
     if (it == S->graphs.end()) {
@@ -632,6 +641,396 @@ void drop_graphs(pamg_solver_s *S)
     S->graphs.clear();
 }
 
+
+// ------------------------------------------------------------------------------------------ Krylov cores
+// CG exactly as the reference's krylov/_cg.py:87-200 runs it under criteria='rr': residual recomputed every 8th step,
+// curvature checks, stopping rule ||r|| < tol ||b||.  precond = nullptr: M = identity (z IS r, as in the reference where
+// the identity operator hands its argument back).  r / z / p / q: n-vectors of work.
+int cg_core(pamg_solver_s *S, pamg_matrix_s *Aop, int64_t n, const std::function<int(const void *, void *)> *precond, void *r, void *z,
+            void *p, void *q, void *x, const void *b, double tol, int maxiter, double *residuals, int *n_iter, int *info, hipStream_t s)
+{
+    const int dt = S->dtype;
+    const size_t vb = (size_t)n * tsize(dt);
+    if (maxiter <= 0) maxiter = (int)(1.3 * (double)n) + 2;                                // _cg.py:93-94
+    if (!precond) z = r;
+    double *slot = S->d_slot;                    // [0] cycle's norm slot (unused here), [1..3] scalars
+    double h[3];
+    auto fetch = [&](int k) -> int {             // h[0..k) <- slot[1..1+k)
+        PAMG_HIP(hipMemcpyAsync(h, slot + 1, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
+        return (int)hipStreamSynchronize(s);
+    };
+    // setup (_cg.py:98-112)
+    PAMG_TRY(stream_launch(Aop, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));              // r = b - A x
+    if (precond) PAMG_TRY((*precond)(r, z));
+    PAMG_HIP(hipMemcpyAsync(p, z, vb, hipMemcpyDeviceToDevice, s));
+    PAMG_TRY(vec_dot(dt, n, r, z, S->d_scratch, slot + 1, s));                           // rz
+    PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 2, s));                            // ||r||^2
+    PAMG_TRY(vec_sumsq(dt, n, b, S->d_scratch, slot + 3, s));                            // ||b||^2
+    PAMG_TRY(fetch(3));
+    double rz = h[0], normr = std::sqrt(h[1]), normb = std::sqrt(h[2]);
+    if (normb == 0.0) normb = 1.0;
+    if (residuals) residuals[0] = normr;
+    const double rtol = tol * normb;
+    int it = 0, inf = -2;
+    if (normr < rtol) inf = 0;
+    while (inf == -2) {
+        PAMG_TRY(stream_launch(Aop, EPI_SET, p, nullptr, q, 0.0, 0.0, nullptr, s));      // Ap
+        PAMG_TRY(vec_dot(dt, n, q, p, S->d_scratch, slot + 1, s));                       // pAp
+        PAMG_TRY(fetch(1));
+        const double pAp = h[0];
+        if (pAp < 0.0) { inf = -1; break; }                                              // indefinite A
+        const double rz_old = rz, alpha = rz / pAp;
+        PAMG_TRY(vec_axpy(dt, n, alpha, p, x, s));                                       // x += alpha p
+        if ((it % 8) != 0 && it > 0) PAMG_TRY(vec_axpy(dt, n, -alpha, q, r, s));        // r -= alpha Ap
+        else PAMG_TRY(stream_launch(Aop, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));     // r = b - A x (every 8th)
+        if (precond) PAMG_TRY((*precond)(r, z));
+        PAMG_TRY(vec_dot(dt, n, r, z, S->d_scratch, slot + 1, s));
+        PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 2, s));
+        PAMG_TRY(fetch(2));
+        rz = h[0];
+        if (rz < 0.0) { inf = -1; break; }                                               // indefinite M
+        PAMG_TRY(vec_xpby(dt, n, rz / rz_old, z, p, s));                                 // p = beta p + z
+        ++it;
+        normr = std::sqrt(h[1]);
+        if (residuals) residuals[it] = normr;
+        if (normr < rtol) inf = 0;
+        else if (it == maxiter) inf = it;
+    }
+    if (n_iter) *n_iter = it;
+    if (info) *info = inf;
+    return PAMG_OK;
+}
+
+// CGNE (krylov/_cgne.py:96-210) and CGNR (krylov/_cgnr.py:96-212), M = identity, criteria 'rr'.  At = A^H as an operator of its
+// own (the reference applies A.H through SciPy's CSC product: the same per-output summation order as the CSR rows of A^T).
+// r, p, w (and rhat for CGNR): n-vectors of work.
+int cgn_core(pamg_solver_s *S, bool nr, pamg_matrix_s *Aop, pamg_matrix_s *At, int64_t n, void *r, void *rhat, void *p, void *w, void *x,
+             const void *b, double tol, int maxiter, int *n_iter, int *info, hipStream_t s)
+{
+    const int dt = S->dtype;
+    const size_t vb = (size_t)n * tsize(dt);
+    if (maxiter <= 0 || (double)maxiter > 1.3 * (double)n) maxiter = (int)std::ceil(1.3 * (double)n) + 2;      // :108-115
+    double *slot = S->d_slot;
+    double h[3];
+    auto fetch = [&](int k) -> int {
+        PAMG_HIP(hipMemcpyAsync(h, slot + 1, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
+        return (int)hipStreamSynchronize(s);
+    };
+    PAMG_TRY(stream_launch(Aop, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));              // r = b - A x
+    if (nr) {
+        PAMG_TRY(stream_launch(At, EPI_SET, r, nullptr, rhat, 0.0, 0.0, nullptr, s));    // rhat = A^H r; z = rhat; p = z
+        PAMG_HIP(hipMemcpyAsync(p, rhat, vb, hipMemcpyDeviceToDevice, s));
+        PAMG_TRY(vec_sumsq(dt, n, rhat, S->d_scratch, slot + 1, s));                     // (z, rhat)
+    } else {
+        PAMG_TRY(stream_launch(At, EPI_SET, r, nullptr, p, 0.0, 0.0, nullptr, s));       // z = r; p = A^H z
+        PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 1, s));                        // (z, r)
+    }
+    PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 2, s));
+    PAMG_TRY(vec_sumsq(dt, n, b, S->d_scratch, slot + 3, s));
+    PAMG_TRY(fetch(3));
+    double old_zr = h[0], normr = std::sqrt(h[1]), normb = std::sqrt(h[2]);
+    if (normb == 0.0) normb = 1.0;
+    const double rtol = tol * normb;
+    int it = 0, inf = -2;
+    if (normr < rtol) inf = 0;
+    while (inf == -2) {
+        double alpha;
+        if (nr) {
+            PAMG_TRY(stream_launch(Aop, EPI_SET, p, nullptr, w, 0.0, 0.0, nullptr, s));  // w = A p
+            PAMG_TRY(vec_sumsq(dt, n, w, S->d_scratch, slot + 1, s));
+        } else {
+            PAMG_TRY(vec_sumsq(dt, n, p, S->d_scratch, slot + 1, s));
+        }
+        PAMG_TRY(fetch(1));
+        alpha = old_zr / h[0];
+        PAMG_TRY(vec_axpy(dt, n, alpha, p, x, s));                                       // x += alpha p
+        if ((it % 8) != 0 && it > 0) {
+            if (!nr) PAMG_TRY(stream_launch(Aop, EPI_SET, p, nullptr, w, 0.0, 0.0, nullptr, s));
+            PAMG_TRY(vec_axpy(dt, n, -alpha, w, r, s));                                  // r -= alpha A p
+        } else {
+            PAMG_TRY(stream_launch(Aop, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));
+        }
+        if (nr) {
+            PAMG_TRY(stream_launch(At, EPI_SET, r, nullptr, rhat, 0.0, 0.0, nullptr, s));
+            PAMG_TRY(vec_sumsq(dt, n, rhat, S->d_scratch, slot + 1, s));
+        } else {
+            PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 1, s));
+        }
+        PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 2, s));
+        PAMG_TRY(fetch(2));
+        const double new_zr = h[0], beta = new_zr / old_zr;
+        old_zr = new_zr;
+        if (nr) {
+            PAMG_TRY(vec_xpby(dt, n, beta, rhat, p, s));                                 // p = beta p + z
+        } else {
+            PAMG_TRY(stream_launch(At, EPI_SET, r, nullptr, w, 0.0, 0.0, nullptr, s));   // p = beta p + A^H z
+            PAMG_TRY(vec_xpby(dt, n, beta, w, p, s));
+        }
+        ++it;
+        normr = std::sqrt(h[1]);
+        if (normr < rtol) inf = 0;
+        else if (it == maxiter) inf = it;
+    }
+    if (n_iter) *n_iter = it;
+    if (info) *info = inf;
+    return PAMG_OK;
+}
+
+// Flexible GMRES with the resident cycle as (right) preconditioner, all vectors on the device: a
+// faithful restatement of the reference's krylov/_fgmres.py:120-345 as driven by
+// MultilevelSolver.solve(accel='fgmres') (multilevel.py:479-535) -- Householder reflectors
+// (amg_core::apply_householders, krylov.h:37-56), Givens rotations on the leading entries
+// (apply_givens, krylov.h:158-183), the same stopping rules, residual history and return codes.  The
+// Householder form is kept on purpose: its basis vectors differ from Gram-Schmidt ones by signs, which a
+// linear preconditioner cannot see but the AMLI cycle (inner Krylov steps from a guess of ones) can.
+// Only the n-vectors live on the device; the leading <= restart+1 entries the rotations work on are read
+// back per iteration.
+// flexible = true: FGMRES (right preconditioning, the preconditioned vectors Z are kept);
+// flexible = false: the reference's default GMRES, krylov/_gmres_householder.py:120-330 (LEFT
+// preconditioning: every norm is a preconditioned-residual norm, tolerance relative to ||M b||; the update
+// is mapped back through the reflectors by amg_core::householder_hornerscheme, krylov.h:106-130).
+// Aop / n: the operator the method runs on (level 0 for the accelerators, any level for a Krylov smoother or coarse solver);
+// cycle < 0: no preconditioner (M = identity), else the resident cycle of the whole hierarchy.
+int krylov_householder(pamg_solver_s *S, pamg_matrix_s *Aop, int64_t n, bool flexible, void *x, const void *b, double tol, int maxiter,
+                       int restart, int cycle, int cycles_per_level, double *residuals, int residuals_cap, int *n_res,
+                       int *n_iter, int *info, hipStream_t s)
+{
+    Level &L0 = S->levels[0];
+    if (n < 2) return PAMG_E_UNSUPPORTED;              // the reference special-cases n == 1 on the host
+    const int dt = S->dtype;
+    const size_t ts = tsize(dt);
+    const size_t vb = (size_t)n * ts;
+    // iteration limits exactly as _fgmres.py:139-160
+    int max_outer, max_inner;
+    if (restart > 0) {
+        max_outer = maxiter > 0 ? maxiter : 1;
+        max_inner = (int)std::min<int64_t>(restart, n);
+    } else {
+        max_outer = 1;
+        max_inner = maxiter > 0 ? (int)std::min<int64_t>(maxiter, n) : (int)std::min<int64_t>(n, 40);
+    }
+    const int m = max_inner;
+    int nres = 0, inf = 0, nit = 0;
+    auto push = [&](double v) { if (residuals && nres < residuals_cap) residuals[nres] = v; ++nres; };
+    std::vector<void *> W((size_t)m, nullptr), Z((size_t)m, nullptr);
+    void *v = nullptr, *u = nullptr, *r = nullptr;
+    auto release = [&]() {
+        for (void *p : W) if (p) hipFree(p);
+        for (void *p : Z) if (p) hipFree(p);
+        if (v) hipFree(v);
+        if (u) hipFree(u);
+        if (r) hipFree(r);
+    };
+    auto grab = [&](void **p) -> int { return *p ? PAMG_OK : (int)hipMalloc(p, vb + 64); };
+    int st = grab(&v);
+    if (!st) st = grab(&u);
+    if (!st) st = grab(&r);
+    if (!st) st = grab(&W[0]);
+    if (st) { release(); return st; }
+    double *slot = S->d_slot;
+    double h1[2];
+    std::vector<unsigned char> hbuf((size_t)(m + 2) * ts);
+    auto fetch = [&](int k) -> int {
+        PAMG_HIP(hipMemcpyAsync(h1, slot + 1, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
+        return (int)hipStreamSynchronize(s);
+    };
+    auto at = [&](void *p, int64_t idx) -> void * { return (unsigned char *)p + (size_t)idx * ts; };
+    auto get = [&](void *p, int64_t idx, int cnt, double *out) -> int {     // out[0..cnt) = p[idx..idx+cnt)
+        PAMG_HIP(hipMemcpyAsync(hbuf.data(), at(p, idx), (size_t)cnt * ts, hipMemcpyDeviceToHost, s));
+        PAMG_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < cnt; ++k)
+            out[k] = dt == PAMG_F64 ? reinterpret_cast<const double *>(hbuf.data())[k] : (double)reinterpret_cast<const float *>(hbuf.data())[k];
+        return PAMG_OK;
+    };
+    auto put = [&](void *p, int64_t idx, double val) -> int {
+        double vd = val; float vf = (float)val;
+        PAMG_HIP(hipMemcpyAsync(at(p, idx), dt == PAMG_F64 ? (const void *)&vd : (const void *)&vf, ts, hipMemcpyHostToDevice, s));
+        return (int)hipStreamSynchronize(s);                               // the host scalar goes out of scope
+    };
+    auto norm2 = [&](const void *p, int64_t len, double *out) -> int {
+        PAMG_TRY(vec_sumsq(dt, len, p, S->d_scratch, slot + 1, s));
+        PAMG_TRY(fetch(1));
+        *out = std::sqrt(h1[0]);
+        return PAMG_OK;
+    };
+    auto reflect = [&](void *z, const void *wj) -> int {                   // z -= 2 (w_j . z) w_j
+        PAMG_TRY(vec_dot(dt, n, wj, z, S->d_scratch, slot + 1, s));
+        PAMG_TRY(fetch(1));
+        return vec_axpy(dt, n, -2.0 * h1[0], wj, z, s);
+    };
+    auto precond = [&](const void *vin, void *zout) -> int {               // z = M v: one cycle from x = 0
+        if (cycle < 0) return (int)hipMemcpyAsync(zout, vin, vb, hipMemcpyDeviceToDevice, s);
+        PAMG_HIP(hipMemcpyAsync(L0.b, vin, vb, hipMemcpyDeviceToDevice, s));
+        PAMG_HIP(hipMemsetAsync(L0.x, 0, vb, s));
+        PAMG_TRY(run_cycle(S, cycle, cycles_per_level, s, false, true));
+        return (int)hipMemcpyAsync(zout, L0.x, vb, hipMemcpyDeviceToDevice, s);
+    };
+    auto mysign = [](double t) { return t == 0.0 ? 1.0 : t / std::fabs(t); };
+    auto body = [&]() -> int {
+        double normr, normb;
+        auto residual = [&]() -> int {                                                    // r = b - A x  (GMRES: M (b - A x))
+            if (flexible) return stream_launch(Aop, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s);
+            PAMG_TRY(stream_launch(Aop, EPI_RESID, x, b, v, 0.0, 0.0, nullptr, s));
+            return precond(v, r);
+        };
+        PAMG_TRY(residual());
+        PAMG_TRY(norm2(r, n, &normr));
+        PAMG_TRY(norm2(b, n, &normb));
+        push(normr);
+        if (normb == 0.0) normb = 1.0;
+        else if (!flexible) {                                                             // tolerance relative to ||M b||
+            PAMG_TRY(precond(b, v));
+            PAMG_TRY(norm2(v, n, &normb));
+        }
+        if (normr < tol * normb) { inf = 0; return PAMG_OK; }
+        int niter = 0;
+        std::vector<double> H((size_t)m * m), Q((size_t)4 * m), g((size_t)m + 1), y((size_t)m), hv((size_t)m + 2);
+        auto Hx = [&](int i, int j) -> double & { return H[(size_t)j * m + i]; };
+        for (int outer = 0; outer < max_outer; ++outer) {
+            std::fill(H.begin(), H.end(), 0.0);
+            std::fill(g.begin(), g.end(), 0.0);
+            // first reflector from the residual (:184-197)
+            double t, nw;
+            PAMG_HIP(hipMemcpyAsync(W[0], r, vb, hipMemcpyDeviceToDevice, s));
+            PAMG_TRY(get(W[0], 0, 1, &t));
+            const double beta = mysign(t) * normr;
+            PAMG_TRY(put(W[0], 0, t + beta));
+            PAMG_TRY(norm2(W[0], n, &nw));
+            PAMG_TRY(vec_scale(dt, n, 1.0 / nw, W[0], W[0], s));
+            g[0] = -beta;
+            int wi = 0, inner = 0;
+            for (inner = 0; inner < m; ++inner) {
+                void *w = W[wi];
+                // v = e_inner - 2 w[inner] w, then the earlier reflectors in reverse (:209-214)
+                PAMG_TRY(get(w, inner, 1, &t));
+                PAMG_TRY(vec_scale(dt, n, -2.0 * t, w, v, s));
+                PAMG_TRY(get(v, inner, 1, &t));
+                PAMG_TRY(put(v, inner, t + 1.0));
+                for (int j = inner - 1; j >= 0; --j) PAMG_TRY(reflect(v, W[j]));
+                if (flexible) {
+                    PAMG_TRY(grab(&Z[inner]));
+                    PAMG_TRY(precond(v, Z[inner]));                                       // z = M v
+                    PAMG_TRY(stream_launch(Aop, EPI_SET, Z[inner], nullptr, v, 0.0, 0.0, nullptr, s));   // v = A z
+                } else {
+                    PAMG_TRY(stream_launch(Aop, EPI_SET, v, nullptr, u, 0.0, 0.0, nullptr, s));          // v = M (A v)
+                    PAMG_TRY(precond(u, v));
+                }
+                for (int j = 0; j <= inner; ++j) PAMG_TRY(reflect(v, W[j]));
+                if (inner != n - 1) {                                                     // next reflector (:229-246)
+                    if (inner < m - 1) wi = inner + 1;
+                    double alpha;
+                    PAMG_TRY(norm2(at(v, inner + 1), n - inner - 1, &alpha));
+                    if (alpha != 0.0) {
+                        PAMG_TRY(get(v, inner + 1, 1, &t));
+                        alpha = mysign(t) * alpha;
+                        if (inner < m - 1) {
+                            PAMG_TRY(grab(&W[inner + 1]));
+                            void *wn = W[inner + 1];
+                            PAMG_HIP(hipMemsetAsync(wn, 0, (size_t)(inner + 1) * ts, s));
+                            PAMG_HIP(hipMemcpyAsync(at(wn, inner + 1), at(v, inner + 1), (size_t)(n - inner - 1) * ts, hipMemcpyDeviceToDevice, s));
+                            PAMG_TRY(put(wn, inner + 1, t + alpha));
+                            PAMG_TRY(norm2(wn, n, &nw));
+                            PAMG_TRY(vec_scale(dt, n, 1.0 / nw, wn, wn, s));
+                        }
+                        PAMG_TRY(put(v, inner + 1, -alpha));                              // v[inner+2:] = 0 is implied below
+                    }
+                }
+                // the rotations work on the leading entries only (:248-266)
+                const int lead = (int)std::min<int64_t>(inner + 2, n);
+                std::fill(hv.begin(), hv.end(), 0.0);
+                PAMG_TRY(get(v, 0, lead, hv.data()));
+                for (int rot = 0; rot < inner; ++rot) {
+                    const double xt = hv[rot];
+                    hv[rot] = Q[4 * rot] * xt + Q[4 * rot + 1] * hv[rot + 1];
+                    hv[rot + 1] = Q[4 * rot + 2] * xt + Q[4 * rot + 3] * hv[rot + 1];
+                }
+                if (inner != n - 1 && hv[inner + 1] != 0.0) {
+                    const double f = hv[inner], gg = hv[inner + 1];                       // LAPACK lartg
+                    double c, sn;
+                    if (f == 0.0) { c = 0.0; sn = 1.0; }
+                    else { const double rr = std::copysign(std::hypot(f, gg), f); c = f / rr; sn = gg / rr; }
+                    Q[4 * inner] = c; Q[4 * inner + 1] = sn; Q[4 * inner + 2] = -sn; Q[4 * inner + 3] = c;
+                    const double g0 = g[inner], g1 = g[inner + 1];
+                    g[inner] = c * g0 + sn * g1;
+                    g[inner + 1] = -sn * g0 + c * g1;
+                    hv[inner] = c * f + sn * gg;
+                    hv[inner + 1] = 0.0;
+                }
+                for (int i = 0; i < m; ++i) Hx(i, inner) = i < lead ? hv[i] : 0.0;
+                if (!flexible) ++niter;                                                   // GMRES counts before the test
+                if (inner < m - 1) {                                                      // :283-289
+                    normr = std::fabs(g[inner + 1]);
+                    if (normr < tol * normb) break;
+                    push(normr);
+                }
+                if (flexible) ++niter;
+            }
+            const int k = std::min(inner + 1, m);
+            for (int i = k - 1; i >= 0; --i) {                                            // H is upper triangular now
+                double acc = g[i];
+                for (int j = i + 1; j < k; ++j) acc -= Hx(i, j) * y[j];
+                y[i] = acc / Hx(i, i);
+            }
+            if (flexible) {
+                PAMG_TRY(vec_scale(dt, n, y[0], Z[0], u, s));                             // update = Z y
+                for (int j = 1; j < k; ++j) PAMG_TRY(vec_axpy(dt, n, y[j], Z[j], u, s));
+            } else {
+                PAMG_HIP(hipMemsetAsync(u, 0, vb, s));                                    // Horner scheme through the reflectors
+                for (int j = k - 1; j >= 0; --j) {
+                    PAMG_TRY(get(u, j, 1, &t));
+                    PAMG_TRY(put(u, j, t + y[j]));
+                    PAMG_TRY(reflect(u, W[j]));
+                }
+            }
+            PAMG_TRY(vec_axpy(dt, n, 1.0, u, x, s));
+            PAMG_TRY(residual());
+            PAMG_TRY(norm2(r, n, &normr));
+            push(normr);
+            PAMG_TRY(vec_maxratio(dt, n, u, x, S->d_scratch, slot + 1, s));               // stagnation, :316-322
+            PAMG_TRY(fetch(1));
+            nit = niter;
+            if (h1[0] >= 0.0 && h1[0] < 1e-12) { inf = -1; return PAMG_OK; }
+            if (normr < tol * normb) { inf = 0; return PAMG_OK; }
+        }
+        inf = niter;
+        nit = niter;
+        return PAMG_OK;
+    };
+    st = body();
+    hipStreamSynchronize(s);
+    release();
+    if (info) *info = inf;
+    if (n_iter) *n_iter = nit;
+    if (n_res) *n_res = nres;
+    return st;
+}
+
+
+// A Krylov method as smoother / coarse solver (smoothing.py:794-830, multilevel.py:752-762): x[:] = method(A, b, x0 = x, ...)[0].
+// The iteration reads scalars back to the host (the reference's stopping rules are data dependent): such a cycle is not captured.
+int krylov_smooth(pamg_solver_s *S, Level &L, const Smoother &sm, hipStream_t s)
+{
+    const int64_t n = L.n;
+    if (n == 0) return PAMG_OK;
+    const size_t ts = tsize(S->dtype);
+    unsigned char *kw = (unsigned char *)sm.kw;
+    void *w0 = kw, *w1 = kw + (size_t)n * ts, *w2 = kw + 2 * (size_t)n * ts, *w3 = kw + 3 * (size_t)n * ts;
+    int it = 0, inf = 0;
+    switch (sm.kmethod) {
+        case PAMG_KRYLOV_CG:
+            return cg_core(S, L.A, n, nullptr, w0, w0, w1, w2, L.x, L.b, sm.ktol, sm.kmaxiter, nullptr, &it, &inf, s);
+        case PAMG_KRYLOV_CGNE:
+            return cgn_core(S, false, L.A, sm.At, n, w0, w3, w1, w2, L.x, L.b, sm.ktol, sm.kmaxiter, &it, &inf, s);
+        case PAMG_KRYLOV_CGNR:
+            return cgn_core(S, true, L.A, sm.At, n, w0, w3, w1, w2, L.x, L.b, sm.ktol, sm.kmaxiter, &it, &inf, s);
+        case PAMG_KRYLOV_GMRES: {
+            int nres = 0;
+            return krylov_householder(S, L.A, n, false, L.x, L.b, sm.ktol, sm.kmaxiter, sm.krestart, -1, 1, nullptr, 0, &nres, &it, &inf, s);
+        }
+    }
+    return PAMG_E_ARG;
+}
+
 }  // namespace
 
 extern "C" {
@@ -738,7 +1137,7 @@ int pamg_solver_destroy(pamg_solver_t S)
         for (Smoother *sm : {&L.pre, &L.post}) {
             if (sm->AF) pamg_matrix_destroy(sm->AF);
             if (sm->AC) pamg_matrix_destroy(sm->AC);
-            hipFree(sm->wF); hipFree(sm->wC); hipFree(sm->iF); hipFree(sm->iC);
+            hipFree(sm->wF); hipFree(sm->wC); hipFree(sm->iF); hipFree(sm->iC); hipFree(sm->kw);
             if (sm->sw) pamg_schwarz_destroy(sm->sw);
         }
     }
@@ -786,7 +1185,7 @@ int pamg_solver_set_smoother(pamg_solver_t S, int level, int which, int kind, in
     if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
-    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC); hipFree(sm.kw);
     if (sm.sw) pamg_schwarz_destroy(sm.sw);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep; sm.blocksize = blocksize;
@@ -818,7 +1217,7 @@ int pamg_solver_set_cf_smoother(pamg_solver_t S, int level, int which, int kind,
     if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
-    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC); hipFree(sm.kw);
     if (sm.sw) pamg_schwarz_destroy(sm.sw);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega;
@@ -849,7 +1248,7 @@ int pamg_solver_set_cf_block_smoother(pamg_solver_t S, int level, int which, int
     if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
-    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC); hipFree(sm.kw);
     if (sm.sw) pamg_schwarz_destroy(sm.sw);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.blocksize = blocksize;
@@ -884,7 +1283,7 @@ int pamg_solver_set_schwarz_smoother(pamg_solver_t S, int level, int which, int 
     if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
-    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC); hipFree(sm.kw);
     if (sm.sw) pamg_schwarz_destroy(sm.sw);
     sm = Smoother();
     sm.kind = PAMG_SMOOTH_SCHWARZ; sm.iterations = iterations; sm.sweep = sweep;
@@ -911,7 +1310,7 @@ int pamg_solver_set_ne_smoother(pamg_solver_t S, int level, int which, int kind,
     if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
     if (sm.AF) pamg_matrix_destroy(sm.AF);
     if (sm.AC) pamg_matrix_destroy(sm.AC);
-    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC); hipFree(sm.kw);
     if (sm.sw) pamg_schwarz_destroy(sm.sw);
     sm = Smoother();
     sm.kind = kind; sm.iterations = iterations; sm.omega = omega; sm.sweep = sweep;
@@ -921,6 +1320,33 @@ int pamg_solver_set_ne_smoother(pamg_solver_t S, int level, int which, int kind,
     PAMG_HIP(hipMalloc(&sm.d_Dinv, std::max<size_t>(sz, 256)));
     PAMG_HIP(hipMemcpy(sm.d_Dinv, Dinv, sz, hipMemcpyHostToDevice));
     S->bytes += sz;
+    return PAMG_OK;
+}
+
+int pamg_solver_set_krylov_smoother(pamg_solver_t S, int level, int which, int method, double tol, int maxiter, int restart,
+                                    pamg_matrix_t At)
+{
+    if (!S || level < 0 || level >= (int)S->levels.size() || (which != 0 && which != 1)) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    if (method < PAMG_KRYLOV_CG || method > PAMG_KRYLOV_CGNR || maxiter < 0 || restart < 0 || !(tol >= 0.0)) return PAMG_E_ARG;
+    Level &L = S->levels[level];
+    if (method == PAMG_KRYLOV_CGNE || method == PAMG_KRYLOV_CGNR) {
+        if (!At || At->dtype != S->dtype || At->nrows != L.A->ncols || At->ncols != L.A->nrows) return PAMG_E_ARG;
+    }
+    Smoother &sm = which == 0 ? L.pre : L.post;
+    if (sm.d_Dinv) { hipFree(sm.d_Dinv); sm.d_Dinv = nullptr; }
+    if (sm.AF) pamg_matrix_destroy(sm.AF);
+    if (sm.AC) pamg_matrix_destroy(sm.AC);
+    hipFree(sm.wF); hipFree(sm.wC); hipFree(sm.iF); hipFree(sm.iC); hipFree(sm.kw);
+    if (sm.sw) pamg_schwarz_destroy(sm.sw);
+    sm = Smoother();
+    sm.kind = PAMG_SMOOTH_KRYLOV; sm.iterations = 1;
+    sm.kmethod = method; sm.ktol = tol; sm.kmaxiter = maxiter; sm.krestart = restart;
+    sm.At = (method == PAMG_KRYLOV_CGNE || method == PAMG_KRYLOV_CGNR) ? At : nullptr;
+    const size_t sz = 4 * (size_t)L.A->nrows * tsize(S->dtype);
+    PAMG_HIP(hipMalloc(&sm.kw, std::max<size_t>(sz, 256)));
+    S->bytes += sz;
+    S->host_sync = true;
     return PAMG_OK;
 }
 
@@ -1178,84 +1604,24 @@ int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int max
     if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));
     Level &L0 = S->levels[0];
     const int64_t n = L0.n;
-    const int dt = S->dtype;
-    const size_t vb = (size_t)n * tsize(dt);
+    const size_t vb = (size_t)n * tsize(S->dtype);
     if (!S->cg_r) {
         PAMG_TRY(dalloc(S, &S->cg_r, vb)); PAMG_TRY(dalloc(S, &S->cg_z, vb));
         PAMG_TRY(dalloc(S, &S->cg_p, vb)); PAMG_TRY(dalloc(S, &S->cg_q, vb));
     }
-    void *r = S->cg_r, *z = S->cg_z, *p = S->cg_p, *q = S->cg_q;
-    double *slot = S->d_slot;                    // [0] cycle's norm slot (unused here), [1..3] scalars
-    double h[3];
-    auto precond = [&]() -> int {                // z = M r
-        PAMG_HIP(hipMemcpyAsync(L0.b, r, vb, hipMemcpyDeviceToDevice, s));
+    const std::function<int(const void *, void *)> precond = [&](const void *rin, void *zout) -> int {   // z = M r: one cycle from x = 0
+        PAMG_HIP(hipMemcpyAsync(L0.b, rin, vb, hipMemcpyDeviceToDevice, s));
         PAMG_HIP(hipMemsetAsync(L0.x, 0, vb, s));
         PAMG_TRY(run_cycle(S, cycle, cycles_per_level, s, false, true));
-        return (int)hipMemcpyAsync(z, L0.x, vb, hipMemcpyDeviceToDevice, s);
+        return (int)hipMemcpyAsync(zout, L0.x, vb, hipMemcpyDeviceToDevice, s);
     };
-    auto fetch = [&](int k) -> int {             // h[0..k) <- slot[1..1+k)
-        PAMG_HIP(hipMemcpyAsync(h, slot + 1, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
-        return (int)hipStreamSynchronize(s);
-    };
-    // setup (_cg.py:98-112)
-    PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));            // r = b - A x
-    PAMG_TRY(precond());
-    PAMG_HIP(hipMemcpyAsync(p, z, vb, hipMemcpyDeviceToDevice, s));
-    PAMG_TRY(vec_dot(dt, n, r, z, S->d_scratch, slot + 1, s));                           // rz
-    PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 2, s));                            // ||r||^2
-    PAMG_TRY(vec_sumsq(dt, n, b, S->d_scratch, slot + 3, s));                            // ||b||^2
-    PAMG_TRY(fetch(3));
-    double rz = h[0], normr = std::sqrt(h[1]), normb = std::sqrt(h[2]);
-    if (normb == 0.0) normb = 1.0;
-    if (residuals) residuals[0] = normr;
-    const double rtol = tol * normb;
-    int it = 0, inf = -2;
-    if (normr < rtol) inf = 0;
-    while (inf == -2) {
-        PAMG_TRY(stream_launch(L0.A, EPI_SET, p, nullptr, q, 0.0, 0.0, nullptr, s));     // Ap
-        PAMG_TRY(vec_dot(dt, n, q, p, S->d_scratch, slot + 1, s));                       // pAp
-        PAMG_TRY(fetch(1));
-        const double pAp = h[0];
-        if (pAp < 0.0) { inf = -1; break; }                                              // indefinite A
-        const double rz_old = rz, alpha = rz / pAp;
-        PAMG_TRY(vec_axpy(dt, n, alpha, p, x, s));                                       // x += alpha p
-        if ((it % 8) != 0 && it > 0) PAMG_TRY(vec_axpy(dt, n, -alpha, q, r, s));        // r -= alpha Ap
-        else PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s));    // r = b - A x (every 8th)
-        PAMG_TRY(precond());
-        PAMG_TRY(vec_dot(dt, n, r, z, S->d_scratch, slot + 1, s));
-        PAMG_TRY(vec_sumsq(dt, n, r, S->d_scratch, slot + 2, s));
-        PAMG_TRY(fetch(2));
-        rz = h[0];
-        if (rz < 0.0) { inf = -1; break; }                                               // indefinite M
-        PAMG_TRY(vec_xpby(dt, n, rz / rz_old, z, p, s));                                 // p = beta p + z
-        ++it;
-        normr = std::sqrt(h[1]);
-        if (residuals) residuals[it] = normr;
-        if (normr < rtol) inf = 0;
-        else if (it == maxiter) inf = it;
-    }
+    PAMG_TRY(cg_core(S, L0.A, n, &precond, S->cg_r, S->cg_z, S->cg_p, S->cg_q, x, b, tol, maxiter, residuals, n_iter, info, s));
     PAMG_HIP(hipStreamSynchronize(s));
-    if (n_iter) *n_iter = it;
-    if (info) *info = inf;
     return check_sweeps(S);
 }
 
-// Flexible GMRES with the resident cycle as (right) preconditioner, all vectors on the device: a
-// faithful restatement of the reference's krylov/_fgmres.py:120-345 as driven by
-// MultilevelSolver.solve(accel='fgmres') (multilevel.py:479-535) -- Householder reflectors
-// (amg_core::apply_householders, krylov.h:37-56), Givens rotations on the leading entries
-// (apply_givens, krylov.h:158-183), the same stopping rules, residual history and return codes.  The
-// Householder form is kept on purpose: its basis vectors differ from Gram-Schmidt ones by signs, which a
-// linear preconditioner cannot see but the AMLI cycle (inner Krylov steps from a guess of ones) can.
-// Only the n-vectors live on the device; the leading <= restart+1 entries the rotations work on are read
-// back per iteration.
-// flexible = true: FGMRES (right preconditioning, the preconditioned vectors Z are kept);
-// flexible = false: the reference's default GMRES, krylov/_gmres_householder.py:120-330 (LEFT
-// preconditioning: every norm is a preconditioned-residual norm, tolerance relative to ||M b||; the update
-// is mapped back through the reflectors by amg_core::householder_hornerscheme, krylov.h:106-130).
-static int krylov_householder(pamg_solver_t S, bool flexible, void *x, const void *b, double tol, int maxiter, int restart,
-                              int cycle, int cycles_per_level, double *residuals, int residuals_cap, int *n_res,
-                              int *n_iter, int *info, pamg_stream_t s_)
+static int krylov_accel(pamg_solver_t S, bool flexible, void *x, const void *b, double tol, int maxiter, int restart, int cycle,
+                        int cycles_per_level, double *residuals, int residuals_cap, int *n_res, int *n_iter, int *info, pamg_stream_t s_)
 {
     if (!S || !x || !b) return PAMG_E_ARG;
     if (!S->finalized) return PAMG_E_STATE;
@@ -1263,214 +1629,8 @@ static int krylov_householder(pamg_solver_t S, bool flexible, void *x, const voi
     hipStream_t s = s_ ? (hipStream_t)s_ : S->own_stream;
     PAMG_TRY(ensure_amli(S, cycle));
     if (!s_) PAMG_HIP(hipStreamSynchronize(nullptr));
-    Level &L0 = S->levels[0];
-    const int64_t n = L0.n;
-    if (n < 2) return PAMG_E_UNSUPPORTED;              // the reference special-cases n == 1 on the host
-    const int dt = S->dtype;
-    const size_t ts = tsize(dt);
-    const size_t vb = (size_t)n * ts;
-    // iteration limits exactly as _fgmres.py:139-160
-    int max_outer, max_inner;
-    if (restart > 0) {
-        max_outer = maxiter > 0 ? maxiter : 1;
-        max_inner = (int)std::min<int64_t>(restart, n);
-    } else {
-        max_outer = 1;
-        max_inner = maxiter > 0 ? (int)std::min<int64_t>(maxiter, n) : (int)std::min<int64_t>(n, 40);
-    }
-    const int m = max_inner;
-    int nres = 0, inf = 0, nit = 0;
-    auto push = [&](double v) { if (residuals && nres < residuals_cap) residuals[nres] = v; ++nres; };
-    std::vector<void *> W((size_t)m, nullptr), Z((size_t)m, nullptr);
-    void *v = nullptr, *u = nullptr, *r = nullptr;
-    auto release = [&]() {
-        for (void *p : W) if (p) hipFree(p);
-        for (void *p : Z) if (p) hipFree(p);
-        if (v) hipFree(v);
-        if (u) hipFree(u);
-        if (r) hipFree(r);
-    };
-    auto grab = [&](void **p) -> int { return *p ? PAMG_OK : (int)hipMalloc(p, vb + 64); };
-    int st = grab(&v);
-    if (!st) st = grab(&u);
-    if (!st) st = grab(&r);
-    if (!st) st = grab(&W[0]);
-    if (st) { release(); return st; }
-    double *slot = S->d_slot;
-    double h1[2];
-    std::vector<unsigned char> hbuf((size_t)(m + 2) * ts);
-    auto fetch = [&](int k) -> int {
-        PAMG_HIP(hipMemcpyAsync(h1, slot + 1, sizeof(double) * (size_t)k, hipMemcpyDeviceToHost, s));
-        return (int)hipStreamSynchronize(s);
-    };
-    auto at = [&](void *p, int64_t idx) -> void * { return (unsigned char *)p + (size_t)idx * ts; };
-    auto get = [&](void *p, int64_t idx, int cnt, double *out) -> int {     // out[0..cnt) = p[idx..idx+cnt)
-        PAMG_HIP(hipMemcpyAsync(hbuf.data(), at(p, idx), (size_t)cnt * ts, hipMemcpyDeviceToHost, s));
-        PAMG_HIP(hipStreamSynchronize(s));
-        for (int k = 0; k < cnt; ++k)
-            out[k] = dt == PAMG_F64 ? reinterpret_cast<const double *>(hbuf.data())[k] : (double)reinterpret_cast<const float *>(hbuf.data())[k];
-        return PAMG_OK;
-    };
-    auto put = [&](void *p, int64_t idx, double val) -> int {
-        double vd = val; float vf = (float)val;
-        PAMG_HIP(hipMemcpyAsync(at(p, idx), dt == PAMG_F64 ? (const void *)&vd : (const void *)&vf, ts, hipMemcpyHostToDevice, s));
-        return (int)hipStreamSynchronize(s);                               // the host scalar goes out of scope
-    };
-    auto norm2 = [&](const void *p, int64_t len, double *out) -> int {
-        PAMG_TRY(vec_sumsq(dt, len, p, S->d_scratch, slot + 1, s));
-        PAMG_TRY(fetch(1));
-        *out = std::sqrt(h1[0]);
-        return PAMG_OK;
-    };
-    auto reflect = [&](void *z, const void *wj) -> int {                   // z -= 2 (w_j . z) w_j
-        PAMG_TRY(vec_dot(dt, n, wj, z, S->d_scratch, slot + 1, s));
-        PAMG_TRY(fetch(1));
-        return vec_axpy(dt, n, -2.0 * h1[0], wj, z, s);
-    };
-    auto precond = [&](const void *vin, void *zout) -> int {               // z = M v: one cycle from x = 0
-        PAMG_HIP(hipMemcpyAsync(L0.b, vin, vb, hipMemcpyDeviceToDevice, s));
-        PAMG_HIP(hipMemsetAsync(L0.x, 0, vb, s));
-        PAMG_TRY(run_cycle(S, cycle, cycles_per_level, s, false, true));
-        return (int)hipMemcpyAsync(zout, L0.x, vb, hipMemcpyDeviceToDevice, s);
-    };
-    auto mysign = [](double t) { return t == 0.0 ? 1.0 : t / std::fabs(t); };
-    auto body = [&]() -> int {
-        double normr, normb;
-        auto residual = [&]() -> int {                                                    // r = b - A x  (GMRES: M (b - A x))
-            if (flexible) return stream_launch(L0.A, EPI_RESID, x, b, r, 0.0, 0.0, nullptr, s);
-            PAMG_TRY(stream_launch(L0.A, EPI_RESID, x, b, v, 0.0, 0.0, nullptr, s));
-            return precond(v, r);
-        };
-        PAMG_TRY(residual());
-        PAMG_TRY(norm2(r, n, &normr));
-        PAMG_TRY(norm2(b, n, &normb));
-        push(normr);
-        if (normb == 0.0) normb = 1.0;
-        else if (!flexible) {                                                             // tolerance relative to ||M b||
-            PAMG_TRY(precond(b, v));
-            PAMG_TRY(norm2(v, n, &normb));
-        }
-        if (normr < tol * normb) { inf = 0; return PAMG_OK; }
-        int niter = 0;
-        std::vector<double> H((size_t)m * m), Q((size_t)4 * m), g((size_t)m + 1), y((size_t)m), hv((size_t)m + 2);
-        auto Hx = [&](int i, int j) -> double & { return H[(size_t)j * m + i]; };
-        for (int outer = 0; outer < max_outer; ++outer) {
-            std::fill(H.begin(), H.end(), 0.0);
-            std::fill(g.begin(), g.end(), 0.0);
-            // first reflector from the residual (:184-197)
-            double t, nw;
-            PAMG_HIP(hipMemcpyAsync(W[0], r, vb, hipMemcpyDeviceToDevice, s));
-            PAMG_TRY(get(W[0], 0, 1, &t));
-            const double beta = mysign(t) * normr;
-            PAMG_TRY(put(W[0], 0, t + beta));
-            PAMG_TRY(norm2(W[0], n, &nw));
-            PAMG_TRY(vec_scale(dt, n, 1.0 / nw, W[0], W[0], s));
-            g[0] = -beta;
-            int wi = 0, inner = 0;
-            for (inner = 0; inner < m; ++inner) {
-                void *w = W[wi];
-                // v = e_inner - 2 w[inner] w, then the earlier reflectors in reverse (:209-214)
-                PAMG_TRY(get(w, inner, 1, &t));
-                PAMG_TRY(vec_scale(dt, n, -2.0 * t, w, v, s));
-                PAMG_TRY(get(v, inner, 1, &t));
-                PAMG_TRY(put(v, inner, t + 1.0));
-                for (int j = inner - 1; j >= 0; --j) PAMG_TRY(reflect(v, W[j]));
-                if (flexible) {
-                    PAMG_TRY(grab(&Z[inner]));
-                    PAMG_TRY(precond(v, Z[inner]));                                       // z = M v
-                    PAMG_TRY(stream_launch(L0.A, EPI_SET, Z[inner], nullptr, v, 0.0, 0.0, nullptr, s));   // v = A z
-                } else {
-                    PAMG_TRY(stream_launch(L0.A, EPI_SET, v, nullptr, u, 0.0, 0.0, nullptr, s));          // v = M (A v)
-                    PAMG_TRY(precond(u, v));
-                }
-                for (int j = 0; j <= inner; ++j) PAMG_TRY(reflect(v, W[j]));
-                if (inner != n - 1) {                                                     // next reflector (:229-246)
-                    if (inner < m - 1) wi = inner + 1;
-                    double alpha;
-                    PAMG_TRY(norm2(at(v, inner + 1), n - inner - 1, &alpha));
-                    if (alpha != 0.0) {
-                        PAMG_TRY(get(v, inner + 1, 1, &t));
-                        alpha = mysign(t) * alpha;
-                        if (inner < m - 1) {
-                            PAMG_TRY(grab(&W[inner + 1]));
-                            void *wn = W[inner + 1];
-                            PAMG_HIP(hipMemsetAsync(wn, 0, (size_t)(inner + 1) * ts, s));
-                            PAMG_HIP(hipMemcpyAsync(at(wn, inner + 1), at(v, inner + 1), (size_t)(n - inner - 1) * ts, hipMemcpyDeviceToDevice, s));
-                            PAMG_TRY(put(wn, inner + 1, t + alpha));
-                            PAMG_TRY(norm2(wn, n, &nw));
-                            PAMG_TRY(vec_scale(dt, n, 1.0 / nw, wn, wn, s));
-                        }
-                        PAMG_TRY(put(v, inner + 1, -alpha));                              // v[inner+2:] = 0 is implied below
-                    }
-                }
-                // the rotations work on the leading entries only (:248-266)
-                const int lead = (int)std::min<int64_t>(inner + 2, n);
-                std::fill(hv.begin(), hv.end(), 0.0);
-                PAMG_TRY(get(v, 0, lead, hv.data()));
-                for (int rot = 0; rot < inner; ++rot) {
-                    const double xt = hv[rot];
-                    hv[rot] = Q[4 * rot] * xt + Q[4 * rot + 1] * hv[rot + 1];
-                    hv[rot + 1] = Q[4 * rot + 2] * xt + Q[4 * rot + 3] * hv[rot + 1];
-                }
-                if (inner != n - 1 && hv[inner + 1] != 0.0) {
-                    const double f = hv[inner], gg = hv[inner + 1];                       // LAPACK lartg
-                    double c, sn;
-                    if (f == 0.0) { c = 0.0; sn = 1.0; }
-                    else { const double rr = std::copysign(std::hypot(f, gg), f); c = f / rr; sn = gg / rr; }
-                    Q[4 * inner] = c; Q[4 * inner + 1] = sn; Q[4 * inner + 2] = -sn; Q[4 * inner + 3] = c;
-                    const double g0 = g[inner], g1 = g[inner + 1];
-                    g[inner] = c * g0 + sn * g1;
-                    g[inner + 1] = -sn * g0 + c * g1;
-                    hv[inner] = c * f + sn * gg;
-                    hv[inner + 1] = 0.0;
-                }
-                for (int i = 0; i < m; ++i) Hx(i, inner) = i < lead ? hv[i] : 0.0;
-                if (!flexible) ++niter;                                                   // GMRES counts before the test
-                if (inner < m - 1) {                                                      // :283-289
-                    normr = std::fabs(g[inner + 1]);
-                    if (normr < tol * normb) break;
-                    push(normr);
-                }
-                if (flexible) ++niter;
-            }
-            const int k = std::min(inner + 1, m);
-            for (int i = k - 1; i >= 0; --i) {                                            // H is upper triangular now
-                double acc = g[i];
-                for (int j = i + 1; j < k; ++j) acc -= Hx(i, j) * y[j];
-                y[i] = acc / Hx(i, i);
-            }
-            if (flexible) {
-                PAMG_TRY(vec_scale(dt, n, y[0], Z[0], u, s));                             // update = Z y
-                for (int j = 1; j < k; ++j) PAMG_TRY(vec_axpy(dt, n, y[j], Z[j], u, s));
-            } else {
-                PAMG_HIP(hipMemsetAsync(u, 0, vb, s));                                    // Horner scheme through the reflectors
-                for (int j = k - 1; j >= 0; --j) {
-                    PAMG_TRY(get(u, j, 1, &t));
-                    PAMG_TRY(put(u, j, t + y[j]));
-                    PAMG_TRY(reflect(u, W[j]));
-                }
-            }
-            PAMG_TRY(vec_axpy(dt, n, 1.0, u, x, s));
-            PAMG_TRY(residual());
-            PAMG_TRY(norm2(r, n, &normr));
-            push(normr);
-            PAMG_TRY(vec_maxratio(dt, n, u, x, S->d_scratch, slot + 1, s));               // stagnation, :316-322
-            PAMG_TRY(fetch(1));
-            nit = niter;
-            if (h1[0] >= 0.0 && h1[0] < 1e-12) { inf = -1; return PAMG_OK; }
-            if (normr < tol * normb) { inf = 0; return PAMG_OK; }
-        }
-        inf = niter;
-        nit = niter;
-        return PAMG_OK;
-    };
-    st = body();
-    hipStreamSynchronize(s);
-    release();
-    if (info) *info = inf;
-    if (n_iter) *n_iter = nit;
-    if (n_res) *n_res = nres;
-    if (st) return st;
+    PAMG_TRY(krylov_householder(S, S->levels[0].A, S->levels[0].n, flexible, x, b, tol, maxiter, restart, cycle, cycles_per_level,
+                                residuals, residuals_cap, n_res, n_iter, info, s));
     return check_sweeps(S);
 }
 
@@ -1478,16 +1638,16 @@ int pamg_solver_fgmres(pamg_solver_t S, void *x, const void *b, double tol, int 
                        int cycles_per_level, double *residuals, int residuals_cap, int *n_res, int *n_iter,
                        int *info, pamg_stream_t s)
 {
-    return krylov_householder(S, true, x, b, tol, maxiter, restart, cycle, cycles_per_level, residuals, residuals_cap,
-                              n_res, n_iter, info, s);
+    return krylov_accel(S, true, x, b, tol, maxiter, restart, cycle, cycles_per_level, residuals, residuals_cap,
+                        n_res, n_iter, info, s);
 }
 
 int pamg_solver_gmres(pamg_solver_t S, void *x, const void *b, double tol, int maxiter, int restart, int cycle,
                       int cycles_per_level, double *residuals, int residuals_cap, int *n_res, int *n_iter,
                       int *info, pamg_stream_t s)
 {
-    return krylov_householder(S, false, x, b, tol, maxiter, restart, cycle, cycles_per_level, residuals, residuals_cap,
-                              n_res, n_iter, info, s);
+    return krylov_accel(S, false, x, b, tol, maxiter, restart, cycle, cycles_per_level, residuals, residuals_cap,
+                        n_res, n_iter, info, s);
 }
 
 int pamg_solver_stats(pamg_solver_t S, int64_t stats[8])

@@ -71,7 +71,9 @@ class SmootherSpec:
 
     kind: 'jacobi' | 'gauss_seidel' | 'sor' | 'polynomial' | 'block_jacobi' |
           'block_gauss_seidel' | 'cf_jacobi' | 'fc_jacobi' | 'gauss_seidel_ne' |
-          'gauss_seidel_nr' | 'jacobi_ne' | 'cf_block_jacobi' | 'fc_block_jacobi' | 'schwarz' | 'none'
+          'gauss_seidel_nr' | 'jacobi_ne' | 'cf_block_jacobi' | 'fc_block_jacobi' | 'schwarz' | 'none' |
+          'cg' | 'gmres' | 'cgne' | 'cgnr' (Krylov methods as smoothers / coarse solvers: iterations = maxiter (0 = the
+          method's default), tol, restart (0 = None), At = A^H for cgne / cgnr)
     """
     kind: str
     iterations: int = 1
@@ -91,6 +93,8 @@ class SmootherSpec:
     subdomain_ptr: Optional[np.ndarray] = None
     inv_subblock: Optional[np.ndarray] = None   # schwarz: inverted diagonal blocks, row-major, one after another
     inv_subblock_ptr: Optional[np.ndarray] = None
+    tol: float = 0.0                            # Krylov smoothers
+    restart: int = 0
 
 
 @dataclass
@@ -225,6 +229,8 @@ def smoother_spec(fn, A) -> SmootherSpec:
         Acsr.sort_indices()
         sub, sptr, inv, iptr = schwarz_parameters(Acsr, cv["subdomain"], cv["subdomain_ptr"], None, None)
         return _schwarz_spec(lvl, A, int(cv["iterations"]), cv["sweep"], sub, sptr, inv, iptr, shown, Acsr=Acsr)
+    if shown in KRYLOV_SMOOTHERS and "tol" in cv and "maxiter" in cv:
+        return _krylov_spec(shown, A, cv.get("tol"), cv.get("maxiter"), cv.get("restart"), cv)
     if shown == "none" and not cv:                                  # smoothing.py setup_none: def none(A, x, b): pass
         return SmootherSpec("none", iterations=0, name="None")
     if shown == "chebyshev" and "coefficients" in cv:
@@ -236,6 +242,31 @@ def smoother_spec(fn, A) -> SmootherSpec:
                             coefficients=np.asarray([cv["omega"]], dtype=np.float64),
                             name="richardson")
     raise NotImplementedError(f"smoother '{shown}' is not on the device path")
+
+
+KRYLOV_SMOOTHERS = ("cg", "gmres", "cgne", "cgnr")
+
+
+def _krylov_spec(method, A, tol, maxiter, restart, other=None) -> SmootherSpec:
+    """cg / gmres / cgne / cgnr as smoother (smoothing.py:794-830) or coarse solver (multilevel.py:752-762).  Only what the
+    device loops restate: no preconditioner, callback or residual list inside the cycle, the default stopping criterion,
+    GMRES with Householder reflectors."""
+    other = other or {}
+    for k in ("M", "callback", "residuals"):
+        if other.get(k) is not None:
+            raise NotImplementedError(f"Krylov smoother '{method}' with {k}= is not on the device path")
+    if other.get("criteria", "rr") != "rr" or other.get("orthog", "householder") != "householder":
+        raise NotImplementedError(f"Krylov smoother '{method}': only criteria='rr' / orthog='householder' are on the device path")
+    if A.dtype.type not in SUPPORTED_DTYPES:
+        raise NotImplementedError(f"Krylov smoother '{method}' on a {A.dtype} level is not on the device path")
+    if maxiter is not None and int(maxiter) < 1:
+        raise ValueError("Number of iterations must be positive")
+    At = None
+    if method in ("cgne", "cgnr"):
+        # the reference applies A.H through SciPy's CSC product: per output the summation order of the sorted CSR rows of A^T
+        At = sparse_op(A.T.conj().tocsr())
+    return SmootherSpec(method, int(maxiter) if maxiter is not None else 0, name=method, tol=float(tol),
+                        restart=int(restart) if restart is not None else 0, At=At)
 
 
 def _schwarz_spec(lvl, A, iterations, sweep, subdomain, subdomain_ptr, inv_subblock, inv_subblock_ptr, name, Acsr=None) -> SmootherSpec:
@@ -327,6 +358,28 @@ def _relaxation_coarse_smoother(ml, cs, A_c):
 
 
 
+_KRYLOV_COARSE = ("cg", "gmres")       # of multilevel.py:752: the two the device Krylov loops restate
+
+
+def _krylov_coarse_smoother(cs, A_c, method):
+    """``coarse_solver='cg' | 'gmres'`` (multilevel.py:752-762): x = fn(A, b, **kwargs)[0] from x0 = None (zeros), with
+    tol = set_tol(A.dtype) (util/params.py:28-31) unless the caller gave one."""
+    call = getattr(type(cs), "__call__", None)
+    cells = dict(zip(getattr(call.__code__, "co_freevars", ()), [c.cell_contents for c in (call.__closure__ or ())]))
+    solve = cells.get("solve")
+    inner = _closure_vars(solve) if solve is not None else {}
+    if "kwargs" not in inner:
+        raise NotImplementedError("coarse solver: cannot read the Krylov method's arguments back")
+    kw = dict(inner["kwargs"])
+    tol = kw.pop("tol", None)
+    if tol is None:
+        tol = (1e3 * np.finfo(np.single).eps) if A_c.dtype.char.lower() == "f" else (1e6 * np.finfo(np.double).eps)
+    maxiter, restart = kw.pop("maxiter", None), kw.pop("restart", None)
+    if kw.pop("x0", None) is not None:
+        raise NotImplementedError("Krylov coarse solver with x0= is not on the device path")
+    return _krylov_spec(method, A_c, tol, maxiter, restart, kw)
+
+
 def _coarse_operator(ml, A_c) -> Tuple[str, Optional[np.ndarray], str]:
     cs = ml.coarse_solver
     name = cs.name() if hasattr(cs, "name") else repr(cs)
@@ -334,9 +387,11 @@ def _coarse_operator(ml, A_c) -> Tuple[str, Optional[np.ndarray], str]:
         return "zero", None, name
     if name.strip("'") in _RELAX_COARSE:
         return "relax", _relaxation_coarse_smoother(ml, cs, A_c), name
+    if name.strip("'") in _KRYLOV_COARSE:
+        return "relax", _krylov_coarse_smoother(cs, A_c, name.strip("'")), name
     if name not in _LINEAR_COARSE:
-        raise NotImplementedError(f"coarse solver {name} is neither a linear direct solver ('pinv', 'lu', 'cholesky', 'splu') "
-                                  "nor a relaxation method; Krylov coarse solvers are not on the device path")
+        raise NotImplementedError(f"coarse solver {name} is neither a linear direct solver ('pinv', 'lu', 'cholesky', 'splu'), "
+                                  "a relaxation method nor 'cg' / 'gmres'; the other Krylov coarse solvers are not on the device path")
     n = A_c.shape[0]
     if n > 4096:
         raise NotImplementedError(f"coarsest level too large for a dense device solve (n={n})")
@@ -432,6 +487,8 @@ def _put_sm(d, key, s: Optional[SmootherSpec]):
     if s.subdomain_ptr is not None:
         d[f"{key}.subdomain"], d[f"{key}.subdomain_ptr"] = s.subdomain, s.subdomain_ptr
         d[f"{key}.inv_subblock"], d[f"{key}.inv_subblock_ptr"] = s.inv_subblock, s.inv_subblock_ptr
+    if s.kind in KRYLOV_SMOOTHERS:
+        d[f"{key}.krylov"] = np.array([s.tol, float(s.restart)], dtype=np.float64)
     if s.Fpts is not None:
         d[f"{key}.Fpts"] = np.asarray(s.Fpts, dtype=np.int32)
         d[f"{key}.Cpts"] = np.asarray(s.Cpts, dtype=np.int32)
@@ -450,6 +507,8 @@ def _get_sm(z, key) -> Optional[SmootherSpec]:
     if f"{key}.subdomain_ptr" in z:
         sm.subdomain, sm.subdomain_ptr = z[f"{key}.subdomain"], z[f"{key}.subdomain_ptr"]
         sm.inv_subblock, sm.inv_subblock_ptr = z[f"{key}.inv_subblock"], z[f"{key}.inv_subblock_ptr"]
+    if f"{key}.krylov" in z:
+        sm.tol, sm.restart = float(z[f"{key}.krylov"][0]), int(z[f"{key}.krylov"][1])
     if f"{key}.Fpts" in z:
         sm.Fpts, sm.Cpts = z[f"{key}.Fpts"], z[f"{key}.Cpts"]
         sm.f_iterations, sm.c_iterations = (int(v) for v in z[f"{key}.fc_iters"])

@@ -188,6 +188,15 @@ def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype, aux):
                                                    Ar.handle if Ar else None),
                    f"pamg_solver_set_ne_smoother({s.kind})")
         return
+    if s.kind in capi.KRYLOV:
+        At = None
+        if s.At is not None:
+            At = DeviceMatrix(s.At)
+            aux.append(At)                      # borrowed by the solver: keep it alive
+        capi.check(lib.pamg_solver_set_krylov_smoother(S, level, which, capi.KRYLOV[s.kind], float(s.tol), int(s.iterations),
+                                                       int(s.restart), At.handle if At else None),
+                   f"pamg_solver_set_krylov_smoother({s.kind})")
+        return
     if s.kind in ("cf_jacobi", "fc_jacobi"):
         F = np.ascontiguousarray(s.Fpts, dtype=np.int32)
         Cp = np.ascontiguousarray(s.Cpts, dtype=np.int32)

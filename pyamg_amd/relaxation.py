@@ -395,11 +395,25 @@ def _block_prep(A, blocksize, Dinv):
     return A, np.ascontiguousarray(Dinv, dtype=A.dtype)
 
 
+def _check_unit_dinv(A, Dinv):
+    """argument checks of the block wrappers for blocksize 1 (relaxation.py:479-484)"""
+    if Dinv is not None:
+        Dinv = np.asarray(Dinv)
+        if Dinv.shape[0] != A.shape[0]:
+            raise ValueError("Dinv and A have incompatible dimensions")
+        if Dinv.ndim != 3 or Dinv.shape[1] != 1 or Dinv.shape[2] != 1:
+            raise ValueError("Dinv and blocksize are incompatible")
+
+
 def block_jacobi(A, x, b, Dinv=None, blocksize=1, iterations=1, omega=1.0):
     """Block Jacobi, in place (reference: relaxation.py:423-499)."""
     A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
     if blocksize == 1:
-        raise NotImplementedError("blocksize 1: use jacobi (the reference's setup does the same, smoothing.py:565-569)")
+        # 1x1 blocks: the point method, like the reference's own smoother setup substitutes it (smoothing.py:565-569).  A
+        # direct call of the reference multiplies by the pseudo-inverse of a_ii where jacobi divides by a_ii: the two
+        # can differ in the last bit per sweep -- the one place where this module is not bit-identical
+        _check_unit_dinv(A, Dinv)
+        return jacobi(A.tocsr(), x, b, iterations=iterations, omega=omega)
     A, Dinv = _block_prep(A, blocksize, Dinv)
     st = _Staged(A, x, b, work=1)
     dD = capi.DeviceArray.from_host(Dinv.reshape(-1))
@@ -412,7 +426,9 @@ def _indexed_block_sweeps(A, x, b, plan, Dinv, blocksize, iterations, omega):
     """Shared body of cf_block_jacobi / fc_block_jacobi: ``plan`` = [(block-row list, sweeps), ...] run ``iterations``
     times, each sweep one amg_core.block_jacobi_indexed (relaxation.h:1129-1199), device-resident."""
     if blocksize == 1:
-        raise NotImplementedError("blocksize 1: use cf_jacobi / fc_jacobi (the reference's setup does the same, smoothing.py:731-734)")
+        # 1x1 blocks: the point methods (smoothing.py:731-734, 768-771); see block_jacobi for the last-bit caveat
+        _check_unit_dinv(A, Dinv)
+        return _indexed_sweeps(A.tocsr(), x, b, plan, iterations, omega)
     A, Dinv = _block_prep(A, blocksize, Dinv)
     nb = A.shape[0] // blocksize
     lists = []
@@ -455,10 +471,12 @@ def fc_block_jacobi(A, x, b, Cpts, Fpts, Dinv=None, blocksize=1, iterations=1, f
 def block_gauss_seidel(A, x, b, iterations=1, sweep="forward", blocksize=1, Dinv=None):
     """Block Gauss-Seidel, in place (reference: relaxation.py:502-582)."""
     A, x, b = make_system(A, x, b, formats=["csr", "bsr"])
-    if blocksize == 1:
-        raise NotImplementedError("blocksize 1: use gauss_seidel (smoothing.py:595-599)")
     if sweep not in ("forward", "backward", "symmetric"):
         raise ValueError('valid sweep directions: "forward", "backward", and "symmetric"')
+    if blocksize == 1:
+        # 1x1 blocks: the point method (smoothing.py:595-599); see block_jacobi for the last-bit caveat
+        _check_unit_dinv(A, Dinv)
+        return gauss_seidel(A.tocsr(), x, b, iterations=iterations, sweep=sweep)
     A, Dinv = _block_prep(A, blocksize, Dinv)
     st = _Staged(A, x, b)
     dD = capi.DeviceArray.from_host(Dinv.reshape(-1))

@@ -136,6 +136,14 @@ def make_hierarchies():
                                                                  coarse_solver=("jacobi", {"iterations": 4})))
     np.random.seed(SEED)
     hier("sa2d_coarse_cheby", pyamg.smoothed_aggregation_solver(A, max_coarse=60, coarse_solver=("chebyshev", {"degree": 4, "iterations": 2})))
+    # Krylov methods as smoothers (smoothing.py:794-830) and as coarse solvers (multilevel.py:752-762)
+    for tag, meth in (("cg", ("cg", {"maxiter": 2})), ("gmres", ("gmres", {"maxiter": 3}))):
+        np.random.seed(SEED)
+        hier(f"sa2d_{tag}", pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother=meth, postsmoother=meth))
+    np.random.seed(SEED)
+    hier("sa2d_coarse_cg", pyamg.smoothed_aggregation_solver(A, max_coarse=60, coarse_solver="cg"))
+    np.random.seed(SEED)
+    hier("sa2d_coarse_gmres", pyamg.smoothed_aggregation_solver(A, max_coarse=60, coarse_solver="gmres"))
     np.random.seed(SEED)
     hier("rs2d_jacobi", pyamg.ruge_stuben_solver(A, max_coarse=10, presmoother=jac, postsmoother=jac))
     np.random.seed(SEED)
@@ -198,6 +206,10 @@ def make_hierarchies():
                      ("jacobine", ("jacobi_ne", {"iterations": 2}))):
         np.random.seed(SEED)
         hier(f"rs2d_nonsym_{tag}", pyamg.ruge_stuben_solver(An, max_coarse=10, presmoother=smo, postsmoother=smo))
+    for tag in ("cgne", "cgnr"):
+        np.random.seed(SEED)
+        hier(f"rs2d_nonsym_{tag}", pyamg.ruge_stuben_solver(An, max_coarse=10, presmoother=(tag, {"maxiter": 2}),
+                                                            postsmoother=(tag, {"maxiter": 2})))
     from pyamg import blackbox
     np.random.seed(SEED)
     hier("bb2d_nonsym_gsnr", blackbox.solver(An, blackbox.solver_configuration(An, verb=False)))

@@ -603,8 +603,22 @@ def test_indexed_block_jacobi_bit_exact():
         assert np.array_equal(y, z[f"{k}.cf_block_jacobi"]), k
     with pytest.raises(ValueError):
         grelax.cf_block_jacobi(M, x.copy(), b, np.array([nb], dtype=np.int32), F, Dinv=Dinv, blocksize=bs)
-    with pytest.raises(NotImplementedError):
-        grelax.cf_block_jacobi(M, x.copy(), b, Cp, F, Dinv=Dinv.reshape(-1, 1, 1)[:nb * bs], blocksize=1)
+    # blocksize 1 = the point method on the scalar rows (what the reference's smoother setup substitutes, smoothing.py:731-734)
+    y1, y2 = x.copy(), x.copy()
+    Cs, Fs = np.arange(0, nb * bs, 2, dtype=np.int32), np.arange(1, nb * bs, 2, dtype=np.int32)
+    grelax.cf_block_jacobi(M, y1, b, Cs, Fs, blocksize=1, iterations=2, omega=0.8)
+    grelax.cf_jacobi(M.tocsr(), y2, b, Cs, Fs, iterations=2, omega=0.8)
+    assert np.array_equal(y1, y2) and not np.array_equal(y1, x)
+    y1, y2 = x.copy(), x.copy()
+    grelax.block_gauss_seidel(M, y1, b, blocksize=1, sweep="symmetric")
+    grelax.gauss_seidel(M.tocsr(), y2, b, sweep="symmetric")
+    assert np.array_equal(y1, y2)
+    y1, y2 = x.copy(), x.copy()
+    grelax.block_jacobi(M, y1, b, blocksize=1, omega=0.7, iterations=2)
+    grelax.jacobi(M.tocsr(), y2, b, omega=0.7, iterations=2)
+    assert np.array_equal(y1, y2)
+    with pytest.raises(ValueError):
+        grelax.block_jacobi(M, x.copy(), b, Dinv=Dinv, blocksize=1)
     with pytest.raises(TypeError):
         gcore.block_jacobi_indexed(Ap, Aj, np.ravel(Ax), x.copy(), b, np.ravel(Dinv), idx.astype(np.int64), np.array([0.7], dtype=Ax.dtype), bs)
 

@@ -143,11 +143,23 @@ def test_extract_reads_back_smoother_parameters():
         assert np.array_equal(L.pre.subdomain, sub) and np.array_equal(L.pre.inv_subblock, inv)
         assert (L.pre.Ar is None) == (lv.A.format == "csr")
     ml3g = pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother=("gmres", {"maxiter": 2}), postsmoother="schwarz")
-    with pytest.raises(NotImplementedError):
-        H.extract(ml3g)
+    # Krylov methods as smoothers (smoothing.py:794-830) and coarse solvers (multilevel.py:752-762): parameters from the closures
+    s3g = H.extract(ml3g)
+    assert s3g.levels[0].pre.kind == "gmres" and s3g.levels[0].pre.iterations == 2 and s3g.levels[0].pre.tol == 1e-12
+    assert s3g.levels[0].pre.restart == 0 and s3g.levels[0].pre.At is None
     ml4 = pyamg.smoothed_aggregation_solver(A, max_coarse=10, coarse_solver="cg")
+    s4 = H.extract(ml4)
+    assert s4.coarse_kind == "relax" and s4.coarse_smoother.kind == "cg" and s4.coarse_smoother.iterations == 0
+    assert s4.coarse_smoother.tol == 1e6 * np.finfo(np.float64).eps
+    ml5 = pyamg.ruge_stuben_solver(A, max_coarse=10, presmoother=("cgnr", {"maxiter": 3, "tol": 1e-9}), postsmoother="cgne")
+    s5 = H.extract(ml5)
+    assert s5.levels[0].pre.kind == "cgnr" and s5.levels[0].pre.iterations == 3 and s5.levels[0].pre.tol == 1e-9
+    At = s5.levels[0].post.At
+    assert s5.levels[0].post.kind == "cgne" and At is not None and np.array_equal(At.indptr, A.T.tocsr().indptr)
     with pytest.raises(NotImplementedError):
-        H.extract(ml4)
+        H.extract(pyamg.smoothed_aggregation_solver(A, max_coarse=10, coarse_solver="bicgstab"))
+    with pytest.raises(NotImplementedError):
+        H.extract(pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother=("cg", {"M": sp.eye_array(900, format="csr")})))
 
 
 def test_extract_new_smoother_kinds_and_roundtrip(tmp_path):
