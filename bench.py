@@ -393,7 +393,7 @@ def main():
                                   "config": {"workload": wls["label"], "key": args.shard_workload}, "error": why}), flush=True)
             os._exit(1)
 
-        budget0 = float(os.environ.get("PAMG_SHARD_TIMEOUT", "2700"))
+        budget0 = float(os.environ.get("PAMG_SHARD_TIMEOUT", "1500"))
         wd0 = threading.Timer(budget0, lambda: fail_line(f"the sharded run did not finish within {budget0:.0f} s"))
         wd0.daemon = True
         wd0.start()

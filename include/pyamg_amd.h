@@ -626,6 +626,9 @@ int pamg_dist_stream(pamg_dist_t D, pamg_stream_t *s);
  * overlapped with interior rows [4] iteration replayed from a hipGraph [5] bytes of vectors [6] values sent per
  * exchange round [7] interior row ranges of the fine-level shard */
 int pamg_dist_info(pamg_dist_t D, int64_t info[8]);
+/* Transport self-test (after pamg_dist_finalize): level `level`'s owned values are set from the HOST array x_owned, one halo
+ * exchange runs through the cycle's own code path, the received halo values come back in the HOST array halo_out. */
+int pamg_dist_exchange_test(pamg_dist_t D, int level, const void *x_owned, void *halo_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Setup-phase operators: what the reference's smoothed-aggregation setup spends its

@@ -184,6 +184,7 @@ def _declare(lib):
     f("pamg_dist_sync", _vp)
     f("pamg_dist_stream", _vp, P(_vp))
     f("pamg_dist_info", _vp, P(C.c_int64))
+    f("pamg_dist_exchange_test", _vp, _i, _vp, _vp)
     f("pamg_csr_create", P(_vp), C.c_int64, C.c_int64, _vp, _vp, _vp)
     f("pamg_csr_view", P(_vp), _vp)
     f("pamg_csr_destroy", _vp)

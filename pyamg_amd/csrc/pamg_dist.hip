@@ -661,6 +661,27 @@ int pamg_dist_stream(pamg_dist_t D, pamg_stream_t *s)
     return PAMG_OK;
 }
 
+/* Transport self-test: the owned part of level `level`'s vector is set from the HOST array x_owned, ONE halo exchange runs
+ * (exactly the code path of the cycle: pack, transfers, wait), the halo part comes back in the HOST array halo_out.  A caller
+ * that fills x_owned with global indices can check every received value (pyamg_amd/dist.py does, before the first cycle). */
+int pamg_dist_exchange_test(pamg_dist_t D, int level, const void *x_owned, void *halo_out)
+{
+    if (!D || !D->finalized || level < 0 || level >= (int)D->lv.size() || !x_owned || !halo_out) return PAMG_E_ARG;
+    DLevel &L = D->lv[level];
+    const size_t ts = ts_of(D);
+    PAMG_HIP(hipStreamSynchronize(D->main));
+    PAMG_HIP(hipMemcpy(L.x, x_owned, (size_t)L.n_owned * ts, hipMemcpyHostToDevice));
+    if (L.n_halo) PAMG_HIP(hipMemset((char *)L.x + (size_t)L.n_owned * ts, 0xFF, (size_t)L.n_halo * ts));
+    if (L.talks()) {
+        PAMG_TRY(begin_exchange(D, level, L.x));
+        PAMG_TRY(finish_exchange(D, level, L.x));
+    }
+    PAMG_HIP(hipStreamSynchronize(D->main));
+    if (D->comm) PAMG_HIP(hipStreamSynchronize(D->comm));
+    if (L.n_halo) PAMG_HIP(hipMemcpy(halo_out, (char *)L.x + (size_t)L.n_owned * ts, (size_t)L.n_halo * ts, hipMemcpyDeviceToHost));
+    return PAMG_OK;
+}
+
 /* info: [0] sharded levels [1] transport mode (0 none, 1 callbacks, 2 RCCL) [2] halo exchanges per iteration (cycle + norm)
  * [3] of those, exchanges overlapped with interior rows [4] whole iteration replayed from a hipGraph [5] bytes of vectors
  * [6] values sent per iteration [7] interior row ranges of the fine-level operator (of [3] of pamg_matrix_info) */

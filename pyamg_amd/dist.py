@@ -376,7 +376,7 @@ class DistMultilevelSolver:
         self.native = None
         if native:
             # every level vector, the exchange buffers and the collapse buffers live inside the driver
-            self.native = _NativeCycle(self)
+            self.native = self._native_with_checked_transport()
             return
         self.send_idx = [o.index(p.send_idx_s) for p in self.sh.plans]
         self.send_buf = [o.vector(p.send_idx.size * p.bs) for p in self.sh.plans]
@@ -394,6 +394,58 @@ class DistMultilevelSolver:
         c0 = int(cplan.off[self.rank])
         fill = np.concatenate([np.arange(c0, c0 + cplan.n_owned, dtype=np.int64), cplan.halo_cols])     # blocks: owned | halo
         self.c_fill_idx = o.index((fill[:, None] * cplan.bs + np.arange(cplan.bs)).ravel().astype(np.int32))
+
+    def _all_agree(self, ok: bool) -> bool:
+        """logical AND of a flag over the ranks of the group"""
+        if self.world == 1:
+            return ok
+        import torch
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        if not self._gloo:
+            t = t.to(self.ops.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.cpu()[0]))
+
+    def _native_with_checked_transport(self):
+        """The C++ driver with its production transport (RCCL under an NCCL process group), CHECKED before the first
+        cycle: every sharded level exchanges a vector of global indices and every received halo value is compared.  If the
+        binding, the communicator or a single value fails on any rank, all ranks switch together to the second transport --
+        torch.distributed's own point-to-point calls on the driver's device buffers -- and say so; the arithmetic is the
+        same either way.  PAMG_DIST_TRANSPORT=rccl|torch pins the choice."""
+        import os
+        import sys
+        want = os.environ.get("PAMG_DIST_TRANSPORT", "")
+        if self.world == 1:
+            return _NativeCycle(self, "none")
+        if self._gloo:                                   # test rigs: several ranks on one GPU, staged through the host
+            nat = _NativeCycle(self, "host")
+            bad = nat.verify_exchange()
+            if not self._all_agree(not bad):
+                raise RuntimeError(f"rank {self.rank}: halo exchange self-test failed ({bad or 'on another rank'})")
+            return nat
+        nat, why = None, ""
+        if want != "torch":
+            try:
+                nat = _NativeCycle(self, "rccl")
+                bad = nat.verify_exchange()
+                if bad:
+                    why = f"halo self-test: {bad}"
+            except Exception as e:                  # noqa: BLE001 -- any failure here means: use the other transport
+                why = repr(e)
+            ok = self._all_agree(nat is not None and not why)
+            if ok or want == "rccl":
+                if not ok:
+                    raise RuntimeError(f"rank {self.rank}: RCCL transport failed its self-test ({why or 'on another rank'})")
+                return nat
+            if nat is not None:
+                nat.free()
+            print(f"[pyamg_amd.dist] rank {self.rank}: RCCL transport not usable ({why or 'failed on another rank'}); "
+                  "using torch.distributed point-to-point on the driver's buffers", file=sys.stderr, flush=True)
+        nat = _NativeCycle(self, "torch")
+        bad = nat.verify_exchange()
+        if not self._all_agree(not bad):
+            raise RuntimeError(f"rank {self.rank}: halo exchange self-test failed on both transports ({bad or 'on another rank'})")
+        return nat
 
     @classmethod
     def from_rank0(cls, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000, native=None):
@@ -614,15 +666,32 @@ class DistMultilevelSolver:
 
 
 # ------------------------------------------------------------------------------- the C++ driver
+class _DeviceBuffer:
+    """a raw device allocation presented through ``__cuda_array_interface__`` (what torch.as_tensor accepts without a copy)"""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _device_tensor(ptr, count, dtype, device):
+    """a torch tensor over ``count`` values of ``dtype`` at device address ``ptr`` (no copy; the memory stays the caller's)"""
+    import torch
+    ptr = getattr(ptr, "value", ptr)                   # ctypes.c_void_p or a plain address
+    return torch.as_tensor(_DeviceBuffer(ptr, count, np.dtype(dtype).str), device=device)
+
+
 class _NativeCycle:
     """``pamg_dist_*`` (csrc/pamg_dist.hip) wired to one rank's plan: the operators are the DeviceMatrix shards the
     solver already holds, the exchange plans are handed over in scalar units, the transport is RCCL when the process
     group is NCCL, two ctypes callbacks staging through the host when it is gloo (test rigs with several ranks on one
     GPU), none when the world is one rank."""
 
-    def __init__(self, sol: "DistMultilevelSolver"):
+    def __init__(self, sol: "DistMultilevelSolver", transport: str = "auto"):
         from . import _capi as capi
         self.capi, self.sol = capi, sol
+        if transport == "auto":
+            transport = "none" if sol.world == 1 else ("host" if sol._gloo else "rccl")
+        self.transport = transport
         lib = capi.lib()
         sh, ns = sol.sh, sol.sh.ns
         h = C.c_void_p()
@@ -657,11 +726,73 @@ class _NativeCycle:
                                                       capi.ptr(Dinv), int(sm.blocksize) if sm else 1),
                            f"pamg_dist_set_smoother({l}, {kind})")
         if sol.world > 1:
-            if sol._gloo:
-                self._host_transport(lib)
-            else:
-                self._rccl_transport(lib)
+            {"host": self._host_transport, "rccl": self._rccl_transport, "torch": self._torch_transport}[transport](lib)
         capi.check(lib.pamg_dist_finalize(h), "pamg_dist_finalize")
+
+    def verify_exchange(self) -> str:
+        """One halo exchange per sharded level with global indices as values (pamg_dist_exchange_test): '' when every
+        received value is the index of the column it stands for, else a description of the first mismatch."""
+        capi, sol = self.capi, self.sol
+        sh, dt = sol.sh, np.dtype(sol.sh.dtype)
+        for l in range(sh.ns):
+            p = sh.plans[l]
+            first = int(p.off[sol.rank]) * p.bs
+            xo = (first + np.arange(p.n_owned_s, dtype=np.int64)).astype(dt) % dt.type(2 ** 20 if dt == np.float32 else 2 ** 40)
+            want = ((np.asarray(p.halo_cols, dtype=np.int64)[:, None] * p.bs + np.arange(p.bs)).ravel()).astype(dt) \
+                % dt.type(2 ** 20 if dt == np.float32 else 2 ** 40)
+            got = np.full(max(p.n_halo_s, 1), -1.0, dtype=dt)
+            xo = np.ascontiguousarray(xo if xo.size else np.zeros(1, dtype=dt))
+            capi.check(capi.lib().pamg_dist_exchange_test(self.handle, l, capi.ptr(xo), capi.ptr(got)), "pamg_dist_exchange_test")
+            if p.n_halo_s and not np.array_equal(got[:p.n_halo_s], want):
+                k = int(np.flatnonzero(got[:p.n_halo_s] != want)[0])
+                return f"level {l}: halo value {k} is {got[k]!r}, expected {want[k]!r} ({int((got[:p.n_halo_s] != want).sum())} of {p.n_halo_s} wrong)"
+        return ""
+
+    # second production transport: torch.distributed's own point-to-point calls, straight on the driver's device buffers
+    # (the buffers are wrapped as tensors through __cuda_array_interface__; blocking, like the host callbacks)
+    def _torch_transport(self, lib):
+        import traceback
+        import torch
+        sol, capi = self.sol, self.capi
+        dist, npdt = sol.dist, np.dtype(sol.sh.dtype)
+        dev = sol.ops.device
+        EX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+        def wrap(ptr, count, dt):
+            return _device_tensor(ptr, count, dt, dev)
+
+        def exchange(_user, level, send_buf, send_count, halo, halo_count):
+            try:
+                plan = sol.sh.plans[level]
+                bs = plan.bs
+                st = wrap(send_buf, send_count, npdt) if send_count else None
+                rt = wrap(halo, halo_count, npdt) if halo_count else None
+                reqs = [dist.P2POp(dist.irecv, rt[beg * bs:(beg + cnt) * bs], sol._peer(src), sol.group) for (src, beg, cnt) in plan.recv]
+                reqs += [dist.P2POp(dist.isend, st[beg * bs:(beg + cnt) * bs], sol._peer(dst), sol.group) for (dst, beg, cnt) in plan.send]
+                if reqs:
+                    for w in dist.batch_isend_irecv(reqs):
+                        w.wait()
+                    torch.cuda.synchronize(dev)
+                return 0
+            except Exception:                    # noqa: BLE001 -- an exception must not unwind through the C frames
+                traceback.print_exc()
+                return capi.E_COMM
+
+        def allreduce(_user, buf, count, dtype):
+            try:
+                dt = np.dtype(np.float64 if dtype == capi.F64 else np.float32)
+                t = wrap(buf, count, dt)
+                dist.all_reduce(t, group=sol.group)
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:                    # noqa: BLE001
+                traceback.print_exc()
+                return capi.E_COMM
+
+        self._cb = (EX(exchange), AR(allreduce))
+        capi.check(lib.pamg_dist_set_callbacks(self.handle, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None),
+                   "pamg_dist_set_callbacks")
 
     # RCCL: rank 0 draws the id, everybody learns it through the process group, the communicator is this library's own
     def _rccl_transport(self, lib):
@@ -761,7 +892,8 @@ class _NativeCycle:
         keys = ("sharded_levels", "transport", "exchanges_per_iteration", "overlapped_exchanges", "graph", "vector_bytes",
                 "values_sent_per_round", "interior_ranges_level0")
         d = dict(zip(keys, [int(v) for v in a]))
-        d["transport"] = {0: "none", 1: "host callbacks (gloo)", 2: "rccl"}[d["transport"]]
+        d["transport"] = {"none": "none", "host": "host callbacks (gloo)", "rccl": "rccl",
+                          "torch": "torch.distributed point-to-point on the driver's buffers"}[self.transport]
         return d
 
     def free(self):

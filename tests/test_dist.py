@@ -232,3 +232,33 @@ def test_rccl_binds_and_initialises_a_communicator():
         "print('rccl communicator ok')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl communicator ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+def test_driver_buffers_as_torch_tensors():
+    """the second production transport (torch.distributed point-to-point on the driver's own buffers) rests on presenting
+    a raw device allocation of this library to torch without a copy: values written by us are seen through the tensor,
+    values written through the tensor are seen by us, and an NCCL collective runs on it (one rank here)."""
+    code = (
+        "import sys, os, numpy as np\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import torch, torch.distributed as dist\n"
+        "from pyamg_amd import _capi as capi\n"
+        "from pyamg_amd.dist import _device_tensor\n"
+        "a = np.arange(1000, dtype=np.float64) * 0.5\n"
+        "d = capi.DeviceArray.from_host(a)\n"
+        "t = _device_tensor(d.ptr, a.size, np.float64, torch.device('cuda', 0))\n"
+        "assert t.is_cuda and t.dtype == torch.float64 and np.array_equal(t.cpu().numpy(), a)\n"
+        "t[10:20] = -3.0\n"
+        "torch.cuda.synchronize()\n"
+        "b = d.download()\n"
+        "assert (b[10:20] == -3.0).all() and np.array_equal(b[:10], a[:10])\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', RANK='0', WORLD_SIZE='1')\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "dist.all_reduce(t[:100])\n"
+        "torch.cuda.synchronize()\n"
+        "assert np.array_equal(d.download()[:10], a[:10])\n"
+        "dist.destroy_process_group()\n"
+        "print('tensor view ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "tensor view ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
