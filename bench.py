@@ -118,7 +118,7 @@ def measure_traffic(grid, nrows):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if r.get("Counter_Name") == cname and "csr_stream_kernel" in r.get("Kernel_Name", "") and \
+                        if r.get("Counter_Name") == cname and any(k in r.get("Kernel_Name", "") for k in ("csr_stream_kernel", "csr_rowgather_kernel")) and \
                                 int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= 256 * 1024:
                             tot += float(r["Counter_Value"])
                             cnt += 1
@@ -449,7 +449,8 @@ def main():
             f1.record(None)
             f1.synchronize()
             ms = f0.elapsed_ms(f1) / 20
-            roofline = {"kernel": "csr_stream_kernel<double, RESID> (rank 0's row shard of the fine level, r = b - A x)", "bound": "hbm",
+            roofline = {"kernel": ("csr_rowgather_kernel<double, RESID>" if A0.value_codes() else "csr_stream_kernel<double, RESID>") +
+                        " (rank 0's row shard of the fine level, r = b - A x)", "bound": "hbm",
                         "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4),
                         "traffic": None, "bytes_per_launch": int(by), "ms_per_launch": round(ms, 5)}
             for d_ in (xs_, bs_, rs_):
@@ -555,23 +556,29 @@ def main():
     # themselves streamed (tune key 21 off) is timed beside it, so both numbers are in the line
     nvals = A0.value_codes()
     plain = None
-    if nvals:
-        A0.tune(val8=0)
+    if nvals and rank == 0 and world == 1 and A.format == "csr":
+        # a second resident copy of the fine-level operator on the plan of an operator WITHOUT value codes (LDS window 1536,
+        # the staged kernel of rounds 1-2): what the same residual costs with 10 bytes per entry
+        from pyamg_amd.hierarchy import sparse_op
+        from pyamg_amd.multilevel import DeviceMatrix
+        Ap_ = DeviceMatrix(sparse_op(A))
+        Ap_.tune(val8=0, rowgather=0, lds_entries=1536, max_rows=1024)
         for _ in range(5):
-            A0.spmv(capi.SPMV_RESID, xd, rd, b=bd, stream=stream)
+            Ap_.spmv(capi.SPMV_RESID, xd, rd, b=bd, stream=stream)
         f0.record(stream)
         for _ in range(reps):
-            A0.spmv(capi.SPMV_RESID, xd, rd, b=bd, stream=stream)
+            Ap_.spmv(capi.SPMV_RESID, xd, rd, b=bd, stream=stream)
         f1.record(stream)
         f1.synchronize()
-        A0.tune(val8=1)
         ms_plain = f0.elapsed_ms(f1) / reps
+        Ap_.free()
         plain = {"ms_per_launch": round(ms_plain, 5), "achieved": round(bytes_resid / ms_plain / 1e6, 1),
-                 "frac": round(bytes_resid / ms_plain / 1e6 / HBM_PEAK_GBPS, 4)}
+                 "frac": round(bytes_resid / ms_plain / 1e6 / HBM_PEAK_GBPS, 4),
+                 "kernel": "csr_stream_kernel<double, RESID>: 16-bit column codes + the values as stored, LDS-staged products"}
     pmc = None
     if rank == 0 and world == 1 and not args.no_pmc and "grid" in wl and not wl.get("elasticity") and not wl.get("convdiff"):
         pmc = measure_traffic(wl["grid"], n)
-    roofline = {"kernel": "csr_stream_kernel<double, RESID> (fine-level r = b - A x)", "bound": "hbm",
+    roofline = {"kernel": ("csr_rowgather_kernel<double, RESID>" if nvals else "csr_stream_kernel<double, RESID>") + " (fine-level r = b - A x)", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc["bytes_per_launch"] if pmc else None,
                 "bytes_per_launch": int(bytes_resid), "ms_per_launch": round(spmv_ms, 5)}
@@ -582,7 +589,8 @@ def main():
         nnz0 = int(A.nnz)
         streamed = bytes_resid - 9 * nnz0             # 2-byte column codes + 1-byte value codes instead of 4 + 8 bytes per entry
         roofline["operator_stream"] = (f"16-bit column codes + 8-bit value codes ({nvals} distinct values): 3 instead of 12 bytes per stored "
-                                       "entry reach the kernel; `achieved` / `frac` keep the SURVEY's CSR byte formula, so they can exceed the peak")
+                                       "entry reach the kernel (lane = row: a gather instruction reads 64 consecutive values of x); "
+                                       "`achieved` / `frac` keep the SURVEY's CSR byte formula, so they can exceed the peak")
         roofline["bytes_streamed_per_launch"] = int(streamed)
         roofline["frac_on_streamed_bytes"] = round(streamed / spmv_ms / 1e6 / HBM_PEAK_GBPS, 4)
         roofline["values_streamed_as_stored"] = plain

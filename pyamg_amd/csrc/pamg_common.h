@@ -170,6 +170,7 @@ struct pamg_matrix_s {
     void *d_vdict = nullptr;         //   stream 1 instead of 8 bytes per value; needs the 16-bit column stream; null otherwise
     int nvdict = 0;
     int use_val8 = 1;                // tune key 21
+    int use_rowg = 0;                // tune key 22: row-gather form of the whole-operator kernels (value-code operators; set with the codes)
     int cap_from_val8 = 0;           // cap was raised to 2048 because the operator streams value codes (level schedules keep 1536)
     int use_xwin = 0;                // LDS-staged x windows for the whole-operator kernels (tune key 9)
     void *d_xwin = nullptr;          // XWin[nblk] window plan (device)

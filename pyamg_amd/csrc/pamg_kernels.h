@@ -254,9 +254,11 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
+                        // unconditional (no branch around the load): an entry outside the range reads the first column of
+                        // the window; its product lands in a slot nobody sums (or is not stored at all)
                         const int e = (j < 4 ? q : qb) + (j & 3);
-                        const bool ok = (e >= p0) && (e < p1) && (j < 4 || two);
-                        xv[j] = ok ? gather_x<COH>(a, cc[j]) : T(0);
+                        const bool ok = (e >= p0) && (e < p1);
+                        xv[j] = gather_x<COH>(a, ok ? cc[j] : wb.x);
                     }
                     T2 o0, o1;
                     o0.x = vd[vca & 0xFFu] * xv[0]; o0.y = vd[(vca >> 8) & 0xFFu] * xv[1];
@@ -592,6 +594,81 @@ __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
     }
     if constexpr (EPI == EPI_SUMSQ) {
         __syncthreads();                                   // LDS reuse for the reduction
+        const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
+        if (threadIdx.x == 0 && live) a.partial[blk] = tot;
+    }
+}
+
+// ---- row-gather form for operators that stream 16-bit column codes and 8-bit value codes.
+// The PMC counters of the staged kernel on the 256^3 stencil (profiles/r03_pmc_stall_probe_*.json) show what binds it once the
+// operator stream is 3 bytes per entry: the L1 (TCP) sees ~1 access per matrix ENTRY -- with several consecutive entries per
+// lane, the 64 lanes of a gather instruction hit 64 different places of x -- and its access rate, not HBM, sets the time.
+// Here the range's codes go to LDS with coalesced 16-byte loads (6 KB), and then lane l takes ROW r0 + l: instruction j gathers
+// the j-th entry of 64 consecutive rows -- on a stencil 64 consecutive values of x, one 512-byte access -- and the lane adds its
+// products in storage order straight from registers: no product array, no second pass.  Same order of additions, same bits.
+template <typename T, int EPI>
+__global__ __launch_bounds__(BLK) void csr_rowgather_kernel(const StreamArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr bool SKIPD = EpiTraits<EPI>::need_cols;          // Jacobi family: the diagonal never enters the sum
+    const int cap = a.cap, tid = threadIdx.x;
+    unsigned short *lc = reinterpret_cast<unsigned short *>(smem_raw);                        // [cap + 16] column codes
+    unsigned char *lv = smem_raw + sizeof(unsigned short) * (size_t)(cap + 16);               // [cap + 16] value codes
+    T *vd = reinterpret_cast<T *>(smem_raw + ((3 * (size_t)(cap + 16) + 15) & ~(size_t)15)); // dictionary
+    double sq = 0.0;
+    int blk = (int)blockIdx.x;
+    if (a.flags & 2) {
+        const int chunk = (a.nblk + 7) >> 3;
+        blk = (blk & 7) * chunk + (blk >> 3);
+    }
+    const bool live = blk < a.nblk;
+    if (live) {
+        if (a.blkmap) blk = a.blkmap[blk];
+        const int4 meta = a.blkmeta[blk];
+        const int4 wb = a.wbase[blk];
+        const int r0 = meta.x, r1 = meta.y, p0 = meta.z, p1 = meta.w;
+        const int base = p0 & ~7;
+        RowPre<T> q;
+        int r = r0 + tid;
+        if (r < r1) q = row_prefetch<T, EPI, 0>(a, r);
+        if (tid < a.nvd) vd[tid] = a.vdict[tid];
+        for (int g = base + 8 * tid; g < p1; g += 8 * BLK) {
+            *reinterpret_cast<uint4 *>(lc + (g - base)) = *reinterpret_cast<const uint4 *>(a.Aj16 + g);
+            *reinterpret_cast<uint2 *>(lv + (g - base)) = *reinterpret_cast<const uint2 *>(a.Ax8 + g);
+        }
+        __syncthreads();
+        while (r < r1) {
+            T s = row_init<T, EPI>(q);
+            const int lo = q.lo - base, hi = q.hi - base;
+            for (int j = lo; j < hi; j += 8) {
+                int col[8];
+                T xv[8], av[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = (j + k < hi) ? j + k : lo;                      // beyond the row: re-read its first entry
+                    const unsigned c = lc[e];
+                    const unsigned w = c >> 14;
+                    col[k] = (w == 0 ? wb.x : w == 1 ? wb.y : w == 2 ? wb.z : wb.w) + (int)(c & 0x3FFFu);
+                    av[k] = vd[lv[e]];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[k] = a.x[col[k]];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (j + k < hi && (!SKIPD || col[k] != q.row)) {
+                        const T pr = av[k] * xv[k];
+                        if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
+                        else s += pr;
+                    }
+                }
+            }
+            row_finish<T, EPI, 0>(a, q, s, sq);
+            r += BLK;
+            if (r < r1) q = row_prefetch<T, EPI, 0>(a, r);
+        }
+    }
+    if constexpr (EPI == EPI_SUMSQ) {
+        __syncthreads();
         const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
         if (threadIdx.x == 0 && live) a.partial[blk] = tot;
     }

@@ -110,6 +110,21 @@ int xw_launch(int epi, int grid, int lds, hipStream_t s, const StreamArgs<T> &a,
     return (int)hipGetLastError();
 }
 
+// row-gather form (csr_rowgather_kernel): operators streaming value codes, no over-long rows
+template <typename T>
+int launch_rowgather(int epi, int grid, int cap, int nvd, hipStream_t s, const StreamArgs<T> &a)
+{
+    const int lds = std::max((int)(((3 * (size_t)(cap + 16) + 15) & ~(size_t)15) + sizeof(T) * (size_t)((nvd + 1) & ~1)), (int)(BLK * sizeof(double)));
+#define PAMG_RG(E) case E: hipLaunchKernelGGL((csr_rowgather_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); break;
+    switch (epi) {
+        PAMG_RG(EPI_SET) PAMG_RG(EPI_ACC) PAMG_RG(EPI_RESID) PAMG_RG(EPI_AXPBY) PAMG_RG(EPI_ACC_AXPBY) PAMG_RG(EPI_SUMSQ)
+        PAMG_RG(EPI_ACCSEQ) PAMG_RG(EPI_JACOBI) PAMG_RG(EPI_JACOBI_B)
+        default: return 1;
+    }
+#undef PAMG_RG
+    return (int)hipGetLastError();
+}
+
 template <typename T>
 int launch_any(int epi, int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a)
 {
@@ -856,17 +871,20 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
         const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2 && !(A->stream_flags & 4);
         const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
         const int lds = lds_bytes(A->dtype, epi, A->cap) + (val8 ? val8_lds(A, epi) : 0);
+        const bool rowg = val8 && A->use_rowg && A->max_row_len <= A->cap;
         if (A->dtype == PAMG_F64) {
             StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
             a.flags = A->stream_flags & ~2;
             a.nblk = n; a.blkmap = A->d_part[part - 1];
             if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+            if (rowg) { const int st = launch_rowgather<double>(epi, n, A->cap, A->nvdict, s, a); if (st != 1) return st; }
             return launch_any<double>(epi, A->npl, n, lds, s, a);
         }
         StreamArgs<float> a = base_args<float>(A, x, b, y, c, omega, partial);
         a.flags = A->stream_flags & ~2;
         a.nblk = n; a.blkmap = A->d_part[part - 1];
         if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+        if (rowg) { const int st = launch_rowgather<float>(epi, n, A->cap, A->nvdict, s, a); if (st != 1) return st; }
         return launch_any<float>(epi, A->npl, n, lds, s, a);
     }
     int lds = lds_bytes(A->dtype, epi, A->cap);
@@ -882,15 +900,18 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
     const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2 && !(A->stream_flags & 4);
     const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
     if (val8) lds += val8_lds(A, epi);
+    const bool rowg = val8 && A->use_rowg && A->max_row_len <= A->cap;
     if (A->dtype == PAMG_F64) {
         StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
         a.flags = A->stream_flags;
         if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+        if (rowg) { const int st = launch_rowgather<double>(epi, grid, A->cap, A->nvdict, s, a); if (st != 1) return st; }
         return launch_any<double>(epi, A->npl, grid, lds, s, a);
     }
     StreamArgs<float> a = base_args<float>(A, x, b, y, c, omega, partial);
     a.flags = A->stream_flags;
     if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+    if (rowg) { const int st = launch_rowgather<float>(epi, grid, A->cap, A->nvdict, s, a); if (st != 1) return st; }
     return launch_any<float>(epi, A->npl, grid, lds, s, a);
 }
 
@@ -1759,8 +1780,24 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
     // with 8-bit value codes the whole-operator kernels stage four entries per lane in two steps that are in flight
     // together: 2048 entries fill both (measured on the 256^3 stencil: 0.242 ms against 0.262 with 1536); the level
     // schedules of the order-exact sweeps keep 1536
-    if (A->d_Ax8 && R == 1 && C == 1) { A->cap = 2048; A->cap_from_val8 = 1; }
+    if (A->d_Ax8 && R == 1 && C == 1) {
+        // ... and run as the row-gather kernel (lane = row): ranges of 512 rows = two full trips of the 256 lanes, the LDS
+        // window sized for them (3 bytes per entry there).  256^3 stencil: 0.179 ms with 512 rows / 3584 entries against
+        // 0.193 (256 rows) and 0.199 (2048 entries, ragged second trip); profiles/r03_microbench_spmv_value_codes.json
+        const int64_t avg = (A->nnz + A->nrows - 1) / std::max<int64_t>(1, A->nrows);
+        A->max_rows = 512;
+        A->cap = (int)std::min<int64_t>(12288, std::max<int64_t>(2048, ((512 * avg + 255) / 256) * 256));
+        A->cap_from_val8 = 1;
+        A->use_rowg = 1;
+    }
     if (!st) st = replan(A);
+    if (!st && A->d_Ax8 && !A->d_Aj16) {
+        // value codes need the 16-bit column stream; without it (a range with more than four column windows) the operator
+        // runs the staged kernel on its own default plan
+        drop_val8(A);
+        A->cap = 1536; A->max_rows = 1024; A->cap_from_val8 = 0; A->use_rowg = 0;
+        st = replan(A);
+    }
     if (st) { pamg_matrix_destroy(A); return st; }
     *out = A;
     return PAMG_OK;
@@ -1806,6 +1843,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
     if (!A) return PAMG_E_ARG;
     // a finalised solver's captured graphs point into the schedules and plans this call would free
     if (key == 21) { A->use_val8 = value != 0; return PAMG_OK; }      // read at launch time only: no plan depends on it
+    if (key == 22) { A->use_rowg = value != 0; return PAMG_OK; }      // likewise
     if (A->borrowed > 0) return PAMG_E_STATE;
     switch (key) {
         case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~3; A->cap_from_val8 = 0; break;

@@ -752,7 +752,9 @@ def test_8bit_value_codes_are_bit_identical(dtype):
     """Operators with at most 256 distinct values (the gallery's stencils: 2) stream one byte per value and look the
     value up in an LDS dictionary (tune key 21 switches back to the values themselves): same bits either way -- on the
     7-point stencil, with exactly 256 and with 257 distinct values (no codes), with +0 / -0 / explicit zeros as
-    separate dictionary entries, with one row longer than the LDS window, and on a BSR(1,1) operator."""
+    separate dictionary entries, with one row longer than the LDS window, and on a BSR(1,1) operator.  Operators with
+    codes run as the row-gather kernel (lane = row, tune key 22) -- checked against the staged kernel on the codes and on the
+    values as stored, every whole-operator epilogue."""
     import scipy.sparse as sp
     from tools.problems import poisson_csr
     rng = np.random.RandomState(8)
@@ -780,8 +782,8 @@ def test_8bit_value_codes_are_bit_identical(dtype):
         assert dA.value_codes() == expect
         dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
         out = {}
-        for flag in (1, 0):
-            dA.tune(val8=flag)
+        for flag in (2, 1, 0):                      # 2: codes + row-gather kernel (the default), 1: codes + staged kernel, 0: values as stored
+            dA.tune(val8=min(flag, 1), rowgather=int(flag == 2))
             assert dA.value_codes() == (expect if flag else 0)
             dy = capi.DeviceArray(n, dtype)
             dA.spmv(capi.SPMV_RESID, dx, dy, b=db)
@@ -792,7 +794,24 @@ def test_8bit_value_codes_are_bit_identical(dtype):
             dA.jacobi(dj, db, dw, 0.8, iterations=2)
             out[flag] = (dy.download(), dz.download(), dj.download())
         for k in range(3):
-            assert np.array_equal(out[0][k], out[1][k], equal_nan=True)
+            assert np.array_equal(out[0][k], out[1][k], equal_nan=True) and np.array_equal(out[0][k], out[2][k], equal_nan=True)
+        # the remaining epilogues of the row-gather kernel against the staged kernel on the values as stored
+        dA.tune(val8=1, rowgather=1)
+        res = {}
+        for flag in (1, 0):
+            dA.tune(val8=flag, rowgather=flag)
+            dy = capi.DeviceArray.from_host(b)
+            dA.spmv(capi.SPMV_ACC, dx, dy)
+            d2 = capi.DeviceArray.from_host(x)
+            dA.spmv(capi.SPMV_ACC_AXPBY, dx, d2, b=db, c=-1.7)
+            d3 = capi.DeviceArray(n, dtype)
+            dA.spmv(capi.SPMV_AXPBY, dx, d3, b=db, c=0.37)
+            o = capi.DeviceArray(1, np.float64)
+            dA.resid_sumsq(dx, db, o)
+            res[flag] = (dy.download(), d2.download(), d3.download(), o.download())
+        for k in range(4):
+            assert np.array_equal(res[0][k], res[1][k], equal_nan=True), k
+        dA.tune(val8=1, rowgather=1)
         if dtype == np.float64:
             assert np.array_equal(out[1][1], sp.csr_array(A) @ x)
         dA.free()

@@ -37,24 +37,31 @@ def timed(fn, reps=30):
 
 
 ref = None
-for v8 in (0, 1):
-    for cap in ((1536, 2048) if v8 == 0 else (1536, 1792, 2048, 2304, 3072, 4096, 1024)):
-        for fl in ((0, 3) if v8 == 0 else (0, 3)):
-            dA.tune(lds_entries=cap, stream_flags=fl, val8=v8)
-            ms = timed(lambda: dA.spmv(capi.SPMV_RESID, x, r, b=b))
-            got = r.download()
-            if ref is None:
-                ref = got
-            same = bool(np.array_equal(ref, got))
-            key = f"val8_{v8}_cap{cap}_flags{fl}"
-            out[key] = {"resid_ms": round(ms, 5), "GBps_csr_formula": round(by / ms / 1e6, 1), "frac_csr_formula": round(by / ms / 1e6 / 8000, 4), "same_bits": same}
-            print(key, out[key], flush=True)
-for v8 in (0, 1):
-    dA.tune(lds_entries=1536, stream_flags=0, val8=v8)
-    xj = capi.DeviceArray.from_host(rng.rand(n))
+
+
+def run(tag, **tune):
+    global ref
+    dA.tune(**tune)
+    ms = timed(lambda: dA.spmv(capi.SPMV_RESID, x, r, b=b))
+    got = r.download()
+    if ref is None:
+        ref = got
+    xj = capi.DeviceArray.from_host(x.download())
     ms_j = timed(lambda: dA.jacobi(xj, b, w, 0.8, iterations=1))
     ms_s = timed(lambda: dA.spmv(capi.SPMV_SET, x, r))
-    out[f"val8_{v8}_jacobi_set"] = {"jacobi_ms": round(ms_j, 5), "set_ms": round(ms_s, 5)}
-    print(f"val8_{v8}", out[f"val8_{v8}_jacobi_set"], flush=True)
+    xj.free()
+    out[tag] = {"resid_ms": round(ms, 5), "frac_csr_formula": round(by / ms / 1e6 / 8000, 4), "jacobi_ms": round(ms_j, 5), "set_ms": round(ms_s, 5),
+                "same_bits": bool(np.array_equal(ref, got)), "ranges": dA.info()["row_blocks"]}
+    print(tag, out[tag], flush=True)
+
+
+plan0 = dA.info()
+print("default plan of the operator:", plan0, flush=True)
+for fl in (0, 1, 2, 3):
+    run(f"rowgather_default_plan_flags{fl}", stream_flags=fl)
+run("values_as_stored_staged_cap1536", val8=0, rowgather=0, lds_entries=1536, max_rows=1024, stream_flags=0)
+run("codes_staged_cap2048", val8=1, rowgather=0, lds_entries=2048, max_rows=1024)
+for cap, mr in ((2048, 1024), (1792, 256), (3584, 512), (5376, 768), (7168, 1024)):
+    run(f"rowgather_cap{cap}_rows{mr}", val8=1, rowgather=1, lds_entries=cap, max_rows=mr)
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
 (ROOT / "gpurun_out" / "microbench_spmv_val8_r03.json").write_text(json.dumps(out, indent=1))
