@@ -585,6 +585,7 @@ def main():
     if pmc:
         roofline["traffic_detail"] = pmc
         roofline["traffic_over_algorithmic"] = round(pmc["bytes_per_launch"] / bytes_resid, 3)
+        roofline["frac_on_measured_traffic"] = round(pmc["bytes_per_launch"] / spmv_ms / 1e6 / HBM_PEAK_GBPS, 4)
     if nvals:
         nnz0 = int(A.nnz)
         streamed = bytes_resid - 9 * nnz0             # 2-byte column codes + 1-byte value codes instead of 4 + 8 bytes per entry

@@ -1784,9 +1784,11 @@ int pamg_matrix_create(pamg_matrix_t *out, int dtype, int flavour, int n_brow, i
         // ... and run as the row-gather kernel (lane = row): ranges of 512 rows = two full trips of the 256 lanes, the LDS
         // window sized for them (3 bytes per entry there).  256^3 stencil: 0.179 ms with 512 rows / 3584 entries against
         // 0.193 (256 rows) and 0.199 (2048 entries, ragged second trip); profiles/r03_microbench_spmv_value_codes.json
+        // Small operators keep at least ~2048 ranges in the launch (8 per CU): 64 .. 512 rows per range.
         const int64_t avg = (A->nnz + A->nrows - 1) / std::max<int64_t>(1, A->nrows);
-        A->max_rows = 512;
-        A->cap = (int)std::min<int64_t>(12288, std::max<int64_t>(2048, ((512 * avg + 255) / 256) * 256));
+        const int64_t rows = std::min<int64_t>(512, std::max<int64_t>(64, ((A->nrows / 2048 + 63) / 64) * 64));
+        A->max_rows = (int)rows;
+        A->cap = (int)std::min<int64_t>(12288, std::max<int64_t>(512, ((rows * avg + 255) / 256) * 256));
         A->cap_from_val8 = 1;
         A->use_rowg = 1;
     }
