@@ -327,7 +327,10 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * multi-XCD granular sweep runs SA-like rows; else 64..2048);
  * 21 = 8-bit value codes of the whole-operator kernels (default 1): an operator with at most 256 distinct values
  * (the stencils of pyamg.gallery: 2) streams one byte per value, the kernel looks the value up in an LDS copy of
- * the dictionary -- same bits, same products; needs key 19.
+ * the dictionary -- same bits, same products; needs key 19;
+ * 22 = row-gather form of the whole-operator kernels on operators with value codes (default 1 there): lane = row, the j-th
+ * entries of 64 consecutive rows in one gather instruction (coalesced on stencils), products summed in storage order in
+ * registers; 0 = the LDS-staged kernel on the codes.
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes
