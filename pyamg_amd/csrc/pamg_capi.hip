@@ -222,7 +222,9 @@ int l1_gs_indexed(const int32_t *Ap, int Ap_size, const int32_t *Aj, int Aj_size
         for (int r = 0; r < n; ++r) { xs[(size_t)r] = x[inv[(size_t)r]]; bs_[(size_t)r] = b[inv[(size_t)r]]; }
         {
             MatGuard g;
-            PAMG_TRY(l1_acquire(g, dt<T>(), PAMG_CSR, n, n, 1, 1, tp.data(), tj.data(), tx.data()));
+            // a temporary of this call (renumbered rows in function-local arrays): created directly, never through the
+            // Layer-1 cache -- it would evict a resident user operator and stay pinned behind dead addresses
+            PAMG_TRY(pamg_matrix_create(&g.A, dt<T>(), PAMG_CSR, n, n, 1, 1, tp.data(), tj.data(), tx.data()));
             DevBuf dx, db;
             PAMG_TRY(dx.put(xs.data(), sizeof(T) * (size_t)n));
             PAMG_TRY(db.put(bs_.data(), sizeof(T) * (size_t)n));

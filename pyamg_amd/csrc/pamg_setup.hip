@@ -20,6 +20,7 @@
 #include <cmath>
 #include <new>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 #include "pamg_common.h"
@@ -828,13 +829,19 @@ int matmat(pamg_csr_s *A, pamg_csr_s *B, int col_block, int keep_zeros, pamg_csr
     if (!A || !B || !out || col_block < 1) return PAMG_E_ARG;
     if (A->n != B->m) return PAMG_E_ARG;
     const int m = (int)A->m;
-    static bool attr_set = false;
+    // the attribute belongs to the (function, device) pair: remember the devices it was set on
+    static std::mutex attr_mu;
+    static unsigned long long attr_devs = 0;
+    int cur_dev = 0;
+    PAMG_HIP(hipGetDevice(&cur_dev));
+    std::lock_guard<std::mutex> attr_lk(attr_mu);
+    const bool attr_set = cur_dev < 64 && ((attr_devs >> cur_dev) & 1ull);
     if (!attr_set) {
         PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<true, SPG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(true)));
         PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<false, SPG_CAP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(false)));
         PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<true, SPG_CAP2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(true, SPG_CAP2)));
         PAMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&spg_kernel<false, SPG_CAP2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)spg_lds(false, SPG_CAP2)));
-        attr_set = true;
+        if (cur_dev < 64) attr_devs |= 1ull << cur_dev;
     }
     int *d_nprod = nullptr, *d_rowcount = nullptr, *d_rcount = nullptr, *d_obase = nullptr, *d_seq = nullptr, *d_long = nullptr,
         *d_lohi = nullptr, *d_ids = nullptr, *d_cnt2 = nullptr;
