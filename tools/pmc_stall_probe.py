@@ -5,9 +5,9 @@ import csv, glob, json, os, subprocess, sys, tempfile
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 grid = ["256", "256", "256"]
-variants = sys.argv[1:] or ["--val8=1", "--val8=0"]
+LEVEL1 = "--level1" in sys.argv
+variants = [a for a in sys.argv[1:] if a != "--level1"] or (["level1"] if LEVEL1 else ["--val8=1", "--val8=0"])
 groups = [["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVES_sum"],
-          ["TA_BUSY_avr", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum", "TA_FLAT_READ_WAVEFRONTS_sum"],
           ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"],
           ["TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_TCR_TCP_STALL_CYCLES_sum"],
           ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_EA0_RDREQ_sum"],
@@ -20,9 +20,12 @@ for var in variants:
     rec = {}
     for g in groups:
         d = tempfile.mkdtemp(prefix="pmcs_")
-        cmd = ["rocprofv3", "--pmc"] + g + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, str(ROOT / "tools" / "spmv_pmc.py")] + grid + var.split() + ["--launches=4"]
+        if LEVEL1:
+            cmd = ["rocprofv3", "--pmc"] + g + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, str(ROOT / "tools" / "spmv_pmc_level1.py")]
+        else:
+            cmd = ["rocprofv3", "--pmc"] + g + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, str(ROOT / "tools" / "spmv_pmc.py")] + grid + var.split() + ["--launches=4"]
         try:
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
         except Exception as e:      # noqa: BLE001
             rec[",".join(g)] = repr(e)
             continue
@@ -30,11 +33,11 @@ for var in variants:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 for r in csv.DictReader(fh):
-                    if any(k in r.get("Kernel_Name", "") for k in ("csr_stream", "csr_rowgather")) and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= 256 * 1024:
+                    if any(k in r.get("Kernel_Name", "") for k in ("csr_stream", "csr_rowgather")) and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= (4096 * 256 if LEVEL1 else 256 * 1024):
                         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in acc.items():
             rec[k] = round(sum(v) / len(v), 1)
     out[var] = rec
     print(var, json.dumps(rec), flush=True)
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
-(ROOT / "gpurun_out" / "pmc_stall_probe_r03.json").write_text(json.dumps(out, indent=1))
+(ROOT / "gpurun_out" / ("pmc_stall_probe_level1_r03.json" if LEVEL1 else "pmc_stall_probe_r03.json")).write_text(json.dumps(out, indent=1))
