@@ -330,12 +330,17 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * the dictionary -- same bits, same products; needs key 19;
  * 22 = row-gather form of the whole-operator kernels on operators with value codes (default 1 there): lane = row, the j-th
  * entries of 64 consecutive rows in one gather instruction (coalesced on stencils), products summed in storage order in
- * registers; 0 = the LDS-staged kernel on the codes.
+ * registers; 0 = the LDS-staged kernel on the codes;
+ * 23 = row-pattern form (default 1 where plan_rowpat found a table, see pamg_matrix_row_patterns).
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes
  * (tune key 21), 0 when they stream the values themselves. */
 int pamg_matrix_value_codes(pamg_matrix_t A, int *n_values);
+/* n_patterns = size of the operator's row-pattern table when the whole-operator kernels run in the row-pattern form (tune
+ * key 23: square operators with value codes whose rows are mostly one of <= 255 lists of (column - row, value) pairs --
+ * constant-coefficient stencils; one byte per such row instead of the row's codes), 0 otherwise. */
+int pamg_matrix_row_patterns(pamg_matrix_t A, int *n_patterns);
 /* Pick the LDS window (key 0) and streaming flags (key 8) of the whole-operator kernels by timing
  * y = A x on the device with a few candidates (results are bit-identical for every choice; this
  * is speed only).  allow_cap = 0 keeps the LDS window (level schedules depend on it).  Operators

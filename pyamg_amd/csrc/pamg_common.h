@@ -83,6 +83,9 @@ struct StreamArgs {
     const unsigned char *Ax8;     // whole-operator kernels: values as 8-bit codes into vdict (operators with <= 256 distinct values) or nullptr
     const T *vdict;               //   the distinct values (bit patterns in increasing order), nvd of them
     int nvd;
+    const unsigned char *pid;     // whole-operator kernels: row-pattern number per row (255 = irregular row) or nullptr
+    const void *ptab;             //   [256] lengths | [npat * lmax] offsets | [npat * lmax] values
+    int npat, lmax;
 };
 
 // One dependency-level schedule for an order-exact sweep (forward or backward, or a
@@ -171,6 +174,10 @@ struct pamg_matrix_s {
     int nvdict = 0;
     int use_val8 = 1;                // tune key 21
     int use_rowg = 0;                // tune key 22: row-gather form of the whole-operator kernels (value-code operators; set with the codes)
+    unsigned char *d_pid = nullptr;  // row patterns (plan_rowpat): list number per row, 255 = walk the row through the code arrays
+    void *d_ptab = nullptr;          //   [256] lengths | [npat * pat_lmax] column offsets | [npat * pat_lmax] values
+    int npat = 0, pat_lmax = 0;
+    int use_rowpat = 1;              // tune key 23
     int cap_from_val8 = 0;           // cap was raised to 2048 because the operator streams value codes (level schedules keep 1536)
     int use_xwin = 0;                // LDS-staged x windows for the whole-operator kernels (tune key 9)
     void *d_xwin = nullptr;          // XWin[nblk] window plan (device)

@@ -674,6 +674,112 @@ __global__ __launch_bounds__(BLK) void csr_rowgather_kernel(const StreamArgs<T> 
     }
 }
 
+// ---- row-pattern form (host plan: plan_rowpat, pamg_matrix.hip) for square operators with value codes whose rows are, nine
+// times out of ten, one of <= 255 lists of (column - row, value) pairs -- constant-coefficient stencils.  Lane l takes row
+// r0 + l and reads ONE byte: the number of its list; offsets and values come from a table in LDS (lanes of a wave mostly
+// share the list: broadcast reads), the gathers x[row + offset] of 64 consecutive rows are 64 consecutive values, the
+// products are added in the list's (= the row's storage) order.  Rows numbered 255 are walked through the code arrays like
+// csr_rowgather_kernel's rows, straight from global memory.  Per regular row the operator costs 1 byte instead of
+// 3 per entry + 4; bit-identical to every other form.
+template <typename T, int EPI>
+__device__ __forceinline__ RowPre<T> row_prefetch_noptr(const StreamArgs<T> &a, int r)
+{
+    RowPre<T> q;
+    q.lo = q.hi = 0;
+    q.row = r;
+    q.pos = r;
+    q.b = q.y = q.xo = q.d = T(0);
+    if constexpr (EPI >= EPI_JACOBI) q.d = a.diag[r];
+    if constexpr (EPI == EPI_RESID || EPI == EPI_AXPBY || EPI == EPI_ACC_AXPBY || EPI == EPI_SUMSQ || EPI >= EPI_JACOBI) q.b = a.b[r];
+    if constexpr (EPI == EPI_ACC || EPI == EPI_ACC_AXPBY || EPI == EPI_ACCSEQ) q.y = a.y[r];
+    if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B) q.xo = a.x[r];
+    return q;
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(BLK) void csr_rowpat_kernel(const StreamArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr bool SKIPD = EpiTraits<EPI>::need_cols;          // Jacobi family: the diagonal never enters the sum
+    const int tid = threadIdx.x, lmax = a.lmax, np = a.npat;
+    int *tl = reinterpret_cast<int *>(smem_raw);               // [256] lengths
+    int *to = tl + 256;                                        // [np * lmax] offsets
+    T *tv = reinterpret_cast<T *>(smem_raw + (((size_t)(256 + np * lmax) * sizeof(int) + 15) & ~(size_t)15));   // [np * lmax] values
+    T *vd = tv + (size_t)np * lmax;                            // value dictionary (irregular rows)
+    {
+        const int *gl = reinterpret_cast<const int *>(a.ptab);
+        const T *gv = reinterpret_cast<const T *>(gl + 256 + np * lmax);
+        for (int k = tid; k < 256 + np * lmax; k += BLK) tl[k] = gl[k];
+        for (int k = tid; k < np * lmax; k += BLK) tv[k] = gv[k];
+        if (tid < a.nvd) vd[tid] = a.vdict[tid];
+    }
+    double sq = 0.0;
+    int blk = (int)blockIdx.x;
+    if (a.flags & 2) {
+        const int chunk = (a.nblk + 7) >> 3;
+        blk = (blk & 7) * chunk + (blk >> 3);
+    }
+    const bool live = blk < a.nblk;
+    if (live && a.blkmap) blk = a.blkmap[blk];
+    int4 meta = make_int4(0, 0, 0, 0), wb = make_int4(0, 0, 0, 0);
+    if (live) { meta = a.blkmeta[blk]; wb = a.wbase[blk]; }
+    const int r0 = meta.x, r1 = meta.y;
+    int r = r0 + tid;
+    RowPre<T> q;
+    unsigned pidv = 255;
+    if (r < r1) { pidv = a.pid[r]; q = row_prefetch_noptr<T, EPI>(a, r); }
+    __syncthreads();                                           // tables in place
+    while (r < r1) {
+        T s = row_init<T, EPI>(q);
+        if (pidv != 255u) {
+            const int len = tl[pidv];
+            const int *po = to + pidv * lmax;
+            const T *pv = tv + pidv * lmax;
+            for (int j = 0; j < len; j += 8) {
+                int col[8];
+                T xv[8], av[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = (j + k < len) ? j + k : 0;                     // beyond the list: re-read its first entry
+                    col[k] = r + po[e];
+                    av[k] = pv[e];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[k] = a.x[col[k]];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (j + k < len && (!SKIPD || col[k] != r)) {
+                        const T pr = av[k] * xv[k];
+                        if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
+                        else s += pr;
+                    }
+                }
+            }
+        } else {
+            // an irregular row (a domain corner beyond the table, a halo row of a shard, a long row): codes from global memory
+            const int lo = a.Ap[r], hi = a.Ap[r + 1];
+            for (int p = lo; p < hi; ++p) {
+                const unsigned c = a.Aj16[p];
+                const unsigned w = c >> 14;
+                const int col = (w == 0 ? wb.x : w == 1 ? wb.y : w == 2 ? wb.z : wb.w) + (int)(c & 0x3FFFu);
+                if (!SKIPD || col != r) {
+                    const T pr = vd[a.Ax8[p]] * a.x[col];
+                    if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
+                    else s += pr;
+                }
+            }
+        }
+        row_finish<T, EPI, 0>(a, q, s, sq);
+        r += BLK;
+        if (r < r1) { pidv = a.pid[r]; q = row_prefetch_noptr<T, EPI>(a, r); }
+    }
+    if constexpr (EPI == EPI_SUMSQ) {
+        __syncthreads();
+        const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
+        if (threadIdx.x == 0 && live) a.partial[blk] = tot;
+    }
+}
+
 // Single-workgroup persistent sweep (gs_flow1_kernel): ONE workgroup walks all row ranges of a
 // schedule, level after level, with __syncthreads() between them -- the scheduler of choice when
 // the levels are so narrow (<= 2 row ranges on average) that there is nothing to share out.

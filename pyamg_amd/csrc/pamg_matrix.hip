@@ -110,6 +110,23 @@ int xw_launch(int epi, int grid, int lds, hipStream_t s, const StreamArgs<T> &a,
     return (int)hipGetLastError();
 }
 
+// row-pattern form (csr_rowpat_kernel): square operators with value codes and a row-pattern plan
+template <typename T>
+int launch_rowpat(int epi, int grid, const pamg_matrix_s *A, hipStream_t s, StreamArgs<T> a)
+{
+    a.pid = A->d_pid; a.ptab = A->d_ptab; a.npat = A->npat; a.lmax = A->pat_lmax;
+    const size_t tabs = (((size_t)(256 + A->npat * A->pat_lmax) * sizeof(int) + 15) & ~(size_t)15) + sizeof(T) * ((size_t)A->npat * A->pat_lmax + 256);
+    const int lds = (int)std::max(tabs + 16, (size_t)BLK * sizeof(double));
+#define PAMG_RP(E) case E: hipLaunchKernelGGL((csr_rowpat_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); break;
+    switch (epi) {
+        PAMG_RP(EPI_SET) PAMG_RP(EPI_ACC) PAMG_RP(EPI_RESID) PAMG_RP(EPI_AXPBY) PAMG_RP(EPI_ACC_AXPBY) PAMG_RP(EPI_SUMSQ)
+        PAMG_RP(EPI_ACCSEQ) PAMG_RP(EPI_JACOBI) PAMG_RP(EPI_JACOBI_B)
+        default: return 1;
+    }
+#undef PAMG_RP
+    return (int)hipGetLastError();
+}
+
 // row-gather form (csr_rowgather_kernel): operators streaming value codes, no over-long rows
 template <typename T>
 int launch_rowgather(int epi, int grid, int cap, int nvd, hipStream_t s, const StreamArgs<T> &a)
@@ -214,6 +231,158 @@ int plan_idx16(pamg_matrix_s *A, const std::vector<int4> &blk)
 // -0, NaN payloads stay apart) -- the stencils of the gallery: 2 values -- streams one byte per value instead of eight;
 // the kernel looks the value up in an LDS copy of the dictionary, so the product is formed from the very same bits.
 // vals: the scalar view's values on the host, in storage order.  Independent of the row-range plan.
+// Row patterns for the whole-operator kernels: on a constant-coefficient stencil almost every row is the same list of
+// (column - row, value) pairs -- 27 different lists on the 7-point grid stencil, boundaries included.  Where the most
+// frequent <= 255 lists cover >= 90 % of the rows of a square operator with value codes, a row stores ONE byte (the number
+// of its list) and the kernel (csr_rowpat_kernel) reads offsets and values from a table in LDS: no column codes, no value
+// codes, no row pointer for those rows -- 1 byte per row instead of 3 bytes per entry + 4 per row.  The other rows (number
+// 255: domain corners beyond the table, the halo rows of a row shard) are walked through the code arrays.  Same products,
+// same order.  code: the value codes on the host; dict: the value dictionary (bit patterns).
+constexpr int RPAT_LMAX = 32;            // entries per list
+constexpr int RPAT_TABLE_BYTES = 24 * 1024;
+
+struct RowPatKey {
+    int len;
+    int off[RPAT_LMAX];
+    unsigned char vc[RPAT_LMAX];
+    bool operator==(const RowPatKey &o) const
+    {
+        return len == o.len && std::memcmp(off, o.off, sizeof(int) * (size_t)len) == 0 && std::memcmp(vc, o.vc, (size_t)len) == 0;
+    }
+};
+
+static inline bool rowpat_key(const int *Ap, const int *Aj, const unsigned char *code, int64_t r, RowPatKey &k, uint64_t &h)
+{
+    const int lo = Ap[r], len = Ap[r + 1] - lo;
+    if (len > RPAT_LMAX) return false;
+    k.len = len;
+    h = 1469598103934665603ull ^ (uint64_t)len;
+    for (int j = 0; j < len; ++j) {
+        k.off[j] = Aj[lo + j] - (int)r;
+        k.vc[j] = code[(size_t)lo + j];
+        h = (h ^ (uint64_t)(uint32_t)k.off[j]) * 1099511628211ull;
+        h = (h ^ (uint64_t)k.vc[j]) * 1099511628211ull;
+    }
+    return true;
+}
+
+void drop_rowpat(pamg_matrix_s *A)
+{
+    if (A->d_pid) { hipFree(A->d_pid); A->d_pid = nullptr; }
+    if (A->d_ptab) { hipFree(A->d_ptab); A->d_ptab = nullptr; }
+    A->npat = 0; A->pat_lmax = 0;
+}
+
+template <typename U>
+static int plan_rowpat(pamg_matrix_s *A, const unsigned char *code, const U *dict)
+{
+    PhaseTimer pt_("plan_rowpat", A->nnz);
+    drop_rowpat(A);
+    if (A->nrows != A->ncols || A->R != 1 || A->C != 1 || A->nrows < 4096) return PAMG_OK;
+    const int64_t n = A->nrows;
+    const int *Ap = A->h_Ap.data(), *Aj = A->h_Aj.data();
+    struct Seen { uint64_t h; int64_t count; int64_t row; };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(64u, hw), n / (1 << 16)));
+    std::vector<std::vector<Seen>> seen((size_t)nt);
+    std::atomic<int> over(0);
+    auto scan = [&](int t) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        std::vector<Seen> &S = seen[(size_t)t];
+        RowPatKey k;
+        uint64_t h = 0;
+        size_t last = 0;
+        for (int64_t r = lo; r < hi; ++r) {
+            if (!rowpat_key(Ap, Aj, code, r, k, h)) continue;                  // a long row: irregular by definition
+            if (last < S.size() && S[last].h == h) { ++S[last].count; continue; }
+            size_t q = 0;
+            while (q < S.size() && S[q].h != h) ++q;
+            if (q == S.size()) {
+                if (S.size() >= 4096) { over = 1; return; }                    // no stencil: too many different rows
+                S.push_back(Seen{h, 0, r});
+            }
+            ++S[q].count;
+            last = q;
+        }
+    };
+    if (nt == 1) scan(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(scan, t);
+        for (auto &x : th) x.join();
+    }
+    if (over.load()) return PAMG_OK;
+    std::vector<Seen> all;
+    for (auto &S : seen)
+        for (const Seen &e : S) {
+            size_t q = 0;
+            while (q < all.size() && all[q].h != e.h) ++q;
+            if (q == all.size()) all.push_back(e);
+            else { all[q].count += e.count; all[q].row = std::min(all[q].row, e.row); }
+            if (all.size() > 16384) return PAMG_OK;
+        }
+    std::sort(all.begin(), all.end(), [](const Seen &a, const Seen &b) { return a.count != b.count ? a.count > b.count : a.row < b.row; });
+    // the table: as many of the most frequent lists as fit (<= 255, <= RPAT_TABLE_BYTES)
+    std::vector<RowPatKey> keys;
+    int lmax = 1;
+    int64_t covered = 0;
+    for (const Seen &e : all) {
+        if (keys.size() == 255) break;
+        RowPatKey k;
+        uint64_t h;
+        if (!rowpat_key(Ap, Aj, code, e.row, k, h)) continue;
+        const int lm = std::max(lmax, k.len);
+        if ((int64_t)(keys.size() + 1) * lm * (int64_t)(sizeof(int) + sizeof(U)) + 1024 > RPAT_TABLE_BYTES) break;
+        lmax = lm;
+        keys.push_back(k);
+        covered += e.count;
+    }
+    if (keys.empty() || covered * 10 < n * 9) return PAMG_OK;
+    lmax = (lmax + 1) & ~1;                           // keeps the value table 8-byte aligned behind the offsets
+    std::vector<uint64_t> kh(keys.size());
+    for (size_t q = 0; q < keys.size(); ++q) {
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)keys[q].len;
+        for (int j = 0; j < keys[q].len; ++j) {
+            h = (h ^ (uint64_t)(uint32_t)keys[q].off[j]) * 1099511628211ull;
+            h = (h ^ (uint64_t)keys[q].vc[j]) * 1099511628211ull;
+        }
+        kh[q] = h;
+    }
+    std::vector<unsigned char> pid((size_t)n + 16, 255);
+    host_parallel(n, [&](int64_t lo, int64_t hi) {
+        RowPatKey k;
+        uint64_t h = 0;
+        size_t last = 0;
+        for (int64_t r = lo; r < hi; ++r) {
+            if (!rowpat_key(Ap, Aj, code, r, k, h)) continue;
+            size_t q = last;
+            if (kh[q] != h) { q = 0; while (q < kh.size() && kh[q] != h) ++q; }
+            if (q < kh.size() && keys[q] == k) { pid[(size_t)r] = (unsigned char)q; last = q; }   // equal lists, not just equal hashes
+        }
+    }, 1 << 16);
+    // device table: [256] lengths | [npat * lmax] offsets | [npat * lmax] values
+    const int np_ = (int)keys.size();
+    const size_t tab_bytes = 256 * sizeof(int) + (size_t)np_ * lmax * (sizeof(int) + sizeof(U));
+    std::vector<unsigned char> tab(tab_bytes + 16, 0);
+    int *tl = reinterpret_cast<int *>(tab.data());
+    int *to = tl + 256;
+    U *tv = reinterpret_cast<U *>(to + (size_t)np_ * lmax);
+    for (int q = 0; q < np_; ++q) {
+        tl[q] = keys[(size_t)q].len;
+        for (int j = 0; j < keys[(size_t)q].len; ++j) {
+            to[(size_t)q * lmax + j] = keys[(size_t)q].off[j];
+            tv[(size_t)q * lmax + j] = dict[keys[(size_t)q].vc[j]];
+        }
+    }
+    size_t bytes = 0;
+    PAMG_TRY(upload_raw((void **)&A->d_pid, pid.data(), pid.size(), 1, &bytes));
+    PAMG_TRY(upload_raw(&A->d_ptab, tab.data(), tab.size(), 1, &bytes));
+    A->npat = np_;
+    A->pat_lmax = lmax;
+    A->bytes += bytes;
+    return PAMG_OK;
+}
+
 template <typename U>
 static int plan_val8_t(pamg_matrix_s *A, const U *v)
 {
@@ -270,7 +439,7 @@ static int plan_val8_t(pamg_matrix_s *A, const U *v)
     PAMG_TRY(upload_raw((void **)&A->d_Ax8, code.data(), code.size(), 1, &bytes));
     PAMG_TRY(upload_raw(&A->d_vdict, dict.data(), dict.size(), sizeof(U), &bytes));
     A->bytes += bytes;
-    return PAMG_OK;
+    return plan_rowpat<U>(A, code.data(), dict.data());
 }
 
 void drop_val8(pamg_matrix_s *A)
@@ -278,6 +447,7 @@ void drop_val8(pamg_matrix_s *A)
     if (A->d_Ax8) { hipFree(A->d_Ax8); A->d_Ax8 = nullptr; }
     if (A->d_vdict) { hipFree(A->d_vdict); A->d_vdict = nullptr; }
     A->nvdict = 0;
+    drop_rowpat(A);
 }
 
 int plan_val8(pamg_matrix_s *A, const void *vals)
@@ -821,6 +991,9 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.Ax8 = nullptr;             // set by stream_launch only, with the 16-bit column stream
     a.vdict = nullptr;
     a.nvd = 0;
+    a.pid = nullptr;
+    a.ptab = nullptr;
+    a.npat = a.lmax = 0;
     return a;
 }
 
@@ -886,11 +1059,13 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
         const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
         const int lds = lds_bytes(A->dtype, epi, A->cap) + (val8 ? val8_lds(A, epi) : 0);
         const bool rowg = val8 && A->use_rowg && A->max_row_len <= A->cap;
+        const bool rowp = val8 && A->use_rowpat && A->d_pid;
         if (A->dtype == PAMG_F64) {
             StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
             a.flags = A->stream_flags & ~2;
             a.nblk = n; a.blkmap = A->d_part[part - 1];
             if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+            if (rowp) { const int st = launch_rowpat<double>(epi, n, A, s, a); if (st != 1) return st; }
             if (rowg) { const int st = launch_rowgather<double>(epi, n, A->cap, A->nvdict, s, a); if (st != 1) return st; }
             return launch_any<double>(epi, A->npl, n, lds, s, a);
         }
@@ -898,6 +1073,7 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
         a.flags = A->stream_flags & ~2;
         a.nblk = n; a.blkmap = A->d_part[part - 1];
         if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+        if (rowp) { const int st = launch_rowpat<float>(epi, n, A, s, a); if (st != 1) return st; }
         if (rowg) { const int st = launch_rowgather<float>(epi, n, A->cap, A->nvdict, s, a); if (st != 1) return st; }
         return launch_any<float>(epi, A->npl, n, lds, s, a);
     }
@@ -915,16 +1091,19 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
     const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
     if (val8) lds += val8_lds(A, epi);
     const bool rowg = val8 && A->use_rowg && A->max_row_len <= A->cap;
+    const bool rowp = val8 && A->use_rowpat && A->d_pid;
     if (A->dtype == PAMG_F64) {
         StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
         a.flags = A->stream_flags;
         if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+        if (rowp) { const int st = launch_rowpat<double>(epi, grid, A, s, a); if (st != 1) return st; }
         if (rowg) { const int st = launch_rowgather<double>(epi, grid, A->cap, A->nvdict, s, a); if (st != 1) return st; }
         return launch_any<double>(epi, A->npl, grid, lds, s, a);
     }
     StreamArgs<float> a = base_args<float>(A, x, b, y, c, omega, partial);
     a.flags = A->stream_flags;
     if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+    if (rowp) { const int st = launch_rowpat<float>(epi, grid, A, s, a); if (st != 1) return st; }
     if (rowg) { const int st = launch_rowgather<float>(epi, grid, A->cap, A->nvdict, s, a); if (st != 1) return st; }
     return launch_any<float>(epi, A->npl, grid, lds, s, a);
 }
@@ -1812,7 +1991,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
 {
     if (!A) return PAMG_OK;
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag); hipFree(A->d_rowid);
-    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta); hipFree(A->d_Aj16); hipFree(A->d_wbase); hipFree(A->d_Ax8); hipFree(A->d_vdict);
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta); hipFree(A->d_Aj16); hipFree(A->d_wbase); hipFree(A->d_Ax8); hipFree(A->d_vdict); hipFree(A->d_pid); hipFree(A->d_ptab);
     hipFree(A->d_part[0]); hipFree(A->d_part[1]);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     for (int k = 0; k < 4; ++k) pamg::free_line_schedule(A->ls[k]);
@@ -1843,12 +2022,20 @@ int pamg_matrix_value_codes(pamg_matrix_t A, int *n_values)
     return PAMG_OK;
 }
 
+int pamg_matrix_row_patterns(pamg_matrix_t A, int *n_patterns)
+{
+    if (!A || !n_patterns) return PAMG_E_ARG;
+    *n_patterns = (A->d_pid && A->use_rowpat && A->d_Ax8 && A->use_val8 && A->use_idx16 && A->d_Aj16 && A->npl == 2) ? A->npat : 0;
+    return PAMG_OK;
+}
+
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
 {
     if (!A) return PAMG_E_ARG;
     // a finalised solver's captured graphs point into the schedules and plans this call would free
     if (key == 21) { A->use_val8 = value != 0; return PAMG_OK; }      // read at launch time only: no plan depends on it
     if (key == 22) { A->use_rowg = value != 0; return PAMG_OK; }      // likewise
+    if (key == 23) { A->use_rowpat = value != 0; return PAMG_OK; }
     if (A->borrowed > 0) return PAMG_E_STATE;
     switch (key) {
         case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~3; A->cap_from_val8 = 0; break;

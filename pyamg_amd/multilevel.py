@@ -104,6 +104,12 @@ class DeviceMatrix:
         capi.check(capi.lib().pamg_matrix_value_codes(self.handle, C.byref(n)), "pamg_matrix_value_codes")
         return int(n.value)
 
+    def row_patterns(self) -> int:
+        """size of the row-pattern table when the whole-operator kernels run in the row-pattern form, else 0"""
+        n = C.c_int(0)
+        capi.check(capi.lib().pamg_matrix_row_patterns(self.handle, C.byref(n)), "pamg_matrix_row_patterns")
+        return int(n.value)
+
     def tile_info(self, which=0):
         """plan of the tiled sweep (schedule 0 = forward, 1 = backward): dict, all zero if none is built"""
         a = (C.c_int64 * 8)()
@@ -114,12 +120,12 @@ class DeviceMatrix:
         return d
 
     def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, xwin=None, gs_prof=None,
-             tile_G=None, tile_W=None, tile_cap=None, tile_default=None, tile_D=None, tile_Q=None, tile_part=None, idx16=None, gs_cap=None, val8=None, rowgather=None):
+             tile_G=None, tile_W=None, tile_cap=None, tile_default=None, tile_D=None, tile_Q=None, tile_part=None, idx16=None, gs_cap=None, val8=None, rowgather=None, rowpat=None):
         """Speed-only knobs (every setting computes the same bits).  Refused (PAMG_E_STATE) once a solver holds the
         operator: captured graphs point into the plans these calls rebuild."""
         lib = capi.lib()
         for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (9, xwin), (11, gs_prof),
-                       (12, tile_G), (13, tile_W), (14, tile_cap), (15, tile_default), (16, tile_D), (17, tile_Q), (18, tile_part), (19, idx16), (20, gs_cap), (21, val8), (22, rowgather)):
+                       (12, tile_G), (13, tile_W), (14, tile_cap), (15, tile_default), (16, tile_D), (17, tile_Q), (18, tile_part), (19, idx16), (20, gs_cap), (21, val8), (22, rowgather), (23, rowpat)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 

@@ -773,18 +773,32 @@ def test_8bit_value_codes_are_bit_identical(dtype):
     long_row = banded([1.0, -2.0, 0.5]).tolil()
     long_row[17, :6000] = rng.choice([3.0, -1.5], size=6000)
     long_row = long_row.tocsr()
-    cases = [(P3, 2), (A256, 256), (A257, 0), (long_row, 5), (sp.bsr_array(poisson_csr((300, 300)), blocksize=(1, 1)), 2)]
-    for A, expect in cases:
+    # a stencil with 400 rows of their own (two entries of each changed to one of 20 x 20 value pairs): more lists than the
+    # table holds -> the rows outside it take the code arrays inside the row-pattern kernel
+    odd = P3.tolil()
+    extra = 1.0 + np.arange(20) / 32.0
+    for k in range(400):
+        i = 5000 + 37 * k
+        odd[i, i - 1] = -extra[k % 20]
+        odd[i, i + 1] = -extra[k // 20]
+    odd = sp.csr_array(odd.tocsr())
+    cases = [(P3, 2, 27), (A256, 256, 0), (A257, 0, 0), (long_row, 5, None), (sp.bsr_array(poisson_csr((300, 300)), blocksize=(1, 1)), 2, 9),
+             (odd, 21, 255)]
+    for A, expect, npat in cases:
         A = A.astype(dtype)
         n = A.shape[0]
         x, b = rng.rand(n).astype(dtype), rng.rand(n).astype(dtype)
         dA = DeviceMatrix(sparse_op(A))
-        assert dA.value_codes() == expect
+        if npat is None:                            # 3 values on 5 diagonals: up to 243 lists + the long row, which no list holds
+            npat = dA.row_patterns()
+            assert npat > 100
+        assert dA.value_codes() == expect and dA.row_patterns() == npat, (dA.value_codes(), dA.row_patterns())
         dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
         out = {}
-        for flag in (2, 1, 0):                      # 2: codes + row-gather kernel (the default), 1: codes + staged kernel, 0: values as stored
-            dA.tune(val8=min(flag, 1), rowgather=int(flag == 2))
-            assert dA.value_codes() == (expect if flag else 0)
+        # 3: row patterns (the default where a table exists), 2: codes + row-gather kernel, 1: codes + staged kernel, 0: values as stored
+        for flag in (3, 2, 1, 0):
+            dA.tune(val8=min(flag, 1), rowgather=int(flag >= 2), rowpat=int(flag == 3))
+            assert dA.value_codes() == (expect if flag else 0) and dA.row_patterns() == (npat if flag == 3 else 0)
             dy = capi.DeviceArray(n, dtype)
             dA.spmv(capi.SPMV_RESID, dx, dy, b=db)
             dz = capi.DeviceArray(n, dtype)
@@ -794,12 +808,12 @@ def test_8bit_value_codes_are_bit_identical(dtype):
             dA.jacobi(dj, db, dw, 0.8, iterations=2)
             out[flag] = (dy.download(), dz.download(), dj.download())
         for k in range(3):
-            assert np.array_equal(out[0][k], out[1][k], equal_nan=True) and np.array_equal(out[0][k], out[2][k], equal_nan=True)
+            assert all(np.array_equal(out[0][k], out[f][k], equal_nan=True) for f in (1, 2, 3)), k
         # the remaining epilogues of the row-gather kernel against the staged kernel on the values as stored
-        dA.tune(val8=1, rowgather=1)
+        dA.tune(val8=1, rowgather=1, rowpat=1)
         res = {}
-        for flag in (1, 0):
-            dA.tune(val8=flag, rowgather=flag)
+        for flag in (2, 1, 0):
+            dA.tune(val8=min(flag, 1), rowgather=min(flag, 1), rowpat=int(flag == 2))
             dy = capi.DeviceArray.from_host(b)
             dA.spmv(capi.SPMV_ACC, dx, dy)
             d2 = capi.DeviceArray.from_host(x)
@@ -810,8 +824,8 @@ def test_8bit_value_codes_are_bit_identical(dtype):
             dA.resid_sumsq(dx, db, o)
             res[flag] = (dy.download(), d2.download(), d3.download(), o.download())
         for k in range(4):
-            assert np.array_equal(res[0][k], res[1][k], equal_nan=True), k
-        dA.tune(val8=1, rowgather=1)
+            assert np.array_equal(res[0][k], res[1][k], equal_nan=True) and np.array_equal(res[0][k], res[2][k], equal_nan=True), k
+        dA.tune(val8=1, rowgather=1, rowpat=1)
         if dtype == np.float64:
             assert np.array_equal(out[1][1], sp.csr_array(A) @ x)
         dA.free()

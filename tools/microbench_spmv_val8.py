@@ -57,11 +57,17 @@ def run(tag, **tune):
 
 plan0 = dA.info()
 print("default plan of the operator:", plan0, flush=True)
+print("row patterns:", dA.row_patterns(), flush=True)
 for fl in (0, 1, 2, 3):
-    run(f"rowgather_default_plan_flags{fl}", stream_flags=fl)
-run("values_as_stored_staged_cap1536", val8=0, rowgather=0, lds_entries=1536, max_rows=1024, stream_flags=0)
+    run(f"rowpat_default_plan_flags{fl}", stream_flags=fl, rowpat=1)
+for mr, cap in ((256, 2048), (512, 3584), (1024, 7168)):
+    run(f"rowpat_rows{mr}", stream_flags=0, rowpat=1, lds_entries=cap, max_rows=mr)
+dA.tune(lds_entries=3584, max_rows=512)
+for fl in (0, 3):
+    run(f"rowgather_default_plan_flags{fl}", stream_flags=fl, rowpat=0)
+run("values_as_stored_staged_cap1536", val8=0, rowgather=0, rowpat=0, lds_entries=1536, max_rows=1024, stream_flags=0)
 run("codes_staged_cap2048", val8=1, rowgather=0, lds_entries=2048, max_rows=1024)
-for cap, mr in ((2048, 1024), (1792, 256), (3584, 512), (5376, 768), (7168, 1024)):
+for cap, mr in ((3584, 512),):
     run(f"rowgather_cap{cap}_rows{mr}", val8=1, rowgather=1, lds_entries=cap, max_rows=mr)
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
 (ROOT / "gpurun_out" / "microbench_spmv_val8_r03.json").write_text(json.dumps(out, indent=1))

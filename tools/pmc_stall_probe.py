@@ -33,7 +33,7 @@ for var in variants:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 for r in csv.DictReader(fh):
-                    if any(k in r.get("Kernel_Name", "") for k in ("csr_stream", "csr_rowgather")) and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= (4096 * 256 if LEVEL1 else 256 * 1024):
+                    if any(k in r.get("Kernel_Name", "") for k in ("csr_stream", "csr_rowgather", "csr_rowpat")) and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= (4096 * 256 if LEVEL1 else 256 * 1024):
                         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in acc.items():
             rec[k] = round(sum(v) / len(v), 1)

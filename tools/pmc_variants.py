@@ -18,7 +18,7 @@ for var in variants:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 for r in csv.DictReader(fh):
-                    if r.get("Counter_Name") == cname and any(k in r.get("Kernel_Name", "") for k in ("csr_stream", "csr_rowgather")) and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= 256 * 1024:
+                    if r.get("Counter_Name") == cname and any(k in r.get("Kernel_Name", "") for k in ("csr_stream", "csr_rowgather", "csr_rowpat")) and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= 256 * 1024:
                         tot += float(r["Counter_Value"]); cnt += 1
         rec[cname] = (tot / cnt * 1024) if cnt else None       # KiB -> bytes
     if rec.get("FETCH_SIZE"):

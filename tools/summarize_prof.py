@@ -17,9 +17,9 @@ def short(name):
     epi = ["SET", "ACC", "RESID", "AXPBY", "ACC_AXPBY", "SUMSQ", "ACCSEQ", "JACOBI", "JACOBI_B", "GS", "GS_B", "SOR"]
     if m:
         return f"csr_stream<{m.group(1)},{epi[int(m.group(2))]},npl{m.group(3)}>"
-    m = re.search(r"csr_rowgather_kernel<(\w+), *(\d+)>", name)
+    m = re.search(r"csr_(rowgather|rowpat)_kernel<(\w+), *(\d+)>", name)
     if m:
-        return f"csr_rowgather<{m.group(1)},{epi[int(m.group(2))]}>"
+        return f"csr_{m.group(1)}<{m.group(2)},{epi[int(m.group(3))]}>"
     name = name.replace("(anonymous namespace)::", "")
     return re.sub(r"\(.*", "", name)[:70]
 
