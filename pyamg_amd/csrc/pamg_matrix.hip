@@ -10,6 +10,7 @@
 #include "pamg_kernels.h"
 #include "pamg_tile_kernels.h"
 #include "pamg_tile_plan.h"
+#include "pamg_stream_plan.h"
 
 using namespace pamg;
 
@@ -42,19 +43,12 @@ int upload_raw(void **dptr, const void *h, size_t n, size_t elt, size_t *bytes)
     return PAMG_OK;
 }
 
-// Greedy split of rows [begin,end) of a CSR row pointer into workgroup row ranges holding
-// at most `cap` stored entries and `max_rows` rows.  A row longer than `cap` gets a range
-// of its own (the kernel streams it in chunks).  Appends {r0, r1, p0, p1} per range.
+// row ranges: plan_row_ranges (pamg_stream_plan.h) as int4 {r0, r1, p0, p1}
 void plan_rows(const int *Ap, int begin, int end, int cap, int max_rows, std::vector<int4> &out)
 {
-    int r = begin;
-    while (r < end) {
-        const int p0 = Ap[r];
-        int e = r + 1;
-        while (e < end && e - r < max_rows && Ap[e + 1] - p0 <= cap) ++e;
-        out.push_back(make_int4(r, e, p0, Ap[e]));
-        r = e;
-    }
+    std::vector<RowRange> rr;
+    plan_row_ranges(Ap, begin, end, cap, max_rows, rr);
+    for (const RowRange &q : rr) out.push_back(make_int4(q.r0, q.r1, q.p0, q.p1));
 }
 
 int lds_bytes(int dtype, int epi, int cap)
@@ -197,26 +191,8 @@ int plan_idx16(pamg_matrix_s *A, const std::vector<int4> &blk)
     parallel_rows(nb, [&](int lo, int hi) {
         std::vector<int> c;
         for (int b = lo; b < hi && ok.load(std::memory_order_relaxed); ++b) {
-            const int p0 = blk[b].z, p1 = blk[b].w;
-            int base[4] = {0, 0, 0, 0};
-            if (p1 > p0) {
-                c.assign(Aj + p0, Aj + p1);
-                std::sort(c.begin(), c.end());
-                int nw = 0;
-                for (int v : c) {
-                    if (nw == 0 || v >= base[nw - 1] + 16384) {
-                        if (nw == 4) { ok = 0; break; }
-                        base[nw++] = v;
-                    }
-                }
-                if (!ok.load(std::memory_order_relaxed)) break;
-                for (int p = p0; p < p1; ++p) {
-                    const int v = Aj[p];
-                    int w = nw - 1;
-                    while (w > 0 && v < base[w]) --w;
-                    code[(size_t)p] = (unsigned short)((w << 14) | (v - base[w]));
-                }
-            }
+            int base[4];
+            if (!plan_range_windows(Aj, blk[b].z, blk[b].w, base, code.data(), c)) { ok = 0; break; }
             wb[(size_t)b] = make_int4(base[0], base[1], base[2], base[3]);
         }
     });
@@ -227,45 +203,8 @@ int plan_idx16(pamg_matrix_s *A, const std::vector<int4> &blk)
     return PAMG_OK;
 }
 
-// 8-bit value codes for the whole-operator kernels: an operator with at most 256 distinct values (bit patterns: +0 and
-// -0, NaN payloads stay apart) -- the stencils of the gallery: 2 values -- streams one byte per value instead of eight;
-// the kernel looks the value up in an LDS copy of the dictionary, so the product is formed from the very same bits.
-// vals: the scalar view's values on the host, in storage order.  Independent of the row-range plan.
-// Row patterns for the whole-operator kernels: on a constant-coefficient stencil almost every row is the same list of
-// (column - row, value) pairs -- 27 different lists on the 7-point grid stencil, boundaries included.  Where the most
-// frequent <= 255 lists cover >= 90 % of the rows of a square operator with value codes, a row stores ONE byte (the number
-// of its list) and the kernel (csr_rowpat_kernel) reads offsets and values from a table in LDS: no column codes, no value
-// codes, no row pointer for those rows -- 1 byte per row instead of 3 bytes per entry + 4 per row.  The other rows (number
-// 255: domain corners beyond the table, the halo rows of a row shard) are walked through the code arrays.  Same products,
-// same order.  code: the value codes on the host; dict: the value dictionary (bit patterns).
-constexpr int RPAT_LMAX = 32;            // entries per list
-constexpr int RPAT_TABLE_BYTES = 24 * 1024;
-
-struct RowPatKey {
-    int len;
-    int off[RPAT_LMAX];
-    unsigned char vc[RPAT_LMAX];
-    bool operator==(const RowPatKey &o) const
-    {
-        return len == o.len && std::memcmp(off, o.off, sizeof(int) * (size_t)len) == 0 && std::memcmp(vc, o.vc, (size_t)len) == 0;
-    }
-};
-
-static inline bool rowpat_key(const int *Ap, const int *Aj, const unsigned char *code, int64_t r, RowPatKey &k, uint64_t &h)
-{
-    const int lo = Ap[r], len = Ap[r + 1] - lo;
-    if (len > RPAT_LMAX) return false;
-    k.len = len;
-    h = 1469598103934665603ull ^ (uint64_t)len;
-    for (int j = 0; j < len; ++j) {
-        k.off[j] = Aj[lo + j] - (int)r;
-        k.vc[j] = code[(size_t)lo + j];
-        h = (h ^ (uint64_t)(uint32_t)k.off[j]) * 1099511628211ull;
-        h = (h ^ (uint64_t)k.vc[j]) * 1099511628211ull;
-    }
-    return true;
-}
-
+// Row patterns / value codes of the whole-operator kernels: the plans are plain host code (pamg_stream_plan.h, replayed
+// on the CPU by tests/stream_emul.cpp); here they are run on the operator's host arrays and shipped.
 void drop_rowpat(pamg_matrix_s *A)
 {
     if (A->d_pid) { hipFree(A->d_pid); A->d_pid = nullptr; }
@@ -279,87 +218,10 @@ static int plan_rowpat(pamg_matrix_s *A, const unsigned char *code, const U *dic
     PhaseTimer pt_("plan_rowpat", A->nnz);
     drop_rowpat(A);
     if (A->nrows != A->ncols || A->R != 1 || A->C != 1 || A->nrows < 4096) return PAMG_OK;
-    const int64_t n = A->nrows;
-    const int *Ap = A->h_Ap.data(), *Aj = A->h_Aj.data();
-    struct Seen { uint64_t h; int64_t count; int64_t row; };
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(64u, hw), n / (1 << 16)));
-    std::vector<std::vector<Seen>> seen((size_t)nt);
-    std::atomic<int> over(0);
-    auto scan = [&](int t) {
-        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
-        std::vector<Seen> &S = seen[(size_t)t];
-        RowPatKey k;
-        uint64_t h = 0;
-        size_t last = 0;
-        for (int64_t r = lo; r < hi; ++r) {
-            if (!rowpat_key(Ap, Aj, code, r, k, h)) continue;                  // a long row: irregular by definition
-            if (last < S.size() && S[last].h == h) { ++S[last].count; continue; }
-            size_t q = 0;
-            while (q < S.size() && S[q].h != h) ++q;
-            if (q == S.size()) {
-                if (S.size() >= 4096) { over = 1; return; }                    // no stencil: too many different rows
-                S.push_back(Seen{h, 0, r});
-            }
-            ++S[q].count;
-            last = q;
-        }
-    };
-    if (nt == 1) scan(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(scan, t);
-        for (auto &x : th) x.join();
-    }
-    if (over.load()) return PAMG_OK;
-    std::vector<Seen> all;
-    for (auto &S : seen)
-        for (const Seen &e : S) {
-            size_t q = 0;
-            while (q < all.size() && all[q].h != e.h) ++q;
-            if (q == all.size()) all.push_back(e);
-            else { all[q].count += e.count; all[q].row = std::min(all[q].row, e.row); }
-            if (all.size() > 16384) return PAMG_OK;
-        }
-    std::sort(all.begin(), all.end(), [](const Seen &a, const Seen &b) { return a.count != b.count ? a.count > b.count : a.row < b.row; });
-    // the table: as many of the most frequent lists as fit (<= 255, <= RPAT_TABLE_BYTES)
+    std::vector<unsigned char> pid;
     std::vector<RowPatKey> keys;
-    int lmax = 1;
-    int64_t covered = 0;
-    for (const Seen &e : all) {
-        if (keys.size() == 255) break;
-        RowPatKey k;
-        uint64_t h;
-        if (!rowpat_key(Ap, Aj, code, e.row, k, h)) continue;
-        const int lm = std::max(lmax, k.len);
-        if ((int64_t)(keys.size() + 1) * lm * (int64_t)(sizeof(int) + sizeof(U)) + 1024 > RPAT_TABLE_BYTES) break;
-        lmax = lm;
-        keys.push_back(k);
-        covered += e.count;
-    }
-    if (keys.empty() || covered * 10 < n * 9) return PAMG_OK;
-    lmax = (lmax + 1) & ~1;                           // keeps the value table 8-byte aligned behind the offsets
-    std::vector<uint64_t> kh(keys.size());
-    for (size_t q = 0; q < keys.size(); ++q) {
-        uint64_t h = 1469598103934665603ull ^ (uint64_t)keys[q].len;
-        for (int j = 0; j < keys[q].len; ++j) {
-            h = (h ^ (uint64_t)(uint32_t)keys[q].off[j]) * 1099511628211ull;
-            h = (h ^ (uint64_t)keys[q].vc[j]) * 1099511628211ull;
-        }
-        kh[q] = h;
-    }
-    std::vector<unsigned char> pid((size_t)n + 16, 255);
-    host_parallel(n, [&](int64_t lo, int64_t hi) {
-        RowPatKey k;
-        uint64_t h = 0;
-        size_t last = 0;
-        for (int64_t r = lo; r < hi; ++r) {
-            if (!rowpat_key(Ap, Aj, code, r, k, h)) continue;
-            size_t q = last;
-            if (kh[q] != h) { q = 0; while (q < kh.size() && kh[q] != h) ++q; }
-            if (q < kh.size() && keys[q] == k) { pid[(size_t)r] = (unsigned char)q; last = q; }   // equal lists, not just equal hashes
-        }
-    }, 1 << 16);
+    int lmax = 0;
+    if (!plan_row_patterns(A->nrows, A->h_Ap.data(), A->h_Aj.data(), code, sizeof(U), pid, keys, lmax)) return PAMG_OK;
     // device table: [256] lengths | [npat * lmax] offsets | [npat * lmax] values
     const int np_ = (int)keys.size();
     const size_t tab_bytes = 256 * sizeof(int) + (size_t)np_ * lmax * (sizeof(int) + sizeof(U));
@@ -383,56 +245,16 @@ static int plan_rowpat(pamg_matrix_s *A, const unsigned char *code, const U *dic
     return PAMG_OK;
 }
 
+// 8-bit value codes for the whole-operator kernels: an operator with at most 256 distinct values (bit patterns: +0 and
+// -0, NaN payloads stay apart) -- the stencils of the gallery: 2 values -- streams one byte per value instead of eight;
+// the kernel looks the value up in an LDS copy of the dictionary, so the product is formed from the very same bits.
+// v: the scalar view's values on the host, in storage order.  Independent of the row-range plan.
 template <typename U>
 static int plan_val8_t(pamg_matrix_s *A, const U *v)
 {
-    const int64_t n = A->nnz;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(64u, hw), n / (1 << 20)));
-    std::vector<std::vector<U>> sets((size_t)nt);
-    std::atomic<int> over(0);
-    auto scan = [&](int t) {
-        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
-        std::vector<U> &d = sets[(size_t)t];
-        U last = 0;
-        bool have = false;
-        for (int64_t p = lo; p < hi; ++p) {
-            const U x = v[p];
-            if (have && x == last) continue;
-            last = x; have = true;
-            auto it = std::lower_bound(d.begin(), d.end(), x);
-            if (it != d.end() && *it == x) continue;
-            if (d.size() == 256) { over = 1; return; }
-            d.insert(it, x);
-            if ((p & 0xFFFF) == 0 && over.load(std::memory_order_relaxed)) return;
-        }
-    };
-    if (nt == 1) scan(0);
-    else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(scan, t);
-        for (auto &x : th) x.join();
-    }
-    if (over.load()) return PAMG_OK;
     std::vector<U> dict;
-    for (auto &d : sets) dict.insert(dict.end(), d.begin(), d.end());
-    std::sort(dict.begin(), dict.end());
-    dict.erase(std::unique(dict.begin(), dict.end()), dict.end());
-    if (dict.size() > 256 || dict.empty()) return PAMG_OK;
-    std::vector<unsigned char> code((size_t)n + 16, 0);
-    host_parallel(n, [&](int64_t lo, int64_t hi) {
-        U last = 0;
-        unsigned char lc = 0;
-        bool have = false;
-        for (int64_t p = lo; p < hi; ++p) {
-            const U x = v[p];
-            if (!have || x != last) {
-                last = x; have = true;
-                lc = (unsigned char)(std::lower_bound(dict.begin(), dict.end(), x) - dict.begin());
-            }
-            code[(size_t)p] = lc;
-        }
-    }, 1 << 20);
+    std::vector<unsigned char> code;
+    if (!plan_value_codes(A->nnz, v, dict, code)) return PAMG_OK;
     A->nvdict = (int)dict.size();
     dict.resize(256, 0);
     size_t bytes = 0;

@@ -783,7 +783,7 @@ def test_8bit_value_codes_are_bit_identical(dtype):
         odd[i, i + 1] = -extra[k // 20]
     odd = sp.csr_array(odd.tocsr())
     cases = [(P3, 2, 27), (A256, 256, 0), (A257, 0, 0), (long_row, 5, None), (sp.bsr_array(poisson_csr((300, 300)), blocksize=(1, 1)), 2, 9),
-             (odd, 21, 255)]
+             (odd, 21, 245 if dtype == np.float64 else 255)]       # 8-entry lists: 245 of them fill the 24 KB table in f64
     for A, expect, npat in cases:
         A = A.astype(dtype)
         n = A.shape[0]

@@ -259,3 +259,77 @@ def test_product_replay_true_blocks(spg):
     Cb = C.tobsr(blocksize=(2, 3))
     assert np.array_equal(Cb.indptr, ref.indptr) and np.array_equal(Cb.indices, ref.indices) and np.array_equal(Cb.data, ref.data)
 
+
+
+# --------------------------------------------------------------------------- compressed operator streams (solve phase)
+@pytest.fixture(scope="module")
+def stream_emul():
+    out = HERE / "build"
+    out.mkdir(exist_ok=True)
+    so = out / "stream_emul.so"
+    src = HERE / "stream_emul.cpp"
+    hdr = HERE.parent / "pyamg_amd" / "csrc" / "pamg_stream_plan.h"
+    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def _stream_replay(lib, A, x, cap=1536, max_rows=1024):
+    A = sp.csr_array(A)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)       # noqa: E731
+    Ap, Aj = np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32)
+    Ax = np.ascontiguousarray(A.data, dtype=np.float64)
+    n = A.shape[0]
+    ys = [np.zeros(n) for _ in range(3)]
+    info = np.zeros(6, dtype=np.int64)
+    assert lib.stream_emul_f64(n, p(Ap), p(Aj), p(Ax), p(x), cap, max_rows, p(ys[0]), p(ys[1]), p(ys[2]), p(info)) == 0
+    return ys, info
+
+
+def test_compressed_operator_streams_deliver_the_csr(stream_emul):
+    """The host plans of the whole-operator kernels' streams (csrc/pamg_stream_plan.h: column windows, value codes, row
+    patterns) decoded on the CPU the way the kernels decode them: every form hands back the CSR's own (column, value)
+    pairs in storage order -- so y = A x has SciPy's bits -- on a 3-D stencil (27 lists), a stencil with more odd rows than
+    the table holds (irregular rows walk the code arrays), operators with 256 / 257 distinct values, unsorted rows, and a
+    wide operator whose ranges need a fifth column window."""
+    from tools.problems import poisson_csr
+    rng = np.random.default_rng(4)
+    P3 = poisson_csr((24, 24, 24))
+    x = rng.random(P3.shape[0])
+    (y16, y8, ypat), info = _stream_replay(stream_emul, P3, x)
+    ref = P3 @ x
+    assert info[0] == 1 and info[1] == 2 and info[2] == 27 and info[3] == 0 and info[4] == 0
+    assert np.array_equal(y16, ref) and np.array_equal(y8, ref) and np.array_equal(ypat, ref)
+    # range plans of the row-gather / row-pattern kernels (512 rows) give the same
+    (_, _, ypat2), info2 = _stream_replay(stream_emul, P3, x, cap=3584, max_rows=512)
+    assert np.array_equal(ypat2, ref) and info2[5] < info[5]
+    # more different rows than the table holds
+    odd = P3.tolil()
+    extra = 1.0 + np.arange(20) / 32.0
+    for k in range(400):
+        i = 3000 + 23 * k
+        odd[i, i - 1] = -extra[k % 20]
+        odd[i, i + 1] = -extra[k // 20]
+    odd = sp.csr_array(odd.tocsr())
+    (y16, y8, ypat), info = _stream_replay(stream_emul, odd, x)
+    assert info[1] == 21 and info[2] == 245 and info[3] > 100 and info[4] == 0       # 245 lists of 8 entries fill the 24 KB table
+    assert np.array_equal(ypat, odd @ x) and np.array_equal(y8, odd @ x)
+    # 256 distinct values (codes) and 257 (none); unsorted rows keep their order
+    nn = 6000
+    cols = (np.arange(nn)[:, None] + np.array([-40, -1, 0, 1, 40])[None, :]) % nn
+    v256 = np.concatenate([[0.0, -0.0], rng.standard_normal(254)])
+    for vals, nv in ((v256, 256), (np.concatenate([v256, [7.25]]), 0)):
+        data = rng.choice(vals, size=cols.size)
+        data[:vals.size] = vals
+        B = sp.csr_array((data, cols.ravel().astype(np.int32), np.arange(0, cols.size + 1, 5, dtype=np.int32)), shape=(nn, nn))
+        xb = rng.random(nn)
+        (y16, y8, ypat), info = _stream_replay(stream_emul, B, xb)
+        assert info[0] == 1 and info[1] == nv and info[4] == 0
+        assert np.array_equal(y16, B @ xb)
+        assert np.array_equal(y8, B @ xb) if nv else np.isnan(y8).all()
+    # a wide random operator: some range needs a fifth window of 16 K columns -> no 16-bit stream at all
+    nw = 90000
+    W = sp.csr_array((rng.random(nw * 12), rng.integers(0, nw, size=nw * 12).astype(np.int32), np.arange(0, nw * 12 + 1, 12, dtype=np.int32)),
+                     shape=(nw, nw))
+    (y16, _, _), info = _stream_replay(stream_emul, W, rng.random(nw))
+    assert info[0] == 0 and np.isnan(y16).all()
