@@ -217,7 +217,9 @@ static int plan_rowpat(pamg_matrix_s *A, const unsigned char *code, const U *dic
 {
     PhaseTimer pt_("plan_rowpat", A->nnz);
     drop_rowpat(A);
-    if (A->nrows != A->ncols || A->R != 1 || A->C != 1 || A->nrows < 4096) return PAMG_OK;
+    // square operators, and row shards in local numbering [owned | halo]: their owned block sits on the diagonal, so interior
+    // rows keep the stencil's lists; rows with halo columns come out as irregular rows
+    if (A->ncols < A->nrows || A->R != 1 || A->C != 1 || A->nrows < 4096) return PAMG_OK;
     std::vector<unsigned char> pid;
     std::vector<RowPatKey> keys;
     int lmax = 0;
