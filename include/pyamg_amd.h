@@ -332,6 +332,15 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * entries of 64 consecutive rows in one gather instruction (coalesced on stencils), products summed in storage order in
  * registers; 0 = the LDS-staged kernel on the codes;
  * 23 = row-pattern form (default 1 where plan_rowpat found a table, see pamg_matrix_row_patterns).
+ * NOT speed-only -- 24 = ORDER of the row sums of the scalar Gauss-Seidel / SOR sweeps: 0 (default of a bare operator) =
+ * order-exact, every sum runs in storage order with an IEEE division, results are the reference's bit for bit
+ * (amg_core/relaxation.h:48-76,116-145,185-266); 1 = FAST order: the same sweep order over the rows (same dependency
+ * DAG, same iterates in exact arithmetic), but L lanes of a wave share a row, add their products in parallel (DPP
+ * butterfly) and finish with (b - sum) * (1 / a_ii) -- agrees with the reference to rounding (a few ulp per sweep), which
+ * is what BASELINE's "residual norms within 1e-10" asks for; schedules the lane form cannot hold (rows with more than
+ * 256 off-diagonal entries, padding above 4x) keep the exact kernels.  25 = lanes per row of the fast order (0 = automatic,
+ * else 4|8|16|32|64), 26 = its persistent workgroups (0 = automatic), 27 = 1: the fast order also takes wide schedules
+ * (>= 2048 rows per dependency level), which the tiled exact sweep keeps by default.
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes
@@ -355,6 +364,12 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
  * flight << 24, steps, early entries served from LDS, early entries served by the global hand-off, publishing
  * rows, LDS bytes}; all zero when that schedule has no tile plan. */
 int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8]);
+/* Layout of the lane-parallel fast-order sweep (tune key 24) for schedule `which`: {lanes per row, entry slots per lane,
+ * groups (one wave each), entry slots, entries that wait for a new value, entries that read an old value, groups of the
+ * widest dependency level, bytes}; all zero when that schedule has no lane layout.  pamg_matrix_lane_profile: with tune
+ * key 11, per group four 64-bit words {start, last operand seen, published (wall clock, 10 ns), XCD | workgroup << 4}. */
+int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8]);
+int pamg_matrix_lane_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count);
 /* Row-subset copy of a CSR operator (rows: HOST list, kept in list order) for the indexed smoothers,
  * and amg_core::jacobi_indexed (relaxation.h:382-427) on it: every listed row of x is relaxed from the
  * OLD x (x, b: DEVICE vectors of the parent's size; work: DEVICE, one value per listed row). */

@@ -115,6 +115,8 @@ struct GsSchedule {
     int cap = 0;                     // entries per row range of the level-permuted copy (the LDS window its kernels run with)
     struct TileSched *tile = nullptr; // tiled sweep (pamg_tile_plan.h / pamg_tile_kernels.h), built on demand
     bool tile_unfit = false;         // the tile planner declined this schedule (a step would not fit): other schedulers run it
+    struct LaneSched *lane = nullptr; // lane-parallel "fast order" sweep (pamg_lane_plan.h / pamg_lane.hip), built on demand
+    bool lane_unfit = false;         // the lane planner declined this schedule (rows too long / padding too wasteful)
 };
 
 // Device side of a tile plan: the step blocks (pamg_tile_plan.h: one fixed-size block of entry codes, values and
@@ -195,6 +197,10 @@ struct pamg_matrix_s {
     int max_row_len = 0;             // longest row of the scalar view
     int borrowed = 0;                // solvers holding this operator (tuning is refused while > 0: captured graphs point into the schedules)
     int gs_prof = 0;                 // granular sweep: record per-range time stamps (tune key 11, diagnostics)
+    int gs_order = 0;                // tune key 24: 0 = order-exact row sums (bit-identical to the reference), 1 = fast order: lane-parallel row
+                                     //   sums and multiplication by 1/a_ii (same sweep order; agrees to rounding) where the schedule fits that form
+    int lane_L = 0, lane_G = 0;      // fast order: lanes per row (0 = automatic) / persistent workgroups (0 = automatic)   (tune keys 25, 26)
+    int lane_wide = 0;               // fast order on wide schedules (>= 2048 rows per dependency level): 0 = the tiled exact sweep keeps them, 1 = lane form   (tune key 27)
     int gs_cap = 0;                  // entries per row range of the level schedules (tune key 20; 0 = automatic: `cap`, 512 on the multi-XCD granular sweep of SA-like rows)
     int nblk = 0;
     int *d_part[2] = {nullptr, nullptr};   // row shards (pamg_dist.hip): row ranges that read owned columns only / that read the halo
@@ -251,6 +257,15 @@ int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step)
 struct CsrArrays { int64_t m, n, nnz; const int *p, *j; const double *x; };
 int csr_device_arrays(struct ::pamg_csr_s *A, CsrArrays *out);                                  // pamg_setup.hip: the device arrays behind a pamg_csr_t
 int solver_cycle_inline(pamg_solver_s *S, void *x, const void *b, int cycle, int cpl, hipStream_t s, bool allow_graph);   // pamg_solver.hip
+bool solver_needs_host_sync(const pamg_solver_s *S);                                                                   // pamg_solver.hip
+// pamg_lane.hip: the lane-parallel fast-order sweep
+bool lane_eligible(const pamg_matrix_s *A, const GsSchedule *g);
+int build_lane_part(pamg_matrix_s *A, GsSchedule *g);
+void free_lane_part(LaneSched *t);
+size_t lane_part_bytes(const GsSchedule *g);
+int lane_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s);
+int lane_info(const GsSchedule *g, int64_t *info);
+int lane_profile(const GsSchedule *g, long long *out, int64_t cap, int64_t *n);
 int sweep_error(pamg_matrix_s *A, bool *error);      // spin bound hit since the last call? (caller has synchronised; clears the flag)
 inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }
 

@@ -156,6 +156,7 @@ bool graph_ok(const pamg_dist_s *D)
 {
     if (!D->use_graph) return false;
     if (D->mode == 1) return false;                          // host callbacks cannot be captured
+    if (solver_needs_host_sync(D->coarse)) return false;     // the collapsed tail synchronises with the host (Krylov smoother / coarse solver)
     bool talks = false;
     for (const DLevel &L : D->lv) talks = talks || L.talks();
     if (D->mode == 2 && (talks || D->world > 1)) {

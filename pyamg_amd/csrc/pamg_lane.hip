@@ -1,0 +1,476 @@
+// pamg_lane.hip -- the LANE-PARALLEL ("fast order") Gauss-Seidel / SOR sweep: layout in pamg_lane_plan.h.
+//
+// Same rows in the same order as amg_core::gauss_seidel (relaxation.h:48-76) / sor_gauss_seidel (:116-145) /
+// bsr_gauss_seidel with 1x1 blocks (:185-266) -- the dependency DAG of the sequential sweep is kept, so the iterates
+// are the reference's up to rounding -- but nothing of the row sum's order is: L lanes of a wave share a row, each adds
+// its K products, a DPP butterfly adds the lanes ("wavefront-wide segmented reduction per row"), and the row is
+// finished with (b - sum) * (1 / a_ii) instead of the IEEE division.  What that buys: the order-exact sweeps spend
+// ~0.9 us per dependency level BEHIND the last hand-off (LDS staging, barrier, 31..70-term in-order add chain, divide);
+// here that tail is ~10 dependent VALU instructions.
+//
+// ONE persistent launch per sweep; a group of 64 / L rows of one dependency level is the work of ONE wave, waves never
+// meet (no LDS, no barrier).  The hand-off is the one of the granular exact sweep: the published 8-byte value is the
+// flag (sentinel-filled buffer xs, write-through store -> polled L1-bypassing load).
+//   static form : wave w takes groups w, w + W, w + 2W, ... (all W waves co-resident; a group only waits for groups
+//                 with smaller numbers -> deadlock-free);
+//   one-XCD form: small operators (vectors fit one XCD's L2).  The first workgroup to arrive claims its XCD, workgroups
+//                 elsewhere leave, the rest draw groups from a ticket counter (two tickets ahead, taken in increasing
+//                 order by running waves: complete for any placement) and publish with ordinary L2-resident stores.
+// The static operands of a wave's NEXT group are requested before it starts to wait for the current one.
+#include "pamg_common.h"
+#include "pamg_lane_plan.h"
+
+namespace pamg {
+
+// Sentinel bit patterns of the hand-off buffer (the ones of the exact sweeps, pamg_kernels.h): xs[j] == sentinel  <=>  row j
+// has not published its new value in this sweep yet.
+template <typename T> struct Sentinel;
+template <> struct Sentinel<double> {
+    using bits_t = unsigned long long;
+    static constexpr bits_t value = 0x7FF8DEADBEEF5A5Aull;
+    static __device__ __forceinline__ bits_t bits(double v) { return (bits_t)__double_as_longlong(v); }
+};
+template <> struct Sentinel<float> {
+    using bits_t = unsigned int;
+    static constexpr bits_t value = 0x7FC5BEEFu;
+    static __device__ __forceinline__ bits_t bits(float v) { return __float_as_uint(v); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(BLK) void lane_fill_sentinel_kernel(T *xs, int64_t n)
+{
+    using B = typename Sentinel<T>::bits_t;
+    B *p = reinterpret_cast<B *>(xs);
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) p[i] = Sentinel<T>::value;
+}
+
+struct LaneSched {
+    int L = 0, K = 0, RPW = 0;
+    int64_t ngroups = 0;
+    int *d_cols = nullptr, *d_rid = nullptr;
+    void *d_vals = nullptr, *d_rdiag = nullptr;
+    long long *d_prof = nullptr;
+    int64_t n_early = 0, n_old = 0, n_slots = 0;
+    int64_t max_level_groups = 0;
+    size_t bytes = 0;
+};
+
+template <typename T>
+struct LaneArgs {
+    const int *cols;
+    const T *vals;
+    const int *rid;
+    const T *rdiag;
+    const T *x;            // OLD values (x itself, or its snapshot for structurally non-symmetric patterns)
+    T *y;                  // destination (the live x)
+    T *xs;                 // hand-off buffer, sentinel-filled
+    const T *b;
+    unsigned *err;         // spin bound hit
+    unsigned *ticket;      // one-XCD form: [0] ticket counter, [1] home XCD + 1
+    long long *prof;       // nullptr or [ngroups][4] time stamps
+    int ngroups, nidle;
+    T omega;
+};
+
+template <typename T, int K>
+struct LaneSet {
+    int c[K];
+    T v[K];
+    int rid;
+    T rd;
+};
+
+// ---- sum over the L lanes that share a row; every lane ends up with the total
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double swz_xor16(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);              // bit mode: lane ^ 16 inside each half of the wave
+    hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float swz_xor16(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); }
+
+template <int L, typename T>
+__device__ __forceinline__ T seg_allreduce(T v)
+{
+    v = v + dpp_mov<0xB1>(v);                                   // quad_perm [1,0,3,2]: lane ^ 1
+    v = v + dpp_mov<0x4E>(v);                                   // quad_perm [2,3,0,1]: lane ^ 2
+    if constexpr (L >= 8) v = v + dpp_mov<0x141>(v);            // row_half_mirror: the other quad of the 8
+    if constexpr (L >= 16) v = v + dpp_mov<0x140>(v);           // row_mirror: the other half of the 16
+    if constexpr (L >= 32) v = v + swz_xor16(v);
+    if constexpr (L >= 64) v = v + __shfl_xor(v, 32);
+    return v;
+}
+
+template <typename T, int L, int K>
+__device__ __forceinline__ void lane_load(const LaneArgs<T> &a, int g, LaneSet<T, K> &S)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t e0 = (size_t)g * (size_t)(K * 64) + (size_t)lane;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        S.c[k] = a.cols[e0 + (size_t)k * 64];
+        S.v[k] = a.vals[e0 + (size_t)k * 64];
+    }
+    const size_t slot = (size_t)g * (size_t)(64 / L) + (size_t)(lane / L);
+    S.rid = a.rid[slot];
+    S.rd = a.rdiag[slot];
+}
+
+// one group, first half: request everything that depends on the group's static operands -- b, the row's own old value,
+// and the first round of operand loads (early entries from the hand-off buffer, the others from x; both bypass the L1,
+// other CUs write these lines during the launch; padding reads a per-wave idle element).  The caller requests the
+// NEXT group's static operands right after this, so that waiting for these loads (the memory counter is in-order)
+// never waits for those.
+template <typename T, int K>
+struct LaneDyn {
+    T bv, xo;
+    T xv[K];
+    long long t0;
+};
+
+template <typename T, int EPI, int K>
+__device__ __forceinline__ void lane_issue(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int idle)
+{
+    D.t0 = 0;
+    if (a.prof && (threadIdx.x & 63) == 0) D.t0 = wall_clock64();
+    const int row = S.rid < 0 ? 0 : (S.rid & LANE_MASK);
+    D.bv = a.b[row];
+    D.xo = T(0);
+    if constexpr (EPI == EPI_SOR) D.xo = a.x[row];
+    else if (S.rid & LANE_NODIAG) D.xo = a.x[row];             // (dummy rows have the bit set too: harmless)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = S.c[k];
+        const int col = c & LANE_MASK;
+        const T *p = (c & LANE_NONE) ? a.x + idle : ((c & LANE_EARLY) ? a.xs + col : a.x + col);
+        D.xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// second half: wait for the early operands, row sums across the lanes, publish
+template <typename T, int EPI, int L, int K, bool XCD>
+__device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int g, int idle)
+{
+    const int lane = threadIdx.x & 63;
+    const bool head = (lane & (L - 1)) == 0;
+    long long t1 = 0;
+    unsigned pend = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if ((S.c[k] & LANE_EARLY) && !(S.c[k] & LANE_NONE) && Sentinel<T>::bits(D.xv[k]) == Sentinel<T>::value) pend |= 1u << k;
+    unsigned spins = 0;
+    while (pend) {
+        __builtin_amdgcn_s_sleep(1);
+        T t[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            t[k] = __hip_atomic_load(((pend >> k) & 1u) ? a.xs + (S.c[k] & LANE_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if ((pend >> k) & 1u) {
+                D.xv[k] = t[k];
+                if (Sentinel<T>::bits(t[k]) != Sentinel<T>::value) pend &= ~(1u << k);
+            }
+        if ((++spins & 1023u) == 0) {
+            // a producer that never comes (not resident / an earlier time-out): give up together, quickly
+            if (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    if (a.prof && lane == 0) t1 = wall_clock64();
+    T s = T(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const T pr = S.v[k] * D.xv[k];
+        s = s + ((S.c[k] & LANE_NONE) ? T(0) : pr);
+    }
+    s = seg_allreduce<L, T>(s);
+    if (head && S.rid >= 0) {
+        const int row = S.rid & LANE_MASK;
+        const bool upd = !(S.rid & LANE_NODIAG);
+        T v = (D.bv - s) * S.rd;
+        if constexpr (EPI == EPI_SOR) v = a.omega * v + (T(1) - a.omega) * D.xo;
+        if (!upd) v = D.xo;
+        if constexpr (XCD) __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (upd) a.y[row] = v;
+    }
+    if (a.prof && lane == 0) {
+        long long *o = a.prof + (size_t)g * 4;
+        o[0] = D.t0; o[1] = t1; o[2] = wall_clock64();
+        o[3] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) | (blockIdx.x << 4));
+    }
+}
+
+constexpr int LANE_WPB = BLK / 64;            // waves per workgroup (they never meet)
+
+template <typename T, int EPI, int L, int K, bool XCD>
+__global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int idle = (int)((((unsigned)blockIdx.x * LANE_WPB + (unsigned)wib) * 16u) % (unsigned)a.nidle);
+    LaneSet<T, K> P, Q;
+    LaneDyn<T, K> D;
+    if constexpr (!XCD) {
+        const int W = (int)gridDim.x * LANE_WPB;
+        int g = (int)blockIdx.x * LANE_WPB + wib;
+        if (g >= a.ngroups) return;
+        lane_load<T, L, K>(a, g, P);
+        while (true) {
+            const int g2 = g + W;
+            lane_issue<T, EPI, K>(a, P, D, idle);
+            lane_load<T, L, K>(a, min(g2, a.ngroups - 1), Q);   // unconditional (a load under a branch makes the compiler drain the counter at the next wait)
+            lane_finish<T, EPI, L, K, XCD>(a, P, D, g, idle);
+            if (g2 >= a.ngroups) break;
+            g = g2 + W;
+            lane_issue<T, EPI, K>(a, Q, D, idle);
+            lane_load<T, L, K>(a, min(g, a.ngroups - 1), P);
+            lane_finish<T, EPI, L, K, XCD>(a, Q, D, g2, idle);
+            if (g >= a.ngroups) break;
+        }
+    } else {
+        __shared__ int sh_home;
+        if (threadIdx.x == 0) {
+            const unsigned me = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1u;     // HW_REG_XCC_ID[3:0] + 1
+            unsigned home = 0u;
+            __hip_atomic_compare_exchange_strong(a.ticket + 1, &home, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_home = (home == 0u || home == me) ? 1 : 0;      // home holds the previous value
+        }
+        __syncthreads();
+        if (!sh_home) return;
+        // tickets: lane 0 draws, the wave reads lane 0's register; two tickets are always ahead of the running group
+        unsigned tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int g = (int)__builtin_amdgcn_readfirstlane(tk);
+        if (g >= a.ngroups) return;
+        lane_load<T, L, K>(a, g, P);
+        if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int g2 = (int)__builtin_amdgcn_readfirstlane(tk);
+        while (true) {
+            unsigned tk3 = 0;
+            lane_issue<T, EPI, K>(a, P, D, idle);
+            if (g2 < a.ngroups) {
+                lane_load<T, L, K>(a, g2, Q);
+                if (lane == 0) tk3 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            lane_finish<T, EPI, L, K, XCD>(a, P, D, g, idle);
+            if (g2 >= a.ngroups) break;
+            g = (int)__builtin_amdgcn_readfirstlane(tk3);
+            unsigned tk4 = 0;
+            lane_issue<T, EPI, K>(a, Q, D, idle);
+            if (g < a.ngroups) {
+                lane_load<T, L, K>(a, g, P);
+                if (lane == 0) tk4 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            lane_finish<T, EPI, L, K, XCD>(a, Q, D, g2, idle);
+            if (g >= a.ngroups) break;
+            g2 = (int)__builtin_amdgcn_readfirstlane(tk4);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+namespace {
+
+template <typename U>
+int lane_upload(U **dst, const void *src, size_t bytes, size_t *total)
+{
+    *dst = nullptr;
+    const size_t alloc = std::max<size_t>(bytes, 256) + 256;   // slack: nothing reads past the end, but keep allocations non-empty
+    PAMG_HIP(hipMalloc((void **)dst, alloc));
+    if (bytes) PAMG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    if (total) *total += alloc;
+    return PAMG_OK;
+}
+
+template <typename T, int EPI, int L, bool XCD>
+const void *lane_kernel_k(int K)
+{
+    switch (K) {
+        case 1: return (const void *)gs_lane_kernel<T, EPI, L, 1, XCD>;
+        case 2: return (const void *)gs_lane_kernel<T, EPI, L, 2, XCD>;
+        case 3: return (const void *)gs_lane_kernel<T, EPI, L, 3, XCD>;
+        case 4: return (const void *)gs_lane_kernel<T, EPI, L, 4, XCD>;
+    }
+    return nullptr;
+}
+
+template <typename T, int EPI, bool XCD>
+const void *lane_kernel_l(int L, int K)
+{
+    switch (L) {
+        case 4: return lane_kernel_k<T, EPI, 4, XCD>(K);
+        case 8: return lane_kernel_k<T, EPI, 8, XCD>(K);
+        case 16: return lane_kernel_k<T, EPI, 16, XCD>(K);
+        case 32: return lane_kernel_k<T, EPI, 32, XCD>(K);
+        case 64: return lane_kernel_k<T, EPI, 64, XCD>(K);
+    }
+    return nullptr;
+}
+
+template <typename T>
+const void *lane_kernel(int epi, int L, int K, bool xcd)
+{
+    // bsr_gauss_seidel with 1x1 blocks computes (b - sum) / a_ii as well: in this form the two are one kernel
+    if (epi == EPI_SOR) return xcd ? lane_kernel_l<T, EPI_SOR, true>(L, K) : lane_kernel_l<T, EPI_SOR, false>(L, K);
+    return xcd ? lane_kernel_l<T, EPI_GS, true>(L, K) : lane_kernel_l<T, EPI_GS, false>(L, K);
+}
+
+}  // namespace
+
+void free_lane_part(LaneSched *t)
+{
+    if (!t) return;
+    hipFree(t->d_cols); hipFree(t->d_rid); hipFree(t->d_vals); hipFree(t->d_rdiag); hipFree(t->d_prof);
+    delete t;
+}
+
+// rows the lane form can hold (LANE_KMAX * 64 off-diagonal entries) -- the padding check is the planner's
+bool lane_eligible(const pamg_matrix_s *A, const GsSchedule *g)
+{
+    return A->R == 1 && g->nlevels > 1 && g->d_xs != nullptr && A->max_row_len <= LANE_KMAX * 64 + 1 && !g->lane_unfit;
+}
+
+int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
+{
+    if (g->lane) return PAMG_OK;
+    PhaseTimer pt_("build_lane_part", A->nnz);
+    const int ts = (int)tsize(A->dtype);
+    std::vector<unsigned char> hAx((size_t)A->nnz * ts);
+    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    LanePlan P;
+    if (build_lane_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), hAx.data(), ts, g->row_start, g->row_step, (int)g->nrows,
+                        g->nlevels, g->h_vis, g->h_lvl, A->lane_L, P))
+        return PAMG_E_ARG;
+    LaneSched *t = new (std::nothrow) LaneSched();
+    if (!t) return PAMG_E_ALLOC;
+    t->L = P.L; t->K = P.K; t->RPW = P.RPW; t->ngroups = P.ngroups;
+    t->n_early = P.n_early; t->n_old = P.n_old; t->n_slots = P.n_slots;
+    for (int l = 0; l < P.nlevels; ++l) t->max_level_groups = std::max(t->max_level_groups, P.level_grp[l + 1] - P.level_grp[l]);
+    int st = lane_upload(&t->d_cols, P.cols.data(), P.cols.size() * sizeof(int), &t->bytes);
+    if (!st) st = lane_upload(&t->d_vals, P.vals.data(), P.vals.size(), &t->bytes);
+    if (!st) st = lane_upload(&t->d_rid, P.rid.data(), P.rid.size() * sizeof(int), &t->bytes);
+    if (!st) st = lane_upload(&t->d_rdiag, P.rdiag.data(), P.rdiag.size(), &t->bytes);
+    if (st) { free_lane_part(t); return st; }
+    g->lane = t;
+    g->bytes += t->bytes;                                      // the caller books them on the operator
+    return PAMG_OK;
+}
+
+size_t lane_part_bytes(const GsSchedule *g) { return (g && g->lane) ? g->lane->bytes : 0; }
+
+// workgroups of the static form that are certainly co-resident: (occupancy - 1, at most 8) per CU -- the occupancy query
+// can over-report by one per CU (MI355X_MICROARCH.md)
+static int lane_grid_cap(const void *k)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, BLK, 0) != hipSuccess) nb = 2;
+    nb = std::max(1, std::min(nb - 1, 8));
+    return nb;
+}
+
+int device_cus_lane()
+{
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 64;
+    return p.multiProcessorCount;
+}
+
+template <typename T>
+static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s)
+{
+    LaneSched *t = g->lane;
+    const size_t ts = tsize(A->dtype);
+    const int64_t n = A->nrows;
+    LaneArgs<T> a;
+    a.cols = t->d_cols; a.vals = (const T *)t->d_vals; a.rid = t->d_rid; a.rdiag = (const T *)t->d_rdiag;
+    a.x = (const T *)x; a.y = (T *)x; a.xs = (T *)g->d_xs; a.b = (const T *)b;
+    a.err = g->d_sync + 1; a.ticket = g->d_sync + 20;
+    a.ngroups = (int)t->ngroups;
+    a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
+    a.omega = (T)omega;
+    if (!g->symmetric) {
+        // write-after-read hazards are not ordered by the waits: old values come from a snapshot
+        if (!g->d_xold) return PAMG_E_STATE;
+        PAMG_HIP(hipMemcpyAsync(g->d_xold, x, (size_t)n * ts, hipMemcpyDeviceToDevice, s));
+        a.x = (const T *)g->d_xold;
+    }
+    if (A->gs_prof && !t->d_prof) {
+        PAMG_HIP(hipMalloc((void **)&t->d_prof, (size_t)t->ngroups * 4 * sizeof(long long)));
+        PAMG_HIP(hipMemset(t->d_prof, 0, (size_t)t->ngroups * 4 * sizeof(long long)));
+    }
+    a.prof = A->gs_prof ? t->d_prof : nullptr;
+    const int fgrid = (int)std::min<int64_t>(4096, (n + BLK - 1) / BLK);
+    hipLaunchKernelGGL((lane_fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)g->d_xs, n);
+    PAMG_HIP(hipGetLastError());
+    const int per_level = (int)((t->ngroups + g->nlevels - 1) / g->nlevels);
+    const bool xcd = A->gran_xcd == 1 || (A->gran_xcd == 0 && n <= 131072 && per_level <= 256);
+    const void *k = lane_kernel<T>(epi, t->L, t->K, xcd);
+    if (!k) return PAMG_E_ARG;
+    static thread_local int cus = 0;
+    if (!cus) cus = device_cus_lane();
+    const int cap = lane_grid_cap(k);
+    // waves wanted: ~12 dependency levels of look-ahead (a wave that runs ahead waits in its poll loop with its operands
+    // in registers), at least one workgroup per CU when the levels are wide
+    const int64_t want_waves = std::max<int64_t>(64, (int64_t)12 * per_level);
+    int G = (int)std::min<int64_t>((want_waves + LANE_WPB - 1) / LANE_WPB, (int64_t)cap * cus);
+    if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + LANE_WPB - 1) / LANE_WPB));
+    void *args[] = {(void *)&a};
+    if (xcd) {
+        // 8x the wanted grid is launched; the workgroups off the home XCD leave at once
+        PAMG_HIP(hipMemsetAsync(g->d_sync + 20, 0, 2 * sizeof(unsigned), s));
+        const int Gx = std::max(1, std::min(G, (cus / 8) * cap));
+        PAMG_HIP(hipLaunchKernel(k, dim3(8 * Gx), dim3(BLK), args, 0, s));
+        return PAMG_OK;
+    }
+    PAMG_HIP(hipLaunchKernel(k, dim3(G), dim3(BLK), args, 0, s));
+    return PAMG_OK;
+}
+
+int lane_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s)
+{
+    if (!g->lane) return PAMG_E_STATE;
+    if (A->dtype == PAMG_F64) return lane_launch_t<double>(A, g, epi, x, b, omega, s);
+    return lane_launch_t<float>(A, g, epi, x, b, omega, s);
+}
+
+// info[0..7] = lanes per row, slots per lane, groups, entry slots, early entries, old entries, widest level (groups), bytes
+int lane_info(const GsSchedule *g, int64_t *info)
+{
+    for (int i = 0; i < 8; ++i) info[i] = 0;
+    if (!g || !g->lane) return PAMG_OK;
+    const LaneSched *t = g->lane;
+    info[0] = t->L; info[1] = t->K; info[2] = t->ngroups; info[3] = t->n_slots; info[4] = t->n_early; info[5] = t->n_old;
+    info[6] = t->max_level_groups; info[7] = (int64_t)t->bytes;
+    return PAMG_OK;
+}
+
+int lane_profile(const GsSchedule *g, long long *out, int64_t cap, int64_t *n)
+{
+    *n = 0;
+    if (!g || !g->lane || !g->lane->d_prof) return PAMG_OK;
+    *n = g->lane->ngroups;
+    if (out && cap >= *n) PAMG_HIP(hipMemcpy(out, g->lane->d_prof, (size_t)*n * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+    return PAMG_OK;
+}
+
+}  // namespace pamg

@@ -358,6 +358,7 @@ void free_schedule(GsSchedule *g)
 {
     if (!g) return;
     free_tile_part(g->tile);
+    free_lane_part(g->lane);
     hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_xold); hipFree(g->d_pblk); hipFree(g->d_dpos); hipFree(g->d_prof);
     delete g;
 }
@@ -1081,10 +1082,27 @@ static bool want_tiles(const pamg_matrix_s *A, const GsSchedule *g)
     return A->gs_mode == 5 || (A->gs_mode == 0 && tile_auto(A, g));
 }
 
+// Fast order (tune key 24 = 1): the lane-parallel sweep wherever the schedule fits its form; wide schedules (the fine levels of
+// 3-D problems) stay with the tiled sweep unless tune key 27 says otherwise.
+static bool want_lanes(const pamg_matrix_s *A, const GsSchedule *g)
+{
+    if (A->gs_order != 1 || !lane_eligible(A, g)) return false;
+    if (A->gs_mode != 0) return false;                     // an explicitly chosen exact scheduler is honoured
+    if (!A->lane_wide && g->nrows > 1024 && g->nrows / std::max(1, g->nlevels) >= 2048 && tile_eligible(A, g) && !g->tile_unfit) return false;
+    return true;
+}
+
 // device copies the scheduler of choice needs (called before any graph capture through ensure_schedule)
 static int ensure_parts(pamg_matrix_s *A, GsSchedule *g)
 {
     if (A->R > 1) return PAMG_OK;
+    if (want_lanes(A, g)) {
+        const size_t before = g->bytes;
+        const int st = build_lane_part(A, g);
+        if (st == PAMG_OK) { std::lock_guard<std::mutex> lk(g_sched_mu); A->bytes += g->bytes - before; }
+        if (st != PAMG_E_ARG) return st;
+        g->lane_unfit = true;                              // rows too long / padding too wasteful: the exact schedulers take it
+    }
     if (want_tiles(A, g)) {
         const int st = build_tile_part(A, g);
         if (st != PAMG_E_ARG) return st;
@@ -1098,6 +1116,7 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
                              double omega, hipStream_t s)
 {
     PAMG_TRY(ensure_parts(A, g));
+    if (want_lanes(A, g)) return lane_launch(A, g, epi, x, b, omega, s);
     if (want_tiles(A, g)) return tile_launch<T>(A, g, epi, x, b, omega, s);
     StreamArgs<T> a = base_args<T>(A, x, b, x, 0.0, omega, nullptr);
     a.Ap = g->d_Ap;
@@ -1881,7 +1900,19 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 18: if (value < 0 || value > 1) return PAMG_E_ARG; A->tile_part = value; break;
         case 19: A->use_idx16 = value != 0; return PAMG_OK;
         case 20: if (value != 0 && (value < 64 || value > 2048)) return PAMG_E_ARG; A->gs_cap = value & ~3; break;
+        case 24: if (value < 0 || value > 1) return PAMG_E_ARG; A->gs_order = value; return PAMG_OK;
+        case 25: if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return PAMG_E_ARG; A->lane_L = value; break;
+        case 26: if (value < 0) return PAMG_E_ARG; A->lane_G = value; return PAMG_OK;
+        case 27: if (value < 0 || value > 1) return PAMG_E_ARG; A->lane_wide = value; return PAMG_OK;
         default: return PAMG_E_ARG;
+    }
+    if (key == 25) {                                  // lane geometry: drop the lane parts only
+        for (int k = 0; k < 4; ++k) {
+            GsSchedule *g = A->gs[k];
+            if (g) g->lane_unfit = false;
+            if (g && g->lane) { const size_t lb = lane_part_bytes(g); A->bytes -= lb; g->bytes -= lb; free_lane_part(g->lane); g->lane = nullptr; }
+        }
+        return PAMG_OK;
     }
     if (key >= 12) {                                  // tile plan parameters: drop the tile parts only
         for (int k = 0; k < 4; ++k) {
@@ -1962,6 +1993,19 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
     for (int l = 0; l < g->nlevels; ++l)
         for (int q = g->level_blk[l]; q < g->level_blk[l + 1]; ++q) out[(size_t)q * 8 + 7] = l;
     return PAMG_OK;
+}
+
+int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8])
+{
+    if (!A || which < 0 || which > 3 || !info) return PAMG_E_ARG;
+    return pamg::lane_info(A->gs[which], info);
+}
+
+int pamg_matrix_lane_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count)
+{
+    if (!A || which < 0 || which > 3 || !count) return PAMG_E_ARG;
+    PAMG_HIP(hipDeviceSynchronize());
+    return pamg::lane_profile(A->gs[which], out, capacity, count);
 }
 
 int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8])

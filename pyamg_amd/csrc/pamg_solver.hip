@@ -1461,6 +1461,10 @@ int solver_cycle_inline(pamg_solver_s *S, void *x, const void *b, int cycle, int
     PAMG_HIP(hipMemcpyAsync(x, L0.x, vb, hipMemcpyDeviceToDevice, s));
     return PAMG_OK;
 }
+
+// true when a cycle of S reads scalars back on the host (Krylov smoothers / coarse solvers): such a cycle cannot be
+// part of somebody else's stream capture either (the sharded driver asks before capturing an iteration)
+bool solver_needs_host_sync(const pamg_solver_s *S) { return S && S->host_sync; }
 }  // namespace pamg
 
 extern "C" {

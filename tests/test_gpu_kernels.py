@@ -323,6 +323,67 @@ def test_gs_sweep_modes_all_exact():
             assert not dA.flow_error(), kw
 
 
+def test_gs_fast_order_agrees_to_rounding():
+    """Fast order (tune gs_order=1, pamg_lane.hip): same sweep order over the rows, lane-parallel row sums and
+    multiplication by 1/a_ii -- every form (automatic lane width, forced widths, static assignment across the chip,
+    ticket form inside one XCD, tiny grids) must agree with the order-exact device sweep (= the reference's bits,
+    relaxation.h:48-76,116-145,185-266) to 1e-13 relative per sweep (f32: 2e-6), on a stencil, an irregular symmetric
+    pattern, BSR(1,1), a NON-symmetric pattern (snapshot), zero / missing diagonals, and in single precision; exact mode
+    is untouched by the switch."""
+    from oracle import oracle as orc
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(3)
+    A3 = poisson_csr((24, 20, 22))
+    S = sp.random(4000, 4000, density=0.004, random_state=rng, format="csr")
+    S = sp.csr_array(S + S.T + sp.diags_array(rng.rand(4000) + 4.0))
+    S.sort_indices()
+    N = sp.random(3000, 3000, density=0.004, random_state=rng, format="csr")
+    N = sp.csr_array(N + sp.diags_array(rng.rand(3000) + 4.0))          # structurally non-symmetric
+    Z = sp.lil_array(S[:1500, :1500])
+    for i in range(0, 1500, 7):
+        Z[i, i] = 0.0                                                    # explicit zero / missing diagonals
+    Z = sp.csr_array(Z)
+    Z.sort_indices()
+    D = sp.random(1200, 1200, density=0.06, random_state=rng, format="csr")   # ~70 entries per row: 32 lanes per row
+    D = sp.csr_array(D + D.T + sp.diags_array(rng.rand(1200) + 80.0))
+    D.sort_indices()
+    cases = [sparse_op(A3), sparse_op(S), sparse_op(A3.tobsr(blocksize=(1, 1))), sparse_op(N), sparse_op(Z), sparse_op(D),
+             sparse_op(sp.csr_array(S.astype(np.float32)))]
+    for ci, op in enumerate(cases):
+        n = op.shape[0]
+        dt = op.data.dtype
+        tol = 1e-13 if dt == np.float64 else 2e-6
+        x = rng.rand(n).astype(dt); b = rng.rand(n).astype(dt)
+        ref = x.copy(); orc.relax_gauss_seidel(op, ref, b, 2, "symmetric")
+        refs = x.copy(); orc.relax_sor(op, refs, b, 1.4, 1, "forward")
+        dA = DeviceMatrix(op)
+        db = capi.DeviceArray.from_host(b)
+        dx = capi.DeviceArray.from_host(x)
+        dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+        assert np.array_equal(dx.download(), ref)                       # a bare operator is order-exact
+        seen = set()
+        for kw in (dict(gs_order=1, lane_wide=1), dict(lane_L=16), dict(lane_L=64), dict(lane_L=0, gran_xcd=1), dict(gran_xcd=2, lane_G=3),
+                   dict(gran_xcd=1, lane_G=1), dict(gran_xcd=0, lane_G=0, lane_L=8)):
+            dA.tune(**kw)
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+            got = dx.download()
+            info = dA.lane_info(0)
+            assert info["groups"] > 0, (kw, ci)                         # the lane form really ran
+            seen.add(info["lanes_per_row"])
+            assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)), (kw, ci, np.max(np.abs(got - ref)))
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="forward", omega=1.4)
+            got = dx.download()
+            assert np.max(np.abs(got - refs)) <= tol * np.max(np.abs(refs)), (kw, ci)
+            assert not dA.flow_error(), kw
+        assert len(seen) >= 2
+        dA.tune(gs_order=0)
+        dx.upload(x)
+        dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+        assert np.array_equal(dx.download(), ref)                       # and back
+
+
 def test_resid_sumsq_two_stage_reduction():
     from tools.problems import poisson_csr
     A = poisson_csr((400, 400))

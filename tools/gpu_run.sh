@@ -1,0 +1,35 @@
+#!/bin/bash
+# The one GPU-box launcher (replaces the per-experiment tools/gpu_r0N_x.sh of earlier rounds):
+#   gpurun --timeout T -- 'bash tools/gpu_run.sh <step> [<step> ...]'
+# Steps run in order; each writes under gpurun_out/ with the TAG prefix (env TAG, default r04).
+#   tests[:expr]      GPU suite (optionally -k expr)            -> ${TAG}_gpu_tests.log
+#   py:<script+args>  python tools/<script> args (',' = space)  -> ${TAG}_<script>.log
+#   bench[:args]      python bench.py args (',' = space)        -> ${TAG}_bench<suffix>.json/.err
+#   prof:<workload>[:args]  rocprofv3 kernel stats of bench.py --workload W -> prof_${TAG}_<W>/
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+TAG=${TAG:-r04}
+for step in "$@"; do
+    kind=${step%%:*}; rest=""; [[ "$step" == *:* ]] && rest=${step#*:}
+    case $kind in
+        tests)
+            if [ -n "$rest" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "${rest//,/ }" > gpurun_out/${TAG}_gpu_tests_k.log 2>&1; tail -5 gpurun_out/${TAG}_gpu_tests_k.log
+            else timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_tests.log 2>&1; tail -5 gpurun_out/${TAG}_gpu_tests.log; fi ;;
+        py)
+            args=${rest//,/ }; name=$(echo "$args" | awk '{print $1}'); name=${name%.py}
+            suffix=${PYTAG:-}
+            timeout ${PYTIMEOUT:-900} python tools/$args > gpurun_out/${TAG}_${name}${suffix}.log 2>&1; echo "$name rc=$?"; tail -${PYTAIL:-40} gpurun_out/${TAG}_${name}${suffix}.log ;;
+        bench)
+            args=${rest//,/ }; suffix=${BENCHTAG:-_n1}
+            timeout 1500 python bench.py $args > gpurun_out/${TAG}_bench${suffix}.json 2> gpurun_out/${TAG}_bench${suffix}.err; echo "bench rc=$?"; tail -c 1500 gpurun_out/${TAG}_bench${suffix}.json ;;
+        prof)
+            wl=${rest%%:*}; extra=""; [[ "$rest" == *:* ]] && extra=${rest#*:}; extra=${extra//,/ }
+            OUT=$PWD/gpurun_out/prof_${TAG}_$wl; mkdir -p $OUT
+            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python /root/repo/bench.py --workload $wl --steps 10 --warmup 2 --cpu-cycles 0 --no-extras --no-pmc --no-setup-compare $extra > $OUT/trace_bench.json 2> $OUT/trace.log)
+            python tools/summarize_prof.py $OUT $wl $TAG > $OUT/summarize.log 2>&1
+            find $OUT -name "*.csv" -size +4M -delete
+            head -12 $OUT/kernel_stats_summary.txt ;;
+        *) echo "unknown step $step" ;;
+    esac
+done
