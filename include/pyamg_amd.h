@@ -340,7 +340,9 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * is what BASELINE's "residual norms within 1e-10" asks for; schedules the lane form cannot hold (rows with more than
  * 256 off-diagonal entries, padding above 4x) keep the exact kernels.  25 = lanes per row of the fast order (0 = automatic,
  * else 4|8|16|32|64), 26 = its persistent workgroups (0 = automatic), 27 = 1: the fast order also takes wide schedules
- * (>= 2048 rows per dependency level), which the tiled exact sweep keeps by default.
+ * (>= 2048 rows per dependency level), which the tiled exact sweep keeps by default, 28 = flags of the fast order (bit 0, default
+ * on: a wave that runs ahead of the sweep polls ONE gate operand instead of all its operands until the sweep is one
+ * dependency level away).
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(BLK) void lane_fill_sentinel_kernel(T *xs, int64_t 
 struct LaneSched {
     int L = 0, K = 0, RPW = 0;
     int64_t ngroups = 0;
-    int *d_cols = nullptr, *d_rid = nullptr;
+    int *d_cols = nullptr, *d_rid = nullptr, *d_gate = nullptr;
     void *d_vals = nullptr, *d_rdiag = nullptr;
     long long *d_prof = nullptr;
     int64_t n_early = 0, n_old = 0, n_slots = 0;
@@ -61,6 +61,7 @@ struct LaneArgs {
     const T *vals;
     const int *rid;
     const T *rdiag;
+    const int *gate;       // per group: gate operand (column) or -1; nullptr = no gating
     const T *x;            // OLD values (x itself, or its snapshot for structurally non-symmetric patterns)
     T *y;                  // destination (the live x)
     T *xs;                 // hand-off buffer, sentinel-filled
@@ -78,6 +79,7 @@ struct LaneSet {
     T v[K];
     int rid;
     T rd;
+    int gate;
 };
 
 // ---- sum over the L lanes that share a row; every lane ends up with the total
@@ -128,6 +130,7 @@ __device__ __forceinline__ void lane_load(const LaneArgs<T> &a, int g, LaneSet<T
     const size_t slot = (size_t)g * (size_t)(64 / L) + (size_t)(lane / L);
     S.rid = a.rid[slot];
     S.rd = a.rdiag[slot];
+    S.gate = a.gate ? a.gate[g] : -1;
 }
 
 // one group, first half: request everything that depends on the group's static operands -- b, the row's own old value,
@@ -173,8 +176,19 @@ __device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<
     for (int k = 0; k < K; ++k)
         if ((S.c[k] & LANE_EARLY) && !(S.c[k] & LANE_NONE) && Sentinel<T>::bits(D.xv[k]) == Sentinel<T>::value) pend |= 1u << k;
     unsigned spins = 0;
+    if (S.gate >= 0 && __builtin_amdgcn_ballot_w64(pend != 0)) {
+        // the sweep is still two or more dependency levels away while the gate operand is missing: the whole wave polls that
+        // ONE value (one request per round) instead of all its operands
+        const T *gp = a.xs + S.gate;
+        while (true) {
+            const T gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (Sentinel<T>::bits(gv) != Sentinel<T>::value) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0 && (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+        }
+    }
     while (pend) {
-        __builtin_amdgcn_s_sleep(1);
+        if (spins) __builtin_amdgcn_s_sleep(1);
         T t[K];
 #pragma unroll
         for (int k = 0; k < K; ++k)
@@ -338,7 +352,7 @@ const void *lane_kernel(int epi, int L, int K, bool xcd)
 void free_lane_part(LaneSched *t)
 {
     if (!t) return;
-    hipFree(t->d_cols); hipFree(t->d_rid); hipFree(t->d_vals); hipFree(t->d_rdiag); hipFree(t->d_prof);
+    hipFree(t->d_cols); hipFree(t->d_rid); hipFree(t->d_vals); hipFree(t->d_rdiag); hipFree(t->d_prof); hipFree(t->d_gate);
     delete t;
 }
 
@@ -346,6 +360,12 @@ void free_lane_part(LaneSched *t)
 bool lane_eligible(const pamg_matrix_s *A, const GsSchedule *g)
 {
     return A->R == 1 && g->nlevels > 1 && g->d_xs != nullptr && A->max_row_len <= LANE_KMAX * 64 + 1 && !g->lane_unfit;
+}
+
+// one-XCD form: the vectors (x, hand-off buffer) and the polling stay inside one XCD's 4 MB L2
+static bool lane_one_xcd(const pamg_matrix_s *A, const GsSchedule *g)
+{
+    return A->gran_xcd == 1 || (A->gran_xcd == 0 && A->nrows <= 131072 && g->nrows / std::max(1, g->nlevels) <= 1024);
 }
 
 int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
@@ -356,8 +376,19 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
     std::vector<unsigned char> hAx((size_t)A->nnz * ts);
     if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
     LanePlan P;
+    // Lanes per row.  Operators small enough for the one-XCD form (32 CUs): the fewest lanes that hold a row (most rows per
+    // wave).  Across the chip waves are plentiful and the sweep is bound by the hand-off latency per dependency level: ONE
+    // ROW PER WAVE where the rows are long enough to fill it (a wave then waits for its own row's operands only, not for the
+    // slowest of 4 or 16 rows) -- level 1 of the 256^3 hierarchy, 31 entries per row: 2.65 ms with 16 lanes per row, 2.49
+    // with 32, 2.37 with 64 (profiles/r04_microbench_lane_width.json).
+    int want_L = A->lane_L;
+    if (!want_L && !lane_one_xcd(A, g)) {
+        want_L = 4;
+        while (want_L < 64 && want_L < A->max_row_len - 1) want_L *= 2;
+        if (want_L < 32) want_L = 0;                           // short rows: several rows per wave (stencils)
+    }
     if (build_lane_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), hAx.data(), ts, g->row_start, g->row_step, (int)g->nrows,
-                        g->nlevels, g->h_vis, g->h_lvl, A->lane_L, P))
+                        g->nlevels, g->h_vis, g->h_lvl, want_L, P))
         return PAMG_E_ARG;
     LaneSched *t = new (std::nothrow) LaneSched();
     if (!t) return PAMG_E_ALLOC;
@@ -368,6 +399,7 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
     if (!st) st = lane_upload(&t->d_vals, P.vals.data(), P.vals.size(), &t->bytes);
     if (!st) st = lane_upload(&t->d_rid, P.rid.data(), P.rid.size() * sizeof(int), &t->bytes);
     if (!st) st = lane_upload(&t->d_rdiag, P.rdiag.data(), P.rdiag.size(), &t->bytes);
+    if (!st) st = lane_upload(&t->d_gate, P.gate.data(), P.gate.size() * sizeof(int), &t->bytes);
     if (st) { free_lane_part(t); return st; }
     g->lane = t;
     g->bytes += t->bytes;                                      // the caller books them on the operator
@@ -402,6 +434,7 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     const int64_t n = A->nrows;
     LaneArgs<T> a;
     a.cols = t->d_cols; a.vals = (const T *)t->d_vals; a.rid = t->d_rid; a.rdiag = (const T *)t->d_rdiag;
+    a.gate = (A->lane_flags & 1) ? t->d_gate : nullptr;
     a.x = (const T *)x; a.y = (T *)x; a.xs = (T *)g->d_xs; a.b = (const T *)b;
     a.err = g->d_sync + 1; a.ticket = g->d_sync + 20;
     a.ngroups = (int)t->ngroups;
@@ -422,15 +455,18 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     hipLaunchKernelGGL((lane_fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)g->d_xs, n);
     PAMG_HIP(hipGetLastError());
     const int per_level = (int)((t->ngroups + g->nlevels - 1) / g->nlevels);
-    const bool xcd = A->gran_xcd == 1 || (A->gran_xcd == 0 && n <= 131072 && per_level <= 256);
+    const bool xcd = lane_one_xcd(A, g);
     const void *k = lane_kernel<T>(epi, t->L, t->K, xcd);
     if (!k) return PAMG_E_ARG;
     static thread_local int cus = 0;
     if (!cus) cus = device_cus_lane();
     const int cap = lane_grid_cap(k);
-    // waves wanted: ~12 dependency levels of look-ahead (a wave that runs ahead waits in its poll loop with its operands
-    // in registers), at least one workgroup per CU when the levels are wide
-    const int64_t want_waves = std::max<int64_t>(64, (int64_t)12 * per_level);
+    // waves wanted: ~4 dependency levels of look-ahead (a wave that runs ahead waits in its poll loop with its operands in
+    // registers) -- more waves poll more and the polls load the memory system (measured on the 256^3 hierarchy,
+    // profiles/r04_microbench_lane_first.json: level 1, 227 groups per dependency level: 2.67 ms with 512 waves, 2.72 with
+    // 1 024, 3.28 with 2 048, 4.71 with 4 096)
+    // with one row per wave 2.3 levels: 2.37 ms with 2 048 waves, 2.40 with 3 072, 2.57 with 6 144, 2.46 with 1 536)
+    const int64_t want_waves = std::max<int64_t>(128, t->RPW == 1 ? ((int64_t)23 * per_level + 9) / 10 : (int64_t)4 * per_level);
     int G = (int)std::min<int64_t>((want_waves + LANE_WPB - 1) / LANE_WPB, (int64_t)cap * cus);
     if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + LANE_WPB - 1) / LANE_WPB));

@@ -18,6 +18,10 @@
 //   rid  [g * RPW + r]               original row (-1: dummy row of the padding) | NODIAG (bit 30: the row has no or a
 //                                    zero diagonal: it is left untouched, relaxation.h:72-74, but still publishes its value)
 //   rdiag[g * RPW + r]               1 / a_ii
+//   gate [g]                         "gate" operand of the group: the column of its early operand with the HIGHEST dependency
+//                                    level among those at least two levels below the group's own (-1: none).  A wave that runs
+//                                    ahead polls this one value until the sweep is one level away, and only then all its
+//                                    operands: polling traffic of ~1 instead of ~3 dependency levels per group.
 // with lane = r * L + i and the row's off-diagonal entries e = 0, 1, ... (storage order) at k = e / L, i = e % L.
 // Diagonal entries are not stored at all (every stored a_ii is skipped by the reference's sum; the last one is the
 // diagonal, relaxation.h:64-69).
@@ -45,6 +49,7 @@ struct LanePlan {
     std::vector<unsigned char> vals;          // ngroups * K * 64 values of tsize bytes
     std::vector<int> rid;
     std::vector<unsigned char> rdiag;         // ngroups * RPW values of tsize bytes
+    std::vector<int> gate;                    // [ngroups] column of the group's latest early operand from a level <= own level - 2, or -1
     std::vector<int64_t> level_grp;           // [nlevels + 1] group range of each dependency level
     int64_t n_early = 0, n_old = 0, n_slots = 0;
 };
@@ -125,6 +130,8 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
     P.vals.assign((size_t)P.n_slots * tsize, 0);
     P.rid.assign((size_t)P.ngroups * RPW, -1);
     P.rdiag.assign((size_t)P.ngroups * RPW * tsize, 0);
+    P.gate.assign((size_t)P.ngroups, -1);
+    std::vector<int> gate_lvl((size_t)P.ngroups, -1);
     std::vector<int64_t> ne((size_t)nl, 0), no((size_t)nl, 0);
     lane_parallel(nl, [&](int64_t l0, int64_t l1) {
         for (int64_t l = l0; l < l1; ++l) {
@@ -144,6 +151,7 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                     ++e;
                     if (j < 0 || j >= n) continue;                                    // not a column of x: no product
                     const bool early = vis[j] >= 0 && vis[j] < ti;
+                    if (early && lvl[j] <= (int)l - 2 && lvl[j] > gate_lvl[(size_t)g]) { gate_lvl[(size_t)g] = lvl[j]; P.gate[(size_t)g] = j; }
                     P.cols[s] = j | (early ? LANE_EARLY : 0);
                     std::memcpy(&P.vals[s * tsize], Ax + (size_t)p * tsize, (size_t)tsize);
                     if (early) ++e_cnt; else ++o_cnt;

@@ -60,6 +60,34 @@ def variants_for(li, n):
                 v.append((f"fast_noxcd_G{G}", dict(lane_G=G, gran_xcd=2)))
             for G in (16, 32, 64, 128):
                 v.append((f"fast_xcd_G{G}", dict(lane_G=G, gran_xcd=1)))
+    if a.exp == "b":                       # gate operand on / off x grid, static and one-XCD forms
+        v.append(("fast_auto", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
+        v.append(("fast_auto_nogate", dict(lane_flags=0)))
+        if li == 1:
+            for fl in (1, 0):
+                for G in (64, 96, 128, 192, 256, 384, 512):
+                    v.append((f"fast_gate{fl}_G{G}", dict(lane_flags=fl, lane_G=G, gran_xcd=2)))
+            for G in (128, 256, 512):
+                v.append((f"fast_L64_gate1_G{G}", dict(lane_L=64, lane_flags=1, lane_G=G, gran_xcd=2)))
+        elif li in (2, 3):
+            for fl in (1, 0):
+                for G in (8, 16, 24, 32, 48):
+                    v.append((f"fast_xcd_gate{fl}_G{G}", dict(lane_flags=fl, lane_G=G, gran_xcd=1)))
+            for G in (16, 32):
+                v.append((f"fast_L64_xcd_gate1_G{G}", dict(lane_L=64, lane_flags=1, lane_G=G, gran_xcd=1)))
+        elif li == 0:
+            for G in (256, 384, 512):
+                v.append((f"fast_gate1_G{G}", dict(lane_flags=1, lane_G=G)))
+    if a.exp == "c":                       # lanes per row x grid (gate on)
+        v.append(("fast_auto", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
+        if li == 1:
+            for L, Gs in ((32, (192, 256, 384, 512, 768)), (64, (384, 512, 640, 768, 1024, 1536))):
+                for G in Gs:
+                    v.append((f"fast_L{L}_G{G}", dict(lane_L=L, lane_G=G, gran_xcd=2)))
+        elif li in (2, 3):
+            for L, Gs in ((32, (32, 40)), (64, (32, 48, 64, 96))):
+                for G in Gs:
+                    v.append((f"fast_L{L}_xcd_G{G}", dict(lane_L=L, lane_G=G, gran_xcd=1)))
     return v
 
 
