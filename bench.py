@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--host-setup", action="store_true", help="build the hierarchies with the reference alone (no device setup operators)")
     ap.add_argument("--no-setup-compare", action="store_true", help="skip the second, reference-only setup of the main workload")
     ap.add_argument("--protocol-cycles", type=int, default=10, help="cycles of the reference-protocol parity run (b = 0, x0 = rand); 0 skips it")
+    ap.add_argument("--kernel-map", default=None, help="write the launch -> (level, operator, bytes) map of the main workload's cycle here (tools/summarize_prof.py joins it with a rocprofv3 trace)")
     ap.add_argument("--shard-workload", default=os.environ.get("PAMG_SHARD_WORKLOAD", "c4x"), choices=sorted(WORKLOADS),
                     help="N > 1: the row-sharded headline workload (BASELINE configs[3] = c4x, 512^3 Chebyshev)")
     args = ap.parse_args()
@@ -343,6 +344,28 @@ def main():
         return {"protocol": "b = 0, x0 = rand (seed 2022), reference residual norms after each cycle", "cycles_compared": int(m),
                 "max_rel_diff": float(rel.max()), "tolerance": "1e-10 relative, every cycle", "ok": bool(rel.max() <= 1e-10),
                 "first_last_norm": [float(c[0]), float(c[m - 1])], "cpu_s": round(tc, 1), "cpu_cycles": int(k)}
+
+    def time_to_tol(dml_, b_, x0_, tol=1e-8, maxit=120):
+        """multilevel.py:558-580 with the reference's stopping rule ||b - A x|| < tol * ||b||: the number of cycles it takes
+        from x0 and the wall time of exactly those cycles (each followed by its convergence-check norm) on the resident state"""
+        xd_, bd_ = capi.DeviceArray.from_host(x0_), capi.DeviceArray.from_host(b_)
+        normb = float(np.linalg.norm(b_)) or 1.0
+        dml_.load_device(xd_, bd_)
+        res_, k = [], None
+        while len(res_) < maxit and k is None:
+            res_ += list(dml_.iterate_device(20))
+            hit = [i for i, r in enumerate(res_) if r < tol * normb]
+            k = hit[0] + 1 if hit else None
+        out_ = {"tol": tol, "cycles": k, "rule": "||b - A x|| < tol * ||b|| (multilevel.py:571)", "final_relative_residual": float(res_[(k or len(res_)) - 1] / normb)}
+        if k is not None:
+            dml_.load_device(xd_, bd_)
+            barrier()
+            t0_ = time.perf_counter()
+            dml_.iterate_device(k, want_residuals=False)
+            barrier()
+            out_["seconds"] = round(time.perf_counter() - t0_, 5)
+        xd_.free(); bd_.free()
+        return out_
 
     def cpu_from_protocol(pp, A, v):
         """the cpu_baseline of a leg whose only reference run is the protocol run (512^3: one reference cycle is ~45 s)"""
@@ -579,39 +602,62 @@ def main():
     if rank == 0 and world == 1 and not args.no_pmc and "grid" in wl and not wl.get("elasticity") and not wl.get("convdiff"):
         pmc = measure_traffic(wl["grid"], n)
     npats = A0.row_patterns()
-    roofline = {"kernel": ("csr_rowpat_kernel<double, RESID>" if npats else "csr_rowgather_kernel<double, RESID>" if nvals else "csr_stream_kernel<double, RESID>") + " (fine-level r = b - A x)", "bound": "hbm",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc["bytes_per_launch"] if pmc else None,
-                "bytes_per_launch": int(bytes_resid), "ms_per_launch": round(spmv_ms, 5)}
-    if pmc:
-        roofline["traffic_detail"] = pmc
-        roofline["traffic_over_algorithmic"] = round(pmc["bytes_per_launch"] / bytes_resid, 3)
-        roofline["frac_on_measured_traffic"] = round(pmc["bytes_per_launch"] / spmv_ms / 1e6 / HBM_PEAK_GBPS, 4)
+    # measured ceiling of this device beside the datasheet peak
+    ceiling = None
+    if rank == 0:
+        try:
+            ceiling = {"copy_GBps": round(capi.bandwidth_probe("copy"), 1), "triad_GBps": round(capi.bandwidth_probe("triad"), 1),
+                       "how": "c = a / c = a + s b over 3 x 1 GiB vectors, 16-byte accesses, 20 launches (pamg_bandwidth_probe)"}
+        except Exception as e:                                  # noqa: BLE001
+            log(f"bandwidth probe failed: {e!r}")
+    # bytes the format that actually ran has to move per launch (its operator stream + the vectors once)
+    nnz0 = int(A.nnz)
     if nvals and npats:
         streamed = 25 * n                             # one pattern byte per row + b, x, r; no entries, no row pointer (irregular rows: a few per mille)
-        roofline["operator_stream"] = (f"row patterns: {npats} lists of (column - row, value) pairs cover the rows of this stencil, a row streams ONE byte "
-                                       f"(its list number) instead of 12 bytes per stored entry + 4 ({nvals} distinct values); `achieved` / `frac` keep "
-                                       "the SURVEY's CSR byte formula, so they exceed the peak")
-        roofline["bytes_streamed_per_launch"] = int(streamed)
-        roofline["frac_on_streamed_bytes"] = round(streamed / spmv_ms / 1e6 / HBM_PEAK_GBPS, 4)
-        roofline["values_streamed_as_stored"] = plain
+        stream_note = (f"row patterns: {npats} lists of (column - row, value) pairs cover the rows of this stencil, a row streams ONE byte "
+                       f"(its list number) instead of 12 bytes per stored entry + 4 ({nvals} distinct values)")
     elif nvals:
-        nnz0 = int(A.nnz)
         streamed = bytes_resid - 9 * nnz0             # 2-byte column codes + 1-byte value codes instead of 4 + 8 bytes per entry
-        roofline["operator_stream"] = (f"16-bit column codes + 8-bit value codes ({nvals} distinct values): 3 instead of 12 bytes per stored "
-                                       "entry reach the kernel (lane = row: a gather instruction reads 64 consecutive values of x); "
-                                       "`achieved` / `frac` keep the SURVEY's CSR byte formula, so they can exceed the peak")
-        roofline["bytes_streamed_per_launch"] = int(streamed)
-        roofline["frac_on_streamed_bytes"] = round(streamed / spmv_ms / 1e6 / HBM_PEAK_GBPS, 4)
-        roofline["values_streamed_as_stored"] = plain
+        stream_note = (f"16-bit column codes + 8-bit value codes ({nvals} distinct values): 3 instead of 12 bytes per stored entry reach the "
+                       "kernel (lane = row: a gather instruction reads 64 consecutive values of x)")
+    else:
+        streamed = bytes_resid - 2 * nnz0             # 16-bit column codes: 10 instead of 12 bytes per stored entry
+        stream_note = "16-bit window codes for the columns, values as stored: 10 bytes per stored entry"
+    # the roofline fraction is taken on what MOVES: the larger of the bytes the running format must stream and the HBM
+    # traffic counted in this run (a compressed format does not move the CSR formula's bytes; that figure stays beside it)
+    moved = max(int(streamed), int(pmc["bytes_per_launch"]) if pmc else 0)
+    kname = ("csr_rowpat_kernel<double, RESID>" if npats else "csr_rowgather_kernel<double, RESID>" if nvals else "csr_stream_kernel<double, RESID>")
+    roofline = {"kernel": kname + " (fine-level r = b - A x)", "bound": "hbm",
+                "achieved": round(moved / spmv_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(moved / spmv_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                "basis": "max(bytes the running operator format must stream, HBM traffic counted by rocprofv3 PMC in this run)",
+                "traffic": pmc["bytes_per_launch"] if pmc else None,
+                "bytes_per_launch": int(moved), "ms_per_launch": round(spmv_ms, 5),
+                "bytes_streamed_per_launch": int(streamed), "operator_stream": stream_note,
+                "bytes_csr_formula": int(bytes_resid), "achieved_csr_formula": round(achieved, 1),
+                "frac_csr_formula": round(achieved / HBM_PEAK_GBPS, 4),
+                "csr_formula_note": "SURVEY 8(d): 12 nnz + 4 (n + 1) + 8 n (x) + 8 n (r) + 8 n (b); exceeds the peak when the operator is streamed compressed"}
+    if ceiling:
+        roofline["ceiling_GBps"] = ceiling["copy_GBps"]
+        roofline["ceiling"] = ceiling
+        roofline["frac_of_ceiling"] = round(moved / spmv_ms / 1e6 / max(ceiling["copy_GBps"], 1.0), 4)
+    if pmc:
+        roofline["traffic_detail"] = pmc
+        roofline["traffic_over_streamed"] = round(pmc["bytes_per_launch"] / max(streamed, 1), 3)
+    if plain:
+        # the general kernel (any operator): 16-bit column codes + values as stored, LDS-staged products -- the north star's
+        # "fine-level CSR SpMV", on the CSR formula's bytes (it streams 10 of the 12 bytes per entry)
+        plain["bytes_per_launch"] = int(bytes_resid)
+        plain["bytes_streamed_per_launch"] = int(bytes_resid - 2 * nnz0)
+        plain["frac_on_streamed_bytes"] = round((bytes_resid - 2 * nnz0) / plain["ms_per_launch"] / 1e6 / HBM_PEAK_GBPS, 4)
+        roofline["general_csr"] = plain
 
     # ---- the order-exact sweeps: latency-bound by the dependency chain of the reference's row order
     #      (levels of the schedule), not by HBM -- reported beside the bandwidth roofline so that the
     #      cycle time can be read: one forward Gauss-Seidel sweep per level, HIP events
-    sweeps = None
-    if wl["smoother"] == GS and rank == 0:
-        sweeps = []
-        for i, (L, dA) in enumerate(zip(ml.levels[:-1], dml.A)):
+    def sweep_table(dml_):
+        rows_ = []
+        for i, (L, dA) in enumerate(zip(ml.levels[:-1], dml_.A)):
             ni = L.A.shape[0]
             inf = dA.info()
             if not inf["gs_levels_fwd"]:
@@ -628,16 +674,58 @@ def main():
             g1.synchronize()
             ms = g0.elapsed_ms(g1) / 5
             Ai = L.A.tocsr() if L.A.format != "csr" else L.A
-            by = spmv_bytes(Ai) + 8 * ni
-            sweeps.append({"level": i, "rows": int(ni), "nnz": int(Ai.nnz), "dependency_levels": int(inf["gs_levels_fwd"]),
-                           "ms_per_forward_sweep": round(ms, 4), "us_per_dependency_level": round(1e3 * ms / inf["gs_levels_fwd"], 3),
-                           "GBps": round(by / ms / 1e6, 1)})
+            by = 12 * int(Ai.nnz) + 4 * (ni + 1) + 24 * ni            # Jacobi / GS / SOR sweep
+            lane, tile = dA.lane_info(0), dA.tile_info(0)
+            sched = (f"lane-parallel fast order: {lane['lanes_per_row']} lanes per row x {lane['slots_per_lane']}, {lane['launch_grid']} workgroups" if lane["groups"] and dml_.order == "fast" and lane["launch_grid"]
+                     else f"tiled exact sweep: {tile['tiles']} tiles" if tile["tiles"] else "granular / single-workgroup exact sweep")
+            rows_.append({"level": i, "rows": int(ni), "nnz": int(Ai.nnz), "dependency_levels": int(inf["gs_levels_fwd"]), "scheduler": sched,
+                          "ms_per_forward_sweep": round(ms, 4), "us_per_dependency_level": round(1e3 * ms / inf["gs_levels_fwd"], 3),
+                          "GBps": round(by / ms / 1e6, 1), "pct_of_hbm_peak": round(100 * by / ms / 1e6 / HBM_PEAK_GBPS, 2)})
             xs_.free(); bs_.free()
+        return rows_
+
+    sweeps = None
+    if wl["smoother"] == GS and rank == 0:
+        sweeps = sweep_table(dml)
+
+    # ---- the same workload with ORDER-EXACT row sums (bit-identical to the reference; the fast order above keeps the sweep
+    #      order and agrees to rounding): both modes are in the line
+    exact_leg = None
+    if wl["smoother"] == GS and rank == 0 and world == 1 and os.environ.get("PAMG_BENCH_EXACT", "1") != "0":
+        try:
+            dml_x = DeviceMultilevelSolver(ml, device=local_rank, graph=not args.no_graph, order="exact")
+            wx, _, res_x, xdx, bdx = time_resident(dml_x, b, x0, args.steps, args.warmup)
+            exact_leg = {"order": "exact", "value": round(args.steps / wx, 3), "unit": "cycles/s", "ms_per_step": round(wx * 1e3 / args.steps, 4),
+                         "residuals_gpu": [float(v) for v in res_x], "gs_sweeps": sweep_table(dml_x),
+                         "max_rel_diff_fast_vs_exact_norms": float(np.max(np.abs(np.asarray(res_x) - np.asarray(res_gpu)) / np.asarray(res_x)))}
+            xdx.free(); bdx.free()
+            dml_x.free()
+            del dml_x
+        except Exception as e:                                  # noqa: BLE001
+            log(f"exact-order leg failed: {e!r}")
+            exact_leg = {"error": repr(e)[:300]}
+
+    if args.kernel_map and rank == 0:
+        try:
+            from tools.kernel_map import kernel_map
+            sm = wl["smoother"]
+            kind = sm if isinstance(sm, str) else sm[0]
+            Path(args.kernel_map).write_text(json.dumps({"workload": args.workload, "peak_GBps": HBM_PEAK_GBPS, "ceiling": ceiling,
+                                                         "entries": kernel_map(dml, kind)}, indent=1))
+        except Exception as e:                                  # noqa: BLE001
+            log(f"kernel map not written: {e!r}")
+
+    ttt = None
+    if rank == 0 and world == 1:
+        try:
+            ttt = time_to_tol(dml, b, x0)
+        except Exception as e:                                  # noqa: BLE001
+            ttt = {"error": repr(e)[:200]}
 
     out = None
     cpu = parity = None
     if rank == 0 and world == 1 and args.cpu_cycles != 0:
-        kcpu = args.cpu_cycles if args.cpu_cycles > 0 else (3 if n > 5_000_000 else 10)
+        kcpu = args.cpu_cycles if args.cpu_cycles > 0 else (6 if n > 5_000_000 else 10)
         cpu, res_cpu = cpu_reference(ml, A, b, x0, kcpu)
         parity = parity_of(res_gpu, res_cpu)
         if args.protocol_cycles > 0:
@@ -668,16 +756,24 @@ def main():
                        "hierarchy_setup": SETUP_NOTE + ("" if args.host_setup else
                                                         "; the CPU reference and the parity runs use this same hierarchy object"),},
             "event_ms_per_step": round(ev_ms / args.steps, 4),
-            "spmv_GBps": round(achieved, 1), "spmv_pct_of_hbm_peak": round(100 * achieved / HBM_PEAK_GBPS, 2),
+            "spmv_GBps": roofline["achieved"], "spmv_pct_of_hbm_peak": round(100 * roofline["frac"], 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
             "host": {"setup_s": round(t_setup, 1), "upload_s": round(t_upload, 1), "cores": os.cpu_count(),
                      "setup": SETUP_NOTE, **(setup_cmp or {})},
             "residuals_gpu": [float(v) for v in res_gpu],
+            "time_to_tol_1e-8": ttt,
         }
+        out["config"]["gs_order"] = dml.order
         if sweeps:
-            out["gs_sweeps"] = {"note": "order-exact Gauss-Seidel: one persistent launch per sweep, element-level hand-off; "
-                                        "time = dependency levels x hand-off latency (a V(1,1) cycle with symmetric GS runs 4 sweeps per level)",
-                                "per_level": sweeps}
+            out["gs_sweeps"] = {"note": "Gauss-Seidel in the reference's row order (same dependency DAG): one persistent launch per sweep, "
+                                        "element-level hand-off; time = dependency levels x hand-off latency (a V(1,1) cycle with symmetric GS "
+                                        "runs 4 sweeps per level).  order = fast: lane-parallel row sums and x 1/a_ii where the schedule fits "
+                                        "(agrees with the reference to rounding); wide schedules keep the tiled exact sweep",
+                                "order": dml.order, "per_level": sweeps}
+        if exact_leg:
+            out["exact_order"] = exact_leg
+            if cpu and "residuals_gpu" in exact_leg:
+                exact_leg["parity"] = parity_of(exact_leg["residuals_gpu"], res_cpu)
         if cpu:
             out["speedup_vs_cpu_reference"] = round(out["value"] / cpu["value"], 1)
 
@@ -754,6 +850,7 @@ def main():
             ex["cpu_baseline"] = c3cpu
             ex["parity"] = parity_of(res3, r3cpu)
             ex["parity"]["reference_protocol"] = protocol_parity(d3, ml2, A2.shape[0])
+        ex["time_to_tol_1e-8"] = time_to_tol(d3, b2, x02)
         out["extra"] = {"c2": ex}
         d3.free()
       except Exception as e:                                    # noqa: BLE001
@@ -779,6 +876,29 @@ def main():
                 leg["cpu_baseline"] = c5cpu
                 leg["parity"] = parity_of(res5, r5cpu)
                 leg["parity"]["reference_protocol"] = protocol_parity(d5, ml5, A5.shape[0])
+            leg["time_to_tol_1e-8"] = time_to_tol(d5, b5, x05)
+            if tag == "block_jacobi":
+                # roofline of the fine-level BSR(3,3) product r = b - A x (8 R C nblk + 4 nblk + 4 (n_brow + 1) + vectors)
+                A5b = A5.tobsr(blocksize=(3, 3)) if A5.format != "bsr" else A5
+                nblk5, nbrow5, n5 = int(A5b.indices.size), int(A5b.shape[0] // 3), int(A5b.shape[0])
+                by5 = 8 * 9 * nblk5 + 4 * nblk5 + 4 * (nbrow5 + 1) + 8 * n5 + 8 * n5 + 8 * n5
+                x5d, b5d, r5d = capi.DeviceArray.from_host(np.random.RandomState(1).rand(n5)), capi.DeviceArray.from_host(b5), capi.DeviceArray(n5, np.float64)
+                st5 = d5.stream()
+                for _ in range(5):
+                    d5.A[0].spmv(capi.SPMV_RESID, x5d, r5d, b=b5d, stream=st5)
+                h0, h1 = capi.Event(), capi.Event()
+                h0.record(st5)
+                for _ in range(50):
+                    d5.A[0].spmv(capi.SPMV_RESID, x5d, r5d, b=b5d, stream=st5)
+                h1.record(st5)
+                h1.synchronize()
+                ms5 = h0.elapsed_ms(h1) / 50
+                ex5["roofline"] = {"kernel": "csr_stream_kernel<double, RESID> on the scalar view of the fine-level BSR(3,3) operator (entry order = SciPy's bsr_matvec)",
+                                   "bound": "hbm", "bytes_per_launch": int(by5), "ms_per_launch": round(ms5, 5), "achieved": round(by5 / ms5 / 1e6, 1),
+                                   "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(by5 / ms5 / 1e6 / HBM_PEAK_GBPS, 4),
+                                   "note": f"{nblk5} blocks of 3x3 in {nbrow5} block rows: the operator is {8 * 9 * nblk5 / 1e6:.0f} MB, L2 / Infinity-Cache resident between launches"}
+                for d_ in (x5d, b5d, r5d):
+                    d_.free()
             d5.free()
             ex5[tag] = leg
         out.setdefault("extra", {})["c5"] = ex5
@@ -803,6 +923,7 @@ def main():
             ex1["cpu_baseline"] = c1cpu
             ex1["parity"] = parity_of(res1, r1cpu)
             ex1["parity"]["reference_protocol"] = protocol_parity(d1, ml1, A1.shape[0])
+        ex1["time_to_tol_1e-8"] = time_to_tol(d1, b1, x01)
         out.setdefault("extra", {})["c1"] = ex1
         d1.free()
       except Exception as e:                                    # noqa: BLE001
@@ -833,6 +954,7 @@ def main():
                     pp = protocol_parity(d4, ml4, A4.shape[0], k=3)
                     ex4["cpu_baseline"] = cpu_from_protocol(pp, A4, b4)
                     ex4["parity"] = {"reference_protocol": pp}
+                ex4["time_to_tol_1e-8"] = time_to_tol(d4, b4, x04)
                 d4.free()
                 break
             except Exception as e:                                    # noqa: BLE001

@@ -68,6 +68,10 @@ int pamg_l1_cache_clear(void);
 int pamg_l1_cache_size(int *entries);
 const char *pamg_status_string(int status);
 int pamg_device_count(int *count);
+/* Measured bandwidth ceiling of the current device: kind 0 = copy c = a (16 bytes per element moved), 1 = triad
+ * c = a + s b (24 bytes), n doubles per vector, 16-byte accesses, `reps` timed launches; *gbps = bytes moved / time.
+ * bench.py reports it beside the datasheet peak ("also measure an on-device copy/triad ceiling"). */
+int pamg_bandwidth_probe(int kind, int64_t n, int reps, double *gbps);
 int pamg_set_device(int device);
 int pamg_get_device(int *device);
 int pamg_device_name(int device, char *buf, int buflen);
@@ -331,7 +335,8 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * 22 = row-gather form of the whole-operator kernels on operators with value codes (default 1 there): lane = row, the j-th
  * entries of 64 consecutive rows in one gather instruction (coalesced on stencils), products summed in storage order in
  * registers; 0 = the LDS-staged kernel on the codes;
- * 23 = row-pattern form (default 1 where plan_rowpat found a table, see pamg_matrix_row_patterns).
+ * 23 = row-pattern form where plan_rowpat found a table (see pamg_matrix_row_patterns): 2 (default) two consecutive rows per
+ * lane -- b, y, the result and every even-offset gather move as 16-byte accesses --, 1 one row per lane, 0 off.
  * NOT speed-only -- 24 = ORDER of the row sums of the scalar Gauss-Seidel / SOR sweeps: 0 (default of a bare operator) =
  * order-exact, every sum runs in storage order with an IEEE division, results are the reference's bit for bit
  * (amg_core/relaxation.h:48-76,116-145,185-266); 1 = FAST order: the same sweep order over the rows (same dependency
@@ -367,8 +372,8 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
  * rows, LDS bytes}; all zero when that schedule has no tile plan. */
 int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8]);
 /* Layout of the lane-parallel fast-order sweep (tune key 24) for schedule `which`: {lanes per row, entry slots per lane,
- * groups (one wave each), entry slots, entries that wait for a new value, entries that read an old value, groups of the
- * widest dependency level, bytes}; all zero when that schedule has no lane layout.  pamg_matrix_lane_profile: with tune
+ * groups (one wave each), entry slots, entries that wait for a new value, workgroups of the last launch (the one-XCD form
+ * launches 8x what stays), groups of the widest dependency level, bytes}; all zero when that schedule has no lane layout.  pamg_matrix_lane_profile: with tune
  * key 11, per group four 64-bit words {start, last operand seen, published (wall clock, 10 ns), XCD | workgroup << 4}. */
 int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8]);
 int pamg_matrix_lane_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count);

@@ -67,6 +67,7 @@ def _declare(lib):
     f("pamg_device_count", P(_i))
     f("pamg_set_device", _i)
     f("pamg_get_device", P(_i))
+    f("pamg_bandwidth_probe", _i, C.c_int64, _i, P(C.c_double))
     f("pamg_device_name", _i, C.c_char_p, _i)
     f("pamg_malloc", P(_vp), _sz)
     f("pamg_free", _vp)
@@ -304,6 +305,13 @@ class DeviceArray:
 
     def __del__(self):
         self.free()
+
+
+def bandwidth_probe(kind: str = "copy", n: int = 1 << 27, reps: int = 20) -> float:
+    """measured GB/s of an on-device copy / triad with 16-byte accesses (pamg_bandwidth_probe)"""
+    out = C.c_double(0.0)
+    check(lib().pamg_bandwidth_probe(0 if kind == "copy" else 1, int(n), int(reps), C.byref(out)), "pamg_bandwidth_probe")
+    return float(out.value)
 
 
 def sync():

@@ -512,6 +512,57 @@ const char *pamg_status_string(int st)
     return "unknown error";
 }
 
+// ---- measured bandwidth ceiling of this device (bench.py reports it beside the 8 TB/s datasheet peak)
+namespace {
+__global__ __launch_bounds__(256) void bw_copy_kernel(const double2 *__restrict__ a, double2 *__restrict__ c, int64_t n2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) c[i] = a[i];
+}
+__global__ __launch_bounds__(256) void bw_triad_kernel(const double2 *__restrict__ a, const double2 *__restrict__ b, double2 *__restrict__ c, double s, int64_t n2)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        const double2 x = a[i], y = b[i];
+        double2 r;
+        r.x = x.x + s * y.x;
+        r.y = x.y + s * y.y;
+        c[i] = r;
+    }
+}
+}  // namespace
+
+int pamg_bandwidth_probe(int kind, int64_t n, int reps, double *gbps)
+{
+    if ((kind != 0 && kind != 1) || n < 1024 || reps < 1 || !gbps) return PAMG_E_ARG;
+    n &= ~(int64_t)1;
+    double *a = nullptr, *b = nullptr, *c = nullptr;
+    PAMG_HIP(hipMalloc((void **)&a, (size_t)n * 8));
+    if (hipMalloc((void **)&b, (size_t)n * 8) != hipSuccess) { hipFree(a); return PAMG_E_ALLOC; }
+    if (hipMalloc((void **)&c, (size_t)n * 8) != hipSuccess) { hipFree(a); hipFree(b); return PAMG_E_ALLOC; }
+    hipMemset(a, 0, (size_t)n * 8); hipMemset(b, 0, (size_t)n * 8); hipMemset(c, 0, (size_t)n * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int64_t n2 = n / 2;
+    const int grid = (int)std::min<int64_t>((n2 + 255) / 256, 256 * 64);
+    auto run = [&]() {
+        if (kind == 0) hipLaunchKernelGGL(bw_copy_kernel, dim3(grid), dim3(256), 0, 0, (const double2 *)a, (double2 *)c, n2);
+        else hipLaunchKernelGGL(bw_triad_kernel, dim3(grid), dim3(256), 0, 0, (const double2 *)a, (const double2 *)b, (double2 *)c, 0.5, n2);
+    };
+    for (int i = 0; i < 3; ++i) run();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) run();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const hipError_t err = hipGetLastError();
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a); hipFree(b); hipFree(c);
+    if (err != hipSuccess) return (int)err;
+    const double bytes = (kind == 0 ? 16.0 : 24.0) * (double)n * reps;
+    *gbps = ms > 0.f ? bytes / ((double)ms * 1e6) : 0.0;
+    return PAMG_OK;
+}
+
 int pamg_device_count(int *count)
 {
     if (!count) return PAMG_E_ARG;

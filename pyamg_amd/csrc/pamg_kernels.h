@@ -780,6 +780,175 @@ __global__ __launch_bounds__(BLK) void csr_rowpat_kernel(const StreamArgs<T> a)
     }
 }
 
+// ---- row-pattern form, TWO consecutive rows per lane (round 4).  The one-row form issues ten 8-byte (and one 1-byte) memory
+// instructions per row and is bound by the requests a CU can keep in flight, not by bytes.  Here lane l takes rows
+// r0 + 2 l and r0 + 2 l + 1: when both are regular rows with the SAME list (all but the boundary rows of a stencil) and
+// the pair starts at an even row, b, y, the diagonal and the result move as ONE 16-byte access per vector, every list entry with
+// an even offset is ONE 16-byte gather x[row + offset .. + 1] for the two rows, and the table in LDS is read once for
+// both.  Per pair of rows of the 7-point stencil: 10 memory instructions instead of 22.  Every row still adds ITS products in
+// ITS list order with the same operands -- bit-identical to the one-row form (and to SciPy).  Pairs that do not qualify
+// (different lists, irregular rows, odd start, the tail of a range, vectors that are not 16-byte aligned) take the one-row
+// path, one row after the other.
+template <typename T, int EPI>
+__device__ __forceinline__ T rowpat_value(const StreamArgs<T> &a, T b, T y, T xo, T d, T s, double &sq)
+{
+    const T one = T(1);
+    if constexpr (EPI == EPI_SET || EPI == EPI_ACCSEQ) return s;
+    else if constexpr (EPI == EPI_ACC) return y + s;
+    else if constexpr (EPI == EPI_RESID) return b - s;
+    else if constexpr (EPI == EPI_AXPBY) { const T t = a.c * b; return t + s; }
+    else if constexpr (EPI == EPI_ACC_AXPBY) { const T t = a.c * b; const T h = t + s; return y + h; }
+    else if constexpr (EPI == EPI_SUMSQ) { const T t = b - s; sq += (double)t * (double)t; return T(0); }
+    else if constexpr (EPI == EPI_JACOBI) return (d != T(0)) ? (one - a.omega) * xo + a.omega * ((b - s) / d) : xo;
+    else return (d != T(0)) ? (one - a.omega) * xo + a.omega * s / d : xo;                  // EPI_JACOBI_B
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(BLK) void csr_rowpat2_kernel(const StreamArgs<T> a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using T2 = typename Vec2<T>::type;
+    constexpr bool SKIPD = EpiTraits<EPI>::need_cols;          // Jacobi family: the diagonal never enters the sum
+    constexpr bool NEEDB = (EPI == EPI_RESID || EPI == EPI_AXPBY || EPI == EPI_ACC_AXPBY || EPI == EPI_SUMSQ || EPI >= EPI_JACOBI);
+    constexpr bool NEEDY = (EPI == EPI_ACC || EPI == EPI_ACC_AXPBY || EPI == EPI_ACCSEQ);
+    constexpr bool NEEDJ = (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B);
+    const int tid = threadIdx.x, lmax = a.lmax, np = a.npat;
+    int *tl = reinterpret_cast<int *>(smem_raw);               // [256] lengths
+    int *to = tl + 256;                                        // [np * lmax] offsets
+    T *tv = reinterpret_cast<T *>(smem_raw + (((size_t)(256 + np * lmax) * sizeof(int) + 15) & ~(size_t)15));   // [np * lmax] values
+    T *vd = tv + (size_t)np * lmax;                            // value dictionary (irregular rows)
+    {
+        const int *gl = reinterpret_cast<const int *>(a.ptab);
+        const T *gv = reinterpret_cast<const T *>(gl + 256 + np * lmax);
+        for (int k = tid; k < 256 + np * lmax; k += BLK) tl[k] = gl[k];
+        for (int k = tid; k < np * lmax; k += BLK) tv[k] = gv[k];
+        if (tid < a.nvd) vd[tid] = a.vdict[tid];
+    }
+    double sq = 0.0;
+    int blk = (int)blockIdx.x;
+    if (a.flags & 2) {
+        const int chunk = (a.nblk + 7) >> 3;
+        blk = (blk & 7) * chunk + (blk >> 3);
+    }
+    const bool live = blk < a.nblk;
+    if (live && a.blkmap) blk = a.blkmap[blk];
+    int4 meta = make_int4(0, 0, 0, 0), wb = make_int4(0, 0, 0, 0);
+    if (live) { meta = a.blkmeta[blk]; wb = a.wbase[blk]; }
+    const int r0 = meta.x, r1 = meta.y;
+    constexpr uintptr_t AL = 2 * sizeof(T) - 1;
+    const bool aligned = (((uintptr_t)a.x | (uintptr_t)a.y | (NEEDB ? (uintptr_t)a.b : 0) | (NEEDJ ? (uintptr_t)a.diag : 0) |
+                           ((EPI == EPI_SET && a.partial) ? (uintptr_t)a.partial : 0)) & AL) == 0;
+    // one row by the one-row path (the arithmetic of csr_rowpat_kernel)
+    auto one_row = [&](int r, unsigned pidv) {
+        RowPre<T> q = row_prefetch_noptr<T, EPI>(a, r);
+        T s = row_init<T, EPI>(q);
+        if (pidv != 255u) {
+            const int len = tl[pidv];
+            const int *po = to + pidv * lmax;
+            const T *pv = tv + pidv * lmax;
+            for (int j = 0; j < len; j += 8) {
+                int col[8];
+                T xv[8], av[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = (j + k < len) ? j + k : 0;
+                    col[k] = r + po[e];
+                    av[k] = pv[e];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) xv[k] = a.x[col[k]];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (j + k < len && (!SKIPD || col[k] != r)) {
+                        const T pr = av[k] * xv[k];
+                        if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
+                        else s += pr;
+                    }
+                }
+            }
+        } else {
+            const int lo = a.Ap[r], hi = a.Ap[r + 1];
+            for (int p = lo; p < hi; ++p) {
+                const unsigned c = a.Aj16[p];
+                const unsigned w = c >> 14;
+                const int col = (w == 0 ? wb.x : w == 1 ? wb.y : w == 2 ? wb.z : wb.w) + (int)(c & 0x3FFFu);
+                if (!SKIPD || col != r) {
+                    const T pr = vd[a.Ax8[p]] * a.x[col];
+                    if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
+                    else s += pr;
+                }
+            }
+        }
+        row_finish<T, EPI, 0>(a, q, s, sq);
+    };
+    __syncthreads();                                           // tables in place
+    for (int r = r0 + 2 * tid; r < r1; r += 2 * BLK) {
+        const bool two = r + 1 < r1;
+        unsigned p0, p1 = 255u;
+        if (two && !(r & 1)) {
+            const unsigned pp = *reinterpret_cast<const unsigned short *>(a.pid + r);
+            p0 = pp & 0xFFu; p1 = pp >> 8;
+        } else {
+            p0 = a.pid[r];
+            if (two) p1 = a.pid[r + 1];
+        }
+        if (aligned && two && !(r & 1) && p0 == p1 && p0 != 255u) {
+            T2 bb, yy, xo, dd;
+            bb.x = bb.y = yy.x = yy.y = xo.x = xo.y = dd.x = dd.y = T(0);
+            if constexpr (NEEDB) bb = *reinterpret_cast<const T2 *>(a.b + r);
+            if constexpr (NEEDY) yy = *reinterpret_cast<const T2 *>(a.y + r);
+            if constexpr (NEEDJ) { dd = *reinterpret_cast<const T2 *>(a.diag + r); xo = *reinterpret_cast<const T2 *>(a.x + r); }
+            T s0, s1;
+            if constexpr (EpiTraits<EPI>::bsr_order) { s0 = bb.x; s1 = bb.y; }
+            else if constexpr (EPI == EPI_ACCSEQ) { s0 = yy.x; s1 = yy.y; }
+            else { s0 = T(0); s1 = T(0); }
+            const int len = tl[p0];
+            const int *po = to + p0 * lmax;
+            const T *pv = tv + p0 * lmax;
+            for (int j = 0; j < len; j += 8) {
+                int off[8];
+                T av[8];
+                T2 xv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = (j + k < len) ? j + k : 0;                     // beyond the list: re-read its first entry
+                    off[k] = po[e];
+                    av[k] = pv[e];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const T *px = a.x + (r + off[k]);
+                    if (!(off[k] & 1)) xv[k] = *reinterpret_cast<const T2 *>(px);   // even offset: the pair is 16-byte aligned
+                    else { xv[k].x = px[0]; xv[k].y = px[1]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (j + k < len && (!SKIPD || off[k] != 0)) {
+                        const T q0 = av[k] * xv[k].x, q1 = av[k] * xv[k].y;
+                        if constexpr (EpiTraits<EPI>::bsr_order) { s0 -= q0; s1 -= q1; }
+                        else { s0 += q0; s1 += q1; }
+                    }
+                }
+            }
+            T2 v;
+            v.x = rowpat_value<T, EPI>(a, bb.x, yy.x, xo.x, dd.x, s0, sq);
+            v.y = rowpat_value<T, EPI>(a, bb.y, yy.y, xo.y, dd.y, s1, sq);
+            if constexpr (EPI != EPI_SUMSQ) *reinterpret_cast<T2 *>(a.y + r) = v;
+            if constexpr (EPI == EPI_SET) {
+                if (a.partial) { T2 z; z.x = z.y = T(0); *reinterpret_cast<T2 *>(reinterpret_cast<T *>(a.partial) + r) = z; }
+            }
+        } else {
+            one_row(r, p0);
+            if (two) one_row(r + 1, p1);
+        }
+    }
+    if constexpr (EPI == EPI_SUMSQ) {
+        __syncthreads();
+        const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
+        if (threadIdx.x == 0 && live) a.partial[blk] = tot;
+    }
+}
+
 // Single-workgroup persistent sweep (gs_flow1_kernel): ONE workgroup walks all row ranges of a
 // schedule, level after level, with __syncthreads() between them -- the scheduler of choice when
 // the levels are so narrow (<= 2 row ranges on average) that there is nothing to share out.

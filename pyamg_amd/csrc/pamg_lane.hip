@@ -52,6 +52,7 @@ struct LaneSched {
     long long *d_prof = nullptr;
     int64_t n_early = 0, n_old = 0, n_slots = 0;
     int64_t max_level_groups = 0;
+    int last_grid = 0;              // workgroups of the last launch (diagnostics)
     size_t bytes = 0;
 };
 
@@ -475,9 +476,11 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
         // 8x the wanted grid is launched; the workgroups off the home XCD leave at once
         PAMG_HIP(hipMemsetAsync(g->d_sync + 20, 0, 2 * sizeof(unsigned), s));
         const int Gx = std::max(1, std::min(G, (cus / 8) * cap));
+        t->last_grid = 8 * Gx;
         PAMG_HIP(hipLaunchKernel(k, dim3(8 * Gx), dim3(BLK), args, 0, s));
         return PAMG_OK;
     }
+    t->last_grid = G;
     PAMG_HIP(hipLaunchKernel(k, dim3(G), dim3(BLK), args, 0, s));
     return PAMG_OK;
 }
@@ -489,13 +492,13 @@ int lane_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b
     return lane_launch_t<float>(A, g, epi, x, b, omega, s);
 }
 
-// info[0..7] = lanes per row, slots per lane, groups, entry slots, early entries, old entries, widest level (groups), bytes
+// info[0..7] = lanes per row, slots per lane, groups, entry slots, early entries, workgroups of the last launch, widest level (groups), bytes
 int lane_info(const GsSchedule *g, int64_t *info)
 {
     for (int i = 0; i < 8; ++i) info[i] = 0;
     if (!g || !g->lane) return PAMG_OK;
     const LaneSched *t = g->lane;
-    info[0] = t->L; info[1] = t->K; info[2] = t->ngroups; info[3] = t->n_slots; info[4] = t->n_early; info[5] = t->n_old;
+    info[0] = t->L; info[1] = t->K; info[2] = t->ngroups; info[3] = t->n_slots; info[4] = t->n_early; info[5] = t->last_grid;
     info[6] = t->max_level_groups; info[7] = (int64_t)t->bytes;
     return PAMG_OK;
 }

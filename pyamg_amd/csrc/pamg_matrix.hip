@@ -111,7 +111,8 @@ int launch_rowpat(int epi, int grid, const pamg_matrix_s *A, hipStream_t s, Stre
     a.pid = A->d_pid; a.ptab = A->d_ptab; a.npat = A->npat; a.lmax = A->pat_lmax;
     const size_t tabs = (((size_t)(256 + A->npat * A->pat_lmax) * sizeof(int) + 15) & ~(size_t)15) + sizeof(T) * ((size_t)A->npat * A->pat_lmax + 256);
     const int lds = (int)std::max(tabs + 16, (size_t)BLK * sizeof(double));
-#define PAMG_RP(E) case E: hipLaunchKernelGGL((csr_rowpat_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); break;
+#define PAMG_RP(E) case E: if (A->use_rowpat >= 2) hipLaunchKernelGGL((csr_rowpat2_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); \
+                        else hipLaunchKernelGGL((csr_rowpat_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); break;
     switch (epi) {
         PAMG_RP(EPI_SET) PAMG_RP(EPI_ACC) PAMG_RP(EPI_RESID) PAMG_RP(EPI_AXPBY) PAMG_RP(EPI_ACC_AXPBY) PAMG_RP(EPI_SUMSQ)
         PAMG_RP(EPI_ACCSEQ) PAMG_RP(EPI_JACOBI) PAMG_RP(EPI_JACOBI_B)
@@ -1878,7 +1879,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
     // a finalised solver's captured graphs point into the schedules and plans this call would free
     if (key == 21) { A->use_val8 = value != 0; return PAMG_OK; }      // read at launch time only: no plan depends on it
     if (key == 22) { A->use_rowg = value != 0; return PAMG_OK; }      // likewise
-    if (key == 23) { A->use_rowpat = value != 0; return PAMG_OK; }
+    if (key == 23) { if (value < 0 || value > 2) return PAMG_E_ARG; A->use_rowpat = value; return PAMG_OK; }
     if (A->borrowed > 0) return PAMG_E_STATE;
     switch (key) {
         case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~3; A->cap_from_val8 = 0; break;

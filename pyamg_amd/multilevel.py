@@ -123,7 +123,7 @@ class DeviceMatrix:
         """layout of the lane-parallel fast-order sweep (schedule 0 = forward, 1 = backward): dict, all zero if none is built"""
         a = (C.c_int64 * 8)()
         capi.check(capi.lib().pamg_matrix_lane_info(self.handle, which, a), "pamg_matrix_lane_info")
-        return dict(zip(("lanes_per_row", "slots_per_lane", "groups", "entry_slots", "early_entries", "old_entries", "widest_level_groups", "bytes"), list(a)))
+        return dict(zip(("lanes_per_row", "slots_per_lane", "groups", "entry_slots", "early_entries", "launch_grid", "widest_level_groups", "bytes"), list(a)))
 
     def lane_profile(self, which=0):
         """time stamps of the lane sweep (tune(gs_prof=1)): int64 array [groups, 4]"""

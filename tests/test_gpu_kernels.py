@@ -856,10 +856,11 @@ def test_8bit_value_codes_are_bit_identical(dtype):
         assert dA.value_codes() == expect and dA.row_patterns() == npat, (dA.value_codes(), dA.row_patterns())
         dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
         out = {}
-        # 3: row patterns (the default where a table exists), 2: codes + row-gather kernel, 1: codes + staged kernel, 0: values as stored
-        for flag in (3, 2, 1, 0):
-            dA.tune(val8=min(flag, 1), rowgather=int(flag >= 2), rowpat=int(flag == 3))
-            assert dA.value_codes() == (expect if flag else 0) and dA.row_patterns() == (npat if flag == 3 else 0)
+        # 4: row patterns, two consecutive rows per lane (the default where a table exists), 3: row patterns, one row per lane,
+        # 2: codes + row-gather kernel, 1: codes + staged kernel, 0: values as stored
+        for flag in (4, 3, 2, 1, 0):
+            dA.tune(val8=min(flag, 1), rowgather=int(flag >= 2), rowpat=2 if flag == 4 else int(flag == 3))
+            assert dA.value_codes() == (expect if flag else 0) and dA.row_patterns() == (npat if flag >= 3 else 0)
             dy = capi.DeviceArray(n, dtype)
             dA.spmv(capi.SPMV_RESID, dx, dy, b=db)
             dz = capi.DeviceArray(n, dtype)
@@ -869,12 +870,12 @@ def test_8bit_value_codes_are_bit_identical(dtype):
             dA.jacobi(dj, db, dw, 0.8, iterations=2)
             out[flag] = (dy.download(), dz.download(), dj.download())
         for k in range(3):
-            assert all(np.array_equal(out[0][k], out[f][k], equal_nan=True) for f in (1, 2, 3)), k
+            assert all(np.array_equal(out[0][k], out[f][k], equal_nan=True) for f in (1, 2, 3, 4)), k
         # the remaining epilogues of the row-gather kernel against the staged kernel on the values as stored
         dA.tune(val8=1, rowgather=1, rowpat=1)
         res = {}
-        for flag in (2, 1, 0):
-            dA.tune(val8=min(flag, 1), rowgather=min(flag, 1), rowpat=int(flag == 2))
+        for flag in (3, 2, 1, 0):
+            dA.tune(val8=min(flag, 1), rowgather=min(flag, 1), rowpat=2 if flag == 3 else int(flag == 2))
             dy = capi.DeviceArray.from_host(b)
             dA.spmv(capi.SPMV_ACC, dx, dy)
             d2 = capi.DeviceArray.from_host(x)
@@ -886,7 +887,11 @@ def test_8bit_value_codes_are_bit_identical(dtype):
             res[flag] = (dy.download(), d2.download(), d3.download(), o.download())
         for k in range(4):
             assert np.array_equal(res[0][k], res[1][k], equal_nan=True) and np.array_equal(res[0][k], res[2][k], equal_nan=True), k
-        dA.tune(val8=1, rowgather=1, rowpat=1)
+        for k in range(3):
+            assert np.array_equal(res[0][k], res[3][k], equal_nan=True), k
+        # the norm's partial sums follow the lane -> row mapping, which the two-row form changes: same terms, another order
+        assert np.allclose(res[0][3], res[3][3], rtol=1e-13, atol=0, equal_nan=True)
+        dA.tune(val8=1, rowgather=1, rowpat=2)
         if dtype == np.float64:
             assert np.array_equal(out[1][1], sp.csr_array(A) @ x)
         dA.free()

@@ -26,10 +26,10 @@ for step in "$@"; do
         prof)
             wl=${rest%%:*}; extra=""; [[ "$rest" == *:* ]] && extra=${rest#*:}; extra=${extra//,/ }
             OUT=$PWD/gpurun_out/prof_${TAG}_$wl; mkdir -p $OUT
-            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python /root/repo/bench.py --workload $wl --steps 10 --warmup 2 --cpu-cycles 0 --no-extras --no-pmc --no-setup-compare $extra > $OUT/trace_bench.json 2> $OUT/trace.log)
+            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python /root/repo/bench.py --workload $wl --steps 10 --warmup 2 --cpu-cycles 0 --no-extras --no-pmc --no-setup-compare --kernel-map $OUT/kernel_map.json $extra > $OUT/trace_bench.json 2> $OUT/trace.log)
             python tools/summarize_prof.py $OUT $wl $TAG > $OUT/summarize.log 2>&1
             find $OUT -name "*.csv" -size +4M -delete
-            head -12 $OUT/kernel_stats_summary.txt ;;
+            head -12 $OUT/kernel_stats_summary.txt; head -30 $OUT/kernel_roofline.txt ;;
         *) echo "unknown step $step" ;;
     esac
 done

@@ -1,0 +1,71 @@
+"""Which launch of a cycle is which: for every operator of a resident hierarchy the kernels a V-cycle launches on it, keyed
+the way rocprofv3's kernel trace shows them (kernel family + epilogue + grid size in workgroups), with the algorithmic bytes
+of SURVEY.md 8(d) and the bytes the operator format that runs actually streams.  bench.py --kernel-map writes it next to
+the trace; tools/summarize_prof.py joins it with the measured durations into the per-kernel roofline table.  Not product
+code."""
+import numpy as np
+
+
+def _vec_bytes(epi, nr, nc, vb=8):
+    return {"SET": vb * (nc + nr), "ACC": vb * (nc + 2 * nr), "RESID": vb * (nc + 2 * nr), "SUMSQ": vb * (nc + nr),
+            "AXPBY": vb * (nc + 2 * nr), "ACC_AXPBY": vb * (nc + 3 * nr), "JACOBI": vb * (nc + 2 * nr), "JACOBI_B": vb * (nc + 2 * nr)}[epi]
+
+
+def _op_entry(level, opname, dA, epi, what):
+    inf = dA.info()
+    nr, nc, nnz = inf["rows"], inf["cols"], inf["nnz"]
+    vb = dA.dtype.itemsize
+    vec = _vec_bytes(epi, nr, nc, vb)
+    alg = (vb + 4) * nnz + 4 * (nr + 1) + vec
+    npat, nval = dA.row_patterns(), dA.value_codes()
+    if npat:
+        streamed, form = nr + vec, "row patterns (1 byte per row)"
+    elif nval:
+        streamed, form = 3 * nnz + 4 * (nr + 1) + vec, "16-bit columns + 8-bit value codes (3 bytes per entry)"
+    else:
+        streamed, form = (vb + 2) * nnz + 4 * (nr + 1) + vec, "16-bit columns + values as stored (10 bytes per entry)"
+    return {"family": "csr", "epi": epi, "grid": int(inf["row_blocks"]), "level": level, "op": opname, "what": what,
+            "rows": int(nr), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": int(streamed), "format": form}
+
+
+def kernel_map(dml, smoother_kind):
+    nlev = len(dml.A)
+    mats = list(dml._mats)
+    out = []
+    k = 0
+    for i in range(nlev):
+        A = mats[k]; k += 1
+        P = R = None
+        if i < nlev - 1:
+            P, R = mats[k], mats[k + 1]
+            k += 2
+        if i == 0:
+            out.append(_op_entry(i, "A", A, "SUMSQ", "convergence-check norm ||b - A x||"))
+        if i < nlev - 1:
+            out.append(_op_entry(i, "A", A, "RESID", "residual r = b - A x"))
+            out.append(_op_entry(i, "R", R, "SET", "restriction b_c = R r"))
+            out.append(_op_entry(i, "P", P, "ACC", "prolongation x += P x_c"))
+            inf = A.info()
+            n, nnz, vb = inf["rows"], inf["nnz"], A.dtype.itemsize
+            if smoother_kind == "gauss_seidel":
+                alg = (vb + 4) * nnz + 4 * (n + 1) + 3 * vb * n
+                for which, dirn in ((0, "forward"), (1, "backward")):
+                    lane, tile = A.lane_info(which), A.tile_info(which)
+                    if lane["groups"] and lane["launch_grid"]:
+                        out.append({"family": "gs_lane", "grid": int(lane["launch_grid"]), "level": i, "op": "A", "what": f"{dirn} Gauss-Seidel sweep (fast order, {lane['lanes_per_row']} lanes per row)",
+                                    "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": int(lane["entry_slots"] * (vb + 4) + n * (4 + 4 * vb)),
+                                    "format": f"{lane['lanes_per_row']} lanes x {lane['slots_per_lane']} slots per row, padded", "dependency_levels": int(inf["gs_levels_fwd"])})
+                    elif tile["tiles"]:
+                        out.append({"family": "gs_tile", "grid": int(tile["tiles"]), "level": i, "op": "A", "what": f"{dirn} Gauss-Seidel sweep (order-exact, tiled)",
+                                    "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": None, "format": "step blocks", "dependency_levels": int(inf["gs_levels_fwd"])})
+                    else:
+                        out.append({"family": "gs_gran", "grid": None, "level": i, "op": "A", "what": f"{dirn} Gauss-Seidel sweep (order-exact)",
+                                    "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": None, "format": "level-permuted CSR", "dependency_levels": int(inf["gs_levels_fwd"])})
+            elif smoother_kind == "jacobi":
+                out.append(_op_entry(i, "A", A, "JACOBI", "weighted Jacobi sweep"))
+                out.append(_op_entry(i, "A", A, "JACOBI_B", "weighted Jacobi sweep (BSR(1,1) levels)"))
+            elif smoother_kind == "chebyshev":
+                out.append(_op_entry(i, "A", A, "AXPBY", "Horner step h = c r + A h"))
+                out.append(_op_entry(i, "A", A, "ACC_AXPBY", "last Horner step folded with x += h"))
+                out.append(_op_entry(i, "A", A, "SET", "first product of the polynomial (x = 0)"))
+    return out

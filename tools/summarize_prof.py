@@ -1,6 +1,14 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output (kernel_stats / kernel_trace / counter_collection CSVs) into
-small text+json summaries that can be committed under profiles/."""
+"""Condense rocprofv3 output (kernel_trace / counter_collection CSVs) into small text + json summaries that can be
+committed under profiles/:
+
+  kernel_stats_summary.txt   kernel x grid -> calls, total, average duration, share of the run
+  kernel_roofline.txt        the same launches joined with bench.py's --kernel-map (which level / operator / role a launch
+                             is, its algorithmic bytes by SURVEY.md 8(d) and the bytes its operator format streams):
+                             GB/s, % of the 8 TB/s HBM peak and % of the measured copy ceiling -- per kernel of the cycle
+
+    python tools/summarize_prof.py <profile dir> <workload> <tag>
+"""
 import csv
 import glob
 import json
@@ -10,22 +18,42 @@ from collections import defaultdict
 from pathlib import Path
 
 out, wl, tag = Path(sys.argv[1]), sys.argv[2], sys.argv[3]
+EPI = ["SET", "ACC", "RESID", "AXPBY", "ACC_AXPBY", "SUMSQ", "ACCSEQ", "JACOBI", "JACOBI_B", "GS", "GS_B", "SOR", "JACOBI_IDX"]
 
 
 def short(name):
     m = re.search(r"csr_stream_kernel<(\w+), *(\d+), *(\d+)>", name)
-    epi = ["SET", "ACC", "RESID", "AXPBY", "ACC_AXPBY", "SUMSQ", "ACCSEQ", "JACOBI", "JACOBI_B", "GS", "GS_B", "SOR"]
     if m:
-        return f"csr_stream<{m.group(1)},{epi[int(m.group(2))]},npl{m.group(3)}>"
+        return f"csr_stream<{m.group(1)},{EPI[int(m.group(2))]},npl{m.group(3)}>"
     m = re.search(r"csr_(rowgather|rowpat)_kernel<(\w+), *(\d+)>", name)
     if m:
-        return f"csr_{m.group(1)}<{m.group(2)},{epi[int(m.group(3))]}>"
-    name = name.replace("(anonymous namespace)::", "")
+        return f"csr_{m.group(1)}<{m.group(2)},{EPI[int(m.group(3))]}>"
+    m = re.search(r"gs_lane_kernel<(\w+), *(\d+), *(\d+), *(\d+), *(\w+)>", name)
+    if m:
+        return f"gs_lane<{m.group(1)},{EPI[int(m.group(2))]},L{m.group(3)},K{m.group(4)},{'oneXCD' if m.group(5) in ('true', '1') else 'chip'}>"
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("pamg::", "")
     return re.sub(r"\(.*", "", name)[:70]
 
 
+def family(k):
+    if k.startswith("csr_"):
+        m = re.search(r",(\w+?)(,npl\d)?>", k)
+        return "csr", (m.group(1) if m else None)
+    if k.startswith("gs_lane"):
+        return "gs_lane", None
+    if k.startswith("gs_tile"):
+        return "gs_tile", None
+    if k.startswith("gs_gran") or k.startswith("gs_flow"):
+        return "gs_gran", None
+    return None, None
+
+
 summary = {"workload": wl, "tag": tag}
-# ---- kernel trace -> per-kernel count / total / avg
+kmap = None
+for f in (out / "kernel_map.json",):
+    if f.exists():
+        kmap = json.loads(f.read_text())
+# ---- kernel trace -> per (kernel, grid) count / total / avg
 for f in glob.glob(str(out / "trace" / "**" / "*kernel_trace.csv"), recursive=True):
     agg = defaultdict(lambda: [0, 0.0])
     with open(f) as fh:
@@ -33,18 +61,53 @@ for f in glob.glob(str(out / "trace" / "**" / "*kernel_trace.csv"), recursive=Tr
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             k = short(r["Kernel_Name"])
             gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
-            if gs >= 256 * 4096:                            # big launches (fine level): keep them apart
-                k = f"{k} [grid {gs // 256} wg]"
-            agg[k][0] += 1
-            agg[k][1] += d
+            wg = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 256)) or 256)
+            agg[(k, gs // max(wg, 1))][0] += 1
+            agg[(k, gs // max(wg, 1))][1] += d
     tot = sum(v[1] for v in agg.values())
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-    lines = [f"{'kernel':55s} {'calls':>8s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}"]
-    for k, (c, t) in rows:
-        lines.append(f"{k:55s} {c:8d} {t:12.1f} {t / c:10.2f} {100 * t / tot:6.2f}")
+    lines = [f"{'kernel [workgroups]':62s} {'calls':>8s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}"]
+    for (k, g), (c, t) in rows:
+        lines.append(f"{(k + ' [' + str(g) + ']'):62s} {c:8d} {t:12.1f} {t / c:10.2f} {100 * t / tot:6.2f}")
     (out / "kernel_stats_summary.txt").write_text("\n".join(lines) + "\n")
-    summary["kernels"] = {k: {"calls": c, "total_us": round(t, 1), "avg_us": round(t / c, 3)} for k, (c, t) in rows}
+    summary["kernels"] = {f"{k} [{g}]": {"calls": c, "total_us": round(t, 1), "avg_us": round(t / c, 3)} for (k, g), (c, t) in rows}
     print("\n".join(lines[:14]))
+    if kmap:
+        peak = float(kmap.get("peak_GBps") or 8000.0)
+        ceil = float((kmap.get("ceiling") or {}).get("copy_GBps") or 0.0)
+        ents = kmap["entries"]
+        rl = [f"per-kernel roofline of one {wl} cycle ({tag}); HBM peak {peak:.0f} GB/s" + (f", measured copy ceiling {ceil:.0f} GB/s" if ceil else ""),
+              "bytes: SURVEY.md 8(d) algorithmic bytes of the launch | bytes the operator format that ran streams; GB/s on each",
+              f"{'kernel [workgroups]':46s} {'lvl':>3s} {'op':>2s} {'role':44s} {'calls':>6s} {'avg_us':>9s} {'alg_MB':>9s} {'alg_GB/s':>9s} {'%peak':>6s} {'strm_MB':>9s} {'strm_GB/s':>9s} {'%peak':>6s} {'%ceil':>6s}"]
+        table = []
+        used = set()
+        for (k, g), (c, t) in rows:
+            fam, epi = family(k)
+            if not fam:
+                continue
+            cand = [i for i, e in enumerate(ents) if e["family"] == fam and (fam != "csr" or e["epi"] == epi) and (e["grid"] is None or e["grid"] == g or (fam == "csr" and 0 <= g - e["grid"] < 8))]
+            if not cand:
+                continue
+            # several operators with one grid size (tiny levels): the first unused entry
+            i = next((i for i in cand if i not in used), cand[0])
+            used.add(i)
+            e = ents[i]
+            avg = t / c
+            a_gbs = e["bytes_alg"] / avg / 1e3
+            s_gbs = e["bytes_streamed"] / avg / 1e3 if e.get("bytes_streamed") else None
+            rec = {"kernel": k, "grid": g, "level": e["level"], "op": e["op"], "role": e["what"], "calls": c, "avg_us": round(avg, 2), "bytes_alg": e["bytes_alg"],
+                   "GBps_alg": round(a_gbs, 1), "pct_peak_alg": round(100 * a_gbs / peak, 2), "bytes_streamed": e.get("bytes_streamed"),
+                   "GBps_streamed": round(s_gbs, 1) if s_gbs else None, "pct_peak_streamed": round(100 * s_gbs / peak, 2) if s_gbs else None,
+                   "pct_ceiling_streamed": round(100 * s_gbs / ceil, 2) if (s_gbs and ceil) else None, "format": e.get("format")}
+            if e.get("dependency_levels"):
+                rec["us_per_dependency_level"] = round(avg / e["dependency_levels"], 3)
+            table.append(rec)
+            rl.append(f"{(k + ' [' + str(g) + ']')[:46]:46s} {e['level']:3d} {e['op']:>2s} {e['what'][:44]:44s} {c:6d} {avg:9.2f} {e['bytes_alg'] / 1e6:9.2f} {a_gbs:9.1f} {100 * a_gbs / peak:6.2f} "
+                      + (f"{e['bytes_streamed'] / 1e6:9.2f} {s_gbs:9.1f} {100 * s_gbs / peak:6.2f} " + (f"{100 * s_gbs / ceil:6.2f}" if ceil else f"{'':6s}") if s_gbs else f"{'-':>9s} {'-':>9s} {'-':>6s} {'-':>6s}")
+                      + (f"   {rec['us_per_dependency_level']} us per dependency level x {e['dependency_levels']}" if e.get("dependency_levels") else ""))
+        (out / "kernel_roofline.txt").write_text("\n".join(rl) + "\n")
+        summary["kernel_roofline"] = table
+        print("\n".join(rl[:24]))
 # ---- PMC passes
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
     sub = "pmc_fetch" if cname == "FETCH_SIZE" else "pmc_write"
@@ -63,4 +126,3 @@ for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         summary[cname] = {k: {"calls": c, "avg_value_KB": round(v / c, 1)} for k, (c, v) in
                           sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]}
 (out / "summary.json").write_text(json.dumps(summary, indent=1))
-print(json.dumps({k: summary.get(k) for k in ("FETCH_SIZE", "WRITE_SIZE")}, indent=1)[:3000])
