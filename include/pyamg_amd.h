@@ -335,8 +335,9 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * 22 = row-gather form of the whole-operator kernels on operators with value codes (default 1 there): lane = row, the j-th
  * entries of 64 consecutive rows in one gather instruction (coalesced on stencils), products summed in storage order in
  * registers; 0 = the LDS-staged kernel on the codes;
- * 23 = row-pattern form where plan_rowpat found a table (see pamg_matrix_row_patterns): 2 (default) two consecutive rows per
- * lane -- b, y, the result and every even-offset gather move as 16-byte accesses --, 1 one row per lane, 0 off.
+ * 23 = row-pattern form where plan_rowpat found a table (see pamg_matrix_row_patterns): 1 (default) one row per lane, 2 two
+ * consecutive rows per lane -- b, y, the result and every even-offset gather move as 16-byte accesses; measured 28 % slower on the
+ * 256^3 stencil (profiles/r04_microbench_rowpat_two_rows_per_lane_slower.json) --, 0 off.
  * NOT speed-only -- 24 = ORDER of the row sums of the scalar Gauss-Seidel / SOR sweeps: 0 (default of a bare operator) =
  * order-exact, every sum runs in storage order with an IEEE division, results are the reference's bit for bit
  * (amg_core/relaxation.h:48-76,116-145,185-266); 1 = FAST order: the same sweep order over the rows (same dependency
@@ -544,6 +545,12 @@ int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c);
  * (coarse_solver='gauss_seidel' / 'jacobi' / 'chebyshev' ...: multilevel.py:765-782).  Call after the level's
  * pamg_solver_set_*smoother. */
 int pamg_solver_set_coarse_relax(pamg_solver_t S);
+/* Coarsest-level solve by a function of the CALLER on the host (multilevel.py:752-762: coarse_solver='bicgstab' | 'cgs' | 'qmr' |
+ * 'minres' | ..., :786-788: a callable): the coarse right-hand side (n_c values, host copy) is handed to fn, which fills x and
+ * returns 0.  Such solvers are not linear in b, so they cannot be tabulated like 'pinv' / 'splu'; n_c is tiny, the two copies
+ * and the synchronisation are the price (cycles of such a solver are not replayed from a hipGraph). */
+typedef int (*pamg_coarse_host_fn)(void *user, const void *b_host, void *x_host, int64_t n_c);
+int pamg_solver_set_coarse_host(pamg_solver_t S, pamg_coarse_host_fn fn, void *user, int n_c);
 int pamg_solver_finalize(pamg_solver_t S);
 /* one multigrid cycle on DEVICE x, b of level 0 (multilevel.py:584-662) */
 int pamg_solver_cycle(pamg_solver_t S, void *x, const void *b, int cycle, int cycles_per_level,
@@ -639,6 +646,21 @@ int pamg_dist_set_collapse(pamg_dist_t D, pamg_solver_t coarse, int64_t nc, int6
 int pamg_dist_set_smoother(pamg_dist_t D, int level, int which, int kind, int iterations, double omega, const double *coeffs,
                            int ncoeffs, const void *Dinv, int blocksize);
 int pamg_dist_set_callbacks(pamg_dist_t D, pamg_dist_exchange_fn exchange, pamg_dist_allreduce_fn allreduce, void *user);
+/* The all-gather form of the halo exchange (the general fallback and the correctness baseline; the default is
+ * point to point with the actual neighbours, which moves world x less): every rank contributes its owned part of the level
+ * vector padded to count_per_rank values (>= the largest owned part), halo_src[i] (HOST, one per halo value) is the position of
+ * halo value i in the gathered vector = owner * count_per_rank + index at the owner.  pamg_dist_set_exchange: 0 = point to
+ * point (default), 1 = all-gather (every level that talks must have been given its halo_src); may be switched between
+ * iterations.  With RCCL the gather is ONE ncclAllGather per exchange on the comm stream; the host-callback transport of the
+ * test rigs forms it with the all-reduce callback (sum of disjoint slices). */
+int pamg_dist_set_allgather(pamg_dist_t D, int level, int64_t count_per_rank, const int32_t *halo_src);
+int pamg_dist_set_exchange(pamg_dist_t D, int mode);
+/* One-rank exercise of every RCCL entry point the sharded cycle uses, on the current device, through the table this library
+ * binds at run time (ncclGetUniqueId, ncclCommInitRank, grouped ncclSend + ncclRecv to itself on a comm stream ordered against
+ * a main stream by events exactly like the halo exchange, ncclAllGather, a one-element ncclAllReduce, ncclCommDestroy) with
+ * n float64 values; *max_err = largest |received - sent|.  PAMG_E_UNSUPPORTED: no librccl to bind. */
+int pamg_rccl_selftest(int64_t n, double *max_err);
+int pamg_rccl_available(void);                             /* PAMG_OK when a librccl could be bound (no communicator is created) */
 int pamg_dist_rccl_unique_id(void *id128);                 /* 128 bytes; PAMG_E_UNSUPPORTED: no librccl to bind */
 int pamg_dist_set_rccl(pamg_dist_t D, const void *id128);  /* collective: ncclCommInitRank(world, id, rank) */
 int pamg_dist_finalize(pamg_dist_t D);

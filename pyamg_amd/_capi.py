@@ -159,6 +159,7 @@ def _declare(lib):
     f("pamg_solver_set_cf_smoother", _vp, _i, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i)
     f("pamg_solver_set_coarse_dense", _vp, _vp, _i)
     f("pamg_solver_set_coarse_relax", _vp)
+    f("pamg_solver_set_coarse_host", _vp, _vp, _vp, _i)
     f("pamg_solver_finalize", _vp)
     f("pamg_solver_cycle", _vp, _vp, _vp, _i, _i, _vp)
     f("pamg_solver_solve", _vp, _vp, _vp, _d, _i, _i, _i, _i, _vp, P(_i), P(_i), _vp)
@@ -188,6 +189,10 @@ def _declare(lib):
     f("pamg_dist_sync", _vp)
     f("pamg_dist_stream", _vp, P(_vp))
     f("pamg_dist_info", _vp, P(C.c_int64))
+    f("pamg_dist_set_allgather", _vp, _i, C.c_int64, _vp)
+    f("pamg_dist_set_exchange", _vp, _i)
+    f("pamg_rccl_selftest", C.c_int64, P(C.c_double))
+    f("pamg_rccl_available")
     f("pamg_dist_exchange_test", _vp, _i, _vp, _vp)
     f("pamg_csr_create", P(_vp), C.c_int64, C.c_int64, _vp, _vp, _vp)
     f("pamg_csr_view", P(_vp), _vp)

@@ -179,7 +179,7 @@ struct pamg_matrix_s {
     unsigned char *d_pid = nullptr;  // row patterns (plan_rowpat): list number per row, 255 = walk the row through the code arrays
     void *d_ptab = nullptr;          //   [256] lengths | [npat * pat_lmax] column offsets | [npat * pat_lmax] values
     int npat = 0, pat_lmax = 0;
-    int use_rowpat = 2;              // tune key 23: 0 off, 1 one row per lane, 2 two consecutive rows per lane (16-byte accesses)
+    int use_rowpat = 1;              // tune key 23: 0 off, 1 one row per lane (default), 2 two consecutive rows per lane (16-byte accesses; measured slower)
     int cap_from_val8 = 0;           // cap was raised to 2048 because the operator streams value codes (level schedules keep 1536)
     int use_xwin = 0;                // LDS-staged x windows for the whole-operator kernels (tune key 9)
     void *d_xwin = nullptr;          // XWin[nblk] window plan (device)

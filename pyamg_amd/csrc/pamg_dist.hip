@@ -43,6 +43,7 @@ struct Rccl {
     int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -75,7 +76,7 @@ Rccl *rccl()
     if (!r.h) return nullptr;
 #define PAMG_SYM(f, name) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.h, name)); if (!r.f) { r.h = nullptr; return nullptr; }
     PAMG_SYM(GetUniqueId, "ncclGetUniqueId") PAMG_SYM(CommInitRank, "ncclCommInitRank") PAMG_SYM(CommDestroy, "ncclCommDestroy")
-    PAMG_SYM(Send, "ncclSend") PAMG_SYM(Recv, "ncclRecv") PAMG_SYM(AllReduce, "ncclAllReduce")
+    PAMG_SYM(Send, "ncclSend") PAMG_SYM(Recv, "ncclRecv") PAMG_SYM(AllReduce, "ncclAllReduce") PAMG_SYM(AllGather, "ncclAllGather")
     PAMG_SYM(GroupStart, "ncclGroupStart") PAMG_SYM(GroupEnd, "ncclGroupEnd") PAMG_SYM(GetErrorString, "ncclGetErrorString")
 #undef PAMG_SYM
     return &r;
@@ -104,6 +105,11 @@ struct DLevel {
     std::vector<int64_t> send_off, recv_off;                    // [n+1] scalar offsets into send_buf / the halo
     int *d_send_idx = nullptr;
     void *send_buf = nullptr;
+    // all-gather form of the exchange ("keep the full all-gather as the general fallback and the correctness baseline"):
+    // every rank contributes its owned part padded to ag_count values, the halo is then picked out of the gathered vector
+    int64_t ag_count = 0;             // values per rank in the gathered vector (max owned over the ranks); 0 = not set up
+    int *d_halo_src = nullptr;        // [n_halo] position of every halo value in the gathered vector
+    void *ag_stage = nullptr, *ag_all = nullptr;   // [ag_count], [world * ag_count]
     void *x = nullptr, *xalt = nullptr, *x_home = nullptr, *b = nullptr, *r = nullptr, *h0 = nullptr, *h1 = nullptr;
     DSmoother pre, post;
     int64_t n_local() const { return n_owned + n_halo; }
@@ -128,6 +134,7 @@ struct pamg_dist_s {
     pamg_dist_allreduce_fn cb_allreduce = nullptr;
     void *cb_user = nullptr;
     void *nccl_comm = nullptr;
+    int xmode = 0;                    // halo exchange: 0 = point to point with the actual neighbours (default), 1 = all-gather of the owned parts
     bool overlap = true;              // interior rows while the halo is in flight
     bool use_graph = true;
     bool capturing = false;
@@ -188,6 +195,20 @@ int begin_exchange(pamg_dist_s *D, int l, void *v)
 {
     DLevel &L = D->lv[l];
     const size_t ts = ts_of(D);
+    if (D->xmode == 1) {
+        // all-gather form: owned part -> staging (padded), gathered over the ranks on the comm stream, halo picked out of it
+        if (!L.ag_count) return PAMG_E_STATE;
+        if (L.n_owned) PAMG_HIP(hipMemcpyAsync(L.ag_stage, v, (size_t)L.n_owned * ts, hipMemcpyDeviceToDevice, D->main));
+        PAMG_HIP(hipEventRecord(D->ev_pack, D->main));
+        if (D->mode == 2) {
+            Rccl *R = rccl();
+            PAMG_HIP(hipStreamWaitEvent(D->comm, D->ev_pack, 0));
+            PAMG_NCCL(R->AllGather(L.ag_stage, L.ag_all, (size_t)L.ag_count, D->dtype == PAMG_F64 ? NCCL_F64 : NCCL_F32, D->nccl_comm, D->comm));
+            if (L.n_halo) PAMG_TRY(pamg_vec_gather(D->dtype, L.n_halo, L.d_halo_src, L.ag_all, (char *)v + (size_t)L.n_owned * ts, D->comm));
+            PAMG_HIP(hipEventRecord(D->ev_halo, D->comm));
+        }
+        return PAMG_OK;
+    }
     const int64_t ns = L.send_off.empty() ? 0 : L.send_off.back();
     if (ns) PAMG_TRY(pamg_vec_gather(D->dtype, ns, L.d_send_idx, v, L.send_buf, D->main));
     PAMG_HIP(hipEventRecord(D->ev_pack, D->main));
@@ -212,6 +233,16 @@ int finish_exchange(pamg_dist_s *D, int l, void *v)
 {
     DLevel &L = D->lv[l];
     if (D->mode == 2) return (int)hipStreamWaitEvent(D->main, D->ev_halo, 0);
+    if (D->mode == 1 && D->xmode == 1) {
+        // host-callback rigs: the all-gather is the sum of the ranks' slices of an otherwise zero vector (the all-reduce callback)
+        const size_t ts = ts_of(D);
+        PAMG_HIP(hipMemsetAsync(L.ag_all, 0, (size_t)D->world * (size_t)L.ag_count * ts, D->main));
+        if (L.n_owned) PAMG_HIP(hipMemcpyAsync((char *)L.ag_all + (size_t)D->rank * (size_t)L.ag_count * ts, L.ag_stage, (size_t)L.n_owned * ts, hipMemcpyDeviceToDevice, D->main));
+        PAMG_HIP(hipStreamSynchronize(D->main));
+        PAMG_TRY(D->cb_allreduce(D->cb_user, L.ag_all, (int64_t)D->world * L.ag_count, D->dtype));
+        if (L.n_halo) PAMG_TRY(pamg_vec_gather(D->dtype, L.n_halo, L.d_halo_src, L.ag_all, (char *)v + (size_t)L.n_owned * ts, D->main));
+        return PAMG_OK;
+    }
     if (D->mode == 1) {
         PAMG_HIP(hipEventSynchronize(D->ev_pack));                 // the packed values are in send_buf; later main-stream work keeps running
         const int64_t ns = L.send_off.empty() ? 0 : L.send_off.back();
@@ -397,6 +428,7 @@ int pamg_dist_destroy(pamg_dist_t D)
     for (DLevel &L : D->lv) {
         for (pamg_matrix_s *M : {L.A, L.P, L.R}) if (M) M->borrowed--;
         hipFree(L.d_send_idx); hipFree(L.send_buf);
+        hipFree(L.d_halo_src); hipFree(L.ag_stage); hipFree(L.ag_all);
         hipFree(L.x_home); hipFree(L.x_home == L.x ? L.xalt : L.x); hipFree(L.b); hipFree(L.r); hipFree(L.h0); hipFree(L.h1);
         free_smoother(L.pre); free_smoother(L.post);
     }
@@ -517,6 +549,105 @@ int pamg_dist_set_callbacks(pamg_dist_t D, pamg_dist_exchange_fn exchange, pamg_
     D->mode = 1; D->cb_exchange = exchange; D->cb_allreduce = allreduce; D->cb_user = user;
     return PAMG_OK;
 }
+
+int pamg_dist_set_allgather(pamg_dist_t D, int level, int64_t count_per_rank, const int32_t *halo_src)
+{
+    if (!D || level < 0 || level >= (int)D->lv.size() || count_per_rank < 0) return PAMG_E_ARG;
+    if (D->finalized) return PAMG_E_STATE;
+    DLevel &L = D->lv[level];
+    if (count_per_rank < L.n_owned || (L.n_halo && !halo_src)) return PAMG_E_ARG;
+    for (int64_t i = 0; i < L.n_halo; ++i)
+        if (halo_src[i] < 0 || (int64_t)halo_src[i] >= (int64_t)D->world * count_per_rank) return PAMG_E_ARG;
+    const size_t ts = ts_of(D);
+    hipFree(L.d_halo_src); hipFree(L.ag_stage); hipFree(L.ag_all);
+    L.d_halo_src = nullptr; L.ag_stage = L.ag_all = nullptr;
+    PAMG_TRY(dmalloc(D, &L.ag_stage, (size_t)std::max<int64_t>(count_per_rank, 1) * ts));
+    PAMG_TRY(dmalloc(D, &L.ag_all, (size_t)std::max<int64_t>(count_per_rank, 1) * (size_t)D->world * ts));
+    if (L.n_halo) {
+        PAMG_HIP(hipMalloc((void **)&L.d_halo_src, sizeof(int) * (size_t)L.n_halo));
+        PAMG_HIP(hipMemcpy(L.d_halo_src, halo_src, sizeof(int) * (size_t)L.n_halo, hipMemcpyHostToDevice));
+    }
+    L.ag_count = std::max<int64_t>(count_per_rank, 1);
+    return PAMG_OK;
+}
+
+int pamg_dist_set_exchange(pamg_dist_t D, int mode)
+{
+    if (!D || (mode != 0 && mode != 1)) return PAMG_E_ARG;
+    if (mode == 1)
+        for (const DLevel &L : D->lv)
+            if (L.talks() && !L.ag_count) return PAMG_E_STATE;
+    if (D->xmode != mode) {
+        for (int k = 0; k < 2; ++k) if (D->graph[k]) { hipGraphExecDestroy(D->graph[k]); D->graph[k] = nullptr; }
+    }
+    D->xmode = mode;
+    return PAMG_OK;
+}
+
+// One-rank exercise of everything the sharded cycle asks of RCCL, on the current device: a communicator from a fresh id, a
+// grouped ncclSend + ncclRecv (to itself) on a comm stream ordered against a main stream by the two events of
+// begin_exchange / finish_exchange, a 1-element ncclAllReduce and an ncclAllGather -- through the dlsym'd table, with the
+// enum constants this file hard-codes.  *max_err = largest deviation of a received value from the value sent.
+int pamg_rccl_selftest(int64_t n, double *max_err)
+{
+    if (n < 1 || !max_err) return PAMG_E_ARG;
+    *max_err = -1.0;
+    Rccl *R = rccl();
+    if (!R) return PAMG_E_UNSUPPORTED;
+    RcclId id;
+    PAMG_NCCL(R->GetUniqueId(&id));
+    void *comm = nullptr;
+    PAMG_NCCL(R->CommInitRank(&comm, 1, id, 0));
+    hipStream_t main = nullptr, cs = nullptr;
+    hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
+    double *src = nullptr, *dst = nullptr, *one = nullptr, *all = nullptr;
+    int st = PAMG_OK;
+    std::vector<double> h((size_t)n), back((size_t)n, -1.0), back2((size_t)n, -1.0);
+    for (int64_t i = 0; i < n; ++i) h[(size_t)i] = 0.25 + (double)(i % 4099) * 1.5;
+    double hone = 3.5, hone_back = 0.0;
+    auto run = [&]() -> int {
+        PAMG_HIP(hipStreamCreateWithFlags(&main, hipStreamNonBlocking));
+        PAMG_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        PAMG_HIP(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
+        PAMG_HIP(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+        PAMG_HIP(hipMalloc((void **)&src, (size_t)n * 8)); PAMG_HIP(hipMalloc((void **)&dst, (size_t)n * 8));
+        PAMG_HIP(hipMalloc((void **)&one, 16)); PAMG_HIP(hipMalloc((void **)&all, (size_t)n * 8));
+        PAMG_HIP(hipMemsetAsync(dst, 0xFF, (size_t)n * 8, main));
+        PAMG_HIP(hipMemcpyAsync(src, h.data(), (size_t)n * 8, hipMemcpyHostToDevice, main));
+        PAMG_HIP(hipMemcpyAsync(one, &hone, 8, hipMemcpyHostToDevice, main));
+        PAMG_HIP(hipEventRecord(ev_pack, main));
+        PAMG_HIP(hipStreamWaitEvent(cs, ev_pack, 0));
+        PAMG_NCCL(R->GroupStart());
+        PAMG_NCCL(R->Recv(dst, (size_t)n, NCCL_F64, 0, comm, cs));
+        PAMG_NCCL(R->Send(src, (size_t)n, NCCL_F64, 0, comm, cs));
+        PAMG_NCCL(R->GroupEnd());
+        PAMG_NCCL(R->AllGather(src, all, (size_t)n, NCCL_F64, comm, cs));
+        PAMG_HIP(hipEventRecord(ev_halo, cs));
+        PAMG_HIP(hipStreamWaitEvent(main, ev_halo, 0));
+        PAMG_NCCL(R->AllReduce(one, one, 1, NCCL_F64, NCCL_SUM, comm, main));
+        PAMG_HIP(hipMemcpyAsync(back.data(), dst, (size_t)n * 8, hipMemcpyDeviceToHost, main));
+        PAMG_HIP(hipMemcpyAsync(back2.data(), all, (size_t)n * 8, hipMemcpyDeviceToHost, main));
+        PAMG_HIP(hipMemcpyAsync(&hone_back, one, 8, hipMemcpyDeviceToHost, main));
+        PAMG_HIP(hipStreamSynchronize(main));
+        return PAMG_OK;
+    };
+    st = run();
+    if (st == PAMG_OK) {
+        double e = std::fabs(hone_back - hone);
+        for (int64_t i = 0; i < n; ++i) e = std::max(e, std::max(std::fabs(back[(size_t)i] - h[(size_t)i]), std::fabs(back2[(size_t)i] - h[(size_t)i])));
+        if (!(e == e)) e = 1e300;                              // NaN (the 0xFF fill survived): nothing arrived
+        *max_err = e;
+    }
+    hipFree(src); hipFree(dst); hipFree(one); hipFree(all);
+    if (ev_pack) hipEventDestroy(ev_pack);
+    if (ev_halo) hipEventDestroy(ev_halo);
+    if (main) hipStreamDestroy(main);
+    if (cs) hipStreamDestroy(cs);
+    R->CommDestroy(comm);
+    return st;
+}
+
+int pamg_rccl_available(void) { return rccl() ? PAMG_OK : PAMG_E_UNSUPPORTED; }
 
 int pamg_dist_rccl_unique_id(void *id128)
 {
@@ -683,7 +814,7 @@ int pamg_dist_exchange_test(pamg_dist_t D, int level, const void *x_owned, void 
     return PAMG_OK;
 }
 
-/* info: [0] sharded levels [1] transport mode (0 none, 1 callbacks, 2 RCCL) [2] halo exchanges per iteration (cycle + norm)
+/* info: [0] sharded levels [1] transport mode (0 none, 1 callbacks, 2 RCCL; + 16 when the exchange is the all-gather form) [2] halo exchanges per iteration (cycle + norm)
  * [3] of those, exchanges overlapped with interior rows [4] whole iteration replayed from a hipGraph [5] bytes of vectors
  * [6] values sent per iteration [7] interior row ranges of the fine-level operator (of [3] of pamg_matrix_info) */
 int pamg_dist_info(pamg_dist_t D, int64_t info[8])
@@ -691,7 +822,7 @@ int pamg_dist_info(pamg_dist_t D, int64_t info[8])
     if (!D || !info) return PAMG_E_ARG;
     for (int k = 0; k < 8; ++k) info[k] = 0;
     info[0] = (int64_t)D->lv.size() - (D->collapse_set ? 1 : 0);
-    info[1] = D->mode;
+    info[1] = D->mode + 16 * D->xmode;               // + 16: all-gather form of the exchange
     info[2] = D->n_exchanges; info[3] = D->n_overlapped;
     info[4] = D->finalized && graph_ok(D) ? 1 : 0;
     info[5] = (int64_t)D->bytes;

@@ -173,6 +173,9 @@ struct pamg_solver_s {
     void *d_coarse = nullptr;     // dense coarse operator (row-major n_c x n_c)
     int n_c = 0;
     bool coarse_set = false, coarse_zero = false, coarse_relax = false;
+    pamg_coarse_host_fn coarse_host = nullptr;   // coarsest solve on the HOST by the caller's own function (multilevel.py:752-762,786-788)
+    void *coarse_host_user = nullptr;
+    std::vector<unsigned char> coarse_hb, coarse_hx;
     bool finalized = false;
     bool use_graph = true;
     hipStream_t own_stream = nullptr;
@@ -337,6 +340,16 @@ int coarse_solve(pamg_solver_s *S, const void *b, void *x, hipStream_t s)
         return PAMG_OK;
     }
     if (S->coarse_zero) return (int)hipMemsetAsync(x, 0, (size_t)S->n_c * tsize(S->dtype), s);
+    if (S->coarse_host) {
+        // the coarse right-hand side (a few hundred values at most) goes down, the caller's solver runs, the answer comes back
+        const size_t vb = (size_t)S->n_c * tsize(S->dtype);
+        PAMG_HIP(hipMemcpyAsync(S->coarse_hb.data(), b, vb, hipMemcpyDeviceToHost, s));
+        PAMG_HIP(hipStreamSynchronize(s));
+        if (S->coarse_host(S->coarse_host_user, S->coarse_hb.data(), S->coarse_hx.data(), (int64_t)S->n_c) != 0) return PAMG_E_STATE;
+        PAMG_HIP(hipMemcpyAsync(x, S->coarse_hx.data(), vb, hipMemcpyHostToDevice, s));
+        PAMG_HIP(hipStreamSynchronize(s));                     // the host buffer is reused by the next cycle
+        return PAMG_OK;
+    }
     return dense_gemv(S->dtype, S->n_c, S->d_coarse, b, x, s);
 }
 
@@ -426,7 +439,7 @@ int build_tail(pamg_solver_s *S)
     const char *e = getenv("PAMG_TAIL");
     if (!e || *e != '1') return PAMG_OK;
     const int nlev = (int)S->levels.size();
-    if (nlev < 2 || S->coarse_relax || S->n_c > TAIL_MAX_ROWS) return PAMG_OK;
+    if (nlev < 2 || S->coarse_relax || S->coarse_host || S->n_c > TAIL_MAX_ROWS) return PAMG_OK;
     int from = nlev - 1;                                           // the coarsest level always qualifies here
     for (int l = nlev - 2; l >= 1; --l) {                          // never level 0: the cycle's entry point stays a normal launch sequence
         const Level &L = S->levels[l];
@@ -1362,6 +1375,18 @@ int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c)
         PAMG_HIP(hipMemcpy(S->d_coarse, M, sz, hipMemcpyHostToDevice));
         S->bytes += sz;
     }
+    return PAMG_OK;
+}
+
+int pamg_solver_set_coarse_host(pamg_solver_t S, pamg_coarse_host_fn fn, void *user, int n_c)
+{
+    if (!S || !fn || n_c < 1) return PAMG_E_ARG;
+    if (S->finalized) return PAMG_E_STATE;
+    S->coarse_host = fn; S->coarse_host_user = user;
+    S->n_c = n_c; S->coarse_set = true; S->coarse_zero = false; S->coarse_relax = false;
+    S->coarse_hb.assign((size_t)n_c * tsize(S->dtype), 0);
+    S->coarse_hx.assign((size_t)n_c * tsize(S->dtype), 0);
+    S->host_sync = true;                                        // the cycle synchronises with the host: no graph capture
     return PAMG_OK;
 }
 

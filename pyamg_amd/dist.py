@@ -349,9 +349,14 @@ class DistMultilevelSolver:
     each rank uses its slice and ``solve`` returns the global solution on every rank).
     """
 
-    def __init__(self, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000, sharded=None, native=None):
+    def __init__(self, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000, sharded=None, native=None,
+                 exchange: Optional[str] = None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
+        # halo exchange of the C++ driver: 'halo' = point to point with the actual neighbours (default), 'allgather' = every
+        # rank's owned part gathered everywhere (the general fallback / correctness baseline of SURVEY 8e)
+        self.exchange = exchange or __import__("os").environ.get("PAMG_DIST_EXCHANGE", "halo")
+        self.transport_tried = []
         if dist.is_initialized():
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
             self._gloo = dist.get_backend(group) == "gloo"
@@ -420,11 +425,21 @@ class DistMultilevelSolver:
         if self._gloo:                                   # test rigs: several ranks on one GPU, staged through the host
             nat = _NativeCycle(self, "host")
             bad = nat.verify_exchange()
-            if not self._all_agree(not bad):
+            okh = self._all_agree(not bad)
+            self.transport_tried.append({"transport": "host callbacks (gloo)", "ok": bool(okh), "why": bad})
+            if not okh:
                 raise RuntimeError(f"rank {self.rank}: halo exchange self-test failed ({bad or 'on another rank'})")
             return nat
         nat, why = None, ""
-        if want != "torch":
+        # agree on the binding BEFORE anybody enters a collective of RCCL's (a rank that cannot bind librccl would otherwise go
+        # straight to the vote below while the others wait for it inside ncclCommInitRank)
+        from . import _capi as capi_
+        have = self._all_agree(capi_.lib().pamg_rccl_available() == 0)
+        if want != "torch" and not have:
+            self.transport_tried.append({"transport": "rccl", "ok": False, "why": "librccl could not be bound on every rank"})
+            if want == "rccl":
+                raise RuntimeError(f"rank {self.rank}: RCCL requested but librccl cannot be bound on every rank")
+        if want != "torch" and have:
             try:
                 nat = _NativeCycle(self, "rccl")
                 bad = nat.verify_exchange()
@@ -433,6 +448,7 @@ class DistMultilevelSolver:
             except Exception as e:                  # noqa: BLE001 -- any failure here means: use the other transport
                 why = repr(e)
             ok = self._all_agree(nat is not None and not why)
+            self.transport_tried.append({"transport": "rccl", "ok": bool(ok), "why": why or ("" if ok else "failed on another rank")})
             if ok or want == "rccl":
                 if not ok:
                     raise RuntimeError(f"rank {self.rank}: RCCL transport failed its self-test ({why or 'on another rank'})")
@@ -443,7 +459,9 @@ class DistMultilevelSolver:
                   "using torch.distributed point-to-point on the driver's buffers", file=sys.stderr, flush=True)
         nat = _NativeCycle(self, "torch")
         bad = nat.verify_exchange()
-        if not self._all_agree(not bad):
+        okt = self._all_agree(not bad)
+        self.transport_tried.append({"transport": "torch point-to-point", "ok": bool(okt), "why": bad})
+        if not okt:
             raise RuntimeError(f"rank {self.rank}: halo exchange self-test failed on both transports ({bad or 'on another rank'})")
         return nat
 
@@ -708,12 +726,14 @@ class _NativeCycle:
             capi.check(lib.pamg_dist_add_level(h, sol.A[l].handle, sol.P[l].handle, sol.R[l].handle, p.n_owned_s, p.n_halo_s,
                                                sp_.size, capi.ptr(sp_), capi.ptr(so_), capi.ptr(sidx),
                                                rp_.size, capi.ptr(rp_), capi.ptr(ro_)), f"pamg_dist_add_level({l})")
+            self._set_allgather(lib, h, l, p)
         cp = sh.plans[ns]
         c0 = int(cp.off[sol.rank])
         fill = np.concatenate([np.arange(c0, c0 + cp.n_owned, dtype=np.int64), cp.halo_cols])
         fill = i32((fill[:, None] * cp.bs + np.arange(cp.bs)).ravel())
         capi.check(lib.pamg_dist_set_collapse(h, sol.coarse.handle, sh.nc, cp.row0_s(sol.rank), cp.n_owned_s, cp.n_halo_s,
                                               capi.ptr(fill)), "pamg_dist_set_collapse")
+        self._set_allgather(lib, h, ns, cp)
         for l in range(ns):
             for which, sm in enumerate(sh.smoothers[l]):
                 kind = "none" if sm is None else sm.kind
@@ -727,7 +747,30 @@ class _NativeCycle:
                            f"pamg_dist_set_smoother({l}, {kind})")
         if sol.world > 1:
             {"host": self._host_transport, "rccl": self._rccl_transport, "torch": self._torch_transport}[transport](lib)
+        self.exchange = "halo"
+        if sol.world > 1 and getattr(sol, "exchange", "halo") == "allgather" and transport in ("host", "rccl"):
+            capi.check(lib.pamg_dist_set_exchange(h, 1), "pamg_dist_set_exchange")
+            self.exchange = "allgather"
         capi.check(lib.pamg_dist_finalize(h), "pamg_dist_finalize")
+
+    def _set_allgather(self, lib, h, l, p):
+        """the all-gather form of level l's exchange (the general fallback and correctness baseline): where every
+        halo value sits in the vector gathered from all ranks' owned parts, each padded to the largest one"""
+        capi = self.capi
+        off = np.asarray(p.off, dtype=np.int64)
+        cnt = int(np.max(np.diff(off))) * p.bs if off.size > 1 else p.n_owned_s
+        hc = np.asarray(p.halo_cols, dtype=np.int64)
+        owner = np.searchsorted(off, hc, side="right") - 1
+        src = ((owner * cnt + (hc - off[owner]) * p.bs)[:, None] + np.arange(p.bs)).ravel() if hc.size else np.zeros(0, dtype=np.int64)
+        if src.size and int(src.max()) >= 2 ** 31:
+            return                                           # beyond 32-bit positions: the point-to-point form only
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        capi.check(lib.pamg_dist_set_allgather(h, l, max(cnt, 1), capi.ptr(src)), f"pamg_dist_set_allgather({l})")
+
+    def set_exchange(self, mode: str):
+        """'halo' (point to point with the actual neighbours) or 'allgather'; between iterations"""
+        self.capi.check(self.capi.lib().pamg_dist_set_exchange(self.handle, 1 if mode == "allgather" else 0), "pamg_dist_set_exchange")
+        self.exchange = mode
 
     def verify_exchange(self) -> str:
         """One halo exchange per sharded level with global indices as values (pamg_dist_exchange_test): '' when every
@@ -894,6 +937,8 @@ class _NativeCycle:
         d = dict(zip(keys, [int(v) for v in a]))
         d["transport"] = {"none": "none", "host": "host callbacks (gloo)", "rccl": "rccl",
                           "torch": "torch.distributed point-to-point on the driver's buffers"}[self.transport]
+        d["exchange"] = self.exchange
+        d["transport_tried"] = list(getattr(self.sol, "transport_tried", []))
         return d
 
     def free(self):

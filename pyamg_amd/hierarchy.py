@@ -113,6 +113,7 @@ class HierarchySpec:
     coarse_op: Optional[np.ndarray] = None      # dense (n_c, n_c), row-major
     coarse_name: str = "'pinv'"
     coarse_smoother: Optional[SmootherSpec] = None   # 'relax': the relaxation method the reference's coarse solver applies
+    coarse_host: Optional[tuple] = None         # 'host': (the caller's coarse solver object, its coarsest operator) -- solved on the host inside the cycle
 
     @property
     def dtype(self):
@@ -361,6 +362,9 @@ def _relaxation_coarse_smoother(ml, cs, A_c):
 _KRYLOV_COARSE = ("cg", "gmres")       # of multilevel.py:752: the two the device Krylov loops restate
 
 
+_KRYLOV_KWARGS = {"M", "callback", "residuals", "criteria", "orthog"}
+
+
 def _krylov_coarse_smoother(cs, A_c, method):
     """``coarse_solver='cg' | 'gmres'`` (multilevel.py:752-762): x = fn(A, b, **kwargs)[0] from x0 = None (zeros), with
     tol = set_tol(A.dtype) (util/params.py:28-31) unless the caller gave one."""
@@ -375,8 +379,16 @@ def _krylov_coarse_smoother(cs, A_c, method):
     if tol is None:
         tol = (1e3 * np.finfo(np.single).eps) if A_c.dtype.char.lower() == "f" else (1e6 * np.finfo(np.double).eps)
     maxiter, restart = kw.pop("maxiter", None), kw.pop("restart", None)
+    if "restrt" in kw:                                   # gmres's legacy spelling (krylov/_gmres.py: restrt -> restart)
+        legacy = kw.pop("restrt")
+        restart = legacy if restart is None else restart
     if kw.pop("x0", None) is not None:
         raise NotImplementedError("Krylov coarse solver with x0= is not on the device path")
+    unknown = set(kw) - _KRYLOV_KWARGS
+    if unknown:
+        raise NotImplementedError(f"Krylov coarse solver '{method}': arguments {sorted(unknown)} are not on the device path")
+    if method == "gmres" and A_c.shape[0] < 2:
+        raise NotImplementedError("coarse_solver='gmres' on a 1 x 1 coarsest level is not on the device path (Householder GMRES needs n >= 2)")
     return _krylov_spec(method, A_c, tol, maxiter, restart, kw)
 
 
@@ -390,8 +402,12 @@ def _coarse_operator(ml, A_c) -> Tuple[str, Optional[np.ndarray], str]:
     if name.strip("'") in _KRYLOV_COARSE:
         return "relax", _krylov_coarse_smoother(cs, A_c, name.strip("'")), name
     if name not in _LINEAR_COARSE:
-        raise NotImplementedError(f"coarse solver {name} is neither a linear direct solver ('pinv', 'lu', 'cholesky', 'splu'), "
-                                  "a relaxation method nor 'cg' / 'gmres'; the other Krylov coarse solvers are not on the device path")
+        # the remaining Krylov names of multilevel.py:752 ('bicgstab', 'cgs', 'qmr', 'minres', ...) and callables (:786-788):
+        # not linear in b, so nothing to tabulate -- the coarse right-hand side (a handful of values) is handed to the
+        # caller's OWN solver object on the host, inside the device cycle (pamg_solver_set_coarse_host)
+        if A_c.dtype.type not in SUPPORTED_DTYPES:
+            raise NotImplementedError(f"coarse solver {name} on a {A_c.dtype} level is not on the device path")
+        return "host", (cs, A_c), name
     n = A_c.shape[0]
     if n > 4096:
         raise NotImplementedError(f"coarsest level too large for a dense device solve (n={n})")
@@ -445,6 +461,8 @@ def extract(ml) -> HierarchySpec:
     spec.coarse_kind = kind
     if kind == "relax":
         spec.coarse_smoother = op
+    elif kind == "host":
+        spec.coarse_host = op
     else:
         spec.coarse_op = op
     return spec
@@ -517,6 +535,9 @@ def _get_sm(z, key) -> Optional[SmootherSpec]:
 
 def save_spec(path, spec: HierarchySpec, **extra):
     """Write a HierarchySpec (+ any extra named arrays) to a compressed ``.npz``."""
+    if spec.coarse_kind == "host":
+        raise NotImplementedError("a hierarchy whose coarse solver runs on the host (a Krylov name other than 'cg' / 'gmres', or a callable) holds a Python "
+                                  "object and cannot be written to a file")
     d = {"nlevels": np.array(len(spec.levels)), "coarse_kind": np.array(spec.coarse_kind),
          "coarse_name": np.array(spec.coarse_name)}
     if spec.coarse_op is not None:

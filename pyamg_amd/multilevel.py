@@ -285,8 +285,30 @@ class DeviceMultilevelSolver:
     """
 
     def __init__(self, ml, device: Optional[int] = None, graph: bool = True, autotune: Optional[bool] = None,
-                 level_tune=None, order: Optional[str] = None):
+                 level_tune=None, order: Optional[str] = None, strict: bool = True):
         import os
+        self.fallback = None
+        if not strict:
+            # "unsupported smoothers / cycles / coarse solvers => transparent fallback to the wrapped ml (or an explicit
+            # NotImplementedError if strict=True)".  The fallback is the CALLER's own solver object -- never the oracle, never a
+            # CPU restatement of ours -- and it is announced once.
+            try:
+                self.__init__(ml, device=device, graph=graph, autotune=autotune, level_tune=level_tune, order=order, strict=True)
+                return
+            except NotImplementedError as e:
+                if isinstance(ml, HierarchySpec) or not hasattr(ml, "solve"):
+                    raise
+                import warnings
+                warnings.warn(f"pyamg_amd: this hierarchy is not on the device path ({e}); strict=False hands every call to the wrapped "
+                              "solver on the host", RuntimeWarning, stacklevel=2)
+                self.free()
+                self.fallback, self.ml, self.spec, self.handle = ml, ml, None, None
+                self.order = order or "fast"
+                A0 = ml.levels[0].A
+                self.dtype, self.shape = np.dtype(A0.dtype), tuple(A0.shape)
+                self.A, self._mats, self._aux = [], [], []
+                self.symmetric_smoothing = getattr(ml, "symmetric_smoothing", False)
+                return
         if autotune is None:
             autotune = os.environ.get("PAMG_AUTOTUNE", "1") != "0"
         if order is None:
@@ -295,11 +317,12 @@ class DeviceMultilevelSolver:
             raise ValueError("order must be 'fast' or 'exact'")
         self.order = order
         self._device, self._graph, self._autotune, self._level_tune = device, graph, autotune, level_tune
+        # reading the hierarchy comes first: what is not on the device path is refused (NotImplementedError) before any device is touched
+        self.ml = None if isinstance(ml, HierarchySpec) else ml
+        self.spec = ml if isinstance(ml, HierarchySpec) else extract(ml)
         lib = capi.lib()
         if device is not None:
             capi.check(lib.pamg_set_device(int(device)), "pamg_set_device")
-        self.ml = None if isinstance(ml, HierarchySpec) else ml
-        self.spec = ml if isinstance(ml, HierarchySpec) else extract(ml)
         self.dtype = np.dtype(self.spec.dtype)
         self.shape = tuple(self.spec.levels[0].A.shape)
         self._mats: List[DeviceMatrix] = []
@@ -367,6 +390,24 @@ class DeviceMultilevelSolver:
             # multilevel.py:765-782: sweeps of a relaxation method from x = 0 -- the smoother slot of the coarsest level
             _set_smoother(lib, h, nlev - 1, 0, self.spec.coarse_smoother, self.dtype, self._aux)
             capi.check(lib.pamg_solver_set_coarse_relax(h), "set_coarse_relax")
+        elif self.spec.coarse_kind == "host":
+            # multilevel.py:752-762 (Krylov names other than 'cg' / 'gmres') and :786-788 (callables): the caller's own solver
+            # object gets the coarse right-hand side on the host, inside the device cycle
+            cs, A_c = self.spec.coarse_host
+            dt = self.dtype
+
+            def _coarse(_user, b_ptr, x_ptr, n):
+                try:
+                    bh = np.ctypeslib.as_array(C.cast(b_ptr, C.POINTER(C.c_double if dt == np.float64 else C.c_float)), shape=(int(n),))
+                    xh = np.ctypeslib.as_array(C.cast(x_ptr, C.POINTER(C.c_double if dt == np.float64 else C.c_float)), shape=(int(n),))
+                    xh[:] = np.ravel(cs(A_c, np.array(bh, dtype=dt))).astype(dt, copy=False)      # coarse_x[:] = coarse_solver(A, coarse_b)  (:618)
+                    return 0
+                except Exception:                    # noqa: BLE001 -- an exception must not unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._coarse_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)(_coarse)
+            capi.check(lib.pamg_solver_set_coarse_host(h, C.cast(self._coarse_cb, C.c_void_p), None, n_c), "set_coarse_host")
         elif self.spec.coarse_kind == "zero":
             capi.check(lib.pamg_solver_set_coarse_dense(h, None, n_c), "set_coarse")
         else:
@@ -381,9 +422,11 @@ class DeviceMultilevelSolver:
     # ------------------------------------------------------------------ reference-like API
     @property
     def levels(self):
-        return self.spec.levels
+        return self.spec.levels if self.spec is not None else self.fallback.levels
 
     def __repr__(self):
+        if self.fallback is not None:
+            return "DeviceMultilevelSolver (strict=False: not on the device path, calls go to the wrapped solver)\n" + repr(self.fallback)
         lines = ["DeviceMultilevelSolver (MI355X resident)", f"Number of Levels:     {len(self.spec.levels)}",
                  f"Coarse Solver:        {self.spec.coarse_name}", "  level   unknowns     nonzeros"]
         tot = sum(L.A.nnz for L in self.spec.levels)
@@ -434,6 +477,9 @@ class DeviceMultilevelSolver:
     def solve(self, b, x0=None, tol=1e-5, maxiter=100, cycle="V", accel=None, callback=None,
               residuals=None, cycles_per_level=1, return_info=False):
         """Execute multigrid cycling on the GPU (reference: multilevel.py:398-582)."""
+        if self.fallback is not None:
+            return self.fallback.solve(b, x0=x0, tol=tol, maxiter=maxiter, cycle=cycle, accel=accel, callback=callback,
+                                       residuals=residuals, cycles_per_level=cycles_per_level, return_info=return_info)
         b = np.asarray(b)
         x = np.zeros_like(b) if x0 is None else np.array(x0)       # copy (:464-467)
         cycle = str(cycle).upper()
@@ -602,6 +648,8 @@ class DeviceMultilevelSolver:
         invalid once the host ``ml`` changes."""
         if self.ml is None:
             raise NotImplementedError("change_solve_matrix needs the wrapped reference solver")
+        if self.fallback is not None:
+            return self.fallback.change_solve_matrix(A)
         self.ml.change_solve_matrix(A)
         ml = self.ml
         device, graph, autotune, level_tune = self._device, self._graph, self._autotune, self._level_tune

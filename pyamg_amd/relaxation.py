@@ -363,6 +363,8 @@ def get_block_diag(A, blocksize, inv_flag=True):
         return cached
     if A.format != "bsr" or tuple(A.blocksize) != (blocksize, blocksize):
         A = A.tobsr(blocksize=(blocksize, blocksize))
+    if A.dtype.kind == "c":
+        raise NotImplementedError("get_block_diag of a complex operator is not on the device path")      # (asfptype keeps complex; a cast would drop the imaginary part)
     if A.dtype.kind != "f":
         A = A.astype(np.float64)
     # the stored block at (i, i); with duplicates SciPy's diagonal() of the position matrix adds the positions up -- the
@@ -396,13 +398,19 @@ def _block_prep(A, blocksize, Dinv):
 
 
 def _check_unit_dinv(A, Dinv):
-    """argument checks of the block wrappers for blocksize 1 (relaxation.py:479-484)"""
+    """argument checks of the block wrappers for blocksize 1 (relaxation.py:479-484).  A caller-supplied Dinv is honoured
+    by the reference (it multiplies by Dinv[i] whatever it holds); the point kernels used here for 1x1 blocks divide by
+    a_ii, so a Dinv that is NOT the inverse of the diagonal is refused instead of silently ignored."""
     if Dinv is not None:
         Dinv = np.asarray(Dinv)
         if Dinv.shape[0] != A.shape[0]:
             raise ValueError("Dinv and A have incompatible dimensions")
         if Dinv.ndim != 3 or Dinv.shape[1] != 1 or Dinv.shape[2] != 1:
             raise ValueError("Dinv and blocksize are incompatible")
+        d = np.asarray(A.diagonal(), dtype=np.float64)
+        want = np.where(d != 0, 1.0 / np.where(d != 0, d, 1.0), 0.0)
+        if not np.allclose(np.ravel(Dinv), want, rtol=1e-12, atol=0):
+            raise NotImplementedError("blocksize=1 with a Dinv that is not 1 / diag(A) is not on the device path")
 
 
 def block_jacobi(A, x, b, Dinv=None, blocksize=1, iterations=1, omega=1.0):

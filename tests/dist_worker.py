@@ -114,7 +114,8 @@ def run(rank, world, port, name, backend, min_rows, out_dir):
     from pyamg_amd.hierarchy import load_spec
     from pyamg_amd.dist import DistMultilevelSolver
     spec, ex = load_spec(ROOT / "tests" / "golden" / f"hier_{name}.npz")
-    scatter = backend.endswith("+rank0")         # the hierarchy exists on rank 0 only, parts are scattered
+    scatter = "+rank0" in backend                 # the hierarchy exists on rank 0 only, parts are scattered
+    exchange = "allgather" if "+allgather" in backend else "halo"    # the all-gather form of the C++ driver's exchange
     backend = backend.split("+")[0]
     native = None
     if backend in ("device", "devicepy"):
@@ -130,8 +131,10 @@ def run(rank, world, port, name, backend, min_rows, out_dir):
         sol = DistMultilevelSolver.from_rank0(spec, ops=ops, min_rows=min_rows, native=native)
         assert sol.sh.spec is None and sol.sh.dtype == dtype
     else:
-        sol = DistMultilevelSolver(spec, ops=ops, min_rows=min_rows, native=native)
+        sol = DistMultilevelSolver(spec, ops=ops, min_rows=min_rows, native=native, exchange=exchange)
     assert (sol.native is not None) == (backend == "device")
+    if sol.native is not None:
+        assert sol.native.info()["exchange"] == exchange
     k = int(ex["k"])
     res = []
     x = sol.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=k, residuals=res)

@@ -155,7 +155,7 @@ def test_part_travels_as_arrays():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("backend", ["device", "devicepy", "device+rank0"])
+@pytest.mark.parametrize("backend", ["device", "devicepy", "device+rank0", "device+allgather"])
 @pytest.mark.parametrize("name", ["sa2d_jacobi", "sa2d_cheby", "el3d_blockjacobi"])
 def test_sharded_cycle_device_kernels(tmp_path, load_hier, name, backend):
     """two ranks (sharing the box's GPU, gloo transport) against the UNSHARDED device run of the same cycles: the
@@ -165,6 +165,8 @@ def test_sharded_cycle_device_kernels(tmp_path, load_hier, name, backend):
     from pyamg_amd import DeviceMultilevelSolver
     if backend == "device+rank0" and name != "sa2d_cheby":
         pytest.skip("one hierarchy is enough for the shipping path")
+    # "+allgather": the exchange as ONE all-gather of the owned parts per operator application (SURVEY 8e's fallback and
+    # correctness baseline; formed by the all-reduce callback on this rig) -- the same halo values, so the same bits
     outs = _run(2, name, backend, 100, tmp_path)
     if backend.startswith("device") and backend != "devicepy":
         assert all(int(o["exchanges"]) > 0 for o in outs)
@@ -232,6 +234,29 @@ def test_rccl_binds_and_initialises_a_communicator():
         "print('rccl communicator ok')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl communicator ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+def test_rccl_self_sendrecv():
+    """Every RCCL entry point of the sharded cycle EXECUTED on the hardware through the dlsym'd table with this library's
+    enum constants (pamg_rccl_selftest): a one-rank communicator, a grouped ncclSend + ncclRecv to itself on a comm stream
+    ordered against the main stream by the events of the halo exchange, ncclAllGather, a one-element ncclAllReduce --
+    every received float64 must be the value sent.  (Two ranks need two GPUs: the driver's node.)"""
+    code = (
+        "import sys, ctypes as C\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "from pyamg_amd import _capi as capi\n"
+        "lib = capi.lib()\n"
+        "assert lib.pamg_rccl_available() == 0\n"
+        "for n in (1, 1000, 1 << 20):\n"
+        "    e = C.c_double(-1.0)\n"
+        "    capi.check(lib.pamg_rccl_selftest(n, C.byref(e)), 'pamg_rccl_selftest')\n"
+        "    assert e.value == 0.0, (n, e.value)\n"
+        "print('rccl self send/recv ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl self send/recv ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
 @pytest.mark.gpu

@@ -891,7 +891,7 @@ def test_8bit_value_codes_are_bit_identical(dtype):
             assert np.array_equal(res[0][k], res[3][k], equal_nan=True), k
         # the norm's partial sums follow the lane -> row mapping, which the two-row form changes: same terms, another order
         assert np.allclose(res[0][3], res[3][3], rtol=1e-13, atol=0, equal_nan=True)
-        dA.tune(val8=1, rowgather=1, rowpat=2)
+        dA.tune(val8=1, rowgather=1, rowpat=1)
         if dtype == np.float64:
             assert np.array_equal(out[1][1], sp.csr_array(A) @ x)
         dA.free()

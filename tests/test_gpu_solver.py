@@ -436,3 +436,31 @@ def test_device_fgmres_matches_reference():
             xr = z[f"{name}.gmres.{tag}.x"]
             assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr), (name, tag, "gmres")
         dml.free()
+
+
+@pytest.mark.parametrize("coarse", ["bicgstab", "cgs", "minres", "callable"])
+def test_host_coarse_solvers_against_the_live_reference(coarse):
+    """coarse_solver = a Krylov name other than 'cg' / 'gmres', or a callable (multilevel.py:752-762, 786-788): the coarse
+    right-hand side goes to the caller's OWN solver object on the host inside the device cycle
+    (pamg_solver_set_coarse_host); residual histories within 1e-10 of the reference's, V and W cycles."""
+    import oracle.refimport as ri
+    if not ri.available():
+        pytest.skip("oracle/_ref not present on this box")
+    import pyamg
+    import scipy.sparse.linalg as sla
+    A = pyamg.gallery.poisson((40, 40), format="csr")
+    cs = (lambda A_, b_: sla.spsolve(sp.csc_array(A_), b_)) if coarse == "callable" else coarse
+    np.random.seed(7)
+    ml = pyamg.smoothed_aggregation_solver(A, max_coarse=40, coarse_solver=cs)
+    b = np.random.rand(A.shape[0])
+    dml = DeviceMultilevelSolver(ml)
+    assert dml.spec.coarse_kind == "host"
+    for cyc in ("V", "W"):
+        r_ref, r_gpu = [], []
+        x_ref = ml.solve(b, tol=1e-30, maxiter=6, cycle=cyc, residuals=r_ref)
+        x = dml.solve(b, tol=1e-30, maxiter=6, cycle=cyc, residuals=r_gpu)
+        r_ref, r_gpu = np.array(r_ref), np.array(r_gpu)
+        assert len(r_gpu) == len(r_ref) == 7
+        assert np.max(np.abs(r_gpu - r_ref)) <= 1e-10 * r_ref[0], (coarse, cyc)
+        assert np.linalg.norm(x - x_ref) <= 1e-10 * np.linalg.norm(x_ref)
+    dml.free()

@@ -49,6 +49,34 @@ def test_product_fails_loudly_without_device():
         grelax.gauss_seidel(A, np.zeros(4), np.ones(4))
 
 
+def test_strict_false_hands_unsupported_hierarchies_to_the_wrapped_solver():
+    """an unsupported configuration (here: a complex operator, instantiate.yml:2-6) raises NotImplementedError
+    by default and, with strict=False, is handed to the caller's OWN solver object with one warning -- same answers as that
+    object gives, nothing of ours computes on the host (needs no device: the refusal happens while reading the hierarchy)."""
+    import oracle.refimport as ri
+    if not ri.available():
+        pytest.skip("oracle/_ref not built")
+    import pyamg
+    from pyamg_amd import DeviceMultilevelSolver
+    A = pyamg.gallery.poisson((12, 12), format="csr").astype(np.complex128)
+    A = sp.csr_array(A + 0.05j * sp.eye_array(A.shape[0]))
+    np.random.seed(0)
+    ml = pyamg.smoothed_aggregation_solver(A, max_coarse=10)
+    with pytest.raises(NotImplementedError):
+        DeviceMultilevelSolver(ml)
+    with pytest.warns(RuntimeWarning, match="strict=False"):
+        dml = DeviceMultilevelSolver(ml, strict=False)
+    assert dml.fallback is ml and dml.shape == A.shape and "strict=False" in repr(dml)
+    b = np.random.rand(A.shape[0]) + 1j * np.random.rand(A.shape[0])
+    r1, r2 = [], []
+    x1 = dml.solve(b, tol=1e-10, residuals=r1)
+    x2 = ml.solve(b, tol=1e-10, residuals=r2)
+    assert np.array_equal(x1, x2) and r1 == r2
+    M = dml.aspreconditioner()
+    assert np.array_equal(M @ b, ml.aspreconditioner() @ b)
+    assert len(dml.levels) == len(ml.levels)
+
+
 def test_product_never_imports_oracle():
     import pathlib
     for p in pathlib.Path(ROOT / "pyamg_amd").rglob("*.py"):
@@ -111,7 +139,7 @@ def test_spec_roundtrip(tmp_path, load_hier, name):
         assert np.isfortran(spec.coarse_op) == np.isfortran(spec2.coarse_op)
 
 
-def test_extract_reads_back_smoother_parameters():
+def test_extract_reads_back_smoother_parameters(tmp_path):
     """Smoother scalars come from the constructed solver (partial keywords / closure cells),
     never recomputed; dispatch on .func, not __name__ (8b)."""
     import oracle.refimport as ri
@@ -156,8 +184,17 @@ def test_extract_reads_back_smoother_parameters():
     assert s5.levels[0].pre.kind == "cgnr" and s5.levels[0].pre.iterations == 3 and s5.levels[0].pre.tol == 1e-9
     At = s5.levels[0].post.At
     assert s5.levels[0].post.kind == "cgne" and At is not None and np.array_equal(At.indptr, A.T.tocsr().indptr)
-    with pytest.raises(NotImplementedError):
-        H.extract(pyamg.smoothed_aggregation_solver(A, max_coarse=10, coarse_solver="bicgstab"))
+    # the remaining Krylov coarse solvers and callables (multilevel.py:752-762, 786-788): solved on the host by the caller's own
+    # solver object inside the device cycle; such a hierarchy holds a Python object and cannot be written to a file
+    for cs in ("bicgstab", "cgs", "minres", lambda A_, b_: np.zeros_like(b_)):
+        ml6 = pyamg.smoothed_aggregation_solver(A, max_coarse=10, coarse_solver=cs)
+        s6 = H.extract(ml6)
+        assert s6.coarse_kind == "host" and s6.coarse_host[0] is ml6.coarse_solver and s6.coarse_op is None
+        with pytest.raises(NotImplementedError):
+            H.save_spec(tmp_path / "host_coarse.npz", s6)
+    # gmres's legacy restrt= is read as restart=; anything else the device loops do not restate is refused at extraction
+    s7 = H.extract(pyamg.smoothed_aggregation_solver(A, max_coarse=10, coarse_solver=("gmres", {"restrt": 7})))
+    assert s7.coarse_smoother.kind == "gmres" and s7.coarse_smoother.restart == 7
     with pytest.raises(NotImplementedError):
         H.extract(pyamg.smoothed_aggregation_solver(A, max_coarse=10, presmoother=("cg", {"M": sp.eye_array(900, format="csr")})))
 
