@@ -16,6 +16,13 @@
 //   one-XCD form: small operators (vectors fit one XCD's L2).  The first workgroup to arrive claims its XCD, workgroups
 //                 elsewhere leave, the rest draw groups from a ticket counter (two tickets ahead, taken in increasing
 //                 order by running waves: complete for any placement) and publish with ordinary L2-resident stores.
+//   slab form   : large operators (round 4).  The rows are cut into 8 slabs of the visit order (pamg_lane_plan.h); the
+//                 workgroups with blockIdx % 8 == s -- one XCD, as the dispatcher places them -- share slab s statically.  Every
+//                 row is published TWICE: an ordinary store into a second buffer xl (stays in the producer XCD's L2) and the
+//                 write-through store into xs.  An operand produced in the consumer's own slab is polled in xl (L2 round trip),
+//                 the others in xs (memory).  Placement is verified, not assumed: every workgroup records its XCD for its slab;
+//                 a workgroup that finds another XCD recorded raises a flag and from then on everybody polls xs only --
+//                 correct for any placement, fast for the usual one.
 // The static operands of a wave's NEXT group are requested before it starts to wait for the current one.
 #include "pamg_common.h"
 #include "pamg_lane_plan.h"
@@ -52,6 +59,10 @@ struct LaneSched {
     long long *d_prof = nullptr;
     int64_t n_early = 0, n_old = 0, n_slots = 0;
     int64_t max_level_groups = 0;
+    int nslabs = 1;
+    int slab_grp[LANE_MAX_SLABS + 1] = {0};
+    int64_t n_local = 0;
+    void *d_xl = nullptr;           // slab form: second hand-off buffer (L2-resident stores)
     int last_grid = 0;              // workgroups of the last launch (diagnostics)
     size_t bytes = 0;
 };
@@ -66,6 +77,9 @@ struct LaneArgs {
     const T *x;            // OLD values (x itself, or its snapshot for structurally non-symmetric patterns)
     T *y;                  // destination (the live x)
     T *xs;                 // hand-off buffer, sentinel-filled
+    T *xl;                 // slab form: the same values stored WITHOUT write-through (same-XCD consumers poll here)
+    unsigned *aff;         // slab form: [0..7] XCD + 1 of the workgroups serving slab s (0 = nobody yet), [8] != 0: a slab is served from two XCDs -> poll xs only
+    int slab_grp[LANE_MAX_SLABS + 1];
     const T *b;
     unsigned *err;         // spin bound hit
     unsigned *ticket;      // one-XCD form: [0] ticket counter, [1] home XCD + 1
@@ -146,8 +160,8 @@ struct LaneDyn {
     long long t0;
 };
 
-template <typename T, int EPI, int K>
-__device__ __forceinline__ void lane_issue(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int idle)
+template <typename T, int EPI, int K, int MODE>
+__device__ __forceinline__ void lane_issue(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int idle, bool local_ok)
 {
     D.t0 = 0;
     if (a.prof && (threadIdx.x & 63) == 0) D.t0 = wall_clock64();
@@ -160,14 +174,16 @@ __device__ __forceinline__ void lane_issue(const LaneArgs<T> &a, const LaneSet<T
     for (int k = 0; k < K; ++k) {
         const int c = S.c[k];
         const int col = c & LANE_MASK;
-        const T *p = (c & LANE_NONE) ? a.x + idle : ((c & LANE_EARLY) ? a.xs + col : a.x + col);
+        const T *hand = a.xs;
+        if constexpr (MODE == 2) hand = ((c & LANE_LOCAL) && local_ok) ? a.xl : a.xs;
+        const T *p = (c & LANE_NONE) ? a.x + idle : ((c & LANE_EARLY) ? hand + col : a.x + col);
         D.xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 // second half: wait for the early operands, row sums across the lanes, publish
-template <typename T, int EPI, int L, int K, bool XCD>
-__device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int g, int idle)
+template <typename T, int EPI, int L, int K, int MODE>
+__device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int g, int idle, bool &local_ok)
 {
     const int lane = threadIdx.x & 63;
     const bool head = (lane & (L - 1)) == 0;
@@ -192,14 +208,22 @@ __device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<
         if (spins) __builtin_amdgcn_s_sleep(1);
         T t[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-            t[k] = __hip_atomic_load(((pend >> k) & 1u) ? a.xs + (S.c[k] & LANE_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < K; ++k) {
+            const T *hand = a.xs;
+            if constexpr (MODE == 2) hand = ((S.c[k] & LANE_LOCAL) && local_ok) ? a.xl : a.xs;
+            t[k] = __hip_atomic_load(((pend >> k) & 1u) ? hand + (S.c[k] & LANE_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if ((pend >> k) & 1u) {
                 D.xv[k] = t[k];
                 if (Sentinel<T>::bits(t[k]) != Sentinel<T>::value) pend &= ~(1u << k);
             }
+        if constexpr (MODE == 2) {
+            // a slab served from two XCDs (flag raised by the workgroup that noticed): its L2-resident stores may never reach this
+            // XCD -- everybody falls back to the write-through buffer
+            if (local_ok && (spins & 63u) == 63u && __hip_atomic_load(a.aff + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) local_ok = false;
+        }
         if ((++spins & 1023u) == 0) {
             // a producer that never comes (not resident / an earlier time-out): give up together, quickly
             if (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -222,8 +246,11 @@ __device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<
         T v = (D.bv - s) * S.rd;
         if constexpr (EPI == EPI_SOR) v = a.omega * v + (T(1) - a.omega) * D.xo;
         if (!upd) v = D.xo;
-        if constexpr (XCD) __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (MODE == 1) __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else {
+            if constexpr (MODE == 2) __hip_atomic_store(a.xl + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (upd) a.y[row] = v;
     }
     if (a.prof && lane == 0) {
@@ -235,7 +262,7 @@ __device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<
 
 constexpr int LANE_WPB = BLK / 64;            // waves per workgroup (they never meet)
 
-template <typename T, int EPI, int L, int K, bool XCD>
+template <typename T, int EPI, int L, int K, int MODE>
 __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
 {
     const int lane = threadIdx.x & 63;
@@ -243,22 +270,37 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
     const int idle = (int)((((unsigned)blockIdx.x * LANE_WPB + (unsigned)wib) * 16u) % (unsigned)a.nidle);
     LaneSet<T, K> P, Q;
     LaneDyn<T, K> D;
-    if constexpr (!XCD) {
-        const int W = (int)gridDim.x * LANE_WPB;
+    bool local_ok = false;
+    if constexpr (MODE != 1) {
+        int W = (int)gridDim.x * LANE_WPB;
         int g = (int)blockIdx.x * LANE_WPB + wib;
-        if (g >= a.ngroups) return;
+        int gend = a.ngroups;
+        if constexpr (MODE == 2) {
+            const int slab = (int)(blockIdx.x & 7u);
+            if (threadIdx.x == 0) {
+                const unsigned me = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1u;     // HW_REG_XCC_ID[3:0] + 1
+                unsigned seen = 0u;
+                __hip_atomic_compare_exchange_strong(a.aff + slab, &seen, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen != 0u && seen != me) __hip_atomic_store(a.aff + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            W = (int)(gridDim.x >> 3) * LANE_WPB;
+            g = a.slab_grp[slab] + (int)(blockIdx.x >> 3) * LANE_WPB + wib;
+            gend = a.slab_grp[slab + 1];
+            local_ok = __hip_atomic_load(a.aff + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+        }
+        if (g >= gend) return;
         lane_load<T, L, K>(a, g, P);
         while (true) {
             const int g2 = g + W;
-            lane_issue<T, EPI, K>(a, P, D, idle);
-            lane_load<T, L, K>(a, min(g2, a.ngroups - 1), Q);   // unconditional (a load under a branch makes the compiler drain the counter at the next wait)
-            lane_finish<T, EPI, L, K, XCD>(a, P, D, g, idle);
-            if (g2 >= a.ngroups) break;
+            lane_issue<T, EPI, K, MODE>(a, P, D, idle, local_ok);
+            lane_load<T, L, K>(a, min(g2, gend - 1), Q);   // unconditional (a load under a branch makes the compiler drain the counter at the next wait)
+            lane_finish<T, EPI, L, K, MODE>(a, P, D, g, idle, local_ok);
+            if (g2 >= gend) break;
             g = g2 + W;
-            lane_issue<T, EPI, K>(a, Q, D, idle);
-            lane_load<T, L, K>(a, min(g, a.ngroups - 1), P);
-            lane_finish<T, EPI, L, K, XCD>(a, Q, D, g2, idle);
-            if (g >= a.ngroups) break;
+            lane_issue<T, EPI, K, MODE>(a, Q, D, idle, local_ok);
+            lane_load<T, L, K>(a, min(g, gend - 1), P);
+            lane_finish<T, EPI, L, K, MODE>(a, Q, D, g2, idle, local_ok);
+            if (g >= gend) break;
         }
     } else {
         __shared__ int sh_home;
@@ -280,21 +322,21 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
         int g2 = (int)__builtin_amdgcn_readfirstlane(tk);
         while (true) {
             unsigned tk3 = 0;
-            lane_issue<T, EPI, K>(a, P, D, idle);
+            lane_issue<T, EPI, K, MODE>(a, P, D, idle, local_ok);
             if (g2 < a.ngroups) {
                 lane_load<T, L, K>(a, g2, Q);
                 if (lane == 0) tk3 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            lane_finish<T, EPI, L, K, XCD>(a, P, D, g, idle);
+            lane_finish<T, EPI, L, K, MODE>(a, P, D, g, idle, local_ok);
             if (g2 >= a.ngroups) break;
             g = (int)__builtin_amdgcn_readfirstlane(tk3);
             unsigned tk4 = 0;
-            lane_issue<T, EPI, K>(a, Q, D, idle);
+            lane_issue<T, EPI, K, MODE>(a, Q, D, idle, local_ok);
             if (g < a.ngroups) {
                 lane_load<T, L, K>(a, g, P);
                 if (lane == 0) tk4 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            lane_finish<T, EPI, L, K, XCD>(a, Q, D, g2, idle);
+            lane_finish<T, EPI, L, K, MODE>(a, Q, D, g2, idle, local_ok);
             if (g >= a.ngroups) break;
             g2 = (int)__builtin_amdgcn_readfirstlane(tk4);
         }
@@ -315,37 +357,38 @@ int lane_upload(U **dst, const void *src, size_t bytes, size_t *total)
     return PAMG_OK;
 }
 
-template <typename T, int EPI, int L, bool XCD>
+template <typename T, int EPI, int L, int MODE>
 const void *lane_kernel_k(int K)
 {
     switch (K) {
-        case 1: return (const void *)gs_lane_kernel<T, EPI, L, 1, XCD>;
-        case 2: return (const void *)gs_lane_kernel<T, EPI, L, 2, XCD>;
-        case 3: return (const void *)gs_lane_kernel<T, EPI, L, 3, XCD>;
-        case 4: return (const void *)gs_lane_kernel<T, EPI, L, 4, XCD>;
+        case 1: return (const void *)gs_lane_kernel<T, EPI, L, 1, MODE>;
+        case 2: return (const void *)gs_lane_kernel<T, EPI, L, 2, MODE>;
+        case 3: return (const void *)gs_lane_kernel<T, EPI, L, 3, MODE>;
+        case 4: return (const void *)gs_lane_kernel<T, EPI, L, 4, MODE>;
     }
     return nullptr;
 }
 
-template <typename T, int EPI, bool XCD>
+template <typename T, int EPI, int MODE>
 const void *lane_kernel_l(int L, int K)
 {
     switch (L) {
-        case 4: return lane_kernel_k<T, EPI, 4, XCD>(K);
-        case 8: return lane_kernel_k<T, EPI, 8, XCD>(K);
-        case 16: return lane_kernel_k<T, EPI, 16, XCD>(K);
-        case 32: return lane_kernel_k<T, EPI, 32, XCD>(K);
-        case 64: return lane_kernel_k<T, EPI, 64, XCD>(K);
+        case 4: return lane_kernel_k<T, EPI, 4, MODE>(K);
+        case 8: return lane_kernel_k<T, EPI, 8, MODE>(K);
+        case 16: return lane_kernel_k<T, EPI, 16, MODE>(K);
+        case 32: return lane_kernel_k<T, EPI, 32, MODE>(K);
+        case 64: return lane_kernel_k<T, EPI, 64, MODE>(K);
     }
     return nullptr;
 }
 
+// mode: 0 static across the chip, 1 one-XCD (tickets), 2 slabs (one per XCD)
 template <typename T>
-const void *lane_kernel(int epi, int L, int K, bool xcd)
+const void *lane_kernel(int epi, int L, int K, int mode)
 {
     // bsr_gauss_seidel with 1x1 blocks computes (b - sum) / a_ii as well: in this form the two are one kernel
-    if (epi == EPI_SOR) return xcd ? lane_kernel_l<T, EPI_SOR, true>(L, K) : lane_kernel_l<T, EPI_SOR, false>(L, K);
-    return xcd ? lane_kernel_l<T, EPI_GS, true>(L, K) : lane_kernel_l<T, EPI_GS, false>(L, K);
+    if (epi == EPI_SOR) return mode == 1 ? lane_kernel_l<T, EPI_SOR, 1>(L, K) : mode == 2 ? lane_kernel_l<T, EPI_SOR, 2>(L, K) : lane_kernel_l<T, EPI_SOR, 0>(L, K);
+    return mode == 1 ? lane_kernel_l<T, EPI_GS, 1>(L, K) : mode == 2 ? lane_kernel_l<T, EPI_GS, 2>(L, K) : lane_kernel_l<T, EPI_GS, 0>(L, K);
 }
 
 }  // namespace
@@ -353,7 +396,7 @@ const void *lane_kernel(int epi, int L, int K, bool xcd)
 void free_lane_part(LaneSched *t)
 {
     if (!t) return;
-    hipFree(t->d_cols); hipFree(t->d_rid); hipFree(t->d_vals); hipFree(t->d_rdiag); hipFree(t->d_prof); hipFree(t->d_gate);
+    hipFree(t->d_cols); hipFree(t->d_rid); hipFree(t->d_vals); hipFree(t->d_rdiag); hipFree(t->d_prof); hipFree(t->d_gate); hipFree(t->d_xl);
     delete t;
 }
 
@@ -388,19 +431,29 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
         while (want_L < 64 && want_L < A->max_row_len - 1) want_L *= 2;
         if (want_L < 32) want_L = 0;                           // short rows: several rows per wave (stencils)
     }
+    // Slabs (one per XCD) for operators that run across the chip and are big enough to keep eight XCDs busy: an operand from the
+    // consumer's own slab is handed over through the XCD's L2 instead of through memory (lane_flags bit 1; profiles/r04_*slab*)
+    const bool slabs = !lane_one_xcd(A, g) && (A->lane_flags & 2) && g->nrows >= 262144 && A->nrows < LANE_LOCAL;
     if (build_lane_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), hAx.data(), ts, g->row_start, g->row_step, (int)g->nrows,
-                        g->nlevels, g->h_vis, g->h_lvl, want_L, P))
+                        g->nlevels, g->h_vis, g->h_lvl, want_L, P, slabs ? LANE_MAX_SLABS : 1))
         return PAMG_E_ARG;
     LaneSched *t = new (std::nothrow) LaneSched();
     if (!t) return PAMG_E_ALLOC;
     t->L = P.L; t->K = P.K; t->RPW = P.RPW; t->ngroups = P.ngroups;
     t->n_early = P.n_early; t->n_old = P.n_old; t->n_slots = P.n_slots;
-    for (int l = 0; l < P.nlevels; ++l) t->max_level_groups = std::max(t->max_level_groups, P.level_grp[l + 1] - P.level_grp[l]);
+    t->max_level_groups = P.max_level_groups;
+    t->nslabs = P.nslabs; t->n_local = P.n_local;
+    for (int k = 0; k <= LANE_MAX_SLABS; ++k) t->slab_grp[k] = (int)P.slab_grp[std::min(k, P.nslabs)];
     int st = lane_upload(&t->d_cols, P.cols.data(), P.cols.size() * sizeof(int), &t->bytes);
     if (!st) st = lane_upload(&t->d_vals, P.vals.data(), P.vals.size(), &t->bytes);
     if (!st) st = lane_upload(&t->d_rid, P.rid.data(), P.rid.size() * sizeof(int), &t->bytes);
     if (!st) st = lane_upload(&t->d_rdiag, P.rdiag.data(), P.rdiag.size(), &t->bytes);
     if (!st) st = lane_upload(&t->d_gate, P.gate.data(), P.gate.size() * sizeof(int), &t->bytes);
+    if (!st && P.nslabs > 1) {
+        const size_t xb = ((size_t)A->nrows + 8) * (size_t)ts;
+        st = (int)hipMalloc(&t->d_xl, xb);
+        if (!st) t->bytes += xb;
+    }
     if (st) { free_lane_part(t); return st; }
     g->lane = t;
     g->bytes += t->bytes;                                      // the caller books them on the operator
@@ -438,6 +491,8 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     a.gate = (A->lane_flags & 1) ? t->d_gate : nullptr;
     a.x = (const T *)x; a.y = (T *)x; a.xs = (T *)g->d_xs; a.b = (const T *)b;
     a.err = g->d_sync + 1; a.ticket = g->d_sync + 20;
+    a.xl = (T *)t->d_xl; a.aff = g->d_sync + 32;
+    for (int k = 0; k <= LANE_MAX_SLABS; ++k) a.slab_grp[k] = t->slab_grp[k];
     a.ngroups = (int)t->ngroups;
     a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
     a.omega = (T)omega;
@@ -457,7 +512,11 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     PAMG_HIP(hipGetLastError());
     const int per_level = (int)((t->ngroups + g->nlevels - 1) / g->nlevels);
     const bool xcd = lane_one_xcd(A, g);
-    const void *k = lane_kernel<T>(epi, t->L, t->K, xcd);
+    const bool slab = !xcd && t->nslabs == LANE_MAX_SLABS && t->d_xl && (A->lane_flags & 2);
+    // (a slab layout can always run in the plain static form: wave w takes groups w, w + W, ...; the slab-major numbering is
+    // still level-ordered inside every slab and no group waits for a group of a LATER slab -- but not the other way round)
+    if (t->nslabs > 1 && !slab) return PAMG_E_STATE;
+    const void *k = lane_kernel<T>(epi, t->L, t->K, xcd ? 1 : slab ? 2 : 0);
     if (!k) return PAMG_E_ARG;
     static thread_local int cus = 0;
     if (!cus) cus = device_cus_lane();
@@ -471,6 +530,15 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     int G = (int)std::min<int64_t>((want_waves + LANE_WPB - 1) / LANE_WPB, (int64_t)cap * cus);
     if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + LANE_WPB - 1) / LANE_WPB));
+    if (slab) {
+        // the front of the sweep is inside about half of the slabs at any time: twice the waves, a multiple of 8 workgroups
+        G = std::min(2 * G, cap * cus);
+        if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
+        G = std::max(8, G & ~7);
+        hipLaunchKernelGGL((lane_fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)t->d_xl, n);
+        PAMG_HIP(hipGetLastError());
+        PAMG_HIP(hipMemsetAsync(g->d_sync + 32, 0, 16 * sizeof(unsigned), s));
+    }
     void *args[] = {(void *)&a};
     if (xcd) {
         // 8x the wanted grid is launched; the workgroups off the home XCD leave at once

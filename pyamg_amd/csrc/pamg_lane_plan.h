@@ -18,6 +18,11 @@
 //   rid  [g * RPW + r]               original row (-1: dummy row of the padding) | NODIAG (bit 30: the row has no or a
 //                                    zero diagonal: it is left untouched, relaxation.h:72-74, but still publishes its value)
 //   rdiag[g * RPW + r]               1 / a_ii
+// Slab layouts (nslabs = 8: one slab per XCD).  The visited rows are cut into nslabs contiguous pieces of the VISIT order and
+// the groups are numbered slab after slab (levels ascending inside a slab); an early operand produced in the consumer's own
+// slab carries LOCAL (bit 29).  The kernel gives slab s to the workgroups with blockIdx % 8 == s -- which the dispatcher
+// places on one XCD -- so a LOCAL operand can be handed over through that XCD's L2 (~0.5 us) instead of through memory
+// (~1 us).  An early operand never comes from a LATER slab, so a dependency chain crosses slab boundaries at most nslabs - 1 times.
 //   gate [g]                         "gate" operand of the group: the column of its early operand with the HIGHEST dependency
 //                                    level among those at least two levels below the group's own (-1: none).  A wave that runs
 //                                    ahead polls this one value until the sweep is one level away, and only then all its
@@ -37,8 +42,10 @@ namespace pamg {
 constexpr int LANE_KMAX = 4;                  // entry slots per lane the kernels are built for
 constexpr int LANE_EARLY = (int)0x80000000u;
 constexpr int LANE_NONE = 0x40000000;
-constexpr int LANE_MASK = 0x3FFFFFFF;
+constexpr int LANE_LOCAL = 0x20000000;        // slab layouts: the early operand is produced in the consumer's own slab
+constexpr int LANE_MASK = 0x1FFFFFFF;
 constexpr int LANE_NODIAG = 0x40000000;       // in rid[]
+constexpr int LANE_MAX_SLABS = 8;
 
 struct LanePlan {
     int L = 0, K = 0, RPW = 0;
@@ -50,8 +57,11 @@ struct LanePlan {
     std::vector<int> rid;
     std::vector<unsigned char> rdiag;         // ngroups * RPW values of tsize bytes
     std::vector<int> gate;                    // [ngroups] column of the group's latest early operand from a level <= own level - 2, or -1
-    std::vector<int64_t> level_grp;           // [nlevels + 1] group range of each dependency level
-    int64_t n_early = 0, n_old = 0, n_slots = 0;
+    std::vector<int64_t> level_grp;           // [nslabs * nlevels + 1] group range of each (slab, dependency level) bucket, slab-major
+    int nslabs = 1;
+    int64_t slab_grp[LANE_MAX_SLABS + 1] = {0};   // group range of each slab
+    int64_t n_early = 0, n_old = 0, n_slots = 0, n_local = 0;
+    int64_t max_level_groups = 0;             // groups of the widest dependency level (all slabs)
 };
 
 template <typename F>
@@ -86,21 +96,25 @@ inline int lane_geometry(int maxlen, int want_L, int &K)
 // visited row: sweep_levels in pamg_tile_plan.h), m visited rows, nl levels.  Ax: the operator's values (tsize bytes
 // each).  Returns 0, or 1 when the rows are too long / the padding too wasteful (caller keeps the exact schedulers).
 inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned char *Ax, int tsize, int row_start, int row_step,
-                           int m, int nl, const std::vector<int> &vis, const std::vector<int> &lvl, int want_L, LanePlan &P)
+                           int m, int nl, const std::vector<int> &vis, const std::vector<int> &lvl, int want_L, LanePlan &P, int nslabs = 1)
 {
     P = LanePlan();
     P.nlevels = nl;
     if (m <= 0 || nl <= 0) return 1;
-    // rows in level order, visit order inside a level
-    std::vector<int64_t> lptr((size_t)nl + 1, 0);
-    for (int t = 0; t < m; ++t) lptr[(size_t)lvl[row_start + (int64_t)t * row_step] + 1]++;
-    for (int l = 0; l < nl; ++l) lptr[l + 1] += lptr[l];
+    if (nslabs < 1 || nslabs > LANE_MAX_SLABS || (int64_t)nslabs * nl >= ((int64_t)1 << 30) || n >= LANE_LOCAL) nslabs = 1;
+    P.nslabs = nslabs;
+    const int64_t nb = (int64_t)nslabs * nl;                                   // buckets (slab, level), slab-major
+    auto slab_of_visit = [&](int t) { return (int)((int64_t)t * nslabs / m); };
+    // rows in bucket order, visit order inside a bucket
+    std::vector<int64_t> lptr((size_t)nb + 1, 0);
+    for (int t = 0; t < m; ++t) lptr[(size_t)((int64_t)slab_of_visit(t) * nl + lvl[row_start + (int64_t)t * row_step]) + 1]++;
+    for (int64_t l = 0; l < nb; ++l) lptr[l + 1] += lptr[l];
     std::vector<int> order((size_t)m);
     {
         std::vector<int64_t> cur(lptr.begin(), lptr.end() - 1);
         for (int t = 0; t < m; ++t) {
             const int i = row_start + t * row_step;
-            order[(size_t)cur[lvl[i]]++] = i;
+            order[(size_t)cur[(size_t)((int64_t)slab_of_visit(t) * nl + lvl[i])]++] = i;
         }
     }
     int maxlen = 0;
@@ -118,9 +132,15 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
     if (!L) return 1;
     const int RPW = 64 / L;
     P.L = L; P.K = K; P.RPW = RPW;
-    P.level_grp.assign((size_t)nl + 1, 0);
-    for (int l = 0; l < nl; ++l) P.level_grp[l + 1] = P.level_grp[l] + (lptr[l + 1] - lptr[l] + RPW - 1) / RPW;
-    P.ngroups = P.level_grp[nl];
+    P.level_grp.assign((size_t)nb + 1, 0);
+    for (int64_t l = 0; l < nb; ++l) P.level_grp[l + 1] = P.level_grp[l] + (lptr[l + 1] - lptr[l] + RPW - 1) / RPW;
+    P.ngroups = P.level_grp[nb];
+    for (int sl = 0; sl <= nslabs; ++sl) P.slab_grp[sl] = P.level_grp[(size_t)((int64_t)sl * nl)];
+    for (int l = 0; l < nl; ++l) {
+        int64_t w = 0;
+        for (int sl = 0; sl < nslabs; ++sl) w += P.level_grp[(size_t)((int64_t)sl * nl + l) + 1] - P.level_grp[(size_t)((int64_t)sl * nl + l)];
+        P.max_level_groups = std::max(P.max_level_groups, w);
+    }
     P.n_slots = P.ngroups * K * 64;
     // padding inside the rows (a few long rows set K for everybody): give up when the rows' slots exceed 4x the entries
     // (+ 8 per row: short rows are fine); the padding of every level to whole groups is at most one group per level
@@ -132,10 +152,12 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
     P.rdiag.assign((size_t)P.ngroups * RPW * tsize, 0);
     P.gate.assign((size_t)P.ngroups, -1);
     std::vector<int> gate_lvl((size_t)P.ngroups, -1);
-    std::vector<int64_t> ne((size_t)nl, 0), no((size_t)nl, 0);
-    lane_parallel(nl, [&](int64_t l0, int64_t l1) {
-        for (int64_t l = l0; l < l1; ++l) {
-            int64_t e_cnt = 0, o_cnt = 0;
+    std::vector<int64_t> ne((size_t)nb, 0), no((size_t)nb, 0), nloc((size_t)nb, 0);
+    lane_parallel(nb, [&](int64_t l0, int64_t l1) {
+        for (int64_t bk = l0; bk < l1; ++bk) {
+            const int64_t l = bk;                                               // bucket index into lptr / level_grp
+            const int mylevel = (int)(bk % nl), myslab = (int)(bk / nl);
+            int64_t e_cnt = 0, o_cnt = 0, l_cnt = 0;
             for (int64_t q = lptr[l]; q < lptr[l + 1]; ++q) {
                 const int64_t rel = q - lptr[l];
                 const int64_t g = P.level_grp[l] + rel / RPW;
@@ -151,8 +173,10 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                     ++e;
                     if (j < 0 || j >= n) continue;                                    // not a column of x: no product
                     const bool early = vis[j] >= 0 && vis[j] < ti;
-                    if (early && lvl[j] <= (int)l - 2 && lvl[j] > gate_lvl[(size_t)g]) { gate_lvl[(size_t)g] = lvl[j]; P.gate[(size_t)g] = j; }
-                    P.cols[s] = j | (early ? LANE_EARLY : 0);
+                    if (early && lvl[j] <= mylevel - 2 && lvl[j] > gate_lvl[(size_t)g]) { gate_lvl[(size_t)g] = lvl[j]; P.gate[(size_t)g] = j; }
+                    const bool local = early && nslabs > 1 && slab_of_visit(vis[j]) == myslab;
+                    if (local) ++l_cnt;
+                    P.cols[s] = j | (early ? LANE_EARLY : 0) | (local ? LANE_LOCAL : 0);
                     std::memcpy(&P.vals[s * tsize], Ax + (size_t)p * tsize, (size_t)tsize);
                     if (early) ++e_cnt; else ++o_cnt;
                 }
@@ -174,10 +198,10 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                 }
                 P.rid[(size_t)(g * RPW + r)] = i | (nodiag ? LANE_NODIAG : 0);
             }
-            ne[(size_t)l] = e_cnt; no[(size_t)l] = o_cnt;
+            ne[(size_t)l] = e_cnt; no[(size_t)l] = o_cnt; nloc[(size_t)l] = l_cnt;
         }
     }, 1);
-    for (int l = 0; l < nl; ++l) { P.n_early += ne[(size_t)l]; P.n_old += no[(size_t)l]; }
+    for (int64_t l = 0; l < nb; ++l) { P.n_early += ne[(size_t)l]; P.n_old += no[(size_t)l]; P.n_local += nloc[(size_t)l]; }
     return 0;
 }
 

@@ -1905,7 +1905,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 25: if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return PAMG_E_ARG; A->lane_L = value; break;
         case 26: if (value < 0) return PAMG_E_ARG; A->lane_G = value; return PAMG_OK;
         case 27: if (value < 0 || value > 1) return PAMG_E_ARG; A->lane_wide = value; return PAMG_OK;
-        case 28: if (value < 0 || value > 15) return PAMG_E_ARG; A->lane_flags = value; return PAMG_OK;
+        case 28: if (value < 0 || value > 15) return PAMG_E_ARG; { const bool relayout = ((A->lane_flags ^ value) & 2) != 0; A->lane_flags = value; if (!relayout) return PAMG_OK; } key = 25; break;
         default: return PAMG_E_ARG;
     }
     if (key == 25) {                                  // lane geometry: drop the lane parts only

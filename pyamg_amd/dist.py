@@ -355,7 +355,7 @@ class DistMultilevelSolver:
         self.dist, self.group = dist, group
         # halo exchange of the C++ driver: 'halo' = point to point with the actual neighbours (default), 'allgather' = every
         # rank's owned part gathered everywhere (the general fallback / correctness baseline of SURVEY 8e)
-        self.exchange = exchange or __import__("os").environ.get("PAMG_DIST_EXCHANGE", "halo")
+        self.exchange_mode = exchange or __import__("os").environ.get("PAMG_DIST_EXCHANGE", "halo")
         self.transport_tried = []
         if dist.is_initialized():
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
@@ -748,7 +748,7 @@ class _NativeCycle:
         if sol.world > 1:
             {"host": self._host_transport, "rccl": self._rccl_transport, "torch": self._torch_transport}[transport](lib)
         self.exchange = "halo"
-        if sol.world > 1 and getattr(sol, "exchange", "halo") == "allgather" and transport in ("host", "rccl"):
+        if sol.world > 1 and getattr(sol, "exchange_mode", "halo") == "allgather" and transport in ("host", "rccl"):
             capi.check(lib.pamg_dist_set_exchange(h, 1), "pamg_dist_set_exchange")
             self.exchange = "allgather"
         capi.check(lib.pamg_dist_finalize(h), "pamg_dist_finalize")

@@ -13,25 +13,40 @@
 
 using namespace pamg;
 
+// nslabs > 1: the slab layout, replayed the way the slab form of the kernel assigns it -- `waves` waves per slab, wave w of slab s
+// takes groups slab_grp[s] + w, + waves, ... in that order; the waves are visited round-robin and a wave runs its next group only
+// when every early operand has been published (else it "polls": it is skipped this round).  A full round without progress is a
+// deadlock (error 20).  LOCAL operands must come from the consumer's own slab (error 21).
 extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const double *Ax, double *x, const double *b, int row_start,
-                                   int row_stop, int row_step, int want_L, int sor, double omega, int snapshot, long long *stats)
+                                   int row_stop, int row_step, int want_L, int sor, double omega, int snapshot, long long *stats,
+                                   int nslabs, int waves)
 {
     std::vector<int> vis, lvl;
     int m = 0, nl = 0;
     if (sweep_levels(n, Ap, Aj, row_start, row_stop, row_step, vis, lvl, m, nl)) return 1;
     if (m == 0) return 0;
     LanePlan P;
-    if (build_lane_plan(n, Ap, Aj, reinterpret_cast<const unsigned char *>(Ax), 8, row_start, row_step, m, nl, vis, lvl, want_L, P)) return 2;
+    if (build_lane_plan(n, Ap, Aj, reinterpret_cast<const unsigned char *>(Ax), 8, row_start, row_step, m, nl, vis, lvl, want_L, P, nslabs < 1 ? 1 : nslabs)) return 2;
     const int L = P.L, K = P.K, RPW = P.RPW;
-    stats[0] = L; stats[1] = K; stats[2] = P.ngroups; stats[3] = P.n_slots; stats[4] = P.n_early; stats[5] = P.n_old; stats[6] = nl;
+    stats[0] = L; stats[1] = K; stats[2] = P.ngroups; stats[3] = P.n_slots; stats[4] = P.n_early; stats[5] = P.n_old; stats[6] = nl; stats[7] = P.n_local;
     std::vector<double> xs((size_t)n), xold;
     std::vector<char> pub((size_t)n, 0), written((size_t)n, 0);
+    std::vector<signed char> pub_slab((size_t)n, -1);
     const double *rd = reinterpret_cast<const double *>(P.rdiag.data());
     const double *vals = reinterpret_cast<const double *>(P.vals.data());
     if (snapshot) xold.assign(x, x + n);
     const double *xsrc = snapshot ? xold.data() : x;
     int64_t rows_done = 0;
-    for (int64_t g = 0; g < P.ngroups; ++g) {
+    auto slab_of_group = [&](int64_t g) { int sl = 0; while (sl + 1 < P.nslabs && g >= P.slab_grp[sl + 1]) ++sl; return sl; };
+    auto run_group = [&](int64_t g, bool may_wait) -> int {
+        const int myslab = slab_of_group(g);
+        if (may_wait) {
+            for (int lane = 0; lane < 64; ++lane)
+                for (int k = 0; k < K; ++k) {
+                    const int c = P.cols[(size_t)((g * K + k) * 64 + lane)];
+                    if (!(c & LANE_NONE) && (c & LANE_EARLY) && !pub[(size_t)(c & LANE_MASK)]) return -1;       // still polling
+                }
+        }
         double lane_sum[64];
         for (int lane = 0; lane < 64; ++lane) {
             double s = 0.0;
@@ -45,6 +60,7 @@ extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const do
                 double xv;
                 if (c & LANE_EARLY) {
                     if (!pub[(size_t)col]) return 12;                     // producer has a larger group number: deadlock on the device
+                    if ((c & LANE_LOCAL) && pub_slab[(size_t)col] != myslab) return 21;   // "local" operand published by another slab
                     xv = xs[(size_t)col];
                 } else {
                     if (!snapshot && written[(size_t)col]) return 13;     // an old value was overwritten before it was read
@@ -70,9 +86,32 @@ extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const do
             if (sor) v = omega * v + (1.0 - omega) * xsrc[row];
             if (!upd) v = xsrc[row];
             if (pub[(size_t)row]) return 14;                              // a row scheduled twice
-            xs[(size_t)row] = v; pub[(size_t)row] = 1;
+            xs[(size_t)row] = v; pub[(size_t)row] = 1; pub_slab[(size_t)row] = (signed char)myslab;
             if (upd) { x[row] = v; written[(size_t)row] = 1; }
             ++rows_done;
+        }
+        return 0;
+    };
+    if (P.nslabs <= 1) {
+        for (int64_t g = 0; g < P.ngroups; ++g) { const int rc = run_group(g, false); if (rc) return rc; }
+    } else {
+        if (waves < 1) waves = 1;
+        std::vector<int64_t> next((size_t)P.nslabs * waves);
+        for (int sl = 0; sl < P.nslabs; ++sl)
+            for (int w = 0; w < waves; ++w) next[(size_t)sl * waves + w] = P.slab_grp[sl] + w;
+        int64_t left = P.ngroups;
+        while (left > 0) {
+            bool progress = false;
+            // slabs visited LAST to first: the adversarial order (later slabs get the first chance to run ahead and wait)
+            for (int sl = P.nslabs - 1; sl >= 0; --sl)
+                for (int w = 0; w < waves; ++w) {
+                    int64_t &g = next[(size_t)sl * waves + w];
+                    if (g >= P.slab_grp[sl + 1]) continue;
+                    const int rc = run_group(g, true);
+                    if (rc > 0) return rc;
+                    if (rc == 0) { g += waves; --left; progress = true; }
+                }
+            if (!progress) return 20;
         }
     }
     if (rows_done != m) return 15;

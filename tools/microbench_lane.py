@@ -88,6 +88,15 @@ def variants_for(li, n):
             for L, Gs in ((32, (32, 40)), (64, (32, 48, 64, 96))):
                 for G in Gs:
                     v.append((f"fast_L{L}_xcd_G{G}", dict(lane_L=L, lane_G=G, gran_xcd=1)))
+    if a.exp == "d":                       # slab form (one slab per XCD) against the plain static form
+        v.append(("fast_static", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
+        v.append(("fast_slabs_auto", dict(lane_flags=3)))
+        for G in (256, 512, 768, 1024, 1536):
+            v.append((f"fast_slabs_G{G}", dict(lane_flags=3, lane_G=G)))
+        for G in (512, 1024):
+            v.append((f"fast_slabs_nogate_G{G}", dict(lane_flags=2, lane_G=G)))
+        for G in (512, 1024):
+            v.append((f"fast_slabs_L16_G{G}", dict(lane_flags=3, lane_L=16, lane_G=G)))
     return v
 
 
@@ -118,7 +127,7 @@ for li in a.levels:
             rec = {"level": li, "n": n, "variant": name, "fwd_ms": round(ms, 4), "max_rel_diff_vs_exact": diff, "timeout": err,
                    "levels": inf["gs_levels_fwd"], "us_per_level": round(1e3 * ms / max(inf["gs_levels_fwd"], 1), 3),
                    "lane": {k: li_[k] for k in ("lanes_per_row", "slots_per_lane", "groups", "widest_level_groups")} if name != "exact_default" else None}
-            if name == "fast_auto":
+            if name in ("fast_auto", "fast_slabs_auto"):
                 dA.tune(gs_prof=1)
                 dx.upload(x)
                 dA.gauss_seidel(dx, db, sweep="forward")
@@ -130,6 +139,7 @@ for li in a.levels:
                     wait = (pr[:, 1] - pr[:, 0]) * 10          # ns: group started -> last operand seen
                     span = (pr[:, 2].max() - pr[:, 0].min()) * 1e-5
                     xcds = np.bincount((pr[:, 3] & 15).astype(int), minlength=8).tolist()
+                    rec["prof_slab_xcd"] = sorted({(int(blk) % 8, int(xc)) for blk, xc in zip(pr[::997, 3] >> 4, pr[::997, 3] & 15)})
                     rec["prof"] = {"tail_ns_median": float(np.median(tail)), "tail_ns_p90": float(np.percentile(tail, 90)),
                                    "wait_ns_median": float(np.median(wait)), "span_ms": float(span), "groups_by_xcd": xcds}
         except Exception as e:  # noqa: BLE001
