@@ -108,6 +108,7 @@ struct GsSchedule {
     int nblk_total = 0;
     unsigned *d_sync = nullptr;      // [0] barrier arrival counter (block sweeps), [1] error flag, [20..21] ticket counter + home XCD
     int max_level_blocks = 0;
+    int max_range_rows = 0, max_range_blocks = 0;   // block schedules: the largest row range (block rows / blocks)
     std::vector<int> level_blk;      // [nlevels+1] workgroup range of each level
     size_t bytes = 0;
     std::vector<int> h_vis, h_lvl;   // scalar schedules: visit index (-1 = not swept) and dependency level of every row
@@ -200,8 +201,9 @@ struct pamg_matrix_s {
     int gs_order = 0;                // tune key 24: 0 = order-exact row sums (bit-identical to the reference), 1 = fast order: lane-parallel row
                                      //   sums and multiplication by 1/a_ii (same sweep order; agrees to rounding) where the schedule fits that form
     int lane_L = 0, lane_G = 0;      // fast order: lanes per row (0 = automatic) / persistent workgroups (0 = automatic)   (tune keys 25, 26)
-    int lane_flags = 3;              // fast order: bit 0 = gate operand (a wave that runs ahead polls one value instead of all its operands), bit 1 = slab form
+    int lane_flags = 1;              // fast order: bit 0 = gate operand (a wave that runs ahead polls one value instead of all its operands), bit 1 = slab form
                                      //   (one slab of the visit order per XCD, same-slab operands through the XCD's L2) for big operators   (tune key 28)
+    int lane_chunk = 2048;           // slab form: visited rows per chunk dealt out to the slabs in turn (0 = eight contiguous slabs)   (tune key 29)
     int lane_wide = 0;               // fast order on wide schedules (>= 2048 rows per dependency level): 0 = the tiled exact sweep keeps them, 1 = lane form   (tune key 27)
     int gs_cap = 0;                  // entries per row range of the level schedules (tune key 20; 0 = automatic: `cap`, 512 on the multi-XCD granular sweep of SA-like rows)
     int nblk = 0;

@@ -1897,6 +1897,167 @@ __global__ __launch_bounds__(BLK) void bsr_stream_kernel(const BlockArgs<T> a, c
 
 // persistent order-exact block sweep over row ranges: levels separated by __syncthreads() (one
 // workgroup) or by the arrival-counter barrier with coherent x traffic (several workgroups)
+// ---- small block levels: ONE workgroup, x and b in LDS (round 4).  bsr_flow_kernel on a level of a few hundred dense-ish block
+// rows (C5's 216 block rows of 6x6, ~41 blocks each: nearly every row its own dependency level) spends ~3.4 us per step in
+// global round trips (the blocks of the step, x_j, the inverted diagonal block) and in ONE lane adding bs x blocks values.
+// Here the iterate lives in LDS, the blocks / inverses of the NEXT range are in registers before the current one is finished,
+// and bs lanes share a block row in the second phase (lane k adds the k-th components of the per-block vectors, still block
+// after block).  Same products, same order of every sum: bit-identical to bsr_range / block_row_finish (and the reference's
+// gemm loops, linalg.h:405-438, relaxation.h:185-266,1242-1298).  No hazards by construction: the ranges run one after the
+// other, rows of one dependency level never touch each other's unknowns.
+constexpr int SMALL_THREADS = 512;
+constexpr int SMALL_NP = 3;                 // prefetched (block, row-of-block) entries per lane
+
+template <typename T, int BSC>
+struct SmallPre {
+    int cj[SMALL_NP];
+    T av[SMALL_NP][BSC ? BSC : MAXBS];
+    T dv[BSC ? BSC : MAXBS];                // row k of the inverted diagonal block (BLK_GS) / of the diagonal block (PNT_GS) for this lane's (row, k)
+    int row, dq;
+};
+
+template <typename T, int KIND, int BSC>
+__device__ __forceinline__ void small_prefetch(const BlockArgs<T> &a, const BsrRange<T> &g, const int4 m, SmallPre<T, BSC> &P)
+{
+    constexpr int MB = BSC ? BSC : MAXBS;
+    const int bs = BSC ? BSC : a.bs, bb = bs * bs;
+    const int tid = threadIdx.x;
+    const int q0 = m.z, nent = (m.w - m.z) * bs;
+#pragma unroll
+    for (int t = 0; t < SMALL_NP; ++t) {
+        const int e = tid + t * SMALL_THREADS;
+        P.cj[t] = DIAG_BIT;
+        if (e < nent) {
+            const int q = q0 + e / bs, r = e % bs;
+            const int cj = g.pbj[q];
+            P.cj[t] = cj;
+            if (!(cj & DIAG_BIT)) {
+                const long p = g.pblk ? g.pblk[q] : q;
+                const T *Arow = a.Ax + p * bb + r * bs;
+#pragma unroll
+                for (int c = 0; c < MB; ++c) if (c < bs) P.av[t][c] = Arow[c];
+            }
+        }
+    }
+    const int nr = (m.y - m.x) * bs;
+    P.row = -1; P.dq = -1;
+    if (tid < nr) {
+        const int rl = m.x + tid / bs, k = tid % bs;
+        const int i = a.rid ? a.rid[rl] : rl;
+        P.row = i;
+        const int dq = g.dpos[rl];
+        P.dq = dq;
+        if constexpr (KIND == BLK_GS) {
+            const T *Di = a.Dinv + (long)i * bb + k * bs;
+#pragma unroll
+            for (int c = 0; c < MB; ++c) if (c < bs) P.dv[c] = Di[c];
+        }
+    }
+}
+
+template <typename T, int KIND, int BSC>
+__global__ __launch_bounds__(SMALL_THREADS) void bsr_small_kernel(const BlockArgs<T> a, const BsrRange<T> g, int nranges, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int MB = BSC ? BSC : MAXBS;
+    const int bs = BSC ? BSC : a.bs, bb = bs * bs;
+    const int tid = threadIdx.x;
+    T *xl = reinterpret_cast<T *>(smem_raw);            // [n] the iterate
+    T *bl = xl + n;                                      // [n] right-hand side
+    T *prodv = bl + n;                                   // [capv] per (block, row-of-block) dot products of the current range
+    T *rs = prodv + g.capv;                              // [SMALL_THREADS] b - sum of the current range's rows (BLK_GS exchange)
+    for (int k = tid; k < n; k += SMALL_THREADS) { xl[k] = a.xsrc[k]; bl[k] = a.b[k]; }
+    SmallPre<T, BSC> P, Q;
+    if (nranges > 0) small_prefetch<T, KIND, BSC>(a, g, g.meta[0], P);
+    __syncthreads();
+    auto step = [&](const int4 m, SmallPre<T, BSC> &C, SmallPre<T, BSC> &N, int nxt) {
+        const int q0 = m.z, nent = (m.w - m.z) * bs;
+        // phase 1: dot of row r of block q with x_j, in c order
+#pragma unroll
+        for (int t = 0; t < SMALL_NP; ++t) {
+            const int e = tid + t * SMALL_THREADS;
+            if (e < nent) {
+                T d = T(0);
+                if (!(C.cj[t] & DIAG_BIT)) {
+                    const T *xj = xl + (long)(C.cj[t] & COL_MASK) * bs;
+#pragma unroll
+                    for (int c = 0; c < MB; ++c) if (c < bs) d += C.av[t][c] * xj[c];
+                }
+                prodv[e] = d;
+            }
+        }
+        for (int e = tid + SMALL_NP * SMALL_THREADS; e < nent; e += SMALL_THREADS) {          // beyond the prefetch window: straight from memory
+            const int q = q0 + e / bs, r = e % bs;
+            const int cj = g.pbj[q];
+            T d = T(0);
+            if (!(cj & DIAG_BIT)) {
+                const long p = g.pblk ? g.pblk[q] : q;
+                const T *Arow = a.Ax + p * bb + r * bs;
+                const T *xj = xl + (long)(cj & COL_MASK) * bs;
+                for (int c = 0; c < bs; ++c) d += Arow[c] * xj[c];
+            }
+            prodv[e] = d;
+        }
+        if (nxt < nranges) small_prefetch<T, KIND, BSC>(a, g, g.meta[nxt], N);        // in flight during the second phase
+        lds_barrier();
+        // phase 2: lane (row, k) adds the k-th components block after block
+        const bool mine = C.row >= 0;
+        const int rl = m.x + tid / bs, k = tid % bs;
+        T acc = T(0);
+        if (mine) {
+            const int i = C.row;
+            if constexpr (KIND == BLK_GS) acc = T(0);
+            else acc = bl[(long)i * bs + k];
+            const int qa = g.pAp[rl], qb = g.pAp[rl + 1];
+            for (int q = qa; q < qb; ++q) {
+                const T v = prodv[(q - q0) * bs + k];
+                if constexpr (KIND == BLK_GS) acc += v;
+                else acc -= v;
+            }
+            if constexpr (KIND == BLK_GS) acc = bl[(long)i * bs + k] - acc;
+            rs[tid] = acc;
+        }
+        lds_barrier();
+        if (mine) {
+            const int i = C.row;
+            const int base = tid - k;                                               // lane of component 0 of this block row
+            if constexpr (KIND == BLK_GS) {
+                T d = T(0);
+#pragma unroll
+                for (int c = 0; c < MB; ++c) if (c < bs) d += C.dv[c] * rs[base + c];
+                xl[(long)i * bs + k] = d;
+                a.xdst[(long)i * bs + k] = d;
+            } else if (k == 0 && C.dq >= 0) {
+                // point sweep inside the diagonal block: sequential over its points (relaxation.h:247-259), one lane per block row
+                const T *D = a.Ax + (long)C.dq * bb;
+                T loc[MB], ac[MB];
+                for (int kk = 0; kk < bs; ++kk) { loc[kk] = xl[(long)i * bs + kk]; ac[kk] = rs[base + kk]; }
+                const int k0 = a.dirn > 0 ? 0 : bs - 1, k1 = a.dirn > 0 ? bs : -1;
+                for (int kk = k0; kk != k1; kk += a.dirn) {
+                    T d = T(1);
+                    for (int c = k0; c != k1; c += a.dirn) {
+                        if (c == kk) d = D[kk * bs + c];
+                        else ac[kk] -= D[kk * bs + c] * loc[c];
+                    }
+                    if (d != T(0)) {
+                        loc[kk] = ac[kk] / d;
+                        xl[(long)i * bs + kk] = loc[kk];
+                        a.xdst[(long)i * bs + kk] = loc[kk];
+                    }
+                }
+            }
+        }
+        lds_barrier();
+    };
+    int blk = 0;
+    while (blk < nranges) {
+        step(g.meta[blk], P, Q, blk + 1);
+        if (++blk >= nranges) break;
+        step(g.meta[blk], Q, P, blk + 1);
+        ++blk;
+    }
+}
+
 template <typename T, int KIND, bool COH>
 __global__ __launch_bounds__(BLK) void bsr_flow_kernel(const BlockArgs<T> a, const BsrRange<T> g, const int *level_blk,
                                                        int nlevels, unsigned *sync)

@@ -85,6 +85,7 @@ struct LaneArgs {
     unsigned *ticket;      // one-XCD form: [0] ticket counter, [1] home XCD + 1
     long long *prof;       // nullptr or [ngroups][4] time stamps
     int ngroups, nidle;
+    int old_l1;            // != 0: old values through the L1 (ordinary loads); 0: L1-bypassing loads like the polls
     T omega;
 };
 
@@ -176,8 +177,17 @@ __device__ __forceinline__ void lane_issue(const LaneArgs<T> &a, const LaneSet<T
         const int col = c & LANE_MASK;
         const T *hand = a.xs;
         if constexpr (MODE == 2) hand = ((c & LANE_LOCAL) && local_ok) ? a.xl : a.xs;
-        const T *p = (c & LANE_NONE) ? a.x + idle : ((c & LANE_EARLY) ? hand + col : a.x + col);
-        D.xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.old_l1) {
+            // two loads: the early operand past the L1 (another CU writes it during the launch), the old value through it.  An old
+            // value is not rewritten before this row has published (its owner waits for this row), and the L1 holds nothing from
+            // before the launch, so a cached copy is the value of before the sweep.
+            const T ve = __hip_atomic_load(((c & LANE_EARLY) && !(c & LANE_NONE)) ? hand + col : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const T vo = a.x[((c & (LANE_EARLY | LANE_NONE)) == 0) ? col : idle];
+            D.xv[k] = (c & LANE_EARLY) ? ve : vo;
+        } else {
+            const T *p = (c & LANE_NONE) ? a.x + idle : ((c & LANE_EARLY) ? hand + col : a.x + col);
+            D.xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -435,7 +445,7 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
     // consumer's own slab is handed over through the XCD's L2 instead of through memory (lane_flags bit 1; profiles/r04_*slab*)
     const bool slabs = !lane_one_xcd(A, g) && (A->lane_flags & 2) && g->nrows >= 262144 && A->nrows < LANE_LOCAL;
     if (build_lane_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), hAx.data(), ts, g->row_start, g->row_step, (int)g->nrows,
-                        g->nlevels, g->h_vis, g->h_lvl, want_L, P, slabs ? LANE_MAX_SLABS : 1))
+                        g->nlevels, g->h_vis, g->h_lvl, want_L, P, slabs ? LANE_MAX_SLABS : 1, A->lane_chunk))
         return PAMG_E_ARG;
     LaneSched *t = new (std::nothrow) LaneSched();
     if (!t) return PAMG_E_ALLOC;
@@ -496,6 +506,7 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     a.ngroups = (int)t->ngroups;
     a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
     a.omega = (T)omega;
+    a.old_l1 = (A->lane_flags & 4) ? 1 : 0;
     if (!g->symmetric) {
         // write-after-read hazards are not ordered by the waits: old values come from a snapshot
         if (!g->d_xold) return PAMG_E_STATE;

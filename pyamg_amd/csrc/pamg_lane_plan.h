@@ -96,7 +96,8 @@ inline int lane_geometry(int maxlen, int want_L, int &K)
 // visited row: sweep_levels in pamg_tile_plan.h), m visited rows, nl levels.  Ax: the operator's values (tsize bytes
 // each).  Returns 0, or 1 when the rows are too long / the padding too wasteful (caller keeps the exact schedulers).
 inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned char *Ax, int tsize, int row_start, int row_step,
-                           int m, int nl, const std::vector<int> &vis, const std::vector<int> &lvl, int want_L, LanePlan &P, int nslabs = 1)
+                           int m, int nl, const std::vector<int> &vis, const std::vector<int> &lvl, int want_L, LanePlan &P, int nslabs = 1,
+                           int chunk = 0)
 {
     P = LanePlan();
     P.nlevels = nl;
@@ -104,7 +105,9 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
     if (nslabs < 1 || nslabs > LANE_MAX_SLABS || (int64_t)nslabs * nl >= ((int64_t)1 << 30) || n >= LANE_LOCAL) nslabs = 1;
     P.nslabs = nslabs;
     const int64_t nb = (int64_t)nslabs * nl;                                   // buckets (slab, level), slab-major
-    auto slab_of_visit = [&](int t) { return (int)((int64_t)t * nslabs / m); };
+    // chunk = 0: nslabs contiguous pieces of the visit order; chunk > 0: pieces of `chunk` visited rows dealt out to the slabs in turn
+    // (the front of a sweep covers a band of the visit order: contiguous slabs would take turns, dealt-out chunks all work at once)
+    auto slab_of_visit = [&](int t) { return chunk > 0 ? (int)((t / chunk) % nslabs) : (int)((int64_t)t * nslabs / m); };
     // rows in bucket order, visit order inside a bucket
     std::vector<int64_t> lptr((size_t)nb + 1, 0);
     for (int t = 0; t < m; ++t) lptr[(size_t)((int64_t)slab_of_visit(t) * nl + lvl[row_start + (int64_t)t * row_step]) + 1]++;
@@ -152,6 +155,20 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
     P.rdiag.assign((size_t)P.ngroups * RPW * tsize, 0);
     P.gate.assign((size_t)P.ngroups, -1);
     std::vector<int> gate_lvl((size_t)P.ngroups, -1);
+    // latest early operand of every visited row (-1: none): where a group has no operand two levels down, an operand OF one of its
+    // operands serves as the gate (stencils: every early operand of a row sits exactly one level below it)
+    std::vector<int> best_dep((size_t)n, -1);
+    lane_parallel(m, [&](int64_t t0, int64_t t1) {
+        for (int64_t t = t0; t < t1; ++t) {
+            const int i = row_start + (int)t * row_step, ti = vis[i];
+            int bl = -1;
+            for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+                const int j = Aj[p];
+                if (j == i || j < 0 || j >= n || vis[j] < 0 || vis[j] >= ti) continue;
+                if (lvl[j] > bl) { bl = lvl[j]; best_dep[(size_t)i] = j; }
+            }
+        }
+    });
     std::vector<int64_t> ne((size_t)nb, 0), no((size_t)nb, 0), nloc((size_t)nb, 0);
     lane_parallel(nb, [&](int64_t l0, int64_t l1) {
         for (int64_t bk = l0; bk < l1; ++bk) {
@@ -173,7 +190,11 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                     ++e;
                     if (j < 0 || j >= n) continue;                                    // not a column of x: no product
                     const bool early = vis[j] >= 0 && vis[j] < ti;
-                    if (early && lvl[j] <= mylevel - 2 && lvl[j] > gate_lvl[(size_t)g]) { gate_lvl[(size_t)g] = lvl[j]; P.gate[(size_t)g] = j; }
+                    if (early) {
+                        int cand = j;
+                        if (lvl[cand] > mylevel - 2) cand = best_dep[(size_t)j];          // one level down: its own latest operand is two or more down
+                        if (cand >= 0 && lvl[cand] <= mylevel - 2 && lvl[cand] > gate_lvl[(size_t)g]) { gate_lvl[(size_t)g] = lvl[cand]; P.gate[(size_t)g] = cand; }
+                    }
                     const bool local = early && nslabs > 1 && slab_of_visit(vis[j]) == myslab;
                     if (local) ++l_cnt;
                     P.cols[s] = j | (early ? LANE_EARLY : 0) | (local ? LANE_LOCAL : 0);

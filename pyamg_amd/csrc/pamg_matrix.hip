@@ -735,6 +735,10 @@ int build_schedule_block(pamg_matrix_s *A, int row_start, int row_stop, int row_
     g->nblk_total = (int)blk.size();
     for (int l = 0; l < g->nlevels; ++l)
         g->max_level_blocks = std::max(g->max_level_blocks, g->level_blk[l + 1] - g->level_blk[l]);
+    for (const int4 &m4 : blk) {
+        g->max_range_rows = std::max(g->max_range_rows, m4.y - m4.x);
+        g->max_range_blocks = std::max(g->max_range_blocks, m4.w - m4.z);
+    }
     int st = upload(&g->d_rid, order.data(), order.size(), &g->bytes);
     if (!st) st = upload(&g->d_Ap, pAp.data(), pAp.size(), &g->bytes);
     if (!st) st = upload(&g->d_pblk, pblk.data(), pblk.size(), &g->bytes);
@@ -1286,6 +1290,27 @@ static int block_sweep_t(pamg_matrix_s *A, GsSchedule *g, int kind, const void *
 #undef PAMG_BGS
 #undef PAMG_BG
         return (int)hipGetLastError();
+    }
+    // small block levels (the iterate fits the LDS next to the range's products): one workgroup, x and b in LDS, the next range's
+    // blocks prefetched -- bit-identical to the kernels below (tune key 5 = 3 keeps bsr_flow_kernel for comparison)
+    if (single && A->gs_mode == 0 && A->R <= MAXBS) {
+        const int64_t n = A->nrows;
+        const size_t need = (size_t)(2 * n + r.capv + SMALL_THREADS) * ts + 64;
+        if (need <= 60 * 1024 && (int64_t)g->max_range_rows * A->R <= SMALL_THREADS && (int64_t)g->max_range_blocks * A->R <= r.capv) {
+#define PAMG_BS(K, B) hipLaunchKernelGGL((bsr_small_kernel<T, K, B>), dim3(1), dim3(SMALL_THREADS), need, s, a, r, g->nblk_total, (int)n)
+#define PAMG_BSS(K)                                                                      \
+            switch (A->R) {                                                              \
+                case 2: PAMG_BS(K, 2); break;                                            \
+                case 3: PAMG_BS(K, 3); break;                                            \
+                case 4: PAMG_BS(K, 4); break;                                            \
+                case 6: PAMG_BS(K, 6); break;                                            \
+                default: PAMG_BS(K, 0); break;                                           \
+            }
+            if (kind == PNT_GS) { PAMG_BSS(PNT_GS) } else { PAMG_BSS(BLK_GS) }
+#undef PAMG_BSS
+#undef PAMG_BS
+            return (int)hipGetLastError();
+        }
     }
     int G = 0;
     if (persist) {
@@ -1905,6 +1930,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 25: if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return PAMG_E_ARG; A->lane_L = value; break;
         case 26: if (value < 0) return PAMG_E_ARG; A->lane_G = value; return PAMG_OK;
         case 27: if (value < 0 || value > 1) return PAMG_E_ARG; A->lane_wide = value; return PAMG_OK;
+        case 29: if (value < 0) return PAMG_E_ARG; A->lane_chunk = value; key = 25; break;
         case 28: if (value < 0 || value > 15) return PAMG_E_ARG; { const bool relayout = ((A->lane_flags ^ value) & 2) != 0; A->lane_flags = value; if (!relayout) return PAMG_OK; } key = 25; break;
         default: return PAMG_E_ARG;
     }

@@ -19,14 +19,14 @@ using namespace pamg;
 // deadlock (error 20).  LOCAL operands must come from the consumer's own slab (error 21).
 extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const double *Ax, double *x, const double *b, int row_start,
                                    int row_stop, int row_step, int want_L, int sor, double omega, int snapshot, long long *stats,
-                                   int nslabs, int waves)
+                                   int nslabs, int waves, int chunk)
 {
     std::vector<int> vis, lvl;
     int m = 0, nl = 0;
     if (sweep_levels(n, Ap, Aj, row_start, row_stop, row_step, vis, lvl, m, nl)) return 1;
     if (m == 0) return 0;
     LanePlan P;
-    if (build_lane_plan(n, Ap, Aj, reinterpret_cast<const unsigned char *>(Ax), 8, row_start, row_step, m, nl, vis, lvl, want_L, P, nslabs < 1 ? 1 : nslabs)) return 2;
+    if (build_lane_plan(n, Ap, Aj, reinterpret_cast<const unsigned char *>(Ax), 8, row_start, row_step, m, nl, vis, lvl, want_L, P, nslabs < 1 ? 1 : nslabs, chunk)) return 2;
     const int L = P.L, K = P.K, RPW = P.RPW;
     stats[0] = L; stats[1] = K; stats[2] = P.ngroups; stats[3] = P.n_slots; stats[4] = P.n_early; stats[5] = P.n_old; stats[6] = nl; stats[7] = P.n_local;
     std::vector<double> xs((size_t)n), xold;

@@ -523,7 +523,26 @@ def test_block_sweep_modes_all_exact():
     M3 = sp.bsr_array((dat, Pn.indices.astype(np.int32), Pn.indptr.astype(np.int32)), shape=(3 * nbr, 3 * nbr), blocksize=(3, 3))
     P6 = poisson_csr((7, 6, 5))
     M6 = sp.kron(P6, rng.rand(6, 6) + 6.0 * np.eye(6), format="bsr")
-    for M, bs in ((M2, 2), (M3, 3), (M6, 6)):
+    # small, dense-ish block levels (the coarse levels of an elasticity hierarchy: nearly every block row its own dependency
+    # level): the single-workgroup kernel with the iterate in LDS (bsr_small_kernel) -- 6x6, a structurally non-symmetric 3x3
+    # pattern with missing / singular diagonal blocks, and 5x5 (run-time block size)
+    def small(nb_, bs_, dens, drop):
+        Pp = sp.random(nb_, nb_, density=dens, random_state=rng, format="lil")
+        for i in range(nb_):
+            if not (drop and i % 9 == 4):
+                Pp[i, i] = 1.0
+        Pp = sp.csr_array(Pp)
+        Pp.sort_indices()
+        dd = rng.rand(Pp.nnz, bs_, bs_) - 0.5
+        for i in range(nb_):
+            for p in range(Pp.indptr[i], Pp.indptr[i + 1]):
+                if Pp.indices[p] == i:
+                    dd[p] += (2.0 * bs_ * dens * nb_ + 4.0) * np.eye(bs_)
+                    if drop and i % 7 == 3:
+                        dd[p][bs_ - 1, bs_ - 1] = 0.0
+        return sp.bsr_array((dd, Pp.indices.astype(np.int32), Pp.indptr.astype(np.int32)), shape=(bs_ * nb_, bs_ * nb_), blocksize=(bs_, bs_))
+    S6, S3, S5 = small(120, 6, 0.3, False), small(200, 3, 0.08, True), small(64, 5, 0.5, False)
+    for M, bs in ((M2, 2), (M3, 3), (M6, 6), (S6, 6), (S3, 3), (S5, 5)):
         M = sp.bsr_array((M.data, M.indices.astype(np.int32), M.indptr.astype(np.int32)), shape=M.shape, blocksize=(bs, bs))
         op = sparse_op(M)
         n = op.shape[0]

@@ -34,7 +34,7 @@ def emul():
     return lib
 
 
-def run_emul(lib, A, x, b, start, stop, step, want_L=0, sor=0, omega=1.0, snapshot=0, nslabs=1, waves=1):
+def run_emul(lib, A, x, b, start, stop, step, want_L=0, sor=0, omega=1.0, snapshot=0, nslabs=1, waves=1, chunk=0):
     A = sp.csr_array(A)
     Ap = np.ascontiguousarray(A.indptr, dtype=np.int32)
     Aj = np.ascontiguousarray(A.indices, dtype=np.int32)
@@ -43,7 +43,7 @@ def run_emul(lib, A, x, b, start, stop, step, want_L=0, sor=0, omega=1.0, snapsh
     stats = np.zeros(8, dtype=np.int64)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     rc = lib.lane_emul_sweep_f64(ctypes.c_int(A.shape[0]), p(Ap), p(Aj), p(Ax), p(xx), p(np.ascontiguousarray(b, dtype=np.float64)),
-                                 start, stop, step, want_L, sor, ctypes.c_double(omega), snapshot, p(stats), nslabs, waves)
+                                 start, stop, step, want_L, sor, ctypes.c_double(omega), snapshot, p(stats), nslabs, waves, chunk)
     return rc, xx, stats
 
 
@@ -174,3 +174,7 @@ def test_slab_layout_is_deadlock_free_and_local_operands_are_local(emul, waves):
     x, b = rng.random(n), rng.random(n)
     rc, got, st = run_emul(emul, P3, x, b, 0, n, 1, nslabs=8, waves=waves)
     assert rc == 0 and close(got, ref_sweep(P3, x, b, 0, n, 1))
+    # chunks of the visit order dealt out to the slabs in turn (the layout the device uses: every slab works on the front at once)
+    for chunk in (16, 100):
+        rc, got, st = run_emul(emul, A, rng.random(4000), b[:0].tolist() or rng.random(4000), 0, 4000, 1, want_L=64, nslabs=8, waves=waves, chunk=chunk)
+        assert rc == 0 and 0 < st[7] < st[4]
