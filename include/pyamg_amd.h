@@ -348,7 +348,7 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * else 4|8|16|32|64), 26 = its persistent workgroups (0 = automatic), 27 = 1: the fast order also takes wide schedules
  * (>= 2048 rows per dependency level), which the tiled exact sweep keeps by default, 28 = flags of the fast order (bit 0, default
  * on: a wave that runs ahead of the sweep polls ONE gate operand instead of all its operands until the sweep is one
- * dependency level away).
+ * dependency level away), 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled.
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes
@@ -377,6 +377,12 @@ int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8]);
  * launches 8x what stays), groups of the widest dependency level, bytes}; all zero when that schedule has no lane layout.  pamg_matrix_lane_profile: with tune
  * key 11, per group four 64-bit words {start, last operand seen, published (wall clock, 10 ns), XCD | workgroup << 4}. */
 int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8]);
+/* Layout of the line-scan fast-order sweep (tune keys 24 / 30: banded operators swept over consecutive rows, i.e. grid
+ * stencils in their natural order -- a run of rows each coupled to its predecessor is a first-order linear recurrence, finished
+ * 64 rows at a time by a scan) for schedule `which`: {entry slots per row, chunks (<= 64 rows, one wave step each), lines (chained
+ * chunks, one wave each), levels of the line graph, entries that wait for a new value, workgroups of the last launch, lines of
+ * the widest level, bytes}; all zero when that schedule has no line layout. */
+int pamg_matrix_line_info(pamg_matrix_t A, int which, int64_t info[8]);
 int pamg_matrix_lane_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count);
 /* Row-subset copy of a CSR operator (rows: HOST list, kept in list order) for the indexed smoothers,
  * and amg_core::jacobi_indexed (relaxation.h:382-427) on it: every listed row of x is relaxed from the

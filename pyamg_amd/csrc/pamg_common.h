@@ -116,6 +116,8 @@ struct GsSchedule {
     int cap = 0;                     // entries per row range of the level-permuted copy (the LDS window its kernels run with)
     struct TileSched *tile = nullptr; // tiled sweep (pamg_tile_plan.h / pamg_tile_kernels.h), built on demand
     bool tile_unfit = false;         // the tile planner declined this schedule (a step would not fit): other schedulers run it
+    struct LineSched *line = nullptr; // line-scan fast-order sweep for banded operators in their natural order (pamg_line_plan.h / pamg_line.hip)
+    bool line_unfit = false;         // the line planner declined this schedule (no runs of coupled consecutive rows / rows too long)
     struct LaneSched *lane = nullptr; // lane-parallel "fast order" sweep (pamg_lane_plan.h / pamg_lane.hip), built on demand
     bool lane_unfit = false;         // the lane planner declined this schedule (rows too long / padding too wasteful)
 };
@@ -204,6 +206,7 @@ struct pamg_matrix_s {
     int lane_flags = 1;              // fast order: bit 0 = gate operand (a wave that runs ahead polls one value instead of all its operands), bit 1 = slab form
                                      //   (one slab of the visit order per XCD, same-slab operands through the XCD's L2) for big operators   (tune key 28)
     int lane_chunk = 2048;           // slab form: visited rows per chunk dealt out to the slabs in turn (0 = eight contiguous slabs)   (tune key 29)
+    int line_scan = 1;               // fast order: line-scan sweep where consecutive rows are coupled (grid stencils), tried before the lane form   (tune key 30)
     int lane_wide = 0;               // fast order on wide schedules (>= 2048 rows per dependency level): 0 = the tiled exact sweep keeps them, 1 = lane form   (tune key 27)
     int gs_cap = 0;                  // entries per row range of the level schedules (tune key 20; 0 = automatic: `cap`, 512 on the multi-XCD granular sweep of SA-like rows)
     int nblk = 0;
@@ -262,6 +265,13 @@ struct CsrArrays { int64_t m, n, nnz; const int *p, *j; const double *x; };
 int csr_device_arrays(struct ::pamg_csr_s *A, CsrArrays *out);                                  // pamg_setup.hip: the device arrays behind a pamg_csr_t
 int solver_cycle_inline(pamg_solver_s *S, void *x, const void *b, int cycle, int cpl, hipStream_t s, bool allow_graph);   // pamg_solver.hip
 bool solver_needs_host_sync(const pamg_solver_s *S);                                                                   // pamg_solver.hip
+// pamg_line.hip: the line-scan fast-order sweep (banded operators in their natural order)
+bool line_eligible(const pamg_matrix_s *A, const GsSchedule *g);
+int build_line_part(pamg_matrix_s *A, GsSchedule *g);
+void free_line_part(LineSched *t);
+size_t line_part_bytes(const GsSchedule *g);
+int line_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s);
+int line_info(const GsSchedule *g, int64_t *info);
 // pamg_lane.hip: the lane-parallel fast-order sweep
 bool lane_eligible(const pamg_matrix_s *A, const GsSchedule *g);
 int build_lane_part(pamg_matrix_s *A, GsSchedule *g);

@@ -362,7 +362,7 @@ def test_gs_fast_order_agrees_to_rounding():
         dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
         assert np.array_equal(dx.download(), ref)                       # a bare operator is order-exact
         seen = set()
-        for kw in (dict(gs_order=1, lane_wide=1), dict(lane_L=16), dict(lane_L=64), dict(lane_L=0, gran_xcd=1), dict(gran_xcd=2, lane_G=3),
+        for kw in (dict(gs_order=1, lane_wide=1, line_scan=0), dict(lane_L=16), dict(lane_L=64), dict(lane_L=0, gran_xcd=1), dict(gran_xcd=2, lane_G=3),
                    dict(gran_xcd=1, lane_G=1), dict(gran_xcd=0, lane_G=0, lane_L=8), dict(lane_flags=0), dict(lane_flags=1, gran_xcd=2)):
             dA.tune(**kw)
             dx.upload(x)
@@ -378,6 +378,19 @@ def test_gs_fast_order_agrees_to_rounding():
             assert np.max(np.abs(got - refs)) <= tol * np.max(np.abs(refs)), (kw, ci)
             assert not dA.flow_error(), kw
         assert len(seen) >= 2 or ci == 5                                # (the ~70-per-row operator needs 64 lanes whatever is asked)
+        # the line-scan form (grid stencils in their natural order: consecutive rows coupled) -- default where it applies
+        for kw in (dict(line_scan=1, lane_G=0), dict(lane_G=2), dict(lane_flags=0, lane_G=0)):
+            dA.tune(**kw)
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+            got = dx.download()
+            assert (dA.line_info(0)["lines"] > 0) == (ci in (0, 2)), (ci, dA.line_info(0))
+            assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)), (kw, ci, np.max(np.abs(got - ref)))
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="forward", omega=1.4)
+            assert np.max(np.abs(dx.download() - refs)) <= tol * np.max(np.abs(refs)), (kw, ci)
+            assert not dA.flow_error(), kw
+        dA.tune(lane_flags=1)
         dA.tune(gs_order=0)
         dx.upload(x)
         dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)

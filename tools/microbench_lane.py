@@ -127,6 +127,13 @@ def variants_for(li, n):
             for G in (384, 512, 768):
                 v.append((f"fast_oldL1_G{G}", dict(lane_flags=5, lane_G=G)))
             v.append(("fast_oldL1_nogate_G512", dict(lane_flags=4, lane_G=512)))
+    if a.exp == "h":                       # line-scan form on the grid stencil
+        v.append(("tile_exact", dict(gs_order=0)))
+        v.append(("lines_auto", dict(gs_order=1, line_scan=1, lane_G=0, lane_flags=1)))
+        for G in (128, 256, 512, 1024, 1536):
+            v.append((f"lines_G{G}", dict(lane_G=G)))
+        for G in (256, 1024):
+            v.append((f"lines_nogate_G{G}", dict(lane_G=G, lane_flags=0)))
     return v
 
 
@@ -154,7 +161,8 @@ for li in a.levels:
             ms = timeit(lambda: dA.gauss_seidel(dx, db, sweep="forward"))
             inf = dA.info()
             li_ = dA.lane_info(0)
-            rec = {"level": li, "n": n, "variant": name, "fwd_ms": round(ms, 4), "max_rel_diff_vs_exact": diff, "timeout": err,
+            ln_ = dA.line_info(0)
+            rec = {"level": li, "n": n, "variant": name, "fwd_ms": round(ms, 4), "max_rel_diff_vs_exact": diff, "timeout": err, "line": ln_ if ln_["lines"] else None,
                    "levels": inf["gs_levels_fwd"], "us_per_level": round(1e3 * ms / max(inf["gs_levels_fwd"], 1), 3),
                    "lane": {k: li_[k] for k in ("lanes_per_row", "slots_per_lane", "groups", "widest_level_groups", "launch_grid")} if name != "exact_default" else None}
             if name in ("fast_auto", "fast_slabs_auto"):
