@@ -675,8 +675,9 @@ def main():
             ms = g0.elapsed_ms(g1) / 5
             Ai = L.A.tocsr() if L.A.format != "csr" else L.A
             by = 12 * int(Ai.nnz) + 4 * (ni + 1) + 24 * ni            # Jacobi / GS / SOR sweep
-            lane, tile = dA.lane_info(0), dA.tile_info(0)
-            sched = (f"lane-parallel fast order: {lane['lanes_per_row']} lanes per row x {lane['slots_per_lane']}, {lane['launch_grid']} workgroups" if lane["groups"] and dml_.order == "fast" and lane["launch_grid"]
+            lane, tile, line = dA.lane_info(0), dA.tile_info(0), dA.line_info(0)
+            sched = (f"line-scan fast order: {line['lines']} lines in {line['line_levels']} line levels, {line['launch_grid']} workgroups" if line["lines"] and dml_.order == "fast" and line["launch_grid"]
+                     else f"lane-parallel fast order: {lane['lanes_per_row']} lanes per row x {lane['slots_per_lane']}, {lane['launch_grid']} workgroups" if lane["groups"] and dml_.order == "fast" and lane["launch_grid"]
                      else f"tiled exact sweep: {tile['tiles']} tiles" if tile["tiles"] else "granular / single-workgroup exact sweep")
             rows_.append({"level": i, "rows": int(ni), "nnz": int(Ai.nnz), "dependency_levels": int(inf["gs_levels_fwd"]), "scheduler": sched,
                           "ms_per_forward_sweep": round(ms, 4), "us_per_dependency_level": round(1e3 * ms / inf["gs_levels_fwd"], 3),

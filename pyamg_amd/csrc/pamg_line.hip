@@ -93,6 +93,47 @@ __device__ __forceinline__ void line_load(const LineArgs<T> &a, int g, LineSet<T
 
 constexpr int LINE_WPB = BLK / 64;
 
+// ---- lane shifts for the scan: DPP row_shr inside the rows of 16 lanes, row_bcast15 / row_bcast31 across them
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double line_dpp(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float line_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWMASK, 0xF, false));
+}
+__device__ __forceinline__ double line_readlane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float line_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// inclusive scan of the pairs (A, B) over the 64 lanes under (A2, B2) o (A1, B1) = (A2 A1, B2 + A2 B1)
+template <typename T>
+__device__ __forceinline__ void line_scan(T &Av, T &Bv, int lane)
+{
+#define PAMG_LS_STEP(CTRL, D)                                                        \
+    {                                                                                \
+        const T Au = line_dpp<CTRL, 0xF>(Av), Bu = line_dpp<CTRL, 0xF>(Bv);          \
+        if ((lane & 15) >= D) { Bv = Bv + Av * Bu; Av = Av * Au; }                   \
+    }
+    PAMG_LS_STEP(0x111, 1) PAMG_LS_STEP(0x112, 2) PAMG_LS_STEP(0x114, 4) PAMG_LS_STEP(0x118, 8)
+#undef PAMG_LS_STEP
+    {   // rows 1 and 3 take over the total of the row before them (its lane 15)
+        const T Au = line_dpp<0x142, 0xA>(Av), Bu = line_dpp<0x142, 0xA>(Bv);
+        if (lane & 16) { Bv = Bv + Av * Bu; Av = Av * Au; }
+    }
+    {   // rows 2 and 3 take over the total of the first half (lane 31)
+        const T Au = line_dpp<0x143, 0xC>(Av), Bu = line_dpp<0x143, 0xC>(Bv);
+        if (lane & 32) { Bv = Bv + Av * Bu; Av = Av * Au; }
+    }
+}
+
 template <typename T, int EPI, int K>
 __global__ __launch_bounds__(BLK) void gs_line_kernel(const LineArgs<T> a)
 {
@@ -168,17 +209,13 @@ __global__ __launch_bounds__(BLK) void gs_line_kernel(const LineArgs<T> a)
             if (S.nod) { Bv = xo; Av = T(0); }
             if (!active) { Bv = T(0); Av = T(0); }
             // ---- inclusive scan over the lanes: (A2, B2) o (A1, B1) = (A2 A1, B2 + A2 B1)
-#pragma unroll
-            for (int d = 1; d < 64; d *= 2) {
-                const T Au = __shfl_up(Av, d), Bu = __shfl_up(Bv, d);
-                if (lane >= d) { Bv = Bv + Av * Bu; Av = Av * Au; }
-            }
+            line_scan<T>(Av, Bv, lane);
             const T v = Bv + Av * carry;
             if (active) {
                 __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!S.nod) a.y[row] = v;
             }
-            carry = __shfl(v, S.cnt - 1);
+            carry = line_readlane(v, S.cnt - 1);
         };
         int g = g0;
         while (true) {

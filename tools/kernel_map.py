@@ -50,8 +50,12 @@ def kernel_map(dml, smoother_kind):
             if smoother_kind == "gauss_seidel":
                 alg = (vb + 4) * nnz + 4 * (n + 1) + 3 * vb * n
                 for which, dirn in ((0, "forward"), (1, "backward")):
-                    lane, tile = A.lane_info(which), A.tile_info(which)
-                    if lane["groups"] and lane["launch_grid"]:
+                    lane, tile, line = A.lane_info(which), A.tile_info(which), A.line_info(which)
+                    if line["lines"] and line["launch_grid"]:
+                        out.append({"family": "gs_line", "grid": int(line["launch_grid"]), "level": i, "op": "A", "what": f"{dirn} Gauss-Seidel sweep (fast order, line scan: {line['lines']} lines, {line['line_levels']} line levels)",
+                                    "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": int(line["chunks"] * 64 * (line["slots_per_row"] * (vb + 4) + 2 * vb + 1) + n * 4 * vb),
+                                    "format": f"chunks of 64 rows x {line['slots_per_row']} slots", "dependency_levels": int(line["line_levels"])})
+                    elif lane["groups"] and lane["launch_grid"]:
                         out.append({"family": "gs_lane", "grid": int(lane["launch_grid"]), "level": i, "op": "A", "what": f"{dirn} Gauss-Seidel sweep (fast order, {lane['lanes_per_row']} lanes per row)",
                                     "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": int(lane["entry_slots"] * (vb + 4) + n * (4 + 4 * vb)),
                                     "format": f"{lane['lanes_per_row']} lanes x {lane['slots_per_lane']} slots per row, padded", "dependency_levels": int(inf["gs_levels_fwd"])})

@@ -31,6 +31,9 @@ def short(name):
     m = re.search(r"gs_lane_kernel<(\w+), *(\d+), *(\d+), *(\d+), *(\w+)>", name)
     if m:
         return f"gs_lane<{m.group(1)},{EPI[int(m.group(2))]},L{m.group(3)},K{m.group(4)},{'oneXCD' if m.group(5) in ('true', '1') else 'chip'}>"
+    m = re.search(r"gs_line_kernel<(\w+), *(\d+), *(\d+)>", name)
+    if m:
+        return f"gs_line<{m.group(1)},{EPI[int(m.group(2))]},K{m.group(3)}>"
     name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("pamg::", "")
     return re.sub(r"\(.*", "", name)[:70]
 
@@ -41,6 +44,8 @@ def family(k):
         return "csr", (m.group(1) if m else None)
     if k.startswith("gs_lane"):
         return "gs_lane", None
+    if k.startswith("gs_line"):
+        return "gs_line", None
     if k.startswith("gs_tile"):
         return "gs_tile", None
     if k.startswith("gs_gran") or k.startswith("gs_flow"):
