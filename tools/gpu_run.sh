@@ -5,7 +5,9 @@
 #   tests[:expr]      GPU suite (optionally -k expr)            -> ${TAG}_gpu_tests.log
 #   py:<script+args>  python tools/<script> args (',' = space)  -> ${TAG}_<script>.log
 #   bench[:args]      python bench.py args (',' = space)        -> ${TAG}_bench<suffix>.json/.err
-#   prof:<workload>[:args]  rocprofv3 kernel stats of bench.py --workload W -> prof_${TAG}_<W>/
+#   prof:<workload>[:args]  rocprofv3 kernel stats of bench.py --workload W -> prof_${TAG}_<W>/  (+ per-kernel roofline table)
+#   pmc:<workload>[:args]   two more passes with --pmc FETCH_SIZE / --pmc WRITE_SIZE (kernel trace only) into the same directory
+#   smoke             __graft_entry__.smoke()
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
@@ -30,6 +32,18 @@ for step in "$@"; do
             python tools/summarize_prof.py $OUT $wl $TAG > $OUT/summarize.log 2>&1
             find $OUT -name "*.csv" -size +4M -delete
             head -12 $OUT/kernel_stats_summary.txt; head -30 $OUT/kernel_roofline.txt ;;
+        pmc)
+            wl=${rest%%:*}; extra=""; [[ "$rest" == *:* ]] && extra=${rest#*:}; extra=${extra//,/ }
+            OUT=$PWD/gpurun_out/prof_${TAG}_$wl; mkdir -p $OUT
+            for c in FETCH_SIZE WRITE_SIZE; do
+                sub=pmc_fetch; [ $c = WRITE_SIZE ] && sub=pmc_write
+                (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$sub -- python /root/repo/bench.py --workload $wl --steps 5 --warmup 1 --cpu-cycles 0 --no-extras --no-pmc --no-setup-compare $extra > $OUT/${sub}_bench.json 2> $OUT/$sub.log)
+            done
+            python tools/summarize_prof.py $OUT $wl $TAG > $OUT/summarize.log 2>&1
+            find $OUT -name "*.csv" -size +4M -delete
+            tail -30 $OUT/summarize.log ;;
+        smoke)
+            timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -4 ;;
         *) echo "unknown step $step" ;;
     esac
 done
