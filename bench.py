@@ -345,7 +345,7 @@ def main():
                 "max_rel_diff": float(rel.max()), "tolerance": "1e-10 relative, every cycle", "ok": bool(rel.max() <= 1e-10),
                 "first_last_norm": [float(c[0]), float(c[m - 1])], "cpu_s": round(tc, 1), "cpu_cycles": int(k)}
 
-    def time_to_tol(dml_, b_, x0_, tol=1e-8, maxit=120):
+    def time_to_tol(dml_, b_, x0_, tol=1e-8, maxit=400):
         """multilevel.py:558-580 with the reference's stopping rule ||b - A x|| < tol * ||b||: the number of cycles it takes
         from x0 and the wall time of exactly those cycles (each followed by its convergence-check norm) on the resident state"""
         xd_, bd_ = capi.DeviceArray.from_host(x0_), capi.DeviceArray.from_host(b_)

@@ -278,20 +278,26 @@ def test_midsize_symmetric_gs_against_the_live_reference():
     b = np.zeros(A.shape[0])
     r_ref = []
     x_ref = ml.solve(b, x0=x0, tol=1e-30, maxiter=10, residuals=r_ref)
-    outs = []
-    for graph in (True, False):
-        dml = DeviceMultilevelSolver(ml, graph=graph)
-        if graph:
-            plans = [dA.tile_info(0)["tiles"] for dA in dml.A[:-1]]
-        r_gpu = []
-        outs.append(dml.solve(b, x0=x0, tol=1e-30, maxiter=10, residuals=r_gpu))
-        dml.free()
-        r_ref_a, r_gpu_a = np.array(r_ref), np.array(r_gpu)
-        assert len(r_gpu_a) == len(r_ref_a) == 11
-        assert np.max(np.abs(r_gpu_a - r_ref_a) / r_ref_a) <= 1e-10
-        assert np.linalg.norm(outs[-1] - x_ref) <= 1e-12 * np.linalg.norm(x_ref)
-    assert np.array_equal(outs[0], outs[1])
-    assert plans[0] > 1                               # the fine level runs the tiled sweep
+    for order in ("fast", "exact"):
+        outs = []
+        for graph in (True, False):
+            dml = DeviceMultilevelSolver(ml, graph=graph, order=order)
+            r_gpu = []
+            outs.append(dml.solve(b, x0=x0, tol=1e-30, maxiter=10, residuals=r_gpu))
+            if graph:
+                tiles = [dA.tile_info(0)["tiles"] for dA in dml.A[:-1]]
+                lines = [dA.line_info(0)["lines"] for dA in dml.A[:-1]]
+                lanes = [dA.lane_info(0)["groups"] for dA in dml.A[:-1]]
+            dml.free()
+            r_ref_a, r_gpu_a = np.array(r_ref), np.array(r_gpu)
+            assert len(r_gpu_a) == len(r_ref_a) == 11
+            assert np.max(np.abs(r_gpu_a - r_ref_a) / r_ref_a) <= 1e-10, order
+            assert np.linalg.norm(outs[-1] - x_ref) <= 1e-12 * np.linalg.norm(x_ref), order
+        assert np.array_equal(outs[0], outs[1]), order
+        if order == "exact":
+            assert tiles[0] > 1 and not any(lines) and not any(lanes)     # the fine level runs the tiled sweep
+        else:
+            assert lines[0] == 96 * 96 and lanes[1] > 0                   # fine level: one line per grid line; SA level 1: lane form
 
 
 @pytest.mark.parametrize("case", ["poisson3d_128", "poisson2d_2000"])
