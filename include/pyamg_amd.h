@@ -348,8 +348,7 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * else 4|8|16|32|64), 26 = its persistent workgroups (0 = automatic), 27 = 1: the fast order also takes wide schedules
  * (>= 2048 rows per dependency level), which the tiled exact sweep keeps by default, 28 = flags of the fast order (bit 0, default
  * on: a wave that runs ahead of the sweep polls ONE gate operand instead of all its operands until the sweep is one
- * dependency level away), 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled, 31 = line-walk form (default 1)
- * where such runs exist but the rows carry more than 8 other entries.
+ * dependency level away), 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled.
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes
@@ -384,12 +383,6 @@ int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8]);
  * chunks, one wave each), levels of the line graph, entries that wait for a new value, workgroups of the last launch, lines of
  * the widest level, bytes}; all zero when that schedule has no line layout. */
 int pamg_matrix_line_info(pamg_matrix_t A, int which, int64_t info[8]);
-/* Layout of the line-walk fast-order sweep (tune keys 24 / 31: a wave walks a run of consecutively visited rows each coupled to
- * its predecessor and keeps the running value in a register; operators numbered along lines whose rows carry too many entries
- * for the scan form -- SA coarse operators on grids) for schedule `which`: {entry slots per lane, rows, lines, levels of the
- * line graph, rows that take their predecessor's value from a register, workgroups of the last launch, lines of the widest
- * level, bytes}; all zero when that schedule has no such layout. */
-int pamg_matrix_walk_info(pamg_matrix_t A, int which, int64_t info[8]);
 int pamg_matrix_lane_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count);
 /* Row-subset copy of a CSR operator (rows: HOST list, kept in list order) for the indexed smoothers,
  * and amg_core::jacobi_indexed (relaxation.h:382-427) on it: every listed row of x is relaxed from the

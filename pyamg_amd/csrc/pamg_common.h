@@ -118,8 +118,6 @@ struct GsSchedule {
     bool tile_unfit = false;         // the tile planner declined this schedule (a step would not fit): other schedulers run it
     struct LineSched *line = nullptr; // line-scan fast-order sweep for banded operators in their natural order (pamg_line_plan.h / pamg_line.hip)
     bool line_unfit = false;         // the line planner declined this schedule (no runs of coupled consecutive rows / rows too long)
-    struct WalkSched *walk = nullptr; // line-walk form of the fast order (pamg_walk_plan.h / pamg_walk.hip): a wave walks a run of coupled rows
-    bool walk_unfit = false;         // the walk planner declined this schedule (no lines to speak of / rows too long)
     struct LaneSched *lane = nullptr; // lane-parallel "fast order" sweep (pamg_lane_plan.h / pamg_lane.hip), built on demand
     bool lane_unfit = false;         // the lane planner declined this schedule (rows too long / padding too wasteful)
 };
@@ -208,7 +206,6 @@ struct pamg_matrix_s {
     int lane_flags = 1;              // fast order: bit 0 = gate operand (a wave that runs ahead polls one value instead of all its operands), bit 1 = slab form
                                      //   (one slab of the visit order per XCD, same-slab operands through the XCD's L2) for big operators   (tune key 28)
     int lane_chunk = 2048;           // slab form: visited rows per chunk dealt out to the slabs in turn (0 = eight contiguous slabs)   (tune key 29)
-    int line_walk = 1;               // fast order: line-walk sweep where runs of coupled rows exist and the scan form does not apply (tune key 31)
     int line_scan = 1;               // fast order: line-scan sweep where consecutive rows are coupled (grid stencils), tried before the lane form   (tune key 30)
     int lane_wide = 0;               // fast order on wide schedules (>= 2048 rows per dependency level): 0 = the tiled exact sweep keeps them, 1 = lane form   (tune key 27)
     int gs_cap = 0;                  // entries per row range of the level schedules (tune key 20; 0 = automatic: `cap`, 512 on the multi-XCD granular sweep of SA-like rows)
@@ -275,13 +272,6 @@ void free_line_part(LineSched *t);
 size_t line_part_bytes(const GsSchedule *g);
 int line_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s);
 int line_info(const GsSchedule *g, int64_t *info);
-// pamg_walk.hip: the line-walk fast-order sweep (rows numbered along lines: SA coarse operators on grids)
-bool walk_eligible(const pamg_matrix_s *A, const GsSchedule *g);
-int build_walk_part(pamg_matrix_s *A, GsSchedule *g);
-void free_walk_part(WalkSched *t);
-size_t walk_part_bytes(const GsSchedule *g);
-int walk_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s);
-int walk_info(const GsSchedule *g, int64_t *info);
 // pamg_lane.hip: the lane-parallel fast-order sweep
 bool lane_eligible(const pamg_matrix_s *A, const GsSchedule *g);
 int build_lane_part(pamg_matrix_s *A, GsSchedule *g);

@@ -361,7 +361,6 @@ void free_schedule(GsSchedule *g)
     free_tile_part(g->tile);
     free_lane_part(g->lane);
     free_line_part(g->line);
-    free_walk_part(g->walk);
     hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_xold); hipFree(g->d_pblk); hipFree(g->d_dpos); hipFree(g->d_prof);
     delete g;
 }
@@ -1105,36 +1104,16 @@ static bool want_lines(const pamg_matrix_s *A, const GsSchedule *g)
     return A->gs_order == 1 && A->gs_mode == 0 && A->line_scan && line_eligible(A, g);
 }
 
-// ... and where the rows are numbered along lines but carry too many entries for the scan form (SA coarse operators on grids): the line walk
-static bool want_walks(const pamg_matrix_s *A, const GsSchedule *g)
-{
-    return A->gs_order == 1 && A->gs_mode == 0 && A->line_walk && walk_eligible(A, g) && !(A->line_scan && line_eligible(A, g));
-}
-
 // device copies the scheduler of choice needs (called before any graph capture through ensure_schedule)
 static int ensure_parts(pamg_matrix_s *A, GsSchedule *g)
 {
     if (A->R > 1) return PAMG_OK;
-    if (want_walks(A, g)) {
-        const size_t before = g->bytes;
-        const int st = build_walk_part(A, g);
-        if (st == PAMG_OK) { std::lock_guard<std::mutex> lk(g_sched_mu); A->bytes += g->bytes - before; }
-        if (st != PAMG_E_ARG) return st;
-        g->walk_unfit = true;
-    }
     if (want_lines(A, g)) {
         const size_t before = g->bytes;
         const int st = build_line_part(A, g);
         if (st == PAMG_OK) { std::lock_guard<std::mutex> lk(g_sched_mu); A->bytes += g->bytes - before; }
         if (st != PAMG_E_ARG) return st;
         g->line_unfit = true;                              // no coupled runs / rows too long: the other schedulers take it
-        if (want_walks(A, g)) {
-            const size_t before2 = g->bytes;
-            const int st2 = build_walk_part(A, g);
-            if (st2 == PAMG_OK) { std::lock_guard<std::mutex> lk(g_sched_mu); A->bytes += g->bytes - before2; }
-            if (st2 != PAMG_E_ARG) return st2;
-            g->walk_unfit = true;
-        }
     }
     if (want_lanes(A, g)) {
         const size_t before = g->bytes;
@@ -1157,7 +1136,6 @@ static int gs_sweep_scalar_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, 
 {
     PAMG_TRY(ensure_parts(A, g));
     if (want_lines(A, g)) return line_launch(A, g, epi, x, b, omega, s);
-    if (want_walks(A, g)) return walk_launch(A, g, epi, x, b, omega, s);
     if (want_lanes(A, g)) return lane_launch(A, g, epi, x, b, omega, s);
     if (want_tiles(A, g)) return tile_launch<T>(A, g, epi, x, b, omega, s);
     StreamArgs<T> a = base_args<T>(A, x, b, x, 0.0, omega, nullptr);
@@ -1969,7 +1947,6 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 27: if (value < 0 || value > 1) return PAMG_E_ARG; A->lane_wide = value; return PAMG_OK;
         case 29: if (value < 0) return PAMG_E_ARG; A->lane_chunk = value; key = 25; break;
         case 30: if (value < 0 || value > 1) return PAMG_E_ARG; A->line_scan = value; return PAMG_OK;
-        case 31: if (value < 0 || value > 1) return PAMG_E_ARG; A->line_walk = value; return PAMG_OK;
         case 28: if (value < 0 || value > 15) return PAMG_E_ARG; { const bool relayout = ((A->lane_flags ^ value) & 2) != 0; A->lane_flags = value; if (!relayout) return PAMG_OK; } key = 25; break;
         default: return PAMG_E_ARG;
     }
@@ -1979,7 +1956,6 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
             if (g) g->lane_unfit = false;
             if (g && g->lane) { const size_t lb = lane_part_bytes(g); A->bytes -= lb; g->bytes -= lb; free_lane_part(g->lane); g->lane = nullptr; }
             if (g) g->line_unfit = false;
-            if (g) g->walk_unfit = false;
         }
         return PAMG_OK;
     }
@@ -2062,12 +2038,6 @@ int pamg_matrix_gs_profile(pamg_matrix_t A, int which, long long *out, int64_t c
     for (int l = 0; l < g->nlevels; ++l)
         for (int q = g->level_blk[l]; q < g->level_blk[l + 1]; ++q) out[(size_t)q * 8 + 7] = l;
     return PAMG_OK;
-}
-
-int pamg_matrix_walk_info(pamg_matrix_t A, int which, int64_t info[8])
-{
-    if (!A || which < 0 || which > 3 || !info) return PAMG_E_ARG;
-    return pamg::walk_info(A->gs[which], info);
 }
 
 int pamg_matrix_line_info(pamg_matrix_t A, int which, int64_t info[8])

@@ -131,12 +131,6 @@ class DeviceMatrix:
         capi.check(capi.lib().pamg_matrix_line_info(self.handle, which, a), "pamg_matrix_line_info")
         return dict(zip(("slots_per_row", "chunks", "lines", "line_levels", "early_entries", "launch_grid", "widest_level_lines", "bytes"), list(a)))
 
-    def walk_info(self, which=0):
-        """layout of the line-walk fast-order sweep (schedule 0 = forward, 1 = backward): dict, all zero if none is built"""
-        a = (C.c_int64 * 8)()
-        capi.check(capi.lib().pamg_matrix_walk_info(self.handle, which, a), "pamg_matrix_walk_info")
-        return dict(zip(("slots_per_lane", "rows", "lines", "line_levels", "forwarded_rows", "launch_grid", "widest_level_lines", "bytes"), list(a)))
-
     def lane_profile(self, which=0):
         """time stamps of the lane sweep (tune(gs_prof=1)): int64 array [groups, 4]"""
         n = C.c_int64(0)
@@ -149,14 +143,14 @@ class DeviceMatrix:
 
     def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, xwin=None, gs_prof=None,
              tile_G=None, tile_W=None, tile_cap=None, tile_default=None, tile_D=None, tile_Q=None, tile_part=None, idx16=None, gs_cap=None, val8=None, rowgather=None, rowpat=None,
-             gs_order=None, lane_L=None, lane_G=None, lane_wide=None, lane_flags=None, lane_chunk=None, line_scan=None, line_walk=None):
+             gs_order=None, lane_L=None, lane_G=None, lane_wide=None, lane_flags=None, lane_chunk=None, line_scan=None):
         """Speed-only knobs (every setting computes the same bits) -- except gs_order: 0 = order-exact row sums (the reference's
         bits), 1 = fast order (lane-parallel row sums, same sweep order, agrees to rounding).  Refused (PAMG_E_STATE) once a solver holds the
         operator: captured graphs point into the plans these calls rebuild."""
         lib = capi.lib()
         for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (9, xwin), (11, gs_prof),
                        (12, tile_G), (13, tile_W), (14, tile_cap), (15, tile_default), (16, tile_D), (17, tile_Q), (18, tile_part), (19, idx16), (20, gs_cap), (21, val8), (22, rowgather), (23, rowpat),
-                       (24, gs_order), (25, lane_L), (26, lane_G), (27, lane_wide), (28, lane_flags), (29, lane_chunk), (30, line_scan), (31, line_walk)):
+                       (24, gs_order), (25, lane_L), (26, lane_G), (27, lane_wide), (28, lane_flags), (29, lane_chunk), (30, line_scan)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 

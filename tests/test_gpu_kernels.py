@@ -397,47 +397,6 @@ def test_gs_fast_order_agrees_to_rounding():
         assert np.array_equal(dx.download(), ref)                       # and back
 
 
-def test_gs_fast_order_line_walk():
-    """Line-walk form of the fast order (pamg_walk.hip): an operator numbered along lines whose rows carry ~27 entries (the shape
-    of SA coarse operators on grids): a wave walks a whole line, the predecessor's new value stays in a register.  Against
-    the oracle's sequential sweep (relaxation.h:48-76,116-145) to 1e-13, forward / backward / symmetric, SOR, a few waves and
-    many, with zero diagonals; and against the lane form on the same operator."""
-    from oracle import oracle as orc
-    rng = np.random.RandomState(21)
-    nx, ny, nz = 64, 40, 30
-    T = lambda m: sp.diags_array([np.ones(m - 1), np.ones(m), np.ones(m - 1)], offsets=[-1, 0, 1])
-    Pm = sp.csr_array(sp.kron(T(nz), sp.kron(T(ny), T(nx))))
-    Pm.sort_indices()
-    R = sp.csr_array((-rng.rand(Pm.nnz), Pm.indices, Pm.indptr), shape=Pm.shape)
-    S = sp.csr_array(R + R.T)
-    S.setdiag(0)
-    S.eliminate_zeros()
-    d = np.asarray(abs(S).sum(axis=1)).ravel() + 1.0
-    d[::97] = 0.0                                                       # zero diagonals: rows left untouched, still forwarded / published
-    A = sp.csr_array(S + sp.diags_array(d))
-    A.sort_indices()
-    op = sparse_op(A)
-    n = op.shape[0]
-    x = rng.rand(n); b = rng.rand(n)
-    ref = x.copy(); orc.relax_gauss_seidel(op, ref, b, 2, "symmetric")
-    refs = x.copy(); orc.relax_sor(op, refs, b, 1.3, 1, "backward")
-    dA = DeviceMatrix(op)
-    db = capi.DeviceArray.from_host(b)
-    dx = capi.DeviceArray.from_host(x)
-    for kw, walk in ((dict(gs_order=1), True), (dict(lane_G=3), True), (dict(lane_G=0, line_walk=0), False), (dict(line_walk=1), True)):
-        dA.tune(**kw)
-        dx.upload(x)
-        dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
-        got = dx.download()
-        wi, li = dA.walk_info(0), dA.lane_info(0)
-        assert (wi["lines"] == ny * nz and wi["forwarded_rows"] == n - ny * nz) if walk else li["groups"] > 0, (kw, wi, li)
-        assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref)), (kw, np.max(np.abs(got - ref)))
-        dx.upload(x)
-        dA.gauss_seidel(dx, db, sweep="backward", omega=1.3)
-        assert np.max(np.abs(dx.download() - refs)) <= 1e-13 * np.max(np.abs(refs)), kw
-        assert not dA.flow_error(), kw
-
-
 def test_resid_sumsq_two_stage_reduction():
     from tools.problems import poisson_csr
     A = poisson_csr((400, 400))

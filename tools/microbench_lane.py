@@ -134,11 +134,6 @@ def variants_for(li, n):
             v.append((f"lines_G{G}", dict(lane_G=G)))
         for G in (256, 1024):
             v.append((f"lines_nogate_G{G}", dict(lane_G=G, lane_flags=0)))
-    if a.exp == "w":                       # line-walk form on the SA levels
-        v.append(("lane_form", dict(gs_order=1, line_walk=0, lane_G=0, lane_flags=1)))
-        v.append(("walk_auto", dict(line_walk=1, lane_G=0)))
-        for G in (64, 128, 256, 384, 512):
-            v.append((f"walk_G{G}", dict(lane_G=G)))
     return v
 
 
@@ -167,8 +162,7 @@ for li in a.levels:
             inf = dA.info()
             li_ = dA.lane_info(0)
             ln_ = dA.line_info(0)
-            wk_ = dA.walk_info(0)
-            rec = {"level": li, "n": n, "variant": name, "fwd_ms": round(ms, 4), "max_rel_diff_vs_exact": diff, "timeout": err, "line": ln_ if ln_["lines"] else None, "walk": wk_ if wk_["lines"] else None,
+            rec = {"level": li, "n": n, "variant": name, "fwd_ms": round(ms, 4), "max_rel_diff_vs_exact": diff, "timeout": err, "line": ln_ if ln_["lines"] else None,
                    "levels": inf["gs_levels_fwd"], "us_per_level": round(1e3 * ms / max(inf["gs_levels_fwd"], 1), 3),
                    "lane": {k: li_[k] for k in ("lanes_per_row", "slots_per_lane", "groups", "widest_level_groups", "launch_grid")} if name != "exact_default" else None}
             if name in ("fast_auto", "fast_slabs_auto"):
