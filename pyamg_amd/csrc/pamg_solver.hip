@@ -439,11 +439,13 @@ int build_tail(pamg_solver_s *S)
     const char *e = getenv("PAMG_TAIL");
     if (!e || *e != '1') return PAMG_OK;
     const int nlev = (int)S->levels.size();
-    if (nlev < 2 || S->coarse_relax || S->coarse_host || S->n_c > TAIL_MAX_ROWS) return PAMG_OK;
+    int64_t max_rows = TAIL_MAX_ROWS;
+    if (const char *r = getenv("PAMG_TAIL_ROWS")) max_rows = std::max<int64_t>(1, std::min<int64_t>(TAIL_MAX_ROWS, atoll(r)));
+    if (nlev < 2 || S->coarse_relax || S->coarse_host || S->n_c > max_rows) return PAMG_OK;
     int from = nlev - 1;                                           // the coarsest level always qualifies here
     for (int l = nlev - 2; l >= 1; --l) {                          // never level 0: the cycle's entry point stays a normal launch sequence
         const Level &L = S->levels[l];
-        const bool small = L.n <= TAIL_MAX_ROWS && L.A->R == 1 && L.A->C == 1 && L.P->R == 1 && L.P->C == 1 && L.R->R == 1 && L.R->C == 1;
+        const bool small = L.n <= max_rows && L.A->R == 1 && L.A->C == 1 && L.P->R == 1 && L.P->C == 1 && L.R->R == 1 && L.R->C == 1;
         if (!small || !tail_smoother_ok(L, L.pre) || !tail_smoother_ok(L, L.post)) break;
         from = l;
     }
