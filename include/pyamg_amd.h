@@ -335,9 +335,15 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * 22 = row-gather form of the whole-operator kernels on operators with value codes (default 1 there): lane = row, the j-th
  * entries of 64 consecutive rows in one gather instruction (coalesced on stencils), products summed in storage order in
  * registers; 0 = the LDS-staged kernel on the codes;
- * 23 = row-pattern form where plan_rowpat found a table (see pamg_matrix_row_patterns): 1 (default) one row per lane, 2 two
- * consecutive rows per lane -- b, y, the result and every even-offset gather move as 16-byte accesses; measured 28 % slower on the
- * 256^3 stencil (profiles/r04_microbench_rowpat_two_rows_per_lane_slower.json) --, 0 off.
+ * 23 = row-pattern form where plan_rowpat found a table (see pamg_matrix_row_patterns): 1 (default) the fastest form the rows
+ * allow -- the row-MASK kernels when every list is the longest list with entries left out (a constant-coefficient stencil: one
+ * mask byte per row, offsets and values are launch constants, no table, no prologue; on a 7-point lattice whose extents fit
+ * 64 x 4 x kz tiles the lattice form csr_rowmask3d_kernel), else the table kernel --, 3 the table kernel (one row per lane)
+ * always, 4 the linear row-mask kernel instead of the lattice form, 2 the table kernel with two consecutive rows per lane
+ * (measured 28 % slower, profiles/r04_microbench_rowpat_two_rows_per_lane_slower.json), 0 off;
+ * 31 = planes per lane of the lattice form (2 | 4 | 8, default 8); 32 = flags of the row-mask kernels (default 3): bit 0 the
+ * streams touched once (mask, b, result) are nontemporal, bit 1 plane-by-plane XCD order (XCD j takes the j-th eighth of
+ * every plane), bit 2 XCD-contiguous eighths of the rows instead, bit 3 offsets +-1 by whole-wave DPP shifts (linear form).
  * NOT speed-only -- 24 = ORDER of the row sums of the scalar Gauss-Seidel / SOR sweeps: 0 (default of a bare operator) =
  * order-exact, every sum runs in storage order with an IEEE division, results are the reference's bit for bit
  * (amg_core/relaxation.h:48-76,116-145,185-266); 1 = FAST order: the same sweep order over the rows (same dependency

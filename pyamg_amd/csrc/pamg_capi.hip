@@ -513,6 +513,7 @@ const char *pamg_status_string(int st)
 }
 
 // ---- measured bandwidth ceiling of this device (bench.py reports it beside the 8 TB/s datasheet peak)
+extern "C++" {
 namespace {
 __global__ __launch_bounds__(256) void bw_copy_kernel(const double2 *__restrict__ a, double2 *__restrict__ c, int64_t n2)
 {
@@ -528,11 +529,70 @@ __global__ __launch_bounds__(256) void bw_triad_kernel(const double2 *__restrict
         c[i] = r;
     }
 }
+// variants of the copy (which access shape gets closest to the HBM on this part): U 16-byte accesses per lane, one block-contiguous
+// piece per workgroup, no loop; NT = nontemporal loads and stores
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void bw_copy_block_kernel(const double2 *__restrict__ a, double2 *__restrict__ c, int64_t n2)
+{
+    const int64_t base = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (int64_t)u * 256;
+        if (i < n2) {
+            if (NT) { v[u].x = __builtin_nontemporal_load(&a[i].x); v[u].y = __builtin_nontemporal_load(&a[i].y); }
+            else v[u] = a[i];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (int64_t)u * 256;
+        if (i < n2) {
+            if (NT) { __builtin_nontemporal_store(v[u].x, &c[i].x); __builtin_nontemporal_store(v[u].y, &c[i].y); }
+            else c[i] = v[u];
+        }
+    }
+}
+template <bool NT>
+__global__ __launch_bounds__(256) void bw_copy8_kernel(const double *__restrict__ a, double *__restrict__ c, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), c + i);
+        else c[i] = a[i];
+    }
+}
+template <int U>
+__global__ __launch_bounds__(256) void bw_read_kernel(const double2 *__restrict__ a, double *__restrict__ c, int64_t n2)
+{
+    const int64_t base = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (int64_t)u * 256;
+        if (i < n2) { const double2 v = a[i]; s += v.x + v.y; }
+    }
+    if (s == 1.2345e300) c[0] = s;                                  // never true for the zero-filled probe vectors; keeps the loads
+}
+template <int U>
+__global__ __launch_bounds__(256) void bw_write_kernel(double2 *__restrict__ c, int64_t n2)
+{
+    const int64_t base = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = base + (int64_t)u * 256;
+        if (i < n2) c[i] = double2{0.0, 0.0};
+    }
+}
 }  // namespace
+}  // extern "C++"
 
+// kind 0 copy (grid-stride), 1 triad, 2 copy 1 x 16 B per lane, 3 copy 4 x 16 B, 4 copy 4 x 16 B nontemporal, 5 copy 8 x 16 B,
+// 6 read only (4 x 16 B), 7 write only (4 x 16 B), 8 hipMemcpyAsync device to device, 9 copy 1 x 8 B per lane, 10 the same nontemporal,
+// 11 copy 1 x 16 B nontemporal
 int pamg_bandwidth_probe(int kind, int64_t n, int reps, double *gbps)
 {
-    if ((kind != 0 && kind != 1) || n < 1024 || reps < 1 || !gbps) return PAMG_E_ARG;
+    if (kind < 0 || kind > 11 || n < 1024 || reps < 1 || !gbps) return PAMG_E_ARG;
     n &= ~(int64_t)1;
     double *a = nullptr, *b = nullptr, *c = nullptr;
     PAMG_HIP(hipMalloc((void **)&a, (size_t)n * 8));
@@ -543,9 +603,22 @@ int pamg_bandwidth_probe(int kind, int64_t n, int reps, double *gbps)
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int64_t n2 = n / 2;
     const int grid = (int)std::min<int64_t>((n2 + 255) / 256, 256 * 64);
+    auto blocks = [&](int U) { return dim3((unsigned)((n2 + 256 * U - 1) / (256 * U))); };
     auto run = [&]() {
-        if (kind == 0) hipLaunchKernelGGL(bw_copy_kernel, dim3(grid), dim3(256), 0, 0, (const double2 *)a, (double2 *)c, n2);
-        else hipLaunchKernelGGL(bw_triad_kernel, dim3(grid), dim3(256), 0, 0, (const double2 *)a, (const double2 *)b, (double2 *)c, 0.5, n2);
+        switch (kind) {
+            case 0: hipLaunchKernelGGL(bw_copy_kernel, dim3(grid), dim3(256), 0, 0, (const double2 *)a, (double2 *)c, n2); break;
+            case 1: hipLaunchKernelGGL(bw_triad_kernel, dim3(grid), dim3(256), 0, 0, (const double2 *)a, (const double2 *)b, (double2 *)c, 0.5, n2); break;
+            case 2: hipLaunchKernelGGL((bw_copy_block_kernel<1, false>), blocks(1), dim3(256), 0, 0, (const double2 *)a, (double2 *)c, n2); break;
+            case 3: hipLaunchKernelGGL((bw_copy_block_kernel<4, false>), blocks(4), dim3(256), 0, 0, (const double2 *)a, (double2 *)c, n2); break;
+            case 4: hipLaunchKernelGGL((bw_copy_block_kernel<4, true>), blocks(4), dim3(256), 0, 0, (const double2 *)a, (double2 *)c, n2); break;
+            case 5: hipLaunchKernelGGL((bw_copy_block_kernel<8, false>), blocks(8), dim3(256), 0, 0, (const double2 *)a, (double2 *)c, n2); break;
+            case 6: hipLaunchKernelGGL((bw_read_kernel<4>), blocks(4), dim3(256), 0, 0, (const double2 *)a, c, n2); break;
+            case 7: hipLaunchKernelGGL((bw_write_kernel<4>), blocks(4), dim3(256), 0, 0, (double2 *)c, n2); break;
+            case 9: hipLaunchKernelGGL((bw_copy8_kernel<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const double *)a, c, n); break;
+            case 10: hipLaunchKernelGGL((bw_copy8_kernel<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const double *)a, c, n); break;
+            case 11: hipLaunchKernelGGL((bw_copy_block_kernel<1, true>), blocks(1), dim3(256), 0, 0, (const double2 *)a, (double2 *)c, n2); break;
+            default: hipMemcpyAsync(c, a, (size_t)n * 8, hipMemcpyDeviceToDevice, 0); break;
+        }
     };
     for (int i = 0; i < 3; ++i) run();
     hipEventRecord(e0, 0);
@@ -558,7 +631,7 @@ int pamg_bandwidth_probe(int kind, int64_t n, int reps, double *gbps)
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(a); hipFree(b); hipFree(c);
     if (err != hipSuccess) return (int)err;
-    const double bytes = (kind == 0 ? 16.0 : 24.0) * (double)n * reps;
+    const double bytes = (kind == 1 ? 24.0 : (kind == 6 || kind == 7) ? 8.0 : 16.0) * (double)n * reps;
     *gbps = ms > 0.f ? bytes / ((double)ms * 1e6) : 0.0;
     return PAMG_OK;
 }

@@ -182,6 +182,12 @@ struct pamg_matrix_s {
     unsigned char *d_pid = nullptr;  // row patterns (plan_rowpat): list number per row, 255 = walk the row through the code arrays
     void *d_ptab = nullptr;          //   [256] lengths | [npat * pat_lmax] column offsets | [npat * pat_lmax] values
     int npat = 0, pat_lmax = 0;
+    unsigned char *d_pmask = nullptr;  // row masks (plan_row_masks): which entries of the longest list a row has, 0 = walk the CSR arrays
+    int rm_nu = 0, rm_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};   //   the longest list: entries, column offsets,
+    unsigned long long rm_val[8] = {0, 0, 0, 0, 0, 0, 0, 0};   //   values (bit patterns, low 32 bits for float)
+    long long rm_walked = 0;
+    int rowmask_kz = 8;              // planes per lane of csr_rowmask3d_kernel (2, 4, 8)
+    int rowmask_flags = 3;           // row-mask kernels: bit 0 nontemporal b / mask / result, bit 1 plane-by-plane XCD order, bit 2 XCD-contiguous eighths, bit 3 +-1 by DPP
     int use_rowpat = 1;              // tune key 23: 0 off, 1 one row per lane (default), 2 two consecutive rows per lane (16-byte accesses; measured slower)
     int cap_from_val8 = 0;           // cap was raised to 2048 because the operator streams value codes (level schedules keep 1536)
     int use_xwin = 0;                // LDS-staged x windows for the whole-operator kernels (tune key 9)

@@ -14,6 +14,7 @@
 // because LDS bandwidth is an order of magnitude above the HBM stream that bounds us.
 #pragma once
 #include "pamg_common.h"
+#include "pamg_rowmask_map.h"
 
 namespace pamg {
 
@@ -959,6 +960,195 @@ struct FlowArgs {
     int nlevels;
     unsigned *sync;           // [1] error flag
 };
+
+// ---- row-mask form (round 4; host plan: plan_row_masks, pamg_stream_plan.h).  When every list of the row-pattern table is
+// the LONGEST list with some entries left out (a constant-coefficient stencil: the boundary rows drop neighbours, offsets and
+// values of the ones that stay are the interior row's), a row is described by one byte: bit k = "entry k of the longest list is
+// present".  Offsets and values are launch constants (scalar registers), so nothing waits for a table: lane l takes row
+// blockIdx * BLK + l, no loop, no workgroup prologue, no barrier, and issues its mask byte, b and ALL gathers
+// x[row + offset_k] at once (absent entries gather a clamped address and are left out of the sum) -- the access shape of the
+// plain copy that reaches the HBM ceiling (bw_copy_block_kernel<1>).  Products are added in the list's (= the row's storage)
+// order: bit-identical to every other form.  Rows with mask 0 (not a sub-list: irregular rows of the pattern plan) walk
+// the operator's CSR arrays.
+template <typename T>
+struct RowMaskArgs {
+    const unsigned char *mask;   // [nrows]
+    int off[8];
+    T val[8];
+    int nrows, ncols;
+    int xcd_chunk;               // > 0: workgroup b works on rows of chunk (b & 7), so every XCD streams one contiguous eighth
+    int xcd_share;               // > 0: workgroups per plane and XCD (plane-by-plane order, see the kernel)
+};
+
+// VAR bit 0: the streams that are touched once (mask, b, the result) bypass the caches' retention (nontemporal), so x stays;
+// bit 1: offsets -1 / +1 are not gathered: lane l's x[row - 1] is lane l - 1's x[row] (whole-wave DPP shift), only lanes 0 and 63
+// load theirs.  Needs offsets -1, 0, +1 in slots NU / 2 - 1, NU / 2, NU / 2 + 1 (the host checks).
+template <int CTRL, typename T>
+__device__ __forceinline__ T rowmask_wave_shift(T v, T edge)
+{
+    if constexpr (sizeof(T) == 8) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(__double2loint(edge), lo, CTRL, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), hi, CTRL, 0xF, 0xF, false);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), CTRL, 0xF, 0xF, false));
+    }
+}
+
+template <typename T, int EPI, int NU, int VAR>
+__global__ __launch_bounds__(BLK) void csr_rowmask_kernel(const StreamArgs<T> a, const RowMaskArgs<T> m)
+{
+    constexpr bool SKIPD = EpiTraits<EPI>::need_cols;          // Jacobi family: the diagonal never enters the sum
+    constexpr bool NT = (VAR & 1) != 0, DPPX = (VAR & 2) != 0;
+    // workgroups go to the XCDs round robin; share > 0: XCD j = blockIdx & 7 takes the j-th eighth of EVERY plane (plane = the
+    // largest offset), planes in order -- the chip works on one plane at a time (one compact window of the HBM) and a row's
+    // neighbours one plane up and down were, or will be, gathered through the same XCD's L2
+    const int blk = rowmask_linear_block((int)blockIdx.x, m.xcd_chunk, m.xcd_share);
+    const int r = blk * BLK + (int)threadIdx.x;
+    const int rc = r < m.nrows ? r : m.nrows - 1;
+    const unsigned mk = NT ? __builtin_nontemporal_load(m.mask + rc) : m.mask[rc];
+    RowPre<T> q;
+    if constexpr (NT) {
+        q.lo = q.hi = 0;
+        q.row = rc;
+        q.pos = rc;
+        q.b = q.y = q.xo = q.d = T(0);
+        if constexpr (EPI >= EPI_JACOBI) q.d = __builtin_nontemporal_load(a.diag + rc);
+        if constexpr (EPI == EPI_RESID || EPI == EPI_AXPBY || EPI == EPI_ACC_AXPBY || EPI >= EPI_JACOBI) q.b = __builtin_nontemporal_load(a.b + rc);
+        if constexpr (EPI == EPI_ACC || EPI == EPI_ACC_AXPBY || EPI == EPI_ACCSEQ) q.y = __builtin_nontemporal_load(a.y + rc);
+        if constexpr (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B) q.xo = a.x[rc];
+    } else {
+        q = row_prefetch_noptr<T, EPI>(a, rc);
+    }
+    T xv[NU];
+    constexpr int near = NU / 2;                                  // DPPX: the host checked that slots near - 1, near, near + 1 hold offsets -1, 0, +1
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        if (DPPX && (k == near - 1 || k == near + 1)) continue;
+        int c = rc + m.off[k];
+        c = c < 0 ? 0 : c;
+        c = c < m.ncols ? c : m.ncols - 1;
+        xv[k] = a.x[c];
+    }
+    if constexpr (DPPX) {
+        const int lane = (int)(threadIdx.x & 63);
+        T em = T(0), ep = T(0);
+        if (lane == 0) em = a.x[rc > 0 ? rc - 1 : 0];
+        if (lane == 63) ep = a.x[rc + 1 < m.ncols ? rc + 1 : m.ncols - 1];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            if (k == near - 1) xv[k] = rowmask_wave_shift<0x138>(xv[k + 1], em);       // wave_shr:1 -- lane l takes lane l - 1's value, lane 0 keeps `em`
+            if (k == near + 1) xv[k] = rowmask_wave_shift<0x130>(xv[k - 1], ep);       // wave_shl:1
+        }
+    }
+    if (r >= m.nrows) return;
+    T s = row_init<T, EPI>(q);
+    double sq = 0.0;
+    // unconditional (mask 0 adds nothing), so that the gathers above do not sink behind a test of the mask byte
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        if (((mk >> k) & 1u) && (!SKIPD || m.off[k] != 0)) {
+            const T pr = m.val[k] * xv[k];
+            if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
+            else s += pr;
+        }
+    }
+    if (!mk) {
+        const int lo = a.Ap[r], hi = a.Ap[r + 1];
+        for (int p = lo; p < hi; ++p) {
+            const int col = a.Aj[p];
+            if (!SKIPD || col != r) {
+                const T pr = a.Ax[p] * a.x[col];
+                if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
+                else s += pr;
+            }
+        }
+    }
+    if constexpr (NT && EPI == EPI_RESID) __builtin_nontemporal_store(q.b - s, a.y + r);
+    else row_finish<T, EPI, 0>(a, q, s, sq);
+}
+
+// ---- row-mask form on a lattice (round 4).  csr_rowmask_kernel asks the L2 for five 128-byte lines of x per 16 rows (the row's
+// own line and its neighbours' one lattice line and one plane up and down); the counters say it is bound by the misses a
+// CU's L1 can keep in flight, not by bytes.  When the longest list is (-P, -L, -1, 0, +1, +L, +P) -- the 7-point
+// stencil of an nx x ny x nz lattice, L = nx, P = nx ny -- a workgroup takes a tile of 64 x 4 x KZ rows instead of 256
+// consecutive ones: wave w the 64 rows [x0, x0 + 64) of lattice line y0 + w, every lane KZ planes of its (x, y).  The KZ + 2
+// values of the lane's column are gathered once and serve as -P / 0 / +P operands of the KZ rows (registers), the +-L lines
+// of the four waves are each other's own lines (the CU's L1), so the L2 is asked for (6 KZ + 8) / (4 KZ) lines per lattice
+// line instead of 5.  Same masks, same products, same order of additions: bit-identical.
+// Host guarantees: L % 64 == 0, (P / L) % 4 == 0, (nrows / P) % KZ == 0, nrows % P == 0.
+
+template <typename T, int EPI, int KZ, bool NT>
+__global__ __launch_bounds__(BLK) void csr_rowmask3d_kernel(const StreamArgs<T> a, const RowMaskArgs<T> m, const RowMaskLattice g)
+{
+    constexpr bool SKIPD = EpiTraits<EPI>::need_cols;
+    constexpr bool NEEDB = (EPI == EPI_RESID || EPI == EPI_AXPBY || EPI == EPI_ACC_AXPBY || EPI >= EPI_JACOBI);
+    constexpr bool NEEDY = (EPI == EPI_ACC || EPI == EPI_ACC_AXPBY || EPI == EPI_ACCSEQ);
+    constexpr bool NEEDJ = (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B);
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int r0 = rowmask_tile_row0(g, KZ, (int)blockIdx.x, wave, lane);
+    const int last = m.ncols - 1;
+    T xc[KZ + 2], xm1[KZ], xp1[KZ], xmL[KZ], xpL[KZ], bb[KZ], yy[KZ], dd[KZ];
+    unsigned mk[KZ];
+#pragma unroll
+    for (int j = 0; j < KZ + 2; ++j) {
+        int c = r0 + (j - 1) * g.P;
+        c = c < 0 ? 0 : c;
+        c = c < last ? c : last;
+        xc[j] = a.x[c];
+    }
+#pragma unroll
+    for (int j = 0; j < KZ; ++j) {
+        const int r = r0 + j * g.P;
+        mk[j] = NT ? __builtin_nontemporal_load(m.mask + r) : m.mask[r];
+        if constexpr (NEEDB) bb[j] = NT ? __builtin_nontemporal_load(a.b + r) : a.b[r];
+        if constexpr (NEEDY) yy[j] = NT ? __builtin_nontemporal_load(a.y + r) : a.y[r];
+        if constexpr (EPI >= EPI_JACOBI) dd[j] = NT ? __builtin_nontemporal_load(a.diag + r) : a.diag[r];
+        int c;
+        c = r - g.L; c = c < 0 ? 0 : c; xmL[j] = a.x[c];
+        c = r - 1; c = c < 0 ? 0 : c; xm1[j] = a.x[c];
+        c = r + 1; c = c < last ? c : last; xp1[j] = a.x[c];
+        c = r + g.L; c = c < last ? c : last; xpL[j] = a.x[c];
+    }
+#pragma unroll
+    for (int j = 0; j < KZ; ++j) {
+        const int r = r0 + j * g.P;
+        RowPre<T> q;
+        q.lo = q.hi = 0;
+        q.row = r;
+        q.pos = r;
+        q.b = q.y = q.xo = q.d = T(0);
+        if constexpr (NEEDB) q.b = bb[j];
+        if constexpr (NEEDY) q.y = yy[j];
+        if constexpr (EPI >= EPI_JACOBI) q.d = dd[j];
+        if constexpr (NEEDJ) q.xo = xc[j + 1];
+        T s = row_init<T, EPI>(q);
+        double sq = 0.0;
+        const T xs[7] = {xc[j], xmL[j], xm1[j], xc[j + 1], xp1[j], xpL[j], xc[j + 2]};
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            if (((mk[j] >> k) & 1u) && (!SKIPD || k != 3)) {
+                const T pr = m.val[k] * xs[k];
+                if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
+                else s += pr;
+            }
+        }
+        if (!mk[j]) {
+            const int lo = a.Ap[r], hi = a.Ap[r + 1];
+            for (int p = lo; p < hi; ++p) {
+                const int col = a.Aj[p];
+                if (!SKIPD || col != r) {
+                    const T pr = a.Ax[p] * a.x[col];
+                    if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
+                    else s += pr;
+                }
+            }
+        }
+        if constexpr (NT && EPI == EPI_RESID) __builtin_nontemporal_store(q.b - s, a.y + r);
+        else row_finish<T, EPI, 0>(a, q, s, sq);
+    }
+}
 
 // ---- software-pipelined row-range processing for the persistent sweeps ------------------
 // Everything a row range needs that does NOT depend on other ranges (its slice of Aj/Ax, row

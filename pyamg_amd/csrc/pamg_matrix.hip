@@ -111,7 +111,7 @@ int launch_rowpat(int epi, int grid, const pamg_matrix_s *A, hipStream_t s, Stre
     a.pid = A->d_pid; a.ptab = A->d_ptab; a.npat = A->npat; a.lmax = A->pat_lmax;
     const size_t tabs = (((size_t)(256 + A->npat * A->pat_lmax) * sizeof(int) + 15) & ~(size_t)15) + sizeof(T) * ((size_t)A->npat * A->pat_lmax + 256);
     const int lds = (int)std::max(tabs + 16, (size_t)BLK * sizeof(double));
-#define PAMG_RP(E) case E: if (A->use_rowpat >= 2) hipLaunchKernelGGL((csr_rowpat2_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); \
+#define PAMG_RP(E) case E: if (A->use_rowpat == 2) hipLaunchKernelGGL((csr_rowpat2_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); \
                         else hipLaunchKernelGGL((csr_rowpat_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); break;
     switch (epi) {
         PAMG_RP(EPI_SET) PAMG_RP(EPI_ACC) PAMG_RP(EPI_RESID) PAMG_RP(EPI_AXPBY) PAMG_RP(EPI_ACC_AXPBY) PAMG_RP(EPI_SUMSQ)
@@ -119,6 +119,65 @@ int launch_rowpat(int epi, int grid, const pamg_matrix_s *A, hipStream_t s, Stre
         default: return 1;
     }
 #undef PAMG_RP
+    return (int)hipGetLastError();
+}
+
+// row-mask form (csr_rowmask_kernel): the whole operator, one row per lane; 1 = not available for this launch
+template <typename T>
+int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamArgs<T> &a)
+{
+    if (!A->d_pmask || A->rm_nu < 1 || A->rm_nu > 8) return 1;
+    RowMaskArgs<T> m;
+    m.mask = A->d_pmask;
+    for (int k = 0; k < 8; ++k) {
+        m.off[k] = A->rm_off[k];
+        if constexpr (sizeof(T) == 8) std::memcpy(&m.val[k], &A->rm_val[k], 8);
+        else { const unsigned v = (unsigned)A->rm_val[k]; std::memcpy(&m.val[k], &v, 4); }
+    }
+    m.nrows = (int)A->nrows; m.ncols = (int)A->ncols;
+    m.xcd_chunk = 0; m.xcd_share = 0;
+    // a 7-point lattice whose extents fit the 64 x 4 x kz tile: csr_rowmask3d_kernel
+    if (A->use_rowpat == 1) {
+        RowMaskLattice g;
+        int grid3 = 0;
+        const int kz = A->rowmask_kz;
+        if (rowmask_lattice_plan(A->rm_nu, A->rm_off, A->nrows, kz, (A->rowmask_flags & 2) != 0, g, grid3)) {
+            const bool nt = A->rowmask_flags & 1;
+#define PAMG_R3K(E, KZ) if (nt) hipLaunchKernelGGL((csr_rowmask3d_kernel<T, E, KZ, true>), dim3(grid3), dim3(BLK), 0, s, a, m, g); \
+                        else hipLaunchKernelGGL((csr_rowmask3d_kernel<T, E, KZ, false>), dim3(grid3), dim3(BLK), 0, s, a, m, g);
+#define PAMG_R3(E) case E: if (kz == 2) { PAMG_R3K(E, 2) } else if (kz == 4) { PAMG_R3K(E, 4) } else { PAMG_R3K(E, 8) } return (int)hipGetLastError();
+            switch (epi) {
+                PAMG_R3(EPI_SET) PAMG_R3(EPI_ACC) PAMG_R3(EPI_RESID) PAMG_R3(EPI_AXPBY) PAMG_R3(EPI_ACC_AXPBY)
+                PAMG_R3(EPI_ACCSEQ) PAMG_R3(EPI_JACOBI) PAMG_R3(EPI_JACOBI_B)
+                default: break;
+            }
+#undef PAMG_R3
+#undef PAMG_R3K
+        }
+    }
+    int grid = (int)((A->nrows + BLK - 1) / BLK);
+    const int plane = A->rm_off[A->rm_nu - 1];                   // the largest offset: rows per plane of a lattice
+    if ((A->rowmask_flags & 2) && plane >= 8 * BLK && plane % (8 * BLK) == 0 && A->nrows % plane == 0) m.xcd_share = plane / (8 * BLK);
+    else if (A->rowmask_flags & 4) { m.xcd_chunk = (grid + 7) >> 3; grid = 8 * m.xcd_chunk; }
+    const int nu = A->rm_nu <= 3 ? 3 : A->rm_nu <= 5 ? 5 : A->rm_nu <= 7 ? 7 : 8;
+    const int near = nu / 2;
+    const bool dppx = A->rm_nu == nu && nu < 8 && A->rm_off[near] == 0 && A->rm_off[near - 1] == -1 && A->rm_off[near + 1] == 1;
+    const int var = (A->rowmask_flags & 1) | (((A->rowmask_flags & 8) && dppx) ? 2 : 0);
+#define PAMG_RMV(E, N) \
+        if (var == 0) hipLaunchKernelGGL((csr_rowmask_kernel<T, E, N, 0>), dim3(grid), dim3(BLK), 0, s, a, m); \
+        else if (var == 1) hipLaunchKernelGGL((csr_rowmask_kernel<T, E, N, 1>), dim3(grid), dim3(BLK), 0, s, a, m); \
+        else if (var == 2) hipLaunchKernelGGL((csr_rowmask_kernel<T, E, N, 2>), dim3(grid), dim3(BLK), 0, s, a, m); \
+        else hipLaunchKernelGGL((csr_rowmask_kernel<T, E, N, 3>), dim3(grid), dim3(BLK), 0, s, a, m);
+#define PAMG_RM(E) case E: \
+        if (nu == 3) { PAMG_RMV(E, 3) } else if (nu == 5) { PAMG_RMV(E, 5) } else if (nu == 7) { PAMG_RMV(E, 7) } else { PAMG_RMV(E, 8) } \
+        break;
+    switch (epi) {
+        PAMG_RM(EPI_SET) PAMG_RM(EPI_ACC) PAMG_RM(EPI_RESID) PAMG_RM(EPI_AXPBY) PAMG_RM(EPI_ACC_AXPBY)
+        PAMG_RM(EPI_ACCSEQ) PAMG_RM(EPI_JACOBI) PAMG_RM(EPI_JACOBI_B)
+        default: return 1;
+    }
+#undef PAMG_RMV
+#undef PAMG_RM
     return (int)hipGetLastError();
 }
 
@@ -210,7 +269,8 @@ void drop_rowpat(pamg_matrix_s *A)
 {
     if (A->d_pid) { hipFree(A->d_pid); A->d_pid = nullptr; }
     if (A->d_ptab) { hipFree(A->d_ptab); A->d_ptab = nullptr; }
-    A->npat = 0; A->pat_lmax = 0;
+    if (A->d_pmask) { hipFree(A->d_pmask); A->d_pmask = nullptr; }
+    A->npat = 0; A->pat_lmax = 0; A->rm_nu = 0;
 }
 
 template <typename U>
@@ -244,6 +304,15 @@ static int plan_rowpat(pamg_matrix_s *A, const unsigned char *code, const U *dic
     PAMG_TRY(upload_raw(&A->d_ptab, tab.data(), tab.size(), 1, &bytes));
     A->npat = np_;
     A->pat_lmax = lmax;
+    // the same rows as masks over the longest list, when the lists allow it (csr_rowmask_kernel)
+    RowMaskPlan M;
+    std::vector<unsigned char> mask;
+    if (A->nrows == A->ncols && plan_row_masks(A->nrows, pid, keys, M, mask)) {
+        PAMG_TRY(upload_raw((void **)&A->d_pmask, mask.data(), mask.size(), 1, &bytes));
+        A->rm_nu = M.nu;
+        A->rm_walked = M.walked;
+        for (int k = 0; k < 8; ++k) { A->rm_off[k] = k < M.nu ? M.off[k] : 0; A->rm_val[k] = k < M.nu ? (unsigned long long)dict[M.vc[k]] : 0ull; }
+    }
     A->bytes += bytes;
     return PAMG_OK;
 }
@@ -927,6 +996,7 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
         StreamArgs<double> a = base_args<double>(A, x, b, y, c, omega, partial);
         a.flags = A->stream_flags;
         if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+        if (rowp && (A->use_rowpat == 1 || A->use_rowpat == 4)) { const int st = launch_rowmask<double>(epi, A, s, a); if (st != 1) return st; }
         if (rowp) { const int st = launch_rowpat<double>(epi, grid, A, s, a); if (st != 1) return st; }
         if (rowg) { const int st = launch_rowgather<double>(epi, grid, A->cap, A->nvdict, s, a); if (st != 1) return st; }
         return launch_any<double>(epi, A->npl, grid, lds, s, a);
@@ -934,6 +1004,7 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
     StreamArgs<float> a = base_args<float>(A, x, b, y, c, omega, partial);
     a.flags = A->stream_flags;
     if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+    if (rowp && (A->use_rowpat == 1 || A->use_rowpat == 4)) { const int st = launch_rowmask<float>(epi, A, s, a); if (st != 1) return st; }
     if (rowp) { const int st = launch_rowpat<float>(epi, grid, A, s, a); if (st != 1) return st; }
     if (rowg) { const int st = launch_rowgather<float>(epi, grid, A->cap, A->nvdict, s, a); if (st != 1) return st; }
     return launch_any<float>(epi, A->npl, grid, lds, s, a);
@@ -1919,7 +1990,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
     // a finalised solver's captured graphs point into the schedules and plans this call would free
     if (key == 21) { A->use_val8 = value != 0; return PAMG_OK; }      // read at launch time only: no plan depends on it
     if (key == 22) { A->use_rowg = value != 0; return PAMG_OK; }      // likewise
-    if (key == 23) { if (value < 0 || value > 2) return PAMG_E_ARG; A->use_rowpat = value; return PAMG_OK; }
+    if (key == 23) { if (value < 0 || value > 4) return PAMG_E_ARG; A->use_rowpat = value; return PAMG_OK; }
     if (A->borrowed > 0) return PAMG_E_STATE;
     switch (key) {
         case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~3; A->cap_from_val8 = 0; break;
@@ -1947,6 +2018,8 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 27: if (value < 0 || value > 1) return PAMG_E_ARG; A->lane_wide = value; return PAMG_OK;
         case 29: if (value < 0) return PAMG_E_ARG; A->lane_chunk = value; key = 25; break;
         case 30: if (value < 0 || value > 1) return PAMG_E_ARG; A->line_scan = value; return PAMG_OK;
+        case 31: if (value != 2 && value != 4 && value != 8) return PAMG_E_ARG; A->rowmask_kz = value; return PAMG_OK;
+        case 32: if (value < 0 || value > 15) return PAMG_E_ARG; A->rowmask_flags = value; return PAMG_OK;
         case 28: if (value < 0 || value > 15) return PAMG_E_ARG; { const bool relayout = ((A->lane_flags ^ value) & 2) != 0; A->lane_flags = value; if (!relayout) return PAMG_OK; } key = 25; break;
         default: return PAMG_E_ARG;
     }

@@ -232,4 +232,75 @@ inline bool plan_row_patterns(int64_t n, const int *Ap, const int *Aj, const uns
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------- row masks
+// The row-mask form of the row patterns (csr_rowmask_kernel): U = the list of the table whose sub-lists cover the most rows (a
+// stencil's interior row); a list is expressible when it is U with entries left out -- a subsequence of U, offset AND value code equal at the matched positions, so that walking
+// U's entries under the mask adds the row's products in the row's storage order.  mask[r] = bit k set when entry k of U is
+// in row r's list; 0 = walk the row through the CSR arrays (irregular rows, rows of lists that are no sub-list, empty rows).
+// false: no such form (U longer than 8 entries, or more than a tenth of the rows would walk the CSR arrays).
+constexpr int RMASK_MAX = 8;
+
+struct RowMaskPlan {
+    int nu = 0;
+    int off[RMASK_MAX] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned char vc[RMASK_MAX] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t walked = 0;            // rows with mask 0
+};
+
+inline bool plan_row_masks(int64_t n, const std::vector<unsigned char> &pid, const std::vector<RowPatKey> &keys, RowMaskPlan &M,
+                           std::vector<unsigned char> &mask, size_t pad = 16)
+{
+    M = RowMaskPlan();
+    mask.clear();
+    if (keys.empty() || (int64_t)pid.size() < n) return false;
+    // U = the list (of at most RMASK_MAX entries) whose sub-lists cover the most rows
+    std::vector<int64_t> hist(256, 0);
+    for (int64_t r = 0; r < n; ++r) ++hist[pid[(size_t)r]];
+    auto sub_bits = [&](const RowPatKey &K, const RowPatKey &U) -> int {          // K as a mask over U, -1: no sub-list
+        int k = 0, bits = 0;
+        for (int j = 0; j < K.len; ++j) {
+            while (k < U.len && !(U.off[k] == K.off[j] && U.vc[k] == K.vc[j])) ++k;
+            if (k == U.len) return -1;
+            bits |= 1 << k;
+            ++k;
+        }
+        return bits;
+    };
+    std::vector<int64_t> cov(keys.size(), -1);
+    int64_t best = -1;
+    for (size_t c = 0; c < keys.size(); ++c) {
+        if (keys[c].len < 1 || keys[c].len > RMASK_MAX) continue;
+        cov[c] = 0;
+        for (size_t q = 0; q < keys.size(); ++q)
+            if (keys[q].len > 0 && sub_bits(keys[q], keys[c]) > 0) cov[c] += hist[q];
+        best = std::max(best, cov[c]);
+    }
+    size_t u = keys.size();                       // within 1 % of the best coverage: the shortest list (fewest gathers per row)
+    for (size_t c = 0; c < keys.size(); ++c)
+        if (cov[c] >= 0 && cov[c] * 100 >= best * 99 && (u == keys.size() || keys[c].len < keys[u].len)) u = c;
+    if (u == keys.size()) return false;
+    const RowPatKey &U = keys[u];
+    M.nu = U.len;
+    for (int k = 0; k < U.len; ++k) { M.off[k] = U.off[k]; M.vc[k] = U.vc[k]; }
+    std::vector<int> mask_of(256, 0);
+    for (size_t q = 0; q < keys.size(); ++q) {
+        const int bits = sub_bits(keys[q], U);
+        mask_of[q] = bits > 0 ? bits : 0;
+    }
+    mask.assign((size_t)n + pad, 0);
+    std::atomic<int64_t> walked(0);
+    plan_parallel(n, [&](int64_t lo, int64_t hi, int) {
+        int64_t w = 0;
+        for (int64_t r = lo; r < hi; ++r) {
+            const unsigned char mk = (unsigned char)mask_of[pid[(size_t)r]];
+            mask[(size_t)r] = mk;
+            w += mk == 0;
+        }
+        walked += w;
+    }, 1 << 18);
+    M.walked = walked.load();
+    if (M.walked * 10 > n) { mask.clear(); return false; }
+    return true;
+}
+
 }  // namespace pamg

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../pyamg_amd/csrc/pamg_stream_plan.h"
+#include "../pyamg_amd/csrc/pamg_rowmask_map.h"
 
 using namespace pamg;
 
@@ -102,6 +103,98 @@ int stream_emul_f64(int n, const int *Ap, const int *Aj, const double *Ax, const
         }
     }
     info[4] = bad;
+    return 0;
+}
+
+// The row-mask forms (plan_row_masks + pamg_rowmask_map.h): ylin = the linear form (csr_rowmask_kernel: workgroup -> 256 rows
+// under the three workgroup orders), ylat = the lattice form (csr_rowmask3d_kernel's 64 x 4 x kz tiles), both decoded the way
+// the kernels decode a row: the longest list under the row's mask, or the CSR arrays for mask 0.
+// info: [0] entries of the longest list (0 = no mask form), [1] rows with mask 0, [2] 1 = lattice form applies, [3] decoded
+// (column, value) pairs that differ from the CSR's (must be 0), [4] rows not visited exactly once by some order (must be 0),
+// [5] L, [6] P, [7] workgroups of the lattice form
+int rowmask_emul_f64(int n, const int *Ap, const int *Aj, const double *Ax, const double *x, int kz, double *ylin, double *ylat, int64_t *info)
+{
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    for (int i = 0; i < n; ++i) ylin[i] = ylat[i] = nan;
+    for (int k = 0; k < 8; ++k) info[k] = 0;
+    const int64_t nnz = Ap[n];
+    std::vector<uint64_t> dict;
+    std::vector<unsigned char> code, pid, mask;
+    std::vector<RowPatKey> keys;
+    int lmax = 0;
+    if (!plan_value_codes<uint64_t>(nnz, reinterpret_cast<const uint64_t *>(Ax), dict, code)) return 0;
+    if (!plan_row_patterns(n, Ap, Aj, code.data(), 8, pid, keys, lmax)) return 0;
+    RowMaskPlan M;
+    if (!plan_row_masks(n, pid, keys, M, mask)) return 0;
+    info[0] = M.nu;
+    info[1] = M.walked;
+    int64_t bad = 0, miss = 0;
+    auto row = [&](int r) {
+        double s = 0.0;
+        const unsigned mk = mask[(size_t)r];
+        if (mk) {
+            int p = Ap[r];
+            for (int k = 0; k < M.nu; ++k)
+                if ((mk >> k) & 1u) {
+                    double v;
+                    std::memcpy(&v, &dict[M.vc[k]], 8);
+                    const int col = r + M.off[k];
+                    bad += p >= Ap[r + 1] || col != Aj[p] || std::memcmp(&v, &Ax[p], 8) != 0;
+                    ++p;
+                    s += v * x[col];
+                }
+            bad += p != Ap[r + 1];
+        } else {
+            for (int p = Ap[r]; p < Ap[r + 1]; ++p) s += Ax[p] * x[Aj[p]];
+        }
+        return s;
+    };
+    // ---- linear form, three workgroup orders
+    std::vector<int> seen((size_t)n);
+    const int grid0 = (n + RMASK_BLK - 1) / RMASK_BLK;
+    const int plane = M.off[M.nu - 1];
+    for (int order = 0; order < 3; ++order) {
+        int chunk = 0, share = 0, grid = grid0;
+        if (order == 1) { chunk = (grid0 + 7) >> 3; grid = 8 * chunk; }
+        if (order == 2) {
+            if (!(plane >= 8 * RMASK_BLK && plane % (8 * RMASK_BLK) == 0 && n % plane == 0)) continue;
+            share = plane / (8 * RMASK_BLK);
+        }
+        std::fill(seen.begin(), seen.end(), 0);
+        for (int b = 0; b < grid; ++b) {
+            const int blk = rowmask_linear_block(b, chunk, share);
+            for (int t = 0; t < RMASK_BLK; ++t) {
+                const int64_t r = (int64_t)blk * RMASK_BLK + t;
+                if (r >= n) continue;
+                ++seen[(size_t)r];
+                ylin[r] = row((int)r);
+            }
+        }
+        for (int r = 0; r < n; ++r) miss += seen[(size_t)r] != 1;
+    }
+    // ---- lattice form, both workgroup orders
+    for (int slabs = 0; slabs < 2; ++slabs) {
+        RowMaskLattice g;
+        int grid = 0;
+        if (!rowmask_lattice_plan(M.nu, M.off, n, kz, slabs != 0, g, grid)) continue;
+        if (slabs && g.slab == 0) continue;
+        info[2] = 1; info[5] = g.L; info[6] = g.P; info[7] = grid;
+        std::fill(seen.begin(), seen.end(), 0);
+        for (int b = 0; b < grid; ++b)
+            for (int w = 0; w < 4; ++w)
+                for (int l = 0; l < 64; ++l) {
+                    const int r0 = rowmask_tile_row0(g, kz, b, w, l);
+                    for (int j = 0; j < kz; ++j) {
+                        const int64_t r = (int64_t)r0 + (int64_t)j * g.P;
+                        if (r < 0 || r >= n) { ++miss; continue; }
+                        ++seen[(size_t)r];
+                        ylat[r] = row((int)r);
+                    }
+                }
+        for (int r = 0; r < n; ++r) miss += seen[(size_t)r] != 1;
+    }
+    info[3] = bad;
+    info[4] = miss;
     return 0;
 }
 

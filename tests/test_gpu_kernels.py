@@ -888,10 +888,11 @@ def test_8bit_value_codes_are_bit_identical(dtype):
         assert dA.value_codes() == expect and dA.row_patterns() == npat, (dA.value_codes(), dA.row_patterns())
         dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
         out = {}
-        # 4: row patterns, two consecutive rows per lane (the default where a table exists), 3: row patterns, one row per lane,
-        # 2: codes + row-gather kernel, 1: codes + staged kernel, 0: values as stored
-        for flag in (4, 3, 2, 1, 0):
-            dA.tune(val8=min(flag, 1), rowgather=int(flag >= 2), rowpat=2 if flag == 4 else int(flag == 3))
+        # 5: row-pattern table kernel, one row per lane, 4: the same, two consecutive rows per lane, 3: the default where a table
+        # exists (row masks where the lists allow it, else the table kernel), 2: codes + row-gather kernel, 1: codes + staged
+        # kernel, 0: values as stored
+        for flag in (5, 4, 3, 2, 1, 0):
+            dA.tune(val8=min(flag, 1), rowgather=int(flag >= 2), rowpat={5: 3, 4: 2, 3: 1}.get(flag, 0))
             assert dA.value_codes() == (expect if flag else 0) and dA.row_patterns() == (npat if flag >= 3 else 0)
             dy = capi.DeviceArray(n, dtype)
             dA.spmv(capi.SPMV_RESID, dx, dy, b=db)
@@ -902,12 +903,12 @@ def test_8bit_value_codes_are_bit_identical(dtype):
             dA.jacobi(dj, db, dw, 0.8, iterations=2)
             out[flag] = (dy.download(), dz.download(), dj.download())
         for k in range(3):
-            assert all(np.array_equal(out[0][k], out[f][k], equal_nan=True) for f in (1, 2, 3, 4)), k
+            assert all(np.array_equal(out[0][k], out[f][k], equal_nan=True) for f in (1, 2, 3, 4, 5)), k
         # the remaining epilogues of the row-gather kernel against the staged kernel on the values as stored
         dA.tune(val8=1, rowgather=1, rowpat=1)
         res = {}
-        for flag in (3, 2, 1, 0):
-            dA.tune(val8=min(flag, 1), rowgather=min(flag, 1), rowpat=2 if flag == 3 else int(flag == 2))
+        for flag in (4, 3, 2, 1, 0):
+            dA.tune(val8=min(flag, 1), rowgather=min(flag, 1), rowpat={4: 3, 3: 2, 2: 1}.get(flag, 0))
             dy = capi.DeviceArray.from_host(b)
             dA.spmv(capi.SPMV_ACC, dx, dy)
             d2 = capi.DeviceArray.from_host(x)
@@ -919,6 +920,7 @@ def test_8bit_value_codes_are_bit_identical(dtype):
             res[flag] = (dy.download(), d2.download(), d3.download(), o.download())
         for k in range(4):
             assert np.array_equal(res[0][k], res[1][k], equal_nan=True) and np.array_equal(res[0][k], res[2][k], equal_nan=True), k
+            assert np.array_equal(res[0][k], res[4][k], equal_nan=True), k
         for k in range(3):
             assert np.array_equal(res[0][k], res[3][k], equal_nan=True), k
         # the norm's partial sums follow the lane -> row mapping, which the two-row form changes: same terms, another order
@@ -926,6 +928,67 @@ def test_8bit_value_codes_are_bit_identical(dtype):
         dA.tune(val8=1, rowgather=1, rowpat=1)
         if dtype == np.float64:
             assert np.array_equal(out[1][1], sp.csr_array(A) @ x)
+        dA.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_row_mask_kernels_are_bit_identical(dtype):
+    """Row masks (tune key 23 = 1 where every list is the stencil's interior list with entries left out): the linear kernel
+    (one row per lane, no table) under its three workgroup orders, nontemporal or not, +-1 by DPP or gathered, and the lattice
+    kernel (64 x 4 x kz tiles, kz = 2, 4, 8, both workgroup orders) against the row-gather form on the same operator -- every
+    epilogue, bit for bit; rows that are no sub-list walk the CSR arrays inside the kernels."""
+    import scipy.sparse as sp
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(12)
+    lat = poisson_csr((16, 32, 64))                      # 64-row lines, 32 lines per plane (XCD slabs: 8 tiles of 4 lines), 16 planes
+    wide = poisson_csr((8, 8, 256))                      # four 64-row tiles per line, 2 tiles of lines: no XCD slabs
+    odd = lat.tolil()
+    for k in range(60):
+        i = 900 + 41 * k
+        odd[i, i + 7] = -0.5
+        odd[i + 3, i + 2] = -1.25
+    odd = sp.csr_array(odd.tocsr())
+    flat = poisson_csr((128, 128))                       # 5 entries: linear form only
+    for A, lattice in ((lat, True), (wide, True), (odd, True), (flat, False)):
+        A = sp.csr_array(A).astype(dtype)
+        n = A.shape[0]
+        x, b = rng.rand(n).astype(dtype), rng.rand(n).astype(dtype)
+        dA = DeviceMatrix(sparse_op(A))
+        assert dA.row_patterns() > 0
+        dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
+
+        def everything():
+            outs = []
+            for mode, kw in ((capi.SPMV_RESID, dict(b=db)), (capi.SPMV_SET, {}), (capi.SPMV_AXPBY, dict(b=db, c=0.37))):
+                dy = capi.DeviceArray(n, dtype)
+                dA.spmv(mode, dx, dy, **kw)
+                outs.append(dy.download())
+                dy.free()
+            dy = capi.DeviceArray.from_host(b)
+            dA.spmv(capi.SPMV_ACC, dx, dy)
+            outs.append(dy.download())
+            dy.free()
+            dy = capi.DeviceArray.from_host(x)
+            dA.spmv(capi.SPMV_ACC_AXPBY, dx, dy, b=db, c=-1.7)
+            outs.append(dy.download())
+            dy.free()
+            dj, dw = capi.DeviceArray.from_host(x), capi.DeviceArray(n, dtype)
+            dA.jacobi(dj, db, dw, 0.8, iterations=2)
+            outs.append(dj.download())
+            dj.free(); dw.free()
+            return outs
+        dA.tune(rowpat=0)
+        ref = everything()
+        if dtype == np.float64:
+            assert np.array_equal(ref[1], A @ x)
+        variants = [dict(rowpat=4, rowmask_flags=f) for f in (0, 1, 2, 3, 4, 5, 8, 9, 11)]
+        if lattice:
+            variants += [dict(rowpat=1, rowmask_kz=kz, rowmask_flags=f) for kz in (2, 4, 8) for f in (0, 1, 2, 3)]
+        for v in variants:
+            dA.tune(**v)
+            got = everything()
+            for k, (r, g) in enumerate(zip(ref, got)):
+                assert np.array_equal(r, g, equal_nan=True), (v, k, int(np.sum(r != g)))
         dA.free()
 
 

@@ -269,7 +269,8 @@ def stream_emul():
     so = out / "stream_emul.so"
     src = HERE / "stream_emul.cpp"
     hdr = HERE.parent / "pyamg_amd" / "csrc" / "pamg_stream_plan.h"
-    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+    hdr2 = HERE.parent / "pyamg_amd" / "csrc" / "pamg_rowmask_map.h"
+    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime, hdr2.stat().st_mtime):
         subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
     return ctypes.CDLL(str(so))
 
@@ -284,6 +285,59 @@ def _stream_replay(lib, A, x, cap=1536, max_rows=1024):
     info = np.zeros(6, dtype=np.int64)
     assert lib.stream_emul_f64(n, p(Ap), p(Aj), p(Ax), p(x), cap, max_rows, p(ys[0]), p(ys[1]), p(ys[2]), p(info)) == 0
     return ys, info
+
+
+def _rowmask_replay(lib, A, x, kz=4):
+    A = sp.csr_array(A)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)       # noqa: E731
+    Ap, Aj = np.ascontiguousarray(A.indptr, dtype=np.int32), np.ascontiguousarray(A.indices, dtype=np.int32)
+    Ax = np.ascontiguousarray(A.data, dtype=np.float64)
+    n = A.shape[0]
+    ylin, ylat = np.zeros(n), np.zeros(n)
+    info = np.zeros(8, dtype=np.int64)
+    assert lib.rowmask_emul_f64(n, p(Ap), p(Aj), p(Ax), p(x), kz, p(ylin), p(ylat), p(info)) == 0
+    return ylin, ylat, info
+
+
+def test_row_masks_deliver_the_csr(stream_emul):
+    """plan_row_masks + the row maps of the row-mask kernels (csrc/pamg_rowmask_map.h), replayed on the CPU: a stencil's rows
+    as masks over its longest list give back the CSR's own (column, value) pairs in storage order (SciPy's bits), every
+    workgroup order visits every row exactly once; lattices that do not fit the 64 x 4 x kz tiles keep the linear form;
+    rows that are no sub-list of the longest list walk the CSR arrays; operators whose lists disagree on a value have no
+    mask form at all."""
+    from tools.problems import poisson_csr
+    rng = np.random.default_rng(7)
+    # 64 x 32 x 8 lattice: the lattice form applies for kz = 2, 4, 8 (tiles_y = 8: XCD slabs too)
+    P3 = poisson_csr((8, 32, 64))                # (nz, ny, nx): rows run fastest along the last extent
+    x = rng.random(P3.shape[0])
+    ref = P3 @ x
+    for kz in (2, 4, 8):
+        ylin, ylat, info = _rowmask_replay(stream_emul, P3, x, kz)
+        assert info[0] == 7 and info[1] == 0 and info[2] == 1 and info[3] == 0 and info[4] == 0, info
+        assert (info[5], info[6]) == (64, 64 * 32) and info[7] == P3.shape[0] // (256 * kz)
+        assert np.array_equal(ylin, ref) and np.array_equal(ylat, ref)
+    # 24^3: no 64-row tiles -> linear form only; 2-D 5-point: 5 entries, linear form
+    for grid, nu in (((24, 24, 24), 7), ((300, 200), 5), ((5000,), 3)):
+        A = poisson_csr(grid)
+        xa = rng.random(A.shape[0])
+        ylin, ylat, info = _rowmask_replay(stream_emul, A, xa)
+        assert info[0] == nu and info[2] == 0 and info[3] == 0 and info[4] == 0, (grid, info)
+        assert np.array_equal(ylin, A @ xa) and np.isnan(ylat).all()
+    # some rows with an extra entry / another value: they are no sub-list of the longest list -> walked through the CSR arrays
+    odd = P3.tolil()
+    for k in range(50):
+        i = 700 + 37 * k
+        odd[i, i + 5] = -0.5
+        odd[i + 3, i + 2] = -1.25
+    odd = sp.csr_array(odd.tocsr())
+    ylin, ylat, info = _rowmask_replay(stream_emul, odd, x)
+    assert info[0] == 7 and info[1] >= 100 and info[2] == 1 and info[3] == 0 and info[4] == 0, info
+    assert np.array_equal(ylin, odd @ x) and np.array_equal(ylat, odd @ x)
+    # an anisotropic operator whose boundary rows carry ANOTHER diagonal value: those lists are no sub-lists; too many -> no mask form
+    n1 = 4096
+    T = sp.diags_array([-np.ones(n1 - 1), 2.0 + (np.arange(n1) % 3 == 0), -np.ones(n1 - 1)], offsets=[-1, 0, 1], format="csr")
+    ylin, _, info = _rowmask_replay(stream_emul, T, rng.random(n1))
+    assert info[0] == 0 and np.isnan(ylin).all()
 
 
 def test_compressed_operator_streams_deliver_the_csr(stream_emul):

@@ -21,12 +21,12 @@ x, b = capi.DeviceArray.from_host(rng.rand(n)), capi.DeviceArray.from_host(rng.r
 r = capi.DeviceArray(n, np.float64)
 w = capi.DeviceArray(n, np.float64)
 streamed = 25 * n
-out = {"copy_GBps": capi.bandwidth_probe("copy"), "triad_GBps": capi.bandwidth_probe("triad")}
+out = {"copy_GBps": capi.bandwidth_probe("copy1"), "copy_grid_stride_GBps": capi.bandwidth_probe("copy")}
 print(out, flush=True)
 
 
-def timed(fn, reps=30):
-    for _ in range(5):
+def timed(fn, reps=100):
+    for _ in range(200):
         fn()
     capi.sync()
     e0, e1 = capi.Event(), capi.Event()
@@ -57,11 +57,21 @@ def run(name, **tune):
 
 
 print("row patterns:", dA.row_patterns(), dA.info(), flush=True)
-for rp in (1, 2):
-    for fl in (0, 1, 2, 3):
-        run(f"rowpat{rp}_flags{fl}", stream_flags=fl, rowpat=rp)
-for mr, cap in ((256, 2048), (1024, 7168), (2048, 12288)):
-    for fl in (0, 2):
-        run(f"rowpat2_rows{mr}_flags{fl}", stream_flags=fl, rowpat=2, lds_entries=cap, max_rows=mr)
+names = {3: "rowpat", 4: "rowmask", 2: "rowpat2"}
+for rp in ([3, 4] if tag.startswith("rowmask") else [3, 2]):
+    if rp != 4:
+        for fl in (0, 2):
+            run(f"{names[rp]}_flags{fl}", stream_flags=fl, rowpat=rp)
+    else:
+        for fl in (0, 1, 2, 3, 5, 11):
+            run(f"rowmask_flags{fl}", rowmask_flags=fl, rowpat=rp)
+if tag.startswith("rowmask"):
+    for kz in (2, 4, 8):
+        for fl in (0, 1, 2, 3):
+            run(f"rowmask3d_kz{kz}_flags{fl}", rowmask_flags=fl, rowpat=1, rowmask_kz=kz)
+if not tag.startswith("rowmask"):
+    for mr, cap in ((256, 2048), (1024, 7168), (2048, 12288)):
+        for fl in (0, 2):
+            run(f"rowpat2_rows{mr}_flags{fl}", stream_flags=fl, rowpat=2, lds_entries=cap, max_rows=mr)
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
 (ROOT / "gpurun_out" / f"microbench_{tag}.json").write_text(json.dumps(out, indent=1))

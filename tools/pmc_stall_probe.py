@@ -33,11 +33,11 @@ for var in variants:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 for r in csv.DictReader(fh):
-                    if any(k in r.get("Kernel_Name", "") for k in ("csr_stream", "csr_rowgather", "csr_rowpat")) and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= (4096 * 256 if LEVEL1 else 256 * 1024):
+                    if any(k in r.get("Kernel_Name", "") for k in ("csr_stream", "csr_rowgather", "csr_rowpat", "csr_rowmask")) and int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= (4096 * 256 if LEVEL1 else 256 * 1024):
                         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in acc.items():
             rec[k] = round(sum(v) / len(v), 1)
     out[var] = rec
     print(var, json.dumps(rec), flush=True)
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
-(ROOT / "gpurun_out" / ("pmc_stall_probe_level1_r03.json" if LEVEL1 else "pmc_stall_probe_r03.json")).write_text(json.dumps(out, indent=1))
+(ROOT / "gpurun_out" / ("pmc_stall_probe_level1.json" if LEVEL1 else "pmc_stall_probe.json")).write_text(json.dumps(out, indent=1))

@@ -34,13 +34,17 @@ for a in sys.argv[1:]:
         idx16 = int(a.split("=", 1)[1])
 if idx16 is not None:
     dA.tune(idx16=idx16)
-opt = {k: int(v) for k, v in (a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a) if k in ("val8", "flags", "cap")}
+opt = {k: int(v) for k, v in (a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a) if k in ("val8", "flags", "cap", "rowpat", "kz")}
 if "cap" in opt:
     dA.tune(lds_entries=opt["cap"])
 if "flags" in opt:
     dA.tune(stream_flags=opt["flags"])
 if "val8" in opt:
     dA.tune(val8=opt["val8"])
+if "rowpat" in opt:
+    dA.tune(rowpat=opt["rowpat"])
+if "kz" in opt:
+    dA.tune(rowmask_kz=opt["kz"])
 for _ in range(launches):
     dA.spmv(capi.SPMV_RESID, x, r, b=b)
 capi.sync()
