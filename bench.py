@@ -118,7 +118,7 @@ def measure_traffic(grid, nrows):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if r.get("Counter_Name") == cname and any(k in r.get("Kernel_Name", "") for k in ("csr_stream_kernel", "csr_rowgather_kernel", "csr_rowpat_kernel")) and \
+                        if r.get("Counter_Name") == cname and any(k in r.get("Kernel_Name", "") for k in ("csr_stream_kernel", "csr_rowgather_kernel", "csr_rowpat_kernel", "csr_rowmask")) and \
                                 int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= 256 * 1024:
                             tot += float(r["Counter_Value"])
                             cnt += 1
@@ -472,7 +472,7 @@ def main():
             f1.record(None)
             f1.synchronize()
             ms = f0.elapsed_ms(f1) / 20
-            roofline = {"kernel": ("csr_rowpat_kernel<double, RESID>" if A0.row_patterns() else "csr_rowgather_kernel<double, RESID>" if A0.value_codes() else "csr_stream_kernel<double, RESID>") +
+            roofline = {"kernel": ("csr_rowmask_kernel<double, RESID>" if (A0.row_patterns() and A0.row_masks()["entries"]) else "csr_rowpat_kernel<double, RESID>" if A0.row_patterns() else "csr_rowgather_kernel<double, RESID>" if A0.value_codes() else "csr_stream_kernel<double, RESID>") +
                         " (rank 0's row shard of the fine level, r = b - A x)", "bound": "hbm",
                         "achieved": round(by / ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(by / ms / 1e6 / HBM_PEAK_GBPS, 4),
                         "traffic": None, "bytes_per_launch": int(by), "ms_per_launch": round(ms, 5)}
@@ -606,13 +606,22 @@ def main():
     ceiling = None
     if rank == 0:
         try:
-            ceiling = {"copy_GBps": round(capi.bandwidth_probe("copy"), 1), "triad_GBps": round(capi.bandwidth_probe("triad"), 1),
-                       "how": "c = a / c = a + s b over 3 x 1 GiB vectors, 16-byte accesses, 20 launches (pamg_bandwidth_probe)"}
+            shapes = {k: round(capi.bandwidth_probe(k), 1) for k in ("copy1nt", "copy1", "copy8b", "copy", "triad", "read", "write")}
+            ceiling = {"copy_GBps": max(shapes["copy1nt"], shapes["copy1"]), "triad_GBps": shapes["triad"], "shapes_GBps": shapes,
+                       "how": "c = a over 1 GiB vectors, 20 launches (pamg_bandwidth_probe): copy1 / copy1nt = one 16-byte access per lane, no loop "
+                              "(nt = nontemporal) -- the ceiling; copy8b = one 8-byte access per lane; copy / triad = grid-stride loops (what round 3 "
+                              "quoted); read / write = one direction only"}
         except Exception as e:                                  # noqa: BLE001
             log(f"bandwidth probe failed: {e!r}")
     # bytes the format that actually ran has to move per launch (its operator stream + the vectors once)
     nnz0 = int(A.nnz)
-    if nvals and npats:
+    masks = A0.row_masks() if npats else {"entries": 0}
+    if nvals and npats and masks["entries"]:
+        streamed = 25 * n                             # one mask byte per row + b, x, r
+        stream_note = (f"row masks: every row of this stencil is the interior row's list of {masks['entries']} (column - row, value) pairs with entries left "
+                       f"out; a row streams ONE byte (which entries it has) instead of 12 bytes per stored entry + 4; offsets and values are launch constants"
+                       + (f"; lattice form: 64 x 4 x {masks['planes_per_lane']} rows per workgroup, lines of {masks['line']}, planes of {masks['plane']} rows" if masks["lattice"] else ""))
+    elif nvals and npats:
         streamed = 25 * n                             # one pattern byte per row + b, x, r; no entries, no row pointer (irregular rows: a few per mille)
         stream_note = (f"row patterns: {npats} lists of (column - row, value) pairs cover the rows of this stencil, a row streams ONE byte "
                        f"(its list number) instead of 12 bytes per stored entry + 4 ({nvals} distinct values)")
@@ -626,7 +635,8 @@ def main():
     # the roofline fraction is taken on what MOVES: the larger of the bytes the running format must stream and the HBM
     # traffic counted in this run (a compressed format does not move the CSR formula's bytes; that figure stays beside it)
     moved = max(int(streamed), int(pmc["bytes_per_launch"]) if pmc else 0)
-    kname = ("csr_rowpat_kernel<double, RESID>" if npats else "csr_rowgather_kernel<double, RESID>" if nvals else "csr_stream_kernel<double, RESID>")
+    kname = ((f"csr_rowmask3d_kernel<double, RESID, {masks['planes_per_lane']}>" if masks["lattice"] else "csr_rowmask_kernel<double, RESID>") if masks["entries"] else
+             "csr_rowpat_kernel<double, RESID>" if npats else "csr_rowgather_kernel<double, RESID>" if nvals else "csr_stream_kernel<double, RESID>")
     roofline = {"kernel": kname + " (fine-level r = b - A x)", "bound": "hbm",
                 "achieved": round(moved / spmv_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(moved / spmv_ms / 1e6 / HBM_PEAK_GBPS, 4),

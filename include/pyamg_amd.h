@@ -364,6 +364,11 @@ int pamg_matrix_value_codes(pamg_matrix_t A, int *n_values);
  * key 23: square operators with value codes whose rows are mostly one of <= 255 lists of (column - row, value) pairs --
  * constant-coefficient stencils; one byte per such row instead of the row's codes), 0 otherwise. */
 int pamg_matrix_row_patterns(pamg_matrix_t A, int *n_patterns);
+/* The row-mask form of the row patterns (tune key 23 = 1 or 4 where every list is one list with entries left out):
+ * info[0] entries of that list (0 = the operator has no mask form, or another form is selected), [1] rows that walk the CSR
+ * arrays, [2] 1 = the lattice kernel runs (64 x 4 x kz tiles), [3] rows per lattice line, [4] rows per plane, [5] planes
+ * per lane (key 31), [6] flags (key 32), [7] workgroups launched per whole-operator kernel. */
+int pamg_matrix_row_masks(pamg_matrix_t A, long long info[8]);
 /* Pick the LDS window (key 0) and streaming flags (key 8) of the whole-operator kernels by timing
  * y = A x on the device with a few candidates (results are bit-identical for every choice; this
  * is speed only).  allow_cap = 0 keeps the LDS window (level schedules depend on it).  Operators

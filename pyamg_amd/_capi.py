@@ -118,6 +118,7 @@ def _declare(lib):
     f("pamg_matrix_tune", _vp, _i, _i)
     f("pamg_matrix_value_codes", _vp, P(C.c_int))
     f("pamg_matrix_row_patterns", _vp, P(C.c_int))
+    f("pamg_matrix_row_masks", _vp, P(C.c_longlong))
     f("pamg_matrix_flow_error", _vp, P(_i))
     f("pamg_matrix_subset_rows", _vp, _vp, _i, P(_vp))
     f("pamg_matrix_kaczmarz", _vp, _i, _vp, _vp, _vp, _d, _i, _i, _vp, _vp)

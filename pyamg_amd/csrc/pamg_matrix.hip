@@ -1984,6 +1984,23 @@ int pamg_matrix_row_patterns(pamg_matrix_t A, int *n_patterns)
     return PAMG_OK;
 }
 
+int pamg_matrix_row_masks(pamg_matrix_t A, long long info[8])
+{
+    if (!A || !info) return PAMG_E_ARG;
+    for (int k = 0; k < 8; ++k) info[k] = 0;
+    int npat = 0;
+    pamg_matrix_row_patterns(A, &npat);
+    if (!npat || !A->d_pmask || (A->use_rowpat != 1 && A->use_rowpat != 4)) return PAMG_OK;
+    info[0] = A->rm_nu; info[1] = A->rm_walked; info[5] = A->rowmask_kz; info[6] = A->rowmask_flags;
+    info[7] = (A->nrows + BLK - 1) / BLK;
+    RowMaskLattice g;
+    int grid3 = 0;
+    if (A->use_rowpat == 1 && rowmask_lattice_plan(A->rm_nu, A->rm_off, A->nrows, A->rowmask_kz, (A->rowmask_flags & 2) != 0, g, grid3)) {
+        info[2] = 1; info[3] = g.L; info[4] = g.P; info[7] = grid3;
+    }
+    return PAMG_OK;
+}
+
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
 {
     if (!A) return PAMG_E_ARG;

@@ -110,6 +110,13 @@ class DeviceMatrix:
         capi.check(capi.lib().pamg_matrix_row_patterns(self.handle, C.byref(n)), "pamg_matrix_row_patterns")
         return int(n.value)
 
+    def row_masks(self) -> dict:
+        """the row-mask form of the row patterns (constant-coefficient stencils): dict, all zero when another form runs"""
+        out = (C.c_longlong * 8)()
+        capi.check(capi.lib().pamg_matrix_row_masks(self.handle, out), "pamg_matrix_row_masks")
+        keys = ("entries", "walked_rows", "lattice", "line", "plane", "planes_per_lane", "flags", "launch_grid")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def tile_info(self, which=0):
         """plan of the tiled sweep (schedule 0 = forward, 1 = backward): dict, all zero if none is built"""
         a = (C.c_int64 * 8)()

@@ -18,13 +18,18 @@ def _op_entry(level, opname, dA, epi, what):
     vec = _vec_bytes(epi, nr, nc, vb)
     alg = (vb + 4) * nnz + 4 * (nr + 1) + vec
     npat, nval = dA.row_patterns(), dA.value_codes()
-    if npat:
+    masks = dA.row_masks() if npat else {"entries": 0}
+    grid = int(inf["row_blocks"])
+    if npat and masks["entries"] and epi != "SUMSQ":
+        streamed, form = nr + vec, ("row masks, lattice tiles 64 x 4 x %d (1 byte per row)" % masks["planes_per_lane"]) if masks["lattice"] else "row masks (1 byte per row)"
+        grid = int(masks["launch_grid"])
+    elif npat:
         streamed, form = nr + vec, "row patterns (1 byte per row)"
     elif nval:
         streamed, form = 3 * nnz + 4 * (nr + 1) + vec, "16-bit columns + 8-bit value codes (3 bytes per entry)"
     else:
         streamed, form = (vb + 2) * nnz + 4 * (nr + 1) + vec, "16-bit columns + values as stored (10 bytes per entry)"
-    return {"family": "csr", "epi": epi, "grid": int(inf["row_blocks"]), "level": level, "op": opname, "what": what,
+    return {"family": "csr", "epi": epi, "grid": grid, "level": level, "op": opname, "what": what,
             "rows": int(nr), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": int(streamed), "format": form}
 
 

@@ -28,6 +28,12 @@ def short(name):
     m = re.search(r"csr_(rowgather|rowpat)_kernel<(\w+), *(\d+)>", name)
     if m:
         return f"csr_{m.group(1)}<{m.group(2)},{EPI[int(m.group(3))]}>"
+    m = re.search(r"csr_rowmask3d_kernel<(\w+), *(\d+), *(\d+), *(\w+)>", name)
+    if m:
+        return f"csr_rowmask3d<{m.group(1)},{EPI[int(m.group(2))]},kz{m.group(3)}>"
+    m = re.search(r"csr_rowmask_kernel<(\w+), *(\d+), *(\d+), *(\d+)>", name)
+    if m:
+        return f"csr_rowmask<{m.group(1)},{EPI[int(m.group(2))]},nu{m.group(3)}>"
     m = re.search(r"gs_lane_kernel<(\w+), *(\d+), *(\d+), *(\d+), *(\w+)>", name)
     if m:
         return f"gs_lane<{m.group(1)},{EPI[int(m.group(2))]},L{m.group(3)},K{m.group(4)},{'oneXCD' if m.group(5) in ('true', '1') else 'chip'}>"
@@ -40,7 +46,7 @@ def short(name):
 
 def family(k):
     if k.startswith("csr_"):
-        m = re.search(r",(\w+?)(,npl\d)?>", k)
+        m = re.search(r",(\w+?)(,npl\d|,kz\d|,nu\d)?>", k)
         return "csr", (m.group(1) if m else None)
     if k.startswith("gs_lane"):
         return "gs_lane", None
