@@ -1069,6 +1069,48 @@ __global__ __launch_bounds__(BLK) void csr_rowmask_kernel(const StreamArgs<T> a,
     else row_finish<T, EPI, 0>(a, q, s, sq);
 }
 
+// the residual's sum of squares in the row-mask form: the launch keeps the row ranges of the other forms (one partial per
+// range, summed in the same order: the norm carries the table kernel's bits), lane l takes rows r0 + l, r0 + l + BLK, ...
+template <typename T, int NU>
+__global__ __launch_bounds__(BLK) void csr_rowmask_sumsq_kernel(const StreamArgs<T> a, const RowMaskArgs<T> m)
+{
+    __shared__ double red[BLK / 64];
+    const int blk = (int)blockIdx.x;
+    const int4 meta = a.blkmeta[blk];
+    double sq = 0.0;
+    for (int r = meta.x + (int)threadIdx.x; r < meta.y; r += BLK) {
+        const unsigned mk = __builtin_nontemporal_load(m.mask + r);
+        const T b = __builtin_nontemporal_load(a.b + r);
+        T xv[NU];
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            int c = r + m.off[k];
+            c = c < 0 ? 0 : c;
+            c = c < m.ncols ? c : m.ncols - 1;
+            xv[k] = a.x[c];
+        }
+        T s = T(0);
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            if ((mk >> k) & 1u) {
+                const T pr = m.val[k] * xv[k];
+                s += pr;
+            }
+        }
+        if (!mk) {
+            const int lo = a.Ap[r], hi = a.Ap[r + 1];
+            for (int p = lo; p < hi; ++p) {
+                const T pr = a.Ax[p] * a.x[a.Aj[p]];
+                s += pr;
+            }
+        }
+        const T t = b - s;
+        sq += (double)t * (double)t;
+    }
+    const double tot = block_sum(sq, red);
+    if (threadIdx.x == 0) a.partial[blk] = tot;
+}
+
 // ---- row-mask form on a lattice (round 4).  csr_rowmask_kernel asks the L2 for five 128-byte lines of x per 16 rows (the row's
 // own line and its neighbours' one lattice line and one plane up and down); the counters say it is bound by the misses a
 // CU's L1 can keep in flight, not by bytes.  When the longest list is (-P, -L, -1, 0, +1, +L, +P) -- the 7-point

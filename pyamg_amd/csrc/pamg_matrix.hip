@@ -136,6 +136,15 @@ int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamA
     }
     m.nrows = (int)A->nrows; m.ncols = (int)A->ncols;
     m.xcd_chunk = 0; m.xcd_share = 0;
+    if (epi == EPI_SUMSQ) {                                        // one partial per row range, as in every other form
+        if (a.blkmap || !a.partial || !a.blkmeta) return 1;
+        const int nu_ = A->rm_nu <= 3 ? 3 : A->rm_nu <= 5 ? 5 : A->rm_nu <= 7 ? 7 : 8;
+        if (nu_ == 3) hipLaunchKernelGGL((csr_rowmask_sumsq_kernel<T, 3>), dim3(a.nblk), dim3(BLK), 0, s, a, m);
+        else if (nu_ == 5) hipLaunchKernelGGL((csr_rowmask_sumsq_kernel<T, 5>), dim3(a.nblk), dim3(BLK), 0, s, a, m);
+        else if (nu_ == 7) hipLaunchKernelGGL((csr_rowmask_sumsq_kernel<T, 7>), dim3(a.nblk), dim3(BLK), 0, s, a, m);
+        else hipLaunchKernelGGL((csr_rowmask_sumsq_kernel<T, 8>), dim3(a.nblk), dim3(BLK), 0, s, a, m);
+        return (int)hipGetLastError();
+    }
     // a 7-point lattice whose extents fit the 64 x 4 x kz tile: csr_rowmask3d_kernel
     if (A->use_rowpat == 1) {
         RowMaskLattice g;

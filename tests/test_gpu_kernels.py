@@ -976,6 +976,10 @@ def test_row_mask_kernels_are_bit_identical(dtype):
             dA.jacobi(dj, db, dw, 0.8, iterations=2)
             outs.append(dj.download())
             dj.free(); dw.free()
+            o = capi.DeviceArray(1, np.float64)
+            dA.resid_sumsq(dx, db, o)                 # one partial per row range in every form: the norm's bits agree too
+            outs.append(o.download())
+            o.free()
             return outs
         dA.tune(rowpat=0)
         ref = everything()

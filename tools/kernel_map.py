@@ -20,9 +20,10 @@ def _op_entry(level, opname, dA, epi, what):
     npat, nval = dA.row_patterns(), dA.value_codes()
     masks = dA.row_masks() if npat else {"entries": 0}
     grid = int(inf["row_blocks"])
-    if npat and masks["entries"] and epi != "SUMSQ":
-        streamed, form = nr + vec, ("row masks, lattice tiles 64 x 4 x %d (1 byte per row)" % masks["planes_per_lane"]) if masks["lattice"] else "row masks (1 byte per row)"
-        grid = int(masks["launch_grid"])
+    if npat and masks["entries"]:
+        streamed, form = nr + vec, ("row masks, lattice tiles 64 x 4 x %d (1 byte per row)" % masks["planes_per_lane"]) if (masks["lattice"] and epi != "SUMSQ") else "row masks (1 byte per row)"
+        if epi != "SUMSQ":
+            grid = int(masks["launch_grid"])
     elif npat:
         streamed, form = nr + vec, "row patterns (1 byte per row)"
     elif nval:

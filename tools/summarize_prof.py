@@ -31,6 +31,9 @@ def short(name):
     m = re.search(r"csr_rowmask3d_kernel<(\w+), *(\d+), *(\d+), *(\w+)>", name)
     if m:
         return f"csr_rowmask3d<{m.group(1)},{EPI[int(m.group(2))]},kz{m.group(3)}>"
+    m = re.search(r"csr_rowmask_sumsq_kernel<(\w+), *(\d+)>", name)
+    if m:
+        return f"csr_rowmask<{m.group(1)},SUMSQ,nu{m.group(2)}>"
     m = re.search(r"csr_rowmask_kernel<(\w+), *(\d+), *(\d+), *(\d+)>", name)
     if m:
         return f"csr_rowmask<{m.group(1)},{EPI[int(m.group(2))]},nu{m.group(3)}>"
