@@ -1121,8 +1121,8 @@ __global__ __launch_bounds__(BLK) void csr_rowmask_sumsq_kernel(const StreamArgs
 // line instead of 5.  Same masks, same products, same order of additions: bit-identical.
 // Host guarantees: L % 64 == 0, (P / L) % 4 == 0, (nrows / P) % KZ == 0, nrows % P == 0.
 
-template <typename T, int EPI, int KZ, bool NT>
-__global__ __launch_bounds__(BLK) void csr_rowmask3d_kernel(const StreamArgs<T> a, const RowMaskArgs<T> m, const RowMaskLattice g)
+template <typename T, int EPI, int KZ, bool NT, int WY>
+__global__ __launch_bounds__(64 * WY) void csr_rowmask3d_kernel(const StreamArgs<T> a, const RowMaskArgs<T> m, const RowMaskLattice g)
 {
     constexpr bool SKIPD = EpiTraits<EPI>::need_cols;
     constexpr bool NEEDB = (EPI == EPI_RESID || EPI == EPI_AXPBY || EPI == EPI_ACC_AXPBY || EPI >= EPI_JACOBI);

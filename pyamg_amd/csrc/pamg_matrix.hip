@@ -150,10 +150,12 @@ int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamA
         RowMaskLattice g;
         int grid3 = 0;
         const int kz = A->rowmask_kz;
-        if (rowmask_lattice_plan(A->rm_nu, A->rm_off, A->nrows, kz, (A->rowmask_flags & 2) != 0, g, grid3)) {
+        if (rowmask_lattice_plan(A->rm_nu, A->rm_off, A->nrows, kz, (A->rowmask_flags & 2) != 0, false, g, grid3)) {
             const bool nt = A->rowmask_flags & 1;
-#define PAMG_R3K(E, KZ) if (nt) hipLaunchKernelGGL((csr_rowmask3d_kernel<T, E, KZ, true>), dim3(grid3), dim3(BLK), 0, s, a, m, g); \
-                        else hipLaunchKernelGGL((csr_rowmask3d_kernel<T, E, KZ, false>), dim3(grid3), dim3(BLK), 0, s, a, m, g);
+// (eight lattice lines per workgroup, 512 lanes: measured -1 % at 256^3 and +2 % at 512^3, profiles/r04_microbench_rowmask_512.json -- the plan and
+// the CPU replay keep the option, the kernels are instantiated for four)
+#define PAMG_R3W(E, KZ, NT_) hipLaunchKernelGGL((csr_rowmask3d_kernel<T, E, KZ, NT_, 4>), dim3(grid3), dim3(BLK), 0, s, a, m, g);
+#define PAMG_R3K(E, KZ) if (nt) { PAMG_R3W(E, KZ, true) } else { PAMG_R3W(E, KZ, false) }
 #define PAMG_R3(E) case E: if (kz == 2) { PAMG_R3K(E, 2) } else if (kz == 4) { PAMG_R3K(E, 4) } else { PAMG_R3K(E, 8) } return (int)hipGetLastError();
             switch (epi) {
                 PAMG_R3(EPI_SET) PAMG_R3(EPI_ACC) PAMG_R3(EPI_RESID) PAMG_R3(EPI_AXPBY) PAMG_R3(EPI_ACC_AXPBY)
@@ -162,6 +164,7 @@ int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamA
             }
 #undef PAMG_R3
 #undef PAMG_R3K
+#undef PAMG_R3W
         }
     }
     int grid = (int)((A->nrows + BLK - 1) / BLK);
@@ -1514,10 +1517,14 @@ int vec_dot(int dtype, int64_t n, const void *x, const void *y, double *scratch,
     return (int)hipGetLastError();
 }
 
+// one element per lane, no loop: the access shape that reaches the HBM ceiling (6.3 TB/s; a grid-stride loop over 8 192 workgroups
+// gets 5.0 -- profiles/r04_microbench_bw_shapes.json); the kernels keep their loops for vectors beyond 2^31 / 4 elements
+static int vgrid(int64_t n) { return (int)std::min<int64_t>(1 << 21, std::max<int64_t>(1, (n + BLK - 1) / BLK)); }
+
 int vec_mul(int dtype, int64_t n, const void *a, const void *b, void *y, hipStream_t s)
 {
     if (n <= 0) return PAMG_OK;
-    const int grid = (int)std::min<int64_t>(8192, (n + BLK - 1) / BLK);
+    const int grid = vgrid(n);
     if (dtype == PAMG_F64)
         hipLaunchKernelGGL((vec_mul_kernel<double>), dim3(grid), dim3(BLK), 0, s, n, (const double *)a, (const double *)b, (double *)y);
     else
@@ -1646,7 +1653,7 @@ int kaczmarz_sweep(pamg_matrix_s *L, bool nr, void *v, const void *b, const void
 int vec_scatter(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s)
 {
     if (n <= 0) return PAMG_OK;
-    const int grid = (int)std::min<int64_t>(8192, (n + BLK - 1) / BLK);
+    const int grid = vgrid(n);
     if (dtype == PAMG_F64)
         hipLaunchKernelGGL((vec_scatter_kernel<double>), dim3(grid), dim3(BLK), 0, s, n, idx, (const double *)src, (double *)dst);
     else
@@ -1657,7 +1664,7 @@ int vec_scatter(int dtype, int64_t n, const int *idx, const void *src, void *dst
 int vec_copy_indexed(int dtype, int64_t n, const int *idx, const void *src, void *dst, hipStream_t s)
 {
     if (n <= 0) return PAMG_OK;
-    const int grid = (int)std::min<int64_t>(8192, (n + BLK - 1) / BLK);
+    const int grid = vgrid(n);
     if (dtype == PAMG_F64)
         hipLaunchKernelGGL((vec_copy_indexed_kernel<double>), dim3(grid), dim3(BLK), 0, s, n, idx, (const double *)src, (double *)dst);
     else
@@ -1733,7 +1740,6 @@ int vec_maxratio(int dtype, int64_t n, const void *u, const void *x, double *scr
     return (int)hipGetLastError();
 }
 
-static int vgrid(int64_t n) { return (int)std::min<int64_t>(8192, std::max<int64_t>(1, (n + BLK - 1) / BLK)); }
 
 int vec_axpy(int dtype, int64_t n, double a, const void *x, void *y, hipStream_t s)
 {
@@ -2004,7 +2010,7 @@ int pamg_matrix_row_masks(pamg_matrix_t A, long long info[8])
     info[7] = (A->nrows + BLK - 1) / BLK;
     RowMaskLattice g;
     int grid3 = 0;
-    if (A->use_rowpat == 1 && rowmask_lattice_plan(A->rm_nu, A->rm_off, A->nrows, A->rowmask_kz, (A->rowmask_flags & 2) != 0, g, grid3)) {
+    if (A->use_rowpat == 1 && rowmask_lattice_plan(A->rm_nu, A->rm_off, A->nrows, A->rowmask_kz, (A->rowmask_flags & 2) != 0, false, g, grid3)) {
         info[2] = 1; info[3] = g.L; info[4] = g.P; info[7] = grid3;
     }
     return PAMG_OK;
@@ -2102,6 +2108,26 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
     }
     A->stream_flags = best_fl;
     if (A->cap != best_cap) { A->cap = best_cap; const int s2 = replan(A); if (st == PAMG_OK) st = s2; }
+    // lattice form of the row masks: planes per lane (the tile's working set against the XCD's L2: 8 on 256^2-row planes, fewer on larger ones)
+    long long rm[8];
+    if (st == PAMG_OK && pamg_matrix_row_masks(A, rm) == PAMG_OK && rm[2]) {
+        const int kz0 = A->rowmask_kz;
+        int best_kz = kz0;
+        float best = 1e30f;
+        for (int kz = 8; kz >= 2 && st == PAMG_OK; kz >>= 1) {
+            A->rowmask_kz = kz;
+            if (pamg_matrix_row_masks(A, rm) != PAMG_OK || !rm[2]) continue;
+            for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
+            hipEventRecord(e0, nullptr);
+            for (int r = 0; r < 8 && st == PAMG_OK; ++r) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
+            hipEventRecord(e1, nullptr);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (st == PAMG_OK && ms < best * 0.98f) { best = ms; best_kz = kz; }
+        }
+        A->rowmask_kz = best_kz;
+    }
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(x); hipFree(y);
     return st;
@@ -2261,7 +2287,7 @@ int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, v
 {
     if (n < 0 || (n > 0 && (!idx || !src || !dst))) return PAMG_E_ARG;
     if (n == 0) return PAMG_OK;
-    const int grid = (int)std::min<int64_t>(8192, (n + BLK - 1) / BLK);
+    const int grid = vgrid(n);
     if (dtype == PAMG_F64)
         hipLaunchKernelGGL((vec_gather_kernel<double>), dim3(grid), dim3(BLK), 0, (hipStream_t)s, n, idx, (const double *)src, (double *)dst);
     else if (dtype == PAMG_F32)

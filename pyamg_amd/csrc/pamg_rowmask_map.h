@@ -26,24 +26,26 @@ PAMG_HD int rowmask_linear_block(int b, int chunk, int share)
     return b;
 }
 
-// lattice form: the longest list is (-P, -L, -1, 0, +1, +L, +P); a workgroup takes 64 x 4 x kz rows
+// lattice form: the longest list is (-P, -L, -1, 0, +1, +L, +P); a workgroup takes 64 x wy x kz rows (wy waves)
 struct RowMaskLattice {
     int L, P;
-    int tiles_x, tiles_y;        // tiles of 64 rows and of 4 lattice lines per plane
+    int wy;                      // lattice lines (= waves) per workgroup: 4 or 8
+    int tiles_x, tiles_y;        // tiles of 64 rows and of wy lattice lines per plane
     int slab;                    // > 0: tiles_y / 8 -- XCD j (blockIdx & 7) takes the j-th eighth of the lines of every plane
 };
 
 // true: the lattice form applies (fills g); grid = workgroups to launch
-inline bool rowmask_lattice_plan(int nu, const int *off, int64_t nrows, int kz, bool xcd_slabs, RowMaskLattice &g, int &grid)
+inline bool rowmask_lattice_plan(int nu, const int *off, int64_t nrows, int kz, bool xcd_slabs, bool eight_lines, RowMaskLattice &g, int &grid)
 {
     if (nu != 7 || off[3] != 0 || off[2] != -1 || off[4] != 1 || off[5] <= 1 || off[1] != -off[5] || off[6] <= off[5] || off[0] != -off[6]) return false;
     if (kz != 2 && kz != 4 && kz != 8) return false;
     g.L = off[5]; g.P = off[6];
     if (g.L % 64 != 0 || g.P % g.L != 0 || (g.P / g.L) % 4 != 0 || nrows % g.P != 0 || (nrows / g.P) % kz != 0) return false;
     if (nrows / RMASK_BLK / kz > 0x7fffffff / 2) return false;
-    g.tiles_x = g.L / 64; g.tiles_y = (g.P / g.L) / 4;
+    g.wy = (eight_lines && (g.P / g.L) % 8 == 0) ? 8 : 4;
+    g.tiles_x = g.L / 64; g.tiles_y = (g.P / g.L) / g.wy;
     g.slab = (xcd_slabs && g.tiles_y % 8 == 0) ? g.tiles_y / 8 : 0;
-    grid = (int)(nrows / ((int64_t)RMASK_BLK * kz));
+    grid = (int)(nrows / ((int64_t)64 * g.wy * kz));
     return true;
 }
 
@@ -64,7 +66,7 @@ PAMG_HD int rowmask_tile_row0(const RowMaskLattice &g, int kz, int bid, int wave
         ty = t / g.tiles_x;
         tx = t - ty * g.tiles_x;
     }
-    return tz * kz * g.P + (ty * 4 + wave) * g.L + tx * 64 + lane;
+    return tz * kz * g.P + (ty * g.wy + wave) * g.L + tx * 64 + lane;
 }
 
 }  // namespace pamg

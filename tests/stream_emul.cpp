@@ -173,15 +173,16 @@ int rowmask_emul_f64(int n, const int *Ap, const int *Aj, const double *Ax, cons
         for (int r = 0; r < n; ++r) miss += seen[(size_t)r] != 1;
     }
     // ---- lattice form, both workgroup orders
-    for (int slabs = 0; slabs < 2; ++slabs) {
+    for (int var = 0; var < 4; ++var) {
+        const int slabs = var & 1, eight = var >> 1;
         RowMaskLattice g;
         int grid = 0;
-        if (!rowmask_lattice_plan(M.nu, M.off, n, kz, slabs != 0, g, grid)) continue;
-        if (slabs && g.slab == 0) continue;
-        info[2] = 1; info[5] = g.L; info[6] = g.P; info[7] = grid;
+        if (!rowmask_lattice_plan(M.nu, M.off, n, kz, slabs != 0, eight != 0, g, grid)) continue;
+        if ((slabs && g.slab == 0) || (eight && g.wy != 8)) continue;
+        info[2] = 1; info[5] = g.L; info[6] = g.P; if (!eight) info[7] = grid;
         std::fill(seen.begin(), seen.end(), 0);
         for (int b = 0; b < grid; ++b)
-            for (int w = 0; w < 4; ++w)
+            for (int w = 0; w < g.wy; ++w)
                 for (int l = 0; l < 64; ++l) {
                     const int r0 = rowmask_tile_row0(g, kz, b, w, l);
                     for (int j = 0; j < kz; ++j) {

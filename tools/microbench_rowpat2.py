@@ -63,11 +63,11 @@ for rp in ([3, 4] if tag.startswith("rowmask") else [3, 2]):
         for fl in (0, 2):
             run(f"{names[rp]}_flags{fl}", stream_flags=fl, rowpat=rp)
     else:
-        for fl in (0, 1, 2, 3, 5, 11):
+        for fl in (0, 3):
             run(f"rowmask_flags{fl}", rowmask_flags=fl, rowpat=rp)
 if tag.startswith("rowmask"):
-    for kz in (2, 4, 8):
-        for fl in (0, 1, 2, 3):
+    for kz in (4, 8):
+        for fl in (3, 19):
             run(f"rowmask3d_kz{kz}_flags{fl}", rowmask_flags=fl, rowpat=1, rowmask_kz=kz)
 if not tag.startswith("rowmask"):
     for mr, cap in ((256, 2048), (1024, 7168), (2048, 12288)):

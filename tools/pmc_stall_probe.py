@@ -4,9 +4,10 @@ kernel trace only) over tools/spmv_pmc.py.  Not product code."""
 import csv, glob, json, os, subprocess, sys, tempfile
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-grid = ["256", "256", "256"]
+grid = os.environ.get("PMC_GRID", "256,256,256").split(",")
 LEVEL1 = "--level1" in sys.argv
-variants = [a for a in sys.argv[1:] if a != "--level1"] or (["level1"] if LEVEL1 else ["--val8=1", "--val8=0"])
+variants = [a.replace("+", " ") for a in sys.argv[1:] if a != "--level1"] or (["level1"] if LEVEL1 else ["--val8=1", "--val8=0"])
+GROUPS_SHORT = os.environ.get("PMC_SHORT", "0") == "1"
 groups = [["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVES_sum"],
           ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"],
           ["TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_TCR_TCP_STALL_CYCLES_sum"],
@@ -15,6 +16,8 @@ groups = [["GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVES_sum"],
           ["SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"],
           ["SQ_INST_LEVEL_VMEM", "SQ_WAVE_CYCLES", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU"],
           ["MemUnitStalled", "VALUBusy", "LDSBankConflict", "OccupancyPercent"]]
+if GROUPS_SHORT:
+    groups = [groups[0], groups[1], groups[3]]
 out = {}
 for var in variants:
     rec = {}
@@ -25,7 +28,7 @@ for var in variants:
         else:
             cmd = ["rocprofv3", "--pmc"] + g + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, str(ROOT / "tools" / "spmv_pmc.py")] + grid + var.split() + ["--launches=4"]
         try:
-            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
         except Exception as e:      # noqa: BLE001
             rec[",".join(g)] = repr(e)
             continue
