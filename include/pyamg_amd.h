@@ -420,6 +420,14 @@ int pamg_matrix_flow_error(pamg_matrix_t A, int *error);
 #define PAMG_SPMV_ACC_AXPBY 4  /* y += c*v + A x        (Horner last step fused with x += h) */
 int pamg_matrix_spmv(pamg_matrix_t A, int mode, const void *x, const void *b_or_v, double c,
                      void *y, pamg_stream_t s);
+/* Row shards (what csrc/pamg_dist.hip drives; exposed for integrators with their own transport): the operator is a block of
+ * rows in local numbering [owned columns | halo columns].  pamg_matrix_split_ranges sorts its row ranges into those that read
+ * owned columns only (part 1, the interior) and those that read the halo (part 2, the boundary); pamg_matrix_spmv_part runs
+ * one part (0 = every range) -- interior while the halo values travel, boundary once they have landed.  Same arithmetic
+ * per row as pamg_matrix_spmv: the two parts together write exactly its bits. */
+int pamg_matrix_split_ranges(pamg_matrix_t A, int64_t n_owned_cols);
+int pamg_matrix_spmv_part(pamg_matrix_t A, int part, int mode, const void *x, const void *b_or_v, double c, void *y,
+                          pamg_stream_t stream);
 /* ||b - A x||_2^2 without storing the residual; result (one value of dtype f64) written
  * to DEVICE address out_sumsq (multilevel.py:545,567 convergence check). */
 int pamg_matrix_resid_sumsq(pamg_matrix_t A, const void *x, const void *b, double *out_sumsq,

@@ -131,6 +131,8 @@ def _declare(lib):
     f("pamg_matrix_lane_profile", _vp, _i, _vp, C.c_int64, P(C.c_int64))
     f("pamg_matrix_autotune", _vp, _i)
     f("pamg_matrix_spmv", _vp, _i, _vp, _vp, _d, _vp, _vp)
+    f("pamg_matrix_split_ranges", _vp, C.c_int64)
+    f("pamg_matrix_spmv_part", _vp, _i, _i, _vp, _vp, _d, _vp, _vp)
     f("pamg_matrix_resid_sumsq", _vp, _vp, _vp, _vp, _vp)
     f("pamg_matrix_jacobi", _vp, _vp, _vp, _vp, _d, _i, _vp)
     f("pamg_l1_cache_clear")

@@ -219,6 +219,7 @@ struct pamg_matrix_s {
     int *d_part[2] = {nullptr, nullptr};   // row shards (pamg_dist.hip): row ranges that read owned columns only / that read the halo
     int npart[2] = {0, 0};
     int64_t part_cols = -1;          //   owned columns the split was made for (-1 = none)
+    int64_t part_row0[2] = {-1, -1}, part_row1[2] = {-1, -1};   //   rows [row0, row1) of a part whose ranges are consecutive (else -1)
     int4 *d_blkmeta = nullptr;
     double *d_partial = nullptr;     // nblk doubles (sum-of-squares partials)
     pamg::GsSchedule *gs[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd, bwd, 2 custom

@@ -975,7 +975,8 @@ struct RowMaskArgs {
     const unsigned char *mask;   // [nrows]
     int off[8];
     T val[8];
-    int nrows, ncols;
+    int nrows, ncols;            // nrows: END of the rows this launch takes (the operator's rows, or a window's end)
+    int row0;                    // first row of this launch (0, or the start of a window of rows: the interior rows of a row shard)
     int xcd_chunk;               // > 0: workgroup b works on rows of chunk (b & 7), so every XCD streams one contiguous eighth
     int xcd_share;               // > 0: workgroups per plane and XCD (plane-by-plane order, see the kernel)
 };
@@ -1005,7 +1006,7 @@ __global__ __launch_bounds__(BLK) void csr_rowmask_kernel(const StreamArgs<T> a,
     // largest offset), planes in order -- the chip works on one plane at a time (one compact window of the HBM) and a row's
     // neighbours one plane up and down were, or will be, gathered through the same XCD's L2
     const int blk = rowmask_linear_block((int)blockIdx.x, m.xcd_chunk, m.xcd_share);
-    const int r = blk * BLK + (int)threadIdx.x;
+    const int r = m.row0 + blk * BLK + (int)threadIdx.x;
     const int rc = r < m.nrows ? r : m.nrows - 1;
     const unsigned mk = NT ? __builtin_nontemporal_load(m.mask + rc) : m.mask[rc];
     RowPre<T> q;
@@ -1129,7 +1130,7 @@ __global__ __launch_bounds__(64 * WY) void csr_rowmask3d_kernel(const StreamArgs
     constexpr bool NEEDY = (EPI == EPI_ACC || EPI == EPI_ACC_AXPBY || EPI == EPI_ACCSEQ);
     constexpr bool NEEDJ = (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B);
     const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    const int r0 = rowmask_tile_row0(g, KZ, (int)blockIdx.x, wave, lane);
+    const int r0 = m.row0 + rowmask_tile_row0(g, KZ, (int)blockIdx.x, wave, lane);
     const int last = m.ncols - 1;
     T xc[KZ + 2], xm1[KZ], xp1[KZ], xmL[KZ], xpL[KZ], bb[KZ], yy[KZ], dd[KZ];
     unsigned mk[KZ];

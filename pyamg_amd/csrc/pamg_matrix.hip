@@ -124,9 +124,12 @@ int launch_rowpat(int epi, int grid, const pamg_matrix_s *A, hipStream_t s, Stre
 
 // row-mask form (csr_rowmask_kernel): the whole operator, one row per lane; 1 = not available for this launch
 template <typename T>
-int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamArgs<T> &a)
+int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamArgs<T> &a, int64_t row0 = 0, int64_t row1 = -1)
 {
     if (!A->d_pmask || A->rm_nu < 1 || A->rm_nu > 8) return 1;
+    if (row1 < 0) row1 = A->nrows;
+    if (row0 < 0 || row1 <= row0 || row1 > A->nrows) return 1;
+    const int64_t nwin = row1 - row0;                              // rows of this launch: all of them, or a window (interior rows of a shard)
     RowMaskArgs<T> m;
     m.mask = A->d_pmask;
     for (int k = 0; k < 8; ++k) {
@@ -134,10 +137,10 @@ int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamA
         if constexpr (sizeof(T) == 8) std::memcpy(&m.val[k], &A->rm_val[k], 8);
         else { const unsigned v = (unsigned)A->rm_val[k]; std::memcpy(&m.val[k], &v, 4); }
     }
-    m.nrows = (int)A->nrows; m.ncols = (int)A->ncols;
+    m.nrows = (int)row1; m.ncols = (int)A->ncols; m.row0 = (int)row0;
     m.xcd_chunk = 0; m.xcd_share = 0;
     if (epi == EPI_SUMSQ) {                                        // one partial per row range, as in every other form
-        if (a.blkmap || !a.partial || !a.blkmeta) return 1;
+        if (a.blkmap || !a.partial || !a.blkmeta || nwin != A->nrows) return 1;
         const int nu_ = A->rm_nu <= 3 ? 3 : A->rm_nu <= 5 ? 5 : A->rm_nu <= 7 ? 7 : 8;
         if (nu_ == 3) hipLaunchKernelGGL((csr_rowmask_sumsq_kernel<T, 3>), dim3(a.nblk), dim3(BLK), 0, s, a, m);
         else if (nu_ == 5) hipLaunchKernelGGL((csr_rowmask_sumsq_kernel<T, 5>), dim3(a.nblk), dim3(BLK), 0, s, a, m);
@@ -145,12 +148,15 @@ int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamA
         else hipLaunchKernelGGL((csr_rowmask_sumsq_kernel<T, 8>), dim3(a.nblk), dim3(BLK), 0, s, a, m);
         return (int)hipGetLastError();
     }
-    // a 7-point lattice whose extents fit the 64 x 4 x kz tile: csr_rowmask3d_kernel
+    // a 7-point lattice whose extents fit the 64 x 4 x kz tile: csr_rowmask3d_kernel (a window must start on a plane; its planes
+    // per lane: the largest of kz, kz / 2, ... that divides its planes)
     if (A->use_rowpat == 1) {
         RowMaskLattice g;
         int grid3 = 0;
-        const int kz = A->rowmask_kz;
-        if (rowmask_lattice_plan(A->rm_nu, A->rm_off, A->nrows, kz, (A->rowmask_flags & 2) != 0, false, g, grid3)) {
+        int kz = A->rowmask_kz;
+        const int plane_ = A->rm_nu == 7 ? A->rm_off[6] : 0;
+        while (kz > 2 && plane_ > 0 && nwin % plane_ == 0 && (nwin / plane_) % kz != 0) kz >>= 1;
+        if ((plane_ <= 0 || row0 % plane_ == 0) && rowmask_lattice_plan(A->rm_nu, A->rm_off, nwin, kz, (A->rowmask_flags & 2) != 0, false, g, grid3)) {
             const bool nt = A->rowmask_flags & 1;
 // (eight lattice lines per workgroup, 512 lanes: measured -1 % at 256^3 and +2 % at 512^3, profiles/r04_microbench_rowmask_512.json -- the plan and
 // the CPU replay keep the option, the kernels are instantiated for four)
@@ -167,9 +173,9 @@ int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamA
 #undef PAMG_R3W
         }
     }
-    int grid = (int)((A->nrows + BLK - 1) / BLK);
+    int grid = (int)((nwin + BLK - 1) / BLK);
     const int plane = A->rm_off[A->rm_nu - 1];                   // the largest offset: rows per plane of a lattice
-    if ((A->rowmask_flags & 2) && plane >= 8 * BLK && plane % (8 * BLK) == 0 && A->nrows % plane == 0) m.xcd_share = plane / (8 * BLK);
+    if ((A->rowmask_flags & 2) && plane >= 8 * BLK && plane % (8 * BLK) == 0 && nwin % plane == 0) m.xcd_share = plane / (8 * BLK);
     else if (A->rowmask_flags & 4) { m.xcd_chunk = (grid + 7) >> 3; grid = 8 * m.xcd_chunk; }
     const int nu = A->rm_nu <= 3 ? 3 : A->rm_nu <= 5 ? 5 : A->rm_nu <= 7 ? 7 : 8;
     const int near = nu / 2;
@@ -319,7 +325,7 @@ static int plan_rowpat(pamg_matrix_s *A, const unsigned char *code, const U *dic
     // the same rows as masks over the longest list, when the lists allow it (csr_rowmask_kernel)
     RowMaskPlan M;
     std::vector<unsigned char> mask;
-    if (A->nrows == A->ncols && plan_row_masks(A->nrows, pid, keys, M, mask)) {
+    if (A->ncols >= A->nrows && plan_row_masks(A->nrows, pid, keys, M, mask)) {
         PAMG_TRY(upload_raw((void **)&A->d_pmask, mask.data(), mask.size(), 1, &bytes));
         A->rm_nu = M.nu;
         A->rm_walked = M.walked;
@@ -925,7 +931,7 @@ void matrix_drop_value_codes(pamg_matrix_s *A) { if (A) drop_val8(A); }
 int matrix_split_ranges(pamg_matrix_s *A, int64_t n_owned_cols)
 {
     if (!A || n_owned_cols < 0) return PAMG_E_ARG;
-    for (int k = 0; k < 2; ++k) { if (A->d_part[k]) { hipFree(A->d_part[k]); A->d_part[k] = nullptr; } A->npart[k] = 0; }
+    for (int k = 0; k < 2; ++k) { if (A->d_part[k]) { hipFree(A->d_part[k]); A->d_part[k] = nullptr; } A->npart[k] = 0; A->part_row0[k] = A->part_row1[k] = -1; }
     A->part_cols = -1;
     if (A->nblk == 0 || A->h_Ap.empty()) { A->part_cols = n_owned_cols; return PAMG_OK; }
     std::vector<int4> blk;
@@ -947,6 +953,12 @@ int matrix_split_ranges(pamg_matrix_s *A, int64_t n_owned_cols)
     for (int k = 0; k < 2; ++k) {
         A->npart[k] = (int)part[k].size();
         PAMG_TRY(upload(&A->d_part[k], part[k].data(), part[k].size(), &A->bytes));
+        // consecutive ranges = one window of rows (the interior planes of a slab shard): the row-mask kernels take it without a range list
+        A->part_row0[k] = A->part_row1[k] = -1;
+        if (!part[k].empty() && part[k].back() - part[k].front() + 1 == (int)part[k].size()) {
+            A->part_row0[k] = blk[(size_t)part[k].front()].x;
+            A->part_row1[k] = blk[(size_t)part[k].back()].y;
+        }
     }
     A->part_cols = n_owned_cols;
     return PAMG_OK;
@@ -977,6 +989,12 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
             a.flags = A->stream_flags & ~2;
             a.nblk = n; a.blkmap = A->d_part[part - 1];
             if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+            if (rowp && A->use_rowpat == 1 && epi != EPI_SUMSQ && part == 1 && A->part_row0[0] >= 0) {     // the interior rows as one window
+                StreamArgs<double> aw = a;
+                aw.blkmap = nullptr;
+                const int st = launch_rowmask<double>(epi, A, s, aw, A->part_row0[0], A->part_row1[0]);
+                if (st != 1) return st;
+            }
             if (rowp) { const int st = launch_rowpat<double>(epi, n, A, s, a); if (st != 1) return st; }
             if (rowg) { const int st = launch_rowgather<double>(epi, n, A->cap, A->nvdict, s, a); if (st != 1) return st; }
             return launch_any<double>(epi, A->npl, n, lds, s, a);
@@ -985,6 +1003,12 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
         a.flags = A->stream_flags & ~2;
         a.nblk = n; a.blkmap = A->d_part[part - 1];
         if (idx16) { a.Aj16 = A->d_Aj16; a.wbase = A->d_wbase; if (val8) { a.Ax8 = A->d_Ax8; a.vdict = (decltype(a.vdict))A->d_vdict; a.nvd = A->nvdict; } }
+        if (rowp && A->use_rowpat == 1 && epi != EPI_SUMSQ && part == 1 && A->part_row0[0] >= 0) {     // the interior rows as one window
+            StreamArgs<float> aw = a;
+            aw.blkmap = nullptr;
+            const int st = launch_rowmask<float>(epi, A, s, aw, A->part_row0[0], A->part_row1[0]);
+            if (st != 1) return st;
+        }
         if (rowp) { const int st = launch_rowpat<float>(epi, n, A, s, a); if (st != 1) return st; }
         if (rowg) { const int st = launch_rowgather<float>(epi, n, A->cap, A->nvdict, s, a); if (st != 1) return st; }
         return launch_any<float>(epi, A->npl, n, lds, s, a);
@@ -2251,6 +2275,29 @@ int pamg_matrix_spmv(pamg_matrix_t A, int mode, const void *x, const void *b_or_
     }
     if (mode >= PAMG_SPMV_RESID && !b_or_v) return PAMG_E_ARG;
     return stream_launch(A, epi, x, b_or_v, y, c, 0.0, nullptr, (hipStream_t)s);
+}
+
+int pamg_matrix_split_ranges(pamg_matrix_t A, int64_t n_owned_cols)
+{
+    if (!A) return PAMG_E_ARG;
+    if (A->borrowed > 0) return PAMG_E_STATE;
+    return matrix_split_ranges(A, n_owned_cols);
+}
+
+int pamg_matrix_spmv_part(pamg_matrix_t A, int part, int mode, const void *x, const void *b_or_v, double c, void *y, pamg_stream_t s)
+{
+    if (!A || !x || !y || part < 0 || part > 2) return PAMG_E_ARG;
+    int epi;
+    switch (mode) {
+        case PAMG_SPMV_SET: epi = EPI_SET; break;
+        case PAMG_SPMV_ACC: epi = EPI_ACC; break;
+        case PAMG_SPMV_RESID: epi = EPI_RESID; break;
+        case PAMG_SPMV_AXPBY: epi = EPI_AXPBY; break;
+        case PAMG_SPMV_ACC_AXPBY: epi = EPI_ACC_AXPBY; break;
+        default: return PAMG_E_ARG;
+    }
+    if (mode >= PAMG_SPMV_RESID && !b_or_v) return PAMG_E_ARG;
+    return stream_launch_part(A, part, epi, x, b_or_v, y, c, 0.0, nullptr, (hipStream_t)s);
 }
 
 int pamg_matrix_resid_sumsq(pamg_matrix_t A, const void *x, const void *b, double *out_sumsq,

@@ -162,9 +162,18 @@ class DeviceMatrix:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 
     # -- kernels on DeviceArray operands
-    def spmv(self, mode, x, y, b=None, c=0.0, stream=None):
+    def spmv(self, mode, x, y, b=None, c=0.0, stream=None, part=None):
+        """y (op)= A x; part = 1 / 2: only the row ranges that read owned columns / the halo (after split_ranges)"""
+        if part is not None:
+            capi.check(capi.lib().pamg_matrix_spmv_part(self.handle, int(part), mode, x.ptr, b.ptr if b is not None else None,
+                                                        float(c), y.ptr, stream), "pamg_matrix_spmv_part")
+            return
         capi.check(capi.lib().pamg_matrix_spmv(self.handle, mode, x.ptr, b.ptr if b is not None else None,
                                                float(c), y.ptr, stream), "pamg_matrix_spmv")
+
+    def split_ranges(self, n_owned_cols: int):
+        """a row shard in local numbering [owned | halo]: sort the row ranges into interior (part 1) and boundary (part 2)"""
+        capi.check(capi.lib().pamg_matrix_split_ranges(self.handle, int(n_owned_cols)), "pamg_matrix_split_ranges")
 
     def resid_sumsq(self, x, b, out, stream=None):
         capi.check(capi.lib().pamg_matrix_resid_sumsq(self.handle, x.ptr, b.ptr, out.ptr, stream),

@@ -996,6 +996,47 @@ def test_row_mask_kernels_are_bit_identical(dtype):
         dA.free()
 
 
+def test_row_masks_on_a_row_shard():
+    """A slab of a 3-D stencil in local numbering [owned | halo] (what pyamg_amd.dist ships to a rank): the interior ranges are
+    one window of whole planes and run in the row-mask kernels (lattice form where the planes divide), the boundary ranges
+    keep the range-list kernels; interior + boundary together = the global product's rows, bit for bit, in every form."""
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(21)
+    nz, ny, nx = 44, 32, 64
+    G = sp.csr_array(poisson_csr((nz, ny, nx)))
+    P = ny * nx
+    xg, bg = rng.rand(G.shape[0]), rng.rand(G.shape[0])
+    for z0, z1 in ((2, 36), (2, 42), (0, 34)):         # 32 / 38 / 33 interior planes: lattice form with 8 / 2 planes per lane, linear form
+        lo, hi = z0 * P, z1 * P
+        rows = G[lo:hi].tocsr()
+        halo = np.unique(rows.indices[(rows.indices < lo) | (rows.indices >= hi)])
+        remap = -np.ones(G.shape[0], dtype=np.int64)
+        remap[lo:hi] = np.arange(hi - lo)
+        remap[halo] = (hi - lo) + np.arange(halo.size)
+        L = sp.csr_array((rows.data, remap[rows.indices].astype(np.int32), rows.indptr), shape=(hi - lo, hi - lo + halo.size))
+        xl = np.concatenate([xg[lo:hi], xg[halo]])
+        ref_set, ref_res = (G @ xg)[lo:hi], (bg - G @ xg)[lo:hi]
+        dA = DeviceMatrix(sparse_op(L))
+        # (rows of the plane under the upper halo are regular rows when that halo directly follows the owned rows: z0 = 0)
+        assert dA.row_patterns() > 0 and dA.row_masks()["entries"] == 7 and dA.row_masks()["walked_rows"] == (2 * P if z0 else 0)
+        dA.split_ranges(hi - lo)
+        dx, db = capi.DeviceArray.from_host(xl), capi.DeviceArray.from_host(bg[lo:hi])
+        for tune in (dict(rowpat=1), dict(rowpat=1, rowmask_kz=4, rowmask_flags=0), dict(rowpat=4), dict(rowpat=3), dict(rowpat=0)):
+            dA.tune(**tune)
+            for mode, kw, ref in ((capi.SPMV_SET, {}, ref_set), (capi.SPMV_RESID, dict(b=db), ref_res)):
+                dy = capi.DeviceArray.from_host(np.full(hi - lo, np.nan))
+                dA.spmv(mode, dx, dy, part=1, **kw)
+                part1 = dy.download()
+                dA.spmv(mode, dx, dy, part=2, **kw)
+                both = dy.download()
+                assert np.isnan(part1).sum() > 0 and not np.isnan(both).any()          # the interior alone leaves the boundary rows untouched
+                assert np.array_equal(both, ref), (z0, z1, tune, mode)
+                dA.spmv(mode, dx, dy, **kw)                                           # every range in one launch
+                assert np.array_equal(dy.download(), ref)
+                dy.free()
+        dA.free()
+
+
 def test_16bit_column_stream_is_bit_identical():
     """The whole-operator kernels read the columns as 16-bit window codes where every row range fits four windows of
     16 K columns (tune key 19 switches back to 32-bit columns): same bits either way, on a banded stencil (three
