@@ -6,6 +6,7 @@
 #   py:<script+args>  python tools/<script> args (',' = space)  -> ${TAG}_<script>.log
 #   bench[:args]      python bench.py args (',' = space)        -> ${TAG}_bench<suffix>.json/.err
 #   prof:<workload>[:args]  rocprofv3 kernel stats of bench.py --workload W -> prof_${TAG}_<W>/  (+ per-kernel roofline table)
+#   dist2[:args]            bench.py --gpus 2 as two ranks sharing the one GPU (gloo transport): rehearsal of the N > 1 line
 #   pmc:<workload>[:args]   two more passes with --pmc FETCH_SIZE / --pmc WRITE_SIZE (kernel trace only) into the same directory
 #   smoke             __graft_entry__.smoke()
 export TMPDIR=/tmp
@@ -25,6 +26,11 @@ for step in "$@"; do
         bench)
             args=${rest//,/ }; suffix=${BENCHTAG:-_n1}
             timeout 1500 python bench.py $args > gpurun_out/${TAG}_bench${suffix}.json 2> gpurun_out/${TAG}_bench${suffix}.err; echo "bench rc=$?"; tail -c 1500 gpurun_out/${TAG}_bench${suffix}.json ;;
+        dist2)
+            # two ranks on the ONE GPU, gloo host-callback transport: rehearsal of the N > 1 line (the rate means nothing)
+            args=${rest//,/ }
+            PAMG_BENCH_BACKEND=gloo PAMG_BENCH_ONE_GPU=1 timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+                bench.py --gpus 2 --steps 5 --warmup 2 $args > gpurun_out/${TAG}_bench_2ranks_one_gpu.json 2> gpurun_out/${TAG}_bench_2ranks_one_gpu.err; echo "dist2 rc=$?"; tail -c 2500 gpurun_out/${TAG}_bench_2ranks_one_gpu.json ;;
         prof)
             wl=${rest%%:*}; extra=""; [[ "$rest" == *:* ]] && extra=${rest#*:}; extra=${extra//,/ }
             OUT=$PWD/gpurun_out/prof_${TAG}_$wl; mkdir -p $OUT
