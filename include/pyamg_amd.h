@@ -354,7 +354,8 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * else 4|8|16|32|64), 26 = its persistent workgroups (0 = automatic), 27 = 1: the fast order also takes wide schedules
  * (>= 2048 rows per dependency level), which the tiled exact sweep keeps by default, 28 = flags of the fast order (bit 0, default
  * on: a wave that runs ahead of the sweep polls ONE gate operand instead of all its operands until the sweep is one
- * dependency level away), 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled.
+ * dependency level away), 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled AND
+ * enough lines run side by side to beat the lane form by the planner's estimate (3-D grids; not 2-D grids in natural order); 2 = wherever it applies.
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes

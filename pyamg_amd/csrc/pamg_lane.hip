@@ -362,7 +362,7 @@ int lane_upload(U **dst, const void *src, size_t bytes, size_t *total)
     *dst = nullptr;
     const size_t alloc = std::max<size_t>(bytes, 256) + 256;   // slack: nothing reads past the end, but keep allocations non-empty
     PAMG_HIP(hipMalloc((void **)dst, alloc));
-    if (bytes) PAMG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    if (bytes && src) PAMG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));      // src = nullptr: allocation only (filled on the device)
     if (total) *total += alloc;
     return PAMG_OK;
 }
@@ -422,13 +422,67 @@ static bool lane_one_xcd(const pamg_matrix_s *A, const GsSchedule *g)
     return A->gran_xcd == 1 || (A->gran_xcd == 0 && A->nrows <= 131072 && g->nrows / std::max(1, g->nlevels) <= 1024);
 }
 
+// The layout filled on the device (default for one slab): the host plan (pattern only, build_lane_plan with fill = false) gives the row
+// of every (group, slot row) and the gates; this kernel writes cols / vals / rdiag and the NODIAG flags from the resident CSR arrays --
+// no download of the values, no upload of the padded 12-byte slots (256^3 level 1: 1.5 GB, 1 s of host time per direction).
+// One wave per group; the L lanes of a row all walk the row (broadcast loads), lane q keeps entries e = q, q + L, ...: the slot rule
+// of the host's fill pass (entries in storage order without the diagonal, the last stored diagonal wins).
+template <typename T>
+__global__ __launch_bounds__(256) void lane_fill_kernel(int n, const int *__restrict__ Ap, const int *__restrict__ Aj, const T *__restrict__ Ax, int row_start,
+                                                        int row_step, long long m, int L, int K, long long ngroups, int *__restrict__ rid,
+                                                        int *__restrict__ cols, T *__restrict__ vals, T *__restrict__ rdiag)
+{
+    const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63);
+    if (g >= ngroups) return;
+    const int RPW = 64 / L, r = lane / L, q = lane - r * L;
+    const int i = rid[g * RPW + r];
+    int e = 0;
+    T d = T(0);
+    if (i >= 0) {
+        const long long ti = ((long long)i - row_start) * row_step;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) { d = Ax[p]; continue; }
+            if (e % L == q) {
+                const size_t s = (size_t)((g * K + e / L) * 64 + lane);
+                if (j < 0 || j >= n) { cols[s] = LANE_NONE; vals[s] = T(0); }
+                else {
+                    const long long tj = ((long long)j - row_start) * row_step;
+                    const bool early = tj >= 0 && tj < m && tj < ti;
+                    cols[s] = j | (early ? LANE_EARLY : 0);
+                    vals[s] = Ax[p];
+                }
+            }
+            ++e;
+        }
+    }
+    // this lane's unused slots: padding
+    for (int k = (e - q + L - 1) / L; k < K; ++k) {
+        const size_t s = (size_t)((g * K + k) * 64 + lane);
+        cols[s] = LANE_NONE; vals[s] = T(0);
+    }
+    if (q == 0) {
+        const bool nodiag = !(d != T(0));
+        rdiag[g * RPW + r] = (i >= 0 && !nodiag) ? T(1) / d : T(0);
+        if (i >= 0 && nodiag) rid[g * RPW + r] = i | LANE_NODIAG;
+    }
+}
+
 int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
 {
     if (g->lane) return PAMG_OK;
     PhaseTimer pt_("build_lane_part", A->nnz);
     const int ts = (int)tsize(A->dtype);
-    std::vector<unsigned char> hAx((size_t)A->nnz * ts);
-    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    // PAMG_LANE_HOST_FILL=1: the whole layout on the host (what the CPU suite replays); default: filled on the device
+    const char *hf = getenv("PAMG_LANE_HOST_FILL");
+    const bool want_slabs = !lane_one_xcd(A, g) && (A->lane_flags & 2) && g->nrows >= 262144 && A->nrows < LANE_LOCAL;
+    const bool host_fill = (hf && *hf == '1') || want_slabs || !A->d_Ap || !A->d_Aj || !A->d_Ax;
+    PlanVec<unsigned char> hAx;
+    if (host_fill) {
+        hAx.resize((size_t)A->nnz * ts);
+        if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    }
     LanePlan P;
     // Lanes per row.  Operators small enough for the one-XCD form (32 CUs): the fewest lanes that hold a row (most rows per
     // wave).  Across the chip waves are plentiful and the sweep is bound by the hand-off latency per dependency level: ONE
@@ -443,9 +497,9 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
     }
     // Slabs (one per XCD) for operators that run across the chip and are big enough to keep eight XCDs busy: an operand from the
     // consumer's own slab is handed over through the XCD's L2 instead of through memory (lane_flags bit 1; profiles/r04_*slab*)
-    const bool slabs = !lane_one_xcd(A, g) && (A->lane_flags & 2) && g->nrows >= 262144 && A->nrows < LANE_LOCAL;
-    if (build_lane_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), hAx.data(), ts, g->row_start, g->row_step, (int)g->nrows,
-                        g->nlevels, g->h_vis, g->h_lvl, want_L, P, slabs ? LANE_MAX_SLABS : 1, A->lane_chunk))
+    const bool slabs = want_slabs;
+    if (build_lane_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), host_fill ? hAx.data() : nullptr, ts, g->row_start, g->row_step, (int)g->nrows,
+                        g->nlevels, g->h_vis, g->h_lvl, want_L, P, slabs ? LANE_MAX_SLABS : 1, A->lane_chunk, host_fill))
         return PAMG_E_ARG;
     LaneSched *t = new (std::nothrow) LaneSched();
     if (!t) return PAMG_E_ALLOC;
@@ -454,11 +508,29 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
     t->max_level_groups = P.max_level_groups;
     t->nslabs = P.nslabs; t->n_local = P.n_local;
     for (int k = 0; k <= LANE_MAX_SLABS; ++k) t->slab_grp[k] = (int)P.slab_grp[std::min(k, P.nslabs)];
-    int st = lane_upload(&t->d_cols, P.cols.data(), P.cols.size() * sizeof(int), &t->bytes);
-    if (!st) st = lane_upload(&t->d_vals, P.vals.data(), P.vals.size(), &t->bytes);
-    if (!st) st = lane_upload(&t->d_rid, P.rid.data(), P.rid.size() * sizeof(int), &t->bytes);
-    if (!st) st = lane_upload(&t->d_rdiag, P.rdiag.data(), P.rdiag.size(), &t->bytes);
+    int st = lane_upload(&t->d_rid, P.rid.data(), P.rid.size() * sizeof(int), &t->bytes);
     if (!st) st = lane_upload(&t->d_gate, P.gate.data(), P.gate.size() * sizeof(int), &t->bytes);
+    if (host_fill) {
+        if (!st) st = lane_upload(&t->d_cols, P.cols.data(), P.cols.size() * sizeof(int), &t->bytes);
+        if (!st) st = lane_upload(&t->d_vals, P.vals.data(), P.vals.size(), &t->bytes);
+        if (!st) st = lane_upload(&t->d_rdiag, P.rdiag.data(), P.rdiag.size(), &t->bytes);
+    } else {
+        if (!st) st = lane_upload(&t->d_cols, nullptr, (size_t)P.n_slots * sizeof(int), &t->bytes);
+        if (!st) st = lane_upload(&t->d_vals, nullptr, (size_t)P.n_slots * ts, &t->bytes);
+        if (!st) st = lane_upload(&t->d_rdiag, nullptr, (size_t)P.ngroups * P.RPW * ts, &t->bytes);
+        if (!st) {
+            const unsigned grid = (unsigned)((P.ngroups + 3) / 4);
+            (void)hipGetLastError();                                  // a stale error of an earlier query must not be taken for this launch's
+            if (ts == 8)
+                hipLaunchKernelGGL((lane_fill_kernel<double>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const double *)A->d_Ax, g->row_start, g->row_step,
+                                   (long long)g->nrows, P.L, P.K, (long long)P.ngroups, t->d_rid, t->d_cols, (double *)t->d_vals, (double *)t->d_rdiag);
+            else
+                hipLaunchKernelGGL((lane_fill_kernel<float>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const float *)A->d_Ax, g->row_start, g->row_step,
+                                   (long long)g->nrows, P.L, P.K, (long long)P.ngroups, t->d_rid, t->d_cols, (float *)t->d_vals, (float *)t->d_rdiag);
+            st = (int)hipGetLastError();
+            if (!st) st = (int)hipDeviceSynchronize();
+        }
+    }
     if (!st && P.nslabs > 1) {
         const size_t xb = ((size_t)A->nrows + 8) * (size_t)ts;
         st = (int)hipMalloc(&t->d_xl, xb);

@@ -35,7 +35,10 @@
 #include <cstdint>
 #include <cstring>
 #include <thread>
+#include <atomic>
 #include <vector>
+
+#include "pamg_plan_vec.h"
 
 namespace pamg {
 
@@ -52,8 +55,8 @@ struct LanePlan {
     int64_t ngroups = 0;
     int nlevels = 0;
     int max_offdiag = 0;
-    std::vector<int> cols;
-    std::vector<unsigned char> vals;          // ngroups * K * 64 values of tsize bytes
+    PlanVec<int> cols;
+    PlanVec<unsigned char> vals;              // ngroups * K * 64 values of tsize bytes
     std::vector<int> rid;
     std::vector<unsigned char> rdiag;         // ngroups * RPW values of tsize bytes
     std::vector<int> gate;                    // [ngroups] column of the group's latest early operand from a level <= own level - 2, or -1
@@ -97,8 +100,11 @@ inline int lane_geometry(int maxlen, int want_L, int &K)
 // each).  Returns 0, or 1 when the rows are too long / the padding too wasteful (caller keeps the exact schedulers).
 inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned char *Ax, int tsize, int row_start, int row_step,
                            int m, int nl, const std::vector<int> &vis, const std::vector<int> &lvl, int want_L, LanePlan &P, int nslabs = 1,
-                           int chunk = 0)
+                           int chunk = 0, bool fill = true)
 {
+    // fill = false (one slab only): the structure, the row of every (group, slot row), the gates and the statistics -- cols, vals,
+    // rdiag and the NODIAG flags are then written by the device from the resident CSR arrays (lane_fill_kernel, pamg_lane.hip);
+    // Ax may be null
     P = LanePlan();
     P.nlevels = nl;
     if (m <= 0 || nl <= 0) return 1;
@@ -122,12 +128,25 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
     }
     int maxlen = 0;
     int64_t total = 0;
-    for (int t = 0; t < m; ++t) {
-        const int i = order[t];
-        int c = 0;
-        for (int p = Ap[i]; p < Ap[i + 1]; ++p) c += Aj[p] != i;
-        maxlen = std::max(maxlen, c);
-        total += c;
+    {
+        std::atomic<int> amax(0);
+        std::atomic<int64_t> atot(0);
+        lane_parallel(m, [&](int64_t t0, int64_t t1) {
+            int ml = 0;
+            int64_t tl = 0;
+            for (int64_t t = t0; t < t1; ++t) {
+                const int i = order[(size_t)t];
+                int c = 0;
+                for (int p = Ap[i]; p < Ap[i + 1]; ++p) c += Aj[p] != i;
+                ml = std::max(ml, c);
+                tl += c;
+            }
+            atot += tl;
+            int cur = amax.load();
+            while (ml > cur && !amax.compare_exchange_weak(cur, ml)) {}
+        });
+        maxlen = amax.load();
+        total = atot.load();
     }
     P.max_offdiag = maxlen;
     int K = 0;
@@ -149,10 +168,13 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
     // (+ 8 per row: short rows are fine); the padding of every level to whole groups is at most one group per level
     if ((int64_t)K * L * m > 4 * total + (int64_t)8 * L * m || P.n_slots >= ((int64_t)1 << 33)) return 1;
     if (P.ngroups >= ((int64_t)1 << 30)) return 1;
-    P.cols.assign((size_t)P.n_slots, LANE_NONE);
-    P.vals.assign((size_t)P.n_slots * tsize, 0);
+    if (nslabs > 1) fill = true;
+    if (fill) {
+        plan_fill(P.cols, (size_t)P.n_slots, (int)LANE_NONE);
+        plan_fill(P.vals, (size_t)P.n_slots * tsize, (unsigned char)0);
+        P.rdiag.assign((size_t)P.ngroups * RPW * tsize, 0);
+    }
     P.rid.assign((size_t)P.ngroups * RPW, -1);
-    P.rdiag.assign((size_t)P.ngroups * RPW * tsize, 0);
     P.gate.assign((size_t)P.ngroups, -1);
     std::vector<int> gate_lvl((size_t)P.ngroups, -1);
     // latest early operand of every visited row (-1: none): where a group has no operand two levels down, an operand OF one of its
@@ -184,7 +206,7 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                 const unsigned char *dptr = nullptr;
                 for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
                     const int j = Aj[p];
-                    if (j == i) { dptr = Ax + (size_t)p * tsize; continue; }          // last stored diagonal wins
+                    if (j == i) { if (fill) dptr = Ax + (size_t)p * tsize; continue; }          // last stored diagonal wins
                     const int k = e / L, lane = r * L + e % L;
                     const size_t s = (size_t)((g * K + k) * 64 + lane);
                     ++e;
@@ -197,8 +219,10 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                     }
                     const bool local = early && nslabs > 1 && slab_of_visit(vis[j]) == myslab;
                     if (local) ++l_cnt;
-                    P.cols[s] = j | (early ? LANE_EARLY : 0) | (local ? LANE_LOCAL : 0);
-                    std::memcpy(&P.vals[s * tsize], Ax + (size_t)p * tsize, (size_t)tsize);
+                    if (fill) {
+                        P.cols[s] = j | (early ? LANE_EARLY : 0) | (local ? LANE_LOCAL : 0);
+                        std::memcpy(&P.vals[s * tsize], Ax + (size_t)p * tsize, (size_t)tsize);
+                    }
                     if (early) ++e_cnt; else ++o_cnt;
                 }
                 bool nodiag = true;
@@ -217,7 +241,7 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                         std::memcpy(&P.rdiag[(size_t)(g * RPW + r) * 4], &rd, 4);
                     }
                 }
-                P.rid[(size_t)(g * RPW + r)] = i | (nodiag ? LANE_NODIAG : 0);
+                P.rid[(size_t)(g * RPW + r)] = fill ? (i | (nodiag ? LANE_NODIAG : 0)) : i;
             }
             ne[(size_t)l] = e_cnt; no[(size_t)l] = o_cnt; nloc[(size_t)l] = l_cnt;
         }

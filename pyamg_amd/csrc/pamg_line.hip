@@ -227,6 +227,69 @@ __global__ __launch_bounds__(BLK) void gs_line_kernel(const LineArgs<T> a)
     }
 }
 
+// ------------------------------------------------------------------ the layout, filled on the device
+// The chunk structure comes from the host (pattern only: pamg_line_plan.h with fill = false); cols / vals / rdiag / acoef /
+// nodiag / gate are written here from the resident CSR arrays -- no download of the values, no upload of the 1.3 GB layout
+// (256^3: 1.6 s of host time per sweep direction before).  One wave per chunk, lane = row; the slots follow the host's rule
+// (build_line_plan's fill pass, which the CPU suite replays): entries in storage order without the diagonal (last stored
+// one wins) and without the FIRST entry of the in-line predecessor.
+template <typename T>
+__global__ __launch_bounds__(256) void line_fill_kernel(int n, const int *__restrict__ Ap, const int *__restrict__ Aj, const T *__restrict__ Ax, int row_start,
+                                                        int row_step, long long m, int K, long long nchunks, const int *__restrict__ row0, const int *__restrict__ cnt,
+                                                        const unsigned char *__restrict__ coupled, int *__restrict__ cols, T *__restrict__ vals, T *__restrict__ rdiag,
+                                                        T *__restrict__ acoef, unsigned char *__restrict__ nodiag, int *__restrict__ gate, unsigned long long *__restrict__ counters)
+{
+    const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63);
+    if (g >= nchunks) return;
+    const int c = cnt[g], r0 = row0[g];
+    int my_gate = -1;
+    unsigned ne = 0, no = 0;
+    // padding lanes keep the host's defaults
+    for (int k = 0; k < K; ++k) { cols[(size_t)((g * K + k) * 64 + lane)] = LINE_NONE; vals[(size_t)((g * K + k) * 64 + lane)] = T(0); }
+    T rd = T(0), ac = T(0);
+    unsigned char nod = 0;
+    if (lane < c) {
+        const int i = r0 + lane * row_step;
+        const long long t = ((long long)i - row_start) * row_step;
+        const int prev = t > 0 ? (int)(row_start + (t - 1) * row_step) : -1;
+        const bool in_line = lane > 0 || coupled[g];
+        T d = T(0), ap = T(0);
+        bool have_p = false;
+        int k = 0;
+        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+            const int j = Aj[p];
+            if (j == i) { d = Ax[p]; continue; }
+            if (j == prev && !have_p && in_line) { ap = Ax[p]; have_p = true; continue; }
+            const size_t s = (size_t)((g * K + k) * 64 + lane);
+            ++k;
+            if (j < 0 || j >= n) continue;
+            const long long tj = ((long long)j - row_start) * row_step;
+            const bool early = tj >= 0 && tj < m && tj < t;
+            cols[s] = j | (early ? LINE_EARLY : 0);
+            vals[s] = Ax[p];
+            if (early) { ++ne; my_gate = j; } else ++no;
+        }
+        nod = !(d != T(0));
+        rd = nod ? T(0) : T(1) / d;
+        ac = nod ? T(0) : -ap * rd;
+    }
+    rdiag[(size_t)(g * 64 + lane)] = rd;
+    acoef[(size_t)(g * 64 + lane)] = ac;
+    nodiag[(size_t)(g * 64 + lane)] = nod;
+    // the chunk's gate: the last early operand in (lane, entry) order = the highest lane that has one
+    const unsigned long long has = __ballot(my_gate >= 0);
+    int gsel = -1;
+    if (has) gsel = __shfl(my_gate, 63 - __builtin_clzll(has));
+    // totals (statistics)
+    for (int o = 32; o > 0; o >>= 1) { ne += __shfl_down(ne, o); no += __shfl_down(no, o); }
+    if (lane == 0) {
+        gate[g] = gsel;
+        if (ne) atomicAdd(&counters[0], (unsigned long long)ne);
+        if (no) atomicAdd(&counters[1], (unsigned long long)no);
+    }
+}
+
 // ------------------------------------------------------------------ host side
 namespace {
 
@@ -236,7 +299,7 @@ int line_upload(U **dst, const void *src, size_t bytes, size_t *total)
     *dst = nullptr;
     const size_t alloc = std::max<size_t>(bytes, 256) + 256;
     PAMG_HIP(hipMalloc((void **)dst, alloc));
-    if (bytes) PAMG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    if (bytes && src) PAMG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));      // src = nullptr: allocation only (filled on the device)
     if (total) *total += alloc;
     return PAMG_OK;
 }
@@ -280,24 +343,72 @@ int build_line_part(pamg_matrix_s *A, GsSchedule *g)
     if (g->line) return PAMG_OK;
     PhaseTimer pt_("build_line_part", A->nnz);
     const int ts = (int)tsize(A->dtype);
-    std::vector<unsigned char> hAx((size_t)A->nnz * ts);
-    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    // PAMG_LINE_HOST_FILL=1: the whole layout on the host (values downloaded, layout uploaded) -- what the CPU suite replays; the
+    // default fills it on the device from the resident arrays (same arrays, tests/test_gpu_kernels.py compares the sweeps)
+    const char *hf = getenv("PAMG_LINE_HOST_FILL");
+    const bool host_fill = (hf && *hf == '1') || !A->d_Ap || !A->d_Aj || !A->d_Ax;
+    PlanVec<unsigned char> hAx;
+    if (host_fill) {
+        hAx.resize((size_t)A->nnz * ts);
+        if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    }
     LinePlan P;
-    if (build_line_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), hAx.data(), ts, g->row_start, g->row_stop, g->row_step, P))
+    if (build_line_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), host_fill ? hAx.data() : nullptr, ts, g->row_start, g->row_stop, g->row_step, P, host_fill))
         return PAMG_E_ARG;
+    // Is the scan worth it?  Lines of one line level run side by side, a line's chunks one after the other in one wave: the sweep takes
+    // about (line levels x chunks per line) chunk steps of 0.39 us (256^3: 511 x 4 steps, 0.79 ms measured), the lane form about
+    // max(row dependency levels x 1.05 us hand-off, rows x 0.115 ns of throughput) (256^3: 1.93 ms).  A 3-D grid has hundreds of lines
+    // per level; a 2-D grid in its natural order has ONE -- 2000 lines of 32 chunks in a row, 25 ms against the lane form's 4.
+    {
+        const double line_est = (double)P.nlevels * std::max(1.0, (double)P.nchunks / std::max<int64_t>(1, P.nlines)) * 0.39e-3;
+        const double lane_est = std::max((double)g->nlevels * 1.05e-3, (double)g->nrows * 0.115e-6);
+        if (A->line_scan < 2 && line_est > lane_est) return PAMG_E_ARG;
+    }
     LineSched *t = new (std::nothrow) LineSched();
     if (!t) return PAMG_E_ALLOC;
     t->K = P.K; t->step = P.step; t->nchunks = P.nchunks; t->nlines = P.nlines; t->nlevels = P.nlevels;
     t->n_early = P.n_early; t->max_level_lines = P.max_level_lines;
-    int st = line_upload(&t->d_cols, P.cols.data(), P.cols.size() * sizeof(int), &t->bytes);
-    if (!st) st = line_upload(&t->d_vals, P.vals.data(), P.vals.size(), &t->bytes);
-    if (!st) st = line_upload(&t->d_rdiag, P.rdiag.data(), P.rdiag.size(), &t->bytes);
-    if (!st) st = line_upload(&t->d_acoef, P.acoef.data(), P.acoef.size(), &t->bytes);
-    if (!st) st = line_upload(&t->d_nodiag, P.nodiag.data(), P.nodiag.size(), &t->bytes);
-    if (!st) st = line_upload(&t->d_row0, P.row0.data(), P.row0.size() * sizeof(int), &t->bytes);
+    int st = line_upload(&t->d_row0, P.row0.data(), P.row0.size() * sizeof(int), &t->bytes);
     if (!st) st = line_upload(&t->d_cnt, P.cnt.data(), P.cnt.size() * sizeof(int), &t->bytes);
-    if (!st) st = line_upload(&t->d_gate, P.gate.data(), P.gate.size() * sizeof(int), &t->bytes);
     if (!st) st = line_upload(&t->d_line_chunk, P.line_chunk.data(), P.line_chunk.size() * sizeof(int), &t->bytes);
+    if (host_fill) {
+        if (!st) st = line_upload(&t->d_cols, P.cols.data(), P.cols.size() * sizeof(int), &t->bytes);
+        if (!st) st = line_upload(&t->d_vals, P.vals.data(), P.vals.size(), &t->bytes);
+        if (!st) st = line_upload(&t->d_rdiag, P.rdiag.data(), P.rdiag.size(), &t->bytes);
+        if (!st) st = line_upload(&t->d_acoef, P.acoef.data(), P.acoef.size(), &t->bytes);
+        if (!st) st = line_upload(&t->d_nodiag, P.nodiag.data(), P.nodiag.size(), &t->bytes);
+        if (!st) st = line_upload(&t->d_gate, P.gate.data(), P.gate.size() * sizeof(int), &t->bytes);
+    } else {
+        const size_t slots = (size_t)P.nchunks * P.K * 64, rows = (size_t)P.nchunks * 64;
+        unsigned char *d_coupled = nullptr;
+        unsigned long long *d_cnt2 = nullptr;
+        if (!st) st = line_upload(&t->d_cols, nullptr, slots * sizeof(int), &t->bytes);
+        if (!st) st = line_upload(&t->d_vals, nullptr, slots * ts, &t->bytes);
+        if (!st) st = line_upload(&t->d_rdiag, nullptr, rows * ts, &t->bytes);
+        if (!st) st = line_upload(&t->d_acoef, nullptr, rows * ts, &t->bytes);
+        if (!st) st = line_upload(&t->d_nodiag, nullptr, rows, &t->bytes);
+        if (!st) st = line_upload(&t->d_gate, nullptr, (size_t)P.nchunks * sizeof(int), &t->bytes);
+        if (!st) st = line_upload(&d_coupled, P.coupled.data(), P.coupled.size(), nullptr);
+        if (!st) st = line_upload(&d_cnt2, nullptr, 16, nullptr);
+        if (!st) st = (int)hipMemset(d_cnt2, 0, 16);
+        if (!st) {
+            const unsigned grid = (unsigned)((P.nchunks + 3) / 4);
+            (void)hipGetLastError();                                  // a stale error of an earlier query must not be taken for this launch's
+            if (ts == 8)
+                hipLaunchKernelGGL((line_fill_kernel<double>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const double *)A->d_Ax, g->row_start, g->row_step,
+                                   (long long)(((int64_t)g->row_stop - g->row_start) / g->row_step), P.K, (long long)P.nchunks, t->d_row0, t->d_cnt, d_coupled, t->d_cols,
+                                   (double *)t->d_vals, (double *)t->d_rdiag, (double *)t->d_acoef, t->d_nodiag, t->d_gate, d_cnt2);
+            else
+                hipLaunchKernelGGL((line_fill_kernel<float>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const float *)A->d_Ax, g->row_start, g->row_step,
+                                   (long long)(((int64_t)g->row_stop - g->row_start) / g->row_step), P.K, (long long)P.nchunks, t->d_row0, t->d_cnt, d_coupled, t->d_cols,
+                                   (float *)t->d_vals, (float *)t->d_rdiag, (float *)t->d_acoef, t->d_nodiag, t->d_gate, d_cnt2);
+            st = (int)hipGetLastError();
+            unsigned long long hc[2] = {0, 0};
+            if (!st) st = (int)hipMemcpy(hc, d_cnt2, 16, hipMemcpyDeviceToHost);      // also the fill's completion
+            t->n_early = (int64_t)hc[0];
+        }
+        hipFree(d_coupled); hipFree(d_cnt2);
+    }
     if (st) { free_line_part(t); return st; }
     g->line = t;
     g->bytes += t->bytes;                                      // the caller books them on the operator

@@ -397,6 +397,88 @@ def test_gs_fast_order_agrees_to_rounding():
         assert np.array_equal(dx.download(), ref)                       # and back
 
 
+def test_line_layout_filled_on_the_device_is_the_host_layout(monkeypatch):
+    """The line-scan layout (chunk slots, 1 / a_ii, recurrence coefficients, gates) is written by the device from the resident
+    CSR arrays by default; PAMG_LINE_HOST_FILL=1 builds the same arrays on the host (the planner the CPU suite replays) and
+    uploads them.  Same plan statistics and bit-identical sweeps either way: 3-D and 2-D stencils, a zero diagonal, rows with
+    a duplicate predecessor entry, f64 / f32, forward / backward / SOR."""
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(17)
+    A3 = sp.csr_array(poisson_csr((24, 20, 22)))
+    A2 = sp.lil_array(poisson_csr((96, 80)))
+    for i in range(5, 7000, 97):
+        A2[i, i] = 0.0                                     # zero diagonals: rows left untouched
+    A2 = sp.csr_array(A2.tocsr())
+    dup = sp.csr_array(poisson_csr((5000,)))
+    # a duplicate of the predecessor entry in some rows (unsummed duplicates are legal CSR): the second one stays a slot
+    ip, ix, dv = dup.indptr.copy(), list(dup.indices), list(dup.data)
+    rows = []
+    for r in range(dup.shape[0]):
+        ent = [(ix[p], dv[p]) for p in range(ip[r], ip[r + 1])]
+        if r % 37 == 3 and r > 0:
+            ent.append((r - 1, -0.25))
+        rows.append(ent)
+    dup = sp.csr_array((np.array([v for e in rows for _, v in e]), np.array([c for e in rows for c, _ in e], dtype=np.int32),
+                        np.cumsum([0] + [len(e) for e in rows]).astype(np.int32)), shape=dup.shape)
+    for M in (A3, A2, dup, sp.csr_array(A3.astype(np.float32))):
+        op = sparse_op(M) if M is not dup else sparse_op(M)
+        n, dt = op.shape[0], op.data.dtype
+        x, b = rng.rand(n).astype(dt), rng.rand(n).astype(dt)
+        res = []
+        for host in ("1", "0"):
+            monkeypatch.setenv("PAMG_LINE_HOST_FILL", host)
+            dA = DeviceMatrix(op)
+            dA.tune(gs_order=1, line_scan=1)
+            dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
+            dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+            a = dx.download()
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="backward", omega=1.3)
+            res.append((a, dx.download(), {k: v for k, v in dA.line_info(0).items() if k != "bytes"}, dA.line_info(1)["early_entries"]))
+            assert dA.line_info(0)["lines"] > 0 and not dA.flow_error()
+            dA.free()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        assert res[0][2] == res[1][2] and res[0][3] == res[1][3], (res[0][2], res[1][2])
+
+
+def test_lane_layout_filled_on_the_device_is_the_host_layout(monkeypatch):
+    """The lane-parallel layout likewise: PAMG_LANE_HOST_FILL=1 builds slots / values / reciprocal diagonals on the host and uploads
+    them, the default writes them on the device from the resident CSR arrays -- bit-identical sweeps and equal statistics on an
+    irregular symmetric pattern (several rows per wave), a ~70-per-row operator (one row per wave, two slots per lane), zero / missing
+    diagonals, a non-symmetric pattern and f32."""
+    rng = np.random.RandomState(19)
+    S = sp.random(4000, 4000, density=0.004, random_state=rng, format="csr")
+    S = sp.csr_array(S + S.T + sp.diags_array(rng.rand(4000) + 4.0))
+    S.sort_indices()
+    Z = sp.lil_array(S[:1500, :1500])
+    for i in range(0, 1500, 7):
+        Z[i, i] = 0.0
+    Z = sp.csr_array(Z)
+    D = sp.random(1200, 1200, density=0.05, random_state=rng, format="csr")
+    D = sp.csr_array(D + D.T + sp.diags_array(rng.rand(1200) + 150.0))
+    N = sp.random(3000, 3000, density=0.004, random_state=rng, format="csr")
+    N = sp.csr_array(N + sp.diags_array(rng.rand(3000) + 4.0))
+    for M in (S, Z, D, N, sp.csr_array(S.astype(np.float32))):
+        op = sparse_op(M)
+        n, dt = op.shape[0], op.data.dtype
+        x, b = rng.rand(n).astype(dt), rng.rand(n).astype(dt)
+        res = []
+        for host in ("1", "0"):
+            monkeypatch.setenv("PAMG_LANE_HOST_FILL", host)
+            dA = DeviceMatrix(op)
+            dA.tune(gs_order=1, lane_wide=1, line_scan=0)
+            dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
+            dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+            a = dx.download()
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="backward", omega=1.3)
+            res.append((a, dx.download(), {k: v for k, v in dA.lane_info(0).items() if k != "bytes"}))
+            assert dA.lane_info(0)["groups"] > 0 and not dA.flow_error()
+            dA.free()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        assert res[0][2] == res[1][2], (res[0][2], res[1][2])
+
+
 def test_resid_sumsq_two_stage_reduction():
     from tools.problems import poisson_csr
     A = poisson_csr((400, 400))

@@ -27,7 +27,7 @@ def emul():
     src = HERE / "line_emul.cpp"
     hdr = ROOT / "pyamg_amd" / "csrc" / "pamg_line_plan.h"
     if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
     lib = ctypes.CDLL(str(so))
     lib.line_emul_sweep_f64.restype = ctypes.c_int
     return lib
@@ -82,6 +82,29 @@ def test_grid_stencils_lines_and_levels(emul, grid, waves):
     assert st[2] == nlines_grid                                   # one line per grid line (its chunks of <= 64 rows chained in one wave)
     assert st[3] == (sum(g - 1 for g in grid[:-1]) + 1 if len(grid) > 1 else 1)     # line levels: j + k hyperplanes, not i + j + k
     assert st[0] == 2 * len(grid) - 1                             # entries per row other than the diagonal and the in-line predecessor
+
+
+def test_duplicate_predecessor_entries_keep_their_slots(emul):
+    """Unsummed duplicates are legal CSR (the reference adds every stored entry, relaxation.h:61-68): the FIRST entry of the in-line
+    predecessor goes into the recurrence, a second one takes a slot like any other early operand -- the slot count per row has to
+    include it (a 1-D chain with duplicated sub-diagonal entries: two slots where the stencil alone needs one)."""
+    rng = np.random.default_rng(11)
+    n = 3000
+    ent = []
+    for r in range(n):
+        row = [(c, v) for c, v in ((r - 1, -1.0), (r, 2.5), (r + 1, -1.0)) if 0 <= c < n]
+        if r % 37 == 3:
+            row.append((r - 1, -0.25))
+        if r % 13 == 5:
+            row.insert(0, (r, 0.5))                                # and a duplicate diagonal: the last stored one wins
+        ent.append(row)
+    A = sp.csr_array((np.array([v for e in ent for _, v in e]), np.array([c for e in ent for c, _ in e], dtype=np.int32),
+                      np.cumsum([0] + [len(e) for e in ent]).astype(np.int32)), shape=(n, n))
+    x, b = rng.random(n), rng.random(n)
+    for rng_ in ((0, n, 1), (n - 1, -1, -1)):
+        rc, got, st = run_emul(emul, A, x, b, *rng_)
+        assert rc == 0 and st[0] == 2, (rc, st)
+        assert close(got, ref_sweep(A, x, b, *rng_)), rng_
 
 
 def test_variable_coefficients_zero_diagonals_and_a_nonsymmetric_band(emul):
