@@ -2138,12 +2138,17 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
         const int kz0 = A->rowmask_kz;
         int best_kz = kz0;
         float best = 1e30f;
+        // timed on the residual r = b - A x (three vectors in flight, like the Horner steps): on 512^2-row planes y = A x alone prefers
+        // 8 planes per lane, the residual 4 (profiles/r04_microbench_rowmask_512.json)
+        void *bvec = nullptr;
+        if (hipMalloc(&bvec, (size_t)(A->nrows + 8) * ts) == hipSuccess) hipMemset(bvec, 0, (size_t)(A->nrows + 8) * ts);
+        const int epi_t = bvec ? EPI_RESID : EPI_SET;
         for (int kz = 8; kz >= 2 && st == PAMG_OK; kz >>= 1) {
             A->rowmask_kz = kz;
             if (pamg_matrix_row_masks(A, rm) != PAMG_OK || !rm[2]) continue;
-            for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
+            for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, epi_t, x, bvec, y, 0.0, 0.0, nullptr, nullptr);
             hipEventRecord(e0, nullptr);
-            for (int r = 0; r < 8 && st == PAMG_OK; ++r) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
+            for (int r = 0; r < 8 && st == PAMG_OK; ++r) st = stream_launch(A, epi_t, x, bvec, y, 0.0, 0.0, nullptr, nullptr);
             hipEventRecord(e1, nullptr);
             hipEventSynchronize(e1);
             float ms = 0.f;
@@ -2151,6 +2156,7 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
             if (st == PAMG_OK && ms < best * 0.98f) { best = ms; best_kz = kz; }
         }
         A->rowmask_kz = best_kz;
+        if (bvec) hipFree(bvec);
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(x); hipFree(y);

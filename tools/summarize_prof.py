@@ -28,7 +28,7 @@ def short(name):
     m = re.search(r"csr_(rowgather|rowpat)_kernel<(\w+), *(\d+)>", name)
     if m:
         return f"csr_{m.group(1)}<{m.group(2)},{EPI[int(m.group(3))]}>"
-    m = re.search(r"csr_rowmask3d_kernel<(\w+), *(\d+), *(\d+), *(\w+)>", name)
+    m = re.search(r"csr_rowmask3d_kernel<(\w+), *(\d+), *(\d+), *(\w+)(?:, *\d+)?>", name)
     if m:
         return f"csr_rowmask3d<{m.group(1)},{EPI[int(m.group(2))]},kz{m.group(3)}>"
     m = re.search(r"csr_rowmask_sumsq_kernel<(\w+), *(\d+)>", name)
