@@ -2116,7 +2116,12 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
     const int caps[2] = {cap0, 512};
     int best_cap = cap0, best_fl = fl0, st = PAMG_OK;
     float best_ms = 1e30f;
-    for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK; ++ci) {
+    // an operator whose whole-operator launches run in the row-mask form has nothing to choose here: its kernels read neither the LDS
+    // window nor the streaming flags, and a noise-picked 512-entry window would only multiply the row ranges of the kernels that still
+    // use them (the norm's partials, the shard parts)
+    long long rm0[8];
+    const bool masked = pamg_matrix_row_masks(A, rm0) == PAMG_OK && rm0[0] > 0;
+    for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK && !masked; ++ci) {
         if (caps[ci] != A->cap) { A->cap = caps[ci]; st = replan(A); if (st) break; }
         for (int fl = 0; fl < 4 && st == PAMG_OK; ++fl) {      // bit 0 non-temporal operator stream, bit 1 XCD-contiguous range order
             A->stream_flags = (fl0 & ~3) | fl;
