@@ -476,7 +476,20 @@ class DeviceMultilevelSolver:
                                                 capi.CYCLE[cycle], int(cycles_per_level), int(check_every),
                                                 capi.ptr(res), C.byref(nit), C.byref(info), stream),
                    "pamg_solver_solve")
+        self._report_sweep_timeouts()
         return res[: nit.value + 1], nit.value, info.value
+
+    def _report_sweep_timeouts(self):
+        """A persistent sweep that gave up waiting (its workgroups were not all running: another process on the device, a debugger,
+        a small partition) makes the engine switch to one launch per dependency level -- correct, but several times slower.  Say so,
+        once per occurrence, instead of slowing down silently."""
+        n = self.stats()["sweep_timeouts_recovered"]
+        if n > getattr(self, "_timeouts_reported", 0):
+            self._timeouts_reported = n
+            import warnings
+            warnings.warn("pyamg_amd: a persistent Gauss-Seidel sweep timed out waiting for its workgroups (is the GPU shared with another "
+                          "process?); this solver now runs its sweeps as one launch per dependency level -- same results, several times "
+                          "slower.  Recreate the solver on an idle device to get the persistent sweeps back.", RuntimeWarning, stacklevel=3)
 
     def load_device(self, xd, bd, stream=None):
         capi.check(capi.lib().pamg_solver_load(self.handle, xd.ptr, bd.ptr, stream), "pamg_solver_load")
@@ -486,6 +499,7 @@ class DeviceMultilevelSolver:
         res = np.zeros(max(int(k), 1), dtype=np.float64) if want_residuals else None
         capi.check(capi.lib().pamg_solver_iterate(self.handle, int(k), capi.CYCLE[cycle], int(cycles_per_level),
                                                   capi.ptr(res), stream), "pamg_solver_iterate")
+        self._report_sweep_timeouts()
         return res[:k] if want_residuals else None
 
     def store_device(self, xd, stream=None):

@@ -378,7 +378,8 @@ def test_hierarchy_tail_in_one_launch_is_bit_identical(load_hier, name, monkeypa
 def test_sweep_timeout_falls_back_to_level_launches():
     """a persistent sweep that reports PAMG_E_TIMEOUT (not all of its workgroups were running -- forced here through the
     PAMG_FORCE_TIMEOUT test hook): solve() switches every order-exact sweep to one launch per dependency level, runs the
-    solve again from the initial guess and returns the reference's answer; the switch is reported in stats()"""
+    solve again from the initial guess and returns the reference's answer; the switch is reported in stats() and by ONE
+    RuntimeWarning"""
     import subprocess
     import sys
     from conftest import ROOT
@@ -402,6 +403,7 @@ def test_sweep_timeout_falls_back_to_level_launches():
     import os
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PAMG_FORCE_TIMEOUT="1"))
     assert r.returncode == 0 and "fallback ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    assert r.stderr.count("a persistent Gauss-Seidel sweep timed out") == 1, r.stderr[-2000:]      # said once, not silently slower
 
 
 def test_device_fgmres_matches_reference():
