@@ -660,11 +660,15 @@ def main():
                 "csr_formula_note": "SURVEY 8(d): 12 nnz + 4 (n + 1) + 8 n (x) + 8 n (r) + 8 n (b); exceeds the peak when the operator is streamed compressed"}
     if ceiling:
         roofline["ceiling_GBps"] = ceiling["copy_GBps"]
+        roofline["ceiling_copy_GBps"] = ceiling["copy_GBps"]
         roofline["ceiling"] = ceiling
         roofline["frac_of_ceiling"] = round(moved / spmv_ms / 1e6 / max(ceiling["copy_GBps"], 1.0), 4)
     if pmc:
         roofline["traffic_detail"] = pmc
         roofline["traffic_over_streamed"] = round(pmc["bytes_per_launch"] / max(streamed, 1), 3)
+        # flat copies: the driver's record keeps scalars of this object only
+        roofline["fetch_bytes"] = pmc["fetch_corrected_x2"]
+        roofline["write_bytes"] = pmc["write_size"]
     if plain:
         # the general kernel (any operator): 16-bit column codes + values as stored, LDS-staged products -- the north star's
         # "fine-level CSR SpMV", on the CSR formula's bytes (it streams 10 of the 12 bytes per entry)
@@ -672,6 +676,10 @@ def main():
         plain["bytes_streamed_per_launch"] = int(bytes_resid - 2 * nnz0)
         plain["frac_on_streamed_bytes"] = round((bytes_resid - 2 * nnz0) / plain["ms_per_launch"] / 1e6 / HBM_PEAK_GBPS, 4)
         roofline["general_csr"] = plain
+        roofline["general_csr_ms"] = plain["ms_per_launch"]
+        roofline["general_csr_GBps"] = plain["achieved"]
+        roofline["general_csr_frac"] = plain["frac"]                      # by the CSR formula of SURVEY 8(d): the north star's "fine-level CSR SpMV"
+        roofline["general_csr_frac_on_streamed_bytes"] = plain["frac_on_streamed_bytes"]
 
     # ---- the order-exact sweeps: latency-bound by the dependency chain of the reference's row order
     #      (levels of the schedule), not by HBM -- reported beside the bandwidth roofline so that the
@@ -786,6 +794,23 @@ def main():
             "time_to_tol_1e-8": ttt,
         }
         out["config"]["gs_order"] = dml.order
+        if sweeps:
+            # what bounds the STEP (not the bandwidth kernel above): the sweep kernel with the largest share, on SURVEY 8(d)'s bytes
+            dom = max(sweeps, key=lambda r_: r_["ms_per_forward_sweep"])
+            roofline["dominant_kernel"] = f"{dom['scheduler'].split(':')[0]}, level {dom['level']} ({dom['dependency_levels']} dependency levels)"
+            roofline["dominant_kernel_ms"] = dom["ms_per_forward_sweep"]
+            roofline["dominant_kernel_frac"] = round(dom["pct_of_hbm_peak"] / 100, 4)
+            roofline["dominant_kernel_share_of_step"] = round(4 * dom["ms_per_forward_sweep"] / out["ms_per_step"], 3)
+            roofline["dominant_kernel_us_per_dependency_level"] = dom["us_per_dependency_level"]
+            roofline["sweeps_share_of_step"] = round(4 * sum(r_["ms_per_forward_sweep"] for r_ in sweeps) / out["ms_per_step"], 3)
+        if parity:
+            out["config"]["parity_random_b_max_abs_diff_over_r0"] = parity.get("max_abs_diff_over_r0")
+            out["config"]["parity_random_b_ok"] = bool(parity.get("max_abs_diff_over_r0", 1.0) <= 1e-10)
+            rp = parity.get("reference_protocol") or {}
+            if rp:
+                out["config"]["parity_protocol_ok"] = rp.get("ok")
+                out["config"]["parity_protocol_max_rel_diff"] = rp.get("max_rel_diff")
+                out["config"]["parity_protocol_cycles"] = rp.get("cycles_compared")
         if sweeps:
             out["gs_sweeps"] = {"note": "Gauss-Seidel in the reference's row order (same dependency DAG): one persistent launch per sweep, "
                                         "element-level hand-off; time = dependency levels x hand-off latency (a V(1,1) cycle with symmetric GS "

@@ -354,7 +354,10 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * else 4|8|16|32|64), 26 = its persistent workgroups (0 = automatic), 27 = 1: the fast order also takes wide schedules
  * (>= 2048 rows per dependency level), which the tiled exact sweep keeps by default, 28 = flags of the fast order (bit 0, default
  * on: a wave that runs ahead of the sweep polls ONE gate operand instead of all its operands until the sweep is one
- * dependency level away), 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled AND
+ * dependency level away; bit 4: rows that fill a wave add ALL their products with the butterfly after the last operand has arrived
+ * (round 4) instead of the ordered tail -- old products by the butterfly while the polls are in flight, early products one by one in the
+ * layout's slot order, the operands of the level just below last (round 5, default); bits 1, 2 retired with the slab form),
+ * 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled AND
  * enough lines run side by side to beat the lane form by the planner's estimate (3-D grids; not 2-D grids in natural order); 2 = wherever it applies.
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);

@@ -3,10 +3,9 @@
 // Same rows in the same order as amg_core::gauss_seidel (relaxation.h:48-76) / sor_gauss_seidel (:116-145) /
 // bsr_gauss_seidel with 1x1 blocks (:185-266) -- the dependency DAG of the sequential sweep is kept, so the iterates
 // are the reference's up to rounding -- but nothing of the row sum's order is: L lanes of a wave share a row, each adds
-// its K products, a DPP butterfly adds the lanes ("wavefront-wide segmented reduction per row"), and the row is
+// its K products, the lanes are added across the wave ("wavefront-wide segmented reduction per row"), and the row is
 // finished with (b - sum) * (1 / a_ii) instead of the IEEE division.  What that buys: the order-exact sweeps spend
-// ~0.9 us per dependency level BEHIND the last hand-off (LDS staging, barrier, 31..70-term in-order add chain, divide);
-// here that tail is ~10 dependent VALU instructions.
+// ~0.9 us per dependency level BEHIND the last hand-off (LDS staging, barrier, 31..70-term in-order add chain, divide).
 //
 // ONE persistent launch per sweep; a group of 64 / L rows of one dependency level is the work of ONE wave, waves never
 // meet (no LDS, no barrier).  The hand-off is the one of the granular exact sweep: the published 8-byte value is the
@@ -16,14 +15,18 @@
 //   one-XCD form: small operators (vectors fit one XCD's L2).  The first workgroup to arrive claims its XCD, workgroups
 //                 elsewhere leave, the rest draw groups from a ticket counter (two tickets ahead, taken in increasing
 //                 order by running waves: complete for any placement) and publish with ordinary L2-resident stores.
-//   slab form   : large operators (round 4).  The rows are cut into 8 slabs of the visit order (pamg_lane_plan.h); the
-//                 workgroups with blockIdx % 8 == s -- one XCD, as the dispatcher places them -- share slab s statically.  Every
-//                 row is published TWICE: an ordinary store into a second buffer xl (stays in the producer XCD's L2) and the
-//                 write-through store into xs.  An operand produced in the consumer's own slab is polled in xl (L2 round trip),
-//                 the others in xs (memory).  Placement is verified, not assumed: every workgroup records its XCD for its slab;
-//                 a workgroup that finds another XCD recorded raises a flag and from then on everybody polls xs only --
-//                 correct for any placement, fast for the usual one.
 // The static operands of a wave's NEXT group are requested before it starts to wait for the current one.
+//
+// Round 5 -- what is left BEHIND the last hand-off.  Round 4 ran the 6-step butterfly over all products after the last operand had
+// arrived: ~40 dependent instructions, two of them through the LDS crossbar, 200 ns of the 1.05 us per dependency level
+// (tail_ns_median in profiles/r04_microbench_lane_exp_i.json).  Now (one row per wave) the slots of a row are ordered -- old operands,
+// then early operands by ascending producer level (pamg_lane_plan.h) -- and the wave
+//   1. adds the OLD products with the butterfly while the first re-poll is in flight,
+//   2. adds the early products ONE BY ONE in slot order (v_readlane of the product + one add each) as they have arrived.
+// The operands of the level just below -- the ones a wave actually waits for -- are the last slots: behind the last hand-off there is
+// a compare, a multiply, a readlane pair, an add and the (b - s) * (1 / a_ii).  The order of the additions is the layout's, not the
+// timing's: bit-reproducible.  The removed slab form (one slab of the visit order per XCD, hand-off through the XCD's L2 for
+// operands of the own slab) never beat the plain static form: profiles/r04_microbench_lane_exp_{g,h}.json, DESIGN 3.
 #include "pamg_common.h"
 #include "pamg_lane_plan.h"
 
@@ -51,19 +54,21 @@ __global__ __launch_bounds__(BLK) void lane_fill_sentinel_kernel(T *xs, int64_t 
     for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) p[i] = Sentinel<T>::value;
 }
 
+// per slot row (group g, row r of the group): original row | NODIAG, the group's gate operand, 1 / a_ii -- ONE 16-byte request
+struct alignas(16) LaneRec { int rid; int gate; int rd_lo; int rd_hi; };
+
 struct LaneSched {
     int L = 0, K = 0, RPW = 0;
     int64_t ngroups = 0;
-    int *d_cols = nullptr, *d_rid = nullptr, *d_gate = nullptr;
-    void *d_vals = nullptr, *d_rdiag = nullptr;
+    int *d_cols = nullptr;
+    LaneRec *d_rec = nullptr;
+    void *d_vals = nullptr;
     long long *d_prof = nullptr;
     int64_t n_early = 0, n_old = 0, n_slots = 0;
     int64_t max_level_groups = 0;
-    int nslabs = 1;
-    int slab_grp[LANE_MAX_SLABS + 1] = {0};
-    int64_t n_local = 0;
-    void *d_xl = nullptr;           // slab form: second hand-off buffer (L2-resident stores)
     int last_grid = 0;              // workgroups of the last launch (diagnostics)
+    int cap = 0;                    // co-resident workgroups per CU of this schedule's kernel (queried once)
+    const void *cap_kernel = nullptr;
     size_t bytes = 0;
 };
 
@@ -71,21 +76,17 @@ template <typename T>
 struct LaneArgs {
     const int *cols;
     const T *vals;
-    const int *rid;
-    const T *rdiag;
-    const int *gate;       // per group: gate operand (column) or -1; nullptr = no gating
+    const LaneRec *rec;
     const T *x;            // OLD values (x itself, or its snapshot for structurally non-symmetric patterns)
     T *y;                  // destination (the live x)
     T *xs;                 // hand-off buffer, sentinel-filled
-    T *xl;                 // slab form: the same values stored WITHOUT write-through (same-XCD consumers poll here)
-    unsigned *aff;         // slab form: [0..7] XCD + 1 of the workgroups serving slab s (0 = nobody yet), [8] != 0: a slab is served from two XCDs -> poll xs only
-    int slab_grp[LANE_MAX_SLABS + 1];
     const T *b;
     unsigned *err;         // spin bound hit
     unsigned *ticket;      // one-XCD form: [0] ticket counter, [1] home XCD + 1
     long long *prof;       // nullptr or [ngroups][4] time stamps
     int ngroups, nidle;
-    int old_l1;            // != 0: old values through the L1 (ordinary loads); 0: L1-bypassing loads like the polls
+    int use_gate;          // != 0: a wave that runs ahead polls its gate operand first
+    int tail;              // != 0 (one row per wave only): early products added one by one in slot order; 0: butterfly over everything
     T omega;
 };
 
@@ -98,7 +99,8 @@ struct LaneSet {
     int gate;
 };
 
-// ---- sum over the L lanes that share a row; every lane ends up with the total
+// ---- sum over the L lanes that share a row; every lane ends up with the total (bit for bit the same total: an XOR butterfly
+//      adds the same two values in both lanes of a pair at every step)
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v)
 {
@@ -133,6 +135,17 @@ __device__ __forceinline__ T seg_allreduce(T v)
     return v;
 }
 
+// value of lane l (wave-uniform l) in every lane
+__device__ __forceinline__ double lane_bcast(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+template <typename T> __device__ __forceinline__ T rec_rd(const int4 &q);
+template <> __device__ __forceinline__ double rec_rd<double>(const int4 &q) { return __hiloint2double(q.w, q.z); }
+template <> __device__ __forceinline__ float rec_rd<float>(const int4 &q) { return __int_as_float(q.z); }
+
 template <typename T, int L, int K>
 __device__ __forceinline__ void lane_load(const LaneArgs<T> &a, int g, LaneSet<T, K> &S)
 {
@@ -144,9 +157,10 @@ __device__ __forceinline__ void lane_load(const LaneArgs<T> &a, int g, LaneSet<T
         S.v[k] = a.vals[e0 + (size_t)k * 64];
     }
     const size_t slot = (size_t)g * (size_t)(64 / L) + (size_t)(lane / L);
-    S.rid = a.rid[slot];
-    S.rd = a.rdiag[slot];
-    S.gate = a.gate ? a.gate[g] : -1;
+    const int4 q = reinterpret_cast<const int4 *>(a.rec)[slot];
+    S.rid = q.x;
+    S.gate = a.use_gate ? q.y : -1;
+    S.rd = rec_rd<T>(q);
 }
 
 // one group, first half: request everything that depends on the group's static operands -- b, the row's own old value,
@@ -161,8 +175,8 @@ struct LaneDyn {
     long long t0;
 };
 
-template <typename T, int EPI, int K, int MODE>
-__device__ __forceinline__ void lane_issue(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int idle, bool local_ok)
+template <typename T, int EPI, int K>
+__device__ __forceinline__ void lane_issue(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int idle)
 {
     D.t0 = 0;
     if (a.prof && (threadIdx.x & 63) == 0) D.t0 = wall_clock64();
@@ -175,25 +189,43 @@ __device__ __forceinline__ void lane_issue(const LaneArgs<T> &a, const LaneSet<T
     for (int k = 0; k < K; ++k) {
         const int c = S.c[k];
         const int col = c & LANE_MASK;
-        const T *hand = a.xs;
-        if constexpr (MODE == 2) hand = ((c & LANE_LOCAL) && local_ok) ? a.xl : a.xs;
-        if (a.old_l1) {
-            // two loads: the early operand past the L1 (another CU writes it during the launch), the old value through it.  An old
-            // value is not rewritten before this row has published (its owner waits for this row), and the L1 holds nothing from
-            // before the launch, so a cached copy is the value of before the sweep.
-            const T ve = __hip_atomic_load(((c & LANE_EARLY) && !(c & LANE_NONE)) ? hand + col : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const T vo = a.x[((c & (LANE_EARLY | LANE_NONE)) == 0) ? col : idle];
-            D.xv[k] = (c & LANE_EARLY) ? ve : vo;
-        } else {
-            const T *p = (c & LANE_NONE) ? a.x + idle : ((c & LANE_EARLY) ? hand + col : a.x + col);
-            D.xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const T *p = (c & LANE_NONE) ? a.x + idle : ((c & LANE_EARLY) ? a.xs + col : a.x + col);
+        D.xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// second half: wait for the early operands, row sums across the lanes, publish
+// a wave that runs ahead: the sweep is still two or more dependency levels away while the gate operand is missing -- the
+// whole wave polls that ONE value (one request per round) instead of all its operands
+template <typename T>
+__device__ __forceinline__ unsigned lane_gate_wait(const LaneArgs<T> &a, int gate)
+{
+    unsigned spins = 0;
+    const T *gp = a.xs + gate;
+    while (true) {
+        const T gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (Sentinel<T>::bits(gv) != Sentinel<T>::value) break;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 1023u) == 0 && (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+    }
+    return spins;
+}
+
+template <typename T, int EPI, int MODE>
+__device__ __forceinline__ void lane_publish(const LaneArgs<T> &a, int rid, T s, T bv, T rd, T xo)
+{
+    const int row = rid & LANE_MASK;
+    const bool upd = !(rid & LANE_NODIAG);
+    T v = (bv - s) * rd;
+    if constexpr (EPI == EPI_SOR) v = a.omega * v + (T(1) - a.omega) * xo;
+    if (!upd) v = xo;
+    if constexpr (MODE == 1) __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (upd) a.y[row] = v;
+}
+
+// second half, butterfly form: wait for the early operands, row sums across the lanes, publish
 template <typename T, int EPI, int L, int K, int MODE>
-__device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int g, int idle, bool &local_ok)
+__device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int g, int idle)
 {
     const int lane = threadIdx.x & 63;
     const bool head = (lane & (L - 1)) == 0;
@@ -203,37 +235,19 @@ __device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<
     for (int k = 0; k < K; ++k)
         if ((S.c[k] & LANE_EARLY) && !(S.c[k] & LANE_NONE) && Sentinel<T>::bits(D.xv[k]) == Sentinel<T>::value) pend |= 1u << k;
     unsigned spins = 0;
-    if (S.gate >= 0 && __builtin_amdgcn_ballot_w64(pend != 0)) {
-        // the sweep is still two or more dependency levels away while the gate operand is missing: the whole wave polls that
-        // ONE value (one request per round) instead of all its operands
-        const T *gp = a.xs + S.gate;
-        while (true) {
-            const T gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (Sentinel<T>::bits(gv) != Sentinel<T>::value) break;
-            __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 1023u) == 0 && (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
-        }
-    }
+    if (S.gate >= 0 && __builtin_amdgcn_ballot_w64(pend != 0)) spins = lane_gate_wait<T>(a, S.gate);
     while (pend) {
         if (spins) __builtin_amdgcn_s_sleep(1);
         T t[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const T *hand = a.xs;
-            if constexpr (MODE == 2) hand = ((S.c[k] & LANE_LOCAL) && local_ok) ? a.xl : a.xs;
-            t[k] = __hip_atomic_load(((pend >> k) & 1u) ? hand + (S.c[k] & LANE_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (int k = 0; k < K; ++k)
+            t[k] = __hip_atomic_load(((pend >> k) & 1u) ? a.xs + (S.c[k] & LANE_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if ((pend >> k) & 1u) {
                 D.xv[k] = t[k];
                 if (Sentinel<T>::bits(t[k]) != Sentinel<T>::value) pend &= ~(1u << k);
             }
-        if constexpr (MODE == 2) {
-            // a slab served from two XCDs (flag raised by the workgroup that noticed): its L2-resident stores may never reach this
-            // XCD -- everybody falls back to the write-through buffer
-            if (local_ok && (spins & 63u) == 63u && __hip_atomic_load(a.aff + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) local_ok = false;
-        }
         if ((++spins & 1023u) == 0) {
             // a producer that never comes (not resident / an earlier time-out): give up together, quickly
             if (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -250,24 +264,104 @@ __device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<
         s = s + ((S.c[k] & LANE_NONE) ? T(0) : pr);
     }
     s = seg_allreduce<L, T>(s);
-    if (head && S.rid >= 0) {
-        const int row = S.rid & LANE_MASK;
-        const bool upd = !(S.rid & LANE_NODIAG);
-        T v = (D.bv - s) * S.rd;
-        if constexpr (EPI == EPI_SOR) v = a.omega * v + (T(1) - a.omega) * D.xo;
-        if (!upd) v = D.xo;
-        if constexpr (MODE == 1) __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else {
-            if constexpr (MODE == 2) __hip_atomic_store(a.xl + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(a.xs + row, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (upd) a.y[row] = v;
-    }
+    if (head && S.rid >= 0) lane_publish<T, EPI, MODE>(a, S.rid, s, D.bv, S.rd, D.xo);
     if (a.prof && lane == 0) {
         long long *o = a.prof + (size_t)g * 4;
         o[0] = D.t0; o[1] = t1; o[2] = wall_clock64();
         o[3] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) | (blockIdx.x << 4));
     }
+}
+
+// second half, ORDERED form (one row per wave): the old products by the butterfly while the first re-poll is in flight, then the early
+// products one by one in slot order as they have arrived (header comment)
+template <typename T, int EPI, int K, int MODE>
+__device__ __forceinline__ void lane_finish_ordered(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int g, int idle)
+{
+    using mask_t = unsigned long long;
+    const int lane = threadIdx.x & 63;
+    long long t1 = 0;
+    mask_t em[K], pm[K];                  // early slots not added yet / early slots whose operand has not arrived yet (wave-uniform)
+    bool pend[K];
+    mask_t anyp = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool early = (S.c[k] & LANE_EARLY) && !(S.c[k] & LANE_NONE);
+        pend[k] = early && Sentinel<T>::bits(D.xv[k]) == Sentinel<T>::value;
+        em[k] = __builtin_amdgcn_ballot_w64(early);
+        pm[k] = __builtin_amdgcn_ballot_w64(pend[k]);
+        anyp |= pm[k];
+    }
+    unsigned spins = 0;
+    if (S.gate >= 0 && anyp) spins = lane_gate_wait<T>(a, S.gate);
+    // the first re-poll goes out before the butterfly (always: a load under a branch would make the next wait drain the counter)
+    T t[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        t[k] = __hip_atomic_load(pend[k] ? a.xs + (S.c[k] & LANE_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    T so = T(0), pr[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        pr[k] = S.v[k] * D.xv[k];                                            // early slots still pending: overwritten when they arrive
+        so = so + (((S.c[k] & (LANE_NONE | LANE_EARLY)) == 0) ? pr[k] : T(0));
+    }
+    T acc = seg_allreduce<64, T>(so);
+    while (true) {
+        // take in the round that is in flight
+        mask_t left = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (pend[k]) {
+                D.xv[k] = t[k];
+                if (Sentinel<T>::bits(t[k]) != Sentinel<T>::value) { pend[k] = false; pr[k] = S.v[k] * t[k]; }
+            }
+            pm[k] = __builtin_amdgcn_ballot_w64(pend[k]);
+            left |= pm[k];
+        }
+        // add what is next in slot order and has arrived: the slots below the first early slot whose operand is still missing
+        bool blocked = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const mask_t pe = em[k] & pm[k];
+            const mask_t below = pe ? ((pe & (~pe + 1)) - 1) : ~(mask_t)0;
+            mask_t take = blocked ? (mask_t)0 : (em[k] & below);
+            em[k] &= ~take;
+            while (take) {
+                const int l = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(take));
+                acc = acc + lane_bcast(pr[k], l);
+                take &= take - 1;
+            }
+            blocked = blocked || pe != 0;
+        }
+        if (!blocked) break;
+        if ((++spins & 1023u) == 0) {
+            // a producer that never comes (not resident / an earlier time-out): give up together, quickly
+            if (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (spins > 1) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            t[k] = __hip_atomic_load(pend[k] ? a.xs + (S.c[k] & LANE_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)left;
+    }
+    if (a.prof && lane == 0) t1 = wall_clock64();
+    if (lane == 0 && S.rid >= 0) lane_publish<T, EPI, MODE>(a, S.rid, acc, D.bv, S.rd, D.xo);
+    if (a.prof && lane == 0) {
+        long long *o = a.prof + (size_t)g * 4;
+        o[0] = D.t0; o[1] = t1; o[2] = wall_clock64();
+        o[3] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) | (blockIdx.x << 4));
+    }
+}
+
+template <typename T, int EPI, int L, int K, int MODE>
+__device__ __forceinline__ void lane_finish_any(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int g, int idle)
+{
+    if constexpr (L == 64) {
+        if (a.tail) { lane_finish_ordered<T, EPI, K, MODE>(a, S, D, g, idle); return; }
+    }
+    lane_finish<T, EPI, L, K, MODE>(a, S, D, g, idle);
 }
 
 constexpr int LANE_WPB = BLK / 64;            // waves per workgroup (they never meet)
@@ -280,36 +374,22 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
     const int idle = (int)((((unsigned)blockIdx.x * LANE_WPB + (unsigned)wib) * 16u) % (unsigned)a.nidle);
     LaneSet<T, K> P, Q;
     LaneDyn<T, K> D;
-    bool local_ok = false;
     if constexpr (MODE != 1) {
-        int W = (int)gridDim.x * LANE_WPB;
+        const int W = (int)gridDim.x * LANE_WPB;
         int g = (int)blockIdx.x * LANE_WPB + wib;
-        int gend = a.ngroups;
-        if constexpr (MODE == 2) {
-            const int slab = (int)(blockIdx.x & 7u);
-            if (threadIdx.x == 0) {
-                const unsigned me = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1u;     // HW_REG_XCC_ID[3:0] + 1
-                unsigned seen = 0u;
-                __hip_atomic_compare_exchange_strong(a.aff + slab, &seen, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (seen != 0u && seen != me) __hip_atomic_store(a.aff + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            W = (int)(gridDim.x >> 3) * LANE_WPB;
-            g = a.slab_grp[slab] + (int)(blockIdx.x >> 3) * LANE_WPB + wib;
-            gend = a.slab_grp[slab + 1];
-            local_ok = __hip_atomic_load(a.aff + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
-        }
+        const int gend = a.ngroups;
         if (g >= gend) return;
         lane_load<T, L, K>(a, g, P);
         while (true) {
             const int g2 = g + W;
-            lane_issue<T, EPI, K, MODE>(a, P, D, idle, local_ok);
+            lane_issue<T, EPI, K>(a, P, D, idle);
             lane_load<T, L, K>(a, min(g2, gend - 1), Q);   // unconditional (a load under a branch makes the compiler drain the counter at the next wait)
-            lane_finish<T, EPI, L, K, MODE>(a, P, D, g, idle, local_ok);
+            lane_finish_any<T, EPI, L, K, MODE>(a, P, D, g, idle);
             if (g2 >= gend) break;
             g = g2 + W;
-            lane_issue<T, EPI, K, MODE>(a, Q, D, idle, local_ok);
+            lane_issue<T, EPI, K>(a, Q, D, idle);
             lane_load<T, L, K>(a, min(g, gend - 1), P);
-            lane_finish<T, EPI, L, K, MODE>(a, Q, D, g2, idle, local_ok);
+            lane_finish_any<T, EPI, L, K, MODE>(a, Q, D, g2, idle);
             if (g >= gend) break;
         }
     } else {
@@ -332,21 +412,21 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
         int g2 = (int)__builtin_amdgcn_readfirstlane(tk);
         while (true) {
             unsigned tk3 = 0;
-            lane_issue<T, EPI, K, MODE>(a, P, D, idle, local_ok);
+            lane_issue<T, EPI, K>(a, P, D, idle);
             if (g2 < a.ngroups) {
                 lane_load<T, L, K>(a, g2, Q);
                 if (lane == 0) tk3 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            lane_finish<T, EPI, L, K, MODE>(a, P, D, g, idle, local_ok);
+            lane_finish_any<T, EPI, L, K, MODE>(a, P, D, g, idle);
             if (g2 >= a.ngroups) break;
             g = (int)__builtin_amdgcn_readfirstlane(tk3);
             unsigned tk4 = 0;
-            lane_issue<T, EPI, K, MODE>(a, Q, D, idle, local_ok);
+            lane_issue<T, EPI, K>(a, Q, D, idle);
             if (g < a.ngroups) {
                 lane_load<T, L, K>(a, g, P);
                 if (lane == 0) tk4 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            lane_finish<T, EPI, L, K, MODE>(a, Q, D, g2, idle, local_ok);
+            lane_finish_any<T, EPI, L, K, MODE>(a, Q, D, g2, idle);
             if (g >= a.ngroups) break;
             g2 = (int)__builtin_amdgcn_readfirstlane(tk4);
         }
@@ -392,13 +472,13 @@ const void *lane_kernel_l(int L, int K)
     return nullptr;
 }
 
-// mode: 0 static across the chip, 1 one-XCD (tickets), 2 slabs (one per XCD)
+// mode: 0 static across the chip, 1 one-XCD (tickets)
 template <typename T>
 const void *lane_kernel(int epi, int L, int K, int mode)
 {
     // bsr_gauss_seidel with 1x1 blocks computes (b - sum) / a_ii as well: in this form the two are one kernel
-    if (epi == EPI_SOR) return mode == 1 ? lane_kernel_l<T, EPI_SOR, 1>(L, K) : mode == 2 ? lane_kernel_l<T, EPI_SOR, 2>(L, K) : lane_kernel_l<T, EPI_SOR, 0>(L, K);
-    return mode == 1 ? lane_kernel_l<T, EPI_GS, 1>(L, K) : mode == 2 ? lane_kernel_l<T, EPI_GS, 2>(L, K) : lane_kernel_l<T, EPI_GS, 0>(L, K);
+    if (epi == EPI_SOR) return mode == 1 ? lane_kernel_l<T, EPI_SOR, 1>(L, K) : lane_kernel_l<T, EPI_SOR, 0>(L, K);
+    return mode == 1 ? lane_kernel_l<T, EPI_GS, 1>(L, K) : lane_kernel_l<T, EPI_GS, 0>(L, K);
 }
 
 }  // namespace
@@ -406,7 +486,7 @@ const void *lane_kernel(int epi, int L, int K, int mode)
 void free_lane_part(LaneSched *t)
 {
     if (!t) return;
-    hipFree(t->d_cols); hipFree(t->d_rid); hipFree(t->d_vals); hipFree(t->d_rdiag); hipFree(t->d_prof); hipFree(t->d_gate); hipFree(t->d_xl);
+    hipFree(t->d_cols); hipFree(t->d_rec); hipFree(t->d_vals); hipFree(t->d_prof);
     delete t;
 }
 
@@ -422,50 +502,71 @@ static bool lane_one_xcd(const pamg_matrix_s *A, const GsSchedule *g)
     return A->gran_xcd == 1 || (A->gran_xcd == 0 && A->nrows <= 131072 && g->nrows / std::max(1, g->nlevels) <= 1024);
 }
 
-// The layout filled on the device (default for one slab): the host plan (pattern only, build_lane_plan with fill = false) gives the row
-// of every (group, slot row) and the gates; this kernel writes cols / vals / rdiag and the NODIAG flags from the resident CSR arrays --
-// no download of the values, no upload of the padded 12-byte slots (256^3 level 1: 1.5 GB, 1 s of host time per direction).
-// One wave per group; the L lanes of a row all walk the row (broadcast loads), lane q keeps entries e = q, q + L, ...: the slot rule
-// of the host's fill pass (entries in storage order without the diagonal, the last stored diagonal wins).
+// The layout filled on the device (the default): the host plan (pattern only, build_lane_plan with fill = false) gives the row of every
+// (group, slot row) and the gates; this kernel writes cols / vals and the 16-byte slot-row records (row | NODIAG, gate, 1 / a_ii) from the
+// resident CSR arrays -- no download of the values, no upload of the padded 12-byte slots (256^3 level 1: 1.5 GB, 1 s of host time per direction).
+// One wave per group; the L lanes of a row all walk the row (broadcast loads), lane q keeps the entries e = q, q + L, ... of the storage order and
+// ranks each of them in the row's SLOT ORDER (lane_slot_order, pamg_lane_plan.h: old operands first, early ones by ascending producer level --
+// lvl[] is the host's analysis, uploaded for this launch) by walking the row once more.
 template <typename T>
-__global__ __launch_bounds__(256) void lane_fill_kernel(int n, const int *__restrict__ Ap, const int *__restrict__ Aj, const T *__restrict__ Ax, int row_start,
-                                                        int row_step, long long m, int L, int K, long long ngroups, int *__restrict__ rid,
-                                                        int *__restrict__ cols, T *__restrict__ vals, T *__restrict__ rdiag)
+__global__ __launch_bounds__(256) void lane_fill_kernel(int n, const int *__restrict__ Ap, const int *__restrict__ Aj, const T *__restrict__ Ax, const int *__restrict__ lvl,
+                                                        int row_start, int row_step, long long m, int L, int K, long long ngroups, const int *__restrict__ rid,
+                                                        const int *__restrict__ gate, int *__restrict__ cols, T *__restrict__ vals, LaneRec *__restrict__ rec)
 {
     const long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63);
     if (g >= ngroups) return;
     const int RPW = 64 / L, r = lane / L, q = lane - r * L;
     const int i = rid[g * RPW + r];
-    int e = 0;
+    int cnt = 0;
     T d = T(0);
     if (i >= 0) {
         const long long ti = ((long long)i - row_start) * row_step;
+        auto key_of = [&](int j) -> int {
+            if (j < 0 || j >= n) return -1;
+            const long long tj = ((long long)j - row_start) * row_step;
+            return (tj >= 0 && tj < m && tj < ti) ? lvl[j] : -1;
+        };
+        int e = 0;
         for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
             const int j = Aj[p];
             if (j == i) { d = Ax[p]; continue; }
             if (e % L == q) {
-                const size_t s = (size_t)((g * K + e / L) * 64 + lane);
+                const int ke = key_of(j);
+                int rank = 0, f = 0;
+                for (int p2 = Ap[i]; p2 < Ap[i + 1]; ++p2) {
+                    const int j2 = Aj[p2];
+                    if (j2 == i) continue;
+                    const int kf = key_of(j2);
+                    rank += (kf < ke) || (kf == ke && f < e);
+                    ++f;
+                }
+                const size_t s = (size_t)((g * K + rank / L) * 64 + r * L + rank % L);
                 if (j < 0 || j >= n) { cols[s] = LANE_NONE; vals[s] = T(0); }
                 else {
-                    const long long tj = ((long long)j - row_start) * row_step;
-                    const bool early = tj >= 0 && tj < m && tj < ti;
-                    cols[s] = j | (early ? LANE_EARLY : 0);
+                    cols[s] = j | (ke >= 0 ? LANE_EARLY : 0);
                     vals[s] = Ax[p];
                 }
             }
             ++e;
         }
+        cnt = e;
     }
-    // this lane's unused slots: padding
-    for (int k = (e - q + L - 1) / L; k < K; ++k) {
-        const size_t s = (size_t)((g * K + k) * 64 + lane);
-        cols[s] = LANE_NONE; vals[s] = T(0);
-    }
+    // the slots behind the row's entries: padding (slot es = k * L + q of this lane)
+    for (int k = 0; k < K; ++k)
+        if (k * L + q >= cnt) {
+            const size_t s = (size_t)((g * K + k) * 64 + lane);
+            cols[s] = LANE_NONE; vals[s] = T(0);
+        }
     if (q == 0) {
         const bool nodiag = !(d != T(0));
-        rdiag[g * RPW + r] = (i >= 0 && !nodiag) ? T(1) / d : T(0);
-        if (i >= 0 && nodiag) rid[g * RPW + r] = i | LANE_NODIAG;
+        const T rd = (i >= 0 && !nodiag) ? T(1) / d : T(0);
+        LaneRec R;
+        R.rid = (i >= 0 && nodiag) ? (i | LANE_NODIAG) : i;
+        R.gate = gate[g];
+        if constexpr (sizeof(T) == 8) { R.rd_lo = __double2loint((double)rd); R.rd_hi = __double2hiint((double)rd); }
+        else { R.rd_lo = __float_as_int((float)rd); R.rd_hi = 0; }
+        rec[g * RPW + r] = R;
     }
 }
 
@@ -474,67 +575,70 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
     if (g->lane) return PAMG_OK;
     PhaseTimer pt_("build_lane_part", A->nnz);
     const int ts = (int)tsize(A->dtype);
-    // PAMG_LANE_HOST_FILL=1: the whole layout on the host (what the CPU suite replays); default: filled on the device
+    // PAMG_LANE_HOST_FILL=1: the whole layout on the host (what the CPU suite replays); default: filled on the device.  The device
+    // fill derives visit indices from (row - row_start) * row_step, which is the host's numbering for unit steps only
     const char *hf = getenv("PAMG_LANE_HOST_FILL");
-    const bool want_slabs = !lane_one_xcd(A, g) && (A->lane_flags & 2) && g->nrows >= 262144 && A->nrows < LANE_LOCAL;
-    const bool host_fill = (hf && *hf == '1') || want_slabs || !A->d_Ap || !A->d_Aj || !A->d_Ax;
+    const bool host_fill = (hf && *hf == '1') || !A->d_Ap || !A->d_Aj || !A->d_Ax || (g->row_step != 1 && g->row_step != -1);
     PlanVec<unsigned char> hAx;
     if (host_fill) {
         hAx.resize((size_t)A->nnz * ts);
         if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
     }
     LanePlan P;
-    // Lanes per row.  Operators small enough for the one-XCD form (32 CUs): the fewest lanes that hold a row (most rows per
-    // wave).  Across the chip waves are plentiful and the sweep is bound by the hand-off latency per dependency level: ONE
-    // ROW PER WAVE where the rows are long enough to fill it (a wave then waits for its own row's operands only, not for the
-    // slowest of 4 or 16 rows) -- level 1 of the 256^3 hierarchy, 31 entries per row: 2.65 ms with 16 lanes per row, 2.49
-    // with 32, 2.37 with 64 (profiles/r04_microbench_lane_width.json).
+    // Lanes per row: ONE ROW PER WAVE where the rows are long enough to fill half of it -- a wave then waits for its own row's
+    // operands only (not for the slowest of 2 .. 16 rows), and the ordered tail of the kernel applies (level 1 of the 256^3
+    // hierarchy, 31 entries per row: 2.65 ms with 16 lanes per row, 2.49 with 32, 2.37 with 64, profiles/r04_microbench_lane_width.json;
+    // levels 2 / 3, 57 .. 68 entries: 0.70 / 0.72 ms with 32 / 64 lanes before the ordered tail).  Short rows (stencils): several rows
+    // per wave.
     int want_L = A->lane_L;
-    if (!want_L && !lane_one_xcd(A, g)) {
+    if (!want_L) {
         want_L = 4;
         while (want_L < 64 && want_L < A->max_row_len - 1) want_L *= 2;
-        if (want_L < 32) want_L = 0;                           // short rows: several rows per wave (stencils)
+        if (want_L < 32) want_L = 0;
+        else want_L = 64;
     }
-    // Slabs (one per XCD) for operators that run across the chip and are big enough to keep eight XCDs busy: an operand from the
-    // consumer's own slab is handed over through the XCD's L2 instead of through memory (lane_flags bit 1; profiles/r04_*slab*)
-    const bool slabs = want_slabs;
     if (build_lane_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), host_fill ? hAx.data() : nullptr, ts, g->row_start, g->row_step, (int)g->nrows,
-                        g->nlevels, g->h_vis, g->h_lvl, want_L, P, slabs ? LANE_MAX_SLABS : 1, A->lane_chunk, host_fill))
+                        g->nlevels, g->h_vis, g->h_lvl, want_L, P, host_fill))
         return PAMG_E_ARG;
     LaneSched *t = new (std::nothrow) LaneSched();
     if (!t) return PAMG_E_ALLOC;
     t->L = P.L; t->K = P.K; t->RPW = P.RPW; t->ngroups = P.ngroups;
     t->n_early = P.n_early; t->n_old = P.n_old; t->n_slots = P.n_slots;
     t->max_level_groups = P.max_level_groups;
-    t->nslabs = P.nslabs; t->n_local = P.n_local;
-    for (int k = 0; k <= LANE_MAX_SLABS; ++k) t->slab_grp[k] = (int)P.slab_grp[std::min(k, P.nslabs)];
-    int st = lane_upload(&t->d_rid, P.rid.data(), P.rid.size() * sizeof(int), &t->bytes);
-    if (!st) st = lane_upload(&t->d_gate, P.gate.data(), P.gate.size() * sizeof(int), &t->bytes);
+    const size_t nrec = (size_t)P.ngroups * P.RPW;
+    int st = PAMG_OK;
     if (host_fill) {
+        std::vector<LaneRec> rec(nrec);
+        for (size_t q = 0; q < nrec; ++q) {
+            rec[q].rid = P.rid[q];
+            rec[q].gate = P.gate[q / (size_t)P.RPW];
+            rec[q].rd_lo = rec[q].rd_hi = 0;
+            std::memcpy(&rec[q].rd_lo, &P.rdiag[q * (size_t)ts], (size_t)ts);
+        }
+        st = lane_upload(&t->d_rec, rec.data(), nrec * sizeof(LaneRec), &t->bytes);
         if (!st) st = lane_upload(&t->d_cols, P.cols.data(), P.cols.size() * sizeof(int), &t->bytes);
         if (!st) st = lane_upload(&t->d_vals, P.vals.data(), P.vals.size(), &t->bytes);
-        if (!st) st = lane_upload(&t->d_rdiag, P.rdiag.data(), P.rdiag.size(), &t->bytes);
     } else {
+        int *d_rid = nullptr, *d_gate = nullptr, *d_lvl = nullptr;
+        st = lane_upload(&d_rid, P.rid.data(), P.rid.size() * sizeof(int), nullptr);
+        if (!st) st = lane_upload(&d_gate, P.gate.data(), P.gate.size() * sizeof(int), nullptr);
+        if (!st) st = lane_upload(&d_lvl, g->h_lvl.data(), g->h_lvl.size() * sizeof(int), nullptr);
+        if (!st) st = lane_upload(&t->d_rec, nullptr, nrec * sizeof(LaneRec), &t->bytes);
         if (!st) st = lane_upload(&t->d_cols, nullptr, (size_t)P.n_slots * sizeof(int), &t->bytes);
         if (!st) st = lane_upload(&t->d_vals, nullptr, (size_t)P.n_slots * ts, &t->bytes);
-        if (!st) st = lane_upload(&t->d_rdiag, nullptr, (size_t)P.ngroups * P.RPW * ts, &t->bytes);
         if (!st) {
             const unsigned grid = (unsigned)((P.ngroups + 3) / 4);
             (void)hipGetLastError();                                  // a stale error of an earlier query must not be taken for this launch's
             if (ts == 8)
-                hipLaunchKernelGGL((lane_fill_kernel<double>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const double *)A->d_Ax, g->row_start, g->row_step,
-                                   (long long)g->nrows, P.L, P.K, (long long)P.ngroups, t->d_rid, t->d_cols, (double *)t->d_vals, (double *)t->d_rdiag);
+                hipLaunchKernelGGL((lane_fill_kernel<double>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const double *)A->d_Ax, d_lvl, g->row_start, g->row_step,
+                                   (long long)g->nrows, P.L, P.K, (long long)P.ngroups, d_rid, d_gate, t->d_cols, (double *)t->d_vals, t->d_rec);
             else
-                hipLaunchKernelGGL((lane_fill_kernel<float>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const float *)A->d_Ax, g->row_start, g->row_step,
-                                   (long long)g->nrows, P.L, P.K, (long long)P.ngroups, t->d_rid, t->d_cols, (float *)t->d_vals, (float *)t->d_rdiag);
+                hipLaunchKernelGGL((lane_fill_kernel<float>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const float *)A->d_Ax, d_lvl, g->row_start, g->row_step,
+                                   (long long)g->nrows, P.L, P.K, (long long)P.ngroups, d_rid, d_gate, t->d_cols, (float *)t->d_vals, t->d_rec);
             st = (int)hipGetLastError();
             if (!st) st = (int)hipDeviceSynchronize();
         }
-    }
-    if (!st && P.nslabs > 1) {
-        const size_t xb = ((size_t)A->nrows + 8) * (size_t)ts;
-        st = (int)hipMalloc(&t->d_xl, xb);
-        if (!st) t->bytes += xb;
+        hipFree(d_rid); hipFree(d_gate); hipFree(d_lvl);
     }
     if (st) { free_lane_part(t); return st; }
     g->lane = t;
@@ -545,12 +649,14 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
 size_t lane_part_bytes(const GsSchedule *g) { return (g && g->lane) ? g->lane->bytes : 0; }
 
 // workgroups of the static form that are certainly co-resident: (occupancy - 1, at most 8) per CU -- the occupancy query
-// can over-report by one per CU (MI355X_MICROARCH.md)
-static int lane_grid_cap(const void *k)
+// can over-report by one per CU (MI355X_MICROARCH.md).  Asked once per schedule and kernel, not per sweep.
+static int lane_grid_cap(LaneSched *t, const void *k)
 {
+    if (t->cap > 0 && t->cap_kernel == k) return t->cap;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, BLK, 0) != hipSuccess) nb = 2;
     nb = std::max(1, std::min(nb - 1, 8));
+    t->cap = nb; t->cap_kernel = k;
     return nb;
 }
 
@@ -569,16 +675,14 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     const size_t ts = tsize(A->dtype);
     const int64_t n = A->nrows;
     LaneArgs<T> a;
-    a.cols = t->d_cols; a.vals = (const T *)t->d_vals; a.rid = t->d_rid; a.rdiag = (const T *)t->d_rdiag;
-    a.gate = (A->lane_flags & 1) ? t->d_gate : nullptr;
+    a.cols = t->d_cols; a.vals = (const T *)t->d_vals; a.rec = t->d_rec;
+    a.use_gate = (A->lane_flags & 1) ? 1 : 0;
+    a.tail = (A->lane_flags & 16) ? 0 : 1;
     a.x = (const T *)x; a.y = (T *)x; a.xs = (T *)g->d_xs; a.b = (const T *)b;
     a.err = g->d_sync + 1; a.ticket = g->d_sync + 20;
-    a.xl = (T *)t->d_xl; a.aff = g->d_sync + 32;
-    for (int k = 0; k <= LANE_MAX_SLABS; ++k) a.slab_grp[k] = t->slab_grp[k];
     a.ngroups = (int)t->ngroups;
     a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
     a.omega = (T)omega;
-    a.old_l1 = (A->lane_flags & 4) ? 1 : 0;
     if (!g->symmetric) {
         // write-after-read hazards are not ordered by the waits: old values come from a snapshot
         if (!g->d_xold) return PAMG_E_STATE;
@@ -595,15 +699,11 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     PAMG_HIP(hipGetLastError());
     const int per_level = (int)((t->ngroups + g->nlevels - 1) / g->nlevels);
     const bool xcd = lane_one_xcd(A, g);
-    const bool slab = !xcd && t->nslabs == LANE_MAX_SLABS && t->d_xl && (A->lane_flags & 2);
-    // (a slab layout can always run in the plain static form: wave w takes groups w, w + W, ...; the slab-major numbering is
-    // still level-ordered inside every slab and no group waits for a group of a LATER slab -- but not the other way round)
-    if (t->nslabs > 1 && !slab) return PAMG_E_STATE;
-    const void *k = lane_kernel<T>(epi, t->L, t->K, xcd ? 1 : slab ? 2 : 0);
+    const void *k = lane_kernel<T>(epi, t->L, t->K, xcd ? 1 : 0);
     if (!k) return PAMG_E_ARG;
     static thread_local int cus = 0;
     if (!cus) cus = device_cus_lane();
-    const int cap = lane_grid_cap(k);
+    const int cap = lane_grid_cap(t, k);
     // waves wanted: ~4 dependency levels of look-ahead (a wave that runs ahead waits in its poll loop with its operands in
     // registers) -- more waves poll more and the polls load the memory system (measured on the 256^3 hierarchy,
     // profiles/r04_microbench_lane_first.json: level 1, 227 groups per dependency level: 2.67 ms with 512 waves, 2.72 with
@@ -613,15 +713,6 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     int G = (int)std::min<int64_t>((want_waves + LANE_WPB - 1) / LANE_WPB, (int64_t)cap * cus);
     if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + LANE_WPB - 1) / LANE_WPB));
-    if (slab) {
-        // the front of the sweep is inside about half of the slabs at any time: twice the waves, a multiple of 8 workgroups
-        G = std::min(2 * G, cap * cus);
-        if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
-        G = std::max(8, G & ~7);
-        hipLaunchKernelGGL((lane_fill_sentinel_kernel<T>), dim3(fgrid), dim3(BLK), 0, s, (T *)t->d_xl, n);
-        PAMG_HIP(hipGetLastError());
-        PAMG_HIP(hipMemsetAsync(g->d_sync + 32, 0, 16 * sizeof(unsigned), s));
-    }
     void *args[] = {(void *)&a};
     if (xcd) {
         // 8x the wanted grid is launched; the workgroups off the home XCD leave at once

@@ -18,16 +18,18 @@
 //   rid  [g * RPW + r]               original row (-1: dummy row of the padding) | NODIAG (bit 30: the row has no or a
 //                                    zero diagonal: it is left untouched, relaxation.h:72-74, but still publishes its value)
 //   rdiag[g * RPW + r]               1 / a_ii
-// Slab layouts (nslabs = 8: one slab per XCD).  The visited rows are cut into nslabs contiguous pieces of the VISIT order and
-// the groups are numbered slab after slab (levels ascending inside a slab); an early operand produced in the consumer's own
-// slab carries LOCAL (bit 29).  The kernel gives slab s to the workgroups with blockIdx % 8 == s -- which the dispatcher
-// places on one XCD -- so a LOCAL operand can be handed over through that XCD's L2 (~0.5 us) instead of through memory
-// (~1 us).  An early operand never comes from a LATER slab, so a dependency chain crosses slab boundaries at most nslabs - 1 times.
 //   gate [g]                         "gate" operand of the group: the column of its early operand with the HIGHEST dependency
 //                                    level among those at least two levels below the group's own (-1: none).  A wave that runs
 //                                    ahead polls this one value until the sweep is one level away, and only then all its
 //                                    operands: polling traffic of ~1 instead of ~3 dependency levels per group.
-// with lane = r * L + i and the row's off-diagonal entries e = 0, 1, ... (storage order) at k = e / L, i = e % L.
+// (on the device rid, gate and rdiag of a slot row travel as ONE 16-byte record, pamg_lane.hip: one request instead of three)
+// with lane = r * L + i and the row's off-diagonal entries in SLOT ORDER e = 0, 1, ... at k = e / L, i = e % L.
+// Slot order (round 5): the OLD operands first (storage order), then the EARLY operands by ascending dependency level of
+// the row that produces them (ties: storage order).  The kernel adds the old products with the butterfly while the polls
+// are in flight and then the early products ONE BY ONE in slot order -- the operands of the level just below, the last
+// to arrive, are the last to be added: behind the last hand-off there is one multiply-add instead of a butterfly
+// (one row per wave; several rows per wave keep the butterfly over everything).  The order is a property of the layout,
+// not of the timing: results are reproducible bit for bit.
 // Diagonal entries are not stored at all (every stored a_ii is skipped by the reference's sum; the last one is the
 // diagonal, relaxation.h:64-69).
 #pragma once
@@ -45,10 +47,8 @@ namespace pamg {
 constexpr int LANE_KMAX = 4;                  // entry slots per lane the kernels are built for
 constexpr int LANE_EARLY = (int)0x80000000u;
 constexpr int LANE_NONE = 0x40000000;
-constexpr int LANE_LOCAL = 0x20000000;        // slab layouts: the early operand is produced in the consumer's own slab
-constexpr int LANE_MASK = 0x1FFFFFFF;
+constexpr int LANE_MASK = 0x3FFFFFFF;
 constexpr int LANE_NODIAG = 0x40000000;       // in rid[]
-constexpr int LANE_MAX_SLABS = 8;
 
 struct LanePlan {
     int L = 0, K = 0, RPW = 0;
@@ -60,11 +60,9 @@ struct LanePlan {
     std::vector<int> rid;
     std::vector<unsigned char> rdiag;         // ngroups * RPW values of tsize bytes
     std::vector<int> gate;                    // [ngroups] column of the group's latest early operand from a level <= own level - 2, or -1
-    std::vector<int64_t> level_grp;           // [nslabs * nlevels + 1] group range of each (slab, dependency level) bucket, slab-major
-    int nslabs = 1;
-    int64_t slab_grp[LANE_MAX_SLABS + 1] = {0};   // group range of each slab
-    int64_t n_early = 0, n_old = 0, n_slots = 0, n_local = 0;
-    int64_t max_level_groups = 0;             // groups of the widest dependency level (all slabs)
+    std::vector<int64_t> level_grp;           // [nlevels + 1] group range of each dependency level
+    int64_t n_early = 0, n_old = 0, n_slots = 0;
+    int64_t max_level_groups = 0;             // groups of the widest dependency level
 };
 
 template <typename F>
@@ -95,35 +93,40 @@ inline int lane_geometry(int maxlen, int want_L, int &K)
     return 0;
 }
 
+// slot order of one row: position in [0, entries) of every off-diagonal entry (storage order e = 0, 1, ...), see the header
+// comment -- OLD operands first, then EARLY operands by ascending producer level, storage order among equals.  key[e] = -1 for
+// an old operand (or an entry that is no column of x), the producer's dependency level for an early one.
+inline void lane_slot_order(const int *key, int cnt, int *slot)
+{
+    for (int e = 0; e < cnt; ++e) {
+        int r = 0;
+        for (int f = 0; f < cnt; ++f) r += (key[f] < key[e]) || (key[f] == key[e] && f < e);
+        slot[e] = r;
+    }
+}
+
 // Build the layout from a finished analysis of the sweep (vis = visit index or -1, lvl = dependency level of every
 // visited row: sweep_levels in pamg_tile_plan.h), m visited rows, nl levels.  Ax: the operator's values (tsize bytes
 // each).  Returns 0, or 1 when the rows are too long / the padding too wasteful (caller keeps the exact schedulers).
 inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned char *Ax, int tsize, int row_start, int row_step,
-                           int m, int nl, const std::vector<int> &vis, const std::vector<int> &lvl, int want_L, LanePlan &P, int nslabs = 1,
-                           int chunk = 0, bool fill = true)
+                           int m, int nl, const std::vector<int> &vis, const std::vector<int> &lvl, int want_L, LanePlan &P, bool fill = true)
 {
-    // fill = false (one slab only): the structure, the row of every (group, slot row), the gates and the statistics -- cols, vals,
-    // rdiag and the NODIAG flags are then written by the device from the resident CSR arrays (lane_fill_kernel, pamg_lane.hip);
-    // Ax may be null
+    // fill = false: the structure, the row of every (group, slot row), the gates and the statistics -- cols, vals, rdiag and the
+    // NODIAG flags are then written by the device from the resident CSR arrays (lane_fill_kernel, pamg_lane.hip); Ax may be null
     P = LanePlan();
     P.nlevels = nl;
     if (m <= 0 || nl <= 0) return 1;
-    if (nslabs < 1 || nslabs > LANE_MAX_SLABS || (int64_t)nslabs * nl >= ((int64_t)1 << 30) || n >= LANE_LOCAL) nslabs = 1;
-    P.nslabs = nslabs;
-    const int64_t nb = (int64_t)nslabs * nl;                                   // buckets (slab, level), slab-major
-    // chunk = 0: nslabs contiguous pieces of the visit order; chunk > 0: pieces of `chunk` visited rows dealt out to the slabs in turn
-    // (the front of a sweep covers a band of the visit order: contiguous slabs would take turns, dealt-out chunks all work at once)
-    auto slab_of_visit = [&](int t) { return chunk > 0 ? (int)((t / chunk) % nslabs) : (int)((int64_t)t * nslabs / m); };
-    // rows in bucket order, visit order inside a bucket
-    std::vector<int64_t> lptr((size_t)nb + 1, 0);
-    for (int t = 0; t < m; ++t) lptr[(size_t)((int64_t)slab_of_visit(t) * nl + lvl[row_start + (int64_t)t * row_step]) + 1]++;
-    for (int64_t l = 0; l < nb; ++l) lptr[l + 1] += lptr[l];
+    if (n > LANE_MASK) return 1;
+    // rows in level order, visit order inside a level
+    std::vector<int64_t> lptr((size_t)nl + 1, 0);
+    for (int t = 0; t < m; ++t) lptr[(size_t)lvl[row_start + (int64_t)t * row_step] + 1]++;
+    for (int l = 0; l < nl; ++l) lptr[l + 1] += lptr[l];
     std::vector<int> order((size_t)m);
     {
         std::vector<int64_t> cur(lptr.begin(), lptr.end() - 1);
         for (int t = 0; t < m; ++t) {
             const int i = row_start + t * row_step;
-            order[(size_t)cur[(size_t)((int64_t)slab_of_visit(t) * nl + lvl[i])]++] = i;
+            order[(size_t)cur[(size_t)lvl[i]]++] = i;
         }
     }
     int maxlen = 0;
@@ -154,21 +157,18 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
     if (!L) return 1;
     const int RPW = 64 / L;
     P.L = L; P.K = K; P.RPW = RPW;
-    P.level_grp.assign((size_t)nb + 1, 0);
-    for (int64_t l = 0; l < nb; ++l) P.level_grp[l + 1] = P.level_grp[l] + (lptr[l + 1] - lptr[l] + RPW - 1) / RPW;
-    P.ngroups = P.level_grp[nb];
-    for (int sl = 0; sl <= nslabs; ++sl) P.slab_grp[sl] = P.level_grp[(size_t)((int64_t)sl * nl)];
+    P.level_grp.assign((size_t)nl + 1, 0);
     for (int l = 0; l < nl; ++l) {
-        int64_t w = 0;
-        for (int sl = 0; sl < nslabs; ++sl) w += P.level_grp[(size_t)((int64_t)sl * nl + l) + 1] - P.level_grp[(size_t)((int64_t)sl * nl + l)];
+        const int64_t w = (lptr[l + 1] - lptr[l] + RPW - 1) / RPW;
+        P.level_grp[l + 1] = P.level_grp[l] + w;
         P.max_level_groups = std::max(P.max_level_groups, w);
     }
+    P.ngroups = P.level_grp[nl];
     P.n_slots = P.ngroups * K * 64;
     // padding inside the rows (a few long rows set K for everybody): give up when the rows' slots exceed 4x the entries
     // (+ 8 per row: short rows are fine); the padding of every level to whole groups is at most one group per level
     if ((int64_t)K * L * m > 4 * total + (int64_t)8 * L * m || P.n_slots >= ((int64_t)1 << 33)) return 1;
     if (P.ngroups >= ((int64_t)1 << 30)) return 1;
-    if (nslabs > 1) fill = true;
     if (fill) {
         plan_fill(P.cols, (size_t)P.n_slots, (int)LANE_NONE);
         plan_fill(P.vals, (size_t)P.n_slots * tsize, (unsigned char)0);
@@ -191,23 +191,34 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
             }
         }
     });
-    std::vector<int64_t> ne((size_t)nb, 0), no((size_t)nb, 0), nloc((size_t)nb, 0);
-    lane_parallel(nb, [&](int64_t l0, int64_t l1) {
-        for (int64_t bk = l0; bk < l1; ++bk) {
-            const int64_t l = bk;                                               // bucket index into lptr / level_grp
-            const int mylevel = (int)(bk % nl), myslab = (int)(bk / nl);
-            int64_t e_cnt = 0, o_cnt = 0, l_cnt = 0;
+    std::vector<int64_t> ne((size_t)nl, 0), no((size_t)nl, 0);
+    lane_parallel(nl, [&](int64_t l0, int64_t l1) {
+        std::vector<int> key, slot;
+        for (int64_t l = l0; l < l1; ++l) {
+            const int mylevel = (int)l;
+            int64_t e_cnt = 0, o_cnt = 0;
             for (int64_t q = lptr[l]; q < lptr[l + 1]; ++q) {
                 const int64_t rel = q - lptr[l];
                 const int64_t g = P.level_grp[l] + rel / RPW;
                 const int r = (int)(rel % RPW);
                 const int i = order[(size_t)q], ti = vis[i];
+                // pass 1: keys of the off-diagonal entries in storage order
+                key.clear();
+                for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+                    const int j = Aj[p];
+                    if (j == i) continue;
+                    const bool early = j >= 0 && j < n && vis[j] >= 0 && vis[j] < ti;
+                    key.push_back(early ? lvl[j] : -1);
+                }
+                slot.resize(key.size());
+                lane_slot_order(key.data(), (int)key.size(), slot.data());
                 int e = 0;
                 const unsigned char *dptr = nullptr;
                 for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
                     const int j = Aj[p];
                     if (j == i) { if (fill) dptr = Ax + (size_t)p * tsize; continue; }          // last stored diagonal wins
-                    const int k = e / L, lane = r * L + e % L;
+                    const int es = slot[(size_t)e];
+                    const int k = es / L, lane = r * L + es % L;
                     const size_t s = (size_t)((g * K + k) * 64 + lane);
                     ++e;
                     if (j < 0 || j >= n) continue;                                    // not a column of x: no product
@@ -217,10 +228,8 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                         if (lvl[cand] > mylevel - 2) cand = best_dep[(size_t)j];          // one level down: its own latest operand is two or more down
                         if (cand >= 0 && lvl[cand] <= mylevel - 2 && lvl[cand] > gate_lvl[(size_t)g]) { gate_lvl[(size_t)g] = lvl[cand]; P.gate[(size_t)g] = cand; }
                     }
-                    const bool local = early && nslabs > 1 && slab_of_visit(vis[j]) == myslab;
-                    if (local) ++l_cnt;
                     if (fill) {
-                        P.cols[s] = j | (early ? LANE_EARLY : 0) | (local ? LANE_LOCAL : 0);
+                        P.cols[s] = j | (early ? LANE_EARLY : 0);
                         std::memcpy(&P.vals[s * tsize], Ax + (size_t)p * tsize, (size_t)tsize);
                     }
                     if (early) ++e_cnt; else ++o_cnt;
@@ -243,10 +252,10 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                 }
                 P.rid[(size_t)(g * RPW + r)] = fill ? (i | (nodiag ? LANE_NODIAG : 0)) : i;
             }
-            ne[(size_t)l] = e_cnt; no[(size_t)l] = o_cnt; nloc[(size_t)l] = l_cnt;
+            ne[(size_t)l] = e_cnt; no[(size_t)l] = o_cnt;
         }
     }, 1);
-    for (int64_t l = 0; l < nb; ++l) { P.n_early += ne[(size_t)l]; P.n_old += no[(size_t)l]; P.n_local += nloc[(size_t)l]; }
+    for (int l = 0; l < nl; ++l) { P.n_early += ne[(size_t)l]; P.n_old += no[(size_t)l]; }
     return 0;
 }
 

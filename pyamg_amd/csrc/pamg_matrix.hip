@@ -2072,11 +2072,14 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 25: if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return PAMG_E_ARG; A->lane_L = value; break;
         case 26: if (value < 0) return PAMG_E_ARG; A->lane_G = value; return PAMG_OK;
         case 27: if (value < 0 || value > 1) return PAMG_E_ARG; A->lane_wide = value; return PAMG_OK;
-        case 29: if (value < 0) return PAMG_E_ARG; A->lane_chunk = value; key = 25; break;
-        case 30: if (value < 0 || value > 2) return PAMG_E_ARG; A->line_scan = value; return PAMG_OK;      // 2: also where the estimate favours the lane form
+        case 30:                                               // 2: also where the estimate favours the lane form
+            if (value < 0 || value > 2) return PAMG_E_ARG;
+            A->line_scan = value;
+            for (int k = 0; k < 4; ++k) if (A->gs[k]) A->gs[k]->line_unfit = false;      // a schedule the planner declined on its estimate is asked again
+            return PAMG_OK;
         case 31: if (value != 2 && value != 4 && value != 8) return PAMG_E_ARG; A->rowmask_kz = value; return PAMG_OK;
         case 32: if (value < 0 || value > 15) return PAMG_E_ARG; A->rowmask_flags = value; return PAMG_OK;
-        case 28: if (value < 0 || value > 15) return PAMG_E_ARG; { const bool relayout = ((A->lane_flags ^ value) & 2) != 0; A->lane_flags = value; if (!relayout) return PAMG_OK; } key = 25; break;
+        case 28: if (value < 0 || value > 31 || (value & 6)) return PAMG_E_ARG; A->lane_flags = value; return PAMG_OK;      // bits 1, 2: retired (slab form, old values through the L1)
         default: return PAMG_E_ARG;
     }
     if (key == 25) {                                  // lane geometry: drop the lane parts only

@@ -1,11 +1,15 @@
 // lane_emul.cpp -- CPU replay of the lane-parallel fast-order sweep (test infrastructure, not product code).
 // Builds the layout with the product's own planner (pyamg_amd/csrc/pamg_lane_plan.h) and consumes it the way
-// gs_lane_kernel does: group after group, lane l of a group adds its K products, the lanes of a row are added by the
-// XOR butterfly (1, 2, 4, ...), the head lane finishes the row with (b - sum) * rdiag, publishes into the
-// sentinel-filled hand-off buffer and stores x.  Checks on the way what the device relies on: every EARLY operand has
-// been published by a group with a SMALLER number (deadlock freedom of the static assignment), every OLD operand is
-// still old when it is read (write-after-read safety on structurally symmetric patterns, else a snapshot is used),
-// dummy rows / padding slots carry no product.
+// gs_lane_kernel does: group after group, lane l of a group forms its K products;
+//   several rows per wave (L < 64): all products of a row are added by the XOR butterfly (1, 2, 4, ...),
+//   one row per wave (L = 64, the ORDERED TAIL of round 5): the OLD products by the butterfly, then the EARLY products one by one in
+//   slot order (k-major, lane ascending) -- the order the layout fixes: old operands first, early ones by ascending producer level;
+// the head lane finishes the row with (b - sum) * rdiag, publishes into the sentinel-filled hand-off buffer and stores x.
+// Checks on the way what the device relies on: every EARLY operand has been published by a group with a SMALLER number
+// (deadlock freedom of the static assignment; with `waves` > 0 the groups are run by that many waves taking w, w + W, ... , visited
+// in the adversarial order: the last wave first), every OLD operand is still old when it is read (write-after-read safety on
+// structurally symmetric patterns, else a snapshot is used), dummy rows / padding slots carry no product, and the slot order itself
+// (no old operand behind an early one, producer levels ascending).
 #include "../pyamg_amd/csrc/pamg_tile_plan.h"
 #include "../pyamg_amd/csrc/pamg_lane_plan.h"
 #include <cmath>
@@ -13,33 +17,27 @@
 
 using namespace pamg;
 
-// nslabs > 1: the slab layout, replayed the way the slab form of the kernel assigns it -- `waves` waves per slab, wave w of slab s
-// takes groups slab_grp[s] + w, + waves, ... in that order; the waves are visited round-robin and a wave runs its next group only
-// when every early operand has been published (else it "polls": it is skipped this round).  A full round without progress is a
-// deadlock (error 20).  LOCAL operands must come from the consumer's own slab (error 21).
 extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const double *Ax, double *x, const double *b, int row_start,
                                    int row_stop, int row_step, int want_L, int sor, double omega, int snapshot, long long *stats,
-                                   int nslabs, int waves, int chunk)
+                                   int waves, int butterfly_only)
 {
     std::vector<int> vis, lvl;
     int m = 0, nl = 0;
     if (sweep_levels(n, Ap, Aj, row_start, row_stop, row_step, vis, lvl, m, nl)) return 1;
     if (m == 0) return 0;
     LanePlan P;
-    if (build_lane_plan(n, Ap, Aj, reinterpret_cast<const unsigned char *>(Ax), 8, row_start, row_step, m, nl, vis, lvl, want_L, P, nslabs < 1 ? 1 : nslabs, chunk)) return 2;
+    if (build_lane_plan(n, Ap, Aj, reinterpret_cast<const unsigned char *>(Ax), 8, row_start, row_step, m, nl, vis, lvl, want_L, P)) return 2;
     const int L = P.L, K = P.K, RPW = P.RPW;
-    stats[0] = L; stats[1] = K; stats[2] = P.ngroups; stats[3] = P.n_slots; stats[4] = P.n_early; stats[5] = P.n_old; stats[6] = nl; stats[7] = P.n_local;
+    stats[0] = L; stats[1] = K; stats[2] = P.ngroups; stats[3] = P.n_slots; stats[4] = P.n_early; stats[5] = P.n_old; stats[6] = nl; stats[7] = 0;
     std::vector<double> xs((size_t)n), xold;
     std::vector<char> pub((size_t)n, 0), written((size_t)n, 0);
-    std::vector<signed char> pub_slab((size_t)n, -1);
     const double *rd = reinterpret_cast<const double *>(P.rdiag.data());
     const double *vals = reinterpret_cast<const double *>(P.vals.data());
     if (snapshot) xold.assign(x, x + n);
     const double *xsrc = snapshot ? xold.data() : x;
     int64_t rows_done = 0;
-    auto slab_of_group = [&](int64_t g) { int sl = 0; while (sl + 1 < P.nslabs && g >= P.slab_grp[sl + 1]) ++sl; return sl; };
+    const bool ordered = (L == 64) && !butterfly_only;
     auto run_group = [&](int64_t g, bool may_wait) -> int {
-        const int myslab = slab_of_group(g);
         if (may_wait) {
             for (int lane = 0; lane < 64; ++lane)
                 for (int k = 0; k < K; ++k) {
@@ -47,27 +45,30 @@ extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const do
                     if (!(c & LANE_NONE) && (c & LANE_EARLY) && !pub[(size_t)(c & LANE_MASK)]) return -1;       // still polling
                 }
         }
-        double lane_sum[64];
+        double lane_sum[64], prod[LANE_KMAX][64];
+        bool is_early[LANE_KMAX][64];
         for (int lane = 0; lane < 64; ++lane) {
             double s = 0.0;
             const int rid = P.rid[(size_t)(g * RPW + lane / L)];
             for (int k = 0; k < K; ++k) {
                 const size_t e = (size_t)((g * K + k) * 64 + lane);
                 const int c = P.cols[e];
-                if (c & LANE_NONE) { if (vals[e] != 0.0 && false) return 10; continue; }
+                prod[k][lane] = 0.0; is_early[k][lane] = false;
+                if (c & LANE_NONE) continue;
                 if (rid < 0) return 11;                                   // an entry in a dummy row
                 const int col = c & LANE_MASK;
                 double xv;
                 if (c & LANE_EARLY) {
                     if (!pub[(size_t)col]) return 12;                     // producer has a larger group number: deadlock on the device
-                    if ((c & LANE_LOCAL) && pub_slab[(size_t)col] != myslab) return 21;   // "local" operand published by another slab
                     xv = xs[(size_t)col];
+                    is_early[k][lane] = true;
                 } else {
                     if (!snapshot && written[(size_t)col]) return 13;     // an old value was overwritten before it was read
                     xv = xsrc[col];
                 }
                 const double pr = vals[e] * xv;
-                s = s + pr;
+                prod[k][lane] = pr;
+                if (!ordered || !(c & LANE_EARLY)) s = s + pr;
             }
             lane_sum[lane] = s;
         }
@@ -75,6 +76,24 @@ extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const do
             double t[64];
             for (int lane = 0; lane < 64; ++lane) t[lane] = lane_sum[lane] + lane_sum[lane ^ step];
             for (int lane = 0; lane < 64; ++lane) lane_sum[lane] = t[lane];
+        }
+        if (ordered) {
+            // early products one by one in slot order; the layout must have put every old operand in front and the producer levels in order
+            double acc = lane_sum[0];
+            int last_lvl = -1;
+            bool seen_early = false;
+            for (int k = 0; k < K; ++k)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int c = P.cols[(size_t)((g * K + k) * 64 + lane)];
+                    if (c & LANE_NONE) continue;
+                    if (is_early[k][lane]) {
+                        const int pl = lvl[c & LANE_MASK];
+                        if (pl < last_lvl) return 16;                     // producer levels not ascending
+                        last_lvl = pl; seen_early = true;
+                        acc = acc + prod[k][lane];
+                    } else if (seen_early) return 17;                     // an old operand behind an early one
+                }
+            for (int lane = 0; lane < 64; ++lane) lane_sum[lane] = acc;
         }
         // all rows of a group publish "at once": operands were read above, before any store of this group
         for (int r = 0; r < RPW; ++r) {
@@ -86,31 +105,29 @@ extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const do
             if (sor) v = omega * v + (1.0 - omega) * xsrc[row];
             if (!upd) v = xsrc[row];
             if (pub[(size_t)row]) return 14;                              // a row scheduled twice
-            xs[(size_t)row] = v; pub[(size_t)row] = 1; pub_slab[(size_t)row] = (signed char)myslab;
+            xs[(size_t)row] = v; pub[(size_t)row] = 1;
             if (upd) { x[row] = v; written[(size_t)row] = 1; }
             ++rows_done;
         }
         return 0;
     };
-    if (P.nslabs <= 1) {
+    if (waves <= 0) {
         for (int64_t g = 0; g < P.ngroups; ++g) { const int rc = run_group(g, false); if (rc) return rc; }
     } else {
-        if (waves < 1) waves = 1;
-        std::vector<int64_t> next((size_t)P.nslabs * waves);
-        for (int sl = 0; sl < P.nslabs; ++sl)
-            for (int w = 0; w < waves; ++w) next[(size_t)sl * waves + w] = P.slab_grp[sl] + w;
+        // `waves` waves, wave w takes groups w, w + waves, ...; visited LAST to first (the adversarial order: the waves that are furthest
+        // ahead get the first chance and must wait); a full round without progress is a deadlock (error 20)
+        std::vector<int64_t> next((size_t)waves);
+        for (int w = 0; w < waves; ++w) next[(size_t)w] = w;
         int64_t left = P.ngroups;
         while (left > 0) {
             bool progress = false;
-            // slabs visited LAST to first: the adversarial order (later slabs get the first chance to run ahead and wait)
-            for (int sl = P.nslabs - 1; sl >= 0; --sl)
-                for (int w = 0; w < waves; ++w) {
-                    int64_t &g = next[(size_t)sl * waves + w];
-                    if (g >= P.slab_grp[sl + 1]) continue;
-                    const int rc = run_group(g, true);
-                    if (rc > 0) return rc;
-                    if (rc == 0) { g += waves; --left; progress = true; }
-                }
+            for (int w = waves - 1; w >= 0; --w) {
+                int64_t &g = next[(size_t)w];
+                if (g >= P.ngroups) continue;
+                const int rc = run_group(g, true);
+                if (rc > 0) return rc;
+                if (rc == 0) { g += waves; --left; progress = true; }
+            }
             if (!progress) return 20;
         }
     }

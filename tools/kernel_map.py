@@ -71,6 +71,25 @@ def kernel_map(dml, smoother_kind):
                     else:
                         out.append({"family": "gs_gran", "grid": None, "level": i, "op": "A", "what": f"{dirn} Gauss-Seidel sweep (order-exact)",
                                     "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": None, "format": "level-permuted CSR", "dependency_levels": int(inf["gs_levels_fwd"])})
+            elif smoother_kind in ("block_gauss_seidel", "block_jacobi") or (A.op.fmt == "bsr" and A.op.blocksize[0] > 1 and smoother_kind in ("gauss_seidel", "jacobi")):
+                # square-block levels: SURVEY 8(d) BSR(R x C) bytes = 8 R C nblk + 4 nblk + 4 (n_brow + 1) + vectors (x read, b read, x
+                # written) + the inverted diagonal blocks of the block smoothers (8 R^2 per block row)
+                bs = int(A.op.blocksize[0])
+                nbrow = n // bs
+                nblk = nnz // (bs * bs)
+                block = smoother_kind.startswith("block_")
+                alg = vb * bs * bs * nblk + 4 * nblk + 4 * (nbrow + 1) + 3 * vb * n + (vb * bs * bs * nbrow if block else 0)
+                gs = smoother_kind.endswith("gauss_seidel")
+                kind = ("BLK_GS" if block else "PNT_GS") if gs else ("BLK_JACOBI" if block else "PNT_JACOBI")
+                if gs:
+                    out.append({"family": "bsr_gs", "kind": kind, "bs": bs, "grid": None, "level": i, "op": "A",
+                                "what": f"{'block' if block else 'point'} Gauss-Seidel sweep on BSR({bs},{bs}) (order-exact; forward and backward launches)",
+                                "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": int(alg + 4 * nbrow), "format": f"level-permuted BSR({bs},{bs}) + row ids",
+                                "dependency_levels": int(inf["gs_levels_fwd"])})
+                else:
+                    out.append({"family": "bsr_stream", "kind": kind, "bs": bs, "grid": int(inf["row_blocks"]), "level": i, "op": "A",
+                                "what": f"{'block' if block else 'point'} Jacobi sweep on BSR({bs},{bs})", "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg),
+                                "bytes_streamed": int(alg), "format": f"BSR({bs},{bs}) as stored"})
             elif smoother_kind == "jacobi":
                 out.append(_op_entry(i, "A", A, "JACOBI", "weighted Jacobi sweep"))
                 out.append(_op_entry(i, "A", A, "JACOBI_B", "weighted Jacobi sweep (BSR(1,1) levels)"))

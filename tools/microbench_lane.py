@@ -88,22 +88,6 @@ def variants_for(li, n):
             for L, Gs in ((32, (32, 40)), (64, (32, 48, 64, 96))):
                 for G in Gs:
                     v.append((f"fast_L{L}_xcd_G{G}", dict(lane_L=L, lane_G=G, gran_xcd=1)))
-    if a.exp == "d":                       # slab form (one slab per XCD) against the plain static form
-        v.append(("fast_static", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
-        v.append(("fast_slabs_auto", dict(lane_flags=3)))
-        for G in (256, 512, 768, 1024, 1536):
-            v.append((f"fast_slabs_G{G}", dict(lane_flags=3, lane_G=G)))
-        for G in (512, 1024):
-            v.append((f"fast_slabs_nogate_G{G}", dict(lane_flags=2, lane_G=G)))
-        for G in (512, 1024):
-            v.append((f"fast_slabs_L16_G{G}", dict(lane_flags=3, lane_L=16, lane_G=G)))
-    if a.exp == "e":                       # slab form with chunks of the visit order dealt out to the XCDs in turn
-        v.append(("fast_static", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
-        for chunk in (256, 1024, 2048, 4096, 16384):
-            for G in (512, 1024):
-                v.append((f"fast_chunk{chunk}_G{G}", dict(lane_flags=3, lane_chunk=chunk, lane_G=G)))
-        v.append(("fast_chunk2048_nogate_G512", dict(lane_flags=2, lane_chunk=2048, lane_G=512)))
-        v.append(("fast_chunk2048_L16_G256", dict(lane_flags=3, lane_chunk=2048, lane_L=16, lane_G=256)))
     if a.exp == "f":                       # deep gate: wide schedules with many waves; static L64 gate on / off
         v.append(("fast_auto", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
         if li == 0:
@@ -115,18 +99,6 @@ def variants_for(li, n):
             for fl in (1, 0):
                 for G in (384, 512, 768, 1024):
                     v.append((f"fast_gate{fl}_G{G}", dict(lane_flags=fl, lane_G=G)))
-    if a.exp == "g":                       # old values through the L1; lines of the grid dealt out to the XCDs (slab form, chunk = nx)
-        v.append(("fast_auto", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
-        v.append(("fast_auto_oldL1", dict(lane_flags=5)))
-        if li == 0:
-            for fl, nm in ((5, "oldL1"), (3, "lines"), (7, "lines_oldL1")):
-                for L in (4, 8):
-                    for G in (256, 512, 1024):
-                        v.append((f"fast_{nm}_L{L}_G{G}", dict(lane_L=L, lane_G=G, lane_flags=fl, lane_chunk=256)))
-        else:
-            for G in (384, 512, 768):
-                v.append((f"fast_oldL1_G{G}", dict(lane_flags=5, lane_G=G)))
-            v.append(("fast_oldL1_nogate_G512", dict(lane_flags=4, lane_G=512)))
     if a.exp == "h":                       # line-scan form on the grid stencil
         v.append(("tile_exact", dict(gs_order=0)))
         v.append(("lines_auto", dict(gs_order=1, line_scan=1, lane_G=0, lane_flags=1)))
@@ -134,6 +106,20 @@ def variants_for(li, n):
             v.append((f"lines_G{G}", dict(lane_G=G)))
         for G in (256, 1024):
             v.append((f"lines_nogate_G{G}", dict(lane_G=G, lane_flags=0)))
+    if a.exp == "k":                       # round 5: ordered tail (lane_flags bit 4 = butterfly over everything, the round-4 arithmetic) x grid
+        v.append(("fast_auto", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
+        v.append(("fast_butterfly", dict(lane_flags=17)))
+        v.append(("fast_ordered_nogate", dict(lane_flags=0)))
+        if li == 1:
+            for fl, nm in ((1, "ordered"), (17, "butterfly")):
+                for G in (384, 448, 512, 640, 768):
+                    v.append((f"fast_{nm}_G{G}", dict(lane_flags=fl, lane_G=G)))
+        elif li in (2, 3):
+            for fl, nm in ((1, "ordered"), (17, "butterfly")):
+                for G in (16, 24, 32, 48, 64):
+                    v.append((f"fast_{nm}_xcd_G{G}", dict(lane_flags=fl, lane_G=G, gran_xcd=1)))
+            v.append(("fast_L32_xcd", dict(lane_flags=1, lane_L=32, lane_G=0, gran_xcd=1)))
+            v.append(("fast_ordered_chip", dict(lane_flags=1, lane_L=0, lane_G=0, gran_xcd=2)))
     return v
 
 
@@ -165,7 +151,7 @@ for li in a.levels:
             rec = {"level": li, "n": n, "variant": name, "fwd_ms": round(ms, 4), "max_rel_diff_vs_exact": diff, "timeout": err, "line": ln_ if ln_["lines"] else None,
                    "levels": inf["gs_levels_fwd"], "us_per_level": round(1e3 * ms / max(inf["gs_levels_fwd"], 1), 3),
                    "lane": {k: li_[k] for k in ("lanes_per_row", "slots_per_lane", "groups", "widest_level_groups", "launch_grid")} if name != "exact_default" else None}
-            if name in ("fast_auto", "fast_slabs_auto"):
+            if name in ("fast_auto", "fast_butterfly"):
                 dA.tune(gs_prof=1)
                 dx.upload(x)
                 dA.gauss_seidel(dx, db, sweep="forward")

@@ -18,6 +18,7 @@ from collections import defaultdict
 from pathlib import Path
 
 out, wl, tag = Path(sys.argv[1]), sys.argv[2], sys.argv[3]
+BKIND = ["BLK_JACOBI", "BLK_GS", "PNT_JACOBI", "PNT_GS"]
 EPI = ["SET", "ACC", "RESID", "AXPBY", "ACC_AXPBY", "SUMSQ", "ACCSEQ", "JACOBI", "JACOBI_B", "GS", "GS_B", "SOR", "JACOBI_IDX"]
 
 
@@ -43,6 +44,10 @@ def short(name):
     m = re.search(r"gs_line_kernel<(\w+), *(\d+), *(\d+)>", name)
     if m:
         return f"gs_line<{m.group(1)},{EPI[int(m.group(2))]},K{m.group(3)}>"
+    m = re.search(r"bsr_(gran|small|flow|stream)_kernel<(\w+), *(\d+)(?:, *(\w+))?>", name)
+    if m:
+        third = m.group(4)
+        return f"bsr_{m.group(1)}<{m.group(2)},{BKIND[int(m.group(3))]}" + (f",{'bs' + third if third.isdigit() else third}" if third else "") + ">"
     name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("pamg::", "")
     return re.sub(r"\(.*", "", name)[:70]
 
@@ -59,6 +64,12 @@ def family(k):
         return "gs_tile", None
     if k.startswith("gs_gran") or k.startswith("gs_flow"):
         return "gs_gran", None
+    if k.startswith("bsr_gran") or k.startswith("bsr_small") or k.startswith("bsr_flow"):
+        m = re.search(r"<\w+,(\w+)(?:,bs(\d+))?", k)
+        return "bsr_gs", (m.group(1), int(m.group(2)) if m and m.group(2) else None)
+    if k.startswith("bsr_stream"):
+        m = re.search(r"<\w+,(\w+)", k)
+        return "bsr_stream", (m.group(1), None)
     return None, None
 
 
@@ -99,7 +110,19 @@ for f in glob.glob(str(out / "trace" / "**" / "*kernel_trace.csv"), recursive=Tr
             fam, epi = family(k)
             if not fam:
                 continue
-            cand = [i for i, e in enumerate(ents) if e["family"] == fam and (fam != "csr" or e["epi"] == epi) and (e["grid"] is None or e["grid"] == g or (fam == "csr" and 0 <= g - e["grid"] < 8))]
+            if fam in ("bsr_gs", "bsr_stream"):
+                # block sweeps: the kernel name carries the flavour (and the compile-time block size); levels with one block size are told
+                # apart by their grids -- the wider grid is the finer level (rows arrive sorted by total time, so order them here)
+                kind, bs = epi
+                same = sorted([(g2, k2) for (k2, g2), _ in rows if family(k2)[0] == fam and family(k2)[1] == epi and (fam == "bsr_gs" or True)], reverse=True)
+                cand_all = [i for i, e in enumerate(ents) if e["family"] == fam and e.get("kind") == kind and (bs is None or e.get("bs") == bs)]
+                if fam == "bsr_stream":
+                    cand = [i for i in cand_all if ents[i]["grid"] == g] or cand_all
+                else:
+                    pos = same.index((g, k)) if (g, k) in same else 0
+                    cand = cand_all[pos:pos + 1] or cand_all[-1:]
+            else:
+                cand = [i for i, e in enumerate(ents) if e["family"] == fam and (fam != "csr" or e["epi"] == epi) and (e["grid"] is None or e["grid"] == g or (fam == "csr" and 0 <= g - e["grid"] < 8))]
             if not cand:
                 continue
             # several operators with one grid size (tiny levels): the first unused entry
@@ -119,6 +142,13 @@ for f in glob.glob(str(out / "trace" / "**" / "*kernel_trace.csv"), recursive=Tr
             rl.append(f"{(k + ' [' + str(g) + ']')[:46]:46s} {e['level']:3d} {e['op']:>2s} {e['what'][:44]:44s} {c:6d} {avg:9.2f} {e['bytes_alg'] / 1e6:9.2f} {a_gbs:9.1f} {100 * a_gbs / peak:6.2f} "
                       + (f"{e['bytes_streamed'] / 1e6:9.2f} {s_gbs:9.1f} {100 * s_gbs / peak:6.2f} " + (f"{100 * s_gbs / ceil:6.2f}" if ceil else f"{'':6s}") if s_gbs else f"{'-':>9s} {'-':>9s} {'-':>6s} {'-':>6s}")
                       + (f"   {rec['us_per_dependency_level']} us per dependency level x {e['dependency_levels']}" if e.get("dependency_levels") else ""))
+        # coverage: launches that belong to the cycle = kernels launched at least once per timed iteration (the level-0 convergence-check norm
+        # runs once per iteration); share of their time that the table explains
+        iters = max([r_["calls"] for r_ in table if "convergence-check" in r_["role"]] or [1])
+        in_cycle = sum(t for (k, g), (c, t) in rows if c >= iters and not k.startswith(("bw_", "__amd_rocclr", "spg_", "lane_fill", "line_fill")))
+        mapped = sum(r_["calls"] * r_["avg_us"] for r_ in table if r_["calls"] >= iters)
+        rl.append(f"coverage: the rows above explain {100 * mapped / max(in_cycle, 1e-9):.1f} % of the time of the kernels launched at least once per iteration ({iters} iterations in the trace)")
+        summary["kernel_roofline_coverage_pct"] = round(100 * mapped / max(in_cycle, 1e-9), 1)
         (out / "kernel_roofline.txt").write_text("\n".join(rl) + "\n")
         summary["kernel_roofline"] = table
         print("\n".join(rl[:24]))
