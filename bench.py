@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--cpu-cycles", type=int, default=-1, help="reference cycles timed on the host (-1 auto, 0 skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the sharded-Chebyshev and configs[1] legs")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-model", action="store_true", help="skip the modelled 2 / 4 / 8 GPU curve of the 512^3 Chebyshev workload (SURVEY 8e availability caveat)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes that measure the SpMV's HBM traffic")
     ap.add_argument("--min-rows", type=int, default=200_000, help="shard levels with at least this many rows")
     ap.add_argument("--host-setup", action="store_true", help="build the hierarchies with the reference alone (no device setup operators)")
@@ -382,6 +383,84 @@ def main():
     import threading
     printed = threading.Event()
     box = {"out": None}
+
+    # ---- the modelled 1 -> 8 GPU curve (SURVEY 8e "availability caveat": no multi-GPU node => the ranks' work on one device + modelled xGMI
+    #      time).  A MODEL, labelled as such everywhere it appears.  For N ranks the hierarchy is partitioned exactly as the N > 1 run does
+    #      (pyamg_amd.dist.ShardedHierarchy); the INTERIOR rank N // 2 (two neighbours: the critical one) runs its own launches on this GPU
+    #      through the C++ driver with nobody on the wire (pamg_dist_set_model_transport): pack, interior ranges, boundary ranges, collapse,
+    #      replicated tail -- the compute critical path.  The wire is added from that rank's exchange plan:
+    #        per halo exchange    t_x = XGMI_MSG_LATENCY_US + (largest message from one neighbour) / XGMI_LINK_GBPS   (every neighbour on its own link)
+    #        exposed per exchange max(0, t_x - interior launch of that level's operator)  [overlap assumed]  or  t_x  [no overlap]
+    #        all-reduces          (collapse: the coarse right-hand side; norm: one value)  ALLREDUCE_LATENCY_US + 2 (N - 1) / N * bytes / XGMI_LINK_GBPS
+    XGMI_LINK_GBPS = 153.0              # per link, the figure this round's hardware notes give (7 links per GPU, point to point)
+    XGMI_MSG_LATENCY_US = 12.0          # one grouped ncclSend / ncclRecv batch end to end (launch on the comm stream + handshake): ASSUMPTION
+    ALLREDUCE_LATENCY_US = 25.0         # small-message ring all-reduce over 8 GPUs: ASSUMPTION
+
+    def model_scaling(spec, label, n1_ms, ranks=(2, 4, 8), cycles=8):
+        from pyamg_amd.dist import DeviceOps, DistMultilevelSolver, ShardedHierarchy
+        rows = []
+        for N in ranks:
+            t0m = time.time()
+            r = N // 2
+            part = ShardedHierarchy(spec, r, N, args.min_rows)
+            part.detach()
+            sol = DistMultilevelSolver.model_rank(part, DeviceOps(local_rank, spec.dtype))
+            nat = sol.native
+            n_own = part.plans[0].n_owned_s
+            rng_ = np.random.RandomState(7)
+            ms = {}
+            for tag, use_graph in (("stream_ordered", 0), ("one_graph", 1)):
+                nat.set_options(use_graph=use_graph)
+                nat.load(rng_.rand(n_own), rng_.rand(n_own))
+                nat.iterate(3, want_residuals=False)
+                t1 = time.perf_counter()
+                nat.iterate(cycles, want_residuals=False)
+                ms[tag] = (time.perf_counter() - t1) * 1e3 / cycles
+            # interior launch of every sharded level's operator (what an exchange can hide behind), and the exchange plan
+            lv, wire_ov, wire_no = [], 0.0, 0.0
+            for l in range(part.ns + 1):
+                li = nat.level_info(l)
+                t_int = 0.0
+                if l < part.ns and li["exchanges_per_iteration"]:
+                    nl_ = part.plans[l].n_local_s
+                    xv, yv = capi.DeviceArray.from_host(rng_.rand(nl_)), capi.DeviceArray(part.plans[l].n_owned_s, np.float64)
+                    try:
+                        for _ in range(3):
+                            sol.A[l].spmv(capi.SPMV_SET, xv, yv, part=1)
+                        q0, q1 = capi.Event(), capi.Event()
+                        q0.record()
+                        for _ in range(10):
+                            sol.A[l].spmv(capi.SPMV_SET, xv, yv, part=1)
+                        q1.record(); q1.synchronize()
+                        t_int = q0.elapsed_ms(q1) / 10
+                    finally:
+                        xv.free(); yv.free()
+                msg_bytes = 8 * max(li["max_received_from_one_peer"], li["max_sent_to_one_peer"])
+                t_x = (XGMI_MSG_LATENCY_US * 1e-3 + msg_bytes / (XGMI_LINK_GBPS * 1e6)) if li["exchanges_per_iteration"] and msg_bytes else 0.0
+                wire_no += li["exchanges_per_iteration"] * t_x
+                wire_ov += li["exchanges_per_iteration"] * max(0.0, t_x - t_int)
+                lv.append({"level": l, "owned": li["owned"], "halo": li["halo"], "exchanges_per_iteration": li["exchanges_per_iteration"],
+                           "largest_message_bytes": int(msg_bytes), "exchange_ms": round(t_x, 5), "interior_launch_ms": round(t_int, 5)})
+            ar = 2 * (ALLREDUCE_LATENCY_US * 1e-3) + 2 * (N - 1) / N * (8 * part.nc + 8) / (XGMI_LINK_GBPS * 1e6)
+            rows.append({"n": N, "model": True, "rank_timed": r, "sharded_levels": part.ns,
+                         "compute_ms": round(ms["stream_ordered"], 4), "compute_ms_one_graph": round(ms["one_graph"], 4),
+                         "exchange_ms_not_overlapped": round(wire_no, 4), "exchange_ms_exposed_with_overlap": round(wire_ov, 4), "allreduce_ms": round(ar, 4),
+                         "ms_per_step": round(ms["stream_ordered"] + wire_ov + ar, 4), "ms_per_step_no_overlap": round(ms["stream_ordered"] + wire_no + ar, 4),
+                         "overlap_assumed": True, "speedup_vs_n1": round(n1_ms / (ms["stream_ordered"] + wire_ov + ar), 2),
+                         "efficiency": round(n1_ms / (ms["stream_ordered"] + wire_ov + ar) / N, 3), "levels": lv, "model_build_s": round(time.time() - t0m, 1)})
+            log(f"modelled scaling {label} N={N}: compute {ms['stream_ordered']:.3f} ms (one graph {ms['one_graph']:.3f}), wire exposed {wire_ov:.3f} / all {wire_no:.3f}, "
+                f"all-reduces {ar:.3f} -> {rows[-1]['ms_per_step']:.3f} ms per cycle ({rows[-1]['speedup_vs_n1']}x of N = 1's {n1_ms:.3f})")
+            nat.free()
+            for m_ in sol.A + sol.P + sol.R:
+                m_.free()
+            sol.coarse.free()
+            del sol, nat, part
+        return {"what": "MODEL, not a measurement: rank N // 2's launches timed on this one GPU through the C++ sharded driver with nobody on the wire, "
+                        "plus the halo exchanges of its plan at the stated xGMI figures (bench.py model_scaling; DESIGN 6)",
+                "workload": label, "n1_ms_per_step_measured": round(n1_ms, 4),
+                "assumptions": {"xgmi_link_GBps": XGMI_LINK_GBPS, "message_latency_us": XGMI_MSG_LATENCY_US, "allreduce_latency_us": ALLREDUCE_LATENCY_US,
+                                "neighbours_on_separate_links": True, "compute": "stream-ordered launches (the production default with RCCL; one hipGraph is the opt-in PAMG_DIST_GRAPH=1)"},
+                "rows": rows}
 
     def emit():
         if rank == 0 and box["out"] is not None and not printed.is_set():
@@ -828,6 +907,15 @@ def main():
     # once.  Exceptions are recorded in the JSON; the watchdog prints the line and ends the process if the extras exceed
     # their time budget (a blocked HIP call cannot be interrupted from Python).
     box["out"] = out
+    # a Chebyshev workload as the MAIN leg (--workload c4s | c4 | c4x): its modelled 2 / 4 / 8 GPU curve right here
+    if rank == 0 and world == 1 and not args.no_model and args.workload in ("c4s", "c4", "c4x"):
+        try:
+            out["modelled_scaling"] = model_scaling(dml.spec, wl["label"], out["ms_per_step"])
+            for r_ in out["modelled_scaling"]["rows"]:
+                out["config"][f"modelled_ms_per_step_n{r_['n']}"] = r_["ms_per_step"]
+        except Exception as e:                                        # noqa: BLE001
+            log(f"scaling model failed: {e!r}")
+            out["modelled_scaling"] = {"error": repr(e)[:300]}
     extras_budget = float(os.environ.get("PAMG_EXTRAS_TIMEOUT", "1500"))
     watchdog = start_watchdog(extras_budget, "the extra legs")
 
@@ -1002,7 +1090,20 @@ def main():
                     ex4["cpu_baseline"] = cpu_from_protocol(pp, A4, b4)
                     ex4["parity"] = {"reference_protocol": pp}
                 ex4["time_to_tol_1e-8"] = time_to_tol(d4, b4, x04)
+                spec4 = d4.spec
                 d4.free()
+                if not args.no_model and key4 == "c4x":
+                    try:
+                        ms_ = model_scaling(spec4, wl4["label"], ex4["ms_per_step"])
+                        out["modelled_scaling"] = ms_
+                        for r_ in ms_["rows"]:
+                            out["config"][f"modelled_c4x_ms_per_step_n{r_['n']}"] = r_["ms_per_step"]
+                            out["config"][f"modelled_c4x_exchange_ms_n{r_['n']}"] = r_["exchange_ms_not_overlapped"]
+                        out["config"]["modelled_c4x_ms_per_step_n1_measured"] = ex4["ms_per_step"]
+                        out["config"]["modelled_note"] = "MODEL: rank N//2 timed on one GPU + halo bytes / 153 GB/s + 12 us per exchange; DESIGN 6"
+                    except Exception as e:                            # noqa: BLE001
+                        log(f"scaling model failed: {e!r}")
+                        out["modelled_scaling"] = {"error": repr(e)[:300]}
                 break
             except Exception as e:                                    # noqa: BLE001
                 log(f"configs[3] leg ({key4}) failed: {e!r}")

@@ -354,9 +354,7 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * else 4|8|16|32|64), 26 = its persistent workgroups (0 = automatic), 27 = 1: the fast order also takes wide schedules
  * (>= 2048 rows per dependency level), which the tiled exact sweep keeps by default, 28 = flags of the fast order (bit 0, default
  * on: a wave that runs ahead of the sweep polls ONE gate operand instead of all its operands until the sweep is one
- * dependency level away; bit 4: rows that fill a wave add ALL their products with the butterfly after the last operand has arrived
- * (round 4) instead of the ordered tail -- old products by the butterfly while the polls are in flight, early products one by one in the
- * layout's slot order, the operands of the level just below last (round 5, default); bits 1, 2 retired with the slab form),
+ * dependency level away; bit 3: the same in the line scan, off; bits 1, 2 retired with the slab form in round 5),
  * 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled AND
  * enough lines run side by side to beat the lane form by the planner's estimate (3-D grids; not 2-D grids in natural order); 2 = wherever it applies.
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
@@ -684,6 +682,16 @@ int pamg_dist_set_callbacks(pamg_dist_t D, pamg_dist_exchange_fn exchange, pamg_
  * test rigs forms it with the all-reduce callback (sum of disjoint slices). */
 int pamg_dist_set_allgather(pamg_dist_t D, int level, int64_t count_per_rank, const int32_t *halo_src);
 int pamg_dist_set_exchange(pamg_dist_t D, int mode);
+/* MODEL transport (instead of callbacks / RCCL; before finalize): the rank runs exactly the launches it would run among `world`
+ * ranks -- pack, interior ranges, boundary ranges, collapse, replicated tail -- but nothing travels: halos keep what they hold,
+ * all-reduces return the rank's own contribution.  What such a run times is the rank's COMPUTE critical path; bench.py adds the
+ * wire from the exchange plans (pamg_dist_level_info) with stated xGMI figures -- SURVEY.md 8(e) "availability caveat": no
+ * multi-GPU node => N ranks' work on one device + modelled xGMI time.  The iterates of such a run are NOT a solve.
+ * pamg_dist_level_info(level; the collapse level = number of sharded levels): {owned values, halo values, exchanges of this
+ * level's vectors per iteration (counted while the last iteration was enqueued), peers sent to, peers received from, most
+ * values sent to one peer, most values received from one peer, values sent per exchange}. */
+int pamg_dist_set_model_transport(pamg_dist_t D);
+int pamg_dist_level_info(pamg_dist_t D, int level, int64_t info[8]);
 /* One-rank exercise of every RCCL entry point the sharded cycle uses, on the current device, through the table this library
  * binds at run time (ncclGetUniqueId, ncclCommInitRank, grouped ncclSend + ncclRecv to itself on a comm stream ordered against
  * a main stream by events exactly like the halo exchange, ncclAllGather, a one-element ncclAllReduce, ncclCommDestroy) with

@@ -195,6 +195,8 @@ def _declare(lib):
     f("pamg_dist_info", _vp, P(C.c_int64))
     f("pamg_dist_set_allgather", _vp, _i, C.c_int64, _vp)
     f("pamg_dist_set_exchange", _vp, _i)
+    f("pamg_dist_set_model_transport", _vp)
+    f("pamg_dist_level_info", _vp, _i, P(C.c_int64))
     f("pamg_rccl_selftest", C.c_int64, P(C.c_double))
     f("pamg_rccl_available")
     f("pamg_dist_exchange_test", _vp, _i, _vp, _vp)

@@ -209,8 +209,7 @@ struct pamg_matrix_s {
     int gs_order = 0;                // tune key 24: 0 = order-exact row sums (bit-identical to the reference), 1 = fast order: lane-parallel row
                                      //   sums and multiplication by 1/a_ii (same sweep order; agrees to rounding) where the schedule fits that form
     int lane_L = 0, lane_G = 0;      // fast order: lanes per row (0 = automatic) / persistent workgroups (0 = automatic)   (tune keys 25, 26)
-    int lane_flags = 1;              // fast order: bit 0 = gate operand (a wave that runs ahead polls one value instead of all its operands), bit 3 = gate in the line scan,
-                                     // bit 4 = butterfly over all products instead of the ordered tail (one row per wave; for comparison)   (tune key 28)
+    int lane_flags = 1;              // fast order: bit 0 = gate operand (a wave that runs ahead polls one value instead of all its operands), bit 3 = gate in the line scan   (tune key 28)
     int line_scan = 1;               // fast order: line-scan sweep where consecutive rows are coupled (grid stencils), tried before the lane form   (tune key 30)
     int lane_wide = 0;               // fast order on wide schedules (>= 2048 rows per dependency level): 0 = the tiled exact sweep keeps them, 1 = lane form   (tune key 27)
     int gs_cap = 0;                  // entries per row range of the level schedules (tune key 20; 0 = automatic: `cap`, 512 on the multi-XCD granular sweep of SA-like rows)

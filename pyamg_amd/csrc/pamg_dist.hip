@@ -112,6 +112,7 @@ struct DLevel {
     void *ag_stage = nullptr, *ag_all = nullptr;   // [ag_count], [world * ag_count]
     void *x = nullptr, *xalt = nullptr, *x_home = nullptr, *b = nullptr, *r = nullptr, *h0 = nullptr, *h1 = nullptr;
     DSmoother pre, post;
+    int64_t n_ex = 0;                 // exchanges of this level's vectors per iteration, counted while enqueueing (diagnostics / the scaling model)
     int64_t n_local() const { return n_owned + n_halo; }
     bool talks() const { return !send_peer.empty() || !recv_peer.empty(); }
 };
@@ -129,7 +130,7 @@ struct pamg_dist_s {
     pamg_solver_s *coarse = nullptr;  // borrowed
     hipStream_t main = nullptr, comm = nullptr;
     hipEvent_t ev_pack = nullptr, ev_halo = nullptr;
-    int mode = 0;                     // 0 none (no peers allowed), 1 host callbacks, 2 RCCL
+    int mode = 0;                     // 0 none (no peers allowed), 1 host callbacks, 2 RCCL, 3 MODEL: the rank's kernels with nobody on the wire (pamg_dist_set_model_transport)
     pamg_dist_exchange_fn cb_exchange = nullptr;
     pamg_dist_allreduce_fn cb_allreduce = nullptr;
     void *cb_user = nullptr;
@@ -185,6 +186,7 @@ int all_reduce(pamg_dist_s *D, void *buf, int64_t count, int dtype)
         PAMG_HIP(hipStreamSynchronize(D->main));
         return D->cb_allreduce(D->cb_user, buf, count, dtype);
     }
+    if (D->mode == 3) return PAMG_OK;                        // model transport: this rank's contribution alone
     return PAMG_E_STATE;
 }
 
@@ -233,6 +235,7 @@ int finish_exchange(pamg_dist_s *D, int l, void *v)
 {
     DLevel &L = D->lv[l];
     if (D->mode == 2) return (int)hipStreamWaitEvent(D->main, D->ev_halo, 0);
+    if (D->mode == 3) return PAMG_OK;                        // model transport: the halo keeps what it holds, the launches are the production ones
     if (D->mode == 1 && D->xmode == 1) {
         // host-callback rigs: the all-gather is the sum of the ranks' slices of an otherwise zero vector (the all-reduce callback)
         const size_t ts = ts_of(D);
@@ -259,6 +262,7 @@ int xlaunch(pamg_dist_s *D, int lvec, void *v, bool exchange, pamg_matrix_s *M, 
     hipStream_t s = D->main;
     if (!exchange || !D->lv[lvec].talks()) return M->nrows ? stream_launch(M, epi, v, b, y, c, omega, partial, s) : PAMG_OK;
     D->n_exchanges++;
+    D->lv[lvec].n_ex++;
     PAMG_TRY(begin_exchange(D, lvec, v));
     const bool split = D->overlap && M->part_cols >= 0 && M->R == 1 && M->C == 1 && M->nrows > 0;
     if (split) {
@@ -276,6 +280,7 @@ int xonly(pamg_dist_s *D, int l, void *v)
 {
     if (!D->lv[l].talks()) return PAMG_OK;
     D->n_exchanges++;
+    D->lv[l].n_ex++;
     PAMG_TRY(begin_exchange(D, l, v));
     return finish_exchange(D, l, v);
 }
@@ -378,6 +383,7 @@ int resid_sumsq(pamg_dist_s *D)
 int enqueue_iteration(pamg_dist_s *D, bool norm)
 {
     D->n_exchanges = D->n_overlapped = 0;
+    for (DLevel &L_ : D->lv) L_.n_ex = 0;
     PAMG_TRY(cycle(D, 0, false));
     if (norm) PAMG_TRY(resid_sumsq(D));
     return PAMG_OK;
@@ -547,6 +553,34 @@ int pamg_dist_set_callbacks(pamg_dist_t D, pamg_dist_exchange_fn exchange, pamg_
     if (!D || !exchange || !allreduce) return PAMG_E_ARG;
     if (D->finalized) return PAMG_E_STATE;
     D->mode = 1; D->cb_exchange = exchange; D->cb_allreduce = allreduce; D->cb_user = user;
+    return PAMG_OK;
+}
+
+// MODEL transport (bench.py's modelled 1 -> 8 GPU curve, SURVEY 8e "availability caveat"): the rank runs exactly the launches it would run
+// among `world` ranks -- pack, interior ranges, boundary ranges, collapse, tail -- but nothing travels: halos keep what they hold and the
+// all-reduces return the rank's own contribution.  What such a run measures is the rank's COMPUTE critical path; the wire is added from the
+// exchange plans (pamg_dist_level_info) with stated link figures.  Results are NOT a solve.
+int pamg_dist_set_model_transport(pamg_dist_t D)
+{
+    if (!D) return PAMG_E_ARG;
+    if (D->finalized) return PAMG_E_STATE;
+    D->mode = 3;
+    return PAMG_OK;
+}
+
+/* info of sharded level `level` (or the collapse level = the number of sharded levels): [0] owned values [1] halo values [2] exchanges of this
+ * level's vectors per iteration (counted while the last iteration was enqueued) [3] peers sent to [4] peers received from [5] most values
+ * sent to one peer [6] most values received from one peer [7] values sent per exchange */
+int pamg_dist_level_info(pamg_dist_t D, int level, int64_t info[8])
+{
+    if (!D || !info || level < 0 || level >= (int)D->lv.size()) return PAMG_E_ARG;
+    const DLevel &L = D->lv[level];
+    for (int k = 0; k < 8; ++k) info[k] = 0;
+    info[0] = L.n_owned; info[1] = L.n_halo; info[2] = L.n_ex;
+    info[3] = (int64_t)L.send_peer.size(); info[4] = (int64_t)L.recv_peer.size();
+    for (size_t k = 0; k + 1 < L.send_off.size(); ++k) info[5] = std::max<int64_t>(info[5], L.send_off[k + 1] - L.send_off[k]);
+    for (size_t k = 0; k + 1 < L.recv_off.size(); ++k) info[6] = std::max<int64_t>(info[6], L.recv_off[k + 1] - L.recv_off[k]);
+    info[7] = L.send_off.empty() ? 0 : L.send_off.back();
     return PAMG_OK;
 }
 

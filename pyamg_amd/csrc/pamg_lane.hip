@@ -17,16 +17,11 @@
 //                 order by running waves: complete for any placement) and publish with ordinary L2-resident stores.
 // The static operands of a wave's NEXT group are requested before it starts to wait for the current one.
 //
-// Round 5 -- what is left BEHIND the last hand-off.  Round 4 ran the 6-step butterfly over all products after the last operand had
-// arrived: ~40 dependent instructions, two of them through the LDS crossbar, 200 ns of the 1.05 us per dependency level
-// (tail_ns_median in profiles/r04_microbench_lane_exp_i.json).  Now (one row per wave) the slots of a row are ordered -- old operands,
-// then early operands by ascending producer level (pamg_lane_plan.h) -- and the wave
-//   1. adds the OLD products with the butterfly while the first re-poll is in flight,
-//   2. adds the early products ONE BY ONE in slot order (v_readlane of the product + one add each) as they have arrived.
-// The operands of the level just below -- the ones a wave actually waits for -- are the last slots: behind the last hand-off there is
-// a compare, a multiply, a readlane pair, an add and the (b - s) * (1 / a_ii).  The order of the additions is the layout's, not the
-// timing's: bit-reproducible.  The removed slab form (one slab of the visit order per XCD, hand-off through the XCD's L2 for
-// operands of the own slab) never beat the plain static form: profiles/r04_microbench_lane_exp_{g,h}.json, DESIGN 3.
+// Round 5: the slab form (one slab of the visit order per XCD, hand-off through the XCD's L2 for operands of the own slab) is gone -- it never
+// beat the plain static form (profiles/r04_microbench_lane_exp_{g,h}.json) --, rid / gate / 1 / a_ii of a slot row travel as ONE 16-byte record,
+// and three forms of a shorter tail behind the last hand-off were built, measured and removed again (early products added one by one by
+// v_readlane in a producer-level slot order; the last two / three early slots polled by every lane at one address each): the butterfly is not
+// what a dependency level costs -- profiles/r05_microbench_lane_tail_*_not_kept.json, DESIGN 3.
 #include "pamg_common.h"
 #include "pamg_lane_plan.h"
 
@@ -86,7 +81,6 @@ struct LaneArgs {
     long long *prof;       // nullptr or [ngroups][4] time stamps
     int ngroups, nidle;
     int use_gate;          // != 0: a wave that runs ahead polls its gate operand first
-    int tail;              // != 0 (one row per wave only): early products added one by one in slot order; 0: butterfly over everything
     T omega;
 };
 
@@ -134,13 +128,6 @@ __device__ __forceinline__ T seg_allreduce(T v)
     if constexpr (L >= 64) v = v + __shfl_xor(v, 32);
     return v;
 }
-
-// value of lane l (wave-uniform l) in every lane
-__device__ __forceinline__ double lane_bcast(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ float lane_bcast(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 template <typename T> __device__ __forceinline__ T rec_rd(const int4 &q);
 template <> __device__ __forceinline__ double rec_rd<double>(const int4 &q) { return __hiloint2double(q.w, q.z); }
@@ -272,98 +259,6 @@ __device__ __forceinline__ void lane_finish(const LaneArgs<T> &a, const LaneSet<
     }
 }
 
-// second half, ORDERED form (one row per wave): the old products by the butterfly while the first re-poll is in flight, then the early
-// products one by one in slot order as they have arrived (header comment)
-template <typename T, int EPI, int K, int MODE>
-__device__ __forceinline__ void lane_finish_ordered(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int g, int idle)
-{
-    using mask_t = unsigned long long;
-    const int lane = threadIdx.x & 63;
-    long long t1 = 0;
-    mask_t em[K], pm[K];                  // early slots not added yet / early slots whose operand has not arrived yet (wave-uniform)
-    bool pend[K];
-    mask_t anyp = 0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const bool early = (S.c[k] & LANE_EARLY) && !(S.c[k] & LANE_NONE);
-        pend[k] = early && Sentinel<T>::bits(D.xv[k]) == Sentinel<T>::value;
-        em[k] = __builtin_amdgcn_ballot_w64(early);
-        pm[k] = __builtin_amdgcn_ballot_w64(pend[k]);
-        anyp |= pm[k];
-    }
-    unsigned spins = 0;
-    if (S.gate >= 0 && anyp) spins = lane_gate_wait<T>(a, S.gate);
-    // the first re-poll goes out before the butterfly (always: a load under a branch would make the next wait drain the counter)
-    T t[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-        t[k] = __hip_atomic_load(pend[k] ? a.xs + (S.c[k] & LANE_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    T so = T(0), pr[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        pr[k] = S.v[k] * D.xv[k];                                            // early slots still pending: overwritten when they arrive
-        so = so + (((S.c[k] & (LANE_NONE | LANE_EARLY)) == 0) ? pr[k] : T(0));
-    }
-    T acc = seg_allreduce<64, T>(so);
-    while (true) {
-        // take in the round that is in flight
-        mask_t left = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (pend[k]) {
-                D.xv[k] = t[k];
-                if (Sentinel<T>::bits(t[k]) != Sentinel<T>::value) { pend[k] = false; pr[k] = S.v[k] * t[k]; }
-            }
-            pm[k] = __builtin_amdgcn_ballot_w64(pend[k]);
-            left |= pm[k];
-        }
-        // add what is next in slot order and has arrived: the slots below the first early slot whose operand is still missing
-        bool blocked = false;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const mask_t pe = em[k] & pm[k];
-            const mask_t below = pe ? ((pe & (~pe + 1)) - 1) : ~(mask_t)0;
-            mask_t take = blocked ? (mask_t)0 : (em[k] & below);
-            em[k] &= ~take;
-            while (take) {
-                const int l = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(take));
-                acc = acc + lane_bcast(pr[k], l);
-                take &= take - 1;
-            }
-            blocked = blocked || pe != 0;
-        }
-        if (!blocked) break;
-        if ((++spins & 1023u) == 0) {
-            // a producer that never comes (not resident / an earlier time-out): give up together, quickly
-            if (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        if (spins > 1) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            t[k] = __hip_atomic_load(pend[k] ? a.xs + (S.c[k] & LANE_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void)left;
-    }
-    if (a.prof && lane == 0) t1 = wall_clock64();
-    if (lane == 0 && S.rid >= 0) lane_publish<T, EPI, MODE>(a, S.rid, acc, D.bv, S.rd, D.xo);
-    if (a.prof && lane == 0) {
-        long long *o = a.prof + (size_t)g * 4;
-        o[0] = D.t0; o[1] = t1; o[2] = wall_clock64();
-        o[3] = (long long)((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) | (blockIdx.x << 4));
-    }
-}
-
-template <typename T, int EPI, int L, int K, int MODE>
-__device__ __forceinline__ void lane_finish_any(const LaneArgs<T> &a, const LaneSet<T, K> &S, LaneDyn<T, K> &D, int g, int idle)
-{
-    if constexpr (L == 64) {
-        if (a.tail) { lane_finish_ordered<T, EPI, K, MODE>(a, S, D, g, idle); return; }
-    }
-    lane_finish<T, EPI, L, K, MODE>(a, S, D, g, idle);
-}
-
 constexpr int LANE_WPB = BLK / 64;            // waves per workgroup (they never meet)
 
 template <typename T, int EPI, int L, int K, int MODE>
@@ -384,12 +279,12 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
             const int g2 = g + W;
             lane_issue<T, EPI, K>(a, P, D, idle);
             lane_load<T, L, K>(a, min(g2, gend - 1), Q);   // unconditional (a load under a branch makes the compiler drain the counter at the next wait)
-            lane_finish_any<T, EPI, L, K, MODE>(a, P, D, g, idle);
+            lane_finish<T, EPI, L, K, MODE>(a, P, D, g, idle);
             if (g2 >= gend) break;
             g = g2 + W;
             lane_issue<T, EPI, K>(a, Q, D, idle);
             lane_load<T, L, K>(a, min(g, gend - 1), P);
-            lane_finish_any<T, EPI, L, K, MODE>(a, Q, D, g2, idle);
+            lane_finish<T, EPI, L, K, MODE>(a, Q, D, g2, idle);
             if (g >= gend) break;
         }
     } else {
@@ -417,7 +312,7 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
                 lane_load<T, L, K>(a, g2, Q);
                 if (lane == 0) tk3 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            lane_finish_any<T, EPI, L, K, MODE>(a, P, D, g, idle);
+            lane_finish<T, EPI, L, K, MODE>(a, P, D, g, idle);
             if (g2 >= a.ngroups) break;
             g = (int)__builtin_amdgcn_readfirstlane(tk3);
             unsigned tk4 = 0;
@@ -426,7 +321,7 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
                 lane_load<T, L, K>(a, g, P);
                 if (lane == 0) tk4 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            lane_finish_any<T, EPI, L, K, MODE>(a, Q, D, g2, idle);
+            lane_finish<T, EPI, L, K, MODE>(a, Q, D, g2, idle);
             if (g >= a.ngroups) break;
             g2 = (int)__builtin_amdgcn_readfirstlane(tk4);
         }
@@ -505,11 +400,10 @@ static bool lane_one_xcd(const pamg_matrix_s *A, const GsSchedule *g)
 // The layout filled on the device (the default): the host plan (pattern only, build_lane_plan with fill = false) gives the row of every
 // (group, slot row) and the gates; this kernel writes cols / vals and the 16-byte slot-row records (row | NODIAG, gate, 1 / a_ii) from the
 // resident CSR arrays -- no download of the values, no upload of the padded 12-byte slots (256^3 level 1: 1.5 GB, 1 s of host time per direction).
-// One wave per group; the L lanes of a row all walk the row (broadcast loads), lane q keeps the entries e = q, q + L, ... of the storage order and
-// ranks each of them in the row's SLOT ORDER (lane_slot_order, pamg_lane_plan.h: old operands first, early ones by ascending producer level --
-// lvl[] is the host's analysis, uploaded for this launch) by walking the row once more.
+// One wave per group; the L lanes of a row all walk the row (broadcast loads), lane q keeps entries e = q, q + L, ...: the slot rule
+// of the host's fill pass (entries in storage order without the diagonal, the last stored diagonal wins).
 template <typename T>
-__global__ __launch_bounds__(256) void lane_fill_kernel(int n, const int *__restrict__ Ap, const int *__restrict__ Aj, const T *__restrict__ Ax, const int *__restrict__ lvl,
+__global__ __launch_bounds__(256) void lane_fill_kernel(int n, const int *__restrict__ Ap, const int *__restrict__ Aj, const T *__restrict__ Ax,
                                                         int row_start, int row_step, long long m, int L, int K, long long ngroups, const int *__restrict__ rid,
                                                         const int *__restrict__ gate, int *__restrict__ cols, T *__restrict__ vals, LaneRec *__restrict__ rec)
 {
@@ -522,29 +416,17 @@ __global__ __launch_bounds__(256) void lane_fill_kernel(int n, const int *__rest
     T d = T(0);
     if (i >= 0) {
         const long long ti = ((long long)i - row_start) * row_step;
-        auto key_of = [&](int j) -> int {
-            if (j < 0 || j >= n) return -1;
-            const long long tj = ((long long)j - row_start) * row_step;
-            return (tj >= 0 && tj < m && tj < ti) ? lvl[j] : -1;
-        };
         int e = 0;
         for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
             const int j = Aj[p];
             if (j == i) { d = Ax[p]; continue; }
             if (e % L == q) {
-                const int ke = key_of(j);
-                int rank = 0, f = 0;
-                for (int p2 = Ap[i]; p2 < Ap[i + 1]; ++p2) {
-                    const int j2 = Aj[p2];
-                    if (j2 == i) continue;
-                    const int kf = key_of(j2);
-                    rank += (kf < ke) || (kf == ke && f < e);
-                    ++f;
-                }
-                const size_t s = (size_t)((g * K + rank / L) * 64 + r * L + rank % L);
+                const size_t s = (size_t)((g * K + e / L) * 64 + lane);
                 if (j < 0 || j >= n) { cols[s] = LANE_NONE; vals[s] = T(0); }
                 else {
-                    cols[s] = j | (ke >= 0 ? LANE_EARLY : 0);
+                    const long long tj = ((long long)j - row_start) * row_step;
+                    const bool early = tj >= 0 && tj < m && tj < ti;
+                    cols[s] = j | (early ? LANE_EARLY : 0);
                     vals[s] = Ax[p];
                 }
             }
@@ -585,17 +467,16 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
         if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
     }
     LanePlan P;
-    // Lanes per row: ONE ROW PER WAVE where the rows are long enough to fill half of it -- a wave then waits for its own row's
-    // operands only (not for the slowest of 2 .. 16 rows), and the ordered tail of the kernel applies (level 1 of the 256^3
-    // hierarchy, 31 entries per row: 2.65 ms with 16 lanes per row, 2.49 with 32, 2.37 with 64, profiles/r04_microbench_lane_width.json;
-    // levels 2 / 3, 57 .. 68 entries: 0.70 / 0.72 ms with 32 / 64 lanes before the ordered tail).  Short rows (stencils): several rows
-    // per wave.
+    // Lanes per row.  Operators small enough for the one-XCD form (32 CUs): the fewest lanes that hold a row (most rows per
+    // wave).  Across the chip waves are plentiful and the sweep is bound by the hand-off latency per dependency level: ONE
+    // ROW PER WAVE where the rows are long enough to fill it (a wave then waits for its own row's operands only, not for the
+    // slowest of 4 or 16 rows) -- level 1 of the 256^3 hierarchy, 31 entries per row: 2.65 ms with 16 lanes per row, 2.49
+    // with 32, 2.37 with 64 (profiles/r04_microbench_lane_width.json).
     int want_L = A->lane_L;
-    if (!want_L) {
+    if (!want_L && !lane_one_xcd(A, g)) {
         want_L = 4;
         while (want_L < 64 && want_L < A->max_row_len - 1) want_L *= 2;
-        if (want_L < 32) want_L = 0;
-        else want_L = 64;
+        if (want_L < 32) want_L = 0;                           // short rows: several rows per wave (stencils)
     }
     if (build_lane_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), host_fill ? hAx.data() : nullptr, ts, g->row_start, g->row_step, (int)g->nrows,
                         g->nlevels, g->h_vis, g->h_lvl, want_L, P, host_fill))
@@ -619,10 +500,9 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
         if (!st) st = lane_upload(&t->d_cols, P.cols.data(), P.cols.size() * sizeof(int), &t->bytes);
         if (!st) st = lane_upload(&t->d_vals, P.vals.data(), P.vals.size(), &t->bytes);
     } else {
-        int *d_rid = nullptr, *d_gate = nullptr, *d_lvl = nullptr;
+        int *d_rid = nullptr, *d_gate = nullptr;
         st = lane_upload(&d_rid, P.rid.data(), P.rid.size() * sizeof(int), nullptr);
         if (!st) st = lane_upload(&d_gate, P.gate.data(), P.gate.size() * sizeof(int), nullptr);
-        if (!st) st = lane_upload(&d_lvl, g->h_lvl.data(), g->h_lvl.size() * sizeof(int), nullptr);
         if (!st) st = lane_upload(&t->d_rec, nullptr, nrec * sizeof(LaneRec), &t->bytes);
         if (!st) st = lane_upload(&t->d_cols, nullptr, (size_t)P.n_slots * sizeof(int), &t->bytes);
         if (!st) st = lane_upload(&t->d_vals, nullptr, (size_t)P.n_slots * ts, &t->bytes);
@@ -630,15 +510,15 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
             const unsigned grid = (unsigned)((P.ngroups + 3) / 4);
             (void)hipGetLastError();                                  // a stale error of an earlier query must not be taken for this launch's
             if (ts == 8)
-                hipLaunchKernelGGL((lane_fill_kernel<double>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const double *)A->d_Ax, d_lvl, g->row_start, g->row_step,
+                hipLaunchKernelGGL((lane_fill_kernel<double>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const double *)A->d_Ax, g->row_start, g->row_step,
                                    (long long)g->nrows, P.L, P.K, (long long)P.ngroups, d_rid, d_gate, t->d_cols, (double *)t->d_vals, t->d_rec);
             else
-                hipLaunchKernelGGL((lane_fill_kernel<float>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const float *)A->d_Ax, d_lvl, g->row_start, g->row_step,
+                hipLaunchKernelGGL((lane_fill_kernel<float>), dim3(grid), dim3(256), 0, 0, (int)A->nrows, A->d_Ap, A->d_Aj, (const float *)A->d_Ax, g->row_start, g->row_step,
                                    (long long)g->nrows, P.L, P.K, (long long)P.ngroups, d_rid, d_gate, t->d_cols, (float *)t->d_vals, t->d_rec);
             st = (int)hipGetLastError();
             if (!st) st = (int)hipDeviceSynchronize();
         }
-        hipFree(d_rid); hipFree(d_gate); hipFree(d_lvl);
+        hipFree(d_rid); hipFree(d_gate);
     }
     if (st) { free_lane_part(t); return st; }
     g->lane = t;
@@ -677,7 +557,6 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     LaneArgs<T> a;
     a.cols = t->d_cols; a.vals = (const T *)t->d_vals; a.rec = t->d_rec;
     a.use_gate = (A->lane_flags & 1) ? 1 : 0;
-    a.tail = (A->lane_flags & 16) ? 0 : 1;
     a.x = (const T *)x; a.y = (T *)x; a.xs = (T *)g->d_xs; a.b = (const T *)b;
     a.err = g->d_sync + 1; a.ticket = g->d_sync + 20;
     a.ngroups = (int)t->ngroups;

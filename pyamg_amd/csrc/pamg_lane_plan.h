@@ -23,13 +23,7 @@
 //                                    ahead polls this one value until the sweep is one level away, and only then all its
 //                                    operands: polling traffic of ~1 instead of ~3 dependency levels per group.
 // (on the device rid, gate and rdiag of a slot row travel as ONE 16-byte record, pamg_lane.hip: one request instead of three)
-// with lane = r * L + i and the row's off-diagonal entries in SLOT ORDER e = 0, 1, ... at k = e / L, i = e % L.
-// Slot order (round 5): the OLD operands first (storage order), then the EARLY operands by ascending dependency level of
-// the row that produces them (ties: storage order).  The kernel adds the old products with the butterfly while the polls
-// are in flight and then the early products ONE BY ONE in slot order -- the operands of the level just below, the last
-// to arrive, are the last to be added: behind the last hand-off there is one multiply-add instead of a butterfly
-// (one row per wave; several rows per wave keep the butterfly over everything).  The order is a property of the layout,
-// not of the timing: results are reproducible bit for bit.
+// with lane = r * L + i and the row's off-diagonal entries e = 0, 1, ... (storage order) at k = e / L, i = e % L.
 // Diagonal entries are not stored at all (every stored a_ii is skipped by the reference's sum; the last one is the
 // diagonal, relaxation.h:64-69).
 #pragma once
@@ -91,18 +85,6 @@ inline int lane_geometry(int maxlen, int want_L, int &K)
     }
     K = 0;
     return 0;
-}
-
-// slot order of one row: position in [0, entries) of every off-diagonal entry (storage order e = 0, 1, ...), see the header
-// comment -- OLD operands first, then EARLY operands by ascending producer level, storage order among equals.  key[e] = -1 for
-// an old operand (or an entry that is no column of x), the producer's dependency level for an early one.
-inline void lane_slot_order(const int *key, int cnt, int *slot)
-{
-    for (int e = 0; e < cnt; ++e) {
-        int r = 0;
-        for (int f = 0; f < cnt; ++f) r += (key[f] < key[e]) || (key[f] == key[e] && f < e);
-        slot[e] = r;
-    }
 }
 
 // Build the layout from a finished analysis of the sweep (vis = visit index or -1, lvl = dependency level of every
@@ -193,7 +175,6 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
     });
     std::vector<int64_t> ne((size_t)nl, 0), no((size_t)nl, 0);
     lane_parallel(nl, [&](int64_t l0, int64_t l1) {
-        std::vector<int> key, slot;
         for (int64_t l = l0; l < l1; ++l) {
             const int mylevel = (int)l;
             int64_t e_cnt = 0, o_cnt = 0;
@@ -202,23 +183,12 @@ inline int build_lane_plan(int n, const int *Ap, const int *Aj, const unsigned c
                 const int64_t g = P.level_grp[l] + rel / RPW;
                 const int r = (int)(rel % RPW);
                 const int i = order[(size_t)q], ti = vis[i];
-                // pass 1: keys of the off-diagonal entries in storage order
-                key.clear();
-                for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
-                    const int j = Aj[p];
-                    if (j == i) continue;
-                    const bool early = j >= 0 && j < n && vis[j] >= 0 && vis[j] < ti;
-                    key.push_back(early ? lvl[j] : -1);
-                }
-                slot.resize(key.size());
-                lane_slot_order(key.data(), (int)key.size(), slot.data());
                 int e = 0;
                 const unsigned char *dptr = nullptr;
                 for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
                     const int j = Aj[p];
                     if (j == i) { if (fill) dptr = Ax + (size_t)p * tsize; continue; }          // last stored diagonal wins
-                    const int es = slot[(size_t)e];
-                    const int k = es / L, lane = r * L + es % L;
+                    const int k = e / L, lane = r * L + e % L;
                     const size_t s = (size_t)((g * K + k) * 64 + lane);
                     ++e;
                     if (j < 0 || j >= n) continue;                                    // not a column of x: no product

@@ -26,6 +26,8 @@ struct LineSched {
     unsigned char *d_nodiag = nullptr;
     int64_t n_early = 0, max_level_lines = 0;
     int last_grid = 0;
+    int cap = 0;                    // co-resident workgroups per CU of this schedule's kernel (queried once)
+    const void *cap_kernel = nullptr;
     size_t bytes = 0;
 };
 
@@ -450,9 +452,13 @@ static int line_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
     if (!k) return PAMG_E_ARG;
     static thread_local int cus = 0;
     if (!cus) cus = line_cus();
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, BLK, 0) != hipSuccess) nb = 2;
-    const int cap = std::max(1, std::min(nb - 1, 8));          // every workgroup must be resident (the query can over-report by one)
+    if (t->cap <= 0 || t->cap_kernel != k) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, BLK, 0) != hipSuccess) nb = 2;
+        t->cap = std::max(1, std::min(nb - 1, 8));              // every workgroup must be resident (the query can over-report by one)
+        t->cap_kernel = k;
+    }
+    const int cap = t->cap;
     // waves: a few dependency levels of lines in flight (a line that runs ahead waits with its operands in registers)
     const int64_t want_waves = std::max<int64_t>(256, 4 * t->max_level_lines);
     int G = (int)std::min<int64_t>((want_waves + LINE_WPB - 1) / LINE_WPB, (int64_t)cap * cus);

@@ -2079,7 +2079,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
             return PAMG_OK;
         case 31: if (value != 2 && value != 4 && value != 8) return PAMG_E_ARG; A->rowmask_kz = value; return PAMG_OK;
         case 32: if (value < 0 || value > 15) return PAMG_E_ARG; A->rowmask_flags = value; return PAMG_OK;
-        case 28: if (value < 0 || value > 31 || (value & 6)) return PAMG_E_ARG; A->lane_flags = value; return PAMG_OK;      // bits 1, 2: retired (slab form, old values through the L1)
+        case 28: if (value < 0 || value > 15 || (value & 6)) return PAMG_E_ARG; A->lane_flags = value; return PAMG_OK;      // bits 1, 2: retired (slab form, old values through the L1)
         default: return PAMG_E_ARG;
     }
     if (key == 25) {                                  // lane geometry: drop the lane parts only

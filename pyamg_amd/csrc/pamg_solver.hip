@@ -1365,11 +1365,22 @@ int pamg_solver_set_krylov_smoother(pamg_solver_t S, int level, int which, int m
     return PAMG_OK;
 }
 
+// the cycle synchronises with the host (no graph capture) exactly when a host coarse solver or a Krylov smoother is installed
+static void recompute_host_sync(pamg_solver_s *S)
+{
+    bool hs = S->coarse_host != nullptr;
+    for (const Level &L : S->levels) hs = hs || L.pre.kind == PAMG_SMOOTH_KRYLOV || L.post.kind == PAMG_SMOOTH_KRYLOV;
+    S->host_sync = hs;
+}
+
 int pamg_solver_set_coarse_dense(pamg_solver_t S, const void *M, int n_c)
 {
     if (!S || n_c < 0) return PAMG_E_ARG;
     if (S->finalized) return PAMG_E_STATE;
     if (S->d_coarse) { hipFree(S->d_coarse); S->d_coarse = nullptr; }
+    // the last coarse solver installed wins: a host callback / relaxation set earlier must not keep running
+    S->coarse_host = nullptr; S->coarse_host_user = nullptr; S->coarse_relax = false;
+    recompute_host_sync(S);
     S->n_c = n_c; S->coarse_set = true; S->coarse_zero = (M == nullptr);
     if (M && n_c > 0) {
         const size_t sz = (size_t)n_c * n_c * tsize(S->dtype);
@@ -1399,6 +1410,8 @@ int pamg_solver_set_coarse_relax(pamg_solver_t S)
     if (S->levels.back().P) return PAMG_E_STATE;
     if (S->levels.back().pre.kind == PAMG_SMOOTH_NONE) return PAMG_E_ARG;
     S->coarse_relax = true; S->coarse_set = true; S->coarse_zero = false;
+    S->coarse_host = nullptr; S->coarse_host_user = nullptr;
+    recompute_host_sync(S);
     S->n_c = (int)S->levels.back().n;
     return PAMG_OK;
 }

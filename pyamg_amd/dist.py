@@ -466,6 +466,25 @@ class DistMultilevelSolver:
         return nat
 
     @classmethod
+    def model_rank(cls, part: "ShardedHierarchy", ops):
+        """ONE rank's share of a ``part.world``-rank solve on this process's device, with nobody on the wire (the C++ driver's MODEL
+        transport): the launches of that rank -- pack, interior / boundary ranges, collapse, replicated tail -- for TIMING; the
+        iterates are not a solve.  bench.py builds the modelled 1 -> 8 GPU curve from such runs + the exchange plans."""
+        self = cls.__new__(cls)
+        import torch.distributed as dist
+        self.dist, self.group = dist, None
+        self.exchange_mode, self.transport_tried = "halo", []
+        self.rank, self.world, self._gloo = part.rank, part.world, False
+        self.sh, self.ops = part, ops
+        self.A = [ops.matrix(m) for m in part.A]
+        self.P = [ops.matrix(m) for m in part.P]
+        self.R = [ops.matrix(m) for m in part.R]
+        self.coarse = ops.coarse_solver(part.coarse_spec)
+        self.shape = part.shape0
+        self.native = _NativeCycle(self, "model" if part.world > 1 else "none")
+        return self
+
+    @classmethod
     def from_rank0(cls, spec: Optional[HierarchySpec], ops=None, group=None, min_rows: int = 200_000, native=None):
         """The hierarchy exists on rank 0 only (``spec`` is None elsewhere): rank 0 partitions it for everybody, one part
         after another, and ships every part to its rank AS ARRAYS -- a small pickled skeleton plus one point-to-point
@@ -746,7 +765,7 @@ class _NativeCycle:
                                                       capi.ptr(Dinv), int(sm.blocksize) if sm else 1),
                            f"pamg_dist_set_smoother({l}, {kind})")
         if sol.world > 1:
-            {"host": self._host_transport, "rccl": self._rccl_transport, "torch": self._torch_transport}[transport](lib)
+            {"host": self._host_transport, "rccl": self._rccl_transport, "torch": self._torch_transport, "model": self._model_transport}[transport](lib)
         self.exchange = "halo"
         if sol.world > 1 and getattr(sol, "exchange_mode", "halo") == "allgather" and transport in ("host", "rccl"):
             capi.check(lib.pamg_dist_set_exchange(h, 1), "pamg_dist_set_exchange")
@@ -838,6 +857,20 @@ class _NativeCycle:
                    "pamg_dist_set_callbacks")
 
     # RCCL: rank 0 draws the id, everybody learns it through the process group, the communicator is this library's own
+    def _model_transport(self, lib):
+        """nobody on the wire (``DistMultilevelSolver.model_rank``): the rank's own launches among ``world`` ranks, for timing only"""
+        self.capi.check(lib.pamg_dist_set_model_transport(self.handle), "pamg_dist_set_model_transport")
+
+    def level_info(self, level: int) -> dict:
+        a = (C.c_int64 * 8)()
+        self.capi.check(self.capi.lib().pamg_dist_level_info(self.handle, int(level), a), "pamg_dist_level_info")
+        return dict(zip(("owned", "halo", "exchanges_per_iteration", "send_peers", "recv_peers", "max_sent_to_one_peer", "max_received_from_one_peer",
+                         "sent_per_exchange"), [int(v) for v in a]))
+
+    def set_options(self, use_graph=None, overlap=None):
+        self.capi.check(self.capi.lib().pamg_dist_set_options(self.handle, -1 if use_graph is None else int(bool(use_graph)),
+                                                              -1 if overlap is None else int(bool(overlap))), "pamg_dist_set_options")
+
     def _rccl_transport(self, lib):
         import torch
         sol, capi = self.sol, self.capi

@@ -381,7 +381,10 @@ def _krylov_coarse_smoother(cs, A_c, method):
     maxiter, restart = kw.pop("maxiter", None), kw.pop("restart", None)
     if "restrt" in kw:                                   # gmres's legacy spelling (krylov/_gmres.py: restrt -> restart)
         legacy = kw.pop("restrt")
-        restart = legacy if restart is None else restart
+        if legacy is not None:
+            if restart is not None:
+                raise ValueError("Only use restart, not restrt (deprecated).")          # krylov/_gmres.py:106-108
+            restart = legacy
     if kw.pop("x0", None) is not None:
         raise NotImplementedError("Krylov coarse solver with x0= is not on the device path")
     unknown = set(kw) - _KRYLOV_KWARGS

@@ -456,7 +456,15 @@ class DeviceMultilevelSolver:
             lines.append(f"{i:>6} {L.A.shape[0]:>11} {L.A.nnz:>12} [{100 * L.A.nnz / max(tot, 1):2.2f}%]")
         return "\n".join(lines) + "\n"
 
+    def _need_device(self, what):
+        # strict=False on a hierarchy that is not on the device path: solve / aspreconditioner / change_solve_matrix / levels go to the
+        # wrapped solver; the device-resident entry points have no host twin to hand the call to
+        if self.fallback is not None:
+            raise NotImplementedError(f"DeviceMultilevelSolver.{what}: this hierarchy is not on the device path (strict=False handed it "
+                                      "to the wrapped solver); only solve(), aspreconditioner(), change_solve_matrix() and levels are available")
+
     def stats(self) -> dict:
+        self._need_device("stats")
         a = (C.c_int64 * 8)()
         capi.check(capi.lib().pamg_solver_stats(self.handle, a), "pamg_solver_stats")
         return {"levels": int(a[0]), "gs_level_launches": int(a[1]), "hbm_bytes": int(a[2]), "graphs": int(a[3]),
@@ -464,12 +472,14 @@ class DeviceMultilevelSolver:
 
     def cycle_device(self, xd, bd, cycle="V", cycles_per_level=1, stream=None):
         """One cycle on DEVICE vectors (DeviceArray) in place."""
+        self._need_device("cycle_device")
         capi.check(capi.lib().pamg_solver_cycle(self.handle, xd.ptr, bd.ptr, capi.CYCLE[cycle],
                                                 int(cycles_per_level), stream), "pamg_solver_cycle")
 
     def solve_device(self, xd, bd, tol=1e-5, maxiter=100, cycle="V", cycles_per_level=1, check_every=1,
                      stream=None):
         """accel=None branch of ``solve`` on DEVICE vectors; returns (residuals, n_iter, info)."""
+        self._need_device("solve_device")
         res = np.zeros(int(maxiter) + 1, dtype=np.float64)
         nit, info = C.c_int(0), C.c_int(0)
         capi.check(capi.lib().pamg_solver_solve(self.handle, xd.ptr, bd.ptr, float(tol), int(maxiter),
@@ -492,10 +502,12 @@ class DeviceMultilevelSolver:
                           "slower.  Recreate the solver on an idle device to get the persistent sweeps back.", RuntimeWarning, stacklevel=3)
 
     def load_device(self, xd, bd, stream=None):
+        self._need_device("load_device")
         capi.check(capi.lib().pamg_solver_load(self.handle, xd.ptr, bd.ptr, stream), "pamg_solver_load")
 
     def iterate_device(self, k, cycle="V", cycles_per_level=1, want_residuals=True, stream=None):
         """Run exactly k x (cycle + convergence-check norm) on the resident state."""
+        self._need_device("iterate_device")
         res = np.zeros(max(int(k), 1), dtype=np.float64) if want_residuals else None
         capi.check(capi.lib().pamg_solver_iterate(self.handle, int(k), capi.CYCLE[cycle], int(cycles_per_level),
                                                   capi.ptr(res), stream), "pamg_solver_iterate")
@@ -503,9 +515,11 @@ class DeviceMultilevelSolver:
         return res[:k] if want_residuals else None
 
     def store_device(self, xd, stream=None):
+        self._need_device("store_device")
         capi.check(capi.lib().pamg_solver_store(self.handle, xd.ptr, stream), "pamg_solver_store")
 
     def stream(self):
+        self._need_device("stream")
         s = C.c_void_p()
         capi.check(capi.lib().pamg_solver_stream(self.handle, C.byref(s)), "pamg_solver_stream")
         return s
@@ -574,6 +588,7 @@ class DeviceMultilevelSolver:
     def pcg_device(self, xd, bd, tol=1e-5, maxiter=100, cycle="V", cycles_per_level=1, stream=None):
         """Device-resident preconditioned CG (krylov/_cg.py, criteria 'rr') on DEVICE vectors;
         returns (residuals, n_iter, info)."""
+        self._need_device("pcg_device")
         if maxiter is None:                                  # krylov/_cg.py:92-96
             maxiter = int(1.3 * self.shape[0]) + 2
         elif maxiter < 1:
@@ -588,12 +603,14 @@ class DeviceMultilevelSolver:
     def gmres_device(self, xd, bd, tol=1e-5, maxiter=None, restart=None, cycle="V", cycles_per_level=1, stream=None):
         """Device-resident GMRES, the reference's default Householder variant (krylov/_gmres_householder.py:
         left-preconditioned, residuals are preconditioned-residual norms); returns (residuals, n_iter, info)."""
+        self._need_device("gmres_device")
         return self.fgmres_device(xd, bd, tol, maxiter, restart, cycle, cycles_per_level, stream, _entry="pamg_solver_gmres")
 
     def fgmres_device(self, xd, bd, tol=1e-5, maxiter=None, restart=None, cycle="V", cycles_per_level=1, stream=None,
                       _entry="pamg_solver_fgmres"):
         """Device-resident flexible GMRES (krylov/_fgmres.py's control flow and residual history) on
         DEVICE vectors; returns (residuals, n_iter, info)."""
+        self._need_device("fgmres_device")
         n = self.shape[0]
         inner = min(int(restart), n) if restart else (min(int(maxiter), n) if maxiter else min(n, 40))
         outer = (int(maxiter) if maxiter else 1) if restart else 1

@@ -1,15 +1,12 @@
 // lane_emul.cpp -- CPU replay of the lane-parallel fast-order sweep (test infrastructure, not product code).
 // Builds the layout with the product's own planner (pyamg_amd/csrc/pamg_lane_plan.h) and consumes it the way
-// gs_lane_kernel does: group after group, lane l of a group forms its K products;
-//   several rows per wave (L < 64): all products of a row are added by the XOR butterfly (1, 2, 4, ...),
-//   one row per wave (L = 64, the ORDERED TAIL of round 5): the OLD products by the butterfly, then the EARLY products one by one in
-//   slot order (k-major, lane ascending) -- the order the layout fixes: old operands first, early ones by ascending producer level;
-// the head lane finishes the row with (b - sum) * rdiag, publishes into the sentinel-filled hand-off buffer and stores x.
-// Checks on the way what the device relies on: every EARLY operand has been published by a group with a SMALLER number
-// (deadlock freedom of the static assignment; with `waves` > 0 the groups are run by that many waves taking w, w + W, ... , visited
-// in the adversarial order: the last wave first), every OLD operand is still old when it is read (write-after-read safety on
-// structurally symmetric patterns, else a snapshot is used), dummy rows / padding slots carry no product, and the slot order itself
-// (no old operand behind an early one, producer levels ascending).
+// gs_lane_kernel does: group after group, lane l of a group adds its K products, the lanes of a row are added by the
+// XOR butterfly (1, 2, 4, ...), the head lane finishes the row with (b - sum) * rdiag, publishes into the
+// sentinel-filled hand-off buffer and stores x.  Checks on the way what the device relies on: every EARLY operand has
+// been published by a group with a SMALLER number (deadlock freedom of the static assignment; with `waves` > 0 the groups are
+// run by that many waves taking w, w + W, ..., visited in the adversarial order: the wave furthest ahead first -- a round without
+// progress is a deadlock), every OLD operand is still old when it is read (write-after-read safety on structurally symmetric
+// patterns, else a snapshot is used), dummy rows / padding slots carry no product.
 #include "../pyamg_amd/csrc/pamg_tile_plan.h"
 #include "../pyamg_amd/csrc/pamg_lane_plan.h"
 #include <cmath>
@@ -19,7 +16,7 @@ using namespace pamg;
 
 extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const double *Ax, double *x, const double *b, int row_start,
                                    int row_stop, int row_step, int want_L, int sor, double omega, int snapshot, long long *stats,
-                                   int waves, int butterfly_only)
+                                   int waves)
 {
     std::vector<int> vis, lvl;
     int m = 0, nl = 0;
@@ -36,7 +33,6 @@ extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const do
     if (snapshot) xold.assign(x, x + n);
     const double *xsrc = snapshot ? xold.data() : x;
     int64_t rows_done = 0;
-    const bool ordered = (L == 64) && !butterfly_only;
     auto run_group = [&](int64_t g, bool may_wait) -> int {
         if (may_wait) {
             for (int lane = 0; lane < 64; ++lane)
@@ -45,15 +41,13 @@ extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const do
                     if (!(c & LANE_NONE) && (c & LANE_EARLY) && !pub[(size_t)(c & LANE_MASK)]) return -1;       // still polling
                 }
         }
-        double lane_sum[64], prod[LANE_KMAX][64];
-        bool is_early[LANE_KMAX][64];
+        double lane_sum[64];
         for (int lane = 0; lane < 64; ++lane) {
             double s = 0.0;
             const int rid = P.rid[(size_t)(g * RPW + lane / L)];
             for (int k = 0; k < K; ++k) {
                 const size_t e = (size_t)((g * K + k) * 64 + lane);
                 const int c = P.cols[e];
-                prod[k][lane] = 0.0; is_early[k][lane] = false;
                 if (c & LANE_NONE) continue;
                 if (rid < 0) return 11;                                   // an entry in a dummy row
                 const int col = c & LANE_MASK;
@@ -61,14 +55,12 @@ extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const do
                 if (c & LANE_EARLY) {
                     if (!pub[(size_t)col]) return 12;                     // producer has a larger group number: deadlock on the device
                     xv = xs[(size_t)col];
-                    is_early[k][lane] = true;
                 } else {
                     if (!snapshot && written[(size_t)col]) return 13;     // an old value was overwritten before it was read
                     xv = xsrc[col];
                 }
                 const double pr = vals[e] * xv;
-                prod[k][lane] = pr;
-                if (!ordered || !(c & LANE_EARLY)) s = s + pr;
+                s = s + pr;
             }
             lane_sum[lane] = s;
         }
@@ -76,24 +68,6 @@ extern "C" int lane_emul_sweep_f64(int n, const int *Ap, const int *Aj, const do
             double t[64];
             for (int lane = 0; lane < 64; ++lane) t[lane] = lane_sum[lane] + lane_sum[lane ^ step];
             for (int lane = 0; lane < 64; ++lane) lane_sum[lane] = t[lane];
-        }
-        if (ordered) {
-            // early products one by one in slot order; the layout must have put every old operand in front and the producer levels in order
-            double acc = lane_sum[0];
-            int last_lvl = -1;
-            bool seen_early = false;
-            for (int k = 0; k < K; ++k)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int c = P.cols[(size_t)((g * K + k) * 64 + lane)];
-                    if (c & LANE_NONE) continue;
-                    if (is_early[k][lane]) {
-                        const int pl = lvl[c & LANE_MASK];
-                        if (pl < last_lvl) return 16;                     // producer levels not ascending
-                        last_lvl = pl; seen_early = true;
-                        acc = acc + prod[k][lane];
-                    } else if (seen_early) return 17;                     // an old operand behind an early one
-                }
-            for (int lane = 0; lane < 64; ++lane) lane_sum[lane] = acc;
         }
         // all rows of a group publish "at once": operands were read above, before any store of this group
         for (int r = 0; r < RPW; ++r) {

@@ -325,8 +325,8 @@ def test_gs_sweep_modes_all_exact():
 
 def test_gs_fast_order_agrees_to_rounding():
     """Fast order (tune gs_order=1, pamg_lane.hip): same sweep order over the rows, lane-parallel row sums and
-    multiplication by 1/a_ii -- every form (automatic lane width, forced widths, ordered tail / butterfly over everything with
-    one row per wave, static assignment across the chip, ticket form inside one XCD, tiny grids) must agree with the order-exact device sweep (= the reference's bits,
+    multiplication by 1/a_ii -- every form (automatic lane width, forced widths, static assignment across the chip,
+    ticket form inside one XCD, tiny grids) must agree with the order-exact device sweep (= the reference's bits,
     relaxation.h:48-76,116-145,185-266) to 1e-13 relative per sweep (f32: 2e-6), on a stencil, an irregular symmetric
     pattern, BSR(1,1), a NON-symmetric pattern (snapshot), zero / missing diagonals, and in single precision; exact mode
     is untouched by the switch."""
@@ -362,7 +362,7 @@ def test_gs_fast_order_agrees_to_rounding():
         dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
         assert np.array_equal(dx.download(), ref)                       # a bare operator is order-exact
         seen = set()
-        for kw in (dict(gs_order=1, lane_wide=1, line_scan=0), dict(lane_L=16), dict(lane_L=64), dict(lane_flags=17), dict(lane_flags=1), dict(lane_L=0, gran_xcd=1), dict(gran_xcd=2, lane_G=3),
+        for kw in (dict(gs_order=1, lane_wide=1, line_scan=0), dict(lane_L=16), dict(lane_L=64), dict(lane_L=0, gran_xcd=1), dict(gran_xcd=2, lane_G=3),
                    dict(gran_xcd=1, lane_G=1), dict(gran_xcd=0, lane_G=0, lane_L=8), dict(lane_flags=0), dict(lane_flags=1, gran_xcd=2)):
             dA.tune(**kw)
             dx.upload(x)
@@ -372,8 +372,7 @@ def test_gs_fast_order_agrees_to_rounding():
             assert info["groups"] > 0, (kw, ci)                         # the lane form really ran
             seen.add(info["lanes_per_row"])
             assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)), (kw, ci, np.max(np.abs(got - ref)))
-            # the order of the additions is the layout's, never the timing's (one row per wave: old products by the butterfly, early
-            # products one by one in slot order): a second run gives the same bits
+            # the order of the additions is the layout's, never the timing's: a second run gives the same bits
             dx.upload(x)
             dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
             assert np.array_equal(dx.download(), got), (kw, ci)

@@ -106,20 +106,6 @@ def variants_for(li, n):
             v.append((f"lines_G{G}", dict(lane_G=G)))
         for G in (256, 1024):
             v.append((f"lines_nogate_G{G}", dict(lane_G=G, lane_flags=0)))
-    if a.exp == "k":                       # round 5: ordered tail (lane_flags bit 4 = butterfly over everything, the round-4 arithmetic) x grid
-        v.append(("fast_auto", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
-        v.append(("fast_butterfly", dict(lane_flags=17)))
-        v.append(("fast_ordered_nogate", dict(lane_flags=0)))
-        if li == 1:
-            for fl, nm in ((1, "ordered"), (17, "butterfly")):
-                for G in (384, 448, 512, 640, 768):
-                    v.append((f"fast_{nm}_G{G}", dict(lane_flags=fl, lane_G=G)))
-        elif li in (2, 3):
-            for fl, nm in ((1, "ordered"), (17, "butterfly")):
-                for G in (16, 24, 32, 48, 64):
-                    v.append((f"fast_{nm}_xcd_G{G}", dict(lane_flags=fl, lane_G=G, gran_xcd=1)))
-            v.append(("fast_L32_xcd", dict(lane_flags=1, lane_L=32, lane_G=0, gran_xcd=1)))
-            v.append(("fast_ordered_chip", dict(lane_flags=1, lane_L=0, lane_G=0, gran_xcd=2)))
     return v
 
 
@@ -151,7 +137,7 @@ for li in a.levels:
             rec = {"level": li, "n": n, "variant": name, "fwd_ms": round(ms, 4), "max_rel_diff_vs_exact": diff, "timeout": err, "line": ln_ if ln_["lines"] else None,
                    "levels": inf["gs_levels_fwd"], "us_per_level": round(1e3 * ms / max(inf["gs_levels_fwd"], 1), 3),
                    "lane": {k: li_[k] for k in ("lanes_per_row", "slots_per_lane", "groups", "widest_level_groups", "launch_grid")} if name != "exact_default" else None}
-            if name in ("fast_auto", "fast_butterfly"):
+            if name == "fast_auto":
                 dA.tune(gs_prof=1)
                 dx.upload(x)
                 dA.gauss_seidel(dx, db, sweep="forward")
