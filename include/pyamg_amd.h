@@ -309,7 +309,7 @@ int pamg_matrix_destroy(pamg_matrix_t A);
  * info[7]=bwd GS levels */
 int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
 /* tuning knobs (speed only: every setting computes the same bits).  key 0 = LDS entries per row
- * range, 1 = entries per lane in the staging phase (1|2|4), 2 = max rows per range (these three
+ * range, 1 = entries per lane in the staging phase (2; 1 and 4 were measured no better and retired in round 5), 2 = max rows per range (these
  * re-plan the operator); 3 = flow_cap: an order-exact sweep whose schedule averages <= flow_cap/16
  * row ranges per dependency level runs as ONE persistent single-workgroup launch (default 32);
  * 5 = scheduler of the scalar order-exact sweeps: 0 automatic (narrow -> single workgroup, else the
@@ -318,7 +318,7 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * with a barrier per level"; 6 = cap on the persistent grid (0 = automatic); 7 = granular sweep
  * inside one XCD's L2: 0 automatic (small operators), 1 always, 2 never; 8 = streaming flags of the
  * whole-operator kernels: bit 0 non-temporal loads of the operator stream, bit 1 XCD-aware
- * row-range order; 9 = LDS-staged x windows for the whole-operator kernels (re-plans);
+ * row-range order (9, LDS-staged x windows, was retired in round 5: 4-7 % slower than the direct gather);
  * 5 also accepts 5 = TILED sweep (one persistent workgroup per contiguous chunk of rows; dependency chains
  * stay in LDS, only chunk-crossing edges use the global hand-off); 11 = record time stamps of the granular /
  * tiled sweep (diagnostics, pamg_matrix_gs_profile); 12 = tiles of the tiled sweep (0 = automatic),
@@ -339,11 +339,11 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * allow -- the row-MASK kernels when every list is the longest list with entries left out (a constant-coefficient stencil: one
  * mask byte per row, offsets and values are launch constants, no table, no prologue; on a 7-point lattice whose extents fit
  * 64 x 4 x kz tiles the lattice form csr_rowmask3d_kernel), else the table kernel --, 3 the table kernel (one row per lane)
- * always, 4 the linear row-mask kernel instead of the lattice form, 2 the table kernel with two consecutive rows per lane
- * (measured 28 % slower, profiles/r04_microbench_rowpat_two_rows_per_lane_slower.json), 0 off;
- * 31 = planes per lane of the lattice form (2 | 4 | 8, default 8); 32 = flags of the row-mask kernels (default 3): bit 0 the
- * streams touched once (mask, b, result) are nontemporal, bit 1 plane-by-plane XCD order (XCD j takes the j-th eighth of
- * every plane), bit 2 XCD-contiguous eighths of the rows instead, bit 3 offsets +-1 by whole-wave DPP shifts (linear form).
+ * always, 4 the linear row-mask kernel instead of the lattice form, 0 off (2, two consecutive rows per lane, measured 28 % slower --
+ * profiles/r04_microbench_rowpat_two_rows_per_lane_slower.json -- and retired in round 5);
+ * 31 = planes per lane of the lattice form (2 | 4 | 8, default 8); 32 = flags of the row-mask kernels (default 3): bit 0 (the
+ * streams touched once -- mask, b, result -- nontemporal) is always on since round 5 and ignored, bit 1 plane-by-plane XCD order (XCD j takes the j-th eighth of
+ * every plane), bit 2 XCD-contiguous eighths of the rows instead.
  * NOT speed-only -- 24 = ORDER of the row sums of the scalar Gauss-Seidel / SOR sweeps: 0 (default of a bare operator) =
  * order-exact, every sum runs in storage order with an IEEE division, results are the reference's bit for bit
  * (amg_core/relaxation.h:48-76,116-145,185-266); 1 = FAST order: the same sweep order over the rows (same dependency

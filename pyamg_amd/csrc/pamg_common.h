@@ -187,12 +187,9 @@ struct pamg_matrix_s {
     unsigned long long rm_val[8] = {0, 0, 0, 0, 0, 0, 0, 0};   //   values (bit patterns, low 32 bits for float)
     long long rm_walked = 0;
     int rowmask_kz = 8;              // planes per lane of csr_rowmask3d_kernel (2, 4, 8)
-    int rowmask_flags = 3;           // row-mask kernels: bit 0 nontemporal b / mask / result, bit 1 plane-by-plane XCD order, bit 2 XCD-contiguous eighths, bit 3 +-1 by DPP
-    int use_rowpat = 1;              // tune key 23: 0 off, 1 one row per lane (default), 2 two consecutive rows per lane (16-byte accesses; measured slower)
+    int rowmask_flags = 3;           // row-mask kernels: (bit 0: nontemporal b / mask / result -- always on since round 5, ignored) bit 1 plane-by-plane XCD order, bit 2 XCD-contiguous eighths
+    int use_rowpat = 1;              // tune key 23: 0 off, 1 the row-mask kernels where the operator has the form, else the table kernel (default), 3 the table kernel always, 4 the linear row-mask kernel instead of the lattice form
     int cap_from_val8 = 0;           // cap was raised to 2048 because the operator streams value codes (level schedules keep 1536)
-    int use_xwin = 0;                // LDS-staged x windows for the whole-operator kernels (tune key 9)
-    void *d_xwin = nullptr;          // XWin[nblk] window plan (device)
-    int xw_cap = 0;                  // window budget (values) the plan was built for
     int stream_flags = 0;            // StreamArgs::flags for the whole-operator launches
     int gran_xcd = 0;                // granular sweep inside one XCD's L2: 0 auto (small operators), 1 always, 2 never
     int gran_cap = 0;                // granular sweep: cap on the persistent grid (0 = auto)

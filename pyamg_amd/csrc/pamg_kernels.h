@@ -19,7 +19,15 @@
 namespace pamg {
 
 }  // namespace pamg
-#include "pamg_tail_kernel.h"      // wave_sum lives there (shared with the solver's translation unit)
+
+namespace pamg {
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+}  // namespace pamg
 namespace pamg {
 
 // sum over the workgroup, result valid in thread 0; sm = >= BLK/64 doubles of LDS
@@ -804,151 +812,6 @@ __device__ __forceinline__ T rowpat_value(const StreamArgs<T> &a, T b, T y, T xo
     else return (d != T(0)) ? (one - a.omega) * xo + a.omega * s / d : xo;                  // EPI_JACOBI_B
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(BLK) void csr_rowpat2_kernel(const StreamArgs<T> a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    using T2 = typename Vec2<T>::type;
-    constexpr bool SKIPD = EpiTraits<EPI>::need_cols;          // Jacobi family: the diagonal never enters the sum
-    constexpr bool NEEDB = (EPI == EPI_RESID || EPI == EPI_AXPBY || EPI == EPI_ACC_AXPBY || EPI == EPI_SUMSQ || EPI >= EPI_JACOBI);
-    constexpr bool NEEDY = (EPI == EPI_ACC || EPI == EPI_ACC_AXPBY || EPI == EPI_ACCSEQ);
-    constexpr bool NEEDJ = (EPI == EPI_JACOBI || EPI == EPI_JACOBI_B);
-    const int tid = threadIdx.x, lmax = a.lmax, np = a.npat;
-    int *tl = reinterpret_cast<int *>(smem_raw);               // [256] lengths
-    int *to = tl + 256;                                        // [np * lmax] offsets
-    T *tv = reinterpret_cast<T *>(smem_raw + (((size_t)(256 + np * lmax) * sizeof(int) + 15) & ~(size_t)15));   // [np * lmax] values
-    T *vd = tv + (size_t)np * lmax;                            // value dictionary (irregular rows)
-    {
-        const int *gl = reinterpret_cast<const int *>(a.ptab);
-        const T *gv = reinterpret_cast<const T *>(gl + 256 + np * lmax);
-        for (int k = tid; k < 256 + np * lmax; k += BLK) tl[k] = gl[k];
-        for (int k = tid; k < np * lmax; k += BLK) tv[k] = gv[k];
-        if (tid < a.nvd) vd[tid] = a.vdict[tid];
-    }
-    double sq = 0.0;
-    int blk = (int)blockIdx.x;
-    if (a.flags & 2) {
-        const int chunk = (a.nblk + 7) >> 3;
-        blk = (blk & 7) * chunk + (blk >> 3);
-    }
-    const bool live = blk < a.nblk;
-    if (live && a.blkmap) blk = a.blkmap[blk];
-    int4 meta = make_int4(0, 0, 0, 0), wb = make_int4(0, 0, 0, 0);
-    if (live) { meta = a.blkmeta[blk]; wb = a.wbase[blk]; }
-    const int r0 = meta.x, r1 = meta.y;
-    constexpr uintptr_t AL = 2 * sizeof(T) - 1;
-    const bool aligned = (((uintptr_t)a.x | (uintptr_t)a.y | (NEEDB ? (uintptr_t)a.b : 0) | (NEEDJ ? (uintptr_t)a.diag : 0) |
-                           ((EPI == EPI_SET && a.partial) ? (uintptr_t)a.partial : 0)) & AL) == 0;
-    // one row by the one-row path (the arithmetic of csr_rowpat_kernel)
-    auto one_row = [&](int r, unsigned pidv) {
-        RowPre<T> q = row_prefetch_noptr<T, EPI>(a, r);
-        T s = row_init<T, EPI>(q);
-        if (pidv != 255u) {
-            const int len = tl[pidv];
-            const int *po = to + pidv * lmax;
-            const T *pv = tv + pidv * lmax;
-            for (int j = 0; j < len; j += 8) {
-                int col[8];
-                T xv[8], av[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int e = (j + k < len) ? j + k : 0;
-                    col[k] = r + po[e];
-                    av[k] = pv[e];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) xv[k] = a.x[col[k]];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (j + k < len && (!SKIPD || col[k] != r)) {
-                        const T pr = av[k] * xv[k];
-                        if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
-                        else s += pr;
-                    }
-                }
-            }
-        } else {
-            const int lo = a.Ap[r], hi = a.Ap[r + 1];
-            for (int p = lo; p < hi; ++p) {
-                const unsigned c = a.Aj16[p];
-                const unsigned w = c >> 14;
-                const int col = (w == 0 ? wb.x : w == 1 ? wb.y : w == 2 ? wb.z : wb.w) + (int)(c & 0x3FFFu);
-                if (!SKIPD || col != r) {
-                    const T pr = vd[a.Ax8[p]] * a.x[col];
-                    if constexpr (EpiTraits<EPI>::bsr_order) s -= pr;
-                    else s += pr;
-                }
-            }
-        }
-        row_finish<T, EPI, 0>(a, q, s, sq);
-    };
-    __syncthreads();                                           // tables in place
-    for (int r = r0 + 2 * tid; r < r1; r += 2 * BLK) {
-        const bool two = r + 1 < r1;
-        unsigned p0, p1 = 255u;
-        if (two && !(r & 1)) {
-            const unsigned pp = *reinterpret_cast<const unsigned short *>(a.pid + r);
-            p0 = pp & 0xFFu; p1 = pp >> 8;
-        } else {
-            p0 = a.pid[r];
-            if (two) p1 = a.pid[r + 1];
-        }
-        if (aligned && two && !(r & 1) && p0 == p1 && p0 != 255u) {
-            T2 bb, yy, xo, dd;
-            bb.x = bb.y = yy.x = yy.y = xo.x = xo.y = dd.x = dd.y = T(0);
-            if constexpr (NEEDB) bb = *reinterpret_cast<const T2 *>(a.b + r);
-            if constexpr (NEEDY) yy = *reinterpret_cast<const T2 *>(a.y + r);
-            if constexpr (NEEDJ) { dd = *reinterpret_cast<const T2 *>(a.diag + r); xo = *reinterpret_cast<const T2 *>(a.x + r); }
-            T s0, s1;
-            if constexpr (EpiTraits<EPI>::bsr_order) { s0 = bb.x; s1 = bb.y; }
-            else if constexpr (EPI == EPI_ACCSEQ) { s0 = yy.x; s1 = yy.y; }
-            else { s0 = T(0); s1 = T(0); }
-            const int len = tl[p0];
-            const int *po = to + p0 * lmax;
-            const T *pv = tv + p0 * lmax;
-            for (int j = 0; j < len; j += 8) {
-                int off[8];
-                T av[8];
-                T2 xv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int e = (j + k < len) ? j + k : 0;                     // beyond the list: re-read its first entry
-                    off[k] = po[e];
-                    av[k] = pv[e];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const T *px = a.x + (r + off[k]);
-                    if (!(off[k] & 1)) xv[k] = *reinterpret_cast<const T2 *>(px);   // even offset: the pair is 16-byte aligned
-                    else { xv[k].x = px[0]; xv[k].y = px[1]; }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (j + k < len && (!SKIPD || off[k] != 0)) {
-                        const T q0 = av[k] * xv[k].x, q1 = av[k] * xv[k].y;
-                        if constexpr (EpiTraits<EPI>::bsr_order) { s0 -= q0; s1 -= q1; }
-                        else { s0 += q0; s1 += q1; }
-                    }
-                }
-            }
-            T2 v;
-            v.x = rowpat_value<T, EPI>(a, bb.x, yy.x, xo.x, dd.x, s0, sq);
-            v.y = rowpat_value<T, EPI>(a, bb.y, yy.y, xo.y, dd.y, s1, sq);
-            if constexpr (EPI != EPI_SUMSQ) *reinterpret_cast<T2 *>(a.y + r) = v;
-            if constexpr (EPI == EPI_SET) {
-                if (a.partial) { T2 z; z.x = z.y = T(0); *reinterpret_cast<T2 *>(reinterpret_cast<T *>(a.partial) + r) = z; }
-            }
-        } else {
-            one_row(r, p0);
-            if (two) one_row(r + 1, p1);
-        }
-    }
-    if constexpr (EPI == EPI_SUMSQ) {
-        __syncthreads();
-        const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
-        if (threadIdx.x == 0 && live) a.partial[blk] = tot;
-    }
-}
 
 // Single-workgroup persistent sweep (gs_flow1_kernel): ONE workgroup walks all row ranges of a
 // schedule, level after level, with __syncthreads() between them -- the scheduler of choice when
@@ -981,27 +844,12 @@ struct RowMaskArgs {
     int xcd_share;               // > 0: workgroups per plane and XCD (plane-by-plane order, see the kernel)
 };
 
-// VAR bit 0: the streams that are touched once (mask, b, the result) bypass the caches' retention (nontemporal), so x stays;
-// bit 1: offsets -1 / +1 are not gathered: lane l's x[row - 1] is lane l - 1's x[row] (whole-wave DPP shift), only lanes 0 and 63
-// load theirs.  Needs offsets -1, 0, +1 in slots NU / 2 - 1, NU / 2, NU / 2 + 1 (the host checks).
-template <int CTRL, typename T>
-__device__ __forceinline__ T rowmask_wave_shift(T v, T edge)
-{
-    if constexpr (sizeof(T) == 8) {
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        lo = __builtin_amdgcn_update_dpp(__double2loint(edge), lo, CTRL, 0xF, 0xF, false);
-        hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), hi, CTRL, 0xF, 0xF, false);
-        return __hiloint2double(hi, lo);
-    } else {
-        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), CTRL, 0xF, 0xF, false));
-    }
-}
-
-template <typename T, int EPI, int NU, int VAR>
+// NT: the streams that are touched once (mask, b, the result) bypass the caches' retention (nontemporal), so x stays.  (Round 4 also had
+// offsets -1 / +1 by whole-wave DPP shifts instead of gathers: measured neutral -- those gathers hit the L1 --, removed in round 5.)
+template <typename T, int EPI, int NU, bool NT>
 __global__ __launch_bounds__(BLK) void csr_rowmask_kernel(const StreamArgs<T> a, const RowMaskArgs<T> m)
 {
     constexpr bool SKIPD = EpiTraits<EPI>::need_cols;          // Jacobi family: the diagonal never enters the sum
-    constexpr bool NT = (VAR & 1) != 0, DPPX = (VAR & 2) != 0;
     // workgroups go to the XCDs round robin; share > 0: XCD j = blockIdx & 7 takes the j-th eighth of EVERY plane (plane = the
     // largest offset), planes in order -- the chip works on one plane at a time (one compact window of the HBM) and a row's
     // neighbours one plane up and down were, or will be, gathered through the same XCD's L2
@@ -1023,25 +871,12 @@ __global__ __launch_bounds__(BLK) void csr_rowmask_kernel(const StreamArgs<T> a,
         q = row_prefetch_noptr<T, EPI>(a, rc);
     }
     T xv[NU];
-    constexpr int near = NU / 2;                                  // DPPX: the host checked that slots near - 1, near, near + 1 hold offsets -1, 0, +1
 #pragma unroll
     for (int k = 0; k < NU; ++k) {
-        if (DPPX && (k == near - 1 || k == near + 1)) continue;
         int c = rc + m.off[k];
         c = c < 0 ? 0 : c;
         c = c < m.ncols ? c : m.ncols - 1;
         xv[k] = a.x[c];
-    }
-    if constexpr (DPPX) {
-        const int lane = (int)(threadIdx.x & 63);
-        T em = T(0), ep = T(0);
-        if (lane == 0) em = a.x[rc > 0 ? rc - 1 : 0];
-        if (lane == 63) ep = a.x[rc + 1 < m.ncols ? rc + 1 : m.ncols - 1];
-#pragma unroll
-        for (int k = 0; k < NU; ++k) {
-            if (k == near - 1) xv[k] = rowmask_wave_shift<0x138>(xv[k + 1], em);       // wave_shr:1 -- lane l takes lane l - 1's value, lane 0 keeps `em`
-            if (k == near + 1) xv[k] = rowmask_wave_shift<0x130>(xv[k - 1], ep);       // wave_shl:1
-        }
     }
     if (r >= m.nrows) return;
     T s = row_init<T, EPI>(q);
@@ -1276,84 +1111,6 @@ __device__ __forceinline__ void range_finish(const StreamArgs<T> &a, const Range
     row_finish<T, EPI, COH>(a, R.q, s, sq);
 }
 
-// ---- LDS-staged x windows -------------------------------------------------------------------
-// For banded operators (stencils: fine levels) the columns touched by one row range fall into a
-// few contiguous windows of x.  The host plan records up to XW_MAX windows per range; the
-// workgroup copies them into LDS with coalesced loads and phase 1 gathers from LDS instead of
-// sending scattered 8-byte requests through the texture-addresser/L1 path.  Ranges whose columns
-// do not fit the window budget (irregular coarse operators) fall back to the direct gather.
-constexpr int XW_MAX = 4;
-
-struct XWin {
-    int start[XW_MAX];     // first column of window w   (start[0] < 0: no plan -> direct gather)
-    int len[XW_MAX];       // its length (0 = unused)
-};
-
-template <typename T, int EPI>
-__global__ __launch_bounds__(BLK) void csr_stream_xw_kernel(const StreamArgs<T> a, const XWin *xwin, int wcap)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    using T2 = typename Vec2<T>::type;
-    constexpr bool NEEDC = EpiTraits<EPI>::need_cols;
-    const int blk = (int)blockIdx.x;
-    const int tid = threadIdx.x;
-    double sq = 0.0;
-    const XWin W = xwin[blk];
-    RangePre<T> R;
-    R.fits = false;
-    if (W.start[0] >= 0) range_prefetch<T, EPI, 0>(a, blk, R);          // operator slice -> registers
-    if (W.start[0] < 0 || !R.fits) {
-        stream_block<T, EPI, 2, 0>(a, a.blkmeta[blk], smem_raw, sq);
-    } else {
-        T *prod = reinterpret_cast<T *>(smem_raw);
-        int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)(a.cap + 8));
-        T *xl = reinterpret_cast<T *>(smem_raw + (sizeof(T) + (NEEDC ? 4 : 0)) * (size_t)(a.cap + 8));
-        int off[XW_MAX];
-        int o = 0;
-#pragma unroll
-        for (int w = 0; w < XW_MAX; ++w) {
-            off[w] = o;
-            for (int t = tid; t < W.len[w]; t += BLK) xl[o + t] = a.x[W.start[w] + t];   // coalesced
-            o += W.len[w];
-        }
-        __syncthreads();
-        const int p0 = R.meta.z, p1 = R.meta.w, base = p0 & ~1;
-#pragma unroll
-        for (int k = 0; k < MAXP; ++k) {
-            const int q = base + 2 * tid + k * 2 * BLK;
-            if (q < p1) {
-                const int2 cc = R.c[k];
-                int i0 = 0, i1 = 0;
-#pragma unroll
-                for (int w = 0; w < XW_MAX; ++w) {
-                    const unsigned d0 = (unsigned)(cc.x - W.start[w]), d1 = (unsigned)(cc.y - W.start[w]);
-                    if (d0 < (unsigned)W.len[w]) i0 = off[w] + (int)d0;
-                    if (d1 < (unsigned)W.len[w]) i1 = off[w] + (int)d1;
-                }
-                const bool ok0 = q >= p0, ok1 = q + 1 < p1;
-                const T x0 = ok0 ? xl[i0] : T(0);
-                const T x1 = ok1 ? xl[i1] : T(0);
-                T2 pr;
-                pr.x = R.v[k].x * x0;
-                pr.y = R.v[k].y * x1;
-                *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
-                if constexpr (NEEDC) *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
-            }
-        }
-        __syncthreads();
-        if (R.has_row) {
-            T s = row_init<T, EPI>(R.q);
-            row_accumulate<T, EPI>(s, prod, cols, R.q.lo - base, R.q.hi - base, R.q.row);
-            row_finish<T, EPI, 0>(a, R.q, s, sq);
-        }
-    }
-    if constexpr (EPI == EPI_SUMSQ) {
-        __syncthreads();
-        const double tot = block_sum(sq, reinterpret_cast<double *>(smem_raw));
-        if (tid == 0) a.partial[blk] = tot;
-    }
-    (void)wcap;
-}
 
 // single-workgroup persistent sweep: ranges taken one after the other, separated by
 // __syncthreads(), ordinary cached x accesses (same CU); the static operands of range k+1 are

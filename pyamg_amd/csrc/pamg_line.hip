@@ -229,6 +229,9 @@ __global__ __launch_bounds__(BLK) void gs_line_kernel(const LineArgs<T> a)
     }
 }
 
+// (Round 5: a WORKGROUP per line -- a wave per chunk, the chunk totals folded through LDS behind one barrier, bit-identical -- was built and measured:
+// 0.91 ms with 256 lines in flight, 1.06 with 768, against 0.80 for the walking wave above on the 256^3 fine level.  Four waves poll for a line where
+// one did; the polls load the memory system more than the shorter chain saves.  profiles/r05_microbench_line_workgroup_per_line_slower_not_kept.json)
 // ------------------------------------------------------------------ the layout, filled on the device
 // The chunk structure comes from the host (pattern only: pamg_line_plan.h with fill = false); cols / vals / rdiag / acoef /
 // nodiag / gate are written here from the resident CSR arrays -- no download of the values, no upload of the 1.3 GB layout

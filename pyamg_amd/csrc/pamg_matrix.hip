@@ -68,39 +68,12 @@ template <typename T, int EPI>
 int launch_epi(int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a)
 {
     if (grid <= 0) return PAMG_OK;
-    if (npl == 4) {
-        if (lds > 48 * 1024)
-            PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 4>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 4>), dim3(grid), dim3(BLK), lds, s, a);
-    } else if (npl == 2) {
-        if (lds > 48 * 1024)
-            PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 2>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 2>), dim3(grid), dim3(BLK), lds, s, a);
-    } else {
-        if (lds > 48 * 1024)
-            PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 1>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 1>), dim3(grid), dim3(BLK), lds, s, a);
-    }
-    return (int)hipGetLastError();
-}
-
-template <typename T>
-int xw_launch(int epi, int grid, int lds, hipStream_t s, const StreamArgs<T> &a, const XWin *xw, int wcap)
-{
-    if (grid <= 0) return PAMG_OK;
-#define PAMG_XW(E) case E:                                                                                        \
-        if (lds > 48 * 1024) PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_xw_kernel<T, E>,               \
-                                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));      \
-        hipLaunchKernelGGL((csr_stream_xw_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a, xw, wcap); break;
-    switch (epi) {
-        PAMG_XW(EPI_SET) PAMG_XW(EPI_ACC) PAMG_XW(EPI_RESID) PAMG_XW(EPI_AXPBY) PAMG_XW(EPI_ACC_AXPBY)
-        PAMG_XW(EPI_SUMSQ) PAMG_XW(EPI_ACCSEQ) PAMG_XW(EPI_JACOBI) PAMG_XW(EPI_JACOBI_B)
-        default: return PAMG_E_ARG;
-    }
-#undef PAMG_XW
+    // two entries per lane and staging step (one and four were measured no better and retired in round 5: tune key 1)
+    (void)npl;
+    if (lds > 48 * 1024)
+        PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 2>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 2>), dim3(grid), dim3(BLK), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -111,8 +84,7 @@ int launch_rowpat(int epi, int grid, const pamg_matrix_s *A, hipStream_t s, Stre
     a.pid = A->d_pid; a.ptab = A->d_ptab; a.npat = A->npat; a.lmax = A->pat_lmax;
     const size_t tabs = (((size_t)(256 + A->npat * A->pat_lmax) * sizeof(int) + 15) & ~(size_t)15) + sizeof(T) * ((size_t)A->npat * A->pat_lmax + 256);
     const int lds = (int)std::max(tabs + 16, (size_t)BLK * sizeof(double));
-#define PAMG_RP(E) case E: if (A->use_rowpat == 2) hipLaunchKernelGGL((csr_rowpat2_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); \
-                        else hipLaunchKernelGGL((csr_rowpat_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); break;
+#define PAMG_RP(E) case E: hipLaunchKernelGGL((csr_rowpat_kernel<T, E>), dim3(grid), dim3(BLK), lds, s, a); break;
     switch (epi) {
         PAMG_RP(EPI_SET) PAMG_RP(EPI_ACC) PAMG_RP(EPI_RESID) PAMG_RP(EPI_AXPBY) PAMG_RP(EPI_ACC_AXPBY) PAMG_RP(EPI_SUMSQ)
         PAMG_RP(EPI_ACCSEQ) PAMG_RP(EPI_JACOBI) PAMG_RP(EPI_JACOBI_B)
@@ -157,11 +129,10 @@ int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamA
         const int plane_ = A->rm_nu == 7 ? A->rm_off[6] : 0;
         while (kz > 2 && plane_ > 0 && nwin % plane_ == 0 && (nwin / plane_) % kz != 0) kz >>= 1;
         if ((plane_ <= 0 || row0 % plane_ == 0) && rowmask_lattice_plan(A->rm_nu, A->rm_off, nwin, kz, (A->rowmask_flags & 2) != 0, false, g, grid3)) {
-            const bool nt = A->rowmask_flags & 1;
 // (eight lattice lines per workgroup, 512 lanes: measured -1 % at 256^3 and +2 % at 512^3, profiles/r04_microbench_rowmask_512.json -- the plan and
 // the CPU replay keep the option, the kernels are instantiated for four)
 #define PAMG_R3W(E, KZ, NT_) hipLaunchKernelGGL((csr_rowmask3d_kernel<T, E, KZ, NT_, 4>), dim3(grid3), dim3(BLK), 0, s, a, m, g);
-#define PAMG_R3K(E, KZ) if (nt) { PAMG_R3W(E, KZ, true) } else { PAMG_R3W(E, KZ, false) }
+#define PAMG_R3K(E, KZ) PAMG_R3W(E, KZ, true)
 #define PAMG_R3(E) case E: if (kz == 2) { PAMG_R3K(E, 2) } else if (kz == 4) { PAMG_R3K(E, 4) } else { PAMG_R3K(E, 8) } return (int)hipGetLastError();
             switch (epi) {
                 PAMG_R3(EPI_SET) PAMG_R3(EPI_ACC) PAMG_R3(EPI_RESID) PAMG_R3(EPI_AXPBY) PAMG_R3(EPI_ACC_AXPBY)
@@ -178,14 +149,8 @@ int launch_rowmask(int epi, const pamg_matrix_s *A, hipStream_t s, const StreamA
     if ((A->rowmask_flags & 2) && plane >= 8 * BLK && plane % (8 * BLK) == 0 && nwin % plane == 0) m.xcd_share = plane / (8 * BLK);
     else if (A->rowmask_flags & 4) { m.xcd_chunk = (grid + 7) >> 3; grid = 8 * m.xcd_chunk; }
     const int nu = A->rm_nu <= 3 ? 3 : A->rm_nu <= 5 ? 5 : A->rm_nu <= 7 ? 7 : 8;
-    const int near = nu / 2;
-    const bool dppx = A->rm_nu == nu && nu < 8 && A->rm_off[near] == 0 && A->rm_off[near - 1] == -1 && A->rm_off[near + 1] == 1;
-    const int var = (A->rowmask_flags & 1) | (((A->rowmask_flags & 8) && dppx) ? 2 : 0);
-#define PAMG_RMV(E, N) \
-        if (var == 0) hipLaunchKernelGGL((csr_rowmask_kernel<T, E, N, 0>), dim3(grid), dim3(BLK), 0, s, a, m); \
-        else if (var == 1) hipLaunchKernelGGL((csr_rowmask_kernel<T, E, N, 1>), dim3(grid), dim3(BLK), 0, s, a, m); \
-        else if (var == 2) hipLaunchKernelGGL((csr_rowmask_kernel<T, E, N, 2>), dim3(grid), dim3(BLK), 0, s, a, m); \
-        else hipLaunchKernelGGL((csr_rowmask_kernel<T, E, N, 3>), dim3(grid), dim3(BLK), 0, s, a, m);
+    // (the single-use streams -- mask, b, result -- are always nontemporal since round 5: 0.112 -> 0.101 ms on the 256^3 residual; flag bit 0 is ignored)
+#define PAMG_RMV(E, N) hipLaunchKernelGGL((csr_rowmask_kernel<T, E, N, true>), dim3(grid), dim3(BLK), 0, s, a, m);
 #define PAMG_RM(E) case E: \
         if (nu == 3) { PAMG_RMV(E, 3) } else if (nu == 5) { PAMG_RMV(E, 5) } else if (nu == 7) { PAMG_RMV(E, 7) } else { PAMG_RMV(E, 8) } \
         break;
@@ -250,7 +215,6 @@ void parallel_rows(int n, F fn)
     for (auto &x : th) x.join();
 }
 
-int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap);
 
 // 16-bit column codes for the whole-operator kernels: per row range up to four windows of 16 K columns (greedy over the
 // range's sorted columns); an entry becomes window << 14 | (column - window base).  All-or-nothing per operator: one
@@ -391,52 +355,7 @@ int replan(pamg_matrix_s *A)
         PAMG_TRY(upload(&A->d_bmeta, bb.data(), bb.size(), nullptr));
     }
     PAMG_TRY(plan_idx16(A, blk));
-    if (A->use_xwin && A->R == 1 && A->npl == 2) PAMG_TRY(plan_windows(A, blk, std::max(256, A->cap)));
-    else if (A->d_xwin) { hipFree(A->d_xwin); A->d_xwin = nullptr; }
     PAMG_HIP(hipMalloc((void **)&A->d_partial, sizeof(double) * (size_t)(A->nblk + 264)));
-    return PAMG_OK;
-}
-
-// x-window plan for the whole-operator kernels: per row range, up to XW_MAX contiguous column
-// windows (gaps > 16 columns split windows) whose total length fits the LDS budget.
-int plan_windows(pamg_matrix_s *A, const std::vector<int4> &blk, int wcap)
-{
-    if (A->d_xwin) { hipFree(A->d_xwin); A->d_xwin = nullptr; }
-    const int nb = (int)blk.size();
-    std::vector<XWin> W((size_t)nb);
-    const int *Aj = A->h_Aj.data();
-    parallel_rows(nb, [&](int lo, int hi) {
-        std::vector<int> c;
-        for (int b = lo; b < hi; ++b) {
-            XWin w;
-            for (int k = 0; k < XW_MAX; ++k) { w.start[k] = 0; w.len[k] = 0; }
-            const int p0 = blk[b].z, p1 = blk[b].w;
-            bool ok = (p1 - p0) <= A->cap && (blk[b].y - blk[b].x) <= BLK && p1 > p0;
-            if (ok) {
-                c.assign(Aj + p0, Aj + p1);
-                std::sort(c.begin(), c.end());
-                int nw = 0, total = 0, ws = c[0], prev = c[0];
-                for (size_t i = 1; i <= c.size() && ok; ++i) {
-                    const bool last = i == c.size();
-                    if (last || c[i] - prev > 16) {
-                        if (nw == XW_MAX) { ok = false; break; }
-                        w.start[nw] = ws; w.len[nw] = prev - ws + 1;
-                        total += w.len[nw];
-                        ++nw;
-                        if (!last) ws = c[i];
-                    }
-                    if (!last) prev = c[i];
-                }
-                if (total > wcap) ok = false;
-            }
-            if (!ok) { w.start[0] = -1; for (int k = 0; k < XW_MAX; ++k) w.len[k] = 0; }
-            W[(size_t)b] = w;
-        }
-    });
-    A->xw_cap = wcap;
-    void *d = nullptr;
-    PAMG_TRY(upload_raw(&d, W.data(), W.size(), sizeof(XWin), nullptr));
-    A->d_xwin = d;
     return PAMG_OK;
 }
 
@@ -1014,14 +933,6 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
         return launch_any<float>(epi, A->npl, n, lds, s, a);
     }
     int lds = lds_bytes(A->dtype, epi, A->cap);
-    if (A->use_xwin && A->d_xwin && A->npl == 2 && epi < EPI_GS) {
-        const int per = (int)tsize(A->dtype) + ((epi == EPI_JACOBI || epi == EPI_JACOBI_B) ? 4 : 0);
-        const int ldsx = per * (A->cap + 8) + (int)tsize(A->dtype) * (A->xw_cap + 8) + 64;
-        if (ldsx <= 60 * 1024) {
-            if (A->dtype == PAMG_F64) return xw_launch<double>(epi, A->nblk, ldsx, s, base_args<double>(A, x, b, y, c, omega, partial), (const XWin *)A->d_xwin, A->xw_cap);
-            return xw_launch<float>(epi, A->nblk, ldsx, s, base_args<float>(A, x, b, y, c, omega, partial), (const XWin *)A->d_xwin, A->xw_cap);
-        }
-    }
     const int grid = (A->stream_flags & 2) ? 8 * ((A->nblk + 7) / 8) : A->nblk;
     const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2 && !(A->stream_flags & 4);
     const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
@@ -1077,8 +988,8 @@ static int gran2_launch(int epi, int grid, int lds, hipStream_t s, const GranArg
 template <typename T, int EPI>
 static int flow1_launch(int npl, int lds, hipStream_t s, const FlowArgs<T> &f)
 {
-    if (npl == 2) hipLaunchKernelGGL((gs_flow1_kernel<T, EPI, 2>), dim3(1), dim3(BLK), lds, s, f);
-    else hipLaunchKernelGGL((gs_flow1_kernel<T, EPI, 1>), dim3(1), dim3(BLK), lds, s, f);
+    (void)npl;
+    hipLaunchKernelGGL((gs_flow1_kernel<T, EPI, 2>), dim3(1), dim3(BLK), lds, s, f);
     return (int)hipGetLastError();
 }
 
@@ -1985,7 +1896,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
 {
     if (!A) return PAMG_OK;
     hipFree(A->d_Ap); hipFree(A->d_Aj); hipFree(A->d_Ax); hipFree(A->d_diag); hipFree(A->d_rowid);
-    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_xwin); hipFree(A->d_bmeta); hipFree(A->d_Aj16); hipFree(A->d_wbase); hipFree(A->d_Ax8); hipFree(A->d_vdict); hipFree(A->d_pid); hipFree(A->d_ptab);
+    hipFree(A->d_bAp); hipFree(A->d_bAj); hipFree(A->d_bAjf); hipFree(A->d_bdiag); hipFree(A->d_bAx); hipFree(A->d_blkmeta); hipFree(A->d_partial); hipFree(A->d_bmeta); hipFree(A->d_Aj16); hipFree(A->d_wbase); hipFree(A->d_Ax8); hipFree(A->d_vdict); hipFree(A->d_pid); hipFree(A->d_ptab);
     hipFree(A->d_part[0]); hipFree(A->d_part[1]);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     for (int k = 0; k < 4; ++k) pamg::free_line_schedule(A->ls[k]);
@@ -2046,18 +1957,17 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
     // a finalised solver's captured graphs point into the schedules and plans this call would free
     if (key == 21) { A->use_val8 = value != 0; return PAMG_OK; }      // read at launch time only: no plan depends on it
     if (key == 22) { A->use_rowg = value != 0; return PAMG_OK; }      // likewise
-    if (key == 23) { if (value < 0 || value > 4) return PAMG_E_ARG; A->use_rowpat = value; return PAMG_OK; }
+    if (key == 23) { if (value < 0 || value > 4 || value == 2) return PAMG_E_ARG; A->use_rowpat = value; return PAMG_OK; }
     if (A->borrowed > 0) return PAMG_E_STATE;
     switch (key) {
         case 0: if (value < 64 || value > 12288) return PAMG_E_ARG; A->cap = value & ~3; A->cap_from_val8 = 0; break;
-        case 1: if (value != 1 && value != 2 && value != 4) return PAMG_E_ARG; A->npl = value; break;
+        case 1: if (value != 2) return PAMG_E_ARG; A->npl = 2; return PAMG_OK;      // 1 and 4 entries per lane: measured no better, retired in round 5
         case 2: if (value < 1) return PAMG_E_ARG; A->max_rows = value; break;
         case 3: if (value < 0 || value > 256) return PAMG_E_ARG; A->flow_cap = value; return PAMG_OK;
         case 5: if (value < 0 || value > 5) return PAMG_E_ARG; A->gs_mode = value; return PAMG_OK;
         case 6: if (value < 0) return PAMG_E_ARG; A->gran_cap = value; return PAMG_OK;
         case 7: if (value < 0 || value > 2) return PAMG_E_ARG; A->gran_xcd = value; return PAMG_OK;
         case 8: if (value < 0 || value > 63) return PAMG_E_ARG; A->stream_flags = value; return PAMG_OK;
-        case 9: A->use_xwin = value != 0; break;
         case 11: A->gs_prof = value != 0; return PAMG_OK;
         case 12: if (value < 0) return PAMG_E_ARG; A->tile_G = value; break;
         case 13: if (value != 0 && (value < 64 || value > 8192 || (value & (value - 1)))) return PAMG_E_ARG; A->tile_W = value; break;
@@ -2078,7 +1988,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
             for (int k = 0; k < 4; ++k) if (A->gs[k]) A->gs[k]->line_unfit = false;      // a schedule the planner declined on its estimate is asked again
             return PAMG_OK;
         case 31: if (value != 2 && value != 4 && value != 8) return PAMG_E_ARG; A->rowmask_kz = value; return PAMG_OK;
-        case 32: if (value < 0 || value > 15) return PAMG_E_ARG; A->rowmask_flags = value; return PAMG_OK;
+        case 32: if (value < 0 || value > 7) return PAMG_E_ARG; A->rowmask_flags = value; return PAMG_OK;
         case 28: if (value < 0 || value > 15 || (value & 6)) return PAMG_E_ARG; A->lane_flags = value; return PAMG_OK;      // bits 1, 2: retired (slab form, old values through the L1)
         default: return PAMG_E_ARG;
     }

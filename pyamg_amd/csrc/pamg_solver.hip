@@ -12,7 +12,7 @@
 #include <new>
 #include <thread>
 
-#include "pamg_tail_kernel.h"
+#include "pamg_common.h"
 
 using namespace pamg;
 
@@ -185,9 +185,6 @@ struct pamg_solver_s {
     double *d_scratch = nullptr;  // 1032 doubles for vector reductions
     void *cg_r = nullptr, *cg_z = nullptr, *cg_p = nullptr, *cg_q = nullptr;   // device PCG work vectors
     std::map<int, hipGraphExec_t> graphs;   // key = cycle*1024 + cycles_per_level
-    int tail_from = -1;           // levels tail_from .. coarsest run as ONE launch (cycle_tail_kernel); -1: none
-    TailOp *d_tail = nullptr;     // its recorded operations
-    int n_tail = 0;
     bool host_sync = false;       // a Krylov smoother / coarse solver reads scalars back inside the cycle: no graph capture
     int fallbacks = 0;            // times a persistent sweep timed out and the solver switched to per-level launches
     size_t bytes = 0;
@@ -353,119 +350,6 @@ int coarse_solve(pamg_solver_s *S, const void *b, void *x, hipStream_t s)
     return dense_gemv(S->dtype, S->n_c, S->d_coarse, b, x, s);
 }
 
-// ---- the tail of the hierarchy as one launch (cycle_tail_kernel, pamg_kernels.h)
-constexpr int64_t TAIL_MAX_ROWS = 2048;        // rows of the largest level the single workgroup takes (two rows per lane)
-
-bool tail_smoother_ok(const Level &L, const Smoother &sm)
-{
-    if (sm.kind == PAMG_SMOOTH_NONE || sm.kind == PAMG_SMOOTH_POLY) return true;
-    return sm.kind == PAMG_SMOOTH_JACOBI && L.A->R == 1 && L.A->C == 1;
-}
-
-TailOp top_spmv(const pamg_matrix_s *M, int epi, const void *x, const void *b, void *y, void *z, double c, double omega)
-{
-    TailOp o{};
-    o.kind = TOP_SPMV; o.epi = epi; o.n = (int)M->nrows;
-    o.Ap = M->d_Ap; o.Aj = M->d_Aj; o.Ax = M->d_Ax; o.diag = M->d_diag;
-    o.x = x; o.b = b; o.y = y; o.z = z; o.c = c; o.omega = omega;
-    return o;
-}
-
-TailOp top_vec(int kind, int n, const void *x, void *y, double c)
-{
-    TailOp o{};
-    o.kind = kind; o.n = n; o.x = x; o.y = y; o.c = c;
-    return o;
-}
-
-// what apply_smoother enqueues for a Jacobi / polynomial smoother, as tail operations (the ping-pong swaps are resolved here)
-void record_smoother(Level &L, const Smoother &sm, bool x_zero, std::vector<TailOp> &ops)
-{
-    const int n = (int)L.n;
-    if (sm.kind == PAMG_SMOOTH_JACOBI) {
-        for (int it = 0; it < sm.iterations; ++it) {
-            ops.push_back(top_spmv(L.A, L.A->flavour == PAMG_BSR ? EPI_JACOBI_B : EPI_JACOBI, L.x, L.b, L.xalt, nullptr, 0.0, sm.omega));
-            std::swap(L.x, L.xalt);
-        }
-    } else if (sm.kind == PAMG_SMOOTH_POLY) {
-        const size_t ts = tsize(L.A->dtype);
-        void *res_buf = L.work, *h0 = (char *)L.work + (size_t)n * ts, *h1 = (char *)L.work + 2 * (size_t)n * ts;
-        const int nc = (int)sm.coeffs.size();
-        for (int it = 0; it < sm.iterations; ++it) {
-            const void *res = L.b;
-            if (!(x_zero && it == 0)) { ops.push_back(top_spmv(L.A, EPI_RESID, L.x, L.b, res_buf, nullptr, 0.0, 0.0)); res = res_buf; }
-            if (nc == 1) { ops.push_back(top_vec(TOP_AXPY, n, res, L.x, sm.coeffs[0])); continue; }
-            ops.push_back(top_vec(TOP_SCALE, n, res, h0, sm.coeffs[0]));
-            void *hc = h0, *hn = h1;
-            for (int k = 1; k < nc - 1; ++k) { ops.push_back(top_spmv(L.A, EPI_AXPBY, hc, res, hn, nullptr, sm.coeffs[k], 0.0)); std::swap(hc, hn); }
-            ops.push_back(top_spmv(L.A, EPI_ACC_AXPBY, hc, res, L.x, nullptr, sm.coeffs[nc - 1], 0.0));
-        }
-    }
-}
-
-// cycle_rec(lvl, V, x_zero) as tail operations
-void record_tail(pamg_solver_s *S, int lvl, bool x_zero, std::vector<TailOp> &ops)
-{
-    const int nlev = (int)S->levels.size();
-    Level &L = S->levels[lvl];
-    if (lvl == nlev - 1) {                                         // the coarsest level on its own: its solve
-        TailOp o{};
-        if (S->coarse_zero) o = top_vec(TOP_ZERO, S->n_c, nullptr, L.x, 0.0);
-        else { o.kind = TOP_GEMV; o.n = S->n_c; o.Ax = S->d_coarse; o.b = L.b; o.y = L.x; }
-        ops.push_back(o);
-        return;
-    }
-    Level &N = S->levels[lvl + 1];
-    record_smoother(L, L.pre, x_zero, ops);
-    ops.push_back(top_spmv(L.A, EPI_RESID, L.x, L.b, L.r, nullptr, 0.0, 0.0));
-    ops.push_back(top_spmv(L.R, EPI_SET, L.r, nullptr, N.b, N.x, 0.0, 0.0));          // b_c = R r, x_c = 0
-    record_tail(S, lvl + 1, true, ops);
-    ops.push_back(top_spmv(L.P, EPI_ACC, N.x, nullptr, L.x, nullptr, 0.0, 0.0));
-    record_smoother(L, L.post, false, ops);
-    if (L.x != L.x_home) {
-        ops.push_back(top_vec(TOP_COPY, (int)L.n, L.x, L.x_home, 0.0));
-        std::swap(L.x, L.xalt);
-    }
-}
-
-// decide where the tail starts and record it (called once, by pamg_solver_finalize)
-int build_tail(pamg_solver_s *S)
-{
-    S->tail_from = -1;
-    // Opt-in (PAMG_TAIL=1).  Measured on MI355X (profiles/r03_tail_kernel_c2_c1.json): inside a hipGraph the small levels'
-    // launches cost ~2 us each, less than one workgroup needs to walk the same rows with dependent loads -- 2000^2 Jacobi
-    // 0.559 ms per cycle with the tail in one launch against 0.521 ms without, 500^2 RS 0.233 against 0.199.  Kept for
-    // eager (graph-less) runs, where a launch costs 6-8 us.
-    const char *e = getenv("PAMG_TAIL");
-    if (!e || *e != '1') return PAMG_OK;
-    const int nlev = (int)S->levels.size();
-    int64_t max_rows = TAIL_MAX_ROWS;
-    if (const char *r = getenv("PAMG_TAIL_ROWS")) max_rows = std::max<int64_t>(1, std::min<int64_t>(TAIL_MAX_ROWS, atoll(r)));
-    if (nlev < 2 || S->coarse_relax || S->coarse_host || S->n_c > max_rows) return PAMG_OK;
-    int from = nlev - 1;                                           // the coarsest level always qualifies here
-    for (int l = nlev - 2; l >= 1; --l) {                          // never level 0: the cycle's entry point stays a normal launch sequence
-        const Level &L = S->levels[l];
-        const bool small = L.n <= max_rows && L.A->R == 1 && L.A->C == 1 && L.P->R == 1 && L.P->C == 1 && L.R->R == 1 && L.R->C == 1;
-        if (!small || !tail_smoother_ok(L, L.pre) || !tail_smoother_ok(L, L.post)) break;
-        from = l;
-    }
-    if (from > nlev - 2) return PAMG_OK;                           // only the coarsest solve would move: nothing to gain
-    std::vector<TailOp> ops;
-    record_tail(S, from, true, ops);
-    PAMG_HIP(hipMalloc((void **)&S->d_tail, sizeof(TailOp) * ops.size()));
-    PAMG_HIP(hipMemcpy(S->d_tail, ops.data(), sizeof(TailOp) * ops.size(), hipMemcpyHostToDevice));
-    S->n_tail = (int)ops.size();
-    S->tail_from = from;
-    return PAMG_OK;
-}
-
-int launch_tail(pamg_solver_s *S, hipStream_t s)
-{
-    if (S->dtype == PAMG_F64) hipLaunchKernelGGL((cycle_tail_kernel<double>), dim3(1), dim3(TAIL_THREADS), 0, s, (const TailOp *)S->d_tail, S->n_tail);
-    else hipLaunchKernelGGL((cycle_tail_kernel<float>), dim3(1), dim3(TAIL_THREADS), 0, s, (const TailOp *)S->d_tail, S->n_tail);
-    return (int)hipGetLastError();
-}
-
 // multilevel.py:584-662
 int cycle_rec(pamg_solver_s *S, int lvl, int type, int cpl, bool x_zero, hipStream_t s)
 {
@@ -477,9 +361,7 @@ int cycle_rec(pamg_solver_s *S, int lvl, int type, int cpl, bool x_zero, hipStre
     PAMG_TRY(stream_launch(L.A, EPI_RESID, L.x, L.b, L.r, 0.0, 0.0, nullptr, s));      // r = b - A x
     // b_c = R r and x_c = 0 in one launch (multilevel.py:613-615)
     PAMG_TRY(stream_launch(L.R, EPI_SET, L.r, nullptr, N.b, 0.0, 0.0, reinterpret_cast<double *>(N.x), s));
-    if (type == PAMG_CYCLE_V && S->tail_from == lvl + 1) {
-        PAMG_TRY(launch_tail(S, s));                               // the rest of the hierarchy in one launch
-    } else if (lvl == nlev - 2) {
+    if (lvl == nlev - 2) {
         PAMG_TRY(coarse_solve(S, N.b, N.x, s));
     } else if (type == PAMG_CYCLE_V) {
         PAMG_TRY(cycle_rec(S, lvl + 1, PAMG_CYCLE_V, 1, true, s));
@@ -1156,7 +1038,7 @@ int pamg_solver_destroy(pamg_solver_t S)
             if (sm->sw) pamg_schwarz_destroy(sm->sw);
         }
     }
-    hipFree(S->d_coarse); hipFree(S->d_norms); hipFree(S->d_slot); hipFree(S->d_scratch); hipFree(S->d_tail);
+    hipFree(S->d_coarse); hipFree(S->d_norms); hipFree(S->d_slot); hipFree(S->d_scratch);
     hipFree(S->cg_r); hipFree(S->cg_z); hipFree(S->cg_p); hipFree(S->cg_q);
     if (S->own_stream) hipStreamDestroy(S->own_stream);
     delete S;
@@ -1447,7 +1329,6 @@ int pamg_solver_finalize(pamg_solver_t S)
         PAMG_TRY(prebuild_schedules(L, L.pre));
         PAMG_TRY(prebuild_schedules(L, L.post));
     }
-    PAMG_TRY(build_tail(S));
     PAMG_TRY(dalloc(S, (void **)&S->d_slot, 16 * sizeof(double)));
     PAMG_TRY(dalloc(S, (void **)&S->d_scratch, 1032 * sizeof(double)));
     PAMG_HIP(hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking));
@@ -1709,8 +1590,7 @@ int pamg_solver_stats(pamg_solver_t S, int64_t stats[8])
     stats[2] = (int64_t)bytes;
     stats[3] = (int64_t)S->graphs.size();
     stats[4] = S->fallbacks;
-    stats[5] = S->tail_from;       // levels from here down run as one launch (-1: none)
-    stats[6] = S->n_tail;       // persistent sweeps timed out: the solver switched to one launch per dependency level
+    stats[5] = -1; stats[6] = 0;   // (round 3's hierarchy tail in one launch: retired in round 5 -- slower than the replayed graph of small launches)
     return PAMG_OK;
 }
 

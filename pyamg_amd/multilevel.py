@@ -148,14 +148,14 @@ class DeviceMatrix:
             capi.check(lib.pamg_matrix_lane_profile(self.handle, which, C.c_void_p(out.ctypes.data), n.value, C.byref(n)), "pamg_matrix_lane_profile")
         return out
 
-    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, xwin=None, gs_prof=None,
+    def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, gs_prof=None,
              tile_G=None, tile_W=None, tile_cap=None, tile_default=None, tile_D=None, tile_Q=None, tile_part=None, idx16=None, gs_cap=None, val8=None, rowgather=None, rowpat=None,
              gs_order=None, lane_L=None, lane_G=None, lane_wide=None, lane_flags=None, line_scan=None, rowmask_kz=None, rowmask_flags=None):
         """Speed-only knobs (every setting computes the same bits) -- except gs_order: 0 = order-exact row sums (the reference's
         bits), 1 = fast order (lane-parallel row sums, same sweep order, agrees to rounding).  Refused (PAMG_E_STATE) once a solver holds the
         operator: captured graphs point into the plans these calls rebuild."""
         lib = capi.lib()
-        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (9, xwin), (11, gs_prof),
+        for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (11, gs_prof),
                        (12, tile_G), (13, tile_W), (14, tile_cap), (15, tile_default), (16, tile_D), (17, tile_Q), (18, tile_part), (19, idx16), (20, gs_cap), (21, val8), (22, rowgather), (23, rowpat),
                        (24, gs_order), (25, lane_L), (26, lane_G), (27, lane_wide), (28, lane_flags), (30, line_scan), (31, rowmask_kz), (32, rowmask_flags)):
             if v is not None:
@@ -468,7 +468,7 @@ class DeviceMultilevelSolver:
         a = (C.c_int64 * 8)()
         capi.check(capi.lib().pamg_solver_stats(self.handle, a), "pamg_solver_stats")
         return {"levels": int(a[0]), "gs_level_launches": int(a[1]), "hbm_bytes": int(a[2]), "graphs": int(a[3]),
-                "sweep_timeouts_recovered": int(a[4]), "tail_from_level": int(a[5]), "tail_operations": int(a[6])}
+                "sweep_timeouts_recovered": int(a[4])}
 
     def cycle_device(self, xd, bd, cycle="V", cycles_per_level=1, stream=None):
         """One cycle on DEVICE vectors (DeviceArray) in place."""

@@ -347,34 +347,6 @@ def test_long_dependency_chains_against_the_live_reference(case):
         assert np.array_equal(o, outs[1])                 # exact schedulers differ in speed only
 
 
-@pytest.mark.parametrize("name", ["sa2d_jacobi", "sa2d_cheby", "rs2d_jacobi", "sa2d_richardson_W", "rs3d_gs_f32", "sa2d_coarse_jacobi"])
-def test_hierarchy_tail_in_one_launch_is_bit_identical(load_hier, name, monkeypatch):
-    """the small levels of a hierarchy (<= 2048 rows, Jacobi / polynomial smoothers, dense coarse solve) can run as ONE
-    launch of one workgroup (cycle_tail_kernel, opt-in with PAMG_TAIL=1): same iterates, same residual norms, bit for bit,
-    as the launch-per-operation cycle; hierarchies it does not apply to (W cycles, Gauss-Seidel levels, relaxation coarse
-    solvers) are left alone"""
-    spec, ex = load_hier(name)
-    cyc = str(ex["cycle"]) if "cycle" in ex else "V"
-    outs = []
-    for tail in ("1", "0"):
-        monkeypatch.setenv("PAMG_TAIL", tail)
-        dml = DeviceMultilevelSolver(spec)
-        st = dml.stats()
-        r = []
-        x = dml.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=int(ex["k"]), cycle=cyc, residuals=r)
-        dml.free()
-        outs.append((x, np.array(r), st))
-    (x1, r1, s1), (x0, r0, s0) = outs
-    assert s0["tail_from_level"] == -1
-    if name in ("sa2d_jacobi", "sa2d_cheby", "rs2d_jacobi"):
-        assert s1["tail_from_level"] >= 1 and s1["tail_operations"] > 5
-    if name in ("rs3d_gs_f32", "sa2d_coarse_jacobi"):
-        assert s1["tail_from_level"] == -1 or s1["tail_from_level"] >= 1
-    assert np.array_equal(x1, x0) and np.array_equal(r1, r0)
-    tol = 1e-10 if spec.dtype == np.float64 else 1e-5
-    assert np.max(np.abs(r1 - ex["res"])) <= tol * ex["res"][0]
-
-
 def test_sweep_timeout_falls_back_to_level_launches():
     """a persistent sweep that reports PAMG_E_TIMEOUT (not all of its workgroups were running -- forced here through the
     PAMG_FORCE_TIMEOUT test hook): solve() switches every order-exact sweep to one launch per dependency level, runs the

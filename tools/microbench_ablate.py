@@ -52,7 +52,7 @@ print(json.dumps({k: v for k, v in out.items() if "vec" in k}))
 dj = capi.DeviceArray.from_host(rng.rand(n)); dw = capi.DeviceArray(n, np.float64)
 for cap in (1024, 1536, 2048):
     for xw in (0, 1):
-        dA.tune(lds_entries=cap, nnz_per_lane=2, stream_flags=0, max_rows=256, xwin=xw)
+        dA.tune(lds_entries=cap, nnz_per_lane=2, stream_flags=0, max_rows=256)
         dA.spmv(capi.SPMV_SET, dx, dy)
         assert np.array_equal(dy.download(), ref), (cap, xw)
         ms = timeit(lambda: dA.spmv(capi.SPMV_RESID, dx, dy, b=db), 20)

@@ -33,7 +33,7 @@ for li, L in enumerate(spec.levels[:2]):
         dx = capi.DeviceArray.from_host(rng.rand(op.shape[1])); dy = capi.DeviceArray(op.shape[0], np.float64)
         rec = {}
         ref = None
-        for npl in (2, 1):
+        for npl in (2,):
             for cap in (1536, 1024, 768, 2048):
                 dM.tune(lds_entries=cap, nnz_per_lane=npl, stream_flags=0)
                 ms = timeit(lambda: dM.spmv(capi.SPMV_SET, dx, dy), 10)
