@@ -35,7 +35,7 @@ def short(name):
     m = re.search(r"csr_rowmask_sumsq_kernel<(\w+), *(\d+)>", name)
     if m:
         return f"csr_rowmask<{m.group(1)},SUMSQ,nu{m.group(2)}>"
-    m = re.search(r"csr_rowmask_kernel<(\w+), *(\d+), *(\d+), *(\d+)>", name)
+    m = re.search(r"csr_rowmask_kernel<(\w+), *(\d+), *(\d+), *(\w+)>", name)
     if m:
         return f"csr_rowmask<{m.group(1)},{EPI[int(m.group(2))]},nu{m.group(3)}>"
     m = re.search(r"gs_lane_kernel<(\w+), *(\d+), *(\d+), *(\d+), *(\w+)>", name)
@@ -145,9 +145,16 @@ for f in glob.glob(str(out / "trace" / "**" / "*kernel_trace.csv"), recursive=Tr
         # coverage: launches that belong to the cycle = kernels launched at least once per timed iteration (the level-0 convergence-check norm
         # runs once per iteration); share of their time that the table explains
         iters = max([r_["calls"] for r_ in table if "convergence-check" in r_["role"]] or [1])
-        in_cycle = sum(t for (k, g), (c, t) in rows if c >= iters and not k.startswith(("bw_", "__amd_rocclr", "spg_", "lane_fill", "line_fill")))
+        SETUP = ("bw_", "__amd_rocclr", "spg_", "lane_fill_kernel", "line_fill_kernel", "arn_", "tr_", "strength", "agg_", "fit_", "pinv", "csr_sub", "scale_rows", "reduce_")
+        in_cycle = sum(t for (k, g), (c, t) in rows if c >= iters and not k.startswith(SETUP))
         mapped = sum(r_["calls"] * r_["avg_us"] for r_ in table if r_["calls"] >= iters)
-        rl.append(f"coverage: the rows above explain {100 * mapped / max(in_cycle, 1e-9):.1f} % of the time of the kernels launched at least once per iteration ({iters} iterations in the trace)")
+        # the cycle's helper launches (hand-off buffer fills of the sweeps, vector updates of the polynomial smoother): no operator behind them
+        helpers = [((k, g), (c, t)) for (k, g), (c, t) in rows if c >= iters and not k.startswith(SETUP) and family(k)[0] is None]
+        if helpers:
+            rl.append("helper launches of the cycle (no operator: sentinel fills of the sweeps' hand-off buffers, vector updates) -- time only:")
+            for (k, g), (c, t) in helpers[:12]:
+                rl.append(f"  {(k + ' [' + str(g) + ']')[:60]:60s} {c:6d} calls {t / c:9.2f} us")
+        rl.append(f"coverage: the operator rows above explain {100 * mapped / max(in_cycle, 1e-9):.1f} % of the time of the kernels launched at least once per iteration ({iters} iterations in the trace); with the helper launches {100 * (mapped + sum(t for _, (c, t) in helpers)) / max(in_cycle, 1e-9):.1f} %")
         summary["kernel_roofline_coverage_pct"] = round(100 * mapped / max(in_cycle, 1e-9), 1)
         (out / "kernel_roofline.txt").write_text("\n".join(rl) + "\n")
         summary["kernel_roofline"] = table
