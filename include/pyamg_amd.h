@@ -390,6 +390,10 @@ int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8]);
  * launches 8x what stays), groups of the widest dependency level, bytes}; all zero when that schedule has no lane layout.  pamg_matrix_lane_profile: with tune
  * key 11, per group four 64-bit words {start, last operand seen, published (wall clock, 10 ns), XCD | workgroup << 4}. */
 int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8]);
+/* Layout of the lane-parallel fast-order Kaczmarz sweep (tune key 24 = 1 on the operator handed to pamg_matrix_kaczmarz; csrc/pamg_kz_plan.h)
+ * of the operator's `which`-th cached line schedule (0 .. 3, in the order the sweep ranges were first used): {lanes per line, entry slots per
+ * lane, groups, dependency levels, groups of the widest level, workgroups of the last launch, bytes, 0}; all zero when that schedule has none. */
+int pamg_matrix_kz_info(pamg_matrix_t A, int which, int64_t info[8]);
 /* Layout of the line-scan fast-order sweep (tune keys 24 / 30: banded operators swept over consecutive rows, i.e. grid
  * stencils in their natural order -- a run of rows each coupled to its predecessor is a first-order linear recurrence, finished
  * 64 rows at a time by a scan) for schedule `which`: {entry slots per row, chunks (<= 64 rows, one wave step each), lines (chained

@@ -144,6 +144,8 @@ struct LineSchedule {
     void *d_ea = nullptr;            //   offset and a dense slab of its first KZ entries (indices / values), schedule order
     std::vector<int> level_ptr;      // [nlevels+1]
     size_t bytes = 0;
+    struct KzLaneSched *kzl = nullptr; // lane-parallel fast-order form of the sweep (pamg_kz_plan.h / pamg_kz.hip), built with the schedule when tune key 24 = 1
+    bool kzl_unfit = false;          // its planner declined (lines too long, an index twice in a line, not f64)
 };
 
 }  // namespace pamg
@@ -274,6 +276,12 @@ void free_line_part(LineSched *t);
 size_t line_part_bytes(const GsSchedule *g);
 int line_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s);
 int line_info(const GsSchedule *g, int64_t *info);
+// pamg_kz.hip: the lane-parallel fast-order Kaczmarz sweeps (gauss_seidel_ne / gauss_seidel_nr)
+int build_kz_lane_part(pamg_matrix_s *Lm, LineSchedule *g);
+void free_kz_lane_part(KzLaneSched *t);
+int kz_lane_launch(pamg_matrix_s *Lm, LineSchedule *g, bool nr, void *v, const void *b, const void *Dinv, double omega, void *xout, hipStream_t s);
+int kz_lane_info(const LineSchedule *g, int64_t *info);
+bool kz_lane_error(LineSchedule *g);
 // pamg_lane.hip: the lane-parallel fast-order sweep
 bool lane_eligible(const pamg_matrix_s *A, const GsSchedule *g);
 int build_lane_part(pamg_matrix_s *A, GsSchedule *g);

@@ -1471,6 +1471,7 @@ void free_line_schedule(LineSchedule *g)
 {
     if (!g) return;
     hipFree(g->d_lines); hipFree(g->d_level_ptr); hipFree(g->d_len); hipFree(g->d_lo); hipFree(g->d_ej); hipFree(g->d_ea);
+    free_kz_lane_part(g->kzl);
     delete g;
 }
 
@@ -1481,7 +1482,11 @@ static int get_line_schedule(pamg_matrix_s *L, int start, int stop, int step, Li
 {
     for (int k = 0; k < 4; ++k) {
         LineSchedule *g = L->ls[k];
-        if (g && g->start == start && g->stop == stop && g->step == step) { *out = g; return PAMG_OK; }
+        if (g && g->start == start && g->stop == stop && g->step == step) {
+            *out = g;
+            if (L->gs_order == 1) PAMG_TRY(build_kz_lane_part(L, g));      // the fast order was asked for after the schedule was made
+            return PAMG_OK;
+        }
     }
     if (step == 0) return PAMG_E_ARG;
     const long span = (long)stop - start;
@@ -1535,6 +1540,7 @@ static int get_line_schedule(pamg_matrix_s *L, int start, int stop, int step, Li
     L->ls[slot] = g;
     L->bytes += g->bytes;
     *out = g;
+    if (L->gs_order == 1) PAMG_TRY(build_kz_lane_part(L, g));
     return PAMG_OK;
 }
 
@@ -1552,6 +1558,8 @@ int kaczmarz_sweep(pamg_matrix_s *L, bool nr, void *v, const void *b, const void
     if (L->R != 1 || L->C != 1) return PAMG_E_UNSUPPORTED;
     LineSchedule *g = nullptr;
     PAMG_TRY(get_line_schedule(L, start, stop, step, &g));
+    // fast order (tune key 24 = 1): ONE persistent launch, lanes share a line, versioned 16-byte slots hand the vector over (pamg_kz.hip)
+    if (L->gs_order == 1 && g->kzl && L->gs_mode == 0) return kz_lane_launch(L, g, nr, v, b, Dinv, omega, xout, s);
     // narrow schedules (on average <= 512 lines per level: 2-D operators): ONE persistent workgroup walks the levels
     // (about 2 us per level instead of a launch per level); gs_mode 1 keeps the per-level launches
     const int m_lines = g->level_ptr.empty() ? 0 : g->level_ptr.back();
@@ -1755,6 +1763,7 @@ int sweep_error(pamg_matrix_s *A, bool *error)
             PAMG_HIP(hipMemset(g->d_sync + 1, 0, sizeof(unsigned)));
         }
     }
+    for (int k = 0; k < 4; ++k) if (A->ls[k] && kz_lane_error(A->ls[k])) *error = true;
     return PAMG_OK;
 }
 }  // namespace pamg
@@ -2128,6 +2137,12 @@ int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8])
 {
     if (!A || which < 0 || which > 3 || !info) return PAMG_E_ARG;
     return pamg::lane_info(A->gs[which], info);
+}
+
+int pamg_matrix_kz_info(pamg_matrix_t A, int which, int64_t info[8])
+{
+    if (!A || !info || which < 0 || which > 3) return PAMG_E_ARG;
+    return pamg::kz_lane_info(A->ls[which], info);
 }
 
 int pamg_matrix_lane_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count)

@@ -138,6 +138,12 @@ class DeviceMatrix:
         capi.check(capi.lib().pamg_matrix_line_info(self.handle, which, a), "pamg_matrix_line_info")
         return dict(zip(("slots_per_row", "chunks", "lines", "line_levels", "early_entries", "launch_grid", "widest_level_lines", "bytes"), list(a)))
 
+    def kz_info(self, which=0):
+        """layout of the lane-parallel fast-order Kaczmarz sweep of the operator's `which`-th line schedule: dict, all zero if none is built"""
+        a = (C.c_int64 * 8)()
+        capi.check(capi.lib().pamg_matrix_kz_info(self.handle, which, a), "pamg_matrix_kz_info")
+        return dict(zip(("lanes_per_line", "slots_per_lane", "groups", "dependency_levels", "widest_level_groups", "launch_grid", "bytes"), list(a)[:7]))
+
     def lane_profile(self, which=0):
         """time stamps of the lane sweep (tune(gs_prof=1)): int64 array [groups, 4]"""
         n = C.c_int64(0)
@@ -216,7 +222,7 @@ class DeviceMatrix:
         self.free()
 
 
-def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype, aux):
+def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype, aux, fast=False):
     if s is None or s.kind == "none":
         capi.check(lib.pamg_solver_set_smoother(S, level, which, 0, 0, 1.0, 0, None, 0, None, 1), "set_smoother")
         return
@@ -230,6 +236,11 @@ def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype, aux):
         if getattr(s, "Ar", None) is not None:
             Ar = DeviceMatrix(s.Ar)
             aux.append(Ar)
+        if fast:
+            # order = 'fast': the Kaczmarz sweeps over these operators run lane-parallel too (csrc/pamg_kz.hip)
+            for m_ in (At, Ar):
+                if m_ is not None:
+                    m_.tune(gs_order=1)
         capi.check(lib.pamg_solver_set_ne_smoother(S, level, which, capi.SMOOTH[s.kind], int(s.iterations), float(s.omega),
                                                    capi.SWEEP.get(s.sweep, 0), capi.ptr(Dinv), At.handle if At else None,
                                                    Ar.handle if Ar else None),
@@ -405,12 +416,12 @@ class DeviceMultilevelSolver:
             capi.check(lib.pamg_solver_add_level(h, A.handle, P.handle if P else None, R.handle if R else None),
                        "pamg_solver_add_level")
             if i < nlev - 1:
-                _set_smoother(lib, h, i, 0, L.pre, self.dtype, self._aux)
-                _set_smoother(lib, h, i, 1, L.post, self.dtype, self._aux)
+                _set_smoother(lib, h, i, 0, L.pre, self.dtype, self._aux, fast=order == "fast")
+                _set_smoother(lib, h, i, 1, L.post, self.dtype, self._aux, fast=order == "fast")
         n_c = self.spec.levels[-1].A.shape[0]
         if self.spec.coarse_kind == "relax":
             # multilevel.py:765-782: sweeps of a relaxation method from x = 0 -- the smoother slot of the coarsest level
-            _set_smoother(lib, h, nlev - 1, 0, self.spec.coarse_smoother, self.dtype, self._aux)
+            _set_smoother(lib, h, nlev - 1, 0, self.spec.coarse_smoother, self.dtype, self._aux, fast=order == "fast")
             capi.check(lib.pamg_solver_set_coarse_relax(h), "set_coarse_relax")
         elif self.spec.coarse_kind == "host":
             # multilevel.py:752-762 (Krylov names other than 'cg' / 'gmres') and :786-788 (callables): the caller's own solver

@@ -824,6 +824,51 @@ def test_normal_equation_smoothers_bit_exact():
     assert np.array_equal(y, z[f"{tag}.jacobi_ne"])
 
 
+def test_kaczmarz_fast_order_agrees_to_rounding():
+    """The lane-parallel fast order of the Kaczmarz sweeps (tune gs_order = 1 on the operator handed to pamg_matrix_kaczmarz; csrc/pamg_kz.hip:
+    one persistent launch, lanes share a line, versioned 16-byte slots hand the rewritten vector over) against the order-exact device sweeps
+    (= the reference's bits: amg_core::gauss_seidel_ne / gauss_seidel_nr, relaxation.h:875-904, 939-975): 1e-13 per call on upwind
+    convection-diffusion (short lines), a dense-ish operator (long lines, two slots per lane), a rectangular one; forward, backward, symmetric,
+    two iterations; the same bits on a second run; the exact kernels untouched by the switch."""
+    from pyamg_amd.hierarchy import _normal_equation_spec as _nes
+    rng = np.random.RandomState(29)
+    n = 4000
+    conv = sp.csr_array(sp.diags_array([np.full(n, 4.0), -np.ones(n - 1), -2 * np.ones(n - 60), -np.ones(n - 60)], offsets=[0, -1, -60, 60], shape=(n, n)))
+    dense = sp.csr_array(sp.random(900, 900, density=0.1, random_state=rng, format="csr") + sp.diags_array(np.full(900, 9.0)))
+    for M in (conv, dense):
+        M.sort_indices()
+        m = M.shape[0]
+        x, b = rng.rand(m), rng.rand(m)
+        for kind, omega in (("gauss_seidel_ne", 0.9), ("gauss_seidel_nr", 1.1)):
+            spec = _nes(kind, M, 1, "forward", omega)
+            Lop = sparse_op(M) if kind == "gauss_seidel_ne" else spec.At
+            dL = DeviceMatrix(Lop)
+            dD = capi.DeviceArray.from_host(spec.Dinv)
+            db = capi.DeviceArray.from_host(b)
+            for sweep in ("forward", "backward", "symmetric"):
+                out = {}
+                for order in (0, 1, 1):
+                    dL.tune(gs_order=order)
+                    if kind == "gauss_seidel_ne":
+                        dv = capi.DeviceArray.from_host(x)
+                        dL.kaczmarz(dv, dD, omega, sweep, 2, b=db)
+                        got = (dv.download(),)
+                    else:
+                        dr = capi.DeviceArray.from_host(b - M @ x)
+                        dxo = capi.DeviceArray.from_host(x)
+                        dL.kaczmarz(dr, dD, omega, sweep, 2, xout=dxo)
+                        got = (dxo.download(), dr.download())
+                    assert not dL.flow_error()
+                    if order == 1:
+                        assert dL.kz_info(0)["groups"] > 0, (kind, sweep)                    # the lane form really ran
+                        if 1 in out:
+                            assert all(np.array_equal(a_, b_) for a_, b_ in zip(out[1], got))      # reproducible
+                    out[order] = got
+                for a_, b_ in zip(out[0], out[1]):
+                    assert np.max(np.abs(a_ - b_)) <= 1e-13 * max(1.0, np.max(np.abs(a_))), (kind, sweep, np.max(np.abs(a_ - b_)))
+            dL.free()
+
+
 def test_layer1_operator_cache():
     """Layer 1 keeps the last operators resident: the same three arrays again -> no new entry; the same arrays with
     CHANGED contents -> the stale copy is replaced and the sweep uses the new values; other arrays -> another entry.
