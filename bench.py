@@ -1040,6 +1040,29 @@ def main():
       except Exception as e:                                    # noqa: BLE001
         log(f"configs[4] leg failed: {e!r}")
         out.setdefault("extra", {})["c5"] = {"error": repr(e)[:300]}
+      # the "next" row that used to lose to one CPU core: what pyamg.solve() configures for a non-symmetric operator --
+      # energy-minimisation SA + gauss_seidel_nr (Kaczmarz) -- on 3-D upwind convection-diffusion 64^3; fast order of round 5 (csrc/pamg_kz.hip)
+      try:
+        wl6 = WORKLOADS["c6n3"]
+        A6, ml6, ts6 = build(wl6)
+        b6, x06 = rhs(A6.shape[0])
+        d6 = DeviceMultilevelSolver(ml6, device=local_rank, graph=not args.no_graph)
+        w6, _, res6, _, _ = time_resident(d6, b6, x06, 20, 3)
+        ex6 = {"workload": wl6["label"], "value": round(20 / w6, 3), "unit": "cycles/s", "ms_per_step": round(w6 * 1e3 / 20, 4), "steps": 20,
+               "host_setup_s": round(ts6, 1), "levels": len(ml6.levels), "gs_order": d6.order}
+        if args.cpu_cycles != 0:
+            c6cpu, r6cpu = cpu_reference(ml6, A6, b6, x06, 10)
+            ex6["cpu_baseline"] = c6cpu
+            ex6["speedup_vs_cpu_reference"] = round(ex6["value"] / c6cpu["value"], 1)
+            ex6["parity"] = parity_of(res6, r6cpu)
+            ex6["parity"]["reference_protocol"] = protocol_parity(d6, ml6, A6.shape[0])
+        out.setdefault("extra", {})["c6n3"] = ex6
+        out["config"]["extra_c6n3_cycles_per_s"] = ex6["value"]
+        out["config"]["extra_c6n3_vs_one_reference_core"] = ex6.get("speedup_vs_cpu_reference")
+        d6.free()
+      except Exception as e:                                    # noqa: BLE001
+        log(f"gauss_seidel_nr leg failed: {e!r}")
+        out.setdefault("extra", {})["c6n3"] = {"error": repr(e)[:300]}
       # configs[0]: the README's Ruge-Stuben example -- an irregular classical hierarchy at size, with the published
       # level sizes as the anchor (README.md:143-151)
       try:
