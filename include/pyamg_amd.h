@@ -388,7 +388,9 @@ int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8]);
 /* Layout of the lane-parallel fast-order sweep (tune key 24) for schedule `which`: {lanes per row, entry slots per lane,
  * groups (one wave each), entry slots, entries that wait for a new value, workgroups of the last launch (the one-XCD form
  * launches 8x what stays), groups of the widest dependency level, bytes}; all zero when that schedule has no lane layout.  pamg_matrix_lane_profile: with tune
- * key 11, per group four 64-bit words {start, last operand seen, published (wall clock, 10 ns), XCD | workgroup << 4}. */
+ * key 11, per group four 64-bit words {start, last operand seen, published (wall clock, 10 ns), XCD | workgroup << 4}.
+ * Block operators (bs > 1): the same fields for the block-row lane form of pamg_matrix_block_gauss_seidel (csrc/pamg_blane.hip: lanes per BLOCK row,
+ * BLOCKS per lane, block slots, blocks that wait for a new x_j). */
 int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8]);
 /* Layout of the lane-parallel fast-order Kaczmarz sweep (tune key 24 = 1 on the operator handed to pamg_matrix_kaczmarz; csrc/pamg_kz_plan.h)
  * of the operator's `which`-th cached line schedule (0 .. 3, in the order the sweep ranges were first used): {lanes per line, entry slots per

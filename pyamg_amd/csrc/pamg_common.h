@@ -120,6 +120,8 @@ struct GsSchedule {
     bool line_unfit = false;         // the line planner declined this schedule (no runs of coupled consecutive rows / rows too long)
     struct LaneSched *lane = nullptr; // lane-parallel "fast order" sweep (pamg_lane_plan.h / pamg_lane.hip), built on demand
     bool lane_unfit = false;         // the lane planner declined this schedule (rows too long / padding too wasteful)
+    struct BlaneSched *blane = nullptr; // block schedules: lane-parallel fast-order block Gauss-Seidel (pamg_blane_plan.h / pamg_blane.hip), built on demand
+    bool blane_unfit = false;        // its planner declined (block rows too long, block size not compiled, not f64)
 };
 
 // Device side of a tile plan: the step blocks (pamg_tile_plan.h: one fixed-size block of entry codes, values and
@@ -264,7 +266,7 @@ int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, i
                    int row_stop, int row_step, hipStream_t s);
 int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *xsrc, void *xdst,
                       const void *b, double omega, hipStream_t s);
-int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step);
+int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step, bool block_gs = false);
 struct CsrArrays { int64_t m, n, nnz; const int *p, *j; const double *x; };
 int csr_device_arrays(struct ::pamg_csr_s *A, CsrArrays *out);                                  // pamg_setup.hip: the device arrays behind a pamg_csr_t
 int solver_cycle_inline(pamg_solver_s *S, void *x, const void *b, int cycle, int cpl, hipStream_t s, bool allow_graph);   // pamg_solver.hip
@@ -282,6 +284,15 @@ void free_kz_lane_part(KzLaneSched *t);
 int kz_lane_launch(pamg_matrix_s *Lm, LineSchedule *g, bool nr, void *v, const void *b, const void *Dinv, double omega, void *xout, hipStream_t s);
 int kz_lane_info(const LineSchedule *g, int64_t *info);
 bool kz_lane_error(LineSchedule *g);
+// pamg_blane.hip: the lane-parallel fast-order block Gauss-Seidel sweep (BSR, square blocks)
+bool blane_eligible(const pamg_matrix_s *A, const GsSchedule *g);
+int build_blane_part(pamg_matrix_s *A, GsSchedule *g);
+void free_blane_part(BlaneSched *t);
+size_t blane_part_bytes(const GsSchedule *g);
+int blane_launch(pamg_matrix_s *A, GsSchedule *g, const void *Dinv, void *x, const void *b, hipStream_t s);
+int blane_info(const GsSchedule *g, int64_t *info);
+int blane_profile(const GsSchedule *g, long long *out, int64_t cap, int64_t *n);
+int device_cus_lane();
 // pamg_lane.hip: the lane-parallel fast-order sweep
 bool lane_eligible(const pamg_matrix_s *A, const GsSchedule *g);
 int build_lane_part(pamg_matrix_s *A, GsSchedule *g);

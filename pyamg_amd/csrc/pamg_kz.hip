@@ -109,16 +109,24 @@ template <int CTRL>
 __device__ __forceinline__ double kz_dpp(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);       // (no `old` operand: every lane has a source, the compiler needs no copy)
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double kz_swz16(double v)
+// lane ^ 16 / lane ^ 32 by v_permlane16_swap / v_permlane32_swap (pamg_lane.hip: swap_sum): no LDS path
+template <bool HALF>
+__device__ __forceinline__ double kz_swap_sum(double v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
-    hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
-    return __hiloint2double(hi, lo);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (HALF) {
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    } else {
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
 }
 // the butterfly of the Gauss-Seidel lane form (pamg_lane.hip: seg_allreduce), same steps in the same order
 template <int L>
@@ -128,8 +136,8 @@ __device__ __forceinline__ double kz_allreduce(double v)
     if constexpr (L >= 4) v = v + kz_dpp<0x4E>(v);
     if constexpr (L >= 8) v = v + kz_dpp<0x141>(v);
     if constexpr (L >= 16) v = v + kz_dpp<0x140>(v);
-    if constexpr (L >= 32) v = v + kz_swz16(v);
-    if constexpr (L >= 64) v = v + __shfl_xor(v, 32);
+    if constexpr (L >= 32) v = kz_swap_sum<false>(v);
+    if constexpr (L >= 64) v = kz_swap_sum<true>(v);
     return v;
 }
 

@@ -99,23 +99,44 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);       // (no `old` operand: every lane has a source, the compiler needs no copy)
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ double swz_xor16(double v)
+// lane ^ 16 and lane ^ 32 without the LDS path (round 5; ds_swizzle + ds_bpermute before): v_permlane16_swap / v_permlane32_swap (CDNA4) exchange
+// the odd 16-lane rows (the upper half) of one copy with the even rows (the lower half) of the other; afterwards one copy holds the even-row
+// (lower-half) values everywhere, the other the odd-row (upper-half) ones, and their sum is the butterfly step
+template <bool HALF>
+__device__ __forceinline__ double swap_sum(double v)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);              // bit mode: lane ^ 16 inside each half of the wave
-    hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
-    return __hiloint2double(hi, lo);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    if constexpr (HALF) {
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    } else {
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
 }
-__device__ __forceinline__ float swz_xor16(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); }
+template <bool HALF>
+__device__ __forceinline__ float swap_sum(float v)
+{
+    const int w = __float_as_int(v);
+    if constexpr (HALF) {
+        const auto a = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+        return __int_as_float(a[0]) + __int_as_float(a[1]);
+    } else {
+        const auto a = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+        return __int_as_float(a[0]) + __int_as_float(a[1]);
+    }
+}
 
 template <int L, typename T>
 __device__ __forceinline__ T seg_allreduce(T v)
@@ -124,8 +145,8 @@ __device__ __forceinline__ T seg_allreduce(T v)
     v = v + dpp_mov<0x4E>(v);                                   // quad_perm [2,3,0,1]: lane ^ 2
     if constexpr (L >= 8) v = v + dpp_mov<0x141>(v);            // row_half_mirror: the other quad of the 8
     if constexpr (L >= 16) v = v + dpp_mov<0x140>(v);           // row_mirror: the other half of the 16
-    if constexpr (L >= 32) v = v + swz_xor16(v);
-    if constexpr (L >= 64) v = v + __shfl_xor(v, 32);
+    if constexpr (L >= 32) v = swap_sum<false>(v);              // lane ^ 16
+    if constexpr (L >= 64) v = swap_sum<true>(v);               // lane ^ 32
     return v;
 }
 

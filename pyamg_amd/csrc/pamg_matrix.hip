@@ -366,6 +366,7 @@ void free_schedule(GsSchedule *g)
     if (!g) return;
     free_tile_part(g->tile);
     free_lane_part(g->lane);
+    free_blane_part(g->blane);
     free_line_part(g->line);
     hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_xold); hipFree(g->d_pblk); hipFree(g->d_dpos); hipFree(g->d_prof);
     delete g;
@@ -1123,9 +1124,24 @@ static bool want_lines(const pamg_matrix_s *A, const GsSchedule *g)
 }
 
 // device copies the scheduler of choice needs (called before any graph capture through ensure_schedule)
-static int ensure_parts(pamg_matrix_s *A, GsSchedule *g)
+static bool want_blanes(const pamg_matrix_s *A, const GsSchedule *g)
 {
-    if (A->R > 1) return PAMG_OK;
+    return A->gs_order == 1 && A->gs_mode == 0 && blane_eligible(A, g);
+}
+
+static int ensure_parts(pamg_matrix_s *A, GsSchedule *g, bool block_gs = false)
+{
+    if (A->R > 1) {
+        // fast order of the block Gauss-Seidel sweep (the BSR point sweep keeps the exact kernels)
+        if (block_gs && want_blanes(A, g) && !g->blane) {
+            const size_t before = g->bytes;
+            const int st = build_blane_part(A, g);
+            if (st == PAMG_OK) { std::lock_guard<std::mutex> lk(g_sched_mu); A->bytes += g->bytes - before; }
+            if (st != PAMG_E_ARG) return st;
+            g->blane_unfit = true;                             // block rows too long / padding too wasteful
+        }
+        return PAMG_OK;
+    }
     if (want_lines(A, g)) {
         const size_t before = g->bytes;
         const int st = build_line_part(A, g);
@@ -1387,6 +1403,8 @@ int block_gs_sweep(pamg_matrix_s *A, void *x, const void *b, const void *Dinv, i
 {
     GsSchedule *g = nullptr;
     PAMG_TRY(get_schedule(A, row_start, row_stop, row_step, &g));
+    PAMG_TRY(ensure_parts(A, g, true));
+    if (want_blanes(A, g) && g->blane) return blane_launch(A, g, Dinv, x, b, s);
     return A->dtype == PAMG_F64 ? block_sweep_t<double>(A, g, BLK_GS, Dinv, x, b, 1, s)
                                 : block_sweep_t<float>(A, g, BLK_GS, Dinv, x, b, 1, s);
 }
@@ -1407,11 +1425,11 @@ int block_jacobi_step(pamg_matrix_s *A, int kind, const void *Dinv, const void *
     return bsr_stream_launch<float>(kind, A->bnblk, lds, s, block_args<float>(A, nullptr, Dinv, xsrc, xdst, b, omega, 1), r, 0);
 }
 
-int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step)
+int ensure_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step, bool block_gs)
 {
     GsSchedule *g = nullptr;
     PAMG_TRY(get_schedule(A, row_start, row_stop, row_step, &g));
-    return ensure_parts(A, g);
+    return ensure_parts(A, g, block_gs);
 }
 
 // deterministic sum of n partials -> out[0].  Large n goes through 256 intermediate sums
@@ -2006,6 +2024,8 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
             GsSchedule *g = A->gs[k];
             if (g) g->lane_unfit = false;
             if (g && g->lane) { const size_t lb = lane_part_bytes(g); A->bytes -= lb; g->bytes -= lb; free_lane_part(g->lane); g->lane = nullptr; }
+            if (g) g->blane_unfit = false;
+            if (g && g->blane) { const size_t lb = blane_part_bytes(g); A->bytes -= lb; g->bytes -= lb; free_blane_part(g->blane); g->blane = nullptr; }
             if (g) g->line_unfit = false;
         }
         return PAMG_OK;
@@ -2136,6 +2156,7 @@ int pamg_matrix_line_info(pamg_matrix_t A, int which, int64_t info[8])
 int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8])
 {
     if (!A || which < 0 || which > 3 || !info) return PAMG_E_ARG;
+    if (A->R > 1) return pamg::blane_info(A->gs[which], info);      // block operators: the block-row lane form (pamg_blane.hip), same fields per block
     return pamg::lane_info(A->gs[which], info);
 }
 
@@ -2149,6 +2170,7 @@ int pamg_matrix_lane_profile(pamg_matrix_t A, int which, long long *out, int64_t
 {
     if (!A || which < 0 || which > 3 || !count) return PAMG_E_ARG;
     PAMG_HIP(hipDeviceSynchronize());
+    if (A->R > 1) return pamg::blane_profile(A->gs[which], out, capacity, count);
     return pamg::lane_profile(A->gs[which], out, capacity, count);
 }
 

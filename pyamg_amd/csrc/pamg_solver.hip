@@ -464,11 +464,11 @@ int prebuild_schedules(Level &L, const Smoother &sm)
     int r0, r1, rs;
     if (sm.sweep == PAMG_FORWARD || sm.sweep == PAMG_SYMMETRIC) {
         PAMG_TRY(sweep_bounds(L.A, PAMG_FORWARD, r0, r1, rs));
-        PAMG_TRY(ensure_schedule(L.A, r0, r1, rs));
+        PAMG_TRY(ensure_schedule(L.A, r0, r1, rs, sm.kind == PAMG_SMOOTH_BLOCK_GS));
     }
     if (sm.sweep == PAMG_BACKWARD || sm.sweep == PAMG_SYMMETRIC) {
         PAMG_TRY(sweep_bounds(L.A, PAMG_BACKWARD, r0, r1, rs));
-        PAMG_TRY(ensure_schedule(L.A, r0, r1, rs));
+        PAMG_TRY(ensure_schedule(L.A, r0, r1, rs, sm.kind == PAMG_SMOOTH_BLOCK_GS));
     }
     return PAMG_OK;
 }
@@ -476,7 +476,7 @@ int prebuild_schedules(Level &L, const Smoother &sm)
 // the order-exact schedules of all levels and both directions, built side by side on host threads (dependency analysis,
 // tile planning and packing are host work: a 256^3 hierarchy spends seconds there).  Jobs are (operator, sweep bounds);
 // duplicates (pre- and post-smoother of a level share theirs) are dropped.
-struct SchedJob { pamg_matrix_s *A; int r0, r1, rs; int st; };
+struct SchedJob { pamg_matrix_s *A; int r0, r1, rs; int st; bool block_gs; };
 
 void sched_jobs_of(Level &L, const Smoother &sm, std::vector<SchedJob> &jobs)
 {
@@ -485,8 +485,8 @@ void sched_jobs_of(Level &L, const Smoother &sm, std::vector<SchedJob> &jobs)
     auto add = [&](int dir) {
         int r0, r1, rs;
         if (sweep_bounds(L.A, dir, r0, r1, rs)) return;
-        for (const SchedJob &j : jobs) if (j.A == L.A && j.r0 == r0 && j.r1 == r1 && j.rs == rs) return;
-        jobs.push_back({L.A, r0, r1, rs, PAMG_OK});
+        for (const SchedJob &j : jobs) if (j.A == L.A && j.r0 == r0 && j.r1 == r1 && j.rs == rs && j.block_gs == (sm.kind == PAMG_SMOOTH_BLOCK_GS)) return;
+        jobs.push_back({L.A, r0, r1, rs, PAMG_OK, sm.kind == PAMG_SMOOTH_BLOCK_GS});
     };
     if (sm.sweep == PAMG_FORWARD || sm.sweep == PAMG_SYMMETRIC) add(PAMG_FORWARD);
     if (sm.sweep == PAMG_BACKWARD || sm.sweep == PAMG_SYMMETRIC) add(PAMG_BACKWARD);
@@ -500,14 +500,14 @@ int run_sched_jobs(std::vector<SchedJob> &jobs)
     const char *e = getenv("PAMG_SCHED_THREADS");
     const bool serial = (e && *e == '1' && !e[1]) || jobs.size() == 1;
     if (serial) {
-        for (SchedJob &j : jobs) PAMG_TRY(ensure_schedule(j.A, j.r0, j.r1, j.rs));
+        for (SchedJob &j : jobs) PAMG_TRY(ensure_schedule(j.A, j.r0, j.r1, j.rs, j.block_gs));
         return PAMG_OK;
     }
     std::vector<std::thread> th;
     for (SchedJob &j : jobs)
         th.emplace_back([&j, dev] {
             j.st = (int)hipSetDevice(dev);
-            if (!j.st) j.st = ensure_schedule(j.A, j.r0, j.r1, j.rs);
+            if (!j.st) j.st = ensure_schedule(j.A, j.r0, j.r1, j.rs, j.block_gs);
         });
     for (auto &t : th) t.join();
     for (const SchedJob &j : jobs) if (j.st) return j.st;

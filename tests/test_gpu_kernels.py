@@ -641,6 +641,74 @@ def test_block_sweep_modes_all_exact():
         dM.tune(lds_entries=1536)
 
 
+def test_block_gauss_seidel_fast_order_agrees_to_rounding():
+    """The lane-parallel fast order of the block Gauss-Seidel sweep (tune gs_order = 1; csrc/pamg_blane.hip: one persistent launch, lanes share a
+    block row, component-wise sentinel hand-off) against the order-exact device sweep (= the reference's bits: amg_core::block_gauss_seidel,
+    relaxation.h:1242-1298): 1e-13 per call on 2x2 blocks on a 3-D grid (several block rows per wave, the chip-wide static form), a structurally
+    NON-symmetric 3x3 pattern with missing diagonal blocks (old values from a snapshot), 27-point 3x3 and 6x6 blocks (one-XCD ticket form),
+    4x4 blocks with block rows of more than 64 blocks (two blocks per lane); forward, backward, symmetric, two iterations; the same bits on a
+    second run; the BSR point sweep stays order-exact; 5x5 blocks (not compiled) stay with the exact kernels."""
+    from oracle import oracle as orc
+    from tools.problems import poisson_csr
+    rng = np.random.RandomState(31)
+    def bsr_of(P, bs, diag_boost, drop=False):
+        P = sp.csr_array(P); P.sort_indices()
+        nb = P.shape[0]
+        dat = (rng.rand(P.nnz, bs, bs) - 0.5) * 0.3
+        rows = np.repeat(np.arange(nb), np.diff(P.indptr))
+        dat[rows == P.indices] += diag_boost * np.eye(bs)
+        return sp.bsr_array((dat, P.indices.astype(np.int32), P.indptr.astype(np.int32)), shape=(bs * nb, bs * nb), blocksize=(bs, bs))
+    P7 = poisson_csr((60, 50, 40))
+    g27 = poisson_csr((14, 12, 10)); g27 = sp.csr_array(((g27 @ g27 @ g27) != 0).astype(float))          # a wide 3-D stencil: ~60 blocks per block row
+    Pn = sp.random(900, 900, density=0.01, random_state=rng, format="lil")
+    for i in range(900):
+        if i % 11 != 5:
+            Pn[i, i] = 1.0
+    long_rows = sp.csr_array(sp.random(400, 400, density=0.22, random_state=rng, format="csr") + sp.eye_array(400))
+    cases = [("2x2 grid", bsr_of(P7, 2, 6.0)), ("3x3 nonsym", bsr_of(Pn, 3, 5.0)), ("3x3 wide", bsr_of(g27, 3, 12.0)), ("6x6 wide", bsr_of(g27, 6, 20.0)),
+             ("4x4 long", bsr_of(long_rows, 4, 40.0)), ("5x5", bsr_of(poisson_csr((9, 8, 7)), 5, 6.0))]
+    for name, M in cases:
+        bs = M.blocksize[0]
+        op = sparse_op(M)
+        n = op.shape[0]; nb = n // bs
+        x, b = rng.rand(n), rng.rand(n)
+        Dinv = np.zeros((nb, bs, bs))
+        rows = np.repeat(np.arange(nb), np.diff(M.indptr))
+        dm = rows == M.indices
+        Dinv[rows[dm]] = np.linalg.inv(M.data[dm])
+        dM = DeviceMatrix(op)
+        db = capi.DeviceArray.from_host(b)
+        dD = capi.DeviceArray.from_host(Dinv.reshape(-1))
+        ref_pnt = x.copy(); orc.relax_gauss_seidel(op, ref_pnt, b, 1, "symmetric")
+        for sweep in ("forward", "backward", "symmetric"):
+            ref = x.copy(); orc.relax_block_gauss_seidel(op, ref, b, Dinv, bs, 2, sweep)
+            out = {}
+            for order in (0, 1, 1):
+                dM.tune(gs_order=order)
+                dx = capi.DeviceArray.from_host(x)
+                dM.block_gauss_seidel(dx, db, dD, sweep=sweep, iterations=2)
+                got = dx.download()
+                assert not dM.flow_error(), (name, sweep, order)
+                if order == 0:
+                    assert np.array_equal(got, ref), (name, sweep)
+                else:
+                    which = 1 if sweep == "backward" else 0
+                    if bs != 5:
+                        assert dM.lane_info(which)["groups"] > 0, (name, sweep)                # the lane form really ran
+                    else:
+                        assert dM.lane_info(which)["groups"] == 0 and np.array_equal(got, ref)
+                    if 1 in out:
+                        assert np.array_equal(out[1], got), (name, sweep)                       # reproducible
+                out[order] = got
+            err = np.max(np.abs(out[0] - out[1]))
+            assert err <= 1e-13 * max(1.0, np.max(np.abs(out[0]))), (name, sweep, err)
+        dM.tune(gs_order=1)
+        dx = capi.DeviceArray.from_host(x)
+        dM.gauss_seidel(dx, db, sweep="symmetric")
+        assert np.array_equal(dx.download(), ref_pnt), name                                          # the BSR point sweep: exact kernels
+        dM.free()
+
+
 def test_indexed_jacobi_bit_exact():
     """jacobi_indexed (Layer 1, the amg_core twin) and the cf_jacobi / fc_jacobi wrappers (resident row-subset
     operators, csr_stream_kernel<JACOBI_IDX> + scatter) vs the reference's outputs in kernels_indexed.npz --

@@ -81,7 +81,21 @@ def kernel_map(dml, smoother_kind):
                 alg = vb * bs * bs * nblk + 4 * nblk + 4 * (nbrow + 1) + 3 * vb * n + (vb * bs * bs * nbrow if block else 0)
                 gs = smoother_kind.endswith("gauss_seidel")
                 kind = ("BLK_GS" if block else "PNT_GS") if gs else ("BLK_JACOBI" if block else "PNT_JACOBI")
-                if gs:
+                blanes = [A.lane_info(w) for w in (0, 1)] if (gs and block) else []
+                if gs and block and any(l_["groups"] and l_["launch_grid"] for l_ in blanes):
+                    # fast order (csrc/pamg_blane.hip): one entry per direction; streamed = the padded block slots (values + block column), the
+                    # block row of every slot row, b / Dinv / the result, the hand-off buffer (filled, written, polled) and x
+                    for which, dirn in ((0, "forward"), (1, "backward")):
+                        l_ = blanes[which]
+                        if not (l_["groups"] and l_["launch_grid"]):
+                            continue
+                        rpw = 64 // l_["lanes_per_row"]
+                        out.append({"family": "bsr_lane", "kind": kind, "bs": bs, "grid": int(l_["launch_grid"]), "level": i, "op": "A",
+                                    "what": f"{dirn} block Gauss-Seidel sweep on BSR({bs},{bs}) (fast order, {l_['lanes_per_row']} lanes per block row)",
+                                    "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg),
+                                    "bytes_streamed": int(l_["entry_slots"] * (vb * bs * bs + 4) + l_["groups"] * rpw * 4 + n * 5 * vb + vb * bs * bs * nbrow),
+                                    "format": f"{l_['lanes_per_row']} lanes x {l_['slots_per_lane']} blocks per block row, padded", "dependency_levels": int(inf["gs_levels_fwd"])})
+                elif gs:
                     out.append({"family": "bsr_gs", "kind": kind, "bs": bs, "grid": None, "level": i, "op": "A",
                                 "what": f"{'block' if block else 'point'} Gauss-Seidel sweep on BSR({bs},{bs}) (order-exact; forward and backward launches)",
                                 "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": int(alg + 4 * nbrow), "format": f"level-permuted BSR({bs},{bs}) + row ids",

@@ -44,6 +44,9 @@ def short(name):
     m = re.search(r"gs_line_kernel<(\w+), *(\d+), *(\d+)>", name)
     if m:
         return f"gs_line<{m.group(1)},{EPI[int(m.group(2))]},K{m.group(3)}>"
+    m = re.search(r"bsr_lane_kernel<(\d+), *(\d+), *(\d+), *(\d+)(?:, *\w+)?>", name)
+    if m:
+        return f"bsr_lane<double,BLK_GS,bs{m.group(1)},L{m.group(2)},K{m.group(3)},{'oneXCD' if m.group(4) == '1' else 'chip'}>"
     m = re.search(r"bsr_(gran|small|flow|stream)_kernel<(\w+), *(\d+)(?:, *(\w+))?>", name)
     if m:
         third = m.group(4)
@@ -64,6 +67,8 @@ def family(k):
         return "gs_tile", None
     if k.startswith("gs_gran") or k.startswith("gs_flow"):
         return "gs_gran", None
+    if k.startswith("bsr_lane"):
+        return "bsr_lane", None
     if k.startswith("bsr_gran") or k.startswith("bsr_small") or k.startswith("bsr_flow"):
         m = re.search(r"<\w+,(\w+)(?:,bs(\d+))?", k)
         return "bsr_gs", (m.group(1), int(m.group(2)) if m and m.group(2) else None)
