@@ -322,7 +322,7 @@ class DeviceArray:
 def bandwidth_probe(kind: str = "copy", n: int = 1 << 27, reps: int = 20) -> float:
     """measured GB/s of an on-device copy / triad with 16-byte accesses (pamg_bandwidth_probe)"""
     out = C.c_double(0.0)
-    kinds = {"copy": 0, "triad": 1, "copy1": 2, "copy4": 3, "copy4nt": 4, "copy8": 5, "read": 6, "write": 7, "memcpy": 8, "copy8b": 9, "copy8bnt": 10, "copy1nt": 11}
+    kinds = {"copy": 0, "triad": 1, "copy1": 2, "copy4": 3, "copy4nt": 4, "copy8": 5, "read": 6, "write": 7, "memcpy": 8, "copy8b": 9, "copy8bnt": 10, "copy1nt": 11, "read_one_xcd": 12, "read_one_xcd_2wg": 13}
     check(lib().pamg_bandwidth_probe(kinds[kind], int(n), int(reps), C.byref(out)), "pamg_bandwidth_probe")
     return float(out.value)
 

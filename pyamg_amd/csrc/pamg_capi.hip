@@ -574,6 +574,23 @@ __global__ __launch_bounds__(256) void bw_read_kernel(const double2 *__restrict_
     }
     if (s == 1.2345e300) c[0] = s;                                  // never true for the zero-filled probe vectors; keeps the loads
 }
+// what ONE XCD reads: workgroups on the other seven leave at once, the 1/8 that stay walk the whole vector (16-byte loads, U per trip).
+// The one-XCD forms of the sweeps are bound by this when a dependency level streams more than the hand-off takes.
+template <int U>
+__global__ __launch_bounds__(256) void bw_read_xcd_kernel(const double2 *__restrict__ a, double *__restrict__ c, int64_t n2, int home_wgs)
+{
+    if ((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) != 0) return;                 // HW_REG_XCC_ID
+    const int64_t w = blockIdx.x >> 3;                                                   // (round-robin placement: every eighth workgroup is here)
+    double s = 0.0;
+    for (int64_t base = w * (256 * U) + threadIdx.x; base < n2; base += (int64_t)home_wgs * (256 * U)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * 256;
+            if (i < n2) { const double2 v = a[i]; s += v.x + v.y; }
+        }
+    }
+    if (s == 1.2345e300) c[0] = s;
+}
 template <int U>
 __global__ __launch_bounds__(256) void bw_write_kernel(double2 *__restrict__ c, int64_t n2)
 {
@@ -592,7 +609,7 @@ __global__ __launch_bounds__(256) void bw_write_kernel(double2 *__restrict__ c, 
 // 11 copy 1 x 16 B nontemporal
 int pamg_bandwidth_probe(int kind, int64_t n, int reps, double *gbps)
 {
-    if (kind < 0 || kind > 11 || n < 1024 || reps < 1 || !gbps) return PAMG_E_ARG;
+    if (kind < 0 || kind > 13 || n < 1024 || reps < 1 || !gbps) return PAMG_E_ARG;
     n &= ~(int64_t)1;
     double *a = nullptr, *b = nullptr, *c = nullptr;
     PAMG_HIP(hipMalloc((void **)&a, (size_t)n * 8));
@@ -617,6 +634,8 @@ int pamg_bandwidth_probe(int kind, int64_t n, int reps, double *gbps)
             case 9: hipLaunchKernelGGL((bw_copy8_kernel<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const double *)a, c, n); break;
             case 10: hipLaunchKernelGGL((bw_copy8_kernel<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const double *)a, c, n); break;
             case 11: hipLaunchKernelGGL((bw_copy_block_kernel<1, true>), blocks(1), dim3(256), 0, 0, (const double2 *)a, (double2 *)c, n2); break;
+            case 12: hipLaunchKernelGGL((bw_read_xcd_kernel<4>), dim3(8 * 256), dim3(256), 0, 0, (const double2 *)a, c, n2, 256); break;    // 8 workgroups per CU of the XCD
+            case 13: hipLaunchKernelGGL((bw_read_xcd_kernel<4>), dim3(8 * 64), dim3(256), 0, 0, (const double2 *)a, c, n2, 64); break;      // 2 per CU
             default: hipMemcpyAsync(c, a, (size_t)n * 8, hipMemcpyDeviceToDevice, 0); break;
         }
     };
@@ -631,7 +650,7 @@ int pamg_bandwidth_probe(int kind, int64_t n, int reps, double *gbps)
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(a); hipFree(b); hipFree(c);
     if (err != hipSuccess) return (int)err;
-    const double bytes = (kind == 1 ? 24.0 : (kind == 6 || kind == 7) ? 8.0 : 16.0) * (double)n * reps;
+    const double bytes = (kind == 1 ? 24.0 : (kind == 6 || kind == 7 || kind == 12 || kind == 13) ? 8.0 : 16.0) * (double)n * reps;
     *gbps = ms > 0.f ? bytes / ((double)ms * 1e6) : 0.0;
     return PAMG_OK;
 }

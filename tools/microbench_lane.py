@@ -99,6 +99,14 @@ def variants_for(li, n):
             for fl in (1, 0):
                 for G in (384, 512, 768, 1024):
                     v.append((f"fast_gate{fl}_G{G}", dict(lane_flags=fl, lane_G=G)))
+    if a.exp == "x":                       # round 5: the one-XCD ticket form on the LARGE level (one XCD reads 1.3 TB/s: profiles/r05_bandwidth_one_xcd.txt)
+        v.append(("fast_auto", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
+        for L in (16, 32, 64):
+            for G in (64, 128, 256):
+                v.append((f"fast_xcd_L{L}_G{G}", dict(lane_L=L, lane_G=G, gran_xcd=1)))
+        v.append(("fast_xcd_L16_G256_nogate", dict(lane_L=16, lane_G=256, gran_xcd=1, lane_flags=0)))
+    # (exp "y", the one-XCD STATIC form -- a census at the start instead of a ticket per group, tune gran_xcd = 3 -- was measured and removed:
+    #  profiles/r05_microbench_lane_one_xcd_static_census_not_kept.json)
     if a.exp == "h":                       # line-scan form on the grid stencil
         v.append(("tile_exact", dict(gs_order=0)))
         v.append(("lines_auto", dict(gs_order=1, line_scan=1, lane_G=0, lane_flags=1)))
