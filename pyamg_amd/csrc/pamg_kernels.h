@@ -295,8 +295,19 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
             }
 #pragma unroll 2
             for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
-                const unsigned pr2 = *reinterpret_cast<const unsigned *>(a.Aj16 + q);
-                const T2 vv = *reinterpret_cast<const T2 *>(a.Ax + q);
+                unsigned pr2;
+                T2 vv;
+                if (nt) {
+                    // the operator stream past the caches' retention, so that what the L1 keeps is x: the SA-level operators of the 256^3
+                    // hierarchy 0.207 -> 0.190 ms (A1 residual), 0.226 -> 0.212 (R0), 0.232 -> 0.228 (P0), profiles/r05_microbench_sa_ops_nontemporal.json
+                    // (the same hint on row pointers / b / y: no further gain, not kept)
+                    pr2 = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(a.Aj16 + q));
+                    const T2n v2 = __builtin_nontemporal_load(reinterpret_cast<const T2n *>(a.Ax + q));
+                    vv.x = v2.x; vv.y = v2.y;
+                } else {
+                    pr2 = *reinterpret_cast<const unsigned *>(a.Aj16 + q);
+                    vv = *reinterpret_cast<const T2 *>(a.Ax + q);
+                }
                 const unsigned c0 = pr2 & 0xFFFFu, c1 = pr2 >> 16;
                 const unsigned w0 = c0 >> 14, w1 = c1 >> 14;
                 int2 cc;

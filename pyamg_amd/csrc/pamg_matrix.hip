@@ -2063,19 +2063,32 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
     // use them (the norm's partials, the shard parts)
     long long rm0[8];
     const bool masked = pamg_matrix_row_masks(A, rm0) == PAMG_OK && rm0[0] > 0;
-    for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK && !masked; ++ci) {
-        if (caps[ci] != A->cap) { A->cap = caps[ci]; st = replan(A); if (st) break; }
-        for (int fl = 0; fl < 4 && st == PAMG_OK; ++fl) {      // bit 0 non-temporal operator stream, bit 1 XCD-contiguous range order
-            A->stream_flags = (fl0 & ~3) | fl;
-            for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
-            hipEventRecord(e0, nullptr);
-            for (int r = 0; r < 6 && st == PAMG_OK; ++r) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
-            hipEventRecord(e1, nullptr);
-            hipEventSynchronize(e1);
-            float ms = 0.f;
-            hipEventElapsedTime(&ms, e0, e1);
-            if (st == PAMG_OK && ms < best_ms * 0.99f) { best_ms = ms; best_cap = A->cap; best_fl = A->stream_flags; }
+    // candidates: the LDS window (as planned / 512 entries) x the nontemporal operator stream (flag bit 0).  Two interleaved rounds, a candidate's
+    // better time counts, and anything but the plan's own setting has to win by 2 %: a single round of six launches picked the XCD-contiguous range
+    // order (bit 1: measured slower on every SA-level operator, profiles/r05_microbench_sa_ops_nontemporal.json) for R0 of the 256^3 hierarchy by noise
+    // and cost 11 % of that product (profiles/r05_c4s_kernel_roofline.txt); bit 1 is left to tune key 8
+    float cand_ms[2][2] = {{1e30f, 1e30f}, {1e30f, 1e30f}};
+    for (int round = 0; round < 2 && st == PAMG_OK && !masked; ++round) {
+        for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK; ++ci) {
+            if (caps[ci] != A->cap) { A->cap = caps[ci]; st = replan(A); if (st) break; }
+            for (int fl = 0; fl < 2 && st == PAMG_OK; ++fl) {
+                A->stream_flags = (fl0 & ~3) | fl;
+                for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
+                hipEventRecord(e0, nullptr);
+                for (int r = 0; r < 6 && st == PAMG_OK; ++r) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
+                hipEventRecord(e1, nullptr);
+                hipEventSynchronize(e1);
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (st == PAMG_OK) cand_ms[ci][fl] = std::min(cand_ms[ci][fl], ms);
+            }
         }
+    }
+    if (st == PAMG_OK && !masked) {
+        best_ms = cand_ms[0][fl0 & 1];
+        for (int ci = 0; ci < (allow_cap ? 2 : 1); ++ci)
+            for (int fl = 0; fl < 2; ++fl)
+                if (cand_ms[ci][fl] < best_ms * 0.98f) { best_ms = cand_ms[ci][fl]; best_cap = caps[ci]; best_fl = (fl0 & ~3) | fl; }
     }
     A->stream_flags = best_fl;
     if (A->cap != best_cap) { A->cap = best_cap; const int s2 = replan(A); if (st == PAMG_OK) st = s2; }
