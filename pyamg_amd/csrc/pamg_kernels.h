@@ -314,8 +314,13 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
                 cc.x = (w0 == 0 ? wb.x : w0 == 1 ? wb.y : w0 == 2 ? wb.z : wb.w) + (int)(c0 & 0x3FFFu);
                 cc.y = (w1 == 0 ? wb.x : w1 == 1 ? wb.y : w1 == 2 ? wb.z : wb.w) + (int)(c1 & 0x3FFFu);
                 const bool ok0 = q >= p0, ok1 = q + 1 < p1;
-                const T x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
-                const T x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
+                T x0, x1;
+                if (a.flags & 4) {                        // ablation: operator stream only, no gather
+                    x0 = T(cc.x); x1 = T(cc.y);
+                } else {
+                    x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
+                    x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
+                }
                 T2 pr;
                 pr.x = vv.x * x0;
                 pr.y = vv.y * x1;

@@ -899,7 +899,7 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
     if (part) {
         const int n = A->npart[part - 1];
         if (n == 0) return PAMG_OK;
-        const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2 && !(A->stream_flags & 4);
+        const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2;
         const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
         const int lds = lds_bytes(A->dtype, epi, A->cap) + (val8 ? val8_lds(A, epi) : 0);
         const bool rowg = val8 && A->use_rowg && A->max_row_len <= A->cap;
@@ -935,7 +935,7 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
     }
     int lds = lds_bytes(A->dtype, epi, A->cap);
     const int grid = (A->stream_flags & 2) ? 8 * ((A->nblk + 7) / 8) : A->nblk;
-    const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2 && !(A->stream_flags & 4);
+    const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2;
     const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
     if (val8) lds += val8_lds(A, epi);
     const bool rowg = val8 && A->use_rowg && A->max_row_len <= A->cap;

@@ -16,6 +16,7 @@ from pyamg_amd.multilevel import DeviceMatrix
 ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, nargs="+", default=[256, 256, 256])
 ap.add_argument("--tag", default="sa_ops")
+ap.add_argument("--ablate", type=int, default=0)      # flags: +4 no gather, +8 no row phase (results are wrong by design)
 a = ap.parse_args()
 A = pyamg.gallery.poisson(tuple(a.grid), format="csr")
 np.random.seed(1)
@@ -31,8 +32,8 @@ for name, op, epi in ops:
     x = capi.DeviceArray.from_host(rng.rand(n)); b = capi.DeviceArray.from_host(rng.rand(m)); y = capi.DeviceArray(m, np.float64)
     ref = None
     by = 12 * op.nnz + 4 * (m + 1) + 8 * n + 8 * m + (8 * m if epi == capi.SPMV_RESID else 0)
-    for cap in (1536, 1024, 2048, 3072):
-        for fl in (0, 1, 2, 3):
+    for cap in ((1536,) if a.ablate else (1536, 1024, 2048, 3072)):
+        for fl in ((1, 5, 9, 13) if a.ablate else (0, 1, 2, 3)):
             dA.tune(lds_entries=cap, stream_flags=fl)
             kw = dict(b=b) if epi == capi.SPMV_RESID else {}
             for _ in range(3):
