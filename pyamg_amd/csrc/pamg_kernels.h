@@ -293,7 +293,7 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
                 }
                 return;
             }
-#pragma unroll 2
+#pragma unroll 4
             for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
                 unsigned pr2;
                 T2 vv;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
             }
             return;
         }
-#pragma unroll 2
+#pragma unroll 4
         for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
             int2 cc;
             T2 vv;
@@ -379,7 +379,8 @@ __device__ __forceinline__ RowPre<T> row_prefetch(const StreamArgs<T> &a, int r)
     RowPre<T> q;
     q.lo = a.Ap[r];
     q.hi = a.Ap[r + 1];
-    q.row = EpiTraits<EPI>::perm ? a.rid[r] : r;
+    if constexpr (EpiTraits<EPI>::perm) q.row = a.rid[r];
+    else q.row = a.rperm ? a.rperm[r] : r;                      // (a row-ordered twin: rows stored aggregate by aggregate)
     q.pos = r;
     q.b = q.y = q.xo = q.d = T(0);
     if constexpr (EPI >= EPI_JACOBI) q.d = a.diag[r];           // precomputed diagonal of stored row r

@@ -809,6 +809,7 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.Aj = A->d_Aj;
     a.Ax = (const T *)A->d_Ax;
     a.rid = A->d_rowid;
+    a.rperm = A->d_rowperm;
     a.diag = (const T *)A->d_diag;
     a.x = (const T *)x;
     a.xs = nullptr;
@@ -887,6 +888,10 @@ int matrix_split_ranges(pamg_matrix_s *A, int64_t n_owned_cols)
 int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void *y, double c,
                   double omega, double *partial, hipStream_t s)
 {
+    // products of an operator with a row-ordered twin run on the twin: same rows, same sums, stored aggregate by aggregate so that the rows of
+    // a range share their columns (the norm keeps the operator's own ranges: its partial sums, hence its bits, stay what they were)
+    if (A->prod && A->use_prod && (epi == EPI_SET || epi == EPI_ACC || epi == EPI_RESID || epi == EPI_AXPBY || epi == EPI_ACC_AXPBY))
+        return stream_launch_part(A->prod, 0, epi, x, b, y, c, omega, partial, s);
     return stream_launch_part(A, 0, epi, x, b, y, c, omega, partial, s);
 }
 
@@ -1927,7 +1932,55 @@ int pamg_matrix_destroy(pamg_matrix_t A)
     hipFree(A->d_part[0]); hipFree(A->d_part[1]);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     for (int k = 0; k < 4; ++k) pamg::free_line_schedule(A->ls[k]);
+    if (A->prod) pamg_matrix_destroy(A->prod);
+    hipFree(A->d_rowperm);
     delete A;
+    return PAMG_OK;
+}
+
+// A row-ordered twin for the products: `order[r]` = the operator's row stored as row r of the twin.  Rows of a product are
+// independent, so any order of the ROWS computes the same bits; an order that keeps rows of one aggregate together lets the rows of a range share
+// their columns (the real A1 of the 256^3 hierarchy: 1 021 -> 320 distinct columns per 1 536 entries).  The operator itself is untouched (sweeps,
+// Jacobi, the norm and the shard parts keep running on it); y = A x, y += A x, r = b - A x, h = c r + A h go to the twin.
+int pamg_matrix_set_row_order(pamg_matrix_t A, const int32_t *order)
+{
+    if (!A) return PAMG_E_ARG;
+    if (A->borrowed > 0) return PAMG_E_STATE;
+    if (A->prod) { A->bytes -= A->prod->bytes; pamg_matrix_destroy(A->prod); A->prod = nullptr; }
+    if (!order) return PAMG_OK;                                    // nullptr: drop the twin
+    if (A->R != 1 || A->C != 1 || A->d_rowid || A->d_rowperm || A->nrows == 0 || A->d_Ax8) return PAMG_OK;   // block / subset / value-coded operators: nothing to gain
+    const int n = (int)A->nrows;
+    {
+        std::vector<unsigned char> seen((size_t)n, 0);
+        for (int r = 0; r < n; ++r) {
+            const int i = order[r];
+            if (i < 0 || i >= n || seen[(size_t)i]) return PAMG_E_ARG;
+            seen[(size_t)i] = 1;
+        }
+    }
+    pamg::PhaseTimer pt_("set_row_order", A->nnz);
+    const size_t ts = pamg::tsize(A->dtype);
+    std::vector<unsigned char> hAx((size_t)A->nnz * ts), Ax2((size_t)A->nnz * ts);
+    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
+    std::vector<int> Ap2((size_t)n + 1, 0), Aj2((size_t)A->nnz);
+    const int *Ap = A->h_Ap.data(), *Aj = A->h_Aj.data();
+    for (int r = 0; r < n; ++r) Ap2[(size_t)r + 1] = Ap2[(size_t)r] + (Ap[order[r] + 1] - Ap[order[r]]);
+    parallel_rows(n, [&](int lo, int hi) {
+        for (int r = lo; r < hi; ++r) {
+            const int i = order[r], len = Ap[i + 1] - Ap[i];
+            std::memcpy(&Aj2[(size_t)Ap2[(size_t)r]], Aj + Ap[i], (size_t)len * sizeof(int));
+            std::memcpy(&Ax2[(size_t)Ap2[(size_t)r] * ts], &hAx[(size_t)Ap[i] * ts], (size_t)len * ts);
+        }
+    });
+    pamg_matrix_t T = nullptr;
+    PAMG_TRY(pamg_matrix_create(&T, A->dtype, PAMG_CSR, n, (int)A->ncols, 1, 1, Ap2.data(), Aj2.data(), Ax2.data()));
+    if (T->d_Ax8) { pamg_matrix_destroy(T); return PAMG_OK; }
+    if (getenv("PAMG_TWIN_DEBUG")) fprintf(stderr, "[twin] rows %d nnz %lld 16-bit codes: operator %d twin %d, ranges %d / %d\n", n, (long long)A->nnz, A->d_Aj16 != nullptr, T->d_Aj16 != nullptr, A->nblk, T->nblk);
+    if (hipMalloc((void **)&T->d_rowperm, (size_t)n * sizeof(int) + 64) != hipSuccess) { pamg_matrix_destroy(T); return PAMG_E_ALLOC; }
+    if (hipMemcpy(T->d_rowperm, order, (size_t)n * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { pamg_matrix_destroy(T); return PAMG_E_ALLOC; }
+    T->bytes += (size_t)n * sizeof(int);
+    A->prod = T;
+    A->bytes += T->bytes;
     return PAMG_OK;
 }
 
@@ -2016,6 +2069,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
             return PAMG_OK;
         case 31: if (value != 2 && value != 4 && value != 8) return PAMG_E_ARG; A->rowmask_kz = value; return PAMG_OK;
         case 32: if (value < 0 || value > 7) return PAMG_E_ARG; A->rowmask_flags = value; return PAMG_OK;
+        case 33: if (value < 0 || value > 1) return PAMG_E_ARG; A->use_prod = value; return PAMG_OK;
         case 28: if (value < 0 || value > 15 || (value & 6)) return PAMG_E_ARG; A->lane_flags = value; return PAMG_OK;      // bits 1, 2: retired (slab form, old values through the L1)
         default: return PAMG_E_ARG;
     }
@@ -2046,6 +2100,7 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
 {
     if (!A) return PAMG_E_ARG;
     if (A->borrowed > 0) return PAMG_E_STATE;
+    if (A->prod) return pamg_matrix_autotune(A->prod, allow_cap);      // the products run on the twin: its window / streaming policy are what counts
     if (A->nnz < 4000000 || A->npl != 2) return PAMG_OK;
     const size_t ts = tsize(A->dtype);
     void *x = nullptr, *y = nullptr;
