@@ -357,16 +357,8 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * dependency level away; bit 3: the same in the line scan, off; bits 1, 2 retired with the slab form in round 5),
  * 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled AND
  * enough lines run side by side to beat the lane form by the planner's estimate (3-D grids; not 2-D grids in natural order); 2 = wherever it applies.
- * 33 = 0: the products ignore a row-ordered twin (pamg_matrix_set_row_order) and run on the operator as stored (default 1).
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
-/* Speed only: a row-ordered twin of a scalar operator for its products.  order[r] (HOST, a permutation of 0 .. rows-1) = the operator's row kept as row r of
- * the twin; y = A x, y += A x, r = b - A x and the Horner steps h = c r + A h then run on the twin (rows of a product are independent: the same bits in
- * any row order), everything else -- sweeps, Jacobi, the norm, the shard parts -- on the operator as stored.  Meant for the SA-level operators, whose rows
- * the reference numbers in short runs: ordered aggregate by aggregate the rows of a row range share their columns (multilevel.py derives the order from
- * the prolongator; tune key 33 = 0 switches back for comparison).  order = NULL drops the twin.  Block, row-subset and value-coded operators: no-op.
- * (No counterpart in the reference: SciPy's csr_matvec walks the rows as stored, multilevel.py:612-660.) */
-int pamg_matrix_set_row_order(pamg_matrix_t A, const int32_t *order);
 /* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes
  * (tune key 21), 0 when they stream the values themselves. */
 int pamg_matrix_value_codes(pamg_matrix_t A, int *n_values);

@@ -128,7 +128,6 @@ def _declare(lib):
     f("pamg_matrix_tile_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_lane_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_kz_info", _vp, _i, P(C.c_int64))
-    f("pamg_matrix_set_row_order", _vp, _vp)
     f("pamg_matrix_line_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_lane_profile", _vp, _i, _vp, C.c_int64, P(C.c_int64))
     f("pamg_matrix_autotune", _vp, _i)

@@ -63,7 +63,6 @@ struct StreamArgs {
     const int *Aj;
     const T *Ax;
     const int *rid;      // original row id of stored row r (permuted copies) or nullptr
-    const int *rperm;    // whole-operator launches of a row-ordered twin (pamg_matrix_set_row_order): original row of stored row r, or nullptr
     const T *diag;       // diagonal value of stored row r (last stored a_ii; 0 = none/zero)
     const T *x;          // gather source
     T *xs;               // granular sweep: hand-off buffer (sentinel = not published yet)
@@ -222,9 +221,6 @@ struct pamg_matrix_s {
     int64_t part_row0[2] = {-1, -1}, part_row1[2] = {-1, -1};   //   rows [row0, row1) of a part whose ranges are consecutive (else -1)
     int4 *d_blkmeta = nullptr;
     double *d_partial = nullptr;     // nblk doubles (sum-of-squares partials)
-    pamg_matrix_s *prod = nullptr;   // row-ordered twin for the products y = A x, y += A x, r = b - A x, h = c r + A h (pamg_matrix_set_row_order); owned
-    int *d_rowperm = nullptr;        //   of a twin: original row of stored row r
-    int use_prod = 1;                //   tune key 33: 0 = the products run on the operator as stored
     pamg::GsSchedule *gs[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd, bwd, 2 custom
     pamg::LineSchedule *ls[4] = {nullptr, nullptr, nullptr, nullptr};  // Kaczmarz sweeps over this operator's rows
     size_t bytes = 0;

@@ -293,14 +293,14 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
                 }
                 return;
             }
-#pragma unroll 4
+#pragma unroll 2
             for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
                 unsigned pr2;
                 T2 vv;
                 if (nt) {
-                    // the operator stream past the caches' retention, so that what the L1 keeps is x: the SA-level operators of the 256^3
-                    // hierarchy 0.207 -> 0.190 ms (A1 residual), 0.226 -> 0.212 (R0), 0.232 -> 0.228 (P0), profiles/r05_microbench_sa_ops_nontemporal.json
-                    // (the same hint on row pointers / b / y: no further gain, not kept)
+                    // the operator stream past the caches' retention, so that what the L1 keeps is x: 1 - 8 % on the SA-level operators of the 256^3
+                    // hierarchy depending on the run (profiles/r05_microbench_sa_ops_nontemporal.json, r05_microbench_sa_ops_unroll_ab.txt); the autotune
+                    // decides per operator (the same hint on row pointers / b / y: no further gain, not kept)
                     pr2 = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(a.Aj16 + q));
                     const T2n v2 = __builtin_nontemporal_load(reinterpret_cast<const T2n *>(a.Ax + q));
                     vv.x = v2.x; vv.y = v2.y;
@@ -329,7 +329,7 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
             }
             return;
         }
-#pragma unroll 4
+#pragma unroll 2
         for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
             int2 cc;
             T2 vv;
@@ -379,8 +379,7 @@ __device__ __forceinline__ RowPre<T> row_prefetch(const StreamArgs<T> &a, int r)
     RowPre<T> q;
     q.lo = a.Ap[r];
     q.hi = a.Ap[r + 1];
-    if constexpr (EpiTraits<EPI>::perm) q.row = a.rid[r];
-    else q.row = a.rperm ? a.rperm[r] : r;                      // (a row-ordered twin: rows stored aggregate by aggregate)
+    q.row = EpiTraits<EPI>::perm ? a.rid[r] : r;
     q.pos = r;
     q.b = q.y = q.xo = q.d = T(0);
     if constexpr (EPI >= EPI_JACOBI) q.d = a.diag[r];           // precomputed diagonal of stored row r

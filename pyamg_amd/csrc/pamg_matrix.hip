@@ -809,7 +809,6 @@ StreamArgs<T> base_args(const pamg_matrix_s *A, const void *x, const void *b, vo
     a.Aj = A->d_Aj;
     a.Ax = (const T *)A->d_Ax;
     a.rid = A->d_rowid;
-    a.rperm = A->d_rowperm;
     a.diag = (const T *)A->d_diag;
     a.x = (const T *)x;
     a.xs = nullptr;
@@ -888,10 +887,6 @@ int matrix_split_ranges(pamg_matrix_s *A, int64_t n_owned_cols)
 int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void *y, double c,
                   double omega, double *partial, hipStream_t s)
 {
-    // products of an operator with a row-ordered twin run on the twin: same rows, same sums, stored aggregate by aggregate so that the rows of
-    // a range share their columns (the norm keeps the operator's own ranges: its partial sums, hence its bits, stay what they were)
-    if (A->prod && A->use_prod && (epi == EPI_SET || epi == EPI_ACC || epi == EPI_RESID || epi == EPI_AXPBY || epi == EPI_ACC_AXPBY))
-        return stream_launch_part(A->prod, 0, epi, x, b, y, c, omega, partial, s);
     return stream_launch_part(A, 0, epi, x, b, y, c, omega, partial, s);
 }
 
@@ -1932,55 +1927,7 @@ int pamg_matrix_destroy(pamg_matrix_t A)
     hipFree(A->d_part[0]); hipFree(A->d_part[1]);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     for (int k = 0; k < 4; ++k) pamg::free_line_schedule(A->ls[k]);
-    if (A->prod) pamg_matrix_destroy(A->prod);
-    hipFree(A->d_rowperm);
     delete A;
-    return PAMG_OK;
-}
-
-// A row-ordered twin for the products: `order[r]` = the operator's row stored as row r of the twin.  Rows of a product are
-// independent, so any order of the ROWS computes the same bits; an order that keeps rows of one aggregate together lets the rows of a range share
-// their columns (the real A1 of the 256^3 hierarchy: 1 021 -> 320 distinct columns per 1 536 entries).  The operator itself is untouched (sweeps,
-// Jacobi, the norm and the shard parts keep running on it); y = A x, y += A x, r = b - A x, h = c r + A h go to the twin.
-int pamg_matrix_set_row_order(pamg_matrix_t A, const int32_t *order)
-{
-    if (!A) return PAMG_E_ARG;
-    if (A->borrowed > 0) return PAMG_E_STATE;
-    if (A->prod) { A->bytes -= A->prod->bytes; pamg_matrix_destroy(A->prod); A->prod = nullptr; }
-    if (!order) return PAMG_OK;                                    // nullptr: drop the twin
-    if (A->R != 1 || A->C != 1 || A->d_rowid || A->d_rowperm || A->nrows == 0 || A->d_Ax8) return PAMG_OK;   // block / subset / value-coded operators: nothing to gain
-    const int n = (int)A->nrows;
-    {
-        std::vector<unsigned char> seen((size_t)n, 0);
-        for (int r = 0; r < n; ++r) {
-            const int i = order[r];
-            if (i < 0 || i >= n || seen[(size_t)i]) return PAMG_E_ARG;
-            seen[(size_t)i] = 1;
-        }
-    }
-    pamg::PhaseTimer pt_("set_row_order", A->nnz);
-    const size_t ts = pamg::tsize(A->dtype);
-    std::vector<unsigned char> hAx((size_t)A->nnz * ts), Ax2((size_t)A->nnz * ts);
-    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * ts, hipMemcpyDeviceToHost));
-    std::vector<int> Ap2((size_t)n + 1, 0), Aj2((size_t)A->nnz);
-    const int *Ap = A->h_Ap.data(), *Aj = A->h_Aj.data();
-    for (int r = 0; r < n; ++r) Ap2[(size_t)r + 1] = Ap2[(size_t)r] + (Ap[order[r] + 1] - Ap[order[r]]);
-    parallel_rows(n, [&](int lo, int hi) {
-        for (int r = lo; r < hi; ++r) {
-            const int i = order[r], len = Ap[i + 1] - Ap[i];
-            std::memcpy(&Aj2[(size_t)Ap2[(size_t)r]], Aj + Ap[i], (size_t)len * sizeof(int));
-            std::memcpy(&Ax2[(size_t)Ap2[(size_t)r] * ts], &hAx[(size_t)Ap[i] * ts], (size_t)len * ts);
-        }
-    });
-    pamg_matrix_t T = nullptr;
-    PAMG_TRY(pamg_matrix_create(&T, A->dtype, PAMG_CSR, n, (int)A->ncols, 1, 1, Ap2.data(), Aj2.data(), Ax2.data()));
-    if (T->d_Ax8) { pamg_matrix_destroy(T); return PAMG_OK; }
-    if (getenv("PAMG_TWIN_DEBUG")) fprintf(stderr, "[twin] rows %d nnz %lld 16-bit codes: operator %d twin %d, ranges %d / %d\n", n, (long long)A->nnz, A->d_Aj16 != nullptr, T->d_Aj16 != nullptr, A->nblk, T->nblk);
-    if (hipMalloc((void **)&T->d_rowperm, (size_t)n * sizeof(int) + 64) != hipSuccess) { pamg_matrix_destroy(T); return PAMG_E_ALLOC; }
-    if (hipMemcpy(T->d_rowperm, order, (size_t)n * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { pamg_matrix_destroy(T); return PAMG_E_ALLOC; }
-    T->bytes += (size_t)n * sizeof(int);
-    A->prod = T;
-    A->bytes += T->bytes;
     return PAMG_OK;
 }
 
@@ -2069,7 +2016,6 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
             return PAMG_OK;
         case 31: if (value != 2 && value != 4 && value != 8) return PAMG_E_ARG; A->rowmask_kz = value; return PAMG_OK;
         case 32: if (value < 0 || value > 7) return PAMG_E_ARG; A->rowmask_flags = value; return PAMG_OK;
-        case 33: if (value < 0 || value > 1) return PAMG_E_ARG; A->use_prod = value; return PAMG_OK;
         case 28: if (value < 0 || value > 15 || (value & 6)) return PAMG_E_ARG; A->lane_flags = value; return PAMG_OK;      // bits 1, 2: retired (slab form, old values through the L1)
         default: return PAMG_E_ARG;
     }
@@ -2100,7 +2046,6 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
 {
     if (!A) return PAMG_E_ARG;
     if (A->borrowed > 0) return PAMG_E_STATE;
-    if (A->prod) return pamg_matrix_autotune(A->prod, allow_cap);      // the products run on the twin: its window / streaming policy are what counts
     if (A->nnz < 4000000 || A->npl != 2) return PAMG_OK;
     const size_t ts = tsize(A->dtype);
     void *x = nullptr, *y = nullptr;
@@ -2118,32 +2063,54 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
     // use them (the norm's partials, the shard parts)
     long long rm0[8];
     const bool masked = pamg_matrix_row_masks(A, rm0) == PAMG_OK && rm0[0] > 0;
-    // candidates: the LDS window (as planned / 512 entries) x the nontemporal operator stream (flag bit 0).  Two interleaved rounds, a candidate's
-    // better time counts, and anything but the plan's own setting has to win by 2 %: a single round of six launches picked the XCD-contiguous range
-    // order (bit 1: measured slower on every SA-level operator, profiles/r05_microbench_sa_ops_nontemporal.json) for R0 of the 256^3 hierarchy by noise
-    // and cost 11 % of that product (profiles/r05_c4s_kernel_roofline.txt); bit 1 is left to tune key 8
-    float cand_ms[2][2] = {{1e30f, 1e30f}, {1e30f, 1e30f}};
+    // candidates: the LDS window (as planned / 512 entries) x the nontemporal operator stream (flag bit 0) x the 16-bit column codes on / off
+    // (operators without value codes: fewer bytes, but half-width requests -- the SA-level operators of the 256^3 hierarchy, profiles/
+    // r05_microbench_sa_ops_wide_codes_vs_32bit_not_kept.json: P0 0.219 ms on codes, 0.199 on 32-bit columns, R0 0.204 against 0.211).  Two interleaved
+    // rounds, a candidate's better time counts, and anything but the plan's own setting has to win by 2 %: a single round of six launches picked the
+    // XCD-contiguous range order (bit 1: measured slower on every SA-level operator, r05_microbench_sa_ops_nontemporal.json) for R0 by noise and cost
+    // 11 % of that product (r05_c4s_kernel_roofline.txt); bit 1 is left to tune key 8
+    const int idx0 = A->use_idx16;
+    const int nidx = (A->d_Aj16 && !A->d_Ax8 && idx0) ? 2 : 1;
+    // timed on what the cycle runs most: r = b - A x for square operators (three vectors in flight: the Horner steps and the residual), y = A x for
+    // the transfer operators -- on A1 of the 256^3 hierarchy the nontemporal stream won up to 8 % on the residual and nothing on y = A x
+    const bool square = A->nrows == A->ncols;
+    const int probe = square ? EPI_RESID : EPI_SET;
+    void *pb = nullptr;
+    if (square) {
+        if (hipMalloc(&pb, (size_t)(A->nrows + 8) * ts) != hipSuccess) { hipFree(x); hipFree(y); hipEventDestroy(e0); hipEventDestroy(e1); return (int)hipErrorOutOfMemory; }
+        hipMemset(pb, 0, (size_t)(A->nrows + 8) * ts);
+    }
+    float cand_ms[2][2][2];
+    for (int q = 0; q < 8; ++q) (&cand_ms[0][0][0])[q] = 1e30f;
     for (int round = 0; round < 2 && st == PAMG_OK && !masked; ++round) {
         for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK; ++ci) {
             if (caps[ci] != A->cap) { A->cap = caps[ci]; st = replan(A); if (st) break; }
-            for (int fl = 0; fl < 2 && st == PAMG_OK; ++fl) {
-                A->stream_flags = (fl0 & ~3) | fl;
-                for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
-                hipEventRecord(e0, nullptr);
-                for (int r = 0; r < 6 && st == PAMG_OK; ++r) st = stream_launch(A, EPI_SET, x, nullptr, y, 0.0, 0.0, nullptr, nullptr);
-                hipEventRecord(e1, nullptr);
-                hipEventSynchronize(e1);
-                float ms = 0.f;
-                hipEventElapsedTime(&ms, e0, e1);
-                if (st == PAMG_OK) cand_ms[ci][fl] = std::min(cand_ms[ci][fl], ms);
+            for (int ix = 0; ix < nidx && st == PAMG_OK; ++ix) {
+                A->use_idx16 = ix == 0 ? idx0 : 0;
+                for (int fl = 0; fl < 2 && st == PAMG_OK; ++fl) {
+                    A->stream_flags = (fl0 & ~3) | fl;
+                    for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, probe, x, pb, y, 0.0, 0.0, nullptr, nullptr);
+                    hipEventRecord(e0, nullptr);
+                    for (int r = 0; r < 6 && st == PAMG_OK; ++r) st = stream_launch(A, probe, x, pb, y, 0.0, 0.0, nullptr, nullptr);
+                    hipEventRecord(e1, nullptr);
+                    hipEventSynchronize(e1);
+                    float ms = 0.f;
+                    hipEventElapsedTime(&ms, e0, e1);
+                    if (st == PAMG_OK) cand_ms[ci][ix][fl] = std::min(cand_ms[ci][ix][fl], ms);
+                }
             }
         }
     }
+    A->use_idx16 = idx0;
+    hipFree(pb);
     if (st == PAMG_OK && !masked) {
-        best_ms = cand_ms[0][fl0 & 1];
+        best_ms = cand_ms[0][0][fl0 & 1];
+        int best_ix = 0;
         for (int ci = 0; ci < (allow_cap ? 2 : 1); ++ci)
-            for (int fl = 0; fl < 2; ++fl)
-                if (cand_ms[ci][fl] < best_ms * 0.98f) { best_ms = cand_ms[ci][fl]; best_cap = caps[ci]; best_fl = (fl0 & ~3) | fl; }
+            for (int ix = 0; ix < nidx; ++ix)
+                for (int fl = 0; fl < 2; ++fl)
+                    if (cand_ms[ci][ix][fl] < best_ms * 0.98f) { best_ms = cand_ms[ci][ix][fl]; best_cap = caps[ci]; best_fl = (fl0 & ~3) | fl; best_ix = ix; }
+        if (best_ix == 1) A->use_idx16 = 0;
     }
     A->stream_flags = best_fl;
     if (A->cap != best_cap) { A->cap = best_cap; const int s2 = replan(A); if (st == PAMG_OK) st = s2; }

@@ -156,14 +156,14 @@ class DeviceMatrix:
 
     def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, gs_prof=None,
              tile_G=None, tile_W=None, tile_cap=None, tile_default=None, tile_D=None, tile_Q=None, tile_part=None, idx16=None, gs_cap=None, val8=None, rowgather=None, rowpat=None,
-             gs_order=None, lane_L=None, lane_G=None, lane_wide=None, lane_flags=None, line_scan=None, rowmask_kz=None, rowmask_flags=None, row_order=None):
+             gs_order=None, lane_L=None, lane_G=None, lane_wide=None, lane_flags=None, line_scan=None, rowmask_kz=None, rowmask_flags=None):
         """Speed-only knobs (every setting computes the same bits) -- except gs_order: 0 = order-exact row sums (the reference's
         bits), 1 = fast order (lane-parallel row sums, same sweep order, agrees to rounding).  Refused (PAMG_E_STATE) once a solver holds the
         operator: captured graphs point into the plans these calls rebuild."""
         lib = capi.lib()
         for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (11, gs_prof),
                        (12, tile_G), (13, tile_W), (14, tile_cap), (15, tile_default), (16, tile_D), (17, tile_Q), (18, tile_part), (19, idx16), (20, gs_cap), (21, val8), (22, rowgather), (23, rowpat),
-                       (24, gs_order), (25, lane_L), (26, lane_G), (27, lane_wide), (28, lane_flags), (30, line_scan), (31, rowmask_kz), (32, rowmask_flags), (33, row_order)):
+                       (24, gs_order), (25, lane_L), (26, lane_G), (27, lane_wide), (28, lane_flags), (30, line_scan), (31, rowmask_kz), (32, rowmask_flags)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 
@@ -210,14 +210,6 @@ class DeviceMatrix:
                                                              capi.SWEEP[sweep], int(iterations), stream),
                    "pamg_matrix_block_gauss_seidel")
 
-    def set_row_order(self, order):
-        """speed only: a row-ordered twin for the products (pamg_matrix_set_row_order); order = None drops it"""
-        if order is None:
-            capi.check(capi.lib().pamg_matrix_set_row_order(self.handle, None), "pamg_matrix_set_row_order")
-            return
-        o = np.ascontiguousarray(order, dtype=np.int32)
-        capi.check(capi.lib().pamg_matrix_set_row_order(self.handle, C.c_void_p(o.ctypes.data)), "pamg_matrix_set_row_order")
-
     def free(self):
         if getattr(self, "handle", None):
             try:
@@ -228,40 +220,6 @@ class DeviceMatrix:
 
     def __del__(self):
         self.free()
-
-
-def _aggregate_row_order(Pop):
-    """Row order for the products of the operators whose ROWS are the rows of the prolongator `Pop` (A of its level, R of the level above): rows
-    sorted by the aggregate they belong to -- the column of the largest |entry| of their row of P (the tentative prolongator has ONE entry per row,
-    its aggregate, aggregate.py:280-431; the smoothed one keeps it as the dominant entry) -- stable, so an aggregate's rows keep their order.
-    Speed only: pamg_matrix_set_row_order.  None if P has blocks."""
-    if tuple(Pop.blocksize) != (1, 1):
-        return None
-    indptr = np.asarray(Pop.indptr)
-    n = indptr.size - 1
-    lens = np.diff(indptr)
-    if n == 0 or Pop.indices.size == 0:
-        return None
-    a = np.abs(np.asarray(Pop.data).ravel())
-    ne = lens > 0
-    mrow = np.zeros(n, dtype=a.dtype)
-    mrow[ne] = np.maximum.reduceat(a, indptr[:-1][ne])
-    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
-    pos = np.flatnonzero(a >= mrow[rows])
-    r_of = rows[pos]
-    first = np.ones(pos.size, dtype=bool)
-    first[1:] = r_of[1:] != r_of[:-1]
-    agg = np.full(n, -1, dtype=np.int64)
-    agg[r_of[first]] = np.asarray(Pop.indices)[pos[first]]
-    # aggregates in the order of their FIRST row (not of their number on the coarse level): the row ranges the chip works on at one time then
-    # still cover one neighbourhood of the index space -- x stays in the L2s as in the stored order -- while each range is one or two aggregates
-    by_agg = np.argsort(agg, kind="stable")
-    sa = agg[by_agg]
-    start = np.ones(n, dtype=bool)
-    start[1:] = sa[1:] != sa[:-1]
-    first_row = np.empty(int(sa.max()) + 2, dtype=np.int64)
-    first_row[sa[start] + 1] = by_agg[start]                       # (+ 1: rows without an aggregate, -1, come first)
-    return np.argsort(first_row[agg + 1], kind="stable").astype(np.int32)
 
 
 def _set_smoother(lib, S, level, which, s: Optional[SmootherSpec], dtype, aux, fast=False):
@@ -432,23 +390,11 @@ class DeviceMultilevelSolver:
             shipped = [ship(op) for op in ops]
         self._mats = list(shipped)
         shipped = iter(shipped)
-        prev_R = None
         for i, L in enumerate(self.spec.levels):
             A = next(shipped)
             P = next(shipped) if i < nlev - 1 else None
             R = next(shipped) if i < nlev - 1 else None
             self.A.append(A)
-            # products of the big SA-level operators on row-ordered twins (rows aggregate by aggregate: the rows of a row range then share their
-            # columns; speed only, the same bits).  A_i and R_{i-1} have the rows of P_i.  PAMG_ROW_ORDER=0 switches it off.
-            if os.environ.get("PAMG_ROW_ORDER", "1") != "0" and i >= 1 and P is not None and self.dtype == np.float64:
-                min_nnz = int(os.environ.get("PAMG_ROW_ORDER_MIN_NNZ", "4000000"))
-                targets = [m for m, op in ((A, L.A), (prev_R, self.spec.levels[i - 1].R)) if m is not None and op.nnz >= min_nnz and tuple(op.blocksize) == (1, 1)]
-                if targets:
-                    ro = _aggregate_row_order(L.P)
-                    if ro is not None:
-                        for m in targets:
-                            m.set_row_order(ro)
-            prev_R = R
             if autotune:
                 # speed-only choice of LDS window / streaming policy per large operator; the window of
                 # an operator that carries order-exact sweeps is left alone (its level schedules and

@@ -709,66 +709,6 @@ def test_block_gauss_seidel_fast_order_agrees_to_rounding():
         dM.free()
 
 
-def test_row_ordered_twin_products_are_bit_identical():
-    """pamg_matrix_set_row_order: the products of an operator with a row-ordered twin (rows stored in another order, original row ids beside them) are
-    the operator's own, bit for bit, in every whole-operator form the cycle uses (y = A x, y += A x, r = b - A x, h = c r + A h, x += c r + A h) --
-    a random order, the aggregate order multilevel.py derives from a prolongator, a rectangular operator; tune key 33 = 0 runs the operator as
-    stored; a non-permutation is refused; block operators ignore the call; sweeps and Jacobi keep running on the operator itself."""
-    from oracle import oracle as orc
-    from tools.problems import poisson_csr
-    from pyamg_amd.multilevel import _aggregate_row_order
-    rng = np.random.RandomState(41)
-    G = poisson_csr((24, 20, 18))
-    S = sp.csr_array(((G @ G) != 0).astype(float))
-    S.data[:] = rng.rand(S.nnz) - 0.3
-    S = sp.csr_array(S + sp.diags_array(np.full(S.shape[0], 9.0)))
-    S.sort_indices()
-    n = S.shape[0]
-    agg_of = rng.randint(0, n // 20, size=n)
-    Pp = sp.csr_array((rng.rand(n) + 0.5, (np.arange(n), agg_of)), shape=(n, n // 20))
-    Rt = sp.csr_array(sp.random(n // 3, n, density=0.004, random_state=rng, format="csr") + sp.csr_array((np.ones(n // 3), (np.arange(n // 3), np.arange(n // 3))), shape=(n // 3, n)))
-    Rt.sort_indices()
-    def products(dM, m, ncol):
-        x = capi.DeviceArray.from_host(xh[:ncol]); b = capi.DeviceArray.from_host(bh[:m])
-        out = []
-        for mode, kw in ((capi.SPMV_SET, {}), (capi.SPMV_ACC, {}), (capi.SPMV_RESID, dict(b=b)), (capi.SPMV_AXPBY, dict(b=b, c=0.37)), (capi.SPMV_ACC_AXPBY, dict(b=b, c=-1.3))):
-            y = capi.DeviceArray.from_host(yh[:m])
-            dM.spmv(mode, x, y, **kw)
-            out.append(y.download())
-        return out
-    xh, bh, yh = rng.rand(n), rng.rand(n), rng.rand(n)
-    for M, orders in ((S, (rng.permutation(n), _aggregate_row_order(sparse_op(Pp)))), (Rt, (rng.permutation(Rt.shape[0]),))):
-        m, ncol = M.shape
-        dM = DeviceMatrix(sparse_op(M))
-        ref = products(dM, m, ncol)
-        assert np.array_equal(ref[0], M @ xh[:ncol]) or np.allclose(ref[0], M @ xh[:ncol], rtol=1e-13)
-        for order in orders:
-            dM.set_row_order(order)
-            got = products(dM, m, ncol)
-            assert all(np.array_equal(a_, b_) for a_, b_ in zip(ref, got))
-            dM.tune(row_order=0)
-            assert all(np.array_equal(a_, b_) for a_, b_ in zip(ref, products(dM, m, ncol)))
-            dM.tune(row_order=1)
-        bad = np.arange(m, dtype=np.int32); bad[3] = bad[4]
-        with pytest.raises(capi.PamgError):
-            dM.set_row_order(bad)
-        if m == ncol:                                              # the operator itself: sweeps and Jacobi untouched by the twin
-            x1 = xh.copy(); orc.relax_gauss_seidel(sparse_op(M), x1, bh, 1, "symmetric")
-            dx = capi.DeviceArray.from_host(xh); db = capi.DeviceArray.from_host(bh)
-            dM.gauss_seidel(dx, db, sweep="symmetric")
-            assert np.array_equal(dx.download(), x1)
-        dM.set_row_order(None)
-        assert all(np.array_equal(a_, b_) for a_, b_ in zip(ref, products(dM, m, ncol)))
-        dM.free()
-    B = sp.kron(poisson_csr((6, 5, 4)), np.array([[2.0, 0.5], [0.25, 3.0]]), format="bsr")
-    dB = DeviceMatrix(sparse_op(sp.bsr_array(B)))
-    dB.set_row_order(rng.permutation(B.shape[0]))                    # block operator: ignored
-    xb = capi.DeviceArray.from_host(xh[:B.shape[0]]); yb = capi.DeviceArray(B.shape[0], np.float64)
-    dB.spmv(capi.SPMV_SET, xb, yb)
-    assert np.allclose(yb.download(), B @ xh[:B.shape[0]], rtol=1e-13)
-    dB.free()
-
-
 def test_indexed_jacobi_bit_exact():
     """jacobi_indexed (Layer 1, the amg_core twin) and the cf_jacobi / fc_jacobi wrappers (resident row-subset
     operators, csr_stream_kernel<JACOBI_IDX> + scatter) vs the reference's outputs in kernels_indexed.npz --

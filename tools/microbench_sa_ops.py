@@ -16,7 +16,7 @@ from pyamg_amd.multilevel import DeviceMatrix
 ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, nargs="+", default=[256, 256, 256])
 ap.add_argument("--tag", default="sa_ops")
-ap.add_argument("--row-order", type=int, default=0)   # 1: A1 / R0 with the row-ordered twin (rows aggregate by aggregate) against the operator as stored
+ap.add_argument("--idx16", type=int, default=0)       # 1: 16-bit column codes (where the plan has them) against 32-bit columns (flags + 16 here = tune idx16 0)
 ap.add_argument("--ablate", type=int, default=0)      # flags: +4 no gather, +8 no row phase (results are wrong by design)
 a = ap.parse_args()
 A = pyamg.gallery.poisson(tuple(a.grid), format="csr")
@@ -26,43 +26,6 @@ with device_setup(pyamg):
 spec = extract(ml)
 ops = [("A1", spec.levels[1].A, capi.SPMV_RESID), ("P0", spec.levels[0].P, capi.SPMV_SET), ("R0", spec.levels[0].R, capi.SPMV_SET)]
 out = []
-if a.row_order:
-    from pyamg_amd.multilevel import _aggregate_row_order
-    t0 = time.time()
-    ro = _aggregate_row_order(spec.levels[1].P)
-    print(f"row order from P1: {time.time() - t0:.2f}s", flush=True)
-    for name, op, epi in ops[:1] + ops[2:]:
-        m, n = op.shape
-        dA = DeviceMatrix(op)
-        t0 = time.time(); dA.set_row_order(ro); t_twin = time.time() - t0
-        dA.autotune(allow_cap=False)
-        rng = np.random.RandomState(0)
-        x = capi.DeviceArray.from_host(rng.rand(n)); b = capi.DeviceArray.from_host(rng.rand(m)); y = capi.DeviceArray(m, np.float64)
-        kw = dict(b=b) if epi == capi.SPMV_RESID else {}
-        res = {}
-        for use in (0, 1, 0, 1):
-            dA.tune(row_order=use)
-            for _ in range(3):
-                dA.spmv(epi, x, y, **kw)
-            capi.sync()
-            got = y.download()
-            e0, e1 = capi.Event(), capi.Event()
-            e0.record()
-            for _ in range(20):
-                dA.spmv(epi, x, y, **kw)
-            e1.record(); e1.synchronize()
-            ms = e0.elapsed_ms(e1) / 20
-            res.setdefault(use, []).append(ms)
-            if use == 0:
-                ref = got
-            same = bool(np.array_equal(got, ref))
-        rec = {"op": name, "shape": [m, n], "nnz": int(op.nnz), "as_stored_ms": [round(v, 5) for v in res[0]], "row_ordered_ms": [round(v, 5) for v in res[1]], "bit_identical": same, "twin_build_s": round(t_twin, 2)}
-        print(rec, flush=True)
-        out.append(rec)
-        dA.free()
-    (ROOT / "gpurun_out").mkdir(exist_ok=True)
-    (ROOT / "gpurun_out" / f"microbench_{a.tag}.json").write_text(json.dumps(out, indent=1))
-    sys.exit(0)
 for name, op, epi in ops:
     m, n = op.shape
     dA = DeviceMatrix(op)
@@ -70,9 +33,9 @@ for name, op, epi in ops:
     x = capi.DeviceArray.from_host(rng.rand(n)); b = capi.DeviceArray.from_host(rng.rand(m)); y = capi.DeviceArray(m, np.float64)
     ref = None
     by = 12 * op.nnz + 4 * (m + 1) + 8 * n + 8 * m + (8 * m if epi == capi.SPMV_RESID else 0)
-    for cap in ((1536,) if a.ablate else (1536, 1024, 2048, 3072)):
-        for fl in ((1, 5, 9, 13) if a.ablate else (0, 1, 2, 3)):
-            dA.tune(lds_entries=cap, stream_flags=fl)
+    for cap in ((1536,) if (a.ablate or a.idx16) else (1536, 1024, 2048, 3072)):
+        for fl in ((1, 5, 9, 13) if a.ablate else (0, 1, 2, 3) if not a.idx16 else (0, 1, 16 + 0, 16 + 1)):
+            dA.tune(lds_entries=cap, stream_flags=fl & 15, idx16=0 if (a.idx16 and fl & 16) else 1)
             kw = dict(b=b) if epi == capi.SPMV_RESID else {}
             for _ in range(3):
                 dA.spmv(epi, x, y, **kw)
