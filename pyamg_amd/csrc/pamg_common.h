@@ -284,6 +284,12 @@ void free_kz_lane_part(KzLaneSched *t);
 int kz_lane_launch(pamg_matrix_s *Lm, LineSchedule *g, bool nr, void *v, const void *b, const void *Dinv, double omega, void *xout, hipStream_t s);
 int kz_lane_info(const LineSchedule *g, int64_t *info);
 bool kz_lane_error(LineSchedule *g);
+// pamg_block.hip: dispatch of the block kernels
+bool want_blanes(const pamg_matrix_s *A, const GsSchedule *g);
+int block_point_sweep(pamg_matrix_s *A, GsSchedule *g, void *x, const void *b, int dirn, hipStream_t s);
+int get_schedule(pamg_matrix_s *A, int row_start, int row_stop, int row_step, GsSchedule **out);
+int ensure_parts(pamg_matrix_s *A, GsSchedule *g, bool block_gs = false);
+int device_cus();
 // pamg_blane.hip: the lane-parallel fast-order block Gauss-Seidel sweep (BSR, square blocks)
 bool blane_eligible(const pamg_matrix_s *A, const GsSchedule *g);
 int build_blane_part(pamg_matrix_s *A, GsSchedule *g);

@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(BLK) void vec_sumsq_kernel(const T *x, int64_t n, d
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(BLK) void reduce_final_kernel(const double *partial, int n, double *out)
+static __global__ __launch_bounds__(BLK) void reduce_final_kernel(const double *partial, int n, double *out)
 {
     __shared__ double sm[BLK / 64];
     double acc = 0.0;
@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(BLK) void reduce_final_kernel(const double *partial
     if (threadIdx.x == 0) out[0] = tot;
 }
 
-__global__ __launch_bounds__(BLK) void reduce_mid_kernel(const double *partial, int n, double *mid)
+static __global__ __launch_bounds__(BLK) void reduce_mid_kernel(const double *partial, int n, double *mid)
 {
     __shared__ double sm[BLK / 64];
     double acc = 0.0;
@@ -1668,7 +1668,7 @@ __global__ __launch_bounds__(BLK) void vec_maxratio_kernel(const T *u, const T *
     if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
 }
 
-__global__ __launch_bounds__(BLK) void reduce_max_kernel(const double *partial, int n, double *out)
+static __global__ __launch_bounds__(BLK) void reduce_max_kernel(const double *partial, int n, double *out)
 {
     __shared__ double sm[BLK];
     double m = -1.0;
