@@ -229,9 +229,11 @@ __device__ __forceinline__ void blane_finish(const BlaneArgs &a, const BlaneSet<
 
 constexpr int BLANE_WPB = BLK / 64;
 
-// PF: the static operands of a wave's NEXT group are requested before it starts to wait for the current one (two sets of blocks in registers);
-// without it (two 6 x 6 blocks per lane) a group's blocks are requested when the wave arrives at it
-template <int BS, int L, int K, int MODE, bool PF>
+// A wave requests a group's blocks when it arrives at the group -- NOT the next group's while it waits for the current one (the scalar lane form's
+// habit, and this kernel's first version): the memory counter is in order, so every poll of the current group would return behind the 9 ... 72 loads of
+// the prefetch, and a wave typically arrives only 1.4 us before its last operand (0.26 us at the 10th percentile, stamps of the sweep).  One session,
+// profiles/r05_microbench_blane_prefetch_ab.txt: level 0 0.316 -> 0.298 ms, level 1 0.223 -> 0.212.
+template <int BS, int L, int K, int MODE>
 __global__ __launch_bounds__(BLK) void bsr_lane_kernel(const BlaneArgs a)
 {
     const int lane = threadIdx.x & 63;
@@ -241,30 +243,10 @@ __global__ __launch_bounds__(BLK) void bsr_lane_kernel(const BlaneArgs a)
     BlaneDyn<BS, K> D;
     if constexpr (MODE != 1) {
         const int W = (int)gridDim.x * BLANE_WPB;
-        int g = (int)blockIdx.x * BLANE_WPB + wib;
-        const int gend = a.ngroups;
-        if (g >= gend) return;
-        if constexpr (PF) {
-            BlaneSet<BS, K> Q;
+        for (int g = (int)blockIdx.x * BLANE_WPB + wib; g < a.ngroups; g += W) {
             blane_load<BS, L, K>(a, g, P);
-            while (true) {
-                const int g2 = g + W;
-                blane_issue<BS, L, K>(a, P, D, idle);
-                blane_load<BS, L, K>(a, min(g2, gend - 1), Q);      // unconditional (a load under a branch makes the compiler drain the counter at the next wait)
-                blane_finish<BS, L, K, MODE>(a, P, D, g, idle);
-                if (g2 >= gend) break;
-                g = g2 + W;
-                blane_issue<BS, L, K>(a, Q, D, idle);
-                blane_load<BS, L, K>(a, min(g, gend - 1), P);
-                blane_finish<BS, L, K, MODE>(a, Q, D, g2, idle);
-                if (g >= gend) break;
-            }
-        } else {
-            for (; g < gend; g += W) {
-                blane_load<BS, L, K>(a, g, P);
-                blane_issue<BS, L, K>(a, P, D, idle);
-                blane_finish<BS, L, K, MODE>(a, P, D, g, idle);
-            }
+            blane_issue<BS, L, K>(a, P, D, idle);
+            blane_finish<BS, L, K, MODE>(a, P, D, g, idle);
         }
     } else {
         __shared__ int sh_home;
@@ -276,44 +258,17 @@ __global__ __launch_bounds__(BLK) void bsr_lane_kernel(const BlaneArgs a)
         }
         __syncthreads();
         if (!sh_home) return;
-        // tickets: lane 0 draws, the wave reads lane 0's register; taken in increasing order by running waves: complete for any placement
+        // tickets: lane 0 draws, the wave reads lane 0's register; taken in increasing order by running waves: complete for any placement.
+        // The next ticket is drawn while the current group waits (the atomic returns long before the group's operands do).
         unsigned tk = 0;
         if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int g = (int)__builtin_amdgcn_readfirstlane(tk);
-        if (g >= a.ngroups) return;
-        if constexpr (PF) {
-            BlaneSet<BS, K> Q;
+        while (g < a.ngroups) {
             blane_load<BS, L, K>(a, g, P);
+            blane_issue<BS, L, K>(a, P, D, idle);
             if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int g2 = (int)__builtin_amdgcn_readfirstlane(tk);
-            while (true) {
-                unsigned tk3 = 0;
-                blane_issue<BS, L, K>(a, P, D, idle);
-                if (g2 < a.ngroups) {
-                    blane_load<BS, L, K>(a, g2, Q);
-                    if (lane == 0) tk3 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                blane_finish<BS, L, K, MODE>(a, P, D, g, idle);
-                if (g2 >= a.ngroups) break;
-                g = (int)__builtin_amdgcn_readfirstlane(tk3);
-                unsigned tk4 = 0;
-                blane_issue<BS, L, K>(a, Q, D, idle);
-                if (g < a.ngroups) {
-                    blane_load<BS, L, K>(a, g, P);
-                    if (lane == 0) tk4 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                blane_finish<BS, L, K, MODE>(a, Q, D, g2, idle);
-                if (g >= a.ngroups) break;
-                g2 = (int)__builtin_amdgcn_readfirstlane(tk4);
-            }
-        } else {
-            while (g < a.ngroups) {
-                blane_load<BS, L, K>(a, g, P);
-                blane_issue<BS, L, K>(a, P, D, idle);
-                if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                blane_finish<BS, L, K, MODE>(a, P, D, g, idle);
-                g = (int)__builtin_amdgcn_readfirstlane(tk);
-            }
+            blane_finish<BS, L, K, MODE>(a, P, D, g, idle);
+            g = (int)__builtin_amdgcn_readfirstlane(tk);
         }
     }
 }
@@ -338,16 +293,16 @@ int blane_upload(U **dst, const void *src, size_t bytes, size_t *total)
     return PAMG_OK;
 }
 
-// two blocks per lane only for whole-wave block rows; two 6 x 6 blocks without the prefetch of the next group (2 x 36 values twice over do not fit the registers)
+// two blocks per lane only for whole-wave block rows
 template <int BS, int MODE>
 const void *blane_kernel_l(int L, int K)
 {
-    if (K == 2) return L == 64 ? (const void *)bsr_lane_kernel<BS, 64, 2, MODE, (BS < 6)> : nullptr;
+    if (K == 2) return L == 64 ? (const void *)bsr_lane_kernel<BS, 64, 2, MODE> : nullptr;
     switch (L) {
-        case 8: return (const void *)bsr_lane_kernel<BS, 8, 1, MODE, true>;
-        case 16: return (const void *)bsr_lane_kernel<BS, 16, 1, MODE, true>;
-        case 32: return (const void *)bsr_lane_kernel<BS, 32, 1, MODE, true>;
-        case 64: return (const void *)bsr_lane_kernel<BS, 64, 1, MODE, true>;
+        case 8: return (const void *)bsr_lane_kernel<BS, 8, 1, MODE>;
+        case 16: return (const void *)bsr_lane_kernel<BS, 16, 1, MODE>;
+        case 32: return (const void *)bsr_lane_kernel<BS, 32, 1, MODE>;
+        case 64: return (const void *)bsr_lane_kernel<BS, 64, 1, MODE>;
     }
     return nullptr;
 }

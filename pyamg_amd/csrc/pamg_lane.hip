@@ -15,7 +15,8 @@
 //   one-XCD form: small operators (vectors fit one XCD's L2).  The first workgroup to arrive claims its XCD, workgroups
 //                 elsewhere leave, the rest draw groups from a ticket counter (two tickets ahead, taken in increasing
 //                 order by running waves: complete for any placement) and publish with ordinary L2-resident stores.
-// The static operands of a wave's NEXT group are requested before it starts to wait for the current one.
+// In the ticket form the static operands of a wave's NEXT group are requested before it starts to wait for the current one (the static form stopped
+// doing that in round 5: - 1.4 % on level 1 of the 256^3 hierarchy, profiles/r05_microbench_lane_prefetch_ab.txt).
 //
 // Round 5: the slab form (one slab of the visit order per XCD, hand-off through the XCD's L2 for operands of the own slab) is gone -- it never
 // beat the plain static form (profiles/r04_microbench_lane_exp_{g,h}.json) --, rid / gate / 1 / a_ii of a slot row travel as ONE 16-byte record,
@@ -295,18 +296,13 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
         int g = (int)blockIdx.x * LANE_WPB + wib;
         const int gend = a.ngroups;
         if (g >= gend) return;
-        lane_load<T, L, K>(a, g, P);
-        while (true) {
-            const int g2 = g + W;
+        // a group's static operands are requested when the wave arrives at it (round 5; until then the NEXT group's were requested before the wave
+        // started to wait for the current one: the in-order memory counter puts every poll behind that prefetch -- level 1 of the 256^3 hierarchy
+        // 2.282 -> 2.249 ms in one session, profiles/r05_microbench_lane_prefetch_ab.txt)
+        for (; g < gend; g += W) {
+            lane_load<T, L, K>(a, g, P);
             lane_issue<T, EPI, K>(a, P, D, idle);
-            lane_load<T, L, K>(a, min(g2, gend - 1), Q);   // unconditional (a load under a branch makes the compiler drain the counter at the next wait)
             lane_finish<T, EPI, L, K, MODE>(a, P, D, g, idle);
-            if (g2 >= gend) break;
-            g = g2 + W;
-            lane_issue<T, EPI, K>(a, Q, D, idle);
-            lane_load<T, L, K>(a, min(g, gend - 1), P);
-            lane_finish<T, EPI, L, K, MODE>(a, Q, D, g2, idle);
-            if (g >= gend) break;
         }
     } else {
         __shared__ int sh_home;
