@@ -214,17 +214,12 @@ __global__ __launch_bounds__(BLK) void kz_lane_kernel(const KzArgs a)
     int g = (int)blockIdx.x * KZ_WPB + wib;
     if (g >= a.ngroups) return;
     const int idle = (int)((((unsigned)blockIdx.x * KZ_WPB + (unsigned)wib) * 4u) % (unsigned)a.nidle);
-    KzSet<K> P, Q;
-    kz_load<L, K>(a, g, P);
-    while (true) {
-        const int g2 = g + W;
-        kz_load<L, K>(a, min(g2, a.ngroups - 1), Q);                 // the next group's static operands fly while this one polls
+    // a group's operands are requested when the wave arrives at it (until round 5's last day the NEXT group's were requested before the wave waited
+    // for the current one: the in-order memory counter put every poll behind that prefetch; c6n3 15.85 -> 15.60 ms, profiles/r05_bench_c6n3_prefetch_ab.txt)
+    KzSet<K> P;
+    for (; g < a.ngroups; g += W) {
+        kz_load<L, K>(a, g, P);
         kz_group<NR, L, K>(a, P, idle);
-        if (g2 >= a.ngroups) break;
-        g = g2 + W;
-        kz_load<L, K>(a, min(g, a.ngroups - 1), P);
-        kz_group<NR, L, K>(a, Q, idle);
-        if (g >= a.ngroups) break;
     }
 }
 

@@ -16,7 +16,8 @@
 //                 elsewhere leave, the rest draw groups from a ticket counter (two tickets ahead, taken in increasing
 //                 order by running waves: complete for any placement) and publish with ordinary L2-resident stores.
 // In the ticket form the static operands of a wave's NEXT group are requested before it starts to wait for the current one (the static form stopped
-// doing that in round 5: - 1.4 % on level 1 of the 256^3 hierarchy, profiles/r05_microbench_lane_prefetch_ab.txt).
+// doing that in round 5: - 1.4 % on level 1 of the 256^3 hierarchy; the ticket form WITHOUT it: level 2 0.705 -> 0.745 ms -- inside one XCD a poll
+// costs little and the operands of the next group are the longer wait; profiles/r05_microbench_lane_prefetch_ab.txt).
 //
 // Round 5: the slab form (one slab of the visit order per XCD, hand-off through the XCD's L2 for operands of the own slab) is gone -- it never
 // beat the plain static form (profiles/r04_microbench_lane_exp_{g,h}.json) --, rid / gate / 1 / a_ii of a slot row travel as ONE 16-byte record,
