@@ -107,6 +107,11 @@ def variants_for(li, n):
         v.append(("fast_xcd_L16_G256_nogate", dict(lane_L=16, lane_G=256, gran_xcd=1, lane_flags=0)))
     # (exp "y", the one-XCD STATIC form -- a census at the start instead of a ticket per group, tune gran_xcd = 3 -- was measured and removed:
     #  profiles/r05_microbench_lane_one_xcd_static_census_not_kept.json)
+    if a.exp == "g":                       # round 5, after the prefetch went: persistent workgroups of the static form on level 1
+        v.append(("fast_auto", dict(gs_order=1, lane_wide=1, lane_L=0, lane_G=0, gran_xcd=0, lane_flags=1)))
+        for G in (384, 448, 521, 640, 768, 1024):
+            v.append((f"fast_G{G}", dict(lane_G=G)))
+        v.append(("fast_auto_again", dict(lane_G=0)))
     if a.exp == "h":                       # line-scan form on the grid stencil
         v.append(("tile_exact", dict(gs_order=0)))
         v.append(("lines_auto", dict(gs_order=1, line_scan=1, lane_G=0, lane_flags=1)))
