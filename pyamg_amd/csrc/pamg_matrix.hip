@@ -1920,9 +1920,9 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
     }
     float cand_ms[2][2][2];
     for (int q = 0; q < 8; ++q) (&cand_ms[0][0][0])[q] = 1e30f;
-    for (int round = 0; round < 2 && st == PAMG_OK && !masked; ++round) {
-        for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK; ++ci) {
-            if (caps[ci] != A->cap) { A->cap = caps[ci]; st = replan(A); if (st) break; }
+    for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK && !masked; ++ci) {
+        if (caps[ci] != A->cap) { A->cap = caps[ci]; st = replan(A); if (st) break; }      // (one re-plan per window: the rounds interleave the other choices)
+        for (int round = 0; round < 2 && st == PAMG_OK; ++round) {
             for (int ix = 0; ix < nidx && st == PAMG_OK; ++ix) {
                 A->use_idx16 = ix == 0 ? idx0 : 0;
                 for (int fl = 0; fl < 2 && st == PAMG_OK; ++fl) {
