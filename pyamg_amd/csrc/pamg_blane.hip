@@ -426,10 +426,11 @@ int blane_launch(pamg_matrix_s *A, GsSchedule *g, const void *Dinv, void *x, con
     const int per_level = (int)((t->ngroups + t->nlevels - 1) / std::max(1, t->nlevels));
     // Look-ahead (a wave that runs ahead waits in its poll loop -- on its gate -- with its blocks in registers): three dependency levels where a
     // wave holds several block rows, six with one block row per wave (its blocks are the longer fetch: 18 KB per 6 x 6 row) -- the elasticity
-    // hierarchy, profiles/r05_microbench_blane_grid.json: level 0 (342 groups per level) 0.313 ms with 256 workgroups, 0.336 with 342, 0.340 with
-    // 128; level 1 (82 per level) 0.236 ms with 128 .. 256, 0.242 with 64, 0.260 with 48
+    // hierarchy, profiles/r05_microbench_blane_grid.json (after the prefetch went): level 0 (342 groups per level) 0.289 ms with 256 workgroups, 0.321 with 512,
+    // 0.316 with 128; level 1 (82 per level) 0.210 ms with 128 .. 256, 0.212 with 64, 0.253 with 32
     const int64_t want_waves = std::max<int64_t>(128, (int64_t)(t->RPW == 1 ? 6 : 3) * per_level);
     int G = (int)std::min<int64_t>((want_waves + BLANE_WPB - 1) / BLANE_WPB, (int64_t)cap * cus);
+    if (G > cus && G <= cus + cus / 4) G = cus;                 // a few workgroups beyond one per CU double up on some CUs: level 0 of the elasticity hierarchy 0.299 ms with 257, 0.289 with 256
     if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + BLANE_WPB - 1) / BLANE_WPB));
     void *args[] = {(void *)&a};
