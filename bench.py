@@ -93,7 +93,123 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def measure_traffic(grid, nrows):
+# ---- what goes to stdout.  Round 5's line had grown to 20.8 KB and the driver no longer parsed it (BENCH_r05.json: parsed = null).  The
+#      full record of a run now goes to a FILE (gpurun_out/bench_detail.json, a copy under profiles/ is committed per round); stdout carries
+#      ONE compact line of flat scalars -- the contract's keys, `roofline`, `cpu_baseline` and one scalar per extra leg.
+HEADLINE_LIMIT = 8_000          # bytes; tests/test_host.py::test_bench_headline_stays_small builds a full fake record against it
+DETAIL_PATH = ROOT / "gpurun_out" / "bench_detail.json"
+
+
+def _short(v, n=160):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 1] + "…"
+
+
+def _flat(d, keep_str=(), n=160):
+    """scalars of a dict (numbers, booleans, None) + the named strings, shortened"""
+    out = {}
+    for k, v in (d or {}).items():
+        if isinstance(v, bool) or v is None or isinstance(v, (int, float)):
+            out[k] = v
+        elif isinstance(v, str) and k in keep_str:
+            out[k] = _short(v, n)
+    return out
+
+
+def headline(out):
+    """the compact stdout line of a run: flat scalars only, <= HEADLINE_LIMIT bytes whatever the legs put into `out`"""
+    h = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    h["config"] = _flat(out.get("config"), keep_str=("workload", "key", "cycle", "gs_order", "parallelism", "n1_point", "modelled_note"), n=200)
+    for k in ("event_ms_per_step", "spmv_GBps", "spmv_pct_of_hbm_peak", "speedup_vs_cpu_reference", "error"):
+        if k in out:
+            h[k] = _short(out[k], 300)
+    rf = out.get("roofline")
+    h["roofline"] = _flat(rf, keep_str=("kernel", "bound", "unit", "structured_kernel", "dominant_kernel"), n=140) if rf else None
+    cpu = out.get("cpu_baseline")
+    h["cpu_baseline"] = _flat(cpu, keep_str=("unit", "kind", "sample"), n=200) if cpu else None
+    par = out.get("parity") or {}
+    if par:
+        h["parity"] = _flat(par)
+        rp = par.get("reference_protocol") or {}
+        if rp:
+            h["parity"].update({"protocol_ok": rp.get("ok"), "protocol_max_rel_diff": rp.get("max_rel_diff"), "protocol_cycles": rp.get("cycles_compared")})
+        sv = par.get("sharded_vs_resident") or {}
+        if sv:
+            h["parity"].update({"sharded_vs_resident_ok": sv.get("ok"), "sharded_vs_resident_max_rel_diff": sv.get("max_rel_diff")})
+    if out.get("host"):
+        h["host"] = _flat(out["host"])
+    t = out.get("time_to_tol_1e-8") or {}
+    if t:
+        h["cycles_to_tol_1e-8"], h["seconds_to_tol_1e-8"] = t.get("cycles"), t.get("seconds")
+    for r_ in (out.get("gs_sweeps") or {}).get("per_level", []):
+        h[f"gs_sweep_ms_level{r_['level']}"] = r_.get("ms_per_forward_sweep")
+        h[f"gs_sweep_dependency_levels_level{r_['level']}"] = r_.get("dependency_levels")
+    if isinstance(out.get("exact_order"), dict):
+        h["exact_order_ms_per_step"] = out["exact_order"].get("ms_per_step")
+    sh = out.get("sharded") or {}
+    if sh:
+        h["cheby_resident_ms_per_step"] = sh.get("ms_per_step")
+        h["cheby_sharded_driver_one_rank_ms_per_step"] = (sh.get("sharded_driver_one_rank") or {}).get("ms_per_step")
+    sd = out.get("sharded_driver") or {}
+    if sd:
+        h["sharded_driver"] = _flat(sd, keep_str=("transport",))
+    # one group of scalars per extra leg
+    for key, leg in (out.get("extra") or {}).items():
+        if not isinstance(leg, dict):
+            continue
+        legs = [(f"extra_{key}", leg)] + [(f"extra_{key}_{k}", v) for k, v in leg.items() if isinstance(v, dict) and "ms_per_step" in v]
+        for tag, lg in legs:
+            if "error" in lg:
+                h[tag + "_error"] = _short(str(lg["error"]), 120)
+            if "ms_per_step" in lg:
+                h[tag + "_ms"], h[tag + "_cycles_per_s"] = lg.get("ms_per_step"), lg.get("value")
+            cb = lg.get("cpu_baseline") or {}
+            if cb:
+                h[tag + "_cpu_cycles_per_s"] = cb.get("value")
+            rp = (lg.get("parity") or {}).get("reference_protocol") or {}
+            if rp:
+                h[tag + "_protocol_ok"], h[tag + "_protocol_max_rel_diff"] = rp.get("ok"), rp.get("max_rel_diff")
+            tt = lg.get("time_to_tol_1e-8") or {}
+            if tt.get("cycles") is not None:
+                h[tag + "_cycles_to_tol"], h[tag + "_s_to_tol"] = tt.get("cycles"), tt.get("seconds")
+            for k, v in lg.items():                       # scalars a leg marks for the line (accelerated solves, ...)
+                if k.startswith("hl_") and (isinstance(v, (int, float, bool)) or v is None):
+                    h[tag + "_" + k[3:]] = v
+    ms_ = out.get("modelled_scaling") or {}
+    for r_ in ms_.get("rows", []):
+        h[f"modelled_ms_n{r_['n']}"] = r_.get("ms_per_step")
+        if "slowest_rank" in r_:
+            h[f"modelled_slowest_rank_n{r_['n']}"] = r_["slowest_rank"]
+    if ms_.get("rows"):
+        h["modelled_ms_n1_measured"] = ms_.get("n1_ms_per_step_measured")
+    if out.get("notes"):
+        h["notes"] = [_short(str(s), 120) for s in out["notes"]][:3]
+    h["detail"] = "gpurun_out/bench_detail.json (the full record of this run; committed copies: profiles/rNN_bench_detail*.json)"
+    # the line must parse whatever happens: shed the least important keys until it fits
+    for drop in ("notes", "host", "sharded_driver", "parity"):
+        if len(json.dumps(h)) <= HEADLINE_LIMIT:
+            break
+        h.pop(drop, None)
+    if len(json.dumps(h)) > HEADLINE_LIMIT:
+        for k in [k for k in h if k.startswith(("extra_", "gs_sweep_", "modelled_"))][::-1]:
+            h.pop(k)
+            if len(json.dumps(h)) <= HEADLINE_LIMIT:
+                break
+    return h
+
+
+def write_detail(out, path=None):
+    path = Path(path or os.environ.get("PAMG_BENCH_DETAIL", DETAIL_PATH))
+    try:
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_text(json.dumps(out, indent=1))
+        return str(path)
+    except OSError as e:                                        # a read-only tree must not cost the line
+        log(f"detail record not written: {e!r}")
+        return None
+
+
+def measure_traffic(grid, nrows, general=False):
     """HBM bytes per launch of the fine-level residual kernel, counted in THIS run: tools/spmv_pmc.py (the same operator,
     the same kernel) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, kernel trace only),
     corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE tallies 128-byte requests at
@@ -106,19 +222,20 @@ def measure_traffic(grid, nrows):
     if not shutil.which("rocprofv3") or any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
         return None
     vals = {}
+    names = ("csr_stream_kernel",) if general else ("csr_stream_kernel", "csr_rowgather_kernel", "csr_rowpat_kernel", "csr_rowmask")
     tmp = tempfile.mkdtemp(prefix="pamg_pmc_")
     try:
         for cname in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, cname)
             cmd = ["rocprofv3", "--pmc", cname, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                   sys.executable, str(ROOT / "tools" / "spmv_pmc.py")] + [str(g) for g in grid]
+                   sys.executable, str(ROOT / "tools" / "spmv_pmc.py")] + [str(g) for g in grid] + (["--general=1"] if general else [])
             subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
                            env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
             tot, cnt = 0.0, 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if r.get("Counter_Name") == cname and any(k in r.get("Kernel_Name", "") for k in ("csr_stream_kernel", "csr_rowgather_kernel", "csr_rowpat_kernel", "csr_rowmask")) and \
+                        if r.get("Counter_Name") == cname and any(k in r.get("Kernel_Name", "") for k in names) and \
                                 int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0) >= 256 * 1024:
                             tot += float(r["Counter_Value"])
                             cnt += 1
@@ -465,7 +582,8 @@ def main():
     def emit():
         if rank == 0 and box["out"] is not None and not printed.is_set():
             printed.set()
-            print(json.dumps(box["out"]), flush=True)
+            write_detail(box["out"])                       # the full record: a file, not stdout
+            print(json.dumps(headline(box["out"])), flush=True)
 
     def start_watchdog(budget, what):
         """whatever happens in the legs that follow (an exception on one rank, a collective that never completes on a node
@@ -727,38 +845,51 @@ def main():
     moved = max(int(streamed), int(pmc["bytes_per_launch"]) if pmc else 0)
     kname = ((f"csr_rowmask3d_kernel<double, RESID, {masks['planes_per_lane']}>" if masks["lattice"] else "csr_rowmask_kernel<double, RESID>") if masks["entries"] else
              "csr_rowpat_kernel<double, RESID>" if npats else "csr_rowgather_kernel<double, RESID>" if nvals else "csr_stream_kernel<double, RESID>")
-    roofline = {"kernel": kname + " (fine-level r = b - A x)", "bound": "hbm",
-                "achieved": round(moved / spmv_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(moved / spmv_ms / 1e6 / HBM_PEAK_GBPS, 4),
-                "basis": "max(bytes the running operator format must stream, HBM traffic counted by rocprofv3 PMC in this run)",
-                "traffic": pmc["bytes_per_launch"] if pmc else None,
-                "bytes_per_launch": int(moved), "ms_per_launch": round(spmv_ms, 5),
-                "bytes_streamed_per_launch": int(streamed), "operator_stream": stream_note,
-                "bytes_csr_formula": int(bytes_resid), "achieved_csr_formula": round(achieved, 1),
-                "frac_csr_formula": round(achieved / HBM_PEAK_GBPS, 4),
-                "csr_formula_note": "SURVEY 8(d): 12 nnz + 4 (n + 1) + 8 n (x) + 8 n (r) + 8 n (b); exceeds the peak when the operator is streamed compressed"}
+    structured = {"kernel": kname + " (fine-level r = b - A x)", "bound": "hbm",
+                  "achieved": round(moved / spmv_ms / 1e6, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                  "frac": round(moved / spmv_ms / 1e6 / HBM_PEAK_GBPS, 4),
+                  "basis": "max(bytes the running operator format must stream, HBM traffic counted by rocprofv3 PMC in this run)",
+                  "traffic": pmc["bytes_per_launch"] if pmc else None,
+                  "bytes_per_launch": int(moved), "ms_per_launch": round(spmv_ms, 5),
+                  "bytes_streamed_per_launch": int(streamed), "operator_stream": stream_note,
+                  "bytes_csr_formula": int(bytes_resid), "achieved_csr_formula": round(achieved, 1),
+                  "frac_csr_formula": round(achieved / HBM_PEAK_GBPS, 4),
+                  "csr_formula_note": "SURVEY 8(d): 12 nnz + 4 (n + 1) + 8 n (x) + 8 n (r) + 8 n (b); exceeds the peak when the operator is streamed compressed"}
+    if pmc:
+        structured["traffic_detail"] = pmc
+        structured["traffic_over_streamed"] = round(pmc["bytes_per_launch"] / max(streamed, 1), 3)
+    if plain:
+        # THE LEAD of the block: the north star's "fine-level CSR SpMV" -- the general kernel on the CSR arrays
+        # (16-bit column codes + the values as stored, LDS-staged products), SURVEY 8(d)'s algorithmic bytes / its HIP-event time:
+        # a fraction of the peak by construction.  The bit-identical structured form that runs inside the cycle on this stencil
+        # (one mask byte per row) stands beside it under structured_*; its fraction is on the bytes that form must move.
+        pmc_g = None
+        if pmc is not None:                                   # the same two counter passes on the general kernel
+            pmc_g = measure_traffic(wl["grid"], n, general=True)
+        roofline = {"kernel": "csr_stream_kernel<double, RESID, npl2> (fine-level r = b - A x on the CSR arrays; 16-bit column codes + values as stored)",
+                    "bound": "hbm", "achieved": plain["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": plain["frac"],
+                    "traffic": pmc_g["bytes_per_launch"] if pmc_g else None,
+                    "bytes_per_launch": int(bytes_resid), "ms_per_launch": plain["ms_per_launch"],
+                    "bytes_streamed_per_launch": int(bytes_resid - 2 * nnz0),
+                    "frac_on_streamed_bytes": round((bytes_resid - 2 * nnz0) / plain["ms_per_launch"] / 1e6 / HBM_PEAK_GBPS, 4),
+                    "basis": "SURVEY 8(d): 12 nnz + 4 (n + 1) + 8 n (x) + 8 n (r) + 8 n (b), HIP events on the solver's stream",
+                    "general_csr_ms": plain["ms_per_launch"], "general_csr_GBps": plain["achieved"], "general_csr_frac": plain["frac"],
+                    "structured_kernel": structured["kernel"], "structured_ms_per_launch": structured["ms_per_launch"],
+                    "structured_bytes_per_launch": structured["bytes_per_launch"], "structured_GBps": structured["achieved"],
+                    "structured_frac": structured["frac"], "structured_traffic": structured["traffic"],
+                    "structured_frac_csr_formula": structured["frac_csr_formula"], "structured": structured}
+        if pmc_g:
+            roofline["traffic_detail"] = pmc_g
+            roofline["fetch_bytes"], roofline["write_bytes"] = pmc_g["fetch_corrected_x2"], pmc_g["write_size"]
+            roofline["traffic_over_algorithmic"] = round(pmc_g["bytes_per_launch"] / bytes_resid, 3)
+    else:
+        roofline = structured
+        if pmc:
+            roofline["fetch_bytes"], roofline["write_bytes"] = pmc["fetch_corrected_x2"], pmc["write_size"]
     if ceiling:
-        roofline["ceiling_GBps"] = ceiling["copy_GBps"]
         roofline["ceiling_copy_GBps"] = ceiling["copy_GBps"]
         roofline["ceiling"] = ceiling
-        roofline["frac_of_ceiling"] = round(moved / spmv_ms / 1e6 / max(ceiling["copy_GBps"], 1.0), 4)
-    if pmc:
-        roofline["traffic_detail"] = pmc
-        roofline["traffic_over_streamed"] = round(pmc["bytes_per_launch"] / max(streamed, 1), 3)
-        # flat copies: the driver's record keeps scalars of this object only
-        roofline["fetch_bytes"] = pmc["fetch_corrected_x2"]
-        roofline["write_bytes"] = pmc["write_size"]
-    if plain:
-        # the general kernel (any operator): 16-bit column codes + values as stored, LDS-staged products -- the north star's
-        # "fine-level CSR SpMV", on the CSR formula's bytes (it streams 10 of the 12 bytes per entry)
-        plain["bytes_per_launch"] = int(bytes_resid)
-        plain["bytes_streamed_per_launch"] = int(bytes_resid - 2 * nnz0)
-        plain["frac_on_streamed_bytes"] = round((bytes_resid - 2 * nnz0) / plain["ms_per_launch"] / 1e6 / HBM_PEAK_GBPS, 4)
-        roofline["general_csr"] = plain
-        roofline["general_csr_ms"] = plain["ms_per_launch"]
-        roofline["general_csr_GBps"] = plain["achieved"]
-        roofline["general_csr_frac"] = plain["frac"]                      # by the CSR formula of SURVEY 8(d): the north star's "fine-level CSR SpMV"
-        roofline["general_csr_frac_on_streamed_bytes"] = plain["frac_on_streamed_bytes"]
+        roofline["frac_of_ceiling"] = round(roofline["achieved"] / max(ceiling["copy_GBps"], 1.0), 4)
 
     # ---- the order-exact sweeps: latency-bound by the dependency chain of the reference's row order
     #      (levels of the schedule), not by HBM -- reported beside the bandwidth roofline so that the

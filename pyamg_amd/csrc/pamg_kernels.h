@@ -168,6 +168,88 @@ __device__ __forceinline__ void stage_val8(const StreamArgs<T> &a, int p0, int p
     }
 }
 
+// two consecutive entries per lane, 16-bit column codes (window << 14 | offset), values as stored; NT = the operator stream past the
+// caches' retention, so that what the L1 keeps is x (1 - 8 % on the SA-level operators, profiles/r05_microbench_sa_ops_nontemporal.json;
+// the autotune decides per operator)
+template <typename T, bool NEEDC, int COH, bool NT>
+__device__ __forceinline__ void stage_pairs16(const StreamArgs<T> &a, int p0, int p1, int base, T *prod, int *cols, const int4 wb)
+{
+    using T2 = typename Vec2<T>::type;
+    typedef T T2n __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+#pragma unroll 2
+    for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
+        unsigned pr2;
+        T2 vv;
+        if constexpr (NT) {
+            pr2 = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(a.Aj16 + q));
+            const T2n v2 = __builtin_nontemporal_load(reinterpret_cast<const T2n *>(a.Ax + q));
+            vv.x = v2.x; vv.y = v2.y;
+        } else {
+            pr2 = *reinterpret_cast<const unsigned *>(a.Aj16 + q);
+            vv = *reinterpret_cast<const T2 *>(a.Ax + q);
+        }
+        const unsigned c0 = pr2 & 0xFFFFu, c1 = pr2 >> 16;
+        const unsigned w0 = c0 >> 14, w1 = c1 >> 14;
+        int2 cc;
+        cc.x = (w0 == 0 ? wb.x : w0 == 1 ? wb.y : w0 == 2 ? wb.z : wb.w) + (int)(c0 & 0x3FFFu);
+        cc.y = (w1 == 0 ? wb.x : w1 == 1 ? wb.y : w1 == 2 ? wb.z : wb.w) + (int)(c1 & 0x3FFFu);
+        const bool ok0 = q >= p0, ok1 = q + 1 < p1;
+        T x0, x1;
+        if (a.flags & 4) {                        // ablation: operator stream only, no gather
+            x0 = T(cc.x); x1 = T(cc.y);
+        } else {
+            x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
+            x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
+        }
+        T2 pr;
+        pr.x = vv.x * x0;
+        pr.y = vv.y * x1;
+        *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
+        if constexpr (NEEDC) *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+    }
+}
+
+// the same with 32-bit columns (and the schedules' flag bits)
+template <typename T, bool NEEDC, int COH, bool DIAGF, bool NT>
+__device__ __forceinline__ void stage_pairs32(const StreamArgs<T> &a, int p0, int p1, int base, T *prod, int *cols)
+{
+    using T2 = typename Vec2<T>::type;
+    typedef int int2n __attribute__((ext_vector_type(2)));
+    typedef T T2n __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+#pragma unroll 2
+    for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
+        int2 cc;
+        T2 vv;
+        if constexpr (NT) {
+            const int2n c2 = __builtin_nontemporal_load(reinterpret_cast<const int2n *>(a.Aj + q));
+            const T2n v2 = __builtin_nontemporal_load(reinterpret_cast<const T2n *>(a.Ax + q));
+            cc.x = c2.x; cc.y = c2.y; vv.x = v2.x; vv.y = v2.y;
+        } else {
+            cc = *reinterpret_cast<const int2 *>(a.Aj + q);
+            vv = *reinterpret_cast<const T2 *>(a.Ax + q);
+        }
+        const bool ok0 = q >= p0, ok1 = q + 1 < p1;
+        T x0, x1;
+        if (a.flags & 4) {                            // ablation: operator stream only, no gather
+            x0 = T(cc.x); x1 = T(cc.y);
+        } else {
+            x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
+            x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
+        }
+        T2 pr;
+        pr.x = (DIAGF && (cc.x & DIAG_BIT)) ? T(0) : vv.x * x0;
+        pr.y = (DIAGF && (cc.y & DIAG_BIT)) ? T(0) : vv.y * x1;
+        *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
+        if constexpr (NEEDC) {
+            cc.x &= COL_MASK;
+            cc.y &= COL_MASK;
+            *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
+        }
+    }
+}
+
 // ---- phase 1: stage products (and column ids) of entries [p0,p1) into LDS slots [p-base]
 template <typename T, bool NEEDC, int NPL, int COH = 0, bool DIAGF = false>
 __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, int p1, int base,
@@ -293,72 +375,15 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
                 }
                 return;
             }
-#pragma unroll 2
-            for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
-                unsigned pr2;
-                T2 vv;
-                if (nt) {
-                    // the operator stream past the caches' retention, so that what the L1 keeps is x: 1 - 8 % on the SA-level operators of the 256^3
-                    // hierarchy depending on the run (profiles/r05_microbench_sa_ops_nontemporal.json, r05_microbench_sa_ops_unroll_ab.txt); the autotune
-                    // decides per operator (the same hint on row pointers / b / y: no further gain, not kept)
-                    pr2 = __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(a.Aj16 + q));
-                    const T2n v2 = __builtin_nontemporal_load(reinterpret_cast<const T2n *>(a.Ax + q));
-                    vv.x = v2.x; vv.y = v2.y;
-                } else {
-                    pr2 = *reinterpret_cast<const unsigned *>(a.Aj16 + q);
-                    vv = *reinterpret_cast<const T2 *>(a.Ax + q);
-                }
-                const unsigned c0 = pr2 & 0xFFFFu, c1 = pr2 >> 16;
-                const unsigned w0 = c0 >> 14, w1 = c1 >> 14;
-                int2 cc;
-                cc.x = (w0 == 0 ? wb.x : w0 == 1 ? wb.y : w0 == 2 ? wb.z : wb.w) + (int)(c0 & 0x3FFFu);
-                cc.y = (w1 == 0 ? wb.x : w1 == 1 ? wb.y : w1 == 2 ? wb.z : wb.w) + (int)(c1 & 0x3FFFu);
-                const bool ok0 = q >= p0, ok1 = q + 1 < p1;
-                T x0, x1;
-                if (a.flags & 4) {                        // ablation: operator stream only, no gather
-                    x0 = T(cc.x); x1 = T(cc.y);
-                } else {
-                    x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
-                    x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
-                }
-                T2 pr;
-                pr.x = vv.x * x0;
-                pr.y = vv.y * x1;
-                *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
-                if constexpr (NEEDC) *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
-            }
+            // the nontemporal choice is made OUTSIDE the loop (round 6): with the run-time test inside the unrolled body (round 5) the loads sat
+            // under a uniform branch and the fine-level residual went 0.332 -> 0.361 ms -- loads under a branch make the compiler wait
+            // conservatively ("three things the compiler taught us" (a))
+            if (nt) stage_pairs16<T, NEEDC, COH, true>(a, p0, p1, base, prod, cols, wb);
+            else stage_pairs16<T, NEEDC, COH, false>(a, p0, p1, base, prod, cols, wb);
             return;
         }
-#pragma unroll 2
-        for (int q = base + 2 * tid; q < p1; q += 2 * BLK) {
-            int2 cc;
-            T2 vv;
-            if (nt) {
-                const int2n c2 = __builtin_nontemporal_load(reinterpret_cast<const int2n *>(a.Aj + q));
-                const T2n v2 = __builtin_nontemporal_load(reinterpret_cast<const T2n *>(a.Ax + q));
-                cc.x = c2.x; cc.y = c2.y; vv.x = v2.x; vv.y = v2.y;
-            } else {
-                cc = *reinterpret_cast<const int2 *>(a.Aj + q);
-                vv = *reinterpret_cast<const T2 *>(a.Ax + q);
-            }
-            const bool ok0 = q >= p0, ok1 = q + 1 < p1;
-            T x0, x1;
-            if (a.flags & 4) {                            // ablation: operator stream only, no gather
-                x0 = T(cc.x); x1 = T(cc.y);
-            } else {
-                x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
-                x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
-            }
-            T2 pr;
-            pr.x = (DIAGF && (cc.x & DIAG_BIT)) ? T(0) : vv.x * x0;
-            pr.y = (DIAGF && (cc.y & DIAG_BIT)) ? T(0) : vv.y * x1;
-            *reinterpret_cast<T2 *>(prod + (q - base)) = pr;
-            if constexpr (NEEDC) {
-                cc.x &= COL_MASK;
-                cc.y &= COL_MASK;
-                *reinterpret_cast<int2 *>(cols + (q - base)) = cc;
-            }
-        }
+        if (nt) stage_pairs32<T, NEEDC, COH, DIAGF, true>(a, p0, p1, base, prod, cols);
+        else stage_pairs32<T, NEEDC, COH, DIAGF, false>(a, p0, p1, base, prod, cols);
     }
 }
 

@@ -29,6 +29,7 @@ struct KzLaneSched {
     kz_i4 *d_slots = nullptr;          // [ncols] {value lo, value hi, version, 0}
     unsigned *d_err = nullptr;
     int last_grid = 0;
+    int occ_cap = 0;                   // workgroups per CU the sweep may count on (occupancy query, asked once)
     size_t bytes = 0;
 };
 
@@ -102,7 +103,9 @@ __device__ __forceinline__ void kz_poll(kz_i4 (&q)[K], const kz_i4 *const (&p)[K
 
 __device__ __forceinline__ void kz_store(kz_i4 *p, kz_i4 q)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(q) : "memory");
+    // s_nop: the store is invisible to the compiler's hazard recogniser -- a VMEM store of more than 64 bits needs one wait state before a
+    // VALU instruction may overwrite its data registers
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(p), "v"(q) : "memory");
 }
 
 template <int CTRL>
@@ -326,11 +329,18 @@ int kz_lane_launch(pamg_matrix_s *Lm, LineSchedule *g, bool nr, void *v, const v
     if (!k) return PAMG_E_ARG;
     static thread_local int cus = 0;
     if (!cus) cus = kz_cus();
-    // a few dependency levels of look-ahead; every workgroup must be resident (2 per CU is far below any occupancy limit of this kernel)
+    // a few dependency levels of look-ahead; every workgroup must be resident: at most 2 per CU, and never more than the occupancy query
+    // allows minus one (asked once per schedule, as the lane / line / block sweeps do)
+    if (t->occ_cap == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, BLK, 0) != hipSuccess || nb < 1) nb = 1;
+        t->occ_cap = std::max(1, std::min(nb > 1 ? nb - 1 : 1, 2));
+    }
+    const int percu = t->occ_cap;
     const int per_level = (int)((t->ngroups + t->nlevels - 1) / std::max(1, t->nlevels));
     const int64_t want_waves = std::max<int64_t>(64, (int64_t)4 * per_level);
-    int G = (int)std::min<int64_t>((want_waves + KZ_WPB - 1) / KZ_WPB, (int64_t)2 * cus);
-    if (Lm->lane_G > 0) G = std::min(Lm->lane_G, 2 * cus);
+    int G = (int)std::min<int64_t>((want_waves + KZ_WPB - 1) / KZ_WPB, (int64_t)percu * cus);
+    if (Lm->lane_G > 0) G = std::min(Lm->lane_G, percu * cus);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + KZ_WPB - 1) / KZ_WPB));
     t->last_grid = G;
     void *args[] = {(void *)&a};

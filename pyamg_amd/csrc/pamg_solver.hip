@@ -298,6 +298,15 @@ int check_sweeps(pamg_solver_s *S)
         bool e = false;
         PAMG_TRY(sweep_error(L.A, &e));
         any = any || e;
+        // the Kaczmarz lane sweeps (pamg_kz.hip) run on the smoothers' own operators: A^T for gauss_seidel_nr, the row-sorted twin for
+        // gauss_seidel_ne -- their spin time-outs are reported on THOSE operators' line schedules
+        for (Smoother *sm : {&L.pre, &L.post})
+            for (pamg_matrix_s *M : {sm->At, sm->Ar})
+                if (M && M != L.A) {
+                    bool e2 = false;
+                    PAMG_TRY(sweep_error(M, &e2));
+                    any = any || e2;
+                }
     }
     static int forced = [] { const char *e = getenv("PAMG_FORCE_TIMEOUT"); return e ? atoi(e) : 0; }();   // test hook: report the first N checks as timed out
     if (forced > 0) { --forced; any = true; }
@@ -316,7 +325,12 @@ int fall_back_to_level_launches(pamg_solver_s *S)
         if (!L.A) continue;
         L.A->gs_mode = 1;
         L.A->tile_default = false;
-        for (Smoother *sm : {&L.pre, &L.post}) PAMG_TRY(prebuild_schedules(L, *sm));
+        for (Smoother *sm : {&L.pre, &L.post}) {
+            // kz_lane_launch is gated on gs_mode == 0 of the operator the sweep runs on (pamg_matrix.hip: kaczmarz_sweep)
+            if (sm->At) sm->At->gs_mode = 1;
+            if (sm->Ar) sm->Ar->gs_mode = 1;
+            PAMG_TRY(prebuild_schedules(L, *sm));
+        }
     }
     S->fallbacks++;
     return PAMG_OK;

@@ -347,11 +347,13 @@ def test_long_dependency_chains_against_the_live_reference(case):
         assert np.array_equal(o, outs[1])                 # exact schedulers differ in speed only
 
 
-def test_sweep_timeout_falls_back_to_level_launches():
+@pytest.mark.parametrize("hier", ["sa3d_gs", "rs2d_nonsym_gsnr", "rs2d_nonsym_gsne"])
+def test_sweep_timeout_falls_back_to_level_launches(hier):
     """a persistent sweep that reports PAMG_E_TIMEOUT (not all of its workgroups were running -- forced here through the
     PAMG_FORCE_TIMEOUT test hook): solve() switches every order-exact sweep to one launch per dependency level, runs the
     solve again from the initial guess and returns the reference's answer; the switch is reported in stats() and by ONE
-    RuntimeWarning"""
+    RuntimeWarning.  The normal-equation hierarchies: their Kaczmarz lane sweeps run on the smoother's OWN operators
+    (A^T / the row-sorted twin), which the fallback must switch to per-level launches too"""
     import subprocess
     import sys
     from conftest import ROOT
@@ -360,7 +362,7 @@ def test_sweep_timeout_falls_back_to_level_launches():
         f"sys.path.insert(0, {str(ROOT)!r})\n"
         "from pyamg_amd import DeviceMultilevelSolver\n"
         "from pyamg_amd.hierarchy import load_spec\n"
-        f"spec, ex = load_spec({str(ROOT / 'tests' / 'golden' / 'hier_sa3d_gs.npz')!r})\n"
+        f"spec, ex = load_spec({str(ROOT / 'tests' / 'golden' / ('hier_' + hier + '.npz'))!r})\n"
         "dml = DeviceMultilevelSolver(spec)\n"
         "r = []\n"
         "x = dml.solve(ex['b'], x0=ex['x0'], tol=1e-30, maxiter=int(ex['k']), residuals=r)\n"

@@ -314,3 +314,48 @@ def test_pybind11_binding_module_surface():
         pb.gauss_seidel(Ap.astype(np.int64), Aj, np.zeros(1), np.zeros(1), np.zeros(1), 0, 1, 1)           # int64 indices
     with pytest.raises(TypeError):
         pb.jacobi(Ap, Aj, np.zeros(1), np.zeros(1), np.zeros(1), np.zeros(1), 0, 1, 1, 1.0)                # omega is an array
+
+
+def test_bench_headline_stays_small():
+    """bench.py prints ONE compact line (the driver stopped parsing round 5's 20.8 KB line): built from a full record of a real run
+    (profiles/r05_bench_n1.json) with every leg inflated, the headline must stay under bench.HEADLINE_LIMIT, be valid JSON of flat
+    scalars inside `roofline` / `cpu_baseline` / `config`, and keep the contract's keys"""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = json.loads((ROOT / "profiles" / "r05_bench_n1.json").read_text())
+    # inflate: long strings, long arrays, more legs, more model rows
+    out["residuals_gpu"] = [1.0] * 4000
+    out["roofline"]["operator_stream"] = "x" * 5000
+    out["roofline"]["kernel"] = "k" * 2000
+    out["cpu_baseline"]["sample"] = "s" * 3000
+    out["config"]["workload"] = "w" * 1000
+    out["config"]["hierarchy_setup"] = "h" * 3000
+    for i in range(12):
+        out["extra"][f"leg{i}"] = dict(out["extra"]["c2"])
+        out["extra"][f"leg{i}"]["hl_cg_s_to_tol"] = 0.1
+    out["modelled_scaling"]["rows"] = out["modelled_scaling"]["rows"] * 3
+    out["notes"] = ["n" * 500] * 10
+    h = bench.headline(out)
+    line = json.dumps(h)
+    assert len(line) <= bench.HEADLINE_LIMIT < 10_000, len(line)
+    h2 = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in h2, k
+    for blk in ("roofline", "cpu_baseline", "config"):
+        assert all(not isinstance(v, (dict, list)) for v in h2[blk].values()), blk
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in h2["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in h2["cpu_baseline"], k
+    assert h2["value"] == out["value"] and h2["config"]["key"] == "c3"
+    # the un-inflated record: everything fits, nothing is shed
+    out2 = json.loads((ROOT / "profiles" / "r05_bench_n1.json").read_text())
+    h3 = bench.headline(out2)
+    assert len(json.dumps(h3)) <= 6_000 and "extra_c4_ms" in h3 and "modelled_ms_n8" in h3 and "extra_c5_block_gauss_seidel_ms" in h3
+    # a failed multi-GPU run's line passes through
+    hf = bench.headline({"metric": "m", "value": None, "error": "e" * 1000, "config": {"workload": "w"}})
+    assert hf["value"] is None and len(hf["error"]) <= 300

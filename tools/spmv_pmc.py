@@ -45,6 +45,9 @@ if "rowpat" in opt:
     dA.tune(rowpat=opt["rowpat"])
 if "kz" in opt:
     dA.tune(rowmask_kz=opt["kz"])
+if any(a == "--general=1" for a in sys.argv[1:]):
+    # the general kernel on the CSR arrays (bench.py's roofline lead): no value codes, no row forms, LDS window 1536
+    dA.tune(val8=0, rowgather=0, lds_entries=1536, max_rows=1024)
 for _ in range(launches):
     dA.spmv(capi.SPMV_RESID, x, r, b=b)
 capi.sync()
