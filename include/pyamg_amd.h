@@ -392,6 +392,14 @@ int pamg_matrix_tile_info(pamg_matrix_t A, int which, int64_t info[8]);
  * Block operators (bs > 1): the same fields for the block-row lane form of pamg_matrix_block_gauss_seidel (csrc/pamg_blane.hip: lanes per BLOCK row,
  * BLOCKS per lane, block slots, blocks that wait for a new x_j). */
 int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8]);
+/* Plan of the MERGED lane-parallel sweep (round 6; tune key 33: dependency levels eliminated into one super-level at most -- 0 automatic, 1 never;
+ * key 34: waves per average super-level x 10; csrc/pamg_lanem_plan.h) for schedule `which`: {super-levels (hand-offs of this form), dependency
+ * levels (hand-offs of the unmerged form), rows, 64-slot operand units, operands polled from earlier super-levels, operands read from the snapshot
+ * of x, operands read from b, longest merged row, levels merged at most, groups closed early by row length, closed early by the growth bound,
+ * workgroups of the last launch}; *growth (may be NULL) = the largest accepted growth factor sum_r |T_ir| |a_ii|.  All zero when the schedule
+ * runs unmerged.  The merged sweep computes the reference's Gauss-Seidel iterates (amg_core::gauss_seidel, relaxation.h:48-76) in another
+ * association: equal in exact arithmetic, to rounding in floating point. */
+int pamg_matrix_lanem_info(pamg_matrix_t A, int which, int64_t info[12], double *growth);
 /* Layout of the lane-parallel fast-order Kaczmarz sweep (tune key 24 = 1 on the operator handed to pamg_matrix_kaczmarz; csrc/pamg_kz_plan.h)
  * of the operator's `which`-th cached line schedule (0 .. 3, in the order the sweep ranges were first used): {lanes per line, entry slots per
  * lane, groups, dependency levels, groups of the widest level, workgroups of the last launch, bytes, 0}; all zero when that schedule has none. */

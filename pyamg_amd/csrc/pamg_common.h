@@ -120,6 +120,8 @@ struct GsSchedule {
     bool line_unfit = false;         // the line planner declined this schedule (no runs of coupled consecutive rows / rows too long)
     struct LaneSched *lane = nullptr; // lane-parallel "fast order" sweep (pamg_lane_plan.h / pamg_lane.hip), built on demand
     bool lane_unfit = false;         // the lane planner declined this schedule (rows too long / padding too wasteful)
+    struct LaneMSched *lanem = nullptr; // MERGED lane-parallel sweep: s dependency levels eliminated into one super-level (pamg_lanem_plan.h / pamg_lane.hip), f64 Gauss-Seidel
+    bool lanem_unfit = false;        // its planner declined (a row beyond 256 operands, nothing to merge, growth bound)
     struct BlaneSched *blane = nullptr; // block schedules: lane-parallel fast-order block Gauss-Seidel (pamg_blane_plan.h / pamg_blane.hip), built on demand
     bool blane_unfit = false;        // its planner declined (block rows too long, block size not compiled, not f64)
 };
@@ -212,6 +214,8 @@ struct pamg_matrix_s {
     int lane_L = 0, lane_G = 0;      // fast order: lanes per row (0 = automatic) / persistent workgroups (0 = automatic)   (tune keys 25, 26)
     int lane_flags = 1;              // fast order: bit 0 = gate operand (a wave that runs ahead polls one value instead of all its operands), bit 3 = gate in the line scan   (tune key 28)
     int line_scan = 1;               // fast order: line-scan sweep where consecutive rows are coupled (grid stencils), tried before the lane form   (tune key 30)
+    int lane_merge = 0;              // fast order: dependency levels merged into one super-level at most (0 = automatic, 1 = never, 2..8)   (tune key 33)
+    int lanem_ahead10 = 23;          // merged form: waves launched = this / 10 x the rows of an average super-level   (tune key 34)
     int lane_wide = 0;               // fast order on wide schedules (>= 2048 rows per dependency level): 0 = the tiled exact sweep keeps them, 1 = lane form   (tune key 27)
     int gs_cap = 0;                  // entries per row range of the level schedules (tune key 20; 0 = automatic: `cap`, 512 on the multi-XCD granular sweep of SA-like rows)
     int nblk = 0;
@@ -307,6 +311,11 @@ size_t lane_part_bytes(const GsSchedule *g);
 int lane_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s);
 int lane_info(const GsSchedule *g, int64_t *info);
 int lane_profile(const GsSchedule *g, long long *out, int64_t cap, int64_t *n);
+int lanem_smax(const pamg_matrix_s *A, const GsSchedule *g);
+int build_lanem_part(pamg_matrix_s *A, GsSchedule *g);
+void free_lanem_part(struct LaneMSched *t);
+size_t lanem_part_bytes(const GsSchedule *g);
+int lanem_info(const GsSchedule *g, int64_t *info, double *growth);
 int sweep_error(pamg_matrix_s *A, bool *error);      // spin bound hit since the last call? (caller has synchronised; clears the flag)
 inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }
 

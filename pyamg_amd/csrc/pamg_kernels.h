@@ -314,8 +314,6 @@ __device__ __forceinline__ void stage_products(const StreamArgs<T> &a, int p0, i
         // LDS stores.  base is even, so every pair is naturally aligned; the operator's
         // arrays are padded so the pair straddling p1 stays inside the allocation.
         using T2 = typename Vec2<T>::type;
-        typedef int int2n __attribute__((ext_vector_type(2)));
-        typedef T T2n __attribute__((ext_vector_type(2)));
         const bool nt = (a.flags & 1) != 0;               // stream the operator past the caches
         if (a.Aj16) {
             // 16-bit column stream: every column of this row range lies in one of (up to) four windows of 16 K columns;

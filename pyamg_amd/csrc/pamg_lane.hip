@@ -26,6 +26,7 @@
 // what a dependency level costs -- profiles/r05_microbench_lane_tail_*_not_kept.json, DESIGN 3.
 #include "pamg_common.h"
 #include "pamg_lane_plan.h"
+#include "pamg_lanem_plan.h"
 
 namespace pamg {
 
@@ -346,6 +347,198 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
     }
 }
 
+
+// =================================================================== the MERGED form (round 6; layout and algebra: pamg_lanem_plan.h)
+// s consecutive dependency levels of the sweep are eliminated into ONE super-level at plan time: the sweep pays one hand-off per
+// super-level instead of one per level.  One row per wave (64 lanes share it), K = 1..8 operand slots per lane chosen PER ROW (the
+// record of a group carries the first 64-slot unit and K), three kinds of operands: NEW values of earlier super-levels (polled in xs),
+// OLD values (the snapshot of x taken by lanem_prepare_kernel) and entries of b.  f64, Gauss-Seidel only (SOR's merged coefficients
+// would depend on the relaxation parameter of the call).
+struct alignas(32) LaneMRec { int rid; int gate; int rd_lo; int rd_hi; int unit; int K; int pad0; int pad1; };
+
+struct LaneMSched {
+    int64_t ngroups = 0, n_units = 0;
+    int nsuper = 0, nlevels = 0, s_max = 0, max_len = 0;
+    int closed_by_length = 0, closed_by_growth = 0;
+    double max_growth = 0.0;
+    int64_t n_early = 0, n_old = 0, n_b = 0, max_super_groups = 0;
+    int *d_cols = nullptr;
+    double *d_vals = nullptr;
+    LaneMRec *d_rec = nullptr;
+    int last_grid = 0;
+    int cap = 0;
+    const void *cap_kernel = nullptr;
+    size_t bytes = 0;
+};
+
+struct LaneMArgs {
+    const int *cols;
+    const double *vals;
+    const LaneMRec *rec;
+    const double *xold;    // snapshot of x from before the sweep
+    double *y;             // the live x
+    double *xs;            // hand-off buffer, sentinel-filled
+    const double *b;
+    unsigned *err;
+    unsigned *ticket;
+    int ngroups, nidle, use_gate;
+};
+
+// x -> snapshot, sentinels -> hand-off buffer: the two passes every merged sweep starts with, in one launch
+__global__ __launch_bounds__(BLK) void lanem_prepare_kernel(const double *__restrict__ x, double *__restrict__ xold, double *__restrict__ xs, int64_t n)
+{
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(xs);
+    for (int64_t i = (int64_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLK) {
+        xold[i] = x[i];
+        p[i] = Sentinel<double>::value;
+    }
+}
+
+template <int K, int MODE>
+__device__ __forceinline__ void lanem_group(const LaneMArgs &a, int rid, int gate, double rd, int unit, int idle)
+{
+    using T = double;
+    const int lane = threadIdx.x & 63;
+    const size_t e0 = (size_t)unit * 64 + (size_t)lane;
+    int c[K];
+    T v[K], xv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        c[k] = a.cols[e0 + (size_t)k * 64];
+        v[k] = a.vals[e0 + (size_t)k * 64];
+    }
+    const int row = rid & LANE_MASK;
+    const T bv = a.b[row];
+    T xo = T(0);
+    if (rid & LANE_NODIAG) xo = a.xold[row];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int col = c[k] & LANEM_MASK;
+        const T *p = (c[k] & LANE_NONE) ? a.xold + idle : ((c[k] & LANE_EARLY) ? a.xs + col : ((c[k] & LANEM_BSRC) ? a.b + col : a.xold + col));
+        xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned pend = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if ((c[k] & LANE_EARLY) && !(c[k] & LANE_NONE) && Sentinel<T>::bits(xv[k]) == Sentinel<T>::value) pend |= 1u << k;
+    unsigned spins = 0;
+    if (gate >= 0 && __builtin_amdgcn_ballot_w64(pend != 0)) {
+        const T *gp = a.xs + gate;
+        while (true) {
+            const T gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (Sentinel<T>::bits(gv) != Sentinel<T>::value) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0 && (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) break;
+        }
+    }
+    while (pend) {
+        if (spins) __builtin_amdgcn_s_sleep(1);
+        T t[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            t[k] = __hip_atomic_load(((pend >> k) & 1u) ? a.xs + (c[k] & LANEM_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if ((pend >> k) & 1u) {
+                xv[k] = t[k];
+                if (Sentinel<T>::bits(t[k]) != Sentinel<T>::value) pend &= ~(1u << k);
+            }
+        if ((++spins & 1023u) == 0) {
+            if (spins > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    T s = T(0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const T pr = v[k] * xv[k];
+        s = s + ((c[k] & LANE_NONE) ? T(0) : pr);
+    }
+    s = seg_allreduce<64, T>(s);
+    if (lane == 0) {
+        const bool upd = !(rid & LANE_NODIAG);
+        T val = (bv - s) * rd;
+        if (!upd) val = xo;
+        if constexpr (MODE == 1) __hip_atomic_store(a.xs + row, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(a.xs + row, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (upd) a.y[row] = val;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void lanem_dispatch(const LaneMArgs &a, const int4 &q0, const int4 &q1, int idle)
+{
+    // everything in the record is the same for the 64 lanes: scalar registers, a uniform branch on K
+    const int rid = __builtin_amdgcn_readfirstlane(q0.x);
+    const int gate = a.use_gate ? __builtin_amdgcn_readfirstlane(q0.y) : -1;
+    const double rd = __hiloint2double(__builtin_amdgcn_readfirstlane(q0.w), __builtin_amdgcn_readfirstlane(q0.z));
+    const int unit = __builtin_amdgcn_readfirstlane(q1.x);
+    const int K = __builtin_amdgcn_readfirstlane(q1.y);
+    switch (K) {
+        case 1: lanem_group<1, MODE>(a, rid, gate, rd, unit, idle); break;
+        case 2: lanem_group<2, MODE>(a, rid, gate, rd, unit, idle); break;
+        case 3: lanem_group<3, MODE>(a, rid, gate, rd, unit, idle); break;
+        case 4: lanem_group<4, MODE>(a, rid, gate, rd, unit, idle); break;
+        case 5: lanem_group<5, MODE>(a, rid, gate, rd, unit, idle); break;
+        case 6: lanem_group<6, MODE>(a, rid, gate, rd, unit, idle); break;
+        case 7: lanem_group<7, MODE>(a, rid, gate, rd, unit, idle); break;
+        default: lanem_group<8, MODE>(a, rid, gate, rd, unit, idle); break;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLK) void gs_lanem_kernel(const LaneMArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int idle = (int)((((unsigned)blockIdx.x * LANE_WPB + (unsigned)wib) * 16u) % (unsigned)a.nidle);
+    const int4 *rp = reinterpret_cast<const int4 *>(a.rec);
+    if constexpr (MODE != 1) {
+        const int W = (int)gridDim.x * LANE_WPB;
+        int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * LANE_WPB + wib);
+        const int gend = a.ngroups;
+        if (g >= gend) return;
+        int4 q0 = rp[2 * (size_t)g], q1 = rp[2 * (size_t)g + 1];
+        for (; g < gend; g += W) {
+            // the NEXT group's record (32 bytes, two requests) travels while this group waits; its slots are requested on arrival
+            const int gn = (g + W < gend) ? g + W : g;
+            const int4 n0 = rp[2 * (size_t)gn], n1 = rp[2 * (size_t)gn + 1];
+            lanem_dispatch<MODE>(a, q0, q1, idle);
+            q0 = n0; q1 = n1;
+        }
+    } else {
+        __shared__ int sh_home;
+        if (threadIdx.x == 0) {
+            const unsigned me = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1u;     // HW_REG_XCC_ID[3:0] + 1
+            unsigned home = 0u;
+            __hip_atomic_compare_exchange_strong(a.ticket + 1, &home, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_home = (home == 0u || home == me) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!sh_home) return;
+        // tickets in increasing order to running waves; a wave holds its group and the next one's ticket (record in flight)
+        unsigned tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int g = (int)__builtin_amdgcn_readfirstlane(tk);
+        if (g >= a.ngroups) return;
+        if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int g2 = (int)__builtin_amdgcn_readfirstlane(tk);
+        int4 q0 = rp[2 * (size_t)g], q1 = rp[2 * (size_t)g + 1];
+        while (true) {
+            const int gn = g2 < a.ngroups ? g2 : g;
+            const int4 n0 = rp[2 * (size_t)gn], n1 = rp[2 * (size_t)gn + 1];
+            unsigned tk3 = 0;
+            if (g2 < a.ngroups && lane == 0) tk3 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lanem_dispatch<MODE>(a, q0, q1, idle);
+            if (g2 >= a.ngroups) break;
+            g = g2; q0 = n0; q1 = n1;
+            g2 = (int)__builtin_amdgcn_readfirstlane(tk3);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 namespace {
 
@@ -546,6 +739,133 @@ int build_lane_part(pamg_matrix_s *A, GsSchedule *g)
 
 size_t lane_part_bytes(const GsSchedule *g) { return (g && g->lane) ? g->lane->bytes : 0; }
 
+// ---- merged form, host side
+void free_lanem_part(LaneMSched *t)
+{
+    if (!t) return;
+    hipFree(t->d_cols); hipFree(t->d_vals); hipFree(t->d_rec);
+    delete t;
+}
+
+size_t lanem_part_bytes(const GsSchedule *g) { return (g && g->lanem) ? g->lanem->bytes : 0; }
+
+// levels merged per super-level: tune key 33 (1 = unmerged form, >= 2 = that many), 0 = automatic -- rows long enough to fill a wave
+// (the SA coarse levels: >= 12 entries per row on average), f64
+int lanem_smax(const pamg_matrix_s *A, const GsSchedule *g)
+{
+    if (A->dtype != PAMG_F64 || A->R != 1 || g->nlevels < 8) return 1;
+    if (A->lane_merge == 1) return 1;
+    if (A->lane_merge >= 2) return A->lane_merge;
+    const char *e = getenv("PAMG_LANE_MERGE");
+    if (e && atoi(e) >= 1) return atoi(e);
+    if (A->nnz < 12 * std::max<int64_t>(1, A->nrows)) return 1;
+    return 3;
+}
+
+int build_lanem_part(pamg_matrix_s *A, GsSchedule *g)
+{
+    if (g->lanem) return PAMG_OK;
+    const int s_max = lanem_smax(A, g);
+    if (s_max < 2) return PAMG_E_ARG;
+    PhaseTimer pt_("build_lanem_part", A->nnz);
+    PlanVec<double> hAx;
+    hAx.resize((size_t)A->nnz + 1);
+    if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    LaneMPlan P;
+    if (build_lanem_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), hAx.data(), g->row_start, g->row_step, (int)g->nrows, g->nlevels, g->h_vis, g->h_lvl,
+                         s_max, 1e3, P))
+        return PAMG_E_ARG;
+    hAx = PlanVec<double>();
+    // nothing gained (every group closed at once: an operator the growth bound rejects): the unmerged form is the cheaper layout
+    if (P.nsuper * 10 > P.nlevels * 9) return PAMG_E_ARG;
+    LaneMSched *t = new (std::nothrow) LaneMSched();
+    if (!t) return PAMG_E_ALLOC;
+    t->ngroups = P.ngroups; t->n_units = P.n_units; t->nsuper = P.nsuper; t->nlevels = P.nlevels; t->s_max = s_max; t->max_len = P.max_len;
+    t->closed_by_length = P.closed_by_length; t->closed_by_growth = P.closed_by_growth; t->max_growth = P.max_growth;
+    t->n_early = P.n_early; t->n_old = P.n_old; t->n_b = P.n_b; t->max_super_groups = P.max_super_groups;
+    std::vector<LaneMRec> rec((size_t)P.ngroups);
+    lane_parallel(P.ngroups, [&](int64_t g0, int64_t g1) {
+        for (int64_t q = g0; q < g1; ++q) {
+            LaneMRec &R = rec[(size_t)q];
+            R.rid = P.rid[(size_t)q]; R.gate = P.gate[(size_t)q];
+            std::memcpy(&R.rd_lo, &P.rdiag[(size_t)q], 8);
+            R.unit = P.unit[(size_t)q]; R.K = P.K[(size_t)q]; R.pad0 = R.pad1 = 0;
+        }
+    });
+    int st = lane_upload(&t->d_rec, rec.data(), rec.size() * sizeof(LaneMRec), &t->bytes);
+    if (!st) st = lane_upload(&t->d_cols, P.cols.data(), P.cols.size() * sizeof(int), &t->bytes);
+    if (!st) st = lane_upload(&t->d_vals, P.vals.data(), P.vals.size() * sizeof(double), &t->bytes);
+    if (!st && !g->d_xold) {                                   // the snapshot of x (allocated here: sweeps may run inside a graph capture)
+        const size_t xb = ((size_t)A->nrows + 8) * sizeof(double);
+        st = (int)hipMalloc(&g->d_xold, xb);
+        if (!st) t->bytes += xb;
+    }
+    if (st) { free_lanem_part(t); return st; }
+    g->lanem = t;
+    g->bytes += t->bytes;
+    return PAMG_OK;
+}
+
+int lanem_launch(pamg_matrix_s *A, GsSchedule *g, void *x, const void *b, hipStream_t s)
+{
+    LaneMSched *t = g->lanem;
+    if (!t || !g->d_xold) return PAMG_E_STATE;
+    const int64_t n = A->nrows;
+    LaneMArgs a;
+    a.cols = t->d_cols; a.vals = t->d_vals; a.rec = t->d_rec;
+    a.use_gate = (A->lane_flags & 1) ? 1 : 0;
+    a.xold = (const double *)g->d_xold; a.y = (double *)x; a.xs = (double *)g->d_xs; a.b = (const double *)b;
+    a.err = g->d_sync + 1; a.ticket = g->d_sync + 20;
+    a.ngroups = (int)t->ngroups;
+    a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
+    const int fgrid = (int)std::min<int64_t>(4096, (n + BLK - 1) / BLK);
+    hipLaunchKernelGGL(lanem_prepare_kernel, dim3(fgrid), dim3(BLK), 0, s, (const double *)x, (double *)g->d_xold, (double *)g->d_xs, n);
+    PAMG_HIP(hipGetLastError());
+    const bool xcd = lane_one_xcd(A, g);
+    const void *k = xcd ? (const void *)gs_lanem_kernel<1> : (const void *)gs_lanem_kernel<0>;
+    static thread_local int cus = 0;
+    if (!cus) cus = device_cus_lane();
+    if (!(t->cap > 0 && t->cap_kernel == k)) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, BLK, 0) != hipSuccess) nb = 2;
+        t->cap = std::max(1, std::min(nb - 1, 8));
+        t->cap_kernel = k;
+    }
+    const int cap = t->cap;
+    // waves wanted: ~2.3 super-levels of look-ahead (one row per wave; the figure of the unmerged form, re-measured for this one: DESIGN 3 round 6)
+    const int per_level = (int)((t->ngroups + t->nsuper - 1) / std::max(1, t->nsuper));
+    const int64_t want_waves = std::max<int64_t>(128, ((int64_t)A->lanem_ahead10 * per_level + 9) / 10);
+    int G = (int)std::min<int64_t>((want_waves + LANE_WPB - 1) / LANE_WPB, (int64_t)cap * cus);
+    if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + LANE_WPB - 1) / LANE_WPB));
+    void *args[] = {(void *)&a};
+    if (xcd) {
+        PAMG_HIP(hipMemsetAsync(g->d_sync + 20, 0, 2 * sizeof(unsigned), s));
+        const int Gx = std::max(1, std::min(G, (cus / 8) * cap));
+        t->last_grid = 8 * Gx;
+        PAMG_HIP(hipLaunchKernel(k, dim3(8 * Gx), dim3(BLK), args, 0, s));
+        return PAMG_OK;
+    }
+    t->last_grid = G;
+    PAMG_HIP(hipLaunchKernel(k, dim3(G), dim3(BLK), args, 0, s));
+    return PAMG_OK;
+}
+
+// info[0..11] = super-levels, dependency levels, groups (rows), 64-slot units, early / old / b operands, longest merged row, levels merged at most,
+//               groups closed early by length / by growth, workgroups of the last launch;  growth = largest accepted growth factor
+int lanem_info(const GsSchedule *g, int64_t *info, double *growth)
+{
+    for (int i = 0; i < 12; ++i) info[i] = 0;
+    if (growth) *growth = 0.0;
+    if (!g || !g->lanem) return PAMG_OK;
+    const LaneMSched *t = g->lanem;
+    info[0] = t->nsuper; info[1] = t->nlevels; info[2] = t->ngroups; info[3] = t->n_units; info[4] = t->n_early; info[5] = t->n_old; info[6] = t->n_b;
+    info[7] = t->max_len; info[8] = t->s_max; info[9] = t->closed_by_length; info[10] = t->closed_by_growth; info[11] = t->last_grid;
+    if (growth) *growth = t->max_growth;
+    return PAMG_OK;
+}
+
+
 // workgroups of the static form that are certainly co-resident: (occupancy - 1, at most 8) per CU -- the occupancy query
 // can over-report by one per CU (MI355X_MICROARCH.md).  Asked once per schedule and kernel, not per sweep.
 static int lane_grid_cap(LaneSched *t, const void *k)
@@ -626,7 +946,14 @@ static int lane_launch_t(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, cons
 
 int lane_launch(pamg_matrix_s *A, GsSchedule *g, int epi, void *x, const void *b, double omega, hipStream_t s)
 {
-    if (!g->lane) return PAMG_E_STATE;
+    if (g->lanem && epi != EPI_SOR && A->dtype == PAMG_F64) return lanem_launch(A, g, x, b, s);
+    if (!g->lane) {
+        // an SOR sweep on an operator that holds the merged layout only (a bare operator tuned by hand; a solver announces SOR before its
+        // schedules are built, pamg_solver.hip: prebuild_schedules): the unmerged layout is built now -- allocations, so not inside a graph capture
+        const size_t before = g->bytes;
+        PAMG_TRY(build_lane_part(A, g));
+        A->bytes += g->bytes - before;
+    }
     if (A->dtype == PAMG_F64) return lane_launch_t<double>(A, g, epi, x, b, omega, s);
     return lane_launch_t<float>(A, g, epi, x, b, omega, s);
 }

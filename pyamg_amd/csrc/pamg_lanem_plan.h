@@ -1,0 +1,296 @@
+// pamg_lanem_plan.h -- host-side plan of the MERGED lane-parallel Gauss-Seidel sweep (plain C++, no HIP: the CPU suite
+// compiles this header with g++ and replays the plan, tests/lanem_emul.cpp).
+//
+// Why.  The lane-parallel sweep (pamg_lane_plan.h) keeps the reference's order of rows (amg_core::gauss_seidel,
+// relaxation.h:48-76) and pays ONE hand-off through memory per dependency level of that order: level 1 of the 256^3
+// SA hierarchy 2 241 levels x 1.01 us = 2.27 ms for 0.82 GB (0.045 of the HBM peak).  The per-hop price is the part's
+// (MI355X_MICROARCH.md, handoff-1to1); what is NOT fixed by the reference's order is the NUMBER of hops: s consecutive
+// dependency levels can be eliminated algebraically into one "super-level".
+//
+// The algebra.  With the rows of a group G of s consecutive levels, the sequential sweep computes
+//     (D + L_in) x_G = b_G - L_out x_new - U x_old
+// (L_in: entries whose column is an earlier row of the SAME group, L_out: earlier rows of earlier groups, U: rows visited
+// later -- or never).  L_in is nilpotent (depth < s), so
+//     x_G = T_G (b_G - L_out x_new - U x_old),   T_G = (D + L_in)^-1 = sum_{k<s} (-D^-1 L_in)^k D^-1 .
+// Row i of that product is again a row of the lane form -- x_i = (b_i - sum_k v_k * operand_k) / a_ii -- with three kinds of
+// operands: NEW values of rows of EARLIER groups (polled in the hand-off buffer, as before), OLD values (read from a
+// snapshot of x taken before the sweep: a merged row reads old values of rows it is not adjacent to, so the waits no
+// longer order those reads before the writes), and entries of b (rows of its own group).  Same iterates in exact
+// arithmetic; in floating point the merged sweep differs from the sequential one by rounding (a few 1e-16 measured on SA
+// levels; the per-row growth factor sum_r |T_ir| |a_ii| is computed at plan time and a group is CLOSED early -- down to
+// s = 1, the unmerged row -- where it exceeds `growth_cap`, e.g. operators that are not diagonally dominant).
+// The recursion used below (v = coefficient in "a_ii x_i = b_i - sum v * operand"): for every in-group operand r of row i
+// with f = a_ir / a_rr:   v_i[b_r] += f,   v_i[op] -= f * v_r[op] for every operand of the (already merged) row r;
+// a row r without a usable diagonal is left untouched by the reference (relaxation.h:72-74): its new value IS its old
+// value, so it contributes a_ir to v_i[old x_r].
+//
+// Layout.  One row per wave (64 lanes share a row; rows of K * 64 operand slots, K = 1..LANEM_KMAX chosen PER ROW): group g
+// = the g-th row in (super-level, dependency level, visit) order; its record {row | NODIAG, gate, 1 / a_ii, first 64-slot
+// unit, K} gives the address of its slots:
+//     cols[(unit + k) * 64 + lane]   column | EARLY (bit 31: poll the hand-off buffer) | NONE (bit 30: padding)
+//                                           | BSRC (bit 29: the operand is b[column])
+//     vals[(unit + k) * 64 + lane]   v
+// A group only waits for groups of EARLIER super-levels (smaller numbers): the static wave assignment g = w, w + W, ...
+// stays deadlock-free.  SOR is not merged (its coefficients depend on the relaxation parameter of the call).
+#pragma once
+#include <cmath>
+
+#include "pamg_lane_plan.h"
+
+namespace pamg {
+
+constexpr int LANEM_BSRC = 0x20000000;        // operand read from b
+constexpr int LANEM_MASK = 0x1FFFFFFF;        // column of a slot
+constexpr int LANEM_KMAX = 8;                 // slots per lane: merged rows of up to 512 operands
+
+struct LaneMPlan {
+    int s_max = 0;
+    int nlevels = 0;                          // dependency levels of the sweep (hand-offs of the unmerged form)
+    int nsuper = 0;                           // super-levels = hand-offs of this form
+    int64_t ngroups = 0;                      // visited rows (one row per group)
+    int64_t n_units = 0;                      // 64-slot units of cols / vals
+    std::vector<int> unit;                    // [ngroups] first unit of the group
+    std::vector<unsigned char> K;             // [ngroups] units of the group
+    std::vector<int> rid;                     // [ngroups] row | LANE_NODIAG
+    std::vector<int> gate;                    // [ngroups] gate operand (pamg_lane_plan.h) in terms of super-levels, or -1
+    std::vector<double> rdiag;                // [ngroups] 1 / a_ii (0: no usable diagonal)
+    std::vector<int> super_of;                // [ngroups] super-level of the group
+    std::vector<int64_t> super_grp;           // [nsuper + 1] group range of each super-level
+    PlanVec<int> cols;
+    PlanVec<double> vals;
+    int64_t n_early = 0, n_old = 0, n_b = 0;  // operands by kind
+    int64_t n_direct = 0;                     // off-diagonal entries of the visited rows (what the unmerged form holds)
+    int max_len = 0;                          // longest merged row (operands)
+    int closed_by_length = 0, closed_by_growth = 0;   // groups closed before s_max levels were in
+    double max_growth = 0.0;                  // largest accepted growth factor
+    int64_t max_super_groups = 0;             // rows of the widest super-level
+};
+
+namespace lanem_detail {
+
+struct Spa {                                  // sparse accumulator over (kind, column); kinds 0 = early, 1 = old, 2 = b
+    std::vector<double> val[3];
+    std::vector<int> stamp[3];
+    std::vector<int> touched;                 // codes (column | kind bits) in first-touch order
+    int token = 0;
+    void init(int n) { for (int k = 0; k < 3; ++k) { val[k].assign((size_t)n, 0.0); stamp[k].assign((size_t)n, 0); } token = 0; }
+    void begin() { ++token; touched.clear(); }
+    static int code(int kind, int col) { return col | (kind == 0 ? LANE_EARLY : kind == 2 ? LANEM_BSRC : 0); }
+    static int kind_of(int c) { return (c & LANE_EARLY) ? 0 : (c & LANEM_BSRC) ? 2 : 1; }
+    void add(int kind, int col, double v)
+    {
+        if (stamp[kind][(size_t)col] != token) { stamp[kind][(size_t)col] = token; val[kind][(size_t)col] = v; touched.push_back(code(kind, col)); }
+        else val[kind][(size_t)col] += v;
+    }
+};
+
+struct RowRef { int64_t off = 0; int len = 0; int arena = -1; };
+
+}  // namespace lanem_detail
+
+// Build the plan from a finished analysis of the sweep (vis / lvl of sweep_levels; m visited rows in nl levels).  Ax: the
+// operator's values (f64).  s_max >= 1 levels per super-level at most.  Returns 0, or 1 when the form does not fit (a row
+// longer than LANEM_KMAX * 64 operands even unmerged, index range) -- the caller keeps the unmerged lane form.
+inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *Ax, int row_start, int row_step, int m, int nl,
+                            const std::vector<int> &vis, const std::vector<int> &lvl, int s_max, double growth_cap, LaneMPlan &P,
+                            int len_cap = LANEM_KMAX * 64)
+{
+    using namespace lanem_detail;
+    P = LaneMPlan();
+    P.s_max = s_max; P.nlevels = nl;
+    if (m <= 0 || nl <= 0 || s_max < 1) return 1;
+    if (n > LANEM_MASK) return 1;
+    len_cap = std::max(1, std::min(len_cap, LANEM_KMAX * 64));
+    // rows in level order, visit order inside a level
+    std::vector<int64_t> lptr((size_t)nl + 1, 0);
+    for (int t = 0; t < m; ++t) lptr[(size_t)lvl[row_start + (int64_t)t * row_step] + 1]++;
+    for (int l = 0; l < nl; ++l) lptr[l + 1] += lptr[l];
+    std::vector<int> order((size_t)m);
+    {
+        std::vector<int64_t> cur(lptr.begin(), lptr.end() - 1);
+        for (int t = 0; t < m; ++t) {
+            const int i = row_start + t * row_step;
+            order[(size_t)cur[(size_t)lvl[i]]++] = i;
+        }
+    }
+    // last stored diagonal of every row (relaxation.h:64-69)
+    std::vector<double> diag((size_t)n, 0.0);
+    lane_parallel(n, [&](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i)
+            for (int p = Ap[i]; p < Ap[i + 1]; ++p) if (Aj[p] == (int)i) diag[(size_t)i] = Ax[p];
+    });
+    // ---- merged rows, window after window of 4 * s_max levels; windows are independent (a merged row only refers to merged rows of
+    //      its own window) and are what the host threads share out.  Inside a window the levels are taken greedily: a super-level is
+    //      closed when it holds s_max levels, or in front of a level whose merged rows would come out too long / too large
+    const int wlev = 4 * s_max;
+    const int nblocks = (nl + wlev - 1) / wlev;
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw, (int64_t)nblocks, std::max<int64_t>(1, (int64_t)m / 4096)}));
+    std::vector<std::vector<int>> acode((size_t)nt);
+    std::vector<std::vector<double>> aval((size_t)nt);
+    std::vector<RowRef> ref((size_t)n);
+    std::vector<unsigned char> starts((size_t)nl, 0);          // level l opens a super-level
+    std::vector<int> cl_len((size_t)nt, 0), cl_gr((size_t)nt, 0);
+    std::vector<double> mg((size_t)nt, 0.0);
+    std::atomic<int> unfit(0);
+    auto work = [&](int tid) {
+        Spa spa;
+        spa.init(n);
+        std::vector<int> &ac = acode[(size_t)tid];
+        std::vector<double> &av = aval[(size_t)tid];
+        std::vector<std::pair<int, double>> sub;
+        const int b0 = (int)((int64_t)nblocks * tid / nt), b1 = (int)((int64_t)nblocks * (tid + 1) / nt);
+        for (int blk = b0; blk < b1 && !unfit.load(); ++blk) {
+            const int lb0 = blk * wlev, lb1 = std::min(nl, lb0 + wlev);
+            int l0 = lb0;                                     // first level of the open super-level
+            starts[(size_t)lb0] = 1;
+            for (int l = lb0; l < lb1; ++l) {
+                if (l - l0 >= s_max) { l0 = l; starts[(size_t)l] = 1; }      // the open super-level is full
+                for (int attempt = 0; attempt < 2; ++attempt) {
+                    const size_t mark = ac.size();
+                    bool too_long = false, too_large = false;
+                    double level_growth = 0.0;
+                    for (int64_t q = lptr[l]; q < lptr[l + 1]; ++q) {
+                        const int i = order[(size_t)q], ti = vis[i];
+                        spa.begin();
+                        sub.clear();
+                        for (int p = Ap[i]; p < Ap[i + 1]; ++p) {
+                            const int j = Aj[p];
+                            if (j == i || j < 0 || j >= n) continue;
+                            const bool early = vis[j] >= 0 && vis[j] < ti;
+                            if (early && lvl[j] >= l0) sub.emplace_back(j, Ax[p]);
+                            else spa.add(early ? 0 : 1, j, Ax[p]);
+                        }
+                        double growth = 1.0;
+                        for (const auto &sr : sub) {
+                            const int r = sr.first;
+                            const double d = diag[(size_t)r];
+                            if (!(d != 0.0)) { spa.add(1, r, sr.second); continue; }     // untouched row: its new value is its old value
+                            const double f = sr.second / d;
+                            spa.add(2, r, f);
+                            const RowRef &rr = ref[(size_t)r];
+                            const int *rc = acode[(size_t)rr.arena].data() + rr.off;
+                            const double *rv = aval[(size_t)rr.arena].data() + rr.off;
+                            for (int e = 0; e < rr.len; ++e) spa.add(Spa::kind_of(rc[e]), rc[e] & LANEM_MASK, -f * rv[e]);
+                        }
+                        RowRef me;
+                        me.arena = tid; me.off = (int64_t)ac.size(); me.len = (int)spa.touched.size();
+                        for (int c : spa.touched) {
+                            const int kind = Spa::kind_of(c);
+                            const double v = spa.val[kind][(size_t)(c & LANEM_MASK)];
+                            ac.push_back(c);
+                            av.push_back(v);
+                            if (kind == 2) growth += std::fabs(v);
+                        }
+                        if (!std::isfinite(growth)) growth = INFINITY;
+                        ref[(size_t)i] = me;
+                        if (me.len > len_cap) too_long = true;
+                        if (growth > growth_cap) too_large = true;
+                        level_growth = std::max(level_growth, growth);
+                    }
+                    if (!too_long && !too_large) { mg[(size_t)tid] = std::max(mg[(size_t)tid], level_growth); break; }
+                    if (l == l0) {
+                        // the rows of this level as they are (no substitution): growth is 1; a row too long for the form ends it
+                        if (too_long) unfit.store(1);
+                        break;
+                    }
+                    // close the open super-level in front of this level and take the level again, unmerged
+                    ac.resize(mark);
+                    av.resize(mark);
+                    if (too_long) cl_len[(size_t)tid]++; else cl_gr[(size_t)tid]++;
+                    l0 = l;
+                    starts[(size_t)l] = 1;
+                }
+                if (unfit.load()) break;
+            }
+        }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    if (unfit.load()) return 1;
+    for (int t = 0; t < nt; ++t) { P.closed_by_length += cl_len[(size_t)t]; P.closed_by_growth += cl_gr[(size_t)t]; P.max_growth = std::max(P.max_growth, mg[(size_t)t]); }
+    // ---- super-levels, groups, units
+    std::vector<int> sup_of_level((size_t)nl, 0);
+    {
+        int s = -1;
+        for (int l = 0; l < nl; ++l) { if (starts[(size_t)l]) ++s; sup_of_level[(size_t)l] = s; }
+        P.nsuper = s + 1;
+    }
+    P.ngroups = m;
+    P.unit.assign((size_t)m, 0); P.K.assign((size_t)m, 1); P.rid.assign((size_t)m, -1); P.gate.assign((size_t)m, -1);
+    P.rdiag.assign((size_t)m, 0.0); P.super_of.assign((size_t)m, 0);
+    P.super_grp.assign((size_t)P.nsuper + 1, 0);
+    for (int l = 0; l < nl; ++l) P.super_grp[(size_t)sup_of_level[(size_t)l] + 1] = lptr[l + 1];
+    for (int s = 0; s < P.nsuper; ++s) P.max_super_groups = std::max(P.max_super_groups, P.super_grp[s + 1] - P.super_grp[s]);
+    int64_t units = 0;
+    for (int64_t g = 0; g < m; ++g) {
+        const int i = order[(size_t)g];
+        const bool nodiag = !(diag[(size_t)i] != 0.0);
+        const int len = nodiag ? 0 : ref[(size_t)i].len;
+        const int k = std::max(1, (len + 63) / 64);
+        P.unit[(size_t)g] = (int)units;
+        P.K[(size_t)g] = (unsigned char)k;
+        units += k;
+        if (units >= ((int64_t)1 << 31)) return 1;
+        P.rid[(size_t)g] = i | (nodiag ? LANE_NODIAG : 0);
+        P.rdiag[(size_t)g] = nodiag ? 0.0 : 1.0 / diag[(size_t)i];
+        P.super_of[(size_t)g] = sup_of_level[(size_t)lvl[i]];
+        P.max_len = std::max(P.max_len, len);
+    }
+    P.n_units = units;
+    // super-level of every visited row, and its latest early operand (the gate rule of pamg_lane_plan.h on super-levels)
+    std::vector<int> sup_row((size_t)n, -1), best_dep((size_t)n, -1);
+    lane_parallel(m, [&](int64_t g0, int64_t g1) { for (int64_t g = g0; g < g1; ++g) sup_row[(size_t)order[(size_t)g]] = P.super_of[(size_t)g]; });
+    lane_parallel(m, [&](int64_t g0, int64_t g1) {
+        for (int64_t g = g0; g < g1; ++g) {
+            const int i = order[(size_t)g];
+            if (P.rid[(size_t)g] & LANE_NODIAG) continue;
+            const RowRef &rr = ref[(size_t)i];
+            const int *rc = acode[(size_t)rr.arena].data() + rr.off;
+            int bl = -1;
+            for (int e = 0; e < rr.len; ++e)
+                if (rc[e] & LANE_EARLY) {
+                    const int j = rc[e] & LANEM_MASK;
+                    if (sup_row[(size_t)j] > bl) { bl = sup_row[(size_t)j]; best_dep[(size_t)i] = j; }
+                }
+        }
+    });
+    plan_fill(P.cols, (size_t)units * 64, (int)LANE_NONE);
+    plan_fill(P.vals, (size_t)units * 64, 0.0);
+    std::vector<int64_t> cnt((size_t)3 * 64, 0);               // per-thread-slot statistics would need atomics: count per chunk below
+    std::atomic<int64_t> ne(0), no(0), nb(0), nd(0);
+    lane_parallel(m, [&](int64_t g0, int64_t g1) {
+        int64_t e_ = 0, o_ = 0, b_ = 0, d_ = 0;
+        for (int64_t g = g0; g < g1; ++g) {
+            const int i = order[(size_t)g];
+            for (int p = Ap[i]; p < Ap[i + 1]; ++p) d_ += (Aj[p] != i && Aj[p] >= 0 && Aj[p] < n);
+            if (P.rid[(size_t)g] & LANE_NODIAG) continue;
+            const RowRef &rr = ref[(size_t)i];
+            const int *rc = acode[(size_t)rr.arena].data() + rr.off;
+            const double *rv = aval[(size_t)rr.arena].data() + rr.off;
+            const size_t s0 = (size_t)P.unit[(size_t)g] * 64;
+            const int mysup = P.super_of[(size_t)g];
+            int gl = -1;
+            for (int e = 0; e < rr.len; ++e) {
+                P.cols[s0 + (size_t)e] = rc[e];
+                P.vals[s0 + (size_t)e] = rv[e];
+                if (rc[e] & LANE_EARLY) {
+                    ++e_;
+                    int cand = rc[e] & LANEM_MASK;
+                    if (sup_row[(size_t)cand] > mysup - 2) cand = best_dep[(size_t)cand];
+                    if (cand >= 0 && sup_row[(size_t)cand] <= mysup - 2 && sup_row[(size_t)cand] > gl) { gl = sup_row[(size_t)cand]; P.gate[(size_t)g] = cand; }
+                } else if (rc[e] & LANEM_BSRC) ++b_;
+                else ++o_;
+            }
+        }
+        ne += e_; no += o_; nb += b_; nd += d_;
+    });
+    P.n_early = ne.load(); P.n_old = no.load(); P.n_b = nb.load(); P.n_direct = nd.load();
+    return 0;
+}
+
+}  // namespace pamg

@@ -366,6 +366,7 @@ void free_schedule(GsSchedule *g)
     if (!g) return;
     free_tile_part(g->tile);
     free_lane_part(g->lane);
+    free_lanem_part(g->lanem);
     free_blane_part(g->blane);
     free_line_part(g->line);
     hipFree(g->d_Ap); hipFree(g->d_Aj); hipFree(g->d_Ax); hipFree(g->d_rid); hipFree(g->d_blkmeta); hipFree(g->d_diag); hipFree(g->d_level_blk); hipFree(g->d_sync); hipFree(g->d_xs); hipFree(g->d_xold); hipFree(g->d_pblk); hipFree(g->d_dpos); hipFree(g->d_prof);
@@ -1152,7 +1153,15 @@ int ensure_parts(pamg_matrix_s *A, GsSchedule *g, bool block_gs)
         if (st != PAMG_E_ARG) return st;
         g->line_unfit = true;                              // no coupled runs / rows too long: the other schedulers take it
     }
-    if (want_lanes(A, g)) {
+    if (want_lanes(A, g) && !g->lanem && !g->lanem_unfit && !g->lane && lanem_smax(A, g) >= 2) {
+        // the merged form first (f64 Gauss-Seidel; an SOR smoother on this operator sets tune key 33 = 1 before its schedules are built)
+        const size_t before = g->bytes;
+        const int st = build_lanem_part(A, g);
+        if (st == PAMG_OK) { std::lock_guard<std::mutex> lk(g_sched_mu); A->bytes += g->bytes - before; return PAMG_OK; }
+        if (st != PAMG_E_ARG) return st;
+        g->lanem_unfit = true;
+    }
+    if (want_lanes(A, g) && !g->lanem) {
         const size_t before = g->bytes;
         const int st = build_lane_part(A, g);
         if (st == PAMG_OK) { std::lock_guard<std::mutex> lk(g_sched_mu); A->bytes += g->bytes - before; }
@@ -1847,6 +1856,8 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 25: if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64) return PAMG_E_ARG; A->lane_L = value; break;
         case 26: if (value < 0) return PAMG_E_ARG; A->lane_G = value; return PAMG_OK;
         case 27: if (value < 0 || value > 1) return PAMG_E_ARG; A->lane_wide = value; return PAMG_OK;
+        case 33: if (value < 0 || value > 8) return PAMG_E_ARG; A->lane_merge = value; break;
+        case 34: if (value < 1 || value > 400) return PAMG_E_ARG; A->lanem_ahead10 = value; return PAMG_OK;
         case 30:                                               // 2: also where the estimate favours the lane form
             if (value < 0 || value > 2) return PAMG_E_ARG;
             A->line_scan = value;
@@ -1857,11 +1868,13 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 28: if (value < 0 || value > 15 || (value & 6)) return PAMG_E_ARG; A->lane_flags = value; return PAMG_OK;      // bits 1, 2: retired (slab form, old values through the L1)
         default: return PAMG_E_ARG;
     }
-    if (key == 25) {                                  // lane geometry: drop the lane parts only
+    if (key == 25 || key == 33) {                     // lane geometry / merging: drop the lane parts only
         for (int k = 0; k < 4; ++k) {
             GsSchedule *g = A->gs[k];
             if (g) g->lane_unfit = false;
             if (g && g->lane) { const size_t lb = lane_part_bytes(g); A->bytes -= lb; g->bytes -= lb; free_lane_part(g->lane); g->lane = nullptr; }
+            if (g) g->lanem_unfit = false;
+            if (g && g->lanem) { const size_t lb = lanem_part_bytes(g); A->bytes -= lb; g->bytes -= lb; free_lanem_part(g->lanem); g->lanem = nullptr; }
             if (g) g->blane_unfit = false;
             if (g && g->blane) { const size_t lb = blane_part_bytes(g); A->bytes -= lb; g->bytes -= lb; free_blane_part(g->blane); g->blane = nullptr; }
             if (g) g->line_unfit = false;
@@ -2037,6 +2050,12 @@ int pamg_matrix_kz_info(pamg_matrix_t A, int which, int64_t info[8])
 {
     if (!A || !info || which < 0 || which > 3) return PAMG_E_ARG;
     return pamg::kz_lane_info(A->ls[which], info);
+}
+
+int pamg_matrix_lanem_info(pamg_matrix_t A, int which, int64_t info[12], double *growth)
+{
+    if (!A || !info || which < 0 || which > 3) return PAMG_E_ARG;
+    return pamg::lanem_info(A->gs[which], info, growth);
 }
 
 int pamg_matrix_lane_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count)

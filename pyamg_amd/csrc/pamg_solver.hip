@@ -475,6 +475,9 @@ int prebuild_schedules(Level &L, const Smoother &sm)
     }
     const bool gs = sm.kind == PAMG_SMOOTH_GS || sm.kind == PAMG_SMOOTH_SOR || sm.kind == PAMG_SMOOTH_BLOCK_GS;
     if (!gs || L.A->nrows == 0) return PAMG_OK;
+    // the merged lane form (pamg_lanem_plan.h) eliminates dependency levels with coefficients that would depend on SOR's relaxation
+    // parameter: an operator swept by SOR keeps the unmerged layout (one layout per schedule)
+    if (sm.kind == PAMG_SMOOTH_SOR && L.A->lane_merge == 0) L.A->lane_merge = 1;
     int r0, r1, rs;
     if (sm.sweep == PAMG_FORWARD || sm.sweep == PAMG_SYMMETRIC) {
         PAMG_TRY(sweep_bounds(L.A, PAMG_FORWARD, r0, r1, rs));

@@ -323,6 +323,103 @@ def test_gs_sweep_modes_all_exact():
             assert not dA.flow_error(), kw
 
 
+def test_gs_merged_fast_order_agrees_to_rounding():
+    """The MERGED fast order (round 6; tune lane_merge = s, csrc/pamg_lanem_plan.h, gs_lanem_kernel in pamg_lane.hip): s consecutive dependency
+    levels of the reference's sweep (relaxation.h:48-76) are eliminated algebraically into one super-level, the sweep pays one hand-off per
+    super-level.  Against the ORACLE's sequential sweep (1e-13 relative per call) and the order-exact device sweep, s = 2 .. 8, static form across the
+    chip and ticket form inside one XCD, with and without the gate operand, tiny grids (waves that wait), forward / backward / symmetric;
+    rows with zero / missing diagonals stay untouched; a structurally non-symmetric pattern; bit-reproducible; an operator that is NOT
+    diagonally dominant must make the planner close groups early (growth bound) or decline, and still give the sequential sweep's answer; SOR on
+    the same operator takes the unmerged layout; f32 keeps the unmerged form."""
+    from oracle import oracle as orc
+    rng = np.random.RandomState(11)
+
+    def sa_like(n, density, seed):
+        r = np.random.RandomState(seed)
+        S = sp.random(n, n, density=density, random_state=r, format="csr")
+        S = sp.csr_array(-abs(S + S.T))
+        S.setdiag(0)
+        S.eliminate_zeros()
+        d = np.asarray(abs(S).sum(axis=1)).ravel() + 0.5 + r.rand(n)
+        A = sp.csr_array(S + sp.diags_array(d))
+        A.sort_indices()
+        return A
+
+    S = sa_like(6000, 0.003, 1)                                              # ~36 entries per row
+    Z = sp.lil_array(sa_like(2500, 0.008, 2))
+    for i in range(0, 2500, 7):
+        Z[i, i] = 0.0
+    Z = sp.csr_array(Z)
+    N = sp.random(3000, 3000, density=0.006, random_state=rng, format="csr")
+    N = sp.csr_array(N + sp.diags_array(rng.rand(3000) + 6.0))                 # structurally non-symmetric
+    n_nd = 3000
+    main, off = np.full(n_nd, 1.0), np.full(n_nd - 1, -3.0)
+    off[23::24] = 0.0
+    ND = sp.csr_array(sp.diags_array([off, main, 0.1 * off], offsets=[-1, 0, 1]) + 0.01 * sa_like(n_nd, 0.006, 3))   # not diagonally dominant: chains of 24 rows with ratio 3
+    for ci, M in enumerate((S, Z, N, ND)):
+        op = sparse_op(M)
+        n = op.shape[0]
+        x, b = rng.rand(n), rng.rand(n)
+        ref = x.copy(); orc.relax_gauss_seidel(op, ref, b, 2, "symmetric")
+        reff = x.copy(); orc.relax_gauss_seidel(op, reff, b, 1, "forward")
+        refb = x.copy(); orc.relax_gauss_seidel(op, refb, b, 1, "backward")
+        refs = x.copy(); orc.relax_sor(op, refs, b, 1.3, 1, "forward")
+        tol = 1e-13 if ci != 3 else 1e-10                                    # growth factors up to the cap (1e3) cost up to three digits
+        dA = DeviceMatrix(op)
+        db, dx = capi.DeviceArray.from_host(b), capi.DeviceArray.from_host(x)
+        dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+        assert np.array_equal(dx.download(), ref)                           # a bare operator is order-exact
+        dA.tune(gs_order=1, lane_wide=1, line_scan=0)
+        hops = {}
+        for kw in (dict(lane_merge=1), dict(lane_merge=2), dict(lane_merge=3), dict(lane_merge=3, gran_xcd=1), dict(lane_merge=4, gran_xcd=2, lane_G=3),
+                   dict(lane_merge=8, gran_xcd=1, lane_G=1), dict(lane_merge=5, gran_xcd=0, lane_G=0, lane_flags=0), dict(lane_merge=0, lane_flags=1, lanem_ahead=60)):
+            dA.tune(**kw)
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+            got = dx.download()
+            mi = dA.lanem_info(0)
+            if kw["lane_merge"] == 1:
+                assert mi["rows"] == 0 and dA.lane_info(0)["groups"] > 0
+            elif ci != 3:
+                assert mi["rows"] == n and mi["super_levels"] < mi["dependency_levels"], (kw, ci, mi)   # the merged form really ran
+                assert mi["max_growth"] < 50.0
+            else:
+                assert mi["rows"] == 0 or (mi["closed_by_growth"] > 0 and mi["max_growth"] <= 1e3), (kw, mi)   # closed early or declined
+            hops[kw["lane_merge"]] = mi["super_levels"]
+            assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)), (kw, ci, np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+            assert np.array_equal(dx.download(), got), (kw, ci)              # the order of the additions is the layout's, never the timing's
+            for sw, r_ in (("forward", reff), ("backward", refb)):
+                dx.upload(x)
+                dA.gauss_seidel(dx, db, sweep=sw)
+                assert np.max(np.abs(dx.download() - r_)) <= tol * np.max(np.abs(r_)), (kw, ci, sw)
+            if ci == 1:
+                assert np.array_equal(got[0::7], x[0::7])                   # zero diagonals: untouched
+            dx.upload(x)
+            dA.gauss_seidel(dx, db, sweep="forward", omega=1.3)              # SOR: the unmerged layout of the same schedule
+            assert np.max(np.abs(dx.download() - refs)) <= tol * np.max(np.abs(refs)), (kw, ci)
+            assert not dA.flow_error(), kw
+        if ci == 0:
+            assert hops[2] <= (mi["dependency_levels"] + 1) // 2 + 2 and hops[3] < hops[2]
+        dA.tune(gs_order=0)
+        dx.upload(x)
+        dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
+        assert np.array_equal(dx.download(), ref)                           # and back to the reference's bits
+        dA.free(); dx.free(); db.free()
+    # f32: the merged form is f64-only, the unmerged lane form runs
+    op32 = sparse_op(sp.csr_array(S.astype(np.float32)))
+    dA = DeviceMatrix(op32)
+    dA.tune(gs_order=1, lane_wide=1, line_scan=0, lane_merge=3)
+    x32, b32 = rng.rand(op32.shape[0]).astype(np.float32), rng.rand(op32.shape[0]).astype(np.float32)
+    r32 = x32.copy(); orc.relax_gauss_seidel(op32, r32, b32, 1, "symmetric")
+    dx, db = capi.DeviceArray.from_host(x32), capi.DeviceArray.from_host(b32)
+    dA.gauss_seidel(dx, db, sweep="symmetric")
+    assert dA.lanem_info(0)["rows"] == 0 and dA.lane_info(0)["groups"] > 0
+    assert np.max(np.abs(dx.download() - r32)) <= 2e-6 * np.max(np.abs(r32))
+    dA.free(); dx.free(); db.free()
+
+
 def test_gs_fast_order_agrees_to_rounding():
     """Fast order (tune gs_order=1, pamg_lane.hip): same sweep order over the rows, lane-parallel row sums and
     multiplication by 1/a_ii -- every form (automatic lane width, forced widths, static assignment across the chip,
@@ -362,7 +459,7 @@ def test_gs_fast_order_agrees_to_rounding():
         dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
         assert np.array_equal(dx.download(), ref)                       # a bare operator is order-exact
         seen = set()
-        for kw in (dict(gs_order=1, lane_wide=1, line_scan=0), dict(lane_L=16), dict(lane_L=64), dict(lane_L=0, gran_xcd=1), dict(gran_xcd=2, lane_G=3),
+        for kw in (dict(gs_order=1, lane_wide=1, line_scan=0, lane_merge=1), dict(lane_L=16), dict(lane_L=64), dict(lane_L=0, gran_xcd=1), dict(gran_xcd=2, lane_G=3),
                    dict(gran_xcd=1, lane_G=1), dict(gran_xcd=0, lane_G=0, lane_L=8), dict(lane_flags=0), dict(lane_flags=1, gran_xcd=2)):
             dA.tune(**kw)
             dx.upload(x)
