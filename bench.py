@@ -138,12 +138,18 @@ def headline(out):
             h["parity"].update({"sharded_vs_resident_ok": sv.get("ok"), "sharded_vs_resident_max_rel_diff": sv.get("max_rel_diff")})
     if out.get("host"):
         h["host"] = _flat(out["host"])
+    ac = out.get("accel") or {}
+    for k, v in ac.items():
+        if k.startswith("hl_"):
+            h["accel_" + k[3:]] = v
     t = out.get("time_to_tol_1e-8") or {}
     if t:
         h["cycles_to_tol_1e-8"], h["seconds_to_tol_1e-8"] = t.get("cycles"), t.get("seconds")
     for r_ in (out.get("gs_sweeps") or {}).get("per_level", []):
         h[f"gs_sweep_ms_level{r_['level']}"] = r_.get("ms_per_forward_sweep")
         h[f"gs_sweep_dependency_levels_level{r_['level']}"] = r_.get("dependency_levels")
+        if r_.get("hand_offs") is not None:
+            h[f"gs_sweep_hand_offs_level{r_['level']}"] = r_.get("hand_offs")
     if isinstance(out.get("exact_order"), dict):
         h["exact_order_ms_per_step"] = out["exact_order"].get("ms_per_step")
     sh = out.get("sharded") or {}
@@ -483,6 +489,39 @@ def main():
             barrier()
             out_["seconds"] = round(time.perf_counter() - t0_, 5)
         xd_.free(); bd_.free()
+        return out_
+
+    def accel_leg(dml_, ml_, b_, x0_, accel, tol=1e-8, maxiter=200, ref_iters=4):
+        """f1: the way the reference is used (multilevel.py:479-535, blackbox.py:285-311) -- a Krylov method preconditioned by one cycle.  Device:
+        solve(b, tol, accel=...) with the Krylov loop resident (pamg_solver_pcg / gmres), host vectors in and out (the PCIe copies are inside
+        the time); the second of two runs is timed.  Reference: the same call with maxiter = ref_iters on the same hierarchy, histories compared."""
+        out_ = {"accel": accel, "tol": tol}
+        r1 = []
+        dml_.solve(b_, x0=x0_, tol=tol, maxiter=maxiter, accel=accel, residuals=r1)              # warm-up (graphs, work vectors)
+        r2 = []
+        t0_ = time.perf_counter()
+        dml_.solve(b_, x0=x0_, tol=tol, maxiter=maxiter, accel=accel, residuals=r2)
+        out_["seconds_to_tol"] = round(time.perf_counter() - t0_, 5)
+        out_["iterations"] = len(r2) - 1
+        out_["final_residual_over_first"] = float(r2[-1] / r2[0]) if r2 and r2[0] else None
+        out_["iterations_per_s"] = round((len(r2) - 1) / max(out_["seconds_to_tol"], 1e-9), 2)
+        if ref_iters > 0:
+            rr = []
+            t0_ = time.perf_counter()
+            ml_.solve(b_, x0=x0_, tol=tol, maxiter=ref_iters, accel=accel, residuals=rr)
+            tc_ = time.perf_counter() - t0_
+            m_ = min(len(rr), len(r2))
+            d_ = np.abs(np.asarray(rr[:m_]) - np.asarray(r2[:m_]))
+            out_["reference"] = {"iterations_timed": len(rr) - 1, "seconds": round(tc_, 2), "seconds_per_iteration": round(tc_ / max(1, len(rr) - 1), 3),
+                                 "norms_compared": int(m_), "max_abs_diff_over_r0": float(d_.max() / rr[0]), "tolerance": "1e-10 * ||r0||",
+                                 "ok": bool(d_.max() <= 1e-10 * rr[0])}
+            out_["cpu_seconds_to_tol_extrapolated"] = round(out_["reference"]["seconds_per_iteration"] * out_["iterations"], 1)
+        # scalars for the headline
+        out_["hl_" + accel + "_s_to_tol"] = out_["seconds_to_tol"]
+        out_["hl_" + accel + "_iterations"] = out_["iterations"]
+        if "reference" in out_:
+            out_["hl_" + accel + "_parity_ok"] = out_["reference"]["ok"]
+            out_["hl_" + accel + "_cpu_s_per_iteration"] = out_["reference"]["seconds_per_iteration"]
         return out_
 
     def cpu_from_protocol(pp, A, v):
@@ -914,11 +953,14 @@ def main():
             ms = g0.elapsed_ms(g1) / 5
             Ai = L.A.tocsr() if L.A.format != "csr" else L.A
             by = 12 * int(Ai.nnz) + 4 * (ni + 1) + 24 * ni            # Jacobi / GS / SOR sweep
-            lane, tile, line = dA.lane_info(0), dA.tile_info(0), dA.line_info(0)
-            sched = (f"line-scan fast order: {line['lines']} lines in {line['line_levels']} line levels, {line['launch_grid']} workgroups" if line["lines"] and dml_.order == "fast" and line["launch_grid"]
+            lane, tile, line, lanem = dA.lane_info(0), dA.tile_info(0), dA.line_info(0), dA.lanem_info(0)
+            sched = (f"merged lane-parallel fast order: up to {lanem['s_max']} dependency levels eliminated into one super-level, {lanem['super_levels']} hand-offs, "
+                     f"{lanem['units'] / max(1, lanem['rows']):.2f} x 64 operand slots per row, {lanem['launch_grid']} workgroups" if lanem["rows"] and dml_.order == "fast" and lanem["launch_grid"]
+                     else f"line-scan fast order: {line['lines']} lines in {line['line_levels']} line levels, {line['launch_grid']} workgroups" if line["lines"] and dml_.order == "fast" and line["launch_grid"]
                      else f"lane-parallel fast order: {lane['lanes_per_row']} lanes per row x {lane['slots_per_lane']}, {lane['launch_grid']} workgroups" if lane["groups"] and dml_.order == "fast" and lane["launch_grid"]
                      else f"tiled exact sweep: {tile['tiles']} tiles" if tile["tiles"] else "granular / single-workgroup exact sweep")
             rows_.append({"level": i, "rows": int(ni), "nnz": int(Ai.nnz), "dependency_levels": int(inf["gs_levels_fwd"]), "scheduler": sched,
+                          "hand_offs": int(lanem["super_levels"] if lanem["rows"] and dml_.order == "fast" and lanem["launch_grid"] else line["line_levels"] if line["lines"] and dml_.order == "fast" and line["launch_grid"] else inf["gs_levels_fwd"]),
                           "ms_per_forward_sweep": round(ms, 4), "us_per_dependency_level": round(1e3 * ms / inf["gs_levels_fwd"], 3),
                           "GBps": round(by / ms / 1e6, 1), "pct_of_hbm_peak": round(100 * by / ms / 1e6 / HBM_PEAK_GBPS, 2)})
             xs_.free(); bs_.free()
@@ -962,6 +1004,13 @@ def main():
         except Exception as e:                                  # noqa: BLE001
             ttt = {"error": repr(e)[:200]}
 
+    accel_main = None
+    if rank == 0 and world == 1 and args.cpu_cycles != 0 and not args.no_extras:
+        try:
+            accel_main = accel_leg(dml, ml, b, x0, "cg" if wl["smoother"] in (GS, JAC, CHEB) else "gmres", ref_iters=3 if n > 5_000_000 else 6)
+        except Exception as e:                                  # noqa: BLE001
+            accel_main = {"error": repr(e)[:200]}
+
     out = None
     cpu = parity = None
     if rank == 0 and world == 1 and args.cpu_cycles != 0:
@@ -1004,6 +1053,8 @@ def main():
             "time_to_tol_1e-8": ttt,
         }
         out["config"]["gs_order"] = dml.order
+        if accel_main:
+            out["accel"] = accel_main
         if sweeps:
             # what bounds the STEP (not the bandwidth kernel above): the sweep kernel with the largest share, on SURVEY 8(d)'s bytes
             dom = max(sweeps, key=lambda r_: r_["ms_per_forward_sweep"])
@@ -1117,6 +1168,12 @@ def main():
             ex["parity"] = parity_of(res3, r3cpu)
             ex["parity"]["reference_protocol"] = protocol_parity(d3, ml2, A2.shape[0])
         ex["time_to_tol_1e-8"] = time_to_tol(d3, b2, x02)
+        if args.cpu_cycles != 0:
+            try:
+                ex["accel"] = accel_leg(d3, ml2, b2, x02, "cg", ref_iters=6)
+                ex.update({k: v for k, v in ex["accel"].items() if k.startswith("hl_")})
+            except Exception as e:                              # noqa: BLE001
+                ex["accel"] = {"error": repr(e)[:200]}
         out["extra"] = {"c2": ex}
         d3.free()
       except Exception as e:                                    # noqa: BLE001
@@ -1187,6 +1244,12 @@ def main():
             ex6["speedup_vs_cpu_reference"] = round(ex6["value"] / c6cpu["value"], 1)
             ex6["parity"] = parity_of(res6, r6cpu)
             ex6["parity"]["reference_protocol"] = protocol_parity(d6, ml6, A6.shape[0])
+        if args.cpu_cycles != 0:
+            try:
+                ex6["accel"] = accel_leg(d6, ml6, b6, x06, "gmres", ref_iters=6)      # what pyamg.solve() runs on a non-symmetric operator (blackbox.py:285-289)
+                ex6.update({k: v for k, v in ex6["accel"].items() if k.startswith("hl_")})
+            except Exception as e:                              # noqa: BLE001
+                ex6["accel"] = {"error": repr(e)[:200]}
         out.setdefault("extra", {})["c6n3"] = ex6
         out["config"]["extra_c6n3_cycles_per_s"] = ex6["value"]
         out["config"]["extra_c6n3_vs_one_reference_core"] = ex6.get("speedup_vs_cpu_reference")

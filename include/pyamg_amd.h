@@ -400,6 +400,9 @@ int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8]);
  * runs unmerged.  The merged sweep computes the reference's Gauss-Seidel iterates (amg_core::gauss_seidel, relaxation.h:48-76) in another
  * association: equal in exact arithmetic, to rounding in floating point. */
 int pamg_matrix_lanem_info(pamg_matrix_t A, int which, int64_t info[12], double *growth);
+/* First row (in the merged plan's order) of every super-level, nsuper + 1 values; out == NULL: only *count.  With tune key 11 the merged sweep records per row
+ * {arrival | polling rounds << 52, operand slots arrived, all operands present, published} (pamg_matrix_lane_profile, 10 ns ticks). */
+int pamg_matrix_lanem_levels(pamg_matrix_t A, int which, int64_t *out, int64_t capacity, int64_t *count);
 /* Layout of the lane-parallel fast-order Kaczmarz sweep (tune key 24 = 1 on the operator handed to pamg_matrix_kaczmarz; csrc/pamg_kz_plan.h)
  * of the operator's `which`-th cached line schedule (0 .. 3, in the order the sweep ranges were first used): {lanes per line, entry slots per
  * lane, groups, dependency levels, groups of the widest level, workgroups of the last launch, bytes, 0}; all zero when that schedule has none. */

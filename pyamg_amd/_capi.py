@@ -128,6 +128,7 @@ def _declare(lib):
     f("pamg_matrix_tile_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_lane_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_lanem_info", _vp, _i, P(C.c_int64), P(C.c_double))
+    f("pamg_matrix_lanem_levels", _vp, _i, _vp, C.c_int64, P(C.c_int64))
     f("pamg_matrix_kz_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_line_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_lane_profile", _vp, _i, _vp, C.c_int64, P(C.c_int64))

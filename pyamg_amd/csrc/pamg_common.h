@@ -316,6 +316,7 @@ int build_lanem_part(pamg_matrix_s *A, GsSchedule *g);
 void free_lanem_part(struct LaneMSched *t);
 size_t lanem_part_bytes(const GsSchedule *g);
 int lanem_info(const GsSchedule *g, int64_t *info, double *growth);
+int lanem_levels(const GsSchedule *g, int64_t *out, int64_t cap, int64_t *n);
 int sweep_error(pamg_matrix_s *A, bool *error);      // spin bound hit since the last call? (caller has synchronised; clears the flag)
 inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }
 

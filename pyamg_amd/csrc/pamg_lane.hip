@@ -365,6 +365,8 @@ struct LaneMSched {
     int *d_cols = nullptr;
     double *d_vals = nullptr;
     LaneMRec *d_rec = nullptr;
+    long long *d_prof = nullptr;
+    std::vector<int64_t> super_grp;   // [nsuper + 1] first row (group) of every super-level
     int last_grid = 0;
     int cap = 0;
     const void *cap_kernel = nullptr;
@@ -382,6 +384,7 @@ struct LaneMArgs {
     unsigned *err;
     unsigned *ticket;
     int ngroups, nidle, use_gate;
+    long long *prof;       // nullptr or [ngroups][4] time stamps (tune key 11; the unpipelined kernel, static form)
 };
 
 // x -> snapshot, sentinels -> hand-off buffer: the two passes every merged sweep starts with, in one launch
@@ -394,36 +397,78 @@ __global__ __launch_bounds__(BLK) void lanem_prepare_kernel(const double *__rest
     }
 }
 
-template <int K, int MODE>
-__device__ __forceinline__ void lanem_group(const LaneMArgs &a, int rid, int gate, double rd, int unit, int idle)
+// ---- the kernel.  One row at a time per wave: the record of the NEXT row travels while this one waits; the first two 64-slot units of a row are
+// held in registers (46 VGPRs: eight waves per SIMD), rows of three and more units (a few per cent) fetch the rest in the tail.
+// What round 6 measured on level 1 of the 256^3 hierarchy (2.03 M rows; profiles/r06_microbench_lanem_*, r06_lanem_row_phase_stamps_level1.txt,
+// r06_pmc_lane_probe_level1_merged_vs_unmerged.json): the forward sweep goes 2.27 -> 1.80 - 1.85 ms at s = 2 AND at s = 3 and stays there -- it is no
+// longer bound by the hand-off: 95 - 98 % of the rows find every early operand in their FIRST poll round (stamps), a row costs its wave 2.2 - 2.9 us
+// (slots from HBM 0.6 - 0.7 us, operands 0.6 - 2.0 us growing with the number of waves, tail 0.16 us), and the sweep delivers 1.1 G rows/s from 768
+// workgroups on, more waves only slow each other down.  The counters: 45 - 52 L1 -> L2 requests per row (35 unmerged), 24 % of them from memory, average
+// latency 390 - 430 cycles.  Built, parity-tested, measured and REMOVED again (git history of this file; numbers in profiles/): every unit of a row in
+// registers (92 VGPRs, five waves per SIMD: same floor); a pipelined kernel with three row contexts in flight (slower: 2.0 - 2.3 ms -- every re-poll
+// waits for the prefetches, the first poll round is stale); the same with a PUBLISHER wave per workgroup taking the stores out of the compute waves'
+// in-order memory queue through an LDS mailbox (2.2 - 2.5 ms); ordinary loads for the static operands (+ 3 - 5 %); the next row's slots requested behind
+// the current row's operands (1.86 - 1.99 ms).  An ablation of the first kernel (wrong results by construction): 1.21 ms without waiting for early
+// operands, 0.94 without the publishing store as well, 0.73 for slots + early operands alone.
+struct MCtx {
+    int c[2];
+    double v[2], xv[2];
+    double bv, xo;
+    int rid, gate, unit, K, g;
+    double rd;
+};
+
+__device__ __forceinline__ void m_rec(const int4 *rp, int g, int gend, int4 &q0, int4 &q1)
+{
+    const size_t gg = (size_t)(g < gend ? g : gend - 1);
+    q0 = rp[2 * gg];
+    q1 = rp[2 * gg + 1];
+}
+
+__device__ __forceinline__ void m_slots(const LaneMArgs &a, MCtx &C, const int4 &q0, const int4 &q1, int g, int lane)
+{
+    C.g = g;
+    C.rid = __builtin_amdgcn_readfirstlane(q0.x);
+    C.gate = a.use_gate ? __builtin_amdgcn_readfirstlane(q0.y) : -1;
+    C.rd = __hiloint2double(__builtin_amdgcn_readfirstlane(q0.w), __builtin_amdgcn_readfirstlane(q0.z));
+    C.unit = __builtin_amdgcn_readfirstlane(q1.x);
+    C.K = __builtin_amdgcn_readfirstlane(q1.y);
+    const size_t e0 = (size_t)C.unit * 64 + (size_t)lane;
+    const size_t e1 = e0 + (C.K > 1 ? 64 : 0);                 // a row of one unit reads it twice (no load under a branch); the copy is masked below
+    C.c[0] = a.cols[e0];
+    C.v[0] = a.vals[e0];
+    C.c[1] = a.cols[e1];
+    C.v[1] = a.vals[e1];
+}
+
+__device__ __forceinline__ void m_gather(const LaneMArgs &a, MCtx &C, int idle)
+{
+    if (C.K == 1) C.c[1] = LANE_NONE;
+    const int row = C.rid & LANE_MASK;
+    C.bv = a.b[row];
+    C.xo = a.xold[row];                                        // used by rows without a diagonal only; one broadcast request
+    // every operand by an L1-bypassing load: early ones poll the hand-off buffer, static ones read the snapshot of x and b (ordinary loads for
+    // the static operands were measured 3 - 5 % slower, profiles/r06_microbench_lanem_plain_loads_for_static_operands_not_kept.json)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int col = C.c[k] & LANEM_MASK;
+        const double *p = (C.c[k] & LANE_NONE) ? a.xold + idle : ((C.c[k] & LANE_EARLY) ? a.xs + col : ((C.c[k] & LANEM_BSRC) ? a.b + col : a.xold + col));
+        C.xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// wait for the row's operands and form x_i; returns the value to publish
+__device__ __forceinline__ double m_finish(const LaneMArgs &a, MCtx &C, int idle, long long *t_ready = nullptr, unsigned *n_spins = nullptr)
 {
     using T = double;
     const int lane = threadIdx.x & 63;
-    const size_t e0 = (size_t)unit * 64 + (size_t)lane;
-    int c[K];
-    T v[K], xv[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        c[k] = a.cols[e0 + (size_t)k * 64];
-        v[k] = a.vals[e0 + (size_t)k * 64];
-    }
-    const int row = rid & LANE_MASK;
-    const T bv = a.b[row];
-    T xo = T(0);
-    if (rid & LANE_NODIAG) xo = a.xold[row];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int col = c[k] & LANEM_MASK;
-        const T *p = (c[k] & LANE_NONE) ? a.xold + idle : ((c[k] & LANE_EARLY) ? a.xs + col : ((c[k] & LANEM_BSRC) ? a.b + col : a.xold + col));
-        xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     unsigned pend = 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-        if ((c[k] & LANE_EARLY) && !(c[k] & LANE_NONE) && Sentinel<T>::bits(xv[k]) == Sentinel<T>::value) pend |= 1u << k;
+    for (int k = 0; k < 2; ++k)
+        if ((C.c[k] & LANE_EARLY) && !(C.c[k] & LANE_NONE) && Sentinel<T>::bits(C.xv[k]) == Sentinel<T>::value) pend |= 1u << k;
     unsigned spins = 0;
-    if (gate >= 0 && __builtin_amdgcn_ballot_w64(pend != 0)) {
-        const T *gp = a.xs + gate;
+    if (C.gate >= 0 && __builtin_amdgcn_ballot_w64(pend != 0)) {
+        const T *gp = a.xs + C.gate;
         while (true) {
             const T gv = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (Sentinel<T>::bits(gv) != Sentinel<T>::value) break;
@@ -433,14 +478,14 @@ __device__ __forceinline__ void lanem_group(const LaneMArgs &a, int rid, int gat
     }
     while (pend) {
         if (spins) __builtin_amdgcn_s_sleep(1);
-        T t[K];
+        T t[2];
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-            t[k] = __hip_atomic_load(((pend >> k) & 1u) ? a.xs + (c[k] & LANEM_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 2; ++k)
+            t[k] = __hip_atomic_load(((pend >> k) & 1u) ? a.xs + (C.c[k] & LANEM_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+        for (int k = 0; k < 2; ++k)
             if ((pend >> k) & 1u) {
-                xv[k] = t[k];
+                C.xv[k] = t[k];
                 if (Sentinel<T>::bits(t[k]) != Sentinel<T>::value) pend &= ~(1u << k);
             }
         if ((++spins & 1023u) == 0) {
@@ -450,41 +495,52 @@ __device__ __forceinline__ void lanem_group(const LaneMArgs &a, int rid, int gat
             }
         }
     }
+    if (t_ready) { *t_ready = wall_clock64(); *n_spins = spins; }
     T s = T(0);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const T pr = v[k] * xv[k];
-        s = s + ((c[k] & LANE_NONE) ? T(0) : pr);
+    for (int k = 0; k < 2; ++k) {
+        const T pr = C.v[k] * C.xv[k];
+        s = s + ((C.c[k] & LANE_NONE) ? T(0) : pr);
+    }
+    if (C.K > 2) {
+        // the units beyond the pipeline's two: fetched now, one after the other (rows this long are a few per cent)
+        for (int k = 2; k < C.K; ++k) {
+            const size_t e = (size_t)(C.unit + k) * 64 + (size_t)lane;
+            const int c = a.cols[e];
+            const T v = a.vals[e];
+            const int col = c & LANEM_MASK;
+            const bool early = (c & LANE_EARLY) && !(c & LANE_NONE);
+            const T *p = (c & LANE_NONE) ? a.xold + idle : ((c & LANE_EARLY) ? a.xs + col : ((c & LANEM_BSRC) ? a.b + col : a.xold + col));
+            T x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned sp2 = 0;
+            while (__builtin_amdgcn_ballot_w64(early && Sentinel<T>::bits(x) == Sentinel<T>::value)) {
+                __builtin_amdgcn_s_sleep(1);
+                const T t = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (early && Sentinel<T>::bits(x) == Sentinel<T>::value) x = t;
+                if ((++sp2 & 1023u) == 0 && (sp2 > (1u << 21) || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            const T pr = v * x;
+            s = s + ((c & LANE_NONE) ? T(0) : pr);
+        }
     }
     s = seg_allreduce<64, T>(s);
-    if (lane == 0) {
-        const bool upd = !(rid & LANE_NODIAG);
-        T val = (bv - s) * rd;
-        if (!upd) val = xo;
-        if constexpr (MODE == 1) __hip_atomic_store(a.xs + row, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else __hip_atomic_store(a.xs + row, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (upd) a.y[row] = val;
-    }
+    const bool upd = !(C.rid & LANE_NODIAG);
+    T val = (C.bv - s) * C.rd;
+    if (!upd) val = C.xo;
+    return val;
 }
 
 template <int MODE>
-__device__ __forceinline__ void lanem_dispatch(const LaneMArgs &a, const int4 &q0, const int4 &q1, int idle)
+__device__ __forceinline__ void m_publish(const LaneMArgs &a, const MCtx &C, double val)
 {
-    // everything in the record is the same for the 64 lanes: scalar registers, a uniform branch on K
-    const int rid = __builtin_amdgcn_readfirstlane(q0.x);
-    const int gate = a.use_gate ? __builtin_amdgcn_readfirstlane(q0.y) : -1;
-    const double rd = __hiloint2double(__builtin_amdgcn_readfirstlane(q0.w), __builtin_amdgcn_readfirstlane(q0.z));
-    const int unit = __builtin_amdgcn_readfirstlane(q1.x);
-    const int K = __builtin_amdgcn_readfirstlane(q1.y);
-    switch (K) {
-        case 1: lanem_group<1, MODE>(a, rid, gate, rd, unit, idle); break;
-        case 2: lanem_group<2, MODE>(a, rid, gate, rd, unit, idle); break;
-        case 3: lanem_group<3, MODE>(a, rid, gate, rd, unit, idle); break;
-        case 4: lanem_group<4, MODE>(a, rid, gate, rd, unit, idle); break;
-        case 5: lanem_group<5, MODE>(a, rid, gate, rd, unit, idle); break;
-        case 6: lanem_group<6, MODE>(a, rid, gate, rd, unit, idle); break;
-        case 7: lanem_group<7, MODE>(a, rid, gate, rd, unit, idle); break;
-        default: lanem_group<8, MODE>(a, rid, gate, rd, unit, idle); break;
+    if ((threadIdx.x & 63) == 0) {
+        const int row = C.rid & LANE_MASK;
+        if constexpr (MODE == 1) __hip_atomic_store(a.xs + row, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(a.xs + row, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(C.rid & LANE_NODIAG)) a.y[row] = val;
     }
 }
 
@@ -495,44 +551,69 @@ __global__ __launch_bounds__(BLK) void gs_lanem_kernel(const LaneMArgs a)
     const int wib = threadIdx.x >> 6;
     const int idle = (int)((((unsigned)blockIdx.x * LANE_WPB + (unsigned)wib) * 16u) % (unsigned)a.nidle);
     const int4 *rp = reinterpret_cast<const int4 *>(a.rec);
+    const int gend = a.ngroups;
+    MCtx X;
     if constexpr (MODE != 1) {
         const int W = (int)gridDim.x * LANE_WPB;
         int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * LANE_WPB + wib);
-        const int gend = a.ngroups;
         if (g >= gend) return;
-        int4 q0 = rp[2 * (size_t)g], q1 = rp[2 * (size_t)g + 1];
+        int4 q0, q1;
+        m_rec(rp, g, gend, q0, q1);
         for (; g < gend; g += W) {
-            // the NEXT group's record (32 bytes, two requests) travels while this group waits; its slots are requested on arrival
-            const int gn = (g + W < gend) ? g + W : g;
-            const int4 n0 = rp[2 * (size_t)gn], n1 = rp[2 * (size_t)gn + 1];
-            lanem_dispatch<MODE>(a, q0, q1, idle);
+            int4 n0, n1;
+            m_rec(rp, g + W, gend, n0, n1);
+            if (a.prof) {
+                // diagnostics: where a row's time goes (forced waits between the phases: the stamps change the timing a little)
+                const long long t0 = wall_clock64();
+                m_slots(a, X, q0, q1, g, lane);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const long long t1 = wall_clock64();
+                m_gather(a, X, idle);
+                long long t2 = 0;
+                unsigned sp = 0;
+                const double val = m_finish(a, X, idle, &t2, &sp);
+                m_publish<MODE>(a, X, val);
+                if (lane == 0) {
+                    long long *o = a.prof + (size_t)g * 4;
+                    o[0] = t0 | ((long long)(sp > 4095u ? 4095u : sp) << 52);
+                    o[1] = t1; o[2] = t2; o[3] = wall_clock64();
+                }
+            } else {
+                m_slots(a, X, q0, q1, g, lane);
+                m_gather(a, X, idle);
+                const double val = m_finish(a, X, idle);
+                m_publish<MODE>(a, X, val);
+            }
             q0 = n0; q1 = n1;
         }
     } else {
         __shared__ int sh_home;
         if (threadIdx.x == 0) {
-            const unsigned me = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1u;     // HW_REG_XCC_ID[3:0] + 1
+            const unsigned me = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF) + 1u;
             unsigned home = 0u;
             __hip_atomic_compare_exchange_strong(a.ticket + 1, &home, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sh_home = (home == 0u || home == me) ? 1 : 0;
         }
         __syncthreads();
         if (!sh_home) return;
-        // tickets in increasing order to running waves; a wave holds its group and the next one's ticket (record in flight)
         unsigned tk = 0;
         if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int g = (int)__builtin_amdgcn_readfirstlane(tk);
-        if (g >= a.ngroups) return;
+        if (g >= gend) return;
         if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int g2 = (int)__builtin_amdgcn_readfirstlane(tk);
-        int4 q0 = rp[2 * (size_t)g], q1 = rp[2 * (size_t)g + 1];
+        int4 q0, q1;
+        m_rec(rp, g, gend, q0, q1);
         while (true) {
-            const int gn = g2 < a.ngroups ? g2 : g;
-            const int4 n0 = rp[2 * (size_t)gn], n1 = rp[2 * (size_t)gn + 1];
+            int4 n0, n1;
+            m_rec(rp, g2, gend, n0, n1);
             unsigned tk3 = 0;
-            if (g2 < a.ngroups && lane == 0) tk3 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            lanem_dispatch<MODE>(a, q0, q1, idle);
-            if (g2 >= a.ngroups) break;
+            if (g2 < gend && lane == 0) tk3 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m_slots(a, X, q0, q1, g, lane);
+            m_gather(a, X, idle);
+            const double val = m_finish(a, X, idle);
+            m_publish<MODE>(a, X, val);
+            if (g2 >= gend) break;
             g = g2; q0 = n0; q1 = n1;
             g2 = (int)__builtin_amdgcn_readfirstlane(tk3);
         }
@@ -743,7 +824,7 @@ size_t lane_part_bytes(const GsSchedule *g) { return (g && g->lane) ? g->lane->b
 void free_lanem_part(LaneMSched *t)
 {
     if (!t) return;
-    hipFree(t->d_cols); hipFree(t->d_vals); hipFree(t->d_rec);
+    hipFree(t->d_cols); hipFree(t->d_vals); hipFree(t->d_rec); hipFree(t->d_prof);
     delete t;
 }
 
@@ -759,7 +840,9 @@ int lanem_smax(const pamg_matrix_s *A, const GsSchedule *g)
     const char *e = getenv("PAMG_LANE_MERGE");
     if (e && atoi(e) >= 1) return atoi(e);
     if (A->nnz < 12 * std::max<int64_t>(1, A->nrows)) return 1;
-    return 3;
+    // large levels: 3 (level 1 of the 256^3 hierarchy: 1.80 ms at 2, 1.76 at 3, 2.14 at 4 -- the sweep is bound by rows per second, longer rows cost);
+    // small levels are bound by their hand-offs: 4, tiny ones 6
+    return A->nrows > 131072 ? 3 : A->nrows > 8192 ? 4 : 6;
 }
 
 int build_lanem_part(pamg_matrix_s *A, GsSchedule *g)
@@ -783,6 +866,7 @@ int build_lanem_part(pamg_matrix_s *A, GsSchedule *g)
     t->ngroups = P.ngroups; t->n_units = P.n_units; t->nsuper = P.nsuper; t->nlevels = P.nlevels; t->s_max = s_max; t->max_len = P.max_len;
     t->closed_by_length = P.closed_by_length; t->closed_by_growth = P.closed_by_growth; t->max_growth = P.max_growth;
     t->n_early = P.n_early; t->n_old = P.n_old; t->n_b = P.n_b; t->max_super_groups = P.max_super_groups;
+    t->super_grp = P.super_grp;
     std::vector<LaneMRec> rec((size_t)P.ngroups);
     lane_parallel(P.ngroups, [&](int64_t g0, int64_t g1) {
         for (int64_t q = g0; q < g1; ++q) {
@@ -818,10 +902,17 @@ int lanem_launch(pamg_matrix_s *A, GsSchedule *g, void *x, const void *b, hipStr
     a.err = g->d_sync + 1; a.ticket = g->d_sync + 20;
     a.ngroups = (int)t->ngroups;
     a.nidle = (int)std::max<int64_t>(1, std::min<int64_t>(n, 1 << 20));
+    if (A->gs_prof && !t->d_prof) {
+        PAMG_HIP(hipMalloc((void **)&t->d_prof, (size_t)t->ngroups * 4 * sizeof(long long)));
+        PAMG_HIP(hipMemset(t->d_prof, 0, (size_t)t->ngroups * 4 * sizeof(long long)));
+    }
+    a.prof = A->gs_prof ? t->d_prof : nullptr;
     const int fgrid = (int)std::min<int64_t>(4096, (n + BLK - 1) / BLK);
     hipLaunchKernelGGL(lanem_prepare_kernel, dim3(fgrid), dim3(BLK), 0, s, (const double *)x, (double *)g->d_xold, (double *)g->d_xs, n);
     PAMG_HIP(hipGetLastError());
-    const bool xcd = lane_one_xcd(A, g);
+    // the ticket form inside one XCD only for tiny levels: one row per group means one ticket per ROW, and the ticket counter is one address whose
+    // atomics serialise (11.4 ns each) -- level 2 of the 256^3 hierarchy (44.6 K rows): 0.58 ms inside one XCD, 0.48 across the chip
+    const bool xcd = A->gran_xcd == 1 || (A->gran_xcd == 0 && lane_one_xcd(A, g) && A->nrows <= 8192);
     const void *k = xcd ? (const void *)gs_lanem_kernel<1> : (const void *)gs_lanem_kernel<0>;
     static thread_local int cus = 0;
     if (!cus) cus = device_cus_lane();
@@ -835,9 +926,12 @@ int lanem_launch(pamg_matrix_s *A, GsSchedule *g, void *x, const void *b, hipStr
     // waves wanted: ~2.3 super-levels of look-ahead (one row per wave; the figure of the unmerged form, re-measured for this one: DESIGN 3 round 6)
     const int per_level = (int)((t->ngroups + t->nsuper - 1) / std::max(1, t->nsuper));
     const int64_t want_waves = std::max<int64_t>(128, ((int64_t)A->lanem_ahead10 * per_level + 9) / 10);
-    int G = (int)std::min<int64_t>((want_waves + LANE_WPB - 1) / LANE_WPB, (int64_t)cap * cus);
+    const int cwpb = LANE_WPB;
+    // four workgroups per CU at most: from 768 workgroups on the sweep delivers what it delivers, more waves only slow each other down
+    // (level 1 of the 256^3 hierarchy, s = 3: 1.76 ms with 768 workgroups, 1.88 with 1 024, 2.17 with 1 536, 2.33 with 1 792)
+    int G = (int)std::min<int64_t>((want_waves + cwpb - 1) / cwpb, (int64_t)std::min(cap, 4) * cus);
     if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
-    G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + LANE_WPB - 1) / LANE_WPB));
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + cwpb - 1) / cwpb));
     void *args[] = {(void *)&a};
     if (xcd) {
         PAMG_HIP(hipMemsetAsync(g->d_sync + 20, 0, 2 * sizeof(unsigned), s));
@@ -969,9 +1063,25 @@ int lane_info(const GsSchedule *g, int64_t *info)
     return PAMG_OK;
 }
 
+// first row of every super-level of the merged plan (nsuper + 1 values)
+int lanem_levels(const GsSchedule *g, int64_t *out, int64_t cap, int64_t *n)
+{
+    *n = 0;
+    if (!g || !g->lanem) return PAMG_OK;
+    *n = (int64_t)g->lanem->super_grp.size();
+    if (out && cap >= *n) std::memcpy(out, g->lanem->super_grp.data(), (size_t)*n * sizeof(int64_t));
+    return PAMG_OK;
+}
+
 int lane_profile(const GsSchedule *g, long long *out, int64_t cap, int64_t *n)
 {
     *n = 0;
+    if (g && g->lanem && g->lanem->d_prof) {
+        // merged form: per ROW {arrival | spins << 52, slots arrived, all operands present, published}
+        *n = g->lanem->ngroups;
+        if (out && cap >= *n) PAMG_HIP(hipMemcpy(out, g->lanem->d_prof, (size_t)*n * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+        return PAMG_OK;
+    }
     if (!g || !g->lane || !g->lane->d_prof) return PAMG_OK;
     *n = g->lane->ngroups;
     if (out && cap >= *n) PAMG_HIP(hipMemcpy(out, g->lane->d_prof, (size_t)*n * 4 * sizeof(long long), hipMemcpyDeviceToHost));

@@ -2058,6 +2058,12 @@ int pamg_matrix_lanem_info(pamg_matrix_t A, int which, int64_t info[12], double 
     return pamg::lanem_info(A->gs[which], info, growth);
 }
 
+int pamg_matrix_lanem_levels(pamg_matrix_t A, int which, int64_t *out, int64_t capacity, int64_t *count)
+{
+    if (!A || !count || which < 0 || which > 3) return PAMG_E_ARG;
+    return pamg::lanem_levels(A->gs[which], out, capacity, count);
+}
+
 int pamg_matrix_lane_profile(pamg_matrix_t A, int which, long long *out, int64_t capacity, int64_t *count)
 {
     if (!A || which < 0 || which > 3 || !count) return PAMG_E_ARG;

@@ -143,6 +143,16 @@ class DeviceMatrix:
         d["max_growth"] = gr.value
         return d
 
+    def lanem_levels(self, which=0):
+        """first row of every super-level of the merged plan: int64 array [super_levels + 1] (empty if the schedule runs unmerged)"""
+        n = C.c_int64(0)
+        lib = capi.lib()
+        capi.check(lib.pamg_matrix_lanem_levels(self.handle, which, None, 0, C.byref(n)), "pamg_matrix_lanem_levels")
+        out = np.zeros(n.value, dtype=np.int64)
+        if n.value:
+            capi.check(lib.pamg_matrix_lanem_levels(self.handle, which, C.c_void_p(out.ctypes.data), n.value, C.byref(n)), "pamg_matrix_lanem_levels")
+        return out
+
     def line_info(self, which=0):
         """layout of the line-scan fast-order sweep (schedule 0 = forward, 1 = backward): dict, all zero if none is built"""
         a = (C.c_int64 * 8)()

@@ -355,7 +355,7 @@ def test_gs_merged_fast_order_agrees_to_rounding():
     n_nd = 3000
     main, off = np.full(n_nd, 1.0), np.full(n_nd - 1, -3.0)
     off[23::24] = 0.0
-    ND = sp.csr_array(sp.diags_array([off, main, 0.1 * off], offsets=[-1, 0, 1]) + 0.01 * sa_like(n_nd, 0.006, 3))   # not diagonally dominant: chains of 24 rows with ratio 3
+    ND = sp.csr_array(sp.diags_array([off, main, 0.1 * off], offsets=[-1, 0, 1]))   # not diagonally dominant: independent chains of 24 rows with ratio 3 (3^23 per sweep: finite)
     for ci, M in enumerate((S, Z, N, ND)):
         op = sparse_op(M)
         n = op.shape[0]
@@ -384,7 +384,9 @@ def test_gs_merged_fast_order_agrees_to_rounding():
                 assert mi["rows"] == n and mi["super_levels"] < mi["dependency_levels"], (kw, ci, mi)   # the merged form really ran
                 assert mi["max_growth"] < 50.0
             else:
-                assert mi["rows"] == 0 or (mi["closed_by_growth"] > 0 and mi["max_growth"] <= 1e3), (kw, mi)   # closed early or declined
+                assert mi["rows"] == 0 or mi["max_growth"] <= 1e3, (kw, mi)    # the growth bound holds for whatever was merged
+                if kw["lane_merge"] == 8:
+                    assert mi["rows"] == 0 or mi["closed_by_growth"] > 0, (kw, mi)   # 3^7 > 1e3: groups closed early (or the form declined)
             hops[kw["lane_merge"]] = mi["super_levels"]
             assert np.max(np.abs(got - ref)) <= tol * np.max(np.abs(ref)), (kw, ci, np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
             dx.upload(x)

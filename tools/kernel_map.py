@@ -56,8 +56,13 @@ def kernel_map(dml, smoother_kind):
             if smoother_kind == "gauss_seidel":
                 alg = (vb + 4) * nnz + 4 * (n + 1) + 3 * vb * n
                 for which, dirn in ((0, "forward"), (1, "backward")):
-                    lane, tile, line = A.lane_info(which), A.tile_info(which), A.line_info(which)
-                    if line["lines"] and line["launch_grid"]:
+                    lane, tile, line, lanem = A.lane_info(which), A.tile_info(which), A.line_info(which), A.lanem_info(which)
+                    if lanem["rows"] and lanem["launch_grid"]:
+                        out.append({"family": "gs_lanem", "grid": int(lanem["launch_grid"]), "level": i, "op": "A",
+                                    "what": f"{dirn} Gauss-Seidel sweep (fast order, merged: {lanem['super_levels']} super-levels of <= {lanem['s_max']} dependency levels)",
+                                    "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": int(lanem["units"] * 64 * (vb + 4) + n * (32 + 4 * vb)),
+                                    "format": f"one row per wave, {lanem['units'] / max(1, lanem['rows']):.2f} x 64 operand slots per row, padded", "dependency_levels": int(lanem["super_levels"])})
+                    elif line["lines"] and line["launch_grid"]:
                         out.append({"family": "gs_line", "grid": int(line["launch_grid"]), "level": i, "op": "A", "what": f"{dirn} Gauss-Seidel sweep (fast order, line scan: {line['lines']} lines, {line['line_levels']} line levels)",
                                     "rows": int(n), "nnz": int(nnz), "bytes_alg": int(alg), "bytes_streamed": int(line["chunks"] * 64 * (line["slots_per_row"] * (vb + 4) + 2 * vb + 1) + n * 4 * vb),
                                     "format": f"chunks of 64 rows x {line['slots_per_row']} slots", "dependency_levels": int(line["line_levels"])})

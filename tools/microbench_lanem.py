@@ -21,6 +21,7 @@ ap.add_argument("--s", type=int, nargs="+", default=[1, 2, 3, 4])
 ap.add_argument("--ahead", type=int, nargs="+", default=[23])
 ap.add_argument("--grids", type=int, nargs="+", default=[0])
 ap.add_argument("--gate", type=int, nargs="+", default=[1])
+ap.add_argument("--xcd", type=int, nargs="+", default=[0])
 ap.add_argument("--tag", default="lanem")
 a = ap.parse_args()
 A = pyamg.gallery.poisson(tuple(a.grid), format="csr")
@@ -65,8 +66,8 @@ for li in a.levels:
         dA.tune(lane_merge=s)
         for gate in a.gate:
             for ah in a.ahead:
-                for G in a.grids:
-                    dA.tune(lanem_ahead=ah, lane_G=G, lane_flags=gate)
+                for G, xcd in [(G_, x_) for G_ in a.grids for x_ in a.xcd]:
+                    dA.tune(lanem_ahead=ah, lane_G=G, lane_flags=gate, gran_xcd=xcd)
                     dx.upload(x0)
                     dA.gauss_seidel(dx, db, sweep="symmetric")
                     got = dx.download()
@@ -75,7 +76,7 @@ for li in a.levels:
                     ms = timeit(lambda: dA.gauss_seidel(dx, db, sweep="forward"))
                     mi, li_ = dA.lanem_info(0), dA.lane_info(0)
                     hops = mi["super_levels"] or rec["dependency_levels"]
-                    v = {"s": s, "gate": gate, "ahead10": ah, "lane_G": G, "ms_forward": round(ms, 4), "hand_offs": int(hops), "us_per_hand_off": round(1e3 * ms / hops, 3),
+                    v = {"s": s, "gate": gate, "ahead10": ah, "lane_G": G, "gran_xcd": xcd, "ms_forward": round(ms, 4), "hand_offs": int(hops), "us_per_hand_off": round(1e3 * ms / hops, 3),
                          "max_rel_diff_vs_exact_symmetric_sweep": err, "units_per_row": round(mi["units"] / max(1, mi["rows"]), 3) if mi["rows"] else None,
                          "operands_per_row": round((mi["early_operands"] + mi["old_operands"] + mi["b_operands"]) / max(1, mi["rows"]), 2) if mi["rows"] else None,
                          "slot_GB": round(mi["units"] * 64 * 12 / 1e9, 3) if mi["rows"] else round(li_["entry_slots"] * 12 / 1e9, 3),

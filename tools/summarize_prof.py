@@ -41,6 +41,9 @@ def short(name):
     m = re.search(r"gs_lane_kernel<(\w+), *(\d+), *(\d+), *(\d+), *(\w+)>", name)
     if m:
         return f"gs_lane<{m.group(1)},{EPI[int(m.group(2))]},L{m.group(3)},K{m.group(4)},{'oneXCD' if m.group(5) in ('true', '1') else 'chip'}>"
+    m = re.search(r"gs_lanem\w*_kernel<(\w+)>", name)
+    if m:
+        return f"gs_lanem<double,GS,{'oneXCD' if m.group(1) in ('true', '1') else 'chip'}>"
     m = re.search(r"gs_line_kernel<(\w+), *(\d+), *(\d+)>", name)
     if m:
         return f"gs_line<{m.group(1)},{EPI[int(m.group(2))]},K{m.group(3)}>"
@@ -59,6 +62,8 @@ def family(k):
     if k.startswith("csr_"):
         m = re.search(r",(\w+?)(,npl\d|,kz\d|,nu\d)?>", k)
         return "csr", (m.group(1) if m else None)
+    if k.startswith("gs_lanem"):
+        return "gs_lanem", None
     if k.startswith("gs_lane"):
         return "gs_lane", None
     if k.startswith("gs_line"):
@@ -86,14 +91,34 @@ for f in (out / "kernel_map.json",):
 # ---- kernel trace -> per (kernel, grid) count / total / avg
 for f in glob.glob(str(out / "trace" / "**" / "*kernel_trace.csv"), recursive=True):
     agg = defaultdict(lambda: [0, 0.0])
+    durs = defaultdict(list)
     with open(f) as fh:
         for r in csv.DictReader(fh):
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             k = short(r["Kernel_Name"])
             gs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
             wg = int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 256)) or 256)
-            agg[(k, gs // max(wg, 1))][0] += 1
-            agg[(k, gs // max(wg, 1))][1] += d
+            durs[(k, gs // max(wg, 1))].append(d)
+    # Two LEVELS of a hierarchy can run one kernel instantiation with one grid size (round 5: levels 2 and 3 both gs_lane<L32,K4,oneXCD> [256]; the
+    # table then showed the mean of a 0.71 ms and a 0.10 ms sweep as "level 2").  Where the kernel map names several levels for a (kernel, grid),
+    # its launches are split into that many groups at the largest gaps of their sorted durations (levels differ by factors in duration); the
+    # longest group is the finest level.  Keys become (kernel, grid) or (kernel + ' #i', grid).
+    if kmap:
+        import math
+        for (k, g) in list(durs):
+            fam, epi = family(k)
+            if fam not in ("gs_lane", "gs_lanem", "gs_line", "gs_tile", "gs_gran", "bsr_lane"):
+                continue
+            lv = sorted({e["level"] for e in kmap["entries"] if e["family"] == fam and (e["grid"] is None or e["grid"] == g)})
+            if len(lv) < 2 or len(durs[(k, g)]) < 2 * len(lv):
+                continue
+            ds = sorted(durs.pop((k, g)), reverse=True)
+            gaps = sorted(range(1, len(ds)), key=lambda i: math.log(ds[i - 1] / max(ds[i], 1e-9)), reverse=True)[:len(lv) - 1]
+            cuts = [0] + sorted(gaps) + [len(ds)]
+            for j in range(len(lv)):
+                durs[(f"{k} #{j}", g)] = ds[cuts[j]:cuts[j + 1]]
+    for key, v in durs.items():
+        agg[key] = [len(v), sum(v)]
     tot = sum(v[1] for v in agg.values())
     rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
     lines = [f"{'kernel [workgroups]':62s} {'calls':>8s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}"]
@@ -130,7 +155,13 @@ for f in glob.glob(str(out / "trace" / "**" / "*kernel_trace.csv"), recursive=Tr
                 cand = [i for i, e in enumerate(ents) if e["family"] == fam and (fam != "csr" or e["epi"] == epi) and (e["grid"] is None or e["grid"] == g or (fam == "csr" and 0 <= g - e["grid"] < 8))]
             if not cand:
                 continue
-            # several operators with one grid size (tiny levels): the first unused entry
+            # several operators with one grid size (tiny levels): the first unused entry; launches split by duration ('kernel #j') take the
+            # entries of the j-th level among the candidates
+            mj = re.search(r" #(\d+)$", k)
+            if mj:
+                lvs = sorted({ents[i]["level"] for i in cand})
+                want = lvs[min(int(mj.group(1)), len(lvs) - 1)]
+                cand = [i for i in cand if ents[i]["level"] == want] or cand
             i = next((i for i in cand if i not in used), cand[0])
             used.add(i)
             e = ents[i]
