@@ -317,12 +317,15 @@ int smooth(pamg_dist_s *D, int l, const DSmoother &sm, bool x_zero)
             const double *co = sm.coeffs.data();
             for (int it = 0; it < sm.iterations; ++it) {
                 const void *res = L.b;
+                bool have_h = false;
                 if (!(x_zero && it == 0)) {
-                    PAMG_TRY(xlaunch(D, l, L.x, true, A, EPI_RESID, L.b, L.r, 0.0, 0.0, nullptr));      // res = b - A x
+                    // res = b - A x, and h = c0 res by the same launch when there is a Horner step to follow (row_finish, pamg_kernels.h)
+                    PAMG_TRY(xlaunch(D, l, L.x, true, A, EPI_RESID, L.b, L.r, nc > 1 ? co[0] : 0.0, 0.0, nc > 1 ? (double *)L.h0 : nullptr));
                     res = L.r;
+                    have_h = nc > 1;
                 }
                 if (nc == 1) { PAMG_TRY(vec_axpy(D->dtype, L.n_owned, co[0], res, L.x, s)); continue; }
-                PAMG_TRY(vec_scale(D->dtype, L.n_owned, co[0], res, L.h0, s));                           // h = c0 res
+                if (!have_h) PAMG_TRY(vec_scale(D->dtype, L.n_owned, co[0], res, L.h0, s));              // h = c0 res
                 void *hc = L.h0, *hn = L.h1;
                 for (int k = 1; k < nc - 1; ++k) {
                     PAMG_TRY(xlaunch(D, l, hc, true, A, EPI_AXPBY, res, hn, co[k], 0.0, nullptr));       // h = c res + A h

@@ -517,7 +517,11 @@ __device__ __forceinline__ void row_finish(const StreamArgs<T> &a, const RowPre<
     } else if constexpr (EPI == EPI_ACC) {
         a.y[row] = q.y + s;
     } else if constexpr (EPI == EPI_RESID) {
-        a.y[row] = q.b - s;
+        const T t = q.b - s;
+        a.y[row] = t;
+        // the polynomial smoother's first Horner step h = c0 * r rides along (relaxation.py:652-653; the same single multiplication as the vector
+        // kernel it replaces: bit-identical) -- one pass over two vectors less per smoother application; the unused `partial` slot carries h
+        if (a.partial) reinterpret_cast<T *>(a.partial)[row] = a.c * t;
     } else if constexpr (EPI == EPI_AXPBY) {
         const T t = a.c * q.b;
         a.y[row] = t + s;
@@ -555,21 +559,25 @@ __device__ __forceinline__ void row_finish(const StreamArgs<T> &a, const RowPre<
     }
 }
 
-template <typename T, int EPI, int NPL, int COH>
+// VC = false: an instantiation WITHOUT the 8-bit value-code paths, for operators that carry none (every SA-level operator; the stencils' general
+// form).  Round 6, one session (profiles/r06_ab_csr_stream.txt): the run-time tests for value codes in the staged kernel cost the fine-level residual
+// of the 256^3 stencil 0.3355 -> 0.3145 ms (0.699 -> 0.745 of the HBM peak by SURVEY 8(d)), 2000^2 0.0649 -> 0.0574 -- what rounds 3 - 5 had lost since
+// round 2's 0.313 (together with the nontemporal test inside the unrolled staging loop: 0.3475 -> 0.3307).
+template <typename T, int EPI, int NPL, int COH, bool VC = true>
 __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 meta, unsigned char *smem_raw,
                                              double &sq)
 {
     constexpr bool NEEDC = EpiTraits<EPI>::need_cols;
     const int cap = a.cap;
     // slots per LDS array: the window + the alignment slack below the first entry + the row phase's batch over-read
-    const int slots = cap + ((NPL == 2 && COH == 0 && a.Ax8) ? 16 : 8);
+    const int slots = cap + ((VC && NPL == 2 && COH == 0 && a.Ax8) ? 16 : 8);
     T *prod = reinterpret_cast<T *>(smem_raw);
     int *cols = reinterpret_cast<int *>(smem_raw + sizeof(T) * (size_t)slots);
     const int tid = threadIdx.x;
     const int r0 = meta.x, r1 = meta.y, p0 = meta.z, p1 = meta.w;
     const T *vd = nullptr;
     int amask = (NPL == 4) ? ~3 : (NPL == 2) ? ~1 : ~0;
-    if constexpr (NPL == 2 && COH == 0) {
+    if constexpr (VC && NPL == 2 && COH == 0) {
         if (a.Ax8) {
             // value dictionary -> LDS (behind the products and column ids); read after the barrier below
             T *d = reinterpret_cast<T *>(smem_raw + ((sizeof(T) * (size_t)slots + (NEEDC ? sizeof(int) * (size_t)slots : 0) + 15) & ~(size_t)15));
@@ -614,7 +622,7 @@ __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 
     }
 }
 
-template <typename T, int EPI, int NPL>
+template <typename T, int EPI, int NPL, bool VC = true>
 __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -635,9 +643,9 @@ __global__ __launch_bounds__(BLK) void csr_stream_kernel(const StreamArgs<T> a)
         if (NPL == 2 && a.Aj16) {
             StreamArgs<T> aw = a;
             aw.wb = a.wbase[blk];
-            stream_block<T, EPI, NPL, 0>(aw, a.blkmeta[blk], smem_raw, sq);
+            stream_block<T, EPI, NPL, 0, VC>(aw, a.blkmeta[blk], smem_raw, sq);
         } else {
-            stream_block<T, EPI, NPL, 0>(a, a.blkmeta[blk], smem_raw, sq);
+            stream_block<T, EPI, NPL, 0, VC>(a, a.blkmeta[blk], smem_raw, sq);
         }
     }
     if constexpr (EPI == EPI_SUMSQ) {
@@ -828,30 +836,6 @@ __global__ __launch_bounds__(BLK) void csr_rowpat_kernel(const StreamArgs<T> a)
     }
 }
 
-// ---- row-pattern form, TWO consecutive rows per lane (round 4).  The one-row form issues ten 8-byte (and one 1-byte) memory
-// instructions per row and is bound by the requests a CU can keep in flight, not by bytes.  Here lane l takes rows
-// r0 + 2 l and r0 + 2 l + 1: when both are regular rows with the SAME list (all but the boundary rows of a stencil) and
-// the pair starts at an even row, b, y, the diagonal and the result move as ONE 16-byte access per vector, every list entry with
-// an even offset is ONE 16-byte gather x[row + offset .. + 1] for the two rows, and the table in LDS is read once for
-// both.  Per pair of rows of the 7-point stencil: 10 memory instructions instead of 22.  Every row still adds ITS products in
-// ITS list order with the same operands -- bit-identical to the one-row form (and to SciPy).  Pairs that do not qualify
-// (different lists, irregular rows, odd start, the tail of a range, vectors that are not 16-byte aligned) take the one-row
-// path, one row after the other.
-template <typename T, int EPI>
-__device__ __forceinline__ T rowpat_value(const StreamArgs<T> &a, T b, T y, T xo, T d, T s, double &sq)
-{
-    const T one = T(1);
-    if constexpr (EPI == EPI_SET || EPI == EPI_ACCSEQ) return s;
-    else if constexpr (EPI == EPI_ACC) return y + s;
-    else if constexpr (EPI == EPI_RESID) return b - s;
-    else if constexpr (EPI == EPI_AXPBY) { const T t = a.c * b; return t + s; }
-    else if constexpr (EPI == EPI_ACC_AXPBY) { const T t = a.c * b; const T h = t + s; return y + h; }
-    else if constexpr (EPI == EPI_SUMSQ) { const T t = b - s; sq += (double)t * (double)t; return T(0); }
-    else if constexpr (EPI == EPI_JACOBI) return (d != T(0)) ? (one - a.omega) * xo + a.omega * ((b - s) / d) : xo;
-    else return (d != T(0)) ? (one - a.omega) * xo + a.omega * s / d : xo;                  // EPI_JACOBI_B
-}
-
-
 // Single-workgroup persistent sweep (gs_flow1_kernel): ONE workgroup walks all row ranges of a
 // schedule, level after level, with __syncthreads() between them -- the scheduler of choice when
 // the levels are so narrow (<= 2 row ranges on average) that there is nothing to share out.
@@ -940,7 +924,11 @@ __global__ __launch_bounds__(BLK) void csr_rowmask_kernel(const StreamArgs<T> a,
             }
         }
     }
-    if constexpr (NT && EPI == EPI_RESID) __builtin_nontemporal_store(q.b - s, a.y + r);
+    if constexpr (NT && EPI == EPI_RESID) {
+            const T t = q.b - s;
+            __builtin_nontemporal_store(t, a.y + r);
+            if (a.partial) __builtin_nontemporal_store(a.c * t, reinterpret_cast<T *>(a.partial) + r);     // h = c0 * r (row_finish)
+        }
     else row_finish<T, EPI, 0>(a, q, s, sq);
 }
 
@@ -1062,7 +1050,11 @@ __global__ __launch_bounds__(64 * WY) void csr_rowmask3d_kernel(const StreamArgs
                 }
             }
         }
-        if constexpr (NT && EPI == EPI_RESID) __builtin_nontemporal_store(q.b - s, a.y + r);
+        if constexpr (NT && EPI == EPI_RESID) {
+            const T t = q.b - s;
+            __builtin_nontemporal_store(t, a.y + r);
+            if (a.partial) __builtin_nontemporal_store(a.c * t, reinterpret_cast<T *>(a.partial) + r);     // h = c0 * r (row_finish)
+        }
         else row_finish<T, EPI, 0>(a, q, s, sq);
     }
 }

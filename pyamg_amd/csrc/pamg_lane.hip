@@ -841,8 +841,8 @@ int lanem_smax(const pamg_matrix_s *A, const GsSchedule *g)
     if (e && atoi(e) >= 1) return atoi(e);
     if (A->nnz < 12 * std::max<int64_t>(1, A->nrows)) return 1;
     // large levels: 3 (level 1 of the 256^3 hierarchy: 1.80 ms at 2, 1.76 at 3, 2.14 at 4 -- the sweep is bound by rows per second, longer rows cost);
-    // small levels are bound by their hand-offs: 4, tiny ones 6
-    return A->nrows > 131072 ? 3 : A->nrows > 8192 ? 4 : 6;
+    // small levels are bound by their hand-offs: 6 (level 2, 44.6 K rows: 0.485 ms at 4, 0.46 at 6 and 8; level 3, 463 rows: 0.042 at 4, 0.034 at 6)
+    return A->nrows > 131072 ? 3 : 6;
 }
 
 int build_lanem_part(pamg_matrix_s *A, GsSchedule *g)
@@ -923,13 +923,14 @@ int lanem_launch(pamg_matrix_s *A, GsSchedule *g, void *x, const void *b, hipStr
         t->cap_kernel = k;
     }
     const int cap = t->cap;
-    // waves wanted: ~2.3 super-levels of look-ahead (one row per wave; the figure of the unmerged form, re-measured for this one: DESIGN 3 round 6)
+    // waves wanted: 4 x the rows of an average super-level (level 2 of the 256^3 hierarchy, 199 rows per super-level at s = 6: 0.487 ms with 115
+    // workgroups, 0.459 with 192, 0.473 with 256, 0.52 with 384), capped below
     const int per_level = (int)((t->ngroups + t->nsuper - 1) / std::max(1, t->nsuper));
     const int64_t want_waves = std::max<int64_t>(128, ((int64_t)A->lanem_ahead10 * per_level + 9) / 10);
     const int cwpb = LANE_WPB;
-    // four workgroups per CU at most: from 768 workgroups on the sweep delivers what it delivers, more waves only slow each other down
+    // three workgroups per CU at most: from 768 workgroups on the sweep delivers what it delivers, more waves only slow each other down
     // (level 1 of the 256^3 hierarchy, s = 3: 1.76 ms with 768 workgroups, 1.88 with 1 024, 2.17 with 1 536, 2.33 with 1 792)
-    int G = (int)std::min<int64_t>((want_waves + cwpb - 1) / cwpb, (int64_t)std::min(cap, 4) * cus);
+    int G = (int)std::min<int64_t>((want_waves + cwpb - 1) / cwpb, (int64_t)std::min(cap, 3) * cus);
     if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + cwpb - 1) / cwpb));
     void *args[] = {(void *)&a};

@@ -70,10 +70,16 @@ int launch_epi(int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a
     if (grid <= 0) return PAMG_OK;
     // two entries per lane and staging step (one and four were measured no better and retired in round 5: tune key 1)
     (void)npl;
-    if (lds > 48 * 1024)
-        PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 2>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 2>), dim3(grid), dim3(BLK), lds, s, a);
+    if (a.Ax8) {
+        if (lds > 48 * 1024)
+            PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 2, true>), dim3(grid), dim3(BLK), lds, s, a);
+    } else {
+        // no value codes on this operator: the instantiation without their run-time tests (pamg_kernels.h: stream_block)
+        if (lds > 48 * 1024)
+            PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 2, false>), dim3(grid), dim3(BLK), lds, s, a);
+    }
     return (int)hipGetLastError();
 }
 

@@ -146,15 +146,18 @@ int poly_apply(pamg_matrix_s *A, void *x, const void *b, void *work, const doubl
     void *res_buf = work, *h0 = (char *)work + n * ts, *h1 = (char *)work + 2 * n * ts;
     for (int it = 0; it < its; ++it) {
         const void *res = b;
+        bool have_h = false;
         if (!(x_is_zero && it == 0)) {
-            PAMG_TRY(stream_launch(A, EPI_RESID, x, b, res_buf, 0.0, 0.0, nullptr, s));
+            // r = b - A x; with more than one coefficient the same launch writes h = c0 * r (epilogue of EPI_RESID, pamg_kernels.h: row_finish)
+            PAMG_TRY(stream_launch(A, EPI_RESID, x, b, res_buf, nc > 1 ? coeffs[0] : 0.0, 0.0, nc > 1 ? (double *)h0 : nullptr, s));
             res = res_buf;
+            have_h = nc > 1;
         }
         if (nc == 1) {
             PAMG_TRY(vec_axpy(A->dtype, n, coeffs[0], res, x, s));          // x += c0*res
             continue;
         }
-        PAMG_TRY(vec_scale(A->dtype, n, coeffs[0], res, h0, s));            // h = c0*res
+        if (!have_h) PAMG_TRY(vec_scale(A->dtype, n, coeffs[0], res, h0, s));            // h = c0*res
         void *hc = h0, *hn = h1;
         for (int k = 1; k < nc - 1; ++k) {                                  // h = c*res + A h
             PAMG_TRY(stream_launch(A, EPI_AXPBY, hc, res, hn, coeffs[k], 0.0, nullptr, s));

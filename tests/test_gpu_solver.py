@@ -288,6 +288,7 @@ def test_midsize_symmetric_gs_against_the_live_reference():
                 tiles = [dA.tile_info(0)["tiles"] for dA in dml.A[:-1]]
                 lines = [dA.line_info(0)["lines"] for dA in dml.A[:-1]]
                 lanes = [dA.lane_info(0)["groups"] for dA in dml.A[:-1]]
+                merged = [dA.lanem_info(0) for dA in dml.A[:-1]]
             dml.free()
             r_ref_a, r_gpu_a = np.array(r_ref), np.array(r_gpu)
             assert len(r_gpu_a) == len(r_ref_a) == 11
@@ -295,9 +296,10 @@ def test_midsize_symmetric_gs_against_the_live_reference():
             assert np.linalg.norm(outs[-1] - x_ref) <= 1e-12 * np.linalg.norm(x_ref), order
         assert np.array_equal(outs[0], outs[1]), order
         if order == "exact":
-            assert tiles[0] > 1 and not any(lines) and not any(lanes)     # the fine level runs the tiled sweep
+            assert tiles[0] > 1 and not any(lines) and not any(lanes) and not any(m["rows"] for m in merged)     # the fine level runs the tiled sweep
         else:
-            assert lines[0] == 96 * 96 and lanes[1] > 0                   # fine level: one line per grid line; SA level 1: lane form
+            # fine level: one line per grid line; SA level 1: the MERGED lane form (round 6: dependency levels eliminated into super-levels)
+            assert lines[0] == 96 * 96 and merged[1]["rows"] > 0 and merged[1]["super_levels"] * 2 < merged[1]["dependency_levels"], merged[1]
 
 
 @pytest.mark.parametrize("case", ["poisson3d_128", "poisson2d_2000"])

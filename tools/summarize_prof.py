@@ -23,7 +23,7 @@ EPI = ["SET", "ACC", "RESID", "AXPBY", "ACC_AXPBY", "SUMSQ", "ACCSEQ", "JACOBI",
 
 
 def short(name):
-    m = re.search(r"csr_stream_kernel<(\w+), *(\d+), *(\d+)>", name)
+    m = re.search(r"csr_stream_kernel<(\w+), *(\d+), *(\d+)(?:, *(\w+))?>", name)
     if m:
         return f"csr_stream<{m.group(1)},{EPI[int(m.group(2))]},npl{m.group(3)}>"
     m = re.search(r"csr_(rowgather|rowpat)_kernel<(\w+), *(\d+)>", name)
