@@ -33,7 +33,10 @@
 // A group only waits for groups of EARLIER super-levels (smaller numbers): the static wave assignment g = w, w + W, ...
 // stays deadlock-free.  SOR is not merged (its coefficients depend on the relaxation parameter of the call).
 #pragma once
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "pamg_lane_plan.h"
 
@@ -69,19 +72,34 @@ struct LaneMPlan {
 namespace lanem_detail {
 
 struct Spa {                                  // sparse accumulator over (kind, column); kinds 0 = early, 1 = old, 2 = b
-    std::vector<double> val[3];
-    std::vector<int> stamp[3];
-    std::vector<int> touched;                 // codes (column | kind bits) in first-touch order
-    int token = 0;
-    void init(int n) { for (int k = 0; k < 3; ++k) { val[k].assign((size_t)n, 0.0); stamp[k].assign((size_t)n, 0); } token = 0; }
-    void begin() { ++token; touched.clear(); }
+    // a small open-addressing table (a merged row holds a few hundred operands at most): it stays in the L1 of the host core, where dense
+    // arrays over all columns cost two cache misses per addition (level 1 of the 256^3 hierarchy: 4.3 s -> see DESIGN 3 round 6)
+    static constexpr int CAP = 4096;          // slots; a row may fill half of them, longer rows are "too long" whatever the caller's cap
+    std::vector<int> key;
+    std::vector<double> val;
+    std::vector<int> used;                    // occupied slots in first-touch order
+    std::vector<int> touched;                 // the row's codes (column | kind bits), filled by finish()
+    bool overflow = false;
+    void init(int) { key.assign((size_t)CAP, (int)LANE_NONE); val.assign((size_t)CAP, 0.0); used.clear(); }
+    void begin() { for (int h : used) key[(size_t)h] = (int)LANE_NONE; used.clear(); touched.clear(); overflow = false; }
     static int code(int kind, int col) { return col | (kind == 0 ? LANE_EARLY : kind == 2 ? LANEM_BSRC : 0); }
     static int kind_of(int c) { return (c & LANE_EARLY) ? 0 : (c & LANEM_BSRC) ? 2 : 1; }
     void add(int kind, int col, double v)
     {
-        if (stamp[kind][(size_t)col] != token) { stamp[kind][(size_t)col] = token; val[kind][(size_t)col] = v; touched.push_back(code(kind, col)); }
-        else val[kind][(size_t)col] += v;
+        const int c = code(kind, col);
+        unsigned h = ((unsigned)c * 2654435761u) >> 20;                  // 12 bits
+        while (key[h] != (int)LANE_NONE && key[h] != c) h = (h + 1) & (CAP - 1);
+        if (key[h] == c) { val[h] += v; return; }
+        if ((int)used.size() >= CAP / 2) { overflow = true; return; }
+        key[h] = c; val[h] = v; used.push_back((int)h);
     }
+    double value_of(int c) const
+    {
+        unsigned h = ((unsigned)c * 2654435761u) >> 20;
+        while (key[h] != c) h = (h + 1) & (CAP - 1);
+        return val[h];
+    }
+    void finish() { touched.clear(); for (int h : used) touched.push_back(key[(size_t)h]); }
 };
 
 struct RowRef { int64_t off = 0; int len = 0; int arena = -1; };
@@ -96,6 +114,14 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
                             int len_cap = LANEM_KMAX * 64)
 {
     using namespace lanem_detail;
+    const bool timing_ = getenv("PAMG_TIMING") != nullptr;
+    auto t_prev_ = std::chrono::steady_clock::now();
+    auto lap_ = [&](const char *what) {
+        if (!timing_) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pamg timing]     lanem plan: %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_prev_).count());
+        t_prev_ = now;
+    };
     P = LaneMPlan();
     P.s_max = s_max; P.nlevels = nl;
     if (m <= 0 || nl <= 0 || s_max < 1) return 1;
@@ -119,6 +145,7 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
         for (int64_t i = i0; i < i1; ++i)
             for (int p = Ap[i]; p < Ap[i + 1]; ++p) if (Aj[p] == (int)i) diag[(size_t)i] = Ax[p];
     });
+    lap_("levels, order, diagonals");
     // ---- merged rows, window after window of 4 * s_max levels; windows are independent (a merged row only refers to merged rows of
     //      its own window) and are what the host threads share out.  Inside a window the levels are taken greedily: a super-level is
     //      closed when it holds s_max levels, or in front of a level whose merged rows would come out too long / too large
@@ -140,6 +167,15 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
         std::vector<double> &av = aval[(size_t)tid];
         std::vector<std::pair<int, double>> sub;
         const int b0 = (int)((int64_t)nblocks * tid / nt), b1 = (int)((int64_t)nblocks * (tid + 1) / nt);
+        {
+            // room for this thread's share of the merged rows up front (a growing vector copies and re-faults what it holds at every doubling)
+            const int lfirst = std::min(nl, b0 * wlev), llast = std::min(nl, b1 * wlev);
+            int64_t direct = 0;
+            for (int64_t q = lptr[lfirst]; q < lptr[llast]; ++q) direct += Ap[order[(size_t)q] + 1] - Ap[order[(size_t)q]];
+            const size_t want = (size_t)((double)direct * (s_max >= 4 ? 3.2 : s_max == 3 ? 2.3 : s_max == 2 ? 1.7 : 1.05)) + 4096;
+            ac.reserve(want);
+            av.reserve(want);
+        }
         for (int blk = b0; blk < b1 && !unfit.load(); ++blk) {
             const int lb0 = blk * wlev, lb1 = std::min(nl, lb0 + wlev);
             int l0 = lb0;                                     // first level of the open super-level
@@ -173,6 +209,7 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
                             const double *rv = aval[(size_t)rr.arena].data() + rr.off;
                             for (int e = 0; e < rr.len; ++e) spa.add(Spa::kind_of(rc[e]), rc[e] & LANEM_MASK, -f * rv[e]);
                         }
+                        spa.finish();
                         RowRef me;
                         me.arena = tid; me.off = (int64_t)ac.size(); me.len = (int)spa.touched.size();
                         // operands by (kind, column): the lanes of a gather instruction that read neighbouring columns of one array share a
@@ -181,14 +218,14 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
                         std::sort(spa.touched.begin(), spa.touched.end(), [](int x, int y) { return (unsigned)x < (unsigned)y; });
                         for (int c : spa.touched) {
                             const int kind = Spa::kind_of(c);
-                            const double v = spa.val[kind][(size_t)(c & LANEM_MASK)];
+                            const double v = spa.value_of(c);
                             ac.push_back(c);
                             av.push_back(v);
                             if (kind == 2) growth += std::fabs(v);
                         }
                         if (!std::isfinite(growth)) growth = INFINITY;
                         ref[(size_t)i] = me;
-                        if (me.len > len_cap) too_long = true;
+                        if (me.len > len_cap || spa.overflow) too_long = true;
                         if (growth > growth_cap) too_large = true;
                         level_growth = std::max(level_growth, growth);
                     }
@@ -216,6 +253,7 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
         for (auto &x : th) x.join();
     }
     if (unfit.load()) return 1;
+    lap_("merged rows");
     for (int t = 0; t < nt; ++t) { P.closed_by_length += cl_len[(size_t)t]; P.closed_by_growth += cl_gr[(size_t)t]; P.max_growth = std::max(P.max_growth, mg[(size_t)t]); }
     // ---- super-levels, groups, units
     std::vector<int> sup_of_level((size_t)nl, 0);
@@ -263,9 +301,9 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
                 }
         }
     });
+    lap_("groups, units, gates' inputs");
     plan_fill(P.cols, (size_t)units * 64, (int)LANE_NONE);
     plan_fill(P.vals, (size_t)units * 64, 0.0);
-    std::vector<int64_t> cnt((size_t)3 * 64, 0);               // per-thread-slot statistics would need atomics: count per chunk below
     std::atomic<int64_t> ne(0), no(0), nb(0), nd(0);
     lane_parallel(m, [&](int64_t g0, int64_t g1) {
         int64_t e_ = 0, o_ = 0, b_ = 0, d_ = 0;
@@ -294,6 +332,7 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
         ne += e_; no += o_; nb += b_; nd += d_;
     });
     P.n_early = ne.load(); P.n_old = no.load(); P.n_b = nb.load(); P.n_direct = nd.load();
+    lap_("slots filled");
     return 0;
 }
 

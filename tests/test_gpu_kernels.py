@@ -569,7 +569,7 @@ def test_lane_layout_filled_on_the_device_is_the_host_layout(monkeypatch):
         for host in ("1", "0"):
             monkeypatch.setenv("PAMG_LANE_HOST_FILL", host)
             dA = DeviceMatrix(op)
-            dA.tune(gs_order=1, lane_wide=1, line_scan=0)
+            dA.tune(gs_order=1, lane_wide=1, line_scan=0, lane_merge=1)             # the unmerged layout is what is filled on the device
             dx, db = capi.DeviceArray.from_host(x), capi.DeviceArray.from_host(b)
             dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)
             a = dx.download()
@@ -995,8 +995,11 @@ def test_kaczmarz_fast_order_agrees_to_rounding():
     """The lane-parallel fast order of the Kaczmarz sweeps (tune gs_order = 1 on the operator handed to pamg_matrix_kaczmarz; csrc/pamg_kz.hip:
     one persistent launch, lanes share a line, versioned 16-byte slots hand the rewritten vector over) against the order-exact device sweeps
     (= the reference's bits: amg_core::gauss_seidel_ne / gauss_seidel_nr, relaxation.h:875-904, 939-975): 1e-13 per call on upwind
-    convection-diffusion (short lines), a dense-ish operator (long lines, two slots per lane), a rectangular one; forward, backward, symmetric,
-    two iterations; the same bits on a second run; the exact kernels untouched by the switch."""
+    convection-diffusion (short lines) and a dense-ish operator (long lines, two slots per lane); forward, backward, symmetric, two iterations; the
+    same bits on a second run; the exact kernels untouched by the switch.  Both device orders are also held against the ORACLE's restatement of the
+    reference loops (oracle.gauss_seidel_ne / gauss_seidel_nr run in the same sequence on the same running arrays): exact order bit for bit, fast
+    order 1e-13 (the chain device-exact == reference was only pinned on other matrices)."""
+    from oracle import oracle as orc
     from pyamg_amd.hierarchy import _normal_equation_spec as _nes
     rng = np.random.RandomState(29)
     n = 4000
@@ -1033,6 +1036,21 @@ def test_kaczmarz_fast_order_agrees_to_rounding():
                     out[order] = got
                 for a_, b_ in zip(out[0], out[1]):
                     assert np.max(np.abs(a_ - b_)) <= 1e-13 * max(1.0, np.max(np.abs(a_))), (kind, sweep, np.max(np.abs(a_ - b_)))
+                # the oracle's loops in the same sequence: `2` iterations of the sweep on the running vectors
+                dirs = {"forward": [(0, m, 1)], "backward": [(m - 1, -1, -1)], "symmetric": [(0, m, 1), (m - 1, -1, -1)]}[sweep] * 2
+                if kind == "gauss_seidel_ne":
+                    xo = x.copy()
+                    for (r0, r1, rs) in dirs:
+                        orc.gauss_seidel_ne(Lop.indptr, Lop.indices, Lop.data, xo, b, r0, r1, rs, spec.Dinv, omega)
+                    want = (xo,)
+                else:
+                    xo, ro = x.copy(), b - M @ x
+                    for (r0, r1, rs) in dirs:
+                        orc.gauss_seidel_nr(Lop.indptr, Lop.indices, Lop.data, xo, ro, r0, r1, rs, spec.Dinv, omega)
+                    want = (xo, ro)
+                for w_, e_, f_ in zip(want, out[0], out[1]):
+                    assert np.array_equal(w_, e_), (kind, sweep)                                   # exact order: the oracle's bits
+                    assert np.max(np.abs(w_ - f_)) <= 1e-13 * max(1.0, np.max(np.abs(w_))), (kind, sweep, np.max(np.abs(w_ - f_)))
             dL.free()
 
 
