@@ -70,7 +70,10 @@ int launch_epi(int npl, int grid, int lds, hipStream_t s, const StreamArgs<T> &a
     if (grid <= 0) return PAMG_OK;
     // two entries per lane and staging step (one and four were measured no better and retired in round 5: tune key 1)
     (void)npl;
-    if (a.Ax8) {
+    // flag bit 5: an operator WITHOUT value codes through the instantiation that carries their paths.  Same arithmetic, another instruction
+    // schedule: on the SA-level operators of the 256^3 hierarchy (one session, profiles/r06_microbench_sa_ops_vc_ab.txt) A1's residual runs 0.198 ms
+    // there and 0.219 in the lean instantiation, R0 0.214 / 0.227 -- but P0 0.187 / 0.162 and the fine-level stencil 0.3355 / 0.3145: the autotune times both
+    if (a.Ax8 || (a.flags & 32)) {
         if (lds > 48 * 1024)
             PAMG_HIP(hipFuncSetAttribute((const void *)csr_stream_kernel<T, EPI, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         hipLaunchKernelGGL((csr_stream_kernel<T, EPI, 2, true>), dim3(grid), dim3(BLK), lds, s, a);
@@ -1920,12 +1923,13 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
     // use them (the norm's partials, the shard parts)
     long long rm0[8];
     const bool masked = pamg_matrix_row_masks(A, rm0) == PAMG_OK && rm0[0] > 0;
-    // candidates: the LDS window (as planned / 512 entries) x the nontemporal operator stream (flag bit 0) x the 16-bit column codes on / off
+    // candidates: the LDS window (as planned / 512 entries) x the nontemporal operator stream (flag bit 0) x the kernel instantiation (flag bit 5,
+    // launch_epi) x the 16-bit column codes on / off
     // (operators without value codes: fewer bytes, but half-width requests -- the SA-level operators of the 256^3 hierarchy, profiles/
     // r05_microbench_sa_ops_wide_codes_vs_32bit_not_kept.json: P0 0.219 ms on codes, 0.199 on 32-bit columns, R0 0.204 against 0.211).  Two interleaved
     // rounds, a candidate's better time counts, and anything but the plan's own setting has to win by 2 %: a single round of six launches picked the
     // XCD-contiguous range order (bit 1: measured slower on every SA-level operator, r05_microbench_sa_ops_nontemporal.json) for R0 by noise and cost
-    // 11 % of that product (r05_c4s_kernel_roofline.txt); bit 1 is left to tune key 8
+    // 11 % of that product (r05_c4s_kernel_roofline.txt); bit 1 is left to tune key 8: every candidate keeps the caller's setting of it
     const int idx0 = A->use_idx16;
     const int nidx = (A->d_Aj16 && !A->d_Ax8 && idx0) ? 2 : 1;
     // timed on what the cycle runs most: r = b - A x for square operators (three vectors in flight: the Horner steps and the residual), y = A x for
@@ -1937,36 +1941,41 @@ int pamg_matrix_autotune(pamg_matrix_t A, int allow_cap)
         if (hipMalloc(&pb, (size_t)(A->nrows + 8) * ts) != hipSuccess) { hipFree(x); hipFree(y); hipEventDestroy(e0); hipEventDestroy(e1); return (int)hipErrorOutOfMemory; }
         hipMemset(pb, 0, (size_t)(A->nrows + 8) * ts);
     }
-    float cand_ms[2][2][2];
-    for (int q = 0; q < 8; ++q) (&cand_ms[0][0][0])[q] = 1e30f;
+    float cand_ms[2][2][2][2];                                  // [window][codes on / off][nontemporal][instantiation]
+    for (int q = 0; q < 16; ++q) (&cand_ms[0][0][0][0])[q] = 1e30f;
+    const int nvc = A->d_Ax8 ? 1 : 2;                           // operators with value codes have one instantiation
     for (int ci = 0; ci < (allow_cap ? 2 : 1) && st == PAMG_OK && !masked; ++ci) {
         if (caps[ci] != A->cap) { A->cap = caps[ci]; st = replan(A); if (st) break; }      // (one re-plan per window: the rounds interleave the other choices)
         for (int round = 0; round < 2 && st == PAMG_OK; ++round) {
             for (int ix = 0; ix < nidx && st == PAMG_OK; ++ix) {
                 A->use_idx16 = ix == 0 ? idx0 : 0;
-                for (int fl = 0; fl < 2 && st == PAMG_OK; ++fl) {
-                    A->stream_flags = (fl0 & ~3) | fl;
-                    for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, probe, x, pb, y, 0.0, 0.0, nullptr, nullptr);
-                    hipEventRecord(e0, nullptr);
-                    for (int r = 0; r < 6 && st == PAMG_OK; ++r) st = stream_launch(A, probe, x, pb, y, 0.0, 0.0, nullptr, nullptr);
-                    hipEventRecord(e1, nullptr);
-                    hipEventSynchronize(e1);
-                    float ms = 0.f;
-                    hipEventElapsedTime(&ms, e0, e1);
-                    if (st == PAMG_OK) cand_ms[ci][ix][fl] = std::min(cand_ms[ci][ix][fl], ms);
-                }
+                for (int fl = 0; fl < 2 && st == PAMG_OK; ++fl)
+                    for (int vc = 0; vc < nvc && st == PAMG_OK; ++vc) {
+                        A->stream_flags = (fl0 & ~(1 | 32)) | fl | (vc ? 32 : 0);
+                        for (int w = 0; w < 2 && st == PAMG_OK; ++w) st = stream_launch(A, probe, x, pb, y, 0.0, 0.0, nullptr, nullptr);
+                        hipEventRecord(e0, nullptr);
+                        for (int r = 0; r < 6 && st == PAMG_OK; ++r) st = stream_launch(A, probe, x, pb, y, 0.0, 0.0, nullptr, nullptr);
+                        hipEventRecord(e1, nullptr);
+                        hipEventSynchronize(e1);
+                        float ms = 0.f;
+                        hipEventElapsedTime(&ms, e0, e1);
+                        if (st == PAMG_OK) cand_ms[ci][ix][fl][vc] = std::min(cand_ms[ci][ix][fl][vc], ms);
+                    }
             }
         }
     }
     A->use_idx16 = idx0;
     hipFree(pb);
     if (st == PAMG_OK && !masked) {
-        best_ms = cand_ms[0][0][fl0 & 1];
+        best_ms = cand_ms[0][0][fl0 & 1][(fl0 & 32) ? nvc - 1 : 0];
         int best_ix = 0;
         for (int ci = 0; ci < (allow_cap ? 2 : 1); ++ci)
             for (int ix = 0; ix < nidx; ++ix)
                 for (int fl = 0; fl < 2; ++fl)
-                    if (cand_ms[ci][ix][fl] < best_ms * 0.98f) { best_ms = cand_ms[ci][ix][fl]; best_cap = caps[ci]; best_fl = (fl0 & ~3) | fl; best_ix = ix; }
+                    for (int vc = 0; vc < nvc; ++vc)
+                        if (cand_ms[ci][ix][fl][vc] < best_ms * 0.98f) {
+                            best_ms = cand_ms[ci][ix][fl][vc]; best_cap = caps[ci]; best_fl = (fl0 & ~(1 | 32)) | fl | (vc ? 32 : 0); best_ix = ix;
+                        }
         if (best_ix == 1) A->use_idx16 = 0;
     }
     A->stream_flags = best_fl;
