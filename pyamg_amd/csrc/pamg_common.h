@@ -215,6 +215,7 @@ struct pamg_matrix_s {
     int lane_flags = 1;              // fast order: bit 0 = gate operand (a wave that runs ahead polls one value instead of all its operands), bit 3 = gate in the line scan   (tune key 28)
     int line_scan = 1;               // fast order: line-scan sweep where consecutive rows are coupled (grid stencils), tried before the lane form   (tune key 30)
     int lane_merge = 0;              // fast order: dependency levels merged into one super-level at most (0 = automatic, 1 = never, 2..8)   (tune key 33)
+    int lanem_rpw = 0;               // merged form: rows per wave (0 = automatic: 2 on levels above 131 072 rows, 1 below)   (tune key 35)
     int lanem_ahead10 = 40;          // merged form: waves launched = this / 10 x the rows of an average super-level   (tune key 34)
     int lane_wide = 0;               // fast order on wide schedules (>= 2048 rows per dependency level): 0 = the tiled exact sweep keeps them, 1 = lane form   (tune key 27)
     int gs_cap = 0;                  // entries per row range of the level schedules (tune key 20; 0 = automatic: `cap`, 512 on the multi-XCD granular sweep of SA-like rows)

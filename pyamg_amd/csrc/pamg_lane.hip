@@ -354,10 +354,11 @@ __global__ __launch_bounds__(BLK) void gs_lane_kernel(const LaneArgs<T> a)
 // record of a group carries the first 64-slot unit and K), three kinds of operands: NEW values of earlier super-levels (polled in xs),
 // OLD values (the snapshot of x taken by lanem_prepare_kernel) and entries of b.  f64, Gauss-Seidel only (SOR's merged coefficients
 // would depend on the relaxation parameter of the call).
-struct alignas(32) LaneMRec { int rid; int gate; int rd_lo; int rd_hi; int unit; int K; int pad0; int pad1; };
+struct alignas(32) LaneMRec { int rid_a; int rid_b; int gate; int unitK; int rda_lo; int rda_hi; int rdb_lo; int rdb_hi; };     // unitK = first unit * 16 + units
 
 struct LaneMSched {
-    int64_t ngroups = 0, n_units = 0;
+    int64_t ngroups = 0, n_units = 0, nrows = 0;
+    int rpw = 1;
     int nsuper = 0, nlevels = 0, s_max = 0, max_len = 0;
     int closed_by_length = 0, closed_by_growth = 0;
     double max_growth = 0.0;
@@ -410,12 +411,14 @@ __global__ __launch_bounds__(BLK) void lanem_prepare_kernel(const double *__rest
 // in-order memory queue through an LDS mailbox (2.2 - 2.5 ms); ordinary loads for the static operands (+ 3 - 5 %); the next row's slots requested behind
 // the current row's operands (1.86 - 1.99 ms).  An ablation of the first kernel (wrong results by construction): 1.21 ms without waiting for early
 // operands, 0.94 without the publishing store as well, 0.73 for slots + early operands alone.
+// RPW rows of one super-level per wave (64 / RPW lanes each), NREG units of 64 slots in registers (the rest of a long group is fetched in the tail)
+template <int NREG>
 struct MCtx {
-    int c[2];
-    double v[2], xv[2];
-    double bv, xo;
-    int rid, gate, unit, K, g;
-    double rd;
+    int c[NREG];
+    double v[NREG], xv[NREG];
+    double bv, xo, rd;         // per lane: its row's b, old value, 1 / a_ii
+    int rid;                   // per lane: its row | NODIAG, -1 = dummy slot
+    int gate, unit, K, g;      // uniform
 };
 
 __device__ __forceinline__ void m_rec(const int4 *rp, int g, int gend, int4 &q0, int4 &q1)
@@ -425,46 +428,59 @@ __device__ __forceinline__ void m_rec(const int4 *rp, int g, int gend, int4 &q0,
     q1 = rp[2 * gg + 1];
 }
 
-__device__ __forceinline__ void m_slots(const LaneMArgs &a, MCtx &C, const int4 &q0, const int4 &q1, int g, int lane)
+template <int RPW, int NREG>
+__device__ __forceinline__ void m_slots(const LaneMArgs &a, MCtx<NREG> &C, const int4 &q0, const int4 &q1, int g, int lane)
 {
+    // record: {row a | NODIAG, row b (RPW = 2; else -1), gate, unit * 16 + K, 1 / a_ii of a (2 words), of b (2 words)}
     C.g = g;
-    C.rid = __builtin_amdgcn_readfirstlane(q0.x);
-    C.gate = a.use_gate ? __builtin_amdgcn_readfirstlane(q0.y) : -1;
-    C.rd = __hiloint2double(__builtin_amdgcn_readfirstlane(q0.w), __builtin_amdgcn_readfirstlane(q0.z));
-    C.unit = __builtin_amdgcn_readfirstlane(q1.x);
-    C.K = __builtin_amdgcn_readfirstlane(q1.y);
+    const int rid_a = __builtin_amdgcn_readfirstlane(q0.x), rid_b = __builtin_amdgcn_readfirstlane(q0.y);
+    C.gate = a.use_gate ? __builtin_amdgcn_readfirstlane(q0.z) : -1;
+    const int uk = __builtin_amdgcn_readfirstlane(q0.w);
+    C.unit = uk >> 4;
+    C.K = uk & 15;
+    const double rd_a = __hiloint2double(__builtin_amdgcn_readfirstlane(q1.y), __builtin_amdgcn_readfirstlane(q1.x));
+    const double rd_b = __hiloint2double(__builtin_amdgcn_readfirstlane(q1.w), __builtin_amdgcn_readfirstlane(q1.z));
+    const bool second = RPW == 2 && lane >= 32;
+    C.rid = second ? rid_b : rid_a;
+    C.rd = second ? rd_b : rd_a;
     const size_t e0 = (size_t)C.unit * 64 + (size_t)lane;
-    const size_t e1 = e0 + (C.K > 1 ? 64 : 0);                 // a row of one unit reads it twice (no load under a branch); the copy is masked below
-    C.c[0] = a.cols[e0];
-    C.v[0] = a.vals[e0];
-    C.c[1] = a.cols[e1];
-    C.v[1] = a.vals[e1];
+#pragma unroll
+    for (int k = 0; k < NREG; ++k) {
+        // a group of fewer units reads its last unit again (no load under a branch); the copies are masked in m_gather
+        const size_t e = e0 + (size_t)64 * (size_t)(k < C.K ? k : C.K - 1);
+        C.c[k] = a.cols[e];
+        C.v[k] = a.vals[e];
+    }
 }
 
-__device__ __forceinline__ void m_gather(const LaneMArgs &a, MCtx &C, int idle)
+template <int NREG>
+__device__ __forceinline__ void m_gather(const LaneMArgs &a, MCtx<NREG> &C, int idle)
 {
-    if (C.K == 1) C.c[1] = LANE_NONE;
-    const int row = C.rid & LANE_MASK;
+#pragma unroll
+    for (int k = 1; k < NREG; ++k)
+        if (k >= C.K) C.c[k] = LANE_NONE;
+    const int row = C.rid < 0 ? 0 : (C.rid & LANE_MASK);
     C.bv = a.b[row];
-    C.xo = a.xold[row];                                        // used by rows without a diagonal only; one broadcast request
+    C.xo = a.xold[row];                                        // used by rows without a diagonal only
     // every operand by an L1-bypassing load: early ones poll the hand-off buffer, static ones read the snapshot of x and b (ordinary loads for
     // the static operands were measured 3 - 5 % slower, profiles/r06_microbench_lanem_plain_loads_for_static_operands_not_kept.json)
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NREG; ++k) {
         const int col = C.c[k] & LANEM_MASK;
         const double *p = (C.c[k] & LANE_NONE) ? a.xold + idle : ((C.c[k] & LANE_EARLY) ? a.xs + col : ((C.c[k] & LANEM_BSRC) ? a.b + col : a.xold + col));
         C.xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// wait for the row's operands and form x_i; returns the value to publish
-__device__ __forceinline__ double m_finish(const LaneMArgs &a, MCtx &C, int idle, long long *t_ready = nullptr, unsigned *n_spins = nullptr)
+// wait for the group's operands and form x_i of its rows; returns the value a row's head lane publishes
+template <int RPW, int NREG>
+__device__ __forceinline__ double m_finish(const LaneMArgs &a, MCtx<NREG> &C, int idle, long long *t_ready = nullptr, unsigned *n_spins = nullptr)
 {
     using T = double;
     const int lane = threadIdx.x & 63;
     unsigned pend = 0;
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < NREG; ++k)
         if ((C.c[k] & LANE_EARLY) && !(C.c[k] & LANE_NONE) && Sentinel<T>::bits(C.xv[k]) == Sentinel<T>::value) pend |= 1u << k;
     unsigned spins = 0;
     if (C.gate >= 0 && __builtin_amdgcn_ballot_w64(pend != 0)) {
@@ -478,12 +494,12 @@ __device__ __forceinline__ double m_finish(const LaneMArgs &a, MCtx &C, int idle
     }
     while (pend) {
         if (spins) __builtin_amdgcn_s_sleep(1);
-        T t[2];
+        T t[NREG];
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < NREG; ++k)
             t[k] = __hip_atomic_load(((pend >> k) & 1u) ? a.xs + (C.c[k] & LANEM_MASK) : a.xs + idle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < NREG; ++k)
             if ((pend >> k) & 1u) {
                 C.xv[k] = t[k];
                 if (Sentinel<T>::bits(t[k]) != Sentinel<T>::value) pend &= ~(1u << k);
@@ -498,13 +514,13 @@ __device__ __forceinline__ double m_finish(const LaneMArgs &a, MCtx &C, int idle
     if (t_ready) { *t_ready = wall_clock64(); *n_spins = spins; }
     T s = T(0);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NREG; ++k) {
         const T pr = C.v[k] * C.xv[k];
         s = s + ((C.c[k] & LANE_NONE) ? T(0) : pr);
     }
-    if (C.K > 2) {
-        // the units beyond the pipeline's two: fetched now, one after the other (rows this long are a few per cent)
-        for (int k = 2; k < C.K; ++k) {
+    if (C.K > NREG) {
+        // the units beyond the registers: fetched now, one after the other (groups this long are a few per cent)
+        for (int k = NREG; k < C.K; ++k) {
             const size_t e = (size_t)(C.unit + k) * 64 + (size_t)lane;
             const int c = a.cols[e];
             const T v = a.vals[e];
@@ -526,17 +542,17 @@ __device__ __forceinline__ double m_finish(const LaneMArgs &a, MCtx &C, int idle
             s = s + ((c & LANE_NONE) ? T(0) : pr);
         }
     }
-    s = seg_allreduce<64, T>(s);
-    const bool upd = !(C.rid & LANE_NODIAG);
+    s = seg_allreduce<64 / RPW, T>(s);
+    const bool upd = C.rid >= 0 && !(C.rid & LANE_NODIAG);
     T val = (C.bv - s) * C.rd;
     if (!upd) val = C.xo;
     return val;
 }
 
-template <int MODE>
-__device__ __forceinline__ void m_publish(const LaneMArgs &a, const MCtx &C, double val)
+template <int RPW, int MODE, int NREG>
+__device__ __forceinline__ void m_publish(const LaneMArgs &a, const MCtx<NREG> &C, double val)
 {
-    if ((threadIdx.x & 63) == 0) {
+    if (((threadIdx.x & 63) & (64 / RPW - 1)) == 0 && C.rid >= 0) {
         const int row = C.rid & LANE_MASK;
         if constexpr (MODE == 1) __hip_atomic_store(a.xs + row, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else __hip_atomic_store(a.xs + row, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -544,15 +560,16 @@ __device__ __forceinline__ void m_publish(const LaneMArgs &a, const MCtx &C, dou
     }
 }
 
-template <int MODE>
+template <int MODE, int RPW>
 __global__ __launch_bounds__(BLK) void gs_lanem_kernel(const LaneMArgs a)
 {
+    constexpr int NREG = RPW == 1 ? 2 : 4;                     // 128 operand slots per row in registers either way
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int idle = (int)((((unsigned)blockIdx.x * LANE_WPB + (unsigned)wib) * 16u) % (unsigned)a.nidle);
     const int4 *rp = reinterpret_cast<const int4 *>(a.rec);
     const int gend = a.ngroups;
-    MCtx X;
+    MCtx<NREG> X;
     if constexpr (MODE != 1) {
         const int W = (int)gridDim.x * LANE_WPB;
         int g = __builtin_amdgcn_readfirstlane((int)blockIdx.x * LANE_WPB + wib);
@@ -563,26 +580,26 @@ __global__ __launch_bounds__(BLK) void gs_lanem_kernel(const LaneMArgs a)
             int4 n0, n1;
             m_rec(rp, g + W, gend, n0, n1);
             if (a.prof) {
-                // diagnostics: where a row's time goes (forced waits between the phases: the stamps change the timing a little)
+                // diagnostics: where a group's time goes (forced waits between the phases: the stamps change the timing a little)
                 const long long t0 = wall_clock64();
-                m_slots(a, X, q0, q1, g, lane);
+                m_slots<RPW, NREG>(a, X, q0, q1, g, lane);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const long long t1 = wall_clock64();
-                m_gather(a, X, idle);
+                m_gather<NREG>(a, X, idle);
                 long long t2 = 0;
                 unsigned sp = 0;
-                const double val = m_finish(a, X, idle, &t2, &sp);
-                m_publish<MODE>(a, X, val);
+                const double val = m_finish<RPW, NREG>(a, X, idle, &t2, &sp);
+                m_publish<RPW, MODE, NREG>(a, X, val);
                 if (lane == 0) {
                     long long *o = a.prof + (size_t)g * 4;
                     o[0] = t0 | ((long long)(sp > 4095u ? 4095u : sp) << 52);
                     o[1] = t1; o[2] = t2; o[3] = wall_clock64();
                 }
             } else {
-                m_slots(a, X, q0, q1, g, lane);
-                m_gather(a, X, idle);
-                const double val = m_finish(a, X, idle);
-                m_publish<MODE>(a, X, val);
+                m_slots<RPW, NREG>(a, X, q0, q1, g, lane);
+                m_gather<NREG>(a, X, idle);
+                const double val = m_finish<RPW, NREG>(a, X, idle);
+                m_publish<RPW, MODE, NREG>(a, X, val);
             }
             q0 = n0; q1 = n1;
         }
@@ -609,10 +626,10 @@ __global__ __launch_bounds__(BLK) void gs_lanem_kernel(const LaneMArgs a)
             m_rec(rp, g2, gend, n0, n1);
             unsigned tk3 = 0;
             if (g2 < gend && lane == 0) tk3 = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            m_slots(a, X, q0, q1, g, lane);
-            m_gather(a, X, idle);
-            const double val = m_finish(a, X, idle);
-            m_publish<MODE>(a, X, val);
+            m_slots<RPW, NREG>(a, X, q0, q1, g, lane);
+            m_gather<NREG>(a, X, idle);
+            const double val = m_finish<RPW, NREG>(a, X, idle);
+            m_publish<RPW, MODE, NREG>(a, X, val);
             if (g2 >= gend) break;
             g = g2; q0 = n0; q1 = n1;
             g2 = (int)__builtin_amdgcn_readfirstlane(tk3);
@@ -855,15 +872,20 @@ int build_lanem_part(pamg_matrix_s *A, GsSchedule *g)
     hAx.resize((size_t)A->nnz + 1);
     if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToHost));
     LaneMPlan P;
+    // two rows per wave (32 lanes each, rows of a super-level paired by length) on the large levels: a fifth fewer padded slots (1.14 instead of 1.44
+    // units per row on level 1 of the 256^3 hierarchy) and 1.74 instead of 1.81 ms -- the sweep there is bound by what the memory system delivers per
+    // row, not by waves or hand-offs (profiles/r06_microbench_lanem_rows_per_wave.json); small levels are bound by their hand-offs: a wave that waits
+    // for ITS row only (tune key 35: 1 / 2, 0 = this rule)
+    const int rpw = A->lanem_rpw ? A->lanem_rpw : (A->nrows > 131072 ? 2 : 1);
     if (build_lanem_plan((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), hAx.data(), g->row_start, g->row_step, (int)g->nrows, g->nlevels, g->h_vis, g->h_lvl,
-                         s_max, 1e3, P))
+                         s_max, 1e3, P, LANEM_KMAX * 64, rpw))
         return PAMG_E_ARG;
     hAx = PlanVec<double>();
     // nothing gained (every group closed at once: an operator the growth bound rejects): the unmerged form is the cheaper layout
     if (P.nsuper * 10 > P.nlevels * 9) return PAMG_E_ARG;
     LaneMSched *t = new (std::nothrow) LaneMSched();
     if (!t) return PAMG_E_ALLOC;
-    t->ngroups = P.ngroups; t->n_units = P.n_units; t->nsuper = P.nsuper; t->nlevels = P.nlevels; t->s_max = s_max; t->max_len = P.max_len;
+    t->ngroups = P.ngroups; t->n_units = P.n_units; t->nrows = P.nrows; t->rpw = P.rpw; t->nsuper = P.nsuper; t->nlevels = P.nlevels; t->s_max = s_max; t->max_len = P.max_len;
     t->closed_by_length = P.closed_by_length; t->closed_by_growth = P.closed_by_growth; t->max_growth = P.max_growth;
     t->n_early = P.n_early; t->n_old = P.n_old; t->n_b = P.n_b; t->max_super_groups = P.max_super_groups;
     t->super_grp = P.super_grp;
@@ -871,9 +893,13 @@ int build_lanem_part(pamg_matrix_s *A, GsSchedule *g)
     lane_parallel(P.ngroups, [&](int64_t g0, int64_t g1) {
         for (int64_t q = g0; q < g1; ++q) {
             LaneMRec &R = rec[(size_t)q];
-            R.rid = P.rid[(size_t)q]; R.gate = P.gate[(size_t)q];
-            std::memcpy(&R.rd_lo, &P.rdiag[(size_t)q], 8);
-            R.unit = P.unit[(size_t)q]; R.K = P.K[(size_t)q]; R.pad0 = R.pad1 = 0;
+            const size_t q0 = (size_t)q * (size_t)P.rpw;
+            const double zero = 0.0;
+            R.rid_a = P.rid[q0]; R.rid_b = P.rpw == 2 ? P.rid[q0 + 1] : -1;
+            R.gate = P.gate[(size_t)q];
+            R.unitK = P.unit[(size_t)q] * 16 + (int)P.K[(size_t)q];
+            std::memcpy(&R.rda_lo, &P.rdiag[q0], 8);
+            std::memcpy(&R.rdb_lo, P.rpw == 2 ? &P.rdiag[q0 + 1] : &zero, 8);
         }
     });
     int st = lane_upload(&t->d_rec, rec.data(), rec.size() * sizeof(LaneMRec), &t->bytes);
@@ -913,7 +939,8 @@ int lanem_launch(pamg_matrix_s *A, GsSchedule *g, void *x, const void *b, hipStr
     // the ticket form inside one XCD only for tiny levels: one row per group means one ticket per ROW, and the ticket counter is one address whose
     // atomics serialise (11.4 ns each) -- level 2 of the 256^3 hierarchy (44.6 K rows): 0.58 ms inside one XCD, 0.48 across the chip
     const bool xcd = A->gran_xcd == 1 || (A->gran_xcd == 0 && lane_one_xcd(A, g) && A->nrows <= 8192);
-    const void *k = xcd ? (const void *)gs_lanem_kernel<1> : (const void *)gs_lanem_kernel<0>;
+    const void *k = t->rpw == 2 ? (xcd ? (const void *)gs_lanem_kernel<1, 2> : (const void *)gs_lanem_kernel<0, 2>)
+                                : (xcd ? (const void *)gs_lanem_kernel<1, 1> : (const void *)gs_lanem_kernel<0, 1>);
     static thread_local int cus = 0;
     if (!cus) cus = device_cus_lane();
     if (!(t->cap > 0 && t->cap_kernel == k)) {
@@ -930,7 +957,8 @@ int lanem_launch(pamg_matrix_s *A, GsSchedule *g, void *x, const void *b, hipStr
     const int cwpb = LANE_WPB;
     // three workgroups per CU at most: from 768 workgroups on the sweep delivers what it delivers, more waves only slow each other down
     // (level 1 of the 256^3 hierarchy, s = 3: 1.76 ms with 768 workgroups, 1.88 with 1 024, 2.17 with 1 536, 2.33 with 1 792)
-    int G = (int)std::min<int64_t>((want_waves + cwpb - 1) / cwpb, (int64_t)std::min(cap, 3) * cus);
+    // (two rows per wave, s = 3: 1.74 ms with 512 workgroups, 1.89 with 768, 2.08 with 1 024: two per CU)
+    int G = (int)std::min<int64_t>((want_waves + cwpb - 1) / cwpb, (int64_t)std::min(cap, t->rpw == 2 ? 2 : 3) * cus);
     if (A->lane_G > 0) G = std::min(A->lane_G, cap * cus);
     G = (int)std::max<int64_t>(1, std::min<int64_t>(G, (t->ngroups + cwpb - 1) / cwpb));
     void *args[] = {(void *)&a};
@@ -954,7 +982,7 @@ int lanem_info(const GsSchedule *g, int64_t *info, double *growth)
     if (growth) *growth = 0.0;
     if (!g || !g->lanem) return PAMG_OK;
     const LaneMSched *t = g->lanem;
-    info[0] = t->nsuper; info[1] = t->nlevels; info[2] = t->ngroups; info[3] = t->n_units; info[4] = t->n_early; info[5] = t->n_old; info[6] = t->n_b;
+    info[0] = t->nsuper; info[1] = t->nlevels; info[2] = t->nrows; info[3] = t->n_units; info[4] = t->n_early; info[5] = t->n_old; info[6] = t->n_b;
     info[7] = t->max_len; info[8] = t->s_max; info[9] = t->closed_by_length; info[10] = t->closed_by_growth; info[11] = t->last_grid;
     if (growth) *growth = t->max_growth;
     return PAMG_OK;

@@ -50,13 +50,15 @@ struct LaneMPlan {
     int s_max = 0;
     int nlevels = 0;                          // dependency levels of the sweep (hand-offs of the unmerged form)
     int nsuper = 0;                           // super-levels = hand-offs of this form
-    int64_t ngroups = 0;                      // visited rows (one row per group)
+    int rpw = 1;                              // rows per wave (1: 64 lanes per row; 2: 32 lanes per row, rows of a super-level paired by length)
+    int64_t nrows = 0;                        // visited rows
+    int64_t ngroups = 0;                      // groups (one wave each): ceil(rows of a super-level / rpw), super-level after super-level
     int64_t n_units = 0;                      // 64-slot units of cols / vals
     std::vector<int> unit;                    // [ngroups] first unit of the group
     std::vector<unsigned char> K;             // [ngroups] units of the group
-    std::vector<int> rid;                     // [ngroups] row | LANE_NODIAG
+    std::vector<int> rid;                     // [ngroups * rpw] row | LANE_NODIAG, -1 = dummy slot of an odd super-level
     std::vector<int> gate;                    // [ngroups] gate operand (pamg_lane_plan.h) in terms of super-levels, or -1
-    std::vector<double> rdiag;                // [ngroups] 1 / a_ii (0: no usable diagonal)
+    std::vector<double> rdiag;                // [ngroups * rpw] 1 / a_ii (0: no usable diagonal)
     std::vector<int> super_of;                // [ngroups] super-level of the group
     std::vector<int64_t> super_grp;           // [nsuper + 1] group range of each super-level
     PlanVec<int> cols;
@@ -111,7 +113,7 @@ struct RowRef { int64_t off = 0; int len = 0; int arena = -1; };
 // longer than LANEM_KMAX * 64 operands even unmerged, index range) -- the caller keeps the unmerged lane form.
 inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *Ax, int row_start, int row_step, int m, int nl,
                             const std::vector<int> &vis, const std::vector<int> &lvl, int s_max, double growth_cap, LaneMPlan &P,
-                            int len_cap = LANEM_KMAX * 64)
+                            int len_cap = LANEM_KMAX * 64, int rpw = 1)
 {
     using namespace lanem_detail;
     const bool timing_ = getenv("PAMG_TIMING") != nullptr;
@@ -124,9 +126,10 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
     };
     P = LaneMPlan();
     P.s_max = s_max; P.nlevels = nl;
-    if (m <= 0 || nl <= 0 || s_max < 1) return 1;
+    if (m <= 0 || nl <= 0 || s_max < 1 || (rpw != 1 && rpw != 2)) return 1;
     if (n > LANEM_MASK) return 1;
-    len_cap = std::max(1, std::min(len_cap, LANEM_KMAX * 64));
+    P.rpw = rpw; P.nrows = m;
+    len_cap = std::max(1, std::min(len_cap, LANEM_KMAX * (64 / rpw)));
     // rows in level order, visit order inside a level
     std::vector<int64_t> lptr((size_t)nl + 1, 0);
     for (int t = 0; t < m; ++t) lptr[(size_t)lvl[row_start + (int64_t)t * row_step] + 1]++;
@@ -262,35 +265,59 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
         for (int l = 0; l < nl; ++l) { if (starts[(size_t)l]) ++s; sup_of_level[(size_t)l] = s; }
         P.nsuper = s + 1;
     }
-    P.ngroups = m;
-    P.unit.assign((size_t)m, 0); P.K.assign((size_t)m, 1); P.rid.assign((size_t)m, -1); P.gate.assign((size_t)m, -1);
-    P.rdiag.assign((size_t)m, 0.0); P.super_of.assign((size_t)m, 0);
+    // ---- groups: RPW rows of one super-level share a wave (64 / RPW lanes each).  With two rows per wave the rows of a super-level are paired by length
+    //      (a pair is padded to the longer row's units; the order of rows INSIDE a super-level is free: they do not depend on each other)
+    const int RPW = P.rpw, LPR = 64 / RPW;
+    std::vector<int64_t> super_first((size_t)P.nsuper + 1, 0);
+    for (int l = 0; l < nl; ++l) super_first[(size_t)sup_of_level[(size_t)l] + 1] = lptr[l + 1];
+    auto klen = [&](int i) { const bool nodiag = !(diag[(size_t)i] != 0.0); const int len = nodiag ? 0 : ref[(size_t)i].len; return std::max(1, (len + LPR - 1) / LPR); };
     P.super_grp.assign((size_t)P.nsuper + 1, 0);
-    for (int l = 0; l < nl; ++l) P.super_grp[(size_t)sup_of_level[(size_t)l] + 1] = lptr[l + 1];
-    for (int s = 0; s < P.nsuper; ++s) P.max_super_groups = std::max(P.max_super_groups, P.super_grp[s + 1] - P.super_grp[s]);
+    for (int s = 0; s < P.nsuper; ++s) {
+        const int64_t rows_s = super_first[s + 1] - super_first[s];
+        P.super_grp[(size_t)s + 1] = P.super_grp[(size_t)s] + (rows_s + RPW - 1) / RPW;
+        P.max_super_groups = std::max(P.max_super_groups, (rows_s + RPW - 1) / RPW);
+    }
+    const int64_t G = P.super_grp[(size_t)P.nsuper];
+    P.ngroups = G;
+    std::vector<int> srow((size_t)G * RPW, -1);                  // the row of every (group, row slot); -1 = dummy
+    lane_parallel(P.nsuper, [&](int64_t s0, int64_t s1) {
+        std::vector<int> rows;
+        for (int64_t s = s0; s < s1; ++s) {
+            rows.assign(order.begin() + super_first[(size_t)s], order.begin() + super_first[(size_t)s + 1]);
+            if (RPW > 1) std::stable_sort(rows.begin(), rows.end(), [&](int x, int y) { return klen(x) < klen(y); });
+            std::copy(rows.begin(), rows.end(), srow.begin() + P.super_grp[(size_t)s] * RPW);
+        }
+    }, 1);
+    P.unit.assign((size_t)G, 0); P.K.assign((size_t)G, 1); P.rid.assign((size_t)G * RPW, -1); P.gate.assign((size_t)G, -1);
+    P.rdiag.assign((size_t)G * RPW, 0.0); P.super_of.assign((size_t)G, 0);
+    for (int s = 0; s < P.nsuper; ++s)
+        for (int64_t g = P.super_grp[(size_t)s]; g < P.super_grp[(size_t)s + 1]; ++g) P.super_of[(size_t)g] = s;
     int64_t units = 0;
-    for (int64_t g = 0; g < m; ++g) {
-        const int i = order[(size_t)g];
-        const bool nodiag = !(diag[(size_t)i] != 0.0);
-        const int len = nodiag ? 0 : ref[(size_t)i].len;
-        const int k = std::max(1, (len + 63) / 64);
+    for (int64_t g = 0; g < G; ++g) {
+        int k = 1;
+        for (int r = 0; r < RPW; ++r) {
+            const int i = srow[(size_t)(g * RPW + r)];
+            if (i < 0) continue;
+            const bool nodiag = !(diag[(size_t)i] != 0.0);
+            k = std::max(k, klen(i));
+            P.rid[(size_t)(g * RPW + r)] = i | (nodiag ? LANE_NODIAG : 0);
+            P.rdiag[(size_t)(g * RPW + r)] = nodiag ? 0.0 : 1.0 / diag[(size_t)i];
+            P.max_len = std::max(P.max_len, nodiag ? 0 : ref[(size_t)i].len);
+        }
+        if (k > LANEM_KMAX) return 1;
         P.unit[(size_t)g] = (int)units;
         P.K[(size_t)g] = (unsigned char)k;
         units += k;
-        if (units >= ((int64_t)1 << 31)) return 1;
-        P.rid[(size_t)g] = i | (nodiag ? LANE_NODIAG : 0);
-        P.rdiag[(size_t)g] = nodiag ? 0.0 : 1.0 / diag[(size_t)i];
-        P.super_of[(size_t)g] = sup_of_level[(size_t)lvl[i]];
-        P.max_len = std::max(P.max_len, len);
+        if (units >= ((int64_t)1 << 27)) return 1;               // the record packs unit * 16 + K into 31 bits
     }
     P.n_units = units;
     // super-level of every visited row, and its latest early operand (the gate rule of pamg_lane_plan.h on super-levels)
     std::vector<int> sup_row((size_t)n, -1), best_dep((size_t)n, -1);
-    lane_parallel(m, [&](int64_t g0, int64_t g1) { for (int64_t g = g0; g < g1; ++g) sup_row[(size_t)order[(size_t)g]] = P.super_of[(size_t)g]; });
-    lane_parallel(m, [&](int64_t g0, int64_t g1) {
-        for (int64_t g = g0; g < g1; ++g) {
-            const int i = order[(size_t)g];
-            if (P.rid[(size_t)g] & LANE_NODIAG) continue;
+    lane_parallel(m, [&](int64_t q0, int64_t q1) { for (int64_t q = q0; q < q1; ++q) { const int i = order[(size_t)q]; sup_row[(size_t)i] = sup_of_level[(size_t)lvl[i]]; } });
+    lane_parallel(m, [&](int64_t q0, int64_t q1) {
+        for (int64_t q = q0; q < q1; ++q) {
+            const int i = order[(size_t)q];
+            if (!(diag[(size_t)i] != 0.0)) continue;
             const RowRef &rr = ref[(size_t)i];
             const int *rc = acode[(size_t)rr.arena].data() + rr.off;
             int bl = -1;
@@ -305,28 +332,31 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
     plan_fill(P.cols, (size_t)units * 64, (int)LANE_NONE);
     plan_fill(P.vals, (size_t)units * 64, 0.0);
     std::atomic<int64_t> ne(0), no(0), nb(0), nd(0);
-    lane_parallel(m, [&](int64_t g0, int64_t g1) {
+    lane_parallel(G, [&](int64_t g0, int64_t g1) {
         int64_t e_ = 0, o_ = 0, b_ = 0, d_ = 0;
         for (int64_t g = g0; g < g1; ++g) {
-            const int i = order[(size_t)g];
-            for (int p = Ap[i]; p < Ap[i + 1]; ++p) d_ += (Aj[p] != i && Aj[p] >= 0 && Aj[p] < n);
-            if (P.rid[(size_t)g] & LANE_NODIAG) continue;
-            const RowRef &rr = ref[(size_t)i];
-            const int *rc = acode[(size_t)rr.arena].data() + rr.off;
-            const double *rv = aval[(size_t)rr.arena].data() + rr.off;
-            const size_t s0 = (size_t)P.unit[(size_t)g] * 64;
             const int mysup = P.super_of[(size_t)g];
             int gl = -1;
-            for (int e = 0; e < rr.len; ++e) {
-                P.cols[s0 + (size_t)e] = rc[e];
-                P.vals[s0 + (size_t)e] = rv[e];
-                if (rc[e] & LANE_EARLY) {
-                    ++e_;
-                    int cand = rc[e] & LANEM_MASK;
-                    if (sup_row[(size_t)cand] > mysup - 2) cand = best_dep[(size_t)cand];
-                    if (cand >= 0 && sup_row[(size_t)cand] <= mysup - 2 && sup_row[(size_t)cand] > gl) { gl = sup_row[(size_t)cand]; P.gate[(size_t)g] = cand; }
-                } else if (rc[e] & LANEM_BSRC) ++b_;
-                else ++o_;
+            for (int r = 0; r < RPW; ++r) {
+                const int i = srow[(size_t)(g * RPW + r)];
+                if (i < 0) continue;
+                for (int p = Ap[i]; p < Ap[i + 1]; ++p) d_ += (Aj[p] != i && Aj[p] >= 0 && Aj[p] < n);
+                if (P.rid[(size_t)(g * RPW + r)] & LANE_NODIAG) continue;
+                const RowRef &rr = ref[(size_t)i];
+                const int *rc = acode[(size_t)rr.arena].data() + rr.off;
+                const double *rv = aval[(size_t)rr.arena].data() + rr.off;
+                for (int e = 0; e < rr.len; ++e) {
+                    const size_t sl = ((size_t)P.unit[(size_t)g] + (size_t)(e / LPR)) * 64 + (size_t)(r * LPR + e % LPR);
+                    P.cols[sl] = rc[e];
+                    P.vals[sl] = rv[e];
+                    if (rc[e] & LANE_EARLY) {
+                        ++e_;
+                        int cand = rc[e] & LANEM_MASK;
+                        if (sup_row[(size_t)cand] > mysup - 2) cand = best_dep[(size_t)cand];
+                        if (cand >= 0 && sup_row[(size_t)cand] <= mysup - 2 && sup_row[(size_t)cand] > gl) { gl = sup_row[(size_t)cand]; P.gate[(size_t)g] = cand; }
+                    } else if (rc[e] & LANEM_BSRC) ++b_;
+                    else ++o_;
+                }
             }
         }
         ne += e_; no += o_; nb += b_; nd += d_;

@@ -1866,6 +1866,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 26: if (value < 0) return PAMG_E_ARG; A->lane_G = value; return PAMG_OK;
         case 27: if (value < 0 || value > 1) return PAMG_E_ARG; A->lane_wide = value; return PAMG_OK;
         case 33: if (value < 0 || value > 8) return PAMG_E_ARG; A->lane_merge = value; break;
+        case 35: if (value < 0 || value > 2) return PAMG_E_ARG; A->lanem_rpw = value; break;
         case 34: if (value < 1 || value > 400) return PAMG_E_ARG; A->lanem_ahead10 = value; return PAMG_OK;
         case 30:                                               // 2: also where the estimate favours the lane form
             if (value < 0 || value > 2) return PAMG_E_ARG;
@@ -1877,7 +1878,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 28: if (value < 0 || value > 15 || (value & 6)) return PAMG_E_ARG; A->lane_flags = value; return PAMG_OK;      // bits 1, 2: retired (slab form, old values through the L1)
         default: return PAMG_E_ARG;
     }
-    if (key == 25 || key == 33) {                     // lane geometry / merging: drop the lane parts only
+    if (key == 25 || key == 33 || key == 35) {         // lane geometry / merging: drop the lane parts only
         for (int k = 0; k < 4; ++k) {
             GsSchedule *g = A->gs[k];
             if (g) g->lane_unfit = false;

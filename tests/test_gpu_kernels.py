@@ -327,7 +327,8 @@ def test_gs_merged_fast_order_agrees_to_rounding():
     """The MERGED fast order (round 6; tune lane_merge = s, csrc/pamg_lanem_plan.h, gs_lanem_kernel in pamg_lane.hip): s consecutive dependency
     levels of the reference's sweep (relaxation.h:48-76) are eliminated algebraically into one super-level, the sweep pays one hand-off per
     super-level.  Against the ORACLE's sequential sweep (1e-13 relative per call) and the order-exact device sweep, s = 2 .. 8, static form across the
-    chip and ticket form inside one XCD, with and without the gate operand, tiny grids (waves that wait), forward / backward / symmetric;
+    chip and ticket form inside one XCD, one row per wave and TWO (32 lanes each, rows of a super-level paired by length), with and without the gate
+    operand, tiny grids (waves that wait), forward / backward / symmetric;
     rows with zero / missing diagonals stay untouched; a structurally non-symmetric pattern; bit-reproducible; an operator that is NOT
     diagonally dominant must make the planner close groups early (growth bound) or decline, and still give the sequential sweep's answer; SOR on
     the same operator takes the unmerged layout; f32 keeps the unmerged form."""
@@ -372,7 +373,9 @@ def test_gs_merged_fast_order_agrees_to_rounding():
         dA.tune(gs_order=1, lane_wide=1, line_scan=0)
         hops = {}
         for kw in (dict(lane_merge=1), dict(lane_merge=2), dict(lane_merge=3), dict(lane_merge=3, gran_xcd=1), dict(lane_merge=4, gran_xcd=2, lane_G=3),
-                   dict(lane_merge=8, gran_xcd=1, lane_G=1), dict(lane_merge=5, gran_xcd=0, lane_G=0, lane_flags=0), dict(lane_merge=0, lane_flags=1, lanem_ahead=60)):
+                   dict(lane_merge=8, gran_xcd=1, lane_G=1), dict(lane_merge=5, gran_xcd=0, lane_G=0, lane_flags=0), dict(lane_merge=0, lane_flags=1, lanem_ahead=60),
+                   dict(lane_merge=3, lanem_rpw=2, gran_xcd=2), dict(lane_merge=2, lanem_rpw=2, gran_xcd=1, lane_G=2), dict(lane_merge=6, lanem_rpw=2, gran_xcd=0, lane_flags=0),
+                   dict(lane_merge=3, lanem_rpw=0)):
             dA.tune(**kw)
             dx.upload(x)
             dA.gauss_seidel(dx, db, sweep="symmetric", iterations=2)

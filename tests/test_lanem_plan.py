@@ -34,7 +34,7 @@ def emul():
     return lib
 
 
-def run_emul(lib, A, x, b, start, stop, step, s_max, growth_cap=1e3, len_cap=512, waves=0, plan_only=0):
+def run_emul(lib, A, x, b, start, stop, step, s_max, growth_cap=1e3, len_cap=512, waves=0, plan_only=0, rpw=1):
     A = sp.csr_array(A)
     Ap = np.ascontiguousarray(A.indptr, dtype=np.int32)
     Aj = np.ascontiguousarray(A.indices, dtype=np.int32)
@@ -44,7 +44,7 @@ def run_emul(lib, A, x, b, start, stop, step, s_max, growth_cap=1e3, len_cap=512
     gs = np.zeros(2)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     rc = lib.lanem_emul_sweep_f64(ctypes.c_int(A.shape[0]), p(Ap), p(Aj), p(Ax), p(xx), p(np.ascontiguousarray(b, dtype=np.float64)),
-                                  start, stop, step, s_max, ctypes.c_double(growth_cap), len_cap, p(stats), p(gs), waves, plan_only)
+                                  start, stop, step, s_max, ctypes.c_double(growth_cap), len_cap, p(stats), p(gs), waves, plan_only, rpw)
     names = ("super", "levels", "rows", "units", "early", "old", "b", "direct", "max_len", "closed_len", "closed_growth", "widest", "k1", "k2", "k3", "k4")
     return rc, xx, dict(zip(names, (int(v) for v in stats)), growth=float(gs[0]))
 
@@ -94,6 +94,14 @@ def test_merged_sweep_agrees_with_the_sequential_sweep(emul):
                     rc, got, st = run_emul(emul, A, x, b, start, stop, step, s, waves=waves)
                     assert rc == 0, (name, s, waves, rc)
                     assert np.max(np.abs(got - ref)) <= TOL * np.max(np.abs(ref)), (name, s, waves, np.max(np.abs(got - ref)))
+                    # two rows per wave (32 lanes each, rows of a super-level paired by length): the same rows, the same super-levels
+                    rc2, got2, st2 = run_emul(emul, A, x, b, start, stop, step, s, waves=waves, rpw=2)
+                    if rc2 == 2:
+                        assert st["max_len"] > 256, (name, s)                      # only rows beyond 8 x 32 operands make the pair form decline
+                        continue
+                    assert rc2 == 0, (name, s, waves, rc2)
+                    assert np.max(np.abs(got2 - ref)) <= TOL * np.max(np.abs(ref)), (name, s, waves)
+                    assert st2["rows"] == st["rows"] and st2["early"] + st2["old"] + st2["b"] > 0 or st["direct"] == 0
                 supers.append(st["super"])
                 assert st["rows"] == len(range(start, stop, step)) and st["b"] >= 0
                 if s == 1:

@@ -17,6 +17,7 @@ ap.add_argument("--grid", type=int, nargs="+", default=[256, 256, 256])
 ap.add_argument("--level", type=int, default=1)
 ap.add_argument("--s", type=int, nargs="+", default=[2, 3])
 ap.add_argument("--grids", type=int, nargs="+", default=[768])
+ap.add_argument("--rpw", type=int, default=0)
 a = ap.parse_args()
 A = pyamg.gallery.poisson(tuple(a.grid), format="csr")
 np.random.seed(1)
@@ -30,7 +31,7 @@ dA = DeviceMatrix(op)
 dx, db = capi.DeviceArray.from_host(rng.rand(n)), capi.DeviceArray.from_host(rng.rand(n))
 dA.tune(gs_order=1, lane_wide=1)
 for s in a.s:
-    dA.tune(lane_merge=s)
+    dA.tune(lane_merge=s, lanem_rpw=a.rpw)
     for G in a.grids:
         dA.tune(lane_G=G, gs_prof=0)
         for _ in range(3):
@@ -53,7 +54,7 @@ for s in a.s:
         t1, t2, t3 = pr[:, 1], pr[:, 2], pr[:, 3]
         base = t0.min()
         us = lambda v: 0.01 * v
-        sup = np.searchsorted(lv, np.arange(n), side="right") - 1
+        sup = np.searchsorted(lv, np.arange(pr.shape[0]), side="right") - 1            # stamps are per GROUP (one or two rows)
         # per super-level: when its last row was published
         last_pub = np.zeros(len(lv) - 1)
         np.maximum.at(last_pub, sup, us(t3 - base))

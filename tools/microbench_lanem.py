@@ -22,6 +22,7 @@ ap.add_argument("--ahead", type=int, nargs="+", default=[23])
 ap.add_argument("--grids", type=int, nargs="+", default=[0])
 ap.add_argument("--gate", type=int, nargs="+", default=[1])
 ap.add_argument("--xcd", type=int, nargs="+", default=[0])
+ap.add_argument("--rpw", type=int, nargs="+", default=[0])
 ap.add_argument("--tag", default="lanem")
 a = ap.parse_args()
 A = pyamg.gallery.poisson(tuple(a.grid), format="csr")
@@ -61,9 +62,9 @@ for li in a.levels:
     t_exact = timeit(lambda: dA.gauss_seidel(dx, db, sweep="forward"))
     rec = {"level": li, "rows": int(n), "nnz": int(op.nnz), "dependency_levels": dA.info()["gs_levels_fwd"], "exact_ms": round(t_exact, 4), "variants": []}
     dA.tune(gs_order=1, lane_wide=1)
-    for s in a.s:
+    for s, rpw in [(s_, r_) for s_ in a.s for r_ in a.rpw]:
         t0 = time.time()
-        dA.tune(lane_merge=s)
+        dA.tune(lane_merge=s, lanem_rpw=rpw)
         for gate in a.gate:
             for ah in a.ahead:
                 for G, xcd in [(G_, x_) for G_ in a.grids for x_ in a.xcd]:
@@ -76,7 +77,7 @@ for li in a.levels:
                     ms = timeit(lambda: dA.gauss_seidel(dx, db, sweep="forward"))
                     mi, li_ = dA.lanem_info(0), dA.lane_info(0)
                     hops = mi["super_levels"] or rec["dependency_levels"]
-                    v = {"s": s, "gate": gate, "ahead10": ah, "lane_G": G, "gran_xcd": xcd, "ms_forward": round(ms, 4), "hand_offs": int(hops), "us_per_hand_off": round(1e3 * ms / hops, 3),
+                    v = {"s": s, "rpw": rpw, "gate": gate, "ahead10": ah, "lane_G": G, "gran_xcd": xcd, "ms_forward": round(ms, 4), "hand_offs": int(hops), "us_per_hand_off": round(1e3 * ms / hops, 3),
                          "max_rel_diff_vs_exact_symmetric_sweep": err, "units_per_row": round(mi["units"] / max(1, mi["rows"]), 3) if mi["rows"] else None,
                          "operands_per_row": round((mi["early_operands"] + mi["old_operands"] + mi["b_operands"]) / max(1, mi["rows"]), 2) if mi["rows"] else None,
                          "slot_GB": round(mi["units"] * 64 * 12 / 1e9, 3) if mi["rows"] else round(li_["entry_slots"] * 12 / 1e9, 3),
