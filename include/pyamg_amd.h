@@ -357,6 +357,14 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * dependency level away; bit 3: the same in the line scan, off; bits 1, 2 retired with the slab form in round 5),
  * 30 = line-scan form of the fast order (default 1) where consecutive swept rows are coupled AND
  * enough lines run side by side to beat the lane form by the planner's estimate (3-D grids; not 2-D grids in natural order); 2 = wherever it applies.
+ * 33 = MERGED fast order (round 6; f64 Gauss-Seidel): dependency levels of the sweep eliminated algebraically into one super-level at most -- 0 (default)
+ * automatic (3 on levels above 131 072 rows, 6 below, off under 12 entries per row or 8 dependency levels), 1 never, 2..8; the sweep then pays one
+ * hand-off per super-level; same iterates in exact arithmetic, another association in floating point; groups are closed early where a merged row would
+ * exceed 512 operands (256 with two rows per wave) or its growth factor 1e3 (csrc/pamg_lanem_plan.h; pamg_matrix_lanem_info); 34 = its persistent waves
+ * as tenths of the rows of an average super-level (default 40); 35 = its rows per wave: 1 (64 lanes per row), 2 (32 lanes per row, rows of a
+ * super-level paired by length), 0 (default) = 2 on levels above 131 072 rows.
+ * Key 8, bit 5 (round 6): an operator WITHOUT 8-bit value codes through the kernel instantiation that carries their paths (same arithmetic, another
+ * instruction schedule; pamg_matrix_autotune times both).
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */
 int pamg_matrix_tune(pamg_matrix_t A, int key, int value);
 /* n_values = size of the operator's value dictionary when the whole-operator kernels stream 8-bit value codes

@@ -560,10 +560,12 @@ __device__ __forceinline__ void m_publish(const LaneMArgs &a, const MCtx<NREG> &
     }
 }
 
-template <int MODE, int RPW>
+// NREG = units of a group held in registers: 2 (one row per wave) / 4 (two rows per wave) on the large levels, where eight waves per SIMD matter;
+// 8 on the small levels, whose sweeps are bound by their hand-offs -- there the sequential tail of a long row sits on the critical path (level 2 of the
+// 256^3 hierarchy at s = 6: 56 % of the rows hold three and more units)
+template <int MODE, int RPW, int NREG>
 __global__ __launch_bounds__(BLK) void gs_lanem_kernel(const LaneMArgs a)
 {
-    constexpr int NREG = RPW == 1 ? 2 : 4;                     // 128 operand slots per row in registers either way
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int idle = (int)((((unsigned)blockIdx.x * LANE_WPB + (unsigned)wib) * 16u) % (unsigned)a.nidle);
@@ -858,8 +860,9 @@ int lanem_smax(const pamg_matrix_s *A, const GsSchedule *g)
     if (e && atoi(e) >= 1) return atoi(e);
     if (A->nnz < 12 * std::max<int64_t>(1, A->nrows)) return 1;
     // large levels: 3 (level 1 of the 256^3 hierarchy: 1.80 ms at 2, 1.76 at 3, 2.14 at 4 -- the sweep is bound by rows per second, longer rows cost);
-    // small levels are bound by their hand-offs: 6 (level 2, 44.6 K rows: 0.485 ms at 4, 0.46 at 6 and 8; level 3, 463 rows: 0.042 at 4, 0.034 at 6)
-    return A->nrows > 131072 ? 3 : 6;
+    // small levels are bound by their hand-offs: 8 (every unit in registers there; level 2, 44.6 K rows: 0.484 ms at 4, 0.447 at 6, 0.440 at 8; level 3,
+    // 463 rows: 0.052 / 0.042 / 0.034)
+    return A->nrows > 131072 ? 3 : 8;
 }
 
 int build_lanem_part(pamg_matrix_s *A, GsSchedule *g)
@@ -939,8 +942,11 @@ int lanem_launch(pamg_matrix_s *A, GsSchedule *g, void *x, const void *b, hipStr
     // the ticket form inside one XCD only for tiny levels: one row per group means one ticket per ROW, and the ticket counter is one address whose
     // atomics serialise (11.4 ns each) -- level 2 of the 256^3 hierarchy (44.6 K rows): 0.58 ms inside one XCD, 0.48 across the chip
     const bool xcd = A->gran_xcd == 1 || (A->gran_xcd == 0 && lane_one_xcd(A, g) && A->nrows <= 8192);
-    const void *k = t->rpw == 2 ? (xcd ? (const void *)gs_lanem_kernel<1, 2> : (const void *)gs_lanem_kernel<0, 2>)
-                                : (xcd ? (const void *)gs_lanem_kernel<1, 1> : (const void *)gs_lanem_kernel<0, 1>);
+    static const int nreg_env = [] { const char *e = getenv("PAMG_LANEM_NREG"); return e ? atoi(e) : 0; }();     // A/B: 2 / 8 units in registers on one-row-per-wave levels
+    const bool all_regs = t->rpw == 1 && (nreg_env ? nreg_env == 8 : A->nrows <= 131072);
+    const void *k = t->rpw == 2 ? (xcd ? (const void *)gs_lanem_kernel<1, 2, 4> : (const void *)gs_lanem_kernel<0, 2, 4>)
+                  : all_regs    ? (xcd ? (const void *)gs_lanem_kernel<1, 1, 8> : (const void *)gs_lanem_kernel<0, 1, 8>)
+                                : (xcd ? (const void *)gs_lanem_kernel<1, 1, 2> : (const void *)gs_lanem_kernel<0, 1, 2>);
     static thread_local int cus = 0;
     if (!cus) cus = device_cus_lane();
     if (!(t->cap > 0 && t->cap_kernel == k)) {

@@ -23,6 +23,7 @@ ap.add_argument("--grids", type=int, nargs="+", default=[0])
 ap.add_argument("--gate", type=int, nargs="+", default=[1])
 ap.add_argument("--xcd", type=int, nargs="+", default=[0])
 ap.add_argument("--rpw", type=int, nargs="+", default=[0])
+ap.add_argument("--sweep", default="forward")
 ap.add_argument("--tag", default="lanem")
 a = ap.parse_args()
 A = pyamg.gallery.poisson(tuple(a.grid), format="csr")
@@ -74,8 +75,9 @@ for li in a.levels:
                     got = dx.download()
                     tb = time.time() - t0
                     err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
-                    ms = timeit(lambda: dA.gauss_seidel(dx, db, sweep="forward"))
-                    mi, li_ = dA.lanem_info(0), dA.lane_info(0)
+                    ms = timeit(lambda: dA.gauss_seidel(dx, db, sweep=a.sweep))
+                    wh_ = 1 if a.sweep == "backward" else 0
+                    mi, li_ = dA.lanem_info(wh_), dA.lane_info(wh_)
                     hops = mi["super_levels"] or rec["dependency_levels"]
                     v = {"s": s, "rpw": rpw, "gate": gate, "ahead10": ah, "lane_G": G, "gran_xcd": xcd, "ms_forward": round(ms, 4), "hand_offs": int(hops), "us_per_hand_off": round(1e3 * ms / hops, 3),
                          "max_rel_diff_vs_exact_symmetric_sweep": err, "units_per_row": round(mi["units"] / max(1, mi["rows"]), 3) if mi["rows"] else None,

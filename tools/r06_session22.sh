@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
+TAG=r06 bash tools/gpu_run.sh tests:merged,or,fast_order,or,midsize,or,long_dep prof:c3 prof:c2 prof:c4x prof:c5 2>&1 | tail -30
+python bench.py > gpurun_out/r06_bench_n1.json 2> gpurun_out/r06_bench_n1.err; echo "bench rc=$?"; wc -c gpurun_out/r06_bench_n1.json; cp gpurun_out/bench_detail.json gpurun_out/r06_bench_detail_n1.json
+python -c "
+import json; d=json.load(open('gpurun_out/r06_bench_n1.json')); print({k:v for k,v in d.items() if k in ('value','ms_per_step','extra_c4_ms','extra_c2_ms','extra_c5_block_gauss_seidel_ms') or k.startswith('gs_sweep_ms')}); print(d['roofline']['general_csr_ms'], d['roofline']['frac'], d['host'])"

@@ -41,9 +41,10 @@ def short(name):
     m = re.search(r"gs_lane_kernel<(\w+), *(\d+), *(\d+), *(\d+), *(\w+)>", name)
     if m:
         return f"gs_lane<{m.group(1)},{EPI[int(m.group(2))]},L{m.group(3)},K{m.group(4)},{'oneXCD' if m.group(5) in ('true', '1') else 'chip'}>"
-    m = re.search(r"gs_lanem\w*_kernel<(\w+)>", name)
+    m = re.search(r"gs_lanem\w*_kernel<(\w+)(?:, *(\d+))?(?:, *(\d+))?>", name)
     if m:
-        return f"gs_lanem<double,GS,{'oneXCD' if m.group(1) in ('true', '1') else 'chip'}>"
+        return (f"gs_lanem<double,GS,{'oneXCD' if m.group(1) in ('true', '1') else 'chip'}" + (f",rpw{m.group(2)}" if m.group(2) else "")
+                + (f",regs{m.group(3)}" if m.group(3) else "") + ">")
     m = re.search(r"gs_line_kernel<(\w+), *(\d+), *(\d+)>", name)
     if m:
         return f"gs_line<{m.group(1)},{EPI[int(m.group(2))]},K{m.group(3)}>"
