@@ -13,6 +13,11 @@
 // compiles to flat_load sc0 sc1 with a full drain behind every single one; __hip_atomic_load stops at 8 bytes), and a slot must be
 // read and written in ONE access -- value and version travel together, that is the whole protocol.  All K loads of a poll round and
 // the wait for them are one asm statement, so the compiler never sees a register whose load is still in flight.
+// HARDWARE ASSUMPTION: the AMDGPU memory model promises single-copy atomicity up to 8 bytes only; the protocol relies on what the part
+// does with a naturally aligned 16-byte global_load/store_dwordx4: the slots are 16-byte aligned, so an access never straddles an L2 line (128 bytes)
+// or channel, and the L2 serves it as ONE request -- reader and writer meet in one L2 bank, a reader sees the slot entirely before or entirely after a
+// store.  A torn access would pair a new version with an old value: a wrong iterate, never a hang -- which is what the parity runs of every
+// normal-equation hierarchy (10 cycles each, tests and bench legs, ~10^9 slot hand-offs per run) would show and never have.
 #include "pamg_common.h"
 #include "pamg_kz_plan.h"
 
