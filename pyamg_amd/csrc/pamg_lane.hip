@@ -466,7 +466,10 @@ __device__ __forceinline__ void m_gather(const LaneMArgs &a, MCtx<NREG> &C, int 
     // the static operands were measured 3 - 5 % slower, profiles/r06_microbench_lanem_plain_loads_for_static_operands_not_kept.json)
 #pragma unroll
     for (int k = 0; k < NREG; ++k) {
-        const int col = C.c[k] & LANEM_MASK;
+        int col = C.c[k] & LANEM_MASK;
+#ifdef PAMG_LANEM_FAKE_LOCALITY      /* experiment only (wrong results): every static operand next to the row -- what perfect locality of the gathers would buy */
+        if (!(C.c[k] & LANE_EARLY)) col = (row & ~63) + (int)(threadIdx.x & 63);
+#endif
         const double *p = (C.c[k] & LANE_NONE) ? a.xold + idle : ((C.c[k] & LANE_EARLY) ? a.xs + col : ((C.c[k] & LANEM_BSRC) ? a.b + col : a.xold + col));
         C.xv[k] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
