@@ -117,6 +117,9 @@ __device__ __forceinline__ T spin_value(const T *xs, int j, unsigned *err)
     return v;
 }
 
+#ifdef PAMG_FAKE_RUNTABLE
+__shared__ double pamg_fake_xl[1024];
+#endif
 // gather of one x value in the three flavours of the kernel family:
 //   plain (COH = 0): ordinary cached load;  COH = 1: L1-bypassing load (block sweeps with a barrier per level);
 //   COH = 2 (granular sweep): early entries spin on the hand-off buffer, the others read x.
@@ -197,7 +200,11 @@ __device__ __forceinline__ void stage_pairs16(const StreamArgs<T> &a, int p0, in
         const bool ok0 = q >= p0, ok1 = q + 1 < p1;
         T x0, x1;
         if (a.flags & 4) {                        // ablation: operator stream only, no gather
+#ifdef PAMG_FAKE_RUNTABLE            /* experiment only (wrong results): the operands from an LDS stage of x, as a run-table kernel would read them */
+            x0 = (T)pamg_fake_xl[cc.x & 1023]; x1 = (T)pamg_fake_xl[cc.y & 1023];
+#else
             x0 = T(cc.x); x1 = T(cc.y);
+#endif
         } else {
             x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
             x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
@@ -233,7 +240,11 @@ __device__ __forceinline__ void stage_pairs32(const StreamArgs<T> &a, int p0, in
         const bool ok0 = q >= p0, ok1 = q + 1 < p1;
         T x0, x1;
         if (a.flags & 4) {                            // ablation: operator stream only, no gather
+#ifdef PAMG_FAKE_RUNTABLE            /* experiment only (wrong results): the operands from an LDS stage of x, as a run-table kernel would read them */
+            x0 = (T)pamg_fake_xl[cc.x & 1023]; x1 = (T)pamg_fake_xl[cc.y & 1023];
+#else
             x0 = T(cc.x); x1 = T(cc.y);
+#endif
         } else {
             x0 = ok0 ? gather_x<COH>(a, cc.x) : T(0);
             x1 = ok1 ? gather_x<COH>(a, cc.y) : T(0);
@@ -591,6 +602,14 @@ __device__ __forceinline__ void stream_block(const StreamArgs<T> &a, const int4 
         int r = r0 + tid;
         RowPre<T> q;
         if (r < r1) q = row_prefetch<T, EPI, COH>(a, r);
+#ifdef PAMG_FAKE_RUNTABLE
+        if constexpr (COH == 0) {
+            // 1 024 values of x (what the ~140 column runs of a range of an SA-level operator hold) by coalesced loads, then the barrier a run-table kernel needs
+            const int c0 = (int)(((unsigned)blockIdx.x * 1024u) & ((1u << 20) - 1u));      // (with flag 4 only, on operators with >= 2^20 + 1024 columns: the SA levels of 256^3)
+            if (a.flags & 4) { for (int i = tid; i < 1024; i += BLK) pamg_fake_xl[i] = (double)a.x[c0 + i]; }     // (ablation flag 4 selects the experiment)
+            __syncthreads();
+        }
+#endif
         if (vd) __syncthreads();
         stage_products<T, NEEDC, NPL, COH, EpiTraits<EPI>::diag_flag>(a, p0, p1, base, prod, cols, vd);
         __syncthreads();
