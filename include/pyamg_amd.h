@@ -363,6 +363,8 @@ int pamg_matrix_info(pamg_matrix_t A, int64_t info[8]);
  * exceed 512 operands (256 with two rows per wave) or its growth factor 1e3 (csrc/pamg_lanem_plan.h; pamg_matrix_lanem_info); 34 = its persistent waves
  * as tenths of the rows of an average super-level (default 40); 35 = its rows per wave: 1 (64 lanes per row), 2 (32 lanes per row, rows of a
  * super-level paired by length), 0 (default) = 2 on levels above 131 072 rows.
+ * 36 = unused dynamic LDS (bytes) added to the launches of the staged whole-operator kernel: caps its workgroups per CU (a measurement knob: on the SA-level
+ * operators the instantiation choice of key 8 bit 5 already sits at the best occupancy, profiles/r06_microbench_sa_ops_lds_pad.json).
  * Key 8, bit 5 (round 6): an operator WITHOUT 8-bit value codes through the kernel instantiation that carries their paths (same arithmetic, another
  * instruction schedule; pamg_matrix_autotune times both).
  * Returns PAMG_E_STATE while a solver holds the operator (captured graphs point into the plans). */

@@ -197,6 +197,7 @@ struct pamg_matrix_s {
     int use_rowpat = 1;              // tune key 23: 0 off, 1 the row-mask kernels where the operator has the form, else the table kernel (default), 3 the table kernel always, 4 the linear row-mask kernel instead of the lattice form
     int cap_from_val8 = 0;           // cap was raised to 2048 because the operator streams value codes (level schedules keep 1536)
     int stream_flags = 0;            // StreamArgs::flags for the whole-operator launches
+    int lds_pad = 0;                 // extra (unused) dynamic LDS of the staged whole-operator kernel: fewer workgroups per CU   (tune key 36, autotune)
     int gran_xcd = 0;                // granular sweep inside one XCD's L2: 0 auto (small operators), 1 always, 2 never
     int gran_cap = 0;                // granular sweep: cap on the persistent grid (0 = auto)
     int gs_mode = 0;                 // scalar sweep scheduler: 0 auto, 1 one launch per level, 2 granular, 3 single workgroup, 5 tiled

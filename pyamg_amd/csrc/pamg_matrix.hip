@@ -919,7 +919,7 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
         if (n == 0) return PAMG_OK;
         const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2;
         const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
-        const int lds = lds_bytes(A->dtype, epi, A->cap) + (val8 ? val8_lds(A, epi) : 0);
+        const int lds = lds_bytes(A->dtype, epi, A->cap) + (val8 ? val8_lds(A, epi) : 0) + A->lds_pad;
         const bool rowg = val8 && A->use_rowg && A->max_row_len <= A->cap;
         const bool rowp = val8 && A->use_rowpat && A->d_pid;
         if (A->dtype == PAMG_F64) {
@@ -951,7 +951,7 @@ int stream_launch_part(pamg_matrix_s *A, int part, int epi, const void *x, const
         if (rowg) { const int st = launch_rowgather<float>(epi, n, A->cap, A->nvdict, s, a); if (st != 1) return st; }
         return launch_any<float>(epi, A->npl, n, lds, s, a);
     }
-    int lds = lds_bytes(A->dtype, epi, A->cap);
+    int lds = lds_bytes(A->dtype, epi, A->cap) + A->lds_pad;        // lds_pad (tune key 36): unused LDS that caps the workgroups per CU of the staged kernel
     const int grid = (A->stream_flags & 2) ? 8 * ((A->nblk + 7) / 8) : A->nblk;
     const bool idx16 = A->use_idx16 && A->d_Aj16 && A->npl == 2;
     const bool val8 = idx16 && A->use_val8 && A->d_Ax8;
@@ -1867,6 +1867,7 @@ int pamg_matrix_tune(pamg_matrix_t A, int key, int value)
         case 27: if (value < 0 || value > 1) return PAMG_E_ARG; A->lane_wide = value; return PAMG_OK;
         case 33: if (value < 0 || value > 8) return PAMG_E_ARG; A->lane_merge = value; break;
         case 35: if (value < 0 || value > 2) return PAMG_E_ARG; A->lanem_rpw = value; break;
+        case 36: if (value < 0 || value > 98304) return PAMG_E_ARG; A->lds_pad = value & ~15; return PAMG_OK;
         case 34: if (value < 1 || value > 400) return PAMG_E_ARG; A->lanem_ahead10 = value; return PAMG_OK;
         case 30:                                               // 2: also where the estimate favours the lane form
             if (value < 0 || value > 2) return PAMG_E_ARG;

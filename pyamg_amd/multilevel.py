@@ -177,14 +177,14 @@ class DeviceMatrix:
 
     def tune(self, lds_entries=None, nnz_per_lane=None, max_rows=None, flow_cap=None, gs_mode=None, gran_cap=None, gran_xcd=None, stream_flags=None, gs_prof=None,
              tile_G=None, tile_W=None, tile_cap=None, tile_default=None, tile_D=None, tile_Q=None, tile_part=None, idx16=None, gs_cap=None, val8=None, rowgather=None, rowpat=None,
-             gs_order=None, lane_L=None, lane_G=None, lane_wide=None, lane_flags=None, line_scan=None, rowmask_kz=None, rowmask_flags=None, lane_merge=None, lanem_ahead=None, lanem_rpw=None):
+             gs_order=None, lane_L=None, lane_G=None, lane_wide=None, lane_flags=None, line_scan=None, rowmask_kz=None, rowmask_flags=None, lane_merge=None, lanem_ahead=None, lanem_rpw=None, lds_pad=None):
         """Speed-only knobs (every setting computes the same bits) -- except gs_order: 0 = order-exact row sums (the reference's
         bits), 1 = fast order (lane-parallel row sums, same sweep order, agrees to rounding).  Refused (PAMG_E_STATE) once a solver holds the
         operator: captured graphs point into the plans these calls rebuild."""
         lib = capi.lib()
         for key, v in ((0, lds_entries), (1, nnz_per_lane), (2, max_rows), (3, flow_cap), (5, gs_mode), (6, gran_cap), (7, gran_xcd), (8, stream_flags), (11, gs_prof),
                        (12, tile_G), (13, tile_W), (14, tile_cap), (15, tile_default), (16, tile_D), (17, tile_Q), (18, tile_part), (19, idx16), (20, gs_cap), (21, val8), (22, rowgather), (23, rowpat),
-                       (24, gs_order), (25, lane_L), (26, lane_G), (27, lane_wide), (28, lane_flags), (30, line_scan), (31, rowmask_kz), (32, rowmask_flags), (33, lane_merge), (34, lanem_ahead), (35, lanem_rpw)):
+                       (24, gs_order), (25, lane_L), (26, lane_G), (27, lane_wide), (28, lane_flags), (30, line_scan), (31, rowmask_kz), (32, rowmask_flags), (33, lane_merge), (34, lanem_ahead), (35, lanem_rpw), (36, lds_pad)):
             if v is not None:
                 capi.check(lib.pamg_matrix_tune(self.handle, key, int(v)), "pamg_matrix_tune")
 

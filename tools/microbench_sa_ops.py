@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--grid", type=int, nargs="+", default=[256, 256, 256])
 ap.add_argument("--tag", default="sa_ops")
 ap.add_argument("--idx16", type=int, default=0)       # 1: 16-bit column codes (where the plan has them) against 32-bit columns (flags + 16 here = tune idx16 0)
+ap.add_argument("--pads", type=int, nargs="+", default=None)   # LDS padding sweep (tune key 36) x stream flags 0 / 32 (instantiation)
 ap.add_argument("--ablate", type=int, default=0)      # flags: +4 no gather, +8 no row phase (results are wrong by design)
 a = ap.parse_args()
 A = pyamg.gallery.poisson(tuple(a.grid), format="csr")
@@ -33,9 +34,12 @@ for name, op, epi in ops:
     x = capi.DeviceArray.from_host(rng.rand(n)); b = capi.DeviceArray.from_host(rng.rand(m)); y = capi.DeviceArray(m, np.float64)
     ref = None
     by = 12 * op.nnz + 4 * (m + 1) + 8 * n + 8 * m + (8 * m if epi == capi.SPMV_RESID else 0)
-    for cap in ((1536,) if (a.ablate or a.idx16) else (1536, 1024, 2048, 3072)):
-        for fl in ((1, 5, 9, 13) if a.ablate else (0, 1, 2, 3) if not a.idx16 else (0, 1, 16 + 0, 16 + 1)):
-            dA.tune(lds_entries=cap, stream_flags=fl & 15, idx16=0 if (a.idx16 and fl & 16) else 1)
+    combos = [(1536, fl, 0) for fl in ((1, 5, 9, 13) if a.ablate else (0, 1, 16 + 0, 16 + 1))] if (a.ablate or a.idx16) else [(c_, f_, 0) for c_ in (1536, 1024, 2048, 3072) for f_ in (0, 1, 2, 3)]
+    if a.pads is not None:
+        combos = [(1536, fl, pad) for pad in a.pads for fl in (0, 32)]
+    for cap, fl, pad in combos:
+        if True:
+            dA.tune(lds_entries=cap, stream_flags=(fl & 15) | (fl & 32), idx16=0 if (a.idx16 and fl & 16) else 1, lds_pad=pad)
             kw = dict(b=b) if epi == capi.SPMV_RESID else {}
             for _ in range(3):
                 dA.spmv(epi, x, y, **kw)
@@ -49,7 +53,7 @@ for name, op, epi in ops:
                 dA.spmv(epi, x, y, **kw)
             e1.record(); e1.synchronize()
             ms = e0.elapsed_ms(e1) / 20
-            rec = {"op": name, "shape": [m, n], "nnz": int(op.nnz), "cap": cap, "flags": fl, "ms": round(ms, 5), "alg_GBps": round(by / ms / 1e6, 1), "bit_identical": bool(np.array_equal(got, ref))}
+            rec = {"op": name, "shape": [m, n], "nnz": int(op.nnz), "cap": cap, "flags": fl, "lds_pad": pad, "ms": round(ms, 5), "alg_GBps": round(by / ms / 1e6, 1), "bit_identical": bool(np.array_equal(got, ref))}
             print(rec, flush=True)
             out.append(rec)
     dA.free()
