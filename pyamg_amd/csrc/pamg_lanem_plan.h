@@ -154,7 +154,7 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
     //      closed when it holds s_max levels, or in front of a level whose merged rows would come out too long / too large
     const int wlev = 4 * s_max;
     const int nblocks = (nl + wlev - 1) / wlev;
-    const unsigned hw = std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::min(96u, std::thread::hardware_concurrency() / 2u + 1u));      // (two sweep directions are planned at once)
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw, (int64_t)nblocks, std::max<int64_t>(1, (int64_t)m / 4096)}));
     std::vector<std::vector<int>> acode((size_t)nt);
     std::vector<std::vector<double>> aval((size_t)nt);
