@@ -108,9 +108,9 @@ for f in glob.glob(str(out / "trace" / "**" / "*kernel_trace.csv"), recursive=Tr
         import math
         for (k, g) in list(durs):
             fam, epi = family(k)
-            if fam not in ("gs_lane", "gs_lanem", "gs_line", "gs_tile", "gs_gran", "bsr_lane"):
+            if fam not in ("gs_lane", "gs_lanem", "gs_line", "gs_tile", "gs_gran"):        # (block sweeps: the kernel name carries the block size of its level)
                 continue
-            lv = sorted({e["level"] for e in kmap["entries"] if e["family"] == fam and (e["grid"] is None or e["grid"] == g)})
+            lv = sorted({e["level"] for e in kmap["entries"] if e["family"] == fam and e.get("grid") == g})      # (entries that name THIS grid: a family without grids is told apart otherwise)
             if len(lv) < 2 or len(durs[(k, g)]) < 2 * len(lv):
                 continue
             ds = sorted(durs.pop((k, g)), reverse=True)
