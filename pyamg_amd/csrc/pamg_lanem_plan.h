@@ -215,11 +215,10 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
                         spa.finish();
                         RowRef me;
                         me.arena = tid; me.off = (int64_t)ac.size(); me.len = (int)spa.touched.size();
-                        // operands by (kind, column): the lanes of a gather instruction that read neighbouring columns of one array share a
-                        // request -- the merged sweep is bound by the L1 -> L2 REQUEST rate of its scattered 8-byte operands (first-touch
-                        // order, measured: level 1 of the 256^3 hierarchy 1.80 ms at s = 2 whatever the number of waves)
-                        // (kinds in the order old, b, early.  Early operands FIRST -- so that the sequential tail of a row of many units is static --
-                        // was measured too: level 1 of the 256^3 hierarchy 1.74 -> 1.92 ms, not kept; the small levels hold every unit in registers)
+                        // operands by (kind, column) -- kinds in the order old, b, early: lanes that read neighbouring columns of one array share a
+                        // request, and the layout is reproducible.  (Neither the order nor the locality of the gathers moves the sweep much: first-touch
+                        // order and this one measured the same on level 1 of the 256^3 hierarchy, early operands FIRST 1.74 -> 1.92 ms, perfectly local
+                        // static gathers - 3 %: DESIGN 3, round 6.)
                         std::sort(spa.touched.begin(), spa.touched.end(), [](int x, int y) { return (unsigned)x < (unsigned)y; });
                         for (int c : spa.touched) {
                             const int kind = Spa::kind_of(c);
