@@ -1070,7 +1070,8 @@ def main():
             "event_ms_per_step": round(ev_ms / args.steps, 4),
             "spmv_GBps": roofline["achieved"], "spmv_pct_of_hbm_peak": round(100 * roofline["frac"], 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
-            "host": {"setup_s": round(t_setup, 1), "upload_s": round(t_upload, 1), "cores": os.cpu_count(),
+            "host": {"setup_s": round(t_setup, 1), "upload_s": round(t_upload, 1), "renumber_s": round(getattr(dml, "renumber_seconds", 0.0), 2),
+                     "renumbered_levels": list(getattr(dml, "renumbered", [])), "cores": os.cpu_count(),
                      "setup": SETUP_NOTE, **(setup_cmp or {})},
             "residuals_gpu": [float(v) for v in res_gpu],
             "time_to_tol_1e-8": ttt,

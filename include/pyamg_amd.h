@@ -512,6 +512,19 @@ int pamg_vec_mul(int dtype, int64_t n, const void *a, const void *b, void *y, pa
 int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, void *dst,
                     pamg_stream_t s);
 
+/* Renumbering of an INTERIOR level (host utilities, no device work).  The unknowns of a level l >= 1 are the solver's own -- the reference
+ * hands level-l vectors to nobody (multilevel.py:566-662 keeps them inside __solve) -- so the device hierarchy may number them as its
+ * gathers like: A_l' = Pi A_l Pi^T, P_{l-1}' = P_{l-1} Pi^T, R_{l-1}' = Pi R_{l-1}, P_l' = Pi P_l, R_l' = R_l Pi^T.  Rows are moved and
+ * columns renamed, the entries of a row keep their stored order: every row sum is the reference's, bit for bit.
+ * pamg_csr_renumber: row i of B = row row_old_of_new[i] of A (NULL = unchanged), column c becomes col_new_of_old[c] (NULL = unchanged);
+ * Bp [nrows + 1], Bj, Bx [nnz] are the caller's HOST arrays.  PAMG_E_ARG when row_old_of_new is not a permutation or a column is out
+ * of range.  pamg_csr_row_argmax_abs: out[i] = column of the entry of largest magnitude of row i (first on ties, -1 for an empty row) --
+ * the aggregate an unknown falls into on the next level, which is what the blob-by-blob order is built from
+ * (pyamg_amd/hierarchy.py renumber_levels). */
+int pamg_csr_renumber(int dtype, int64_t nrows, int64_t ncols, const int32_t *Ap, const int32_t *Aj, const void *Ax,
+                      const int32_t *row_old_of_new, const int32_t *col_new_of_old, int32_t *Bp, int32_t *Bj, void *Bx);
+int pamg_csr_row_argmax_abs(int dtype, int64_t nrows, const int32_t *Ap, const int32_t *Aj, const void *Ax, int32_t *out);
+
 /* Hierarchy / cycle / outer iteration (MultilevelSolver, multilevel.py:17-662).         */
 #define PAMG_SMOOTH_NONE        0
 #define PAMG_SMOOTH_JACOBI      1

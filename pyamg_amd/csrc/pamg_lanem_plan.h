@@ -162,24 +162,24 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
     std::vector<unsigned char> starts((size_t)nl, 0);          // level l opens a super-level
     std::vector<int> cl_len((size_t)nt, 0), cl_gr((size_t)nt, 0);
     std::vector<double> mg((size_t)nt, 0.0);
-    std::atomic<int> unfit(0);
+    std::atomic<int> unfit(0), next_blk(0);
+    int64_t total_direct = 0;
+    for (int t = 0; t < m; ++t) { const int i = row_start + t * row_step; total_direct += Ap[i + 1] - Ap[i]; }
     auto work = [&](int tid) {
         Spa spa;
         spa.init(n);
         std::vector<int> &ac = acode[(size_t)tid];
         std::vector<double> &av = aval[(size_t)tid];
         std::vector<std::pair<int, double>> sub;
-        const int b0 = (int)((int64_t)nblocks * tid / nt), b1 = (int)((int64_t)nblocks * (tid + 1) / nt);
         {
-            // room for this thread's share of the merged rows up front (a growing vector copies and re-faults what it holds at every doubling)
-            const int lfirst = std::min(nl, b0 * wlev), llast = std::min(nl, b1 * wlev);
-            int64_t direct = 0;
-            for (int64_t q = lptr[lfirst]; q < lptr[llast]; ++q) direct += Ap[order[(size_t)q] + 1] - Ap[order[(size_t)q]];
-            const size_t want = (size_t)((double)direct * (s_max >= 4 ? 3.2 : s_max == 3 ? 2.3 : s_max == 2 ? 1.7 : 1.05)) + 4096;
+            // room for this thread's share of the merged rows up front (a growing vector copies and re-faults what it holds at every doubling);
+            // the windows are handed out one by one (below), so the share is an estimate: a thread that outgrows it pays the doubling
+            const size_t want = (size_t)((double)total_direct / nt * 1.25 * (s_max >= 4 ? 3.2 : s_max == 3 ? 2.3 : s_max == 2 ? 1.7 : 1.05)) + 4096;
             ac.reserve(want);
             av.reserve(want);
         }
-        for (int blk = b0; blk < b1 && !unfit.load(); ++blk) {
+        // windows differ by an order of magnitude (the sweep's wavefront grows and shrinks): first come, first served
+        for (int blk = next_blk.fetch_add(1); blk < nblocks && !unfit.load(); blk = next_blk.fetch_add(1)) {
             const int lb0 = blk * wlev, lb1 = std::min(nl, lb0 + wlev);
             int l0 = lb0;                                     // first level of the open super-level
             starts[(size_t)lb0] = 1;

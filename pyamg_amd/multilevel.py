@@ -336,10 +336,15 @@ class DeviceMultilevelSolver:
         a wave share a row (parallel partial sums, multiplication by 1/a_ii): the same iterates up to rounding -- residual
         norms agree with the reference to ~1e-15 relative per cycle (BASELINE's bar is 1e-10) -- at about half the
         latency per dependency level.  Every other kernel is bit-identical to the reference in both modes.
+    renumber : bool, number the unknowns of the large interior levels blob by blob on the DEVICE copy of the hierarchy (renumber.py;
+        default OFF, PAMG_RENUMBER=1 enables -- it costs about as much host time as the upload of the level and pays back only over
+        hundreds of cycles: DESIGN 3, round 6).  Speed only: rows are moved and columns renamed, row sums keep their stored order, the
+        caller never sees a level >= 1 vector -- results are bit-identical.  Levels with order-dependent smoothers (Gauss-Seidel,
+        Kaczmarz, Schwarz, block sweeps, Krylov) keep the reference's numbering; ``renumbered`` lists the levels that were changed.
     """
 
     def __init__(self, ml, device: Optional[int] = None, graph: bool = True, autotune: Optional[bool] = None,
-                 level_tune=None, order: Optional[str] = None, strict: bool = True):
+                 level_tune=None, order: Optional[str] = None, strict: bool = True, renumber: Optional[bool] = None):
         import os
         self.fallback = None
         if not strict:
@@ -347,7 +352,7 @@ class DeviceMultilevelSolver:
             # NotImplementedError if strict=True)".  The fallback is the CALLER's own solver object -- never the oracle, never a
             # CPU restatement of ours -- and it is announced once.
             try:
-                self.__init__(ml, device=device, graph=graph, autotune=autotune, level_tune=level_tune, order=order, strict=True)
+                self.__init__(ml, device=device, graph=graph, autotune=autotune, level_tune=level_tune, order=order, strict=True, renumber=renumber)
                 return
             except NotImplementedError as e:
                 if isinstance(ml, HierarchySpec) or not hasattr(ml, "solve"):
@@ -357,6 +362,7 @@ class DeviceMultilevelSolver:
                               "solver on the host", RuntimeWarning, stacklevel=2)
                 self.free()
                 self.fallback, self.ml, self.spec, self.handle = ml, ml, None, None
+                self.renumbered, self.renumber_seconds = [], 0.0
                 self.order = order or "fast"
                 A0 = ml.levels[0].A
                 self.dtype, self.shape = np.dtype(A0.dtype), tuple(A0.shape)
@@ -375,6 +381,16 @@ class DeviceMultilevelSolver:
         self.ml = None if isinstance(ml, HierarchySpec) else ml
         self.spec = ml if isinstance(ml, HierarchySpec) else extract(ml)
         lib = capi.lib()
+        if renumber is None:
+            renumber = os.environ.get("PAMG_RENUMBER", "0") != "0"
+        # the DEVICE copy of the hierarchy: self.spec (what `levels` shows) keeps the reference's numbering
+        dev_spec, self.renumbered, self.renumber_seconds = self.spec, [], 0.0
+        if renumber:
+            import time
+            from .renumber import renumber_levels
+            t0 = time.perf_counter()
+            dev_spec, orders = renumber_levels(self.spec)
+            self.renumbered, self.renumber_seconds = sorted(orders), time.perf_counter() - t0
         if device is not None:
             capi.check(lib.pamg_set_device(int(device)), "pamg_set_device")
         self.dtype = np.dtype(self.spec.dtype)
@@ -389,7 +405,7 @@ class DeviceMultilevelSolver:
         # every operator of the hierarchy is shipped by its own host thread: structure checks, the diagonal scan, the
         # row-range and 16-bit column plans and the (pageable) copies of different operators overlap
         ops = []
-        for i, L in enumerate(self.spec.levels):
+        for i, L in enumerate(dev_spec.levels):
             ops += [L.A] + ([L.P, L.R] if i < nlev - 1 else [])
 
         # HIP's current device is per host thread and a new thread starts on device 0: the workers take over the device
@@ -411,7 +427,7 @@ class DeviceMultilevelSolver:
             shipped = [ship(op) for op in ops]
         self._mats = list(shipped)
         shipped = iter(shipped)
-        for i, L in enumerate(self.spec.levels):
+        for i, L in enumerate(dev_spec.levels):
             A = next(shipped)
             P = next(shipped) if i < nlev - 1 else None
             R = next(shipped) if i < nlev - 1 else None

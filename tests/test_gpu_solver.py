@@ -40,6 +40,38 @@ def test_solve_matches_reference(load_hier, name, graph):
     assert np.linalg.norm(xz - ex["xz"]) <= (2e-4 if f32 else 1e-12) * max(np.linalg.norm(ex["xz"]), 1e-300) + 1e-300
 
 
+@pytest.mark.parametrize("name", ["sa2d_cheby", "sa2d_jacobi", "rs2d_jacobi", "rs3d_jacobi_f32", "sa2d_richardson_W", "sa2d_coarse_jacobi", "sa2d_jacobi_AMLI"])
+def test_renumbered_interior_levels_give_the_same_iterates(load_hier, name, monkeypatch):
+    """renumber=True moves the unknowns of the interior levels (pyamg_amd/renumber.py): rows moved, columns renamed, row sums in stored
+    order -- the level-0 iterates are the SAME BITS as with the reference's numbering (AMLI adds inner products over level vectors, whose
+    order of summation moves: 1e-12 there), and both match the reference's recorded run."""
+    spec, ex = load_hier(name)
+    k, cycle = int(ex["k"]), str(ex["cycle"])
+    f32 = spec.dtype == np.float32
+    monkeypatch.setenv("PAMG_RENUMBER_MIN_ROWS", "8")
+    on = DeviceMultilevelSolver(spec, renumber=True)
+    off = DeviceMultilevelSolver(spec, renumber=False)
+    assert on.renumbered and off.renumbered == []
+    assert on.levels[1].A is spec.levels[1].A                     # what the caller sees keeps the reference's numbering
+    for cyc in ([cycle] if cycle == "AMLI" else [cycle, "W", "F"]):
+        r1, r2 = [], []
+        x1 = on.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=k, cycle=cyc, residuals=r1)
+        x2 = off.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=k, cycle=cyc, residuals=r2)
+        if cyc == "AMLI":
+            assert np.linalg.norm(x1 - x2) <= 1e-12 * np.linalg.norm(x2)
+        else:
+            assert np.array_equal(x1, x2) and np.array_equal(r1, r2), cyc
+    res = []
+    x = on.solve(ex["b"], x0=ex["x0"], tol=1e-30, maxiter=k, cycle=cycle, residuals=res)
+    assert np.max(np.abs(np.array(res) - ex["res"])) <= (2e-4 if f32 else 1e-10) * ex["res"][0]
+    assert np.linalg.norm(x - ex["x"]) <= (2e-4 if f32 else 1e-12) * np.linalg.norm(ex["x"])
+    # Krylov acceleration around the renumbered hierarchy
+    if cycle != "AMLI":
+        xa = on.solve(ex["b"], tol=1e-10, accel="cg" if name.startswith("sa2d") else "gmres")
+        xb = off.solve(ex["b"], tol=1e-10, accel="cg" if name.startswith("sa2d") else "gmres")
+        assert np.array_equal(xa, xb)
+
+
 def test_solve_api_conventions(load_hier):
     """Return/shape/info/callback conventions of multilevel.py:398-582."""
     spec, ex = load_hier("sa2d_gs")
