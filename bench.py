@@ -37,6 +37,10 @@ import json
 import os
 import sys
 import time
+
+# the host-side sweep planners first-touch gigabytes from a hundred threads: 2 MB pages where the kernel grants them (csrc/pamg_plan_vec.h; -0.3 s of the
+# 256^3 upload on the GPU box, slower inside a small container -- hence an application's choice, not the library's default)
+os.environ.setdefault("PAMG_PLAN_HUGEPAGES", "1")
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
@@ -71,6 +75,9 @@ WORKLOADS = {
     # SA with Jacobi prolongation smoothing and 6 rigid-body modes, block Jacobi / the default block GS
     "c5": dict(grid=(64,), elasticity=True, smoother="block_gauss_seidel",
                label="3D linear elasticity 64^3 vertices (BSR 3x3, 774K dof, 6 rigid-body modes) SA with Jacobi prolongation smoothing, V-cycle, block Gauss-Seidel (SA default), fp64"),
+    # ... and with the POINT sweep on the block operators (relaxation.gauss_seidel on BSR -> amg_core::bsr_gauss_seidel): fast order through the scalar twin (round 6)
+    "c5p": dict(grid=(64,), elasticity=True, smoother=("gauss_seidel", {"sweep": "symmetric"}),
+                label="3D linear elasticity 64^3 vertices (BSR 3x3, 774K dof) SA V-cycle, point Gauss-Seidel on the block operators (symmetric), fp64"),
     "c5s": dict(grid=(40,), elasticity=True, smoother="block_jacobi",
                 label="3D linear elasticity 40^3 vertices (BSR 3x3, 187K dof) SA V-cycle, block Jacobi, fp64"),
     "c5g": dict(grid=(40,), elasticity=True, smoother="block_gauss_seidel",
@@ -84,6 +91,10 @@ WORKLOADS = {
                  label="3D upwind convection-diffusion 64^3, pyamg.solve() configuration (SA energy-min, gauss_seidel_nr x2 symmetric) V-cycle, fp64"),
     "c7a": dict(grid=(512, 512), convdiff=3.0, kind="air", smoother="fc_jacobi",
                 label="2D upwind convection-diffusion 512^2, AIR V-cycle (FC Jacobi: 2 F-sweeps + 1 C-sweep), fp64"),
+    # the "next" row f2's last smoother: multiplicative overlapping Schwarz (relaxation.py:157-262), one subdomain per row (its pattern) -- 4 n dependency
+    # levels on an n x n grid; since round 6 one persistent launch per sweep (csrc/pamg_schwarz.hip)
+    "c8s": dict(grid=(384, 384), smoother=("schwarz", {"sweep": "symmetric"}),
+                label="2D 5-pt Poisson 384^2 SA V-cycle, overlapping Schwarz (symmetric sweeps, one subdomain per row), fp64"),
     "small": dict(grid=(64, 64, 64), smoother=GS,
                   label="3D 7-pt Poisson 64^3 SA V-cycle, symmetric Gauss-Seidel, fp64 (smoke)"),
 }
@@ -1281,6 +1292,26 @@ def main():
       except Exception as e:                                    # noqa: BLE001
         log(f"gauss_seidel_nr leg failed: {e!r}")
         out.setdefault("extra", {})["c6n3"] = {"error": repr(e)[:300]}
+      # f2's last smoother: overlapping Schwarz, 4 n dependency levels per sweep of an n x n grid -- one persistent launch per sweep since round 6
+      try:
+        wl8 = WORKLOADS["c8s"]
+        A8, ml8, ts8 = build(wl8, device=False)          # the subdomains and inverted blocks are the reference's own (schwarz_parameters)
+        b8, x08 = rhs(A8.shape[0])
+        d8 = DeviceMultilevelSolver(ml8, device=local_rank, graph=not args.no_graph)
+        w8, _, res8, _, _ = time_resident(d8, b8, x08, 20, 3)
+        ex8 = {"workload": wl8["label"], "value": round(20 / w8, 3), "unit": "cycles/s", "ms_per_step": round(w8 * 1e3 / 20, 4), "steps": 20,
+               "host_setup_s": round(ts8, 1), "levels": len(ml8.levels), "round5_ms_per_step_one_launch_per_level": 78.4}
+        if args.cpu_cycles != 0:
+            c8cpu, r8cpu = cpu_reference(ml8, A8, b8, x08, 6)
+            ex8["cpu_baseline"] = c8cpu
+            ex8["speedup_vs_cpu_reference"] = round(ex8["value"] / c8cpu["value"], 1)
+            ex8["parity"] = parity_of(res8, r8cpu)
+            ex8["parity"]["reference_protocol"] = protocol_parity(d8, ml8, A8.shape[0])
+        out.setdefault("extra", {})["c8s"] = ex8
+        d8.free()
+      except Exception as e:                                    # noqa: BLE001
+        log(f"Schwarz leg failed: {e!r}")
+        out.setdefault("extra", {})["c8s"] = {"error": repr(e)[:300]}
       # configs[0]: the README's Ruge-Stuben example -- an irregular classical hierarchy at size, with the published
       # level sizes as the anchor (README.md:143-151)
       try:

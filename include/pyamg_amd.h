@@ -410,6 +410,12 @@ int pamg_matrix_lane_info(pamg_matrix_t A, int which, int64_t info[8]);
  * runs unmerged.  The merged sweep computes the reference's Gauss-Seidel iterates (amg_core::gauss_seidel, relaxation.h:48-76) in another
  * association: equal in exact arithmetic, to rounding in floating point. */
 int pamg_matrix_lanem_info(pamg_matrix_t A, int which, int64_t info[12], double *growth);
+/* Fast order (tune key 24 = 1) of the BSR POINT sweep (amg_core::bsr_gauss_seidel, relaxation.h:185-266: what relaxation.gauss_seidel runs on a
+ * block operator): the same rows in the same order are the scalar Gauss-Seidel sweep of the flattened operator, so the block operator builds a
+ * scalar CSR twin of itself with its schedules and sweeps it in the lane-parallel / merged / line-scan form (same iterates to rounding, like every
+ * fast-order sweep; order 'exact' keeps the block kernels and the reference's bits).  state: 0 = no twin (exact order, or not swept yet),
+ * 1 = the twin carries the point sweeps, 2 = no fast-order form fits the flattened rows: the exact block kernels sweep. */
+int pamg_matrix_point_twin(pamg_matrix_t A, int *state);
 /* First row (in the merged plan's order) of every super-level, nsuper + 1 values; out == NULL: only *count.  With tune key 11 the merged sweep records per row
  * {arrival | polling rounds << 52, operand slots arrived, all operands present, published} (pamg_matrix_lane_profile, 10 ns ticks). */
 int pamg_matrix_lanem_levels(pamg_matrix_t A, int which, int64_t *out, int64_t capacity, int64_t *count);
@@ -524,6 +530,10 @@ int pamg_vec_gather(int dtype, int64_t n, const int32_t *idx, const void *src, v
 int pamg_csr_renumber(int dtype, int64_t nrows, int64_t ncols, const int32_t *Ap, const int32_t *Aj, const void *Ax,
                       const int32_t *row_old_of_new, const int32_t *col_new_of_old, int32_t *Bp, int32_t *Bj, void *Bx);
 int pamg_csr_row_argmax_abs(int dtype, int64_t nrows, const int32_t *Ap, const int32_t *Aj, const void *Ax, int32_t *out);
+/* Rows of a CSR / BSR operator (HOST arrays) sorted by column in place, on the host threads: scipy's sort_indices(), which the reference
+ * runs on every Galerkin product before reading its diagonal (util/utils.py:583).  block = values per stored entry (R * C; 1 for CSR).
+ * Stable, so equal columns keep their stored order like SciPy's. */
+int pamg_csr_sort_rows(int dtype, int64_t nrows, const int32_t *Ap, int32_t *Aj, void *Ax, int block);
 
 /* Hierarchy / cycle / outer iteration (MultilevelSolver, multilevel.py:17-662).         */
 #define PAMG_SMOOTH_NONE        0
@@ -585,6 +595,14 @@ int pamg_schwarz_destroy(pamg_schwarz_t h);
 int pamg_schwarz_sweep(pamg_schwarz_t h, void *x, const void *b, int row_start, int row_stop, int row_step,
                        pamg_stream_t s);
 int pamg_schwarz_info(pamg_schwarz_t h, int64_t info[4]);   /* subdomains, largest, dependency levels fwd / bwd */
+/* Scheduler of the sweep: 0 (default) = ONE persistent launch per sweep -- every update of a row gets its own slot of a hand-off buffer
+ * (version v of row i), every read is told which version the reference's sequential sweep would find, co-resident waves walk the
+ * subdomains in level order and poll the slots they read (csrc/pamg_schwarz.hip); 1 = one launch per dependency level (always live;
+ * what pamg_solver_solve switches to after a PAMG_E_TIMEOUT, and what a schedule runs as when a row is updated more than 255 times, a
+ * subdomain lists a row twice or the version table would exceed a gigabyte).  Same arithmetic, same bits.  PAMG_SCHWARZ_LEVELS=1 forces 1.
+ * pamg_schwarz_error: after a synchronising call -- did a wave of a persistent sweep give up waiting (1) since the last query? */
+int pamg_schwarz_set_mode(pamg_schwarz_t h, int mode);
+int pamg_schwarz_error(pamg_schwarz_t h, int *error);
 /* Schwarz as a level's smoother: `iterations` x (forward | backward | forward then backward) sweeps.  Ar: the level's
  * operator as the reference's smoother sees it (lvl.Acsr; NULL = the level operator itself); the solver borrows it. */
 int pamg_solver_set_schwarz_smoother(pamg_solver_t S, int level, int which, int iterations, int sweep, pamg_matrix_t Ar,

@@ -128,6 +128,7 @@ def _declare(lib):
     f("pamg_matrix_tile_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_lane_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_lanem_info", _vp, _i, P(C.c_int64), P(C.c_double))
+    f("pamg_matrix_point_twin", _vp, P(_i))
     f("pamg_matrix_lanem_levels", _vp, _i, _vp, C.c_int64, P(C.c_int64))
     f("pamg_matrix_kz_info", _vp, _i, P(C.c_int64))
     f("pamg_matrix_line_info", _vp, _i, P(C.c_int64))
@@ -147,6 +148,8 @@ def _declare(lib):
     f("pamg_schwarz_destroy", _vp)
     f("pamg_schwarz_sweep", _vp, _vp, _vp, _i, _i, _i, _vp)
     f("pamg_schwarz_info", _vp, P(C.c_int64))
+    f("pamg_schwarz_set_mode", _vp, _i)
+    f("pamg_schwarz_error", _vp, P(_i))
     f("pamg_solver_set_schwarz_smoother", _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp)
     f("pamg_solver_set_cf_block_smoother", _vp, _i, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _vp, _i)
     f("pamg_matrix_gauss_seidel", _vp, _vp, _vp, _i, _d, _i, _vp)
@@ -159,6 +162,7 @@ def _declare(lib):
     f("pamg_vec_gather", _i, C.c_int64, _vp, _vp, _vp, _vp)
     f("pamg_csr_renumber", _i, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
     f("pamg_csr_row_argmax_abs", _i, C.c_int64, _vp, _vp, _vp, _vp)
+    f("pamg_csr_sort_rows", _i, C.c_int64, _vp, _vp, _vp, _i)
     f("pamg_solver_create", P(_vp), _i)
     f("pamg_solver_destroy", _vp)
     f("pamg_solver_add_level", _vp, _vp, _vp, _vp)

@@ -228,6 +228,10 @@ struct pamg_matrix_s {
     int4 *d_blkmeta = nullptr;
     double *d_partial = nullptr;     // nblk doubles (sum-of-squares partials)
     pamg::GsSchedule *gs[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd, bwd, 2 custom
+    // fast order of the BSR POINT sweep (amg_core::bsr_gauss_seidel): the same rows in the same order are the scalar Gauss-Seidel sweep of the
+    // flattened view, so a block operator swept in fast order owns a scalar CSR twin of itself that carries the lane / merged / line schedules
+    pamg_matrix_s *point_twin = nullptr;
+    bool point_twin_unfit = false;   // no fast-order form fits the flattened rows (or the twin could not be built): the exact block kernels sweep
     pamg::LineSchedule *ls[4] = {nullptr, nullptr, nullptr, nullptr};  // Kaczmarz sweeps over this operator's rows
     size_t bytes = 0;
 };
@@ -240,6 +244,8 @@ namespace pamg {
 // pamg_schwarz.hip
 int schwarz_sweep(pamg_schwarz_s *h, void *x, const void *b, int start, int stop, int step, hipStream_t s);
 int schwarz_prepare(pamg_schwarz_s *h, int sweep);
+int schwarz_error(pamg_schwarz_s *h, bool *error);
+void schwarz_level_launches(pamg_schwarz_s *h);
 // launch wrappers implemented in pamg_matrix.hip
 int stream_launch(pamg_matrix_s *A, int epi, const void *x, const void *b, void *y, double c,
                   double omega, double *partial, hipStream_t s);

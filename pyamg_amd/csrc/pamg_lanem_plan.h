@@ -156,8 +156,8 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
     const int nblocks = (nl + wlev - 1) / wlev;
     const unsigned hw = std::max(1u, std::min(96u, std::thread::hardware_concurrency() / 2u + 1u));      // (two sweep directions are planned at once)
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw, (int64_t)nblocks, std::max<int64_t>(1, (int64_t)m / 4096)}));
-    std::vector<std::vector<int>> acode((size_t)nt);
-    std::vector<std::vector<double>> aval((size_t)nt);
+    std::vector<PlanVec<int>> acode((size_t)nt);
+    std::vector<PlanVec<double>> aval((size_t)nt);
     std::vector<RowRef> ref((size_t)n);
     std::vector<unsigned char> starts((size_t)nl, 0);          // level l opens a super-level
     std::vector<int> cl_len((size_t)nt, 0), cl_gr((size_t)nt, 0);
@@ -168,8 +168,8 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
     auto work = [&](int tid) {
         Spa spa;
         spa.init(n);
-        std::vector<int> &ac = acode[(size_t)tid];
-        std::vector<double> &av = aval[(size_t)tid];
+        PlanVec<int> &ac = acode[(size_t)tid];
+        PlanVec<double> &av = aval[(size_t)tid];
         std::vector<std::pair<int, double>> sub;
         {
             // room for this thread's share of the merged rows up front (a growing vector copies and re-faults what it holds at every doubling);

@@ -1141,6 +1141,53 @@ static bool want_lines(const pamg_matrix_s *A, const GsSchedule *g)
     return A->gs_order == 1 && A->gs_mode == 0 && A->line_scan && line_eligible(A, g);
 }
 
+int ensure_parts(pamg_matrix_s *A, GsSchedule *g, bool block_gs);
+// Fast order of the BSR point sweep (amg_core::bsr_gauss_seidel, relaxation.h:185-266): block rows in sweep order, the points of a block row
+// one after another (backwards in a backward sweep), every point with the newest values of everything before it -- that IS the scalar
+// Gauss-Seidel sweep over the flattened rows.  The order-exact block kernels reproduce the reference's order of additions (off-diagonal blocks
+// first, the diagonal block last); in fast order the sums are reordered anyway, so the sweep runs on a scalar CSR twin of the operator through
+// the lane-parallel / merged / line-scan forms.  Built with the schedules (never inside a capture), once per operator.
+static bool point_twin_bounds(const pamg_matrix_s *A, const GsSchedule *g, int &r0, int &r1, int &rs)
+{
+    const int R = A->R;
+    if (g->row_step == 1 && g->row_start == 0 && g->row_stop == A->n_brow) { r0 = 0; r1 = A->n_brow * R; rs = 1; return true; }
+    if (g->row_step == -1 && g->row_start == A->n_brow - 1 && g->row_stop == -1) { r0 = A->n_brow * R - 1; r1 = -1; rs = -1; return true; }
+    return false;
+}
+
+int ensure_point_twin(pamg_matrix_s *A, GsSchedule *g)
+{
+    int r0, r1, rs;
+    if (A->gs_order != 1 || A->gs_mode != 0 || A->R != A->C || A->point_twin_unfit || !point_twin_bounds(A, g, r0, r1, rs)) return PAMG_OK;
+    static std::mutex twin_mu;                                 // both sweep directions arrive here at once (run_sched_jobs)
+    {
+        std::lock_guard<std::mutex> lk(twin_mu);
+        if (A->point_twin_unfit) return PAMG_OK;
+        if (!A->point_twin) {
+            PhaseTimer pt_("point twin of a block operator", A->nnz);
+            std::vector<unsigned char> hAx((size_t)A->nnz * tsize(A->dtype));
+            if (A->nnz) PAMG_HIP(hipMemcpy(hAx.data(), A->d_Ax, hAx.size(), hipMemcpyDeviceToHost));
+            pamg_matrix_s *T = nullptr;
+            const int st = pamg_matrix_create(&T, A->dtype, PAMG_CSR, (int)A->nrows, (int)A->ncols, 1, 1, A->h_Ap.data(), A->h_Aj.data(), hAx.data());
+            if (st != PAMG_OK) { A->point_twin_unfit = true; return st == PAMG_E_UNSUPPORTED || st == PAMG_E_ARG ? PAMG_OK : st; }
+            T->gs_order = 1;
+            T->lane_L = A->lane_L; T->lane_G = A->lane_G; T->lane_flags = A->lane_flags; T->lane_merge = A->lane_merge; T->line_scan = A->line_scan;
+            T->lane_wide = A->lane_wide;
+            A->point_twin = T;
+            A->bytes += T->bytes;
+        }
+    }
+    GsSchedule *tg = nullptr;
+    PAMG_TRY(get_schedule(A->point_twin, r0, r1, rs, &tg));
+    PAMG_TRY(ensure_parts(A->point_twin, tg, false));
+    if (!tg->lane && !tg->lanem && !tg->line) {
+        // the flattened rows fit none of the fast-order forms: the exact block kernels keep the sweep (the twin stays unused until the operator goes)
+        std::lock_guard<std::mutex> lk(twin_mu);
+        A->point_twin_unfit = true;
+    }
+    return PAMG_OK;
+}
+
 // device copies the scheduler of choice needs (called before any graph capture through ensure_schedule)
 int ensure_parts(pamg_matrix_s *A, GsSchedule *g, bool block_gs)
 {
@@ -1153,6 +1200,7 @@ int ensure_parts(pamg_matrix_s *A, GsSchedule *g, bool block_gs)
             if (st != PAMG_E_ARG) return st;
             g->blane_unfit = true;                             // block rows too long / padding too wasteful
         }
+        if (!block_gs) PAMG_TRY(ensure_point_twin(A, g));
         return PAMG_OK;
     }
     if (want_lines(A, g)) {
@@ -1277,6 +1325,11 @@ int gs_sweep(pamg_matrix_s *A, int epi, void *x, const void *b, double omega, in
     if (A->R == 1) {
         return A->dtype == PAMG_F64 ? gs_sweep_scalar_t<double>(A, g, epi, x, b, omega, s)
                                     : gs_sweep_scalar_t<float>(A, g, epi, x, b, omega, s);
+    }
+    if (A->gs_order == 1 && A->gs_mode == 0 && !A->point_twin && !A->point_twin_unfit) PAMG_TRY(ensure_point_twin(A, g));   // (a solver built it with its schedules)
+    if (A->point_twin && !A->point_twin_unfit && A->gs_order == 1 && A->gs_mode == 0) {
+        int r0, r1, rs;
+        if (point_twin_bounds(A, g, r0, r1, rs)) return gs_sweep(A->point_twin, EPI_GS, x, b, 1.0, r0, r1, rs, s);      // fast order (the BSR flavour ignores omega, relaxation.py:343-346)
     }
     return block_point_sweep(A, g, x, b, row_step < 0 ? -1 : 1, s);      // pamg_block.hip
 }
@@ -1638,6 +1691,11 @@ int sweep_error(pamg_matrix_s *A, bool *error)
         }
     }
     for (int k = 0; k < 4; ++k) if (A->ls[k] && kz_lane_error(A->ls[k])) *error = true;
+    if (A->point_twin) {
+        bool e2 = false;
+        PAMG_TRY(sweep_error(A->point_twin, &e2));
+        if (e2) *error = true;
+    }
     return PAMG_OK;
 }
 }  // namespace pamg
@@ -1783,7 +1841,15 @@ int pamg_matrix_destroy(pamg_matrix_t A)
     hipFree(A->d_part[0]); hipFree(A->d_part[1]);
     for (int k = 0; k < 4; ++k) free_schedule(A->gs[k]);
     for (int k = 0; k < 4; ++k) pamg::free_line_schedule(A->ls[k]);
+    if (A->point_twin) pamg_matrix_destroy(A->point_twin);
     delete A;
+    return PAMG_OK;
+}
+
+int pamg_matrix_point_twin(pamg_matrix_t A, int *state)
+{
+    if (!A || !state) return PAMG_E_ARG;
+    *state = A->point_twin_unfit ? 2 : A->point_twin ? 1 : 0;
     return PAMG_OK;
 }
 

@@ -75,3 +75,39 @@ int pamg_csr_row_argmax_abs(int dtype, int64_t nrows, const int32_t *Ap, const i
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Rows of a CSR / BSR operator sorted by column, in place, on the host threads: what scipy's sort_indices() does (the reference calls
+// it on every Galerkin product before it reads the diagonal, util/utils.py:583 -- SciPy's SpGEMM leaves the rows in first-touch
+// order), 63 M entries in 0.13 s on one core there.  Columns inside a row are distinct after a product, so the result is unique.
+// block = R * C values per stored entry (1 for CSR).
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+extern "C" int pamg_csr_sort_rows(int dtype, int64_t nrows, const int32_t *Ap, int32_t *Aj, void *Ax, int block)
+{
+    if (nrows < 0 || !Ap || block < 1 || (dtype != PAMG_F64 && dtype != PAMG_F32)) return PAMG_E_ARG;
+    if (Ap[nrows] > 0 && (!Aj || !Ax)) return PAMG_E_ARG;
+    const size_t eb = tsize(dtype) * (size_t)block;
+    host_parallel(nrows, [&](int64_t lo, int64_t hi) {
+        std::vector<int> perm;
+        std::vector<int32_t> cj;
+        std::vector<unsigned char> cx;
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t s = Ap[i];
+            const int len = (int)(Ap[i + 1] - s);
+            if (len < 2 || std::is_sorted(Aj + s, Aj + s + len)) continue;
+            perm.resize((size_t)len);
+            std::iota(perm.begin(), perm.end(), 0);
+            std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return Aj[s + a] < Aj[s + b]; });
+            cj.assign(Aj + s, Aj + s + len);
+            cx.assign((const unsigned char *)Ax + (size_t)s * eb, (const unsigned char *)Ax + (size_t)(s + len) * eb);
+            for (int k = 0; k < len; ++k) {
+                Aj[s + k] = cj[(size_t)perm[(size_t)k]];
+                memcpy((unsigned char *)Ax + (size_t)(s + k) * eb, cx.data() + (size_t)perm[(size_t)k] * eb, eb);
+            }
+        }
+    }, 1 << 14);
+    return PAMG_OK;
+}

@@ -303,13 +303,19 @@ int check_sweeps(pamg_solver_s *S)
         any = any || e;
         // the Kaczmarz lane sweeps (pamg_kz.hip) run on the smoothers' own operators: A^T for gauss_seidel_nr, the row-sorted twin for
         // gauss_seidel_ne -- their spin time-outs are reported on THOSE operators' line schedules
-        for (Smoother *sm : {&L.pre, &L.post})
+        for (Smoother *sm : {&L.pre, &L.post}) {
             for (pamg_matrix_s *M : {sm->At, sm->Ar})
                 if (M && M != L.A) {
                     bool e2 = false;
                     PAMG_TRY(sweep_error(M, &e2));
                     any = any || e2;
                 }
+            if (sm->sw) {                                     // the persistent Schwarz sweep (pamg_schwarz.hip)
+                bool e3 = false;
+                PAMG_TRY(schwarz_error(sm->sw, &e3));
+                any = any || e3;
+            }
+        }
     }
     static int forced = [] { const char *e = getenv("PAMG_FORCE_TIMEOUT"); return e ? atoi(e) : 0; }();   // test hook: report the first N checks as timed out
     if (forced > 0) { --forced; any = true; }
@@ -332,6 +338,7 @@ int fall_back_to_level_launches(pamg_solver_s *S)
             // kz_lane_launch is gated on gs_mode == 0 of the operator the sweep runs on (pamg_matrix.hip: kaczmarz_sweep)
             if (sm->At) sm->At->gs_mode = 1;
             if (sm->Ar) sm->Ar->gs_mode = 1;
+            if (sm->sw) schwarz_level_launches(sm->sw);
             PAMG_TRY(prebuild_schedules(L, *sm));
         }
     }

@@ -143,6 +143,12 @@ class DeviceMatrix:
         d["max_growth"] = gr.value
         return d
 
+    def point_twin(self) -> int:
+        """fast order of the BSR point sweep: 0 = no scalar twin (exact order / not swept yet), 1 = the twin carries the sweeps, 2 = no fast form fits"""
+        st = C.c_int(0)
+        capi.check(capi.lib().pamg_matrix_point_twin(self.handle, C.byref(st)), "pamg_matrix_point_twin")
+        return int(st.value)
+
     def lanem_levels(self, which=0):
         """first row of every super-level of the merged plan: int64 array [super_levels + 1] (empty if the schedule runs unmerged)"""
         n = C.c_int64(0)

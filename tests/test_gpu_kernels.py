@@ -749,7 +749,7 @@ def test_block_gauss_seidel_fast_order_agrees_to_rounding():
     relaxation.h:1242-1298): 1e-13 per call on 2x2 blocks on a 3-D grid (several block rows per wave, the chip-wide static form), a structurally
     NON-symmetric 3x3 pattern with missing diagonal blocks (old values from a snapshot), 27-point 3x3 and 6x6 blocks (one-XCD ticket form),
     4x4 blocks with block rows of more than 64 blocks (two blocks per lane); forward, backward, symmetric, two iterations; the same bits on a
-    second run; the BSR point sweep stays order-exact; 5x5 blocks (not compiled) stay with the exact kernels."""
+    second run; 5x5 blocks (not compiled) stay with the exact kernels; the BSR point sweep: exact order bit for bit, fast order through the scalar twin."""
     from oracle import oracle as orc
     from tools.problems import poisson_csr
     rng = np.random.RandomState(31)
@@ -804,10 +804,30 @@ def test_block_gauss_seidel_fast_order_agrees_to_rounding():
                 out[order] = got
             err = np.max(np.abs(out[0] - out[1]))
             assert err <= 1e-13 * max(1.0, np.max(np.abs(out[0]))), (name, sweep, err)
-        dM.tune(gs_order=1)
+        # the BSR POINT sweep (amg_core::bsr_gauss_seidel): exact order = the reference's bits; fast order (round 6) = the scalar sweep of the
+        # flattened rows on the operator's CSR twin, lane-parallel: 1e-13, reproducible
+        dM.tune(gs_order=0)
         dx = capi.DeviceArray.from_host(x)
         dM.gauss_seidel(dx, db, sweep="symmetric")
-        assert np.array_equal(dx.download(), ref_pnt), name                                          # the BSR point sweep: exact kernels
+        assert np.array_equal(dx.download(), ref_pnt), name
+        assert dM.point_twin() == 0
+        dM.tune(gs_order=1)
+        got = []
+        for _ in range(2):
+            dx = capi.DeviceArray.from_host(x)
+            dM.gauss_seidel(dx, db, sweep="symmetric")
+            got.append(dx.download())
+            assert not dM.flow_error(), name
+        assert dM.point_twin() in (1, 2), name
+        if name in ("2x2 grid", "3x3 wide"):                                                     # (6x6 wide: 360 entries per flattened row, beyond the lane forms)
+            assert dM.point_twin() == 1, name                                                        # a fast-order form really ran
+        assert np.array_equal(got[0], got[1]), name
+        assert np.max(np.abs(got[0] - ref_pnt)) <= 1e-13 * max(1.0, np.max(np.abs(ref_pnt))), name
+        for sweep in ("forward", "backward"):
+            ref1 = x.copy(); orc.relax_gauss_seidel(op, ref1, b, 2, sweep)
+            dx = capi.DeviceArray.from_host(x)
+            dM.gauss_seidel(dx, db, sweep=sweep, iterations=2)
+            assert np.max(np.abs(dx.download() - ref1)) <= 1e-13 * max(1.0, np.max(np.abs(ref1))), (name, sweep)
         dM.free()
 
 
@@ -867,6 +887,53 @@ def test_schwarz_bit_exact():
         grelax.schwarz(M, x.copy(), b, inv_subblock=inv)
     with pytest.raises(ValueError):
         grelax.schwarz(M, x.copy(), b, sweep="sideways")
+
+
+def test_schwarz_persistent_sweep_is_the_level_launches_and_the_oracle():
+    """the ONE persistent launch per Schwarz sweep (waves walk the subdomains in level order and wait on the counter of the level before)
+    against one launch per dependency level and against the oracle's sequential sweep (relaxation.h:1420-1492): the same bits, on operators with
+    hundreds of dependency levels (2-D Poisson: 4 n levels), in both directions, strided, f64 and f32; the error word stays clear."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from pyamg_amd import _capi as capi
+    from pyamg_amd.hierarchy import sparse_op
+    from pyamg_amd.multilevel import DeviceMatrix
+    from tools.problems import poisson_csr
+    lib = capi.lib()
+    rng = np.random.RandomState(11)
+    for grid, dtype in (((90, 90), np.float64), ((20, 20, 20), np.float64), ((70, 70), np.float32)):
+        A = sp.csr_matrix(poisson_csr(grid)).astype(dtype)
+        A.sort_indices()
+        n = A.shape[0]
+        sub, sptr, inv, iptr = grelax.schwarz_parameters(A)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)       # noqa: E731
+        Sp, Sj, Tp, Tx = i32(sptr), i32(sub), i32(iptr), np.ascontiguousarray(inv, dtype=dtype)
+        dA = DeviceMatrix(sparse_op(A))
+        h = C.c_void_p()
+        capi.check(lib.pamg_schwarz_create(C.byref(h), dA.handle, n, capi.ptr(Sp), capi.ptr(Sj), capi.ptr(Tp), capi.ptr(Tx)), "pamg_schwarz_create")
+        x0, b = rng.rand(n).astype(dtype), rng.rand(n).astype(dtype)
+        bd = capi.DeviceArray.from_host(b)
+        for (r0, r1, rs) in ((0, n, 1), (n - 1, -1, -1), (3, n - 1, 2)):
+            want = x0.copy()
+            orc.overlapping_schwarz_csr(i32(A.indptr), i32(A.indices), A.data, want, b, Tx, Tp, Sj, Sp, r0, r1, rs)
+            got = []
+            for mode in (0, 1):
+                capi.check(lib.pamg_schwarz_set_mode(h, mode), "pamg_schwarz_set_mode")
+                xd = capi.DeviceArray.from_host(x0)
+                for _ in range(2):                                    # a second sweep on the result: counters are reset per sweep
+                    capi.check(lib.pamg_schwarz_sweep(h, xd.ptr, bd.ptr, r0, r1, rs, None), "pamg_schwarz_sweep")
+                err = C.c_int(0)
+                capi.check(lib.pamg_schwarz_error(h, C.byref(err)), "pamg_schwarz_error")
+                assert err.value == 0
+                got.append(xd.download())
+            want2 = want.copy()
+            orc.overlapping_schwarz_csr(i32(A.indptr), i32(A.indices), A.data, want2, b, Tx, Tp, Sj, Sp, r0, r1, rs)
+            assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], want2), (grid, dtype, r0, rs)
+        info = (C.c_int64 * 4)()
+        capi.check(lib.pamg_schwarz_info(h, info), "pamg_schwarz_info")
+        assert info[2] >= 2 * grid[0] and info[3] >= 2 * grid[0]      # long chains: what the persistent form is for
+        capi.check(lib.pamg_schwarz_destroy(h), "pamg_schwarz_destroy")
+        dA.free()
 
 
 def test_indexed_gauss_seidel_bit_exact():

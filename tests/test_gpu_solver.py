@@ -381,13 +381,13 @@ def test_long_dependency_chains_against_the_live_reference(case):
         assert np.array_equal(o, outs[1])                 # exact schedulers differ in speed only
 
 
-@pytest.mark.parametrize("hier", ["sa3d_gs", "rs2d_nonsym_gsnr", "rs2d_nonsym_gsne"])
+@pytest.mark.parametrize("hier", ["sa3d_gs", "rs2d_nonsym_gsnr", "rs2d_nonsym_gsne", "sa2d_schwarz"])
 def test_sweep_timeout_falls_back_to_level_launches(hier):
     """a persistent sweep that reports PAMG_E_TIMEOUT (not all of its workgroups were running -- forced here through the
     PAMG_FORCE_TIMEOUT test hook): solve() switches every order-exact sweep to one launch per dependency level, runs the
     solve again from the initial guess and returns the reference's answer; the switch is reported in stats() and by ONE
     RuntimeWarning.  The normal-equation hierarchies: their Kaczmarz lane sweeps run on the smoother's OWN operators
-    (A^T / the row-sorted twin), which the fallback must switch to per-level launches too"""
+    (A^T / the row-sorted twin), which the fallback must switch to per-level launches too; so must the persistent Schwarz sweep (round 6)"""
     import subprocess
     import sys
     from conftest import ROOT

@@ -119,3 +119,23 @@ def test_nested_order_groups_unknowns_by_their_next_level_aggregate():
     dev, orders = RN.renumber_levels(mixed, min_rows=8)
     assert sorted(orders) == [1]
     assert dev.levels[2].A is mixed.levels[2].A and dev.levels[1].A is not mixed.levels[1].A
+
+
+@pytest.mark.parametrize("fmt,dtype", [("csr", np.float64), ("csr", np.float32), ("bsr", np.float64)])
+def test_sort_rows_is_scipys_sort_indices(fmt, dtype):
+    from pyamg_amd.aggregation import _sort_indices
+    rng = np.random.RandomState(7)
+    op = _random_csr(rng, 300, 200, dtype, density=0.1)
+    if fmt == "csr":
+        a = sp.csr_matrix((op.data.copy(), op.indices.copy(), op.indptr.copy()), shape=op.shape)
+        b = sp.csr_matrix((op.data.copy(), op.indices.copy(), op.indptr.copy()), shape=op.shape)
+    else:
+        blocks = rng.rand(op.indices.size, 2, 3).astype(dtype)
+        a = sp.bsr_matrix((blocks.copy(), op.indices.copy(), op.indptr.copy()), shape=(600, 600))
+        b = sp.bsr_matrix((blocks.copy(), op.indices.copy(), op.indptr.copy()), shape=(600, 600))
+    assert not a.has_sorted_indices
+    _sort_indices(a)
+    b.sort_indices()
+    assert a.has_sorted_indices and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data) and np.array_equal(a.indptr, b.indptr)
+    _sort_indices(a)                                   # sorted already: nothing moves
+    assert np.array_equal(a.indices, b.indices)
