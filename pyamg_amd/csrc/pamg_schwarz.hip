@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "pamg_common.h"
+#include "pamg_schwarz_plan.h"
 
 namespace pamg {
 struct SchwarzSchedule {
@@ -323,10 +324,9 @@ __global__ __launch_bounds__(SW_THREADS) void schwarz_versioned_kernel(const int
     }
 }
 
-// the version table of a sweep (header): which update writes which slot, and which version every read wants.  Leaves g.versioned
-// false (the schedule then runs as one launch per level) when a subdomain lists a row twice, a row is updated more than 255 times or
-// the tables would not fit 31-bit offsets / a gigabyte.
-int build_versions(pamg_schwarz_s *h, SchwarzSchedule &g, const std::vector<int> &order)
+// the version table of a sweep (pamg_schwarz_plan.h) on the device.  Leaves g.versioned false (the schedule then runs as one launch per
+// level) when the planner declines: a subdomain lists a row twice, a row is updated more than 255 times, tables beyond a gigabyte.
+int upload_versions(pamg_schwarz_s *h, SchwarzSchedule &g, const SchwarzLevels &lv)
 {
     const pamg_matrix_s *A = h->A;
     const int n = (int)A->nrows, m = g.m;
@@ -334,71 +334,22 @@ int build_versions(pamg_schwarz_s *h, SchwarzSchedule &g, const std::vector<int>
     for (void *p : {(void *)g.d_ebase, (void *)g.d_wslot, (void *)g.d_prev, (void *)g.d_roff, (void *)g.d_rver, (void *)g.d_vbase, (void *)g.d_last}) hipFree(p);
     g.d_ebase = g.d_wslot = g.d_prev = g.d_roff = g.d_vbase = g.d_last = nullptr;
     g.d_rver = nullptr;
-    // updates per row, entries and reads of the visited subdomains
-    std::vector<int> nupd((size_t)n, 0);
-    int64_t E = 0, R = 0;
-    for (int t = 0; t < m; ++t) {
-        const int d = g.start + t * g.step;
-        for (int q = h->h_Sp[d]; q < h->h_Sp[d + 1]; ++q) {
-            const int row = h->h_Sj[q];
-            if (++nupd[(size_t)row] > 255) return PAMG_OK;
-            R += A->h_Ap[row + 1] - A->h_Ap[row];
-        }
-        E += h->h_Sp[d + 1] - h->h_Sp[d];
-    }
-    if (E >= ((int64_t)1 << 31) - 1 || R >= ((int64_t)1 << 30)) return PAMG_OK;
-    std::vector<int> vbase((size_t)n + 1, 0), last((size_t)n, -1);
-    for (int i = 0; i < n; ++i) vbase[(size_t)i + 1] = vbase[i] + nupd[i];
-    for (int i = 0; i < n; ++i) if (nupd[i]) last[i] = vbase[(size_t)i + 1] - 1;
-    // entries are laid out by POSITION in the level-sorted order (what a wave walks); the versions are counted in SWEEP order
-    std::vector<int> pos_of((size_t)h->nsub, -1);
-    for (int q = 0; q < m; ++q) pos_of[(size_t)order[q]] = q;
-    std::vector<int> ebase((size_t)m + 1, 0);
-    for (int q = 0; q < m; ++q) ebase[(size_t)q + 1] = ebase[q] + (h->h_Sp[order[q] + 1] - h->h_Sp[order[q]]);
-    std::vector<int> wslot((size_t)E), prev((size_t)E), roff((size_t)E);
-    {
-        // read offsets: rows of a position one after another
-        int64_t ro = 0;
-        for (int q = 0; q < m; ++q) {
-            const int d = order[q];
-            for (int k = 0; k < h->h_Sp[d + 1] - h->h_Sp[d]; ++k) {
-                const int row = h->h_Sj[h->h_Sp[d] + k];
-                roff[(size_t)ebase[q] + k] = (int)ro;
-                ro += A->h_Ap[row + 1] - A->h_Ap[row];
-            }
-        }
-    }
-    std::vector<unsigned char> rver((size_t)std::max<int64_t>(R, 1), 0);
-    std::vector<int> cnt((size_t)n, 0), seen((size_t)n, -1);
-    for (int t = 0; t < m; ++t) {
-        const int d = g.start + t * g.step, q = pos_of[(size_t)d];
-        const int s0 = h->h_Sp[d], size = h->h_Sp[d + 1] - s0;
-        for (int k = 0; k < size; ++k) {                          // every residual of the subdomain sees the state BEFORE its own updates
-            const int row = h->h_Sj[s0 + k];
-            if (seen[(size_t)row] == t) return PAMG_OK;            // a row listed twice: the reference updates it twice in a row; not this form
-            seen[(size_t)row] = t;
-            unsigned char *rv = rver.data() + roff[(size_t)ebase[q] + k];
-            for (int p = A->h_Ap[row]; p < A->h_Ap[row + 1]; ++p) rv[p - A->h_Ap[row]] = (unsigned char)cnt[(size_t)A->h_Aj[p]];
-        }
-        for (int k = 0; k < size; ++k) {
-            const int row = h->h_Sj[s0 + k];
-            const int v = cnt[(size_t)row]++;
-            wslot[(size_t)ebase[q] + k] = vbase[row] + v;
-            prev[(size_t)ebase[q] + k] = v == 0 ? ~row : vbase[row] + v - 1;
-        }
-    }
+    SchwarzVersions V;
+    schwarz_versions(n, A->h_Ap.data(), A->h_Aj.data(), h->nsub, h->h_Sp.data(), h->h_Sj.data(), g.start, g.step, lv, V);
+    if (!V.ok) return PAMG_OK;
+    const int64_t E = V.nslots, R = V.nreads;
     auto up = [](auto **dp, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc((void **)dp, std::max<size_t>(bytes, 256));
         if (e == hipSuccess && bytes) e = hipMemcpy(*dp, src, bytes, hipMemcpyHostToDevice);
         return e;
     };
-    PAMG_HIP(up(&g.d_ebase, ebase.data(), sizeof(int) * ((size_t)m + 1)));
-    PAMG_HIP(up(&g.d_wslot, wslot.data(), sizeof(int) * (size_t)E));
-    PAMG_HIP(up(&g.d_prev, prev.data(), sizeof(int) * (size_t)E));
-    PAMG_HIP(up(&g.d_roff, roff.data(), sizeof(int) * (size_t)E));
-    PAMG_HIP(up(&g.d_rver, rver.data(), (size_t)R));
-    PAMG_HIP(up(&g.d_vbase, vbase.data(), sizeof(int) * (size_t)n));
-    PAMG_HIP(up(&g.d_last, last.data(), sizeof(int) * (size_t)n));
+    PAMG_HIP(up(&g.d_ebase, V.ebase.data(), sizeof(int) * ((size_t)m + 1)));
+    PAMG_HIP(up(&g.d_wslot, V.wslot.data(), sizeof(int) * (size_t)E));
+    PAMG_HIP(up(&g.d_prev, V.prev.data(), sizeof(int) * (size_t)E));
+    PAMG_HIP(up(&g.d_roff, V.roff.data(), sizeof(int) * (size_t)E));
+    PAMG_HIP(up(&g.d_rver, V.rver.data(), (size_t)R));
+    PAMG_HIP(up(&g.d_vbase, V.vbase.data(), sizeof(int) * (size_t)n));
+    PAMG_HIP(up(&g.d_last, V.last.data(), sizeof(int) * (size_t)n));
     g.nslots = E;
     if (E > h->xs_cap) {
         hipFree(h->d_xs);
@@ -411,55 +362,25 @@ int build_versions(pamg_schwarz_s *h, SchwarzSchedule &g, const std::vector<int>
     return PAMG_OK;
 }
 
-// dependency levels of the subdomains visited in (start, stop, step) order
+// dependency levels of the subdomains visited in (start, stop, step) order, and the version table of the persistent sweep
 int build_schedule(pamg_schwarz_s *h, int start, int stop, int step, SchwarzSchedule &g)
 {
     const pamg_matrix_s *A = h->A;
-    const int n = (int)A->nrows;
-    if (step == 0) return PAMG_E_ARG;
-    const long span = (long)stop - start;
-    if (span % step != 0 || span / step < 0) return PAMG_E_ARG;
-    const int m = (int)(span / step);
+    SchwarzLevels lv;
+    if (schwarz_levels((int)A->nrows, A->h_Ap.data(), A->h_Aj.data(), h->nsub, h->h_Sp.data(), h->h_Sj.data(), start, stop, step, lv)) return PAMG_E_ARG;
     g.start = start; g.stop = stop; g.step = step;
-    g.level_ptr.assign(1, 0);
-    g.nlevels = 0;
-    if (m == 0) return PAMG_OK;
-    if (start < 0 || start >= h->nsub || start + (long)(m - 1) * step < 0 || start + (long)(m - 1) * step >= h->nsub) return PAMG_E_ARG;
-    std::vector<int> lastW((size_t)n, -1), lastR((size_t)n, -1), lvl((size_t)m, 0);
-    int maxl = 0;
-    for (int t = 0; t < m; ++t) {
-        const int d = start + t * step;
-        int L = 0;
-        for (int q = h->h_Sp[d]; q < h->h_Sp[d + 1]; ++q) {
-            const int row = h->h_Sj[q];
-            L = std::max(L, std::max(lastW[row], lastR[row]) + 1);                 // write after write / write after read
-            for (int p = A->h_Ap[row]; p < A->h_Ap[row + 1]; ++p) L = std::max(L, lastW[A->h_Aj[p]] + 1);   // read after write
-        }
-        lvl[t] = L;
-        maxl = std::max(maxl, L);
-        for (int q = h->h_Sp[d]; q < h->h_Sp[d + 1]; ++q) {
-            const int row = h->h_Sj[q];
-            lastW[row] = std::max(lastW[row], L);
-            for (int p = A->h_Ap[row]; p < A->h_Ap[row + 1]; ++p) { const int j = A->h_Aj[p]; lastR[j] = std::max(lastR[j], L); }
-        }
-    }
-    g.nlevels = maxl + 1;
-    g.level_ptr.assign((size_t)g.nlevels + 1, 0);
-    for (int t = 0; t < m; ++t) g.level_ptr[(size_t)lvl[t] + 1]++;
-    for (int l = 0; l < g.nlevels; ++l) g.level_ptr[(size_t)l + 1] += g.level_ptr[l];
-    std::vector<int> order((size_t)m), cur(g.level_ptr.begin(), g.level_ptr.end() - 1);
-    for (int t = 0; t < m; ++t) order[(size_t)cur[lvl[t]]++] = start + t * step;
-    g.m = m; g.max_width = 0;
-    for (int l = 0; l < g.nlevels; ++l) g.max_width = std::max(g.max_width, g.level_ptr[(size_t)l + 1] - g.level_ptr[l]);
+    g.level_ptr = lv.level_ptr;
+    g.nlevels = lv.nlevels; g.m = lv.m; g.max_width = lv.max_width;
+    if (lv.m == 0) return PAMG_OK;
     hipFree(g.d_order);
     g.d_order = nullptr;
-    PAMG_HIP(hipMalloc((void **)&g.d_order, sizeof(int) * (size_t)m));
-    PAMG_HIP(hipMemcpy(g.d_order, order.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
+    PAMG_HIP(hipMalloc((void **)&g.d_order, sizeof(int) * (size_t)lv.m));
+    PAMG_HIP(hipMemcpy(g.d_order, lv.order.data(), sizeof(int) * (size_t)lv.m, hipMemcpyHostToDevice));
     if (!h->d_err) {
         PAMG_HIP(hipMalloc((void **)&h->d_err, 256));
         PAMG_HIP(hipMemset(h->d_err, 0, 256));
     }
-    PAMG_TRY(build_versions(h, g, order));
+    PAMG_TRY(upload_versions(h, g, lv));
     return PAMG_OK;
 }
 
