@@ -1557,17 +1557,17 @@ int pamg_solver_pcg(pamg_solver_t S, void *x, const void *b, double tol, int max
     Level &L0 = S->levels[0];
     const int64_t n = L0.n;
     const size_t vb = (size_t)n * tsize(S->dtype);
-    if (!S->cg_r) {
-        PAMG_TRY(dalloc(S, &S->cg_r, vb)); PAMG_TRY(dalloc(S, &S->cg_z, vb));
-        PAMG_TRY(dalloc(S, &S->cg_p, vb)); PAMG_TRY(dalloc(S, &S->cg_q, vb));
-    }
+    if (!S->cg_p) { PAMG_TRY(dalloc(S, &S->cg_p, vb)); PAMG_TRY(dalloc(S, &S->cg_q, vb)); }
+    // CG's residual LIVES in the fine level's right-hand side and its preconditioned residual in the fine level's iterate: z = M r is then
+    // "x = 0, one cycle" with nothing copied in or out (three full-vector passes per iteration around the cycle)
     const std::function<int(const void *, void *)> precond = [&](const void *rin, void *zout) -> int {   // z = M r: one cycle from x = 0
-        PAMG_HIP(hipMemcpyAsync(L0.b, rin, vb, hipMemcpyDeviceToDevice, s));
+        if (rin != L0.b) PAMG_HIP(hipMemcpyAsync(L0.b, rin, vb, hipMemcpyDeviceToDevice, s));
         PAMG_HIP(hipMemsetAsync(L0.x, 0, vb, s));
         PAMG_TRY(run_cycle(S, cycle, cycles_per_level, s, false, true));
-        return (int)hipMemcpyAsync(zout, L0.x, vb, hipMemcpyDeviceToDevice, s);
+        if (zout != L0.x) PAMG_HIP(hipMemcpyAsync(zout, L0.x, vb, hipMemcpyDeviceToDevice, s));
+        return PAMG_OK;
     };
-    PAMG_TRY(cg_core(S, L0.A, n, &precond, S->cg_r, S->cg_z, S->cg_p, S->cg_q, x, b, tol, maxiter, residuals, n_iter, info, s));
+    PAMG_TRY(cg_core(S, L0.A, n, &precond, L0.b, L0.x, S->cg_p, S->cg_q, x, b, tol, maxiter, residuals, n_iter, info, s));
     PAMG_HIP(hipStreamSynchronize(s));
     return check_sweeps(S);
 }
