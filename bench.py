@@ -100,6 +100,15 @@ WORKLOADS = {
 }
 
 
+def cpu_quota_cores():
+    """cores the container's cgroup grants (cpu.max), None without a quota -- os.cpu_count() reports the machine (the pool's GPU boxes: 256 threads, quota 16)"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 1)
+    except Exception:                                   # noqa: BLE001
+        return None
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -1082,7 +1091,7 @@ def main():
             "spmv_GBps": roofline["achieved"], "spmv_pct_of_hbm_peak": round(100 * roofline["frac"], 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
             "host": {"setup_s": round(t_setup, 1), "upload_s": round(t_upload, 1), "renumber_s": round(getattr(dml, "renumber_seconds", 0.0), 2),
-                     "renumbered_levels": list(getattr(dml, "renumbered", [])), "cores": os.cpu_count(),
+                     "renumbered_levels": list(getattr(dml, "renumbered", [])), "cores": os.cpu_count(), "cpu_quota_cores": cpu_quota_cores(),
                      "setup": SETUP_NOTE, **(setup_cmp or {})},
             "residuals_gpu": [float(v) for v in res_gpu],
             "time_to_tol_1e-8": ttt,

@@ -18,7 +18,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libpyamg_amd.so"
 SOURCES = ["pamg_matrix.hip", "pamg_solver.hip", "pamg_capi.hip", "pamg_setup.hip", "pamg_schwarz.hip", "pamg_dist.hip", "pamg_aggregate.hip", "pamg_lane.hip", "pamg_line.hip", "pamg_kz.hip", "pamg_blane.hip", "pamg_block.hip", "pamg_renumber.hip"]
-HEADERS = ["pamg_common.h", "pamg_kernels.h", "pamg_tile_kernels.h", "pamg_tile_plan.h", "pamg_lane_plan.h", "pamg_lanem_plan.h", "pamg_schwarz_plan.h", "pamg_line_plan.h", "pamg_kz_plan.h", "pamg_blane_plan.h", "pamg_spg_plan.h", "pamg_stream_plan.h", "pamg_rowmask_map.h", "pamg_plan_vec.h", "amg_core_bind.cpp", "../../include/pyamg_amd.h"]
+HEADERS = ["pamg_common.h", "pamg_kernels.h", "pamg_tile_kernels.h", "pamg_tile_plan.h", "pamg_lane_plan.h", "pamg_lanem_plan.h", "pamg_schwarz_plan.h", "pamg_line_plan.h", "pamg_kz_plan.h", "pamg_blane_plan.h", "pamg_spg_plan.h", "pamg_stream_plan.h", "pamg_rowmask_map.h", "pamg_plan_vec.h", "pamg_host_threads.h", "amg_core_bind.cpp", "../../include/pyamg_amd.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 

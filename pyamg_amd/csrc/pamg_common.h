@@ -1,5 +1,6 @@
 // pamg_common.h -- shared declarations for libpyamg_amd.so (gfx950 / CDNA4 only).
 #pragma once
+#include "pamg_host_threads.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -332,7 +333,7 @@ inline size_t tsize(int dtype) { return dtype == PAMG_F64 ? 8 : 4; }
 template <typename F>
 inline void host_parallel(int64_t n, F fn, int64_t grain = 1 << 20)
 {
-    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::min(32u, pamg::host_cpus()));
     const int nt = n < 2 * grain ? 1 : (int)std::min<int64_t>(hw, n / grain);
     if (nt <= 1) { fn((int64_t)0, n); return; }
     std::vector<std::thread> th;

@@ -1,0 +1,40 @@
+// pamg_host_threads.h -- how many host threads a planner may count on (plain C++).  std::thread::hardware_concurrency() reports the machine;
+// a container sees what its cgroup grants.  The GPU boxes of this pool show 256 hardware threads and a quota of 16 cores (cpu.max =
+// "1600000 100000"): a planner that started 96 threads per sweep direction there got 16 cores' worth of time slices, and LESS work done than
+// 16 threads would (tools/cpu_quota_probe.py: 8 / 16 / 32 / 64 / 128 busy threads = 8.3 / 10.8 / 9.5 / 7.2 / 6.8 x one thread).
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include <sched.h>
+
+namespace pamg {
+
+inline unsigned host_cpus()
+{
+    static const unsigned n = [] {
+        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        if (const char *e = getenv("PAMG_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)v; }
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) hw = std::min(hw, (unsigned)c); }
+        // cgroup v2: "<quota> <period>" or "max <period>"; cgroup v1: two files
+        long long quota = -1, period = -1;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else {
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+        }
+        if (quota > 0 && period > 0) hw = std::min(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        return std::max(1u, hw);
+    }();
+    return n;
+}
+
+}  // namespace pamg

@@ -27,6 +27,7 @@
 // Diagonal entries are not stored at all (every stored a_ii is skipped by the reference's sum; the last one is the
 // diagonal, relaxation.h:64-69).
 #pragma once
+#include "pamg_host_threads.h"
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -62,7 +63,7 @@ struct LanePlan {
 template <typename F>
 inline void lane_parallel(int64_t n, F fn, int64_t grain = 4096)
 {
-    const unsigned hw = std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::min(48u, pamg::host_cpus()));
     const int nt = (n < 2 * grain) ? 1 : (int)std::min<int64_t>(hw, n / grain);
     if (nt <= 1) { fn((int64_t)0, n); return; }
     std::vector<std::thread> th;

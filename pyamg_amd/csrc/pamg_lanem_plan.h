@@ -33,6 +33,7 @@
 // A group only waits for groups of EARLIER super-levels (smaller numbers): the static wave assignment g = w, w + W, ...
 // stays deadlock-free.  SOR is not merged (its coefficients depend on the relaxation parameter of the call).
 #pragma once
+#include "pamg_host_threads.h"
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -154,7 +155,8 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
     //      closed when it holds s_max levels, or in front of a level whose merged rows would come out too long / too large
     const int wlev = 4 * s_max;
     const int nblocks = (nl + wlev - 1) / wlev;
-    const unsigned hw = std::max(1u, std::min(96u, std::thread::hardware_concurrency() / 2u + 1u));      // (two sweep directions are planned at once)
+    static const unsigned want_threads = [] { const char *e = getenv("PAMG_PLAN_THREADS"); return e ? (unsigned)atoi(e) : 0u; }();
+    const unsigned hw = want_threads ? want_threads : std::max(1u, std::min(96u, pamg::host_cpus() / 2u + 1u));      // (two sweep directions are planned at once)
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw, (int64_t)nblocks, std::max<int64_t>(1, (int64_t)m / 4096)}));
     std::vector<PlanVec<int>> acode((size_t)nt);
     std::vector<PlanVec<double>> aval((size_t)nt);
@@ -163,6 +165,7 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
     std::vector<int> cl_len((size_t)nt, 0), cl_gr((size_t)nt, 0);
     std::vector<double> mg((size_t)nt, 0.0);
     std::atomic<int> unfit(0), next_blk(0);
+    std::vector<double> t_res_((size_t)nt, 0.0), t_row_((size_t)nt, 0.0), t_end_((size_t)nt, 0.0);      // PAMG_TIMING: per-thread phases
     int64_t total_direct = 0;
     for (int t = 0; t < m; ++t) { const int i = row_start + t * row_step; total_direct += Ap[i + 1] - Ap[i]; }
     auto work = [&](int tid) {
@@ -171,6 +174,7 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
         PlanVec<int> &ac = acode[(size_t)tid];
         PlanVec<double> &av = aval[(size_t)tid];
         std::vector<std::pair<int, double>> sub;
+        const auto tw0_ = std::chrono::steady_clock::now();
         {
             // room for this thread's share of the merged rows up front (a growing vector copies and re-faults what it holds at every doubling);
             // the windows are handed out one by one (below), so the share is an estimate: a thread that outgrows it pays the doubling
@@ -178,6 +182,7 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
             ac.reserve(want);
             av.reserve(want);
         }
+        const auto tw1_ = std::chrono::steady_clock::now();
         // windows differ by an order of magnitude (the sweep's wavefront grows and shrinks): first come, first served
         for (int blk = next_blk.fetch_add(1); blk < nblocks && !unfit.load(); blk = next_blk.fetch_add(1)) {
             const int lb0 = blk * wlev, lb1 = std::min(nl, lb0 + wlev);
@@ -249,6 +254,12 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
                 if (unfit.load()) break;
             }
         }
+        if (timing_) {
+            const auto tw2_ = std::chrono::steady_clock::now();
+            t_res_[(size_t)tid] = std::chrono::duration<double>(tw1_ - tw0_).count();
+            t_row_[(size_t)tid] = std::chrono::duration<double>(tw2_ - tw1_).count();
+            t_end_[(size_t)tid] = std::chrono::duration<double>(tw2_ - t_prev_).count();
+        }
     };
     if (nt == 1) work(0);
     else {
@@ -257,6 +268,11 @@ inline int build_lanem_plan(int n, const int *Ap, const int *Aj, const double *A
         for (auto &x : th) x.join();
     }
     if (unfit.load()) return 1;
+    if (timing_) {
+        double sr = 0, mr = 0, sw = 0, mw = 0, me = 0, mn = 1e9;
+        for (int t = 0; t < nt; ++t) { sr += t_res_[(size_t)t]; mr = std::max(mr, t_res_[(size_t)t]); sw += t_row_[(size_t)t]; mw = std::max(mw, t_row_[(size_t)t]); me = std::max(me, t_end_[(size_t)t]); mn = std::min(mn, t_end_[(size_t)t]); }
+        fprintf(stderr, "[pamg timing]     lanem plan: %d threads, %d windows: reserve sum %.3f max %.3f s, rows sum %.3f max %.3f s, thread end (since lap) min %.3f max %.3f s\n", nt, nblocks, sr, mr, sw, mw, mn, me);
+    }
     lap_("merged rows");
     for (int t = 0; t < nt; ++t) { P.closed_by_length += cl_len[(size_t)t]; P.closed_by_growth += cl_gr[(size_t)t]; P.max_growth = std::max(P.max_growth, mg[(size_t)t]); }
     // ---- super-levels, groups, units

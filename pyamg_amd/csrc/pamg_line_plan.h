@@ -26,6 +26,7 @@
 //   acoef[g * 64 + l]             - a_{t,t-1} / a_tt  (0: not coupled to the predecessor / first row of a line)
 //   meta [g] = {row0, rows | NODIAG mask is kept per lane in the sign of rdiag's companion array `flag`}
 #pragma once
+#include "pamg_host_threads.h"
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -60,7 +61,7 @@ struct LinePlan {
 template <typename F>
 inline void line_parallel(int64_t n, F fn, int64_t grain = 1 << 15)
 {
-    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    unsigned nt = std::max(1u, std::min(32u, pamg::host_cpus()));
     nt = (unsigned)std::max<int64_t>(1, std::min<int64_t>(nt, n / std::max<int64_t>(grain, 1)));
     if (nt <= 1) { fn((int64_t)0, n, 0); return; }
     std::vector<std::thread> th;

@@ -1,5 +1,6 @@
 // pamg_matrix.hip -- operator handle: upload, planning, dependency-level analysis for the
 // order-exact Gauss-Seidel family, kernel dispatch.
+#include "pamg_host_threads.h"
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -213,7 +214,7 @@ template <typename F>
 void parallel_rows(int n, F fn)
 {
     // n counts rows or row ranges (of ~1.5 K entries): a few hundred of either are worth a thread
-    const unsigned hw = std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::min(48u, pamg::host_cpus()));
     const int nt = (n < 512) ? 1 : (int)std::min<unsigned>(hw, (unsigned)(n / 256));
     if (nt == 1) { fn(0, n); return; }
     std::vector<std::thread> th;

@@ -4,6 +4,7 @@
 // first-touching gigabytes in 4 KB pages queue up behind the process's page-table lock (the merged plan of level 1 of the 256^3
 // hierarchy spent most of its second in page faults), 2 MB pages are 512 times fewer faults where the kernel grants them.
 #pragma once
+#include "pamg_host_threads.h"
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -58,7 +59,7 @@ inline void plan_fill(PlanVec<T> &v, size_t n, T value)
     v.resize(n);                                        // uninitialised
     T *p = v.data();
     const size_t grain = (size_t)1 << 22;
-    unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    unsigned nt = std::max(1u, std::min(32u, pamg::host_cpus()));
     nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n / grain));
     if (nt <= 1) { std::fill(p, p + n, value); return; }
     std::vector<std::thread> th;

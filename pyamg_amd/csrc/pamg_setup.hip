@@ -14,6 +14,7 @@
 // list from its head) and exact zeros are dropped as SciPy drops them, so the result is the array SciPy would have
 // produced, entry for entry.  No atomics on values.  Rows with more than SPG_CAP products (coarse Galerkin products:
 // tens of thousands) go through spg_long_kernel: dense per-column accumulators over a window of output columns.
+#include "pamg_host_threads.h"
 #include <algorithm>
 #include <atomic>
 #include <climits>
@@ -769,7 +770,7 @@ int grid_for(int64_t n, int cap = 8192) { return (int)std::min<int64_t>(cap, std
 template <typename F>
 void par_for(int n, F fn)
 {
-    const int hw = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int hw = (int)std::max(1u, std::min(32u, pamg::host_cpus()));
     const int nt = n < (1 << 16) ? 1 : hw;
     if (nt == 1) { fn(0, n); return; }
     std::vector<std::thread> th;

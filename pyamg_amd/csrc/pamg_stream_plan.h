@@ -9,6 +9,7 @@
 // Every form delivers the very same (column, value) pairs in the row's storage order: the kernels that read them add the
 // same products in the same order.
 #pragma once
+#include "pamg_host_threads.h"
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -21,7 +22,7 @@ namespace pamg {
 template <typename F>
 inline void plan_parallel(int64_t n, F fn, int64_t grain)
 {
-    const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::min(64u, pamg::host_cpus()));
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(hw, n / std::max<int64_t>(1, grain)));
     if (nt == 1) { fn((int64_t)0, n, 0); return; }
     std::vector<std::thread> th;
@@ -33,7 +34,7 @@ inline void plan_parallel(int64_t n, F fn, int64_t grain)
 }
 inline int plan_threads(int64_t n, int64_t grain)
 {
-    const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::min(64u, pamg::host_cpus()));
     return (int)std::max<int64_t>(1, std::min<int64_t>(hw, n / std::max<int64_t>(1, grain)));
 }
 

@@ -33,6 +33,7 @@
 //     0       1     diagonal (staged as +0)      j
 //     1       1     NEW value, same tile         LDS ring slot
 #pragma once
+#include "pamg_host_threads.h"
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -66,7 +67,7 @@ struct TilePlan {
 template <typename F>
 inline void tp_parallel(int n, F fn, int grain = 64)
 {
-    const unsigned hw = std::max(1u, std::min(48u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::min(48u, pamg::host_cpus()));
     const int nt = (n < 4 * grain) ? 1 : (int)std::min<unsigned>(hw, (unsigned)(n / grain));
     if (nt == 1) { fn(0, n); return; }
     std::vector<std::thread> th;
