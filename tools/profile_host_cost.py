@@ -18,6 +18,7 @@ with device_setup(pyamg):
 for what in ("setup", "upload"):
     pr = cProfile.Profile()
     t0 = time.perf_counter()
+    c0 = time.process_time()
     pr.enable()
     if what == "setup":
         with device_setup(pyamg):
@@ -25,7 +26,7 @@ for what in ("setup", "upload"):
     else:
         dml = DeviceMultilevelSolver(ml)
     pr.disable()
-    print(f"== {what}: {time.perf_counter() - t0:.2f} s", flush=True)
+    print(f"== {what}: {time.perf_counter() - t0:.2f} s wall, {time.process_time() - c0:.1f} CPU-seconds of this process (all threads)", flush=True)
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
     print("\n".join(l[:200] for l in s.getvalue().splitlines()[:75]))
