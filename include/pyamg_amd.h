@@ -534,6 +534,10 @@ int pamg_csr_row_argmax_abs(int dtype, int64_t nrows, const int32_t *Ap, const i
  * runs on every Galerkin product before reading its diagonal (util/utils.py:583).  block = values per stored entry (R * C; 1 for CSR).
  * Stable, so equal columns keep their stored order like SciPy's. */
 int pamg_csr_sort_rows(int dtype, int64_t nrows, const int32_t *Ap, int32_t *Aj, void *Ax, int block);
+/* Host threads the library's planners count on: min(hardware threads, affinity mask, cgroup CPU quota) -- a container may see 256
+ * hardware threads and own 16 cores (PAMG_HOST_THREADS overrides).  fresh != 0 evaluates the environment again instead of the
+ * per-process value. */
+int pamg_host_cpus(int fresh);
 
 /* Hierarchy / cycle / outer iteration (MultilevelSolver, multilevel.py:17-662).         */
 #define PAMG_SMOOTH_NONE        0

@@ -163,6 +163,7 @@ def _declare(lib):
     f("pamg_csr_renumber", _i, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp)
     f("pamg_csr_row_argmax_abs", _i, C.c_int64, _vp, _vp, _vp, _vp)
     f("pamg_csr_sort_rows", _i, C.c_int64, _vp, _vp, _vp, _i)
+    f("pamg_host_cpus", _i)
     f("pamg_solver_create", P(_vp), _i)
     f("pamg_solver_destroy", _vp)
     f("pamg_solver_add_level", _vp, _vp, _vp, _vp)

@@ -13,27 +13,41 @@
 
 namespace pamg {
 
+// cores a cgroup-v2 "cpu.max" file grants ("<quota> <period>" | "max <period>"), rounded up; 0 = no quota / unreadable
+inline unsigned cgroup_quota_cores(const char *path)
+{
+    long long quota = -1, period = -1;
+    if (FILE *f = fopen(path, "r")) {
+        char q[64] = {0};
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    }
+    if (quota > 0 && period > 0) return (unsigned)std::max<long long>(1, (quota + period - 1) / period);
+    return 0u;
+}
+
+inline unsigned host_cpus_now()
+{
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    if (const char *e = getenv("PAMG_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)v; }
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) hw = std::min(hw, (unsigned)c); }
+    const char *v2 = getenv("PAMG_CGROUP_CPU_MAX");                      // (tests point this at a file of their own)
+    unsigned q = cgroup_quota_cores(v2 ? v2 : "/sys/fs/cgroup/cpu.max");
+    if (!q && !v2) {                                                     // cgroup v1: two files
+        long long quota = -1, period = -1;
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+        if (quota > 0 && period > 0) q = (unsigned)std::max<long long>(1, (quota + period - 1) / period);
+    }
+    if (q) hw = std::min(hw, q);
+    return std::max(1u, hw);
+}
+
 inline unsigned host_cpus()
 {
-    static const unsigned n = [] {
-        unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        if (const char *e = getenv("PAMG_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)v; }
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) hw = std::min(hw, (unsigned)c); }
-        // cgroup v2: "<quota> <period>" or "max <period>"; cgroup v1: two files
-        long long quota = -1, period = -1;
-        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-            char q[64] = {0};
-            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-            fclose(f);
-        } else {
-            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
-            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
-        }
-        if (quota > 0 && period > 0) hw = std::min(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
-        return std::max(1u, hw);
-    }();
+    static const unsigned n = host_cpus_now();
     return n;
 }
 

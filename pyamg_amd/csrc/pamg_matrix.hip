@@ -1175,7 +1175,7 @@ int ensure_point_twin(pamg_matrix_s *A, GsSchedule *g)
             T->lane_L = A->lane_L; T->lane_G = A->lane_G; T->lane_flags = A->lane_flags; T->lane_merge = A->lane_merge; T->line_scan = A->line_scan;
             T->lane_wide = A->lane_wide;
             A->point_twin = T;
-            A->bytes += T->bytes;
+            { std::lock_guard<std::mutex> lk2(g_sched_mu); A->bytes += T->bytes; }
         }
     }
     GsSchedule *tg = nullptr;

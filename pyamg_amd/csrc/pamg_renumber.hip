@@ -74,6 +74,10 @@ int pamg_csr_row_argmax_abs(int dtype, int64_t nrows, const int32_t *Ap, const i
     return PAMG_OK;
 }
 
+// host threads the library's planners count on: hardware threads, affinity mask and cgroup quota (csrc/pamg_host_threads.h).  fresh != 0 evaluates
+// the environment again (tests); 0 returns what the planners use (evaluated once per process)
+int pamg_host_cpus(int fresh) { return (int)(fresh ? host_cpus_now() : host_cpus()); }
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -139,3 +139,19 @@ def test_sort_rows_is_scipys_sort_indices(fmt, dtype):
     assert a.has_sorted_indices and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data) and np.array_equal(a.indptr, b.indptr)
     _sort_indices(a)                                   # sorted already: nothing moves
     assert np.array_equal(a.indices, b.indices)
+
+
+def test_host_cpus_honours_the_cgroup_quota(tmp_path, monkeypatch):
+    """csrc/pamg_host_threads.h: planners size their thread pools by what the container OWNS (the pool's GPU boxes: 256 hardware threads, a quota of 16 cores)"""
+    import os
+    lib = capi.load()
+    f = tmp_path / "cpu.max"
+    monkeypatch.delenv("PAMG_HOST_THREADS", raising=False)
+    machine = min(os.cpu_count(), len(os.sched_getaffinity(0)))
+    for text, want in (("1600000 100000\n", min(16, machine)), ("max 100000\n", machine), ("150000 100000\n", min(2, machine)), ("garbage", machine), ("50000 100000", 1)):
+        f.write_text(text)
+        monkeypatch.setenv("PAMG_CGROUP_CPU_MAX", str(f))
+        assert lib.pamg_host_cpus(1) == want, text
+    monkeypatch.setenv("PAMG_HOST_THREADS", "5")
+    assert lib.pamg_host_cpus(1) == 5
+    assert lib.pamg_host_cpus(0) >= 1
