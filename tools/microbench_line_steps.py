@@ -17,14 +17,14 @@ out = []
 for (nz, ny, nx) in ((128, 128, 128), (128, 128, 256), (128, 128, 512), (128, 128, 1024), (256, 256, 256), (256, 256, 128), (64, 64, 256), (64, 64, 1024)):
     A = sp.csr_matrix(poisson_csr((nz, ny, nx)))
     n = A.shape[0]
-    dA = DeviceMatrix(sparse_op(A))
     rng = np.random.RandomState(0)
     x0, bh = rng.rand(n), rng.rand(n)
     b = capi.DeviceArray.from_host(bh)
     got = {}
-    # (round 6 A/B: flag bit 4 selected round 5's kernel against a variant that requested a chunk's operands one chunk ahead -- slower, removed:
-    #  profiles/r06_microbench_line_steps_operands_ahead_not_kept.json; the loop is kept for the next variant)
-    for flags, name in ((1, "operands_at_chunk_start"),):
+    # (round 6 A/Bs through this loop, both removed: a variant that requested a chunk's operands one chunk ahead, and the lines in eight strips of the visit
+    #  order with one XCD each -- profiles/r06_microbench_line_steps_operands_ahead_not_kept.json, r06_microbench_line_strips_one_xcd_each_not_kept.json)
+    for flags, name in ((1, "chip_wide"),):
+        dA = DeviceMatrix(sparse_op(A))
         dA.tune(gs_order=1, lane_flags=flags)
         x = capi.DeviceArray.from_host(x0)
         dA.gauss_seidel(x, b, sweep="symmetric")
@@ -41,11 +41,11 @@ for (nz, ny, nx) in ((128, 128, 128), (128, 128, 256), (128, 128, 512), (128, 12
         ms = e0.elapsed_ms(e1) / reps
         info = dA.line_info(0)
         steps = ny + nz - 1
-        rec = {"grid": [nz, ny, nx], "kernel": name, "rows": n, "chunks_per_line": (nx + 63) // 64, "wavefront_steps": steps, "ms": round(ms, 4),
+        rec = {"grid": [nz, ny, nx], "form": name, "rows": n, "chunks_per_line": (nx + 63) // 64, "wavefront_steps": steps, "ms": round(ms, 4),
                "us_per_step": round(1e3 * ms / steps, 3), "GBps": round((12 * A.nnz + 24 * n) / ms / 1e6, 1), "launch_grid": info.get("launch_grid"),
                "timeout": bool(dA.flow_error())}
         print(rec, flush=True)
         out.append(rec)
-    dA.free()
+        dA.free()
 (ROOT / "gpurun_out").mkdir(exist_ok=True)
 (ROOT / "gpurun_out" / "microbench_line_steps.json").write_text(json.dumps(out, indent=1))
